@@ -1,0 +1,96 @@
+"""ctypes binding of libreart_hip.so (C ABI declared in include/reart_hip.h).
+
+PyTorch is used for device memory and streams only: tensors are passed as raw device
+pointers (``tensor.data_ptr()``) together with torch's current HIP stream.
+"""
+import ctypes
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libreart_hip.so")
+
+c_int, c_float, c_size_t, c_void_p = ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p
+P = c_void_p  # every device pointer
+
+# name -> (restype, argtypes); mirrors include/reart_hip.h one to one
+PROTOTYPES = {
+    "reart_version": (c_int, []),
+    "reart_device_count": (c_int, []),
+    "reart_status_string": (ctypes.c_char_p, [c_int]),
+    "reart_knn_points_workspace_bytes": (c_size_t, [c_int] * 4),
+    "reart_knn_points_idx": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, c_size_t, P]),
+    "reart_knn_points_backward_workspace_bytes": (c_size_t, [c_int] * 4),
+    "reart_knn_points_backward": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, c_size_t, P]),
+    "reart_chamfer_bidir_workspace_bytes": (c_size_t, [c_int] * 2),
+    "reart_chamfer_bidir": (c_int, [P, P, c_int, c_int, P, P, P, P, P, c_size_t, P]),
+    "reart_knn_cuda": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, c_size_t, P]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class ReartHipError(RuntimeError):
+    """A libreart_hip.so entry point returned a negative reart_status."""
+
+
+def lib():
+    """Load libreart_hip.so (once).  Fails loudly: there is no fallback implementation."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise ImportError(
+                        f"{LIB_PATH} is missing: build it with `make -C reart_amd/csrc -j8` "
+                        "(or `python -c 'import __graft_entry__ as g; g.build()'`). "
+                        "reart_amd has no CPU / PyTorch fallback."
+                    )
+                handle = ctypes.CDLL(LIB_PATH)
+                for name, (res, args) in PROTOTYPES.items():
+                    fn = getattr(handle, name)  # AttributeError if the .so is stale
+                    fn.restype, fn.argtypes = res, args
+                _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().reart_status_string(rc).decode()
+        raise ReartHipError(f"{what} failed: {msg} (status {rc})")
+
+
+def require_gpu(*tensors):
+    """Every operand must live on a HIP device; reart_amd never computes on the host."""
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "reart_amd operators run on an AMD GPU only (tensor is on "
+                f"{t.device}); there is no CPU fallback."
+            )
+
+
+def ptr(t):
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes, device):
+    """Scratch buffer reused across calls on the same (device, stream): calls on one
+    stream are ordered, so a shared buffer is safe; the library itself never allocates."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream(device).cuda_stream)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf

@@ -1,0 +1,55 @@
+// reart_amd/csrc/common.h -- shared device helpers for libreart_hip.so (gfx950 only).
+//
+// Floating-point contract: the whole library is compiled with -ffp-contract=off, so
+// every rounding in the source is a rounding in the ISA.  Where a fused multiply-add
+// is wanted it is written as fmaf() explicitly.  The CPU oracle (oracle/*.c, test
+// infrastructure) is compiled under the same rule, which is what makes bit-exact
+// comparisons of indices and most fp32 values possible.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/reart_hip.h"
+
+#define REART_WAVE 64
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+#define REART_CHECK_LAUNCH()                                     \
+    do {                                                         \
+        if (hipGetLastError() != hipSuccess) return REART_ERR_LAUNCH; \
+    } while (0)
+
+static inline size_t reart_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static inline int reart_div_up(int a, int b) { return (a + b - 1) / b; }
+
+// Squared distance with the library-wide rounding contract:
+//   ((dx*dx) + (dy*dy)) + (dz*dz), fp32, no contraction.
+__device__ __forceinline__ float reart_sqdist3(float ax, float ay, float az,
+                                               float bx, float by, float bz) {
+    float dx = ax - bx, dy = ay - by, dz = az - bz;
+    return (dx * dx + dy * dy) + dz * dz;
+}
+
+// Wave-level sum in a FIXED order (butterfly over lane xor 32,16,...,1) so that results
+// do not depend on scheduling.  All 64 lanes get the total.
+__device__ __forceinline__ float reart_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double reart_wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// XCD-aware remap of a linear workgroup id (cdna guide T1): the dispatcher places
+// workgroup L on XCD L % 8; give each XCD a contiguous chunk of work items so that
+// neighbours (same batch / same target slice) share one L2.  Returns -1 for the
+// padding ids of a grid rounded up to a multiple of 8.
+__device__ __forceinline__ int reart_xcd_remap(int L, int n_items) {
+    const int per = (n_items + 7) >> 3;
+    const int w = (L & 7) * per + (L >> 3);
+    return (w < n_items && (L >> 3) < per) ? w : -1;
+}
+static inline int reart_xcd_grid(int n_items) { return ((n_items + 7) / 8) * 8; }
