@@ -89,3 +89,84 @@ def knn_cuda(ref, query, k, euclidean=True):
     idx = np.empty((B, nq, k), np.int64)
     lib().oracle_knn_cuda(_p(ref), _p(query), B, nr, nq, D, k, int(bool(euclidean)), _p(dist), _p(idx))
     return dist, idx
+
+
+# ---- flow.c ------------------------------------------------------------------------------
+def blend_anchor_motion(query, ref, ref_flow, k=3, euclidean=True):
+    """utils/flow_utils.py:147-170 -> (flow [nq,3], mask bool [nq])."""
+    query, ref, ref_flow = _f(query), _f(ref), _f(ref_flow)
+    nq, nr = query.shape[0], ref.shape[0]
+    flow = np.empty((nq, 3), np.float32)
+    mask = np.empty((nq,), np.uint8)
+    lib().oracle_blend_anchor_motion(_p(query), _p(ref), _p(ref_flow), nq, nr, k, int(bool(euclidean)),
+                                     _p(flow), _p(mask))
+    return flow, mask.astype(bool)
+
+
+def flow_loss(gt, pred, mask=None, robust=False, smooth_weight=1e-2, want_grad=True):
+    """networks/loss.py:10-21 -> (loss float, grad wrt pred or None)."""
+    gt, pred = _f(gt), _f(pred)
+    B, N, _ = pred.shape
+    m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+    grad = np.empty_like(pred) if want_grad else None
+    loss = lib().oracle_flow_loss(_p(gt), _p(pred), _p(m), B, N, int(bool(robust)),
+                                  ctypes.c_float(smooth_weight), _p(grad))
+    return loss, grad
+
+
+# ---- model.c -----------------------------------------------------------------------------
+def rotation_6d_to_matrix(d6):
+    d6 = _f(d6).reshape(-1, 6)
+    R = np.empty((d6.shape[0], 3, 3), np.float32)
+    lib().oracle_rotation_6d_to_matrix(_p(d6), d6.shape[0], _p(R))
+    return R
+
+
+def rotation_6d_backward(d6, gR):
+    d6, gR = _f(d6).reshape(-1, 6), _f(gR).reshape(-1, 9)
+    g = np.empty_like(d6)
+    lib().oracle_rotation_6d_backward(_p(d6), _p(gR), d6.shape[0], _p(g))
+    return g
+
+
+def base_forward(cano, W1, b1, W2, p6d, pt, gumbel, tau):
+    """networks/model.py:39-70 with injected noise ->
+    dict(out [B,N,3], seg_part [N], trans_list [B,P,4,4], y_soft [N,P], hard_idx [N])."""
+    cano, W1, b1, W2, p6d, pt, gumbel = map(_f, (cano, W1, b1, W2, p6d, pt, gumbel))
+    N, (B, P), H = cano.shape[0], p6d.shape[:2], W1.shape[0]
+    out = np.empty((B, N, 3), np.float32)
+    seg = np.empty((N,), np.int64)
+    trans = np.empty((B, P, 4, 4), np.float32)
+    y = np.empty((N, P), np.float32)
+    k = np.empty((N,), np.int32)
+    lib().oracle_base_forward(_p(cano), N, P, B, _p(W1), _p(b1), _p(W2), H, _p(p6d), _p(pt), _p(gumbel),
+                              ctypes.c_float(tau), _p(out), _p(seg), _p(trans), _p(y), _p(k))
+    return dict(out=out, seg_part=seg, trans_list=trans, y_soft=y, hard_idx=k)
+
+
+def base_backward(cano, W1, b1, W2, p6d, pt, y_soft, hard_idx, tau, G):
+    cano, W1, b1, W2, p6d, pt, y_soft, G = map(_f, (cano, W1, b1, W2, p6d, pt, y_soft, G))
+    hard_idx = np.ascontiguousarray(hard_idx, dtype=np.int32)
+    N, (B, P), H = cano.shape[0], p6d.shape[:2], W1.shape[0]
+    gW1, gb1, gW2 = np.empty_like(W1), np.empty_like(b1), np.empty_like(W2)
+    g6d, gt = np.empty_like(p6d), np.empty_like(pt)
+    lib().oracle_base_backward(_p(cano), N, P, B, _p(W1), _p(b1), _p(W2), H, _p(p6d), _p(pt), _p(y_soft),
+                               _p(hard_idx), ctypes.c_float(tau), _p(G), _p(gW1), _p(gb1), _p(gW2), _p(g6d), _p(gt))
+    return dict(gW1=gW1, gb1=gb1, gW2=gW2, g6d=g6d, gt=gt)
+
+
+def compute_pc_transform(cano, pose, part):
+    cano, pose = _f(cano), _f(pose)
+    part = np.ascontiguousarray(part, dtype=np.int64)
+    B, P = pose.shape[:2]
+    out = np.empty((B, cano.shape[0], 3), np.float32)
+    lib().oracle_compute_pc_transform(_p(cano), _p(pose), _p(part), cano.shape[0], P, B, _p(out))
+    return out
+
+
+def adam(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+    """In-place torch.optim.Adam step on float32 arrays p, m, v."""
+    assert p.dtype == np.float32 and p.flags.c_contiguous
+    g = _f(g)
+    lib().oracle_adam(_p(p), _p(g), _p(m), _p(v), p.size, step, ctypes.c_float(lr), ctypes.c_float(beta1),
+                      ctypes.c_float(beta2), ctypes.c_float(eps))

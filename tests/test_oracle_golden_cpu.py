@@ -1,0 +1,100 @@
+"""CPU: pin the oracle against the golden vectors generated from the reference's own Python
+(tests/golden/make_golden.py).  These are the known-answer tests that make the oracle a
+trustworthy checker for the HIP kernels."""
+import os
+
+import numpy as np
+import pytest
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(G, name + ".npz"))
+
+
+def test_chamfer_golden(oracle):
+    g = load("chamfer")
+    d, i = oracle.knn_points(g["a"], g["b"], K=1)
+    np.testing.assert_array_equal(i, g["k1_i"]); np.testing.assert_array_equal(d, g["k1_d"])
+    d, i = oracle.knn_points(g["a"], g["b"], K=3)
+    np.testing.assert_array_equal(i, g["k3_i"]); np.testing.assert_array_equal(d, g["k3_d"])
+    d1, i1, d2, i2 = oracle.chamfer_bidir(g["src"], g["tgt"])
+    np.testing.assert_array_equal(i1, g["fwd_idx"]); np.testing.assert_array_equal(i2, g["bwd_idx"])
+    np.testing.assert_array_equal(d1 + d2, g["cd"])
+    assert abs((d1 + d2).astype(np.float64).sum() - float(g["recon_loss"])) <= 1e-5 * float(g["recon_loss"])
+    # the reference's independent KD-tree Chamfer (utils/eval_utils.py:39-66) on the same clouds
+    assert abs((d1 + d2).astype(np.float64).sum() - float(g["kdtree_sum"])) <= 1e-5 * float(g["kdtree_sum"])
+    ones = np.ones(d1.shape + (1,), np.float32)
+    gx1, _ = oracle.knn_points_backward(g["src"], g["tgt"], i1[..., None], ones)
+    _, gx2 = oracle.knn_points_backward(g["tgt"], g["src"], i2[..., None], ones)
+    np.testing.assert_allclose(gx1 + gx2, g["grad_src"], rtol=0, atol=1e-6)
+
+
+def test_flow_golden(oracle):
+    g = load("flow")
+    for robust in (0, 1):
+        loss, grad = oracle.flow_loss(g["gt"], g["pred"], g["mask"], robust=bool(robust))
+        assert abs(loss - float(g[f"loss_r{robust}"])) <= 1e-5 * abs(float(g[f"loss_r{robust}"]))
+        np.testing.assert_allclose(grad, g[f"grad_r{robust}"], rtol=1e-6, atol=1e-7)
+    loss, grad = oracle.flow_loss(g["gt"], g["pred"], None)
+    assert abs(loss - float(g["loss_nomask"])) <= 1e-5 * abs(float(g["loss_nomask"]))
+    np.testing.assert_allclose(grad, g["grad_nomask"], rtol=1e-6, atol=1e-7)
+    for q, f, m in (("query", "blend", "blend_mask"), ("query_far", "blend_far", "blend_mask_far")):
+        flow, mask = oracle.blend_anchor_motion(g[q], g["ref"], g["ref_flow"], k=3)
+        np.testing.assert_array_equal(mask, g[m])
+        np.testing.assert_allclose(flow, g[f], rtol=1e-5, atol=1e-8)
+    assert g["blend_mask"].any() and not g["blend_mask_far"].all()  # both mask outcomes covered
+
+
+def test_rotation_6d_golden(oracle):
+    g = load("se3")
+    R = oracle.rotation_6d_to_matrix(g["d6"])
+    np.testing.assert_allclose(R, g["R"], rtol=2e-6, atol=1e-6)  # fp32: norm/dot rounding order differs from torch
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_base_model_golden(oracle, tag):
+    g = load("base_model")
+    p6d = g["p6d_c"] if tag == "c" else g["p6d"]
+    tau = float(g[f"tau_{tag}"])
+    f = oracle.base_forward(g["cano"], g["W1"], g["b1"], g["W2"], p6d, g["pt"], g[f"noise_{tag}"], tau)
+    np.testing.assert_array_equal(f["seg_part"], g[f"seg_{tag}"])
+    np.testing.assert_allclose(f["trans_list"], g[f"trans_{tag}"], rtol=0, atol=3e-7)
+    np.testing.assert_allclose(f["out"], g[f"out_{tag}"], rtol=0, atol=5e-7)
+    b = oracle.base_backward(g["cano"], g["W1"], g["b1"], g["W2"], p6d, g["pt"], f["y_soft"], f["hard_idx"], tau,
+                             g[f"G_{tag}"])
+
+    def close(x, y, rel=2e-4):
+        scale = np.abs(y).max()
+        np.testing.assert_allclose(x, y, rtol=0, atol=rel * scale)
+
+    close(b["g6d"], g[f"g6d_{tag}"]); close(b["gt"], g[f"gt_{tag}"])
+    if tag != "c":
+        close(b["gW1"], g[f"gW1_{tag}"]); close(b["gb1"], g[f"gb1_{tag}"]); close(b["gW2"], g[f"gW2_{tag}"])
+
+
+def test_known_answers(oracle):
+    """Committed artefacts: compute_pc_transform on result_14999.pkl (512-pt subsample)."""
+    g = load("known_answers")
+    pred = oracle.compute_pc_transform(g["cano_sub"], g["pose"], g["part"][g["sub"]])
+    np.testing.assert_allclose(pred, g["pred_sub"], rtol=0, atol=3e-7)
+    assert abs(float(g["cd_result_x100"]) - 0.012520) < 5e-7
+    assert abs(float(g["cd_ckpt_x100"]) - 0.012503) < 5e-7
+    assert abs(float(g["cd_kin_x100"]) - 0.013050) < 5e-7
+
+
+def test_adam_matches_torch(oracle):
+    import torch
+
+    rng = np.random.default_rng(0)
+    p = rng.normal(size=200).astype(np.float32)
+    pt = torch.tensor(p.copy(), requires_grad=True)
+    opt = torch.optim.Adam([pt], lr=1e-2)
+    m, v = np.zeros_like(p), np.zeros_like(p)
+    for step in range(1, 6):
+        g = rng.normal(size=200).astype(np.float32)
+        pt.grad = torch.tensor(g)
+        opt.step()
+        oracle.adam(p, g, m, v, step, 1e-2)
+        np.testing.assert_allclose(p, pt.detach().numpy(), rtol=0, atol=2e-7)
