@@ -94,6 +94,73 @@ int reart_knn_cuda(const float *ref, const float *query, int B, int nr, int nq,
                    int D, int k, int euclidean, float *dist, int64_t *idx,
                    void *workspace, size_t workspace_bytes, void *stream);
 
+/* ------------------------------------------------------------------------ */
+/* Flow loss                                                                 */
+/* ------------------------------------------------------------------------ */
+
+/* Replaces blend_anchor_motion(query_loc, reference_loc, reference_flow, knn, return_mask=True)
+ * (utils/flow_utils.py:147-170) including its knn_cuda.KNN(k) call (:158):
+ *   query [nq,3], ref [nr,3], ref_flow [nr,3] -> flow [nq,3], mask [nq] (uint8 0/1). */
+size_t reart_blend_anchor_motion_workspace_bytes(int nq, int nr, int k);
+int reart_blend_anchor_motion(const float *query, const float *ref, const float *ref_flow,
+                              int nq, int nr, int k, int euclidean,
+                              float *flow, uint8_t *mask,
+                              void *workspace, size_t workspace_bytes, void *stream);
+
+/* Replaces flow_loss(gt_flow_list, pred_flow_list, flow_mask_list, robust, smooth_weight)
+ * (networks/loss.py:10-21): gt, pred [B,N,3]; mask [B,N] uint8 or NULL (= all ones);
+ * loss: device float scalar; grad_pred [B,N,3] or NULL = d loss / d pred. */
+size_t reart_flow_loss_workspace_bytes(void);
+int reart_flow_loss(const float *gt, const float *pred, const uint8_t *mask, int B, int N,
+                    int robust, float smooth_weight, float *loss, float *grad_pred,
+                    void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------ */
+/* Relaxation model (BaseModel) and rigid transforms                         */
+/* ------------------------------------------------------------------------ */
+
+/* Replaces BaseModel.forward(cano_pc, tau=...) (networks/model.py:39-70): seg head
+ * 3->H->P (networks/blocks.py:99-118; W1 [H,3], b1 [H], W2 [P,H], last layer bias-free),
+ * hard Gumbel-softmax with the -log(Exp(1)) noise `gumbel` [N,P] supplied by the caller
+ * (F.gumbel_softmax draws it from torch's generator), rotation_6d_to_matrix
+ * (screw_se3/geo_utils.py:632-651) and the per-part rigid apply.
+ *   out [B,N,3]; seg_part [N] i64 = arg-max of the noise-free logits (:70);
+ *   trans_list [B,P,4,4]; saved for backward: yT [P,N], hT [H,N], hard_idx [N] i32.
+ *   seg_part / trans_list / yT / hT / hard_idx may be NULL.  P <= 32. */
+int reart_base_forward(const float *cano, int N, int P, int B,
+                       const float *W1, const float *b1, const float *W2, int H,
+                       const float *prop6d, const float *propt,
+                       const float *gumbel, float tau,
+                       float *out, int64_t *seg_part, float *trans_list,
+                       float *yT, float *hT, int32_t *hard_idx, void *stream);
+
+/* Backward of the above (the reference relies on autograd): G = dL/d out [B,N,3] ->
+ * gradients of W1, b1, W2, proposal_6d [B,P,6], proposal_t [B,P,3].  Deterministic
+ * (fixed-order chunked reductions, no atomics). */
+size_t reart_base_backward_workspace_bytes(int N, int P, int B, int H);
+int reart_base_backward(const float *cano, int N, int P, int B,
+                        const float *W1, const float *b1, const float *W2, int H,
+                        const float *prop6d, const float *propt,
+                        const float *yT, const float *hT, const int32_t *hard_idx, float tau,
+                        const float *G,
+                        float *gW1, float *gb1, float *gW2, float *g6d, float *gt,
+                        void *workspace, size_t workspace_bytes, void *stream);
+
+/* Replaces compute_pc_transform(cano_pc, pose_list, cano_part) (utils/model_utils.py:54-67)
+ * and the hard-label apply of KinematicModel.forward (networks/model.py:161-165):
+ *   cano [N,3], pose [B,P,4,4], part [N] i64 -> out [B,N,3]. */
+int reart_compute_pc_transform(const float *cano, const float *pose, const int64_t *part,
+                               int N, int P, int B, float *out, void *stream);
+
+/* Replaces rotation_6d_to_matrix (screw_se3/geo_utils.py:632-651): d6 [n,6] -> R [n,3,3]. */
+int reart_rotation_6d_to_matrix(const float *d6, int n, float *R, void *stream);
+
+/* One torch.optim.Adam step on one tensor (run_robot.py:145-151,219-221; amsgrad off,
+ * weight_decay 0).  `step` is the 1-based step count. */
+int reart_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
+                    int n, int step, float lr, float beta1, float beta2, float eps,
+                    void *stream);
+
 #ifdef __cplusplus
 }
 #endif

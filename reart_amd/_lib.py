@@ -27,6 +27,17 @@ PROTOTYPES = {
     "reart_chamfer_bidir_workspace_bytes": (c_size_t, [c_int] * 2),
     "reart_chamfer_bidir": (c_int, [P, P, c_int, c_int, P, P, P, P, P, c_size_t, P]),
     "reart_knn_cuda": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, c_size_t, P]),
+    "reart_blend_anchor_motion_workspace_bytes": (c_size_t, [c_int] * 3),
+    "reart_blend_anchor_motion": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P, P, c_size_t, P]),
+    "reart_flow_loss_workspace_bytes": (c_size_t, []),
+    "reart_flow_loss": (c_int, [P, P, P, c_int, c_int, c_int, c_float, P, P, P, c_size_t, P]),
+    "reart_base_forward": (c_int, [P, c_int, c_int, c_int, P, P, P, c_int, P, P, P, c_float, P, P, P, P, P, P, P]),
+    "reart_base_backward_workspace_bytes": (c_size_t, [c_int] * 4),
+    "reart_base_backward": (c_int, [P, c_int, c_int, c_int, P, P, P, c_int, P, P, P, P, P, c_float, P,
+                                    P, P, P, P, P, P, c_size_t, P]),
+    "reart_compute_pc_transform": (c_int, [P, P, P, c_int, c_int, c_int, P, P]),
+    "reart_rotation_6d_to_matrix": (c_int, [P, c_int, P, P]),
+    "reart_adam_step": (c_int, [P, P, P, P, c_int, c_int, c_float, c_float, c_float, c_float, P]),
 }
 
 _lib = None

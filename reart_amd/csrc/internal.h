@@ -1,0 +1,53 @@
+// reart_amd/csrc/internal.h -- argument blocks shared between the operator files and the
+// fused relaxation step (step.hip).  Not part of the C ABI.
+#pragma once
+#include "common.h"
+
+struct BaseFwdArgs {
+    const float *cano;
+    const float *W1, *b1, *W2, *p6d, *pt;
+    const float *gumbel;        // [N,P] injected noise, or NULL -> Philox(seed, *iter)
+    const float *tau_ptr;       // device scalar, or NULL -> tau
+    const int64_t *iter_ptr;    // device counter used as Philox offset (nullable -> 0)
+    uint64_t seed;
+    float tau;
+    int N, P, B, H, Npad;
+    float *out;                 // [B,N,3]
+    float *out_soa;             // [B,3,Npad] nullable (+INF beyond N), for the K-NN kernels
+    int64_t *seg_part;          // [N] nullable
+    float *trans_list;          // [B,P,4,4] nullable
+    float *yT;                  // [P,N] nullable
+    float *hT;                  // [H,N] nullable
+    int *hard_idx;              // [N] nullable
+};
+
+struct BaseBwdArgs {
+    const float *cano, *W2, *p6d, *pt;
+    const float *yT, *hT;
+    const int *hard_idx;
+    const float *tau_ptr;
+    float tau;
+    const float *G;             // [B,N,3]
+    int N, P, B, H;
+    float *dsT;                 // [P,N]   dL/d logits
+    float *dpT;                 // [H,N]   dL/d pre-activation of the hidden layer
+    int nchunk;                 // ceil(N / RED_CHUNK)
+    float *partial;             // [nchunk][n_out]
+    // finalize
+    const float *W1dummy;
+    float *gW1, *gb1, *gW2, *g6d, *gt;
+};
+
+struct AdamSeg { float *p; const float *g; float *m; float *v; int n; float lr; };
+struct AdamArgs { AdamSeg seg[8]; int nseg; float beta1, beta2, eps; const int64_t *step_ptr; int step; };
+
+int reart_base_forward_ex(const BaseFwdArgs &a, hipStream_t st);
+int reart_base_backward_ex(BaseBwdArgs a, void *workspace, size_t workspace_bytes, hipStream_t st);
+int reart_adam_ex(const AdamArgs &a, hipStream_t st);
+
+// generic K-NN driver (knn.hip): njobs in {1,2}; job j searches q[j] ([N,P1[j],3] AoS) in t[j]
+// ([N,P2[j],3] AoS); outputs dists/idx [N,P1[j],K].  Workspace: see knn_plan().
+int reart_knn_run(int njobs, const float *const *q, const float *const *t,
+                  const int64_t *const *lenq, const int64_t *const *lent, int N, const int *P1,
+                  const int *P2, int K, int euclidean, float *const *dists, int64_t *const *idx,
+                  void *workspace, size_t workspace_bytes, hipStream_t st);

@@ -20,6 +20,7 @@
 //   * Rounding contract: d = ((dx*dx)+(dy*dy))+(dz*dz), fp32, no FMA (file compiled with
 //     -ffp-contract=off), strict '<' while scanning ascending j.
 #include "common.h"
+#include "internal.h"
 #include <math.h>
 
 #define NN_BS 64   // threads per workgroup (one wave)
@@ -288,7 +289,7 @@ static void knn_launch(const KnnArgs &a, int njobs, int maxP1, hipStream_t st) {
 }
 
 // Generic driver: njobs in {1,2}
-static int knn_run(int njobs, const float *const *q, const float *const *t,
+int reart_knn_run(int njobs, const float *const *q, const float *const *t,
                    const int64_t *const *lenq, const int64_t *const *lent, int N, const int *P1,
                    const int *P2, int K, int euclidean, float *const *dists, int64_t *const *idx,
                    void *workspace, size_t workspace_bytes, hipStream_t st) {
@@ -373,7 +374,7 @@ extern "C" int reart_knn_points_idx(const float *p1, const float *p2, const int6
     }
     if (!p1 || !p2) return REART_ERR_INVALID_ARG;
     const int64_t *lq[1] = {lengths1}, *lt[1] = {lengths2};
-    return knn_run(1, &p1, &p2, lq, lt, N, &P1, &P2, K, 0, &dists, &idx, workspace, workspace_bytes, st);
+    return reart_knn_run(1, &p1, &p2, lq, lt, N, &P1, &P2, K, 0, &dists, &idx, workspace, workspace_bytes, st);
 }
 
 extern "C" int reart_chamfer_bidir(const float *x, const float *y, int N, int P, float *d_xy,
@@ -386,7 +387,7 @@ extern "C" int reart_chamfer_bidir(const float *x, const float *y, int N, int P,
     const int Ps[2] = {P, P};
     float *dd[2] = {d_xy, d_yx};
     int64_t *ii[2] = {i_xy, i_yx};
-    return knn_run(2, q, t, nullptr, nullptr, N, Ps, Ps, 1, 0, dd, ii, workspace, workspace_bytes,
+    return reart_knn_run(2, q, t, nullptr, nullptr, N, Ps, Ps, 1, 0, dd, ii, workspace, workspace_bytes,
                    (hipStream_t)stream);
 }
 
@@ -398,7 +399,7 @@ extern "C" int reart_knn_cuda(const float *ref, const float *query, int B, int n
     if (k > nr) return REART_ERR_INVALID_ARG;  // knn_cuda asserts k <= number of references
     if (B == 0 || nq == 0) return REART_OK;
     if (!ref || !query || !dist || !idx) return REART_ERR_INVALID_ARG;
-    return knn_run(1, &query, &ref, nullptr, nullptr, B, &nq, &nr, k, euclidean ? 1 : 0, &dist, &idx,
+    return reart_knn_run(1, &query, &ref, nullptr, nullptr, B, &nq, &nr, k, euclidean ? 1 : 0, &dist, &idx,
                    workspace, workspace_bytes, (hipStream_t)stream);
 }
 

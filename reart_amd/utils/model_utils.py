@@ -1,0 +1,49 @@
+"""Host-side mirror of the hot-path helpers of the reference's ``utils/model_utils.py``."""
+import math
+
+import torch
+
+from .. import _lib
+
+
+def tau_cosine(cur_iter, max_iter, end_temp, start_temp):
+    """Cosine temperature schedule (utils/model_utils.py:33-37)."""
+    assert end_temp <= start_temp
+    return end_temp + (start_temp - end_temp) * (math.cos(math.pi * cur_iter / max_iter) + 1.0) * 0.5
+
+
+def th_with_zeros(tensor):
+    """[B,3,4] -> [B,4,4] by appending the row (0,0,0,1) (utils/model_utils.py:12-19)."""
+    pad = tensor.new_tensor([0.0, 0.0, 0.0, 1.0]).view(1, 1, 4).expand(tensor.shape[0], 1, 4)
+    return torch.cat([tensor, pad], dim=1)
+
+
+def create_transformation(rotation, translation):
+    """rotation [B,3,3], translation [B,3,1] -> [B,4,4] (utils/model_utils.py:22-30)."""
+    top = torch.cat([rotation, translation], dim=2)
+    return th_with_zeros(top)
+
+
+def compute_pc_transform(cano_pc, pose_list, cano_part):
+    """Apply each point's part transform (utils/model_utils.py:54-67):
+    cano_pc [N,3], pose_list [T-1,P,4,4], cano_part [N] -> [T-1,N,3]."""
+    _lib.require_gpu(cano_pc, pose_list, cano_part)
+    cano = cano_pc.contiguous().float()
+    pose = pose_list.contiguous().float()
+    part = cano_part.contiguous().long()
+    B, P = pose.shape[:2]
+    N = cano.shape[0]
+    out = torch.empty((B, N, 3), dtype=torch.float32, device=cano.device)
+    rc = _lib.lib().reart_compute_pc_transform(_lib.ptr(cano), _lib.ptr(pose), _lib.ptr(part), N, P, B,
+                                               _lib.ptr(out), _lib.stream())
+    _lib.check(rc, "reart_compute_pc_transform")
+    return out
+
+
+def knn_query(query_pc, src_pc, src_input, knn):
+    """Label / feature transfer from the k nearest source points (utils/model_utils.py:41-51)."""
+    _, idx = knn(ref=src_pc.unsqueeze(0), query=query_pc.unsqueeze(0))  # [1, nq, k]
+    idx = idx.squeeze(0).reshape(-1)
+    if src_input.dim() == 2:
+        return src_input[idx].reshape(-1, knn.k, src_input.shape[1]).mean(dim=1)
+    return torch.mode(src_input[idx].reshape(-1, knn.k), dim=1)[0]

@@ -129,10 +129,12 @@ def test_chamfer_full_size_properties(dev):
     diff = x - nn
     rec = (diff[..., 0] * diff[..., 0] + diff[..., 1] * diff[..., 1]) + diff[..., 2] * diff[..., 2]
     assert torch.equal(rec, d_xy)
-    # 2. it is a minimum: no target is strictly closer (checked against torch.cdist within rounding)
+    # 2. it is the minimum (and the lowest index attaining it) over all targets, on a query subsample
     for b in range(0, 19, 6):
-        ref = torch.cdist(x[b], y[b], compute_mode="donot_use_mm_for_euclid_dist").min(dim=1).values ** 2
-        assert torch.allclose(ref, d_xy[b], rtol=1e-5, atol=1e-9)
+        diff = x[b, ::8, None, :] - y[b, None, :, :]  # [512, 4096, 3]
+        sq = (diff[..., 0] * diff[..., 0] + diff[..., 1] * diff[..., 1]) + diff[..., 2] * diff[..., 2]
+        mn, am = sq.min(dim=1)
+        assert torch.equal(mn, d_xy[b, ::8]) and torch.equal(am, i_xy[b, ::8])
     # 3. self query: distance 0 at own index (ties -> lowest index == itself for distinct points)
     d_xx, i_xx, _, _ = C.chamfer_bidir(x, x)
     assert (d_xx == 0).all() and torch.equal(i_xx, torch.arange(4096, device=dev).expand(19, -1))
