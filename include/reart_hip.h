@@ -161,6 +161,70 @@ int reart_adam_step(float *param, const float *grad, float *exp_avg, float *exp_
                     int n, int step, float lr, float beta1, float beta2, float eps,
                     void *stream);
 
+/* ------------------------------------------------------------------------ */
+/* Fused relaxation iteration                                                */
+/* ------------------------------------------------------------------------ */
+
+/* One iteration of the reference's optimisation loop (run_robot.py:154-221, branch
+ * "Chamfer reconstruction loss [+ flow loss]", i.e. i < assign_iter): BaseModel forward
+ * with in-kernel Gumbel noise, recon_loss, blend_anchor_motion x (T-1) + flow_loss,
+ * backward, Adam with the reference's two parameter groups, cosine temperature schedule.
+ * Everything that changes between iterations (counter, RNG offset, tau, loss log) lives in
+ * device memory, so one call enqueues a fixed launch sequence: capture it once in a
+ * hipGraph / torch.cuda.CUDAGraph and replay. */
+typedef struct reart_relax_config {
+    int N, P, B, H;          /* points, parts (<=32), frames-1, seg-head width (128)      */
+    int cano_idx;            /* position of the canonical frame in the T = B+1 sequence   */
+    int use_flow;            /* --use_flow_loss                                           */
+    int robust;              /* --use_robust_loss (Huber, delta 1)                        */
+    int euclidean;           /* knn_cuda distance convention: 1 = sqrt (upstream)         */
+    int flow_k;              /* neighbours blended; 3 (run_robot.py:66)                   */
+    int M_max;               /* largest flow reference set                                */
+    int M_total;             /* sum of the reference set sizes                            */
+    int n_iter;              /* --n_iter: period of the cosine schedule                   */
+    int ring;                /* rows in the loss log                                      */
+    float lambda_flow;       /* --lambda_flow                                             */
+    float smooth_weight;     /* flow_loss smooth_weight, 1e-2                             */
+    float trans_lr, seg_lr;  /* --trans_lr, --seg_lr                                      */
+    float beta1, beta2, eps; /* Adam defaults 0.9, 0.999, 1e-8                            */
+    float start_tau, end_tau;/* --start_tau, --end_tau                                    */
+    float fixed_tau;         /* > 0: frozen temperature (resume, run_robot.py:96-97)      */
+    uint64_t seed;           /* Philox key of the Gumbel noise                            */
+} reart_relax_config;
+
+typedef struct reart_relax_buffers {
+    const float *cano;       /* [N,3]                                                     */
+    const float *pc_list;    /* [B,N,3] observed frames without the canonical one         */
+    const float *ref_loc;    /* [M_total,3] flow reference points, sets concatenated      */
+    const float *ref_flow;   /* [M_total,3] their flow vectors                            */
+    const int *ref_off;      /* [B+1] int32 prefix offsets of the sets                    */
+    const float *gumbel;     /* NULL (in-kernel Philox) or injected noise [N,P] (tests)   */
+    float *W1, *b1, *W2;     /* seg head [H,3], [H], [P,H]; updated in place              */
+    float *p6d, *pt;         /* proposal_6d [B,P,6], proposal_t [B,P,3]                   */
+    float *adam_m, *adam_v;  /* [3H+H+PH+9BP] each, order W1|b1|W2|p6d|pt, start at zero   */
+    int64_t *iter;           /* device scalar: completed iterations (caller initialises)  */
+    float *tau;              /* device scalar: temperature of the next iteration          */
+    float *losses;           /* [ring][4]: recon, lambda*flow, total, tau; row iter%ring  */
+    float *pc_trans;         /* [B,N,3] forward output of the last iteration              */
+    int64_t *seg_part;       /* [N] or NULL                                               */
+    float *trans_list;       /* [B,P,4,4] or NULL                                         */
+} reart_relax_buffers;
+
+size_t reart_relax_workspace_bytes(const reart_relax_config *cfg);
+/* once per problem: static SoA images of pc_list / reference sets, tau(iter) */
+int reart_relax_prepare(const reart_relax_config *cfg, const reart_relax_buffers *bufs,
+                        void *workspace, size_t workspace_bytes, void *stream);
+/* enqueue one iteration (10 launches, no host sync) */
+int reart_relax_step(const reart_relax_config *cfg, const reart_relax_buffers *bufs,
+                     void *workspace, size_t workspace_bytes, void *stream);
+/* measurement aid: the same sequence with hipEvents between phases on `stream`; synchronises
+ * and ADDS per-phase milliseconds to the HOST array h_ms[REART_RELAX_PHASES]:
+ * 0 forward, 1 Chamfer K=1 search, 2 flow K=3 search, 3 flow blend, 4 Chamfer merge+grad,
+ * 5 model backward, 6 Adam, 7 bookkeeping. */
+#define REART_RELAX_PHASES 8
+int reart_relax_step_timed(const reart_relax_config *cfg, const reart_relax_buffers *bufs,
+                           void *workspace, size_t workspace_bytes, void *stream, float *h_ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -38,6 +38,11 @@ PROTOTYPES = {
     "reart_compute_pc_transform": (c_int, [P, P, P, c_int, c_int, c_int, P, P]),
     "reart_rotation_6d_to_matrix": (c_int, [P, c_int, P, P]),
     "reart_adam_step": (c_int, [P, P, P, P, c_int, c_int, c_float, c_float, c_float, c_float, P]),
+    # struct-taking entry points: full prototypes are set in reart_amd/relax.py
+    "reart_relax_workspace_bytes": (c_size_t, None),
+    "reart_relax_prepare": (c_int, None),
+    "reart_relax_step": (c_int, None),
+    "reart_relax_step_timed": (c_int, None),
 }
 
 _lib = None
@@ -63,7 +68,9 @@ def lib():
                 handle = ctypes.CDLL(LIB_PATH)
                 for name, (res, args) in PROTOTYPES.items():
                     fn = getattr(handle, name)  # AttributeError if the .so is stale
-                    fn.restype, fn.argtypes = res, args
+                    fn.restype = res
+                    if args is not None:
+                        fn.argtypes = args
                 _lib = handle
     return _lib
 

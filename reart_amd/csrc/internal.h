@@ -51,3 +51,42 @@ int reart_knn_run(int njobs, const float *const *q, const float *const *t,
                   const int64_t *const *lenq, const int64_t *const *lent, int N, const int *P1,
                   const int *P2, int K, int euclidean, float *const *dists, int64_t *const *idx,
                   void *workspace, size_t workspace_bytes, hipStream_t st);
+
+// ---- K-NN internals (knn.hip) -----------------------------------------------------------
+#define NN_BS 64   // threads per workgroup (one wave)
+#define NN_UB 16   // targets per unrolled block; slice lengths are multiples of this
+struct SoaJob {
+    const float *src;
+    const int64_t *len;  // nullable
+    float *dst;
+    int P, Ppad;
+};
+struct SoaArgs {
+    SoaJob job[2];
+};
+
+struct KnnJob {
+    const float *q;        // [N,P1,3] AoS queries
+    const float *tsoa;     // [N,3,Ppad] SoA targets
+    const int64_t *lenq;   // nullable, rows >= lenq[n] produce zeros
+    const int64_t *lent;   // nullable, number of valid targets
+    const float *q_alt;    // fused step: query cloud used where qmap[b] < 0
+    const int *qmap;       // nullable per-batch query frame index into q
+    const int *tlen;       // nullable per-batch target count (ragged SoA rows, stride Ppad)
+    int P1, P2, Ppad, L;   // Ppad = S*L, L % NN_UB == 0
+    int nqg;               // ceil(P1/64)
+    float *pd;             // partial dists [S][N][P1][KK]   (S > 1)
+    int *pi;               // partial idx   [S][N][P1][KK]
+    float *dists;          // final [N,P1,K]
+    int64_t *idx;          // final [N,P1,K]
+};
+struct KnnArgs {
+    KnnJob job[2];
+    int N, S, K, euclidean;
+    int items0;            // work items belonging to job 0
+    int items;             // total work items
+};
+
+int reart_knn_launch_slices(const KnnArgs &a, int KK, hipStream_t st);
+int reart_soa_launch(const SoaArgs &sa, int maxPpad, int N, int njobs, hipStream_t st);
+int reart_knn_pick_split(long waves, int P2);

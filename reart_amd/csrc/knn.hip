@@ -21,23 +21,15 @@
 //     -ffp-contract=off), strict '<' while scanning ascending j.
 #include "common.h"
 #include "internal.h"
+#include "blocksort.h"
 #include <math.h>
 
-#define NN_BS 64   // threads per workgroup (one wave)
-#define NN_UB 16   // targets per unrolled block; slice lengths are multiples of this
+
+
 
 // ---------------------------------------------------------------------------------
 // AoS [n][P][3]  ->  SoA [n][3][Ppad], entries j >= length padded with +INF
 // ---------------------------------------------------------------------------------
-struct SoaJob {
-    const float *src;
-    const int64_t *len;  // nullable
-    float *dst;
-    int P, Ppad;
-};
-struct SoaArgs {
-    SoaJob job[2];
-};
 
 __global__ __launch_bounds__(256) void soa_kernel(SoaArgs a) {
     const SoaJob jb = a.job[blockIdx.z];
@@ -60,24 +52,6 @@ __global__ __launch_bounds__(256) void soa_kernel(SoaArgs a) {
 // ---------------------------------------------------------------------------------
 // Slice kernel
 // ---------------------------------------------------------------------------------
-struct KnnJob {
-    const float *q;        // [N,P1,3] AoS queries
-    const float *tsoa;     // [N,3,Ppad] SoA targets
-    const int64_t *lenq;   // nullable, rows >= lenq[n] produce zeros
-    const int64_t *lent;   // nullable, number of valid targets
-    int P1, P2, Ppad, L;   // Ppad = S*L, L % NN_UB == 0
-    int nqg;               // ceil(P1/64)
-    float *pd;             // partial dists [S][N][P1][KK]   (S > 1)
-    int *pi;               // partial idx   [S][N][P1][KK]
-    float *dists;          // final [N,P1,K]
-    int64_t *idx;          // final [N,P1,K]
-};
-struct KnnArgs {
-    KnnJob job[2];
-    int N, S, K, euclidean;
-    int items0;            // work items belonging to job 0
-    int items;             // total work items
-};
 
 template <int KK>
 __device__ __forceinline__ void knn_insert(float (&kd)[KK], int (&ki)[KK], float d, int j) {
@@ -124,14 +98,18 @@ __global__ __launch_bounds__(NN_BS) void knn_slice_kernel(KnnArgs a) {
 
     const int i = g * NN_BS + threadIdx.x;
     const int ic = i < jb.P1 ? i : jb.P1 - 1;  // clamp: tail lanes redo the last query
-    const float *qp = jb.q + ((size_t)b * jb.P1 + ic) * 3;
+    // optional per-batch query remap (fused step: pair f queries frame qmap[f], <0 = q_alt)
+    const int qb = jb.qmap ? jb.qmap[b] : b;
+    const float *qp = (qb < 0 ? jb.q_alt : jb.q + (size_t)qb * jb.P1 * 3) + (size_t)ic * 3;
     const float qx = qp[0], qy = qp[1], qz = qp[2];
     const f2 qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
 
     const float *tx = jb.tsoa + (size_t)b * 3 * jb.Ppad;
     const float *ty = tx + jb.Ppad;
     const float *tz = ty + jb.Ppad;
-    const int j0 = s * jb.L, j1 = j0 + jb.L;
+    // ragged targets: per-batch slice length from the batch's own target count
+    const int Lb = jb.tlen ? (((jb.tlen[b] + a.S - 1) / a.S + NN_UB - 1) / NN_UB) * NN_UB : jb.L;
+    const int j0 = s * Lb, j1 = j0 + Lb;
 
     float kd[KK];
     int ki[KK];
@@ -238,6 +216,8 @@ static int knn_pick_split(long waves, int P2) {
     return S < 1 ? 1 : S;
 }
 
+int reart_knn_pick_split(long waves, int P2) { return knn_pick_split(waves, P2); }
+
 struct KnnPlan {
     int KK, S;
     int L[2], Ppad[2];
@@ -273,6 +253,23 @@ static int knn_plan(int njobs, int N, const int *P1, const int *P2, int K, KnnPl
         }
     }
     pl->total = off;
+    return REART_OK;
+}
+
+// partial-only launch used by the fused step (merge happens in its consumer kernels)
+int reart_knn_launch_slices(const KnnArgs &a, int KK, hipStream_t st) {
+    const int grid = reart_xcd_grid(a.items);
+    switch (KK) {
+        case 1: hipLaunchKernelGGL((knn_slice_kernel<1, false>), dim3(grid), dim3(NN_BS), 0, st, a); break;
+        case 3: hipLaunchKernelGGL((knn_slice_kernel<3, false>), dim3(grid), dim3(NN_BS), 0, st, a); break;
+        default: return REART_ERR_UNSUPPORTED;
+    }
+    REART_CHECK_LAUNCH();
+    return REART_OK;
+}
+int reart_soa_launch(const SoaArgs &sa, int maxPpad, int N, int njobs, hipStream_t st) {
+    hipLaunchKernelGGL(soa_kernel, dim3(reart_div_up(maxPpad, 256), N, njobs), dim3(256), 0, st, sa);
+    REART_CHECK_LAUNCH();
     return REART_OK;
 }
 
@@ -313,6 +310,7 @@ int reart_knn_run(int njobs, const float *const *q, const float *const *t,
         sa.job[j].Ppad = pl.Ppad[jj];
         KnnJob &kj = a.job[j];
         kj.q = q[jj];
+        kj.q_alt = nullptr; kj.qmap = nullptr; kj.tlen = nullptr;
         kj.tsoa = (const float *)(ws + pl.off_soa[jj]);
         kj.lenq = lenq ? lenq[jj] : nullptr;
         kj.lent = lent ? lent[jj] : nullptr;
@@ -411,14 +409,15 @@ extern "C" int reart_knn_cuda(const float *ref, const float *query, int B, int n
 // index in the caller's workspace, sorts every bucket ascending and accumulates in that
 // order -- the same order the CPU loop uses, with no floating-point atomics.
 // ---------------------------------------------------------------------------------
-#define BWD_BS 1024
+#define BWD_BS RS_BS
 
 __global__ __launch_bounds__(BWD_BS) void knn_bwd_kernel(
     const float *__restrict__ p1, const float *__restrict__ p2, const int64_t *__restrict__ len1,
     const int64_t *__restrict__ len2, const int64_t *__restrict__ idx,
-    const float *__restrict__ gd, int P1, int P2, int K, float *__restrict__ g1,
+    const float *__restrict__ gd, int P1, int P2, int K, int nbits, float *__restrict__ g1,
     float *__restrict__ g2, int *__restrict__ ws) {
-    __shared__ int s_scan[BWD_BS];
+    __shared__ int s_cnt[RS_DIG * RS_BS];
+    __shared__ int s_wave[RS_BS / 64];
     const int n = blockIdx.x, tid = threadIdx.x;
     int n1 = len1 ? (int)len1[n] : P1;
     int n2 = len2 ? (int)len2[n] : P2;
@@ -428,13 +427,13 @@ __global__ __launch_bounds__(BWD_BS) void knn_bwd_kernel(
     p1 += (size_t)n * P1 * 3; p2 += (size_t)n * P2 * 3;
     idx += (size_t)n * P1 * K; gd += (size_t)n * P1 * K;
     g1 += (size_t)n * P1 * 3; g2 += (size_t)n * P2 * 3;
-    int *cnt = ws + (size_t)n * (2 * (size_t)P2 + (size_t)P1 * K);  // [P2]
-    int *off = cnt + P2;                                             // [P2]
-    int *lst = off + P2;                                             // [P1*K]
+    int *cnt = ws + (size_t)n * (2 * (size_t)P2 + 2 * (size_t)P1 * K);  // [P2]
+    int *off = cnt + P2;                                                 // [P2]
+    int *bufA = off + P2, *bufB = bufA + (size_t)P1 * K;                 // [P1*K] each
 
     for (int j = tid; j < P2; j += BWD_BS) cnt[j] = 0;
     __syncthreads();
-    // grad_p1 and bucket counts
+    // grad_p1 and bucket counts (integer atomics: order-independent result)
     for (int i = tid; i < P1; i += BWD_BS) {
         float ax = 0.f, ay = 0.f, az = 0.f;
         if (i < n1) {
@@ -451,44 +450,26 @@ __global__ __launch_bounds__(BWD_BS) void knn_bwd_kernel(
         g1[3 * i] = ax; g1[3 * i + 1] = ay; g1[3 * i + 2] = az;
     }
     __syncthreads();
-    // exclusive scan of cnt -> off (chunk per thread + block scan of chunk totals)
+    // exclusive scan of cnt -> off
     const int chunk = (P2 + BWD_BS - 1) / BWD_BS;
-    const int c0 = tid * chunk, c1 = (c0 + chunk < P2) ? c0 + chunk : P2;
+    const int c0 = tid * chunk < P2 ? tid * chunk : P2, c1 = (c0 + chunk < P2) ? c0 + chunk : P2;
     int tot = 0;
     for (int j = c0; j < c1; ++j) tot += cnt[j];
-    s_scan[tid] = tot;
-    __syncthreads();
-    for (int o = 1; o < BWD_BS; o <<= 1) {
-        const int v = (tid >= o) ? s_scan[tid - o] : 0;
-        __syncthreads();
-        s_scan[tid] += v;
-        __syncthreads();
-    }
-    int run = s_scan[tid] - tot;
-    for (int j = c0; j < c1; ++j) { off[j] = run; run += cnt[j]; cnt[j] = 0; }
-    __syncthreads();
-    // scatter pair ids into buckets (order inside a bucket fixed by the sort below)
-    for (int i = tid; i < n1; i += BWD_BS)
-        for (int k = 0; k < kk; ++k) {
-            const int j = (int)idx[(size_t)i * K + k];
-            const int pos = off[j] + atomicAdd(&cnt[j], 1);
-            lst[pos] = i * K + k;
-        }
-    __syncthreads();
+    int run = block_excl_scan(tot, s_wave, nullptr);
+    for (int j = c0; j < c1; ++j) { off[j] = run; run += cnt[j]; }
+    // valid (i,k) pairs, id e = i*kk + k, stably sorted by target index
+    const int M = n1 * kk;
+    const int *sorted = block_stable_sort_ids(M, nbits, bufA, bufB, s_cnt, s_wave, [&](int e) {
+        return (int)idx[(size_t)(e / kk) * K + (e % kk)];
+    });
     for (int j = tid; j < P2; j += BWD_BS) {
         const int o = off[j], c = cnt[j];
-        for (int a = 1; a < c; ++a) {  // insertion sort, buckets are tiny
-            const int v = lst[o + a];
-            int bpos = a - 1;
-            while (bpos >= 0 && lst[o + bpos] > v) { lst[o + bpos + 1] = lst[o + bpos]; --bpos; }
-            lst[o + bpos + 1] = v;
-        }
         float ax = 0.f, ay = 0.f, az = 0.f;
         const float x = p2[3 * j], y = p2[3 * j + 1], z = p2[3 * j + 2];
         for (int a = 0; a < c; ++a) {
-            const int e = lst[o + a];
-            const int i = e / K;
-            const float cf = 2.0f * gd[e];
+            const int e = sorted[o + a];
+            const int i = e / kk, k = e % kk;
+            const float cf = 2.0f * gd[(size_t)i * K + k];
             ax -= cf * (p1[3 * i] - x);
             ay -= cf * (p1[3 * i + 1] - y);
             az -= cf * (p1[3 * i + 2] - z);
@@ -499,7 +480,7 @@ __global__ __launch_bounds__(BWD_BS) void knn_bwd_kernel(
 
 extern "C" size_t reart_knn_points_backward_workspace_bytes(int N, int P1, int P2, int K) {
     if (N <= 0 || P1 < 0 || P2 < 0 || K < 1) return 0;
-    return sizeof(int) * (size_t)N * (2 * (size_t)P2 + (size_t)P1 * K);
+    return sizeof(int) * (size_t)N * (2 * (size_t)P2 + 2 * (size_t)P1 * K);
 }
 
 extern "C" int reart_knn_points_backward(const float *p1, const float *p2, const int64_t *lengths1,
@@ -523,7 +504,7 @@ extern "C" int reart_knn_points_backward(const float *p1, const float *p2, const
     if (workspace_bytes < reart_knn_points_backward_workspace_bytes(N, P1, P2, K))
         return REART_ERR_INVALID_ARG;
     hipLaunchKernelGGL(knn_bwd_kernel, dim3(N), dim3(BWD_BS), 0, st, p1, p2, lengths1, lengths2, idx,
-                       grad_dists, P1, P2, K, grad_p1, grad_p2, (int *)workspace);
+                       grad_dists, P1, P2, K, reart_bits_for(P2), grad_p1, grad_p2, (int *)workspace);
     REART_CHECK_LAUNCH();
     return REART_OK;
 }

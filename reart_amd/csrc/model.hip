@@ -118,9 +118,11 @@ __device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2
     }
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
-// -log(Exp(1)) sample: u in (0,1) -> e = -log u -> g = -log e   (F.gumbel_softmax recipe)
+// -log(Exp(1)) sample: u in (0,1) -> e = -log u -> g = -log e   (F.gumbel_softmax recipe).
+// 23 random bits + 0.5: every value (k + 0.5) * 2^-23 is exactly representable, so u never
+// rounds to 1.0 (which would give e = 0, g = +inf and a NaN softmax once in 2^24 draws).
 __device__ __forceinline__ float gumbel_from_bits(uint32_t bits) {
-    const float u = ((float)(bits >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float u = ((float)(bits >> 9) + 0.5f) * (1.0f / 8388608.0f);
     return -logf(-logf(u));
 }
 

@@ -1,0 +1,509 @@
+// reart_amd/csrc/step.hip -- the fused relaxation iteration (reference run_robot.py:154-221,
+// Chamfer + flow branch): forward, both Chamfer directions, k=3 flow blending, losses, the
+// whole backward and the Adam update as a fixed sequence of ten kernel launches with NO host
+// interaction -- iteration counter, Gumbel RNG offset, temperature and loss log all live in
+// device memory, so the sequence can be captured once in a hipGraph and replayed.
+//
+// The reference does, per iteration: ~40 PyTorch ops for the model, 2 knn_points launches,
+// 19 KNN(k=3) launches + ~200 small ops for the flow blend, autograd, Adam, and 2-4
+// .cpu() syncs plus a print (run_robot.py:186,190,212,216-217).
+#include "common.h"
+#include "internal.h"
+#include "blocksort.h"
+#include <math.h>
+
+// ------------------------------------------------------------------------------ layout
+struct StepPlan {
+    int S1, L1, Npad;        // Chamfer K=1: slices, slice length, padded SoA row
+    int S3, Mpad;            // flow K=3: slices, padded SoA row of the reference sets
+    int nchunk, nparams;
+    size_t o_ysoa, o_xsoa, o_rsoa, o_rlen, o_qmap;
+    size_t o_pd0, o_pi0, o_pd1, o_pi1, o_pd3, o_pi3;
+    size_t o_yT, o_hT, o_hard, o_G, o_gpf, o_cint, o_floss, o_fpart, o_grads, o_bwd;
+    size_t bwd_bytes, total;
+};
+
+static size_t take(size_t &off, size_t bytes) {
+    const size_t o = off;
+    off += reart_align_up(bytes, 256);
+    return o;
+}
+
+#define FLOW_BS 256
+
+static int step_plan(const reart_relax_config *c, StepPlan *p) {
+    if (c->N <= 0 || c->P <= 0 || c->P > 32 || c->B <= 0 || c->H <= 0) return REART_ERR_INVALID_ARG;
+    if (c->use_flow && (c->flow_k != 3 || c->M_max < 3)) return REART_ERR_UNSUPPORTED;
+    const long waves1 = 2L * c->B * reart_div_up(c->N, NN_BS);
+    p->S1 = reart_knn_pick_split(waves1, c->N);
+    p->L1 = (int)reart_align_up((size_t)reart_div_up(c->N, p->S1), NN_UB);
+    p->Npad = p->L1 * p->S1;
+    p->S3 = 1; p->Mpad = 0;
+    if (c->use_flow) {
+        const long waves3 = (long)c->B * reart_div_up(c->N, NN_BS);
+        p->S3 = reart_knn_pick_split(waves3, c->M_max);
+        p->Mpad = (int)reart_align_up((size_t)reart_div_up(c->M_max, p->S3), NN_UB) * p->S3;
+    }
+    p->nchunk = reart_div_up(c->N, 64);
+    p->nparams = 3 * c->H + c->H + c->P * c->H + 6 * c->B * c->P + 3 * c->B * c->P;
+    size_t off = 0;
+    const size_t BN = (size_t)c->B * c->N;
+    p->o_ysoa = take(off, sizeof(float) * 3 * c->B * (size_t)p->Npad);
+    p->o_xsoa = take(off, sizeof(float) * 3 * c->B * (size_t)p->Npad);
+    p->o_rsoa = take(off, sizeof(float) * 3 * c->B * (size_t)p->Mpad);
+    p->o_rlen = take(off, sizeof(int) * c->B);
+    p->o_qmap = take(off, sizeof(int) * (c->B + 1));
+    p->o_pd0 = take(off, sizeof(float) * p->S1 * BN);
+    p->o_pi0 = take(off, sizeof(int) * p->S1 * BN);
+    p->o_pd1 = take(off, sizeof(float) * p->S1 * BN);
+    p->o_pi1 = take(off, sizeof(int) * p->S1 * BN);
+    p->o_pd3 = take(off, c->use_flow ? sizeof(float) * p->S3 * BN * 3 : 0);
+    p->o_pi3 = take(off, c->use_flow ? sizeof(int) * p->S3 * BN * 3 : 0);
+    p->o_yT = take(off, sizeof(float) * (size_t)c->P * c->N);
+    p->o_hT = take(off, sizeof(float) * (size_t)c->H * c->N);
+    p->o_hard = take(off, sizeof(int) * (size_t)c->N);
+    p->o_G = take(off, sizeof(float) * 3 * BN);
+    p->o_gpf = take(off, sizeof(float) * 3 * BN);
+    p->o_cint = take(off, sizeof(int) * 5 * BN);
+    p->o_floss = take(off, sizeof(double) * c->B);
+    p->o_fpart = take(off, sizeof(double) * (size_t)c->B * reart_div_up(c->N, FLOW_BS));
+    p->o_grads = take(off, sizeof(float) * p->nparams);
+    p->bwd_bytes = reart_base_backward_workspace_bytes(c->N, c->P, c->B, c->H);
+    p->o_bwd = take(off, p->bwd_bytes);
+    p->total = off;
+    return REART_OK;
+}
+
+extern "C" size_t reart_relax_workspace_bytes(const reart_relax_config *cfg) {
+    StepPlan p;
+    if (!cfg || step_plan(cfg, &p) != REART_OK) return 0;
+    return p.total;
+}
+
+// ------------------------------------------------------------------------------ prepare
+// cosine schedule of utils/model_utils.py:33-37 evaluated in double like the host code
+__device__ __forceinline__ float tau_schedule(long cur_iter, int n_iter, float end_t, float start_t) {
+    const double c = cos(3.14159265358979323846 * (double)cur_iter / (double)n_iter);
+    return (float)((double)end_t + ((double)start_t - (double)end_t) * (c + 1.0) * 0.5);
+}
+
+__global__ void relax_init_kernel(reart_relax_config c, const int *__restrict__ ref_off,
+                                  int *__restrict__ rlen, int *__restrict__ qmap,
+                                  int64_t *__restrict__ iter, float *__restrict__ tau) {
+    const int t = threadIdx.x;
+    if (t < c.B) {
+        // flow pair f (complete frames f -> f+1) queries complete frame f (run_robot.py:196):
+        // complete frame f is pc_trans[f] before the canonical index, the canonical cloud at it,
+        // pc_trans[f-1] after it.
+        qmap[t] = (t < c.cano_idx) ? t : (t == c.cano_idx ? -1 : t - 1);
+        if (c.use_flow) rlen[t] = ref_off[t + 1] - ref_off[t];
+    }
+    if (t == 0) {
+        // `iter` is caller state: it is NOT reset here, so a resumed run continues its schedule
+        const long it = (long)iter[0];
+        tau[0] = c.fixed_tau > 0.f ? c.fixed_tau : tau_schedule(it + 1, c.n_iter, c.end_tau, c.start_tau);
+    }
+}
+
+// ragged reference sets -> +INF padded SoA [B][3][Mpad]
+__global__ __launch_bounds__(256) void ref_soa_kernel(const float *__restrict__ ref_loc,
+                                                      const int *__restrict__ ref_off, int Mpad,
+                                                      float *__restrict__ soa) {
+    const int f = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= Mpad) return;
+    const int o = ref_off[f], m = ref_off[f + 1] - o;
+    float x = INFINITY, y = INFINITY, z = INFINITY;
+    if (j < m) {
+        const float *p = ref_loc + 3 * ((size_t)o + j);
+        x = p[0]; y = p[1]; z = p[2];
+    }
+    float *d = soa + (size_t)f * 3 * Mpad;
+    d[j] = x; d[Mpad + j] = y; d[2 * (size_t)Mpad + j] = z;
+}
+
+extern "C" int reart_relax_prepare(const reart_relax_config *cfg, const reart_relax_buffers *bufs,
+                                   void *workspace, size_t workspace_bytes, void *stream) {
+    StepPlan p;
+    if (!cfg || !bufs) return REART_ERR_INVALID_ARG;
+    int rc = step_plan(cfg, &p);
+    if (rc != REART_OK) return rc;
+    if (!workspace || workspace_bytes < p.total) return REART_ERR_INVALID_ARG;
+    if (!bufs->cano || !bufs->pc_list || !bufs->iter || !bufs->tau) return REART_ERR_INVALID_ARG;
+    if (cfg->use_flow && (!bufs->ref_loc || !bufs->ref_flow || !bufs->ref_off)) return REART_ERR_INVALID_ARG;
+    if (cfg->B > 1024) return REART_ERR_UNSUPPORTED;
+    char *ws = (char *)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    SoaArgs sa = {};
+    for (int j = 0; j < 2; ++j) {
+        sa.job[j].src = bufs->pc_list; sa.job[j].len = nullptr;
+        sa.job[j].dst = (float *)(ws + p.o_ysoa); sa.job[j].P = cfg->N; sa.job[j].Ppad = p.Npad;
+    }
+    rc = reart_soa_launch(sa, p.Npad, cfg->B, 1, st);
+    if (rc != REART_OK) return rc;
+    hipLaunchKernelGGL(relax_init_kernel, dim3(1), dim3(1024), 0, st, *cfg, bufs->ref_off,
+                       (int *)(ws + p.o_rlen), (int *)(ws + p.o_qmap), bufs->iter, bufs->tau);
+    if (cfg->use_flow)
+        hipLaunchKernelGGL(ref_soa_kernel, dim3(reart_div_up(p.Mpad, 256), cfg->B), dim3(256), 0, st,
+                           bufs->ref_loc, bufs->ref_off, p.Mpad, (float *)(ws + p.o_rsoa));
+    REART_CHECK_LAUNCH();
+    return REART_OK;
+}
+
+// ------------------------------------------------------------------------------ flow blend
+// merge the S3 partial top-3 lists, blend (utils/flow_utils.py:160-167), flow-loss term and
+// d loss / d pred_flow (networks/loss.py:10-21, x lambda_flow) for pair f = blockIdx.y
+struct FlowArgs {
+    const float *pd; const int *pi;      // [S3][B][N][3]
+    const float *ref_flow; const int *ref_off; const int *qmap;
+    const float *X; const float *cano;   // pc_trans [B,N,3], canonical cloud
+    int N, B, S, euclidean, robust, cano_idx;
+    float smooth, lambda;
+    float *gpf;                          // [B,N,3]
+    double *part;                        // [B][gridDim.x]
+};
+
+__device__ __forceinline__ const float *complete_frame(const FlowArgs &a, int f) {
+    // complete_pred = cat(pc_trans[:cano], cano, pc_trans[cano:])   (run_robot.py:206)
+    return f < a.cano_idx ? a.X + (size_t)f * a.N * 3
+                          : (f == a.cano_idx ? a.cano : a.X + (size_t)(f - 1) * a.N * 3);
+}
+
+__device__ __forceinline__ float huber1s(float x) {
+    const float ax = fabsf(x);
+    return ax <= 1.0f ? 0.5f * x * x : (ax - 0.5f);
+}
+__device__ __forceinline__ float huber1s_grad(float x) {
+    return fabsf(x) <= 1.0f ? x : (x > 0.f ? 1.0f : -1.0f);
+}
+
+__global__ __launch_bounds__(FLOW_BS) void flow_blend_kernel(FlowArgs a) {
+    __shared__ double s_red[FLOW_BS / REART_WAVE];
+    const int f = blockIdx.y, n = blockIdx.x * FLOW_BS + threadIdx.x;
+    double term = 0.0;
+    if (n < a.N) {
+        float kd[3] = {INFINITY, INFINITY, INFINITY};
+        int ki[3] = {0, 0, 0};
+        for (int s = 0; s < a.S; ++s) {
+            const size_t o = (((size_t)s * a.B + f) * a.N + n) * 3;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float d = a.pd[o + k];
+                const int j = a.pi[o + k];
+                if (d < kd[2]) {
+#pragma unroll
+                    for (int q = 2; q >= 0; --q) {
+                        const bool lp = (q > 0) && (d < kd[q > 0 ? q - 1 : 0]);
+                        const bool lc = d < kd[q];
+                        kd[q] = lp ? kd[q > 0 ? q - 1 : 0] : (lc ? d : kd[q]);
+                        ki[q] = lp ? ki[q > 0 ? q - 1 : 0] : (lc ? j : ki[q]);
+                    }
+                }
+            }
+        }
+        const float *rf = a.ref_flow + 3 * (size_t)a.ref_off[f];
+        float w[3], wsum = 0.f, dmin = INFINITY, fmx = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float d = a.euclidean ? sqrtf(kd[k]) : kd[k];
+            if (d < 1e-10f) d = 1e-10f;
+            w[k] = 1.0f / d;
+            wsum += w[k];
+            dmin = fminf(dmin, d);
+            const float *fl = rf + 3 * (size_t)ki[k];
+            fmx = fmaxf(fmx, (fl[0] * fl[0] + fl[1] * fl[1]) + fl[2] * fl[2]);
+        }
+        float gtf[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float wn = w[k] / wsum;
+            const float *fl = rf + 3 * (size_t)ki[k];
+            gtf[0] += fl[0] * wn; gtf[1] += fl[1] * wn; gtf[2] += fl[2] * wn;
+        }
+        const bool m = (dmin <= fmx) || (dmin <= 0.05f);
+        const float *c0 = complete_frame(a, f) + 3 * (size_t)n;
+        const float *c1 = complete_frame(a, f + 1) + 3 * (size_t)n;
+        float fl = 0.f, sm = 0.f;
+        float *go = a.gpf + 3 * ((size_t)f * a.N + n);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float p = c1[c] - c0[c];  // pred_flow (run_robot.py:207)
+            const float d = p - gtf[c];
+            fl += a.robust ? huber1s(d) : d * d;
+            sm += p * p;
+            const float gf = a.robust ? huber1s_grad(d) : 2.0f * d;
+            go[c] = a.lambda * (m ? gf : a.smooth * (2.0f * p));
+        }
+        term = m ? (double)fl : (double)(a.smooth * sm);
+    }
+    term = reart_wave_sum_d(term);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = term;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < FLOW_BS / REART_WAVE; ++w) t += s_red[w];
+        a.part[(size_t)f * gridDim.x + blockIdx.x] = t;
+    }
+}
+
+// ------------------------------------------------------------------------------ Chamfer grad
+// One workgroup per frame b: merge the slice partials of both directions, per-frame recon
+// loss (networks/loss.py:27-28), and G[b,i] = d(recon + lambda*flow)/d pc_trans[b,i]:
+//   2 (x_i - y_nn(i))  +  sum_{j: nn_yx(j) = i} 2 (x_i - y_j)  +  flow terms.
+// The second sum is a per-target gather over a counting sort of nn_yx (integer atomics
+// only), each bucket sorted ascending before accumulation: deterministic, no float atomics.
+struct CGradArgs {
+    const float *X, *Y;                  // pc_trans, pc_list [B,N,3]
+    const float *pd0; const int *pi0;    // x -> y partials [S][B][N]
+    const float *pd1; const int *pi1;    // y -> x partials
+    const float *gpf;                    // [B,N,3] or NULL (no flow)
+    int N, B, S, cano_idx, nbits;
+    float *G;                            // [B,N,3]
+    int *cint;                           // [B][5N] scratch: count | offset | nn_yx | sort ping | pong
+    double *frame_loss;                  // [B]
+};
+#define CG_BS RS_BS
+
+__global__ __launch_bounds__(CG_BS) void chamfer_grad_kernel(CGradArgs a) {
+    __shared__ int s_cnt[RS_DIG * RS_BS];
+    __shared__ int s_wave[RS_BS / 64];
+    __shared__ double s_red[CG_BS / REART_WAVE];
+    const int b = blockIdx.x, tid = threadIdx.x, N = a.N;
+    const float *x = a.X + (size_t)b * N * 3, *y = a.Y + (size_t)b * N * 3;
+    float *G = a.G + (size_t)b * N * 3;
+    int *cnt = a.cint + (size_t)b * 5 * N, *off = cnt + N, *nn1 = off + N, *bufA = nn1 + N, *bufB = bufA + N;
+    for (int j = tid; j < N; j += CG_BS) cnt[j] = 0;
+    __syncthreads();
+    double lsum = 0.0;
+    for (int i = tid; i < N; i += CG_BS) {
+        float d0 = INFINITY, d1 = INFINITY;
+        int j0 = 0, j1 = 0;
+        for (int s = 0; s < a.S; ++s) {
+            const size_t o = ((size_t)s * a.B + b) * N + i;
+            const float e0 = a.pd0[o], e1 = a.pd1[o];
+            if (e0 < d0) { d0 = e0; j0 = a.pi0[o]; }
+            if (e1 < d1) { d1 = e1; j1 = a.pi1[o]; }
+        }
+        lsum += (double)(d0 + d1);  // chamfer_forward + chamfer_backward (utils/chamfer.py:119-123)
+        G[3 * i] = 2.0f * (x[3 * i] - y[3 * j0]);
+        G[3 * i + 1] = 2.0f * (x[3 * i + 1] - y[3 * j0 + 1]);
+        G[3 * i + 2] = 2.0f * (x[3 * i + 2] - y[3 * j0 + 2]);
+        nn1[i] = j1;
+        atomicAdd(&cnt[j1], 1);  // integer atomics: order-independent result
+    }
+    lsum = reart_wave_sum_d(lsum);
+    if ((tid & 63) == 0) s_red[tid >> 6] = lsum;
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0.0;
+        for (int w = 0; w < CG_BS / REART_WAVE; ++w) t += s_red[w];
+        a.frame_loss[b] = t;
+    }
+    const int chunk = (N + CG_BS - 1) / CG_BS;
+    const int c0 = tid * chunk < N ? tid * chunk : N, c1 = (c0 + chunk < N) ? c0 + chunk : N;
+    int tot = 0;
+    for (int j = c0; j < c1; ++j) tot += cnt[j];
+    int run = block_excl_scan(tot, s_wave, nullptr);
+    for (int j = c0; j < c1; ++j) { off[j] = run; run += cnt[j]; }
+    // sources i stably sorted by their nearest x: bucket j = the y's that chose x_j, ascending i
+    const int *sorted = block_stable_sort_ids(N, a.nbits, bufA, bufB, s_cnt, s_wave,
+                                              [&](int i) { return nn1[i]; });
+    // complete-sequence index of this frame and its two adjacent flow pairs
+    const int fc = b < a.cano_idx ? b : b + 1;
+    const float *g_head = (a.gpf && fc - 1 >= 0) ? a.gpf + (size_t)(fc - 1) * N * 3 : nullptr;
+    const float *g_tail = (a.gpf && fc <= a.B - 1) ? a.gpf + (size_t)fc * N * 3 : nullptr;
+    for (int j = tid; j < N; j += CG_BS) {
+        const int o = off[j], c = cnt[j];
+        const float xj0 = x[3 * j], xj1 = x[3 * j + 1], xj2 = x[3 * j + 2];
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        for (int u = 0; u < c; ++u) {
+            const int i = sorted[o + u];
+            a0 -= 2.0f * (y[3 * i] - xj0);
+            a1 -= 2.0f * (y[3 * i + 1] - xj1);
+            a2 -= 2.0f * (y[3 * i + 2] - xj2);
+        }
+        float g0 = G[3 * j] + a0, g1 = G[3 * j + 1] + a1, g2 = G[3 * j + 2] + a2;
+        if (g_head) { g0 += g_head[3 * j]; g1 += g_head[3 * j + 1]; g2 += g_head[3 * j + 2]; }
+        if (g_tail) { g0 -= g_tail[3 * j]; g1 -= g_tail[3 * j + 1]; g2 -= g_tail[3 * j + 2]; }
+        G[3 * j] = g0; G[3 * j + 1] = g1; G[3 * j + 2] = g2;
+    }
+}
+
+// ------------------------------------------------------------------------------ bookkeeping
+// after the Adam launch: loss log, iteration counter, next temperature
+struct BookArgs {
+    reart_relax_config c;
+    const double *frame_loss; const double *flow_part; int n_flow_part;
+    int64_t *iter; float *tau; float *losses;
+};
+__global__ void bookkeep_kernel(BookArgs a) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double recon = 0.0, flow = 0.0;
+    for (int b = 0; b < a.c.B; ++b) recon += a.frame_loss[b];
+    for (int i = 0; i < a.n_flow_part; ++i) flow += a.flow_part[i];
+    flow *= (double)a.c.lambda_flow;
+    const long it = (long)a.iter[0];
+    if (a.losses && a.c.ring > 0) {
+        float *row = a.losses + 4 * (size_t)(it % a.c.ring);
+        row[0] = (float)recon; row[1] = (float)flow; row[2] = (float)(recon + flow); row[3] = a.tau[0];
+    }
+    a.iter[0] = it + 1;
+    // iteration i (0-based) uses tau_cosine(i+1, ...) (run_robot.py:157)
+    a.tau[0] = a.c.fixed_tau > 0.f ? a.c.fixed_tau
+                                   : tau_schedule(it + 2, a.c.n_iter, a.c.end_tau, a.c.start_tau);
+}
+
+// ------------------------------------------------------------------------------ the step
+#define MARK(k) do { if (ev) (void)hipEventRecord(ev[k], st); } while (0)
+
+static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buffers *bufs,
+                           void *workspace, size_t workspace_bytes, void *stream, hipEvent_t *ev) {
+    StepPlan p;
+    if (!cfg || !bufs) return REART_ERR_INVALID_ARG;
+    int rc = step_plan(cfg, &p);
+    if (rc != REART_OK) return rc;
+    if (!workspace || workspace_bytes < p.total) return REART_ERR_INVALID_ARG;
+    if (!bufs->W1 || !bufs->b1 || !bufs->W2 || !bufs->p6d || !bufs->pt || !bufs->adam_m || !bufs->adam_v ||
+        !bufs->pc_trans || !bufs->iter || !bufs->tau)
+        return REART_ERR_INVALID_ARG;
+    const reart_relax_config &c = *cfg;
+    char *ws = (char *)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    const int N = c.N, B = c.B, P = c.P, H = c.H;
+    float *G = (float *)(ws + p.o_G);
+
+    // 1. forward: seg head + Gumbel-softmax + 6D + rigid apply (networks/model.py:39-70)
+    BaseFwdArgs fa = {};
+    fa.cano = bufs->cano; fa.W1 = bufs->W1; fa.b1 = bufs->b1; fa.W2 = bufs->W2; fa.p6d = bufs->p6d;
+    fa.pt = bufs->pt; fa.gumbel = bufs->gumbel; fa.tau_ptr = bufs->tau; fa.iter_ptr = bufs->iter;
+    fa.seed = c.seed; fa.tau = 1.0f; fa.N = N; fa.P = P; fa.B = B; fa.H = H; fa.Npad = p.Npad;
+    fa.out = bufs->pc_trans; fa.out_soa = (float *)(ws + p.o_xsoa); fa.seg_part = bufs->seg_part;
+    fa.trans_list = bufs->trans_list; fa.yT = (float *)(ws + p.o_yT); fa.hT = (float *)(ws + p.o_hT);
+    fa.hard_idx = (int *)(ws + p.o_hard);
+    MARK(0);
+    rc = reart_base_forward_ex(fa, st);
+    if (rc != REART_OK) return rc;
+    MARK(1);
+
+    // 2. Chamfer, both directions in one launch (utils/chamfer.py:78-94)
+    KnnArgs ka = {};
+    ka.N = B; ka.S = p.S1; ka.K = 1; ka.euclidean = 0;
+    for (int j = 0; j < 2; ++j) {
+        KnnJob &kj = ka.job[j];
+        kj.q = j == 0 ? bufs->pc_trans : bufs->pc_list;
+        kj.tsoa = (const float *)(ws + (j == 0 ? p.o_ysoa : p.o_xsoa));
+        kj.P1 = N; kj.P2 = N; kj.Ppad = p.Npad; kj.L = p.L1; kj.nqg = reart_div_up(N, NN_BS);
+        kj.pd = (float *)(ws + (j == 0 ? p.o_pd0 : p.o_pd1));
+        kj.pi = (int *)(ws + (j == 0 ? p.o_pi0 : p.o_pi1));
+    }
+    ka.items0 = B * ka.job[0].nqg * p.S1;
+    ka.items = 2 * ka.items0;
+    rc = reart_knn_launch_slices(ka, 1, st);
+    if (rc != REART_OK) return rc;
+    MARK(2);
+
+    // 3-4. flow: k=3 search of every complete frame in its reference set + blend + loss grad
+    int nfp = 0;
+    if (c.use_flow) {
+        KnnArgs k3 = {};
+        k3.N = B; k3.S = p.S3; k3.K = 3; k3.euclidean = 0;
+        KnnJob &kj = k3.job[0];
+        kj.q = bufs->pc_trans; kj.q_alt = bufs->cano; kj.qmap = (const int *)(ws + p.o_qmap);
+        kj.tsoa = (const float *)(ws + p.o_rsoa); kj.tlen = (const int *)(ws + p.o_rlen);
+        kj.P1 = N; kj.P2 = c.M_max; kj.Ppad = p.Mpad; kj.L = p.Mpad / p.S3; kj.nqg = reart_div_up(N, NN_BS);
+        kj.pd = (float *)(ws + p.o_pd3); kj.pi = (int *)(ws + p.o_pi3);
+        k3.job[1] = kj;
+        k3.items0 = B * kj.nqg * p.S3;
+        k3.items = k3.items0;
+        rc = reart_knn_launch_slices(k3, 3, st);
+        if (rc != REART_OK) return rc;
+        MARK(3);
+        FlowArgs fl = {};
+        fl.pd = kj.pd; fl.pi = kj.pi; fl.ref_flow = bufs->ref_flow; fl.ref_off = bufs->ref_off;
+        fl.qmap = kj.qmap; fl.X = bufs->pc_trans; fl.cano = bufs->cano; fl.N = N; fl.B = B; fl.S = p.S3;
+        fl.euclidean = c.euclidean; fl.robust = c.robust; fl.cano_idx = c.cano_idx;
+        fl.smooth = c.smooth_weight; fl.lambda = c.lambda_flow;
+        fl.gpf = (float *)(ws + p.o_gpf); fl.part = (double *)(ws + p.o_fpart);
+        const dim3 fg(reart_div_up(N, FLOW_BS), B);
+        nfp = fg.x * fg.y;
+        hipLaunchKernelGGL(flow_blend_kernel, fg, dim3(FLOW_BS), 0, st, fl);
+    } else {
+        MARK(3);
+    }
+    MARK(4);
+
+    // 5. merge + recon loss + dL/d pc_trans
+    CGradArgs cg = {};
+    cg.X = bufs->pc_trans; cg.Y = bufs->pc_list;
+    cg.pd0 = (const float *)(ws + p.o_pd0); cg.pi0 = (const int *)(ws + p.o_pi0);
+    cg.pd1 = (const float *)(ws + p.o_pd1); cg.pi1 = (const int *)(ws + p.o_pi1);
+    cg.gpf = c.use_flow ? (const float *)(ws + p.o_gpf) : nullptr;
+    cg.N = N; cg.B = B; cg.S = p.S1; cg.cano_idx = c.cano_idx; cg.nbits = reart_bits_for(N); cg.G = G;
+    cg.cint = (int *)(ws + p.o_cint); cg.frame_loss = (double *)(ws + p.o_floss);
+    hipLaunchKernelGGL(chamfer_grad_kernel, dim3(B), dim3(CG_BS), 0, st, cg);
+    REART_CHECK_LAUNCH();
+    MARK(5);
+
+    // 6-8. model backward
+    float *grads = (float *)(ws + p.o_grads);
+    float *gW1 = grads, *gb1 = gW1 + 3 * H, *gW2 = gb1 + H, *g6d = gW2 + P * H, *gt = g6d + 6 * B * P;
+    BaseBwdArgs ba = {};
+    ba.cano = bufs->cano; ba.W2 = bufs->W2; ba.p6d = bufs->p6d; ba.pt = bufs->pt; ba.yT = fa.yT; ba.hT = fa.hT;
+    ba.hard_idx = fa.hard_idx; ba.tau_ptr = bufs->tau; ba.tau = 1.0f; ba.G = G; ba.N = N; ba.P = P; ba.B = B;
+    ba.H = H; ba.gW1 = gW1; ba.gb1 = gb1; ba.gW2 = gW2; ba.g6d = g6d; ba.gt = gt;
+    rc = reart_base_backward_ex(ba, ws + p.o_bwd, p.bwd_bytes, st);
+    if (rc != REART_OK) return rc;
+    MARK(6);
+
+    // 9. Adam: two parameter groups (run_robot.py:146-148)
+    AdamArgs ad = {};
+    float *m = bufs->adam_m, *v = bufs->adam_v;
+    const int nW1 = 3 * H, nb1 = H, nW2 = P * H, n6 = 6 * B * P, nt = 3 * B * P;
+    ad.seg[0] = {bufs->W1, gW1, m, v, nW1, c.seg_lr};
+    ad.seg[1] = {bufs->b1, gb1, m + nW1, v + nW1, nb1, c.seg_lr};
+    ad.seg[2] = {bufs->W2, gW2, m + nW1 + nb1, v + nW1 + nb1, nW2, c.seg_lr};
+    ad.seg[3] = {bufs->p6d, g6d, m + nW1 + nb1 + nW2, v + nW1 + nb1 + nW2, n6, c.trans_lr};
+    ad.seg[4] = {bufs->pt, gt, m + nW1 + nb1 + nW2 + n6, v + nW1 + nb1 + nW2 + n6, nt, c.trans_lr};
+    ad.nseg = 5; ad.beta1 = c.beta1; ad.beta2 = c.beta2; ad.eps = c.eps; ad.step_ptr = bufs->iter; ad.step = 0;
+    rc = reart_adam_ex(ad, st);
+    if (rc != REART_OK) return rc;
+    MARK(7);
+
+    // 10. loss log, iter++, next tau
+    BookArgs bk = {};
+    bk.c = c; bk.frame_loss = (const double *)(ws + p.o_floss); bk.flow_part = (const double *)(ws + p.o_fpart);
+    bk.n_flow_part = nfp; bk.iter = bufs->iter; bk.tau = bufs->tau; bk.losses = bufs->losses;
+    hipLaunchKernelGGL(bookkeep_kernel, dim3(1), dim3(64), 0, st, bk);
+    REART_CHECK_LAUNCH();
+    MARK(8);
+    return REART_OK;
+}
+
+extern "C" int reart_relax_step(const reart_relax_config *cfg, const reart_relax_buffers *bufs,
+                                void *workspace, size_t workspace_bytes, void *stream) {
+    return relax_step_impl(cfg, bufs, workspace, workspace_bytes, stream, nullptr);
+}
+
+// Same launch sequence with a hipEvent between phases, recorded on `stream`; synchronises the
+// stream and ADDS the per-phase milliseconds to h_ms[REART_RELAX_PHASES] (host memory).
+// Phases: 0 forward, 1 Chamfer K=1 search, 2 flow K=3 search, 3 flow blend, 4 Chamfer
+// merge+grad, 5 model backward (3 launches), 6 Adam, 7 bookkeeping.  Measurement aid for
+// bench.py / profiling -- not graph-capturable.
+extern "C" int reart_relax_step_timed(const reart_relax_config *cfg, const reart_relax_buffers *bufs,
+                                      void *workspace, size_t workspace_bytes, void *stream,
+                                      float *h_ms) {
+    if (!h_ms) return REART_ERR_INVALID_ARG;
+    hipEvent_t ev[REART_RELAX_PHASES + 1];
+    for (int k = 0; k <= REART_RELAX_PHASES; ++k)
+        if (hipEventCreate(&ev[k]) != hipSuccess) return REART_ERR_LAUNCH;
+    int rc = relax_step_impl(cfg, bufs, workspace, workspace_bytes, stream, ev);
+    if (rc == REART_OK) {
+        if (hipEventSynchronize(ev[REART_RELAX_PHASES]) != hipSuccess) rc = REART_ERR_LAUNCH;
+        for (int k = 0; k < REART_RELAX_PHASES && rc == REART_OK; ++k) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, ev[k], ev[k + 1]) != hipSuccess) rc = REART_ERR_LAUNCH;
+            h_ms[k] += ms;
+        }
+    }
+    for (int k = 0; k <= REART_RELAX_PHASES; ++k) (void)hipEventDestroy(ev[k]);
+    return rc;
+}

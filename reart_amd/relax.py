@@ -1,0 +1,171 @@
+"""Fused relaxation engine: the reference's optimisation loop body (run_robot.py:154-221,
+Chamfer [+ flow] branch) as ten HIP kernel launches per iteration, optionally replayed from a
+captured graph.  ``RelaxEngine`` owns the torch tensors (device memory) and hands raw pointers
+to ``reart_relax_prepare`` / ``reart_relax_step`` (include/reart_hip.h)."""
+import ctypes
+
+import torch
+
+from . import _lib
+
+c_int, c_float, c_void_p = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
+
+
+class RelaxConfig(ctypes.Structure):
+    _fields_ = [(n, c_int) for n in ("N", "P", "B", "H", "cano_idx", "use_flow", "robust", "euclidean", "flow_k",
+                                     "M_max", "M_total", "n_iter", "ring")] + \
+               [(n, c_float) for n in ("lambda_flow", "smooth_weight", "trans_lr", "seg_lr", "beta1", "beta2", "eps",
+                                       "start_tau", "end_tau", "fixed_tau")] + [("seed", ctypes.c_uint64)]
+
+
+class RelaxBuffers(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in ("cano", "pc_list", "ref_loc", "ref_flow", "ref_off", "gumbel", "W1", "b1", "W2",
+                                        "p6d", "pt", "adam_m", "adam_v", "iter", "tau", "losses", "pc_trans",
+                                        "seg_part", "trans_list")]
+
+
+_L = None
+
+
+def _lib_fns():
+    global _L
+    if _L is None:
+        L = _lib.lib()
+        L.reart_relax_workspace_bytes.restype = ctypes.c_size_t
+        L.reart_relax_workspace_bytes.argtypes = [ctypes.POINTER(RelaxConfig)]
+        for fn in (L.reart_relax_prepare, L.reart_relax_step):
+            fn.restype = c_int
+            fn.argtypes = [ctypes.POINTER(RelaxConfig), ctypes.POINTER(RelaxBuffers), c_void_p, ctypes.c_size_t, c_void_p]
+        L.reart_relax_step_timed.restype = c_int
+        L.reart_relax_step_timed.argtypes = [ctypes.POINTER(RelaxConfig), ctypes.POINTER(RelaxBuffers), c_void_p,
+                                             ctypes.c_size_t, c_void_p, ctypes.POINTER(c_float)]
+        _L = L
+    return _L
+
+
+class RelaxEngine:
+    """State of one optimisation instance on one GPU.
+
+    cano_pc [N,3], pc_list [T-1,N,3]; ``model`` is a ``reart_amd.networks.model.BaseModel`` whose
+    parameters are optimised IN PLACE; ``pc_ref_list`` / ``flow_ref_list`` are the ragged flow
+    references of run_robot.py:81-84 (lists of [M_i,3] tensors) or None for Chamfer only.
+    Hyper-parameters carry the reference's flag names and defaults (run_robot.py:362-420).
+    """
+
+    def __init__(self, cano_pc, pc_list, model, cano_idx, pc_ref_list=None, flow_ref_list=None, n_iter=15000,
+                 start_tau=5.0, end_tau=1.0, trans_lr=1e-2, seg_lr=1e-3, lambda_flow=1.0, use_robust_loss=False,
+                 smooth_weight=1e-2, fixed_tau=0.0, seed=2, ring=1024, knn_squared=False, start_iter=0):
+        _lib.require_gpu(cano_pc, pc_list)
+        dev = cano_pc.device
+        self.device, self.model = dev, model
+        self.cano = cano_pc.contiguous().float()
+        self.pc_list = pc_list.contiguous().float()
+        B, N, _ = self.pc_list.shape
+        c1, c2 = model.seg_head.model[0], model.seg_head.model[2]
+        H, P = c1.weight.shape[0], c2.weight.shape[0]
+        self.params = [c1.weight, c1.bias, c2.weight, model.proposal_6d, model.proposal_t]
+        for p in self.params:
+            assert p.is_cuda and p.is_contiguous() and p.dtype == torch.float32
+        nparams = sum(p.numel() for p in self.params)
+        self.adam_m = torch.zeros(nparams, device=dev)
+        self.adam_v = torch.zeros(nparams, device=dev)
+        self.iter = torch.full((1,), int(start_iter), dtype=torch.int64, device=dev)
+        self.tau = torch.zeros(1, device=dev)
+        self.ring = ring
+        self.losses = torch.zeros((ring, 4), device=dev)
+        self.pc_trans = torch.empty((B, N, 3), device=dev)
+        self.seg_part = torch.empty((N,), dtype=torch.int64, device=dev)
+        self.trans_list = torch.empty((B, P, 4, 4), device=dev)
+        self.gumbel = None
+        use_flow = pc_ref_list is not None
+        if use_flow:
+            assert len(pc_ref_list) == B and len(flow_ref_list) == B
+            lens = [int(r.shape[0]) for r in pc_ref_list]
+            self.ref_loc = torch.cat([r.reshape(-1, 3) for r in pc_ref_list]).contiguous().float().to(dev)
+            self.ref_flow = torch.cat([r.reshape(-1, 3) for r in flow_ref_list]).contiguous().float().to(dev)
+            off = [0]
+            for m in lens:
+                off.append(off[-1] + m)
+            self.ref_off = torch.tensor(off, dtype=torch.int32, device=dev)
+        else:
+            lens, self.ref_loc, self.ref_flow, self.ref_off = [0], None, None, None
+        self.cfg = RelaxConfig(N=N, P=P, B=B, H=H, cano_idx=cano_idx, use_flow=int(use_flow),
+                               robust=int(bool(use_robust_loss)), euclidean=0 if knn_squared else 1, flow_k=3,
+                               M_max=max(lens), M_total=sum(lens), n_iter=n_iter, ring=ring, lambda_flow=lambda_flow,
+                               smooth_weight=smooth_weight, trans_lr=trans_lr, seg_lr=seg_lr, beta1=0.9, beta2=0.999,
+                               eps=1e-8, start_tau=start_tau, end_tau=end_tau, fixed_tau=fixed_tau, seed=seed)
+        L = _lib_fns()
+        nbytes = L.reart_relax_workspace_bytes(ctypes.byref(self.cfg))
+        if nbytes == 0:
+            raise _lib.ReartHipError("reart_relax_workspace_bytes: unsupported configuration")
+        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        self._graph = None
+        self._bufs = None
+        self._refresh_buffers()
+        rc = L.reart_relax_prepare(ctypes.byref(self.cfg), ctypes.byref(self._bufs), _lib.ptr(self.workspace),
+                                   self.workspace.numel(), _lib.stream())
+        _lib.check(rc, "reart_relax_prepare")
+
+    def _refresh_buffers(self):
+        p = _lib.ptr
+        v = lambda t: None if t is None else t.data_ptr()
+        W1, b1, W2, p6d, pt = self.params
+        self._bufs = RelaxBuffers(cano=v(self.cano), pc_list=v(self.pc_list), ref_loc=v(self.ref_loc),
+                                  ref_flow=v(self.ref_flow), ref_off=v(self.ref_off), gumbel=v(self.gumbel),
+                                  W1=v(W1), b1=v(b1), W2=v(W2), p6d=v(p6d), pt=v(pt), adam_m=v(self.adam_m),
+                                  adam_v=v(self.adam_v), iter=v(self.iter), tau=v(self.tau), losses=v(self.losses),
+                                  pc_trans=v(self.pc_trans), seg_part=v(self.seg_part), trans_list=v(self.trans_list))
+
+    def set_gumbel(self, noise):
+        """Inject the Gumbel noise [N,P] used by every following step (tests); None = in-kernel Philox."""
+        assert self._graph is None, "noise injection is an eager-mode (test) feature"
+        self.gumbel = None if noise is None else noise.contiguous().float()
+        self._refresh_buffers()
+
+    def _enqueue(self):
+        rc = _lib_fns().reart_relax_step(ctypes.byref(self.cfg), ctypes.byref(self._bufs), _lib.ptr(self.workspace),
+                                         self.workspace.numel(), _lib.stream())
+        _lib.check(rc, "reart_relax_step")
+
+    def capture(self, steps_per_graph=1):
+        """Capture ``steps_per_graph`` iterations into one graph; ``step()`` then replays it."""
+        self._enqueue()  # warm-up outside capture (lazy module load)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(steps_per_graph):
+                self._enqueue()
+        self._graph, self._steps_per_graph = g, steps_per_graph
+        return 1  # iterations consumed by the warm-up
+
+    def step(self, n=1):
+        """Enqueue n iterations (asynchronous; no host sync)."""
+        if self._graph is not None:
+            assert n % self._steps_per_graph == 0
+            for _ in range(n // self._steps_per_graph):
+                self._graph.replay()
+        else:
+            for _ in range(n):
+                self._enqueue()
+
+    PHASES = ("forward", "chamfer_nn", "flow_knn3", "flow_blend", "chamfer_grad", "backward", "adam", "bookkeep")
+
+    def step_timed(self, n=1):
+        """Run n eager iterations with hipEvents between phases (on the launch stream); returns
+        {phase: mean milliseconds per iteration}.  Synchronises; for measurement only."""
+        acc = (c_float * len(self.PHASES))()
+        for _ in range(n):
+            rc = _lib_fns().reart_relax_step_timed(ctypes.byref(self.cfg), ctypes.byref(self._bufs),
+                                                   _lib.ptr(self.workspace), self.workspace.numel(), _lib.stream(), acc)
+            _lib.check(rc, "reart_relax_step_timed")
+        return {k: acc[i] / n for i, k in enumerate(self.PHASES)}
+
+    def loss_log(self):
+        """(iterations done, tensor [min(iter, ring), 4]: recon, lambda*flow, total, tau); syncs."""
+        it = int(self.iter.item())
+        rows = self.losses[: min(it, self.ring)] if it <= self.ring else torch.roll(self.losses, -(it % self.ring), 0)
+        return it, rows.clone()
+
+    def last_losses(self):
+        it = int(self.iter.item())
+        return self.losses[(it - 1) % self.ring].clone()

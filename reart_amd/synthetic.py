@@ -1,0 +1,99 @@
+"""Synthetic articulated point-cloud sequence for the headline benchmark.
+
+An articulated tree of 8 boxes (512 surface points each, N = 4096), side lengths U(0.04, 0.12),
+scaled into [-0.35, 0.35]^3 (the range of the reference's nao demo data); T frames with
+revolute joint angles theta_{t,e} = A_e sin(2 pi t / T + phi_e); every frame is sampled
+independently on the surfaces (no point correspondence between frames, like the robot data
+where each state_i.pkl is its own sample, reference dataset/dataset_robot.py:52-61).
+Flow references: M points per pair drawn from frame i with flow = true motion + N(0, 0.002^2).
+numpy only; deterministic in ``seed``.
+"""
+import numpy as np
+
+
+def _rot(axis, ang):
+    axis = axis / np.linalg.norm(axis)
+    K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    return np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * K @ K
+
+
+def _box_points(rng, size, n):
+    """n points uniform on the surface of an axis-aligned box centred at 0, as (face, u, v)."""
+    areas = np.array([size[1] * size[2], size[0] * size[2], size[0] * size[1]] * 2)
+    face = rng.choice(6, size=n, p=areas / areas.sum())
+    uv = rng.uniform(-0.5, 0.5, (n, 2))
+    pts = np.empty((n, 3))
+    for f in range(6):
+        m = face == f
+        ax = f % 3
+        o = [a for a in range(3) if a != ax]
+        pts[m, ax] = (0.5 if f < 3 else -0.5) * size[ax]
+        pts[m, o[0]] = uv[m, 0] * size[o[0]]
+        pts[m, o[1]] = uv[m, 1] * size[o[1]]
+    return pts
+
+
+def make_sequence(T=20, n_parts=8, pts_per_part=512, seed=2, n_ref=3000, with_flow=True):
+    """-> dict(complete [T,N,3] f32, part [N] i64, ref_idx/ref_loc/ref_flow lists for the T-1 pairs)."""
+    rng = np.random.default_rng(seed)
+    sizes = rng.uniform(0.04, 0.12, (n_parts, 3))
+    parent = [-1] + [int(rng.integers(0, i)) for i in range(1, n_parts)]
+    # joint placement: child attached at a random face centre of the parent
+    attach = rng.uniform(-0.5, 0.5, (n_parts, 3))
+    axes = rng.normal(size=(n_parts, 3))
+    amp = rng.uniform(0.2, 0.8, n_parts)
+    phi = rng.uniform(0, 2 * np.pi, n_parts)
+    N = n_parts * pts_per_part
+
+    def poses(t):
+        Rw, tw = [None] * n_parts, [None] * n_parts
+        for e in range(n_parts):
+            if parent[e] < 0:
+                Rw[e], tw[e] = np.eye(3), np.zeros(3)
+                continue
+            p = parent[e]
+            ang = amp[e] * np.sin(2 * np.pi * t / T + phi[e])
+            Rl = _rot(axes[e], ang)
+            joint = attach[e] * sizes[p]                      # in the parent's frame
+            child_off = np.array([0.0, 0.0, 0.5 * sizes[e][2]])  # child centre relative to the joint
+            Rw[e] = Rw[p] @ Rl
+            tw[e] = tw[p] + Rw[p] @ joint + Rw[e] @ child_off
+        return Rw, tw
+
+    def sample(t, local=None):
+        Rw, tw = poses(t)
+        pts = np.empty((N, 3))
+        loc = [] if local is None else local
+        for e in range(n_parts):
+            if local is None:
+                loc.append(_box_points(rng, sizes[e], pts_per_part))
+            pts[e * pts_per_part:(e + 1) * pts_per_part] = loc[e] @ Rw[e].T + tw[e]
+        return pts, loc
+
+    frames, locals_ = [], []
+    for t in range(T):
+        pts, loc = sample(t)
+        frames.append(pts)
+        locals_.append(loc)
+    allp = np.stack(frames)
+    centre = 0.5 * (allp.reshape(-1, 3).max(0) + allp.reshape(-1, 3).min(0))
+    scale = 0.35 / np.abs(allp - centre).max()
+    complete = ((allp - centre) * scale).astype(np.float32)
+    part = np.repeat(np.arange(n_parts), pts_per_part).astype(np.int64)
+    out = dict(complete=complete, part=part, scale=scale)
+    if with_flow:
+        ref_loc, ref_flow = [], []
+        for t in range(T - 1):
+            nxt, _ = sample(t + 1, local=locals_[t])         # the same material points, next frame
+            nxt = ((nxt - centre) * scale)
+            idx = rng.permutation(N)[: min(n_ref, N)]
+            flow = nxt[idx] - complete[t][idx] + rng.normal(0, 0.002, (len(idx), 3))
+            ref_loc.append(complete[t][idx].astype(np.float32))
+            ref_flow.append(flow.astype(np.float32))
+        out.update(ref_loc=ref_loc, ref_flow=ref_flow)
+    return out
+
+
+def split_canonical(complete, cano_idx):
+    """-> (cano_pc [N,3], pc_list [T-1,N,3]) as reference dataset_robot.Sequence does (:88-89)."""
+    return complete[cano_idx], np.concatenate([complete[:cano_idx], complete[cano_idx + 1:]], axis=0)

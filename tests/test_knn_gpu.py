@@ -142,3 +142,21 @@ def test_chamfer_full_size_properties(dev):
     perm = torch.randperm(4096, generator=g).to(dev)
     d_p, i_p, _, _ = C.chamfer_bidir(x, y[:, perm])
     assert torch.equal(d_p, d_xy)
+
+
+def test_knn_backward_degenerate_buckets(oracle, dev):
+    """Every source picks the same target (P2 = 1 and a cluster): buckets of thousands of pairs
+    must still be summed in ascending source order, bit-exact, in O(M) work."""
+    from reart_amd import chamferdist_C as C
+
+    rng = np.random.default_rng(6)
+    for P2 in (1, 3):
+        a = rng.uniform(-1, 1, (2, 5000, 3)).astype(np.float32)
+        b = rng.uniform(-1, 1, (2, P2, 3)).astype(np.float32)
+        d, i = oracle.knn_points(a, b, K=1)
+        g = rng.normal(size=d.shape).astype(np.float32)
+        g1_ref, g2_ref = oracle.knn_points_backward(a, b, i, g)
+        g1, g2 = C.knn_points_backward(torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev), None, None,
+                                       torch.from_numpy(i).to(dev), torch.from_numpy(g).to(dev))
+        np.testing.assert_array_equal(g1.cpu().numpy(), g1_ref)
+        np.testing.assert_array_equal(g2.cpu().numpy(), g2_ref)
