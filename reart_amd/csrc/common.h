@@ -14,9 +14,18 @@
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-#define REART_CHECK_LAUNCH()                                     \
-    do {                                                         \
-        if (hipGetLastError() != hipSuccess) return REART_ERR_LAUNCH; \
+#include <stdio.h>
+#include <stdlib.h>
+// Launch-error check; with REART_DEBUG set in the environment the HIP error string and the
+// source location go to stderr (the library itself never prints otherwise).
+#define REART_CHECK_LAUNCH()                                                          \
+    do {                                                                              \
+        hipError_t e_ = hipGetLastError();                                            \
+        if (e_ != hipSuccess) {                                                       \
+            if (getenv("REART_DEBUG"))                                                \
+                fprintf(stderr, "[reart] %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+            return REART_ERR_LAUNCH;                                                  \
+        }                                                                             \
     } while (0)
 
 static inline size_t reart_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

@@ -19,6 +19,7 @@ struct BaseFwdArgs {
     float *yT;                  // [P,N] nullable
     float *hT;                  // [H,N] nullable
     int *hard_idx;              // [N] nullable
+    float *rt_table;            // [B*P][12] nullable: [R|t] rows for the backward's scalar loads
 };
 
 struct BaseBwdArgs {
@@ -28,13 +29,11 @@ struct BaseBwdArgs {
     const float *tau_ptr;
     float tau;
     const float *G;             // [B,N,3]
+    const float *rt_table;      // [B*P][12] or NULL (built into the workspace)
     int N, P, B, H;
-    float *dsT;                 // [P,N]   dL/d logits
-    float *dpT;                 // [H,N]   dL/d pre-activation of the hidden layer
     int nchunk;                 // ceil(N / RED_CHUNK)
     float *partial;             // [nchunk][n_out]
     // finalize
-    const float *W1dummy;
     float *gW1, *gb1, *gW2, *g6d, *gt;
 };
 
@@ -42,7 +41,16 @@ struct AdamSeg { float *p; const float *g; float *m; float *v; int n; float lr; 
 struct AdamArgs { AdamSeg seg[8]; int nseg; float beta1, beta2, eps; const int64_t *step_ptr; int step; };
 
 int reart_base_forward_ex(const BaseFwdArgs &a, hipStream_t st);
-int reart_base_backward_ex(BaseBwdArgs a, void *workspace, size_t workspace_bytes, hipStream_t st);
+struct FinalizeAdam {
+    int enabled;
+    float *W1, *b1, *W2, *p6d, *pt;   // parameters (updated in place)
+    float *m, *v;                     // moments, order W1|b1|W2|p6d|pt
+    float seg_lr, trans_lr, beta1, beta2, eps;
+    const int64_t *step_ptr;
+};
+
+int reart_base_backward_ex(BaseBwdArgs a, const FinalizeAdam *adam, void *workspace,
+                           size_t workspace_bytes, hipStream_t st);
 int reart_adam_ex(const AdamArgs &a, hipStream_t st);
 
 // generic K-NN driver (knn.hip): njobs in {1,2}; job j searches q[j] ([N,P1[j],3] AoS) in t[j]

@@ -53,8 +53,19 @@ __global__ __launch_bounds__(256) void soa_kernel(SoaArgs a) {
 // Slice kernel
 // ---------------------------------------------------------------------------------
 
+// insertion under the precondition d < kd[KK-1] (checked by the caller)
 template <int KK>
 __device__ __forceinline__ void knn_insert(float (&kd)[KK], int (&ki)[KK], float d, int j) {
+    if (KK == 3) {  // 2 compares + 8 selects instead of the generic 6 + 12
+        const bool c1 = d < kd[1], c0 = d < kd[0];
+        kd[2] = c1 ? kd[1] : d;
+        ki[2] = c1 ? ki[1] : j;
+        kd[1] = c0 ? kd[0] : (c1 ? d : kd[1]);
+        ki[1] = c0 ? ki[0] : (c1 ? j : ki[1]);
+        kd[0] = c0 ? d : kd[0];
+        ki[0] = c0 ? j : ki[0];
+        return;
+    }
 #pragma unroll
     for (int s = KK - 1; s >= 0; --s) {
         const bool lt_prev = (s > 0) && (d < kd[s > 0 ? s - 1 : 0]);

@@ -18,9 +18,7 @@
 #include "internal.h"
 #include <math.h>
 
-#define MB_BS 64        // threads per workgroup in the per-point kernels
 #define RED_CHUNK 64    // points per partial-reduction chunk
-#define RED_BS 256
 
 // ------------------------------------------------------------------------------- helpers
 __device__ __forceinline__ float dot3f(const float *a, const float *b) {
@@ -127,52 +125,93 @@ __device__ __forceinline__ float gumbel_from_bits(uint32_t bits) {
 }
 
 // ------------------------------------------------------------------------------- forward
+// Workgroup = 4 waves x the same 64 points.  Wave g evaluates the logits of parts
+// [g*PG, (g+1)*PG) (each a full ascending-j fmaf chain, so the rounding order is the
+// oracle's), the four slices meet in LDS, then every wave redoes the cheap softmax /
+// arg-max and applies the rigid transforms of frames t = g, g+4, ...
+#define FW_BS 256
+#define FW_PTS 64
 
 template <int PP>
-__global__ __launch_bounds__(MB_BS) void base_fwd_kernel(BaseFwdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float s_rt[];  // [B*P][12]
-    const int tid = threadIdx.x;
+__global__ __launch_bounds__(FW_BS) void base_fwd_kernel(BaseFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int PMAX = (PP > 0) ? PP : 32;
+    constexpr int PG = (PMAX + 3) / 4;
+    float *s_rt = smem;                                   // [B*P][12]
+    float *s_log = smem + 12 * (size_t)a.B * a.P;         // [FW_PTS][PMAX]
+    float *s_wb = s_log + FW_PTS * PMAX;                  // [H][4]  W1 row | b1
+    float *s_w2T = s_wb + 4 * (size_t)a.H;                // [H][PMAX]  W2 transposed
+    const int tid = threadIdx.x, lane = tid & 63, grp = tid >> 6;
     const int P = (PP > 0) ? PP : a.P;
-    for (int e = tid; e < a.B * a.P; e += MB_BS) {
+    // weights -> LDS once per workgroup (coalesced); the inner loop then reads them as
+    // wave-uniform LDS broadcasts instead of one scalar-load round trip per hidden unit
+    for (int e = tid; e < 4 * a.H; e += FW_BS) {
+        const int j = e >> 2, c = e & 3;
+        s_wb[e] = c < 3 ? a.W1[3 * j + c] : a.b1[j];
+    }
+    for (int e = tid; e < a.P * a.H; e += FW_BS) {
+        const int p = e / a.H, j = e % a.H;
+        s_w2T[j * PMAX + p] = a.W2[e];
+    }
+    for (int e = tid; e < a.B * a.P; e += FW_BS) {
         float R[9];
         r6d_to_matrix(a.p6d + 6 * (size_t)e, R);
 #pragma unroll
         for (int c = 0; c < 9; ++c) s_rt[12 * e + c] = R[c];
 #pragma unroll
         for (int c = 0; c < 3; ++c) s_rt[12 * e + 9 + c] = a.pt[3 * (size_t)e + c];
-        if (blockIdx.x == 0 && a.trans_list) {
-            float *T = a.trans_list + 16 * (size_t)e;
+        if (blockIdx.x == 0) {
+            if (a.trans_list) {
+                float *T = a.trans_list + 16 * (size_t)e;
 #pragma unroll
-            for (int r = 0; r < 3; ++r) {
+                for (int r = 0; r < 3; ++r) {
 #pragma unroll
-                for (int c = 0; c < 3; ++c) T[4 * r + c] = R[3 * r + c];
-                T[4 * r + 3] = a.pt[3 * (size_t)e + r];
+                    for (int c = 0; c < 3; ++c) T[4 * r + c] = R[3 * r + c];
+                    T[4 * r + 3] = a.pt[3 * (size_t)e + r];
+                }
+                T[12] = 0.f; T[13] = 0.f; T[14] = 0.f; T[15] = 1.f;
             }
-            T[12] = 0.f; T[13] = 0.f; T[14] = 0.f; T[15] = 1.f;
+            if (a.rt_table) {
+#pragma unroll
+                for (int c = 0; c < 9; ++c) a.rt_table[12 * (size_t)e + c] = R[c];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) a.rt_table[12 * (size_t)e + 9 + c] = a.pt[3 * (size_t)e + c];
+            }
         }
     }
-    __syncthreads();
 
-    const int n = blockIdx.x * MB_BS + tid;
+    const int n = blockIdx.x * FW_PTS + lane;
     const bool live = n < a.N;
     const int nc = live ? n : a.N - 1;
     const float x0 = a.cano[3 * (size_t)nc], x1 = a.cano[3 * (size_t)nc + 1], x2 = a.cano[3 * (size_t)nc + 2];
 
-    constexpr int PMAX = (PP > 0) ? PP : 32;
+    // logits of this wave's parts: s[p] = sum_j W2[p,j] relu(W1[j].x + b1[j]), j ascending
+    float sp[PG];
+#pragma unroll
+    for (int q = 0; q < PG; ++q) sp[q] = 0.f;
+    const int p0 = grp * PG;
+    __syncthreads();
+#pragma unroll 8
+    for (int j = 0; j < a.H; ++j) {
+        const float4 wb = *(const float4 *)(s_wb + 4 * j);
+        float acc = wb.x * x0;
+        acc = fmaf(wb.y, x1, acc);
+        acc = fmaf(wb.z, x2, acc);
+        acc = acc + wb.w;
+        const float h = acc > 0.f ? acc : 0.f;
+        if (grp == 0 && a.hT && live) a.hT[(size_t)j * a.N + n] = h;
+#pragma unroll
+        for (int q = 0; q < PG; ++q)
+            if (p0 + q < P) sp[q] = fmaf(s_w2T[j * PMAX + p0 + q], h, sp[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < PG; ++q)
+        if (p0 + q < P) s_log[lane * PMAX + p0 + q] = sp[q];
+    __syncthreads();
+
     float s[PMAX];
 #pragma unroll
-    for (int p = 0; p < PMAX; ++p) s[p] = 0.f;
-    for (int j = 0; j < a.H; ++j) {
-        float acc = a.W1[3 * j] * x0;
-        acc = fmaf(a.W1[3 * j + 1], x1, acc);
-        acc = fmaf(a.W1[3 * j + 2], x2, acc);
-        acc = acc + a.b1[j];
-        const float h = acc > 0.f ? acc : 0.f;
-        if (a.hT && live) a.hT[(size_t)j * a.N + n] = h;
-#pragma unroll
-        for (int p = 0; p < PMAX; ++p)
-            if (PP > 0 || p < P) s[p] = fmaf(a.W2[(size_t)p * a.H + j], h, s[p]);
-    }
+    for (int p = 0; p < PMAX; ++p) s[p] = (PP > 0 || p < P) ? s_log[lane * PMAX + p] : 0.f;
     // noise-free arg-max (networks/model.py:70) -- first maximum
     int am = 0;
     float sm = s[0];
@@ -214,14 +253,14 @@ __global__ __launch_bounds__(MB_BS) void base_fwd_kernel(BaseFwdArgs a) {
         if (PP > 0 || p < P) {
             z[p] = z[p] / sum;
             if (z[p] > yk) { yk = z[p]; k = p; }
-            if (a.yT && live) a.yT[(size_t)p * a.N + n] = z[p];
+            if (grp == 0 && a.yT && live) a.yT[(size_t)p * a.N + n] = z[p];
         }
     const float w = (1.0f - yk) + yk;  // y_hard - y_soft.detach() + y_soft
-    if (live) {
+    if (live && grp == 0) {
         if (a.seg_part) a.seg_part[n] = am;
         if (a.hard_idx) a.hard_idx[n] = k;
     }
-    for (int t = 0; t < a.B; ++t) {
+    for (int t = grp; t < a.B; t += FW_BS / 64) {
         float v[3];
         apply_rt(s_rt + 12 * (t * a.P + k), x0, x1, x2, v);
         v[0] = w * v[0]; v[1] = w * v[1]; v[2] = w * v[2];
@@ -240,14 +279,15 @@ __global__ __launch_bounds__(MB_BS) void base_fwd_kernel(BaseFwdArgs a) {
 
 template <int PP>
 static void launch_base_fwd(const BaseFwdArgs &a, hipStream_t st) {
+    constexpr int PMAX = (PP > 0) ? PP : 32;
     const int cover = a.out_soa ? (a.Npad > a.N ? a.Npad : a.N) : a.N;
-    const size_t lds = sizeof(float) * 12 * (size_t)a.B * a.P;
-    hipLaunchKernelGGL((base_fwd_kernel<PP>), dim3(reart_div_up(cover, MB_BS)), dim3(MB_BS), lds, st, a);
+    const size_t lds = sizeof(float) * (12 * (size_t)a.B * a.P + (size_t)FW_PTS * PMAX + (size_t)a.H * (4 + PMAX));
+    hipLaunchKernelGGL((base_fwd_kernel<PP>), dim3(reart_div_up(cover, FW_PTS)), dim3(FW_BS), lds, st, a);
 }
 
 static int dispatch_base_fwd(const BaseFwdArgs &a, hipStream_t st) {
     if (a.P < 1 || a.P > 32) return REART_ERR_UNSUPPORTED;
-    if ((size_t)a.B * a.P * 12 * sizeof(float) > 64 * 1024) return REART_ERR_UNSUPPORTED;
+    if (((size_t)a.B * a.P * 12 + FW_PTS * 32 + (size_t)a.H * 36) * sizeof(float) > 64 * 1024) return REART_ERR_UNSUPPORTED;
     switch (a.P) {
         case 20: launch_base_fwd<20>(a, st); break;
         case 10: launch_base_fwd<10>(a, st); break;
@@ -279,7 +319,6 @@ extern "C" int reart_base_forward(const float *cano, int N, int P, int B, const 
 int reart_base_forward_ex(const BaseFwdArgs &a, hipStream_t st) { return dispatch_base_fwd(a, st); }
 
 // ------------------------------------------------------------------------------- backward
-// (1) per point: dL/dw (dense in p) -> softmax backward -> ds; hidden-layer gradient.
 // layout of one partial row / of the reduced gradient vector
 __host__ __device__ static inline int off_gW2() { return 0; }
 __host__ __device__ static inline int off_gW1(int P, int H) { return P * H; }
@@ -287,112 +326,131 @@ __host__ __device__ static inline int off_gb1(int P, int H) { return P * H + 3 *
 __host__ __device__ static inline int off_gRt(int P, int H) { return P * H + 4 * H; }
 __host__ __device__ static inline int n_out(int P, int H, int B) { return P * H + 4 * H + 12 * B * P; }
 
-template <int PP>
-__global__ __launch_bounds__(MB_BS) void base_bwd_point_kernel(BaseBwdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float s_rt[];
-    const int tid = threadIdx.x;
-    const int P = (PP > 0) ? PP : a.P;
-    for (int e = tid; e < a.B * a.P; e += MB_BS) {
-        float R[9];
-        r6d_to_matrix(a.p6d + 6 * (size_t)e, R);
+// [R|t] table [B*P][12] in global memory, so that the backward can read it with scalar loads
+__global__ __launch_bounds__(256) void rt_table_kernel(const float *__restrict__ p6d,
+                                                       const float *__restrict__ pt, int n,
+                                                       float *__restrict__ table) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    float R[9];
+    r6d_to_matrix(p6d + 6 * (size_t)e, R);
 #pragma unroll
-        for (int c = 0; c < 9; ++c) s_rt[12 * e + c] = R[c];
+    for (int c = 0; c < 9; ++c) table[12 * (size_t)e + c] = R[c];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) s_rt[12 * e + 9 + c] = a.pt[3 * (size_t)e + c];
-    }
-    __syncthreads();
-    const int n = blockIdx.x * MB_BS + tid;
-    if (n >= a.N) return;
-    const float x0 = a.cano[3 * (size_t)n], x1 = a.cano[3 * (size_t)n + 1], x2 = a.cano[3 * (size_t)n + 2];
-    constexpr int PMAX = (PP > 0) ? PP : 32;
-    float dw[PMAX];
-#pragma unroll
-    for (int p = 0; p < PMAX; ++p) dw[p] = 0.f;
-    for (int t = 0; t < a.B; ++t) {
-        const float *g = a.G + 3 * ((size_t)t * a.N + n);
-        const float gv[3] = {g[0], g[1], g[2]};
-#pragma unroll
-        for (int p = 0; p < PMAX; ++p)
-            if (PP > 0 || p < P) {
-                float v[3];
-                apply_rt(s_rt + 12 * (t * a.P + p), x0, x1, x2, v);
-                dw[p] += dot3f(gv, v);
-            }
-    }
-    const float tau = a.tau_ptr ? a.tau_ptr[0] : a.tau;
-    float y[PMAX];
-    float dot = 0.f;
-#pragma unroll
-    for (int p = 0; p < PMAX; ++p)
-        if (PP > 0 || p < P) { y[p] = a.yT[(size_t)p * a.N + n]; dot = fmaf(y[p], dw[p], dot); }
-#pragma unroll
-    for (int p = 0; p < PMAX; ++p)
-        if (PP > 0 || p < P) {
-            dw[p] = (y[p] * (dw[p] - dot)) / tau;  // now ds[p]
-            a.dsT[(size_t)p * a.N + n] = dw[p];
-        }
-    for (int j = 0; j < a.H; ++j) {
-        float dh = 0.f;
-#pragma unroll
-        for (int p = 0; p < PMAX; ++p)
-            if (PP > 0 || p < P) dh = fmaf(a.W2[(size_t)p * a.H + j], dw[p], dh);
-        const float h = a.hT[(size_t)j * a.N + n];
-        a.dpT[(size_t)j * a.N + n] = h > 0.f ? dh : 0.f;
-    }
+    for (int c = 0; c < 3; ++c) table[12 * (size_t)e + 9 + c] = pt[3 * (size_t)e + c];
 }
 
-// (2) per chunk of RED_CHUNK points: partial sums of every parameter gradient, each output
-// accumulated sequentially over the chunk's points (ascending n) -> deterministic.
-//   gW2[p,j] = sum_n ds[n,p] h[n,j];  gW1[j,c] = sum_n dp[n,j] x[n,c];  gb1[j] = sum_n dp[n,j]
-//   gR[t,p]  = sum_{n:k_n=p} w_n G[t,n] x_n^T;  gt[t,p] = sum_{n:k_n=p} w_n G[t,n]
-__global__ __launch_bounds__(RED_BS) void base_bwd_reduce_kernel(BaseBwdArgs a) {
+// (1) One workgroup per chunk of 64 points (4 waves x the same points):
+//   a. wave g: dL/dw[n,p] = sum_t G[t,n].(R[t,p] x_n + t[t,p]) for its parts -- the [R|t] table
+//      is wave-uniform, read with scalar loads
+//   b. softmax backward -> ds[n,:] (LDS), wave g: hidden gradient dp[n,j] for its quarter of j
+//   c. partial sums over the chunk of every parameter gradient, each output accumulated
+//      sequentially over the chunk's points (ascending n) -> deterministic:
+//        gW2[p,j] = sum_n ds[n,p] h[n,j];  gW1[j,c] = sum_n dp[n,j] x[n,c];  gb1[j] = sum_n dp[n,j]
+//        gR[t,p]  = sum_{n:k_n=p} w_n G[t,n] x_n^T;  gt[t,p] = sum_{n:k_n=p} w_n G[t,n]
+#define BW_BS 256
+#define BW_LD (RED_CHUNK + 1)
+
+template <int PP>
+__global__ __launch_bounds__(BW_BS) void base_bwd_block_kernel(BaseBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int LD = RED_CHUNK + 1;  // +1 pad: rows indexed by lane -> conflict-free columns
-    float *s_h = smem;                         // [H][LD]   (hT tile, then dpT tile)
-    float *s_ds = s_h + (size_t)a.H * LD;      // [P][LD]
-    float *s_x = s_ds + (size_t)a.P * LD;      // [RED_CHUNK][3]
-    float *s_w = s_x + RED_CHUNK * 3;          // [RED_CHUNK]
-    int *s_k = (int *)(s_w + RED_CHUNK);       // [RED_CHUNK]
-    float *s_acc = (float *)(s_k + RED_CHUNK); // [B*P*12]
-    const int tid = threadIdx.x, chunk = blockIdx.x;
+    constexpr int PMAX = (PP > 0) ? PP : 32;
+    constexpr int PG = (PMAX + 3) / 4;
+    const int P = (PP > 0) ? PP : a.P;
+    float *s_h = smem;                               // [H][BW_LD]  hT tile, later dp tile
+    float *s_ds = s_h + (size_t)a.H * BW_LD;         // [PMAX][BW_LD]
+    float *s_x = s_ds + (size_t)PMAX * BW_LD;        // [RED_CHUNK][3]
+    float *s_w = s_x + RED_CHUNK * 3;                // [RED_CHUNK]
+    int *s_k = (int *)(s_w + RED_CHUNK);             // [RED_CHUNK]
+    float *s_acc = (float *)(s_k + RED_CHUNK);       // [B*P*12]
+    float *s_G = s_acc + (size_t)a.B * a.P * 12;     // [B][RED_CHUNK*3]  upstream gradient tile
+    float *s_w2T = s_G + (size_t)a.B * RED_CHUNK * 3;// [H][PMAX]
+    const int tid = threadIdx.x, lane = tid & 63, grp = tid >> 6, chunk = blockIdx.x;
     const int n0 = chunk * RED_CHUNK;
     const int cn = (a.N - n0) < RED_CHUNK ? (a.N - n0) : RED_CHUNK;
     float *prow = a.partial + (size_t)chunk * n_out(a.P, a.H, a.B);
 
-    for (int e = tid; e < a.H * RED_CHUNK; e += RED_BS) {
+    for (int e = tid; e < a.H * RED_CHUNK; e += BW_BS) {
         const int j = e / RED_CHUNK, i = e % RED_CHUNK;
-        s_h[j * LD + i] = (i < cn) ? a.hT[(size_t)j * a.N + n0 + i] : 0.f;
+        s_h[j * BW_LD + i] = (i < cn) ? a.hT[(size_t)j * a.N + n0 + i] : 0.f;
     }
-    for (int e = tid; e < a.P * RED_CHUNK; e += RED_BS) {
-        const int p = e / RED_CHUNK, i = e % RED_CHUNK;
-        s_ds[p * LD + i] = (i < cn) ? a.dsT[(size_t)p * a.N + n0 + i] : 0.f;
+    for (int e = tid; e < a.B * a.P * 12; e += BW_BS) s_acc[e] = 0.f;
+    for (int e = tid; e < a.B * RED_CHUNK * 3; e += BW_BS) {
+        const int t = e / (RED_CHUNK * 3), r = e % (RED_CHUNK * 3);
+        s_G[e] = (r < 3 * cn) ? a.G[3 * ((size_t)t * a.N + n0) + r] : 0.f;
     }
-    for (int i = tid; i < RED_CHUNK; i += RED_BS) {
-        const bool ok = i < cn;
-        const int n = ok ? n0 + i : n0;
-        const int k = a.hard_idx[n];
-        const float yk = a.yT[(size_t)k * a.N + n];
-        s_k[i] = ok ? k : -1;
-        s_w[i] = (1.0f - yk) + yk;
-        s_x[3 * i] = ok ? a.cano[3 * (size_t)n] : 0.f;
-        s_x[3 * i + 1] = ok ? a.cano[3 * (size_t)n + 1] : 0.f;
-        s_x[3 * i + 2] = ok ? a.cano[3 * (size_t)n + 2] : 0.f;
+    for (int e = tid; e < a.P * a.H; e += BW_BS) {
+        const int p = e / a.H, j = e % a.H;
+        s_w2T[j * PMAX + p] = a.W2[e];
     }
-    for (int e = tid; e < a.B * a.P * 12; e += RED_BS) s_acc[e] = 0.f;
+    const bool live = lane < cn;
+    const int n = live ? n0 + lane : n0;
+    const float x0 = a.cano[3 * (size_t)n], x1 = a.cano[3 * (size_t)n + 1], x2 = a.cano[3 * (size_t)n + 2];
+    const int kn = a.hard_idx[n];
+    if (grp == 0) {
+        const float yk = a.yT[(size_t)kn * a.N + n];
+        s_k[lane] = live ? kn : -1;
+        s_w[lane] = (1.0f - yk) + yk;
+        s_x[3 * lane] = live ? x0 : 0.f; s_x[3 * lane + 1] = live ? x1 : 0.f; s_x[3 * lane + 2] = live ? x2 : 0.f;
+    }
+    // a. dw for this wave's parts
+    float dwp[PG];
+#pragma unroll
+    for (int q = 0; q < PG; ++q) dwp[q] = 0.f;
+    const int p0 = grp * PG;
     __syncthreads();
-    // gW2
-    for (int o = tid; o < a.P * a.H; o += RED_BS) {
+#pragma unroll 2
+    for (int t = 0; t < a.B; ++t) {
+        const float *g = s_G + t * (RED_CHUNK * 3) + 3 * lane;
+        const float gv[3] = {g[0], g[1], g[2]};
+#pragma unroll
+        for (int q = 0; q < PG; ++q)
+            if (p0 + q < P) {
+                float v[3];
+                apply_rt(a.rt_table + 12 * ((size_t)t * a.P + p0 + q), x0, x1, x2, v);
+                dwp[q] += dot3f(gv, v);
+            }
+    }
+#pragma unroll
+    for (int q = 0; q < PG; ++q)
+        if (p0 + q < P) s_ds[(p0 + q) * BW_LD + lane] = dwp[q];
+    __syncthreads();
+    // b. softmax backward (every wave redoes it for its lanes; wave 0 publishes ds)
+    const float tau = a.tau_ptr ? a.tau_ptr[0] : a.tau;
+    float ds[PMAX];
+    float dot = 0.f;
+#pragma unroll
+    for (int p = 0; p < PMAX; ++p)
+        if (PP > 0 || p < P) dot = fmaf(a.yT[(size_t)p * a.N + n], s_ds[p * BW_LD + lane], dot);
+#pragma unroll
+    for (int p = 0; p < PMAX; ++p)
+        if (PP > 0 || p < P) {
+            const float y = a.yT[(size_t)p * a.N + n];  // second read hits L1
+            ds[p] = (y * (s_ds[p * BW_LD + lane] - dot)) / tau;
+        }
+    __syncthreads();  // all waves have read dw before it is overwritten by ds
+    if (grp == 0) {
+#pragma unroll
+        for (int p = 0; p < PMAX; ++p)
+            if (PP > 0 || p < P) s_ds[p * BW_LD + lane] = live ? ds[p] : 0.f;
+    }
+    // hidden gradient for this wave's quarter of the hidden units (kept in registers until the
+    // gW2 pass below has consumed the h tile)
+    const int jq = (a.H + 3) / 4, j0 = grp * jq, j1 = (j0 + jq < a.H) ? j0 + jq : a.H;
+    __syncthreads();
+    // c1. gW2 partial from (ds, h)
+    for (int o = tid; o < a.P * a.H; o += BW_BS) {
         const int p = o / a.H, j = o % a.H;
         float acc = 0.f;
-        for (int i = 0; i < RED_CHUNK; ++i) acc = fmaf(s_ds[p * LD + i], s_h[j * LD + i], acc);
+        for (int i = 0; i < RED_CHUNK; ++i) acc = fmaf(s_ds[p * BW_LD + i], s_h[j * BW_LD + i], acc);
         prow[off_gW2() + o] = acc;
     }
-    // gR | gt : thread (t, c) walks the chunk, scattering into its own LDS column
-    for (int o = tid; o < a.B * 12; o += RED_BS) {
+    // c2. gR | gt: thread (t, c) walks the chunk, scattering into its own LDS column
+    for (int o = tid; o < a.B * 12; o += BW_BS) {
         const int t = o / 12, c = o % 12;
         for (int i = 0; i < cn; ++i) {
             const int k = s_k[i];
-            const float *g = a.G + 3 * ((size_t)t * a.N + n0 + i);
+            const float *g = s_G + t * (RED_CHUNK * 3) + 3 * i;
             float v;
             if (c < 9) v = (s_w[i] * g[c / 3]) * s_x[3 * i + c % 3];
             else v = s_w[i] * g[c - 9];
@@ -400,43 +458,95 @@ __global__ __launch_bounds__(RED_BS) void base_bwd_reduce_kernel(BaseBwdArgs a) 
         }
     }
     __syncthreads();
-    for (int e = tid; e < a.B * a.P * 12; e += RED_BS) prow[off_gRt(a.P, a.H) + e] = s_acc[e];
-    // reload the tile with dpT for gW1 / gb1
-    __syncthreads();
-    for (int e = tid; e < a.H * RED_CHUNK; e += RED_BS) {
-        const int j = e / RED_CHUNK, i = e % RED_CHUNK;
-        s_h[j * LD + i] = (i < cn) ? a.dpT[(size_t)j * a.N + n0 + i] : 0.f;
+    for (int e = tid; e < a.B * a.P * 12; e += BW_BS) prow[off_gRt(a.P, a.H) + e] = s_acc[e];
+    // b'. dp[n,j] = relu'(h) * sum_p W2[p,j] ds[p], written over the h tile
+    for (int j = j0; j < j1; ++j) {
+        float dh = 0.f;
+#pragma unroll
+        for (int p = 0; p < PMAX; ++p)
+            if (PP > 0 || p < P) dh = fmaf(s_w2T[j * PMAX + p], ds[p], dh);
+        const float h = s_h[j * BW_LD + lane];
+        s_h[j * BW_LD + lane] = (live && h > 0.f) ? dh : 0.f;
     }
     __syncthreads();
-    for (int o = tid; o < 4 * a.H; o += RED_BS) {
+    // c3. gW1 / gb1 partial from (dp, x)
+    for (int o = tid; o < 4 * a.H; o += BW_BS) {
         const int j = o / 4, c = o % 4;
         float acc = 0.f;
         if (c < 3) {
-            for (int i = 0; i < RED_CHUNK; ++i) acc = fmaf(s_h[j * LD + i], s_x[3 * i + c], acc);
+            for (int i = 0; i < RED_CHUNK; ++i) acc = fmaf(s_h[j * BW_LD + i], s_x[3 * i + c], acc);
             prow[off_gW1(a.P, a.H) + 3 * j + c] = acc;
         } else {
-            for (int i = 0; i < RED_CHUNK; ++i) acc += s_h[j * LD + i];
+            for (int i = 0; i < RED_CHUNK; ++i) acc += s_h[j * BW_LD + i];
             prow[off_gb1(a.P, a.H) + j] = acc;
         }
     }
 }
 
-// (3) sum the chunk partials in ascending chunk order; Gram-Schmidt backward for the 6-vectors
-__global__ __launch_bounds__(256) void base_bwd_finalize_kernel(BaseBwdArgs a) {
+// (2) sum the chunk partials in ascending chunk order; Gram-Schmidt backward for the
+// 6-vectors; optionally the Adam update of the very parameter this thread reduced.
+
+__device__ __forceinline__ void adam_update(float *p, float g, float *m, float *v, float lr,
+                                            float step_size_base, float bc2s, float beta1, float beta2,
+                                            float eps) {
+    (void)lr;
+    float mm = *m, vv = *v;
+    mm = mm + (g - mm) * (1.0f - beta1);
+    vv = vv * beta2 + ((1.0f - beta2) * g) * g;
+    const float denom = sqrtf(vv) / bc2s + eps;
+    *m = mm; *v = vv;
+    *p = *p - step_size_base * (mm / denom);
+}
+
+__global__ __launch_bounds__(256) void base_bwd_finalize_kernel(BaseBwdArgs a, FinalizeAdam ad) {
     const int o = blockIdx.x * 256 + threadIdx.x;
     const int nW = a.P * a.H + 4 * a.H;
     const int no = n_out(a.P, a.H, a.B);
+    float ss_seg = 0.f, ss_tr = 0.f, bc2s = 1.f;
+    if (ad.enabled) {
+        const int step = (int)ad.step_ptr[0] + 1;
+        const double bc1 = 1.0 - pow((double)ad.beta1, (double)step);
+        const double bc2 = 1.0 - pow((double)ad.beta2, (double)step);
+        ss_seg = (float)((double)ad.seg_lr / bc1);
+        ss_tr = (float)((double)ad.trans_lr / bc1);
+        bc2s = (float)sqrt(bc2);
+    }
     if (o < nW) {
         float acc = 0.f;
-        for (int c = 0; c < a.nchunk; ++c) acc += a.partial[(size_t)c * no + o];
-        if (o < a.P * a.H) a.gW2[o] = acc;
-        else if (o < a.P * a.H + 3 * a.H) a.gW1[o - a.P * a.H] = acc;
-        else a.gb1[o - a.P * a.H - 3 * a.H] = acc;
+        int c = 0;
+        for (; c + 8 <= a.nchunk; c += 8) {  // 8 independent loads in flight, fixed add order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = a.partial[(size_t)(c + u) * no + o];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        for (; c < a.nchunk; ++c) acc += a.partial[(size_t)c * no + o];
+        // partial-row order is W2 | W1 | b1; moment order is W1 | b1 | W2
+        const int nW2 = a.P * a.H, nW1 = 3 * a.H;
+        if (o < nW2) {
+            a.gW2[o] = acc;
+            if (ad.enabled)
+                adam_update(ad.W2 + o, acc, ad.m + nW1 + a.H + o, ad.v + nW1 + a.H + o, ad.seg_lr, ss_seg, bc2s,
+                            ad.beta1, ad.beta2, ad.eps);
+        } else if (o < nW2 + nW1) {
+            const int q = o - nW2;
+            a.gW1[q] = acc;
+            if (ad.enabled)
+                adam_update(ad.W1 + q, acc, ad.m + q, ad.v + q, ad.seg_lr, ss_seg, bc2s, ad.beta1, ad.beta2, ad.eps);
+        } else {
+            const int q = o - nW2 - nW1;
+            a.gb1[q] = acc;
+            if (ad.enabled)
+                adam_update(ad.b1 + q, acc, ad.m + nW1 + q, ad.v + nW1 + q, ad.seg_lr, ss_seg, bc2s, ad.beta1,
+                            ad.beta2, ad.eps);
+        }
     } else if (o < nW + a.B * a.P) {
         const int e = o - nW;
         float gRt[12];
 #pragma unroll
         for (int c = 0; c < 12; ++c) gRt[c] = 0.f;
+#pragma unroll 4
         for (int ch = 0; ch < a.nchunk; ++ch) {
             const float *pr = a.partial + (size_t)ch * no + off_gRt(a.P, a.H) + 12 * e;
 #pragma unroll
@@ -444,49 +554,83 @@ __global__ __launch_bounds__(256) void base_bwd_finalize_kernel(BaseBwdArgs a) {
         }
         float g6[6];
         r6d_backward(a.p6d + 6 * (size_t)e, gRt, g6);
+        const int base6 = 3 * a.H + a.H + a.P * a.H, baset = base6 + 6 * a.B * a.P;
 #pragma unroll
-        for (int c = 0; c < 6; ++c) a.g6d[6 * (size_t)e + c] = g6[c];
+        for (int c = 0; c < 6; ++c) {
+            a.g6d[6 * (size_t)e + c] = g6[c];
+            if (ad.enabled)
+                adam_update(ad.p6d + 6 * (size_t)e + c, g6[c], ad.m + base6 + 6 * e + c, ad.v + base6 + 6 * e + c,
+                            ad.trans_lr, ss_tr, bc2s, ad.beta1, ad.beta2, ad.eps);
+        }
 #pragma unroll
-        for (int c = 0; c < 3; ++c) a.gt[3 * (size_t)e + c] = gRt[9 + c];
+        for (int c = 0; c < 3; ++c) {
+            a.gt[3 * (size_t)e + c] = gRt[9 + c];
+            if (ad.enabled)
+                adam_update(ad.pt + 3 * (size_t)e + c, gRt[9 + c], ad.m + baset + 3 * e + c, ad.v + baset + 3 * e + c,
+                            ad.trans_lr, ss_tr, bc2s, ad.beta1, ad.beta2, ad.eps);
+        }
     }
 }
 
-static size_t base_bwd_ws_layout(int N, int P, int B, int H, size_t *o_ds, size_t *o_dp, size_t *o_part) {
+static size_t base_bwd_ws_layout(int N, int P, int B, int H, size_t *o_rt, size_t *o_part) {
     const int nchunk = reart_div_up(N, RED_CHUNK);
     size_t off = 0;
-    *o_ds = off; off += reart_align_up(sizeof(float) * (size_t)P * N, 256);
-    *o_dp = off; off += reart_align_up(sizeof(float) * (size_t)H * N, 256);
+    *o_rt = off; off += reart_align_up(sizeof(float) * 12 * (size_t)B * P, 256);
     *o_part = off; off += reart_align_up(sizeof(float) * (size_t)nchunk * n_out(P, H, B), 256);
     return off;
 }
 
 extern "C" size_t reart_base_backward_workspace_bytes(int N, int P, int B, int H) {
     if (N <= 0 || P <= 0 || B <= 0 || H <= 0) return 0;
-    size_t a, b, c;
-    return base_bwd_ws_layout(N, P, B, H, &a, &b, &c);
+    size_t a, b;
+    return base_bwd_ws_layout(N, P, B, H, &a, &b);
 }
 
-int reart_base_backward_ex(BaseBwdArgs a, void *workspace, size_t workspace_bytes, hipStream_t st) {
+template <int PP>
+static int launch_bwd_block(const BaseBwdArgs &a, size_t lds, hipStream_t st) {
+    static bool attr_set = false;  // raise the dynamic-LDS cap once (160 KiB per CU on gfx950)
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)base_bwd_block_kernel<PP>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)
+            return REART_ERR_LAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((base_bwd_block_kernel<PP>), dim3(a.nchunk), dim3(BW_BS), lds, st, a);
+    return REART_OK;
+}
+
+// a.rt_table == NULL: the table is built into the workspace first (one extra tiny launch)
+int reart_base_backward_ex(BaseBwdArgs a, const FinalizeAdam *adam, void *workspace,
+                           size_t workspace_bytes, hipStream_t st) {
     if (a.P > 32) return REART_ERR_UNSUPPORTED;
-    size_t o_ds, o_dp, o_part;
-    const size_t need = base_bwd_ws_layout(a.N, a.P, a.B, a.H, &o_ds, &o_dp, &o_part);
+    size_t o_rt, o_part;
+    const size_t need = base_bwd_ws_layout(a.N, a.P, a.B, a.H, &o_rt, &o_part);
     if (!workspace || workspace_bytes < need) return REART_ERR_INVALID_ARG;
     char *ws = (char *)workspace;
-    a.dsT = (float *)(ws + o_ds); a.dpT = (float *)(ws + o_dp); a.partial = (float *)(ws + o_part);
+    a.partial = (float *)(ws + o_part);
     a.nchunk = reart_div_up(a.N, RED_CHUNK);
-    const size_t lds1 = sizeof(float) * 12 * (size_t)a.B * a.P;
-    const size_t lds2 = sizeof(float) * ((size_t)(a.H + a.P) * (RED_CHUNK + 1) + RED_CHUNK * 5 + (size_t)a.B * a.P * 12);
-    if (lds1 > 64 * 1024 || lds2 > 64 * 1024) return REART_ERR_UNSUPPORTED;
-    const dim3 g1(reart_div_up(a.N, MB_BS));
-    switch (a.P) {
-        case 20: hipLaunchKernelGGL((base_bwd_point_kernel<20>), g1, dim3(MB_BS), lds1, st, a); break;
-        case 10: hipLaunchKernelGGL((base_bwd_point_kernel<10>), g1, dim3(MB_BS), lds1, st, a); break;
-        case 8: hipLaunchKernelGGL((base_bwd_point_kernel<8>), g1, dim3(MB_BS), lds1, st, a); break;
-        default: hipLaunchKernelGGL((base_bwd_point_kernel<0>), g1, dim3(MB_BS), lds1, st, a); break;
+    if (!a.rt_table) {
+        float *table = (float *)(ws + o_rt);
+        hipLaunchKernelGGL(rt_table_kernel, dim3(reart_div_up(a.B * a.P, 256)), dim3(256), 0, st, a.p6d, a.pt,
+                           a.B * a.P, table);
+        a.rt_table = table;
     }
-    hipLaunchKernelGGL(base_bwd_reduce_kernel, dim3(a.nchunk), dim3(RED_BS), lds2, st, a);
+    const int PMAX = (a.P == 20 || a.P == 10 || a.P == 8) ? a.P : 32;
+    const size_t lds = sizeof(float) * ((size_t)(a.H + PMAX) * BW_LD + RED_CHUNK * 5 + (size_t)a.B * a.P * 12 +
+                                        (size_t)a.B * RED_CHUNK * 3 + (size_t)a.H * PMAX);
+    if (lds > 152 * 1024) return REART_ERR_UNSUPPORTED;
+    int rc;
+    switch (a.P) {
+        case 20: rc = launch_bwd_block<20>(a, lds, st); break;
+        case 10: rc = launch_bwd_block<10>(a, lds, st); break;
+        case 8: rc = launch_bwd_block<8>(a, lds, st); break;
+        default: rc = launch_bwd_block<0>(a, lds, st); break;
+    }
+    if (rc != REART_OK) return rc;
+    FinalizeAdam none = {};
     const int nfin = a.P * a.H + 4 * a.H + a.B * a.P;
-    hipLaunchKernelGGL(base_bwd_finalize_kernel, dim3(reart_div_up(nfin, 256)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(base_bwd_finalize_kernel, dim3(reart_div_up(nfin, 256)), dim3(256), 0, st, a,
+                       adam ? *adam : none);
     REART_CHECK_LAUNCH();
     return REART_OK;
 }
@@ -506,7 +650,7 @@ extern "C" int reart_base_backward(const float *cano, int N, int P, int B, const
     a.cano = cano; a.W2 = W2; a.p6d = prop6d; a.pt = propt; a.yT = yT; a.hT = hT;
     a.hard_idx = hard_idx; a.tau = tau; a.G = G; a.N = N; a.P = P; a.B = B; a.H = H;
     a.gW1 = gW1; a.gb1 = gb1; a.gW2 = gW2; a.g6d = g6d; a.gt = gt;
-    return reart_base_backward_ex(a, workspace, workspace_bytes, (hipStream_t)stream);
+    return reart_base_backward_ex(a, nullptr, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 // --------------------------------------------------------------- hard-label rigid apply

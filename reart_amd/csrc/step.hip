@@ -19,7 +19,7 @@ struct StepPlan {
     int nchunk, nparams;
     size_t o_ysoa, o_xsoa, o_rsoa, o_rlen, o_qmap;
     size_t o_pd0, o_pi0, o_pd1, o_pi1, o_pd3, o_pi3;
-    size_t o_yT, o_hT, o_hard, o_G, o_gpf, o_cint, o_floss, o_fpart, o_grads, o_bwd;
+    size_t o_yT, o_hT, o_hard, o_rt, o_G, o_gpf, o_cint, o_floss, o_fpart, o_grads, o_bwd;
     size_t bwd_bytes, total;
 };
 
@@ -62,6 +62,7 @@ static int step_plan(const reart_relax_config *c, StepPlan *p) {
     p->o_yT = take(off, sizeof(float) * (size_t)c->P * c->N);
     p->o_hT = take(off, sizeof(float) * (size_t)c->H * c->N);
     p->o_hard = take(off, sizeof(int) * (size_t)c->N);
+    p->o_rt = take(off, sizeof(float) * 12 * (size_t)c->B * c->P);
     p->o_G = take(off, sizeof(float) * 3 * BN);
     p->o_gpf = take(off, sizeof(float) * 3 * BN);
     p->o_cint = take(off, sizeof(int) * 5 * BN);
@@ -263,25 +264,36 @@ struct CGradArgs {
 };
 #define CG_BS RS_BS
 
+// LDSBUF: the five N-int arrays (count | offset | nn_yx | sort ping | pong) live in dynamic LDS
+// (N <= CG_LDS_MAXN) instead of the global scratch: the sort's dependent loads then cost an LDS
+// round trip (~100 cycles) instead of an L2 one (~500+).
+#define CG_LDS_MAXN 6400
+template <bool LDSBUF>
 __global__ __launch_bounds__(CG_BS) void chamfer_grad_kernel(CGradArgs a) {
-    __shared__ int s_cnt[RS_DIG * RS_BS];
+    extern __shared__ __attribute__((aligned(16))) int s_dyn[];
     __shared__ int s_wave[RS_BS / 64];
     __shared__ double s_red[CG_BS / REART_WAVE];
+    int *s_cnt = s_dyn;  // [RS_DIG * RS_BS]
     const int b = blockIdx.x, tid = threadIdx.x, N = a.N;
     const float *x = a.X + (size_t)b * N * 3, *y = a.Y + (size_t)b * N * 3;
     float *G = a.G + (size_t)b * N * 3;
-    int *cnt = a.cint + (size_t)b * 5 * N, *off = cnt + N, *nn1 = off + N, *bufA = nn1 + N, *bufB = bufA + N;
+    int *cnt = LDSBUF ? s_dyn + RS_DIG * RS_BS : a.cint + (size_t)b * 5 * N;
+    int *off = cnt + N, *nn1 = off + N, *bufA = nn1 + N, *bufB = bufA + N;
     for (int j = tid; j < N; j += CG_BS) cnt[j] = 0;
     __syncthreads();
     double lsum = 0.0;
     for (int i = tid; i < N; i += CG_BS) {
         float d0 = INFINITY, d1 = INFINITY;
         int j0 = 0, j1 = 0;
+        // all loads issued unconditionally (memory-level parallelism), then an ordered select
+#pragma unroll 4
         for (int s = 0; s < a.S; ++s) {
             const size_t o = ((size_t)s * a.B + b) * N + i;
             const float e0 = a.pd0[o], e1 = a.pd1[o];
-            if (e0 < d0) { d0 = e0; j0 = a.pi0[o]; }
-            if (e1 < d1) { d1 = e1; j1 = a.pi1[o]; }
+            const int q0 = a.pi0[o], q1 = a.pi1[o];
+            const bool l0 = e0 < d0, l1 = e1 < d1;
+            d0 = l0 ? e0 : d0; j0 = l0 ? q0 : j0;
+            d1 = l1 ? e1 : d1; j1 = l1 ? q1 : j1;
         }
         lsum += (double)(d0 + d1);  // chamfer_forward + chamfer_backward (utils/chamfer.py:119-123)
         G[3 * i] = 2.0f * (x[3 * i] - y[3 * j0]);
@@ -335,12 +347,20 @@ struct BookArgs {
     const double *frame_loss; const double *flow_part; int n_flow_part;
     int64_t *iter; float *tau; float *losses;
 };
-__global__ void bookkeep_kernel(BookArgs a) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(256) void bookkeep_kernel(BookArgs a) {
+    __shared__ double s_r[4], s_f[4];
+    const int tid = threadIdx.x;
+    // fixed assignment of terms to lanes + fixed-order tree: deterministic sums
     double recon = 0.0, flow = 0.0;
-    for (int b = 0; b < a.c.B; ++b) recon += a.frame_loss[b];
-    for (int i = 0; i < a.n_flow_part; ++i) flow += a.flow_part[i];
-    flow *= (double)a.c.lambda_flow;
+    for (int b = tid; b < a.c.B; b += 256) recon += a.frame_loss[b];
+    for (int i = tid; i < a.n_flow_part; i += 256) flow += a.flow_part[i];
+    recon = reart_wave_sum_d(recon);
+    flow = reart_wave_sum_d(flow);
+    if ((tid & 63) == 0) { s_r[tid >> 6] = recon; s_f[tid >> 6] = flow; }
+    __syncthreads();
+    if (tid != 0) return;
+    recon = (s_r[0] + s_r[1]) + (s_r[2] + s_r[3]);
+    flow = ((s_f[0] + s_f[1]) + (s_f[2] + s_f[3])) * (double)a.c.lambda_flow;
     const long it = (long)a.iter[0];
     if (a.losses && a.c.ring > 0) {
         float *row = a.losses + 4 * (size_t)(it % a.c.ring);
@@ -379,6 +399,7 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
     fa.out = bufs->pc_trans; fa.out_soa = (float *)(ws + p.o_xsoa); fa.seg_part = bufs->seg_part;
     fa.trans_list = bufs->trans_list; fa.yT = (float *)(ws + p.o_yT); fa.hT = (float *)(ws + p.o_hT);
     fa.hard_idx = (int *)(ws + p.o_hard);
+    fa.rt_table = (float *)(ws + p.o_rt);
     MARK(0);
     rc = reart_base_forward_ex(fa, st);
     if (rc != REART_OK) return rc;
@@ -439,40 +460,44 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
     cg.gpf = c.use_flow ? (const float *)(ws + p.o_gpf) : nullptr;
     cg.N = N; cg.B = B; cg.S = p.S1; cg.cano_idx = c.cano_idx; cg.nbits = reart_bits_for(N); cg.G = G;
     cg.cint = (int *)(ws + p.o_cint); cg.frame_loss = (double *)(ws + p.o_floss);
-    hipLaunchKernelGGL(chamfer_grad_kernel, dim3(B), dim3(CG_BS), 0, st, cg);
+    if (N <= CG_LDS_MAXN) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute((const void *)chamfer_grad_kernel<true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)
+                return REART_ERR_LAUNCH;
+            attr_set = true;
+        }
+        const size_t lds = sizeof(int) * ((size_t)RS_DIG * RS_BS + 5 * (size_t)N);
+        hipLaunchKernelGGL(chamfer_grad_kernel<true>, dim3(B), dim3(CG_BS), lds, st, cg);
+    } else {
+        hipLaunchKernelGGL(chamfer_grad_kernel<false>, dim3(B), dim3(CG_BS), sizeof(int) * RS_DIG * RS_BS, st, cg);
+    }
     REART_CHECK_LAUNCH();
     MARK(5);
 
-    // 6-8. model backward
+    // 6-7. model backward; the finalize kernel also applies Adam with the reference's two
+    // parameter groups (run_robot.py:146-148) to the parameter each thread just reduced
     float *grads = (float *)(ws + p.o_grads);
     float *gW1 = grads, *gb1 = gW1 + 3 * H, *gW2 = gb1 + H, *g6d = gW2 + P * H, *gt = g6d + 6 * B * P;
     BaseBwdArgs ba = {};
     ba.cano = bufs->cano; ba.W2 = bufs->W2; ba.p6d = bufs->p6d; ba.pt = bufs->pt; ba.yT = fa.yT; ba.hT = fa.hT;
-    ba.hard_idx = fa.hard_idx; ba.tau_ptr = bufs->tau; ba.tau = 1.0f; ba.G = G; ba.N = N; ba.P = P; ba.B = B;
-    ba.H = H; ba.gW1 = gW1; ba.gb1 = gb1; ba.gW2 = gW2; ba.g6d = g6d; ba.gt = gt;
-    rc = reart_base_backward_ex(ba, ws + p.o_bwd, p.bwd_bytes, st);
+    ba.hard_idx = fa.hard_idx; ba.tau_ptr = bufs->tau; ba.tau = 1.0f; ba.G = G; ba.rt_table = fa.rt_table;
+    ba.N = N; ba.P = P; ba.B = B; ba.H = H; ba.gW1 = gW1; ba.gb1 = gb1; ba.gW2 = gW2; ba.g6d = g6d; ba.gt = gt;
+    FinalizeAdam ad = {};
+    ad.enabled = 1; ad.W1 = bufs->W1; ad.b1 = bufs->b1; ad.W2 = bufs->W2; ad.p6d = bufs->p6d; ad.pt = bufs->pt;
+    ad.m = bufs->adam_m; ad.v = bufs->adam_v; ad.seg_lr = c.seg_lr; ad.trans_lr = c.trans_lr;
+    ad.beta1 = c.beta1; ad.beta2 = c.beta2; ad.eps = c.eps; ad.step_ptr = bufs->iter;
+    rc = reart_base_backward_ex(ba, &ad, ws + p.o_bwd, p.bwd_bytes, st);
     if (rc != REART_OK) return rc;
     MARK(6);
-
-    // 9. Adam: two parameter groups (run_robot.py:146-148)
-    AdamArgs ad = {};
-    float *m = bufs->adam_m, *v = bufs->adam_v;
-    const int nW1 = 3 * H, nb1 = H, nW2 = P * H, n6 = 6 * B * P, nt = 3 * B * P;
-    ad.seg[0] = {bufs->W1, gW1, m, v, nW1, c.seg_lr};
-    ad.seg[1] = {bufs->b1, gb1, m + nW1, v + nW1, nb1, c.seg_lr};
-    ad.seg[2] = {bufs->W2, gW2, m + nW1 + nb1, v + nW1 + nb1, nW2, c.seg_lr};
-    ad.seg[3] = {bufs->p6d, g6d, m + nW1 + nb1 + nW2, v + nW1 + nb1 + nW2, n6, c.trans_lr};
-    ad.seg[4] = {bufs->pt, gt, m + nW1 + nb1 + nW2 + n6, v + nW1 + nb1 + nW2 + n6, nt, c.trans_lr};
-    ad.nseg = 5; ad.beta1 = c.beta1; ad.beta2 = c.beta2; ad.eps = c.eps; ad.step_ptr = bufs->iter; ad.step = 0;
-    rc = reart_adam_ex(ad, st);
-    if (rc != REART_OK) return rc;
     MARK(7);
 
     // 10. loss log, iter++, next tau
     BookArgs bk = {};
     bk.c = c; bk.frame_loss = (const double *)(ws + p.o_floss); bk.flow_part = (const double *)(ws + p.o_fpart);
     bk.n_flow_part = nfp; bk.iter = bufs->iter; bk.tau = bufs->tau; bk.losses = bufs->losses;
-    hipLaunchKernelGGL(bookkeep_kernel, dim3(1), dim3(64), 0, st, bk);
+    hipLaunchKernelGGL(bookkeep_kernel, dim3(1), dim3(256), 0, st, bk);
     REART_CHECK_LAUNCH();
     MARK(8);
     return REART_OK;
