@@ -225,6 +225,32 @@ int reart_relax_step(const reart_relax_config *cfg, const reart_relax_buffers *b
 int reart_relax_step_timed(const reart_relax_config *cfg, const reart_relax_buffers *bufs,
                            void *workspace, size_t workspace_bytes, void *stream, float *h_ms);
 
+/* ------------------------------------------------------------------------ */
+/* PointNet++ sampling / grouping (the live kernels of pointnet2_cuda)       */
+/* ------------------------------------------------------------------------ */
+
+/* Replaces furthest_point_sampling_wrapper(b,n,m, points, temp, idx)
+ * (networks/pointnet_lib/src/sampling.cpp:38-49 -> sampling_gpu.cu:93-209) and the CPU
+ * fallback farthest_point_sample (networks/pointnet2_utils.py:74-99).
+ *   xyz [B,N,3]; start [B] i32 first index per cloud or NULL (= 0, the CUDA kernel's rule;
+ *   the CPU fallback draws it from torch's RNG: inject it);  cuda_mode = 0: arg-max = first
+ *   maximum (torch.max), 1: the CUDA kernel's block-tree tie rule.  No `temp` buffer is
+ *   needed: the running minimum distances live in registers.
+ *   idx32 [B,npoint] i32 and/or idx64 [B,npoint] i64 (either may be NULL).  N <= 12288. */
+int reart_fps(const float *xyz, int B, int N, int npoint, const int32_t *start, int cuda_mode,
+              int32_t *idx32, int64_t *idx64, void *stream);
+
+/* Replaces ball_query_wrapper(b,n,m,radius,nsample,new_xyz,xyz,idx)
+ * (networks/pointnet_lib/src/ball_query.cpp:15-26 -> ball_query_gpu.cu:9-45) and the CPU
+ * fallback query_ball_point (networks/pointnet2_utils.py:102-140).
+ *   cuda_mode = 0: d2 <= float32(radius^2), first nsample in index order, padded with the
+ *   nearest point;  1: d2 < float(radius)*float(radius), padded with the first hit (0 if none).
+ *   Distance: direct difference ((dx*dx)+(dy*dy))+(dz*dz).
+ *   idx32 [B,S,nsample] i32 and/or idx64 [B,S,nsample] i64. */
+int reart_ball_query(const float *xyz, const float *new_xyz, int B, int N, int S,
+                     double radius, int nsample, int cuda_mode,
+                     int32_t *idx32, int64_t *idx64, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -170,3 +170,27 @@ def adam(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8):
     g = _f(g)
     lib().oracle_adam(_p(p), _p(g), _p(m), _p(v), p.size, step, ctypes.c_float(lr), ctypes.c_float(beta1),
                       ctypes.c_float(beta2), ctypes.c_float(eps))
+
+
+# ---- pointnet.c --------------------------------------------------------------------------
+def fps(xyz, npoint, start=None, cuda_mode=False):
+    """networks/pointnet2_utils.py:74-99 (start injected) / sampling_gpu.cu:93-209 -> idx i64 [B,npoint]."""
+    xyz = _f(xyz)
+    B, N, _ = xyz.shape
+    st = None if start is None else np.ascontiguousarray(start, dtype=np.int32)
+    idx = np.empty((B, npoint), np.int64)
+    lib().oracle_fps(_p(xyz), B, N, npoint, _p(st), int(bool(cuda_mode)), _p(idx))
+    return idx
+
+
+def ball_query(radius, nsample, xyz, new_xyz, cuda_mode=False, want_margin=False):
+    """networks/pointnet2_utils.py:102-140 / ball_query_gpu.cu:9-45 -> idx i64 [B,S,nsample]
+    (and per-row relative boundary margin min |d2-r2|/r2)."""
+    xyz, new_xyz = _f(xyz), _f(new_xyz)
+    B, N, _ = xyz.shape
+    S = new_xyz.shape[1]
+    idx = np.empty((B, S, nsample), np.int64)
+    mg = np.empty((B, S), np.float32) if want_margin else None
+    lib().oracle_ball_query(_p(xyz), _p(new_xyz), B, N, S, ctypes.c_double(radius), nsample, int(bool(cuda_mode)),
+                            _p(idx), _p(mg))
+    return (idx, mg) if want_margin else idx

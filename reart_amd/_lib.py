@@ -38,6 +38,8 @@ PROTOTYPES = {
     "reart_compute_pc_transform": (c_int, [P, P, P, c_int, c_int, c_int, P, P]),
     "reart_rotation_6d_to_matrix": (c_int, [P, c_int, P, P]),
     "reart_adam_step": (c_int, [P, P, P, P, c_int, c_int, c_float, c_float, c_float, c_float, P]),
+    "reart_fps": (c_int, [P, c_int, c_int, c_int, P, c_int, P, P, P]),
+    "reart_ball_query": (c_int, [P, P, c_int, c_int, c_int, ctypes.c_double, c_int, c_int, P, P, P]),
     # struct-taking entry points: full prototypes are set in reart_amd/relax.py
     "reart_relax_workspace_bytes": (c_size_t, None),
     "reart_relax_prepare": (c_int, None),

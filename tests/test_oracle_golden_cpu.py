@@ -98,3 +98,23 @@ def test_adam_matches_torch(oracle):
         opt.step()
         oracle.adam(p, g, m, v, step, 1e-2)
         np.testing.assert_allclose(p, pt.detach().numpy(), rtol=0, atol=2e-7)
+
+
+def test_pointnet_ops_golden(oracle):
+    """FPS (start injected) and ball query (5 extractor shapes) vs the reference CPU fallbacks."""
+    g = load("pointnet_ops")
+    xyz = g["xyz"]
+    f1 = oracle.fps(xyz, 512, start=g["start1"])
+    np.testing.assert_array_equal(f1, g["fps1"])
+    new = np.take_along_axis(xyz, f1[..., None].repeat(3, -1), 1)
+    f2 = oracle.fps(new, 128, start=g["start2"])
+    np.testing.assert_array_equal(f2, g["fps2"])
+    new2 = np.take_along_axis(new, f2[..., None].repeat(3, -1), 1)
+    boundary = 0
+    for r, K, src, ctr, tag in ((0.05, 32, xyz, new, "a"), (0.1, 64, xyz, new, "b"), (0.2, 128, xyz, new, "c"),
+                                (0.2, 64, new, new2, "d"), (0.4, 128, new, new2, "e")):
+        idx, mg = oracle.ball_query(r, K, src, ctr, want_margin=True)
+        safe = mg > 1e-5  # rows whose membership cannot flip with the distance expression
+        boundary += int((~safe).sum())
+        np.testing.assert_array_equal(idx[safe], g["bq_" + tag][safe])
+    assert boundary < 8  # boundary rows are counted and reported, not hidden

@@ -1,0 +1,98 @@
+"""GPU parity of FPS and ball query: bit-exact indices vs the oracle and vs the golden vectors
+produced by the reference's own CPU fallbacks (tests/golden/pointnet_ops.npz)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def test_fps_and_ball_query_reference_golden(dev):
+    from reart_amd.networks.pointnet2_utils import farthest_point_sample, index_points, query_ball_point
+
+    g = np.load(os.path.join(G, "pointnet_ops.npz"))
+    xyz = t(g["xyz"], dev)
+    f1 = farthest_point_sample(xyz, 512, start=t(g["start1"], dev))
+    np.testing.assert_array_equal(f1.cpu().numpy(), g["fps1"])
+    new = index_points(xyz, f1)
+    f2 = farthest_point_sample(new, 128, start=t(g["start2"], dev))
+    np.testing.assert_array_equal(f2.cpu().numpy(), g["fps2"])
+    new2 = index_points(new, f2)
+    for r, K, src, ctr, tag in ((0.05, 32, xyz, new, "a"), (0.1, 64, xyz, new, "b"), (0.2, 128, xyz, new, "c"),
+                                (0.2, 64, new, new2, "d"), (0.4, 128, new, new2, "e")):
+        idx = query_ball_point(r, K, src, ctr)
+        assert idx.dtype == torch.int64
+        np.testing.assert_array_equal(idx.cpu().numpy(), g["bq_" + tag])
+
+
+@pytest.mark.parametrize("cuda_mode", [False, True])
+@pytest.mark.parametrize("N,M", [(1, 1), (70, 70), (1000, 33), (4096, 1024), (5000, 64)])
+def test_fps_vs_oracle(oracle, dev, cuda_mode, N, M):
+    from reart_amd.networks.pointnet2_utils import farthest_point_sample
+
+    rng = np.random.default_rng(N + M)
+    xyz = rng.uniform(-1, 1, (3, N, 3)).astype(np.float32)
+    if N >= 70:
+        xyz[:, 5] = xyz[:, 40]  # duplicated points: exercises the arg-max tie rules
+        xyz[1, : N // 2] = np.round(xyz[1, : N // 2] * 4) / 4  # lattice: many exact distance ties
+    start = rng.integers(0, N, 3).astype(np.int32)
+    ref = oracle.fps(xyz, M, start=start, cuda_mode=cuda_mode)
+    got = farthest_point_sample(t(xyz, dev), M, start=t(start, dev), cuda_mode=cuda_mode)
+    np.testing.assert_array_equal(got.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("cuda_mode", [False, True])
+def test_ball_query_vs_oracle(oracle, dev, cuda_mode):
+    from reart_amd.networks.pointnet2_utils import query_ball_point
+
+    rng = np.random.default_rng(3)
+    xyz = rng.uniform(-1, 1, (2, 1500, 3)).astype(np.float32)
+    ctr = np.concatenate([xyz[:, :100], rng.uniform(-3, 3, (2, 30, 3)).astype(np.float32)], axis=1)  # some empty balls
+    for r, K in ((0.05, 16), (0.3, 32), (0.3, 200), (5.0, 64)):
+        ref = oracle.ball_query(r, K, xyz, ctr, cuda_mode=cuda_mode)
+        got = query_ball_point(r, K, t(xyz, dev), t(ctr, dev), cuda_mode=cuda_mode)
+        np.testing.assert_array_equal(got.cpu().numpy(), ref)
+
+
+def test_pointnet2_cuda_wrappers(oracle, dev):
+    """The pybind-compatible entry points (int32, caller-allocated, CUDA-kernel semantics)."""
+    from reart_amd import pointnet2_cuda as pc
+
+    rng = np.random.default_rng(5)
+    xyz = rng.uniform(-1, 1, (2, 777, 3)).astype(np.float32)
+    pts = t(xyz, dev)
+    idx = torch.zeros((2, 64), dtype=torch.int32, device=dev)
+    temp = torch.full((2, 777), 1e10, device=dev)
+    assert pc.furthest_point_sampling_wrapper(2, 777, 64, pts, temp, idx) == 1
+    ref = oracle.fps(xyz, 64, start=None, cuda_mode=True)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ref)
+    new = np.take_along_axis(xyz, ref[..., None].repeat(3, -1), 1)
+    bidx = torch.zeros((2, 64, 16), dtype=torch.int32, device=dev)
+    assert pc.ball_query_wrapper(2, 777, 64, 0.25, 16, t(new, dev), pts, bidx) == 1
+    np.testing.assert_array_equal(bidx.cpu().numpy(), oracle.ball_query(0.25, 16, xyz, new, cuda_mode=True))
+    with pytest.raises(NotImplementedError):
+        pc.three_nn_wrapper()
+
+
+def test_fps_full_size_properties(dev):
+    """19 x 4096 -> 1024 (the assignment-loss shape): min-distance sequence is non-increasing,
+    indices are distinct, first index is the injected start."""
+    from reart_amd.networks.pointnet2_utils import farthest_point_sample, index_points
+
+    gen = torch.Generator().manual_seed(0)
+    xyz = (torch.rand((19, 4096, 3), generator=gen) - 0.5).to(dev)
+    start = torch.arange(19, device=dev) * 7
+    idx = farthest_point_sample(xyz, 1024, start=start)
+    assert torch.equal(idx[:, 0], start)
+    assert all(len(set(row.tolist())) == 1024 for row in idx.cpu())
+    sel = index_points(xyz, idx)  # [19,1024,3]
+    d = torch.cdist(sel[0], sel[0])
+    prev = torch.tensor([d[i, :i].min() for i in range(1, 1024)])
+    assert (prev[1:] <= prev[:-1] + 1e-6).all()
