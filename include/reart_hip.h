@@ -251,6 +251,35 @@ int reart_ball_query(const float *xyz, const float *new_xyz, int B, int N, int S
                      double radius, int nsample, int cuda_mode,
                      int32_t *idx32, int64_t *idx64, void *stream);
 
+/* ------------------------------------------------------------------------ */
+/* Projection model: screw-joint forward kinematics                          */
+/* ------------------------------------------------------------------------ */
+
+/* Replaces fk(paths_to_base, reverse_topo, edge_index, axis_list, moment_list, theta_list,
+ * distance_list) (utils/kinematic_utils.py:151-198) including
+ * screw_param_to_exponential_coordinates / transform_from_exponential_coordinates
+ * (screw_se3/screw_utils.py:6-30) and se3_exp_map (screw_se3/geo_utils.py:147-222).
+ * The joint tree is passed as arrays instead of the reference's dicts:
+ *   parent[c] (-1 = root), edge_of_part[c] (index of edge "c_parent" in edge_index),
+ *   order = reverse_topo (parts from root to leaf), all i32 [P];
+ *   axis, moment [E,3]; theta [B,E]; distance [B,E] or NULL (= 1e-6, :176);
+ *   trans [B,P,4,4] out. */
+int reart_fk_forward(const int32_t *parent, const int32_t *edge_of_part, const int32_t *order,
+                     int P, const float *axis, const float *moment, const float *theta,
+                     const float *distance, int B, int E, float *trans, void *stream);
+
+/* Backward of `fk` + the hard-label rigid apply of KinematicModel.forward
+ * (networks/model.py:161-165): x [N,3], part [N] i64, G = dL/d pc_trans [B,N,3], trans = the
+ * forward's output -> g_axis [E,3], g_moment [E,3], g_theta [B,E], g_distance [B,E] or NULL.
+ * Deterministic (ordered reductions).  P <= 64. */
+size_t reart_fk_backward_workspace_bytes(int P, int B, int E);
+int reart_fk_backward(const float *x, const int64_t *part, const float *G, int N,
+                      const int32_t *parent, const int32_t *edge_of_part, const int32_t *order,
+                      int P, const float *axis, const float *moment, const float *theta,
+                      const float *distance, int B, int E, const float *trans,
+                      float *g_axis, float *g_moment, float *g_theta, float *g_distance,
+                      void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -194,3 +194,34 @@ def ball_query(radius, nsample, xyz, new_xyz, cuda_mode=False, want_margin=False
     lib().oracle_ball_query(_p(xyz), _p(new_xyz), B, N, S, ctypes.c_double(radius), nsample, int(bool(cuda_mode)),
                             _p(idx), _p(mg))
     return (idx, mg) if want_margin else idx
+
+
+# ---- screw.c -----------------------------------------------------------------------------
+def se3_exp_map(log_transform):
+    """screw_se3/geo_utils.py:147-222 -> [n,4,4] (pytorch3d row-vector form)."""
+    lt = _f(log_transform)
+    T = np.empty((lt.shape[0], 4, 4), np.float32)
+    lib().oracle_se3_exp_map(_p(lt), lt.shape[0], _p(T))
+    return T
+
+
+def screw_to_transform(l, m, theta, d):
+    """screw_se3/screw_utils.py:6-30 composed -> [n,4,4] column-vector transforms."""
+    l, m, theta, d = _f(l), _f(m), _f(theta), _f(d)
+    T = np.empty((l.shape[0], 4, 4), np.float32)
+    lib().oracle_screw_to_transform(_p(l), _p(m), _p(theta), _p(d), l.shape[0], _p(T))
+    return T
+
+
+def fk(parent, edge_of_part, order, axis, moment, theta, distance=None):
+    """utils/kinematic_utils.py:151-198 with the tree as arrays -> trans [B,P,4,4]."""
+    parent = np.ascontiguousarray(parent, np.int32)
+    eop = np.ascontiguousarray(edge_of_part, np.int32)
+    order = np.ascontiguousarray(order, np.int32)
+    axis, moment, theta = _f(axis), _f(moment), _f(theta)
+    dist = None if distance is None else _f(distance)
+    B, E = theta.shape
+    P = parent.shape[0]
+    T = np.empty((B, P, 4, 4), np.float32)
+    lib().oracle_fk(_p(parent), _p(eop), _p(order), P, _p(axis), _p(moment), _p(theta), _p(dist), B, E, _p(T))
+    return T

@@ -106,3 +106,64 @@ class BaseModel(nn.Module):
             gumbel = sample_gumbel((cano_pc.shape[0], self.num_parts), cano_pc.device)
         W1, b1, W2 = self._weights()
         return _BaseForward.apply(cano_pc, W1, b1, W2, p6d, pt, gumbel, tau)
+
+
+class KinematicModel(nn.Module):
+    """Projection model over a screw-joint tree, cf. networks/model.py:73-166.
+
+    Same constructor keywords and parameter names as the reference (its checkpoints load with
+    ``strict=True``): ``axis_list`` [E,3], ``moment_list`` [E,3], ``theta_list`` [T-1,E] and the
+    optional ``distance_list``.  forward = k-NN label transfer (utils/model_utils.py:41-51) +
+    fused FK kernel + hard-label rigid apply.  Root motion (``root_trans``: SAPIEN / real scans
+    only, run_real.py / run_sapien.py) is not built."""
+
+    def __init__(self, pose_len, seg_part, cano_pc, knn, **kwargs):
+        super().__init__()
+        from ..utils.kinematic_utils import tree_arrays
+
+        self.seg_part = seg_part.long()
+        self.cano_pc = cano_pc
+        self.pose_len = pose_len
+        self.num_parts = len(torch.unique(self.seg_part))
+        self.knn = knn
+        if knn is not None:
+            assert self.knn.k == 1
+        self.edge_index = kwargs["edge_index"]
+        self.paths_to_base = kwargs["paths_to_base"]
+        self.reverse_topo = kwargs["reverse_topo"]
+        E = len(self.edge_index)
+        assert self.num_parts == E + 1  # P = E + 1
+        if "root_trans" in kwargs or kwargs.get("load_root_trans"):
+            raise NotImplementedError("root motion is only used by run_real.py / run_sapien.py (out of scope)")
+        for name, shape in (("axis_list", (E, 3)), ("moment_list", (E, 3)), ("theta_list", (pose_len, E))):
+            init = kwargs[name] if name in kwargs else torch.zeros(shape)
+            setattr(self, name, nn.Parameter(init.clone().float(), requires_grad=True))
+        if "distance_list" in kwargs:
+            self.distance_list = nn.Parameter(kwargs["distance_list"], requires_grad=True)
+        elif kwargs.get("load_distance"):
+            self.distance_list = nn.Parameter(torch.zeros(pose_len, E), requires_grad=True)
+        self.joint_type_list = kwargs.get("joint_type_list")
+        self._tree_np = tree_arrays(self.edge_index, self.reverse_topo)
+        self._tree_dev = {}
+
+    def _tree(self, device):
+        if device not in self._tree_dev:
+            self._tree_dev[device] = tuple(torch.from_numpy(a).to(device) for a in self._tree_np)
+        return self._tree_dev[device]
+
+    def seg_forward(self, input_pc, **kwargs):
+        from ..utils.model_utils import knn_query
+
+        return knn_query(input_pc, self.cano_pc, self.seg_part, self.knn)
+
+    def forward(self, input_pc, **kwargs):
+        from ..utils.kinematic_utils import _FK, _effective_joint_values
+
+        seg_part = self.seg_forward(input_pc)
+        theta_list = kwargs.get("theta_list", self.theta_list)
+        distance_list = self.distance_list if hasattr(self, "distance_list") else None
+        theta, dist = _effective_joint_values(theta_list, distance_list, self.joint_type_list)
+        parent, edge_of, order = self._tree(input_pc.device)
+        pc_trans_list, trans_list = _FK.apply(input_pc, seg_part, self.axis_list, self.moment_list, theta, dist,
+                                              parent, edge_of, order)
+        return pc_trans_list, seg_part, trans_list
