@@ -280,6 +280,36 @@ int reart_fk_backward(const float *x, const int64_t *part, const float *G, int N
                       float *g_axis, float *g_moment, float *g_theta, float *g_distance,
                       void *workspace, size_t workspace_bytes, void *stream);
 
+/* ------------------------------------------------------------------------ */
+/* PointNet++ correspondence extractor: dense layers and interpolation       */
+/* ------------------------------------------------------------------------ */
+
+/* One fused layer  Y = relu(X Wt + bias) [max-pooled over pool_k consecutive rows]  on the fp32
+ * matrix cores (v_mfma_f32_32x32x2_f32, exact fp32).  Replaces Conv2d/Conv1d(1x1) + BatchNorm
+ * (eval, folded into Wt/bias by the caller) + ReLU and the max over nsample of
+ * PointNetSetAbstractionMsg / PointNetSetAbstraction / PointNetFeaturePropagation
+ * (networks/pointnet2_utils.py:209-235, 257-295, 309-348).
+ *   Plain input: X [rows, ldx].  Gathered input (gather_idx != NULL; replaces index_points +
+ *   centre subtraction + cat of :270-281 / sample_and_group_all :186-188 without materialising
+ *   the grouped tensor): row r takes point gather_idx[r] (i64, [B,S,K] flattened) of cloud
+ *   r / (S*K); columns = [F (D) | Q - C[r / K]] (xyz_first = 0) or [Q | F] (xyz_first = 1,
+ *   C may be NULL); F [B*Npts, D], Q [B*Npts, 3], C [B*S, 3]; Cin must equal D + 3.
+ *   Wt [Cin, Cout] (transposed conv weight), bias [Cout] or NULL; pool_k in {0, 32, 64, 128};
+ *   Y [rows (/pool_k), ldy], written at columns ycol0 .. ycol0 + Cout. */
+int reart_mlp_layer(const float *X, int ldx, const int64_t *gather_idx, int K, int S, int Npts,
+                    const float *F, int D, const float *Q, const float *C, int xyz_first,
+                    const float *Wt, const float *bias, int rows, int Cin, int Cout, int relu,
+                    int pool_k, float *Y, int ldy, int ycol0, void *stream);
+
+/* 3-NN inverse-distance interpolation of PointNetFeaturePropagation
+ * (networks/pointnet2_utils.py:326-336): xyz1 [B,N,3], xyz2 [B,S2,3], points2 [B,S2,D] ->
+ * out [B*N, ldo] columns col0 .. col0 + D (so the cat with the skip features, :338-342, is free).
+ * Distances: direct difference (the reference's matmul expansion differs by ~1e-8 absolute). */
+size_t reart_three_interpolate_workspace_bytes(int B, int N, int S2);
+int reart_three_interpolate(const float *xyz1, const float *xyz2, const float *points2, int B,
+                            int N, int S2, int D, float *out, int ldo, int col0,
+                            void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -44,6 +44,10 @@ PROTOTYPES = {
     "reart_fk_backward_workspace_bytes": (c_size_t, [c_int] * 3),
     "reart_fk_backward": (c_int, [P, P, P, c_int, P, P, P, c_int, P, P, P, P, c_int, c_int, P, P, P, P, P, P,
                                   c_size_t, P]),
+    "reart_mlp_layer": (c_int, [P, c_int, P, c_int, c_int, c_int, P, c_int, P, P, c_int, P, P, c_int, c_int, c_int,
+                                c_int, c_int, P, c_int, c_int, P]),
+    "reart_three_interpolate_workspace_bytes": (c_size_t, [c_int] * 3),
+    "reart_three_interpolate": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, c_int, c_int, P, c_size_t, P]),
     # struct-taking entry points: full prototypes are set in reart_amd/relax.py
     "reart_relax_workspace_bytes": (c_size_t, None),
     "reart_relax_prepare": (c_int, None),
