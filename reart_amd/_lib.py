@@ -10,7 +10,8 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libreart_hip.so")
+# REART_LIB overrides the library path (kernel A/B experiments); the default is the in-tree build
+LIB_PATH = os.environ.get("REART_LIB") or os.path.join(_HERE, "csrc", "libreart_hip.so")
 
 c_int, c_float, c_size_t, c_void_p = ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p
 P = c_void_p  # every device pointer

@@ -97,4 +97,4 @@ struct KnnArgs {
 
 int reart_knn_launch_slices(const KnnArgs &a, int KK, hipStream_t st);
 int reart_soa_launch(const SoaArgs &sa, int maxPpad, int N, int njobs, hipStream_t st);
-int reart_knn_pick_split(long waves, int P2);
+int reart_knn_pick_split(long waves, int P2, int K);

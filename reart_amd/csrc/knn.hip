@@ -150,23 +150,54 @@ __global__ __launch_bounds__(NN_BS) void knn_slice_kernel(KnnArgs a) {
         }
         ki[0] = bi;
     } else {
-        for (int j = j0; j < j1; j += NN_UB) {
-            float dd[NN_UB];
+        // K > 1.  Phase A keeps the KK best BLOCKS of 8 targets by (block minimum, block id):
+        // one min per pair and one branch-free insertion per block, instead of a divergent
+        // insertion test per target.  The KK nearest targets lie inside those blocks (any
+        // other block's minimum key exceeds the KK-th smallest target key), so phase B rescans
+        // only KK*8 targets per query with an exact (d, index) insertion.
+        constexpr int UBK = 8;
+        float bm[KK];
+        int bb[KK];
+#pragma unroll
+        for (int k = 0; k < KK; ++k) { bm[k] = INFINITY; bb[k] = -1; }
+        for (int j = j0; j < j1; j += UBK) {
             float m = INFINITY;
 #pragma unroll
-            for (int u = 0; u < NN_UB; u += 2) {
+            for (int u = 0; u < UBK; u += 2) {
                 const f2 dx = qx2 - *(const f2 *)(tx + j + u);
                 const f2 dy = qy2 - *(const f2 *)(ty + j + u);
                 const f2 dz = qz2 - *(const f2 *)(tz + j + u);
                 const f2 d = (dx * dx + dy * dy) + dz * dz;
-                dd[u] = d.x;
-                dd[u + 1] = d.y;
                 m = fminf(fminf(m, d.x), d.y);
             }
-            if (m < kd[KK - 1]) {
+            // strict '<': on equal minima the earlier (lower-index) block stays ahead
 #pragma unroll
-                for (int u = 0; u < NN_UB; ++u)
-                    if (dd[u] < kd[KK - 1]) knn_insert<KK>(kd, ki, dd[u], j + u);
+            for (int s = KK - 1; s >= 0; --s) {
+                const bool lt_prev = (s > 0) && (m < bm[s > 0 ? s - 1 : 0]);
+                const bool lt_cur = m < bm[s];
+                bm[s] = lt_prev ? bm[s > 0 ? s - 1 : 0] : (lt_cur ? m : bm[s]);
+                bb[s] = lt_prev ? bb[s > 0 ? s - 1 : 0] : (lt_cur ? j : bb[s]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < KK; ++c) {
+            const int blk = bb[c];
+            if (blk < 0) continue;
+#pragma unroll
+            for (int u = 0; u < UBK; ++u) {
+                const float d = reart_sqdist3(qx, qy, qz, tx[blk + u], ty[blk + u], tz[blk + u]);
+                const int jj = blk + u;
+                // candidates arrive in block-rank order, not index order: compare the full key
+                if (d < kd[KK - 1] || (d == kd[KK - 1] && d < INFINITY && jj < ki[KK - 1])) {
+#pragma unroll
+                    for (int s = KK - 1; s >= 0; --s) {
+                        const int sp = s > 0 ? s - 1 : 0;
+                        const bool lt_prev = (s > 0) && (d < kd[sp] || (d == kd[sp] && jj < ki[sp]));
+                        const bool lt_cur = d < kd[s] || (d == kd[s] && jj < ki[s]);
+                        kd[s] = lt_prev ? kd[sp] : (lt_cur ? d : kd[s]);
+                        ki[s] = lt_prev ? ki[sp] : (lt_cur ? jj : ki[s]);
+                    }
+                }
             }
         }
     }
@@ -215,19 +246,22 @@ static int knn_round_k(int K) {
 }
 
 // number of target slices: enough wave-sized work items to balance 1024 SIMDs
-static int knn_pick_split(long waves, int P2) {
-    const char *env = getenv("REART_NN_SPLIT");
+// K > 1 restarts its sorted list in every slice (each restart re-runs the insertion path for
+// the first ~64*K*ln targets), so it wants fewer, longer slices than K = 1.
+static int knn_pick_split(long waves, int P2, int K) {
+    const char *env = getenv(K > 1 ? "REART_KNN_SPLIT" : "REART_NN_SPLIT");
     int S = 1;
     if (env && atoi(env) > 0) {
         S = atoi(env);
     } else {
-        while (waves * S < 8192 && S < 16) S *= 2;
+        const long want = 8192;  // measured: K = 3 also prefers many short slices (S=8: 82 us, S=4: 90, S=2: 106)
+        while (waves * S < want && S < 16) S *= 2;
     }
     while (S > 1 && reart_div_up(P2, S) < 128) S /= 2;  // keep slices meaningful
     return S < 1 ? 1 : S;
 }
 
-int reart_knn_pick_split(long waves, int P2) { return knn_pick_split(waves, P2); }
+int reart_knn_pick_split(long waves, int P2, int K) { return knn_pick_split(waves, P2, K); }
 
 struct KnnPlan {
     int KK, S;
@@ -245,7 +279,7 @@ static int knn_plan(int njobs, int N, const int *P1, const int *P2, int K, KnnPl
         waves += (long)N * reart_div_up(P1[j], NN_BS);
         minP2 = P2[j] < minP2 ? P2[j] : minP2;
     }
-    pl->S = knn_pick_split(waves, minP2);
+    pl->S = knn_pick_split(waves, minP2, K);
     size_t off = 0;
     for (int j = 0; j < njobs; ++j) {
         pl->L[j] = (int)reart_align_up((size_t)reart_div_up(P2[j], pl->S), NN_UB);

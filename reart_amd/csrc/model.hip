@@ -125,35 +125,32 @@ __device__ __forceinline__ float gumbel_from_bits(uint32_t bits) {
 }
 
 // ------------------------------------------------------------------------------- forward
-// Workgroup = 4 waves x the same 64 points.  Wave g evaluates the logits of parts
-// [g*PG, (g+1)*PG) (each a full ascending-j fmaf chain, so the rounding order is the
-// oracle's), the four slices meet in LDS, then every wave redoes the cheap softmax /
-// arg-max and applies the rigid transforms of frames t = g, g+4, ...
-#define FW_BS 256
+// Workgroup = W waves x the same 64 points, W = ceil(P/2): wave g owns parts {2g, 2g+1}.
+//   * logits: each wave runs the full ascending-j fmaf chain of ITS parts (the oracle's
+//     rounding order), weights broadcast from LDS;
+//   * Gumbel noise, (s+g)/tau, exp and the division are evaluated only for the wave's own
+//     parts; max / sum / arg-max meet in LDS (the sum is re-done by every lane in ascending
+//     part order, again the oracle's order);
+//   * the rigid apply of frame t is done by wave t mod W.
+// The kernel is latency bound (a few thousand dependent instructions per wave at one wave per
+// SIMD), so the design goal is the shortest per-wave instruction stream, not occupancy.
 #define FW_PTS 64
+#define FW_PG 2
 
 template <int PP>
-__global__ __launch_bounds__(FW_BS) void base_fwd_kernel(BaseFwdArgs a) {
+__global__ __launch_bounds__(64 * (((PP > 0 ? PP : 32) + FW_PG - 1) / FW_PG)) void base_fwd_kernel(BaseFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int PMAX = (PP > 0) ? PP : 32;
-    constexpr int PG = (PMAX + 3) / 4;
+    constexpr int W = (PMAX + FW_PG - 1) / FW_PG;
+    constexpr int BS = 64 * W;
     float *s_rt = smem;                                   // [B*P][12]
-    float *s_log = smem + 12 * (size_t)a.B * a.P;         // [FW_PTS][PMAX]
-    float *s_wb = s_log + FW_PTS * PMAX;                  // [H][4]  W1 row | b1
+    float *s_wb = s_rt + 12 * (size_t)a.B * a.P;          // [H][4]  W1 row | b1
     float *s_w2T = s_wb + 4 * (size_t)a.H;                // [H][PMAX]  W2 transposed
+    float *s_a = s_w2T + (size_t)a.H * PMAX;              // [PMAX][64]  logits, later y
+    float *s_e = s_a + PMAX * FW_PTS;                     // [PMAX][64]  z, later exp(z - max)
     const int tid = threadIdx.x, lane = tid & 63, grp = tid >> 6;
     const int P = (PP > 0) ? PP : a.P;
-    // weights -> LDS once per workgroup (coalesced); the inner loop then reads them as
-    // wave-uniform LDS broadcasts instead of one scalar-load round trip per hidden unit
-    for (int e = tid; e < 4 * a.H; e += FW_BS) {
-        const int j = e >> 2, c = e & 3;
-        s_wb[e] = c < 3 ? a.W1[3 * j + c] : a.b1[j];
-    }
-    for (int e = tid; e < a.P * a.H; e += FW_BS) {
-        const int p = e / a.H, j = e % a.H;
-        s_w2T[j * PMAX + p] = a.W2[e];
-    }
-    for (int e = tid; e < a.B * a.P; e += FW_BS) {
+    for (int e = tid; e < a.B * a.P; e += BS) {
         float R[9];
         r6d_to_matrix(a.p6d + 6 * (size_t)e, R);
 #pragma unroll
@@ -179,18 +176,35 @@ __global__ __launch_bounds__(FW_BS) void base_fwd_kernel(BaseFwdArgs a) {
             }
         }
     }
+    for (int e = tid; e < 4 * a.H; e += BS) {
+        const int j = e >> 2, c = e & 3;
+        s_wb[e] = c < 3 ? a.W1[3 * j + c] : a.b1[j];
+    }
+    for (int j = tid; j < a.H; j += BS)          // one hidden unit per thread: no integer division
+        for (int p = 0; p < P; ++p) s_w2T[j * PMAX + p] = a.W2[(size_t)p * a.H + j];
 
     const int n = blockIdx.x * FW_PTS + lane;
     const bool live = n < a.N;
     const int nc = live ? n : a.N - 1;
     const float x0 = a.cano[3 * (size_t)nc], x1 = a.cano[3 * (size_t)nc + 1], x2 = a.cano[3 * (size_t)nc + 2];
-
-    // logits of this wave's parts: s[p] = sum_j W2[p,j] relu(W1[j].x + b1[j]), j ascending
-    float sp[PG];
-#pragma unroll
-    for (int q = 0; q < PG; ++q) sp[q] = 0.f;
-    const int p0 = grp * PG;
+    const int p0 = grp * FW_PG;
+    const bool has1 = p0 + 1 < P;
+    const float tau = a.tau_ptr ? a.tau_ptr[0] : a.tau;
+    // Gumbel noise of this wave's parts (issued early: independent of the logits)
+    float g0, g1 = 0.f;
+    if (a.gumbel) {
+        g0 = a.gumbel[(size_t)nc * P + (p0 < P ? p0 : 0)];
+        if (has1) g1 = a.gumbel[(size_t)nc * P + p0 + 1];
+    } else {
+        const uint64_t it = a.iter_ptr ? (uint64_t)a.iter_ptr[0] : 0ull;
+        uint32_t r[4];
+        philox4x32((uint32_t)n, (uint32_t)(p0 >> 2), (uint32_t)it, (uint32_t)(it >> 32), (uint32_t)a.seed,
+                   (uint32_t)(a.seed >> 32), r);
+        g0 = gumbel_from_bits(r[p0 & 3]);
+        g1 = gumbel_from_bits(r[(p0 & 3) + 1]);   // p0 is even: p0 & 3 in {0, 2}
+    }
     __syncthreads();
+    float sp0 = 0.f, sp1 = 0.f;
 #pragma unroll 8
     for (int j = 0; j < a.H; ++j) {
         const float4 wb = *(const float4 *)(s_wb + 4 * j);
@@ -200,67 +214,53 @@ __global__ __launch_bounds__(FW_BS) void base_fwd_kernel(BaseFwdArgs a) {
         acc = acc + wb.w;
         const float h = acc > 0.f ? acc : 0.f;
         if (grp == 0 && a.hT && live) a.hT[(size_t)j * a.N + n] = h;
-#pragma unroll
-        for (int q = 0; q < PG; ++q)
-            if (p0 + q < P) sp[q] = fmaf(s_w2T[j * PMAX + p0 + q], h, sp[q]);
+        sp0 = fmaf(s_w2T[j * PMAX + p0], h, sp0);
+        sp1 = fmaf(s_w2T[j * PMAX + p0 + 1], h, sp1);   // PMAX is even: in range, ignored when !has1
     }
-#pragma unroll
-    for (int q = 0; q < PG; ++q)
-        if (p0 + q < P) s_log[lane * PMAX + p0 + q] = sp[q];
+    const float z0 = (sp0 + g0) / tau, z1 = has1 ? (sp1 + g1) / tau : -INFINITY;
+    if (p0 < P) { s_a[p0 * FW_PTS + lane] = sp0; s_e[p0 * FW_PTS + lane] = z0; }
+    if (has1) { s_a[(p0 + 1) * FW_PTS + lane] = sp1; s_e[(p0 + 1) * FW_PTS + lane] = z1; }
     __syncthreads();
-
-    float s[PMAX];
-#pragma unroll
-    for (int p = 0; p < PMAX; ++p) s[p] = (PP > 0 || p < P) ? s_log[lane * PMAX + p] : 0.f;
-    // noise-free arg-max (networks/model.py:70) -- first maximum
-    int am = 0;
-    float sm = s[0];
-#pragma unroll
-    for (int p = 1; p < PMAX; ++p)
-        if ((PP > 0 || p < P) && s[p] > sm) { sm = s[p]; am = p; }
-
-    const float tau = a.tau_ptr ? a.tau_ptr[0] : a.tau;
-    float g[PMAX];
-    if (a.gumbel) {
-#pragma unroll
-        for (int p = 0; p < PMAX; ++p)
-            g[p] = (PP > 0 || p < P) ? a.gumbel[(size_t)nc * P + p] : 0.f;
-    } else {
-        const uint64_t it = a.iter_ptr ? (uint64_t)a.iter_ptr[0] : 0ull;
-#pragma unroll
-        for (int q = 0; q < PMAX; q += 4) {
-            uint32_t r[4];
-            philox4x32((uint32_t)n, (uint32_t)(q >> 2), (uint32_t)it, (uint32_t)(it >> 32),
-                       (uint32_t)a.seed, (uint32_t)(a.seed >> 32), r);
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (q + u < PMAX) g[q + u] = gumbel_from_bits(r[u]);
-        }
-    }
-    float z[PMAX];
+    // noise-free arg-max (networks/model.py:70, first maximum) and the softmax max
     float m = -INFINITY;
+    int am = 0;
+    float sm = -INFINITY;
 #pragma unroll
     for (int p = 0; p < PMAX; ++p)
-        if (PP > 0 || p < P) { z[p] = (s[p] + g[p]) / tau; m = fmaxf(m, z[p]); }
+        if (PP > 0 || p < P) {
+            m = fmaxf(m, s_e[p * FW_PTS + lane]);
+            if (grp == 0) {
+                const float sv = s_a[p * FW_PTS + lane];
+                if (sv > sm) { sm = sv; am = p; }
+            }
+        }
+    __syncthreads();
+    const float e0 = expf(z0 - m), e1 = has1 ? expf(z1 - m) : 0.f;
+    if (p0 < P) s_e[p0 * FW_PTS + lane] = e0;
+    if (has1) s_e[(p0 + 1) * FW_PTS + lane] = e1;
+    __syncthreads();
     float sum = 0.f;
 #pragma unroll
     for (int p = 0; p < PMAX; ++p)
-        if (PP > 0 || p < P) { z[p] = expf(z[p] - m); sum += z[p]; }
+        if (PP > 0 || p < P) sum += s_e[p * FW_PTS + lane];   // ascending part order
+    const float y0 = e0 / sum, y1 = e1 / sum;
+    if (p0 < P) { s_a[p0 * FW_PTS + lane] = y0; if (a.yT && live) a.yT[(size_t)p0 * a.N + n] = y0; }
+    if (has1) { s_a[(p0 + 1) * FW_PTS + lane] = y1; if (a.yT && live) a.yT[(size_t)(p0 + 1) * a.N + n] = y1; }
+    __syncthreads();
     int k = 0;
     float yk = -1.f;
 #pragma unroll
     for (int p = 0; p < PMAX; ++p)
         if (PP > 0 || p < P) {
-            z[p] = z[p] / sum;
-            if (z[p] > yk) { yk = z[p]; k = p; }
-            if (grp == 0 && a.yT && live) a.yT[(size_t)p * a.N + n] = z[p];
+            const float yv = s_a[p * FW_PTS + lane];
+            if (yv > yk) { yk = yv; k = p; }
         }
     const float w = (1.0f - yk) + yk;  // y_hard - y_soft.detach() + y_soft
     if (live && grp == 0) {
         if (a.seg_part) a.seg_part[n] = am;
         if (a.hard_idx) a.hard_idx[n] = k;
     }
-    for (int t = grp; t < a.B; t += FW_BS / 64) {
+    for (int t = grp; t < a.B; t += W) {
         float v[3];
         apply_rt(s_rt + 12 * (t * a.P + k), x0, x1, x2, v);
         v[0] = w * v[0]; v[1] = w * v[1]; v[2] = w * v[2];
@@ -280,14 +280,15 @@ __global__ __launch_bounds__(FW_BS) void base_fwd_kernel(BaseFwdArgs a) {
 template <int PP>
 static void launch_base_fwd(const BaseFwdArgs &a, hipStream_t st) {
     constexpr int PMAX = (PP > 0) ? PP : 32;
+    constexpr int W = (PMAX + FW_PG - 1) / FW_PG;
     const int cover = a.out_soa ? (a.Npad > a.N ? a.Npad : a.N) : a.N;
-    const size_t lds = sizeof(float) * (12 * (size_t)a.B * a.P + (size_t)FW_PTS * PMAX + (size_t)a.H * (4 + PMAX));
-    hipLaunchKernelGGL((base_fwd_kernel<PP>), dim3(reart_div_up(cover, FW_PTS)), dim3(FW_BS), lds, st, a);
+    const size_t lds = sizeof(float) * (12 * (size_t)a.B * a.P + (size_t)a.H * (4 + PMAX) + 2 * (size_t)FW_PTS * PMAX);
+    hipLaunchKernelGGL((base_fwd_kernel<PP>), dim3(reart_div_up(cover, FW_PTS)), dim3(64 * W), lds, st, a);
 }
 
 static int dispatch_base_fwd(const BaseFwdArgs &a, hipStream_t st) {
     if (a.P < 1 || a.P > 32) return REART_ERR_UNSUPPORTED;
-    if (((size_t)a.B * a.P * 12 + FW_PTS * 32 + (size_t)a.H * 36) * sizeof(float) > 64 * 1024) return REART_ERR_UNSUPPORTED;
+    if (((size_t)a.B * a.P * 12 + 2 * FW_PTS * 32 + (size_t)a.H * 36) * sizeof(float) > 64 * 1024) return REART_ERR_UNSUPPORTED;
     switch (a.P) {
         case 20: launch_base_fwd<20>(a, st); break;
         case 10: launch_base_fwd<10>(a, st); break;

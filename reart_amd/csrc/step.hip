@@ -19,7 +19,7 @@ struct StepPlan {
     int nchunk, nparams;
     size_t o_ysoa, o_xsoa, o_rsoa, o_rlen, o_qmap;
     size_t o_pd0, o_pi0, o_pd1, o_pi1, o_pd3, o_pi3;
-    size_t o_yT, o_hT, o_hard, o_rt, o_G, o_gpf, o_cint, o_floss, o_fpart, o_grads, o_bwd;
+    size_t o_yT, o_hT, o_hard, o_rt, o_G, o_gpf, o_cint, o_fx, o_floss, o_fpart, o_grads, o_bwd;
     size_t bwd_bytes, total;
 };
 
@@ -35,13 +35,13 @@ static int step_plan(const reart_relax_config *c, StepPlan *p) {
     if (c->N <= 0 || c->P <= 0 || c->P > 32 || c->B <= 0 || c->H <= 0) return REART_ERR_INVALID_ARG;
     if (c->use_flow && (c->flow_k != 3 || c->M_max < 3)) return REART_ERR_UNSUPPORTED;
     const long waves1 = 2L * c->B * reart_div_up(c->N, NN_BS);
-    p->S1 = reart_knn_pick_split(waves1, c->N);
+    p->S1 = reart_knn_pick_split(waves1, c->N, 1);
     p->L1 = (int)reart_align_up((size_t)reart_div_up(c->N, p->S1), NN_UB);
     p->Npad = p->L1 * p->S1;
     p->S3 = 1; p->Mpad = 0;
     if (c->use_flow) {
         const long waves3 = (long)c->B * reart_div_up(c->N, NN_BS);
-        p->S3 = reart_knn_pick_split(waves3, c->M_max);
+        p->S3 = reart_knn_pick_split(waves3, c->M_max, 3);
         p->Mpad = (int)reart_align_up((size_t)reart_div_up(c->M_max, p->S3), NN_UB) * p->S3;
     }
     p->nchunk = reart_div_up(c->N, 64);
@@ -65,7 +65,8 @@ static int step_plan(const reart_relax_config *c, StepPlan *p) {
     p->o_rt = take(off, sizeof(float) * 12 * (size_t)c->B * c->P);
     p->o_G = take(off, sizeof(float) * 3 * BN);
     p->o_gpf = take(off, sizeof(float) * 3 * BN);
-    p->o_cint = take(off, sizeof(int) * 5 * BN);
+    p->o_cint = take(off, 32 * BN);          // per point: 3 x int64 fixed-point sums + count (+pad)
+    p->o_fx = take(off, sizeof(double));
     p->o_floss = take(off, sizeof(double) * c->B);
     p->o_fpart = take(off, sizeof(double) * (size_t)c->B * reart_div_up(c->N, FLOW_BS));
     p->o_grads = take(off, sizeof(float) * p->nparams);
@@ -90,8 +91,24 @@ __device__ __forceinline__ float tau_schedule(long cur_iter, int n_iter, float e
 
 __global__ void relax_init_kernel(reart_relax_config c, const int *__restrict__ ref_off,
                                   int *__restrict__ rlen, int *__restrict__ qmap,
-                                  int64_t *__restrict__ iter, float *__restrict__ tau) {
+                                  int64_t *__restrict__ iter, float *__restrict__ tau,
+                                  const float *__restrict__ pc_list, double *__restrict__ fx_scale) {
+    __shared__ float s_max[1024];
     const int t = threadIdx.x;
+    // fixed-point scale for the exact (order-independent) sums of observed points in
+    // chamfer_grad_kernel: N * max|y| * scale < 2^61
+    float mx = 0.f;
+    for (size_t e = t; e < (size_t)c.B * c.N * 3; e += 1024) mx = fmaxf(mx, fabsf(pc_list[e]));
+    s_max[t] = mx;
+    __syncthreads();
+    for (int o = 512; o >= 1; o >>= 1) {
+        if (t < o) s_max[t] = fmaxf(s_max[t], s_max[t + o]);
+        __syncthreads();
+    }
+    if (t == 0) {
+        const double bound = (double)c.N * fmax((double)s_max[0], 1e-30);
+        fx_scale[0] = exp2(floor(61.0 - log2(bound)));
+    }
     if (t < c.B) {
         // flow pair f (complete frames f -> f+1) queries complete frame f (run_robot.py:196):
         // complete frame f is pc_trans[f] before the canonical index, the canonical cloud at it,
@@ -142,7 +159,8 @@ extern "C" int reart_relax_prepare(const reart_relax_config *cfg, const reart_re
     rc = reart_soa_launch(sa, p.Npad, cfg->B, 1, st);
     if (rc != REART_OK) return rc;
     hipLaunchKernelGGL(relax_init_kernel, dim3(1), dim3(1024), 0, st, *cfg, bufs->ref_off,
-                       (int *)(ws + p.o_rlen), (int *)(ws + p.o_qmap), bufs->iter, bufs->tau);
+                       (int *)(ws + p.o_rlen), (int *)(ws + p.o_qmap), bufs->iter, bufs->tau, bufs->pc_list,
+                       (double *)(ws + p.o_fx));
     if (cfg->use_flow)
         hipLaunchKernelGGL(ref_soa_kernel, dim3(reart_div_up(p.Mpad, 256), cfg->B), dim3(256), 0, st,
                            bufs->ref_loc, bufs->ref_off, p.Mpad, (float *)(ws + p.o_rsoa));
@@ -250,37 +268,35 @@ __global__ __launch_bounds__(FLOW_BS) void flow_blend_kernel(FlowArgs a) {
 // One workgroup per frame b: merge the slice partials of both directions, per-frame recon
 // loss (networks/loss.py:27-28), and G[b,i] = d(recon + lambda*flow)/d pc_trans[b,i]:
 //   2 (x_i - y_nn(i))  +  sum_{j: nn_yx(j) = i} 2 (x_i - y_j)  +  flow terms.
-// The second sum is a per-target gather over a counting sort of nn_yx (integer atomics
-// only), each bucket sorted ascending before accumulation: deterministic, no float atomics.
+// The scatter-add of the reference's knn_points_backward (utils/chamfer.py:206-208) becomes, per
+// target x_i, 2 (c_i x_i - sum_j y_j) with the sum of the observed points y_j accumulated in
+// 64-bit FIXED POINT by integer atomics: exact to 2^-scale, independent of the order in which
+// the sources arrive -> deterministic without sorting, O(N) even when every source picks the same
+// target.  (The stand-alone reart_knn_points_backward keeps the sorted, bit-reproducing gather.)
 struct CGradArgs {
     const float *X, *Y;                  // pc_trans, pc_list [B,N,3]
     const float *pd0; const int *pi0;    // x -> y partials [S][B][N]
     const float *pd1; const int *pi1;    // y -> x partials
     const float *gpf;                    // [B,N,3] or NULL (no flow)
-    int N, B, S, cano_idx, nbits;
+    const double *fx_scale;              // device scalar, power of two
+    int N, B, S, cano_idx, use_lds;
     float *G;                            // [B,N,3]
-    int *cint;                           // [B][5N] scratch: count | offset | nn_yx | sort ping | pong
+    long long *acc;                      // [B][N][4] global scratch (used when !use_lds)
     double *frame_loss;                  // [B]
 };
-#define CG_BS RS_BS
+#define CG_BS 1024
+#define CG_LDS_MAXN 4608                 // 32 B per point of dynamic LDS
 
-// LDSBUF: the five N-int arrays (count | offset | nn_yx | sort ping | pong) live in dynamic LDS
-// (N <= CG_LDS_MAXN) instead of the global scratch: the sort's dependent loads then cost an LDS
-// round trip (~100 cycles) instead of an L2 one (~500+).
-#define CG_LDS_MAXN 6400
-template <bool LDSBUF>
 __global__ __launch_bounds__(CG_BS) void chamfer_grad_kernel(CGradArgs a) {
-    extern __shared__ __attribute__((aligned(16))) int s_dyn[];
-    __shared__ int s_wave[RS_BS / 64];
+    extern __shared__ __attribute__((aligned(16))) long long s_acc[];
     __shared__ double s_red[CG_BS / REART_WAVE];
-    int *s_cnt = s_dyn;  // [RS_DIG * RS_BS]
     const int b = blockIdx.x, tid = threadIdx.x, N = a.N;
     const float *x = a.X + (size_t)b * N * 3, *y = a.Y + (size_t)b * N * 3;
     float *G = a.G + (size_t)b * N * 3;
-    int *cnt = LDSBUF ? s_dyn + RS_DIG * RS_BS : a.cint + (size_t)b * 5 * N;
-    int *off = cnt + N, *nn1 = off + N, *bufA = nn1 + N, *bufB = bufA + N;
-    for (int j = tid; j < N; j += CG_BS) cnt[j] = 0;
+    long long *acc = a.use_lds ? s_acc : a.acc + (size_t)b * N * 4;  // [N][4]: sx, sy, sz, count
+    for (int e = tid; e < 4 * N; e += CG_BS) acc[e] = 0;
     __syncthreads();
+    const double scale = a.fx_scale[0];
     double lsum = 0.0;
     for (int i = tid; i < N; i += CG_BS) {
         float d0 = INFINITY, d1 = INFINITY;
@@ -299,8 +315,12 @@ __global__ __launch_bounds__(CG_BS) void chamfer_grad_kernel(CGradArgs a) {
         G[3 * i] = 2.0f * (x[3 * i] - y[3 * j0]);
         G[3 * i + 1] = 2.0f * (x[3 * i + 1] - y[3 * j0 + 1]);
         G[3 * i + 2] = 2.0f * (x[3 * i + 2] - y[3 * j0 + 2]);
-        nn1[i] = j1;
-        atomicAdd(&cnt[j1], 1);  // integer atomics: order-independent result
+        // y_i chose x_{j1}: add y_i to that target's fixed-point sum
+        unsigned long long *t = (unsigned long long *)(acc + 4 * (size_t)j1);
+        atomicAdd(t + 0, (unsigned long long)llrint((double)y[3 * i] * scale));
+        atomicAdd(t + 1, (unsigned long long)llrint((double)y[3 * i + 1] * scale));
+        atomicAdd(t + 2, (unsigned long long)llrint((double)y[3 * i + 2] * scale));
+        atomicAdd(t + 3, 1ull);
     }
     lsum = reart_wave_sum_d(lsum);
     if ((tid & 63) == 0) s_red[tid >> 6] = lsum;
@@ -310,33 +330,22 @@ __global__ __launch_bounds__(CG_BS) void chamfer_grad_kernel(CGradArgs a) {
         for (int w = 0; w < CG_BS / REART_WAVE; ++w) t += s_red[w];
         a.frame_loss[b] = t;
     }
-    const int chunk = (N + CG_BS - 1) / CG_BS;
-    const int c0 = tid * chunk < N ? tid * chunk : N, c1 = (c0 + chunk < N) ? c0 + chunk : N;
-    int tot = 0;
-    for (int j = c0; j < c1; ++j) tot += cnt[j];
-    int run = block_excl_scan(tot, s_wave, nullptr);
-    for (int j = c0; j < c1; ++j) { off[j] = run; run += cnt[j]; }
-    // sources i stably sorted by their nearest x: bucket j = the y's that chose x_j, ascending i
-    const int *sorted = block_stable_sort_ids(N, a.nbits, bufA, bufB, s_cnt, s_wave,
-                                              [&](int i) { return nn1[i]; });
     // complete-sequence index of this frame and its two adjacent flow pairs
     const int fc = b < a.cano_idx ? b : b + 1;
     const float *g_head = (a.gpf && fc - 1 >= 0) ? a.gpf + (size_t)(fc - 1) * N * 3 : nullptr;
     const float *g_tail = (a.gpf && fc <= a.B - 1) ? a.gpf + (size_t)fc * N * 3 : nullptr;
+    const double inv = 1.0 / scale;
     for (int j = tid; j < N; j += CG_BS) {
-        const int o = off[j], c = cnt[j];
-        const float xj0 = x[3 * j], xj1 = x[3 * j + 1], xj2 = x[3 * j + 2];
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-        for (int u = 0; u < c; ++u) {
-            const int i = sorted[o + u];
-            a0 -= 2.0f * (y[3 * i] - xj0);
-            a1 -= 2.0f * (y[3 * i + 1] - xj1);
-            a2 -= 2.0f * (y[3 * i + 2] - xj2);
+        const double c = (double)acc[4 * (size_t)j + 3];
+        float g[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double sy = (double)acc[4 * (size_t)j + k] * inv;
+            g[k] = G[3 * j + k] + (float)(2.0 * (c * (double)x[3 * j + k] - sy));
+            if (g_head) g[k] += g_head[3 * j + k];
+            if (g_tail) g[k] -= g_tail[3 * j + k];
+            G[3 * j + k] = g[k];
         }
-        float g0 = G[3 * j] + a0, g1 = G[3 * j + 1] + a1, g2 = G[3 * j + 2] + a2;
-        if (g_head) { g0 += g_head[3 * j]; g1 += g_head[3 * j + 1]; g2 += g_head[3 * j + 2]; }
-        if (g_tail) { g0 -= g_tail[3 * j]; g1 -= g_tail[3 * j + 1]; g2 -= g_tail[3 * j + 2]; }
-        G[3 * j] = g0; G[3 * j + 1] = g1; G[3 * j + 2] = g2;
     }
 }
 
@@ -458,20 +467,21 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
     cg.pd0 = (const float *)(ws + p.o_pd0); cg.pi0 = (const int *)(ws + p.o_pi0);
     cg.pd1 = (const float *)(ws + p.o_pd1); cg.pi1 = (const int *)(ws + p.o_pi1);
     cg.gpf = c.use_flow ? (const float *)(ws + p.o_gpf) : nullptr;
-    cg.N = N; cg.B = B; cg.S = p.S1; cg.cano_idx = c.cano_idx; cg.nbits = reart_bits_for(N); cg.G = G;
-    cg.cint = (int *)(ws + p.o_cint); cg.frame_loss = (double *)(ws + p.o_floss);
-    if (N <= CG_LDS_MAXN) {
+    cg.N = N; cg.B = B; cg.S = p.S1; cg.cano_idx = c.cano_idx; cg.G = G;
+    cg.frame_loss = (double *)(ws + p.o_floss);
+    cg.fx_scale = (const double *)(ws + p.o_fx);
+    cg.acc = (long long *)(ws + p.o_cint);
+    cg.use_lds = N <= CG_LDS_MAXN;
+    {
         static bool attr_set = false;
         if (!attr_set) {
-            if (hipFuncSetAttribute((const void *)chamfer_grad_kernel<true>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)
+            if (hipFuncSetAttribute((const void *)chamfer_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    152 * 1024) != hipSuccess)
                 return REART_ERR_LAUNCH;
             attr_set = true;
         }
-        const size_t lds = sizeof(int) * ((size_t)RS_DIG * RS_BS + 5 * (size_t)N);
-        hipLaunchKernelGGL(chamfer_grad_kernel<true>, dim3(B), dim3(CG_BS), lds, st, cg);
-    } else {
-        hipLaunchKernelGGL(chamfer_grad_kernel<false>, dim3(B), dim3(CG_BS), sizeof(int) * RS_DIG * RS_BS, st, cg);
+        const size_t lds = cg.use_lds ? 32 * (size_t)N : 0;
+        hipLaunchKernelGGL(chamfer_grad_kernel, dim3(B), dim3(CG_BS), lds, st, cg);
     }
     REART_CHECK_LAUNCH();
     MARK(5);
