@@ -341,143 +341,150 @@ __global__ __launch_bounds__(256) void rt_table_kernel(const float *__restrict__
     for (int c = 0; c < 3; ++c) table[12 * (size_t)e + 9 + c] = pt[3 * (size_t)e + c];
 }
 
-// (1) One workgroup per chunk of 64 points (4 waves x the same points):
-//   a. wave g: dL/dw[n,p] = sum_t G[t,n].(R[t,p] x_n + t[t,p]) for its parts -- the [R|t] table
-//      is wave-uniform, read with scalar loads
-//   b. softmax backward -> ds[n,:] (LDS), wave g: hidden gradient dp[n,j] for its quarter of j
+// (1) One workgroup per chunk of 64 points, W = ceil(P/2) waves x the same points:
+//   a. wave g: dL/dw[n,p] = sum_t G[t,n].(R[t,p] x_n + t[t,p]) for parts {2g, 2g+1}; the [R|t]
+//      table is wave-uniform and read with scalar loads
+//   b. softmax backward -> ds[n,:] (LDS); wave g: hidden gradient dp[n,j] for its slice of j
 //   c. partial sums over the chunk of every parameter gradient, each output accumulated
 //      sequentially over the chunk's points (ascending n) -> deterministic:
 //        gW2[p,j] = sum_n ds[n,p] h[n,j];  gW1[j,c] = sum_n dp[n,j] x[n,c];  gb1[j] = sum_n dp[n,j]
 //        gR[t,p]  = sum_{n:k_n=p} w_n G[t,n] x_n^T;  gt[t,p] = sum_{n:k_n=p} w_n G[t,n]
-#define BW_BS 256
+//      For gR/gt the chunk's points are first ordered by part with a stable in-wave counting
+//      sort (ballot + popcount), so thread (t, entry) walks each part's points in ascending n
+//      with a register accumulator -- no LDS read-modify-write chain, no atomics.
 #define BW_LD (RED_CHUNK + 1)
 
 template <int PP>
-__global__ __launch_bounds__(BW_BS) void base_bwd_block_kernel(BaseBwdArgs a) {
+__global__ __launch_bounds__(64 * (((PP > 0 ? PP : 32) + FW_PG - 1) / FW_PG)) void base_bwd_block_kernel(BaseBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int PMAX = (PP > 0) ? PP : 32;
-    constexpr int PG = (PMAX + 3) / 4;
+    constexpr int W = (PMAX + FW_PG - 1) / FW_PG;
+    constexpr int BS = 64 * W;
     const int P = (PP > 0) ? PP : a.P;
     float *s_h = smem;                               // [H][BW_LD]  hT tile, later dp tile
-    float *s_ds = s_h + (size_t)a.H * BW_LD;         // [PMAX][BW_LD]
+    float *s_ds = s_h + (size_t)a.H * BW_LD;         // [PMAX][BW_LD]  dw, later ds
     float *s_x = s_ds + (size_t)PMAX * BW_LD;        // [RED_CHUNK][3]
     float *s_w = s_x + RED_CHUNK * 3;                // [RED_CHUNK]
-    int *s_k = (int *)(s_w + RED_CHUNK);             // [RED_CHUNK]
-    float *s_acc = (float *)(s_k + RED_CHUNK);       // [B*P*12]
-    float *s_G = s_acc + (size_t)a.B * a.P * 12;     // [B][RED_CHUNK*3]  upstream gradient tile
+    int *s_ord = (int *)(s_w + RED_CHUNK);           // [RED_CHUNK] chunk points ordered by part
+    int *s_seg = s_ord + RED_CHUNK;                  // [PMAX + 1] segment starts in s_ord
+    float *s_G = (float *)(s_seg + PMAX + 4);        // [B][RED_CHUNK*3]  upstream gradient tile
     float *s_w2T = s_G + (size_t)a.B * RED_CHUNK * 3;// [H][PMAX]
     const int tid = threadIdx.x, lane = tid & 63, grp = tid >> 6, chunk = blockIdx.x;
     const int n0 = chunk * RED_CHUNK;
     const int cn = (a.N - n0) < RED_CHUNK ? (a.N - n0) : RED_CHUNK;
     float *prow = a.partial + (size_t)chunk * n_out(a.P, a.H, a.B);
 
-    for (int e = tid; e < a.H * RED_CHUNK; e += BW_BS) {
-        const int j = e / RED_CHUNK, i = e % RED_CHUNK;
+    for (int e = tid; e < a.H * RED_CHUNK; e += BS) {
+        const int j = e >> 6, i = e & 63;            // RED_CHUNK == 64
         s_h[j * BW_LD + i] = (i < cn) ? a.hT[(size_t)j * a.N + n0 + i] : 0.f;
     }
-    for (int e = tid; e < a.B * a.P * 12; e += BW_BS) s_acc[e] = 0.f;
-    for (int e = tid; e < a.B * RED_CHUNK * 3; e += BW_BS) {
+    for (int e = tid; e < a.B * RED_CHUNK * 3; e += BS) {
         const int t = e / (RED_CHUNK * 3), r = e % (RED_CHUNK * 3);
         s_G[e] = (r < 3 * cn) ? a.G[3 * ((size_t)t * a.N + n0) + r] : 0.f;
     }
-    for (int e = tid; e < a.P * a.H; e += BW_BS) {
-        const int p = e / a.H, j = e % a.H;
-        s_w2T[j * PMAX + p] = a.W2[e];
-    }
+    for (int j = tid; j < a.H; j += BS)
+        for (int p = 0; p < P; ++p) s_w2T[j * PMAX + p] = a.W2[(size_t)p * a.H + j];
     const bool live = lane < cn;
     const int n = live ? n0 + lane : n0;
     const float x0 = a.cano[3 * (size_t)n], x1 = a.cano[3 * (size_t)n + 1], x2 = a.cano[3 * (size_t)n + 2];
-    const int kn = a.hard_idx[n];
     if (grp == 0) {
-        const float yk = a.yT[(size_t)kn * a.N + n];
-        s_k[lane] = live ? kn : -1;
+        const int kn = live ? a.hard_idx[n] : -1;
+        const float yk = a.yT[(size_t)(kn < 0 ? 0 : kn) * a.N + n];
         s_w[lane] = (1.0f - yk) + yk;
         s_x[3 * lane] = live ? x0 : 0.f; s_x[3 * lane + 1] = live ? x1 : 0.f; s_x[3 * lane + 2] = live ? x2 : 0.f;
+        // stable counting sort of the chunk's points by part
+        int base = 0;
+        for (int p = 0; p < P; ++p) {
+            const unsigned long long mk = __ballot(kn == p);
+            if (lane == 0) s_seg[p] = base;
+            if (kn == p) s_ord[base + __popcll(mk & ((1ull << lane) - 1ull))] = lane;
+            base += __popcll(mk);
+        }
+        if (lane == 0) s_seg[P] = base;
     }
-    // a. dw for this wave's parts
-    float dwp[PG];
-#pragma unroll
-    for (int q = 0; q < PG; ++q) dwp[q] = 0.f;
-    const int p0 = grp * PG;
+    // a. dw for this wave's two parts
+    float dw0 = 0.f, dw1 = 0.f;
+    const int p0 = grp * FW_PG;
+    const bool has0 = p0 < P, has1 = p0 + 1 < P;
     __syncthreads();
+    if (has0) {
 #pragma unroll 2
-    for (int t = 0; t < a.B; ++t) {
-        const float *g = s_G + t * (RED_CHUNK * 3) + 3 * lane;
-        const float gv[3] = {g[0], g[1], g[2]};
-#pragma unroll
-        for (int q = 0; q < PG; ++q)
-            if (p0 + q < P) {
-                float v[3];
-                apply_rt(a.rt_table + 12 * ((size_t)t * a.P + p0 + q), x0, x1, x2, v);
-                dwp[q] += dot3f(gv, v);
+        for (int t = 0; t < a.B; ++t) {
+            const float *g = s_G + t * (RED_CHUNK * 3) + 3 * lane;
+            const float gv[3] = {g[0], g[1], g[2]};
+            float v[3];
+            apply_rt(a.rt_table + 12 * ((size_t)t * a.P + p0), x0, x1, x2, v);
+            dw0 += dot3f(gv, v);
+            if (has1) {
+                apply_rt(a.rt_table + 12 * ((size_t)t * a.P + p0 + 1), x0, x1, x2, v);
+                dw1 += dot3f(gv, v);
             }
+        }
+        s_ds[p0 * BW_LD + lane] = dw0;
+        if (has1) s_ds[(p0 + 1) * BW_LD + lane] = dw1;
     }
-#pragma unroll
-    for (int q = 0; q < PG; ++q)
-        if (p0 + q < P) s_ds[(p0 + q) * BW_LD + lane] = dwp[q];
     __syncthreads();
-    // b. softmax backward (every wave redoes it for its lanes; wave 0 publishes ds)
+    // b. softmax backward: dot over all parts in ascending order, ds for this wave's parts
     const float tau = a.tau_ptr ? a.tau_ptr[0] : a.tau;
-    float ds[PMAX];
     float dot = 0.f;
 #pragma unroll
     for (int p = 0; p < PMAX; ++p)
         if (PP > 0 || p < P) dot = fmaf(a.yT[(size_t)p * a.N + n], s_ds[p * BW_LD + lane], dot);
-#pragma unroll
-    for (int p = 0; p < PMAX; ++p)
-        if (PP > 0 || p < P) {
-            const float y = a.yT[(size_t)p * a.N + n];  // second read hits L1
-            ds[p] = (y * (s_ds[p * BW_LD + lane] - dot)) / tau;
-        }
-    __syncthreads();  // all waves have read dw before it is overwritten by ds
-    if (grp == 0) {
-#pragma unroll
-        for (int p = 0; p < PMAX; ++p)
-            if (PP > 0 || p < P) s_ds[p * BW_LD + lane] = live ? ds[p] : 0.f;
-    }
-    // hidden gradient for this wave's quarter of the hidden units (kept in registers until the
-    // gW2 pass below has consumed the h tile)
-    const int jq = (a.H + 3) / 4, j0 = grp * jq, j1 = (j0 + jq < a.H) ? j0 + jq : a.H;
+    float ds0 = 0.f, ds1 = 0.f;
+    if (has0) ds0 = (a.yT[(size_t)p0 * a.N + n] * (dw0 - dot)) / tau;
+    if (has1) ds1 = (a.yT[(size_t)(p0 + 1) * a.N + n] * (dw1 - dot)) / tau;
+    __syncthreads();  // every wave has read dw before it is overwritten by ds
+    if (has0) s_ds[p0 * BW_LD + lane] = live ? ds0 : 0.f;
+    if (has1) s_ds[(p0 + 1) * BW_LD + lane] = live ? ds1 : 0.f;
     __syncthreads();
     // c1. gW2 partial from (ds, h)
-    for (int o = tid; o < a.P * a.H; o += BW_BS) {
-        const int p = o / a.H, j = o % a.H;
+    for (int o = tid; o < a.P * a.H; o += BS) {
+        const int p = o / a.H, j = o - p * a.H;
         float acc = 0.f;
+#pragma unroll 8
         for (int i = 0; i < RED_CHUNK; ++i) acc = fmaf(s_ds[p * BW_LD + i], s_h[j * BW_LD + i], acc);
         prow[off_gW2() + o] = acc;
     }
-    // c2. gR | gt: thread (t, c) walks the chunk, scattering into its own LDS column
-    for (int o = tid; o < a.B * 12; o += BW_BS) {
-        const int t = o / 12, c = o % 12;
-        for (int i = 0; i < cn; ++i) {
-            const int k = s_k[i];
-            const float *g = s_G + t * (RED_CHUNK * 3) + 3 * i;
-            float v;
-            if (c < 9) v = (s_w[i] * g[c / 3]) * s_x[3 * i + c % 3];
-            else v = s_w[i] * g[c - 9];
-            s_acc[(t * a.P + k) * 12 + c] += v;
+    // c2. gR | gt: thread (t, entry c) walks every part's points (ascending n) with a register
+    for (int o = tid; o < a.B * 12; o += BS) {
+        const int t = o / 12, c = o - t * 12;
+        const float *gt_ = s_G + t * (RED_CHUNK * 3);
+        for (int p = 0; p < P; ++p) {
+            float acc = 0.f;
+            for (int q = s_seg[p]; q < s_seg[p + 1]; ++q) {
+                const int i = s_ord[q];
+                if (c < 9) acc += (s_w[i] * gt_[3 * i + c / 3]) * s_x[3 * i + c % 3];
+                else acc += s_w[i] * gt_[3 * i + c - 9];
+            }
+            prow[off_gRt(a.P, a.H) + (t * a.P + p) * 12 + c] = acc;
         }
     }
-    __syncthreads();
-    for (int e = tid; e < a.B * a.P * 12; e += BW_BS) prow[off_gRt(a.P, a.H) + e] = s_acc[e];
+    // every lane needs all ds of its point for the hidden gradient
+    float dsr[PMAX];
+#pragma unroll
+    for (int p = 0; p < PMAX; ++p) dsr[p] = (PP > 0 || p < P) ? s_ds[p * BW_LD + lane] : 0.f;
+    __syncthreads();  // the h tile and ds have been consumed by c1
     // b'. dp[n,j] = relu'(h) * sum_p W2[p,j] ds[p], written over the h tile
+    const int jq = (a.H + W - 1) / W, j0 = grp * jq, j1 = (j0 + jq < a.H) ? j0 + jq : a.H;
     for (int j = j0; j < j1; ++j) {
         float dh = 0.f;
 #pragma unroll
         for (int p = 0; p < PMAX; ++p)
-            if (PP > 0 || p < P) dh = fmaf(s_w2T[j * PMAX + p], ds[p], dh);
+            if (PP > 0 || p < P) dh = fmaf(s_w2T[j * PMAX + p], dsr[p], dh);
         const float h = s_h[j * BW_LD + lane];
         s_h[j * BW_LD + lane] = (live && h > 0.f) ? dh : 0.f;
     }
     __syncthreads();
     // c3. gW1 / gb1 partial from (dp, x)
-    for (int o = tid; o < 4 * a.H; o += BW_BS) {
-        const int j = o / 4, c = o % 4;
+    for (int o = tid; o < 4 * a.H; o += BS) {
+        const int j = o >> 2, c = o & 3;
         float acc = 0.f;
         if (c < 3) {
+#pragma unroll 8
             for (int i = 0; i < RED_CHUNK; ++i) acc = fmaf(s_h[j * BW_LD + i], s_x[3 * i + c], acc);
             prow[off_gW1(a.P, a.H) + 3 * j + c] = acc;
         } else {
+#pragma unroll 8
             for (int i = 0; i < RED_CHUNK; ++i) acc += s_h[j * BW_LD + i];
             prow[off_gb1(a.P, a.H) + j] = acc;
         }
@@ -596,7 +603,8 @@ static int launch_bwd_block(const BaseBwdArgs &a, size_t lds, hipStream_t st) {
             return REART_ERR_LAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL((base_bwd_block_kernel<PP>), dim3(a.nchunk), dim3(BW_BS), lds, st, a);
+    constexpr int W = (((PP > 0) ? PP : 32) + FW_PG - 1) / FW_PG;
+    hipLaunchKernelGGL((base_bwd_block_kernel<PP>), dim3(a.nchunk), dim3(64 * W), lds, st, a);
     return REART_OK;
 }
 
@@ -617,7 +625,7 @@ int reart_base_backward_ex(BaseBwdArgs a, const FinalizeAdam *adam, void *worksp
         a.rt_table = table;
     }
     const int PMAX = (a.P == 20 || a.P == 10 || a.P == 8) ? a.P : 32;
-    const size_t lds = sizeof(float) * ((size_t)(a.H + PMAX) * BW_LD + RED_CHUNK * 5 + (size_t)a.B * a.P * 12 +
+    const size_t lds = sizeof(float) * ((size_t)(a.H + PMAX) * BW_LD + RED_CHUNK * 5 + PMAX + 4 +
                                         (size_t)a.B * RED_CHUNK * 3 + (size_t)a.H * PMAX);
     if (lds > 152 * 1024) return REART_ERR_UNSUPPORTED;
     int rc;

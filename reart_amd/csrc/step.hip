@@ -92,7 +92,7 @@ __device__ __forceinline__ float tau_schedule(long cur_iter, int n_iter, float e
 __global__ void relax_init_kernel(reart_relax_config c, const int *__restrict__ ref_off,
                                   int *__restrict__ rlen, int *__restrict__ qmap,
                                   int64_t *__restrict__ iter, float *__restrict__ tau,
-                                  const float *__restrict__ pc_list, double *__restrict__ fx_scale) {
+                                  const float *__restrict__ pc_list, int *__restrict__ fx_bits) {
     __shared__ float s_max[1024];
     const int t = threadIdx.x;
     // fixed-point scale for the exact (order-independent) sums of observed points in
@@ -106,8 +106,10 @@ __global__ void relax_init_kernel(reart_relax_config c, const int *__restrict__ 
         __syncthreads();
     }
     if (t == 0) {
+        // N * max|y| * 2^bits < 2^61, and bits <= 39 so that a 24-bit mantissa never overflows the shift
         const double bound = (double)c.N * fmax((double)s_max[0], 1e-30);
-        fx_scale[0] = exp2(floor(61.0 - log2(bound)));
+        int bits = (int)floor(61.0 - log2(bound));
+        fx_bits[0] = bits > 39 ? 39 : (bits < 0 ? 0 : bits);
     }
     if (t < c.B) {
         // flow pair f (complete frames f -> f+1) queries complete frame f (run_robot.py:196):
@@ -160,7 +162,7 @@ extern "C" int reart_relax_prepare(const reart_relax_config *cfg, const reart_re
     if (rc != REART_OK) return rc;
     hipLaunchKernelGGL(relax_init_kernel, dim3(1), dim3(1024), 0, st, *cfg, bufs->ref_off,
                        (int *)(ws + p.o_rlen), (int *)(ws + p.o_qmap), bufs->iter, bufs->tau, bufs->pc_list,
-                       (double *)(ws + p.o_fx));
+                       (int *)(ws + p.o_fx));
     if (cfg->use_flow)
         hipLaunchKernelGGL(ref_soa_kernel, dim3(reart_div_up(p.Mpad, 256), cfg->B), dim3(256), 0, st,
                            bufs->ref_loc, bufs->ref_off, p.Mpad, (float *)(ws + p.o_rsoa));
@@ -273,12 +275,24 @@ __global__ __launch_bounds__(FLOW_BS) void flow_blend_kernel(FlowArgs a) {
 // 64-bit FIXED POINT by integer atomics: exact to 2^-scale, independent of the order in which
 // the sources arrive -> deterministic without sorting, O(N) even when every source picks the same
 // target.  (The stand-alone reart_knn_points_backward keeps the sorted, bit-reproducing gather.)
+// float -> 64-bit fixed point with `sbits` fractional bits, by integer shifts of the mantissa
+// (gfx950 has no f64 -> i64 convert; llrint() is a long emulation).  Truncates toward zero below
+// 2^-sbits: deterministic, error < 2^-sbits per term.
+__device__ __forceinline__ long long fixed_from_float(float v, int sbits) {
+    const unsigned bits = __float_as_uint(v);
+    const int ex = (int)((bits >> 23) & 0xffu);
+    const long long mant = (long long)((bits & 0x7fffffu) | (ex ? 0x800000u : 0u));
+    const int sh = (ex ? ex : 1) - 150 + sbits;
+    const long long mag = sh >= 0 ? (sh < 40 ? (mant << sh) : 0x7fffffffffffffffll) : (sh > -64 ? (mant >> (-sh)) : 0ll);
+    return (bits >> 31) ? -mag : mag;
+}
+
 struct CGradArgs {
     const float *X, *Y;                  // pc_trans, pc_list [B,N,3]
     const float *pd0; const int *pi0;    // x -> y partials [S][B][N]
     const float *pd1; const int *pi1;    // y -> x partials
     const float *gpf;                    // [B,N,3] or NULL (no flow)
-    const double *fx_scale;              // device scalar, power of two
+    const int *fx_bits;                  // device scalar: fractional bits of the fixed-point sums
     int N, B, S, cano_idx, use_lds;
     float *G;                            // [B,N,3]
     long long *acc;                      // [B][N][4] global scratch (used when !use_lds)
@@ -296,7 +310,7 @@ __global__ __launch_bounds__(CG_BS) void chamfer_grad_kernel(CGradArgs a) {
     long long *acc = a.use_lds ? s_acc : a.acc + (size_t)b * N * 4;  // [N][4]: sx, sy, sz, count
     for (int e = tid; e < 4 * N; e += CG_BS) acc[e] = 0;
     __syncthreads();
-    const double scale = a.fx_scale[0];
+    const int sbits = a.fx_bits[0];
     double lsum = 0.0;
     for (int i = tid; i < N; i += CG_BS) {
         float d0 = INFINITY, d1 = INFINITY;
@@ -317,9 +331,9 @@ __global__ __launch_bounds__(CG_BS) void chamfer_grad_kernel(CGradArgs a) {
         G[3 * i + 2] = 2.0f * (x[3 * i + 2] - y[3 * j0 + 2]);
         // y_i chose x_{j1}: add y_i to that target's fixed-point sum
         unsigned long long *t = (unsigned long long *)(acc + 4 * (size_t)j1);
-        atomicAdd(t + 0, (unsigned long long)llrint((double)y[3 * i] * scale));
-        atomicAdd(t + 1, (unsigned long long)llrint((double)y[3 * i + 1] * scale));
-        atomicAdd(t + 2, (unsigned long long)llrint((double)y[3 * i + 2] * scale));
+        atomicAdd(t + 0, (unsigned long long)fixed_from_float(y[3 * i], sbits));
+        atomicAdd(t + 1, (unsigned long long)fixed_from_float(y[3 * i + 1], sbits));
+        atomicAdd(t + 2, (unsigned long long)fixed_from_float(y[3 * i + 2], sbits));
         atomicAdd(t + 3, 1ull);
     }
     lsum = reart_wave_sum_d(lsum);
@@ -334,7 +348,7 @@ __global__ __launch_bounds__(CG_BS) void chamfer_grad_kernel(CGradArgs a) {
     const int fc = b < a.cano_idx ? b : b + 1;
     const float *g_head = (a.gpf && fc - 1 >= 0) ? a.gpf + (size_t)(fc - 1) * N * 3 : nullptr;
     const float *g_tail = (a.gpf && fc <= a.B - 1) ? a.gpf + (size_t)fc * N * 3 : nullptr;
-    const double inv = 1.0 / scale;
+    const double inv = exp2((double)-sbits);
     for (int j = tid; j < N; j += CG_BS) {
         const double c = (double)acc[4 * (size_t)j + 3];
         float g[3];
@@ -469,7 +483,7 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
     cg.gpf = c.use_flow ? (const float *)(ws + p.o_gpf) : nullptr;
     cg.N = N; cg.B = B; cg.S = p.S1; cg.cano_idx = c.cano_idx; cg.G = G;
     cg.frame_loss = (double *)(ws + p.o_floss);
-    cg.fx_scale = (const double *)(ws + p.o_fx);
+    cg.fx_bits = (const int *)(ws + p.o_fx);
     cg.acc = (long long *)(ws + p.o_cint);
     cg.use_lds = N <= CG_LDS_MAXN;
     {
