@@ -190,6 +190,9 @@ typedef struct reart_relax_config {
     float start_tau, end_tau;/* --start_tau, --end_tau                                    */
     float fixed_tau;         /* > 0: frozen temperature (resume, run_robot.py:96-97)      */
     uint64_t seed;           /* Philox key of the Gumbel noise                            */
+    int use_grid;            /* 1: exact grid search for the static targets (pc_list, flow */
+                             /*    references); 0: brute force everywhere (same results)   */
+    int reserved;
 } reart_relax_config;
 
 typedef struct reart_relax_buffers {
@@ -309,6 +312,22 @@ size_t reart_three_interpolate_workspace_bytes(int B, int N, int S2);
 int reart_three_interpolate(const float *xyz1, const float *xyz2, const float *points2, int B,
                             int N, int S2, int D, float *out, int ldo, int col0,
                             void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------ */
+/* Exact K-NN against static target sets (uniform grid)                      */
+/* ------------------------------------------------------------------------ */
+
+/* Same result, bit for bit, as reart_knn_points_idx / reart_knn_cuda (same distance expression,
+ * ties -> lowest index) for K in {1, 3}, computed through a 16^3 uniform grid over each target
+ * set: ~30-50x fewer distance evaluations when the targets do not change between calls (the
+ * observed frames and the flow reference sets of the relaxation loop).  This entry builds the grid
+ * and queries it in one call; the fused step (reart_relax_prepare/step) builds once.
+ *   targets: [E,Nt_max,3] (offsets NULL) or ragged sets concatenated with offsets [E+1] i32;
+ *   queries [E,nq,3]; dists [E,nq,K] squared, ascending; idx [E,nq,K] i32.  Every set needs >= K points. */
+size_t reart_grid_knn_workspace_bytes(int E, int Nt_max);
+int reart_grid_knn(const float *targets, const int32_t *offsets, int E, int Nt_max,
+                   const float *queries, int nq, int K, float *dists, int32_t *idx,
+                   void *workspace, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

@@ -30,6 +30,13 @@ struct BaseBwdArgs {
     float tau;
     const float *G;             // [B,N,3]
     const float *rt_table;      // [B*P][12] or NULL (built into the workspace)
+    // fused step only: G holds the direct Chamfer term; the tile load adds the gathered term
+    // 2 (c_j x_j - sum y) from the fixed-point accumulators (and zeroes them) and the flow terms
+    long long *acc;             // [B][N][4] or NULL
+    const int *fx_bits;
+    const float *X;             // pc_trans [B,N,3]
+    const float *gpf;           // [B,N,3] d(lambda*flow)/d pred_flow or NULL
+    int cano_idx;
     int N, P, B, H;
     int nchunk;                 // ceil(N / RED_CHUNK)
     float *partial;             // [nchunk][n_out]
@@ -47,6 +54,7 @@ struct FinalizeAdam {
     float *m, *v;                     // moments, order W1|b1|W2|p6d|pt
     float seg_lr, trans_lr, beta1, beta2, eps;
     const int64_t *step_ptr;
+    const double *bias_corr;          // device [2]: 1 - beta1^step, sqrt(1 - beta2^step) of the coming step
 };
 
 int reart_base_backward_ex(BaseBwdArgs a, const FinalizeAdam *adam, void *workspace,
@@ -98,3 +106,33 @@ struct KnnArgs {
 int reart_knn_launch_slices(const KnnArgs &a, int KK, hipStream_t st);
 int reart_soa_launch(const SoaArgs &sa, int maxPpad, int N, int njobs, hipStream_t st);
 int reart_knn_pick_split(long waves, int P2, int K);
+
+// ---- exact grid search over static target sets (grid.hip) -----------------------------------
+struct GridBuildArgs {
+    const float *pts;         // AoS points; set e starts at pts + 3 * off(e)
+    const int *offsets;       // [E+1] prefix offsets (ragged) or NULL -> e * N
+    int N;                    // points per set when offsets == NULL; max set size otherwise
+    int stride;               // row stride of the sorted SoA arrays (>= max set size)
+    float *gx, *gy, *gz;      // [E][stride] coordinates sorted by cell
+    int *gorig;               // [E][stride] original index of each sorted point
+    int *cell_start;          // [E][GR_CELLS + 1]
+    float *meta;              // [E][GR_META]
+    int *scratch;             // [E][3 * stride] ints: cell id | sort ping | pong
+};
+
+struct GridQueryArgs {
+    const float *q;           // [E][nq][3] AoS queries
+    const float *q_alt;       // used where qmap[e] < 0
+    const int *qmap;          // nullable per-set query frame index
+    int nq, E, stride, euclid_unused;
+    const float *gx, *gy, *gz;
+    const int *gorig, *cell_start;
+    const float *meta;
+    float *od;                // [E][nq][KK] squared distances, ascending
+    int *oi;                  // [E][nq][KK] original indices
+};
+
+size_t reart_grid_bytes(int E, int stride);
+void reart_grid_layout(void *mem, int E, int stride, GridBuildArgs *b);
+int reart_grid_build_launch(const GridBuildArgs &b, int E, hipStream_t st);
+int reart_grid_query_launch(const GridQueryArgs &q, int K, hipStream_t st);

@@ -378,9 +378,40 @@ __global__ __launch_bounds__(64 * (((PP > 0 ? PP : 32) + FW_PG - 1) / FW_PG)) vo
         const int j = e >> 6, i = e & 63;            // RED_CHUNK == 64
         s_h[j * BW_LD + i] = (i < cn) ? a.hT[(size_t)j * a.N + n0 + i] : 0.f;
     }
-    for (int e = tid; e < a.B * RED_CHUNK * 3; e += BS) {
-        const int t = e / (RED_CHUNK * 3), r = e % (RED_CHUNK * 3);
-        s_G[e] = (r < 3 * cn) ? a.G[3 * ((size_t)t * a.N + n0) + r] : 0.f;
+    if (!a.acc) {
+        for (int e = tid; e < a.B * RED_CHUNK * 3; e += BS) {
+            const int t = e / (RED_CHUNK * 3), r = e % (RED_CHUNK * 3);
+            s_G[e] = (r < 3 * cn) ? a.G[3 * ((size_t)t * a.N + n0) + r] : 0.f;
+        }
+    } else {
+        // fused step: complete the upstream gradient on the fly.  G already holds 2 (x - y_nn(x));
+        // add the gathered term 2 (c x - sum of the y's that chose x) from the fixed-point
+        // accumulators (consumed and reset here) and the flow-loss terms of the two adjacent pairs.
+        const double inv = exp2((double)-a.fx_bits[0]);
+        for (int e = tid; e < a.B * RED_CHUNK; e += BS) {
+            const int t = e >> 6, i = e & 63;
+            float g[3] = {0.f, 0.f, 0.f};
+            if (i < cn) {
+                const size_t pt = (size_t)t * a.N + n0 + i;
+                long long *ac = a.acc + 4 * pt;
+                const double c = (double)ac[3];
+                const int fc = t < a.cano_idx ? t : t + 1;   // complete-sequence index of frame t
+                const float *gh = (a.gpf && fc - 1 >= 0) ? a.gpf + 3 * ((size_t)(fc - 1) * a.N + n0 + i) : nullptr;
+                const float *gl = (a.gpf && fc <= a.B - 1) ? a.gpf + 3 * ((size_t)fc * a.N + n0 + i) : nullptr;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const double sy = (double)ac[k] * inv;
+                    g[k] = a.G[3 * pt + k] + (float)(2.0 * (c * (double)a.X[3 * pt + k] - sy));
+                    if (gh) g[k] += gh[k];
+                    if (gl) g[k] -= gl[k];
+                    ac[k] = 0;
+                }
+                ac[3] = 0;
+            }
+            s_G[t * (RED_CHUNK * 3) + 3 * i] = g[0];
+            s_G[t * (RED_CHUNK * 3) + 3 * i + 1] = g[1];
+            s_G[t * (RED_CHUNK * 3) + 3 * i + 2] = g[2];
+        }
     }
     for (int j = tid; j < a.H; j += BS)
         for (int p = 0; p < P; ++p) s_w2T[j * PMAX + p] = a.W2[(size_t)p * a.H + j];
@@ -512,12 +543,11 @@ __global__ __launch_bounds__(256) void base_bwd_finalize_kernel(BaseBwdArgs a, F
     const int no = n_out(a.P, a.H, a.B);
     float ss_seg = 0.f, ss_tr = 0.f, bc2s = 1.f;
     if (ad.enabled) {
-        const int step = (int)ad.step_ptr[0] + 1;
-        const double bc1 = 1.0 - pow((double)ad.beta1, (double)step);
-        const double bc2 = 1.0 - pow((double)ad.beta2, (double)step);
+        // bias corrections of THIS step, written by the previous bookkeeping kernel / prepare
+        const double bc1 = ad.bias_corr[0];
         ss_seg = (float)((double)ad.seg_lr / bc1);
         ss_tr = (float)((double)ad.trans_lr / bc1);
-        bc2s = (float)sqrt(bc2);
+        bc2s = (float)ad.bias_corr[1];
     }
     if (o < nW) {
         float acc = 0.f;

@@ -20,6 +20,9 @@ struct StepPlan {
     size_t o_ysoa, o_xsoa, o_rsoa, o_rlen, o_qmap;
     size_t o_pd0, o_pi0, o_pd1, o_pi1, o_pd3, o_pi3;
     size_t o_yT, o_hT, o_hard, o_rt, o_G, o_gpf, o_cint, o_fx, o_floss, o_fpart, o_grads, o_bwd;
+    size_t o_bc;              // Adam bias corrections of the coming step (double[2])
+    size_t o_gridY, o_gridR;  // exact-search grids over pc_list and the flow reference sets
+    int gstrideY, gstrideR;
     size_t bwd_bytes, total;
 };
 
@@ -67,11 +70,16 @@ static int step_plan(const reart_relax_config *c, StepPlan *p) {
     p->o_gpf = take(off, sizeof(float) * 3 * BN);
     p->o_cint = take(off, 32 * BN);          // per point: 3 x int64 fixed-point sums + count (+pad)
     p->o_fx = take(off, sizeof(double));
-    p->o_floss = take(off, sizeof(double) * c->B);
+    p->o_floss = take(off, sizeof(double) * (size_t)c->B * reart_div_up(c->N, 256));
     p->o_fpart = take(off, sizeof(double) * (size_t)c->B * reart_div_up(c->N, FLOW_BS));
     p->o_grads = take(off, sizeof(float) * p->nparams);
     p->bwd_bytes = reart_base_backward_workspace_bytes(c->N, c->P, c->B, c->H);
     p->o_bwd = take(off, p->bwd_bytes);
+    p->o_bc = take(off, 2 * sizeof(double));
+    p->gstrideY = (int)reart_align_up((size_t)c->N, 64);
+    p->gstrideR = (int)reart_align_up((size_t)(c->M_max > 0 ? c->M_max : 1), 64);
+    p->o_gridY = take(off, c->use_grid ? reart_grid_bytes(c->B, p->gstrideY) : 0);
+    p->o_gridR = take(off, (c->use_grid && c->use_flow) ? reart_grid_bytes(c->B, p->gstrideR) : 0);
     p->total = off;
     return REART_OK;
 }
@@ -92,7 +100,8 @@ __device__ __forceinline__ float tau_schedule(long cur_iter, int n_iter, float e
 __global__ void relax_init_kernel(reart_relax_config c, const int *__restrict__ ref_off,
                                   int *__restrict__ rlen, int *__restrict__ qmap,
                                   int64_t *__restrict__ iter, float *__restrict__ tau,
-                                  const float *__restrict__ pc_list, int *__restrict__ fx_bits) {
+                                  const float *__restrict__ pc_list, int *__restrict__ fx_bits,
+                                  double *__restrict__ bias_corr) {
     __shared__ float s_max[1024];
     const int t = threadIdx.x;
     // fixed-point scale for the exact (order-independent) sums of observed points in
@@ -122,6 +131,8 @@ __global__ void relax_init_kernel(reart_relax_config c, const int *__restrict__ 
         // `iter` is caller state: it is NOT reset here, so a resumed run continues its schedule
         const long it = (long)iter[0];
         tau[0] = c.fixed_tau > 0.f ? c.fixed_tau : tau_schedule(it + 1, c.n_iter, c.end_tau, c.start_tau);
+        bias_corr[0] = 1.0 - pow((double)c.beta1, (double)(it + 1));
+        bias_corr[1] = sqrt(1.0 - pow((double)c.beta2, (double)(it + 1)));
     }
 }
 
@@ -162,7 +173,22 @@ extern "C" int reart_relax_prepare(const reart_relax_config *cfg, const reart_re
     if (rc != REART_OK) return rc;
     hipLaunchKernelGGL(relax_init_kernel, dim3(1), dim3(1024), 0, st, *cfg, bufs->ref_off,
                        (int *)(ws + p.o_rlen), (int *)(ws + p.o_qmap), bufs->iter, bufs->tau, bufs->pc_list,
-                       (int *)(ws + p.o_fx));
+                       (int *)(ws + p.o_fx), (double *)(ws + p.o_bc));
+    if (hipMemsetAsync(ws + p.o_cint, 0, 32 * (size_t)cfg->B * cfg->N, st) != hipSuccess) return REART_ERR_LAUNCH;
+    if (cfg->use_grid) {
+        GridBuildArgs gb = {};
+        reart_grid_layout(ws + p.o_gridY, cfg->B, p.gstrideY, &gb);
+        gb.pts = bufs->pc_list; gb.offsets = nullptr; gb.N = cfg->N;
+        rc = reart_grid_build_launch(gb, cfg->B, st);
+        if (rc != REART_OK) return rc;
+        if (cfg->use_flow) {
+            GridBuildArgs gr = {};
+            reart_grid_layout(ws + p.o_gridR, cfg->B, p.gstrideR, &gr);
+            gr.pts = bufs->ref_loc; gr.offsets = bufs->ref_off; gr.N = cfg->M_max;
+            rc = reart_grid_build_launch(gr, cfg->B, st);
+            if (rc != REART_OK) return rc;
+        }
+    }
     if (cfg->use_flow)
         hipLaunchKernelGGL(ref_soa_kernel, dim3(reart_div_up(p.Mpad, 256), cfg->B), dim3(256), 0, st,
                            bufs->ref_loc, bufs->ref_off, p.Mpad, (float *)(ws + p.o_rsoa));
@@ -291,91 +317,75 @@ struct CGradArgs {
     const float *X, *Y;                  // pc_trans, pc_list [B,N,3]
     const float *pd0; const int *pi0;    // x -> y partials [S][B][N]
     const float *pd1; const int *pi1;    // y -> x partials
-    const float *gpf;                    // [B,N,3] or NULL (no flow)
     const int *fx_bits;                  // device scalar: fractional bits of the fixed-point sums
-    int N, B, S, cano_idx, use_lds;
-    float *G;                            // [B,N,3]
-    long long *acc;                      // [B][N][4] global scratch (used when !use_lds)
-    double *frame_loss;                  // [B]
+    int N, B, S0, S1;                    // slices of the x->y / y->x partial lists
+    float *G;                            // [B,N,3]: receives the direct term 2 (x_i - y_nn(i))
+    long long *acc;                      // [B][N][4]: fixed-point sum of the y's that chose x_j, count
+    double *loss_part;                   // [B][gridDim.x]
 };
-#define CG_BS 1024
-#define CG_LDS_MAXN 4608                 // 32 B per point of dynamic LDS
+#define CG_BS 256
 
-__global__ __launch_bounds__(CG_BS) void chamfer_grad_kernel(CGradArgs a) {
-    extern __shared__ __attribute__((aligned(16))) long long s_acc[];
+// Fully parallel over (frame, point): merge, loss term, direct gradient term, and the
+// order-independent scatter of y_i into its nearest x's accumulator (global integer atomics).
+// The accumulators are consumed -- and reset to zero -- by the backward kernel's G-tile load
+// (model.hip), which adds 2 (c_j x_j - sum y) and the flow terms on the fly.
+__global__ __launch_bounds__(CG_BS) void chamfer_acc_kernel(CGradArgs a) {
     __shared__ double s_red[CG_BS / REART_WAVE];
-    const int b = blockIdx.x, tid = threadIdx.x, N = a.N;
-    const float *x = a.X + (size_t)b * N * 3, *y = a.Y + (size_t)b * N * 3;
-    float *G = a.G + (size_t)b * N * 3;
-    long long *acc = a.use_lds ? s_acc : a.acc + (size_t)b * N * 4;  // [N][4]: sx, sy, sz, count
-    for (int e = tid; e < 4 * N; e += CG_BS) acc[e] = 0;
-    __syncthreads();
-    const int sbits = a.fx_bits[0];
-    double lsum = 0.0;
-    for (int i = tid; i < N; i += CG_BS) {
+    const int b = blockIdx.y, tid = threadIdx.x, N = a.N;
+    const int i = blockIdx.x * CG_BS + tid;
+    double term = 0.0;
+    if (i < N) {
+        const float *x = a.X + (size_t)b * N * 3, *y = a.Y + (size_t)b * N * 3;
         float d0 = INFINITY, d1 = INFINITY;
         int j0 = 0, j1 = 0;
-        // all loads issued unconditionally (memory-level parallelism), then an ordered select
 #pragma unroll 4
-        for (int s = 0; s < a.S; ++s) {
+        for (int s = 0; s < a.S0; ++s) {
             const size_t o = ((size_t)s * a.B + b) * N + i;
-            const float e0 = a.pd0[o], e1 = a.pd1[o];
-            const int q0 = a.pi0[o], q1 = a.pi1[o];
-            const bool l0 = e0 < d0, l1 = e1 < d1;
+            const float e0 = a.pd0[o];
+            const int q0 = a.pi0[o];
+            const bool l0 = e0 < d0;
             d0 = l0 ? e0 : d0; j0 = l0 ? q0 : j0;
+        }
+#pragma unroll 4
+        for (int s = 0; s < a.S1; ++s) {
+            const size_t o = ((size_t)s * a.B + b) * N + i;
+            const float e1 = a.pd1[o];
+            const int q1 = a.pi1[o];
+            const bool l1 = e1 < d1;
             d1 = l1 ? e1 : d1; j1 = l1 ? q1 : j1;
         }
-        lsum += (double)(d0 + d1);  // chamfer_forward + chamfer_backward (utils/chamfer.py:119-123)
-        G[3 * i] = 2.0f * (x[3 * i] - y[3 * j0]);
-        G[3 * i + 1] = 2.0f * (x[3 * i + 1] - y[3 * j0 + 1]);
-        G[3 * i + 2] = 2.0f * (x[3 * i + 2] - y[3 * j0 + 2]);
-        // y_i chose x_{j1}: add y_i to that target's fixed-point sum
-        unsigned long long *t = (unsigned long long *)(acc + 4 * (size_t)j1);
-        atomicAdd(t + 0, (unsigned long long)fixed_from_float(y[3 * i], sbits));
-        atomicAdd(t + 1, (unsigned long long)fixed_from_float(y[3 * i + 1], sbits));
-        atomicAdd(t + 2, (unsigned long long)fixed_from_float(y[3 * i + 2], sbits));
+        term = (double)(d0 + d1);  // chamfer_forward + chamfer_backward (utils/chamfer.py:119-123)
+        const float yi0 = y[3 * i], yi1 = y[3 * i + 1], yi2 = y[3 * i + 2];
+        float *G = a.G + 3 * ((size_t)b * N + i);
+        G[0] = 2.0f * (x[3 * i] - y[3 * j0]);
+        G[1] = 2.0f * (x[3 * i + 1] - y[3 * j0 + 1]);
+        G[2] = 2.0f * (x[3 * i + 2] - y[3 * j0 + 2]);
+        const int sbits = a.fx_bits[0];
+        unsigned long long *t = (unsigned long long *)(a.acc + 4 * ((size_t)b * N + j1));
+        atomicAdd(t + 0, (unsigned long long)fixed_from_float(yi0, sbits));
+        atomicAdd(t + 1, (unsigned long long)fixed_from_float(yi1, sbits));
+        atomicAdd(t + 2, (unsigned long long)fixed_from_float(yi2, sbits));
         atomicAdd(t + 3, 1ull);
     }
-    lsum = reart_wave_sum_d(lsum);
-    if ((tid & 63) == 0) s_red[tid >> 6] = lsum;
+    term = reart_wave_sum_d(term);
+    if ((tid & 63) == 0) s_red[tid >> 6] = term;
     __syncthreads();
-    if (tid == 0) {
-        double t = 0.0;
-        for (int w = 0; w < CG_BS / REART_WAVE; ++w) t += s_red[w];
-        a.frame_loss[b] = t;
-    }
-    // complete-sequence index of this frame and its two adjacent flow pairs
-    const int fc = b < a.cano_idx ? b : b + 1;
-    const float *g_head = (a.gpf && fc - 1 >= 0) ? a.gpf + (size_t)(fc - 1) * N * 3 : nullptr;
-    const float *g_tail = (a.gpf && fc <= a.B - 1) ? a.gpf + (size_t)fc * N * 3 : nullptr;
-    const double inv = exp2((double)-sbits);
-    for (int j = tid; j < N; j += CG_BS) {
-        const double c = (double)acc[4 * (size_t)j + 3];
-        float g[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const double sy = (double)acc[4 * (size_t)j + k] * inv;
-            g[k] = G[3 * j + k] + (float)(2.0 * (c * (double)x[3 * j + k] - sy));
-            if (g_head) g[k] += g_head[3 * j + k];
-            if (g_tail) g[k] -= g_tail[3 * j + k];
-            G[3 * j + k] = g[k];
-        }
-    }
+    if (tid == 0) a.loss_part[(size_t)b * gridDim.x + blockIdx.x] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
 }
 
 // ------------------------------------------------------------------------------ bookkeeping
 // after the Adam launch: loss log, iteration counter, next temperature
 struct BookArgs {
     reart_relax_config c;
-    const double *frame_loss; const double *flow_part; int n_flow_part;
-    int64_t *iter; float *tau; float *losses;
+    const double *frame_loss; int n_frame_part; const double *flow_part; int n_flow_part;
+    int64_t *iter; float *tau; float *losses; double *bias_corr;
 };
 __global__ __launch_bounds__(256) void bookkeep_kernel(BookArgs a) {
     __shared__ double s_r[4], s_f[4];
     const int tid = threadIdx.x;
     // fixed assignment of terms to lanes + fixed-order tree: deterministic sums
     double recon = 0.0, flow = 0.0;
-    for (int b = tid; b < a.c.B; b += 256) recon += a.frame_loss[b];
+    for (int b = tid; b < a.n_frame_part; b += 256) recon += a.frame_loss[b];
     for (int i = tid; i < a.n_flow_part; i += 256) flow += a.flow_part[i];
     recon = reart_wave_sum_d(recon);
     flow = reart_wave_sum_d(flow);
@@ -390,6 +400,8 @@ __global__ __launch_bounds__(256) void bookkeep_kernel(BookArgs a) {
         row[0] = (float)recon; row[1] = (float)flow; row[2] = (float)(recon + flow); row[3] = a.tau[0];
     }
     a.iter[0] = it + 1;
+    a.bias_corr[0] = 1.0 - pow((double)a.c.beta1, (double)(it + 2));   // Adam step count of the next iteration
+    a.bias_corr[1] = sqrt(1.0 - pow((double)a.c.beta2, (double)(it + 2)));
     // iteration i (0-based) uses tau_cosine(i+1, ...) (run_robot.py:157)
     a.tau[0] = a.c.fixed_tau > 0.f ? a.c.fixed_tau
                                    : tau_schedule(it + 2, a.c.n_iter, a.c.end_tau, a.c.start_tau);
@@ -428,7 +440,9 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
     if (rc != REART_OK) return rc;
     MARK(1);
 
-    // 2. Chamfer, both directions in one launch (utils/chamfer.py:78-94)
+    // 2. Chamfer (utils/chamfer.py:78-94).  pc_list never changes: with use_grid the direction
+    // pc_trans -> pc_list goes through its pre-built exact grid, and only pc_list -> pc_trans (moving
+    // targets) is searched by brute force; without it both directions share one brute-force launch.
     KnnArgs ka = {};
     ka.N = B; ka.S = p.S1; ka.K = 1; ka.euclidean = 0;
     for (int j = 0; j < 2; ++j) {
@@ -439,8 +453,24 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
         kj.pd = (float *)(ws + (j == 0 ? p.o_pd0 : p.o_pd1));
         kj.pi = (int *)(ws + (j == 0 ? p.o_pi0 : p.o_pi1));
     }
-    ka.items0 = B * ka.job[0].nqg * p.S1;
-    ka.items = 2 * ka.items0;
+    int S0 = p.S1;
+    if (c.use_grid) {
+        GridBuildArgs gy = {};
+        reart_grid_layout(ws + p.o_gridY, B, p.gstrideY, &gy);
+        GridQueryArgs gq = {};
+        gq.q = bufs->pc_trans; gq.nq = N; gq.E = B; gq.stride = p.gstrideY; gq.gx = gy.gx; gq.gy = gy.gy; gq.gz = gy.gz;
+        gq.gorig = gy.gorig; gq.cell_start = gy.cell_start; gq.meta = gy.meta;
+        gq.od = (float *)(ws + p.o_pd0); gq.oi = (int *)(ws + p.o_pi0);
+        rc = reart_grid_query_launch(gq, 1, st);
+        if (rc != REART_OK) return rc;
+        S0 = 1;
+        ka.job[0] = ka.job[1];
+        ka.items0 = B * ka.job[0].nqg * p.S1;
+        ka.items = ka.items0;
+    } else {
+        ka.items0 = B * ka.job[0].nqg * p.S1;
+        ka.items = 2 * ka.items0;
+    }
     rc = reart_knn_launch_slices(ka, 1, st);
     if (rc != REART_OK) return rc;
     MARK(2);
@@ -448,23 +478,37 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
     // 3-4. flow: k=3 search of every complete frame in its reference set + blend + loss grad
     int nfp = 0;
     if (c.use_flow) {
-        KnnArgs k3 = {};
-        k3.N = B; k3.S = p.S3; k3.K = 3; k3.euclidean = 0;
-        KnnJob &kj = k3.job[0];
-        kj.q = bufs->pc_trans; kj.q_alt = bufs->cano; kj.qmap = (const int *)(ws + p.o_qmap);
-        kj.tsoa = (const float *)(ws + p.o_rsoa); kj.tlen = (const int *)(ws + p.o_rlen);
-        kj.P1 = N; kj.P2 = c.M_max; kj.Ppad = p.Mpad; kj.L = p.Mpad / p.S3; kj.nqg = reart_div_up(N, NN_BS);
-        kj.pd = (float *)(ws + p.o_pd3); kj.pi = (int *)(ws + p.o_pi3);
-        k3.job[1] = kj;
-        k3.items0 = B * kj.nqg * p.S3;
-        k3.items = k3.items0;
-        rc = reart_knn_launch_slices(k3, 3, st);
-        if (rc != REART_OK) return rc;
+        const int *qmap = (const int *)(ws + p.o_qmap);
+        int S3 = p.S3;
+        if (c.use_grid) {
+            GridBuildArgs gr = {};
+            reart_grid_layout(ws + p.o_gridR, B, p.gstrideR, &gr);
+            GridQueryArgs gq = {};
+            gq.q = bufs->pc_trans; gq.q_alt = bufs->cano; gq.qmap = qmap; gq.nq = N; gq.E = B; gq.stride = p.gstrideR;
+            gq.gx = gr.gx; gq.gy = gr.gy; gq.gz = gr.gz; gq.gorig = gr.gorig; gq.cell_start = gr.cell_start;
+            gq.meta = gr.meta; gq.od = (float *)(ws + p.o_pd3); gq.oi = (int *)(ws + p.o_pi3);
+            rc = reart_grid_query_launch(gq, 3, st);
+            if (rc != REART_OK) return rc;
+            S3 = 1;
+        } else {
+            KnnArgs k3 = {};
+            k3.N = B; k3.S = p.S3; k3.K = 3; k3.euclidean = 0;
+            KnnJob &kj = k3.job[0];
+            kj.q = bufs->pc_trans; kj.q_alt = bufs->cano; kj.qmap = qmap;
+            kj.tsoa = (const float *)(ws + p.o_rsoa); kj.tlen = (const int *)(ws + p.o_rlen);
+            kj.P1 = N; kj.P2 = c.M_max; kj.Ppad = p.Mpad; kj.L = p.Mpad / p.S3; kj.nqg = reart_div_up(N, NN_BS);
+            kj.pd = (float *)(ws + p.o_pd3); kj.pi = (int *)(ws + p.o_pi3);
+            k3.job[1] = kj;
+            k3.items0 = B * kj.nqg * p.S3;
+            k3.items = k3.items0;
+            rc = reart_knn_launch_slices(k3, 3, st);
+            if (rc != REART_OK) return rc;
+        }
         MARK(3);
         FlowArgs fl = {};
-        fl.pd = kj.pd; fl.pi = kj.pi; fl.ref_flow = bufs->ref_flow; fl.ref_off = bufs->ref_off;
-        fl.qmap = kj.qmap; fl.X = bufs->pc_trans; fl.cano = bufs->cano; fl.N = N; fl.B = B; fl.S = p.S3;
-        fl.euclidean = c.euclidean; fl.robust = c.robust; fl.cano_idx = c.cano_idx;
+        fl.pd = (const float *)(ws + p.o_pd3); fl.pi = (const int *)(ws + p.o_pi3); fl.ref_flow = bufs->ref_flow;
+        fl.ref_off = bufs->ref_off; fl.qmap = qmap; fl.X = bufs->pc_trans; fl.cano = bufs->cano; fl.N = N; fl.B = B;
+        fl.S = S3; fl.euclidean = c.euclidean; fl.robust = c.robust; fl.cano_idx = c.cano_idx;
         fl.smooth = c.smooth_weight; fl.lambda = c.lambda_flow;
         fl.gpf = (float *)(ws + p.o_gpf); fl.part = (double *)(ws + p.o_fpart);
         const dim3 fg(reart_div_up(N, FLOW_BS), B);
@@ -475,28 +519,17 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
     }
     MARK(4);
 
-    // 5. merge + recon loss + dL/d pc_trans
+    // 5. merge + recon loss + direct gradient term + fixed-point scatter (fully parallel)
     CGradArgs cg = {};
     cg.X = bufs->pc_trans; cg.Y = bufs->pc_list;
     cg.pd0 = (const float *)(ws + p.o_pd0); cg.pi0 = (const int *)(ws + p.o_pi0);
     cg.pd1 = (const float *)(ws + p.o_pd1); cg.pi1 = (const int *)(ws + p.o_pi1);
-    cg.gpf = c.use_flow ? (const float *)(ws + p.o_gpf) : nullptr;
-    cg.N = N; cg.B = B; cg.S = p.S1; cg.cano_idx = c.cano_idx; cg.G = G;
-    cg.frame_loss = (double *)(ws + p.o_floss);
     cg.fx_bits = (const int *)(ws + p.o_fx);
+    cg.N = N; cg.B = B; cg.S0 = S0; cg.S1 = p.S1; cg.G = G;
     cg.acc = (long long *)(ws + p.o_cint);
-    cg.use_lds = N <= CG_LDS_MAXN;
-    {
-        static bool attr_set = false;
-        if (!attr_set) {
-            if (hipFuncSetAttribute((const void *)chamfer_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    152 * 1024) != hipSuccess)
-                return REART_ERR_LAUNCH;
-            attr_set = true;
-        }
-        const size_t lds = cg.use_lds ? 32 * (size_t)N : 0;
-        hipLaunchKernelGGL(chamfer_grad_kernel, dim3(B), dim3(CG_BS), lds, st, cg);
-    }
+    cg.loss_part = (double *)(ws + p.o_floss);
+    const int ncg = reart_div_up(N, CG_BS);
+    hipLaunchKernelGGL(chamfer_acc_kernel, dim3(ncg, B), dim3(CG_BS), 0, st, cg);
     REART_CHECK_LAUNCH();
     MARK(5);
 
@@ -507,11 +540,14 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
     BaseBwdArgs ba = {};
     ba.cano = bufs->cano; ba.W2 = bufs->W2; ba.p6d = bufs->p6d; ba.pt = bufs->pt; ba.yT = fa.yT; ba.hT = fa.hT;
     ba.hard_idx = fa.hard_idx; ba.tau_ptr = bufs->tau; ba.tau = 1.0f; ba.G = G; ba.rt_table = fa.rt_table;
+    ba.acc = cg.acc; ba.fx_bits = cg.fx_bits; ba.X = bufs->pc_trans; ba.cano_idx = c.cano_idx;
+    ba.gpf = c.use_flow ? (const float *)(ws + p.o_gpf) : nullptr;
     ba.N = N; ba.P = P; ba.B = B; ba.H = H; ba.gW1 = gW1; ba.gb1 = gb1; ba.gW2 = gW2; ba.g6d = g6d; ba.gt = gt;
     FinalizeAdam ad = {};
     ad.enabled = 1; ad.W1 = bufs->W1; ad.b1 = bufs->b1; ad.W2 = bufs->W2; ad.p6d = bufs->p6d; ad.pt = bufs->pt;
     ad.m = bufs->adam_m; ad.v = bufs->adam_v; ad.seg_lr = c.seg_lr; ad.trans_lr = c.trans_lr;
     ad.beta1 = c.beta1; ad.beta2 = c.beta2; ad.eps = c.eps; ad.step_ptr = bufs->iter;
+    ad.bias_corr = (const double *)(ws + p.o_bc);
     rc = reart_base_backward_ex(ba, &ad, ws + p.o_bwd, p.bwd_bytes, st);
     if (rc != REART_OK) return rc;
     MARK(6);
@@ -519,8 +555,9 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
 
     // 10. loss log, iter++, next tau
     BookArgs bk = {};
-    bk.c = c; bk.frame_loss = (const double *)(ws + p.o_floss); bk.flow_part = (const double *)(ws + p.o_fpart);
+    bk.c = c; bk.frame_loss = (const double *)(ws + p.o_floss); bk.n_frame_part = B * ncg; bk.flow_part = (const double *)(ws + p.o_fpart);
     bk.n_flow_part = nfp; bk.iter = bufs->iter; bk.tau = bufs->tau; bk.losses = bufs->losses;
+    bk.bias_corr = (double *)(ws + p.o_bc);
     hipLaunchKernelGGL(bookkeep_kernel, dim3(1), dim3(256), 0, st, bk);
     REART_CHECK_LAUNCH();
     MARK(8);

@@ -15,7 +15,8 @@ class RelaxConfig(ctypes.Structure):
     _fields_ = [(n, c_int) for n in ("N", "P", "B", "H", "cano_idx", "use_flow", "robust", "euclidean", "flow_k",
                                      "M_max", "M_total", "n_iter", "ring")] + \
                [(n, c_float) for n in ("lambda_flow", "smooth_weight", "trans_lr", "seg_lr", "beta1", "beta2", "eps",
-                                       "start_tau", "end_tau", "fixed_tau")] + [("seed", ctypes.c_uint64)]
+                                       "start_tau", "end_tau", "fixed_tau")] + [("seed", ctypes.c_uint64),
+                                                                                 ("use_grid", c_int), ("reserved", c_int)]
 
 
 class RelaxBuffers(ctypes.Structure):
@@ -54,7 +55,7 @@ class RelaxEngine:
 
     def __init__(self, cano_pc, pc_list, model, cano_idx, pc_ref_list=None, flow_ref_list=None, n_iter=15000,
                  start_tau=5.0, end_tau=1.0, trans_lr=1e-2, seg_lr=1e-3, lambda_flow=1.0, use_robust_loss=False,
-                 smooth_weight=1e-2, fixed_tau=0.0, seed=2, ring=1024, knn_squared=False, start_iter=0):
+                 smooth_weight=1e-2, fixed_tau=0.0, seed=2, ring=1024, knn_squared=False, start_iter=0, use_grid=False):
         _lib.require_gpu(cano_pc, pc_list)
         dev = cano_pc.device
         self.device, self.model = dev, model
@@ -93,7 +94,8 @@ class RelaxEngine:
                                robust=int(bool(use_robust_loss)), euclidean=0 if knn_squared else 1, flow_k=3,
                                M_max=max(lens), M_total=sum(lens), n_iter=n_iter, ring=ring, lambda_flow=lambda_flow,
                                smooth_weight=smooth_weight, trans_lr=trans_lr, seg_lr=seg_lr, beta1=0.9, beta2=0.999,
-                               eps=1e-8, start_tau=start_tau, end_tau=end_tau, fixed_tau=fixed_tau, seed=seed)
+                               eps=1e-8, start_tau=start_tau, end_tau=end_tau, fixed_tau=fixed_tau, seed=seed,
+                               use_grid=int(bool(use_grid)), reserved=0)
         L = _lib_fns()
         nbytes = L.reart_relax_workspace_bytes(ctypes.byref(self.cfg))
         if nbytes == 0:
