@@ -211,6 +211,9 @@ typedef struct reart_relax_buffers {
     float *pc_trans;         /* [B,N,3] forward output of the last iteration              */
     int64_t *seg_part;       /* [N] or NULL                                               */
     float *trans_list;       /* [B,P,4,4] or NULL                                         */
+    /* optional fork/join: with all three set, the flow branch (K=3 search + blend) runs on      */
+    /* aux_stream concurrently with the Chamfer search; the hipEvent_t's are caller-owned.       */
+    void *aux_stream, *ev_fork, *ev_join;
 } reart_relax_buffers;
 
 size_t reart_relax_workspace_bytes(const reart_relax_config *cfg);
@@ -222,8 +225,8 @@ int reart_relax_step(const reart_relax_config *cfg, const reart_relax_buffers *b
                      void *workspace, size_t workspace_bytes, void *stream);
 /* measurement aid: the same sequence with hipEvents between phases on `stream`; synchronises
  * and ADDS per-phase milliseconds to the HOST array h_ms[REART_RELAX_PHASES]:
- * 0 forward, 1 Chamfer K=1 search, 2 flow K=3 search, 3 flow blend, 4 Chamfer merge+grad,
- * 5 model backward, 6 Adam, 7 bookkeeping. */
+ * 0 forward, 1 flow K=3 search, 2 flow blend, 3 Chamfer K=1 search, 4 Chamfer merge + gradient
+ * scatter, 5 model backward + Adam, 6 unused, 7 bookkeeping.  Always serial (no fork/join). */
 #define REART_RELAX_PHASES 8
 int reart_relax_step_timed(const reart_relax_config *cfg, const reart_relax_buffers *bufs,
                            void *workspace, size_t workspace_bytes, void *stream, float *h_ms);

@@ -440,6 +440,59 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
     if (rc != REART_OK) return rc;
     MARK(1);
 
+    // Fork: the flow branch depends only on the forward output, like the Chamfer search; with an
+    // auxiliary stream it runs concurrently (its latency-bound blend then hides under the search).
+    const bool forked = !ev && bufs->aux_stream && bufs->ev_fork && bufs->ev_join && c.use_flow;
+    hipStream_t fst = forked ? (hipStream_t)bufs->aux_stream : st;
+    if (forked) {
+        if (hipEventRecord((hipEvent_t)bufs->ev_fork, st) != hipSuccess) return REART_ERR_LAUNCH;
+        if (hipStreamWaitEvent(fst, (hipEvent_t)bufs->ev_fork, 0) != hipSuccess) return REART_ERR_LAUNCH;
+    }
+    // 3-4. flow: k=3 search of every complete frame in its reference set + blend + loss grad
+    int nfp = 0;
+    if (c.use_flow) {
+        const int *qmap = (const int *)(ws + p.o_qmap);
+        int S3 = p.S3;
+        if (c.use_grid) {
+            GridBuildArgs gr = {};
+            reart_grid_layout(ws + p.o_gridR, B, p.gstrideR, &gr);
+            GridQueryArgs gq = {};
+            gq.q = bufs->pc_trans; gq.q_alt = bufs->cano; gq.qmap = qmap; gq.nq = N; gq.E = B; gq.stride = p.gstrideR;
+            gq.gx = gr.gx; gq.gy = gr.gy; gq.gz = gr.gz; gq.gorig = gr.gorig; gq.cell_start = gr.cell_start;
+            gq.meta = gr.meta; gq.od = (float *)(ws + p.o_pd3); gq.oi = (int *)(ws + p.o_pi3);
+            rc = reart_grid_query_launch(gq, 3, fst);
+            if (rc != REART_OK) return rc;
+            S3 = 1;
+        } else {
+            KnnArgs k3 = {};
+            k3.N = B; k3.S = p.S3; k3.K = 3; k3.euclidean = 0;
+            KnnJob &kj = k3.job[0];
+            kj.q = bufs->pc_trans; kj.q_alt = bufs->cano; kj.qmap = qmap;
+            kj.tsoa = (const float *)(ws + p.o_rsoa); kj.tlen = (const int *)(ws + p.o_rlen);
+            kj.P1 = N; kj.P2 = c.M_max; kj.Ppad = p.Mpad; kj.L = p.Mpad / p.S3; kj.nqg = reart_div_up(N, NN_BS);
+            kj.pd = (float *)(ws + p.o_pd3); kj.pi = (int *)(ws + p.o_pi3);
+            k3.job[1] = kj;
+            k3.items0 = B * kj.nqg * p.S3;
+            k3.items = k3.items0;
+            rc = reart_knn_launch_slices(k3, 3, fst);
+            if (rc != REART_OK) return rc;
+        }
+        MARK(2);
+        FlowArgs fl = {};
+        fl.pd = (const float *)(ws + p.o_pd3); fl.pi = (const int *)(ws + p.o_pi3); fl.ref_flow = bufs->ref_flow;
+        fl.ref_off = bufs->ref_off; fl.qmap = qmap; fl.X = bufs->pc_trans; fl.cano = bufs->cano; fl.N = N; fl.B = B;
+        fl.S = S3; fl.euclidean = c.euclidean; fl.robust = c.robust; fl.cano_idx = c.cano_idx;
+        fl.smooth = c.smooth_weight; fl.lambda = c.lambda_flow;
+        fl.gpf = (float *)(ws + p.o_gpf); fl.part = (double *)(ws + p.o_fpart);
+        const dim3 fg(reart_div_up(N, FLOW_BS), B);
+        nfp = fg.x * fg.y;
+        hipLaunchKernelGGL(flow_blend_kernel, fg, dim3(FLOW_BS), 0, fst, fl);
+    }
+
+    if (forked && hipEventRecord((hipEvent_t)bufs->ev_join, fst) != hipSuccess) return REART_ERR_LAUNCH;
+    if (!c.use_flow) MARK(2);
+    MARK(3);
+
     // 2. Chamfer (utils/chamfer.py:78-94).  pc_list never changes: with use_grid the direction
     // pc_trans -> pc_list goes through its pre-built exact grid, and only pc_list -> pc_trans (moving
     // targets) is searched by brute force; without it both directions share one brute-force launch.
@@ -473,50 +526,7 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
     }
     rc = reart_knn_launch_slices(ka, 1, st);
     if (rc != REART_OK) return rc;
-    MARK(2);
 
-    // 3-4. flow: k=3 search of every complete frame in its reference set + blend + loss grad
-    int nfp = 0;
-    if (c.use_flow) {
-        const int *qmap = (const int *)(ws + p.o_qmap);
-        int S3 = p.S3;
-        if (c.use_grid) {
-            GridBuildArgs gr = {};
-            reart_grid_layout(ws + p.o_gridR, B, p.gstrideR, &gr);
-            GridQueryArgs gq = {};
-            gq.q = bufs->pc_trans; gq.q_alt = bufs->cano; gq.qmap = qmap; gq.nq = N; gq.E = B; gq.stride = p.gstrideR;
-            gq.gx = gr.gx; gq.gy = gr.gy; gq.gz = gr.gz; gq.gorig = gr.gorig; gq.cell_start = gr.cell_start;
-            gq.meta = gr.meta; gq.od = (float *)(ws + p.o_pd3); gq.oi = (int *)(ws + p.o_pi3);
-            rc = reart_grid_query_launch(gq, 3, st);
-            if (rc != REART_OK) return rc;
-            S3 = 1;
-        } else {
-            KnnArgs k3 = {};
-            k3.N = B; k3.S = p.S3; k3.K = 3; k3.euclidean = 0;
-            KnnJob &kj = k3.job[0];
-            kj.q = bufs->pc_trans; kj.q_alt = bufs->cano; kj.qmap = qmap;
-            kj.tsoa = (const float *)(ws + p.o_rsoa); kj.tlen = (const int *)(ws + p.o_rlen);
-            kj.P1 = N; kj.P2 = c.M_max; kj.Ppad = p.Mpad; kj.L = p.Mpad / p.S3; kj.nqg = reart_div_up(N, NN_BS);
-            kj.pd = (float *)(ws + p.o_pd3); kj.pi = (int *)(ws + p.o_pi3);
-            k3.job[1] = kj;
-            k3.items0 = B * kj.nqg * p.S3;
-            k3.items = k3.items0;
-            rc = reart_knn_launch_slices(k3, 3, st);
-            if (rc != REART_OK) return rc;
-        }
-        MARK(3);
-        FlowArgs fl = {};
-        fl.pd = (const float *)(ws + p.o_pd3); fl.pi = (const int *)(ws + p.o_pi3); fl.ref_flow = bufs->ref_flow;
-        fl.ref_off = bufs->ref_off; fl.qmap = qmap; fl.X = bufs->pc_trans; fl.cano = bufs->cano; fl.N = N; fl.B = B;
-        fl.S = S3; fl.euclidean = c.euclidean; fl.robust = c.robust; fl.cano_idx = c.cano_idx;
-        fl.smooth = c.smooth_weight; fl.lambda = c.lambda_flow;
-        fl.gpf = (float *)(ws + p.o_gpf); fl.part = (double *)(ws + p.o_fpart);
-        const dim3 fg(reart_div_up(N, FLOW_BS), B);
-        nfp = fg.x * fg.y;
-        hipLaunchKernelGGL(flow_blend_kernel, fg, dim3(FLOW_BS), 0, st, fl);
-    } else {
-        MARK(3);
-    }
     MARK(4);
 
     // 5. merge + recon loss + direct gradient term + fixed-point scatter (fully parallel)
@@ -533,6 +543,7 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
     REART_CHECK_LAUNCH();
     MARK(5);
 
+    if (forked && hipStreamWaitEvent(st, (hipEvent_t)bufs->ev_join, 0) != hipSuccess) return REART_ERR_LAUNCH;
     // 6-7. model backward; the finalize kernel also applies Adam with the reference's two
     // parameter groups (run_robot.py:146-148) to the parameter each thread just reduced
     float *grads = (float *)(ws + p.o_grads);
@@ -571,8 +582,8 @@ extern "C" int reart_relax_step(const reart_relax_config *cfg, const reart_relax
 
 // Same launch sequence with a hipEvent between phases, recorded on `stream`; synchronises the
 // stream and ADDS the per-phase milliseconds to h_ms[REART_RELAX_PHASES] (host memory).
-// Phases: 0 forward, 1 Chamfer K=1 search, 2 flow K=3 search, 3 flow blend, 4 Chamfer
-// merge+grad, 5 model backward (3 launches), 6 Adam, 7 bookkeeping.  Measurement aid for
+// Phases: 0 forward, 1 flow K=3 search, 2 flow blend, 3 Chamfer K=1 search, 4 Chamfer merge +
+// gradient scatter, 5 model backward + Adam (2 launches), 6 unused, 7 bookkeeping (always serial).  Measurement aid for
 // bench.py / profiling -- not graph-capturable.
 extern "C" int reart_relax_step_timed(const reart_relax_config *cfg, const reart_relax_buffers *bufs,
                                       void *workspace, size_t workspace_bytes, void *stream,

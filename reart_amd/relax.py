@@ -22,7 +22,7 @@ class RelaxConfig(ctypes.Structure):
 class RelaxBuffers(ctypes.Structure):
     _fields_ = [(n, c_void_p) for n in ("cano", "pc_list", "ref_loc", "ref_flow", "ref_off", "gumbel", "W1", "b1", "W2",
                                         "p6d", "pt", "adam_m", "adam_v", "iter", "tau", "losses", "pc_trans",
-                                        "seg_part", "trans_list")]
+                                        "seg_part", "trans_list", "aux_stream", "ev_fork", "ev_join")]
 
 
 _L = None
@@ -55,7 +55,8 @@ class RelaxEngine:
 
     def __init__(self, cano_pc, pc_list, model, cano_idx, pc_ref_list=None, flow_ref_list=None, n_iter=15000,
                  start_tau=5.0, end_tau=1.0, trans_lr=1e-2, seg_lr=1e-3, lambda_flow=1.0, use_robust_loss=False,
-                 smooth_weight=1e-2, fixed_tau=0.0, seed=2, ring=1024, knn_squared=False, start_iter=0, use_grid=False):
+                 smooth_weight=1e-2, fixed_tau=0.0, seed=2, ring=1024, knn_squared=False, start_iter=0, use_grid=False,
+                 overlap_flow=True):
         _lib.require_gpu(cano_pc, pc_list)
         dev = cano_pc.device
         self.device, self.model = dev, model
@@ -103,6 +104,13 @@ class RelaxEngine:
         self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         self._graph = None
         self._bufs = None
+        # fork/join resources for running the flow branch beside the Chamfer search (caller-owned)
+        self._aux = None
+        if use_flow and overlap_flow:
+            self._aux = torch.cuda.Stream(device=dev)
+            self._ev = (torch.cuda.Event(), torch.cuda.Event())
+            for ev in self._ev:
+                ev.record()  # materialise the hipEvent_t handles
         self._refresh_buffers()
         rc = L.reart_relax_prepare(ctypes.byref(self.cfg), ctypes.byref(self._bufs), _lib.ptr(self.workspace),
                                    self.workspace.numel(), _lib.stream())
@@ -116,7 +124,10 @@ class RelaxEngine:
                                   ref_flow=v(self.ref_flow), ref_off=v(self.ref_off), gumbel=v(self.gumbel),
                                   W1=v(W1), b1=v(b1), W2=v(W2), p6d=v(p6d), pt=v(pt), adam_m=v(self.adam_m),
                                   adam_v=v(self.adam_v), iter=v(self.iter), tau=v(self.tau), losses=v(self.losses),
-                                  pc_trans=v(self.pc_trans), seg_part=v(self.seg_part), trans_list=v(self.trans_list))
+                                  pc_trans=v(self.pc_trans), seg_part=v(self.seg_part), trans_list=v(self.trans_list),
+                                  aux_stream=None if self._aux is None else self._aux.cuda_stream,
+                                  ev_fork=None if self._aux is None else self._ev[0].cuda_event,
+                                  ev_join=None if self._aux is None else self._ev[1].cuda_event)
 
     def set_gumbel(self, noise):
         """Inject the Gumbel noise [N,P] used by every following step (tests); None = in-kernel Philox."""
@@ -150,7 +161,7 @@ class RelaxEngine:
             for _ in range(n):
                 self._enqueue()
 
-    PHASES = ("forward", "chamfer_nn", "flow_knn3", "flow_blend", "chamfer_grad", "backward", "adam", "bookkeep")
+    PHASES = ("forward", "flow_knn3", "flow_blend", "chamfer_nn", "chamfer_grad", "backward", "adam", "bookkeep")
 
     def step_timed(self, n=1):
         """Run n eager iterations with hipEvents between phases (on the launch stream); returns
