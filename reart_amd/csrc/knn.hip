@@ -96,7 +96,7 @@ __device__ __forceinline__ void knn_write_final(const KnnJob &jb, int b, int i, 
     }
 }
 
-template <int KK, bool FINAL>
+template <int KK, bool FINAL, bool BLK = false>
 __global__ __launch_bounds__(NN_BS) void knn_slice_kernel(KnnArgs a) {
     const int w = reart_xcd_remap(blockIdx.x, a.items);
     if (w < 0) return;
@@ -179,6 +179,10 @@ __global__ __launch_bounds__(NN_BS) void knn_slice_kernel(KnnArgs a) {
                 bb[s] = lt_prev ? bb[s > 0 ? s - 1 : 0] : (lt_cur ? j : bb[s]);
             }
         }
+        if (BLK) {  // fused step: the consumer merges the slices' blocks and rescans once per query
+#pragma unroll
+            for (int k = 0; k < KK; ++k) { kd[k] = bm[k]; ki[k] = bb[k]; }
+        } else
 #pragma unroll
         for (int c = 0; c < KK; ++c) {
             const int blk = bb[c];
@@ -306,7 +310,7 @@ int reart_knn_launch_slices(const KnnArgs &a, int KK, hipStream_t st) {
     const int grid = reart_xcd_grid(a.items);
     switch (KK) {
         case 1: hipLaunchKernelGGL((knn_slice_kernel<1, false>), dim3(grid), dim3(NN_BS), 0, st, a); break;
-        case 3: hipLaunchKernelGGL((knn_slice_kernel<3, false>), dim3(grid), dim3(NN_BS), 0, st, a); break;
+        case 3: hipLaunchKernelGGL((knn_slice_kernel<3, false, true>), dim3(grid), dim3(NN_BS), 0, st, a); break;
         default: return REART_ERR_UNSUPPORTED;
     }
     REART_CHECK_LAUNCH();

@@ -204,6 +204,8 @@ struct FlowArgs {
     const float *ref_flow; const int *ref_off; const int *qmap;
     const float *X; const float *cano;   // pc_trans [B,N,3], canonical cloud
     int N, B, S, euclidean, robust, cano_idx;
+    int blocks;                          // 1: the partial lists hold 8-target BLOCKS (minimum, first index)
+    const float *rsoa; int Mpad;         //    of the SoA reference image, to be rescanned here
     float smooth, lambda;
     float *gpf;                          // [B,N,3]
     double *part;                        // [B][gridDim.x]
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(FLOW_BS) void flow_blend_kernel(FlowArgs a) {
     double term = 0.0;
     if (n < a.N) {
         float kd[3] = {INFINITY, INFINITY, INFINITY};
-        int ki[3] = {0, 0, 0};
+        int ki[3] = {a.blocks ? -1 : 0, a.blocks ? -1 : 0, a.blocks ? -1 : 0};
         for (int s = 0; s < a.S; ++s) {
             const size_t o = (((size_t)s * a.B + f) * a.N + n) * 3;
 #pragma unroll
@@ -243,6 +245,36 @@ __global__ __launch_bounds__(FLOW_BS) void flow_blend_kernel(FlowArgs a) {
                         const bool lc = d < kd[q];
                         kd[q] = lp ? kd[q > 0 ? q - 1 : 0] : (lc ? d : kd[q]);
                         ki[q] = lp ? ki[q > 0 ? q - 1 : 0] : (lc ? j : ki[q]);
+                    }
+                }
+            }
+        }
+        const float *c0q = complete_frame(a, f) + 3 * (size_t)n;
+        if (a.blocks) {
+            // kd/ki are the 3 best blocks over all slices (by minimum, then index); the 3 nearest
+            // targets lie inside them: one exact rescan of 24 targets with the full (d, index) key
+            const float qx = c0q[0], qy = c0q[1], qz = c0q[2];
+            const float *tx = a.rsoa + (size_t)f * 3 * a.Mpad, *ty = tx + a.Mpad, *tz = ty + a.Mpad;
+            int bb[3] = {ki[0], ki[1], ki[2]};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { kd[k] = INFINITY; ki[k] = 0; }
+#pragma unroll
+            for (int cb = 0; cb < 3; ++cb) {
+                const int blk = bb[cb];
+                if (blk < 0) continue;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int jj = blk + u;
+                    const float d = reart_sqdist3(qx, qy, qz, tx[jj], ty[jj], tz[jj]);
+                    if (d < kd[2] || (d == kd[2] && d < INFINITY && jj < ki[2])) {
+#pragma unroll
+                        for (int q = 2; q >= 0; --q) {
+                            const int sp = q > 0 ? q - 1 : 0;
+                            const bool lp = (q > 0) && (d < kd[sp] || (d == kd[sp] && jj < ki[sp]));
+                            const bool lc = d < kd[q] || (d == kd[q] && jj < ki[q]);
+                            kd[q] = lp ? kd[sp] : (lc ? d : kd[q]);
+                            ki[q] = lp ? ki[sp] : (lc ? jj : ki[q]);
+                        }
                     }
                 }
             }
@@ -481,6 +513,7 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
         FlowArgs fl = {};
         fl.pd = (const float *)(ws + p.o_pd3); fl.pi = (const int *)(ws + p.o_pi3); fl.ref_flow = bufs->ref_flow;
         fl.ref_off = bufs->ref_off; fl.qmap = qmap; fl.X = bufs->pc_trans; fl.cano = bufs->cano; fl.N = N; fl.B = B;
+        fl.blocks = c.use_grid ? 0 : 1; fl.rsoa = (const float *)(ws + p.o_rsoa); fl.Mpad = p.Mpad;
         fl.S = S3; fl.euclidean = c.euclidean; fl.robust = c.robust; fl.cano_idx = c.cano_idx;
         fl.smooth = c.smooth_weight; fl.lambda = c.lambda_flow;
         fl.gpf = (float *)(ws + p.o_gpf); fl.part = (double *)(ws + p.o_fpart);
