@@ -192,7 +192,8 @@ typedef struct reart_relax_config {
     uint64_t seed;           /* Philox key of the Gumbel noise                            */
     int use_grid;            /* 1: exact grid search for the static targets (pc_list, flow */
                              /*    references); 0: brute force everywhere (same results)   */
-    int reserved;
+    int use_boxes;           /* 1: bounding-box block-skip test in the brute-force searches */
+                             /*    (exact; pays off when the clouds are stored in Morton order) */
 } reart_relax_config;
 
 typedef struct reart_relax_buffers {

@@ -20,6 +20,7 @@ struct BaseFwdArgs {
     float *hT;                  // [H,N] nullable
     int *hard_idx;              // [N] nullable
     float *rt_table;            // [B*P][12] nullable: [R|t] rows for the backward's scalar loads
+    float *boxes;               // [B][Npad/64][8] nullable: AABB of every 64 output points per frame
 };
 
 struct BaseBwdArgs {
@@ -89,6 +90,7 @@ struct KnnJob {
     const float *q_alt;    // fused step: query cloud used where qmap[b] < 0
     const int *qmap;       // nullable per-batch query frame index into q
     const int *tlen;       // nullable per-batch target count (ragged SoA rows, stride Ppad)
+    const float *boxes;    // nullable [N][Ppad/64][8]: AABB (lo xyz, hi xyz, pad) of every 64 targets
     int P1, P2, Ppad, L;   // Ppad = S*L, L % NN_UB == 0
     int nqg;               // ceil(P1/64)
     float *pd;             // partial dists [S][N][P1][KK]   (S > 1)
@@ -106,6 +108,8 @@ struct KnnArgs {
 int reart_knn_launch_slices(const KnnArgs &a, int KK, hipStream_t st);
 int reart_soa_launch(const SoaArgs &sa, int maxPpad, int N, int njobs, hipStream_t st);
 int reart_knn_pick_split(long waves, int P2, int K);
+#define NN_BOX 64   // targets per bounding box of the block-skip test
+int reart_boxes_launch(const float *soa, int N, int Ppad, float *boxes, hipStream_t st);
 
 // ---- exact grid search over static target sets (grid.hip) -----------------------------------
 struct GridBuildArgs {

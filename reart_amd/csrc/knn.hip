@@ -53,6 +53,53 @@ __global__ __launch_bounds__(256) void soa_kernel(SoaArgs a) {
 // Slice kernel
 // ---------------------------------------------------------------------------------
 
+// Block-skip test.  box = AABB (lo xyz, hi xyz) of 64 consecutive targets, read through the scalar
+// path (wave-uniform).  lb = ((ex*ex)+(ey*ey))+(ez*ez) with e = max(lo - q, q - hi, 0) per axis uses
+// the SAME operations as the distance itself, and fp32 rounding is monotone, so lb <= d for every
+// target inside the box: if lb > thr for all 64 lanes no target of the box can win or tie.
+// (Pays off when a wave's queries are spatially coherent, i.e. clouds stored in Morton order.)
+__device__ __forceinline__ bool box_skip(const float *box, float qx, float qy, float qz, float thr) {
+    const float ex = fmaxf(fmaxf(box[0] - qx, qx - box[3]), 0.f);
+    const float ey = fmaxf(fmaxf(box[1] - qy, qy - box[4]), 0.f);
+    const float ez = fmaxf(fmaxf(box[2] - qz, qz - box[5]), 0.f);
+    const float lb = (ex * ex + ey * ey) + ez * ez;
+    return !__any(lb <= thr);
+}
+
+// AABB of every 64 consecutive entries of a (+INF padded) SoA image [N][3][Ppad]; an all-padding
+// box is (+INF, +INF) and is always skipped.  One wave per box.
+__global__ __launch_bounds__(256) void box_kernel(const float *__restrict__ soa, int Ppad,
+                                                  float *__restrict__ boxes) {
+    const int lane = threadIdx.x & 63;
+    const int bxi = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
+    const int nbox = Ppad / NN_BOX;
+    if (bxi >= nbox) return;
+    const float *p = soa + (size_t)b * 3 * Ppad + (size_t)bxi * NN_BOX + lane;
+    float lo[3], hi[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float v = p[(size_t)c * Ppad];
+        lo[c] = v;
+        hi[c] = (v == INFINITY) ? -INFINITY : v;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            lo[c] = fminf(lo[c], __shfl_xor(lo[c], o, 64));
+            hi[c] = fmaxf(hi[c], __shfl_xor(hi[c], o, 64));
+        }
+        if (hi[c] == -INFINITY) hi[c] = INFINITY;
+    }
+    if (lane == 0) {
+        float *o = boxes + ((size_t)b * nbox + bxi) * 8;
+        o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = hi[0]; o[4] = hi[1]; o[5] = hi[2]; o[6] = 0.f; o[7] = 0.f;
+    }
+}
+
+int reart_boxes_launch(const float *soa, int N, int Ppad, float *boxes, hipStream_t st) {
+    hipLaunchKernelGGL(box_kernel, dim3(reart_div_up(Ppad / NN_BOX, 4), N), dim3(256), 0, st, soa, Ppad, boxes);
+    REART_CHECK_LAUNCH();
+    return REART_OK;
+}
+
 // insertion under the precondition d < kd[KK-1] (checked by the caller)
 template <int KK>
 __device__ __forceinline__ void knn_insert(float (&kd)[KK], int (&ki)[KK], float d, int j) {
@@ -119,7 +166,9 @@ __global__ __launch_bounds__(NN_BS) void knn_slice_kernel(KnnArgs a) {
     const float *ty = tx + jb.Ppad;
     const float *tz = ty + jb.Ppad;
     // ragged targets: per-batch slice length from the batch's own target count
-    const int Lb = jb.tlen ? (((jb.tlen[b] + a.S - 1) / a.S + NN_UB - 1) / NN_UB) * NN_UB : jb.L;
+    const int algn = jb.boxes ? NN_BOX : NN_UB;
+    const int Lb = jb.tlen ? (((jb.tlen[b] + a.S - 1) / a.S + algn - 1) / algn) * algn : jb.L;
+    const float *bx = jb.boxes ? jb.boxes + (size_t)b * (jb.Ppad / NN_BOX) * 8 : nullptr;
     const int j0 = s * Lb, j1 = j0 + Lb;
 
     float kd[KK];
@@ -129,7 +178,10 @@ __global__ __launch_bounds__(NN_BS) void knn_slice_kernel(KnnArgs a) {
 
     if (KK == 1) {
         int blk = j0;
-        for (int j = j0; j < j1; j += NN_UB) {
+        for (int jo = j0; jo < j1; jo += NN_BOX) {
+            if (bx && box_skip(bx + (jo / NN_BOX) * 8, qx, qy, qz, kd[0])) continue;
+            const int je = (jo + NN_BOX < j1) ? jo + NN_BOX : j1;
+        for (int j = jo; j < je; j += NN_UB) {
             float m = INFINITY;
 #pragma unroll
             for (int u = 0; u < NN_UB; u += 2) {
@@ -140,6 +192,7 @@ __global__ __launch_bounds__(NN_BS) void knn_slice_kernel(KnnArgs a) {
                 m = fminf(fminf(m, d.x), d.y);
             }
             if (m < kd[0]) { kd[0] = m; blk = j; }
+        }
         }
         // recover the exact (lowest) index inside the winning block
         int bi = blk;
@@ -160,7 +213,10 @@ __global__ __launch_bounds__(NN_BS) void knn_slice_kernel(KnnArgs a) {
         int bb[KK];
 #pragma unroll
         for (int k = 0; k < KK; ++k) { bm[k] = INFINITY; bb[k] = -1; }
-        for (int j = j0; j < j1; j += UBK) {
+        for (int jo = j0; jo < j1; jo += NN_BOX) {
+            if (bx && box_skip(bx + (jo / NN_BOX) * 8, qx, qy, qz, bm[KK - 1])) continue;
+            const int je = (jo + NN_BOX < j1) ? jo + NN_BOX : j1;
+        for (int j = jo; j < je; j += UBK) {
             float m = INFINITY;
 #pragma unroll
             for (int u = 0; u < UBK; u += 2) {
@@ -178,6 +234,7 @@ __global__ __launch_bounds__(NN_BS) void knn_slice_kernel(KnnArgs a) {
                 bm[s] = lt_prev ? bm[s > 0 ? s - 1 : 0] : (lt_cur ? m : bm[s]);
                 bb[s] = lt_prev ? bb[s > 0 ? s - 1 : 0] : (lt_cur ? j : bb[s]);
             }
+        }
         }
         if (BLK) {  // fused step: the consumer merges the slices' blocks and rescans once per query
 #pragma unroll
@@ -359,7 +416,7 @@ int reart_knn_run(int njobs, const float *const *q, const float *const *t,
         sa.job[j].Ppad = pl.Ppad[jj];
         KnnJob &kj = a.job[j];
         kj.q = q[jj];
-        kj.q_alt = nullptr; kj.qmap = nullptr; kj.tlen = nullptr;
+        kj.q_alt = nullptr; kj.qmap = nullptr; kj.tlen = nullptr; kj.boxes = nullptr;
         kj.tsoa = (const float *)(ws + pl.off_soa[jj]);
         kj.lenq = lenq ? lenq[jj] : nullptr;
         kj.lent = lent ? lent[jj] : nullptr;

@@ -21,6 +21,7 @@ struct StepPlan {
     size_t o_pd0, o_pi0, o_pd1, o_pi1, o_pd3, o_pi3;
     size_t o_yT, o_hT, o_hard, o_rt, o_G, o_gpf, o_cint, o_fx, o_floss, o_fpart, o_grads, o_bwd;
     size_t o_bc;              // Adam bias corrections of the coming step (double[2])
+    size_t o_boxY, o_boxX, o_boxR;  // AABBs of every 64 targets (block-skip test)
     size_t o_gridY, o_gridR;  // exact-search grids over pc_list and the flow reference sets
     int gstrideY, gstrideR;
     size_t bwd_bytes, total;
@@ -39,13 +40,13 @@ static int step_plan(const reart_relax_config *c, StepPlan *p) {
     if (c->use_flow && (c->flow_k != 3 || c->M_max < 3)) return REART_ERR_UNSUPPORTED;
     const long waves1 = 2L * c->B * reart_div_up(c->N, NN_BS);
     p->S1 = reart_knn_pick_split(waves1, c->N, 1);
-    p->L1 = (int)reart_align_up((size_t)reart_div_up(c->N, p->S1), NN_UB);
+    p->L1 = (int)reart_align_up((size_t)reart_div_up(c->N, p->S1), NN_BOX);
     p->Npad = p->L1 * p->S1;
     p->S3 = 1; p->Mpad = 0;
     if (c->use_flow) {
         const long waves3 = (long)c->B * reart_div_up(c->N, NN_BS);
         p->S3 = reart_knn_pick_split(waves3, c->M_max, 3);
-        p->Mpad = (int)reart_align_up((size_t)reart_div_up(c->M_max, p->S3), NN_UB) * p->S3;
+        p->Mpad = (int)reart_align_up((size_t)reart_div_up(c->M_max, p->S3), NN_BOX) * p->S3;
     }
     p->nchunk = reart_div_up(c->N, 64);
     p->nparams = 3 * c->H + c->H + c->P * c->H + 6 * c->B * c->P + 3 * c->B * c->P;
@@ -76,6 +77,9 @@ static int step_plan(const reart_relax_config *c, StepPlan *p) {
     p->bwd_bytes = reart_base_backward_workspace_bytes(c->N, c->P, c->B, c->H);
     p->o_bwd = take(off, p->bwd_bytes);
     p->o_bc = take(off, 2 * sizeof(double));
+    p->o_boxY = take(off, sizeof(float) * 8 * (size_t)c->B * (p->Npad / NN_BOX));
+    p->o_boxX = take(off, sizeof(float) * 8 * (size_t)c->B * (p->Npad / NN_BOX));
+    p->o_boxR = take(off, sizeof(float) * 8 * (size_t)c->B * (p->Mpad / NN_BOX + 1));
     p->gstrideY = (int)reart_align_up((size_t)c->N, 64);
     p->gstrideR = (int)reart_align_up((size_t)(c->M_max > 0 ? c->M_max : 1), 64);
     p->o_gridY = take(off, c->use_grid ? reart_grid_bytes(c->B, p->gstrideY) : 0);
@@ -175,6 +179,8 @@ extern "C" int reart_relax_prepare(const reart_relax_config *cfg, const reart_re
                        (int *)(ws + p.o_rlen), (int *)(ws + p.o_qmap), bufs->iter, bufs->tau, bufs->pc_list,
                        (int *)(ws + p.o_fx), (double *)(ws + p.o_bc));
     if (hipMemsetAsync(ws + p.o_cint, 0, 32 * (size_t)cfg->B * cfg->N, st) != hipSuccess) return REART_ERR_LAUNCH;
+    rc = reart_boxes_launch((const float *)(ws + p.o_ysoa), cfg->B, p.Npad, (float *)(ws + p.o_boxY), st);
+    if (rc != REART_OK) return rc;
     if (cfg->use_grid) {
         GridBuildArgs gb = {};
         reart_grid_layout(ws + p.o_gridY, cfg->B, p.gstrideY, &gb);
@@ -190,8 +196,12 @@ extern "C" int reart_relax_prepare(const reart_relax_config *cfg, const reart_re
         }
     }
     if (cfg->use_flow)
+    {
         hipLaunchKernelGGL(ref_soa_kernel, dim3(reart_div_up(p.Mpad, 256), cfg->B), dim3(256), 0, st,
                            bufs->ref_loc, bufs->ref_off, p.Mpad, (float *)(ws + p.o_rsoa));
+        rc = reart_boxes_launch((const float *)(ws + p.o_rsoa), cfg->B, p.Mpad, (float *)(ws + p.o_boxR), st);
+        if (rc != REART_OK) return rc;
+    }
     REART_CHECK_LAUNCH();
     return REART_OK;
 }
@@ -467,6 +477,7 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
     fa.trans_list = bufs->trans_list; fa.yT = (float *)(ws + p.o_yT); fa.hT = (float *)(ws + p.o_hT);
     fa.hard_idx = (int *)(ws + p.o_hard);
     fa.rt_table = (float *)(ws + p.o_rt);
+    fa.boxes = c.use_boxes ? (float *)(ws + p.o_boxX) : nullptr;
     MARK(0);
     rc = reart_base_forward_ex(fa, st);
     if (rc != REART_OK) return rc;
@@ -501,6 +512,7 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
             KnnJob &kj = k3.job[0];
             kj.q = bufs->pc_trans; kj.q_alt = bufs->cano; kj.qmap = qmap;
             kj.tsoa = (const float *)(ws + p.o_rsoa); kj.tlen = (const int *)(ws + p.o_rlen);
+            kj.boxes = c.use_boxes ? (const float *)(ws + p.o_boxR) : nullptr;
             kj.P1 = N; kj.P2 = c.M_max; kj.Ppad = p.Mpad; kj.L = p.Mpad / p.S3; kj.nqg = reart_div_up(N, NN_BS);
             kj.pd = (float *)(ws + p.o_pd3); kj.pi = (int *)(ws + p.o_pi3);
             k3.job[1] = kj;
@@ -538,6 +550,7 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
         kj.P1 = N; kj.P2 = N; kj.Ppad = p.Npad; kj.L = p.L1; kj.nqg = reart_div_up(N, NN_BS);
         kj.pd = (float *)(ws + (j == 0 ? p.o_pd0 : p.o_pd1));
         kj.pi = (int *)(ws + (j == 0 ? p.o_pi0 : p.o_pi1));
+        kj.boxes = c.use_boxes ? (const float *)(ws + (j == 0 ? p.o_boxY : p.o_boxX)) : nullptr;
     }
     int S0 = p.S1;
     if (c.use_grid) {

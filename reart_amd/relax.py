@@ -16,13 +16,32 @@ class RelaxConfig(ctypes.Structure):
                                      "M_max", "M_total", "n_iter", "ring")] + \
                [(n, c_float) for n in ("lambda_flow", "smooth_weight", "trans_lr", "seg_lr", "beta1", "beta2", "eps",
                                        "start_tau", "end_tau", "fixed_tau")] + [("seed", ctypes.c_uint64),
-                                                                                 ("use_grid", c_int), ("reserved", c_int)]
+                                                                                 ("use_grid", c_int), ("use_boxes", c_int)]
 
 
 class RelaxBuffers(ctypes.Structure):
     _fields_ = [(n, c_void_p) for n in ("cano", "pc_list", "ref_loc", "ref_flow", "ref_off", "gumbel", "W1", "b1", "W2",
                                         "p6d", "pt", "adam_m", "adam_v", "iter", "tau", "losses", "pc_trans",
                                         "seg_part", "trans_list", "aux_stream", "ev_fork", "ev_join")]
+
+
+def morton_order(points):
+    """Permutation that sorts a cloud [N,3] along a 30-bit Morton (Z-order) curve.  Setup-time
+    plumbing: waves of 64 consecutive points become spatially compact, which is what makes the
+    bounding-box block-skip test of the K-NN kernels effective.  Deterministic (stable sort)."""
+    p = points.detach().float()
+    lo, hi = p.min(dim=0).values, p.max(dim=0).values
+    q = ((p - lo) / (hi - lo).clamp_min(1e-20).max() * 1023.0).clamp(0, 1023).long()
+
+    def spread(v):  # 10 bits -> every third bit
+        v = (v | (v << 16)) & 0x030000FF
+        v = (v | (v << 8)) & 0x0300F00F
+        v = (v | (v << 4)) & 0x030C30C3
+        v = (v | (v << 2)) & 0x09249249
+        return v
+
+    code = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
+    return torch.sort(code, stable=True).indices
 
 
 _L = None
@@ -56,12 +75,25 @@ class RelaxEngine:
     def __init__(self, cano_pc, pc_list, model, cano_idx, pc_ref_list=None, flow_ref_list=None, n_iter=15000,
                  start_tau=5.0, end_tau=1.0, trans_lr=1e-2, seg_lr=1e-3, lambda_flow=1.0, use_robust_loss=False,
                  smooth_weight=1e-2, fixed_tau=0.0, seed=2, ring=1024, knn_squared=False, start_iter=0, use_grid=False,
-                 overlap_flow=True):
+                 overlap_flow=True, spatial_sort=True):
         _lib.require_gpu(cano_pc, pc_list)
         dev = cano_pc.device
         self.device, self.model = dev, model
-        self.cano = cano_pc.contiguous().float()
-        self.pc_list = pc_list.contiguous().float()
+        cano_pc, pc_list = cano_pc.float(), pc_list.float()
+        # Internal storage order: every cloud along its own Morton curve (results are returned in
+        # the caller's order; the optimisation problem is invariant to point order).
+        self._perm = morton_order(cano_pc) if spatial_sort else None
+        if spatial_sort:
+            cano_pc = cano_pc[self._perm]
+            pc_list = torch.stack([f[morton_order(f)] for f in pc_list])
+            if pc_ref_list is not None:
+                orders = [morton_order(r.reshape(-1, 3)) for r in pc_ref_list]
+                pc_ref_list = [r.reshape(-1, 3)[o] for r, o in zip(pc_ref_list, orders)]
+                flow_ref_list = [f.reshape(-1, 3)[o] for f, o in zip(flow_ref_list, orders)]
+            self._inv = torch.empty_like(self._perm)
+            self._inv[self._perm] = torch.arange(self._perm.numel(), device=dev)
+        self.cano = cano_pc.contiguous()
+        self.pc_list = pc_list.contiguous()
         B, N, _ = self.pc_list.shape
         c1, c2 = model.seg_head.model[0], model.seg_head.model[2]
         H, P = c1.weight.shape[0], c2.weight.shape[0]
@@ -75,8 +107,8 @@ class RelaxEngine:
         self.tau = torch.zeros(1, device=dev)
         self.ring = ring
         self.losses = torch.zeros((ring, 4), device=dev)
-        self.pc_trans = torch.empty((B, N, 3), device=dev)
-        self.seg_part = torch.empty((N,), dtype=torch.int64, device=dev)
+        self._pc_trans = torch.empty((B, N, 3), device=dev)
+        self._seg_part = torch.empty((N,), dtype=torch.int64, device=dev)
         self.trans_list = torch.empty((B, P, 4, 4), device=dev)
         self.gumbel = None
         use_flow = pc_ref_list is not None
@@ -96,7 +128,7 @@ class RelaxEngine:
                                M_max=max(lens), M_total=sum(lens), n_iter=n_iter, ring=ring, lambda_flow=lambda_flow,
                                smooth_weight=smooth_weight, trans_lr=trans_lr, seg_lr=seg_lr, beta1=0.9, beta2=0.999,
                                eps=1e-8, start_tau=start_tau, end_tau=end_tau, fixed_tau=fixed_tau, seed=seed,
-                               use_grid=int(bool(use_grid)), reserved=0)
+                               use_grid=int(bool(use_grid)), use_boxes=int(bool(spatial_sort)))
         L = _lib_fns()
         nbytes = L.reart_relax_workspace_bytes(ctypes.byref(self.cfg))
         if nbytes == 0:
@@ -124,14 +156,26 @@ class RelaxEngine:
                                   ref_flow=v(self.ref_flow), ref_off=v(self.ref_off), gumbel=v(self.gumbel),
                                   W1=v(W1), b1=v(b1), W2=v(W2), p6d=v(p6d), pt=v(pt), adam_m=v(self.adam_m),
                                   adam_v=v(self.adam_v), iter=v(self.iter), tau=v(self.tau), losses=v(self.losses),
-                                  pc_trans=v(self.pc_trans), seg_part=v(self.seg_part), trans_list=v(self.trans_list),
+                                  pc_trans=v(self._pc_trans), seg_part=v(self._seg_part), trans_list=v(self.trans_list),
                                   aux_stream=None if self._aux is None else self._aux.cuda_stream,
                                   ev_fork=None if self._aux is None else self._ev[0].cuda_event,
                                   ev_join=None if self._aux is None else self._ev[1].cuda_event)
 
+    @property
+    def pc_trans(self):
+        """[T-1,N,3] forward output of the last iteration, in the caller's point order."""
+        return self._pc_trans if self._perm is None else self._pc_trans[:, self._inv]
+
+    @property
+    def seg_part(self):
+        """[N] arg-max part of the noise-free logits (last iteration), in the caller's point order."""
+        return self._seg_part if self._perm is None else self._seg_part[self._inv]
+
     def set_gumbel(self, noise):
         """Inject the Gumbel noise [N,P] used by every following step (tests); None = in-kernel Philox."""
         assert self._graph is None, "noise injection is an eager-mode (test) feature"
+        if noise is not None and self._perm is not None:
+            noise = noise[self._perm]
         self.gumbel = None if noise is None else noise.contiguous().float()
         self._refresh_buffers()
 
