@@ -28,7 +28,7 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 vector peak (counts FMA as 2)
 
 
-def build_instance(dev, T, N, cano_idx, seed, use_flow=True, n_iter=15000, use_grid=False):
+def build_instance(dev, T, N, cano_idx, seed, use_flow=True, n_iter=15000, use_grid=False, overlap=True):
     from reart_amd.networks.model import BaseModel
     from reart_amd.relax import RelaxEngine
     from reart_amd.synthetic import make_sequence, split_canonical
@@ -40,7 +40,8 @@ def build_instance(dev, T, N, cano_idx, seed, use_flow=True, n_iter=15000, use_g
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     refs = [t(r) for r in seq["ref_loc"]] if use_flow else None
     flows = [t(f) for f in seq["ref_flow"]] if use_flow else None
-    eng = RelaxEngine(t(cano), t(pcs), model, cano_idx, refs, flows, n_iter=n_iter, seed=seed, use_grid=use_grid)
+    eng = RelaxEngine(t(cano), t(pcs), model, cano_idx, refs, flows, n_iter=n_iter, seed=seed, use_grid=use_grid,
+                      overlap_flow=overlap)
     return eng, seq, model
 
 
@@ -82,6 +83,7 @@ def main():
     ap.add_argument("--points", type=int, default=4096)
     ap.add_argument("--no-flow", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="run the flow branch serially (profiling: isolated kernel durations)")
     ap.add_argument("--grid", action="store_true", help="exact grid search for the static targets (same results; slower at this size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=20, help="eager steps timed per phase with HIP events")
@@ -104,7 +106,8 @@ def main():
     # independent instances: rank r optimises canonical index (T//2 + r) % T (README: the
     # canonical frame is selected by the lowest final energy -> sweep over cano_idx)
     cano_idx = (T // 2 + rank) % T
-    eng, seq, model = build_instance(dev, T, N, cano_idx, seed=2 + rank, use_flow=use_flow, use_grid=args.grid)
+    eng, seq, model = build_instance(dev, T, N, cano_idx, seed=2 + rank, use_flow=use_flow, use_grid=args.grid,
+                                      overlap=not args.no_overlap)
     used = 0
     if not args.no_graph:
         used = eng.capture()
@@ -154,7 +157,8 @@ def main():
                     "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": traffic,
                     "kernel": "knn_slice_kernel<1,false> (Chamfer K=1 search, both directions)",
                     "kernel_ms": round(phases["chamfer_nn"], 5), "algorithmic_bytes": nn_bytes,
-                    "note": "kernel is fp32-VALU bound by construction (910 flop/B); see `valu`",
+                    "note": "kernel is fp32-VALU bound by construction (910 flop/B); see `valu`. kernel_ms: HIP events "
+                            "on the launch stream over eager, serial (no fork/join) steps after the timed region",
                     "valu": {"achieved": round(nn_flops / t_nn / 1e12, 3), "peak": FP32_PEAK_TFLOPS,
                              "unit": "TFLOP/s", "frac": round(nn_flops / t_nn / 1e12 / FP32_PEAK_TFLOPS, 4),
                              "flops": nn_flops}}
@@ -178,7 +182,7 @@ def main():
                                    + ("+flow loss (k=3 blend, 3000 refs/pair)" if use_flow else " only")
                                    + ", full iteration fwd+loss+bwd+Adam, one instance per GPU",
                        "frames": T, "points": N, "parts": 20, "flow": use_flow,
-                       "graph": not args.no_graph, "grid_search_static_targets": args.grid, "parallelism": f"instances x{world}"},
+                       "graph": not args.no_graph, "grid_search_static_targets": args.grid, "flow_branch_overlap": not args.no_overlap, "parallelism": f"instances x{world}"},
             "roofline": roof,
             "cpu_baseline": cpu,
             "phases_ms": {k: round(v, 5) for k, v in phases.items()},
