@@ -333,6 +333,20 @@ int reart_grid_knn(const float *targets, const int32_t *offsets, int E, int Nt_m
                    const float *queries, int nq, int K, float *dists, int32_t *idx,
                    void *workspace, size_t workspace_bytes, void *stream);
 
+/* ------------------------------------------------------------------------ */
+/* Correspondence matching on the extractor's descriptors                    */
+/* ------------------------------------------------------------------------ */
+
+/* Replaces match_smnn(desc1, desc2, th=0.9) (utils/flow_utils.py:48-100; called once per frame pair
+ * by compute_corr_list_filter :116-143): nearest / second-nearest descriptor ratio test in both
+ * directions and the mutual filter, without the [N1,N2] distance matrix.
+ *   desc1 [E,N1,64], desc2 [E,N2,64] (point-major rows);  keep [E,N1] u8 = 1 where point i of desc1
+ *   has a mutual match; tgt [E,N1] i64 = its nearest descriptor in desc2 (valid where keep).
+ *   The matches of pair e, sorted by source index, are {(i, tgt[e,i]) : keep[e,i]}. */
+size_t reart_match_smnn_workspace_bytes(int E, int N1, int N2);
+int reart_match_smnn(const float *desc1, const float *desc2, int E, int N1, int N2, int D, float th,
+                     uint8_t *keep, int64_t *tgt, void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,267 @@
+#!/usr/bin/env python3
+"""Drop-in counterpart of the reference's ``run_robot.py`` optimisation loop (``:154-221``) on the
+HIP path: same command-line flags and defaults (``run_robot.py:362-420``), same checkpoint keys
+(``:340-356``), same loss branches.
+
+What is built: the loop itself.
+  * ``--model base`` without assignment loss (the first ``--assign_iter`` iterations of every run,
+    and whole runs without ``--use_assign_loss``): the fused ``RelaxEngine`` -- eight kernel launches
+    per iteration replayed from a graph, no host sync inside the loop.
+  * everything else (assignment loss, ``--model kinematic``): the reference's own loop structure with
+    the HIP operators underneath (``BaseModel`` / ``KinematicModel``, ``ChamferDistance``,
+    ``blend_anchor_motion``, ``flow_loss``, FPS) and ``torch.optim.Adam``; the Hungarian step stays on
+    the host exactly like the reference (``run_robot.py:172-176``; SURVEY.md 8f-2 "next").
+What is NOT built (SURVEY.md section 8 out of scope): visualisation, GT-graph evaluation, structure
+extraction (merging / MST / ik) and ``result.txt``; a snapshot prints the losses and the Chamfer error.
+
+Data: ``--seq_path`` with the reference's pickle layout (``dataset/dataset_robot.py``), or
+``--synthetic`` for the generated articulated sequence of ``reart_amd/synthetic.py``.
+"""
+import argparse
+import functools
+import glob
+import os
+import pickle
+import random
+
+import numpy as np
+import torch
+
+from reart_amd.knn_cuda import KNN
+from reart_amd.networks.loss import flow_loss, recon_loss
+from reart_amd.networks.model import BaseModel, KinematicModel
+from reart_amd.networks.pointnet2_utils import farthest_point_sample, index_points
+from reart_amd.relax import RelaxEngine
+from reart_amd.utils.chamfer import ChamferDistance
+from reart_amd.utils.flow_utils import blend_anchor_motion
+from reart_amd.utils.model_utils import tau_cosine
+
+
+def load_sequence(seq_path, num_points, cano_idx):
+    """Restates dataset/dataset_robot.py:9-100 for what the loop needs (clouds only):
+    state_0.pkl plus one state_i.pkl per pose_i.pkl, each a (points [n,3], part ids [n]) pair."""
+    pose_files = sorted(glob.glob(os.path.join(seq_path, "pose_*.pkl")),
+                        key=lambda f: int(os.path.basename(f).split(".")[0].split("_")[-1]))
+    ids = [0] + [int(os.path.basename(f).split(".")[0].split("_")[-1]) for f in pose_files]
+    clouds, parts = [], []
+    for i in ids:
+        with open(os.path.join(seq_path, f"state_{i}.pkl"), "rb") as f:
+            state = pickle.load(f)
+        pc, part = (state["pc"], state["part"]) if isinstance(state, dict) else state[:2]
+        clouds.append(np.asarray(pc)[:num_points])
+        parts.append(np.asarray(part)[:num_points])
+    complete = np.stack(clouds).astype("float32")
+    cano = complete[cano_idx]
+    pc_list = np.concatenate([complete[:cano_idx], complete[cano_idx + 1:]], axis=0)
+    return dict(cano_pc=cano, pc_list=pc_list, complete_pc_list=complete, gt_cano_part=parts[cano_idx])
+
+
+def synthetic_sequence(num_points, cano_idx, frames, with_flow):
+    from reart_amd.synthetic import make_sequence, split_canonical
+
+    seq = make_sequence(T=frames, n_parts=8, pts_per_part=num_points // 8, seed=2, with_flow=with_flow)
+    cano, pc_list = split_canonical(seq["complete"], cano_idx)
+    out = dict(cano_pc=cano, pc_list=pc_list, complete_pc_list=seq["complete"], gt_cano_part=seq["part"])
+    if with_flow:
+        out.update(ref_loc=seq["ref_loc"], ref_flow=seq["ref_flow"])
+    return out
+
+
+def main(args):
+    torch.cuda.manual_seed_all(args.manual_seed)
+    torch.manual_seed(args.manual_seed)
+    np.random.seed(args.manual_seed)
+    random.seed(args.manual_seed)
+    if not torch.cuda.is_available():
+        raise SystemExit("reart_amd runs on an AMD GPU only (no CPU fallback)")
+    device = torch.device("cuda")
+    if args.synthetic:
+        sample = synthetic_sequence(args.num_points, args.cano_idx, args.synthetic_frames, args.use_flow_loss)
+    else:
+        sample = load_sequence(args.seq_path, args.num_points, args.cano_idx)
+    cano_pc = torch.from_numpy(sample["cano_pc"]).float().to(device)
+    pc_list = torch.from_numpy(sample["pc_list"]).float().to(device)
+    save_dir = os.path.join(args.save_root, os.path.basename(args.seq_path.rstrip("/")) or "synthetic")
+    os.makedirs(save_dir, exist_ok=True)
+
+    pc_ref_list = flow_ref_list = None
+    if args.use_flow_loss:
+        if "ref_loc" in sample:  # synthetic references (true motion + noise)
+            pc_ref_list = [torch.from_numpy(r).to(device) for r in sample["ref_loc"]]
+            flow_ref_list = [torch.from_numpy(f).to(device) for f in sample["ref_flow"]]
+        else:  # run_robot.py:64-84: descriptors -> SMNN matches -> reference flows
+            from reart_amd.networks.feature_extractor import get_extractor
+            from reart_amd.utils.flow_utils import compute_corr_list_filter, normalize_pc_list
+            from reart_amd.utils.dataset_utils import load_normalize_dict
+
+            extractor = get_extractor(args)
+            info = load_normalize_dict(args.normalize_file)[os.path.basename(args.seq_path.rstrip("/"))]
+            centroid = torch.from_numpy(info["centroid"]).float().to(device)
+            complete = torch.from_numpy(sample["complete_pc_list"]).float().to(device)
+            norm = normalize_pc_list(complete, centroid, info["scale"].item())
+            src_list, tgt_list = compute_corr_list_filter(norm, extractor, None, matching="smnn")
+            pc_ref_list = [complete[i][s] for i, s in enumerate(src_list)]
+            flow_ref_list = [complete[i + 1][t] - complete[i][s] for i, (s, t) in enumerate(zip(src_list, tgt_list))]
+
+    tau_func = functools.partial(tau_cosine, max_iter=args.n_iter, end_temp=args.end_tau, start_temp=args.start_tau)
+    fixed_tau = 0.0
+    if args.model == "base":
+        model = BaseModel(num_parts=args.num_parts, pose_len=pc_list.shape[0])
+        if args.resume is not None:
+            ckpt = torch.load(args.resume[0], map_location=device, weights_only=False)
+            model.load_state_dict(ckpt["state_dict"], strict=False)
+            fixed_tau = float(ckpt["tau"])  # the reference freezes tau on resume (:96-97)
+            tau_func = lambda cur_iter: fixed_tau
+            assert args.cano_idx == ckpt.get("cano_idx", args.cano_idx)
+    else:
+        if args.resume is None:
+            raise SystemExit("--model kinematic needs --resume (graph construction from a base result is "
+                             "structure extraction: out of scope, SURVEY.md section 8)")
+        ckpt = torch.load(args.resume[0], map_location=device, weights_only=False)
+        model = KinematicModel(pose_len=pc_list.shape[0], seg_part=ckpt["seg_part"].to(device),
+                               cano_pc=ckpt["cano_pc"].to(device), knn=KNN(k=1, transpose_mode=True),
+                               edge_index=ckpt["edge_index"], paths_to_base=ckpt["paths_to_base"],
+                               reverse_topo=ckpt["reverse_topo"])
+        model.load_state_dict(ckpt["state_dict"], strict=True)
+    model.to(device)
+    chamfer_dist = ChamferDistance()
+    knn_flow = KNN(k=3, transpose_mode=True)
+
+    def snapshot(i, losses):
+        with torch.no_grad():
+            pred, _, _ = model(cano_pc, tau=tau_func(cur_iter=i + 1)) if args.model == "base" else model(cano_pc)
+            cd = recon_loss(pred, pc_list, chamfer_dist).item() / (2 * pred.shape[0] * pred.shape[1])
+        print(f"iteration: {i} | " + " | ".join(f"{k}: {v:.3f}" for k, v in losses.items())
+              + f" | mean squared NN distance: {cd:.3e}")
+
+    n_iter = 1 if args.evaluate else args.n_iter
+    i = 0
+    # ---- phase 1: fused engine (base model, Chamfer [+ flow]) until the assignment loss takes over
+    fused_until = n_iter if not args.use_assign_loss else min(args.assign_iter, n_iter)
+    if args.model == "base" and not args.evaluate and fused_until > 0:
+        eng = RelaxEngine(cano_pc, pc_list, model, args.cano_idx, pc_ref_list, flow_ref_list, n_iter=args.n_iter,
+                          start_tau=args.start_tau, end_tau=args.end_tau, trans_lr=args.trans_lr, seg_lr=args.seg_lr,
+                          lambda_flow=args.lambda_flow, use_robust_loss=args.use_robust_loss, fixed_tau=fixed_tau,
+                          seed=args.manual_seed)
+        i += eng.capture()
+        while i < fused_until:
+            chunk = min(args.snapshot_gap, fused_until - i)
+            eng.step(chunk)
+            i += chunk
+            row = eng.last_losses().cpu().numpy()
+            snapshot(i - 1, {"recon Loss": row[0], "flow Loss": row[1], "total Loss": row[2]})
+    # ---- phase 2: the reference's loop with HIP operators (assignment loss / kinematic model)
+    if i < n_iter and not args.evaluate:
+        from scipy.optimize import linear_sum_assignment
+
+        if args.model == "base":
+            seg_params = [p for p in model.seg_head.parameters() if p.requires_grad]
+            optimizer = torch.optim.Adam([{"params": [model.proposal_6d, model.proposal_t], "lr": args.trans_lr},
+                                          {"params": seg_params, "lr": args.seg_lr}], lr=1e-3,
+                                         weight_decay=args.weight_decay)
+        else:
+            optimizer = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=args.trans_lr,
+                                         weight_decay=args.weight_decay)
+        assign = None
+        while i < n_iter:
+            kwargs = {"tau": tau_func(cur_iter=i + 1)} if args.model == "base" else {}
+            pc_trans_list, seg_part, trans_list = model(cano_pc, **kwargs)
+            losses, loss = {}, 0
+            if args.use_assign_loss and i >= args.assign_iter:
+                if assign is None or i % args.assign_gap == 0:  # run_robot.py:165-178
+                    num_fps = pc_trans_list.shape[1] // args.downsample
+                    src_idx = farthest_point_sample(cano_pc[None], num_fps).expand(pc_trans_list.shape[0], num_fps)
+                    tgt_idx = farthest_point_sample(pc_list, num_fps)
+                    with torch.no_grad():
+                        cost = torch.cdist(index_points(pc_trans_list, src_idx), index_points(pc_list, tgt_idx))
+                    assign = [linear_sum_assignment(c) for c in cost.cpu().numpy()]
+                pc_src, pc_tgt = index_points(pc_trans_list, src_idx), index_points(pc_list, tgt_idx)
+                rows = torch.cat([torch.as_tensor(r) for r, _ in assign]).to(device)
+                cols = torch.cat([torch.as_tensor(c) for _, c in assign]).to(device)
+                bidx = torch.cat([torch.full((len(r),), b) for b, (r, _) in enumerate(assign)]).to(device)
+                ass = args.lambda_assign * ((pc_src[bidx, rows] - pc_tgt[bidx, cols]) ** 2).sum(-1).sum()
+                losses["opt assignment loss"] = ass.item()
+                loss = loss + ass
+            else:
+                rec = recon_loss(pc_trans_list, pc_list, chamfer_dist)
+                losses["recon Loss"] = rec.item()
+                loss = loss + rec
+            if args.use_flow_loss:
+                c = args.cano_idx
+                with torch.no_grad():
+                    comp = torch.cat((pc_trans_list[:c], cano_pc[None], pc_trans_list[c:]), dim=0)
+                    blended = [blend_anchor_motion(q, r, f, knn_flow, return_mask=True)
+                               for q, r, f in zip(comp[:-1], pc_ref_list, flow_ref_list)]
+                comp = torch.cat((pc_trans_list[:c], cano_pc[None], pc_trans_list[c:]), dim=0)
+                fl = args.lambda_flow * flow_loss(torch.stack([b[0] for b in blended]), comp[1:] - comp[:-1],
+                                                  flow_mask_list=torch.stack([b[1] for b in blended]),
+                                                  robust=args.use_robust_loss)
+                losses["flow Loss"] = fl.item()
+                loss = loss + fl
+            losses["total Loss"] = float(loss.detach())
+            optimizer.zero_grad()
+            loss.backward()
+            optimizer.step()
+            if i % args.snapshot_gap == 0 or i == n_iter - 1:
+                snapshot(i, losses)
+            i += 1
+    if args.evaluate:
+        snapshot(0, {})
+    else:  # checkpoint with the reference's keys (run_robot.py:340-356)
+        tau = tau_func(cur_iter=n_iter)
+        model_dict = {"state_dict": model.state_dict(), "tau": tau, "cano_idx": args.cano_idx}
+        if isinstance(model, KinematicModel):
+            model_dict.update(seg_part=model.seg_part, cano_pc=model.cano_pc, edge_index=model.edge_index,
+                              paths_to_base=model.paths_to_base, reverse_topo=model.reverse_topo)
+        torch.save(model_dict, os.path.join(save_dir, "model.pth.tar"))
+        print("saved", os.path.join(save_dir, "model.pth.tar"))
+    print("all done!")
+    return model
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description="Robot (reart_amd)")
+    # same flags and defaults as the reference, run_robot.py:362-420
+    p.add_argument("--manual_seed", default=2, type=int)
+    p.add_argument("--resume", type=str, nargs="+", metavar="PATH")
+    p.add_argument("--evaluate", dest="evaluate", action="store_true")
+    p.add_argument("--snapshot_gap", default=100, type=int)
+    p.add_argument("--use_cuda", default=1, type=int)
+    p.add_argument("--cano_idx", default=0, type=int)
+    p.add_argument("--num_points", default=4096, type=int)
+    p.add_argument("--seq_path", default="data/robot/nao", type=str)
+    p.add_argument("--normalize_file", default="data/category_normalize_scale.pkl", type=str)
+    p.add_argument("--start_tau", default=5, type=float)
+    p.add_argument("--end_tau", default=1, type=float)
+    p.add_argument("--seg_lr", default=1e-3, type=float)
+    p.add_argument("--trans_lr", default=1e-2, type=float)
+    p.add_argument("--weight_decay", default=0, type=float)
+    p.add_argument("--n_iter", default=15000, type=int)
+    p.add_argument("--assign_iter", default=5000, type=int)
+    p.add_argument("--num_parts", default=20, type=int)
+    p.add_argument("--model", default="base", type=str, choices=["base", "kinematic"])
+    p.add_argument("--base_result_path", default=None, type=str)
+    p.add_argument("--corr_model_path", default="pretrained/corr_model.pth.tar")
+    p.add_argument("--use_flow_loss", action="store_true")
+    p.add_argument("--use_robust_loss", action="store_true")
+    p.add_argument("--use_assign_loss", action="store_true")
+    p.add_argument("--use_nproc", action="store_true")
+    p.add_argument("--downsample", default=4, type=int)
+    p.add_argument("--assign_gap", default=5, type=int)
+    p.add_argument("--lambda_assign", default=3e-1, type=float)
+    p.add_argument("--lambda_flow", default=1, type=float)
+    p.add_argument("--lambda_joint", default=100, type=float)
+    p.add_argument("--cano_dist_thr", default=1e-2, type=float)
+    p.add_argument("--merge_thr", default=3e-2, type=float)
+    p.add_argument("--merge_it", default=2, type=int)
+    p.add_argument("--save_root", default="exp", type=str)
+    # additions
+    p.add_argument("--synthetic", action="store_true", help="generated articulated sequence instead of --seq_path")
+    p.add_argument("--synthetic_frames", default=20, type=int)
+    return p
+
+
+if __name__ == "__main__":
+    a = build_parser().parse_args()
+    os.makedirs(a.save_root, exist_ok=True)
+    main(a)

@@ -28,3 +28,50 @@ def blend_anchor_motion(query_loc, reference_loc, reference_flow, knn, return_ma
 def normalize_pc_list(pc_list, centroid, scale):
     """utils/flow_utils.py:173-175."""
     return (pc_list - centroid) * scale
+
+
+@torch.no_grad()
+def match_smnn(desc1, desc2, th=0.9):
+    """Mutual second-nearest-neighbour ratio matching (utils/flow_utils.py:48-100).
+    desc1 [B1,D], desc2 [B2,D] -> (match_dists [B3,1], matches_idxs [B3,2]) sorted by the desc1 index.
+    (match_dists is the larger of the two ratios like the reference; its callers ignore it.)"""
+    if desc1.shape[0] < 2 or desc2.shape[0] < 2:
+        raise AssertionError
+    keep, tgt = _smnn_batched(desc1[None], desc2[None], th)
+    src = torch.nonzero(keep[0], as_tuple=False)[:, 0]
+    idx = torch.stack([src, tgt[0][src]], dim=1)
+    return torch.empty((idx.shape[0], 1), device=desc1.device), idx
+
+
+def _smnn_batched(d1, d2, th):
+    _lib.require_gpu(d1, d2)
+    d1, d2 = d1.contiguous().float(), d2.contiguous().float()
+    E, N1, D = d1.shape
+    N2 = d2.shape[1]
+    keep = torch.empty((E, N1), dtype=torch.bool, device=d1.device)
+    tgt = torch.empty((E, N1), dtype=torch.int64, device=d1.device)
+    L = _lib.lib()
+    ws = _lib.workspace(L.reart_match_smnn_workspace_bytes(E, N1, N2), d1.device)
+    rc = L.reart_match_smnn(_lib.ptr(d1), _lib.ptr(d2), E, N1, N2, D, float(th), _lib.ptr(keep), _lib.ptr(tgt),
+                            _lib.ptr(ws), ws.numel(), _lib.stream())
+    _lib.check(rc, "reart_match_smnn")
+    return keep, tgt
+
+
+@torch.no_grad()
+def compute_corr_list_filter(norm_pc_list, feature_extractor, knn=None, matching="smnn"):
+    """One-time correspondence extraction (utils/flow_utils.py:116-143): descriptors of frames
+    [:-1] and [1:], then per pair the mutual SMNN matches.  norm_pc_list [T,N,3] ->
+    (corrs_src_list, corrs_tgt_list): ragged index lists per consecutive frame pair.
+    Every frame's descriptors are computed once (the reference evaluates interior frames twice)."""
+    if matching != "smnn":
+        raise NotImplementedError("only the reference's default matching='smnn' is built (run_robot.py:80)")
+    feats = feature_extractor(norm_pc_list.transpose(1, 2).contiguous())   # [T,64,N]
+    feats = feats.permute(0, 2, 1).contiguous()                            # point-major rows
+    keep, tgt = _smnn_batched(feats[:-1], feats[1:], 0.9)
+    src_list, tgt_list = [], []
+    for e in range(keep.shape[0]):
+        src = torch.nonzero(keep[e], as_tuple=False)[:, 0]
+        src_list.append(src)
+        tgt_list.append(tgt[e][src])
+    return src_list, tgt_list
