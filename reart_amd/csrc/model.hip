@@ -413,19 +413,16 @@ __global__ __launch_bounds__(64 * (((PP > 0 ? PP : 32) + FW_PG - 1) / FW_PG)) vo
             if (i < cn) {
                 const size_t pt = (size_t)t * a.N + n0 + i;
                 long long *ac = a.acc + 4 * pt;
-                const double c = (double)ac[3];
                 const int fc = t < a.cano_idx ? t : t + 1;   // complete-sequence index of frame t
                 const float *gh = (a.gpf && fc - 1 >= 0) ? a.gpf + 3 * ((size_t)(fc - 1) * a.N + n0 + i) : nullptr;
                 const float *gl = (a.gpf && fc <= a.B - 1) ? a.gpf + 3 * ((size_t)fc * a.N + n0 + i) : nullptr;
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    const double sy = (double)ac[k] * inv;
-                    g[k] = a.G[3 * pt + k] + (float)(2.0 * (c * (double)a.X[3 * pt + k] - sy));
+                    g[k] = a.G[3 * pt + k] + (float)(2.0 * ((double)ac[k] * inv));   // 2 sum (x - y_i)
                     if (gh) g[k] += gh[k];
                     if (gl) g[k] -= gl[k];
                     ac[k] = 0;
                 }
-                ac[3] = 0;
             }
             s_G[t * (RED_CHUNK * 3) + 3 * i] = g[0];
             s_G[t * (RED_CHUNK * 3) + 3 * i + 1] = g[1];
@@ -571,7 +568,14 @@ __global__ __launch_bounds__(256) void base_bwd_finalize_kernel(BaseBwdArgs a, F
     if (o < nW) {
         float acc = 0.f;
         int c = 0;
-        for (; c + 8 <= a.nchunk; c += 8) {  // 8 independent loads in flight, fixed add order
+        for (; c + 32 <= a.nchunk; c += 32) {  // 32 independent loads in flight, fixed add order
+            float v[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) v[u] = a.partial[(size_t)(c + u) * no + o];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) acc += v[u];
+        }
+        for (; c + 8 <= a.nchunk; c += 8) {
             float v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) v[u] = a.partial[(size_t)(c + u) * no + o];
@@ -603,7 +607,7 @@ __global__ __launch_bounds__(256) void base_bwd_finalize_kernel(BaseBwdArgs a, F
         float gRt[12];
 #pragma unroll
         for (int c = 0; c < 12; ++c) gRt[c] = 0.f;
-#pragma unroll 4
+#pragma unroll 8
         for (int ch = 0; ch < a.nchunk; ++ch) {
             const float *pr = a.partial + (size_t)ch * no + off_gRt(a.P, a.H) + 12 * e;
 #pragma unroll

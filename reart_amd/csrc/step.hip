@@ -119,8 +119,9 @@ __global__ void relax_init_kernel(reart_relax_config c, const int *__restrict__ 
         __syncthreads();
     }
     if (t == 0) {
-        // N * max|y| * 2^bits < 2^61, and bits <= 39 so that a 24-bit mantissa never overflows the shift
-        const double bound = (double)c.N * fmax((double)s_max[0], 1e-30);
+        // sums of up to N differences |x - y| (allow 8 x the data range): N * 8 max|y| * 2^bits < 2^61, and
+        // bits <= 39 so that a 24-bit mantissa never overflows the shift
+        const double bound = 8.0 * (double)c.N * fmax((double)s_max[0], 1e-30);
         int bits = (int)floor(61.0 - log2(bound));
         fx_bits[0] = bits > 39 ? 39 : (bits < 0 ? 0 : bits);
     }
@@ -402,12 +403,14 @@ __global__ __launch_bounds__(CG_BS) void chamfer_acc_kernel(CGradArgs a) {
         G[0] = 2.0f * (x[3 * i] - y[3 * j0]);
         G[1] = 2.0f * (x[3 * i + 1] - y[3 * j0 + 1]);
         G[2] = 2.0f * (x[3 * i + 2] - y[3 * j0 + 2]);
+        // y_i chose x_{j1}: add the difference (x_{j1} - y_i) to that target's fixed-point sum
+        // (3 integer atomics per point; differences are small, so they are also the better-conditioned
+        // quantity to accumulate)
         const int sbits = a.fx_bits[0];
         unsigned long long *t = (unsigned long long *)(a.acc + 4 * ((size_t)b * N + j1));
-        atomicAdd(t + 0, (unsigned long long)fixed_from_float(yi0, sbits));
-        atomicAdd(t + 1, (unsigned long long)fixed_from_float(yi1, sbits));
-        atomicAdd(t + 2, (unsigned long long)fixed_from_float(yi2, sbits));
-        atomicAdd(t + 3, 1ull);
+        atomicAdd(t + 0, (unsigned long long)fixed_from_float(x[3 * j1] - yi0, sbits));
+        atomicAdd(t + 1, (unsigned long long)fixed_from_float(x[3 * j1 + 1] - yi1, sbits));
+        atomicAdd(t + 2, (unsigned long long)fixed_from_float(x[3 * j1 + 2] - yi2, sbits));
     }
     term = reart_wave_sum_d(term);
     if ((tid & 63) == 0) s_red[tid >> 6] = term;
