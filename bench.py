@@ -92,7 +92,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    distributed = "RANK" in os.environ  # launched by torch.distributed.run (also with a single rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
