@@ -86,6 +86,9 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="run the flow branch serially (profiling: isolated kernel durations)")
     ap.add_argument("--grid", action="store_true", help="exact grid search for the static targets (same results; slower at this size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--instances-per-gpu", type=int, default=1,
+                    help="sweep mode: K independent instances share each GPU on separate streams (secondary figure; "
+                         "the headline is K=1)")
     ap.add_argument("--profile-steps", type=int, default=20, help="eager steps timed per phase with HIP events")
     args = ap.parse_args()
 
@@ -106,12 +109,27 @@ def main():
     # independent instances: rank r optimises canonical index (T//2 + r) % T (README: the
     # canonical frame is selected by the lowest final energy -> sweep over cano_idx)
     cano_idx = (T // 2 + rank) % T
-    eng, seq, model = build_instance(dev, T, N, cano_idx, seed=2 + rank, use_flow=use_flow, use_grid=args.grid,
-                                      overlap=not args.no_overlap)
-    used = 0
-    if not args.no_graph:
-        used = eng.capture()
-    eng.step(max(args.warmup - used, 0))
+    K = max(1, args.instances_per_gpu)
+    engines, streams = [], []
+    for k in range(K):
+        st = torch.cuda.Stream(device=dev) if K > 1 else torch.cuda.current_stream(dev)
+        with torch.cuda.stream(st):
+            e_, seq, model = build_instance(dev, T, N, (cano_idx + k) % T, seed=2 + rank + 101 * k, use_flow=use_flow,
+                                            use_grid=args.grid, overlap=not args.no_overlap)
+            used = 0 if args.no_graph else e_.capture()
+            e_.step(max(args.warmup - used, 0))
+        engines.append(e_)
+        streams.append(st)
+    eng = engines[0]
+
+    def run_steps(n):
+        if K == 1:
+            eng.step(n)
+            return
+        for _ in range(n):  # round-robin so that the instances' graphs interleave on the device
+            for e_, st in zip(engines, streams):
+                with torch.cuda.stream(st):
+                    e_.step(1)
 
     def barrier():
         torch.cuda.synchronize()
@@ -121,7 +139,7 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
-    eng.step(args.steps)
+    run_steps(args.steps)
     barrier()
     el = time.perf_counter() - t0
     if distributed:
@@ -167,7 +185,7 @@ def main():
             cpu = cpu_baseline(seq, T, N, cano_idx)
         out = {
             "metric": "relaxation-loop iterations/sec",
-            "value": round(world * args.steps / el, 3),
+            "value": round(world * K * args.steps / el, 3),
             "unit": "iterations/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -182,7 +200,8 @@ def main():
                                    + ("+flow loss (k=3 blend, 3000 refs/pair)" if use_flow else " only")
                                    + ", full iteration fwd+loss+bwd+Adam, one instance per GPU",
                        "frames": T, "points": N, "parts": 20, "flow": use_flow,
-                       "graph": not args.no_graph, "grid_search_static_targets": args.grid, "flow_branch_overlap": not args.no_overlap, "parallelism": f"instances x{world}"},
+                       "graph": not args.no_graph, "grid_search_static_targets": args.grid, "flow_branch_overlap": not args.no_overlap, "parallelism": f"instances x{world}" + (f" x{K} per GPU" if K > 1 else ""),
+                       "instances_per_gpu": K},
             "roofline": roof,
             "cpu_baseline": cpu,
             "phases_ms": {k: round(v, 5) for k, v in phases.items()},

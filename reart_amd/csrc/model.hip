@@ -555,7 +555,8 @@ __device__ __forceinline__ void adam_update(float *p, float g, float *m, float *
 
 __global__ __launch_bounds__(256) void base_bwd_finalize_kernel(BaseBwdArgs a, FinalizeAdam ad) {
     const int o = blockIdx.x * 256 + threadIdx.x;
-    const int nW = a.P * a.H + 4 * a.H;
+    const int nWr = a.P * a.H + 4 * a.H;                 // real weight entries
+    const int nW = (nWr + 63) & ~63;                     // pose groups start wave-aligned
     const int no = n_out(a.P, a.H, a.B);
     float ss_seg = 0.f, ss_tr = 0.f, bc2s = 1.f;
     if (ad.enabled) {
@@ -566,6 +567,7 @@ __global__ __launch_bounds__(256) void base_bwd_finalize_kernel(BaseBwdArgs a, F
         bc2s = (float)ad.bias_corr[1];
     }
     if (o < nW) {
+        if (o >= nWr) return;
         float acc = 0.f;
         int c = 0;
         for (; c + 32 <= a.nchunk; c += 32) {  // 32 independent loads in flight, fixed add order
@@ -602,32 +604,43 @@ __global__ __launch_bounds__(256) void base_bwd_finalize_kernel(BaseBwdArgs a, F
                 adam_update(ad.b1 + q, acc, ad.m + nW1 + q, ad.v + nW1 + q, ad.seg_lr, ss_seg, bc2s, ad.beta1,
                             ad.beta2, ad.eps);
         }
-    } else if (o < nW + a.B * a.P) {
-        const int e = o - nW;
-        float gRt[12];
+    } else if (o < nW + 16 * a.B * a.P) {
+        // 16 lanes per (frame, part): lane c < 12 sums one entry of dL/d[R|t] over the chunks (all its
+        // loads in flight at once), then lane 0 gathers the 12 sums and runs the Gram-Schmidt backward
+        const int q = o - nW, e = q >> 4, c = q & 15;
+        float acc = 0.f;
+        if (c < 12) {
+            const float *pr = a.partial + off_gRt(a.P, a.H) + 12 * (size_t)e + c;
+            int ch = 0;
+            for (; ch + 32 <= a.nchunk; ch += 32) {
+                float v[32];
 #pragma unroll
-        for (int c = 0; c < 12; ++c) gRt[c] = 0.f;
-#pragma unroll 8
-        for (int ch = 0; ch < a.nchunk; ++ch) {
-            const float *pr = a.partial + (size_t)ch * no + off_gRt(a.P, a.H) + 12 * e;
+                for (int u = 0; u < 32; ++u) v[u] = pr[(size_t)(ch + u) * no];
 #pragma unroll
-            for (int c = 0; c < 12; ++c) gRt[c] += pr[c];
+                for (int u = 0; u < 32; ++u) acc += v[u];
+            }
+            for (; ch < a.nchunk; ++ch) acc += pr[(size_t)ch * no];
         }
+        float gRt[12];
+        const int lane0 = (threadIdx.x & 63) & ~15;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) gRt[k] = __shfl(acc, lane0 + k, 64);
+        if (c != 0) return;
         float g6[6];
         r6d_backward(a.p6d + 6 * (size_t)e, gRt, g6);
         const int base6 = 3 * a.H + a.H + a.P * a.H, baset = base6 + 6 * a.B * a.P;
 #pragma unroll
-        for (int c = 0; c < 6; ++c) {
-            a.g6d[6 * (size_t)e + c] = g6[c];
+        for (int k = 0; k < 6; ++k) {
+            a.g6d[6 * (size_t)e + k] = g6[k];
             if (ad.enabled)
-                adam_update(ad.p6d + 6 * (size_t)e + c, g6[c], ad.m + base6 + 6 * e + c, ad.v + base6 + 6 * e + c,
+                adam_update(ad.p6d + 6 * (size_t)e + k, g6[k], ad.m + base6 + 6 * e + k, ad.v + base6 + 6 * e + k,
                             ad.trans_lr, ss_tr, bc2s, ad.beta1, ad.beta2, ad.eps);
         }
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            a.gt[3 * (size_t)e + c] = gRt[9 + c];
+        for (int k = 0; k < 3; ++k) {
+            a.gt[3 * (size_t)e + k] = gRt[9 + k];
             if (ad.enabled)
-                adam_update(ad.pt + 3 * (size_t)e + c, gRt[9 + c], ad.m + baset + 3 * e + c, ad.v + baset + 3 * e + c,
+                adam_update(ad.pt + 3 * (size_t)e + k, gRt[9 + k], ad.m + baset + 3 * e + k, ad.v + baset + 3 * e + k,
                             ad.trans_lr, ss_tr, bc2s, ad.beta1, ad.beta2, ad.eps);
         }
     }
@@ -690,7 +703,9 @@ int reart_base_backward_ex(BaseBwdArgs a, const FinalizeAdam *adam, void *worksp
     }
     if (rc != REART_OK) return rc;
     FinalizeAdam none = {};
-    const int nfin = a.P * a.H + 4 * a.H + a.B * a.P;
+    // weights: one thread per entry; poses: 16 lanes per (frame, part); nW is rounded up to a multiple of 64
+    // inside the kernel's indexing so that a 16-lane group never straddles a wave
+    const int nfin = (int)reart_align_up((size_t)(a.P * a.H + 4 * a.H), 64) + 16 * a.B * a.P;
     hipLaunchKernelGGL(base_bwd_finalize_kernel, dim3(reart_div_up(nfin, 256)), dim3(256), 0, st, a,
                        adam ? *adam : none);
     REART_CHECK_LAUNCH();
