@@ -108,7 +108,9 @@ struct KnnArgs {
 int reart_knn_launch_slices(const KnnArgs &a, int KK, hipStream_t st);
 int reart_soa_launch(const SoaArgs &sa, int maxPpad, int N, int njobs, hipStream_t st);
 int reart_knn_pick_split(long waves, int P2, int K);
-#define NN_BOX 64   // targets per bounding box of the block-skip test
+#ifndef NN_BOX
+#define NN_BOX 16   // targets per bounding box of the block-skip test (16, 32 or 64; measured 4545 / 4438 / 4321 it/s)
+#endif
 int reart_boxes_launch(const float *soa, int N, int Ppad, float *boxes, hipStream_t st);
 
 // ---- exact grid search over static target sets (grid.hip) -----------------------------------

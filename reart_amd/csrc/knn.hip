@@ -71,31 +71,32 @@ __device__ __forceinline__ bool box_skip(const float *box, float qx, float qy, f
 __global__ __launch_bounds__(256) void box_kernel(const float *__restrict__ soa, int Ppad,
                                                   float *__restrict__ boxes) {
     const int lane = threadIdx.x & 63;
-    const int bxi = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
+    const int e0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64, b = blockIdx.y;   // 64 entries per wave
+    if (e0 >= Ppad) return;
     const int nbox = Ppad / NN_BOX;
-    if (bxi >= nbox) return;
-    const float *p = soa + (size_t)b * 3 * Ppad + (size_t)bxi * NN_BOX + lane;
+    const float *p = soa + (size_t)b * 3 * Ppad + e0 + lane;
+    const bool in = e0 + lane < Ppad;
     float lo[3], hi[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const float v = p[(size_t)c * Ppad];
+        const float v = in ? p[(size_t)c * Ppad] : INFINITY;
         lo[c] = v;
         hi[c] = (v == INFINITY) ? -INFINITY : v;
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
+        for (int o = NN_BOX / 2; o >= 1; o >>= 1) {   // reduce within groups of NN_BOX lanes
             lo[c] = fminf(lo[c], __shfl_xor(lo[c], o, 64));
             hi[c] = fmaxf(hi[c], __shfl_xor(hi[c], o, 64));
         }
         if (hi[c] == -INFINITY) hi[c] = INFINITY;
     }
-    if (lane == 0) {
-        float *o = boxes + ((size_t)b * nbox + bxi) * 8;
+    if ((lane & (NN_BOX - 1)) == 0 && in) {
+        float *o = boxes + ((size_t)b * nbox + (e0 + lane) / NN_BOX) * 8;
         o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = hi[0]; o[4] = hi[1]; o[5] = hi[2]; o[6] = 0.f; o[7] = 0.f;
     }
 }
 
 int reart_boxes_launch(const float *soa, int N, int Ppad, float *boxes, hipStream_t st) {
-    hipLaunchKernelGGL(box_kernel, dim3(reart_div_up(Ppad / NN_BOX, 4), N), dim3(256), 0, st, soa, Ppad, boxes);
+    hipLaunchKernelGGL(box_kernel, dim3(reart_div_up(reart_div_up(Ppad, 64), 4), N), dim3(256), 0, st, soa, Ppad, boxes);
     REART_CHECK_LAUNCH();
     return REART_OK;
 }

@@ -275,21 +275,23 @@ __global__ __launch_bounds__(64 * (((PP > 0 ? PP : 32) + FW_PG - 1) / FW_PG)) vo
             o[2 * (size_t)a.Npad + n] = live ? v[2] : INFINITY;
         }
         if (a.boxes && blockIdx.x * FW_PTS < a.Npad) {
-            // AABB of this workgroup's 64 output points of frame t (block-skip test of the K-NN kernels)
+            // AABBs of this workgroup's output points of frame t, one per NN_BOX consecutive points
+            // (block-skip test of the K-NN kernels)
             float lo[3], hi[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 lo[c] = live ? v[c] : INFINITY;
                 hi[c] = live ? v[c] : -INFINITY;
 #pragma unroll
-                for (int o = 32; o >= 1; o >>= 1) {
+                for (int o = NN_BOX / 2; o >= 1; o >>= 1) {
                     lo[c] = fminf(lo[c], __shfl_xor(lo[c], o, 64));
                     hi[c] = fmaxf(hi[c], __shfl_xor(hi[c], o, 64));
                 }
                 if (hi[c] == -INFINITY) hi[c] = INFINITY;
             }
-            if (lane == 0) {
-                float *o = a.boxes + ((size_t)t * (a.Npad / FW_PTS) + blockIdx.x) * 8;
+            const int pos = blockIdx.x * FW_PTS + lane;
+            if ((lane & (NN_BOX - 1)) == 0 && pos < a.Npad) {
+                float *o = a.boxes + ((size_t)t * (a.Npad / NN_BOX) + pos / NN_BOX) * 8;
                 o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = hi[0]; o[4] = hi[1]; o[5] = hi[2];
             }
         }
