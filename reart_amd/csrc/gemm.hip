@@ -38,19 +38,37 @@ struct GemmArgs {
     float *Y; int ldy, ycol0;         // [rows, ldy] or [rows / pool_k, ldy], written at columns ycol0..
 };
 
-__device__ __forceinline__ float gemm_load_a(const GemmArgs &a, int r, int k) {
-    if (r >= a.rows || k >= a.Cin) return 0.f;
-    if (!a.idx) return a.X[(size_t)r * a.ldx + k];
+// Per-thread description of the A row this thread stages (fixed for the whole K loop): the
+// gather index arithmetic (two integer divisions) is done once, not once per element.
+struct ARow {
+    const float *x;    // plain row, or NULL
+    const float *f;    // gathered feature row (D floats), or NULL
+    const float *q;    // gathered xyz row
+    float c0, c1, c2;  // centre to subtract (0 when absolute)
+    bool valid;
+};
+
+__device__ __forceinline__ ARow gemm_row(const GemmArgs &a, int r) {
+    ARow w = {nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, r < a.rows};
+    if (!w.valid) return w;
+    if (!a.idx) { w.x = a.X + (size_t)r * a.ldx; return w; }
     const int b = r / (a.S * a.K);
     const size_t prow = (size_t)b * a.Npts + (size_t)a.idx[r];
-    int kx = a.xyz_first ? k : k - a.D;      // index into the xyz part, valid when 0 <= kx < 3
-    int kf = a.xyz_first ? k - 3 : k;        // index into the feature part
-    if (kx >= 0 && kx < 3) {
-        float v = a.Q[prow * 3 + kx];
-        if (a.C) v -= a.C[(size_t)(r / a.K) * 3 + kx];
-        return v;
+    w.q = a.Q + prow * 3;
+    w.f = a.F ? a.F + prow * a.D : nullptr;
+    if (a.C) {
+        const float *c = a.C + (size_t)(r / a.K) * 3;
+        w.c0 = c[0]; w.c1 = c[1]; w.c2 = c[2];
     }
-    return a.F[prow * a.D + kf];
+    return w;
+}
+
+__device__ __forceinline__ float gemm_load_a(const GemmArgs &a, const ARow &w, int k) {
+    if (!w.valid || k >= a.Cin) return 0.f;
+    if (w.x) return w.x[k];
+    const int kx = a.xyz_first ? k : k - a.D;      // index into the xyz part, valid when 0 <= kx < 3
+    if (kx >= 0 && kx < 3) return w.q[kx] - (kx == 0 ? w.c0 : (kx == 1 ? w.c1 : w.c2));
+    return w.f[a.xyz_first ? k - 3 : k];
 }
 
 __global__ __launch_bounds__(256) void mlp_gemm_kernel(GemmArgs a) {
@@ -63,9 +81,10 @@ __global__ __launch_bounds__(256) void mlp_gemm_kernel(GemmArgs a) {
     f16v c1 = c0;
     const int ar = tid >> 1, ak = (tid & 1) * 8;      // A tile: 128 rows x 2 half-rows of 8
     const int bk = tid >> 4, bc = (tid & 15) * 4;     // B tile: 16 k x 16 float4
+    const ARow arow = gemm_row(a, row0 + ar);
     for (int k0 = 0; k0 < a.Cin; k0 += GM_BK) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) As[ar * GM_LDA + ak + u] = gemm_load_a(a, row0 + ar, k0 + ak + u);
+        for (int u = 0; u < 8; ++u) As[ar * GM_LDA + ak + u] = gemm_load_a(a, arow, k0 + ak + u);
         {
             const int k = k0 + bk, c = col0 + bc;
             float4 w = {0.f, 0.f, 0.f, 0.f};
