@@ -90,7 +90,8 @@ struct KnnJob {
     const float *q_alt;    // fused step: query cloud used where qmap[b] < 0
     const int *qmap;       // nullable per-batch query frame index into q
     const int *tlen;       // nullable per-batch target count (ragged SoA rows, stride Ppad)
-    const float *boxes;    // nullable [N][Ppad/64][8]: AABB (lo xyz, hi xyz, pad) of every 64 targets
+    const float *boxes;    // nullable [N][Ppad/NN_BOX][8]: AABB (lo xyz, hi xyz, pad) of every NN_BOX targets
+    const int *seed;       // pruned search only: [N][P1][KK] candidate neighbour indices (warm start)
     int P1, P2, Ppad, L;   // Ppad = S*L, L % NN_UB == 0
     int nqg;               // ceil(P1/64)
     float *pd;             // partial dists [S][N][P1][KK]   (S > 1)
@@ -112,6 +113,9 @@ int reart_knn_pick_split(long waves, int P2, int K);
 #define NN_BOX 16   // targets per bounding box of the block-skip test (16, 32 or 64; measured 4545 / 4438 / 4321 it/s)
 #endif
 int reart_boxes_launch(const float *soa, int N, int Ppad, float *boxes, hipStream_t st);
+// exact search with box pruning + warm start (prune.hip); partial lists only, boxes dealt round-robin to slices
+int reart_knn_launch_pruned(const KnnArgs &a, int KK, hipStream_t st);
+int reart_prune_pick_split(void);
 
 // ---- exact grid search over static target sets (grid.hip) -----------------------------------
 struct GridBuildArgs {

@@ -1,0 +1,241 @@
+// reart_amd/csrc/prune.hip -- EXACT nearest-neighbour search with bounding-box pruning and a
+// warm start, for the relaxation loop (reference run_robot.py:154-221: every iteration repeats the
+// Chamfer search of utils/chamfer.py:78-94 and the k=3 search of utils/flow_utils.py:158 on clouds
+// that moved a little since the previous iteration).
+//
+// Same answer, bit for bit, as the brute-force kernels of knn.hip (same distance expression,
+// strict '<', ties -> lowest index); what changes is how many targets are looked at.
+//
+//   * Clouds are stored in Morton order (host side, relax.py), so 16 consecutive targets form a
+//     compact box and the 64 queries of a wave are neighbours.
+//   * Warm start: the neighbour indices of the PREVIOUS iteration (any valid indices would do)
+//     give each query an upper bound thr on its K-th neighbour distance before anything is
+//     scanned:  thr = max_k d(q, t[seed_k])  over K distinct seeds.
+//   * Coarse filter, one box per lane: the wave's queries are summarised by 4 group boxes
+//     (16 lanes each) with the group's largest thr; a target box survives if its box-to-box
+//     lower bound is <= that thr for some group.  One ballot gives the survivor mask of 64 boxes.
+//   * Precise filter, one query per lane: point-to-box lower bound against the lane's own thr
+//     (which keeps shrinking as better candidates are found); the box is scanned if any lane
+//     needs it.  Scanning is the brute-force inner loop of knn.hip (scalar loads of the SoA
+//     targets feeding packed fp32 VALU).
+//
+// Exactness.  Both lower bounds are evaluated with the operations of the distance itself,
+//   lb = ((ex*ex)+(ey*ey))+(ez*ez),  e = max(lo - q, q - hi, 0)  per axis,
+// and fp32 subtraction, multiplication and addition are monotone, so lb <= d(q,t) for every
+// target t inside the box (and the box-to-box bound is <= the point-to-box bound of every query
+// of the group).  A box is dropped only when lb > thr strictly; a target that beats or TIES the
+// current K-th candidate has d <= thr and therefore sits in a box that is scanned.  Boxes are
+// dealt to the S slices round-robin; the consumer merges slice results by the full (d, index) key.
+#include "common.h"
+#include "internal.h"
+#include <math.h>
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+#ifdef REART_PRUNE_STATS   // diagnostic build only (tools/prune_stats.py): how much the filters let through
+__device__ unsigned long long g_prune_stats[8];
+extern "C" int reart_debug_prune_stats(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prune_stats), sizeof(g_prune_stats)) != hipSuccess) return REART_ERR_LAUNCH;
+    if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prune_stats), z, sizeof(z)); }
+    return REART_OK;
+}
+#define PRUNE_STAT(k, v) do { if (threadIdx.x == 0) atomicAdd(&g_prune_stats[k], (unsigned long long)(v)); } while (0)
+#else
+#define PRUNE_STAT(k, v) do { } while (0)
+#endif
+
+__device__ __forceinline__ float rl(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+__device__ __forceinline__ float box_lb(float lo0, float lo1, float lo2, float hi0, float hi1, float hi2,
+                                        float qlo0, float qlo1, float qlo2, float qhi0, float qhi1, float qhi2) {
+    const float ex = fmaxf(fmaxf(lo0 - qhi0, qlo0 - hi0), 0.f);
+    const float ey = fmaxf(fmaxf(lo1 - qhi1, qlo1 - hi1), 0.f);
+    const float ez = fmaxf(fmaxf(lo2 - qhi2, qlo2 - hi2), 0.f);
+    return (ex * ex + ey * ey) + ez * ez;
+}
+
+// KK = 1: partial (distance, exact index) per slice.  KK = 3: partial top-3 BLOCKS of 8 targets
+// (block minimum, first index of the block), rescanned by the consumer (flow_blend_kernel).
+template <int KK>
+__global__ __launch_bounds__(NN_BS) void knn_pruned_kernel(KnnArgs a) {
+    // Work per item varies (it depends on how tight the warm start is), and the working set fits
+    // every XCD's L2: no XCD-contiguous remap here -- consecutive items go to different XCDs and
+    // the two jobs alternate, so every XCD gets the same mix of light and heavy items.
+    const int w = blockIdx.x;
+    if (w >= a.items) return;
+    const bool two = a.items > a.items0;
+    const int jsel = two ? (w & 1) : 0;
+    const KnnJob jb = a.job[jsel];
+    const int wl = two ? (w >> 1) : w;
+    const int s = wl % a.S;                      // slices of one query group are neighbours
+    const int g = (wl / a.S) % jb.nqg;
+    const int b = wl / (jb.nqg * a.S);
+    const int lane = threadIdx.x;
+
+    const int i = g * NN_BS + lane;
+    const int ic = i < jb.P1 ? i : jb.P1 - 1;
+    const int qb = jb.qmap ? jb.qmap[b] : b;
+    const float *qp = (qb < 0 ? jb.q_alt : jb.q + (size_t)qb * jb.P1 * 3) + (size_t)ic * 3;
+    const float qx = qp[0], qy = qp[1], qz = qp[2];
+    const f2 qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
+
+    const float *tx = jb.tsoa + (size_t)b * 3 * jb.Ppad;
+    const float *ty = tx + jb.Ppad;
+    const float *tz = ty + jb.Ppad;
+    const int n2 = jb.tlen ? jb.tlen[b] : jb.P2;
+    const int nbox = (n2 + NN_BOX - 1) / NN_BOX;
+    const float *bx = jb.boxes + (size_t)b * (jb.Ppad / NN_BOX) * 8;
+
+    // ---- warm start
+    float thr = 0.f;
+    {
+        const int *sd = jb.seed + ((size_t)b * jb.P1 + ic) * KK;
+        int sj[KK];
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < KK; ++k) {
+            sj[k] = sd[k];
+            ok = ok && sj[k] >= 0 && sj[k] < n2;
+#pragma unroll
+            for (int k2 = 0; k2 < k; ++k2) ok = ok && sj[k] != sj[k2];
+        }
+#pragma unroll
+        for (int k = 0; k < KK; ++k) {
+            const int j = ok ? sj[k] : 0;
+            thr = fmaxf(thr, reart_sqdist3(qx, qy, qz, tx[j], ty[j], tz[j]));
+        }
+        if (!ok || !(thr >= 0.f)) thr = INFINITY;   // unusable seeds / NaN: no pruning for this lane
+    }
+
+    // ---- group summaries: 4 groups of 16 lanes
+    float gl0 = qx, gl1 = qy, gl2 = qz, gh0 = qx, gh1 = qy, gh2 = qz, gt = thr;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+        gl0 = fminf(gl0, __shfl_xor(gl0, o, 64)); gh0 = fmaxf(gh0, __shfl_xor(gh0, o, 64));
+        gl1 = fminf(gl1, __shfl_xor(gl1, o, 64)); gh1 = fmaxf(gh1, __shfl_xor(gh1, o, 64));
+        gl2 = fminf(gl2, __shfl_xor(gl2, o, 64)); gh2 = fmaxf(gh2, __shfl_xor(gh2, o, 64));
+        gt = fmaxf(gt, __shfl_xor(gt, o, 64));
+    }
+    float G[4][7];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        G[q][0] = rl(gl0, 16 * q); G[q][1] = rl(gl1, 16 * q); G[q][2] = rl(gl2, 16 * q);
+        G[q][3] = rl(gh0, 16 * q); G[q][4] = rl(gh1, 16 * q); G[q][5] = rl(gh2, 16 * q);
+        G[q][6] = rl(gt, 16 * q);
+    }
+
+    float bm[KK];
+    int bb[KK];
+#pragma unroll
+    for (int k = 0; k < KK; ++k) { bm[k] = INFINITY; bb[k] = -1; }
+
+    const int per = 64 * a.S;
+    for (int base = 0; base < nbox; base += per) {
+        // ---- coarse filter: lane l looks at box base + l*S + s
+        const int bid = base + lane * a.S + s;
+        bool pass = false;
+        float lo0 = INFINITY, lo1 = INFINITY, lo2 = INFINITY, hi0 = INFINITY, hi1 = INFINITY, hi2 = INFINITY;
+        if (bid < nbox) {
+            const float4 A = *(const float4 *)(bx + (size_t)bid * 8);
+            const float4 Bv = *(const float4 *)(bx + (size_t)bid * 8 + 4);
+            lo0 = A.x; lo1 = A.y; lo2 = A.z; hi0 = A.w; hi1 = Bv.x; hi2 = Bv.y;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float lb = box_lb(lo0, lo1, lo2, hi0, hi1, hi2, G[q][0], G[q][1], G[q][2], G[q][3], G[q][4], G[q][5]);
+                pass = pass || (lb <= G[q][6]);
+            }
+        }
+        unsigned long long mask = __ballot(pass);
+        PRUNE_STAT(KK == 1 ? 0 : 4, 1);                                  // coarse rounds
+        PRUNE_STAT(KK == 1 ? 1 : 5, __builtin_popcountll(mask));         // boxes passing the coarse filter
+        PRUNE_STAT(KK == 1 ? 3 : 7, __builtin_popcountll(__ballot(thr == INFINITY)));  // lanes without a bound
+        while (mask) {
+            const int bit = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            // ---- precise filter with the lane's current bound
+            const float lb = box_lb(rl(lo0, bit), rl(lo1, bit), rl(lo2, bit), rl(hi0, bit), rl(hi1, bit), rl(hi2, bit),
+                                    qx, qy, qz, qx, qy, qz);
+            if (!__any(lb <= thr)) continue;
+            PRUNE_STAT(KK == 1 ? 2 : 6, 1);                              // boxes scanned
+            const int j0 = (base + bit * a.S + s) * NN_BOX;
+            if (KK == 1) {
+                float m = INFINITY;
+#pragma unroll
+                for (int u = 0; u < NN_BOX; u += 2) {
+                    const f2 dx = qx2 - *(const f2 *)(tx + j0 + u);
+                    const f2 dy = qy2 - *(const f2 *)(ty + j0 + u);
+                    const f2 dz = qz2 - *(const f2 *)(tz + j0 + u);
+                    const f2 d = (dx * dx + dy * dy) + dz * dz;
+                    m = fminf(fminf(m, d.x), d.y);
+                }
+                if (m < bm[0]) { bm[0] = m; bb[0] = j0; }   // ascending visits: ties keep the lower box
+                thr = fminf(thr, m);
+            } else {
+                constexpr int UBK = 8;
+#pragma unroll
+                for (int h = 0; h < NN_BOX; h += UBK) {
+                    float m = INFINITY;
+#pragma unroll
+                    for (int u = 0; u < UBK; u += 2) {
+                        const f2 dx = qx2 - *(const f2 *)(tx + j0 + h + u);
+                        const f2 dy = qy2 - *(const f2 *)(ty + j0 + h + u);
+                        const f2 dz = qz2 - *(const f2 *)(tz + j0 + h + u);
+                        const f2 d = (dx * dx + dy * dy) + dz * dz;
+                        m = fminf(fminf(m, d.x), d.y);
+                    }
+#pragma unroll
+                    for (int c = KK - 1; c >= 0; --c) {
+                        const int cp = c > 0 ? c - 1 : 0;
+                        const bool lt_prev = (c > 0) && (m < bm[cp]);
+                        const bool lt_cur = m < bm[c];
+                        bm[c] = lt_prev ? bm[cp] : (lt_cur ? m : bm[c]);
+                        bb[c] = lt_prev ? bb[cp] : (lt_cur ? j0 + h : bb[c]);
+                    }
+                }
+                // KK distinct blocks hold KK distinct targets no farther than bm[KK-1]
+                thr = fminf(thr, bm[KK - 1]);
+            }
+        }
+    }
+
+    if (KK == 1) {
+        // exact (lowest) index inside the winning box
+        int bi = 0x7fffffff;
+        if (bb[0] >= 0) {
+            const int blk = bb[0];
+#pragma unroll
+            for (int u = NN_BOX - 1; u >= 0; --u) {
+                const float d = reart_sqdist3(qx, qy, qz, tx[blk + u], ty[blk + u], tz[blk + u]);
+                if (d == bm[0]) bi = blk + u;
+            }
+        }
+        bb[0] = bi;
+    }
+    if (i >= jb.P1) return;
+    const size_t o = (((size_t)s * a.N + b) * jb.P1 + i) * KK;
+#pragma unroll
+    for (int k = 0; k < KK; ++k) { jb.pd[o + k] = bm[k]; jb.pi[o + k] = bb[k]; }
+}
+
+int reart_knn_launch_pruned(const KnnArgs &a, int KK, hipStream_t st) {
+    const int grid = reart_xcd_grid(a.items);
+    for (int j = 0; j < 2; ++j)
+        if (!a.job[j].boxes || !a.job[j].seed) return REART_ERR_INVALID_ARG;
+    if (a.items != a.items0 && a.items != 2 * a.items0) return REART_ERR_INVALID_ARG;   // the two jobs alternate
+    switch (KK) {
+        case 1: hipLaunchKernelGGL((knn_pruned_kernel<1>), dim3(grid), dim3(NN_BS), 0, st, a); break;
+        case 3: hipLaunchKernelGGL((knn_pruned_kernel<3>), dim3(grid), dim3(NN_BS), 0, st, a); break;
+        default: return REART_ERR_UNSUPPORTED;
+    }
+    REART_CHECK_LAUNCH();
+    return REART_OK;
+}
+
+// split for the pruned search: the per-item work is small and uneven, a few slices even it out
+int reart_prune_pick_split(void) {
+    const char *env = getenv("REART_PRUNE_SPLIT");
+    const int S = env ? atoi(env) : 4;
+    return S >= 1 && S <= 16 ? S : 4;
+}

@@ -21,7 +21,9 @@ struct StepPlan {
     size_t o_pd0, o_pi0, o_pd1, o_pi1, o_pd3, o_pi3;
     size_t o_yT, o_hT, o_hard, o_rt, o_G, o_gpf, o_cint, o_fx, o_floss, o_fpart, o_grads, o_bwd;
     size_t o_bc;              // Adam bias corrections of the coming step (double[2])
-    size_t o_boxY, o_boxX, o_boxR;  // AABBs of every 64 targets (block-skip test)
+    size_t o_boxY, o_boxX, o_boxR;  // AABBs of every NN_BOX targets (block-skip test)
+    int pruned;               // box-pruned, warm-started search (prune.hip) instead of the slice kernels
+    size_t o_seed0, o_seed1, o_seed3;  // last iteration's neighbour indices: x->y [B,N], y->x [B,N], flow [B,N,3]
     size_t o_gridY, o_gridR;  // exact-search grids over pc_list and the flow reference sets
     int gstrideY, gstrideR;
     size_t bwd_bytes, total;
@@ -39,13 +41,14 @@ static int step_plan(const reart_relax_config *c, StepPlan *p) {
     if (c->N <= 0 || c->P <= 0 || c->P > 32 || c->B <= 0 || c->H <= 0) return REART_ERR_INVALID_ARG;
     if (c->use_flow && (c->flow_k != 3 || c->M_max < 3)) return REART_ERR_UNSUPPORTED;
     const long waves1 = 2L * c->B * reart_div_up(c->N, NN_BS);
-    p->S1 = reart_knn_pick_split(waves1, c->N, 1);
+    p->pruned = (c->use_boxes && !c->use_grid) ? 1 : 0;
+    p->S1 = p->pruned ? reart_prune_pick_split() : reart_knn_pick_split(waves1, c->N, 1);
     p->L1 = (int)reart_align_up((size_t)reart_div_up(c->N, p->S1), NN_BOX);
     p->Npad = p->L1 * p->S1;
     p->S3 = 1; p->Mpad = 0;
     if (c->use_flow) {
         const long waves3 = (long)c->B * reart_div_up(c->N, NN_BS);
-        p->S3 = reart_knn_pick_split(waves3, c->M_max, 3);
+        p->S3 = p->pruned ? reart_prune_pick_split() : reart_knn_pick_split(waves3, c->M_max, 3);
         p->Mpad = (int)reart_align_up((size_t)reart_div_up(c->M_max, p->S3), NN_BOX) * p->S3;
     }
     p->nchunk = reart_div_up(c->N, 64);
@@ -80,6 +83,9 @@ static int step_plan(const reart_relax_config *c, StepPlan *p) {
     p->o_boxY = take(off, sizeof(float) * 8 * (size_t)c->B * (p->Npad / NN_BOX));
     p->o_boxX = take(off, sizeof(float) * 8 * (size_t)c->B * (p->Npad / NN_BOX));
     p->o_boxR = take(off, sizeof(float) * 8 * (size_t)c->B * (p->Mpad / NN_BOX + 1));
+    p->o_seed0 = take(off, p->pruned ? sizeof(int) * BN : 0);
+    p->o_seed1 = take(off, p->pruned ? sizeof(int) * BN : 0);
+    p->o_seed3 = take(off, (p->pruned && c->use_flow) ? sizeof(int) * BN * 3 : 0);
     p->gstrideY = (int)reart_align_up((size_t)c->N, 64);
     p->gstrideR = (int)reart_align_up((size_t)(c->M_max > 0 ? c->M_max : 1), 64);
     p->o_gridY = take(off, c->use_grid ? reart_grid_bytes(c->B, p->gstrideY) : 0);
@@ -105,9 +111,12 @@ __global__ void relax_init_kernel(reart_relax_config c, const int *__restrict__ 
                                   int *__restrict__ rlen, int *__restrict__ qmap,
                                   int64_t *__restrict__ iter, float *__restrict__ tau,
                                   const float *__restrict__ pc_list, int *__restrict__ fx_bits,
-                                  double *__restrict__ bias_corr) {
+                                  double *__restrict__ bias_corr, int *__restrict__ seed3) {
     __shared__ float s_max[1024];
     const int t = threadIdx.x;
+    // warm start of the first k=3 search: any 3 distinct valid indices
+    if (seed3)
+        for (size_t e = t; e < (size_t)c.B * c.N * 3; e += 1024) seed3[e] = (int)(e % 3);
     // fixed-point scale for the exact (order-independent) sums of observed points in
     // chamfer_grad_kernel: N * max|y| * scale < 2^61
     float mx = 0.f;
@@ -178,7 +187,12 @@ extern "C" int reart_relax_prepare(const reart_relax_config *cfg, const reart_re
     if (rc != REART_OK) return rc;
     hipLaunchKernelGGL(relax_init_kernel, dim3(1), dim3(1024), 0, st, *cfg, bufs->ref_off,
                        (int *)(ws + p.o_rlen), (int *)(ws + p.o_qmap), bufs->iter, bufs->tau, bufs->pc_list,
-                       (int *)(ws + p.o_fx), (double *)(ws + p.o_bc));
+                       (int *)(ws + p.o_fx), (double *)(ws + p.o_bc),
+                       (p.pruned && cfg->use_flow) ? (int *)(ws + p.o_seed3) : nullptr);
+    if (p.pruned) {  // warm start of the first Chamfer search: index 0 (any valid index)
+        if (hipMemsetAsync(ws + p.o_seed0, 0, sizeof(int) * (size_t)cfg->B * cfg->N, st) != hipSuccess) return REART_ERR_LAUNCH;
+        if (hipMemsetAsync(ws + p.o_seed1, 0, sizeof(int) * (size_t)cfg->B * cfg->N, st) != hipSuccess) return REART_ERR_LAUNCH;
+    }
     if (hipMemsetAsync(ws + p.o_cint, 0, 32 * (size_t)cfg->B * cfg->N, st) != hipSuccess) return REART_ERR_LAUNCH;
     rc = reart_boxes_launch((const float *)(ws + p.o_ysoa), cfg->B, p.Npad, (float *)(ws + p.o_boxY), st);
     if (rc != REART_OK) return rc;
@@ -220,6 +234,7 @@ struct FlowArgs {
     float smooth, lambda;
     float *gpf;                          // [B,N,3]
     double *part;                        // [B][gridDim.x]
+    int *seed_out;                       // nullable [B,N,3]: the 3 neighbour indices, warm start of the next search
 };
 
 __device__ __forceinline__ const float *complete_frame(const FlowArgs &a, int f) {
@@ -249,13 +264,15 @@ __global__ __launch_bounds__(FLOW_BS) void flow_blend_kernel(FlowArgs a) {
             for (int k = 0; k < 3; ++k) {
                 const float d = a.pd[o + k];
                 const int j = a.pi[o + k];
-                if (d < kd[2]) {
+                // full (distance, index) key: slices may interleave index ranges (prune.hip)
+                if (d < INFINITY && (d < kd[2] || (d == kd[2] && j < ki[2]))) {
 #pragma unroll
                     for (int q = 2; q >= 0; --q) {
-                        const bool lp = (q > 0) && (d < kd[q > 0 ? q - 1 : 0]);
-                        const bool lc = d < kd[q];
-                        kd[q] = lp ? kd[q > 0 ? q - 1 : 0] : (lc ? d : kd[q]);
-                        ki[q] = lp ? ki[q > 0 ? q - 1 : 0] : (lc ? j : ki[q]);
+                        const int sp = q > 0 ? q - 1 : 0;
+                        const bool lp = (q > 0) && (d < kd[sp] || (d == kd[sp] && j < ki[sp]));
+                        const bool lc = d < kd[q] || (d == kd[q] && j < ki[q]);
+                        kd[q] = lp ? kd[sp] : (lc ? d : kd[q]);
+                        ki[q] = lp ? ki[sp] : (lc ? j : ki[q]);
                     }
                 }
             }
@@ -289,6 +306,10 @@ __global__ __launch_bounds__(FLOW_BS) void flow_blend_kernel(FlowArgs a) {
                     }
                 }
             }
+        }
+        if (a.seed_out) {
+            int *so = a.seed_out + 3 * ((size_t)f * a.N + n);
+            so[0] = ki[0]; so[1] = ki[1]; so[2] = ki[2];
         }
         const float *rf = a.ref_flow + 3 * (size_t)a.ref_off[f];
         float w[3], wsum = 0.f, dmin = INFINITY, fmx = -INFINITY;
@@ -365,6 +386,7 @@ struct CGradArgs {
     float *G;                            // [B,N,3]: receives the direct term 2 (x_i - y_nn(i))
     long long *acc;                      // [B][N][4]: fixed-point sum of the y's that chose x_j, count
     double *loss_part;                   // [B][gridDim.x]
+    int *seed0, *seed1;                  // nullable [B,N]: the neighbour indices, warm start of the next search
 };
 #define CG_BS 256
 
@@ -386,7 +408,7 @@ __global__ __launch_bounds__(CG_BS) void chamfer_acc_kernel(CGradArgs a) {
             const size_t o = ((size_t)s * a.B + b) * N + i;
             const float e0 = a.pd0[o];
             const int q0 = a.pi0[o];
-            const bool l0 = e0 < d0;
+            const bool l0 = e0 < d0 || (e0 == d0 && q0 < j0);   // full key: slices may interleave index ranges
             d0 = l0 ? e0 : d0; j0 = l0 ? q0 : j0;
         }
 #pragma unroll 4
@@ -394,9 +416,10 @@ __global__ __launch_bounds__(CG_BS) void chamfer_acc_kernel(CGradArgs a) {
             const size_t o = ((size_t)s * a.B + b) * N + i;
             const float e1 = a.pd1[o];
             const int q1 = a.pi1[o];
-            const bool l1 = e1 < d1;
+            const bool l1 = e1 < d1 || (e1 == d1 && q1 < j1);
             d1 = l1 ? e1 : d1; j1 = l1 ? q1 : j1;
         }
+        if (a.seed0) { a.seed0[(size_t)b * N + i] = j0; a.seed1[(size_t)b * N + i] = j1; }
         term = (double)(d0 + d1);  // chamfer_forward + chamfer_backward (utils/chamfer.py:119-123)
         const float yi0 = y[3 * i], yi1 = y[3 * i + 1], yi2 = y[3 * i + 2];
         float *G = a.G + 3 * ((size_t)b * N + i);
@@ -521,7 +544,9 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
             k3.job[1] = kj;
             k3.items0 = B * kj.nqg * p.S3;
             k3.items = k3.items0;
-            rc = reart_knn_launch_slices(k3, 3, fst);
+            kj.seed = p.pruned ? (const int *)(ws + p.o_seed3) : nullptr;
+            k3.job[1] = kj;
+            rc = p.pruned ? reart_knn_launch_pruned(k3, 3, fst) : reart_knn_launch_slices(k3, 3, fst);
             if (rc != REART_OK) return rc;
         }
         MARK(2);
@@ -532,6 +557,7 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
         fl.S = S3; fl.euclidean = c.euclidean; fl.robust = c.robust; fl.cano_idx = c.cano_idx;
         fl.smooth = c.smooth_weight; fl.lambda = c.lambda_flow;
         fl.gpf = (float *)(ws + p.o_gpf); fl.part = (double *)(ws + p.o_fpart);
+        fl.seed_out = p.pruned ? (int *)(ws + p.o_seed3) : nullptr;
         const dim3 fg(reart_div_up(N, FLOW_BS), B);
         nfp = fg.x * fg.y;
         hipLaunchKernelGGL(flow_blend_kernel, fg, dim3(FLOW_BS), 0, fst, fl);
@@ -554,6 +580,7 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
         kj.pd = (float *)(ws + (j == 0 ? p.o_pd0 : p.o_pd1));
         kj.pi = (int *)(ws + (j == 0 ? p.o_pi0 : p.o_pi1));
         kj.boxes = c.use_boxes ? (const float *)(ws + (j == 0 ? p.o_boxY : p.o_boxX)) : nullptr;
+        kj.seed = p.pruned ? (const int *)(ws + (j == 0 ? p.o_seed0 : p.o_seed1)) : nullptr;
     }
     int S0 = p.S1;
     if (c.use_grid) {
@@ -573,7 +600,7 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
         ka.items0 = B * ka.job[0].nqg * p.S1;
         ka.items = 2 * ka.items0;
     }
-    rc = reart_knn_launch_slices(ka, 1, st);
+    rc = p.pruned ? reart_knn_launch_pruned(ka, 1, st) : reart_knn_launch_slices(ka, 1, st);
     if (rc != REART_OK) return rc;
 
     MARK(4);
@@ -587,6 +614,8 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
     cg.N = N; cg.B = B; cg.S0 = S0; cg.S1 = p.S1; cg.G = G;
     cg.acc = (long long *)(ws + p.o_cint);
     cg.loss_part = (double *)(ws + p.o_floss);
+    cg.seed0 = p.pruned ? (int *)(ws + p.o_seed0) : nullptr;
+    cg.seed1 = p.pruned ? (int *)(ws + p.o_seed1) : nullptr;
     const int ncg = reart_div_up(N, CG_BS);
     hipLaunchKernelGGL(chamfer_acc_kernel, dim3(ncg, B), dim3(CG_BS), 0, st, cg);
     REART_CHECK_LAUNCH();
