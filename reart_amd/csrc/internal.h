@@ -31,11 +31,7 @@ struct BaseBwdArgs {
     float tau;
     const float *G;             // [B,N,3]
     const float *rt_table;      // [B*P][12] or NULL (built into the workspace)
-    // fused step only: G holds the direct Chamfer term; the tile load adds the gathered term
-    // 2 (c_j x_j - sum y) from the fixed-point accumulators (and zeroes them) and the flow terms
-    long long *acc;             // [B][N][4] or NULL
-    const int *fx_bits;
-    const float *X;             // pc_trans [B,N,3]
+    // fused step only: the tile load adds the flow-loss terms of the two adjacent frame pairs
     const float *gpf;           // [B,N,3] d(lambda*flow)/d pred_flow or NULL
     int cano_idx;
     int N, P, B, H;

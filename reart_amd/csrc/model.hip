@@ -21,6 +21,15 @@
 #define RED_CHUNK 64    // points per partial-reduction chunk
 
 // ------------------------------------------------------------------------------- helpers
+#ifdef REART_PHASE_CLOCK   // diagnostic build only: shader-clock stamps of workgroup 0 per phase
+__device__ unsigned long long g_phase_ts[2][16];
+extern "C" int reart_debug_phase_clock(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_ts), sizeof(g_phase_ts)) == hipSuccess ? REART_OK : REART_ERR_LAUNCH;
+}
+#define PHASE_TS(which, k) do { if (blockIdx.x == 1 && threadIdx.x == 0) g_phase_ts[which][k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PHASE_TS(which, k) do { } while (0)
+#endif
 __device__ __forceinline__ float dot3f(const float *a, const float *b) {
     return fmaf(a[2], b[2], fmaf(a[1], b[1], a[0] * b[0]));
 }
@@ -148,7 +157,9 @@ __global__ __launch_bounds__(64 * (((PP > 0 ? PP : 32) + FW_PG - 1) / FW_PG)) vo
     float *s_w2T = s_wb + 4 * (size_t)a.H;                // [H][PMAX]  W2 transposed
     float *s_a = s_w2T + (size_t)a.H * PMAX;              // [PMAX][64]  logits, later y
     float *s_e = s_a + PMAX * FW_PTS;                     // [PMAX][64]  z, later exp(z - max)
+    float *s_hh = s_e + PMAX * FW_PTS;                    // [H][64]  hidden activations of the 64 points
     const int tid = threadIdx.x, lane = tid & 63, grp = tid >> 6;
+    PHASE_TS(0, 0);
     const int P = (PP > 0) ? PP : a.P;
     for (int e = tid; e < a.B * a.P; e += BS) {
         float R[9];
@@ -204,19 +215,32 @@ __global__ __launch_bounds__(64 * (((PP > 0 ? PP : 32) + FW_PG - 1) / FW_PG)) vo
         g1 = gumbel_from_bits(r[(p0 & 3) + 1]);   // p0 is even: p0 & 3 in {0, 2}
     }
     __syncthreads();
+    PHASE_TS(0, 1);
+    // hidden layer once per point: wave g evaluates its slice of the H units for the 64 points
+    {
+        const int jq = (a.H + W - 1) / W, j0 = grp * jq, j1 = (j0 + jq < a.H) ? j0 + jq : a.H;
+        for (int j = j0; j < j1; ++j) {
+            const float4 wb = *(const float4 *)(s_wb + 4 * j);
+            float acc = wb.x * x0;
+            acc = fmaf(wb.y, x1, acc);
+            acc = fmaf(wb.z, x2, acc);
+            acc = acc + wb.w;
+            const float h = acc > 0.f ? acc : 0.f;
+            s_hh[j * FW_PTS + lane] = h;
+            if (a.hT && live) a.hT[(size_t)j * a.N + n] = h;
+        }
+    }
+    __syncthreads();
+    // logits of this wave's two parts: the full ascending-j fmaf chain (the oracle's rounding order)
     float sp0 = 0.f, sp1 = 0.f;
 #pragma unroll 8
     for (int j = 0; j < a.H; ++j) {
-        const float4 wb = *(const float4 *)(s_wb + 4 * j);
-        float acc = wb.x * x0;
-        acc = fmaf(wb.y, x1, acc);
-        acc = fmaf(wb.z, x2, acc);
-        acc = acc + wb.w;
-        const float h = acc > 0.f ? acc : 0.f;
-        if (grp == 0 && a.hT && live) a.hT[(size_t)j * a.N + n] = h;
-        sp0 = fmaf(s_w2T[j * PMAX + p0], h, sp0);
-        sp1 = fmaf(s_w2T[j * PMAX + p0 + 1], h, sp1);   // PMAX is even: in range, ignored when !has1
+        const float h = s_hh[j * FW_PTS + lane];
+        const float2 w2 = *(const float2 *)(s_w2T + j * PMAX + p0);   // p0 and PMAX are even
+        sp0 = fmaf(w2.x, h, sp0);
+        sp1 = fmaf(w2.y, h, sp1);   // in range, ignored when !has1
     }
+    PHASE_TS(0, 2);
     const float z0 = (sp0 + g0) / tau, z1 = has1 ? (sp1 + g1) / tau : -INFINITY;
     if (p0 < P) { s_a[p0 * FW_PTS + lane] = sp0; s_e[p0 * FW_PTS + lane] = z0; }
     if (has1) { s_a[(p0 + 1) * FW_PTS + lane] = sp1; s_e[(p0 + 1) * FW_PTS + lane] = z1; }
@@ -247,6 +271,7 @@ __global__ __launch_bounds__(64 * (((PP > 0 ? PP : 32) + FW_PG - 1) / FW_PG)) vo
     if (p0 < P) { s_a[p0 * FW_PTS + lane] = y0; if (a.yT && live) a.yT[(size_t)p0 * a.N + n] = y0; }
     if (has1) { s_a[(p0 + 1) * FW_PTS + lane] = y1; if (a.yT && live) a.yT[(size_t)(p0 + 1) * a.N + n] = y1; }
     __syncthreads();
+    PHASE_TS(0, 3);
     int k = 0;
     float yk = -1.f;
 #pragma unroll
@@ -260,6 +285,7 @@ __global__ __launch_bounds__(64 * (((PP > 0 ? PP : 32) + FW_PG - 1) / FW_PG)) vo
         if (a.seg_part) a.seg_part[n] = am;
         if (a.hard_idx) a.hard_idx[n] = k;
     }
+    PHASE_TS(0, 4);
     for (int t = grp; t < a.B; t += W) {
         float v[3];
         apply_rt(s_rt + 12 * (t * a.P + k), x0, x1, x2, v);
@@ -296,6 +322,7 @@ __global__ __launch_bounds__(64 * (((PP > 0 ? PP : 32) + FW_PG - 1) / FW_PG)) vo
             }
         }
     }
+    PHASE_TS(0, 5);
 }
 
 template <int PP>
@@ -303,13 +330,19 @@ static void launch_base_fwd(const BaseFwdArgs &a, hipStream_t st) {
     constexpr int PMAX = (PP > 0) ? PP : 32;
     constexpr int W = (PMAX + FW_PG - 1) / FW_PG;
     const int cover = a.out_soa ? (a.Npad > a.N ? a.Npad : a.N) : a.N;
-    const size_t lds = sizeof(float) * (12 * (size_t)a.B * a.P + (size_t)a.H * (4 + PMAX) + 2 * (size_t)FW_PTS * PMAX);
+    const size_t lds = sizeof(float) * (12 * (size_t)a.B * a.P + (size_t)a.H * (4 + PMAX) + 2 * (size_t)FW_PTS * PMAX +
+                                        (size_t)a.H * FW_PTS);
+    static bool attr_set = false;  // raise the dynamic-LDS cap once (160 KiB per CU on gfx950)
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)base_fwd_kernel<PP>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+        attr_set = true;
+    }
     hipLaunchKernelGGL((base_fwd_kernel<PP>), dim3(reart_div_up(cover, FW_PTS)), dim3(64 * W), lds, st, a);
 }
 
 static int dispatch_base_fwd(const BaseFwdArgs &a, hipStream_t st) {
     if (a.P < 1 || a.P > 32) return REART_ERR_UNSUPPORTED;
-    if (((size_t)a.B * a.P * 12 + 2 * FW_PTS * 32 + (size_t)a.H * 36) * sizeof(float) > 64 * 1024) return REART_ERR_UNSUPPORTED;
+    if (((size_t)a.B * a.P * 12 + 2 * FW_PTS * 32 + (size_t)a.H * (36 + FW_PTS)) * sizeof(float) > 152 * 1024) return REART_ERR_UNSUPPORTED;
     switch (a.P) {
         case 20: launch_base_fwd<20>(a, st); break;
         case 10: launch_base_fwd<10>(a, st); break;
@@ -390,47 +423,33 @@ __global__ __launch_bounds__(64 * (((PP > 0 ? PP : 32) + FW_PG - 1) / FW_PG)) vo
     int *s_seg = s_ord + RED_CHUNK;                  // [PMAX + 1] segment starts in s_ord
     float *s_G = (float *)(s_seg + PMAX + 4);        // [B][RED_CHUNK*3]  upstream gradient tile
     float *s_w2T = s_G + (size_t)a.B * RED_CHUNK * 3;// [H][PMAX]
+    float *s_rt = s_w2T + (size_t)a.H * PMAX;        // [B*P][12]  [R|t] rows
     const int tid = threadIdx.x, lane = tid & 63, grp = tid >> 6, chunk = blockIdx.x;
     const int n0 = chunk * RED_CHUNK;
     const int cn = (a.N - n0) < RED_CHUNK ? (a.N - n0) : RED_CHUNK;
     float *prow = a.partial + (size_t)chunk * n_out(a.P, a.H, a.B);
+    PHASE_TS(1, 0);
 
     for (int e = tid; e < a.H * RED_CHUNK; e += BS) {
         const int j = e >> 6, i = e & 63;            // RED_CHUNK == 64
         s_h[j * BW_LD + i] = (i < cn) ? a.hT[(size_t)j * a.N + n0 + i] : 0.f;
     }
-    if (!a.acc) {
-        for (int e = tid; e < a.B * RED_CHUNK * 3; e += BS) {
-            const int t = e / (RED_CHUNK * 3), r = e % (RED_CHUNK * 3);
-            s_G[e] = (r < 3 * cn) ? a.G[3 * ((size_t)t * a.N + n0) + r] : 0.f;
-        }
-    } else {
-        // fused step: complete the upstream gradient on the fly.  G already holds 2 (x - y_nn(x));
-        // add the gathered term 2 (c x - sum of the y's that chose x) from the fixed-point
-        // accumulators (consumed and reset here) and the flow-loss terms of the two adjacent pairs.
-        const double inv = exp2((double)-a.fx_bits[0]);
-        for (int e = tid; e < a.B * RED_CHUNK; e += BS) {
-            const int t = e >> 6, i = e & 63;
-            float g[3] = {0.f, 0.f, 0.f};
-            if (i < cn) {
-                const size_t pt = (size_t)t * a.N + n0 + i;
-                long long *ac = a.acc + 4 * pt;
+    // upstream gradient tile; the fused step adds the flow-loss terms of the two adjacent pairs here
+    // (complete frame fc = t or t + 1: + d/d pred_flow of pair fc - 1, - d/d pred_flow of pair fc)
+    for (int e = tid; e < a.B * RED_CHUNK * 3; e += BS) {
+        const int t = e / (RED_CHUNK * 3), r = e - t * (RED_CHUNK * 3);
+        float g = 0.f;
+        if (r < 3 * cn) {
+            g = a.G[3 * ((size_t)t * a.N + n0) + r];
+            if (a.gpf) {
                 const int fc = t < a.cano_idx ? t : t + 1;   // complete-sequence index of frame t
-                const float *gh = (a.gpf && fc - 1 >= 0) ? a.gpf + 3 * ((size_t)(fc - 1) * a.N + n0 + i) : nullptr;
-                const float *gl = (a.gpf && fc <= a.B - 1) ? a.gpf + 3 * ((size_t)fc * a.N + n0 + i) : nullptr;
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    g[k] = a.G[3 * pt + k] + (float)(2.0 * ((double)ac[k] * inv));   // 2 sum (x - y_i)
-                    if (gh) g[k] += gh[k];
-                    if (gl) g[k] -= gl[k];
-                    ac[k] = 0;
-                }
+                if (fc - 1 >= 0) g += a.gpf[3 * ((size_t)(fc - 1) * a.N + n0) + r];
+                if (fc <= a.B - 1) g -= a.gpf[3 * ((size_t)fc * a.N + n0) + r];
             }
-            s_G[t * (RED_CHUNK * 3) + 3 * i] = g[0];
-            s_G[t * (RED_CHUNK * 3) + 3 * i + 1] = g[1];
-            s_G[t * (RED_CHUNK * 3) + 3 * i + 2] = g[2];
         }
+        s_G[e] = g;
     }
+    for (int e = tid; e < a.B * a.P * 12; e += BS) s_rt[e] = a.rt_table[e];
     for (int j = tid; j < a.H; j += BS)
         for (int p = 0; p < P; ++p) s_w2T[j * PMAX + p] = a.W2[(size_t)p * a.H + j];
     const bool live = lane < cn;
@@ -456,16 +475,17 @@ __global__ __launch_bounds__(64 * (((PP > 0 ? PP : 32) + FW_PG - 1) / FW_PG)) vo
     const int p0 = grp * FW_PG;
     const bool has0 = p0 < P, has1 = p0 + 1 < P;
     __syncthreads();
+    PHASE_TS(1, 1);
     if (has0) {
 #pragma unroll 2
         for (int t = 0; t < a.B; ++t) {
             const float *g = s_G + t * (RED_CHUNK * 3) + 3 * lane;
             const float gv[3] = {g[0], g[1], g[2]};
             float v[3];
-            apply_rt(a.rt_table + 12 * ((size_t)t * a.P + p0), x0, x1, x2, v);
+            apply_rt(s_rt + 12 * (t * a.P + p0), x0, x1, x2, v);
             dw0 += dot3f(gv, v);
             if (has1) {
-                apply_rt(a.rt_table + 12 * ((size_t)t * a.P + p0 + 1), x0, x1, x2, v);
+                apply_rt(s_rt + 12 * (t * a.P + p0 + 1), x0, x1, x2, v);
                 dw1 += dot3f(gv, v);
             }
         }
@@ -473,6 +493,7 @@ __global__ __launch_bounds__(64 * (((PP > 0 ? PP : 32) + FW_PG - 1) / FW_PG)) vo
         if (has1) s_ds[(p0 + 1) * BW_LD + lane] = dw1;
     }
     __syncthreads();
+    PHASE_TS(1, 2);
     // b. softmax backward: dot over all parts in ascending order, ds for this wave's parts
     const float tau = a.tau_ptr ? a.tau_ptr[0] : a.tau;
     float dot = 0.f;
@@ -486,33 +507,50 @@ __global__ __launch_bounds__(64 * (((PP > 0 ? PP : 32) + FW_PG - 1) / FW_PG)) vo
     if (has0) s_ds[p0 * BW_LD + lane] = live ? ds0 : 0.f;
     if (has1) s_ds[(p0 + 1) * BW_LD + lane] = live ? ds1 : 0.f;
     __syncthreads();
-    // c1. gW2 partial from (ds, h)
-    for (int o = tid; o < a.P * a.H; o += BS) {
-        const int p = o / a.H, j = o - p * a.H;
-        float acc = 0.f;
+    PHASE_TS(1, 3);
+    // c1. gW2[p,j] = sum_i ds[p,i] h[j,i] on the matrix cores: v_mfma_f32_32x32x2_f32 is bit for bit the
+    // ascending-i fmaf chain (cdna guide section 3).  One 32 (parts) x 32 (hidden) tile per wave.
+    for (int tile = grp; tile * 32 < a.H; tile += W) {
+        typedef float f16v __attribute__((ext_vector_type(16)));
+        f16v c = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const int pr = lane & 31, jc = tile * 32 + (lane & 31), kh = lane >> 5;
+        const float *ap = s_ds + (pr < P ? pr : 0) * BW_LD + kh;
+        const float *bp = s_h + (jc < a.H ? jc : 0) * BW_LD + kh;
+        const bool aok = pr < P, bok = jc < a.H;
 #pragma unroll 8
-        for (int i = 0; i < RED_CHUNK; ++i) acc = fmaf(s_ds[p * BW_LD + i], s_h[j * BW_LD + i], acc);
-        prow[off_gW2() + o] = acc;
-    }
-    // c2. gR | gt: thread (t, entry c) walks every part's points (ascending n) with a register
-    for (int o = tid; o < a.B * 12; o += BS) {
-        const int t = o / 12, c = o - t * 12;
-        const float *gt_ = s_G + t * (RED_CHUNK * 3);
-        for (int p = 0; p < P; ++p) {
-            float acc = 0.f;
-            for (int q = s_seg[p]; q < s_seg[p + 1]; ++q) {
-                const int i = s_ord[q];
-                if (c < 9) acc += (s_w[i] * gt_[3 * i + c / 3]) * s_x[3 * i + c % 3];
-                else acc += s_w[i] * gt_[3 * i + c - 9];
-            }
-            prow[off_gRt(a.P, a.H) + (t * a.P + p) * 12 + c] = acc;
+        for (int kk = 0; kk < RED_CHUNK; kk += 2) {
+            const float av = aok ? ap[kk] : 0.f;
+            const float bv = bok ? bp[kk] : 0.f;
+            c = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, c, 0, 0, 0);
+        }
+        // C/D layout: row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5), col = lane & 31
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int prow_p = (reg & 3) + 8 * (reg >> 2) + 4 * kh;
+            if (prow_p < P && bok) prow[off_gW2() + prow_p * a.H + jc] = c[reg];
         }
     }
+    PHASE_TS(1, 4);
+    // c2. gR | gt: thread (t, p, entry c) walks its part's points (ascending n) with a register
+    for (int o = tid; o < a.B * a.P * 12; o += BS) {
+        const int tp = o / 12, c = o - tp * 12;
+        const int t = tp / a.P, p = tp - t * a.P;
+        const float *gt_ = s_G + t * (RED_CHUNK * 3);
+        float acc = 0.f;
+        for (int q = s_seg[p]; q < s_seg[p + 1]; ++q) {
+            const int i = s_ord[q];
+            if (c < 9) acc += (s_w[i] * gt_[3 * i + c / 3]) * s_x[3 * i + c % 3];
+            else acc += s_w[i] * gt_[3 * i + c - 9];
+        }
+        prow[off_gRt(a.P, a.H) + o] = acc;
+    }
+    PHASE_TS(1, 5);
     // every lane needs all ds of its point for the hidden gradient
     float dsr[PMAX];
 #pragma unroll
     for (int p = 0; p < PMAX; ++p) dsr[p] = (PP > 0 || p < P) ? s_ds[p * BW_LD + lane] : 0.f;
     __syncthreads();  // the h tile and ds have been consumed by c1
+    PHASE_TS(1, 6);
     // b'. dp[n,j] = relu'(h) * sum_p W2[p,j] ds[p], written over the h tile
     const int jq = (a.H + W - 1) / W, j0 = grp * jq, j1 = (j0 + jq < a.H) ? j0 + jq : a.H;
     for (int j = j0; j < j1; ++j) {
@@ -524,6 +562,7 @@ __global__ __launch_bounds__(64 * (((PP > 0 ? PP : 32) + FW_PG - 1) / FW_PG)) vo
         s_h[j * BW_LD + lane] = (live && h > 0.f) ? dh : 0.f;
     }
     __syncthreads();
+    PHASE_TS(1, 7);
     // c3. gW1 / gb1 partial from (dp, x)
     for (int o = tid; o < 4 * a.H; o += BS) {
         const int j = o >> 2, c = o & 3;
@@ -538,6 +577,7 @@ __global__ __launch_bounds__(64 * (((PP > 0 ? PP : 32) + FW_PG - 1) / FW_PG)) vo
             prow[off_gb1(a.P, a.H) + j] = acc;
         }
     }
+    PHASE_TS(1, 8);
 }
 
 // (2) sum the chunk partials in ascending chunk order; Gram-Schmidt backward for the
@@ -694,7 +734,7 @@ int reart_base_backward_ex(BaseBwdArgs a, const FinalizeAdam *adam, void *worksp
     }
     const int PMAX = (a.P == 20 || a.P == 10 || a.P == 8) ? a.P : 32;
     const size_t lds = sizeof(float) * ((size_t)(a.H + PMAX) * BW_LD + RED_CHUNK * 5 + PMAX + 4 +
-                                        (size_t)a.B * RED_CHUNK * 3 + (size_t)a.H * PMAX);
+                                        (size_t)a.B * RED_CHUNK * 3 + (size_t)a.H * PMAX + 12 * (size_t)a.B * a.P);
     if (lds > 152 * 1024) return REART_ERR_UNSUPPORTED;
     int rc;
     switch (a.P) {

@@ -19,7 +19,7 @@ struct StepPlan {
     int nchunk, nparams;
     size_t o_ysoa, o_xsoa, o_rsoa, o_rlen, o_qmap;
     size_t o_pd0, o_pi0, o_pd1, o_pi1, o_pd3, o_pi3;
-    size_t o_yT, o_hT, o_hard, o_rt, o_G, o_gpf, o_cint, o_fx, o_floss, o_fpart, o_grads, o_bwd;
+    size_t o_yT, o_hT, o_hard, o_rt, o_G, o_gpf, o_fx, o_floss, o_fpart, o_grads, o_bwd;
     size_t o_bc;              // Adam bias corrections of the coming step (double[2])
     size_t o_boxY, o_boxX, o_boxR;  // AABBs of every NN_BOX targets (block-skip test)
     int pruned;               // box-pruned, warm-started search (prune.hip) instead of the slice kernels
@@ -36,6 +36,9 @@ static size_t take(size_t &off, size_t bytes) {
 }
 
 #define FLOW_BS 256
+#define CG_BS 1024
+#define CG_RANGE 1024   // targets x_j owned by one workgroup of chamfer_grad_kernel
+static_assert(CG_BS == CG_RANGE, "chamfer_grad_kernel: thread tid owns target r0 + tid");
 
 static int step_plan(const reart_relax_config *c, StepPlan *p) {
     if (c->N <= 0 || c->P <= 0 || c->P > 32 || c->B <= 0 || c->H <= 0) return REART_ERR_INVALID_ARG;
@@ -72,9 +75,8 @@ static int step_plan(const reart_relax_config *c, StepPlan *p) {
     p->o_rt = take(off, sizeof(float) * 12 * (size_t)c->B * c->P);
     p->o_G = take(off, sizeof(float) * 3 * BN);
     p->o_gpf = take(off, sizeof(float) * 3 * BN);
-    p->o_cint = take(off, 32 * BN);          // per point: 3 x int64 fixed-point sums + count (+pad)
     p->o_fx = take(off, sizeof(double));
-    p->o_floss = take(off, sizeof(double) * (size_t)c->B * reart_div_up(c->N, 256));
+    p->o_floss = take(off, sizeof(double) * (size_t)c->B * reart_div_up(c->N, CG_RANGE));
     p->o_fpart = take(off, sizeof(double) * (size_t)c->B * reart_div_up(c->N, FLOW_BS));
     p->o_grads = take(off, sizeof(float) * p->nparams);
     p->bwd_bytes = reart_base_backward_workspace_bytes(c->N, c->P, c->B, c->H);
@@ -193,7 +195,6 @@ extern "C" int reart_relax_prepare(const reart_relax_config *cfg, const reart_re
         if (hipMemsetAsync(ws + p.o_seed0, 0, sizeof(int) * (size_t)cfg->B * cfg->N, st) != hipSuccess) return REART_ERR_LAUNCH;
         if (hipMemsetAsync(ws + p.o_seed1, 0, sizeof(int) * (size_t)cfg->B * cfg->N, st) != hipSuccess) return REART_ERR_LAUNCH;
     }
-    if (hipMemsetAsync(ws + p.o_cint, 0, 32 * (size_t)cfg->B * cfg->N, st) != hipSuccess) return REART_ERR_LAUNCH;
     rc = reart_boxes_launch((const float *)(ws + p.o_ysoa), cfg->B, p.Npad, (float *)(ws + p.o_boxY), st);
     if (rc != REART_OK) return rc;
     if (cfg->use_grid) {
@@ -251,31 +252,46 @@ __device__ __forceinline__ float huber1s_grad(float x) {
     return fabsf(x) <= 1.0f ? x : (x > 0.f ? 1.0f : -1.0f);
 }
 
+// branch-free insertion of key (d, j) into an ascending top-3 list ordered by (distance, index)
+__device__ __forceinline__ void top3_insert(float (&kd)[3], int (&ki)[3], float d, int j) {
+    const bool l0 = (d < kd[0]) | ((d == kd[0]) & (j < ki[0]));
+    const bool l1 = (d < kd[1]) | ((d == kd[1]) & (j < ki[1]));
+    const bool l2 = (d < kd[2]) | ((d == kd[2]) & (j < ki[2]));
+    kd[2] = l1 ? kd[1] : (l2 ? d : kd[2]);
+    ki[2] = l1 ? ki[1] : (l2 ? j : ki[2]);
+    kd[1] = l0 ? kd[0] : (l1 ? d : kd[1]);
+    ki[1] = l0 ? ki[0] : (l1 ? j : ki[1]);
+    kd[0] = l0 ? d : kd[0];
+    ki[0] = l0 ? j : ki[0];
+}
+
+template <bool ONE>   // ONE: S <= 4 -- every partial of a query is loaded before the first compare
 __global__ __launch_bounds__(FLOW_BS) void flow_blend_kernel(FlowArgs a) {
     __shared__ double s_red[FLOW_BS / REART_WAVE];
     const int f = blockIdx.y, n = blockIdx.x * FLOW_BS + threadIdx.x;
     double term = 0.0;
     if (n < a.N) {
+        // the kernel is a chain of dependent gathers (partials -> blocks -> reference flows): every
+        // stage issues all of its loads first and then reduces them without branches
         float kd[3] = {INFINITY, INFINITY, INFINITY};
-        int ki[3] = {a.blocks ? -1 : 0, a.blocks ? -1 : 0, a.blocks ? -1 : 0};
-        for (int s = 0; s < a.S; ++s) {
-            const size_t o = (((size_t)s * a.B + f) * a.N + n) * 3;
+        int ki[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff};
+        const size_t stride = (size_t)a.B * a.N * 3, o0 = ((size_t)f * a.N + n) * 3;
+        for (int s0 = 0; s0 < (ONE ? 1 : a.S); s0 += 4) {
+            float e[4][3];
+            int q[4][3];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const float d = a.pd[o + k];
-                const int j = a.pi[o + k];
-                // full (distance, index) key: slices may interleave index ranges (prune.hip)
-                if (d < INFINITY && (d < kd[2] || (d == kd[2] && j < ki[2]))) {
+            for (int u = 0; u < 4; ++u) {
+                const bool ok = s0 + u < a.S;
+                const size_t o = o0 + (size_t)(ok ? s0 + u : 0) * stride;
 #pragma unroll
-                    for (int q = 2; q >= 0; --q) {
-                        const int sp = q > 0 ? q - 1 : 0;
-                        const bool lp = (q > 0) && (d < kd[sp] || (d == kd[sp] && j < ki[sp]));
-                        const bool lc = d < kd[q] || (d == kd[q] && j < ki[q]);
-                        kd[q] = lp ? kd[sp] : (lc ? d : kd[q]);
-                        ki[q] = lp ? ki[sp] : (lc ? j : ki[q]);
-                    }
-                }
+                for (int k = 0; k < 3; ++k) { e[u][k] = a.pd[o + k]; q[u][k] = a.pi[o + k]; }
+                if (!ok) { e[u][0] = INFINITY; e[u][1] = INFINITY; e[u][2] = INFINITY; }
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int k = 0; k < 3; ++k)   // (INF, x) never enters: INF < INF is false and ids of real entries are smaller
+                    top3_insert(kd, ki, e[u][k], e[u][k] < INFINITY ? q[u][k] : 0x7fffffff);
         }
         const float *c0q = complete_frame(a, f) + 3 * (size_t)n;
         if (a.blocks) {
@@ -283,35 +299,51 @@ __global__ __launch_bounds__(FLOW_BS) void flow_blend_kernel(FlowArgs a) {
             // targets lie inside them: one exact rescan of 24 targets with the full (d, index) key
             const float qx = c0q[0], qy = c0q[1], qz = c0q[2];
             const float *tx = a.rsoa + (size_t)f * 3 * a.Mpad, *ty = tx + a.Mpad, *tz = ty + a.Mpad;
-            int bb[3] = {ki[0], ki[1], ki[2]};
-#pragma unroll
-            for (int k = 0; k < 3; ++k) { kd[k] = INFINITY; ki[k] = 0; }
+            int bb[3];
+            float4 X[3][2], Y[3][2], Z[3][2];
 #pragma unroll
             for (int cb = 0; cb < 3; ++cb) {
-                const int blk = bb[cb];
-                if (blk < 0) continue;
+                bb[cb] = (kd[cb] < INFINITY) ? ki[cb] : -1;
+                const int blk = bb[cb] < 0 ? 0 : bb[cb];          // blocks are 8-aligned: two 16-byte loads per axis
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    X[cb][h] = *(const float4 *)(tx + blk + 4 * h);
+                    Y[cb][h] = *(const float4 *)(ty + blk + 4 * h);
+                    Z[cb][h] = *(const float4 *)(tz + blk + 4 * h);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { kd[k] = INFINITY; ki[k] = 0x7fffffff; }
+#pragma unroll
+            for (int cb = 0; cb < 3; ++cb) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const int jj = blk + u;
-                    const float d = reart_sqdist3(qx, qy, qz, tx[jj], ty[jj], tz[jj]);
-                    if (d < kd[2] || (d == kd[2] && d < INFINITY && jj < ki[2])) {
-#pragma unroll
-                        for (int q = 2; q >= 0; --q) {
-                            const int sp = q > 0 ? q - 1 : 0;
-                            const bool lp = (q > 0) && (d < kd[sp] || (d == kd[sp] && jj < ki[sp]));
-                            const bool lc = d < kd[q] || (d == kd[q] && jj < ki[q]);
-                            kd[q] = lp ? kd[sp] : (lc ? d : kd[q]);
-                            ki[q] = lp ? ki[sp] : (lc ? jj : ki[q]);
-                        }
-                    }
+                    const float4 vx = X[cb][u >> 2], vy = Y[cb][u >> 2], vz = Z[cb][u >> 2];
+                    const int c = u & 3;
+                    const float px = c == 0 ? vx.x : (c == 1 ? vx.y : (c == 2 ? vx.z : vx.w));
+                    const float py = c == 0 ? vy.x : (c == 1 ? vy.y : (c == 2 ? vy.z : vy.w));
+                    const float pz = c == 0 ? vz.x : (c == 1 ? vz.y : (c == 2 ? vz.z : vz.w));
+                    float d = reart_sqdist3(qx, qy, qz, px, py, pz);
+                    if (bb[cb] < 0) d = INFINITY;
+                    top3_insert(kd, ki, d, d < INFINITY ? bb[cb] + u : 0x7fffffff);
                 }
             }
         }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) ki[k] = ki[k] == 0x7fffffff ? 0 : ki[k];   // fewer than 3 finite candidates
         if (a.seed_out) {
             int *so = a.seed_out + 3 * ((size_t)f * a.N + n);
             so[0] = ki[0]; so[1] = ki[1]; so[2] = ki[2];
         }
         const float *rf = a.ref_flow + 3 * (size_t)a.ref_off[f];
+        float rfl[3][3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) rfl[k][c] = rf[3 * (size_t)ki[k] + c];
+        const float *c0 = complete_frame(a, f) + 3 * (size_t)n;
+        const float *c1 = complete_frame(a, f + 1) + 3 * (size_t)n;
+        const float c0v[3] = {c0[0], c0[1], c0[2]}, c1v[3] = {c1[0], c1[1], c1[2]};
         float w[3], wsum = 0.f, dmin = INFINITY, fmx = -INFINITY;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -320,24 +352,20 @@ __global__ __launch_bounds__(FLOW_BS) void flow_blend_kernel(FlowArgs a) {
             w[k] = 1.0f / d;
             wsum += w[k];
             dmin = fminf(dmin, d);
-            const float *fl = rf + 3 * (size_t)ki[k];
-            fmx = fmaxf(fmx, (fl[0] * fl[0] + fl[1] * fl[1]) + fl[2] * fl[2]);
+            fmx = fmaxf(fmx, (rfl[k][0] * rfl[k][0] + rfl[k][1] * rfl[k][1]) + rfl[k][2] * rfl[k][2]);
         }
         float gtf[3] = {0.f, 0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const float wn = w[k] / wsum;
-            const float *fl = rf + 3 * (size_t)ki[k];
-            gtf[0] += fl[0] * wn; gtf[1] += fl[1] * wn; gtf[2] += fl[2] * wn;
+            gtf[0] += rfl[k][0] * wn; gtf[1] += rfl[k][1] * wn; gtf[2] += rfl[k][2] * wn;
         }
         const bool m = (dmin <= fmx) || (dmin <= 0.05f);
-        const float *c0 = complete_frame(a, f) + 3 * (size_t)n;
-        const float *c1 = complete_frame(a, f + 1) + 3 * (size_t)n;
         float fl = 0.f, sm = 0.f;
         float *go = a.gpf + 3 * ((size_t)f * a.N + n);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float p = c1[c] - c0[c];  // pred_flow (run_robot.py:207)
+            const float p = c1v[c] - c0v[c];  // pred_flow (run_robot.py:207)
             const float d = p - gtf[c];
             fl += a.robust ? huber1s(d) : d * d;
             sm += p * p;
@@ -383,62 +411,117 @@ struct CGradArgs {
     const float *pd1; const int *pi1;    // y -> x partials
     const int *fx_bits;                  // device scalar: fractional bits of the fixed-point sums
     int N, B, S0, S1;                    // slices of the x->y / y->x partial lists
-    float *G;                            // [B,N,3]: receives the direct term 2 (x_i - y_nn(i))
-    long long *acc;                      // [B][N][4]: fixed-point sum of the y's that chose x_j, count
+    float *G;                            // [B,N,3]: d recon / d pc_trans (both directions)
     double *loss_part;                   // [B][gridDim.x]
     int *seed0, *seed1;                  // nullable [B,N]: the neighbour indices, warm start of the next search
 };
-#define CG_BS 256
+// Workgroup (r, b) owns the targets x_j, j in [r*CG_RANGE, (r+1)*CG_RANGE), of frame b:
+//   1. it walks ALL observed points y_i of the frame (merging their slice partials), and adds the
+//      difference (x_j - y_i) of those that chose one of its targets to that target's 64-bit
+//      fixed-point sum in LDS (integer atomics: exact, order-independent -> deterministic);
+//   2. for its own range it merges the x -> y partials, and writes the complete gradient
+//      G[b,j] = 2 (x_j - y_nn(j)) + 2 sum_{i: nn(i) = j} (x_j - y_i), the loss terms and the seeds.
+// No global atomics, no accumulator buffer to clear.
+// Smallest (distance, index) key over the S slice partials of one query.  All loads of a batch of
+// four slices are issued before the first compare, and the compare is branch-free: the partial lists
+// come straight from the search kernel, so this is a chain of L2 round trips if written naively.
+template <bool ONE>   // ONE: S <= 4, a single batch (no loop: independent merges interleave)
+__device__ __forceinline__ void merge_slices(const float *__restrict__ pd, const int *__restrict__ pi, int S,
+                                             size_t stride, size_t o0, int nmax, float &d, int &j) {
+    d = INFINITY; j = 0x7fffffff;
+    for (int s0 = 0; s0 < (ONE ? 1 : S); s0 += 4) {
+        float e[4];
+        int q[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const size_t o = o0 + (size_t)(s0 + u < S ? s0 + u : S - 1) * stride;   // duplicates change nothing
+            e[u] = pd[o]; q[u] = pi[o];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool l = (e[u] < d) | ((e[u] == d) & (q[u] < j));
+            d = l ? e[u] : d; j = l ? q[u] : j;
+        }
+    }
+    j = j < 0 ? 0 : (j >= nmax ? nmax - 1 : j);   // in range whatever the inputs (NaN clouds)
+}
 
-// Fully parallel over (frame, point): merge, loss term, direct gradient term, and the
-// order-independent scatter of y_i into its nearest x's accumulator (global integer atomics).
-// The accumulators are consumed -- and reset to zero -- by the backward kernel's G-tile load
-// (model.hip), which adds 2 (c_j x_j - sum y) and the flow terms on the fly.
-__global__ __launch_bounds__(CG_BS) void chamfer_acc_kernel(CGradArgs a) {
+template <bool ONE>
+__global__ __launch_bounds__(CG_BS) void chamfer_grad_kernel(CGradArgs a) {
+    __shared__ unsigned long long s_acc[CG_RANGE * 3];
     __shared__ double s_red[CG_BS / REART_WAVE];
     const int b = blockIdx.y, tid = threadIdx.x, N = a.N;
-    const int i = blockIdx.x * CG_BS + tid;
+    const int r0 = blockIdx.x * CG_RANGE;
+    const float *x = a.X + (size_t)b * N * 3, *y = a.Y + (size_t)b * N * 3;
+    const size_t stride = (size_t)a.B * N, ob = (size_t)b * N;
+    for (int e = tid; e < CG_RANGE * 3; e += CG_BS) s_acc[e] = 0ull;
+    const int sbits = a.fx_bits[0];
+    // own target: x -> y partials (loads issued before the barrier)
+    const int io = r0 + tid;
+    float d0 = INFINITY;
+    int j0 = 0;
+    if (io < N) merge_slices<ONE>(a.pd0, a.pi0, a.S0, stride, ob + io, N, d0, j0);
+    __syncthreads();
+    float d1own = 0.f;
+    constexpr int IL = 4;   // observed points in flight per thread
+    for (int ib = tid; ib < N; ib += IL * CG_BS) {
+        float d1[IL];
+        int j1[IL];
+#pragma unroll
+        for (int u = 0; u < IL; ++u) {
+            const int i = ib + u * CG_BS;
+            merge_slices<ONE>(a.pd1, a.pi1, a.S1, stride, ob + (i < N ? i : N - 1), N, d1[u], j1[u]);   // no branch: 4 merges in flight
+        }
+        float df[IL][3];
+#pragma unroll
+        for (int u = 0; u < IL; ++u) {
+            const int i = ib + u * CG_BS;
+            const int ic = i < N ? i : N - 1;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) df[u][k] = x[3 * j1[u] + k] - y[3 * ic + k];
+        }
+#pragma unroll
+        for (int u = 0; u < IL; ++u) {
+            const int i = ib + u * CG_BS;
+            if (i >= N) continue;
+            if (i == io) {   // this thread's own point
+                d1own = d1[u];
+                if (a.seed1) a.seed1[ob + i] = j1[u];
+            }
+            const int jl = j1[u] - r0;
+            if (jl >= 0 && jl < CG_RANGE) {
+                // y_i chose x_{j1}: differences are small, so they are also the better-conditioned
+                // quantity to accumulate
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    atomicAdd(&s_acc[3 * jl + k], (unsigned long long)fixed_from_float(df[u][k], sbits));
+            }
+        }
+    }
+    float yn[3] = {0.f, 0.f, 0.f}, xo[3] = {0.f, 0.f, 0.f};
+    if (io < N) {
+        if (a.seed0) a.seed0[ob + io] = j0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { yn[k] = y[3 * j0 + k]; xo[k] = x[3 * io + k]; }
+    }
+    __syncthreads();
     double term = 0.0;
-    if (i < N) {
-        const float *x = a.X + (size_t)b * N * 3, *y = a.Y + (size_t)b * N * 3;
-        float d0 = INFINITY, d1 = INFINITY;
-        int j0 = 0, j1 = 0;
-#pragma unroll 4
-        for (int s = 0; s < a.S0; ++s) {
-            const size_t o = ((size_t)s * a.B + b) * N + i;
-            const float e0 = a.pd0[o];
-            const int q0 = a.pi0[o];
-            const bool l0 = e0 < d0 || (e0 == d0 && q0 < j0);   // full key: slices may interleave index ranges
-            d0 = l0 ? e0 : d0; j0 = l0 ? q0 : j0;
-        }
-#pragma unroll 4
-        for (int s = 0; s < a.S1; ++s) {
-            const size_t o = ((size_t)s * a.B + b) * N + i;
-            const float e1 = a.pd1[o];
-            const int q1 = a.pi1[o];
-            const bool l1 = e1 < d1 || (e1 == d1 && q1 < j1);
-            d1 = l1 ? e1 : d1; j1 = l1 ? q1 : j1;
-        }
-        if (a.seed0) { a.seed0[(size_t)b * N + i] = j0; a.seed1[(size_t)b * N + i] = j1; }
-        term = (double)(d0 + d1);  // chamfer_forward + chamfer_backward (utils/chamfer.py:119-123)
-        const float yi0 = y[3 * i], yi1 = y[3 * i + 1], yi2 = y[3 * i + 2];
-        float *G = a.G + 3 * ((size_t)b * N + i);
-        G[0] = 2.0f * (x[3 * i] - y[3 * j0]);
-        G[1] = 2.0f * (x[3 * i + 1] - y[3 * j0 + 1]);
-        G[2] = 2.0f * (x[3 * i + 2] - y[3 * j0 + 2]);
-        // y_i chose x_{j1}: add the difference (x_{j1} - y_i) to that target's fixed-point sum
-        // (3 integer atomics per point; differences are small, so they are also the better-conditioned
-        // quantity to accumulate)
-        const int sbits = a.fx_bits[0];
-        unsigned long long *t = (unsigned long long *)(a.acc + 4 * ((size_t)b * N + j1));
-        atomicAdd(t + 0, (unsigned long long)fixed_from_float(x[3 * j1] - yi0, sbits));
-        atomicAdd(t + 1, (unsigned long long)fixed_from_float(x[3 * j1 + 1] - yi1, sbits));
-        atomicAdd(t + 2, (unsigned long long)fixed_from_float(x[3 * j1 + 2] - yi2, sbits));
+    if (io < N) {
+        term = (double)(d0 + d1own);  // chamfer_forward + chamfer_backward (utils/chamfer.py:119-123)
+        const double inv2 = 2.0 * exp2((double)-sbits);
+        float *G = a.G + 3 * (ob + io);
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            G[k] = 2.0f * (xo[k] - yn[k]) + (float)((double)(long long)s_acc[3 * tid + k] * inv2);
     }
     term = reart_wave_sum_d(term);
     if ((tid & 63) == 0) s_red[tid >> 6] = term;
     __syncthreads();
-    if (tid == 0) a.loss_part[(size_t)b * gridDim.x + blockIdx.x] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    if (tid == 0) {
+        double t = 0.0;
+        for (int w = 0; w < CG_BS / REART_WAVE; ++w) t += s_red[w];
+        a.loss_part[(size_t)b * gridDim.x + blockIdx.x] = t;
+    }
 }
 
 // ------------------------------------------------------------------------------ bookkeeping
@@ -560,7 +643,8 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
         fl.seed_out = p.pruned ? (int *)(ws + p.o_seed3) : nullptr;
         const dim3 fg(reart_div_up(N, FLOW_BS), B);
         nfp = fg.x * fg.y;
-        hipLaunchKernelGGL(flow_blend_kernel, fg, dim3(FLOW_BS), 0, fst, fl);
+        if (fl.S <= 4) hipLaunchKernelGGL(flow_blend_kernel<true>, fg, dim3(FLOW_BS), 0, fst, fl);
+        else hipLaunchKernelGGL(flow_blend_kernel<false>, fg, dim3(FLOW_BS), 0, fst, fl);
     }
 
     if (forked && hipEventRecord((hipEvent_t)bufs->ev_join, fst) != hipSuccess) return REART_ERR_LAUNCH;
@@ -612,12 +696,12 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
     cg.pd1 = (const float *)(ws + p.o_pd1); cg.pi1 = (const int *)(ws + p.o_pi1);
     cg.fx_bits = (const int *)(ws + p.o_fx);
     cg.N = N; cg.B = B; cg.S0 = S0; cg.S1 = p.S1; cg.G = G;
-    cg.acc = (long long *)(ws + p.o_cint);
     cg.loss_part = (double *)(ws + p.o_floss);
     cg.seed0 = p.pruned ? (int *)(ws + p.o_seed0) : nullptr;
     cg.seed1 = p.pruned ? (int *)(ws + p.o_seed1) : nullptr;
-    const int ncg = reart_div_up(N, CG_BS);
-    hipLaunchKernelGGL(chamfer_acc_kernel, dim3(ncg, B), dim3(CG_BS), 0, st, cg);
+    const int ncg = reart_div_up(N, CG_RANGE);
+    if (cg.S0 <= 4 && cg.S1 <= 4) hipLaunchKernelGGL(chamfer_grad_kernel<true>, dim3(ncg, B), dim3(CG_BS), 0, st, cg);
+    else hipLaunchKernelGGL(chamfer_grad_kernel<false>, dim3(ncg, B), dim3(CG_BS), 0, st, cg);
     REART_CHECK_LAUNCH();
     MARK(5);
 
@@ -629,7 +713,7 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
     BaseBwdArgs ba = {};
     ba.cano = bufs->cano; ba.W2 = bufs->W2; ba.p6d = bufs->p6d; ba.pt = bufs->pt; ba.yT = fa.yT; ba.hT = fa.hT;
     ba.hard_idx = fa.hard_idx; ba.tau_ptr = bufs->tau; ba.tau = 1.0f; ba.G = G; ba.rt_table = fa.rt_table;
-    ba.acc = cg.acc; ba.fx_bits = cg.fx_bits; ba.X = bufs->pc_trans; ba.cano_idx = c.cano_idx;
+    ba.cano_idx = c.cano_idx;
     ba.gpf = c.use_flow ? (const float *)(ws + p.o_gpf) : nullptr;
     ba.N = N; ba.P = P; ba.B = B; ba.H = H; ba.gW1 = gW1; ba.gb1 = gb1; ba.gW2 = gW2; ba.g6d = g6d; ba.gt = gt;
     FinalizeAdam ad = {};
