@@ -83,6 +83,9 @@ def main():
     ap.add_argument("--points", type=int, default=4096)
     ap.add_argument("--no-flow", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--steps-per-graph", type=int, default=10,
+                    help="iterations captured per graph (a graph launch costs ~8 us of idle GPU; the loop has no "
+                         "host interaction, so several iterations replay as one graph)")
     ap.add_argument("--no-overlap", action="store_true", help="run the flow branch serially (profiling: isolated kernel durations)")
     ap.add_argument("--grid", action="store_true", help="exact grid search for the static targets (same results; slower at this size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -116,7 +119,7 @@ def main():
         with torch.cuda.stream(st):
             e_, seq, model = build_instance(dev, T, N, (cano_idx + k) % T, seed=2 + rank + 101 * k, use_flow=use_flow,
                                             use_grid=args.grid, overlap=not args.no_overlap)
-            used = 0 if args.no_graph else e_.capture()
+            used = 0 if args.no_graph else e_.capture(steps_per_graph=max(1, args.steps_per_graph))
             e_.step(max(args.warmup - used, 0))
         engines.append(e_)
         streams.append(st)
@@ -200,7 +203,7 @@ def main():
                                    + ("+flow loss (k=3 blend, 3000 refs/pair)" if use_flow else " only")
                                    + ", full iteration fwd+loss+bwd+Adam, one instance per GPU",
                        "frames": T, "points": N, "parts": 20, "flow": use_flow,
-                       "graph": not args.no_graph, "grid_search_static_targets": args.grid, "flow_branch_overlap": not args.no_overlap, "parallelism": f"instances x{world}" + (f" x{K} per GPU" if K > 1 else ""),
+                       "graph": not args.no_graph, "steps_per_graph": (0 if args.no_graph else max(1, args.steps_per_graph)), "grid_search_static_targets": args.grid, "flow_branch_overlap": not args.no_overlap, "parallelism": f"instances x{world}" + (f" x{K} per GPU" if K > 1 else ""),
                        "instances_per_gpu": K},
             "roofline": roof,
             "cpu_baseline": cpu,

@@ -112,6 +112,8 @@ int reart_boxes_launch(const float *soa, int N, int Ppad, float *boxes, hipStrea
 // exact search with box pruning + warm start (prune.hip); partial lists only, boxes dealt round-robin to slices
 int reart_knn_launch_pruned(const KnnArgs &a, int KK, hipStream_t st);
 int reart_prune_pick_split(void);
+// exact search with per-query candidate lists, target cloud staged in LDS (lane.hip); a.S must be 1
+int reart_knn_launch_lane(const KnnArgs &a, int KK, hipStream_t st);
 
 // ---- exact grid search over static target sets (grid.hip) -----------------------------------
 struct GridBuildArgs {

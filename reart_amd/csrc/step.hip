@@ -11,6 +11,7 @@
 #include "internal.h"
 #include "blocksort.h"
 #include <math.h>
+#include <string.h>
 
 // ------------------------------------------------------------------------------ layout
 struct StepPlan {
@@ -44,14 +45,17 @@ static int step_plan(const reart_relax_config *c, StepPlan *p) {
     if (c->N <= 0 || c->P <= 0 || c->P > 32 || c->B <= 0 || c->H <= 0) return REART_ERR_INVALID_ARG;
     if (c->use_flow && (c->flow_k != 3 || c->M_max < 3)) return REART_ERR_UNSUPPORTED;
     const long waves1 = 2L * c->B * reart_div_up(c->N, NN_BS);
-    p->pruned = (c->use_boxes && !c->use_grid) ? 1 : 0;
-    p->S1 = p->pruned ? reart_prune_pick_split() : reart_knn_pick_split(waves1, c->N, 1);
+    // 1: per-wave pruning (prune.hip, default); 2: per-lane candidate lists (lane.hip, REART_SEARCH=lane: fewer
+    // distance evaluations but divergent and latency bound -- slower, kept as an experiment); 0: brute force
+    const char *mode = getenv("REART_SEARCH");
+    p->pruned = (c->use_boxes && !c->use_grid) ? ((mode && !strcmp(mode, "lane")) ? 2 : 1) : 0;
+    p->S1 = p->pruned == 2 ? 1 : (p->pruned ? reart_prune_pick_split() : reart_knn_pick_split(waves1, c->N, 1));
     p->L1 = (int)reart_align_up((size_t)reart_div_up(c->N, p->S1), NN_BOX);
     p->Npad = p->L1 * p->S1;
     p->S3 = 1; p->Mpad = 0;
     if (c->use_flow) {
         const long waves3 = (long)c->B * reart_div_up(c->N, NN_BS);
-        p->S3 = p->pruned ? reart_prune_pick_split() : reart_knn_pick_split(waves3, c->M_max, 3);
+        p->S3 = p->pruned == 2 ? 1 : (p->pruned ? reart_prune_pick_split() : reart_knn_pick_split(waves3, c->M_max, 3));
         p->Mpad = (int)reart_align_up((size_t)reart_div_up(c->M_max, p->S3), NN_BOX) * p->S3;
     }
     p->nchunk = reart_div_up(c->N, 64);
@@ -559,6 +563,12 @@ __global__ __launch_bounds__(256) void bookkeep_kernel(BookArgs a) {
 }
 
 // ------------------------------------------------------------------------------ the step
+// Timed variant only: keeps the GPU busy while the host enqueues the whole step, so that the events
+// between the launches measure device time and not the host's launch rate.
+__global__ void spin_kernel(long long ticks) {
+    const long long t0 = (long long)__builtin_amdgcn_s_memtime();
+    while ((long long)__builtin_amdgcn_s_memtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
 #define MARK(k) do { if (ev) (void)hipEventRecord(ev[k], st); } while (0)
 
 static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buffers *bufs,
@@ -587,6 +597,7 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
     fa.hard_idx = (int *)(ws + p.o_hard);
     fa.rt_table = (float *)(ws + p.o_rt);
     fa.boxes = c.use_boxes ? (float *)(ws + p.o_boxX) : nullptr;
+    if (ev) hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(1), 0, st, 700000ll);   // ~0.3 ms at 2.4 GHz
     MARK(0);
     rc = reart_base_forward_ex(fa, st);
     if (rc != REART_OK) return rc;
@@ -629,7 +640,8 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
             k3.items = k3.items0;
             kj.seed = p.pruned ? (const int *)(ws + p.o_seed3) : nullptr;
             k3.job[1] = kj;
-            rc = p.pruned ? reart_knn_launch_pruned(k3, 3, fst) : reart_knn_launch_slices(k3, 3, fst);
+            rc = p.pruned == 2 ? reart_knn_launch_lane(k3, 3, fst)
+                               : (p.pruned ? reart_knn_launch_pruned(k3, 3, fst) : reart_knn_launch_slices(k3, 3, fst));
             if (rc != REART_OK) return rc;
         }
         MARK(2);
@@ -684,7 +696,8 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
         ka.items0 = B * ka.job[0].nqg * p.S1;
         ka.items = 2 * ka.items0;
     }
-    rc = p.pruned ? reart_knn_launch_pruned(ka, 1, st) : reart_knn_launch_slices(ka, 1, st);
+    rc = p.pruned == 2 ? reart_knn_launch_lane(ka, 1, st)
+                       : (p.pruned ? reart_knn_launch_pruned(ka, 1, st) : reart_knn_launch_slices(ka, 1, st));
     if (rc != REART_OK) return rc;
 
     MARK(4);

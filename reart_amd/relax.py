@@ -3,6 +3,7 @@ Chamfer [+ flow] branch) as ten HIP kernel launches per iteration, optionally re
 captured graph.  ``RelaxEngine`` owns the torch tensors (device memory) and hands raw pointers
 to ``reart_relax_prepare`` / ``reart_relax_step`` (include/reart_hip.h)."""
 import ctypes
+import os
 
 import torch
 
@@ -44,6 +45,30 @@ def morton_order(points):
     return torch.sort(code, stable=True).indices
 
 
+def kd_order(points, leaf=16):
+    """Permutation that stores a cloud [N,3] in the leaf order of a balanced k-d tree (median split
+    along the longest axis, leaves of ``leaf`` = NN_BOX points, left halves rounded up to whole leaves).
+    Every 16 consecutive points then form a tight box and every 64 a compact group: on the loop's
+    clouds the box-pruned searches look at about half the boxes a Morton order needs.  Setup-time
+    plumbing on the host (N log N, numpy); deterministic (stable sorts)."""
+    import numpy as np
+
+    p = points.detach().float().cpu().numpy()
+    out, stack = [], [np.arange(p.shape[0])]
+    while stack:
+        ids = stack.pop()
+        if ids.shape[0] <= leaf:
+            out.append(ids)
+            continue
+        pts = p[ids]
+        ax = int(np.argmax(pts.max(0) - pts.min(0)))
+        o = ids[np.argsort(pts[:, ax], kind="stable")]
+        half = (o.shape[0] // 2 + leaf - 1) // leaf * leaf
+        stack.append(o[half:])   # popped after the left half: leaves come out left to right
+        stack.append(o[:half])
+    return torch.from_numpy(np.concatenate(out)).to(points.device)
+
+
 _L = None
 
 
@@ -80,14 +105,15 @@ class RelaxEngine:
         dev = cano_pc.device
         self.device, self.model = dev, model
         cano_pc, pc_list = cano_pc.float(), pc_list.float()
-        # Internal storage order: every cloud along its own Morton curve (results are returned in
-        # the caller's order; the optimisation problem is invariant to point order).
-        self._perm = morton_order(cano_pc) if spatial_sort else None
+        # Internal storage order: every cloud in the leaf order of its own k-d tree (results are returned
+        # in the caller's order; the optimisation problem is invariant to point order).
+        order = {"kd": kd_order, "morton": morton_order}[os.environ.get("REART_ORDER", "kd")]
+        self._perm = order(cano_pc) if spatial_sort else None
         if spatial_sort:
             cano_pc = cano_pc[self._perm]
-            pc_list = torch.stack([f[morton_order(f)] for f in pc_list])
+            pc_list = torch.stack([f[order(f)] for f in pc_list])
             if pc_ref_list is not None:
-                orders = [morton_order(r.reshape(-1, 3)) for r in pc_ref_list]
+                orders = [order(r.reshape(-1, 3)) for r in pc_ref_list]
                 pc_ref_list = [r.reshape(-1, 3)[o] for r, o in zip(pc_ref_list, orders)]
                 flow_ref_list = [f.reshape(-1, 3)[o] for f, o in zip(flow_ref_list, orders)]
             self._inv = torch.empty_like(self._perm)
@@ -198,12 +224,11 @@ class RelaxEngine:
     def step(self, n=1):
         """Enqueue n iterations (asynchronous; no host sync)."""
         if self._graph is not None:
-            assert n % self._steps_per_graph == 0
             for _ in range(n // self._steps_per_graph):
                 self._graph.replay()
-        else:
-            for _ in range(n):
-                self._enqueue()
+            n %= self._steps_per_graph   # the remainder runs eagerly (same launches, same results)
+        for _ in range(n):
+            self._enqueue()
 
     PHASES = ("forward", "flow_knn3", "flow_blend", "chamfer_nn", "chamfer_grad", "backward", "adam", "bookkeep")
 
