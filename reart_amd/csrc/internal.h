@@ -54,8 +54,27 @@ struct FinalizeAdam {
     const double *bias_corr;          // device [2]: 1 - beta1^step, sqrt(1 - beta2^step) of the coming step
 };
 
-int reart_base_backward_ex(BaseBwdArgs a, const FinalizeAdam *adam, void *workspace,
+// Fused step only: end-of-iteration bookkeeping (loss log, iteration counter, next temperature and
+// Adam bias corrections), done by the LAST finishing workgroup of the finalize kernel -- by then
+// every other workgroup has read this iteration's counters, so no extra launch is needed.
+struct StepBook {
+    int enabled;
+    const double *frame_loss; int n_frame_part;
+    const double *flow_part; int n_flow_part;
+    int64_t *iter; float *tau; float *losses; double *bias_corr;
+    unsigned int *ticket;      // device counter, zero between launches
+    int ring, n_iter;
+    float lambda_flow, fixed_tau, end_tau, start_tau, beta1, beta2;
+};
+int reart_base_backward_ex(BaseBwdArgs a, const FinalizeAdam *adam, const StepBook *book, void *workspace,
                            size_t workspace_bytes, hipStream_t st);
+#ifdef __HIPCC__
+// cosine schedule of utils/model_utils.py:33-37 evaluated in double like the host code
+__device__ __forceinline__ float reart_tau_schedule(long cur_iter, int n_iter, float end_t, float start_t) {
+    const double c = cos(3.14159265358979323846 * (double)cur_iter / (double)n_iter);
+    return (float)((double)end_t + ((double)start_t - (double)end_t) * (c + 1.0) * 0.5);
+}
+#endif
 int reart_adam_ex(const AdamArgs &a, hipStream_t st);
 
 // generic K-NN driver (knn.hip): njobs in {1,2}; job j searches q[j] ([N,P1[j],3] AoS) in t[j]
@@ -112,6 +131,8 @@ int reart_boxes_launch(const float *soa, int N, int Ppad, float *boxes, hipStrea
 // exact search with box pruning + warm start (prune.hip); partial lists only, boxes dealt round-robin to slices
 int reart_knn_launch_pruned(const KnnArgs &a, int KK, hipStream_t st);
 int reart_prune_pick_split(void);
+// K = 1 (two jobs) and K = 3 (one job) pruned searches in one launch
+int reart_knn_launch_pruned_pair(const KnnArgs &k1, const KnnArgs &k3, hipStream_t st);
 // exact search with per-query candidate lists, target cloud staged in LDS (lane.hip); a.S must be 1
 int reart_knn_launch_lane(const KnnArgs &a, int KK, hipStream_t st);
 

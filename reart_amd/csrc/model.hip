@@ -30,6 +30,11 @@ extern "C" int reart_debug_phase_clock(unsigned long long *out) {
 #else
 #define PHASE_TS(which, k) do { } while (0)
 #endif
+#ifdef REART_PHASE_CLOCK
+#define PHASE_SYNC_TS(which, k) do { __syncthreads(); PHASE_TS(which, k); } while (0)   // serialises: attribution only
+#else
+#define PHASE_SYNC_TS(which, k) do { } while (0)
+#endif
 __device__ __forceinline__ float dot3f(const float *a, const float *b) {
     return fmaf(a[2], b[2], fmaf(a[1], b[1], a[0] * b[0]));
 }
@@ -419,9 +424,8 @@ __global__ __launch_bounds__(64 * (((PP > 0 ? PP : 32) + FW_PG - 1) / FW_PG)) vo
     float *s_ds = s_h + (size_t)a.H * BW_LD;         // [PMAX][BW_LD]  dw, later ds
     float *s_x = s_ds + (size_t)PMAX * BW_LD;        // [RED_CHUNK][3]
     float *s_w = s_x + RED_CHUNK * 3;                // [RED_CHUNK]
-    int *s_ord = (int *)(s_w + RED_CHUNK);           // [RED_CHUNK] chunk points ordered by part
-    int *s_seg = s_ord + RED_CHUNK;                  // [PMAX + 1] segment starts in s_ord
-    float *s_G = (float *)(s_seg + PMAX + 4);        // [B][RED_CHUNK*3]  upstream gradient tile
+    int *s_kn = (int *)(s_w + RED_CHUNK);            // [RED_CHUNK] hard part of each point (-1: padding)
+    float *s_G = (float *)(s_kn + RED_CHUNK + PMAX + 4);  // [B][RED_CHUNK*3]  upstream gradient tile
     float *s_w2T = s_G + (size_t)a.B * RED_CHUNK * 3;// [H][PMAX]
     float *s_rt = s_w2T + (size_t)a.H * PMAX;        // [B*P][12]  [R|t] rows
     const int tid = threadIdx.x, lane = tid & 63, grp = tid >> 6, chunk = blockIdx.x;
@@ -430,45 +434,104 @@ __global__ __launch_bounds__(64 * (((PP > 0 ? PP : 32) + FW_PG - 1) / FW_PG)) vo
     float *prow = a.partial + (size_t)chunk * n_out(a.P, a.H, a.B);
     PHASE_TS(1, 0);
 
-    for (int e = tid; e < a.H * RED_CHUNK; e += BS) {
-        const int j = e >> 6, i = e & 63;            // RED_CHUNK == 64
-        s_h[j * BW_LD + i] = (i < cn) ? a.hT[(size_t)j * a.N + n0 + i] : 0.f;
-    }
-    // upstream gradient tile; the fused step adds the flow-loss terms of the two adjacent pairs here
-    // (complete frame fc = t or t + 1: + d/d pred_flow of pair fc - 1, - d/d pred_flow of pair fc)
-    for (int e = tid; e < a.B * RED_CHUNK * 3; e += BS) {
-        const int t = e / (RED_CHUNK * 3), r = e - t * (RED_CHUNK * 3);
-        float g = 0.f;
-        if (r < 3 * cn) {
-            g = a.G[3 * ((size_t)t * a.N + n0) + r];
-            if (a.gpf) {
-                const int fc = t < a.cano_idx ? t : t + 1;   // complete-sequence index of frame t
-                if (fc - 1 >= 0) g += a.gpf[3 * ((size_t)(fc - 1) * a.N + n0) + r];
-                if (fc <= a.B - 1) g -= a.gpf[3 * ((size_t)fc * a.N + n0) + r];
-            }
-        }
-        s_G[e] = g;
-    }
-    for (int e = tid; e < a.B * a.P * 12; e += BS) s_rt[e] = a.rt_table[e];
-    for (int j = tid; j < a.H; j += BS)
-        for (int p = 0; p < P; ++p) s_w2T[j * PMAX + p] = a.W2[(size_t)p * a.H + j];
+    // Tile loads.  Every group issues a batch of unconditional loads (clamped addresses, masked
+    // afterwards), and the first batch of EVERY group is in flight before anything is stored to LDS:
+    // written as plain guarded loops the compiler serialises the loads and the prologue becomes a
+    // chain of a dozen L2 / HBM round trips (measured 25 k cycles, now one round trip deep).
+    constexpr int UH = 13, UG = 6, UR = 8;   // H = 128, B = 19, P = 20: one batch each
+    const int ilast = cn - 1, nH = a.H * RED_CHUNK, nG = a.B * RED_CHUNK * 3, rlast = 3 * cn - 1, nR = a.B * a.P * 12;
     const bool live = lane < cn;
     const int n = live ? n0 + lane : n0;
+    auto load_h = [&](int e0, float (&v)[UH]) {
+#pragma unroll
+        for (int u = 0; u < UH; ++u) {
+            const int e = e0 + u * BS;
+            const int ec = e < nH ? e : tid;
+            const int j = ec >> 6, i = ec & 63;            // RED_CHUNK == 64
+            v[u] = a.hT[(size_t)j * a.N + n0 + (i < cn ? i : ilast)];
+        }
+    };
+    auto store_h = [&](int e0, const float (&v)[UH]) {
+#pragma unroll
+        for (int u = 0; u < UH; ++u) {
+            const int e = e0 + u * BS;
+            if (e < nH) s_h[(e >> 6) * BW_LD + (e & 63)] = ((e & 63) < cn) ? v[u] : 0.f;
+        }
+    };
+    // upstream gradient tile; the fused step adds the flow-loss terms of the two adjacent pairs
+    // (complete frame fc = t or t + 1: + d/d pred_flow of pair fc - 1, - d/d pred_flow of pair fc)
+    auto load_g = [&](int e0, float (&g)[UG], float (&gh)[UG], float (&gl)[UG]) {
+#pragma unroll
+        for (int u = 0; u < UG; ++u) {
+            const int e = e0 + u * BS;
+            const int ec = e < nG ? e : tid;
+            const int t = ec / (RED_CHUNK * 3), r0_ = ec - t * (RED_CHUNK * 3);
+            const int r = r0_ < 3 * cn ? r0_ : rlast;
+            g[u] = a.G[3 * ((size_t)t * a.N + n0) + r];
+            gh[u] = 0.f; gl[u] = 0.f;
+            if (a.gpf) {   // uniform
+                const int fc = t < a.cano_idx ? t : t + 1;   // complete-sequence index of frame t
+                const int fh = fc - 1 >= 0 ? fc - 1 : 0, fl = fc <= a.B - 1 ? fc : a.B - 1;
+                gh[u] = a.gpf[3 * ((size_t)fh * a.N + n0) + r];
+                gl[u] = a.gpf[3 * ((size_t)fl * a.N + n0) + r];
+            }
+        }
+    };
+    auto store_g = [&](int e0, const float (&g)[UG], const float (&gh)[UG], const float (&gl)[UG]) {
+#pragma unroll
+        for (int u = 0; u < UG; ++u) {
+            const int e = e0 + u * BS;
+            if (e < nG) {
+                const int t = e / (RED_CHUNK * 3), r0_ = e - t * (RED_CHUNK * 3);
+                float v = g[u];
+                if (a.gpf) {
+                    const int fc = t < a.cano_idx ? t : t + 1;
+                    if (fc - 1 >= 0) v += gh[u];       // operation order: (G + gh) - gl
+                    if (fc <= a.B - 1) v -= gl[u];
+                }
+                s_G[e] = r0_ < 3 * cn ? v : 0.f;
+            }
+        }
+    };
+    auto load_r = [&](int e0, float (&v)[UR]) {
+#pragma unroll
+        for (int u = 0; u < UR; ++u) v[u] = a.rt_table[e0 + u * BS < nR ? e0 + u * BS : tid];
+    };
+    auto store_r = [&](int e0, const float (&v)[UR]) {
+#pragma unroll
+        for (int u = 0; u < UR; ++u)
+            if (e0 + u * BS < nR) s_rt[e0 + u * BS] = v[u];
+    };
+    float vh[UH], vg[UG], vgh[UG], vgl[UG], vr[UR], vw[PMAX];
+    load_g(tid, vg, vgh, vgl);     // produced by the previous kernels on other XCDs: the longest latency first
+    load_h(tid, vh);
+    load_r(tid, vr);
+    const int jw = tid < a.H ? tid : 0;
+#pragma unroll
+    for (int p = 0; p < PMAX; ++p) vw[p] = a.W2[(size_t)(p < P ? p : 0) * a.H + jw];
     const float x0 = a.cano[3 * (size_t)n], x1 = a.cano[3 * (size_t)n + 1], x2 = a.cano[3 * (size_t)n + 2];
+    int kn = -1;
+    float yk = 0.f;
     if (grp == 0) {
-        const int kn = live ? a.hard_idx[n] : -1;
-        const float yk = a.yT[(size_t)(kn < 0 ? 0 : kn) * a.N + n];
+        kn = live ? a.hard_idx[n] : -1;
+        yk = a.yT[(size_t)(kn < 0 ? 0 : kn) * a.N + n];
+    }
+    store_g(tid, vg, vgh, vgl);
+    store_h(tid, vh);
+    store_r(tid, vr);
+    if (tid < a.H) {
+#pragma unroll
+        for (int p = 0; p < PMAX; ++p) s_w2T[tid * PMAX + p] = vw[p];
+    }
+    for (int e0 = tid + UG * BS; e0 < nG; e0 += UG * BS) { load_g(e0, vg, vgh, vgl); store_g(e0, vg, vgh, vgl); }
+    for (int e0 = tid + UH * BS; e0 < nH; e0 += UH * BS) { load_h(e0, vh); store_h(e0, vh); }
+    for (int e0 = tid + UR * BS; e0 < nR; e0 += UR * BS) { load_r(e0, vr); store_r(e0, vr); }
+    for (int j = tid + BS; j < a.H; j += BS)
+        for (int p = 0; p < P; ++p) s_w2T[j * PMAX + p] = a.W2[(size_t)p * a.H + j];
+    if (grp == 0) {
         s_w[lane] = (1.0f - yk) + yk;
         s_x[3 * lane] = live ? x0 : 0.f; s_x[3 * lane + 1] = live ? x1 : 0.f; s_x[3 * lane + 2] = live ? x2 : 0.f;
-        // stable counting sort of the chunk's points by part
-        int base = 0;
-        for (int p = 0; p < P; ++p) {
-            const unsigned long long mk = __ballot(kn == p);
-            if (lane == 0) s_seg[p] = base;
-            if (kn == p) s_ord[base + __popcll(mk & ((1ull << lane) - 1ull))] = lane;
-            base += __popcll(mk);
-        }
-        if (lane == 0) s_seg[P] = base;
+        s_kn[lane] = kn;
     }
     // a. dw for this wave's two parts
     float dw0 = 0.f, dw1 = 0.f;
@@ -477,7 +540,7 @@ __global__ __launch_bounds__(64 * (((PP > 0 ? PP : 32) + FW_PG - 1) / FW_PG)) vo
     __syncthreads();
     PHASE_TS(1, 1);
     if (has0) {
-#pragma unroll 2
+#pragma unroll 4
         for (int t = 0; t < a.B; ++t) {
             const float *g = s_G + t * (RED_CHUNK * 3) + 3 * lane;
             const float gv[3] = {g[0], g[1], g[2]};
@@ -531,18 +594,32 @@ __global__ __launch_bounds__(64 * (((PP > 0 ? PP : 32) + FW_PG - 1) / FW_PG)) vo
         }
     }
     PHASE_TS(1, 4);
-    // c2. gR | gt: thread (t, p, entry c) walks its part's points (ascending n) with a register
-    for (int o = tid; o < a.B * a.P * 12; o += BS) {
-        const int tp = o / 12, c = o - tp * 12;
-        const int t = tp / a.P, p = tp - t * a.P;
-        const float *gt_ = s_G + t * (RED_CHUNK * 3);
-        float acc = 0.f;
-        for (int q = s_seg[p]; q < s_seg[p + 1]; ++q) {
-            const int i = s_ord[q];
-            if (c < 9) acc += (s_w[i] * gt_[3 * i + c / 3]) * s_x[3 * i + c % 3];
-            else acc += s_w[i] * gt_[3 * i + c - 9];
+    // c2. gR | gt on the matrix cores:  out[p][(t, e)] = sum_n onehot[p][n] * v[n][(t, e)]  with
+    //   v = (w_n G[t,n,r]) x_n[c]  (e = 3 r + c < 9)   or   w_n G[t,n,e-9]  (translation),
+    // the operands built on the fly from the LDS tiles.  A one-hot left factor makes every product
+    // exact (1 * v = v, 0 * v = 0), so each output is the ascending-n running sum of its part's
+    // points: deterministic, no sorting, no atomics.
+    for (int tile = grp; tile * 32 < a.B * 12; tile += W) {
+        typedef float f16v __attribute__((ext_vector_type(16)));
+        f16v c = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const int pr = lane & 31, col = tile * 32 + (lane & 31), kh = lane >> 5;
+        const bool cok = col < a.B * 12;
+        const int t = cok ? col / 12 : 0, e = cok ? col - t * 12 : 0;
+        const int gr = e < 9 ? e / 3 : e - 9, xc = e < 9 ? e - 3 * (e / 3) : 0;
+        const float *gcol = s_G + t * (RED_CHUNK * 3) + gr;
+#pragma unroll 8
+        for (int kk = 0; kk < RED_CHUNK; kk += 2) {
+            const int n = kk + kh;
+            const float av = (s_kn[n] == pr) ? 1.f : 0.f;
+            float bv = s_w[n] * gcol[3 * n];
+            if (e < 9) bv = bv * s_x[3 * n + xc];
+            c = __builtin_amdgcn_mfma_f32_32x32x2f32(av, cok ? bv : 0.f, c, 0, 0, 0);
         }
-        prow[off_gRt(a.P, a.H) + o] = acc;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int prow_p = (reg & 3) + 8 * (reg >> 2) + 4 * kh;
+            if (prow_p < P && cok) prow[off_gRt(a.P, a.H) + (t * a.P + prow_p) * 12 + e] = c[reg];
+        }
     }
     PHASE_TS(1, 5);
     // every lane needs all ds of its point for the hidden gradient
@@ -555,9 +632,20 @@ __global__ __launch_bounds__(64 * (((PP > 0 ? PP : 32) + FW_PG - 1) / FW_PG)) vo
     const int jq = (a.H + W - 1) / W, j0 = grp * jq, j1 = (j0 + jq < a.H) ? j0 + jq : a.H;
     for (int j = j0; j < j1; ++j) {
         float dh = 0.f;
+        if (PMAX % 4 == 0) {
 #pragma unroll
-        for (int p = 0; p < PMAX; ++p)
-            if (PP > 0 || p < P) dh = fmaf(s_w2T[j * PMAX + p], dsr[p], dh);
+            for (int p4 = 0; p4 < PMAX / 4; ++p4) {
+                const float4 wv = *(const float4 *)(s_w2T + j * PMAX + 4 * p4);
+                const float w4[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (PP > 0 || 4 * p4 + u < P) dh = fmaf(w4[u], dsr[4 * p4 + u], dh);
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < PMAX; ++p)
+                if (PP > 0 || p < P) dh = fmaf(s_w2T[j * PMAX + p], dsr[p], dh);
+        }
         const float h = s_h[j * BW_LD + lane];
         s_h[j * BW_LD + lane] = (live && h > 0.f) ? dh : 0.f;
     }
@@ -595,7 +683,7 @@ __device__ __forceinline__ void adam_update(float *p, float g, float *m, float *
     *p = *p - step_size_base * (mm / denom);
 }
 
-__global__ __launch_bounds__(256) void base_bwd_finalize_kernel(BaseBwdArgs a, FinalizeAdam ad) {
+__device__ __forceinline__ void base_bwd_finalize_body(const BaseBwdArgs &a, const FinalizeAdam &ad) {
     const int o = blockIdx.x * 256 + threadIdx.x;
     const int nWr = a.P * a.H + 4 * a.H;                 // real weight entries
     const int nW = (nWr + 63) & ~63;                     // pose groups start wave-aligned
@@ -688,6 +776,45 @@ __global__ __launch_bounds__(256) void base_bwd_finalize_kernel(BaseBwdArgs a, F
     }
 }
 
+__global__ __launch_bounds__(256) void base_bwd_finalize_kernel(BaseBwdArgs a, FinalizeAdam ad, StepBook bk) {
+    base_bwd_finalize_body(a, ad);
+    if (!bk.enabled) return;
+    // last-workgroup pattern: the ticket is taken after this workgroup has consumed the iteration's
+    // counters, so the workgroup that draws the last ticket may overwrite them
+    __shared__ int s_last;
+    __shared__ double s_r[4], s_f[4];
+    const int tid = threadIdx.x;
+    __syncthreads();
+    if (tid == 0) {
+        __threadfence();
+        s_last = (atomicAdd(bk.ticket, 1u) == gridDim.x - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    // fixed assignment of terms to lanes + fixed-order tree: deterministic sums
+    double recon = 0.0, flow = 0.0;
+    for (int b = tid; b < bk.n_frame_part; b += 256) recon += bk.frame_loss[b];
+    for (int i = tid; i < bk.n_flow_part; i += 256) flow += bk.flow_part[i];
+    recon = reart_wave_sum_d(recon);
+    flow = reart_wave_sum_d(flow);
+    if ((tid & 63) == 0) { s_r[tid >> 6] = recon; s_f[tid >> 6] = flow; }
+    __syncthreads();
+    if (tid != 0) return;
+    recon = (s_r[0] + s_r[1]) + (s_r[2] + s_r[3]);
+    flow = ((s_f[0] + s_f[1]) + (s_f[2] + s_f[3])) * (double)bk.lambda_flow;
+    const long it = (long)bk.iter[0];
+    if (bk.losses && bk.ring > 0) {
+        float *row = bk.losses + 4 * (size_t)(it % bk.ring);
+        row[0] = (float)recon; row[1] = (float)flow; row[2] = (float)(recon + flow); row[3] = bk.tau[0];
+    }
+    bk.iter[0] = it + 1;
+    bk.bias_corr[0] = 1.0 - pow((double)bk.beta1, (double)(it + 2));   // Adam step count of the next iteration
+    bk.bias_corr[1] = sqrt(1.0 - pow((double)bk.beta2, (double)(it + 2)));
+    // iteration i (0-based) uses tau_cosine(i+1, ...) (run_robot.py:157)
+    bk.tau[0] = bk.fixed_tau > 0.f ? bk.fixed_tau : reart_tau_schedule(it + 2, bk.n_iter, bk.end_tau, bk.start_tau);
+    *bk.ticket = 0u;
+}
+
 static size_t base_bwd_ws_layout(int N, int P, int B, int H, size_t *o_rt, size_t *o_part) {
     const int nchunk = reart_div_up(N, RED_CHUNK);
     size_t off = 0;
@@ -717,7 +844,7 @@ static int launch_bwd_block(const BaseBwdArgs &a, size_t lds, hipStream_t st) {
 }
 
 // a.rt_table == NULL: the table is built into the workspace first (one extra tiny launch)
-int reart_base_backward_ex(BaseBwdArgs a, const FinalizeAdam *adam, void *workspace,
+int reart_base_backward_ex(BaseBwdArgs a, const FinalizeAdam *adam, const StepBook *book, void *workspace,
                            size_t workspace_bytes, hipStream_t st) {
     if (a.P > 32) return REART_ERR_UNSUPPORTED;
     size_t o_rt, o_part;
@@ -745,11 +872,12 @@ int reart_base_backward_ex(BaseBwdArgs a, const FinalizeAdam *adam, void *worksp
     }
     if (rc != REART_OK) return rc;
     FinalizeAdam none = {};
+    StepBook nobook = {};
     // weights: one thread per entry; poses: 16 lanes per (frame, part); nW is rounded up to a multiple of 64
     // inside the kernel's indexing so that a 16-lane group never straddles a wave
     const int nfin = (int)reart_align_up((size_t)(a.P * a.H + 4 * a.H), 64) + 16 * a.B * a.P;
     hipLaunchKernelGGL(base_bwd_finalize_kernel, dim3(reart_div_up(nfin, 256)), dim3(256), 0, st, a,
-                       adam ? *adam : none);
+                       adam ? *adam : none, book ? *book : nobook);
     REART_CHECK_LAUNCH();
     return REART_OK;
 }
@@ -769,7 +897,7 @@ extern "C" int reart_base_backward(const float *cano, int N, int P, int B, const
     a.cano = cano; a.W2 = W2; a.p6d = prop6d; a.pt = propt; a.yT = yT; a.hT = hT;
     a.hard_idx = hard_idx; a.tau = tau; a.G = G; a.N = N; a.P = P; a.B = B; a.H = H;
     a.gW1 = gW1; a.gb1 = gb1; a.gW2 = gW2; a.g6d = g6d; a.gt = gt;
-    return reart_base_backward_ex(a, nullptr, workspace, workspace_bytes, (hipStream_t)stream);
+    return reart_base_backward_ex(a, nullptr, nullptr, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 // --------------------------------------------------------------- hard-label rigid apply

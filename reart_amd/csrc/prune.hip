@@ -39,7 +39,7 @@ extern "C" int reart_debug_prune_stats(unsigned long long *out, int reset) {
     if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prune_stats), z, sizeof(z)); }
     return REART_OK;
 }
-#define PRUNE_STAT(k, v) do { if (threadIdx.x == 0) atomicAdd(&g_prune_stats[k], (unsigned long long)(v)); } while (0)
+#define PRUNE_STAT(k, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_prune_stats[k], (unsigned long long)(v)); } while (0)
 #else
 #define PRUNE_STAT(k, v) do { } while (0)
 #endif
@@ -59,11 +59,10 @@ __device__ __forceinline__ float box_lb(float lo0, float lo1, float lo2, float h
 // KK = 1: partial (distance, exact index) per slice.  KK = 3: partial top-3 BLOCKS of 8 targets
 // (block minimum, first index of the block), rescanned by the consumer (flow_blend_kernel).
 template <int KK>
-__global__ __launch_bounds__(NN_BS) void knn_pruned_kernel(KnnArgs a) {
+__device__ __forceinline__ void knn_pruned_body(const KnnArgs &a, const int w) {
     // Work per item varies (it depends on how tight the warm start is), and the working set fits
     // every XCD's L2: no XCD-contiguous remap here -- consecutive items go to different XCDs and
     // the two jobs alternate, so every XCD gets the same mix of light and heavy items.
-    const int w = blockIdx.x;
     if (w >= a.items) return;
     const bool two = a.items > a.items0;
     const int jsel = two ? (w & 1) : 0;
@@ -72,7 +71,7 @@ __global__ __launch_bounds__(NN_BS) void knn_pruned_kernel(KnnArgs a) {
     const int s = wl % a.S;                      // slices of one query group are neighbours
     const int g = (wl / a.S) % jb.nqg;
     const int b = wl / (jb.nqg * a.S);
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
 
     const int i = g * NN_BS + lane;
     const int ic = i < jb.P1 ? i : jb.P1 - 1;
@@ -219,14 +218,53 @@ __global__ __launch_bounds__(NN_BS) void knn_pruned_kernel(KnnArgs a) {
     for (int k = 0; k < KK; ++k) { jb.pd[o + k] = bm[k]; jb.pi[o + k] = bb[k]; }
 }
 
+// Workgroups hold PR_WPB independent waves (one work item each, no barrier).
+#define PR_WPB 1   // measured: 4 waves per workgroup is slower (a workgroup's slots are held until its slowest wave ends)
+template <int KK>
+__global__ __launch_bounds__(NN_BS * PR_WPB) void knn_pruned_kernel(KnnArgs a) {
+    knn_pruned_body<KK>(a, blockIdx.x * PR_WPB + (threadIdx.x >> 6));
+}
+
+// Both searches of one iteration in ONE launch: the K = 1 Chamfer items and the K = 3 flow items are
+// independent, and a single dispatch lets them share the chip without the cross-queue fork / join of
+// two streams (measured ~6-12 us per dependency edge in a replayed graph).  Two K = 1 items alternate
+// with one K = 3 item while both kinds last.
+struct KnnPairArgs { KnnArgs k1, k3; int mixed; };   // mixed = 3 * min(items1 / 2, items3)
+__global__ __launch_bounds__(NN_BS * PR_WPB) void knn_pruned_pair_kernel(KnnPairArgs a) {
+    const int w = blockIdx.x * PR_WPB + (threadIdx.x >> 6);
+    if (w < a.mixed) {
+        const int q = w / 3, r = w - 3 * q;
+        if (r < 2) knn_pruned_body<1>(a.k1, 2 * q + r);
+        else knn_pruned_body<3>(a.k3, q);
+    } else {
+        const int d1 = 2 * (a.mixed / 3), d3 = a.mixed / 3;   // items already dealt
+        const int v = w - a.mixed;
+        if (v < a.k1.items - d1) knn_pruned_body<1>(a.k1, d1 + v);
+        else if (v - (a.k1.items - d1) < a.k3.items - d3) knn_pruned_body<3>(a.k3, d3 + (v - (a.k1.items - d1)));
+    }
+}
+
+int reart_knn_launch_pruned_pair(const KnnArgs &k1, const KnnArgs &k3, hipStream_t st) {
+    for (int j = 0; j < 2; ++j)
+        if (!k1.job[j].boxes || !k1.job[j].seed || !k3.job[j].boxes || !k3.job[j].seed) return REART_ERR_INVALID_ARG;
+    if (k1.items != 2 * k1.items0 || k3.items != k3.items0) return REART_ERR_INVALID_ARG;
+    KnnPairArgs a;
+    a.k1 = k1; a.k3 = k3;
+    const int m = (k1.items / 2 < k3.items) ? k1.items / 2 : k3.items;
+    a.mixed = 3 * m;
+    hipLaunchKernelGGL(knn_pruned_pair_kernel, dim3(reart_div_up(k1.items + k3.items, PR_WPB)), dim3(NN_BS * PR_WPB), 0, st, a);
+    REART_CHECK_LAUNCH();
+    return REART_OK;
+}
+
 int reart_knn_launch_pruned(const KnnArgs &a, int KK, hipStream_t st) {
-    const int grid = reart_xcd_grid(a.items);
+    const int grid = reart_div_up(a.items, PR_WPB);
     for (int j = 0; j < 2; ++j)
         if (!a.job[j].boxes || !a.job[j].seed) return REART_ERR_INVALID_ARG;
     if (a.items != a.items0 && a.items != 2 * a.items0) return REART_ERR_INVALID_ARG;   // the two jobs alternate
     switch (KK) {
-        case 1: hipLaunchKernelGGL((knn_pruned_kernel<1>), dim3(grid), dim3(NN_BS), 0, st, a); break;
-        case 3: hipLaunchKernelGGL((knn_pruned_kernel<3>), dim3(grid), dim3(NN_BS), 0, st, a); break;
+        case 1: hipLaunchKernelGGL((knn_pruned_kernel<1>), dim3(grid), dim3(NN_BS * PR_WPB), 0, st, a); break;
+        case 3: hipLaunchKernelGGL((knn_pruned_kernel<3>), dim3(grid), dim3(NN_BS * PR_WPB), 0, st, a); break;
         default: return REART_ERR_UNSUPPORTED;
     }
     REART_CHECK_LAUNCH();

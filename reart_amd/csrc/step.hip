@@ -22,6 +22,7 @@ struct StepPlan {
     size_t o_pd0, o_pi0, o_pd1, o_pi1, o_pd3, o_pi3;
     size_t o_yT, o_hT, o_hard, o_rt, o_G, o_gpf, o_fx, o_floss, o_fpart, o_grads, o_bwd;
     size_t o_bc;              // Adam bias corrections of the coming step (double[2])
+    size_t o_ticket;          // last-workgroup ticket of the finalize kernel (zero between launches)
     size_t o_boxY, o_boxX, o_boxR;  // AABBs of every NN_BOX targets (block-skip test)
     int pruned;               // box-pruned, warm-started search (prune.hip) instead of the slice kernels
     size_t o_seed0, o_seed1, o_seed3;  // last iteration's neighbour indices: x->y [B,N], y->x [B,N], flow [B,N,3]
@@ -36,7 +37,7 @@ static size_t take(size_t &off, size_t bytes) {
     return o;
 }
 
-#define FLOW_BS 256
+#define FLOW_BS 256    // stand-alone flow_blend_kernel; inside post_kernel the blend uses CG_BS threads
 #define CG_BS 1024
 #define CG_RANGE 1024   // targets x_j owned by one workgroup of chamfer_grad_kernel
 static_assert(CG_BS == CG_RANGE, "chamfer_grad_kernel: thread tid owns target r0 + tid");
@@ -86,6 +87,7 @@ static int step_plan(const reart_relax_config *c, StepPlan *p) {
     p->bwd_bytes = reart_base_backward_workspace_bytes(c->N, c->P, c->B, c->H);
     p->o_bwd = take(off, p->bwd_bytes);
     p->o_bc = take(off, 2 * sizeof(double));
+    p->o_ticket = take(off, sizeof(unsigned int));
     p->o_boxY = take(off, sizeof(float) * 8 * (size_t)c->B * (p->Npad / NN_BOX));
     p->o_boxX = take(off, sizeof(float) * 8 * (size_t)c->B * (p->Npad / NN_BOX));
     p->o_boxR = take(off, sizeof(float) * 8 * (size_t)c->B * (p->Mpad / NN_BOX + 1));
@@ -107,12 +109,6 @@ extern "C" size_t reart_relax_workspace_bytes(const reart_relax_config *cfg) {
 }
 
 // ------------------------------------------------------------------------------ prepare
-// cosine schedule of utils/model_utils.py:33-37 evaluated in double like the host code
-__device__ __forceinline__ float tau_schedule(long cur_iter, int n_iter, float end_t, float start_t) {
-    const double c = cos(3.14159265358979323846 * (double)cur_iter / (double)n_iter);
-    return (float)((double)end_t + ((double)start_t - (double)end_t) * (c + 1.0) * 0.5);
-}
-
 __global__ void relax_init_kernel(reart_relax_config c, const int *__restrict__ ref_off,
                                   int *__restrict__ rlen, int *__restrict__ qmap,
                                   int64_t *__restrict__ iter, float *__restrict__ tau,
@@ -150,7 +146,7 @@ __global__ void relax_init_kernel(reart_relax_config c, const int *__restrict__ 
     if (t == 0) {
         // `iter` is caller state: it is NOT reset here, so a resumed run continues its schedule
         const long it = (long)iter[0];
-        tau[0] = c.fixed_tau > 0.f ? c.fixed_tau : tau_schedule(it + 1, c.n_iter, c.end_tau, c.start_tau);
+        tau[0] = c.fixed_tau > 0.f ? c.fixed_tau : reart_tau_schedule(it + 1, c.n_iter, c.end_tau, c.start_tau);
         bias_corr[0] = 1.0 - pow((double)c.beta1, (double)(it + 1));
         bias_corr[1] = sqrt(1.0 - pow((double)c.beta2, (double)(it + 1)));
     }
@@ -195,6 +191,7 @@ extern "C" int reart_relax_prepare(const reart_relax_config *cfg, const reart_re
                        (int *)(ws + p.o_rlen), (int *)(ws + p.o_qmap), bufs->iter, bufs->tau, bufs->pc_list,
                        (int *)(ws + p.o_fx), (double *)(ws + p.o_bc),
                        (p.pruned && cfg->use_flow) ? (int *)(ws + p.o_seed3) : nullptr);
+    if (hipMemsetAsync(ws + p.o_ticket, 0, sizeof(unsigned int), st) != hipSuccess) return REART_ERR_LAUNCH;
     if (p.pruned) {  // warm start of the first Chamfer search: index 0 (any valid index)
         if (hipMemsetAsync(ws + p.o_seed0, 0, sizeof(int) * (size_t)cfg->B * cfg->N, st) != hipSuccess) return REART_ERR_LAUNCH;
         if (hipMemsetAsync(ws + p.o_seed1, 0, sizeof(int) * (size_t)cfg->B * cfg->N, st) != hipSuccess) return REART_ERR_LAUNCH;
@@ -269,10 +266,10 @@ __device__ __forceinline__ void top3_insert(float (&kd)[3], int (&ki)[3], float 
     ki[0] = l0 ? j : ki[0];
 }
 
-template <bool ONE>   // ONE: S <= 4 -- every partial of a query is loaded before the first compare
-__global__ __launch_bounds__(FLOW_BS) void flow_blend_kernel(FlowArgs a) {
-    __shared__ double s_red[FLOW_BS / REART_WAVE];
-    const int f = blockIdx.y, n = blockIdx.x * FLOW_BS + threadIdx.x;
+template <bool ONE, int FBS>   // ONE: S <= 4 -- every partial of a query is loaded before the first compare
+__device__ __forceinline__ void flow_blend_body(const FlowArgs &a, const int bx, const int f, const int nbx) {
+    __shared__ double s_red[FBS / REART_WAVE];
+    const int n = bx * FBS + threadIdx.x;
     double term = 0.0;
     if (n < a.N) {
         // the kernel is a chain of dependent gathers (partials -> blocks -> reference flows): every
@@ -383,8 +380,8 @@ __global__ __launch_bounds__(FLOW_BS) void flow_blend_kernel(FlowArgs a) {
     __syncthreads();
     if (threadIdx.x == 0) {
         double t = 0.0;
-        for (int w = 0; w < FLOW_BS / REART_WAVE; ++w) t += s_red[w];
-        a.part[(size_t)f * gridDim.x + blockIdx.x] = t;
+        for (int w = 0; w < FBS / REART_WAVE; ++w) t += s_red[w];
+        a.part[(size_t)f * nbx + bx] = t;
     }
 }
 
@@ -451,11 +448,11 @@ __device__ __forceinline__ void merge_slices(const float *__restrict__ pd, const
 }
 
 template <bool ONE>
-__global__ __launch_bounds__(CG_BS) void chamfer_grad_kernel(CGradArgs a) {
+__device__ __forceinline__ void chamfer_grad_body(const CGradArgs &a, const int bx, const int b, const int nbx) {
     __shared__ unsigned long long s_acc[CG_RANGE * 3];
     __shared__ double s_red[CG_BS / REART_WAVE];
-    const int b = blockIdx.y, tid = threadIdx.x, N = a.N;
-    const int r0 = blockIdx.x * CG_RANGE;
+    const int tid = threadIdx.x, N = a.N;
+    const int r0 = bx * CG_RANGE;
     const float *x = a.X + (size_t)b * N * 3, *y = a.Y + (size_t)b * N * 3;
     const size_t stride = (size_t)a.B * N, ob = (size_t)b * N;
     for (int e = tid; e < CG_RANGE * 3; e += CG_BS) s_acc[e] = 0ull;
@@ -524,42 +521,26 @@ __global__ __launch_bounds__(CG_BS) void chamfer_grad_kernel(CGradArgs a) {
     if (tid == 0) {
         double t = 0.0;
         for (int w = 0; w < CG_BS / REART_WAVE; ++w) t += s_red[w];
-        a.loss_part[(size_t)b * gridDim.x + blockIdx.x] = t;
+        a.loss_part[(size_t)b * nbx + bx] = t;
     }
 }
 
-// ------------------------------------------------------------------------------ bookkeeping
-// after the Adam launch: loss log, iteration counter, next temperature
-struct BookArgs {
-    reart_relax_config c;
-    const double *frame_loss; int n_frame_part; const double *flow_part; int n_flow_part;
-    int64_t *iter; float *tau; float *losses; double *bias_corr;
-};
-__global__ __launch_bounds__(256) void bookkeep_kernel(BookArgs a) {
-    __shared__ double s_r[4], s_f[4];
-    const int tid = threadIdx.x;
-    // fixed assignment of terms to lanes + fixed-order tree: deterministic sums
-    double recon = 0.0, flow = 0.0;
-    for (int b = tid; b < a.n_frame_part; b += 256) recon += a.frame_loss[b];
-    for (int i = tid; i < a.n_flow_part; i += 256) flow += a.flow_part[i];
-    recon = reart_wave_sum_d(recon);
-    flow = reart_wave_sum_d(flow);
-    if ((tid & 63) == 0) { s_r[tid >> 6] = recon; s_f[tid >> 6] = flow; }
-    __syncthreads();
-    if (tid != 0) return;
-    recon = (s_r[0] + s_r[1]) + (s_r[2] + s_r[3]);
-    flow = ((s_f[0] + s_f[1]) + (s_f[2] + s_f[3])) * (double)a.c.lambda_flow;
-    const long it = (long)a.iter[0];
-    if (a.losses && a.c.ring > 0) {
-        float *row = a.losses + 4 * (size_t)(it % a.c.ring);
-        row[0] = (float)recon; row[1] = (float)flow; row[2] = (float)(recon + flow); row[3] = a.tau[0];
-    }
-    a.iter[0] = it + 1;
-    a.bias_corr[0] = 1.0 - pow((double)a.c.beta1, (double)(it + 2));   // Adam step count of the next iteration
-    a.bias_corr[1] = sqrt(1.0 - pow((double)a.c.beta2, (double)(it + 2)));
-    // iteration i (0-based) uses tau_cosine(i+1, ...) (run_robot.py:157)
-    a.tau[0] = a.c.fixed_tau > 0.f ? a.c.fixed_tau
-                                   : tau_schedule(it + 2, a.c.n_iter, a.c.end_tau, a.c.start_tau);
+template <bool ONE>
+__global__ __launch_bounds__(CG_BS) void chamfer_grad_kernel(CGradArgs a) {
+    chamfer_grad_body<ONE>(a, blockIdx.x, blockIdx.y, gridDim.x);
+}
+template <bool ONE>
+__global__ __launch_bounds__(FLOW_BS) void flow_blend_kernel(FlowArgs a) {
+    flow_blend_body<ONE, FLOW_BS>(a, blockIdx.x, blockIdx.y, gridDim.x);
+}
+// Both consumers of the searches in ONE launch (same reason as knn_pruned_pair_kernel): workgroups
+// [0, nflow) blend the flow of (frame pair, 1024 points), the rest reduce the Chamfer gradient.
+struct PostArgs { FlowArgs fl; CGradArgs cg; int nfx, nflow, ncx; };
+template <bool ONE>
+__global__ __launch_bounds__(CG_BS) void post_kernel(PostArgs a) {
+    const int w = blockIdx.x;
+    if (w < a.nflow) flow_blend_body<ONE, CG_BS>(a.fl, w % a.nfx, w / a.nfx, a.nfx);
+    else chamfer_grad_body<ONE>(a.cg, (w - a.nflow) % a.ncx, (w - a.nflow) / a.ncx, a.ncx);
 }
 
 // ------------------------------------------------------------------------------ the step
@@ -605,7 +586,12 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
 
     // Fork: the flow branch depends only on the forward output, like the Chamfer search; with an
     // auxiliary stream it runs concurrently (its latency-bound blend then hides under the search).
-    const bool forked = !ev && bufs->aux_stream && bufs->ev_fork && bufs->ev_join && c.use_flow;
+    // merged: both searches in one launch and both of their consumers in one launch (single stream, no
+    // fork / join).  Otherwise (brute force / grid / per-lane variants): separate launches, the flow
+    // branch on the auxiliary stream when the caller provides one.  The timed variant is always separate.
+    const char *mg = getenv("REART_MERGE");
+    const bool merged = !ev && c.use_flow && p.pruned == 1 && !c.use_grid && !(mg && mg[0] == '0');
+    const bool forked = !merged && !ev && bufs->aux_stream && bufs->ev_fork && bufs->ev_join && c.use_flow;
     hipStream_t fst = forked ? (hipStream_t)bufs->aux_stream : st;
     if (forked) {
         if (hipEventRecord((hipEvent_t)bufs->ev_fork, st) != hipSuccess) return REART_ERR_LAUNCH;
@@ -613,6 +599,8 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
     }
     // 3-4. flow: k=3 search of every complete frame in its reference set + blend + loss grad
     int nfp = 0;
+    KnnArgs k3 = {};
+    FlowArgs fl = {};
     if (c.use_flow) {
         const int *qmap = (const int *)(ws + p.o_qmap);
         int S3 = p.S3;
@@ -627,7 +615,6 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
             if (rc != REART_OK) return rc;
             S3 = 1;
         } else {
-            KnnArgs k3 = {};
             k3.N = B; k3.S = p.S3; k3.K = 3; k3.euclidean = 0;
             KnnJob &kj = k3.job[0];
             kj.q = bufs->pc_trans; kj.q_alt = bufs->cano; kj.qmap = qmap;
@@ -640,12 +627,13 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
             k3.items = k3.items0;
             kj.seed = p.pruned ? (const int *)(ws + p.o_seed3) : nullptr;
             k3.job[1] = kj;
-            rc = p.pruned == 2 ? reart_knn_launch_lane(k3, 3, fst)
-                               : (p.pruned ? reart_knn_launch_pruned(k3, 3, fst) : reart_knn_launch_slices(k3, 3, fst));
-            if (rc != REART_OK) return rc;
+            if (!merged) {
+                rc = p.pruned == 2 ? reart_knn_launch_lane(k3, 3, fst)
+                                   : (p.pruned ? reart_knn_launch_pruned(k3, 3, fst) : reart_knn_launch_slices(k3, 3, fst));
+                if (rc != REART_OK) return rc;
+            }
         }
         MARK(2);
-        FlowArgs fl = {};
         fl.pd = (const float *)(ws + p.o_pd3); fl.pi = (const int *)(ws + p.o_pi3); fl.ref_flow = bufs->ref_flow;
         fl.ref_off = bufs->ref_off; fl.qmap = qmap; fl.X = bufs->pc_trans; fl.cano = bufs->cano; fl.N = N; fl.B = B;
         fl.blocks = c.use_grid ? 0 : 1; fl.rsoa = (const float *)(ws + p.o_rsoa); fl.Mpad = p.Mpad;
@@ -653,10 +641,12 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
         fl.smooth = c.smooth_weight; fl.lambda = c.lambda_flow;
         fl.gpf = (float *)(ws + p.o_gpf); fl.part = (double *)(ws + p.o_fpart);
         fl.seed_out = p.pruned ? (int *)(ws + p.o_seed3) : nullptr;
-        const dim3 fg(reart_div_up(N, FLOW_BS), B);
+        const dim3 fg(reart_div_up(N, merged ? CG_BS : FLOW_BS), B);
         nfp = fg.x * fg.y;
-        if (fl.S <= 4) hipLaunchKernelGGL(flow_blend_kernel<true>, fg, dim3(FLOW_BS), 0, fst, fl);
-        else hipLaunchKernelGGL(flow_blend_kernel<false>, fg, dim3(FLOW_BS), 0, fst, fl);
+        if (!merged) {
+            if (fl.S <= 4) hipLaunchKernelGGL(flow_blend_kernel<true>, fg, dim3(FLOW_BS), 0, fst, fl);
+            else hipLaunchKernelGGL(flow_blend_kernel<false>, fg, dim3(FLOW_BS), 0, fst, fl);
+        }
     }
 
     if (forked && hipEventRecord((hipEvent_t)bufs->ev_join, fst) != hipSuccess) return REART_ERR_LAUNCH;
@@ -696,8 +686,9 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
         ka.items0 = B * ka.job[0].nqg * p.S1;
         ka.items = 2 * ka.items0;
     }
-    rc = p.pruned == 2 ? reart_knn_launch_lane(ka, 1, st)
-                       : (p.pruned ? reart_knn_launch_pruned(ka, 1, st) : reart_knn_launch_slices(ka, 1, st));
+    if (merged) rc = reart_knn_launch_pruned_pair(ka, k3, st);
+    else rc = p.pruned == 2 ? reart_knn_launch_lane(ka, 1, st)
+                            : (p.pruned ? reart_knn_launch_pruned(ka, 1, st) : reart_knn_launch_slices(ka, 1, st));
     if (rc != REART_OK) return rc;
 
     MARK(4);
@@ -713,7 +704,13 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
     cg.seed0 = p.pruned ? (int *)(ws + p.o_seed0) : nullptr;
     cg.seed1 = p.pruned ? (int *)(ws + p.o_seed1) : nullptr;
     const int ncg = reart_div_up(N, CG_RANGE);
-    if (cg.S0 <= 4 && cg.S1 <= 4) hipLaunchKernelGGL(chamfer_grad_kernel<true>, dim3(ncg, B), dim3(CG_BS), 0, st, cg);
+    if (merged) {
+        PostArgs pa;
+        pa.fl = fl; pa.cg = cg; pa.nfx = reart_div_up(N, CG_BS); pa.nflow = pa.nfx * B; pa.ncx = ncg;
+        const int nblk = pa.nflow + ncg * B;
+        if (cg.S0 <= 4 && cg.S1 <= 4 && fl.S <= 4) hipLaunchKernelGGL(post_kernel<true>, dim3(nblk), dim3(CG_BS), 0, st, pa);
+        else hipLaunchKernelGGL(post_kernel<false>, dim3(nblk), dim3(CG_BS), 0, st, pa);
+    } else if (cg.S0 <= 4 && cg.S1 <= 4) hipLaunchKernelGGL(chamfer_grad_kernel<true>, dim3(ncg, B), dim3(CG_BS), 0, st, cg);
     else hipLaunchKernelGGL(chamfer_grad_kernel<false>, dim3(ncg, B), dim3(CG_BS), 0, st, cg);
     REART_CHECK_LAUNCH();
     MARK(5);
@@ -734,18 +731,19 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
     ad.m = bufs->adam_m; ad.v = bufs->adam_v; ad.seg_lr = c.seg_lr; ad.trans_lr = c.trans_lr;
     ad.beta1 = c.beta1; ad.beta2 = c.beta2; ad.eps = c.eps; ad.step_ptr = bufs->iter;
     ad.bias_corr = (const double *)(ws + p.o_bc);
-    rc = reart_base_backward_ex(ba, &ad, ws + p.o_bwd, p.bwd_bytes, st);
+    // loss log, iter++, next tau and bias corrections: last workgroup of the finalize kernel
+    const int ncgp = reart_div_up(N, CG_RANGE);
+    StepBook bk = {};
+    bk.enabled = 1; bk.frame_loss = (const double *)(ws + p.o_floss); bk.n_frame_part = B * ncgp;
+    bk.flow_part = (const double *)(ws + p.o_fpart); bk.n_flow_part = nfp;
+    bk.iter = bufs->iter; bk.tau = bufs->tau; bk.losses = bufs->losses; bk.bias_corr = (double *)(ws + p.o_bc);
+    bk.ticket = (unsigned int *)(ws + p.o_ticket);
+    bk.ring = c.ring; bk.n_iter = c.n_iter; bk.lambda_flow = c.lambda_flow; bk.fixed_tau = c.fixed_tau;
+    bk.end_tau = c.end_tau; bk.start_tau = c.start_tau; bk.beta1 = c.beta1; bk.beta2 = c.beta2;
+    rc = reart_base_backward_ex(ba, &ad, &bk, ws + p.o_bwd, p.bwd_bytes, st);
     if (rc != REART_OK) return rc;
     MARK(6);
     MARK(7);
-
-    // 10. loss log, iter++, next tau
-    BookArgs bk = {};
-    bk.c = c; bk.frame_loss = (const double *)(ws + p.o_floss); bk.n_frame_part = B * ncg; bk.flow_part = (const double *)(ws + p.o_fpart);
-    bk.n_flow_part = nfp; bk.iter = bufs->iter; bk.tau = bufs->tau; bk.losses = bufs->losses;
-    bk.bias_corr = (double *)(ws + p.o_bc);
-    hipLaunchKernelGGL(bookkeep_kernel, dim3(1), dim3(256), 0, st, bk);
-    REART_CHECK_LAUNCH();
     MARK(8);
     return REART_OK;
 }

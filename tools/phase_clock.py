@@ -15,4 +15,7 @@ for rep in range(3):
     v = list(buf)
     for w, name, n in ((0, "fwd", 6), (1, "bwd_block", 9)):
         ts = v[16 * w:16 * w + n]
+        if w == 1:
+            x = v[16:32]
+            print("bwd prologue (serialised): hT tile", x[9] - x[0], "G tile", x[10] - x[9], "rt", x[11] - x[10], "W2T", x[12] - x[11], "rest", x[1] - x[12])
         print(name, "deltas (shader cycles; /2400 = us @2.4GHz... s_memtime may tick at 100 MHz):", [ts[i + 1] - ts[i] for i in range(n - 1)], "total", ts[n - 1] - ts[0])
