@@ -333,6 +333,19 @@ int reart_grid_knn(const float *targets, const int32_t *offsets, int E, int Nt_m
                    const float *queries, int nq, int K, float *dists, int32_t *idx,
                    void *workspace, size_t workspace_bytes, void *stream);
 
+/* Warm-started exact K-NN for repeated searches on slowly moving clouds (the relaxation loop repeats
+ * the searches of utils/chamfer.py:78-94 and utils/flow_utils.py:158 every iteration).  Same result,
+ * bit for bit, as reart_knn_points_idx for K in {1, 3} (full lengths), whatever `seed` holds: the
+ * seeds (neighbour indices of an earlier call, -1 / out-of-range / repeated entries are tolerated)
+ * only bound the search so that bounding boxes of 16 consecutive targets can be skipped, which pays
+ * when both clouds are stored in a spatially coherent order (k-d tree leaf or Morton order).
+ *   p1 [N,P1,3] queries, p2 [N,P2,3] targets; seed [N,P1,K] i32 in/out (receives idx);
+ *   dists [N,P1,K] squared, ascending; idx [N,P1,K] i64.  The fused step uses the same kernels. */
+size_t reart_knn_points_warm_workspace_bytes(int N, int P1, int P2, int K);
+int reart_knn_points_idx_warm(const float *p1, const float *p2, int N, int P1, int P2, int K,
+                              int32_t *seed, float *dists, int64_t *idx, void *workspace,
+                              size_t workspace_bytes, void *stream);
+
 /* ------------------------------------------------------------------------ */
 /* Correspondence matching on the extractor's descriptors                    */
 /* ------------------------------------------------------------------------ */

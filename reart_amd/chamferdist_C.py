@@ -76,3 +76,31 @@ def chamfer_bidir(x, y):
                                _lib.ptr(i_yx), _lib.ptr(ws), ws.numel(), _lib.stream())
     _lib.check(rc, "reart_chamfer_bidir")
     return d_xy, i_xy, d_yx, i_yx
+
+
+def knn_points_idx_warm(p1, p2, K, seed=None):
+    """Warm-started exact search (``reart_knn_points_idx_warm``): same (idx, dists) as
+    ``knn_points_idx(p1, p2, None, None, K)`` for K in {1, 3}, bit for bit, whatever ``seed`` holds.
+    ``seed`` [N,P1,K] int32 is updated in place with the new neighbour indices (pass it to the next
+    call on the moved clouds); ``None`` starts cold.  Not part of the reference's ``_C`` module: it is
+    the stand-alone form of the search the fused relaxation step runs every iteration.
+    -> (idx int64 [N,P1,K], dists float32 [N,P1,K], seed)"""
+    _lib.require_gpu(p1, p2)
+    if p1.dtype != torch.float32 or p2.dtype != torch.float32:
+        raise TypeError("knn_points_idx_warm expects float32 point clouds")
+    p1, p2 = p1.contiguous(), p2.contiguous()
+    N, P1, _ = p1.shape
+    P2 = p2.shape[1]
+    if seed is None:
+        seed = torch.full((N, P1, K), -1, dtype=torch.int32, device=p1.device)
+    if seed.dtype != torch.int32 or not seed.is_contiguous() or tuple(seed.shape) != (N, P1, K):
+        raise TypeError("seed must be a contiguous int32 tensor [N,P1,K]")
+    dists = torch.empty((N, P1, K), dtype=torch.float32, device=p1.device)
+    idx = torch.empty((N, P1, K), dtype=torch.int64, device=p1.device)
+    L = _lib.lib()
+    nbytes = L.reart_knn_points_warm_workspace_bytes(N, P1, P2, K)
+    ws = _lib.workspace(nbytes, p1.device)
+    rc = L.reart_knn_points_idx_warm(_lib.ptr(p1), _lib.ptr(p2), N, P1, P2, K, _lib.ptr(seed), _lib.ptr(dists),
+                                     _lib.ptr(idx), _lib.ptr(ws), ws.numel(), _lib.stream())
+    _lib.check(rc, "reart_knn_points_idx_warm")
+    return idx, dists, seed

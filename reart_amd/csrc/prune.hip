@@ -277,3 +277,121 @@ int reart_prune_pick_split(void) {
     const int S = env ? atoi(env) : 4;
     return S >= 1 && S <= 16 ? S : 4;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Stand-alone entry: warm-started exact K-NN (K = 1 or 3) through the C ABI.
+// ---------------------------------------------------------------------------------------------
+// merge the S slice partials of one query by the (distance, index) key; K = 3 partials are blocks of
+// 8 targets (block minimum, first index) that are rescanned here with the exact key
+template <int KK>
+__global__ __launch_bounds__(256) void knn_warm_finish_kernel(KnnArgs a) {
+    const KnnJob jb = a.job[0];
+    const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= jb.P1) return;
+    float kd[KK];
+    int ki[KK];
+#pragma unroll
+    for (int k = 0; k < KK; ++k) { kd[k] = INFINITY; ki[k] = 0x7fffffff; }
+    auto insert = [&](float d, int j) {
+#pragma unroll
+        for (int s = KK - 1; s >= 0; --s) {
+            const int sp = s > 0 ? s - 1 : 0;
+            const bool lp = (s > 0) && ((d < kd[sp]) | ((d == kd[sp]) & (j < ki[sp])));
+            const bool lc = (d < kd[s]) | ((d == kd[s]) & (j < ki[s]));
+            kd[s] = lp ? kd[sp] : (lc ? d : kd[s]);
+            ki[s] = lp ? ki[sp] : (lc ? j : ki[s]);
+        }
+    };
+    for (int s = 0; s < a.S; ++s) {
+        const size_t o = (((size_t)s * a.N + b) * jb.P1 + i) * KK;
+#pragma unroll
+        for (int k = 0; k < KK; ++k) {
+            const float d = jb.pd[o + k];
+            insert(d, d < INFINITY ? jb.pi[o + k] : 0x7fffffff);
+        }
+    }
+    if (KK > 1) {
+        const float *qp = jb.q + ((size_t)b * jb.P1 + i) * 3;
+        const float qx = qp[0], qy = qp[1], qz = qp[2];
+        const float *tx = jb.tsoa + (size_t)b * 3 * jb.Ppad, *ty = tx + jb.Ppad, *tz = ty + jb.Ppad;
+        int blk[KK];
+#pragma unroll
+        for (int k = 0; k < KK; ++k) { blk[k] = kd[k] < INFINITY ? ki[k] : -1; kd[k] = INFINITY; ki[k] = 0x7fffffff; }
+#pragma unroll
+        for (int c = 0; c < KK; ++c) {
+            if (blk[c] < 0) continue;
+            for (int u = 0; u < 8; ++u) {
+                const int jj = blk[c] + u;
+                const float d = reart_sqdist3(qx, qy, qz, tx[jj], ty[jj], tz[jj]);
+                insert(d, d < INFINITY ? jj : 0x7fffffff);
+            }
+        }
+    }
+    const int n2 = jb.P2;
+    const int valid = KK < n2 ? KK : n2;
+#pragma unroll
+    for (int k = 0; k < KK; ++k) {
+        const bool ok = k < valid && ki[k] != 0x7fffffff;
+        const size_t o = ((size_t)b * jb.P1 + i) * KK + k;
+        jb.dists[o] = ok ? kd[k] : 0.0f;
+        jb.idx[o] = ok ? (int64_t)ki[k] : (int64_t)0;
+        ((int *)jb.seed)[o] = ok ? ki[k] : -1;     // warm start of the next call
+    }
+}
+
+struct WarmPlan { int S, Ppad; size_t o_soa, o_box, o_pd, o_pi, total; };
+static int warm_plan(int N, int P1, int P2, int K, WarmPlan *p) {
+    if (N < 0 || P1 < 0 || P2 < 0 || (K != 1 && K != 3)) return REART_ERR_INVALID_ARG;
+    p->S = reart_prune_pick_split();
+    while (p->S > 1 && reart_div_up(P2, p->S) < 64) p->S /= 2;
+    p->Ppad = (int)reart_align_up((size_t)(P2 > 0 ? P2 : 1), NN_BOX);
+    size_t off = 0;
+    p->o_soa = off; off += reart_align_up(sizeof(float) * 3 * (size_t)N * p->Ppad, 256);
+    p->o_box = off; off += reart_align_up(sizeof(float) * 8 * (size_t)N * (p->Ppad / NN_BOX), 256);
+    p->o_pd = off; off += reart_align_up(sizeof(float) * (size_t)p->S * N * P1 * K, 256);
+    p->o_pi = off; off += reart_align_up(sizeof(int) * (size_t)p->S * N * P1 * K, 256);
+    p->total = off;
+    return REART_OK;
+}
+
+extern "C" size_t reart_knn_points_warm_workspace_bytes(int N, int P1, int P2, int K) {
+    WarmPlan p;
+    return warm_plan(N, P1, P2, K, &p) == REART_OK ? p.total : 0;
+}
+
+extern "C" int reart_knn_points_idx_warm(const float *p1, const float *p2, int N, int P1, int P2, int K,
+                                         int32_t *seed, float *dists, int64_t *idx, void *workspace,
+                                         size_t workspace_bytes, void *stream) {
+    WarmPlan p;
+    int rc = warm_plan(N, P1, P2, K, &p);
+    if (rc != REART_OK) return rc;
+    if (N == 0 || P1 == 0) return REART_OK;
+    if (!p1 || !p2 || !seed || !dists || !idx || P2 < 1) return REART_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < p.total) return REART_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    char *ws = (char *)workspace;
+    SoaArgs sa = {};
+    for (int j = 0; j < 2; ++j) {
+        sa.job[j].src = p2; sa.job[j].len = nullptr; sa.job[j].dst = (float *)(ws + p.o_soa);
+        sa.job[j].P = P2; sa.job[j].Ppad = p.Ppad;
+    }
+    rc = reart_soa_launch(sa, p.Ppad, N, 1, st);
+    if (rc != REART_OK) return rc;
+    rc = reart_boxes_launch((const float *)(ws + p.o_soa), N, p.Ppad, (float *)(ws + p.o_box), st);
+    if (rc != REART_OK) return rc;
+    KnnArgs a = {};
+    a.N = N; a.S = p.S; a.K = K; a.euclidean = 0;
+    KnnJob &jb = a.job[0];
+    jb.q = p1; jb.tsoa = (const float *)(ws + p.o_soa); jb.boxes = (const float *)(ws + p.o_box);
+    jb.seed = seed; jb.P1 = P1; jb.P2 = P2; jb.Ppad = p.Ppad; jb.L = 0; jb.nqg = reart_div_up(P1, NN_BS);
+    jb.pd = (float *)(ws + p.o_pd); jb.pi = (int *)(ws + p.o_pi); jb.dists = dists; jb.idx = idx;
+    a.job[1] = jb;
+    a.items0 = N * jb.nqg * p.S; a.items = a.items0;
+    rc = reart_knn_launch_pruned(a, K, st);
+    if (rc != REART_OK) return rc;
+    const dim3 fg(reart_div_up(P1, 256), N);
+    if (K == 1) hipLaunchKernelGGL((knn_warm_finish_kernel<1>), fg, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((knn_warm_finish_kernel<3>), fg, dim3(256), 0, st, a);
+    REART_CHECK_LAUNCH();
+    return REART_OK;
+}
