@@ -86,7 +86,7 @@ def main():
     ap.add_argument("--steps-per-graph", type=int, default=10,
                     help="iterations captured per graph (a graph launch costs ~8 us of idle GPU; the loop has no "
                          "host interaction, so several iterations replay as one graph)")
-    ap.add_argument("--no-overlap", action="store_true", help="run the flow branch serially (profiling: isolated kernel durations)")
+    ap.add_argument("--no-overlap", action="store_true", help="only affects the non-default search paths (brute force / grid): run their flow branch serially instead of on a second stream")
     ap.add_argument("--grid", action="store_true", help="exact grid search for the static targets (same results; slower at this size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--instances-per-gpu", type=int, default=1,
@@ -162,27 +162,43 @@ def main():
     phases = eng.step_timed(args.profile_steps) if args.profile_steps > 0 else {}
     if rank == 0:
         B = T - 1
-        # algorithmic bytes / flops of the dominant kernel (Chamfer K=1 search, both directions),
-        # per direction read both clouds once + write f32 dist + i64 idx
+        # Dominant kernel: the search launch.  With the flow loss it is ONE kernel (knn_pruned_pair_kernel)
+        # holding the Chamfer K=1 search in both directions and the flow K=3 search.
+        # Algorithmic bytes / flops per launch: every operand once, 8 flop per pair:
+        #   Chamfer, per direction: read both clouds + write f32 dist + i64 idx; 2 B N^2 pairs
+        #   flow: read queries and reference sets + write 3 x (f32 + i64);      B N M pairs
+        M = 3000
         nn_bytes = 2 * (B * (N + N) * 12 + B * N * (4 + 8))
         nn_flops = 2 * B * N * N * 8
+        kname = "knn_pruned_kernel<1> (Chamfer K=1 search, both directions)"
+        if use_flow:
+            nn_bytes += B * (N * 12 + M * 12 + N * 3 * (4 + 8))
+            nn_flops += B * N * M * 8
+            kname = "knn_pruned_pair_kernel (Chamfer K=1 both directions + flow K=3, one launch)"
         roof = None
         if phases:
-            t_nn = phases["chamfer_nn"] * 1e-3
+            try:   # back-to-back launches of the search alone between two HIP events on the launch stream
+                k_ms, how = eng.search_ms(20), "mean of 20 back-to-back launches of the search kernel between two HIP events on the launch stream, at the optimisation state reached after the timed region"
+            except RuntimeError:
+                k_ms, how = phases["chamfer_nn"], "HIP events around the launch in eager serial steps after the timed region"
+                if use_flow:
+                    k_ms += phases["flow_knn3"]
+            t_nn = k_ms * 1e-3
             ach = nn_bytes / t_nn / 1e9
             traffic = None
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc_chamfer_nn.json")
-            if os.path.exists(pmc):
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc_search.json")
+            if os.path.exists(pmc) and use_flow:
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
             roof = {"bound": "hbm", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": traffic,
-                    "kernel": "knn_slice_kernel<1,false> (Chamfer K=1 search, both directions)",
-                    "kernel_ms": round(phases["chamfer_nn"], 5), "algorithmic_bytes": nn_bytes,
-                    "note": "kernel is fp32-VALU bound by construction (910 flop/B); see `valu`. kernel_ms: HIP events "
-                            "on the launch stream over eager, serial (no fork/join) steps after the timed region",
+                    "kernel": kname, "kernel_ms": round(k_ms, 5), "algorithmic_bytes": nn_bytes,
+                    "note": "the search is fp32-VALU bound by construction (>900 flop/B), see `valu`; kernel_ms: " + how,
                     "valu": {"achieved": round(nn_flops / t_nn / 1e12, 3), "peak": FP32_PEAK_TFLOPS,
                              "unit": "TFLOP/s", "frac": round(nn_flops / t_nn / 1e12 / FP32_PEAK_TFLOPS, 4),
-                             "flops": nn_flops}}
+                             "flops": nn_flops,
+                             "note": "ALGORITHMIC flops (8 per query-target pair of the brute-force definition) over "
+                                     "time; the exact box-pruned search evaluates only the pairs it cannot rule out, "
+                                     "so this is work delivered, not ALU activity"}}
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(seq, T, N, cano_idx)
@@ -203,7 +219,7 @@ def main():
                                    + ("+flow loss (k=3 blend, 3000 refs/pair)" if use_flow else " only")
                                    + ", full iteration fwd+loss+bwd+Adam, one instance per GPU",
                        "frames": T, "points": N, "parts": 20, "flow": use_flow,
-                       "graph": not args.no_graph, "steps_per_graph": (0 if args.no_graph else max(1, args.steps_per_graph)), "grid_search_static_targets": args.grid, "flow_branch_overlap": not args.no_overlap, "parallelism": f"instances x{world}" + (f" x{K} per GPU" if K > 1 else ""),
+                       "graph": not args.no_graph, "steps_per_graph": (0 if args.no_graph else max(1, args.steps_per_graph)), "grid_search_static_targets": args.grid, "parallelism": f"instances x{world}" + (f" x{K} per GPU" if K > 1 else ""),
                        "instances_per_gpu": K},
             "roofline": roof,
             "cpu_baseline": cpu,

@@ -221,16 +221,25 @@ size_t reart_relax_workspace_bytes(const reart_relax_config *cfg);
 /* once per problem: static SoA images of pc_list / reference sets, tau(iter) */
 int reart_relax_prepare(const reart_relax_config *cfg, const reart_relax_buffers *bufs,
                         void *workspace, size_t workspace_bytes, void *stream);
-/* enqueue one iteration (10 launches, no host sync) */
+/* enqueue one iteration (5 launches in the default configuration, no host sync) */
 int reart_relax_step(const reart_relax_config *cfg, const reart_relax_buffers *bufs,
                      void *workspace, size_t workspace_bytes, void *stream);
 /* measurement aid: the same sequence with hipEvents between phases on `stream`; synchronises
  * and ADDS per-phase milliseconds to the HOST array h_ms[REART_RELAX_PHASES]:
- * 0 forward, 1 flow K=3 search, 2 flow blend, 3 Chamfer K=1 search, 4 Chamfer merge + gradient
- * scatter, 5 model backward + Adam, 6 unused, 7 bookkeeping.  Always serial (no fork/join). */
+ * 0 forward, 1 flow K=3 search, 2 flow blend, 3 Chamfer K=1 search, 4 Chamfer merge + gradient,
+ * 5 model backward + Adam + bookkeeping, 6-7 unused.  In the default configuration (pruned searches,
+ * flow loss on) both searches share ONE launch and both consumers share ONE launch: phases 1-2 are
+ * then empty, 3 = the search launch, 4 = the consumer launch.  Always serial (no fork/join); event
+ * pairs around single launches over-read short kernels by a few microseconds. */
 #define REART_RELAX_PHASES 8
 int reart_relax_step_timed(const reart_relax_config *cfg, const reart_relax_buffers *bufs,
                            void *workspace, size_t workspace_bytes, void *stream, float *h_ms);
+/* measurement aid: average milliseconds of the search launch alone (both Chamfer directions + flow
+ * K=3 in one kernel) at the current optimisation state: forward once, then `reps` back-to-back search
+ * launches between two events on `stream`.  Modifies no parameter, counter or seed; synchronises.
+ * REART_ERR_UNSUPPORTED outside the default configuration (pruned searches with the flow loss). */
+int reart_relax_search_ms(const reart_relax_config *cfg, const reart_relax_buffers *bufs,
+                          void *workspace, size_t workspace_bytes, void *stream, int reps, float *h_ms);
 
 /* ------------------------------------------------------------------------ */
 /* PointNet++ sampling / grouping (the live kernels of pointnet2_cuda)       */

@@ -60,6 +60,7 @@ PROTOTYPES = {
     "reart_relax_prepare": (c_int, None),
     "reart_relax_step": (c_int, None),
     "reart_relax_step_timed": (c_int, None),
+    "reart_relax_search_ms": (c_int, None),
 }
 
 _lib = None

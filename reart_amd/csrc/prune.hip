@@ -229,9 +229,8 @@ __global__ __launch_bounds__(NN_BS * PR_WPB) void knn_pruned_kernel(KnnArgs a) {
 // independent, and a single dispatch lets them share the chip without the cross-queue fork / join of
 // two streams (measured ~6-12 us per dependency edge in a replayed graph).  Two K = 1 items alternate
 // with one K = 3 item while both kinds last.
-struct KnnPairArgs { KnnArgs k1, k3; int mixed; };   // mixed = 3 * min(items1 / 2, items3)
-__global__ __launch_bounds__(NN_BS * PR_WPB) void knn_pruned_pair_kernel(KnnPairArgs a) {
-    const int w = blockIdx.x * PR_WPB + (threadIdx.x >> 6);
+struct KnnPairArgs { KnnArgs k1, k3; int mixed; unsigned int *ctr; };   // mixed = 3 * min(items1 / 2, items3)
+__device__ __forceinline__ void knn_pruned_pair_item(const KnnPairArgs &a, const int w) {
     if (w < a.mixed) {
         const int q = w / 3, r = w - 3 * q;
         if (r < 2) knn_pruned_body<1>(a.k1, 2 * q + r);
@@ -243,8 +242,18 @@ __global__ __launch_bounds__(NN_BS * PR_WPB) void knn_pruned_pair_kernel(KnnPair
         else if (v - (a.k1.items - d1) < a.k3.items - d3) knn_pruned_body<3>(a.k3, d3 + (v - (a.k1.items - d1)));
     }
 }
+__global__ __launch_bounds__(NN_BS * PR_WPB) void knn_pruned_pair_kernel(KnnPairArgs a) {
+    knn_pruned_pair_item(a, blockIdx.x * PR_WPB + (threadIdx.x >> 6));
+}
+// Persistent form: a fixed number of one-wave workgroups (a few per SIMD) each take every
+// gridDim.x-th work item.  (Drawing items from one device counter was tried: ~15 k atomics on one
+// address serialise at the memory side and tripled the kernel time.)
+__global__ __launch_bounds__(NN_BS) void knn_pruned_pair_persistent_kernel(KnnPairArgs a) {
+    const int total = a.k1.items + a.k3.items;
+    for (int w = blockIdx.x; w < total; w += gridDim.x) knn_pruned_pair_item(a, w);
+}
 
-int reart_knn_launch_pruned_pair(const KnnArgs &k1, const KnnArgs &k3, hipStream_t st) {
+int reart_knn_launch_pruned_pair(const KnnArgs &k1, const KnnArgs &k3, unsigned int *counters, hipStream_t st) {
     for (int j = 0; j < 2; ++j)
         if (!k1.job[j].boxes || !k1.job[j].seed || !k3.job[j].boxes || !k3.job[j].seed) return REART_ERR_INVALID_ARG;
     if (k1.items != 2 * k1.items0 || k3.items != k3.items0) return REART_ERR_INVALID_ARG;
@@ -252,7 +261,18 @@ int reart_knn_launch_pruned_pair(const KnnArgs &k1, const KnnArgs &k3, hipStream
     a.k1 = k1; a.k3 = k3;
     const int m = (k1.items / 2 < k3.items) ? k1.items / 2 : k3.items;
     a.mixed = 3 * m;
-    hipLaunchKernelGGL(knn_pruned_pair_kernel, dim3(reart_div_up(k1.items + k3.items, PR_WPB)), dim3(NN_BS * PR_WPB), 0, st, a);
+    a.ctr = counters;
+    const char *pe = getenv("REART_PERSIST");
+    // persistent waves per SIMD; 0 (default) = one workgroup per item.  Measured equal at 7 per SIMD and
+    // slower below: the launch is bound by its arithmetic, not by the rate at which workgroups start.
+    const int wps = pe ? atoi(pe) : 0;
+    if (counters && wps > 0) {
+        int nwg = 256 * 4 * wps;
+        if (nwg > k1.items + k3.items) nwg = k1.items + k3.items;
+        hipLaunchKernelGGL(knn_pruned_pair_persistent_kernel, dim3(nwg), dim3(NN_BS), 0, st, a);
+    } else {
+        hipLaunchKernelGGL(knn_pruned_pair_kernel, dim3(reart_div_up(k1.items + k3.items, PR_WPB)), dim3(NN_BS * PR_WPB), 0, st, a);
+    }
     REART_CHECK_LAUNCH();
     return REART_OK;
 }

@@ -87,7 +87,7 @@ static int step_plan(const reart_relax_config *c, StepPlan *p) {
     p->bwd_bytes = reart_base_backward_workspace_bytes(c->N, c->P, c->B, c->H);
     p->o_bwd = take(off, p->bwd_bytes);
     p->o_bc = take(off, 2 * sizeof(double));
-    p->o_ticket = take(off, sizeof(unsigned int));
+    p->o_ticket = take(off, 4 * sizeof(unsigned int));   // [0] finalize ticket, [2..3] persistent-search counters
     p->o_boxY = take(off, sizeof(float) * 8 * (size_t)c->B * (p->Npad / NN_BOX));
     p->o_boxX = take(off, sizeof(float) * 8 * (size_t)c->B * (p->Npad / NN_BOX));
     p->o_boxR = take(off, sizeof(float) * 8 * (size_t)c->B * (p->Mpad / NN_BOX + 1));
@@ -191,7 +191,7 @@ extern "C" int reart_relax_prepare(const reart_relax_config *cfg, const reart_re
                        (int *)(ws + p.o_rlen), (int *)(ws + p.o_qmap), bufs->iter, bufs->tau, bufs->pc_list,
                        (int *)(ws + p.o_fx), (double *)(ws + p.o_bc),
                        (p.pruned && cfg->use_flow) ? (int *)(ws + p.o_seed3) : nullptr);
-    if (hipMemsetAsync(ws + p.o_ticket, 0, sizeof(unsigned int), st) != hipSuccess) return REART_ERR_LAUNCH;
+    if (hipMemsetAsync(ws + p.o_ticket, 0, 4 * sizeof(unsigned int), st) != hipSuccess) return REART_ERR_LAUNCH;
     if (p.pruned) {  // warm start of the first Chamfer search: index 0 (any valid index)
         if (hipMemsetAsync(ws + p.o_seed0, 0, sizeof(int) * (size_t)cfg->B * cfg->N, st) != hipSuccess) return REART_ERR_LAUNCH;
         if (hipMemsetAsync(ws + p.o_seed1, 0, sizeof(int) * (size_t)cfg->B * cfg->N, st) != hipSuccess) return REART_ERR_LAUNCH;
@@ -544,16 +544,13 @@ __global__ __launch_bounds__(CG_BS) void post_kernel(PostArgs a) {
 }
 
 // ------------------------------------------------------------------------------ the step
-// Timed variant only: keeps the GPU busy while the host enqueues the whole step, so that the events
-// between the launches measure device time and not the host's launch rate.
-__global__ void spin_kernel(long long ticks) {
-    const long long t0 = (long long)__builtin_amdgcn_s_memtime();
-    while ((long long)__builtin_amdgcn_s_memtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
-}
 #define MARK(k) do { if (ev) (void)hipEventRecord(ev[k], st); } while (0)
 
+// search_reps > 0: measurement of the search launch alone -- forward once, then the search launch
+// `search_reps` times between ev[0] and ev[1] (its inputs do not change between repetitions), nothing else.
 static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buffers *bufs,
-                           void *workspace, size_t workspace_bytes, void *stream, hipEvent_t *ev) {
+                           void *workspace, size_t workspace_bytes, void *stream, hipEvent_t *ev,
+                           int search_reps = 0) {
     StepPlan p;
     if (!cfg || !bufs) return REART_ERR_INVALID_ARG;
     int rc = step_plan(cfg, &p);
@@ -578,11 +575,10 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
     fa.hard_idx = (int *)(ws + p.o_hard);
     fa.rt_table = (float *)(ws + p.o_rt);
     fa.boxes = c.use_boxes ? (float *)(ws + p.o_boxX) : nullptr;
-    if (ev) hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(1), 0, st, 700000ll);   // ~0.3 ms at 2.4 GHz
-    MARK(0);
+    if (!search_reps) MARK(0);
     rc = reart_base_forward_ex(fa, st);
     if (rc != REART_OK) return rc;
-    MARK(1);
+    if (!search_reps) MARK(1);
 
     // Fork: the flow branch depends only on the forward output, like the Chamfer search; with an
     // auxiliary stream it runs concurrently (its latency-bound blend then hides under the search).
@@ -590,7 +586,7 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
     // fork / join).  Otherwise (brute force / grid / per-lane variants): separate launches, the flow
     // branch on the auxiliary stream when the caller provides one.  The timed variant is always separate.
     const char *mg = getenv("REART_MERGE");
-    const bool merged = !ev && c.use_flow && p.pruned == 1 && !c.use_grid && !(mg && mg[0] == '0');
+    const bool merged = c.use_flow && p.pruned == 1 && !c.use_grid && !(mg && mg[0] == '0');
     const bool forked = !merged && !ev && bufs->aux_stream && bufs->ev_fork && bufs->ev_join && c.use_flow;
     hipStream_t fst = forked ? (hipStream_t)bufs->aux_stream : st;
     if (forked) {
@@ -633,7 +629,7 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
                 if (rc != REART_OK) return rc;
             }
         }
-        MARK(2);
+        if (!search_reps) MARK(2);
         fl.pd = (const float *)(ws + p.o_pd3); fl.pi = (const int *)(ws + p.o_pi3); fl.ref_flow = bufs->ref_flow;
         fl.ref_off = bufs->ref_off; fl.qmap = qmap; fl.X = bufs->pc_trans; fl.cano = bufs->cano; fl.N = N; fl.B = B;
         fl.blocks = c.use_grid ? 0 : 1; fl.rsoa = (const float *)(ws + p.o_rsoa); fl.Mpad = p.Mpad;
@@ -650,8 +646,8 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
     }
 
     if (forked && hipEventRecord((hipEvent_t)bufs->ev_join, fst) != hipSuccess) return REART_ERR_LAUNCH;
-    if (!c.use_flow) MARK(2);
-    MARK(3);
+    if (!c.use_flow && !search_reps) MARK(2);
+    if (!search_reps) MARK(3);
 
     // 2. Chamfer (utils/chamfer.py:78-94).  pc_list never changes: with use_grid the direction
     // pc_trans -> pc_list goes through its pre-built exact grid, and only pc_list -> pc_trans (moving
@@ -686,7 +682,24 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
         ka.items0 = B * ka.job[0].nqg * p.S1;
         ka.items = 2 * ka.items0;
     }
-    if (merged) rc = reart_knn_launch_pruned_pair(ka, k3, st);
+    if (search_reps) {
+        if (!merged) return REART_ERR_UNSUPPORTED;
+        // two untimed launches first: the host gets ahead of the device (each launch takes the host a few
+        // microseconds, the kernel tens), so the timed launches run back to back.  (A one-wave spin kernel
+        // as a host-side head start was tried and rejected: the chip drops its clock while it spins.)
+        for (int r = 0; r < 2; ++r) {
+            rc = reart_knn_launch_pruned_pair(ka, k3, (unsigned int *)(ws + p.o_ticket) + 2, st);
+            if (rc != REART_OK) return rc;
+        }
+        (void)hipEventRecord(ev[0], st);
+        for (int r = 0; r < search_reps; ++r) {
+            rc = reart_knn_launch_pruned_pair(ka, k3, (unsigned int *)(ws + p.o_ticket) + 2, st);
+            if (rc != REART_OK) return rc;
+        }
+        (void)hipEventRecord(ev[1], st);
+        return REART_OK;
+    }
+    if (merged) rc = reart_knn_launch_pruned_pair(ka, k3, (unsigned int *)(ws + p.o_ticket) + 2, st);
     else rc = p.pruned == 2 ? reart_knn_launch_lane(ka, 1, st)
                             : (p.pruned ? reart_knn_launch_pruned(ka, 1, st) : reart_knn_launch_slices(ka, 1, st));
     if (rc != REART_OK) return rc;
@@ -775,5 +788,27 @@ extern "C" int reart_relax_step_timed(const reart_relax_config *cfg, const reart
         }
     }
     for (int k = 0; k <= REART_RELAX_PHASES; ++k) (void)hipEventDestroy(ev[k]);
+    return rc;
+}
+
+// Average duration of the search launch (knn_pruned_pair_kernel: Chamfer K = 1 both directions + flow
+// K = 3) at the CURRENT state of the optimisation: the forward is run once, then the search `reps` times
+// back to back between two events on `stream`.  Parameters, counters and seeds are not modified.
+// Only for the default fused configuration (merged launches); synchronises.
+extern "C" int reart_relax_search_ms(const reart_relax_config *cfg, const reart_relax_buffers *bufs,
+                                     void *workspace, size_t workspace_bytes, void *stream, int reps,
+                                     float *h_ms) {
+    if (!h_ms || reps < 1) return REART_ERR_INVALID_ARG;
+    hipEvent_t ev[2];
+    for (int k = 0; k < 2; ++k)
+        if (hipEventCreate(&ev[k]) != hipSuccess) return REART_ERR_LAUNCH;
+    int rc = relax_step_impl(cfg, bufs, workspace, workspace_bytes, stream, ev, reps);
+    if (rc == REART_OK) {
+        float ms = 0.f;
+        if (hipEventSynchronize(ev[1]) != hipSuccess || hipEventElapsedTime(&ms, ev[0], ev[1]) != hipSuccess)
+            rc = REART_ERR_LAUNCH;
+        *h_ms = ms / (float)reps;
+    }
+    for (int k = 0; k < 2; ++k) (void)hipEventDestroy(ev[k]);
     return rc;
 }

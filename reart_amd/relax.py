@@ -1,5 +1,5 @@
 """Fused relaxation engine: the reference's optimisation loop body (run_robot.py:154-221,
-Chamfer [+ flow] branch) as ten HIP kernel launches per iteration, optionally replayed from a
+Chamfer [+ flow] branch) as five HIP kernel launches per iteration, optionally replayed from a
 captured graph.  ``RelaxEngine`` owns the torch tensors (device memory) and hands raw pointers
 to ``reart_relax_prepare`` / ``reart_relax_step`` (include/reart_hip.h)."""
 import ctypes
@@ -84,6 +84,9 @@ def _lib_fns():
         L.reart_relax_step_timed.restype = c_int
         L.reart_relax_step_timed.argtypes = [ctypes.POINTER(RelaxConfig), ctypes.POINTER(RelaxBuffers), c_void_p,
                                              ctypes.c_size_t, c_void_p, ctypes.POINTER(c_float)]
+        L.reart_relax_search_ms.restype = c_int
+        L.reart_relax_search_ms.argtypes = [ctypes.POINTER(RelaxConfig), ctypes.POINTER(RelaxBuffers), c_void_p,
+                                            ctypes.c_size_t, c_void_p, c_int, ctypes.POINTER(c_float)]
         _L = L
     return _L
 
@@ -241,6 +244,15 @@ class RelaxEngine:
                                                    _lib.ptr(self.workspace), self.workspace.numel(), _lib.stream(), acc)
             _lib.check(rc, "reart_relax_step_timed")
         return {k: acc[i] / n for i, k in enumerate(self.PHASES)}
+
+    def search_ms(self, reps=20):
+        """Average milliseconds of the search launch alone (both Chamfer directions + flow K=3 in one
+        kernel) at the current state; ``reps`` back-to-back launches between two events.  Synchronises."""
+        ms = c_float(0.0)
+        rc = _lib_fns().reart_relax_search_ms(ctypes.byref(self.cfg), ctypes.byref(self._bufs), _lib.ptr(self.workspace),
+                                              self.workspace.numel(), _lib.stream(), int(reps), ctypes.byref(ms))
+        _lib.check(rc, "reart_relax_search_ms")
+        return float(ms.value)
 
     def loss_log(self):
         """(iterations done, tensor [min(iter, ring), 4]: recon, lambda*flow, total, tau); syncs."""
