@@ -77,8 +77,8 @@ def cpu_baseline(seq, T, N, cano_idx, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=1500)
+    ap.add_argument("--warmup", type=int, default=150)
     ap.add_argument("--frames", type=int, default=20)
     ap.add_argument("--points", type=int, default=4096)
     ap.add_argument("--no-flow", action="store_true")
