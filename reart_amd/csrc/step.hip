@@ -1,6 +1,7 @@
 // reart_amd/csrc/step.hip -- the fused relaxation iteration (reference run_robot.py:154-221,
 // Chamfer + flow branch): forward, both Chamfer directions, k=3 flow blending, losses, the
-// whole backward and the Adam update as a fixed sequence of ten kernel launches with NO host
+// whole backward and the Adam update as a fixed sequence of five kernel launches (forward, both
+// searches, both of their consumers, backward, finalize + Adam + bookkeeping) with NO host
 // interaction -- iteration counter, Gumbel RNG offset, temperature and loss log all live in
 // device memory, so the sequence can be captured once in a hipGraph and replayed.
 //
@@ -50,6 +51,7 @@ static int step_plan(const reart_relax_config *c, StepPlan *p) {
     // distance evaluations but divergent and latency bound -- slower, kept as an experiment); 0: brute force
     const char *mode = getenv("REART_SEARCH");
     p->pruned = (c->use_boxes && !c->use_grid) ? ((mode && !strcmp(mode, "lane")) ? 2 : 1) : 0;
+    if (mode && !strcmp(mode, "brute")) p->pruned = 0;   // cold brute-force slices (A/B and in-situ parity checks)
     p->S1 = p->pruned == 2 ? 1 : (p->pruned ? reart_prune_pick_split() : reart_knn_pick_split(waves1, c->N, 1));
     p->L1 = (int)reart_align_up((size_t)reart_div_up(c->N, p->S1), NN_BOX);
     p->Npad = p->L1 * p->S1;

@@ -5,7 +5,7 @@ HIP path: same command-line flags and defaults (``run_robot.py:362-420``), same 
 
 What is built: the loop itself.
   * ``--model base`` without assignment loss (the first ``--assign_iter`` iterations of every run,
-    and whole runs without ``--use_assign_loss``): the fused ``RelaxEngine`` -- eight kernel launches
+    and whole runs without ``--use_assign_loss``): the fused ``RelaxEngine`` -- five kernel launches
     per iteration replayed from a graph, no host sync inside the loop.
   * everything else (assignment loss, ``--model kinematic``): the reference's own loop structure with
     the HIP operators underneath (``BaseModel`` / ``KinematicModel``, ``ChamferDistance``,
