@@ -16,8 +16,11 @@
 //     lower bound is <= that thr for some group.  One ballot gives the survivor mask of 64 boxes.
 //   * Precise filter, one query per lane: point-to-box lower bound against the lane's own thr
 //     (which keeps shrinking as better candidates are found); the box is scanned if any lane
-//     needs it.  Scanning is the brute-force inner loop of knn.hip (scalar loads of the SoA
-//     targets feeding packed fp32 VALU).
+//     needs it.  Scanning is the brute-force inner loop of knn.hip in packed fp32; the targets of
+//     the surviving boxes are fetched eight boxes at a time through the vector memory path into a
+//     small LDS buffer and read back as broadcasts (a chain of scalar loads per scanned box -- the
+//     brute-force kernel's operand path -- stalled on scalar-cache misses here: boxes are visited in
+//     a data-dependent order and each is one cache line per axis).
 //
 // Exactness.  Both lower bounds are evaluated with the operations of the distance itself,
 //   lb = ((ex*ex)+(ey*ey))+(ez*ez),  e = max(lo - q, q - hi, 0)  per axis,
@@ -31,6 +34,9 @@
 #include <math.h>
 
 typedef float f2 __attribute__((ext_vector_type(2)));
+#define PR_WPB 1   // waves per workgroup (independent work items, no barrier); measured: 4 is slower (a
+                   // workgroup's slots are held until its slowest wave ends)
+#define PR_PF 8    // boxes whose targets are prefetched together
 
 #ifdef REART_PRUNE_STATS   // diagnostic build only (tools/prune_stats.py): how much the filters let through
 __device__ unsigned long long g_prune_stats[8];
@@ -129,6 +135,9 @@ __device__ __forceinline__ void knn_pruned_body(const KnnArgs &a, const int w) {
     int bb[KK];
 #pragma unroll
     for (int k = 0; k < KK; ++k) { bm[k] = INFINITY; bb[k] = -1; }
+    __shared__ __attribute__((aligned(16))) float s_tg_all[PR_WPB * PR_PF * 48];
+    float *s_tg = s_tg_all + (threadIdx.x >> 6) * (PR_PF * 48);
+    const float *tx_g = tx;
 
     const int per = 64 * a.S;
     for (int base = 0; base < nbox; base += per) {
@@ -150,15 +159,13 @@ __device__ __forceinline__ void knn_pruned_body(const KnnArgs &a, const int w) {
         PRUNE_STAT(KK == 1 ? 0 : 4, 1);                                  // coarse rounds
         PRUNE_STAT(KK == 1 ? 1 : 5, __builtin_popcountll(mask));         // boxes passing the coarse filter
         PRUNE_STAT(KK == 1 ? 3 : 7, __builtin_popcountll(__ballot(thr == INFINITY)));  // lanes without a bound
-        while (mask) {
-            const int bit = __builtin_ctzll(mask);
-            mask &= mask - 1;
-            // ---- precise filter with the lane's current bound
-            const float lb = box_lb(rl(lo0, bit), rl(lo1, bit), rl(lo2, bit), rl(hi0, bit), rl(hi1, bit), rl(hi2, bit),
-                                    qx, qy, qz, qx, qy, qz);
-            if (!__any(lb <= thr)) continue;
+        // scan of one box: the brute-force inner loop of knn.hip on its 16 targets
+        auto scan_box = [&](const int bit, const int slot) {
             PRUNE_STAT(KK == 1 ? 2 : 6, 1);                              // boxes scanned
             const int j0 = (base + bit * a.S + s) * NN_BOX;
+            // the box's 16 targets were staged in LDS slot `slot` (x[16] | y[16] | z[16]); all lanes read
+            // the same addresses (broadcast) -- the operands of the packed ops are VGPR pairs
+            const float *tx = s_tg + slot * 48 - j0, *ty = tx + 16, *tz = tx + 32;
             if (KK == 1) {
                 float m = INFINITY;
 #pragma unroll
@@ -196,6 +203,56 @@ __device__ __forceinline__ void knn_pruned_body(const KnnArgs &a, const int w) {
                 // KK distinct blocks hold KK distinct targets no farther than bm[KK-1]
                 thr = fminf(thr, bm[KK - 1]);
             }
+        };
+        while (mask) {
+            // ---- take the next PR_PF surviving boxes and put ALL their targets in flight: lane l < 48
+            // loads one float of each box (192 coalesced bytes per box) through the vector memory path,
+            // then the values are parked in the wave's LDS slots.  (Targets used to come through scalar
+            // loads, s_load_dwordx16 x 3 per scanned box: one dependent scalar-cache miss chain per scan;
+            // measured 95 -> 80 us for the launch with the vector path alone, before prefetching.)
+            unsigned long long rest = mask;
+#pragma unroll
+            for (int k = 0; k < PR_PF; ++k) rest &= rest - 1;            // x & (x - 1) of 0 is 0
+            unsigned long long cm = mask & ~rest;                        // this chunk's boxes
+            mask = rest;
+            {
+                const int l = lane < 48 ? lane : 47;
+                const float *src = tx_g + (size_t)(l >> 4) * jb.Ppad + (l & 15);
+                float pv[PR_PF];
+                unsigned long long t = cm;
+#pragma unroll
+                for (int k = 0; k < PR_PF; ++k) {
+                    const int bit = t ? __builtin_ctzll(t) : 0;          // clamped: an unused slot re-reads box `base`
+                    t &= t - 1;
+                    pv[k] = src[(base + bit * a.S + s) * NN_BOX];
+                }
+#pragma unroll
+                for (int k = 0; k < PR_PF; ++k)
+                    if (lane < 48) s_tg[k * 48 + lane] = pv[k];
+            }
+            // ---- precise filter with the lane's current bound, two boxes per step in packed fp32 (same
+            // operation order per box as box_lb; the second box is judged after the first one's scan)
+            int slot = 0;
+            while (cm) {
+            const int bA = __builtin_ctzll(cm);
+            cm &= cm - 1;
+            const bool hasB = cm != 0;
+            const int bB = hasB ? __builtin_ctzll(cm) : bA;
+            if (hasB) cm &= cm - 1;
+            const f2 L0 = {rl(lo0, bA), rl(lo0, bB)}, L1 = {rl(lo1, bA), rl(lo1, bB)}, L2 = {rl(lo2, bA), rl(lo2, bB)};
+            const f2 H0 = {rl(hi0, bA), rl(hi0, bB)}, H1 = {rl(hi1, bA), rl(hi1, bB)}, H2 = {rl(hi2, bA), rl(hi2, bB)};
+            const f2 a0 = L0 - qx2, c0 = qx2 - H0, a1 = L1 - qy2, c1 = qy2 - H1, a2 = L2 - qz2, c2 = qz2 - H2;
+            const f2 e0 = {fmaxf(fmaxf(a0.x, c0.x), 0.f), fmaxf(fmaxf(a0.y, c0.y), 0.f)};
+            const f2 e1 = {fmaxf(fmaxf(a1.x, c1.x), 0.f), fmaxf(fmaxf(a1.y, c1.y), 0.f)};
+            const f2 e2 = {fmaxf(fmaxf(a2.x, c2.x), 0.f), fmaxf(fmaxf(a2.y, c2.y), 0.f)};
+            const f2 lb = (e0 * e0 + e1 * e1) + e2 * e2;
+#pragma unroll 1   // one copy of the scan code (two copies cost 30 VGPRs of occupancy)
+            for (int h = 0; h < (hasB ? 2 : 1); ++h) {
+                const float lbh = h ? lb.y : lb.x;
+                if (__any(lbh <= thr)) scan_box(h ? bB : bA, slot + h);
+            }
+            slot += 2;
+            }
         }
     }
 
@@ -218,8 +275,6 @@ __device__ __forceinline__ void knn_pruned_body(const KnnArgs &a, const int w) {
     for (int k = 0; k < KK; ++k) { jb.pd[o + k] = bm[k]; jb.pi[o + k] = bb[k]; }
 }
 
-// Workgroups hold PR_WPB independent waves (one work item each, no barrier).
-#define PR_WPB 1   // measured: 4 waves per workgroup is slower (a workgroup's slots are held until its slowest wave ends)
 template <int KK>
 __global__ __launch_bounds__(NN_BS * PR_WPB) void knn_pruned_kernel(KnnArgs a) {
     knn_pruned_body<KK>(a, blockIdx.x * PR_WPB + (threadIdx.x >> 6));
