@@ -755,46 +755,61 @@ __device__ __forceinline__ void base_bwd_finalize_body(const BaseBwdArgs &a, con
         const int lane0 = (threadIdx.x & 63) & ~15;
 #pragma unroll
         for (int k = 0; k < 12; ++k) gRt[k] = __shfl(acc, lane0 + k, 64);
-        if (c != 0) return;
+        // every lane of the group runs the (cheap) Gram-Schmidt backward; lane c < 6 then owns rotation
+        // entry c and lanes 6..8 the translation entries: nine independent Adam updates instead of a
+        // chain of nine on one lane
+        if (c >= 9) return;
         float g6[6];
         r6d_backward(a.p6d + 6 * (size_t)e, gRt, g6);
         const int base6 = 3 * a.H + a.H + a.P * a.H, baset = base6 + 6 * a.B * a.P;
+        if (c < 6) {
+            float g = g6[0];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            a.g6d[6 * (size_t)e + k] = g6[k];
+            for (int k = 1; k < 6; ++k) g = (c == k) ? g6[k] : g;
+            a.g6d[6 * (size_t)e + c] = g;
             if (ad.enabled)
-                adam_update(ad.p6d + 6 * (size_t)e + k, g6[k], ad.m + base6 + 6 * e + k, ad.v + base6 + 6 * e + k,
+                adam_update(ad.p6d + 6 * (size_t)e + c, g, ad.m + base6 + 6 * e + c, ad.v + base6 + 6 * e + c,
                             ad.trans_lr, ss_tr, bc2s, ad.beta1, ad.beta2, ad.eps);
-        }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            a.gt[3 * (size_t)e + k] = gRt[9 + k];
+        } else {
+            const int k = c - 6;
+            const float g = k == 0 ? gRt[9] : (k == 1 ? gRt[10] : gRt[11]);
+            a.gt[3 * (size_t)e + k] = g;
             if (ad.enabled)
-                adam_update(ad.pt + 3 * (size_t)e + k, gRt[9 + k], ad.m + baset + 3 * e + k, ad.v + baset + 3 * e + k,
+                adam_update(ad.pt + 3 * (size_t)e + k, g, ad.m + baset + 3 * e + k, ad.v + baset + 3 * e + k,
                             ad.trans_lr, ss_tr, bc2s, ad.beta1, ad.beta2, ad.eps);
         }
     }
 }
 
 __global__ __launch_bounds__(256) void base_bwd_finalize_kernel(BaseBwdArgs a, FinalizeAdam ad, StepBook bk) {
-    base_bwd_finalize_body(a, ad);
-    if (!bk.enabled) return;
-    // last-workgroup pattern: the ticket is taken after this workgroup has consumed the iteration's
-    // counters, so the workgroup that draws the last ticket may overwrite them
+    // Bookkeeping is done by the LAST workgroup to finish (ticket): by then every other workgroup has
+    // consumed this iteration's counters.  Every workgroup prepares it speculatively up front -- the
+    // loss partials are loaded and the next temperature / bias corrections computed while the main
+    // work's loads are in flight -- so that the winner only has to reduce and store.
     __shared__ int s_last;
     __shared__ double s_r[4], s_f[4];
     const int tid = threadIdx.x;
-    __syncthreads();
-    if (tid == 0) {
-        __threadfence();
-        s_last = (atomicAdd(bk.ticket, 1u) == gridDim.x - 1) ? 1 : 0;
+    double recon = 0.0, flow = 0.0, bc0 = 0.0, bc1 = 0.0;
+    float tau_next = 0.f;
+    long it = 0;
+    if (bk.enabled) {
+        // fixed assignment of terms to lanes + fixed-order tree: deterministic sums
+        for (int b = tid; b < bk.n_frame_part; b += 256) recon += bk.frame_loss[b];
+        for (int i = tid; i < bk.n_flow_part; i += 256) flow += bk.flow_part[i];
+        if (tid == 0) {
+            it = (long)bk.iter[0];
+            bc0 = 1.0 - pow((double)bk.beta1, (double)(it + 2));   // Adam step count of the next iteration
+            bc1 = sqrt(1.0 - pow((double)bk.beta2, (double)(it + 2)));
+            // iteration i (0-based) uses tau_cosine(i+1, ...) (run_robot.py:157)
+            tau_next = bk.fixed_tau > 0.f ? bk.fixed_tau : reart_tau_schedule(it + 2, bk.n_iter, bk.end_tau, bk.start_tau);
+        }
     }
+    base_bwd_finalize_body(a, ad);
+    if (!bk.enabled) return;
+    __syncthreads();   // every thread of this workgroup has read the counters it needs (values already used)
+    if (tid == 0) s_last = (atomicAdd(bk.ticket, 1u) == gridDim.x - 1) ? 1 : 0;
     __syncthreads();
     if (!s_last) return;
-    // fixed assignment of terms to lanes + fixed-order tree: deterministic sums
-    double recon = 0.0, flow = 0.0;
-    for (int b = tid; b < bk.n_frame_part; b += 256) recon += bk.frame_loss[b];
-    for (int i = tid; i < bk.n_flow_part; i += 256) flow += bk.flow_part[i];
     recon = reart_wave_sum_d(recon);
     flow = reart_wave_sum_d(flow);
     if ((tid & 63) == 0) { s_r[tid >> 6] = recon; s_f[tid >> 6] = flow; }
@@ -802,16 +817,14 @@ __global__ __launch_bounds__(256) void base_bwd_finalize_kernel(BaseBwdArgs a, F
     if (tid != 0) return;
     recon = (s_r[0] + s_r[1]) + (s_r[2] + s_r[3]);
     flow = ((s_f[0] + s_f[1]) + (s_f[2] + s_f[3])) * (double)bk.lambda_flow;
-    const long it = (long)bk.iter[0];
     if (bk.losses && bk.ring > 0) {
         float *row = bk.losses + 4 * (size_t)(it % bk.ring);
         row[0] = (float)recon; row[1] = (float)flow; row[2] = (float)(recon + flow); row[3] = bk.tau[0];
     }
     bk.iter[0] = it + 1;
-    bk.bias_corr[0] = 1.0 - pow((double)bk.beta1, (double)(it + 2));   // Adam step count of the next iteration
-    bk.bias_corr[1] = sqrt(1.0 - pow((double)bk.beta2, (double)(it + 2)));
-    // iteration i (0-based) uses tau_cosine(i+1, ...) (run_robot.py:157)
-    bk.tau[0] = bk.fixed_tau > 0.f ? bk.fixed_tau : reart_tau_schedule(it + 2, bk.n_iter, bk.end_tau, bk.start_tau);
+    bk.bias_corr[0] = bc0;
+    bk.bias_corr[1] = bc1;
+    bk.tau[0] = tau_next;
     *bk.ticket = 0u;
 }
 
