@@ -533,30 +533,59 @@ __global__ __launch_bounds__(64 * (((PP > 0 ? PP : 32) + FW_PG - 1) / FW_PG)) vo
         s_x[3 * lane] = live ? x0 : 0.f; s_x[3 * lane + 1] = live ? x1 : 0.f; s_x[3 * lane + 2] = live ? x2 : 0.f;
         s_kn[lane] = kn;
     }
-    // a. dw for this wave's two parts
-    float dw0 = 0.f, dw1 = 0.f;
+    // a. dw[n,p] = sum_t G[t,n] . (R[t,p] x_n + t[t,p]) as ONE matrix product on the matrix cores:
+    //      dw = A Bm,   A[n][(t,r,c)] = G[t,n,r] * (c < 3 ? x_n[c] : 1),   Bm[(t,r,c)][p] = [R|t][t,p][r][c]
+    //    (K = 12 B, ascending (t, r, c): a fixed summation order, deterministic).  v_mfma_f32_16x16x4_f32:
+    //    one 16 (points) x 16 (parts) tile per wave, the four k of an instruction are c = 0..3 of one (t, r).
+    //    The per-lane VALU form of this sum (apply, then dot) was LDS-bound on the broadcast [R|t] rows.
     const int p0 = grp * FW_PG;
     const bool has0 = p0 < P, has1 = p0 + 1 < P;
     __syncthreads();
     PHASE_TS(1, 1);
-    if (has0) {
-#pragma unroll 4
-        for (int t = 0; t < a.B; ++t) {
-            const float *g = s_G + t * (RED_CHUNK * 3) + 3 * lane;
-            const float gv[3] = {g[0], g[1], g[2]};
-            float v[3];
-            apply_rt(s_rt + 12 * (t * a.P + p0), x0, x1, x2, v);
-            dw0 += dot3f(gv, v);
-            if (has1) {
-                apply_rt(s_rt + 12 * (t * a.P + p0 + 1), x0, x1, x2, v);
-                dw1 += dot3f(gv, v);
+    {
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        const int ntn = (P + 15) / 16;                       // part tiles
+        for (int tile = grp; tile < 4 * ntn; tile += W) {
+            const int mt = tile & 3, nt = tile >> 2;
+            const int nl = 16 * mt + (lane & 15), kq = lane >> 4;          // A row (point), k within the instruction
+            const int pc = 16 * nt + (lane & 15);                          // B column (part)
+            const bool pok = pc < P;
+            const float xt = kq < 3 ? s_x[3 * nl + kq] : 1.0f;
+            const float *gp = s_G + 3 * nl;                                // + t * 192 + r
+            const float *bp = s_rt + 12 * (pok ? pc : 0);                  // + t * 12 P + (kq < 3 ? 3 r + kq : 9 + r)
+            f4v c = {0.f, 0.f, 0.f, 0.f};
+            const int bo = kq < 3 ? kq : 9;                     // offset of (r = 0, c = kq) inside a [R|t] row
+            const int bs = kq < 3 ? 3 : 1;                      // stride over r
+            constexpr int TU = 4;                               // frames per batch: 24 LDS reads in flight, then 12 MFMAs
+            for (int t0 = 0; t0 < a.B; t0 += TU) {
+                float av[TU][3], bv[TU][3];
+#pragma unroll
+                for (int u = 0; u < TU; ++u) {
+                    const int t = t0 + u < a.B ? t0 + u : a.B - 1;
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        av[u][r] = gp[t * (RED_CHUNK * 3) + r];
+                        bv[u][r] = bp[t * 12 * a.P + bo + bs * r];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < TU; ++u) {
+                    const bool tok = t0 + u < a.B;
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+                        c = __builtin_amdgcn_mfma_f32_16x16x4f32(tok ? av[u][r] * xt : 0.f, (pok && tok) ? bv[u][r] : 0.f, c, 0, 0, 0);
+                }
             }
+            // C/D layout: row = 4 (lane >> 4) + reg, col = lane & 15
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg)
+                if (pok) s_ds[pc * BW_LD + 16 * mt + 4 * kq + reg] = c[reg];
         }
-        s_ds[p0 * BW_LD + lane] = dw0;
-        if (has1) s_ds[(p0 + 1) * BW_LD + lane] = dw1;
     }
     __syncthreads();
     PHASE_TS(1, 2);
+    const float dw0 = has0 ? s_ds[p0 * BW_LD + lane] : 0.f;
+    const float dw1 = has1 ? s_ds[(p0 + 1) * BW_LD + lane] : 0.f;
     // b. softmax backward: dot over all parts in ascending order, ds for this wave's parts
     const float tau = a.tau_ptr ? a.tau_ptr[0] : a.tau;
     float dot = 0.f;

@@ -464,6 +464,12 @@ __device__ __forceinline__ void chamfer_grad_body(const CGradArgs &a, const int 
     float d0 = INFINITY;
     int j0 = 0;
     if (io < N) merge_slices<ONE>(a.pd0, a.pi0, a.S0, stride, ob + io, N, d0, j0);
+    // the gathers of the own target are issued now: they complete under the walk over the observed points
+    float yn[3] = {0.f, 0.f, 0.f}, xo[3] = {0.f, 0.f, 0.f};
+    if (io < N) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { yn[k] = y[3 * j0 + k]; xo[k] = x[3 * io + k]; }
+    }
     __syncthreads();
     float d1own = 0.f;
     constexpr int IL = 4;   // observed points in flight per thread
@@ -501,12 +507,7 @@ __device__ __forceinline__ void chamfer_grad_body(const CGradArgs &a, const int 
             }
         }
     }
-    float yn[3] = {0.f, 0.f, 0.f}, xo[3] = {0.f, 0.f, 0.f};
-    if (io < N) {
-        if (a.seed0) a.seed0[ob + io] = j0;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { yn[k] = y[3 * j0 + k]; xo[k] = x[3 * io + k]; }
-    }
+    if (io < N && a.seed0) a.seed0[ob + io] = j0;
     __syncthreads();
     double term = 0.0;
     if (io < N) {
