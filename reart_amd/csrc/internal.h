@@ -134,6 +134,10 @@ int reart_prune_pick_split(void);
 // K = 1 (two jobs) and K = 3 (one job) pruned searches in one launch
 // counters: 2 zero-initialised uints for the persistent form (NULL: one workgroup per item)
 int reart_knn_launch_pruned_pair(const KnnArgs &k1, const KnnArgs &k3, unsigned int *counters, hipStream_t st);
+// exact pruned search, one wave = 16 queries x 4 box slots (quad.hip); a.S must be 1 and
+// items0 = N * ceil(P1 / 16) per job
+int reart_knn_launch_quad(const KnnArgs &a, int KK, hipStream_t st);
+int reart_knn_launch_quad_pair(const KnnArgs &k1, const KnnArgs &k3, hipStream_t st);
 // exact search with per-query candidate lists, target cloud staged in LDS (lane.hip); a.S must be 1
 int reart_knn_launch_lane(const KnnArgs &a, int KK, hipStream_t st);
 

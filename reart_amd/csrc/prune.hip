@@ -32,6 +32,7 @@
 #include "common.h"
 #include "internal.h"
 #include <math.h>
+#include <string.h>
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 #define PR_WPB 1   // waves per workgroup (independent work items, no barrier); measured: 4 is slower (a
@@ -417,7 +418,8 @@ __global__ __launch_bounds__(256) void knn_warm_finish_kernel(KnnArgs a) {
 struct WarmPlan { int S, Ppad; size_t o_soa, o_box, o_pd, o_pi, total; };
 static int warm_plan(int N, int P1, int P2, int K, WarmPlan *p) {
     if (N < 0 || P1 < 0 || P2 < 0 || (K != 1 && K != 3)) return REART_ERR_INVALID_ARG;
-    p->S = reart_prune_pick_split();
+    const char *mode = getenv("REART_SEARCH");
+    p->S = (mode && !strcmp(mode, "quad")) ? 1 : reart_prune_pick_split();   // quad.hip leaves one record per query
     while (p->S > 1 && reart_div_up(P2, p->S) < 64) p->S /= 2;
     p->Ppad = (int)reart_align_up((size_t)(P2 > 0 ? P2 : 1), NN_BOX);
     size_t off = 0;
@@ -461,8 +463,10 @@ extern "C" int reart_knn_points_idx_warm(const float *p1, const float *p2, int N
     jb.seed = seed; jb.P1 = P1; jb.P2 = P2; jb.Ppad = p.Ppad; jb.L = 0; jb.nqg = reart_div_up(P1, NN_BS);
     jb.pd = (float *)(ws + p.o_pd); jb.pi = (int *)(ws + p.o_pi); jb.dists = dists; jb.idx = idx;
     a.job[1] = jb;
-    a.items0 = N * jb.nqg * p.S; a.items = a.items0;
-    rc = reart_knn_launch_pruned(a, K, st);
+    const char *mode = getenv("REART_SEARCH");
+    const bool quad = mode && !strcmp(mode, "quad");
+    a.items0 = quad ? N * reart_div_up(P1, 16) : N * jb.nqg * p.S; a.items = a.items0;
+    rc = quad ? reart_knn_launch_quad(a, K, st) : reart_knn_launch_pruned(a, K, st);
     if (rc != REART_OK) return rc;
     const dim3 fg(reart_div_up(P1, 256), N);
     if (K == 1) hipLaunchKernelGGL((knn_warm_finish_kernel<1>), fg, dim3(256), 0, st, a);

@@ -52,13 +52,14 @@ static int step_plan(const reart_relax_config *c, StepPlan *p) {
     const char *mode = getenv("REART_SEARCH");
     p->pruned = (c->use_boxes && !c->use_grid) ? ((mode && !strcmp(mode, "lane")) ? 2 : 1) : 0;
     if (mode && !strcmp(mode, "brute")) p->pruned = 0;   // cold brute-force slices (A/B and in-situ parity checks)
-    p->S1 = p->pruned == 2 ? 1 : (p->pruned ? reart_prune_pick_split() : reart_knn_pick_split(waves1, c->N, 1));
+    if (p->pruned == 1 && mode && !strcmp(mode, "quad")) p->pruned = 3;   // 16 queries x 4 box slots per wave (quad.hip)
+    p->S1 = p->pruned >= 2 ? 1 : (p->pruned ? reart_prune_pick_split() : reart_knn_pick_split(waves1, c->N, 1));
     p->L1 = (int)reart_align_up((size_t)reart_div_up(c->N, p->S1), NN_BOX);
     p->Npad = p->L1 * p->S1;
     p->S3 = 1; p->Mpad = 0;
     if (c->use_flow) {
         const long waves3 = (long)c->B * reart_div_up(c->N, NN_BS);
-        p->S3 = p->pruned == 2 ? 1 : (p->pruned ? reart_prune_pick_split() : reart_knn_pick_split(waves3, c->M_max, 3));
+        p->S3 = p->pruned >= 2 ? 1 : (p->pruned ? reart_prune_pick_split() : reart_knn_pick_split(waves3, c->M_max, 3));
         p->Mpad = (int)reart_align_up((size_t)reart_div_up(c->M_max, p->S3), NN_BOX) * p->S3;
     }
     p->nchunk = reart_div_up(c->N, 64);
@@ -589,7 +590,7 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
     // fork / join).  Otherwise (brute force / grid / per-lane variants): separate launches, the flow
     // branch on the auxiliary stream when the caller provides one.  The timed variant is always separate.
     const char *mg = getenv("REART_MERGE");
-    const bool merged = c.use_flow && p.pruned == 1 && !c.use_grid && !(mg && mg[0] == '0');
+    const bool merged = c.use_flow && (p.pruned == 1 || p.pruned == 3) && !c.use_grid && !(mg && mg[0] == '0');
     const bool forked = !merged && !ev && bufs->aux_stream && bufs->ev_fork && bufs->ev_join && c.use_flow;
     hipStream_t fst = forked ? (hipStream_t)bufs->aux_stream : st;
     if (forked) {
@@ -622,12 +623,12 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
             kj.P1 = N; kj.P2 = c.M_max; kj.Ppad = p.Mpad; kj.L = p.Mpad / p.S3; kj.nqg = reart_div_up(N, NN_BS);
             kj.pd = (float *)(ws + p.o_pd3); kj.pi = (int *)(ws + p.o_pi3);
             k3.job[1] = kj;
-            k3.items0 = B * kj.nqg * p.S3;
+            k3.items0 = p.pruned == 3 ? B * reart_div_up(N, 16) : B * kj.nqg * p.S3;
             k3.items = k3.items0;
             kj.seed = p.pruned ? (const int *)(ws + p.o_seed3) : nullptr;
             k3.job[1] = kj;
             if (!merged) {
-                rc = p.pruned == 2 ? reart_knn_launch_lane(k3, 3, fst)
+                rc = p.pruned == 3 ? reart_knn_launch_quad(k3, 3, fst) : p.pruned == 2 ? reart_knn_launch_lane(k3, 3, fst)
                                    : (p.pruned ? reart_knn_launch_pruned(k3, 3, fst) : reart_knn_launch_slices(k3, 3, fst));
                 if (rc != REART_OK) return rc;
             }
@@ -682,7 +683,7 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
         ka.items0 = B * ka.job[0].nqg * p.S1;
         ka.items = ka.items0;
     } else {
-        ka.items0 = B * ka.job[0].nqg * p.S1;
+        ka.items0 = p.pruned == 3 ? B * reart_div_up(N, 16) : B * ka.job[0].nqg * p.S1;
         ka.items = 2 * ka.items0;
     }
     if (search_reps) {
@@ -691,19 +692,22 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
         // microseconds, the kernel tens), so the timed launches run back to back.  (A one-wave spin kernel
         // as a host-side head start was tried and rejected: the chip drops its clock while it spins.)
         for (int r = 0; r < 2; ++r) {
-            rc = reart_knn_launch_pruned_pair(ka, k3, (unsigned int *)(ws + p.o_ticket) + 2, st);
+            rc = p.pruned == 3 ? reart_knn_launch_quad_pair(ka, k3, st)
+                               : reart_knn_launch_pruned_pair(ka, k3, (unsigned int *)(ws + p.o_ticket) + 2, st);
             if (rc != REART_OK) return rc;
         }
         (void)hipEventRecord(ev[0], st);
         for (int r = 0; r < search_reps; ++r) {
-            rc = reart_knn_launch_pruned_pair(ka, k3, (unsigned int *)(ws + p.o_ticket) + 2, st);
+            rc = p.pruned == 3 ? reart_knn_launch_quad_pair(ka, k3, st)
+                               : reart_knn_launch_pruned_pair(ka, k3, (unsigned int *)(ws + p.o_ticket) + 2, st);
             if (rc != REART_OK) return rc;
         }
         (void)hipEventRecord(ev[1], st);
         return REART_OK;
     }
-    if (merged) rc = reart_knn_launch_pruned_pair(ka, k3, (unsigned int *)(ws + p.o_ticket) + 2, st);
-    else rc = p.pruned == 2 ? reart_knn_launch_lane(ka, 1, st)
+    if (merged) rc = p.pruned == 3 ? reart_knn_launch_quad_pair(ka, k3, st)
+                               : reart_knn_launch_pruned_pair(ka, k3, (unsigned int *)(ws + p.o_ticket) + 2, st);
+    else rc = p.pruned == 3 ? reart_knn_launch_quad(ka, 1, st) : p.pruned == 2 ? reart_knn_launch_lane(ka, 1, st)
                             : (p.pruned ? reart_knn_launch_pruned(ka, 1, st) : reart_knn_launch_slices(ka, 1, st));
     if (rc != REART_OK) return rc;
 

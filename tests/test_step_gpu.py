@@ -180,7 +180,8 @@ def test_search_variants_give_identical_trajectories(dev, monkeypatch):
     cano, pcs = split_canonical(seq["complete"], 2)
     runs = {}
     for name, env in (("pruned", {}), ("separate", {"REART_MERGE": "0"}), ("lane", {"REART_SEARCH": "lane"}),
-                      ("brute", {"REART_SEARCH": "brute"})):
+                      ("quad", {"REART_SEARCH": "quad"}), ("quad_separate", {"REART_SEARCH": "quad", "REART_MERGE": "0"}),
+                      ("wave", {"REART_SEARCH": "wave"}), ("brute", {"REART_SEARCH": "brute"})):
         for k in ("REART_MERGE", "REART_SEARCH"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
@@ -195,6 +196,6 @@ def test_search_variants_give_identical_trajectories(dev, monkeypatch):
                       model.seg_head.model[2].weight.detach().cpu().numpy().copy(), eng.seg_part.cpu().numpy())
     ref = runs["brute"]
     assert np.isfinite(ref[0]).all()
-    for name in ("pruned", "separate", "lane"):
+    for name in ("pruned", "separate", "lane", "quad", "quad_separate", "wave"):
         for a, b in zip(runs[name], ref):
             np.testing.assert_array_equal(a, b, err_msg=name)
