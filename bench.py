@@ -92,6 +92,9 @@ def main():
     ap.add_argument("--instances-per-gpu", type=int, default=1,
                     help="sweep mode: K independent instances share each GPU on separate streams (secondary figure; "
                          "the headline is K=1)")
+    ap.add_argument("--sweep-instances", type=int, default=3,
+                    help="after the headline (one instance per GPU) also time this many concurrent instances per GPU on "
+                         "separate streams and report the aggregate as `sweep` (0 = skip)")
     ap.add_argument("--profile-steps", type=int, default=20, help="eager steps timed per phase with HIP events")
     args = ap.parse_args()
 
@@ -129,10 +132,12 @@ def main():
         if K == 1:
             eng.step(n)
             return
-        for _ in range(n):  # round-robin so that the instances' graphs interleave on the device
+        spg = 1 if args.no_graph else max(1, args.steps_per_graph)
+        chunks = [spg] * (n // spg) + ([n % spg] if n % spg else [])
+        for c in chunks:  # round-robin in whole graphs so that the instances interleave on the device
             for e_, st in zip(engines, streams):
                 with torch.cuda.stream(st):
-                    e_.step(1)
+                    e_.step(c)
 
     def barrier():
         torch.cuda.synchronize()
@@ -149,6 +154,40 @@ def main():
         tt = torch.tensor([el], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
+    # secondary figure: the sweep the reference runs (one optimisation per canonical index) packs several
+    # independent instances on a GPU; their launches interleave on separate streams and fill the issue slots
+    # a single latency-bound instance leaves idle
+    sweep = None
+    if K == 1 and args.sweep_instances > 1:
+        Ks = args.sweep_instances
+        sw_eng, sw_st = [], []
+        for k in range(Ks):
+            st = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(st):
+                e_, _, _ = build_instance(dev, T, N, (cano_idx + 1 + k) % T, seed=1000 + rank + 101 * k, use_flow=use_flow,
+                                          use_grid=args.grid, overlap=not args.no_overlap)
+                used = 0 if args.no_graph else e_.capture(steps_per_graph=max(1, args.steps_per_graph))
+                e_.step(max(args.warmup - used, 0))
+            sw_eng.append(e_)
+            sw_st.append(st)
+        spg = 1 if args.no_graph else max(1, args.steps_per_graph)
+        chunks = [spg] * (args.steps // spg) + ([args.steps % spg] if args.steps % spg else [])
+        barrier()
+        t1 = time.perf_counter()
+        for c in chunks:
+            for e_, st in zip(sw_eng, sw_st):
+                with torch.cuda.stream(st):
+                    e_.step(c)
+        barrier()
+        el_s = time.perf_counter() - t1
+        if distributed:
+            tt = torch.tensor([el_s], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el_s = float(tt.item())
+        sweep = {"instances_per_gpu": Ks, "value": round(world * Ks * args.steps / el_s, 3), "unit": "iterations/s",
+                 "note": "aggregate over all GPUs of Ks concurrent independent instances per GPU (separate streams); "
+                         "`value` above is one instance per GPU"}
+        del sw_eng
     losses = eng.last_losses()
     # gather of the final energies only (the reference's sweep picks argmin total energy)
     if distributed:
@@ -223,6 +262,7 @@ def main():
                        "instances_per_gpu": K},
             "roofline": roof,
             "cpu_baseline": cpu,
+            "sweep": sweep,
             "phases_ms": {k: round(v, 5) for k, v in phases.items()},
             "final_losses": {"recon": float(energies[0][0]), "flow": float(energies[0][1]),
                              "per_rank_total": [float(e[2]) for e in energies]},
