@@ -9,7 +9,8 @@
 // MFMA: v_mfma_f32_32x32x2_f32 -- f32 in, f32 accumulate, bit-identical to a k-ordered fmaf
 // chain (cdna guide section 3), so results stay within fp32 round-off of the reference's conv.
 // Tile: 128 rows x 64 cols per workgroup (4 waves, each 32 x 64 = two accumulators sharing
-// the A fragment), K step 16 through LDS.  The A tile can be GATHERED on the fly from the ball
+// the A fragment), K step 16 through LDS, the global loads of step i+1 in flight (registers) while step i
+// runs on the matrix cores; 16-byte loads for contiguous row segments.  The A tile can be GATHERED on the fly from the ball
 // query indices (grouped features | relative xyz), so the grouped tensor [B,S,K,C] of the
 // reference (up to 400 MB per scale at T=20) is never materialised.
 #include "common.h"
@@ -18,7 +19,7 @@
 
 #define GM_BM 128
 #define GM_BN 64
-#define GM_BK 16
+#define GM_BK 16   // measured: 32 is slower (8.3 vs 6.7 ms for the extractor: the Cin = 6 layers pad twice as far, fewer resident waves)
 #define GM_LDA (GM_BK + 1)   // +1: column reads by 32 lanes hit 32 different banks
 #define GM_LDB (GM_BN + 4)
 
@@ -79,28 +80,60 @@ __global__ __launch_bounds__(256) void mlp_gemm_kernel(GemmArgs a) {
     const int row0 = blockIdx.x * GM_BM, col0 = blockIdx.y * GM_BN;
     f16v c0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     f16v c1 = c0;
-    const int ar = tid >> 1, ak = (tid & 1) * 8;      // A tile: 128 rows x 2 half-rows of 8
-    const int bk = tid >> 4, bc = (tid & 15) * 4;     // B tile: 16 k x 16 float4
+    constexpr int AK = GM_BK / 2;                     // k per thread of the A tile
+    const int ar = tid >> 1, ak = (tid & 1) * AK;     // A tile: 128 rows x 2 half-rows of AK
+    const int bk = tid >> 4, bc = (tid & 15) * 4;     // B tile: GM_BK k x 16 float4, rows bk, bk + 16, ...
     const ARow arow = gemm_row(a, row0 + ar);
+    // 16-byte path for the A tile: the thread's 8 consecutive k lie inside one contiguous, aligned row
+    // segment (plain rows, or the feature part of a gathered row); anything else goes element by element
+    const float *aseg = arow.x ? arow.x : ((!a.xyz_first && arow.f) ? arow.f : nullptr);
+    const int aseg_len = arow.x ? a.Cin : ((!a.xyz_first && arow.f) ? a.D : 0);
+    const bool avec = arow.valid && aseg && ((((size_t)aseg) & 15) == 0);
+    auto load_a = [&](int k0, float (&v)[AK]) {
+        const int k = k0 + ak;
+        if (avec && k + AK <= aseg_len) {
+#pragma unroll
+            for (int u = 0; u < AK; u += 4) {
+                const float4 p = *(const float4 *)(aseg + k + u);
+                v[u] = p.x; v[u + 1] = p.y; v[u + 2] = p.z; v[u + 3] = p.w;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < AK; ++u) v[u] = gemm_load_a(a, arow, k + u);
+        }
+    };
+    auto load_b = [&](int kq) {
+        const int k = kq + bk, c = col0 + bc;
+        float4 w = {0.f, 0.f, 0.f, 0.f};
+        if (k < a.Cin) {
+            if (c + 3 < a.Cout && (a.Cout & 3) == 0) {
+                w = *(const float4 *)(a.Wt + (size_t)k * a.Cout + c);
+            } else {
+                if (c < a.Cout) w.x = a.Wt[(size_t)k * a.Cout + c];
+                if (c + 1 < a.Cout) w.y = a.Wt[(size_t)k * a.Cout + c + 1];
+                if (c + 2 < a.Cout) w.z = a.Wt[(size_t)k * a.Cout + c + 2];
+                if (c + 3 < a.Cout) w.w = a.Wt[(size_t)k * a.Cout + c + 3];
+            }
+        }
+        return w;
+    };
+    // register double buffering: the loads of K-step i+1 are in flight while step i runs on the matrix cores
+    float av8[AK];
+    float4 bw[GM_BK / 16];
+    load_a(0, av8);
+#pragma unroll
+    for (int h = 0; h < GM_BK / 16; ++h) bw[h] = load_b(16 * h);
     for (int k0 = 0; k0 < a.Cin; k0 += GM_BK) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) As[ar * GM_LDA + ak + u] = gemm_load_a(a, arow, k0 + ak + u);
-        {
-            const int k = k0 + bk, c = col0 + bc;
-            float4 w = {0.f, 0.f, 0.f, 0.f};
-            if (k < a.Cin) {
-                if (c + 3 < a.Cout && (a.Cout & 3) == 0) {
-                    w = *(const float4 *)(a.Wt + (size_t)k * a.Cout + c);
-                } else {
-                    if (c < a.Cout) w.x = a.Wt[(size_t)k * a.Cout + c];
-                    if (c + 1 < a.Cout) w.y = a.Wt[(size_t)k * a.Cout + c + 1];
-                    if (c + 2 < a.Cout) w.z = a.Wt[(size_t)k * a.Cout + c + 2];
-                    if (c + 3 < a.Cout) w.w = a.Wt[(size_t)k * a.Cout + c + 3];
-                }
-            }
-            *(float4 *)(Bs + bk * GM_LDB + bc) = w;
-        }
+        for (int u = 0; u < AK; ++u) As[ar * GM_LDA + ak + u] = av8[u];
+#pragma unroll
+        for (int h = 0; h < GM_BK / 16; ++h) *(float4 *)(Bs + (bk + 16 * h) * GM_LDB + bc) = bw[h];
         __syncthreads();
+        if (k0 + GM_BK < a.Cin) {
+            load_a(k0 + GM_BK, av8);
+#pragma unroll
+            for (int h = 0; h < GM_BK / 16; ++h) bw[h] = load_b(k0 + GM_BK + 16 * h);
+        }
 #pragma unroll
         for (int kk = 0; kk < GM_BK; kk += 2) {
             const int kl = kk + (lane >> 5);
