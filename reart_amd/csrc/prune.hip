@@ -157,12 +157,12 @@ __device__ __forceinline__ void knn_pruned_body(const KnnArgs &a, const int w) {
             }
         }
         unsigned long long mask = __ballot(pass);
-        PRUNE_STAT(KK == 1 ? 0 : 4, 1);                                  // coarse rounds
-        PRUNE_STAT(KK == 1 ? 1 : 5, __builtin_popcountll(mask));         // boxes passing the coarse filter
-        PRUNE_STAT(KK == 1 ? 3 : 7, __builtin_popcountll(__ballot(thr == INFINITY)));  // lanes without a bound
+        PRUNE_STAT(KK == 1 ? 0 : 3, 0);                                  // coarse rounds (K = 1)
+        if (KK == 1) PRUNE_STAT(1, __builtin_popcountll(mask));          // boxes passing the coarse filter
+        if (KK == 1) PRUNE_STAT(3, __builtin_popcountll(__ballot(thr == INFINITY)));  // lanes without a bound
         // scan of one box: the brute-force inner loop of knn.hip on its 16 targets
         auto scan_box = [&](const int bit, const int slot) {
-            PRUNE_STAT(KK == 1 ? 2 : 6, 1);                              // boxes scanned
+            if (KK == 1) PRUNE_STAT(2, 1);                               // boxes scanned
             const int j0 = (base + bit * a.S + s) * NN_BOX;
             // the box's 16 targets were staged in LDS slot `slot` (x[16] | y[16] | z[16]); all lanes read
             // the same addresses (broadcast) -- the operands of the packed ops are VGPR pairs
@@ -250,6 +250,12 @@ __device__ __forceinline__ void knn_pruned_body(const KnnArgs &a, const int w) {
 #pragma unroll 1   // one copy of the scan code (two copies cost 30 VGPRs of occupancy)
             for (int h = 0; h < (hasB ? 2 : 1); ++h) {
                 const float lbh = h ? lb.y : lb.x;
+#ifdef REART_PRUNE_STATS   // how many of the 64 queries need a scanned box: 1 | 2-3 | 4-7 | 8+  (K = 1 only)
+                if (KK == 1) {
+                    const int nl = __builtin_popcountll(__ballot(lbh <= thr));
+                    if (nl) PRUNE_STAT(nl == 1 ? 4 : (nl < 4 ? 5 : (nl < 8 ? 6 : 7)), 1);
+                }
+#endif
                 if (__any(lbh <= thr)) scan_box(h ? bB : bA, slot + h);
             }
             slot += 2;

@@ -27,7 +27,7 @@ have = hasattr(lib, "reart_debug_prune_stats") and not args.no_stats
 buf = (ctypes.c_ulonglong * 8)()
 eng.capture()
 done = 0
-print("iter  it/s   | K=1: coarse-pass scanned (of 256 boxes per cloud, per wave) | K=3: coarse scanned (of ~188) | recon flow")
+print("iter  it/s   | K=1: coarse-pass scanned (of 256 boxes per cloud, per wave); scanned boxes needed by 1 / 2-3 / 4-7 / 8+ of the 64 queries | recon flow")
 while done < args.iters:
     if have:
         lib.reart_debug_prune_stats(buf, 1)
@@ -40,7 +40,8 @@ while done < args.iters:
         v = list(buf)
         n1 = args.probe * 2 * 19 * 64    # (wave, cloud) pairs per probe; slices share the boxes of a cloud
         n3 = args.probe * 19 * 64
-        line += f" | {v[1] / n1:7.1f} {v[2] / n1:7.1f} noBound {v[3] / (n1 * 64) if n1 else 0:.4f} | {v[5] / n3:7.1f} {v[6] / n3:7.1f} noBound {v[7] / (n3 * 64):.4f}"
+        h = max(sum(v[4:8]), 1)
+        line += f" | {v[1] / n1:7.1f} {v[2] / n1:7.1f}; {v[4] / h:.0%} {v[5] / h:.0%} {v[6] / h:.0%} {v[7] / h:.0%}"
     l = eng.last_losses()
     line += f" | {l}"
     print(line, flush=True)
