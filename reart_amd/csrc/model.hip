@@ -166,13 +166,16 @@ __global__ __launch_bounds__(64 * (((PP > 0 ? PP : 32) + FW_PG - 1) / FW_PG)) vo
     const int tid = threadIdx.x, lane = tid & 63, grp = tid >> 6;
     PHASE_TS(0, 0);
     const int P = (PP > 0) ? PP : a.P;
-    for (int e = tid; e < a.B * a.P; e += BS) {
+    // Prologue loads: the first batch of every group (pose parameters, W1|b1, one W2 column per thread) is
+    // issued before anything is stored to LDS, so the prologue is one memory round trip deep
+    const int nRT = a.B * a.P;
+    auto put_rt = [&](int e, const float (&d6)[6], const float (&tv)[3]) {
         float R[9];
-        r6d_to_matrix(a.p6d + 6 * (size_t)e, R);
+        r6d_to_matrix(d6, R);
 #pragma unroll
         for (int c = 0; c < 9; ++c) s_rt[12 * e + c] = R[c];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) s_rt[12 * e + 9 + c] = a.pt[3 * (size_t)e + c];
+        for (int c = 0; c < 3; ++c) s_rt[12 * e + 9 + c] = tv[c];
         if (blockIdx.x == 0) {
             if (a.trans_list) {
                 float *T = a.trans_list + 16 * (size_t)e;
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(64 * (((PP > 0 ? PP : 32) + FW_PG - 1) / FW_PG)) vo
                 for (int r = 0; r < 3; ++r) {
 #pragma unroll
                     for (int c = 0; c < 3; ++c) T[4 * r + c] = R[3 * r + c];
-                    T[4 * r + 3] = a.pt[3 * (size_t)e + r];
+                    T[4 * r + 3] = tv[r];
                 }
                 T[12] = 0.f; T[13] = 0.f; T[14] = 0.f; T[15] = 1.f;
             }
@@ -188,15 +191,42 @@ __global__ __launch_bounds__(64 * (((PP > 0 ? PP : 32) + FW_PG - 1) / FW_PG)) vo
 #pragma unroll
                 for (int c = 0; c < 9; ++c) a.rt_table[12 * (size_t)e + c] = R[c];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) a.rt_table[12 * (size_t)e + 9 + c] = a.pt[3 * (size_t)e + c];
+                for (int c = 0; c < 3; ++c) a.rt_table[12 * (size_t)e + 9 + c] = tv[c];
             }
         }
+    };
+    {
+        float d6[6], tv[3], vw[PMAX];
+        const int e0 = tid < nRT ? tid : 0;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) d6[c] = a.p6d[6 * (size_t)e0 + c];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) tv[c] = a.pt[3 * (size_t)e0 + c];
+        const int ew = tid < 4 * a.H ? tid : 0;
+        const float wbv = (ew & 3) < 3 ? a.W1[3 * (ew >> 2) + (ew & 3)] : a.b1[ew >> 2];
+        const int jw = tid < a.H ? tid : 0;
+#pragma unroll
+        for (int p = 0; p < PMAX; ++p) vw[p] = a.W2[(size_t)(p < P ? p : 0) * a.H + jw];
+        if (tid < nRT) put_rt(tid, d6, tv);
+        if (tid < 4 * a.H) s_wb[tid] = wbv;
+        if (tid < a.H) {
+#pragma unroll
+            for (int p = 0; p < PMAX; ++p) s_w2T[tid * PMAX + p] = vw[p];
+        }
     }
-    for (int e = tid; e < 4 * a.H; e += BS) {
+    for (int e = tid + BS; e < nRT; e += BS) {
+        float d6[6], tv[3];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) d6[c] = a.p6d[6 * (size_t)e + c];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) tv[c] = a.pt[3 * (size_t)e + c];
+        put_rt(e, d6, tv);
+    }
+    for (int e = tid + BS; e < 4 * a.H; e += BS) {
         const int j = e >> 2, c = e & 3;
         s_wb[e] = c < 3 ? a.W1[3 * j + c] : a.b1[j];
     }
-    for (int j = tid; j < a.H; j += BS)          // one hidden unit per thread: no integer division
+    for (int j = tid + BS; j < a.H; j += BS)          // one hidden unit per thread: no integer division
         for (int p = 0; p < P; ++p) s_w2T[j * PMAX + p] = a.W2[(size_t)p * a.H + j];
 
     const int n = blockIdx.x * FW_PTS + lane;
