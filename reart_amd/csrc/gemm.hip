@@ -8,7 +8,7 @@
 //
 // MFMA: v_mfma_f32_32x32x2_f32 -- f32 in, f32 accumulate, bit-identical to a k-ordered fmaf
 // chain (cdna guide section 3), so results stay within fp32 round-off of the reference's conv.
-// Tile: 128 rows x 64 cols per workgroup (4 waves, each 32 x 64 = two accumulators sharing
+// Tile: 128 rows x 32 NB cols per workgroup (4 waves, each 32 x 32 NB = NB accumulators sharing
 // the A fragment), K step 16 through LDS, the global loads of step i+1 in flight (registers) while step i
 // runs on the matrix cores; 16-byte loads for contiguous row segments.  The A tile can be GATHERED on the fly from the ball
 // query indices (grouped features | relative xyz), so the grouped tensor [B,S,K,C] of the
@@ -18,10 +18,8 @@
 #include <math.h>
 
 #define GM_BM 128
-#define GM_BN 64
 #define GM_BK 16   // measured: 32 is slower (8.3 vs 6.7 ms for the extractor: the Cin = 6 layers pad twice as far, fewer resident waves)
 #define GM_LDA (GM_BK + 1)   // +1: column reads by 32 lanes hit 32 different banks
-#define GM_LDB (GM_BN + 4)
 
 typedef float f16v __attribute__((ext_vector_type(16)));
 
@@ -72,17 +70,26 @@ __device__ __forceinline__ float gemm_load_a(const GemmArgs &a, const ARow &w, i
     return w.f[a.xyz_first ? k - 3 : k];
 }
 
+// NB = number of 32-column accumulators per wave: the workgroup tile is 128 rows x 32 NB columns.  The
+// layers pick the NB that wastes the fewest columns (Cout = 32 -> 1, 64 -> 2, 96 -> 3); wider layers use
+// NB = 2 (NB = 4 reuses the A fragment four times but halves the resident waves: measured slower).
+template <int NB>
 __global__ __launch_bounds__(256) void mlp_gemm_kernel(GemmArgs a) {
+    constexpr int BN = 32 * NB, LDB = BN + 4;
     __shared__ float As[GM_BM * GM_LDA];
-    __shared__ float Bs[GM_BK * GM_LDB];
-    __shared__ float Pm[4][GM_BN];
+    __shared__ float Bs[GM_BK * LDB];
+    __shared__ float Pm[4][BN];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int row0 = blockIdx.x * GM_BM, col0 = blockIdx.y * GM_BN;
-    f16v c0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    f16v c1 = c0;
+    const int row0 = blockIdx.x * GM_BM, col0 = blockIdx.y * BN;
+    f16v c[NB];
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c[n][r] = 0.f;
     constexpr int AK = GM_BK / 2;                     // k per thread of the A tile
     const int ar = tid >> 1, ak = (tid & 1) * AK;     // A tile: 128 rows x 2 half-rows of AK
-    const int bk = tid >> 4, bc = (tid & 15) * 4;     // B tile: GM_BK k x 16 float4, rows bk, bk + 16, ...
+    constexpr int NBF = GM_BK * BN / 4;               // float4 of the B tile
+    constexpr int BPT = (NBF + 255) / 256;            // per thread
     const ARow arow = gemm_row(a, row0 + ar);
     // 16-byte path for the A tile: the thread's 8 consecutive k lie inside one contiguous, aligned row
     // segment (plain rows, or the feature part of a gathered row); anything else goes element by element
@@ -102,80 +109,86 @@ __global__ __launch_bounds__(256) void mlp_gemm_kernel(GemmArgs a) {
             for (int u = 0; u < AK; ++u) v[u] = gemm_load_a(a, arow, k + u);
         }
     };
-    auto load_b = [&](int kq) {
-        const int k = kq + bk, c = col0 + bc;
+    auto load_b = [&](int k0, int f) {                // float4 number f of the tile: row f / (BN/4), column group f % (BN/4)
+        const int k = k0 + f / (BN / 4), cc = col0 + (f % (BN / 4)) * 4;
         float4 w = {0.f, 0.f, 0.f, 0.f};
-        if (k < a.Cin) {
-            if (c + 3 < a.Cout && (a.Cout & 3) == 0) {
-                w = *(const float4 *)(a.Wt + (size_t)k * a.Cout + c);
+        if (f < NBF && k < a.Cin) {
+            if (cc + 3 < a.Cout && (a.Cout & 3) == 0) {
+                w = *(const float4 *)(a.Wt + (size_t)k * a.Cout + cc);
             } else {
-                if (c < a.Cout) w.x = a.Wt[(size_t)k * a.Cout + c];
-                if (c + 1 < a.Cout) w.y = a.Wt[(size_t)k * a.Cout + c + 1];
-                if (c + 2 < a.Cout) w.z = a.Wt[(size_t)k * a.Cout + c + 2];
-                if (c + 3 < a.Cout) w.w = a.Wt[(size_t)k * a.Cout + c + 3];
+                if (cc < a.Cout) w.x = a.Wt[(size_t)k * a.Cout + cc];
+                if (cc + 1 < a.Cout) w.y = a.Wt[(size_t)k * a.Cout + cc + 1];
+                if (cc + 2 < a.Cout) w.z = a.Wt[(size_t)k * a.Cout + cc + 2];
+                if (cc + 3 < a.Cout) w.w = a.Wt[(size_t)k * a.Cout + cc + 3];
             }
         }
         return w;
     };
     // register double buffering: the loads of K-step i+1 are in flight while step i runs on the matrix cores
     float av8[AK];
-    float4 bw[GM_BK / 16];
+    float4 bw[BPT];
     load_a(0, av8);
 #pragma unroll
-    for (int h = 0; h < GM_BK / 16; ++h) bw[h] = load_b(16 * h);
+    for (int h = 0; h < BPT; ++h) bw[h] = load_b(0, tid + 256 * h);
     for (int k0 = 0; k0 < a.Cin; k0 += GM_BK) {
 #pragma unroll
         for (int u = 0; u < AK; ++u) As[ar * GM_LDA + ak + u] = av8[u];
 #pragma unroll
-        for (int h = 0; h < GM_BK / 16; ++h) *(float4 *)(Bs + (bk + 16 * h) * GM_LDB + bc) = bw[h];
+        for (int h = 0; h < BPT; ++h) {
+            const int f = tid + 256 * h;
+            if (f < NBF) *(float4 *)(Bs + (f / (BN / 4)) * LDB + (f % (BN / 4)) * 4) = bw[h];
+        }
         __syncthreads();
         if (k0 + GM_BK < a.Cin) {
             load_a(k0 + GM_BK, av8);
 #pragma unroll
-            for (int h = 0; h < GM_BK / 16; ++h) bw[h] = load_b(k0 + GM_BK + 16 * h);
+            for (int h = 0; h < BPT; ++h) bw[h] = load_b(k0 + GM_BK, tid + 256 * h);
         }
 #pragma unroll
         for (int kk = 0; kk < GM_BK; kk += 2) {
             const int kl = kk + (lane >> 5);
             const float av = As[(wv * 32 + (lane & 31)) * GM_LDA + kl];
-            const float b0 = Bs[kl * GM_LDB + (lane & 31)];
-            const float b1 = Bs[kl * GM_LDB + 32 + (lane & 31)];
-            c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, c1, 0, 0, 0);
+#pragma unroll
+            for (int n = 0; n < NB; ++n)
+                c[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Bs[kl * LDB + 32 * n + (lane & 31)], c[n], 0, 0, 0);
         }
         __syncthreads();
     }
     // epilogue: C/D layout row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), col = lane & 31
-    const int cA = col0 + (lane & 31), cB = cA + 32;
-    const float biasA = (a.bias && cA < a.Cout) ? a.bias[cA] : 0.f;
-    const float biasB = (a.bias && cB < a.Cout) ? a.bias[cB] : 0.f;
-    float mA = -INFINITY, mB = -INFINITY;
+    float mx[NB];
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-        const int r = row0 + wv * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-        float vA = c0[reg] + biasA, vB = c1[reg] + biasB;
-        if (a.relu) { vA = vA > 0.f ? vA : 0.f; vB = vB > 0.f ? vB : 0.f; }
-        if (a.pool_k) {
-            if (r < a.rows) { mA = fmaxf(mA, vA); mB = fmaxf(mB, vB); }
-        } else if (r < a.rows) {
-            if (cA < a.Cout) a.Y[(size_t)r * a.ldy + a.ycol0 + cA] = vA;
-            if (cB < a.Cout) a.Y[(size_t)r * a.ldy + a.ycol0 + cB] = vB;
+    for (int n = 0; n < NB; ++n) {
+        const int cn = col0 + 32 * n + (lane & 31);
+        const float bias = (a.bias && cn < a.Cout) ? a.bias[cn] : 0.f;
+        mx[n] = -INFINITY;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int r = row0 + wv * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+            float v = c[n][reg] + bias;
+            if (a.relu) v = v > 0.f ? v : 0.f;
+            if (a.pool_k) {
+                if (r < a.rows) mx[n] = fmaxf(mx[n], v);
+            } else if (r < a.rows && cn < a.Cout) {
+                a.Y[(size_t)r * a.ldy + a.ycol0 + cn] = v;
+            }
         }
     }
     if (!a.pool_k) return;
     // max over the wave's 32 rows, then over pool_k / 32 waves
-    mA = fmaxf(mA, __shfl_xor(mA, 32, 64));
-    mB = fmaxf(mB, __shfl_xor(mB, 32, 64));
-    if (lane < 32) { Pm[wv][lane] = mA; Pm[wv][32 + lane] = mB; }
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+        mx[n] = fmaxf(mx[n], __shfl_xor(mx[n], 32, 64));
+        if (lane < 32) Pm[wv][32 * n + lane] = mx[n];
+    }
     __syncthreads();
     const int wpg = a.pool_k / 32;                 // waves per pooled group: 1, 2 or 4
     const int groups = 4 / wpg;
-    for (int e = tid; e < groups * GM_BN; e += 256) {
-        const int g = e / GM_BN, c = e % GM_BN;
+    for (int e = tid; e < groups * BN; e += 256) {
+        const int g = e / BN, cc = e % BN;
         float m = -INFINITY;
-        for (int w = 0; w < wpg; ++w) m = fmaxf(m, Pm[g * wpg + w][c]);
+        for (int w = 0; w < wpg; ++w) m = fmaxf(m, Pm[g * wpg + w][cc]);
         const int prow = (row0 + g * a.pool_k) / a.pool_k;
-        if (row0 + g * a.pool_k < a.rows && col0 + c < a.Cout) a.Y[(size_t)prow * a.ldy + a.ycol0 + col0 + c] = m;
+        if (row0 + g * a.pool_k < a.rows && col0 + cc < a.Cout) a.Y[(size_t)prow * a.ldy + a.ycol0 + col0 + cc] = m;
     }
 }
 
@@ -197,8 +210,14 @@ extern "C" int reart_mlp_layer(const float *X, int ldx, const int64_t *gather_id
     a.X = X; a.ldx = ldx; a.idx = gather_idx; a.K = K; a.S = S; a.Npts = Npts; a.F = F; a.D = D; a.Q = Q; a.C = C;
     a.xyz_first = xyz_first; a.Wt = Wt; a.bias = bias; a.rows = rows; a.Cin = Cin; a.Cout = Cout; a.relu = relu;
     a.pool_k = pool_k; a.Y = Y; a.ldy = ldy; a.ycol0 = ycol0;
-    const dim3 grid(reart_div_up(rows, GM_BM), reart_div_up(Cout, GM_BN));
-    hipLaunchKernelGGL(mlp_gemm_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    const int NB = Cout <= 32 ? 1 : (Cout <= 64 ? 2 : (Cout <= 96 ? 3 : 2));   // measured: NB = 4 for wide layers is slower (7.5 vs 6.7 ms)
+    const dim3 grid(reart_div_up(rows, GM_BM), reart_div_up(Cout, 32 * NB));
+    switch (NB) {
+        case 1: hipLaunchKernelGGL(mlp_gemm_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a); break;
+        case 2: hipLaunchKernelGGL(mlp_gemm_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, a); break;
+        case 3: hipLaunchKernelGGL(mlp_gemm_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, a); break;
+        default: hipLaunchKernelGGL(mlp_gemm_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, a); break;
+    }
     REART_CHECK_LAUNCH();
     return REART_OK;
 }
