@@ -280,6 +280,10 @@ __device__ __forceinline__ void flow_blend_body(const FlowArgs &a, const int bx,
         float kd[3] = {INFINITY, INFINITY, INFINITY};
         int ki[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff};
         const size_t stride = (size_t)a.B * a.N * 3, o0 = ((size_t)f * a.N + n) * 3;
+        // the point in both frames of the pair: independent of the search results, issued first
+        const float *c0 = complete_frame(a, f) + 3 * (size_t)n;
+        const float *c1 = complete_frame(a, f + 1) + 3 * (size_t)n;
+        const float c0v[3] = {c0[0], c0[1], c0[2]}, c1v[3] = {c1[0], c1[1], c1[2]};
         for (int s0 = 0; s0 < (ONE ? 1 : a.S); s0 += 4) {
             float e[4][3];
             int q[4][3];
@@ -297,11 +301,10 @@ __device__ __forceinline__ void flow_blend_body(const FlowArgs &a, const int bx,
                 for (int k = 0; k < 3; ++k)   // (INF, x) never enters: INF < INF is false and ids of real entries are smaller
                     top3_insert(kd, ki, e[u][k], e[u][k] < INFINITY ? q[u][k] : 0x7fffffff);
         }
-        const float *c0q = complete_frame(a, f) + 3 * (size_t)n;
         if (a.blocks) {
             // kd/ki are the 3 best blocks over all slices (by minimum, then index); the 3 nearest
             // targets lie inside them: one exact rescan of 24 targets with the full (d, index) key
-            const float qx = c0q[0], qy = c0q[1], qz = c0q[2];
+            const float qx = c0v[0], qy = c0v[1], qz = c0v[2];
             const float *tx = a.rsoa + (size_t)f * 3 * a.Mpad, *ty = tx + a.Mpad, *tz = ty + a.Mpad;
             int bb[3];
             float4 X[3][2], Y[3][2], Z[3][2];
@@ -345,9 +348,6 @@ __device__ __forceinline__ void flow_blend_body(const FlowArgs &a, const int bx,
         for (int k = 0; k < 3; ++k)
 #pragma unroll
             for (int c = 0; c < 3; ++c) rfl[k][c] = rf[3 * (size_t)ki[k] + c];
-        const float *c0 = complete_frame(a, f) + 3 * (size_t)n;
-        const float *c1 = complete_frame(a, f + 1) + 3 * (size_t)n;
-        const float c0v[3] = {c0[0], c0[1], c0[2]}, c1v[3] = {c1[0], c1[1], c1[2]};
         float w[3], wsum = 0.f, dmin = INFINITY, fmx = -INFINITY;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
