@@ -52,6 +52,28 @@ __device__ __forceinline__ double reart_wave_sum_d(double v) {
     return v;
 }
 
+// Minimum / maximum over each group of 16 consecutive lanes (a DPP row), every lane receives the result.
+// Four DPP steps (quad xor 1, quad xor 2, half-row mirror, row mirror): one VALU instruction each, where
+// __shfl_xor lowers to ds_bpermute_b32 (an LDS crossbar round trip per step).
+template <int CTRL>
+__device__ __forceinline__ float reart_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float reart_row16_min(float v) {
+    v = fminf(v, reart_dpp<0xB1>(v));    // quad_perm [1,0,3,2]
+    v = fminf(v, reart_dpp<0x4E>(v));    // quad_perm [2,3,0,1]
+    v = fminf(v, reart_dpp<0x141>(v));   // row_half_mirror
+    v = fminf(v, reart_dpp<0x140>(v));   // row_mirror
+    return v;
+}
+__device__ __forceinline__ float reart_row16_max(float v) {
+    v = fmaxf(v, reart_dpp<0xB1>(v));
+    v = fmaxf(v, reart_dpp<0x4E>(v));
+    v = fmaxf(v, reart_dpp<0x141>(v));
+    v = fmaxf(v, reart_dpp<0x140>(v));
+    return v;
+}
+
 // XCD-aware remap of a linear workgroup id (cdna guide T1): the dispatcher places
 // workgroup L on XCD L % 8; give each XCD a contiguous chunk of work items so that
 // neighbours (same batch / same target slice) share one L2.  Returns -1 for the

@@ -116,14 +116,9 @@ __device__ __forceinline__ void knn_pruned_body(const KnnArgs &a, const int w) {
     }
 
     // ---- group summaries: 4 groups of 16 lanes
-    float gl0 = qx, gl1 = qy, gl2 = qz, gh0 = qx, gh1 = qy, gh2 = qz, gt = thr;
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) {
-        gl0 = fminf(gl0, __shfl_xor(gl0, o, 64)); gh0 = fmaxf(gh0, __shfl_xor(gh0, o, 64));
-        gl1 = fminf(gl1, __shfl_xor(gl1, o, 64)); gh1 = fmaxf(gh1, __shfl_xor(gh1, o, 64));
-        gl2 = fminf(gl2, __shfl_xor(gl2, o, 64)); gh2 = fmaxf(gh2, __shfl_xor(gh2, o, 64));
-        gt = fmaxf(gt, __shfl_xor(gt, o, 64));
-    }
+    const float gl0 = reart_row16_min(qx), gl1 = reart_row16_min(qy), gl2 = reart_row16_min(qz);
+    const float gh0 = reart_row16_max(qx), gh1 = reart_row16_max(qy), gh2 = reart_row16_max(qz);
+    const float gt = reart_row16_max(thr);
     float G[4][7];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
