@@ -288,16 +288,21 @@ __global__ __launch_bounds__(NN_BS * PR_WPB) void knn_pruned_kernel(KnnArgs a) {
 // with one K = 3 item while both kinds last.
 struct KnnPairArgs { KnnArgs k1, k3; int mixed; unsigned int *ctr; };   // mixed = 3 * min(items1 / 2, items3)
 __device__ __forceinline__ void knn_pruned_pair_item(const KnnPairArgs &a, const int w) {
+    // item kind and index first, then ONE call site per body (each inlined copy is ~1 k instructions)
+    int kind, idx;
     if (w < a.mixed) {
         const int q = w / 3, r = w - 3 * q;
-        if (r < 2) knn_pruned_body<1>(a.k1, 2 * q + r);
-        else knn_pruned_body<3>(a.k3, q);
+        kind = r < 2 ? 1 : 3;
+        idx = r < 2 ? 2 * q + r : q;
     } else {
         const int d1 = 2 * (a.mixed / 3), d3 = a.mixed / 3;   // items already dealt
-        const int v = w - a.mixed;
-        if (v < a.k1.items - d1) knn_pruned_body<1>(a.k1, d1 + v);
-        else if (v - (a.k1.items - d1) < a.k3.items - d3) knn_pruned_body<3>(a.k3, d3 + (v - (a.k1.items - d1)));
+        const int v = w - a.mixed, left1 = a.k1.items - d1;
+        kind = v < left1 ? 1 : 3;
+        idx = v < left1 ? d1 + v : d3 + (v - left1);
+        if (kind == 3 && idx >= a.k3.items) return;
     }
+    if (kind == 1) knn_pruned_body<1>(a.k1, idx);
+    else knn_pruned_body<3>(a.k3, idx);
 }
 __global__ __launch_bounds__(NN_BS * PR_WPB) void knn_pruned_pair_kernel(KnnPairArgs a) {
     knn_pruned_pair_item(a, blockIdx.x * PR_WPB + (threadIdx.x >> 6));
