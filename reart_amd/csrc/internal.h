@@ -107,6 +107,8 @@ struct KnnJob {
     const int *tlen;       // nullable per-batch target count (ragged SoA rows, stride Ppad)
     const float *boxes;    // nullable [N][Ppad/NN_BOX][8]: AABB (lo xyz, hi xyz, pad) of every NN_BOX targets
     const int *seed;       // pruned search only: [N][P1][KK] candidate neighbour indices (warm start)
+    const int *border;     // pruned search only, nullable: batch index handled at launch position k (heavy batches
+                           // first: the items of a launch are dealt in order, late heavy items make a long tail)
     int P1, P2, Ppad, L;   // Ppad = S*L, L % NN_UB == 0
     int nqg;               // ceil(P1/64)
     float *pd;             // partial dists [S][N][P1][KK]   (S > 1)

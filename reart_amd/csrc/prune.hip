@@ -50,6 +50,14 @@ extern "C" int reart_debug_prune_stats(unsigned long long *out, int reset) {
 #else
 #define PRUNE_STAT(k, v) do { } while (0)
 #endif
+#ifdef REART_ITEM_CLOCK   // diagnostic build only (tools/item_clock.py): wave lifetime of every work item
+// (start, end in s_memtime ticks, XCC id) of the last pair launch, items in launch order
+__device__ unsigned long long g_item_clock[3 * 16384];
+extern "C" int reart_debug_item_clock(unsigned long long *out, int n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_item_clock), sizeof(unsigned long long) * 3 * (n < 16384 ? n : 16384)) == hipSuccess
+               ? REART_OK : REART_ERR_LAUNCH;
+}
+#endif
 
 __device__ __forceinline__ float rl(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
@@ -77,7 +85,8 @@ __device__ __forceinline__ void knn_pruned_body(const KnnArgs &a, const int w) {
     const int wl = two ? (w >> 1) : w;
     const int s = wl % a.S;                      // slices of one query group are neighbours
     const int g = (wl / a.S) % jb.nqg;
-    const int b = wl / (jb.nqg * a.S);
+    const int bpos = wl / (jb.nqg * a.S);
+    const int b = jb.border ? jb.border[bpos] : bpos;
     const int lane = threadIdx.x & 63;
 
     const int i = g * NN_BS + lane;
@@ -305,7 +314,17 @@ __device__ __forceinline__ void knn_pruned_pair_item(const KnnPairArgs &a, const
     else knn_pruned_body<3>(a.k3, idx);
 }
 __global__ __launch_bounds__(NN_BS * PR_WPB) void knn_pruned_pair_kernel(KnnPairArgs a) {
+#ifdef REART_ITEM_CLOCK
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#endif
     knn_pruned_pair_item(a, blockIdx.x * PR_WPB + (threadIdx.x >> 6));
+#ifdef REART_ITEM_CLOCK
+    if (threadIdx.x == 0 && blockIdx.x < 16384) {
+        g_item_clock[3 * blockIdx.x] = t0;
+        g_item_clock[3 * blockIdx.x + 1] = __builtin_amdgcn_s_memtime();
+        g_item_clock[3 * blockIdx.x + 2] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 0xf;   // HW_REG_XCC_ID
+    }
+#endif
 }
 // Persistent form: a fixed number of one-wave workgroups (a few per SIMD) each take every
 // gridDim.x-th work item.  (Drawing items from one device counter was tried: ~15 k atomics on one

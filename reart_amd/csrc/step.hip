@@ -27,6 +27,7 @@ struct StepPlan {
     size_t o_boxY, o_boxX, o_boxR;  // AABBs of every NN_BOX targets (block-skip test)
     int pruned;               // box-pruned, warm-started search (prune.hip) instead of the slice kernels
     size_t o_seed0, o_seed1, o_seed3;  // last iteration's neighbour indices: x->y [B,N], y->x [B,N], flow [B,N,3]
+    size_t o_border;          // [2][B] launch order of the frames (Chamfer) / frame pairs (flow): farthest from the canonical frame first
     size_t o_gridY, o_gridR;  // exact-search grids over pc_list and the flow reference sets
     int gstrideY, gstrideR;
     size_t bwd_bytes, total;
@@ -97,6 +98,7 @@ static int step_plan(const reart_relax_config *c, StepPlan *p) {
     p->o_seed0 = take(off, p->pruned ? sizeof(int) * BN : 0);
     p->o_seed1 = take(off, p->pruned ? sizeof(int) * BN : 0);
     p->o_seed3 = take(off, (p->pruned && c->use_flow) ? sizeof(int) * BN * 3 : 0);
+    p->o_border = take(off, sizeof(int) * 2 * c->B);
     p->gstrideY = (int)reart_align_up((size_t)c->N, 64);
     p->gstrideR = (int)reart_align_up((size_t)(c->M_max > 0 ? c->M_max : 1), 64);
     p->o_gridY = take(off, c->use_grid ? reart_grid_bytes(c->B, p->gstrideY) : 0);
@@ -116,7 +118,7 @@ __global__ void relax_init_kernel(reart_relax_config c, const int *__restrict__ 
                                   int *__restrict__ rlen, int *__restrict__ qmap,
                                   int64_t *__restrict__ iter, float *__restrict__ tau,
                                   const float *__restrict__ pc_list, int *__restrict__ fx_bits,
-                                  double *__restrict__ bias_corr, int *__restrict__ seed3) {
+                                  double *__restrict__ bias_corr, int *__restrict__ seed3, int *__restrict__ border) {
     __shared__ float s_max[1024];
     const int t = threadIdx.x;
     // warm start of the first k=3 search: any 3 distinct valid indices
@@ -140,6 +142,24 @@ __global__ void relax_init_kernel(reart_relax_config c, const int *__restrict__ 
         fx_bits[0] = bits > 39 ? 39 : (bits < 0 ? 0 : bits);
     }
     if (t < c.B) {
+        // Launch order of the search items: frames far from the canonical frame move most, have the largest
+        // neighbour distances and therefore the most candidate boxes -- they go first, so that the launch does not
+        // end on its heaviest items.  Rank by distance (descending), ties by index.
+        {
+            const int fc = t < c.cano_idx ? t : t + 1;                 // complete-sequence index of pc_list[t]
+            const int dt = fc > c.cano_idx ? fc - c.cano_idx : c.cano_idx - fc;
+            const int d3 = t >= c.cano_idx ? t - c.cano_idx : c.cano_idx - 1 - t;   // pair t = frames t, t+1
+            int r1 = 0, r3 = 0;
+            for (int o = 0; o < c.B; ++o) {
+                const int fo = o < c.cano_idx ? o : o + 1;
+                const int dox = fo > c.cano_idx ? fo - c.cano_idx : c.cano_idx - fo;
+                const int do3 = o >= c.cano_idx ? o - c.cano_idx : c.cano_idx - 1 - o;
+                r1 += (dox > dt || (dox == dt && o < t)) ? 1 : 0;
+                r3 += (do3 > d3 || (do3 == d3 && o < t)) ? 1 : 0;
+            }
+            border[r1] = t;
+            border[c.B + r3] = t;
+        }
         // flow pair f (complete frames f -> f+1) queries complete frame f (run_robot.py:196):
         // complete frame f is pc_trans[f] before the canonical index, the canonical cloud at it,
         // pc_trans[f-1] after it.
@@ -193,7 +213,7 @@ extern "C" int reart_relax_prepare(const reart_relax_config *cfg, const reart_re
     hipLaunchKernelGGL(relax_init_kernel, dim3(1), dim3(1024), 0, st, *cfg, bufs->ref_off,
                        (int *)(ws + p.o_rlen), (int *)(ws + p.o_qmap), bufs->iter, bufs->tau, bufs->pc_list,
                        (int *)(ws + p.o_fx), (double *)(ws + p.o_bc),
-                       (p.pruned && cfg->use_flow) ? (int *)(ws + p.o_seed3) : nullptr);
+                       (p.pruned && cfg->use_flow) ? (int *)(ws + p.o_seed3) : nullptr, (int *)(ws + p.o_border));
     if (hipMemsetAsync(ws + p.o_ticket, 0, 4 * sizeof(unsigned int), st) != hipSuccess) return REART_ERR_LAUNCH;
     if (p.pruned) {  // warm start of the first Chamfer search: index 0 (any valid index)
         if (hipMemsetAsync(ws + p.o_seed0, 0, sizeof(int) * (size_t)cfg->B * cfg->N, st) != hipSuccess) return REART_ERR_LAUNCH;
@@ -626,6 +646,7 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
             k3.items0 = p.pruned == 3 ? B * reart_div_up(N, 16) : B * kj.nqg * p.S3;
             k3.items = k3.items0;
             kj.seed = p.pruned ? (const int *)(ws + p.o_seed3) : nullptr;
+            kj.border = (const int *)(ws + p.o_border) + B;
             k3.job[1] = kj;
             if (!merged) {
                 rc = p.pruned == 3 ? reart_knn_launch_quad(k3, 3, fst) : p.pruned == 2 ? reart_knn_launch_lane(k3, 3, fst)
@@ -667,6 +688,7 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
         kj.pi = (int *)(ws + (j == 0 ? p.o_pi0 : p.o_pi1));
         kj.boxes = c.use_boxes ? (const float *)(ws + (j == 0 ? p.o_boxY : p.o_boxX)) : nullptr;
         kj.seed = p.pruned ? (const int *)(ws + (j == 0 ? p.o_seed0 : p.o_seed1)) : nullptr;
+        kj.border = (const int *)(ws + p.o_border);
     }
     int S0 = p.S1;
     if (c.use_grid) {
