@@ -109,6 +109,8 @@ struct KnnJob {
     const int *seed;       // pruned search only: [N][P1][KK] candidate neighbour indices (warm start)
     const int *border;     // pruned search only, nullable: batch index handled at launch position k (heavy batches
                            // first: the items of a launch are dealt in order, late heavy items make a long tail)
+    unsigned int *cost;    // pruned search only, nullable: [items of this job] work done by each item (boxes tested
+                           // and scanned, launch order), input of the next launch's order
     int P1, P2, Ppad, L;   // Ppad = S*L, L % NN_UB == 0
     int nqg;               // ceil(P1/64)
     float *pd;             // partial dists [S][N][P1][KK]   (S > 1)

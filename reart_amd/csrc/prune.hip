@@ -144,6 +144,7 @@ __device__ __forceinline__ void knn_pruned_body(const KnnArgs &a, const int w) {
     float *s_tg = s_tg_all + (threadIdx.x >> 6) * (PR_PF * 48);
     const float *tx_g = tx;
 
+    int work = 16;   // uniform work counter of this item (prologue ~ 16 tests)
     const int per = 64 * a.S;
     for (int base = 0; base < nbox; base += per) {
         // ---- coarse filter: lane l looks at box base + l*S + s
@@ -166,6 +167,7 @@ __device__ __forceinline__ void knn_pruned_body(const KnnArgs &a, const int w) {
         if (KK == 1) PRUNE_STAT(3, __builtin_popcountll(__ballot(thr == INFINITY)));  // lanes without a bound
         // scan of one box: the brute-force inner loop of knn.hip on its 16 targets
         auto scan_box = [&](const int bit, const int slot) {
+            work += 5;                                                   // a scan costs about five tests
             if (KK == 1) PRUNE_STAT(2, 1);                               // boxes scanned
             const int j0 = (base + bit * a.S + s) * NN_BOX;
             // the box's 16 targets were staged in LDS slot `slot` (x[16] | y[16] | z[16]); all lanes read
@@ -251,6 +253,7 @@ __device__ __forceinline__ void knn_pruned_body(const KnnArgs &a, const int w) {
             const f2 e1 = {fmaxf(fmaxf(a1.x, c1.x), 0.f), fmaxf(fmaxf(a1.y, c1.y), 0.f)};
             const f2 e2 = {fmaxf(fmaxf(a2.x, c2.x), 0.f), fmaxf(fmaxf(a2.y, c2.y), 0.f)};
             const f2 lb = (e0 * e0 + e1 * e1) + e2 * e2;
+            work += 2;
 #pragma unroll 1   // one copy of the scan code (two copies cost 30 VGPRs of occupancy)
             for (int h = 0; h < (hasB ? 2 : 1); ++h) {
                 const float lbh = h ? lb.y : lb.x;
@@ -280,6 +283,7 @@ __device__ __forceinline__ void knn_pruned_body(const KnnArgs &a, const int w) {
         }
         bb[0] = bi;
     }
+    if (jb.cost && lane == 0) jb.cost[wl] = (unsigned int)work;
     if (i >= jb.P1) return;
     const size_t o = (((size_t)s * a.N + b) * jb.P1 + i) * KK;
 #pragma unroll
