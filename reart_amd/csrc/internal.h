@@ -107,8 +107,9 @@ struct KnnJob {
     const int *tlen;       // nullable per-batch target count (ragged SoA rows, stride Ppad)
     const float *boxes;    // nullable [N][Ppad/NN_BOX][8]: AABB (lo xyz, hi xyz, pad) of every NN_BOX targets
     const int *seed;       // pruned search only: [N][P1][KK] candidate neighbour indices (warm start)
-    const int *border;     // pruned search only, nullable: batch index handled at launch position k (heavy batches
-                           // first: the items of a launch are dealt in order, late heavy items make a long tail)
+    const int *border;     // pruned search only, nullable: [N * nqg] (batch, query group) pair = b * nqg + g handled at
+                           // launch position k (heavy pairs first: the items of a launch are dealt in order, late
+                           // heavy items make a long tail)
     unsigned int *cost;    // pruned search only, nullable: [items of this job] work done by each item (boxes tested
                            // and scanned, launch order), input of the next launch's order
     int P1, P2, Ppad, L;   // Ppad = S*L, L % NN_UB == 0

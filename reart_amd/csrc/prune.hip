@@ -84,9 +84,9 @@ __device__ __forceinline__ void knn_pruned_body(const KnnArgs &a, const int w) {
     const KnnJob jb = a.job[jsel];
     const int wl = two ? (w >> 1) : w;
     const int s = wl % a.S;                      // slices of one query group are neighbours
-    const int g = (wl / a.S) % jb.nqg;
-    const int bpos = wl / (jb.nqg * a.S);
-    const int b = jb.border ? jb.border[bpos] : bpos;
+    const int gpos = wl / a.S;                                   // launch position of the (batch, query group) pair
+    const int grp = jb.border ? jb.border[gpos] : gpos;
+    const int b = grp / jb.nqg, g = grp - b * jb.nqg;
     const int lane = threadIdx.x & 63;
 
     const int i = g * NN_BS + lane;

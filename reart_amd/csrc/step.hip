@@ -27,7 +27,7 @@ struct StepPlan {
     size_t o_boxY, o_boxX, o_boxR;  // AABBs of every NN_BOX targets (block-skip test)
     int pruned;               // box-pruned, warm-started search (prune.hip) instead of the slice kernels
     size_t o_seed0, o_seed1, o_seed3;  // last iteration's neighbour indices: x->y [B,N], y->x [B,N], flow [B,N,3]
-    size_t o_border;          // [3][B] launch order of the frames (Chamfer x -> y, y -> x) / frame pairs (flow): heaviest first
+    size_t o_border;          // [3][B * nqg] launch order of the (frame, query group) pairs of the three search jobs: heaviest first
     size_t o_cost;            // per-item work counts of the last search launch (3 jobs)
     size_t o_gridY, o_gridR;  // exact-search grids over pc_list and the flow reference sets
     int gstrideY, gstrideR;
@@ -99,7 +99,7 @@ static int step_plan(const reart_relax_config *c, StepPlan *p) {
     p->o_seed0 = take(off, p->pruned ? sizeof(int) * BN : 0);
     p->o_seed1 = take(off, p->pruned ? sizeof(int) * BN : 0);
     p->o_seed3 = take(off, (p->pruned && c->use_flow) ? sizeof(int) * BN * 3 : 0);
-    p->o_border = take(off, sizeof(int) * 3 * c->B);
+    p->o_border = take(off, sizeof(int) * 3 * (size_t)c->B * reart_div_up(c->N, NN_BS));
     p->o_cost = take(off, sizeof(unsigned int) * 3 * (size_t)c->B * reart_div_up(c->N, NN_BS) * 16);
     p->gstrideY = (int)reart_align_up((size_t)c->N, 64);
     p->gstrideR = (int)reart_align_up((size_t)(c->M_max > 0 ? c->M_max : 1), 64);
@@ -159,9 +159,12 @@ __global__ void relax_init_kernel(reart_relax_config c, const int *__restrict__ 
                 r1 += (dox > dt || (dox == dt && o < t)) ? 1 : 0;
                 r3 += (do3 > d3 || (do3 == d3 && o < t)) ? 1 : 0;
             }
-            border[r1] = t;
-            border[c.B + r1] = t;
-            border[2 * c.B + r3] = t;
+            const int nqg = (c.N + NN_BS - 1) / NN_BS, ng = c.B * nqg;
+            for (int g = 0; g < nqg; ++g) {
+                border[r1 * nqg + g] = t * nqg + g;
+                border[ng + r1 * nqg + g] = t * nqg + g;
+                border[2 * ng + r3 * nqg + g] = t * nqg + g;
+            }
         }
         // flow pair f (complete frames f -> f+1) queries complete frame f (run_robot.py:196):
         // complete frame f is pc_trans[f] before the canonical index, the canonical cloud at it,
@@ -567,36 +570,42 @@ __global__ __launch_bounds__(FLOW_BS) void flow_blend_kernel(FlowArgs a) {
 // workgroup of the consumer launch sums them per frame (integer sums: deterministic) and ranks the frames,
 // heaviest first.
 struct OrderArgs {
-    const unsigned int *cost[3];   // per job: x -> y, y -> x, flow; [B * per_frame] in the CURRENT launch order
-    int *border[3];                // per job: launch position -> frame (read for the mapping, then rewritten)
-    int per_frame[3];              // items per frame
-    int B;
+    const unsigned int *cost[3];   // per job: x -> y, y -> x, flow; [groups * S] work counts in the CURRENT launch order
+    int *border[3];                // per job: launch position -> (frame, query group) pair (read, then rewritten)
+    int S[3];                      // items (slices) per pair
+    int groups;                    // B * nqg pairs per job
 };
-__device__ __forceinline__ void order_body(const OrderArgs &o) {
-    __shared__ unsigned int s_sum[3 * 64];
-    __shared__ int s_old[3 * 64];
+#define ORD_MAX 4                  // pairs per thread: groups <= ORD_MAX * CG_BS, otherwise the order is left alone
+// one workgroup per job: counting sort of the pairs by their work of the iteration that just ran, heaviest first
+__device__ __forceinline__ void order_body(const OrderArgs &o, const int j) {
+    __shared__ unsigned int s_hist[256];
     const int tid = threadIdx.x;
-    if (o.B > 64) return;                       // more frames than the table holds: keep the static order
-    for (int e = tid; e < 3 * 64; e += CG_BS) { s_sum[e] = 0u; s_old[e] = 0; }
+    if (!o.cost[j] || o.groups > ORD_MAX * CG_BS) return;
+    for (int e = tid; e < 256; e += CG_BS) s_hist[e] = 0u;
     __syncthreads();
-    for (int j = 0; j < 3; ++j) {
-        if (!o.cost[j]) continue;
-        if (tid < o.B) s_old[64 * j + tid] = o.border[j][tid];
-        const int n = o.B * o.per_frame[j];
-        for (int e = tid; e < n; e += CG_BS) atomicAdd(&s_sum[64 * j + e / o.per_frame[j]], o.cost[j][e]);
-    }
-    __syncthreads();
-    for (int e = tid; e < 3 * o.B; e += CG_BS) {
-        const int j = e / o.B, k = e - j * o.B;             // launch position k of job j
-        if (!o.cost[j]) continue;
-        const unsigned int c = s_sum[64 * j + k];
-        int r = 0;
-        for (int q = 0; q < o.B; ++q) {
-            const unsigned int cq = s_sum[64 * j + q];
-            r += (cq > c || (cq == c && q < k)) ? 1 : 0;
+    int old[ORD_MAX], bucket[ORD_MAX];
+#pragma unroll
+    for (int u = 0; u < ORD_MAX; ++u) {
+        const int k = tid + u * CG_BS;
+        old[u] = 0; bucket[u] = -1;
+        if (k < o.groups) {
+            unsigned int c = 0u;
+            for (int s = 0; s < o.S[j]; ++s) c += o.cost[j][(size_t)k * o.S[j] + s];
+            old[u] = o.border[j][k];
+            c >>= 3;
+            bucket[u] = 255 - (int)(c < 255u ? c : 255u);        // heaviest pairs in the first buckets
+            atomicAdd(&s_hist[bucket[u]], 1u);
         }
-        o.border[j][r] = s_old[64 * j + k];
     }
+    __syncthreads();
+    if (tid == 0) {   // exclusive prefix of 256 counters
+        unsigned int run = 0u;
+        for (int e = 0; e < 256; ++e) { const unsigned int c = s_hist[e]; s_hist[e] = run; run += c; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < ORD_MAX; ++u)
+        if (bucket[u] >= 0) o.border[j][atomicAdd(&s_hist[bucket[u]], 1u)] = old[u];
 }
 struct PostArgs { FlowArgs fl; CGradArgs cg; OrderArgs od; int nfx, nflow, ncx, nwork; };
 template <bool ONE>
@@ -604,7 +613,7 @@ __global__ __launch_bounds__(CG_BS) void post_kernel(PostArgs a) {
     const int w = blockIdx.x;
     if (w < a.nflow) flow_blend_body<ONE, CG_BS>(a.fl, w % a.nfx, w / a.nfx, a.nfx);
     else if (w < a.nwork) chamfer_grad_body<ONE>(a.cg, (w - a.nflow) % a.ncx, (w - a.nflow) / a.ncx, a.ncx);
-    else order_body(a.od);
+    else order_body(a.od, w - a.nwork);
 }
 
 // ------------------------------------------------------------------------------ the step
@@ -686,7 +695,7 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
             k3.items0 = p.pruned == 3 ? B * reart_div_up(N, 16) : B * kj.nqg * p.S3;
             k3.items = k3.items0;
             kj.seed = p.pruned ? (const int *)(ws + p.o_seed3) : nullptr;
-            kj.border = (const int *)(ws + p.o_border) + 2 * B;
+            kj.border = (const int *)(ws + p.o_border) + 2 * (size_t)B * kj.nqg;
             kj.cost = p.pruned == 1 ? (unsigned int *)(ws + p.o_cost) + 2 * (size_t)B * kj.nqg * 16 : nullptr;
             k3.job[1] = kj;
             if (!merged) {
@@ -729,7 +738,7 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
         kj.pi = (int *)(ws + (j == 0 ? p.o_pi0 : p.o_pi1));
         kj.boxes = c.use_boxes ? (const float *)(ws + (j == 0 ? p.o_boxY : p.o_boxX)) : nullptr;
         kj.seed = p.pruned ? (const int *)(ws + (j == 0 ? p.o_seed0 : p.o_seed1)) : nullptr;
-        kj.border = (const int *)(ws + p.o_border) + j * B;
+        kj.border = (const int *)(ws + p.o_border) + (size_t)j * B * kj.nqg;
         kj.cost = p.pruned == 1 ? (unsigned int *)(ws + p.o_cost) + (size_t)j * B * kj.nqg * 16 : nullptr;
     }
     int S0 = p.S1;
@@ -797,11 +806,11 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
         for (int j = 0; j < 3; ++j) {
             const KnnJob &kj = j < 2 ? ka.job[j] : k3.job[0];
             pa.od.cost[j] = reorder ? kj.cost : nullptr;
-            pa.od.border[j] = (int *)(ws + p.o_border) + j * B;
-            pa.od.per_frame[j] = kj.nqg * (j < 2 ? p.S1 : p.S3);
+            pa.od.border[j] = (int *)(ws + p.o_border) + (size_t)j * B * kj.nqg;
+            pa.od.S[j] = j < 2 ? p.S1 : p.S3;
         }
-        pa.od.B = B;
-        const int nblk = pa.nwork + (reorder ? 1 : 0);
+        pa.od.groups = B * ka.job[0].nqg;
+        const int nblk = pa.nwork + (reorder ? 3 : 0);
         if (cg.S0 <= 4 && cg.S1 <= 4 && fl.S <= 4) hipLaunchKernelGGL(post_kernel<true>, dim3(nblk), dim3(CG_BS), 0, st, pa);
         else hipLaunchKernelGGL(post_kernel<false>, dim3(nblk), dim3(CG_BS), 0, st, pa);
     } else if (cg.S0 <= 4 && cg.S1 <= 4) hipLaunchKernelGGL(chamfer_grad_kernel<true>, dim3(ncg, B), dim3(CG_BS), 0, st, cg);
