@@ -16,9 +16,9 @@
 //     lower bound is <= that thr for some group.  One ballot gives the survivor mask of 64 boxes.
 //   * Precise filter, one query per lane: point-to-box lower bound against the lane's own thr
 //     (which keeps shrinking as better candidates are found); the box is scanned if any lane
-//     needs it.  Scanning is the brute-force inner loop of knn.hip in packed fp32; the targets of
-//     the surviving boxes are fetched eight boxes at a time through the vector memory path into a
-//     small LDS buffer and read back as broadcasts (a chain of scalar loads per scanned box -- the
+//     needs it.  Scanning is the brute-force inner loop of knn.hip in packed fp32; the 48 coordinates
+//     of a scanned box are fetched through the vector memory path (lane l < 48 loads one float) into
+//     a small LDS buffer and read back as broadcasts (a chain of scalar loads per scanned box -- the
 //     brute-force kernel's operand path -- stalled on scalar-cache misses here: boxes are visited in
 //     a data-dependent order and each is one cache line per axis).
 //
@@ -38,6 +38,11 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #define PR_WPB 1   // waves per workgroup (independent work items, no barrier); measured: 4 is slower (a
                    // workgroup's slots are held until its slowest wave ends)
 #define PR_PF 8    // boxes whose targets are prefetched together
+#ifndef PR_PREFETCH
+#define PR_PREFETCH 0   // 1: fetch the targets of every surviving box PR_PF at a time, before the precise tests.  0: fetch a
+                        // box's targets when it is scanned -- fewer instructions and no loads for the 60 % of the boxes
+                        // the precise test rejects; with 4 waves per SIMD the exposed latency is covered (56 -> 53 us)
+#endif
 
 #ifdef REART_PRUNE_STATS   // diagnostic build only (tools/prune_stats.py): how much the filters let through
 __device__ unsigned long long g_prune_stats[8];
@@ -172,7 +177,12 @@ __device__ __forceinline__ void knn_pruned_body(const KnnArgs &a, const int w) {
             const int j0 = (base + bit * a.S + s) * NN_BOX;
             // the box's 16 targets were staged in LDS slot `slot` (x[16] | y[16] | z[16]); all lanes read
             // the same addresses (broadcast) -- the operands of the packed ops are VGPR pairs
-            const float *tx = s_tg + slot * 48 - j0, *ty = tx + 16, *tz = tx + 32;
+            if (!PR_PREFETCH) {
+                const int l = lane < 48 ? lane : 47;
+                const float v = tx_g[(size_t)(l >> 4) * jb.Ppad + j0 + (l & 15)];
+                if (lane < 48) s_tg[lane] = v;
+            }
+            const float *tx = s_tg + (PR_PREFETCH ? slot * 48 : 0) - j0, *ty = tx + 16, *tz = tx + 32;
             if (KK == 1) {
                 float m = INFINITY;
 #pragma unroll
@@ -217,12 +227,12 @@ __device__ __forceinline__ void knn_pruned_body(const KnnArgs &a, const int w) {
             // then the values are parked in the wave's LDS slots.  (Targets used to come through scalar
             // loads, s_load_dwordx16 x 3 per scanned box: one dependent scalar-cache miss chain per scan;
             // measured 95 -> 80 us for the launch with the vector path alone, before prefetching.)
-            unsigned long long rest = mask;
+            unsigned long long rest = PR_PREFETCH ? mask : 0ull;
 #pragma unroll
             for (int k = 0; k < PR_PF; ++k) rest &= rest - 1;            // x & (x - 1) of 0 is 0
             unsigned long long cm = mask & ~rest;                        // this chunk's boxes
             mask = rest;
-            {
+            if (PR_PREFETCH) {
                 const int l = lane < 48 ? lane : 47;
                 const float *src = tx_g + (size_t)(l >> 4) * jb.Ppad + (l & 15);
                 float pv[PR_PF];
