@@ -1,0 +1,193 @@
+// reart_amd/csrc/lap.hip -- batched linear assignment on the GPU for the assignment loss
+// (reference run_robot.py:164-187: `scipy.optimize.linear_sum_assignment` on (T-1) cost matrices
+// `cdist(pc_src, pc_tgt)` of num_fps x num_fps, recomputed every `assign_gap` iterations; the reference
+// ships them to a CPU process pool, utils/model_utils.py:85-103 -- SURVEY.md 8f-2).
+//
+// scipy's solver is a sequential shortest-augmenting-path method (~150 k dependent steps for n = 1024):
+// latency-bound on a GPU.  Here:
+//   1. forward AUCTION with epsilon scaling (Bertsekas), Jacobi rounds, one workgroup per matrix: every
+//      unassigned row bids for its cheapest column at the current prices; a column takes the highest bid.
+//      Ends with an assignment whose cost is within n * eps_final of the optimum.
+//   2. CERTIFICATE: starting from the auction's prices, Bellman-Ford rounds on the column potentials d
+//      (d_sigma(i) <- min_k (c_ik + d_k) - c_i,sigma(i)) until every row's assigned column is an exact
+//      arg-min of c_ik + d_k.  Then (u, d) is a dual solution tight on the assignment: the assignment is
+//      OPTIMAL (same optimum as scipy's; the permutation is the same whenever the optimum is unique).
+//      If the rounds do not settle (the auction's result was not optimal, or an exact tie cycles within
+//      rounding), the matrix is reported uncertified and the host falls back to scipy for it.
+// All arithmetic on prices / potentials is fp64 on the fp32 costs.  Deterministic: bids meet through
+// integer atomics on ordered keys (max bid, then lowest row).
+#include "common.h"
+#include "internal.h"
+#include <math.h>
+
+#define LAP_BS 1024
+#define LAP_NMAX 2048
+
+struct LapArgs {
+    const float *cost;     // [B][n][n]
+    int B, n;
+    int *col4row;          // [B][n]
+    int *certified;        // [B]
+    double *price_out;     // [B][n] final potentials (workspace)
+    int max_rounds_cert;
+};
+
+__device__ __forceinline__ unsigned long long lap_key(double v) { return (unsigned long long)__double_as_longlong(v); }  // v >= 0
+
+// smallest (value, column) and second smallest value of row i under prices p; all lanes get the result
+__device__ __forceinline__ void lap_row_top2(const float *__restrict__ row, const double *__restrict__ p, int n, int lane,
+                                             double &v1, int &j1, double &v2) {
+    v1 = INFINITY; v2 = INFINITY; j1 = 0x7fffffff;
+    for (int j = lane; j < n; j += 64) {
+        const double v = (double)row[j] + p[j];
+        if (v < v1) { v2 = v1; v1 = v; j1 = j; }
+        else if (v < v2) v2 = v;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const double ov1 = __shfl_xor(v1, o, 64), ov2 = __shfl_xor(v2, o, 64);
+        const int oj1 = __shfl_xor(j1, o, 64);
+        const bool take = (ov1 < v1) || (ov1 == v1 && oj1 < j1);
+        const double lose = take ? v1 : ov1;           // the larger of the two minima
+        v2 = fmin(fmin(v2, ov2), lose);
+        v1 = take ? ov1 : v1;
+        j1 = take ? oj1 : j1;
+    }
+}
+
+__global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lsm[];
+    const int n = a.n, b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    constexpr int NW = LAP_BS / 64;
+    double *price = (double *)lsm;                                  // [n] column prices
+    unsigned long long *bidval = (unsigned long long *)(price + n); // [n] highest bid (ordered key)
+    double *pbval = (double *)(bidval + n);                         // [n] row's bid
+    int *owner = (int *)(pbval + n);                                // [n] column -> row
+    int *assigned = owner + n;                                      // [n] row -> column
+    int *bidder = assigned + n;                                     // [n] winning row of the round
+    int *pbobj = bidder + n;                                        // [n] row's bid column
+    int *ulist = pbobj + n;                                         // [n] unassigned rows
+    __shared__ int s_cnt, s_flag;
+    __shared__ double s_red[NW];
+    const float *C = a.cost + (size_t)b * n * n;
+
+    // largest cost
+    double mx = 0.0;
+    for (size_t e = tid; e < (size_t)n * n; e += LAP_BS) mx = fmax(mx, (double)C[e]);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+    if (lane == 0) s_red[wv] = mx;
+    for (int j = tid; j < n; j += LAP_BS) { price[j] = 0.0; owner[j] = -1; assigned[j] = -1; bidval[j] = 0ull; bidder[j] = 0x7fffffff; }
+    __syncthreads();
+    mx = 0.0;
+    for (int w = 0; w < NW; ++w) mx = fmax(mx, s_red[w]);
+    if (!(mx > 0.0)) mx = 1.0;
+    const double eps_final = mx * 1e-11;
+
+    for (double eps = mx * 0.125; ; eps = fmax(eps * (1.0 / 6.0), eps_final)) {
+        // a phase starts with every row unassigned (prices are kept)
+        for (int j = tid; j < n; j += LAP_BS) { owner[j] = -1; assigned[j] = -1; }
+        __syncthreads();
+        for (;;) {
+            if (tid == 0) s_cnt = 0;
+            __syncthreads();
+            for (int i = tid; i < n; i += LAP_BS)
+                if (assigned[i] < 0) ulist[atomicAdd(&s_cnt, 1)] = i;
+            __syncthreads();
+            const int nu = s_cnt;
+            if (nu == 0) break;
+            // bids: one wave per unassigned row
+            for (int u = wv; u < nu; u += NW) {
+                const int i = ulist[u];
+                double v1, v2;
+                int j1;
+                lap_row_top2(C + (size_t)i * n, price, n, lane, v1, j1, v2);
+                if (lane == 0) {
+                    if (!(v2 < INFINITY)) v2 = v1;                  // n == 1
+                    const double bid = price[j1] + (v2 - v1) + eps;
+                    pbobj[i] = j1; pbval[i] = bid;
+                    atomicMax(&bidval[j1], lap_key(bid));
+                }
+            }
+            __syncthreads();
+            for (int u = tid; u < nu; u += LAP_BS) {
+                const int i = ulist[u], j = pbobj[i];
+                if (lap_key(pbval[i]) == bidval[j]) atomicMin(&bidder[j], i);
+            }
+            __syncthreads();
+            for (int j = tid; j < n; j += LAP_BS) {
+                const int w = bidder[j];
+                if (w != 0x7fffffff) {
+                    const int prev = owner[j];
+                    if (prev >= 0) assigned[prev] = -1;
+                    owner[j] = w; assigned[w] = j;
+                    price[j] = __longlong_as_double((long long)bidval[j]);
+                    bidder[j] = 0x7fffffff;
+                }
+                bidval[j] = 0ull;
+            }
+            __syncthreads();
+        }
+        if (eps <= eps_final) break;
+        __syncthreads();
+    }
+
+    // ---- certificate: potentials d (start: the prices) such that every assigned column is an exact arg-min
+    double *d = price;
+    const double tol = mx * 1e-13;
+    int certified = 0;
+    for (int round = 0; round < a.max_rounds_cert; ++round) {
+        if (tid == 0) s_flag = 0;
+        __syncthreads();
+        // Jacobi round: m_i = min_k (c_ik + d_k) with the old d; new d_sigma(i) = m_i - c_i,sigma(i)
+        for (int i = wv; i < n; i += NW) {
+            double v1, v2;
+            int j1;
+            lap_row_top2(C + (size_t)i * n, d, n, lane, v1, j1, v2);
+            if (lane == 0) {
+                const int j = assigned[i];
+                const double cur = (double)C[(size_t)i * n + j] + d[j];
+                pbval[i] = (cur - v1 > tol) ? v1 - (double)C[(size_t)i * n + j] : d[j];
+                if (cur - v1 > tol) s_flag = 1;
+            }
+        }
+        __syncthreads();
+        const int changed = s_flag;
+        for (int i = tid; i < n; i += LAP_BS) d[assigned[i]] = pbval[i];
+        __syncthreads();
+        if (!changed) { certified = 1; break; }
+    }
+    for (int i = tid; i < n; i += LAP_BS) a.col4row[(size_t)b * n + i] = assigned[i];
+    if (a.price_out)
+        for (int j = tid; j < n; j += LAP_BS) a.price_out[(size_t)b * n + j] = d[j];
+    if (tid == 0) a.certified[b] = certified;
+}
+
+extern "C" size_t reart_lap_workspace_bytes(int B, int n) {
+    if (B < 0 || n < 1 || n > LAP_NMAX) return 0;
+    return reart_align_up(sizeof(double) * (size_t)B * n, 256);
+}
+
+// cost [B,n,n] fp32 (row-major: rows = sources), n <= 2048.  col4row [B,n] i32: column assigned to each row
+// (minimum total cost); certified [B] i32: 1 when the dual certificate closed (the assignment is optimal),
+// 0 when the caller must solve that matrix on the host.
+extern "C" int reart_lap_auction(const float *cost, int B, int n, int32_t *col4row, int32_t *certified, void *workspace,
+                                 size_t workspace_bytes, void *stream) {
+    if (B < 0 || n < 1 || n > LAP_NMAX) return REART_ERR_INVALID_ARG;
+    if (B == 0) return REART_OK;
+    if (!cost || !col4row || !certified) return REART_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < reart_lap_workspace_bytes(B, n)) return REART_ERR_INVALID_ARG;
+    LapArgs a = {};
+    a.cost = cost; a.B = B; a.n = n; a.col4row = col4row; a.certified = certified; a.price_out = (double *)workspace;
+    a.max_rounds_cert = 4 * n;
+    const size_t lds = (size_t)n * (3 * 8 + 5 * 4);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)lap_auction_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)
+            return REART_ERR_LAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(lap_auction_kernel, dim3(B), dim3(LAP_BS), lds, (hipStream_t)stream, a);
+    REART_CHECK_LAUNCH();
+    return REART_OK;
+}

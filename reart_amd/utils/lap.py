@@ -1,0 +1,39 @@
+"""Batched linear assignment for the assignment loss (reference run_robot.py:164-187,
+utils/model_utils.py:85-103): ``[linear_sum_assignment(c) for c in cost]`` / ``parallel_lap(cost, nproc)``
+on the GPU (``reart_lap_auction``: epsilon-scaling auction + exact dual certificate).  A matrix whose
+certificate does not close is solved with scipy on the host, so the result is always an optimal assignment."""
+import numpy as np
+import torch
+
+from .. import _lib
+
+
+def linear_sum_assignment_batch(cost, return_stats=False):
+    """cost [B,n,n] float32 CUDA tensor (square) -> list of (row_ind, col_ind) int64 numpy arrays, like
+    ``[scipy.optimize.linear_sum_assignment(c) for c in cost]`` (rows in ascending order)."""
+    _lib.require_gpu(cost)
+    if cost.dim() != 3 or cost.shape[1] != cost.shape[2]:
+        raise ValueError("linear_sum_assignment_batch expects square matrices [B,n,n]")
+    cost = cost.detach().float().contiguous()
+    B, n, _ = cost.shape
+    L = _lib.lib()
+    col = torch.empty((B, n), dtype=torch.int32, device=cost.device)
+    cert = torch.empty((B,), dtype=torch.int32, device=cost.device)
+    nbytes = L.reart_lap_workspace_bytes(B, n)
+    if nbytes == 0:
+        raise ValueError("linear_sum_assignment_batch: n must be in 1..2048")
+    ws = _lib.workspace(nbytes, cost.device)
+    rc = L.reart_lap_auction(_lib.ptr(cost), B, n, _lib.ptr(col), _lib.ptr(cert), _lib.ptr(ws), ws.numel(), _lib.stream())
+    _lib.check(rc, "reart_lap_auction")
+    col_h, cert_h = col.cpu().numpy().astype(np.int64), cert.cpu().numpy()
+    rows = np.arange(n, dtype=np.int64)
+    out, fallbacks = [], 0
+    for b in range(B):
+        if cert_h[b]:
+            out.append((rows, col_h[b]))
+        else:  # certificate did not close: exact host solve for this matrix
+            from scipy.optimize import linear_sum_assignment
+
+            fallbacks += 1
+            out.append(linear_sum_assignment(cost[b].cpu().numpy()))
+    return (out, fallbacks) if return_stats else out

@@ -1,0 +1,55 @@
+"""GPU linear assignment (reart_lap_auction) against scipy.optimize.linear_sum_assignment, the solver the
+reference calls (run_robot.py:172-176): same optimal cost, and the same permutation when the optimum is unique."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _compare(cost_np, dev, expect_same_perm=True):
+    from scipy.optimize import linear_sum_assignment
+
+    from reart_amd.utils.lap import linear_sum_assignment_batch
+
+    out, fallbacks = linear_sum_assignment_batch(torch.from_numpy(cost_np).to(dev), return_stats=True)
+    for b, (r, c) in enumerate(out):
+        rr, cc = linear_sum_assignment(cost_np[b])
+        assert sorted(c.tolist()) == list(range(cost_np.shape[1]))                    # a permutation
+        ours = cost_np[b][r, c].astype(np.float64).sum()
+        ref = cost_np[b][rr, cc].astype(np.float64).sum()
+        assert abs(ours - ref) <= 1e-9 * max(1.0, abs(ref)), (b, ours, ref)
+        if expect_same_perm:
+            np.testing.assert_array_equal(c, cc)
+    return fallbacks
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 64, 300, 1024])
+def test_lap_random_matrices(dev, n):
+    rng = np.random.default_rng(n)
+    cost = rng.uniform(0.0, 1.0, (3, n, n)).astype(np.float32)
+    _compare(cost, dev)
+
+
+def test_lap_point_cloud_costs(dev):
+    """The loop's matrices: Euclidean distances between two FPS subsets of nearly the same cloud."""
+    from reart_amd.synthetic import make_sequence
+
+    seq = make_sequence(T=4, n_parts=4, pts_per_part=256, seed=9, with_flow=False)
+    pts = torch.from_numpy(seq["complete"]).float()
+    rng = np.random.default_rng(0)
+    src = pts[:3, rng.permutation(1024)[:512]]
+    tgt = pts[1:4, rng.permutation(1024)[:512]]
+    cost = torch.cdist(src, tgt).numpy().astype(np.float32)
+    fb = _compare(cost, dev)
+    assert fb == 0      # the certificate closes on the loop's kind of matrices
+
+
+def test_lap_ties(dev):
+    """Duplicated rows / columns: many optimal assignments; the cost must still be the optimum."""
+    rng = np.random.default_rng(3)
+    base = rng.uniform(0, 1, (1, 40, 40)).astype(np.float32)
+    cost = np.concatenate([base, base], axis=1)           # 80 x 40 -> make square by duplicating columns too
+    cost = np.concatenate([cost, cost], axis=2)
+    _compare(cost, dev, expect_same_perm=False)
+    _compare(np.zeros((2, 17, 17), np.float32), dev, expect_same_perm=False)
