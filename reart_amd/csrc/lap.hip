@@ -30,6 +30,8 @@ struct LapArgs {
     int *certified;        // [B]
     double *price_out;     // [B][n] final potentials (workspace)
     int max_rounds_cert;
+    int *stats;            // nullable [B][4]: phases, auction rounds, bids, certificate rounds
+    double eps0, theta_inv, eps_final;   // first epsilon and final epsilon as fractions of the largest cost, 1 / scaling factor
 };
 
 __device__ __forceinline__ unsigned long long lap_key(double v) { return (unsigned long long)__double_as_longlong(v); }  // v >= 0
@@ -38,10 +40,19 @@ __device__ __forceinline__ unsigned long long lap_key(double v) { return (unsign
 __device__ __forceinline__ void lap_row_top2(const float *__restrict__ row, const double *__restrict__ p, int n, int lane,
                                              double &v1, int &j1, double &v2) {
     v1 = INFINITY; v2 = INFINITY; j1 = 0x7fffffff;
-    for (int j = lane; j < n; j += 64) {
-        const double v = (double)row[j] + p[j];
-        if (v < v1) { v2 = v1; v1 = v; j1 = j; }
-        else if (v < v2) v2 = v;
+    for (int j0 = lane; j0 < n; j0 += 64 * 8) {     // 8 loads in flight per lane: the scan is a dependent global read
+        float r[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) r[u] = row[j0 + 64 * u < n ? j0 + 64 * u : lane];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = j0 + 64 * u;
+            if (j < n) {
+                const double v = (double)r[u] + p[j];
+                if (v < v1) { v2 = v1; v1 = v; j1 = j; }
+                else if (v < v2) v2 = v;
+            }
+        }
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
@@ -82,11 +93,27 @@ __global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
     mx = 0.0;
     for (int w = 0; w < NW; ++w) mx = fmax(mx, s_red[w]);
     if (!(mx > 0.0)) mx = 1.0;
-    const double eps_final = mx * 1e-11;
+    const double eps_final = mx * a.eps_final;
 
-    for (double eps = mx * 0.125; ; eps = fmax(eps * (1.0 / 6.0), eps_final)) {
-        // a phase starts with every row unassigned (prices are kept)
-        for (int j = tid; j < n; j += LAP_BS) { owner[j] = -1; assigned[j] = -1; }
+    int st_phases = 0, st_rounds = 0, st_bids = 0, st_cert = 0;
+    for (double eps = mx * a.eps0; ; eps = fmax(eps * a.theta_inv, eps_final)) {
+        ++st_phases;
+        // a phase keeps the prices and every pair that already satisfies the new, tighter epsilon-complementary
+        // slackness  c_i,s(i) + p_s(i) <= min_k (c_ik + p_k) + eps ; the other rows are released and bid again
+        if (st_phases > 1) {
+            for (int i = wv; i < n; i += NW) {
+                double v1, v2;
+                int j1;
+                lap_row_top2(C + (size_t)i * n, price, n, lane, v1, j1, v2);
+                if (lane == 0) {
+                    const int j = assigned[i];
+                    if ((double)C[(size_t)i * n + j] + price[j] > v1 + eps) pbobj[i] = -1; else pbobj[i] = j;
+                }
+            }
+            __syncthreads();
+            for (int i = tid; i < n; i += LAP_BS)
+                if (pbobj[i] < 0) { owner[assigned[i]] = -1; assigned[i] = -1; }
+        }
         __syncthreads();
         for (;;) {
             if (tid == 0) s_cnt = 0;
@@ -96,6 +123,32 @@ __global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
             __syncthreads();
             const int nu = s_cnt;
             if (nu == 0) break;
+            ++st_rounds; st_bids += nu;
+            if (nu == 1) {
+                // a single bidder: no conflicts are possible, so wave 0 follows the chain (the row bids, takes the
+                // column, the displaced owner bids next, ...) without workgroup barriers until nobody is displaced.
+                // The end of a phase is mostly such chains: thousands of one-bid rounds of four barriers each otherwise.
+                if (wv == 0) {
+                    int i = ulist[0];
+                    for (;;) {
+                        double v1, v2;
+                        int j1;
+                        lap_row_top2(C + (size_t)i * n, price, n, lane, v1, j1, v2);
+                        if (!(v2 < INFINITY)) v2 = v1;
+                        const int prev = owner[j1];
+                        if (lane == 0) {
+                            price[j1] = price[j1] + (v2 - v1) + eps;
+                            owner[j1] = i; assigned[i] = j1;
+                            if (prev >= 0) assigned[prev] = -1;
+                        }
+                        ++st_bids;
+                        if (prev < 0) break;
+                        i = prev;
+                    }
+                }
+                __syncthreads();
+                continue;
+            }
             // bids: one wave per unassigned row
             for (int u = wv; u < nu; u += NW) {
                 const int i = ulist[u];
@@ -138,6 +191,7 @@ __global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
     int certified = 0;
     for (int round = 0; round < a.max_rounds_cert; ++round) {
         if (tid == 0) s_flag = 0;
+        ++st_cert;
         __syncthreads();
         // Jacobi round: m_i = min_k (c_ik + d_k) with the old d; new d_sigma(i) = m_i - c_i,sigma(i)
         for (int i = wv; i < n; i += NW) {
@@ -161,11 +215,12 @@ __global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
     if (a.price_out)
         for (int j = tid; j < n; j += LAP_BS) a.price_out[(size_t)b * n + j] = d[j];
     if (tid == 0) a.certified[b] = certified;
+    if (tid == 0 && a.stats) { int *o = a.stats + 4 * b; o[0] = st_phases; o[1] = st_rounds; o[2] = st_bids; o[3] = st_cert; }
 }
 
 extern "C" size_t reart_lap_workspace_bytes(int B, int n) {
     if (B < 0 || n < 1 || n > LAP_NMAX) return 0;
-    return reart_align_up(sizeof(double) * (size_t)B * n, 256);
+    return reart_align_up(sizeof(double) * (size_t)B * n, 256) + reart_align_up(sizeof(int) * 4 * (size_t)B, 256);
 }
 
 // cost [B,n,n] fp32 (row-major: rows = sources), n <= 2048.  col4row [B,n] i32: column assigned to each row
@@ -180,6 +235,13 @@ extern "C" int reart_lap_auction(const float *cost, int B, int n, int32_t *col4r
     LapArgs a = {};
     a.cost = cost; a.B = B; a.n = n; a.col4row = col4row; a.certified = certified; a.price_out = (double *)workspace;
     a.max_rounds_cert = 4 * n;
+    {   // tuning knobs (defaults measured on the loop's matrices)
+        const char *e0 = getenv("REART_LAP_EPS0"), *th = getenv("REART_LAP_THETA"), *ef = getenv("REART_LAP_EPSF");
+        a.eps0 = e0 ? atof(e0) : 0.125;
+        a.theta_inv = 1.0 / (th ? atof(th) : 6.0);
+        a.eps_final = ef ? atof(ef) : 1e-11;
+    }
+    a.stats = (int *)((char *)workspace + reart_align_up(sizeof(double) * (size_t)B * n, 256));   // diagnostics, after the potentials
     const size_t lds = (size_t)n * (3 * 8 + 5 * 4);
     static bool attr_set = false;
     if (!attr_set) {

@@ -9,8 +9,9 @@ What is built: the loop itself.
     per iteration replayed from a graph, no host sync inside the loop.
   * everything else (assignment loss, ``--model kinematic``): the reference's own loop structure with
     the HIP operators underneath (``BaseModel`` / ``KinematicModel``, ``ChamferDistance``,
-    ``blend_anchor_motion``, ``flow_loss``, FPS) and ``torch.optim.Adam``; the Hungarian step stays on
-    the host exactly like the reference (``run_robot.py:172-176``; SURVEY.md 8f-2 "next").
+    ``blend_anchor_motion``, ``flow_loss``, FPS) and ``torch.optim.Adam``; the linear assignment of the
+    reference (``run_robot.py:172-176``, scipy on a process pool) runs on the GPU (``reart_lap_auction``:
+    auction + exact dual certificate, host fallback for an uncertified matrix).
 What is NOT built (SURVEY.md section 8 out of scope): visualisation, GT-graph evaluation, structure
 extraction (merging / MST / ik) and ``result.txt``; a snapshot prints the losses and the Chamfer error.
 
@@ -152,7 +153,7 @@ def main(args):
             snapshot(i - 1, {"recon Loss": row[0], "flow Loss": row[1], "total Loss": row[2]})
     # ---- phase 2: the reference's loop with HIP operators (assignment loss / kinematic model)
     if i < n_iter and not args.evaluate:
-        from scipy.optimize import linear_sum_assignment
+        from reart_amd.utils.lap import linear_sum_assignment_batch
 
         if args.model == "base":
             seg_params = [p for p in model.seg_head.parameters() if p.requires_grad]
@@ -174,7 +175,9 @@ def main(args):
                     tgt_idx = farthest_point_sample(pc_list, num_fps)
                     with torch.no_grad():
                         cost = torch.cdist(index_points(pc_trans_list, src_idx), index_points(pc_list, tgt_idx))
-                    assign = [linear_sum_assignment(c) for c in cost.cpu().numpy()]
+                    # GPU auction + exact dual certificate; an uncertified matrix falls back to scipy on the host,
+                    # so this is always the optimum the reference's linear_sum_assignment / parallel_lap returns
+                    assign = linear_sum_assignment_batch(cost)
                 pc_src, pc_tgt = index_points(pc_trans_list, src_idx), index_points(pc_list, tgt_idx)
                 rows = torch.cat([torch.as_tensor(r) for r, _ in assign]).to(device)
                 cols = torch.cat([torch.as_tensor(c) for _, c in assign]).to(device)

@@ -36,4 +36,8 @@ def linear_sum_assignment_batch(cost, return_stats=False):
 
             fallbacks += 1
             out.append(linear_sum_assignment(cost[b].cpu().numpy()))
+    if return_stats == "full":   # per matrix: phases, auction rounds, bids, certificate rounds
+        off = ((8 * B * n + 255) // 256) * 256
+        st = ws[off:off + 16 * B].view(torch.int32).reshape(B, 4).cpu().numpy()
+        return out, fallbacks, st
     return (out, fallbacks) if return_stats else out

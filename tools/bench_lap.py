@@ -24,6 +24,8 @@ for n in (1024, 2048):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     out, fb = linear_sum_assignment_batch(cost, return_stats=True)
     torch.cuda.synchronize(); t_gpu = time.perf_counter() - t0
+    _, _, st = linear_sum_assignment_batch(cost, return_stats="full")
+    print("   per matrix (mean): phases %.0f, auction rounds %.0f, bids %.0f, certificate rounds %.0f" % tuple(st.mean(0)), " max rounds", st[:, 1].max(), "max cert", st[:, 3].max())
     ch = cost.cpu().numpy()
     t0 = time.perf_counter(); ref = [linear_sum_assignment(c) for c in ch]; t_cpu = time.perf_counter() - t0
     t0 = time.perf_counter()
