@@ -364,10 +364,14 @@ int reart_knn_points_idx_warm(const float *p1, const float *p2, int N, int P1, i
  *   cost [B,n,n] fp32, n <= 2048; col4row [B,n] i32 = column assigned to row i (minimum total cost).
  * epsilon-scaling auction + an exact dual certificate in fp64: certified[b] = 1 means the assignment of matrix
  * b is optimal (equal to scipy's whenever the optimum is unique); certified[b] = 0 means the certificate
- * did not close and the caller must solve that matrix with the host solver (the Python wrapper does). */
+ * did not close and the caller must solve that matrix with the host solver (the Python wrapper does).
+ * price_in (nullable, [B,n] f64): column potentials returned by an earlier call on a similar batch (the loop
+ * re-solves slowly moving matrices every assign_gap iterations): warm start; price_out (nullable, [B,n] f64)
+ * receives the potentials of this batch (may alias price_in). */
 size_t reart_lap_workspace_bytes(int B, int n);
-int reart_lap_auction(const float *cost, int B, int n, int32_t *col4row, int32_t *certified, void *workspace,
-                      size_t workspace_bytes, void *stream);
+int reart_lap_auction(const float *cost, int B, int n, int32_t *col4row, int32_t *certified,
+                      const double *price_in, double *price_out, void *workspace, size_t workspace_bytes,
+                      void *stream);
 
 /* ------------------------------------------------------------------------ */
 /* Correspondence matching on the extractor's descriptors                    */

@@ -32,6 +32,7 @@ struct LapArgs {
     int max_rounds_cert;
     int *stats;            // nullable [B][4]: phases, auction rounds, bids, certificate rounds
     double eps0, theta_inv, eps_final;   // first epsilon and final epsilon as fractions of the largest cost, 1 / scaling factor
+    const double *price_in; // nullable [B][n]: potentials of an earlier, similar problem (warm start)
 };
 
 __device__ __forceinline__ unsigned long long lap_key(double v) { return (unsigned long long)__double_as_longlong(v); }  // v >= 0
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
     int *pbobj = bidder + n;                                        // [n] row's bid column
     int *ulist = pbobj + n;                                         // [n] unassigned rows
     __shared__ int s_cnt, s_flag;
-    __shared__ double s_red[NW];
+    __shared__ double s_red[NW], s_red2[NW];
     const float *C = a.cost + (size_t)b * n * n;
 
     // largest cost
@@ -88,7 +89,25 @@ __global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
     if (lane == 0) s_red[wv] = mx;
-    for (int j = tid; j < n; j += LAP_BS) { price[j] = 0.0; owner[j] = -1; assigned[j] = -1; bidval[j] = 0ull; bidder[j] = 0x7fffffff; }
+    // warm start: potentials of an earlier problem, shifted to be non-negative (bids are ordered as unsigned keys)
+    double pmin = 0.0;
+    if (a.price_in) {
+        pmin = INFINITY;
+        for (int j = tid; j < n; j += LAP_BS) pmin = fmin(pmin, a.price_in[(size_t)b * n + j]);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) pmin = fmin(pmin, __shfl_xor(pmin, o, 64));
+        if (lane == 0) s_red2[wv] = pmin;
+    }
+    __syncthreads();
+    if (a.price_in) {
+        pmin = INFINITY;
+        for (int w = 0; w < NW; ++w) pmin = fmin(pmin, s_red2[w]);
+    }
+    __syncthreads();
+    for (int j = tid; j < n; j += LAP_BS) {
+        price[j] = a.price_in ? a.price_in[(size_t)b * n + j] - pmin : 0.0;
+        owner[j] = -1; assigned[j] = -1; bidval[j] = 0ull; bidder[j] = 0x7fffffff;
+    }
     __syncthreads();
     mx = 0.0;
     for (int w = 0; w < NW; ++w) mx = fmax(mx, s_red[w]);
@@ -225,19 +244,24 @@ extern "C" size_t reart_lap_workspace_bytes(int B, int n) {
 
 // cost [B,n,n] fp32 (row-major: rows = sources), n <= 2048.  col4row [B,n] i32: column assigned to each row
 // (minimum total cost); certified [B] i32: 1 when the dual certificate closed (the assignment is optimal),
-// 0 when the caller must solve that matrix on the host.
-extern "C" int reart_lap_auction(const float *cost, int B, int n, int32_t *col4row, int32_t *certified, void *workspace,
-                                 size_t workspace_bytes, void *stream) {
+// 0 when the caller must solve that matrix on the host.  price_in (nullable, [B,n] f64): potentials returned for
+// an earlier, similar batch (the loop re-solves slowly moving matrices) -- the auction then starts from them
+// with a small epsilon; price_out (nullable, [B,n] f64) receives this batch's potentials (may alias price_in).
+extern "C" int reart_lap_auction(const float *cost, int B, int n, int32_t *col4row, int32_t *certified,
+                                 const double *price_in, double *price_out, void *workspace, size_t workspace_bytes,
+                                 void *stream) {
     if (B < 0 || n < 1 || n > LAP_NMAX) return REART_ERR_INVALID_ARG;
     if (B == 0) return REART_OK;
     if (!cost || !col4row || !certified) return REART_ERR_INVALID_ARG;
     if (!workspace || workspace_bytes < reart_lap_workspace_bytes(B, n)) return REART_ERR_INVALID_ARG;
     LapArgs a = {};
-    a.cost = cost; a.B = B; a.n = n; a.col4row = col4row; a.certified = certified; a.price_out = (double *)workspace;
+    a.cost = cost; a.B = B; a.n = n; a.col4row = col4row; a.certified = certified;
+    a.price_out = price_out ? price_out : (double *)workspace; a.price_in = price_in;
     a.max_rounds_cert = 4 * n;
     {   // tuning knobs (defaults measured on the loop's matrices)
         const char *e0 = getenv("REART_LAP_EPS0"), *th = getenv("REART_LAP_THETA"), *ef = getenv("REART_LAP_EPSF");
-        a.eps0 = e0 ? atof(e0) : 0.125;
+        const char *ew = getenv("REART_LAP_EPS0_WARM");
+        a.eps0 = price_in ? (ew ? atof(ew) : 1e-3) : (e0 ? atof(e0) : 0.125);
         a.theta_inv = 1.0 / (th ? atof(th) : 6.0);
         a.eps_final = ef ? atof(ef) : 1e-11;
     }

@@ -163,7 +163,7 @@ def main(args):
         else:
             optimizer = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=args.trans_lr,
                                          weight_decay=args.weight_decay)
-        assign = None
+        assign, lap_state = None, {}   # lap_state: potentials of the previous solve (warm start of the next)
         while i < n_iter:
             kwargs = {"tau": tau_func(cur_iter=i + 1)} if args.model == "base" else {}
             pc_trans_list, seg_part, trans_list = model(cano_pc, **kwargs)
@@ -177,7 +177,7 @@ def main(args):
                         cost = torch.cdist(index_points(pc_trans_list, src_idx), index_points(pc_list, tgt_idx))
                     # GPU auction + exact dual certificate; an uncertified matrix falls back to scipy on the host,
                     # so this is always the optimum the reference's linear_sum_assignment / parallel_lap returns
-                    assign = linear_sum_assignment_batch(cost)
+                    assign = linear_sum_assignment_batch(cost, state=lap_state)
                 pc_src, pc_tgt = index_points(pc_trans_list, src_idx), index_points(pc_list, tgt_idx)
                 rows = torch.cat([torch.as_tensor(r) for r, _ in assign]).to(device)
                 cols = torch.cat([torch.as_tensor(c) for _, c in assign]).to(device)

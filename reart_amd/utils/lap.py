@@ -8,9 +8,11 @@ import torch
 from .. import _lib
 
 
-def linear_sum_assignment_batch(cost, return_stats=False):
+def linear_sum_assignment_batch(cost, return_stats=False, state=None):
     """cost [B,n,n] float32 CUDA tensor (square) -> list of (row_ind, col_ind) int64 numpy arrays, like
-    ``[scipy.optimize.linear_sum_assignment(c) for c in cost]`` (rows in ascending order)."""
+    ``[scipy.optimize.linear_sum_assignment(c) for c in cost]`` (rows in ascending order).
+    ``state``: a dict kept by the caller between calls on slowly changing matrices (the loop re-solves every
+    ``assign_gap`` iterations); it carries the column potentials of the previous solve as a warm start."""
     _lib.require_gpu(cost)
     if cost.dim() != 3 or cost.shape[1] != cost.shape[2]:
         raise ValueError("linear_sum_assignment_batch expects square matrices [B,n,n]")
@@ -23,7 +25,16 @@ def linear_sum_assignment_batch(cost, return_stats=False):
     if nbytes == 0:
         raise ValueError("linear_sum_assignment_batch: n must be in 1..2048")
     ws = _lib.workspace(nbytes, cost.device)
-    rc = L.reart_lap_auction(_lib.ptr(cost), B, n, _lib.ptr(col), _lib.ptr(cert), _lib.ptr(ws), ws.numel(), _lib.stream())
+    prices = None
+    if state is not None:
+        prices = state.get("prices")
+        warm = prices is not None and tuple(prices.shape) == (B, n) and prices.device == cost.device
+        if not warm:
+            prices = torch.empty((B, n), dtype=torch.float64, device=cost.device)
+        state["prices"] = prices
+    rc = L.reart_lap_auction(_lib.ptr(cost), B, n, _lib.ptr(col), _lib.ptr(cert),
+                             _lib.ptr(prices) if (state is not None and warm) else None,
+                             _lib.ptr(prices) if state is not None else None, _lib.ptr(ws), ws.numel(), _lib.stream())
     _lib.check(rc, "reart_lap_auction")
     col_h, cert_h = col.cpu().numpy().astype(np.int64), cert.cpu().numpy()
     rows = np.arange(n, dtype=np.int64)

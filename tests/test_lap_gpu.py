@@ -53,3 +53,23 @@ def test_lap_ties(dev):
     cost = np.concatenate([cost, cost], axis=2)
     _compare(cost, dev, expect_same_perm=False)
     _compare(np.zeros((2, 17, 17), np.float32), dev, expect_same_perm=False)
+
+
+def test_lap_warm_start_same_result(dev):
+    """Potentials of an earlier solve as a warm start: the result stays the optimum, for the same and for a
+    perturbed batch."""
+    from scipy.optimize import linear_sum_assignment
+
+    from reart_amd.utils.lap import linear_sum_assignment_batch
+
+    rng = np.random.default_rng(11)
+    pts = rng.uniform(-1, 1, (2, 256, 3)).astype(np.float32)
+    state = {}
+    for k in range(3):
+        moved = pts + rng.normal(0, 0.01 * k, pts.shape).astype(np.float32)
+        cost = torch.cdist(torch.from_numpy(moved), torch.from_numpy(pts[::-1].copy())).numpy().astype(np.float32)
+        out = linear_sum_assignment_batch(torch.from_numpy(cost).to(dev), state=state)
+        for b, (r, c) in enumerate(out):
+            rr, cc = linear_sum_assignment(cost[b])
+            np.testing.assert_array_equal(c, cc)
+    assert state["prices"].shape == (2, 256)
