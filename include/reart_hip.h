@@ -194,6 +194,10 @@ typedef struct reart_relax_config {
                              /*    references); 0: brute force everywhere (same results)   */
     int use_boxes;           /* 1: bounding-box block-skip test in the brute-force searches */
                              /*    (exact; pays off when the clouds are stored in Morton order) */
+    int use_assign;          /* 1: the assignment loss replaces the Chamfer loss (run_robot.py:164-187, */
+                             /*    i >= assign_iter): lambda_assign * sum |x_src - y_assigned|^2 over   */
+                             /*    the pairs of `assign_map`                                            */
+    float lambda_assign;     /* --lambda_assign                                           */
 } reart_relax_config;
 
 typedef struct reart_relax_buffers {
@@ -215,11 +219,20 @@ typedef struct reart_relax_buffers {
     /* optional fork/join: with all three set, the flow branch (K=3 search + blend) runs on      */
     /* aux_stream concurrently with the Chamfer search; the hipEvent_t's are caller-owned.       */
     void *aux_stream, *ev_fork, *ev_join;
+    /* use_assign: [B,N] int32, assign_map[b][i] = index into pc_list[b] of the point assigned to     */
+    /* pc_trans[b][i], or -1 when point i is not among the sampled sources (the caller refreshes it   */
+    /* every assign_gap iterations from FPS + linear assignment, run_robot.py:165-178)                */
+    const int *assign_map;
 } reart_relax_buffers;
 
 size_t reart_relax_workspace_bytes(const reart_relax_config *cfg);
 /* once per problem: static SoA images of pc_list / reference sets, tau(iter) */
 int reart_relax_prepare(const reart_relax_config *cfg, const reart_relax_buffers *bufs,
+                        void *workspace, size_t workspace_bytes, void *stream);
+/* forward only, for the CURRENT iteration (same temperature and Gumbel noise the next reart_relax_step
+ * will use): fills pc_trans / seg_part / trans_list and changes nothing else.  The assignment loss needs
+ * the transformed clouds of iteration i to compute the assignment used in iteration i. */
+int reart_relax_forward(const reart_relax_config *cfg, const reart_relax_buffers *bufs,
                         void *workspace, size_t workspace_bytes, void *stream);
 /* enqueue one iteration (5 launches in the default configuration, no host sync) */
 int reart_relax_step(const reart_relax_config *cfg, const reart_relax_buffers *bufs,

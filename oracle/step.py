@@ -29,7 +29,9 @@ class RelaxOracle:
         self.n_iter, self.start_tau, self.end_tau, self.euclidean = n_iter, start_tau, end_tau, euclidean
         self.it = 0
 
-    def step(self, gumbel, tau=None):
+    def step(self, gumbel, tau=None, assign=None):
+        """assign = (src_idx [n], tgt_idx [B,n], lambda_assign): the assignment loss of run_robot.py:181-184
+        replaces the Chamfer loss (pairs fixed by the caller)."""
         p = self.params
         if tau is None:
             tau = tau_cosine(self.it + 1, self.n_iter, self.end_tau, self.start_tau)
@@ -37,14 +39,25 @@ class RelaxOracle:
         fw = base_forward(self.cano, p["W1"], p["b1"], p["W2"], p["p6d"], p["pt"], gumbel, tau)
         X, Y = fw["out"], self.pc_list
         B, N = X.shape[:2]
-        # recon_loss (networks/loss.py:24-29) and its gradient w.r.t. pc_trans
-        d1, i1 = knn_points(X, Y)
-        d2, i2 = knn_points(Y, X)
-        recon = float((d1[..., 0] + d2[..., 0]).astype(np.float64).sum())
-        ones = np.ones((B, N, 1), np.float32)
-        gx1, _ = knn_points_backward(X, Y, i1, ones)
-        _, gx2 = knn_points_backward(Y, X, i2, ones)
-        G = gx1 + gx2
+        if assign is not None:
+            src, tgt, lam = assign
+            lam = np.float32(lam)
+            G = np.zeros_like(X)
+            recon = 0.0
+            for b_ in range(B):
+                d = X[b_, src] - Y[b_, tgt[b_]]
+                recon += float(((d * d)[:, 0] + (d * d)[:, 1] + (d * d)[:, 2]).astype(np.float64).sum())
+                G[b_, src] = lam * (np.float32(2.0) * d)
+            recon *= float(lam)
+        else:
+            # recon_loss (networks/loss.py:24-29) and its gradient w.r.t. pc_trans
+            d1, i1 = knn_points(X, Y)
+            d2, i2 = knn_points(Y, X)
+            recon = float((d1[..., 0] + d2[..., 0]).astype(np.float64).sum())
+            ones = np.ones((B, N, 1), np.float32)
+            gx1, _ = knn_points_backward(X, Y, i1, ones)
+            _, gx2 = knn_points_backward(Y, X, i2, ones)
+            G = gx1 + gx2
         flow = 0.0
         if self.refs is not None:
             # run_robot.py:194-209

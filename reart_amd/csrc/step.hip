@@ -616,6 +616,48 @@ __global__ __launch_bounds__(CG_BS) void post_kernel(PostArgs a) {
     else order_body(a.od, w - a.nwork);
 }
 
+// ------------------------------------------------------------------------------ assignment loss
+// run_robot.py:181-184 for fixed assignments: loss = lambda * sum_b sum_r |x[b,src_r] - y[b,tgt_(b,r)]|^2 and its
+// gradient w.r.t. pc_trans (zero for the points that are not among the sampled sources)
+struct AssignArgs {
+    const float *X, *Y;      // pc_trans, pc_list [B,N,3]
+    const int *map;          // [B,N] index into Y[b] or -1
+    int N, B;
+    float lambda;
+    float *G;                // [B,N,3]
+    double *loss_part;       // [B][gridDim.x]
+};
+__global__ __launch_bounds__(CG_BS) void assign_grad_kernel(AssignArgs a) {
+    __shared__ double s_red[CG_BS / REART_WAVE];
+    const int b = blockIdx.y, i = blockIdx.x * CG_BS + threadIdx.x, tid = threadIdx.x;
+    double term = 0.0;
+    if (i < a.N) {
+        const size_t o = (size_t)b * a.N + i;
+        const int m = a.map[o];
+        float g[3] = {0.f, 0.f, 0.f};
+        if (m >= 0 && m < a.N) {
+            float sq = 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float d = a.X[3 * o + k] - a.Y[3 * ((size_t)b * a.N + m) + k];
+                sq += d * d;
+                g[k] = a.lambda * (2.0f * d);
+            }
+            term = (double)sq;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) a.G[3 * o + k] = g[k];
+    }
+    term = reart_wave_sum_d(term);
+    if ((tid & 63) == 0) s_red[tid >> 6] = term;
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0.0;
+        for (int w = 0; w < CG_BS / REART_WAVE; ++w) t += s_red[w];
+        a.loss_part[(size_t)b * gridDim.x + blockIdx.x] = t * (double)a.lambda;
+    }
+}
+
 // ------------------------------------------------------------------------------ the step
 #define MARK(k) do { if (ev) (void)hipEventRecord(ev[k], st); } while (0)
 
@@ -623,7 +665,7 @@ __global__ __launch_bounds__(CG_BS) void post_kernel(PostArgs a) {
 // `search_reps` times between ev[0] and ev[1] (its inputs do not change between repetitions), nothing else.
 static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buffers *bufs,
                            void *workspace, size_t workspace_bytes, void *stream, hipEvent_t *ev,
-                           int search_reps = 0) {
+                           int search_reps = 0, bool forward_only = false) {
     StepPlan p;
     if (!cfg || !bufs) return REART_ERR_INVALID_ARG;
     int rc = step_plan(cfg, &p);
@@ -652,6 +694,8 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
     rc = reart_base_forward_ex(fa, st);
     if (rc != REART_OK) return rc;
     if (!search_reps) MARK(1);
+    if (forward_only) return REART_OK;
+    if (c.use_assign && !bufs->assign_map) return REART_ERR_INVALID_ARG;
 
     // Fork: the flow branch depends only on the forward output, like the Chamfer search; with an
     // auxiliary stream it runs concurrently (its latency-bound blend then hides under the search).
@@ -659,7 +703,8 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
     // fork / join).  Otherwise (brute force / grid / per-lane variants): separate launches, the flow
     // branch on the auxiliary stream when the caller provides one.  The timed variant is always separate.
     const char *mg = getenv("REART_MERGE");
-    const bool merged = c.use_flow && (p.pruned == 1 || p.pruned == 3) && !c.use_grid && !(mg && mg[0] == '0');
+    const bool merged = c.use_flow && (p.pruned == 1 || p.pruned == 3) && !c.use_grid && !(mg && mg[0] == '0') &&
+                        !c.use_assign;   // assignment loss: flow search and blend as separate launches, no Chamfer search
     const bool forked = !merged && !ev && bufs->aux_stream && bufs->ev_fork && bufs->ev_join && c.use_flow;
     hipStream_t fst = forked ? (hipStream_t)bufs->aux_stream : st;
     if (forked) {
@@ -724,6 +769,16 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
     if (!c.use_flow && !search_reps) MARK(2);
     if (!search_reps) MARK(3);
 
+    if (c.use_assign) {
+        // assignment loss instead of the Chamfer loss: no search, the pairs come from the caller's assign_map
+        if (search_reps) return REART_ERR_UNSUPPORTED;
+        MARK(4);
+        AssignArgs aa = {};
+        aa.X = bufs->pc_trans; aa.Y = bufs->pc_list; aa.map = bufs->assign_map; aa.N = N; aa.B = B;
+        aa.lambda = c.lambda_assign; aa.G = G; aa.loss_part = (double *)(ws + p.o_floss);
+        hipLaunchKernelGGL(assign_grad_kernel, dim3(reart_div_up(N, CG_BS), B), dim3(CG_BS), 0, st, aa);
+        REART_CHECK_LAUNCH();
+    } else {
     // 2. Chamfer (utils/chamfer.py:78-94).  pc_list never changes: with use_grid the direction
     // pc_trans -> pc_list goes through its pre-built exact grid, and only pc_list -> pc_trans (moving
     // targets) is searched by brute force; without it both directions share one brute-force launch.
@@ -816,6 +871,7 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
     } else if (cg.S0 <= 4 && cg.S1 <= 4) hipLaunchKernelGGL(chamfer_grad_kernel<true>, dim3(ncg, B), dim3(CG_BS), 0, st, cg);
     else hipLaunchKernelGGL(chamfer_grad_kernel<false>, dim3(ncg, B), dim3(CG_BS), 0, st, cg);
     REART_CHECK_LAUNCH();
+    }
     MARK(5);
 
     if (forked && hipStreamWaitEvent(st, (hipEvent_t)bufs->ev_join, 0) != hipSuccess) return REART_ERR_LAUNCH;
@@ -901,4 +957,9 @@ extern "C" int reart_relax_search_ms(const reart_relax_config *cfg, const reart_
     }
     for (int k = 0; k < 2; ++k) (void)hipEventDestroy(ev[k]);
     return rc;
+}
+
+extern "C" int reart_relax_forward(const reart_relax_config *cfg, const reart_relax_buffers *bufs,
+                                   void *workspace, size_t workspace_bytes, void *stream) {
+    return relax_step_impl(cfg, bufs, workspace, workspace_bytes, stream, nullptr, 0, true);
 }

@@ -17,13 +17,14 @@ class RelaxConfig(ctypes.Structure):
                                      "M_max", "M_total", "n_iter", "ring")] + \
                [(n, c_float) for n in ("lambda_flow", "smooth_weight", "trans_lr", "seg_lr", "beta1", "beta2", "eps",
                                        "start_tau", "end_tau", "fixed_tau")] + [("seed", ctypes.c_uint64),
-                                                                                 ("use_grid", c_int), ("use_boxes", c_int)]
+                                                                                 ("use_grid", c_int), ("use_boxes", c_int),
+                                                                                 ("use_assign", c_int), ("lambda_assign", c_float)]
 
 
 class RelaxBuffers(ctypes.Structure):
     _fields_ = [(n, c_void_p) for n in ("cano", "pc_list", "ref_loc", "ref_flow", "ref_off", "gumbel", "W1", "b1", "W2",
                                         "p6d", "pt", "adam_m", "adam_v", "iter", "tau", "losses", "pc_trans",
-                                        "seg_part", "trans_list", "aux_stream", "ev_fork", "ev_join")]
+                                        "seg_part", "trans_list", "aux_stream", "ev_fork", "ev_join", "assign_map")]
 
 
 def morton_order(points):
@@ -78,7 +79,7 @@ def _lib_fns():
         L = _lib.lib()
         L.reart_relax_workspace_bytes.restype = ctypes.c_size_t
         L.reart_relax_workspace_bytes.argtypes = [ctypes.POINTER(RelaxConfig)]
-        for fn in (L.reart_relax_prepare, L.reart_relax_step):
+        for fn in (L.reart_relax_prepare, L.reart_relax_step, L.reart_relax_forward):
             fn.restype = c_int
             fn.argtypes = [ctypes.POINTER(RelaxConfig), ctypes.POINTER(RelaxBuffers), c_void_p, ctypes.c_size_t, c_void_p]
         L.reart_relax_step_timed.restype = c_int
@@ -112,9 +113,11 @@ class RelaxEngine:
         # in the caller's order; the optimisation problem is invariant to point order).
         order = {"kd": kd_order, "morton": morton_order}[os.environ.get("REART_ORDER", "kd")]
         self._perm = order(cano_pc) if spatial_sort else None
+        self._perm_frames = None
         if spatial_sort:
             cano_pc = cano_pc[self._perm]
-            pc_list = torch.stack([f[order(f)] for f in pc_list])
+            self._perm_frames = torch.stack([order(f) for f in pc_list])
+            pc_list = torch.stack([f[o] for f, o in zip(pc_list, self._perm_frames)])
             if pc_ref_list is not None:
                 orders = [order(r.reshape(-1, 3)) for r in pc_ref_list]
                 pc_ref_list = [r.reshape(-1, 3)[o] for r, o in zip(pc_ref_list, orders)]
@@ -137,6 +140,7 @@ class RelaxEngine:
         self.ring = ring
         self.losses = torch.zeros((ring, 4), device=dev)
         self._pc_trans = torch.empty((B, N, 3), device=dev)
+        self._assign_map = torch.full((B, N), -1, dtype=torch.int32, device=dev)
         self._seg_part = torch.empty((N,), dtype=torch.int64, device=dev)
         self.trans_list = torch.empty((B, P, 4, 4), device=dev)
         self.gumbel = None
@@ -188,7 +192,8 @@ class RelaxEngine:
                                   pc_trans=v(self._pc_trans), seg_part=v(self._seg_part), trans_list=v(self.trans_list),
                                   aux_stream=None if self._aux is None else self._aux.cuda_stream,
                                   ev_fork=None if self._aux is None else self._ev[0].cuda_event,
-                                  ev_join=None if self._aux is None else self._ev[1].cuda_event)
+                                  ev_join=None if self._aux is None else self._ev[1].cuda_event,
+                                  assign_map=v(self._assign_map))
 
     @property
     def pc_trans(self):
@@ -207,6 +212,37 @@ class RelaxEngine:
             noise = noise[self._perm]
         self.gumbel = None if noise is None else noise.contiguous().float()
         self._refresh_buffers()
+
+    # ---- assignment loss (run_robot.py:164-187): the caller refreshes the pairs every assign_gap iterations
+    def peek_forward(self):
+        """Forward of the CURRENT iteration only (the temperature and Gumbel noise the next ``step`` will use);
+        afterwards ``pc_trans`` / ``seg_part`` hold that iteration's output.  Changes nothing else."""
+        rc = _lib_fns().reart_relax_forward(ctypes.byref(self.cfg), ctypes.byref(self._bufs), _lib.ptr(self.workspace),
+                                            self.workspace.numel(), _lib.stream())
+        _lib.check(rc, "reart_relax_forward")
+
+    def set_assignment(self, src_idx, tgt_idx, lambda_assign):
+        """Switch to the assignment loss ``lambda_assign * sum |pc_trans[b, src_idx[r]] - pc_list[b, tgt_idx[b, r]]|^2``.
+        src_idx [n] (indices into the canonical cloud), tgt_idx [B,n] (indices into pc_list[b]), both in the
+        caller's point order.  A captured graph is dropped when the mode changes (capture again)."""
+        B, N = self._assign_map.shape
+        src = src_idx.to(self.device).long().reshape(-1)
+        tgt = tgt_idx.to(self.device).long().reshape(B, -1)
+        if self._perm is not None:   # caller order -> internal storage order
+            src = self._inv[src]
+            inv_f = torch.empty_like(self._perm_frames)
+            inv_f.scatter_(1, self._perm_frames, torch.arange(N, device=self.device).expand(B, N))
+            tgt = inv_f.gather(1, tgt)
+        self._assign_map.fill_(-1)
+        self._assign_map[:, src] = tgt.to(torch.int32)
+        if not self.cfg.use_assign or self.cfg.lambda_assign != lambda_assign:
+            self.cfg.use_assign, self.cfg.lambda_assign = 1, float(lambda_assign)
+            self._graph = None
+
+    def clear_assignment(self):
+        if self.cfg.use_assign:
+            self.cfg.use_assign = 0
+            self._graph = None
 
     def _enqueue(self):
         rc = _lib_fns().reart_relax_step(ctypes.byref(self.cfg), ctypes.byref(self._bufs), _lib.ptr(self.workspace),

@@ -7,7 +7,10 @@ What is built: the loop itself.
   * ``--model base`` without assignment loss (the first ``--assign_iter`` iterations of every run,
     and whole runs without ``--use_assign_loss``): the fused ``RelaxEngine`` -- five kernel launches
     per iteration replayed from a graph, no host sync inside the loop.
-  * everything else (assignment loss, ``--model kinematic``): the reference's own loop structure with
+  * ``--model base`` with ``--use_assign_loss`` after ``--assign_iter``: the same engine in its
+    assignment-loss mode; every ``--assign_gap`` iterations the host refreshes the pairs (forward of the
+    coming iteration, FPS, cost matrices, GPU linear assignment), in between the engine runs alone.
+  * ``--model kinematic``: the reference's own loop structure with
     the HIP operators underneath (``BaseModel`` / ``KinematicModel``, ``ChamferDistance``,
     ``blend_anchor_motion``, ``flow_loss``, FPS) and ``torch.optim.Adam``; the linear assignment of the
     reference (``run_robot.py:172-176``, scipy on a process pool) runs on the GPU (``reart_lap_auction``:
@@ -139,19 +142,49 @@ def main(args):
     i = 0
     # ---- phase 1: fused engine (base model, Chamfer [+ flow]) until the assignment loss takes over
     fused_until = n_iter if not args.use_assign_loss else min(args.assign_iter, n_iter)
-    if args.model == "base" and not args.evaluate and fused_until > 0:
+    if args.model == "base" and not args.evaluate:
         eng = RelaxEngine(cano_pc, pc_list, model, args.cano_idx, pc_ref_list, flow_ref_list, n_iter=args.n_iter,
                           start_tau=args.start_tau, end_tau=args.end_tau, trans_lr=args.trans_lr, seg_lr=args.seg_lr,
                           lambda_flow=args.lambda_flow, use_robust_loss=args.use_robust_loss, fixed_tau=fixed_tau,
                           seed=args.manual_seed)
-        i += eng.capture()
+        if fused_until > 0:
+            i += eng.capture()
         while i < fused_until:
             chunk = min(args.snapshot_gap, fused_until - i)
             eng.step(chunk)
             i += chunk
             row = eng.last_losses().cpu().numpy()
             snapshot(i - 1, {"recon Loss": row[0], "flow Loss": row[1], "total Loss": row[2]})
-    # ---- phase 2: the reference's loop with HIP operators (assignment loss / kinematic model)
+        # ---- phase 2 (base model): assignment loss on the same engine (run_robot.py:164-187).  Every
+        # assign_gap iterations: forward of the coming iteration -> FPS of both sides -> Euclidean cost matrices ->
+        # linear assignment (GPU auction + exact certificate) -> the pairs go to the engine, which then runs
+        # the iterations up to the next refresh without touching the host.
+        if i < n_iter and args.use_assign_loss:
+            from reart_amd.utils.lap import linear_sum_assignment_batch
+
+            lap_state, have = {}, False
+            B_, N_ = pc_list.shape[0], pc_list.shape[1]
+            while i < n_iter:
+                if not have or i % args.assign_gap == 0:
+                    eng.peek_forward()
+                    pred = eng.pc_trans
+                    num_fps = N_ // args.downsample
+                    src_idx = farthest_point_sample(cano_pc[None], num_fps)                      # [1, n]
+                    tgt_idx = farthest_point_sample(pc_list, num_fps)                            # [B, n]
+                    cost = torch.cdist(index_points(pred, src_idx.expand(B_, num_fps)), index_points(pc_list, tgt_idx))
+                    assign = linear_sum_assignment_batch(cost, state=lap_state)
+                    cols = torch.from_numpy(np.stack([c for _, c in assign])).to(device)       # rows are 0..n-1
+                    eng.set_assignment(src_idx[0], tgt_idx.gather(1, cols), args.lambda_assign)
+                    have = True
+                nxt = (i // args.assign_gap + 1) * args.assign_gap                              # next refresh
+                snap = (i // args.snapshot_gap + 1) * args.snapshot_gap
+                chunk = max(1, min(nxt, snap, n_iter) - i)
+                eng.step(chunk)
+                i += chunk
+                if i % args.snapshot_gap == 0 or i == n_iter:
+                    row = eng.last_losses().cpu().numpy()
+                    snapshot(i - 1, {"opt assignment loss": row[0], "flow Loss": row[1], "total Loss": row[2]})
+    # ---- phase 2 (kinematic model; base model without the engine): the reference's loop with HIP operators
     if i < n_iter and not args.evaluate:
         from reart_amd.utils.lap import linear_sum_assignment_batch
 

@@ -222,3 +222,51 @@ def test_full_size_pruned_equals_brute_force(dev, monkeypatch):
         np.testing.assert_array_equal(a, b)
     # the losses go down over the first iterations on this well-posed synthetic instance
     assert runs["pruned"][0][-1, 2] < runs["pruned"][0][0, 2]
+
+
+def test_assignment_loss_step_matches_oracle(oracle, dev):
+    """Assignment-loss phase (run_robot.py:164-187, i >= assign_iter): fixed source / target pairs replace the
+    Chamfer loss, the flow loss stays.  Two Chamfer iterations, then three assignment iterations with the pairs
+    refreshed in between, against the oracle's iteration; peek_forward() returns the coming iteration's clouds."""
+    from oracle.step import RelaxOracle
+    from reart_amd.relax import RelaxEngine
+
+    rng = np.random.default_rng(21)
+    N, P, B, H, cano_idx = 260, 12, 3, 128, 2
+    cano = rng.uniform(-0.3, 0.3, (N, 3)).astype(np.float32)
+    pcs = (cano[None] + rng.normal(0, 0.02, (B, N, 3))).astype(np.float32)
+    W1, b1 = rng.normal(0, 0.6, (H, 3)).astype(np.float32), rng.normal(0, 0.1, H).astype(np.float32)
+    W2 = rng.normal(0, 0.2, (P, H)).astype(np.float32)
+    p6d = (np.tile(np.array([1, 0, 0, 0, 1, 0], np.float32), (B, P, 1)) + rng.normal(0, 0.05, (B, P, 6))).astype(np.float32)
+    pt = rng.normal(0, 0.01, (B, P, 3)).astype(np.float32)
+    refs = [rng.uniform(-0.3, 0.3, (m, 3)).astype(np.float32) for m in (150, 90, 200)]
+    flows = [rng.normal(0, 0.02, r.shape).astype(np.float32) for r in refs]
+    lam = 0.3
+    orc = RelaxOracle(cano, pcs, W1, b1, W2, p6d, pt, cano_idx, refs, flows, lambda_flow=0.7, n_iter=50)
+    model = _make_model(dev, P, B, W1, b1, W2, p6d, pt)
+    eng = RelaxEngine(t(cano, dev), t(pcs, dev), model, cano_idx, [t(r, dev) for r in refs], [t(f, dev) for f in flows],
+                      n_iter=50, lambda_flow=0.7)
+    assign = None
+    for i in range(5):
+        noise = -np.log(rng.exponential(size=(N, P))).astype(np.float32)
+        eng.set_gumbel(t(noise, dev))
+        if i >= 2:
+            if i != 3:   # refresh the pairs at iterations 2 and 4
+                src = rng.permutation(N)[:64]
+                tgt = np.stack([rng.permutation(N)[:64] for _ in range(B)])
+                assign = (src, tgt, lam)
+                eng.peek_forward()
+                peek = eng.pc_trans.cpu().numpy().copy()
+                eng.set_assignment(torch.from_numpy(src), torch.from_numpy(tgt), lam)
+        ref = orc.step(noise, assign=assign)
+        eng.step()
+        if i >= 2 and i != 3:
+            np.testing.assert_array_equal(peek, eng.pc_trans.cpu().numpy())     # the step redoes the same forward
+        row = eng.last_losses().cpu().numpy()
+        assert abs(row[0] - ref["recon"]) <= 1e-5 * abs(ref["recon"]), (i, row, ref["recon"])
+        assert abs(row[1] - ref["flow"]) <= 1e-5 * abs(ref["flow"]) + 1e-9, (i, row, ref["flow"])
+        np.testing.assert_allclose(eng.pc_trans.cpu().numpy(), ref["pc_trans"], rtol=0, atol=5e-7)
+        for k, prm in (("p6d", model.proposal_6d), ("pt", model.proposal_t), ("W2", model.seg_head.model[2].weight),
+                       ("W1", model.seg_head.model[0].weight), ("b1", model.seg_head.model[0].bias)):
+            got = prm.detach().cpu().numpy().reshape(orc.params[k].shape)
+            np.testing.assert_allclose(got, orc.params[k], rtol=0, atol=2e-5, err_msg=f"iter {i} param {k}")
