@@ -61,6 +61,7 @@ PROTOTYPES = {
     "reart_relax_workspace_bytes": (c_size_t, None),
     "reart_relax_prepare": (c_int, None),
     "reart_relax_step": (c_int, None),
+    "reart_relax_forward": (c_int, None),
     "reart_relax_step_timed": (c_int, None),
     "reart_relax_search_ms": (c_int, None),
 }
