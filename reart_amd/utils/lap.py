@@ -22,8 +22,13 @@ def linear_sum_assignment_batch(cost, return_stats=False, state=None):
     col = torch.empty((B, n), dtype=torch.int32, device=cost.device)
     cert = torch.empty((B,), dtype=torch.int32, device=cost.device)
     nbytes = L.reart_lap_workspace_bytes(B, n)
-    if nbytes == 0:
-        raise ValueError("linear_sum_assignment_batch: n must be in 1..2048")
+    if nbytes == 0:   # n > 2048: beyond the kernel's LDS state -- the reference's host solver
+        from scipy.optimize import linear_sum_assignment
+
+        out = [linear_sum_assignment(c) for c in cost.cpu().numpy()]
+        if return_stats == "full":
+            return out, B, np.zeros((B, 4), np.int32)
+        return (out, B) if return_stats else out
     ws = _lib.workspace(nbytes, cost.device)
     prices = None
     if state is not None:
