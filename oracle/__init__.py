@@ -225,3 +225,13 @@ def fk(parent, edge_of_part, order, axis, moment, theta, distance=None):
     T = np.empty((B, P, 4, 4), np.float32)
     lib().oracle_fk(_p(parent), _p(eop), _p(order), P, _p(axis), _p(moment), _p(theta), _p(dist), B, E, _p(T))
     return T
+
+
+def linear_sum_assignment(cost):
+    """The assignment loss's solver (reference run_robot.py:7,172-176; utils/model_utils.py:85-103): the
+    reference calls scipy.optimize.linear_sum_assignment (requirements.txt:6, unpinned; 1.15.3 in this image)
+    on every float32 `cdist` matrix.  No restatement: the reference's own third-party call IS the oracle here.
+    cost [B,n,n] -> list of (row_ind, col_ind)."""
+    from scipy.optimize import linear_sum_assignment as _lsa
+
+    return [_lsa(np.asarray(c)) for c in np.asarray(cost)]
