@@ -18,8 +18,8 @@ def _compare(cost_np, dev, expect_same_perm=True):
         rr, cc = ref[b]
         assert sorted(c.tolist()) == list(range(cost_np.shape[1]))                    # a permutation
         ours = cost_np[b][r, c].astype(np.float64).sum()
-        ref = cost_np[b][rr, cc].astype(np.float64).sum()
-        assert abs(ours - ref) <= 1e-9 * max(1.0, abs(ref)), (b, ours, ref)
+        best = cost_np[b][rr, cc].astype(np.float64).sum()
+        assert abs(ours - best) <= 1e-9 * max(1.0, abs(best)), (b, ours, best)
         if expect_same_perm:
             np.testing.assert_array_equal(c, cc)
     return fallbacks
