@@ -400,6 +400,47 @@ size_t reart_match_smnn_workspace_bytes(int E, int N1, int N2);
 int reart_match_smnn(const float *desc1, const float *desc2, int E, int N1, int N2, int D, float th,
                      uint8_t *keep, int64_t *tgt, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ------------------------------------------------------------------------ */
+/* End-of-run structure extraction (run_robot.py:224-330)                     */
+/* ------------------------------------------------------------------------ */
+
+/* Screw decomposition and joint-type costs of relative part motions, one launch.  Replaces
+ * compute_relative_trans + compute_geo_cost (utils/graph_utils.py:170-186, :131-167), compute_screw_trans /
+ * compute_screw_cost (:235-292), compute_mean_screw_param (:207-232), frobenius_cost (:189-196), the identity
+ * cost of merge_graph (:338-342) and the per-edge screw parameters of build_graph
+ * (utils/kinematic_utils.py:84-99), with transform_to_dq / dq_to_screw (screw_se3/dq_utils.py:129-182).
+ *   trans [T,P,4,4]; pairs [E,2] i32 (src, tgt): the relative motion of edge e in frame t is
+ *   inv(trans[t,src]) * trans[t,tgt].  pairs == NULL: trans IS the relative motion, [T,E,4,4] (P ignored).
+ *   plain_mean != 0: mean axis / moment over all frames (build_graph's single-edge call); 0: over the frames
+ *   that are not a unit transform (compute_mean_screw_param), all frames when every frame is one or E <= 1.
+ * Outputs (nullable unless noted): screw [T,E,8] = axis(3), moment(3), theta, distance;  rel [T,E,4,4];
+ * mean [E,6] = mean axis, mean moment;  recon [T,E,4,4] = reconstruction with the cheaper joint type;
+ * cost [E,4] (required) = revolute cost, prismatic cost, their minimum, mean over frames of |rel - I|^2;
+ * mean_cost = mean_e(minimum) / T (compute_screw_cost's scalar).  workspace is needed when mean == NULL. */
+size_t reart_screw_fit_workspace_bytes(int T, int E);
+int reart_screw_fit(const float *trans, int T, int P, const int32_t *pairs, int E, int plain_mean,
+                    float *screw, float *rel, float *mean, float *recon, float *cost, float *mean_cost,
+                    void *workspace, size_t workspace_bytes, void *stream);
+
+/* Replaces fps_sample_cano (utils/graph_utils.py:37-52): farthest point sampling inside every part, one
+ * workgroup per part.  cano [N,3], seg [N] i64, labels [Ps] i64 -> idx [Ps,num_fps] i64 (indices into cano,
+ * start = the part's first point like the reference's CUDA FPS; -1 when the part has fewer than num_fps
+ * points), count [Ps] i32 = part sizes.  cuda_mode as in reart_fps. */
+int reart_part_fps(const float *cano, const int64_t *seg, int N, const int64_t *labels, int Ps, int num_fps,
+                   int cuda_mode, int64_t *idx, int32_t *count, void *stream);
+
+/* Replaces compute_spatial_cost (utils/graph_utils.py:70-84) and compute_joint_cost (:87-100) over all
+ * ordered part pairs.  cano_fps [Ps,F,3]; frame_fps [T,Ps,F,3] (nullable: the same points in the predicted
+ * frames) -> cano_dist [Ps,Ps] = squared distance of the closest pair (i -> j), pair [Ps,Ps,2] i64 = that
+ * pair's (source, target) FPS slots (first minimum), joint [Ps,Ps] = its squared distance summed over frames. */
+int reart_part_pair_cost(const float *cano_fps, const float *frame_fps, int T, int Ps, int F, float *cano_dist,
+                         int64_t *pair, float *joint, void *stream);
+
+/* Replaces compute_group_temporal_err (utils/model_utils.py:107-118).  pcs [T,N,3], seg [N] i64,
+ * labels [Ps] i64 -> per_part [Ps], worst = max over parts. */
+int reart_group_temporal_err(const float *pcs, int T, int N, const int64_t *seg, const int64_t *labels, int Ps,
+                             float *per_part, float *worst, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

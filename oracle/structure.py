@@ -210,28 +210,44 @@ def mst(cost, labels=None, max_cost=None):
     return np.asarray(out, np.int64).reshape(-1, 2)
 
 
-def merge_graph(seg, connection, trans, merge_thr):
-    """gu:327-385: contract tree edges whose relative motion stays within merge_thr of the identity."""
+def contract_edges(edges, cost, merge_thr):
+    """The networkx part of gu:344-385 -> (relabel {old: surviving}, remaining edges in M.edges order)."""
     import networkx as nx
 
-    seg = np.asarray(seg).copy()
-    c = np.asarray(connection)
-    rel = relative_trans(trans, c[:, 0], c[:, 1])
-    van = frobenius_cost(rel, np.broadcast_to(np.eye(4, dtype=F32), rel.shape)).mean(0, dtype=F32)
     G = nx.DiGraph()
-    for p in np.unique(c):
-        G.add_node(int(p))
-    for k, (a, b) in enumerate(c.tolist()):
-        G.add_edge(a, b, cost=float(van[k]))
+    for p in sorted({int(x) for e in edges for x in e}):
+        G.add_node(p)
+    for (a, b), c in zip(edges, cost):
+        G.add_edge(int(a), int(b), cost=float(c))
     M = G.copy()
+    relabel = {v: v for v in G.nodes}
     for node in list(nx.topological_sort(G)):
         if not M.has_node(node):
             continue
         for e in list(nx.edges(M, node)):
             if M.has_node(e[1]) and M.get_edge_data(e[0], e[1])["cost"] < merge_thr:
                 M = nx.contracted_edge(M, e, self_loops=False)
-                seg[seg == e[1]] = e[0]
-    return seg, np.asarray([[a, b] for a, b in M.edges], np.int64).reshape(-1, 2)
+                for k, v in relabel.items():
+                    if v == e[1]:
+                        relabel[k] = e[0]
+    if not nx.is_weakly_connected(M):
+        raise ValueError("New graph are not all connected.")
+    if not nx.is_directed_acyclic_graph(M):
+        raise ValueError("There are cycles in the link graph")
+    return relabel, [[a, b] for a, b in M.edges]
+
+
+def merge_graph(seg, connection, trans, merge_thr):
+    """gu:327-385: contract tree edges whose relative motion stays within merge_thr of the identity."""
+    seg = np.asarray(seg)
+    c = np.asarray(connection)
+    rel = relative_trans(trans, c[:, 0], c[:, 1])
+    van = frobenius_cost(rel, np.broadcast_to(np.eye(4, dtype=F32), rel.shape)).mean(0, dtype=F32)
+    relabel, remaining = contract_edges(c.tolist(), van.tolist(), merge_thr)
+    lut = np.arange(max(int(seg.max()), max(relabel)) + 1)
+    for k, v in relabel.items():
+        lut[k] = v
+    return lut[seg], np.asarray(remaining, np.int64).reshape(-1, 2)
 
 
 def denoise_seg_label(seg, cano, min_num=10):

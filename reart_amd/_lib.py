@@ -57,6 +57,11 @@ PROTOTYPES = {
     "reart_lap_auction": (c_int, [P, c_int, c_int, P, P, P, P, P, c_size_t, P]),
     "reart_match_smnn_workspace_bytes": (c_size_t, [c_int] * 3),
     "reart_match_smnn": (c_int, [P, P, c_int, c_int, c_int, c_int, c_float, P, P, P, c_size_t, P]),
+    "reart_screw_fit_workspace_bytes": (c_size_t, [c_int] * 2),
+    "reart_screw_fit": (c_int, [P, c_int, c_int, P, c_int, c_int, P, P, P, P, P, P, P, c_size_t, P]),
+    "reart_part_fps": (c_int, [P, P, c_int, P, c_int, c_int, c_int, P, P, P]),
+    "reart_part_pair_cost": (c_int, [P, P, c_int, c_int, c_int, P, P, P, P]),
+    "reart_group_temporal_err": (c_int, [P, c_int, c_int, P, P, c_int, P, P, P]),
     # struct-taking entry points: full prototypes are set in reart_amd/relax.py
     "reart_relax_workspace_bytes": (c_size_t, None),
     "reart_relax_prepare": (c_int, None),

@@ -18,3 +18,15 @@ def rotation_6d_to_matrix(d6):
 def matrix_to_rotation_6d(matrix):
     """First two rows, flattened (screw_se3/geo_utils.py:654-667)."""
     return matrix[..., :2, :].clone().reshape(matrix.shape[:-2] + (6,))
+
+
+def inverse_transformation(trans_12):
+    """[R|t] -> [R^T | -R^T t] for [N,4,4] or [4,4] (screw_se3/geo_utils.py:9-53)."""
+    if not torch.is_tensor(trans_12):
+        raise TypeError("Input type is not a torch.Tensor. Got {}".format(type(trans_12)))
+    Rt = trans_12[..., :3, :3].transpose(-1, -2)
+    out = torch.zeros_like(trans_12)
+    out[..., :3, :3] = Rt
+    out[..., :3, 3:4] = torch.matmul(-Rt, trans_12[..., :3, 3:4])
+    out[..., 3, 3] = 1.0
+    return out

@@ -88,3 +88,150 @@ def _effective_joint_values(theta_list, distance_list, joint_type_list):
     theta = torch.where(pris[None, :], torch.full_like(theta_list, 1e-6), theta_list)
     dist = torch.where(pris[None, :], distance_list, torch.full_like(distance_list, 1e-6))
     return theta, dist
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Structure extraction: relabelling and the joint tree (utils/kinematic_utils.py:18-149).  The graph has at most
+# num_parts nodes: its bookkeeping is host integer work; the screw parameters of the edges are one kernel launch.
+def extract_kinematic(seg_part, trans_list, joint_connection):
+    """utils/kinematic_utils.py:18-34: renumber the surviving parts 0..P-1 in label order."""
+    uni_label = torch.unique(seg_part, sorted=True)
+    assert torch.equal(torch.unique(joint_connection, sorted=True), uni_label)
+    new_seg = torch.searchsorted(uni_label, seg_part.contiguous())
+    new_conn = torch.searchsorted(uni_label, joint_connection.contiguous())
+    return new_seg, trans_list[:, uni_label], new_conn
+
+
+def _paths_to(adj, root):
+    """Breadth-first parent links towards ``root`` in an undirected tree -> {node: [node, ..., root]}."""
+    parent, order = {root: None}, [root]
+    for u in order:
+        for v in adj[u]:
+            if v not in parent:
+                parent[v] = u
+                order.append(v)
+    paths = {}
+    for v in parent:
+        p, cur = [], v
+        while cur is not None:
+            p.append(cur)
+            cur = parent[cur]
+        paths[v] = p
+    return paths
+
+
+class JointTree:
+    """The directed joint tree (edges child -> parent) with the orderings the reference derives from its networkx
+    graph: ``edges`` in the order ``G.edges()`` lists them, ``nodes`` in insertion order, ``paths_to_base``
+    (= ``nx.shortest_path(G, target=root)``) and ``reverse_topo`` (root to leaf)."""
+
+    def __init__(self, edges_list, root):
+        und, first_seen = {}, []
+        for a, b in edges_list:
+            for x, y in ((a, b), (b, a)):
+                if x not in und:
+                    und[x] = []
+                    first_seen.append(x)
+                und[x].append(y)
+        paths = _paths_to(und, root)
+        if len(paths) != len(first_seen):
+            raise AssertionError("invalid tree structure")
+        new_edges = []
+        for part in first_seen:                           # utils/kinematic_utils.py:41-47
+            path = paths[part]
+            for i in range(len(path) - 1):
+                if (path[i], path[i + 1]) not in new_edges:
+                    new_edges.append((path[i], path[i + 1]))
+        assert len(new_edges) == len(first_seen) - 1, "invalid tree structure"
+        self.root = root
+        self.nodes, self.parent = [], {}
+        for c, p in new_edges:                            # DiGraph insertion order
+            for x in (c, p):
+                if x not in self.nodes:
+                    self.nodes.append(x)
+            self.parent[c] = p
+        self.edges = [(c, self.parent[c]) for c in self.nodes if c in self.parent]
+        self.paths_to_base = {}
+        for v in self.nodes:
+            p, cur = [v], v
+            while cur in self.parent:
+                cur = self.parent[cur]
+                p.append(cur)
+            self.paths_to_base[v] = p
+        # topological order by generations (children before parents), reversed: root first
+        indeg = {v: 0 for v in self.nodes}
+        for c, p in self.edges:
+            indeg[p] += 1
+        gen, topo = [v for v in self.nodes if indeg[v] == 0], []
+        while gen:
+            nxt = []
+            for u in gen:
+                topo.append(u)
+                if u in self.parent:
+                    indeg[self.parent[u]] -= 1
+                    if indeg[self.parent[u]] == 0:
+                        nxt.append(self.parent[u])
+            gen = nxt
+        self.reverse_topo = list(reversed(topo))
+
+    def number_of_nodes(self):
+        return len(self.nodes)
+
+
+def to_DAG(edges_list, root_node):
+    """utils/kinematic_utils.py:37-53 on a plain edge list -> JointTree (children point to parents)."""
+    return JointTree([(int(a), int(b)) for a, b in edges_list], int(root_node))
+
+
+def build_graph(edges_list, trans_list, verbose=False, root_part=None, revolute_only=True, return_joint_type=False):
+    """utils/kinematic_utils.py:57-139: root = the part that moves least; per edge (child, parent) the mean screw
+    axis / moment of inv(T_parent) T_child and its angle per frame.
+    -> (tree, root_part, axis_list [E,3], moment_list [E,3], theta_list [T,E], edge_index) and, with
+    ``revolute_only=False``, distance_list [T,E] (+ joint types): the cheaper of the revolute / prismatic fits."""
+    from .graph_utils import compute_root_cost, screw_fit
+
+    edges = torch.as_tensor(edges_list).cpu().tolist()
+    P = trans_list.shape[1]
+    assert sorted({int(x) for e in edges for x in e}) == list(range(P))
+    if root_part is None:
+        root_part = int(compute_root_cost(trans_list).argmin().item())
+    if verbose:
+        print("root part id", root_part)
+    G = to_DAG(edges, root_part)
+    pairs = torch.tensor([[p, c] for c, p in G.edges], dtype=torch.int32, device=trans_list.device)
+    # build_graph averages over all frames per edge (its compute_mean_screw_param calls see E = 1)
+    f = screw_fit(trans_list, pairs, plain_mean=True, want=("screw",))
+    screw = f["screw"]
+    axis_list, moment_list = f["mean"][:, 0:3].contiguous(), f["mean"][:, 3:6].contiguous()
+    theta, distance = screw[..., 6], screw[..., 7]
+    edge_index = {"_".join([str(c), str(p)]): k for k, (c, p) in enumerate(G.edges)}
+    if revolute_only:
+        no_rot = (theta.abs() < 1e-6) | ((theta - np.pi).abs() < 1e-6)
+        assert int(no_rot.sum()) == 0
+        joint_type_list = ["revolute"] * len(G.edges)
+        print("joint types at each edge: {}".format(joint_type_list))
+        return G, root_part, axis_list, moment_list, theta.contiguous(), edge_index
+    per_edge = screw_fit_per_edge_costs(trans_list, pairs)
+    pris = per_edge[:, 1] <= per_edge[:, 0]
+    joint_type_list = ["prismatic" if bool(b) else "revolute" for b in pris]
+    tiny = torch.full_like(theta, 1e-6)
+    theta_list = torch.where(pris[None, :], tiny, theta)
+    distance_list = torch.where(pris[None, :], distance, tiny)
+    print("joint types at each edge: {}".format(joint_type_list))
+    if return_joint_type:
+        return G, root_part, axis_list, moment_list, theta_list, distance_list, edge_index, joint_type_list
+    return G, root_part, axis_list, moment_list, theta_list, distance_list, edge_index
+
+
+def screw_fit_per_edge_costs(trans_list, pairs):
+    """(revolute, prismatic) cost of every edge fitted ON ITS OWN (utils/kinematic_utils.py:100-126: there the
+    rotation residual ``F.mse_loss`` is averaged over one edge, not over all edges as in compute_geo_cost)."""
+    from .graph_utils import screw_fit
+
+    rows = [screw_fit(trans_list, pairs[e:e + 1], plain_mean=True)["cost"][0, :2] for e in range(pairs.shape[0])]
+    return torch.stack(rows)
+
+
+def edge_index2edges(edge_index):
+    """utils/kinematic_utils.py:142-149."""
+    return [[int(v) for v in name.split("_")] for name in edge_index.keys()]

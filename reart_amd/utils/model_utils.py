@@ -1,6 +1,8 @@
 """Host-side mirror of the hot-path helpers of the reference's ``utils/model_utils.py``."""
 import math
 
+import numpy as np
+
 import torch
 
 from .. import _lib
@@ -47,3 +49,47 @@ def knn_query(query_pc, src_pc, src_input, knn):
     if src_input.dim() == 2:
         return src_input[idx].reshape(-1, knn.k, src_input.shape[1]).mean(dim=1)
     return torch.mode(src_input[idx].reshape(-1, knn.k), dim=1)[0]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Energy terms of the model selection (run_robot.py:306-321)
+def parallel_lap(cost, nproc=None):
+    """utils/model_utils.py:85-89: the reference's process pool of host solvers -> one batched GPU solve
+    (``nproc`` is accepted and ignored).  cost [T,n,n] tensor or array -> list of (row_ind, col_ind)."""
+    from .lap import linear_sum_assignment_batch
+
+    return linear_sum_assignment_batch(torch.as_tensor(cost))
+
+
+def compute_ass_err(pc_trans_list, pc_list, use_nproc=True):
+    """utils/model_utils.py:92-104: mean squared distance under each frame's optimal one-to-one assignment
+    (Euclidean cost)."""
+    from .lap import linear_sum_assignment_batch
+
+    _lib.require_gpu(pc_trans_list, pc_list)
+    with torch.no_grad():
+        cost = torch.cdist(pc_trans_list, pc_list)
+        cols = torch.from_numpy(np.stack([c for _, c in linear_sum_assignment_batch(cost)])).to(pc_list.device)
+        matched = torch.gather(pc_list, 1, cols[..., None].expand(-1, -1, 3))
+        return ((pc_trans_list - matched) ** 2).sum(dim=-1).mean()
+
+
+def compute_group_temporal_err(pc_list, seg_part):
+    """utils/model_utils.py:107-118: the worst part's mean squared distance to its per-frame centroid."""
+    _lib.require_gpu(pc_list, seg_part)
+    pcs = pc_list.detach().contiguous().float()
+    seg = seg_part.contiguous().long()
+    lab = torch.unique(seg, sorted=True)
+    per = torch.empty((lab.shape[0],), dtype=torch.float32, device=pcs.device)
+    worst = torch.empty((1,), dtype=torch.float32, device=pcs.device)
+    rc = _lib.lib().reart_group_temporal_err(_lib.ptr(pcs), pcs.shape[0], pcs.shape[1], _lib.ptr(seg), _lib.ptr(lab),
+                                             lab.shape[0], _lib.ptr(per), _lib.ptr(worst), _lib.stream())
+    _lib.check(rc, "reart_group_temporal_err")
+    return worst[0].cpu()
+
+
+def compute_align_trans(trans_list, root_trans):
+    """utils/model_utils.py:121-126: express every part's motion in the root's frame."""
+    from ..screw_se3 import inverse_transformation
+
+    return torch.matmul(inverse_transformation(root_trans)[:, None, :, :], trans_list)

@@ -1,0 +1,202 @@
+"""End-of-run structure extraction on the GPU (reart_amd/utils/graph_utils.py, kinematic_utils.py, model_utils.py over
+csrc/structure.hip) against tests/golden/structure.npz -- produced by the reference's own functions from its shipped
+base-2 checkpoint -- and against the numpy oracle on random inputs.  Labels, FPS indices, closest pairs and tree edges
+are bit-exact; floating-point results within 1e-4 relative (north_star's tolerance), most within 1e-6."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "structure.npz"))
+
+
+def T_(a, dev, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    return t if dtype is None else t.to(dtype)
+
+
+def close(a, b, atol=2e-6, rtol=1e-4):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    np.testing.assert_allclose(np.asarray(a, np.float64), np.asarray(b, np.float64), rtol=rtol, atol=atol)
+
+
+def same(a, b):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    np.testing.assert_array_equal(a, np.asarray(b))
+
+
+def test_denoise_part_fps_and_pair_costs_match_the_reference(dev):
+    from reart_amd.knn_cuda import KNN
+    from reart_amd.utils import graph_utils as gu
+    from reart_amd.utils.model_utils import compute_pc_transform
+
+    cano, trans = T_(G["cano"], dev), T_(G["trans0"], dev)
+    seg = gu.denoise_seg_label(T_(G["seg0"], dev).clone(), cano, KNN(k=1, transpose_mode=True), min_num=20)
+    same(seg, G["seg_denoised"])
+    uni = torch.unique(seg, sorted=True)
+    same(uni, G["uni0"])
+    pts, idx = gu.fps_sample_cano(cano, seg, uni, num_fps=20)
+    same(idx, G["fps_idx0"])
+    same(pts, G["fps_pts0"])
+    pred = compute_pc_transform(cano, trans, seg)
+    dist, pair = gu.compute_spatial_cost(pts, None, return_index=True)
+    same(dist, G["cano_dist0"])
+    same(pair, G["pair_idx0"])
+    _, _, joint = gu._pair_cost(pts, gu.fps_index_list(pred, idx))
+    close(joint, G["joint0"], atol=1e-7)
+    P = len(uni)
+    ar = torch.arange(P, device=dev)
+    allp = torch.stack([ar.repeat_interleave(P), ar.repeat(P)], 1)
+    j2 = gu.compute_joint_cost(gu.fps_index_list(pred, idx), allp, pair.reshape(-1, 2)).reshape(-1, P, P).sum(0)
+    close(j2, G["joint0"], atol=1e-7)
+    cost = dist + joint + 1e4 * torch.eye(P, device=dev)
+    cand = gu.mst(cost, uni_label=uni)
+    same(cand, G["mst_merge0"])
+    seg1, conn1 = gu.merge_graph(seg, cand, trans, float(G["merge_thr"]), verbose=False)
+    same(seg1, G["seg_merge1"])
+    same(conn1, G["conn_merge1"])
+    with pytest.raises(ValueError, match="too small"):
+        gu.fps_sample_cano(cano, seg, uni, num_fps=5000)
+
+
+def test_relative_screw_parameters_and_geo_cost_match_the_reference(dev):
+    from reart_amd.utils import graph_utils as gu
+
+    trans = T_(G["trans0"], dev)
+    axis, moment, theta, dist, rel = gu.compute_relative_trans(trans, return_trans=True)
+    off = ~np.eye(20, dtype=bool)
+    for ours, key in ((axis, "rel_axis"), (moment, "rel_moment"), (theta, "rel_theta"), (dist, "rel_distance")):
+        close(ours.cpu().numpy()[:, off], G[key][:, off], atol=5e-6)
+    uni = T_(G["uni_merged"], dev)
+    sel = rel[:, uni][:, :, uni]
+    close(gu.compute_geo_cost(sel), G["geo_cost"], atol=1e-6)
+
+
+def test_wrappers_reproduce_the_reference_structure(dev):
+    from reart_amd.utils import graph_utils as gu
+    from reart_amd.utils import kinematic_utils as ku
+
+    cano, trans = T_(G["cano"], dev), T_(G["trans0"], dev)
+    seg = gu.merging_wrapper(T_(G["seg_denoised"], dev), trans, cano, None, float(G["merge_thr"]), n_it=int(G["merge_it"]))
+    same(seg, G["seg_merged"])
+    conn = gu.mst_wrapper(seg, trans, cano, None, num_fps=20, cano_dist_thr=float(G["cano_dist_thr"]),
+                          joint_cost_weight=float(G["lambda_joint"]))
+    same(conn, G["joint_connection_raw"])
+    ns, nt, nc = ku.extract_kinematic(seg, trans, conn)
+    same(ns, G["new_seg"])
+    same(nt, G["new_trans"])
+    same(nc, G["new_conn"])
+    tree, root, axis, moment, theta, edge_index = ku.build_graph(nc, nt)
+    assert root == int(G["root_part"])
+    names = sorted(edge_index, key=edge_index.get)
+    same([int(n.split("_")[0]) for n in names], G["edge_child"])
+    same([int(n.split("_")[1]) for n in names], G["edge_parent"])
+    same(tree.reverse_topo, G["reverse_topo"])
+    same(tree.nodes, G["graph_nodes"])
+    same(np.concatenate([tree.paths_to_base[p] for p in range(nt.shape[1])]), G["path_flat"])
+    close(axis, G["axis_list"])
+    close(moment, G["moment_list"])
+    close(theta, G["theta_list"])
+    assert ku.edge_index2edges(edge_index) == [[int(c), int(p)] for c, p in zip(G["edge_child"], G["edge_parent"])]
+    # the same undirected tree and root as the result the reference ships (base-2/result_14999.pkl, kinematic-2)
+    und = lambda e: sorted(tuple(sorted(x)) for x in np.asarray(e).tolist())
+    assert und(nc.cpu().numpy()) == und(G["shipped_conn"])
+    same(ns, G["shipped_seg"])
+    # the kinematic model built from this tree runs on the HIP forward kinematics
+    from reart_amd.knn_cuda import KNN
+    from reart_amd.networks.model import KinematicModel
+
+    model = KinematicModel(pose_len=nt.shape[0], seg_part=ns, cano_pc=cano, knn=KNN(k=1, transpose_mode=True),
+                           edge_index=edge_index, paths_to_base=tree.paths_to_base, reverse_topo=tree.reverse_topo,
+                           axis_list=axis, moment_list=moment, theta_list=theta).to(dev)
+    out, seg_k, tr = model(cano)
+    assert out.shape == (nt.shape[0], cano.shape[0], 3) and torch.isfinite(out).all()
+
+
+def test_energy_terms_match_the_reference(dev):
+    from reart_amd.utils import graph_utils as gu
+    from reart_amd.utils import model_utils as mu
+
+    nt, nc, ns, cano = T_(G["new_trans"], dev), T_(G["new_conn"], dev), T_(G["new_seg"], dev), T_(G["cano"], dev)
+    close(gu.compute_root_cost(nt), G["root_cost"])
+    close(gu.compute_screw_cost(nt, nc), G["screw_err"], atol=1e-8)
+    from reart_amd.screw_se3 import inverse_transformation
+
+    rel = torch.matmul(inverse_transformation(nt[:, nc[:, 0]]), nt[:, nc[:, 1]])
+    recon, cost = gu.compute_screw_trans(rel, return_cost=True)
+    close(recon, G["screw_recon"], atol=5e-6)
+    close(cost, G["screw_cost_direct"], atol=1e-8)
+    pred = mu.compute_pc_transform(cano, nt, ns)
+    same(pred, G["pred"])
+    comp = torch.cat((pred[:2], cano[None], pred[2:]), dim=0)
+    close(mu.compute_group_temporal_err(comp, ns), G["group_err"], atol=1e-9, rtol=1e-5)
+    close(mu.compute_ass_err(pred[:1], T_(G["pc_list"][:1], dev)), G["ass_err_frame0"], atol=1e-10, rtol=1e-5)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_screw_fit_random_motions_vs_oracle(dev, seed):
+    """Random articulated motions incl. identity frames (unit transforms are masked out of the means), pure
+    translations (prismatic wins) and a single edge (plain mean)."""
+    from oracle import structure as S
+    from reart_amd.utils import graph_utils as gu
+    import oracle
+
+    rng = np.random.default_rng(seed)
+    Tn, P = 7, 6
+    trans = np.tile(np.eye(4, dtype=np.float32), (Tn, P, 1, 1))
+    for p in range(1, P):
+        ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+        pt = rng.uniform(-0.3, 0.3, 3)
+        for t in range(Tn):
+            if p == 2:                       # prismatic part
+                trans[t, p, :3, 3] = ax * 0.05 * t
+                continue
+            if p == 3 and t < 3:             # stays put for the first frames
+                continue
+            ang = np.float32(0.25 * (t + 1) * (1 if p % 2 else -1))
+            l, m = ax.astype(np.float32), np.cross(pt, ax).astype(np.float32)
+            trans[t, p] = oracle.screw_to_transform(l[None], m[None], np.array([ang], np.float32), np.array([1e-6], np.float32))[0]
+    lab = np.arange(P)
+    src, tgt = np.repeat(lab, P), np.tile(lab, P)
+    ref = S.screw_fit(S.relative_trans(trans, src, tgt))
+    pairs = torch.from_numpy(np.stack([src, tgt], 1)).to(dev)
+    out = gu.screw_fit(T_(trans, dev), pairs, want=("screw", "recon", "mean_cost"))
+    off = (src != tgt)
+    cost = out["cost"].cpu().numpy()
+    close(cost[off, 0], ref["cost_r"][off], atol=2e-5)
+    close(cost[off, 1], ref["cost_p"][off], atol=2e-5)
+    close(cost[off, 2], ref["cost"][off], atol=2e-5)
+    moving = off & ~((src == 0) & (tgt == 0))
+    sc = out["screw"].cpu().numpy()
+    rot = np.abs(ref["theta"]) > 1e-3       # the axis of a (near) unit transform is rounding noise
+    close(sc[..., 6][:, off], ref["theta"][:, off], atol=2e-5)
+    close(sc[..., 7][:, off], ref["distance"][:, off], atol=2e-5)
+    close(sc[..., 0:3][rot & off[None]], ref["axis"][rot & off[None]], atol=5e-5)
+    # a single edge: plain mean over all frames
+    one = gu.screw_fit(T_(trans, dev), torch.tensor([[0, 1]], device=dev), want=("screw",))
+    l, m, th, d = S.transform_to_screw(S.relative_trans(trans, [0], [1])[:, 0])
+    close(one["mean"][0, :3], l.mean(0), atol=5e-6)
+    close(one["mean"][0, 3:], m.mean(0), atol=5e-6)
+    del moving
+
+
+def test_part_fps_random_labels_vs_oracle(dev):
+    from oracle import structure as S
+    from reart_amd.utils import graph_utils as gu
+
+    rng = np.random.default_rng(5)
+    cano = rng.uniform(-0.3, 0.3, (3000, 3)).astype(np.float32)
+    seg = rng.integers(0, 7, 3000) * 3          # labels 0,3,..,18
+    seg[:40] = 21                               # a small part
+    lab = np.unique(seg)
+    ref = S.part_fps(cano, seg, lab, 20)
+    pts, idx = gu.fps_sample_cano(T_(cano, dev), T_(seg, dev), T_(lab, dev), num_fps=20)
+    same(idx, ref)
+    grid = np.stack(np.meshgrid(np.arange(8), np.arange(8), np.arange(8)), -1).reshape(-1, 3).astype(np.float32) * 0.1
+    seg2 = (np.arange(512) % 2)                 # lattice: every round is a tie
+    ref2 = S.part_fps(grid, seg2, np.array([0, 1]), 20)
+    _, idx2 = gu.fps_sample_cano(T_(grid, dev), T_(seg2, dev), T_(np.array([0, 1]), dev), num_fps=20)
+    same(idx2, ref2)
