@@ -374,7 +374,7 @@ int reart_knn_points_idx_warm(const float *p1, const float *p2, int N, int P1, i
 
 /* Replaces `[linear_sum_assignment(c) for c in cost]` / `parallel_lap(cost)` of the assignment loss
  * (run_robot.py:172-176, utils/model_utils.py:85-89) for square cost matrices.
- *   cost [B,n,n] fp32, n <= 2048; col4row [B,n] i32 = column assigned to row i (minimum total cost).
+ *   cost [B,n,n] fp32, n <= 4096; col4row [B,n] i32 = column assigned to row i (minimum total cost).
  * epsilon-scaling auction + an exact dual certificate in fp64: certified[b] = 1 means the assignment of matrix
  * b is optimal (equal to scipy's whenever the optimum is unique); certified[b] = 0 means the certificate
  * did not close and the caller must solve that matrix with the host solver (the Python wrapper does).

@@ -21,7 +21,8 @@
 #include <math.h>
 
 #define LAP_BS 1024
-#define LAP_NMAX 2048
+#define LAP_NMAX 4096
+#define LAP_NLDS 2048   // up to here the rows' bids live in LDS too; above, in the workspace (36 B of LDS per row/column)
 
 struct LapArgs {
     const float *cost;     // [B][n][n]
@@ -29,6 +30,7 @@ struct LapArgs {
     int *col4row;          // [B][n]
     int *certified;        // [B]
     double *price_out;     // [B][n] final potentials (workspace)
+    double *pbval_ws;      // [B][n] rows' bids when n > LAP_NLDS (LDS holds the rest of the state)
     int max_rounds_cert;
     int *stats;            // nullable [B][4]: phases, auction rounds, bids, certificate rounds
     double eps0, theta_inv, eps_final;   // first epsilon and final epsilon as fractions of the largest cost, 1 / scaling factor
@@ -73,8 +75,9 @@ __global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
     constexpr int NW = LAP_BS / 64;
     double *price = (double *)lsm;                                  // [n] column prices
     unsigned long long *bidval = (unsigned long long *)(price + n); // [n] highest bid (ordered key)
-    double *pbval = (double *)(bidval + n);                         // [n] row's bid
-    int *owner = (int *)(pbval + n);                                // [n] column -> row
+    const bool bids_in_lds = n <= LAP_NLDS;
+    double *pbval = bids_in_lds ? (double *)(bidval + n) : a.pbval_ws + (size_t)b * n;   // [n] row's bid
+    int *owner = (int *)(bidval + n + (bids_in_lds ? n : 0));       // [n] column -> row
     int *assigned = owner + n;                                      // [n] row -> column
     int *bidder = assigned + n;                                     // [n] winning row of the round
     int *pbobj = bidder + n;                                        // [n] row's bid column
@@ -239,10 +242,11 @@ __global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
 
 extern "C" size_t reart_lap_workspace_bytes(int B, int n) {
     if (B < 0 || n < 1 || n > LAP_NMAX) return 0;
-    return reart_align_up(sizeof(double) * (size_t)B * n, 256) + reart_align_up(sizeof(int) * 4 * (size_t)B, 256);
+    return reart_align_up(sizeof(double) * (size_t)B * n, 256) + reart_align_up(sizeof(int) * 4 * (size_t)B, 256) +
+           (n > LAP_NLDS ? reart_align_up(sizeof(double) * (size_t)B * n, 256) : 0);
 }
 
-// cost [B,n,n] fp32 (row-major: rows = sources), n <= 2048.  col4row [B,n] i32: column assigned to each row
+// cost [B,n,n] fp32 (row-major: rows = sources), n <= 4096.  col4row [B,n] i32: column assigned to each row
 // (minimum total cost); certified [B] i32: 1 when the dual certificate closed (the assignment is optimal),
 // 0 when the caller must solve that matrix on the host.  price_in (nullable, [B,n] f64): potentials returned for
 // an earlier, similar batch (the loop re-solves slowly moving matrices) -- the auction then starts from them
@@ -266,7 +270,8 @@ extern "C" int reart_lap_auction(const float *cost, int B, int n, int32_t *col4r
         a.eps_final = ef ? atof(ef) : 1e-11;
     }
     a.stats = (int *)((char *)workspace + reart_align_up(sizeof(double) * (size_t)B * n, 256));   // diagnostics, after the potentials
-    const size_t lds = (size_t)n * (3 * 8 + 5 * 4);
+    a.pbval_ws = (double *)((char *)a.stats + reart_align_up(sizeof(int) * 4 * (size_t)B, 256));
+    const size_t lds = (size_t)n * ((n <= LAP_NLDS ? 3 : 2) * 8 + 5 * 4);
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void *)lap_auction_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)

@@ -22,7 +22,7 @@ def linear_sum_assignment_batch(cost, return_stats=False, state=None):
     col = torch.empty((B, n), dtype=torch.int32, device=cost.device)
     cert = torch.empty((B,), dtype=torch.int32, device=cost.device)
     nbytes = L.reart_lap_workspace_bytes(B, n)
-    if nbytes == 0:   # n > 2048: beyond the kernel's LDS state -- the reference's host solver
+    if nbytes == 0:   # n > 4096: beyond the kernel's LDS state -- the reference's host solver
         from scipy.optimize import linear_sum_assignment
 
         out = [linear_sum_assignment(c) for c in cost.cpu().numpy()]

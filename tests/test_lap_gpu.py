@@ -32,6 +32,14 @@ def test_lap_random_matrices(dev, n):
     _compare(cost, dev)
 
 
+def test_lap_above_the_lds_resident_size(dev):
+    """n > 2048: the rows' bids move to the workspace (full-size compute_ass_err runs 4096 x 4096)."""
+    rng = np.random.default_rng(77)
+    pts = rng.uniform(-0.3, 0.3, (2, 2500, 3)).astype(np.float32)
+    cost = torch.cdist(torch.from_numpy(pts[:1]), torch.from_numpy(pts[1:] + 0.01)).numpy().astype(np.float32)
+    assert _compare(cost, dev) == 0
+
+
 def test_lap_point_cloud_costs(dev):
     """The loop's matrices: Euclidean distances between two FPS subsets of nearly the same cloud."""
     from reart_amd.synthetic import make_sequence

@@ -200,3 +200,27 @@ def test_part_fps_random_labels_vs_oracle(dev):
     ref2 = S.part_fps(grid, seg2, np.array([0, 1]), 20)
     _, idx2 = gu.fps_sample_cano(T_(grid, dev), T_(seg2, dev), T_(np.array([0, 1]), dev), num_fps=20)
     same(idx2, ref2)
+
+
+def test_whole_tail_from_the_checkpoint_outputs(dev):
+    """reart_amd.tail on the base-2 checkpoint's forward outputs: the reference's structure, energies and metrics."""
+    from reart_amd import tail
+
+    cano, pcs = T_(G["cano"], dev), T_(G["pc_list"], dev)
+    seg, trans, conn = tail.extract_structure(T_(G["seg0"], dev), T_(G["trans0"], dev), cano)
+    same(seg, G["new_seg"])
+    same(conn, G["new_conn"])
+    e = tail.energy_terms(cano, pcs, seg, trans, conn, int(G["cano_idx"]))
+    close(e["ass_err"], 100 * G["ass_err"], atol=1e-7, rtol=2e-5)
+    close(e["screw_err"], G["screw_err"], atol=1e-8)
+    close(e["group_err"], G["group_err"], atol=1e-9, rtol=1e-5)
+    sample = dict(gt_flow_list=G["gt_flow_list"], gt_cano_part=G["gt_cano_part"], complete_gt_pc_list=G["complete_gt_pc_list"])
+    m = tail.snapshot_metrics(cano, pcs, seg, trans, int(G["cano_idx"]), sample)
+    close(m["epe"], 100 * G["epe"], rtol=1e-5)
+    close(m["acc5"], G["acc5"], atol=1e-6)
+    close(m["acc10"], G["acc10"], atol=1e-6)
+    close(m["angle"], G["angle"], rtol=2e-5)
+    close(m["ri"], G["ri"], atol=1e-7)
+    close(m["recon_err"], G["recon_err"], rtol=1e-5)
+    new_seg, kw = tail.kinematic_init(seg, trans, conn)
+    close(kw["theta_list"], G["theta_list"])
