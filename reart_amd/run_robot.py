@@ -15,8 +15,12 @@ What is built: the loop itself.
     ``blend_anchor_motion``, ``flow_loss``, FPS) and ``torch.optim.Adam``; the linear assignment of the
     reference (``run_robot.py:172-176``, scipy on a process pool) runs on the GPU (``reart_lap_auction``:
     auction + exact dual certificate, host fallback for an uncertified matrix).
-What is NOT built (SURVEY.md section 8 out of scope): visualisation, GT-graph evaluation, structure
-extraction (merging / MST / ik) and ``result.txt``; a snapshot prints the losses and the Chamfer error.
+  * end of run (``run_robot.py:224-330``): ``reart_amd.tail`` -- denoise / merge / spanning tree / renumbering,
+    the model-selection energy (assignment, screw and group errors), ``result.pkl`` / ``result.txt`` /
+    ``model.pth.tar`` with the reference's keys; ``--model kinematic --base_result_path result.pkl`` builds the
+    joint tree from a base result (``run_robot.py:101-124``).
+What is NOT built (SURVEY.md section 8 out of scope): visualisation (gif / html), the GT-graph tree edit distance
+(``apted``), inverse-kinematics retargeting; ground-truth metrics are printed when the sample carries ground truth.
 
 Data: ``--seq_path`` with the reference's pickle layout (``dataset/dataset_robot.py``), or
 ``--synthetic`` for the generated articulated sequence of ``reart_amd/synthetic.py``.
@@ -118,15 +122,32 @@ def main(args):
             tau_func = lambda cur_iter: fixed_tau
             assert args.cano_idx == ckpt.get("cano_idx", args.cano_idx)
     else:
-        if args.resume is None:
-            raise SystemExit("--model kinematic needs --resume (graph construction from a base result is "
-                             "structure extraction: out of scope, SURVEY.md section 8)")
-        ckpt = torch.load(args.resume[0], map_location=device, weights_only=False)
-        model = KinematicModel(pose_len=pc_list.shape[0], seg_part=ckpt["seg_part"].to(device),
-                               cano_pc=ckpt["cano_pc"].to(device), knn=KNN(k=1, transpose_mode=True),
-                               edge_index=ckpt["edge_index"], paths_to_base=ckpt["paths_to_base"],
-                               reverse_topo=ckpt["reverse_topo"])
-        model.load_state_dict(ckpt["state_dict"], strict=True)
+        if args.resume is None:  # run_robot.py:101-124: joint tree from a base result
+            assert args.base_result_path is not None, "--model kinematic needs --base_result_path or --resume"
+            from reart_amd import tail
+
+            with open(args.base_result_path, "rb") as f:
+                result = pickle.load(f)
+            print(f"load base result from {args.base_result_path}")
+            assert args.cano_idx == result["cano_idx"]
+            seg_part = torch.from_numpy(np.asarray(result["pred_cano_part"])).long().to(device)
+            trans_list = torch.from_numpy(np.asarray(result["pred_pose_list"])).float().to(device)
+            if "joint_connection" in result:
+                joint_connection = torch.from_numpy(np.array(result["joint_connection"])).long().to(device)
+            else:
+                seg_part, trans_list, joint_connection = tail.extract_structure(
+                    seg_part, trans_list, cano_pc, merge_thr=args.merge_thr, cano_dist_thr=args.cano_dist_thr,
+                    lambda_joint=args.lambda_joint, min_num=0)
+            new_seg, kin_kwargs = tail.kinematic_init(seg_part, trans_list, joint_connection)
+            model = KinematicModel(pose_len=pc_list.shape[0], seg_part=new_seg, cano_pc=cano_pc,
+                                   knn=KNN(k=1, transpose_mode=True), **kin_kwargs)
+        else:
+            ckpt = torch.load(args.resume[0], map_location=device, weights_only=False)
+            model = KinematicModel(pose_len=pc_list.shape[0], seg_part=ckpt["seg_part"].to(device),
+                                   cano_pc=ckpt["cano_pc"].to(device), knn=KNN(k=1, transpose_mode=True),
+                                   edge_index=ckpt["edge_index"], paths_to_base=ckpt["paths_to_base"],
+                                   reverse_topo=ckpt["reverse_topo"])
+            model.load_state_dict(ckpt["state_dict"], strict=True)
     model.to(device)
     chamfer_dist = ChamferDistance()
     knn_flow = KNN(k=3, transpose_mode=True)
@@ -243,16 +264,67 @@ def main(args):
             i += 1
     if args.evaluate:
         snapshot(0, {})
-    else:  # checkpoint with the reference's keys (run_robot.py:340-356)
-        tau = tau_func(cur_iter=n_iter)
-        model_dict = {"state_dict": model.state_dict(), "tau": tau, "cano_idx": args.cano_idx}
-        if isinstance(model, KinematicModel):
-            model_dict.update(seg_part=model.seg_part, cano_pc=model.cano_pc, edge_index=model.edge_index,
-                              paths_to_base=model.paths_to_base, reverse_topo=model.reverse_topo)
-        torch.save(model_dict, os.path.join(save_dir, "model.pth.tar"))
-        print("saved", os.path.join(save_dir, "model.pth.tar"))
+    finish(args, model, cano_pc, pc_list, sample, save_dir, tau_func(cur_iter=n_iter))
     print("all done!")
     return model
+
+
+def finish(args, model, cano_pc, pc_list, sample, save_dir, tau):
+    """run_robot.py:227-356: structure, energies, result files (the reference's file names and keys)."""
+    from reart_amd import tail
+    from reart_amd.utils.kinematic_utils import edge_index2edges
+    from reart_amd.utils.model_utils import compute_pc_transform
+
+    device = cano_pc.device
+    with torch.no_grad():
+        _, seg_part, trans_list = model(cano_pc)
+    trans_list = trans_list.detach()
+    if isinstance(model, KinematicModel):   # the tree is the model's own (run_robot.py:235-237)
+        from reart_amd.utils.graph_utils import denoise_seg_label
+
+        seg_part = denoise_seg_label(seg_part.clone(), cano_pc, KNN(k=1, transpose_mode=True), min_num=20)
+        conn = torch.tensor(edge_index2edges(model.edge_index), dtype=torch.long, device=device)
+        from reart_amd.utils.kinematic_utils import extract_kinematic
+
+        seg_part, trans_list, conn = extract_kinematic(seg_part, trans_list, conn)
+    else:
+        seg_part, trans_list, conn = tail.extract_structure(
+            seg_part, trans_list, cano_pc, merge_thr=args.merge_thr, merge_it=args.merge_it,
+            cano_dist_thr=args.cano_dist_thr, lambda_joint=args.lambda_joint)
+    conn_list = conn.cpu().numpy().tolist()
+    print("parts:", trans_list.shape[1], "| joint connection:", conn_list)
+    metrics = tail.snapshot_metrics(cano_pc, pc_list, seg_part, trans_list, args.cano_idx, sample)
+    if "epe" in metrics:
+        print(f"Flow eval: EPE: {metrics['epe']:.3f} | Acc 5: {metrics['acc5']:.3f} | Acc 10: {metrics['acc10']:.3f} | "
+              f"Angle: {metrics['angle']:.3f}")
+    if "ri" in metrics:
+        print(f"Seg eval: RI: {metrics['ri']:.3f}")
+    if "recon_err" in metrics:
+        print(f"Recon eval: recon: {metrics['recon_err']:.3f}")
+    with open(os.path.join(save_dir, "result.txt"), "w") as f_result:
+        for k in ("recon_err", "epe", "acc5", "acc10", "angle", "ri", "cd_err"):
+            if k in metrics:
+                f_result.write(f"{k}: {metrics[k]:.3f}\n")
+        if not args.evaluate:
+            energy = tail.energy_terms(cano_pc, pc_list, seg_part, trans_list, conn, args.cano_idx)
+            print(f"Energy eval: total: {energy['total_err']:.3f}")
+            for k in ("ass_err", "screw_err", "group_err", "total_err"):
+                print(f"{k}: {energy[k]:.3f}")
+                f_result.write(f"{k}: {energy[k]:.3f}\n")
+            print(f"cd_err: {metrics['cd_err']:.3f}")
+    if args.evaluate:
+        return
+    save_dict = {"pred_cano_part": seg_part.cpu().numpy(), "pred_pose_list": trans_list.cpu().numpy(),
+                 "cano_idx": args.cano_idx, "joint_connection": conn_list}
+    save_dict.update(sample)
+    with open(os.path.join(save_dir, "result.pkl"), "wb") as f:
+        pickle.dump(save_dict, f)
+    model_dict = {"state_dict": model.state_dict(), "tau": tau, "cano_idx": args.cano_idx}
+    if isinstance(model, KinematicModel):
+        model_dict.update(seg_part=model.seg_part, cano_pc=model.cano_pc, edge_index=model.edge_index,
+                          paths_to_base=model.paths_to_base, reverse_topo=model.reverse_topo)
+    torch.save(model_dict, os.path.join(save_dir, "model.pth.tar"))
+    print("saved", os.path.join(save_dir, "result.pkl"), "and", os.path.join(save_dir, "model.pth.tar"))
 
 
 def build_parser():

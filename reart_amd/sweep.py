@@ -11,7 +11,41 @@ rank can take the arg-min.
 import torch
 import torch.distributed as dist
 
-RECORD = 8  # floats per instance: [instance id, cano_idx, recon, flow, total, iterations, 0, 0]
+# floats per instance (a fixed 16-float record):
+# [instance id, cano_idx, recon loss, flow loss, total loss, iterations, failed, parts,
+#  total_err, ass_err, screw_err, group_err, cd_err, 0, 0, 0]   (energies: run_robot.py:306-321; NaN when not computed)
+RECORD = 16
+E_TOTAL = 8
+
+
+def _record(inst, spec, losses=None, done=0, failed=0, energy=None):
+    nan = float("nan")
+    rec = [inst, spec.get("cano_idx", -1)] + (list(losses) if losses is not None else [nan] * 3) + [done, failed]
+    if energy is None:
+        rec += [nan] * 6
+    else:
+        rec += [energy.get("parts", nan), energy["total_err"], energy["ass_err"], energy["screw_err"], energy["group_err"],
+                energy.get("cd_err", nan)]
+    return torch.tensor(rec + [0.0] * (RECORD - len(rec)), dtype=torch.float32)
+
+
+def best_instance(records):
+    """Index of the instance the reference would keep: lowest energy (README.md:60); the final loss decides when no
+    energies were computed."""
+    key = records[:, E_TOTAL].clone()
+    if torch.isnan(key).all():
+        key = records[:, 4].clone()
+    key[torch.isnan(key)] = float("inf")
+    return int(torch.argmin(key).item())
+
+
+def instance_energy(eng, spec, **thresholds):
+    """Structure + model-selection energy of a finished engine (reart_amd.tail) -> dict for the record."""
+    from . import tail
+
+    res = tail.finish_instance(eng.model, eng.cano, eng.pc_list, int(spec.get("cano_idx", eng.cfg.cano_idx)), **thresholds)
+    res["parts"] = int(res["trans_list"].shape[1])
+    return res
 
 
 def shard(n_instances, rank, world):
@@ -51,17 +85,15 @@ def run_sweep(instances, run_instance, device):
         spec = instances[inst]
         try:
             res = run_instance(spec)
-            rec = [inst, spec.get("cano_idx", -1), res["recon"], res["flow"], res["total"], res["iterations"], 0, 0]
+            local[inst] = _record(inst, spec, (res["recon"], res["flow"], res["total"]), res["iterations"], 0,
+                                  res if "total_err" in res else None)
         except Exception:  # a failed instance is reported (NaN energy), it does not kill the job
-            rec = [inst, spec.get("cano_idx", -1), float("nan"), float("nan"), float("nan"), 0, 1, 0]
-        local[inst] = torch.tensor(rec, dtype=torch.float32)
+            local[inst] = _record(inst, spec, failed=1)
     records = gather_records(local, len(instances), device)
-    total = records[:, 4].clone()
-    total[torch.isnan(total)] = float("inf")
-    return records, int(torch.argmin(total).item())
+    return records, best_instance(records)
 
 
-def run_sweep_engines(instances, make_engine, n_iter, device, per_gpu=3, chunk=100):
+def run_sweep_engines(instances, make_engine, n_iter, device, per_gpu=3, chunk=100, energy=False):
     """Sweep of fused-loop instances with ``per_gpu`` of them in flight per GPU.
 
     One instance of the relaxation loop is a chain of short, latency-bound launches that leaves
@@ -69,7 +101,8 @@ def run_sweep_engines(instances, make_engine, n_iter, device, per_gpu=3, chunk=1
     8.0 k it/s for one instance, 14.2 k it/s aggregate for three).  ``make_engine(spec)`` returns a
     prepared ``reart_amd.relax.RelaxEngine`` (its tensors live on ``device``); this rank's instances
     are optimised ``per_gpu`` at a time, stepped round-robin in graph replays of ``chunk``
-    iterations.  Returns (records [n, RECORD], index of the lowest-energy instance) like ``run_sweep``."""
+    iterations.  ``energy=True`` finishes every instance with the reference's structure extraction and energy terms
+    (``instance_energy``), which then decide the winner.  Returns (records [n, RECORD], best index) like ``run_sweep``."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     mine = shard(len(instances), rank, world)
@@ -86,8 +119,7 @@ def run_sweep_engines(instances, make_engine, n_iter, device, per_gpu=3, chunk=1
                     done = eng.capture(steps_per_graph=min(chunk, n_iter))
                 live.append([inst, spec, eng, st, done])
             except Exception:  # a failed instance is reported (NaN energy), it does not kill the job
-                local[inst] = torch.tensor([inst, spec.get("cano_idx", -1), float("nan"), float("nan"), float("nan"), 0, 1, 0],
-                                           dtype=torch.float32)
+                local[inst] = _record(inst, spec, failed=1)
         while any(e[4] < n_iter for e in live):
             for e in live:
                 if e[4] < n_iter:
@@ -98,9 +130,13 @@ def run_sweep_engines(instances, make_engine, n_iter, device, per_gpu=3, chunk=1
         for inst, spec, eng, st, done in live:
             st.synchronize()
             row = eng.last_losses().cpu()
-            local[inst] = torch.tensor([inst, spec.get("cano_idx", -1), float(row[0]), float(row[1]), float(row[2]), done, 0, 0],
-                                       dtype=torch.float32)
+            en = None
+            if energy:
+                try:
+                    with torch.cuda.stream(st):
+                        en = instance_energy(eng, spec)
+                except Exception:      # e.g. every part merged away: the losses still describe the instance
+                    en = None
+            local[inst] = _record(inst, spec, (float(row[0]), float(row[1]), float(row[2])), done, 0, en)
     records = gather_records(local, len(instances), device)
-    total = records[:, 4].clone()
-    total[torch.isnan(total)] = float("inf")
-    return records, int(torch.argmin(total).item())
+    return records, best_instance(records)

@@ -96,7 +96,8 @@ def _effective_joint_values(theta_list, distance_list, joint_type_list):
 def extract_kinematic(seg_part, trans_list, joint_connection):
     """utils/kinematic_utils.py:18-34: renumber the surviving parts 0..P-1 in label order."""
     uni_label = torch.unique(seg_part, sorted=True)
-    assert torch.equal(torch.unique(joint_connection, sorted=True), uni_label)
+    if joint_connection.numel():       # a single surviving part has no edges
+        assert torch.equal(torch.unique(joint_connection, sorted=True), uni_label)
     new_seg = torch.searchsorted(uni_label, seg_part.contiguous())
     new_conn = torch.searchsorted(uni_label, joint_connection.contiguous())
     return new_seg, trans_list[:, uni_label], new_conn

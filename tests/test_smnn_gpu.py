@@ -48,3 +48,29 @@ def test_run_robot_driver_synthetic(dev, tmp_path):
     assert set(ck) == {"state_dict", "tau", "cano_idx"} and ck["cano_idx"] == 2
     assert {"proposal_6d", "proposal_t", "seg_head.model.0.weight", "seg_head.model.2.weight"} <= set(ck["state_dict"])
     assert all(torch.isfinite(p).all() for p in model.parameters())
+
+
+def test_run_robot_end_of_run_files_and_kinematic_from_base_result(dev, tmp_path):
+    """End of run (run_robot.py:224-356): result.pkl / result.txt / model.pth.tar with the reference's keys, then the
+    kinematic model built from that base result (run_robot.py:101-124) optimises and saves its tree."""
+    import pickle
+
+    from reart_amd.run_robot import build_parser, main
+
+    base = ["--synthetic", "--synthetic_frames", "6", "--num_points", "1024", "--cano_idx", "2", "--snapshot_gap", "500"]
+    main(build_parser().parse_args(base + ["--n_iter", "1500", "--save_root", str(tmp_path / "base")]))
+    res_path = next((tmp_path / "base").rglob("result.pkl"))
+    with open(res_path, "rb") as f:
+        res = pickle.load(f)
+    assert {"pred_cano_part", "pred_pose_list", "cano_idx", "joint_connection", "cano_pc", "pc_list"} <= set(res)
+    P = res["pred_pose_list"].shape[1]
+    assert res["pred_pose_list"].shape == (5, P, 4, 4) and res["pred_cano_part"].max() == P - 1
+    assert len(res["joint_connection"]) == P - 1
+    txt = next((tmp_path / "base").rglob("result.txt")).read_text()
+    assert "total_err" in txt and "ass_err" in txt and "cd_err" in txt
+    if P > 1:
+        model = main(build_parser().parse_args(base + ["--model", "kinematic", "--base_result_path", str(res_path),
+                                                       "--n_iter", "40", "--save_root", str(tmp_path / "kin")]))
+        ck = torch.load(next((tmp_path / "kin").rglob("model.pth.tar")), weights_only=False)
+        assert {"state_dict", "tau", "cano_idx", "seg_part", "cano_pc", "edge_index", "paths_to_base", "reverse_topo"} <= set(ck)
+        assert len(ck["edge_index"]) == P - 1 and all(torch.isfinite(p).all() for p in model.parameters())

@@ -33,3 +33,33 @@ def test_concurrent_instances_match_solo_runs(dev):
         solo = eng.last_losses().cpu().numpy()
         np.testing.assert_array_equal(rec[c, 2:5], solo[:3])
     assert best == int(np.argmin(rec[:, 4]))
+
+
+def test_sweep_records_carry_the_reference_energy(dev):
+    """energy=True: every instance ends with structure extraction + the model-selection energy (run_robot.py:306-321);
+    the record equals a solo run's tail and the winner is the lowest total energy."""
+    from reart_amd import sweep
+    from reart_amd.networks.model import BaseModel
+    from reart_amd.relax import RelaxEngine
+    from reart_amd.synthetic import make_sequence, split_canonical
+
+    seq = make_sequence(T=5, n_parts=3, pts_per_part=300, seed=4, with_flow=False)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+    def make_engine(spec):
+        cano, pcs = split_canonical(seq["complete"], spec["cano_idx"])
+        torch.manual_seed(spec["cano_idx"])
+        model = BaseModel(num_parts=6, pose_len=4).to(dev)
+        return RelaxEngine(t(cano), t(pcs), model, spec["cano_idx"], n_iter=400, seed=3 + spec["cano_idx"])
+
+    instances = [{"cano_idx": c} for c in (1, 2, 3)]
+    rec, best = sweep.run_sweep_engines(instances, make_engine, 400, dev, per_gpu=3, chunk=100, energy=True)
+    rec = rec.cpu().numpy()
+    assert rec.shape == (3, sweep.RECORD) and np.isfinite(rec[:, 7:13]).all()
+    np.testing.assert_allclose(rec[:, 8], rec[:, 9] + rec[:, 10] + rec[:, 11], rtol=1e-6)
+    assert best == int(np.argmin(rec[:, 8]))
+    eng = make_engine(instances[1])
+    eng.step(400)
+    solo = sweep.instance_energy(eng, instances[1])
+    np.testing.assert_allclose(rec[1, 8:12], [solo["total_err"], solo["ass_err"], solo["screw_err"], solo["group_err"]], rtol=1e-6)
+    assert rec[1, 7] == solo["parts"]
