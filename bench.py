@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--instances-per-gpu", type=int, default=1,
                     help="sweep mode: K independent instances share each GPU on separate streams (secondary figure; "
                          "the headline is K=1)")
+    ap.add_argument("--no-tail", action="store_true", help="skip the end-of-run structure / energy timing (secondary figure)")
     ap.add_argument("--sweep-instances", type=int, default=3,
                     help="after the headline (one instance per GPU) also time this many concurrent instances per GPU on "
                          "separate streams and report the aggregate as `sweep` (0 = skip)")
@@ -241,6 +242,33 @@ def main():
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(seq, T, N, cano_idx)
+        # secondary figure: what ends an instance (reference run_robot.py:224-330) -- structure extraction and
+        # the model-selection energy on the state reached above; outside the timed region, never part of `value`
+        end_of_run = None
+        if not args.no_tail:
+            try:
+                from reart_amd import tail
+
+                def _timed(fn):
+                    torch.cuda.synchronize()
+                    t_ = time.perf_counter()
+                    r_ = fn()
+                    torch.cuda.synchronize()
+                    return r_, 1e3 * (time.perf_counter() - t_)
+
+                with torch.no_grad():
+                    _, seg0, trans0 = eng.model(eng.cano)
+                tail.extract_structure(seg0, trans0, eng.cano)                   # warm-up (lazy module / kernel load)
+                (seg_s, trans_s, conn_s), ms_struct = _timed(lambda: tail.extract_structure(seg0, trans0, eng.cano))
+                en, ms_energy = _timed(lambda: tail.energy_terms(eng.cano, eng.pc_list, seg_s, trans_s, conn_s, cano_idx))
+                end_of_run = {"structure_ms": round(ms_struct, 3), "energy_ms": round(ms_energy, 3),
+                              "parts": int(trans_s.shape[1]), "total_err": round(en["total_err"], 6),
+                              "ass_err": round(en["ass_err"], 6), "screw_err": round(en["screw_err"], 6),
+                              "group_err": round(en["group_err"], 6),
+                              "note": "after warmup+steps iterations; energy_ms is dominated by the (T-1) optimal "
+                                      "assignments of 4096 x 4096 (GPU auction + exact certificate)"}
+            except Exception as exc:      # a degenerate early state (e.g. every part merged) must not cost the bench line
+                end_of_run = {"error": f"{type(exc).__name__}: {exc}"}
         out = {
             "metric": "relaxation-loop iterations/sec",
             "value": round(world * K * args.steps / el, 3),
@@ -263,6 +291,7 @@ def main():
             "roofline": roof,
             "cpu_baseline": cpu,
             "sweep": sweep,
+            "end_of_run": end_of_run,
             "phases_ms": {k: round(v, 5) for k, v in phases.items()},
             "final_losses": {"recon": float(energies[0][0]), "flow": float(energies[0][1]),
                              "per_rank_total": [float(e[2]) for e in energies]},

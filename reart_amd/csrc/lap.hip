@@ -39,18 +39,44 @@ struct LapArgs {
 
 __device__ __forceinline__ unsigned long long lap_key(double v) { return (unsigned long long)__double_as_longlong(v); }  // v >= 0
 
-// smallest (value, column) and second smallest value of row i under prices p; all lanes get the result
-__device__ __forceinline__ void lap_row_top2(const float *__restrict__ row, const double *__restrict__ p, int n, int lane,
-                                             double &v1, int &j1, double &v2) {
+// smallest (value, column) and second smallest value of row i under prices p over the columns [jb, je); all lanes
+// get the result (an empty range gives +inf).  Exact selections only, so any split of a row into ranges followed by
+// lap_merge_top2 gives the same triple as one scan of the whole row.
+__device__ __forceinline__ void lap_row_top2_range(const float *__restrict__ row, const double *__restrict__ p, int jb, int je,
+                                                   int lane, double &v1, int &j1, double &v2) {
     v1 = INFINITY; v2 = INFINITY; j1 = 0x7fffffff;
-    for (int j0 = lane; j0 < n; j0 += 64 * 8) {     // 8 loads in flight per lane: the scan is a dependent global read
+    if ((((uintptr_t)(row + jb)) & 15) == 0) {
+        // 16-byte loads, up to 8 per lane in flight (2048 columns per pass): the scan is a dependent global read and
+        // its latency, not its bandwidth, is what a bid costs.  Each lane still meets its columns in ascending order.
+        const int je4 = jb + ((je - jb) & ~3);
+        for (int j0 = jb + 4 * lane; j0 < je4; j0 += 256 * 8) {
+            float4 r[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) r[u] = *(const float4 *)(row + (j0 + 256 * u < je4 ? j0 + 256 * u : jb));
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + 256 * u;
+                if (j < je4) {
+                    const float rr[4] = {r[u].x, r[u].y, r[u].z, r[u].w};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const double v = (double)rr[c] + p[j + c];
+                        if (v < v1) { v2 = v1; v1 = v; j1 = j + c; }
+                        else if (v < v2) v2 = v;
+                    }
+                }
+            }
+        }
+        jb = je4;     // a tail of at most three columns follows
+    }
+    for (int j0 = jb + lane; j0 < je; j0 += 64 * 8) {
         float r[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) r[u] = row[j0 + 64 * u < n ? j0 + 64 * u : lane];
+        for (int u = 0; u < 8; ++u) r[u] = row[j0 + 64 * u < je ? j0 + 64 * u : jb];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int j = j0 + 64 * u;
-            if (j < n) {
+            if (j < je) {
                 const double v = (double)r[u] + p[j];
                 if (v < v1) { v2 = v1; v1 = v; j1 = j; }
                 else if (v < v2) v2 = v;
@@ -69,6 +95,19 @@ __device__ __forceinline__ void lap_row_top2(const float *__restrict__ row, cons
     }
 }
 
+__device__ __forceinline__ void lap_row_top2(const float *__restrict__ row, const double *__restrict__ p, int n, int lane,
+                                             double &v1, int &j1, double &v2) {
+    lap_row_top2_range(row, p, 0, n, lane, v1, j1, v2);
+}
+
+__device__ __forceinline__ void lap_merge_top2(double ov1, int oj1, double ov2, double &v1, int &j1, double &v2) {
+    const bool take = (ov1 < v1) || (ov1 == v1 && oj1 < j1);
+    const double lose = take ? v1 : ov1;
+    v2 = fmin(fmin(v2, ov2), lose);
+    v1 = take ? ov1 : v1;
+    j1 = take ? oj1 : j1;
+}
+
 __global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lsm[];
     const int n = a.n, b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -82,8 +121,9 @@ __global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
     int *bidder = assigned + n;                                     // [n] winning row of the round
     int *pbobj = bidder + n;                                        // [n] row's bid column
     int *ulist = pbobj + n;                                         // [n] unassigned rows
-    __shared__ int s_cnt, s_flag;
-    __shared__ double s_red[NW], s_red2[NW];
+    __shared__ int s_cnt, s_flag, s_next;
+    __shared__ double s_red[NW], s_red2[NW], s_pv1[NW], s_pv2[NW];
+    __shared__ int s_pj1[NW];
     const float *C = a.cost + (size_t)b * n * n;
 
     // largest cost
@@ -147,30 +187,63 @@ __global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
             if (nu == 0) break;
             ++st_rounds; st_bids += nu;
             if (nu == 1) {
-                // a single bidder: no conflicts are possible, so wave 0 follows the chain (the row bids, takes the
-                // column, the displaced owner bids next, ...) without workgroup barriers until nobody is displaced.
-                // The end of a phase is mostly such chains: thousands of one-bid rounds of four barriers each otherwise.
-                if (wv == 0) {
-                    int i = ulist[0];
-                    for (;;) {
-                        double v1, v2;
-                        int j1;
-                        lap_row_top2(C + (size_t)i * n, price, n, lane, v1, j1, v2);
-                        if (!(v2 < INFINITY)) v2 = v1;
-                        const int prev = owner[j1];
+                // a single bidder: no conflicts are possible, so the chain (the row bids, takes the column, the displaced
+                // owner bids next, ...) is followed without rebuilding the bidder list until nobody is displaced.  The end
+                // of a phase is mostly such chains.  Every link is one row scan -- a dependent read of n costs -- so all
+                // 16 waves take a sixteenth of the row each; wave 0 merges the partial results and moves the price.
+                int i = ulist[0];
+                const int len = (((n + NW - 1) / NW) + 63) & ~63;
+                for (;;) {
+                    double v1, v2;
+                    int j1;
+                    lap_row_top2_range(C + (size_t)i * n, price, min(n, wv * len), min(n, (wv + 1) * len), lane, v1, j1, v2);
+                    if (lane == 0) { s_pv1[wv] = v1; s_pv2[wv] = v2; s_pj1[wv] = j1; }
+                    __syncthreads();
+                    if (wv == 0) {
+                        v1 = s_pv1[lane & (NW - 1)]; v2 = s_pv2[lane & (NW - 1)]; j1 = s_pj1[lane & (NW - 1)];
+#pragma unroll
+                        for (int o = NW / 2; o >= 1; o >>= 1)
+                            lap_merge_top2(__shfl_xor(v1, o, 64), __shfl_xor(j1, o, 64), __shfl_xor(v2, o, 64), v1, j1, v2);
                         if (lane == 0) {
+                            if (!(v2 < INFINITY)) v2 = v1;
+                            const int prev = owner[j1];
                             price[j1] = price[j1] + (v2 - v1) + eps;
                             owner[j1] = i; assigned[i] = j1;
                             if (prev >= 0) assigned[prev] = -1;
+                            s_next = prev;
                         }
-                        ++st_bids;
-                        if (prev < 0) break;
-                        i = prev;
                     }
+                    __syncthreads();
+                    ++st_bids;
+                    i = s_next;
+                    if (i < 0) break;
                 }
-                __syncthreads();
                 continue;
             }
+            if (nu * 2 <= NW) {
+                // few bidders: several waves per row (a power of two), merged by one thread per row
+                int wpr = 2;
+                while (wpr * 2 * nu <= NW) wpr *= 2;
+                const int g = wv / wpr, seg = wv % wpr;
+                const int len = (((n + wpr - 1) / wpr) + 63) & ~63;
+                if (g < nu) {
+                    double v1, v2;
+                    int j1;
+                    lap_row_top2_range(C + (size_t)ulist[g] * n, price, min(n, seg * len), min(n, (seg + 1) * len), lane, v1, j1, v2);
+                    if (lane == 0) { s_pv1[wv] = v1; s_pv2[wv] = v2; s_pj1[wv] = j1; }
+                }
+                __syncthreads();
+                if (tid < nu) {
+                    const int i = ulist[tid];
+                    double v1 = INFINITY, v2 = INFINITY;
+                    int j1 = 0x7fffffff;
+                    for (int w = tid * wpr; w < (tid + 1) * wpr; ++w) lap_merge_top2(s_pv1[w], s_pj1[w], s_pv2[w], v1, j1, v2);
+                    if (!(v2 < INFINITY)) v2 = v1;
+                    const double bid = price[j1] + (v2 - v1) + eps;
+                    pbobj[i] = j1; pbval[i] = bid;
+                    atomicMax(&bidval[j1], lap_key(bid));
+                }
+            } else
             // bids: one wave per unassigned row
             for (int u = wv; u < nu; u += NW) {
                 const int i = ulist[u];
