@@ -9,8 +9,6 @@ the edge contraction -- a few microseconds of integer work after ONE device-to-h
 No networkx here: the orderings networkx would produce (Kahn generations, adjacency insertion order) are
 written out, and the tests compare them with networkx through the oracle.
 """
-import math
-
 import numpy as np
 import torch
 
@@ -68,10 +66,6 @@ def _pair_cost(cano_fps, frame_fps=None):
 
 
 # ------------------------------------------------------------------------------------ reference interface
-def index_rows(points, idx):
-    return points[idx]
-
-
 def fps_sample_cano(cano_pc, cano_part, uni_label, num_fps=20, cuda_mode=False):
     """utils/graph_utils.py:37-52: farthest point sampling inside every part of ``uni_label`` (one launch).
     -> (points [P,num_fps,3], indices into cano_pc [P,num_fps]).  Raises ValueError for a part below num_fps."""

@@ -224,3 +224,60 @@ def test_whole_tail_from_the_checkpoint_outputs(dev):
     close(m["recon_err"], G["recon_err"], rtol=1e-5)
     new_seg, kw = tail.kinematic_init(seg, trans, conn)
     close(kw["theta_list"], G["theta_list"])
+
+
+def test_build_graph_with_joint_types_vs_oracle(dev):
+    """revolute_only=False (the reference's sapien / real drivers, utils/kinematic_utils.py:100-126): every edge is
+    fitted on its own and takes the cheaper joint type; a translating part must come out prismatic."""
+    import oracle
+    from oracle import structure as S
+    from reart_amd.utils import kinematic_utils as ku
+
+    rng = np.random.default_rng(11)
+    Tn, P = 8, 4
+    trans = np.tile(np.eye(4, dtype=np.float32), (Tn, P, 1, 1))
+    ax = np.array([[0.0, 0.0, 1.0], [0.6, 0.0, 0.8], [0.0, 1.0, 0.0]], np.float32)
+    for t in range(Tn):
+        ang = np.array([0.2 * (t + 1)], np.float32)
+        trans[t, 1] = oracle.screw_to_transform(ax[0:1], np.cross([0.1, 0.2, 0.0], ax[0])[None].astype(np.float32), ang,
+                                                np.array([1e-6], np.float32))[0]
+        trans[t, 2, :3, 3] = ax[1] * 0.03 * (t + 1)                       # slides along its axis
+        trans[t, 3] = trans[t, 1] @ oracle.screw_to_transform(ax[2:3], np.cross([0.0, 0.0, 0.3], ax[2])[None].astype(np.float32),
+                                                              -ang, np.array([1e-6], np.float32))[0]
+    edges = np.array([[1, 0], [0, 2], [3, 1]])
+    out = ku.build_graph(T_(edges, dev), T_(trans, dev), revolute_only=False, return_joint_type=True)
+    tree, root, axis, moment, theta, dist, edge_index, types = out
+    assert root == 0 and tree.edges == [(1, 0), (2, 0), (3, 1)]
+    assert types == ["revolute", "prismatic", "revolute"]
+    for k, (c, p) in enumerate(tree.edges):
+        f = S.screw_fit(S.relative_trans(trans, [p], [c]))                # E = 1: plain means, own rotation residual
+        assert (f["cost_p"][0] <= f["cost_r"][0]) == (types[k] == "prismatic")
+        close(axis[k], f["mean_axis"][0], atol=5e-6)
+        close(moment[k], f["mean_moment"][0], atol=5e-6)
+        if types[k] == "prismatic":
+            close(dist[:, k], f["distance"][:, 0], atol=5e-6)
+            close(theta[:, k], np.full(Tn, 1e-6), atol=1e-9)
+        else:
+            close(theta[:, k], f["theta"][:, 0], atol=5e-6)
+            close(dist[:, k], np.full(Tn, 1e-6), atol=1e-9)
+    # the forward kinematics of the fitted joints reproduces the motions
+    from reart_amd.utils.kinematic_utils import fk
+
+    rec = fk(tree.paths_to_base, tree.reverse_topo, edge_index, axis, moment, theta, dist, types)
+    close(rec, trans, atol=2e-4)
+
+
+def test_part_fps_cuda_tie_rule_and_small_part_error(dev):
+    from reart_amd.utils import graph_utils as gu
+
+    grid = np.stack(np.meshgrid(np.arange(6), np.arange(6), np.arange(6)), -1).reshape(-1, 3).astype(np.float32) * 0.1
+    seg = np.zeros(216, np.int64)
+    _, a = gu.fps_sample_cano(T_(grid, dev), T_(seg, dev), T_(np.array([0]), dev), num_fps=20, cuda_mode=False)
+    _, b = gu.fps_sample_cano(T_(grid, dev), T_(seg, dev), T_(np.array([0]), dev), num_fps=20, cuda_mode=True)
+    import oracle
+
+    same(a[0], oracle.fps(grid[None], 20, start=np.zeros(1, np.int64))[0])
+    same(b[0], oracle.fps(grid[None], 20, start=np.zeros(1, np.int64), cuda_mode=True)[0])
+    seg[:5] = 3
+    with pytest.raises(ValueError, match="part id 3 too small, only 5 points"):
+        gu.fps_sample_cano(T_(grid, dev), T_(seg, dev), T_(np.array([0, 3]), dev), num_fps=20)
