@@ -235,3 +235,26 @@ def linear_sum_assignment(cost):
     from scipy.optimize import linear_sum_assignment as _lsa
 
     return [_lsa(np.asarray(c)) for c in np.asarray(cost)]
+
+
+def match_smnn(desc1, desc2, th=0.9):
+    """Mutual second-nearest-neighbour ratio matching (reference utils/flow_utils.py:7-100: cdist -> topk(2) -> ratio
+    test in both directions -> mutual filter, sorted by the desc1 index) -> (pairs [M,2] int64, ratio [M] = the larger
+    of the two directions' ratios, margin = the closest any ratio comes to ``th``).  Distances in float64."""
+    a, b = np.asarray(desc1, np.float64), np.asarray(desc2, np.float64)
+    d2 = np.maximum((a * a).sum(1)[:, None] + (b * b).sum(1)[None, :] - 2.0 * a @ b.T, 0.0)
+    dm = np.sqrt(d2)
+
+    def top2(m):
+        i1 = m.argmin(1)
+        v1 = m[np.arange(m.shape[0]), i1]
+        m2 = m.copy()
+        m2[np.arange(m.shape[0]), i1] = np.inf
+        return i1, v1 / m2.min(1)
+
+    i12, r12 = top2(dm)
+    i21, r21 = top2(dm.T)
+    rows = np.nonzero((r12 <= th) & (r21[i12] <= th) & (i21[i12] == np.arange(dm.shape[0])))[0]
+    pairs = np.stack([rows, i12[rows]], 1).astype(np.int64)
+    margin = min(np.abs(r12 - th).min(), np.abs(r21 - th).min())
+    return pairs, np.maximum(r12[rows], r21[i12[rows]]), float(margin)

@@ -36,6 +36,19 @@ def test_match_smnn_vs_torch(dev):
     np.testing.assert_array_equal(got.cpu().numpy(), ref)
 
 
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_match_smnn_vs_reference_golden(dev, tag):
+    """tests/golden/smnn.npz: the reference's own match_smnn (utils/flow_utils.py:48-100) on these descriptors."""
+    import os
+
+    from reart_amd.utils.flow_utils import match_smnn
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "smnn.npz"))
+    assert float(g[f"margin_{tag}"]) > 1e-4      # no borderline ratio: the match set is well defined in fp32
+    _, got = match_smnn(torch.from_numpy(g[f"d1_{tag}"]).to(dev), torch.from_numpy(g[f"d2_{tag}"]).to(dev))
+    np.testing.assert_array_equal(got.cpu().numpy(), g[f"idx_{tag}"])
+
+
 def test_run_robot_driver_synthetic(dev, tmp_path):
     """The drop-in loop: fused phase, hand-over to the assignment-loss phase, checkpoint keys."""
     from reart_amd.run_robot import build_parser, main
