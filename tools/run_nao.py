@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""End-to-end on the reference's demo sequence (nao, 10 frames x 4096 points; clouds and ground truth travel inside
+tests/golden/structure.npz): the reference's base recipe without the flow loss (its extractor weights are not shipped)
+-- 15 000 iterations, assignment loss after 5 000 -- then structure extraction and the reference's metrics, next to the
+numbers the reference's own shipped base-2 checkpoint gives (same fixture)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from reart_amd import tail
+from reart_amd.networks.model import BaseModel
+from reart_amd.networks.pointnet2_utils import farthest_point_sample, index_points
+from reart_amd.relax import RelaxEngine
+from reart_amd.utils.lap import linear_sum_assignment_batch
+
+dev = torch.device("cuda:0")
+g = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "structure.npz"))
+t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+cano, pcs, cano_idx = t(g["cano"]), t(g["pc_list"]), int(g["cano_idx"])
+n_iter = int(os.environ.get("ITERS", 15000)); assign_iter = int(os.environ.get("ASSIGN_ITER", 5000))
+use_assign = os.environ.get("ASSIGN", "1") == "1"
+# FLOW=gt: flow references from the ground-truth flow (3000 points per frame pair) instead of the SMNN matches of the
+# unshipped extractor -- shows what the loop reaches when the flow branch has good references
+refs = flows = None
+if os.environ.get("FLOW", "") == "gt":
+    gt_pos = t(g["complete_gt_pc_list"])       # the canonical points moved by the ground-truth poses; gt_flow_list is theirs
+    rng = np.random.default_rng(0)
+    sel = [torch.from_numpy(rng.permutation(gt_pos.shape[1])[:3000]).to(dev) for _ in range(pcs.shape[0])]
+    refs = [gt_pos[k][s] for k, s in enumerate(sel)]
+    flows = [t(g["gt_flow_list"][k])[s] for k, s in enumerate(sel)]
+torch.manual_seed(2)
+model = BaseModel(num_parts=20, pose_len=pcs.shape[0]).to(dev)
+t0 = time.perf_counter()
+eng = RelaxEngine(cano, pcs, model, cano_idx, refs, flows, n_iter=n_iter, seed=2)
+i = eng.capture(steps_per_graph=10)
+first = assign_iter if use_assign else n_iter
+eng.step(first - i); i = first
+if use_assign:
+    B, N = pcs.shape[:2]; nf = N // 4; state = {}
+    while i < n_iter:
+        eng.peek_forward()
+        src = farthest_point_sample(cano[None], nf); tgt = farthest_point_sample(pcs, nf)
+        cost = torch.cdist(index_points(eng.pc_trans, src.expand(B, nf)), index_points(pcs, tgt))
+        cols = torch.from_numpy(np.stack([c for _, c in linear_sum_assignment_batch(cost, state=state)])).to(dev)
+        eng.set_assignment(src[0], tgt.gather(1, cols), 0.3)
+        eng.step(5); i += 5
+torch.cuda.synchronize(); t_opt = time.perf_counter() - t0
+sample = dict(gt_flow_list=g["gt_flow_list"], gt_cano_part=g["gt_cano_part"], complete_gt_pc_list=g["complete_gt_pc_list"])
+t0 = time.perf_counter()
+res = tail.finish_instance(model, cano, pcs, cano_idx, sample)
+torch.cuda.synchronize(); t_tail = time.perf_counter() - t0
+keys = ("total_err", "ass_err", "screw_err", "group_err", "cd_err", "epe", "acc5", "acc10", "ri", "recon_err")
+print(f"optimisation {t_opt:.2f} s ({n_iter} iterations), end of run {t_tail:.2f} s; parts {res['trans_list'].shape[1]}, tree {res['joint_connection'].tolist()}")
+print("ours     :", {k: round(float(res[k]), 4) for k in keys})
+ref = dict(total_err=100 * float(g["ass_err"]) + float(g["screw_err"]) + float(g["group_err"]), ass_err=100 * float(g["ass_err"]),
+           screw_err=float(g["screw_err"]), group_err=float(g["group_err"]), cd_err=float("nan"), epe=100 * float(g["epe"]),
+           acc5=float(g["acc5"]), acc10=float(g["acc10"]), ri=float(g["ri"]), recon_err=float(g["recon_err"]))
+print("reference:", {k: round(ref[k], 4) for k in keys}, "(shipped base-2 checkpoint: trained with flow + assignment losses)")
