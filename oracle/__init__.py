@@ -258,3 +258,12 @@ def match_smnn(desc1, desc2, th=0.9):
     pairs = np.stack([rows, i12[rows]], 1).astype(np.int64)
     margin = min(np.abs(r12 - th).min(), np.abs(r21 - th).min())
     return pairs, np.maximum(r12[rows], r21[i12[rows]]), float(margin)
+
+
+def cdist(a, b):
+    """Euclidean cost matrices of the assignment loss (reference run_robot.py:171 / utils/model_utils.py:93,
+    `torch.cdist`), by the library-wide distance contract: sqrt(((dx*dx)+(dy*dy))+(dz*dz)) in fp32.  [B,n,3],[B,m,3] -> [B,n,m]."""
+    a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+    d = a[:, :, None, :] - b[:, None, :, :]
+    sq = (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
+    return np.sqrt(sq, dtype=np.float32)

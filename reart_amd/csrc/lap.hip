@@ -355,3 +355,38 @@ extern "C" int reart_lap_auction(const float *cost, int B, int n, int32_t *col4r
     REART_CHECK_LAUNCH();
     return REART_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// Cost matrices of the assignment loss / assignment error: Euclidean distances between two batches of points
+// (`torch.cdist(pc_src, pc_tgt)` at run_robot.py:171 and utils/model_utils.py:93).  Direct differences in fp32,
+// ((dx*dx)+(dy*dy))+(dz*dz) then sqrt -- the library-wide distance contract -- and one pass over the output, which is
+// all the traffic there is (B*n*m*4 bytes; torch's matmul-based cdist took 17 ms for 19 x 1024 x 1024 here).
+__global__ __launch_bounds__(256) void cdist_kernel(const float *__restrict__ a, const float *__restrict__ b, int n, int m,
+                                                    float *__restrict__ out) {
+    const int bi = blockIdx.z, i = blockIdx.y;
+    const float *pa = a + ((size_t)bi * n + i) * 3;
+    const float ax = pa[0], ay = pa[1], az = pa[2];
+    const float *pb = b + (size_t)bi * m * 3;
+    float *o = out + ((size_t)bi * n + i) * m;
+    for (int j = (blockIdx.x * 256 + threadIdx.x) * 4; j < m; j += gridDim.x * 256 * 4) {
+        float r[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int jj = j + c < m ? j + c : m - 1;
+            r[c] = sqrtf(reart_sqdist3(ax, ay, az, pb[3 * jj], pb[3 * jj + 1], pb[3 * jj + 2]));
+        }
+        if (j + 3 < m && (((size_t)(o + j)) & 15) == 0) *(float4 *)(o + j) = make_float4(r[0], r[1], r[2], r[3]);
+        else
+            for (int c = 0; c < 4 && j + c < m; ++c) o[j + c] = r[c];
+    }
+}
+
+extern "C" int reart_cdist(const float *a, const float *b, int B, int n, int m, float *out, void *stream) {
+    if (B < 0 || n < 0 || m < 0 || n > 65535 || B > 65535) return REART_ERR_INVALID_ARG;
+    if (B == 0 || n == 0 || m == 0) return REART_OK;
+    if (!a || !b || !out) return REART_ERR_INVALID_ARG;
+    const int gx = (m + 1023) / 1024 < 4 ? (m + 1023) / 1024 : 4;
+    hipLaunchKernelGGL(cdist_kernel, dim3(gx, n, B), dim3(256), 0, (hipStream_t)stream, a, b, n, m, out);
+    REART_CHECK_LAUNCH();
+    return REART_OK;
+}

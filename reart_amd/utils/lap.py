@@ -8,6 +8,19 @@ import torch
 from .. import _lib
 
 
+def cdist(a, b):
+    """``torch.cdist(a, b)`` for point batches a [B,n,3], b [B,m,3] -> [B,n,m] Euclidean distances by direct
+    differences (run_robot.py:171, utils/model_utils.py:93): one pass over the output."""
+    _lib.require_gpu(a, b)
+    a, b = a.detach().contiguous().float(), b.detach().contiguous().float()
+    if a.dim() != 3 or b.dim() != 3 or a.shape[0] != b.shape[0] or a.shape[2] != 3 or b.shape[2] != 3:
+        raise ValueError("cdist expects [B,n,3] and [B,m,3]")
+    out = torch.empty((a.shape[0], a.shape[1], b.shape[1]), dtype=torch.float32, device=a.device)
+    rc = _lib.lib().reart_cdist(_lib.ptr(a), _lib.ptr(b), a.shape[0], a.shape[1], b.shape[1], _lib.ptr(out), _lib.stream())
+    _lib.check(rc, "reart_cdist")
+    return out
+
+
 def linear_sum_assignment_batch(cost, return_stats=False, state=None):
     """cost [B,n,n] float32 CUDA tensor (square) -> list of (row_ind, col_ind) int64 numpy arrays, like
     ``[scipy.optimize.linear_sum_assignment(c) for c in cost]`` (rows in ascending order).

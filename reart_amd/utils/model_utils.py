@@ -64,11 +64,11 @@ def parallel_lap(cost, nproc=None):
 def compute_ass_err(pc_trans_list, pc_list, use_nproc=True):
     """utils/model_utils.py:92-104: mean squared distance under each frame's optimal one-to-one assignment
     (Euclidean cost)."""
-    from .lap import linear_sum_assignment_batch
+    from .lap import cdist, linear_sum_assignment_batch
 
     _lib.require_gpu(pc_trans_list, pc_list)
     with torch.no_grad():
-        cost = torch.cdist(pc_trans_list, pc_list)
+        cost = cdist(pc_trans_list, pc_list)
         cols = torch.from_numpy(np.stack([c for _, c in linear_sum_assignment_batch(cost)])).to(pc_list.device)
         matched = torch.gather(pc_list, 1, cols[..., None].expand(-1, -1, 3))
         return ((pc_trans_list - matched) ** 2).sum(dim=-1).mean()

@@ -82,3 +82,20 @@ def test_lap_warm_start_same_result(dev):
             rr, cc = linear_sum_assignment(cost[b])
             np.testing.assert_array_equal(c, cc)
     assert state["prices"].shape == (2, 256)
+
+
+def test_cdist_matches_oracle_bitwise_and_torch(dev):
+    """reart_cdist (the cost matrices of the assignment loss / error) = the oracle's direct-difference distances bit
+    for bit; torch.cdist agrees to rounding."""
+    import oracle
+    from reart_amd.utils.lap import cdist
+
+    rng = np.random.default_rng(4)
+    for B, n, m in ((3, 257, 130), (2, 64, 1027), (1, 1, 1)):
+        a = rng.uniform(-0.4, 0.4, (B, n, 3)).astype(np.float32)
+        b = rng.uniform(-0.4, 0.4, (B, m, 3)).astype(np.float32)
+        b[0, 0] = a[0, 0]                                   # an exact zero
+        got = cdist(torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev))
+        np.testing.assert_array_equal(got.cpu().numpy(), oracle.cdist(a, b))
+        ref = torch.cdist(torch.from_numpy(a).double(), torch.from_numpy(b).double()).numpy()
+        np.testing.assert_allclose(got.cpu().numpy(), ref, atol=2e-7)

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""One refresh cycle of the assignment-loss phase (run_robot.py:164-187 as reart_amd/run_robot.py runs it), stage by
+stage, at T = 20 x N = 4096, downsample 4 (19 matrices of 1024 x 1024), assign_gap 5."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import bench
+from reart_amd.networks.pointnet2_utils import farthest_point_sample, index_points
+from reart_amd.utils.lap import cdist, linear_sum_assignment_batch
+
+dev = torch.device("cuda:0")
+eng, seq, model = bench.build_instance(dev, 20, 4096, 10, 2, n_iter=15000)
+eng.capture(steps_per_graph=10)
+eng.step(5000); torch.cuda.synchronize()
+cano, pcs = eng.cano, eng.pc_list
+B, N = pcs.shape[:2]; nf = N // 4
+acc = {}
+def T(name, fn):
+    torch.cuda.synchronize(); t0 = time.perf_counter(); r = fn(); torch.cuda.synchronize()
+    acc[name] = acc.get(name, 0.0) + time.perf_counter() - t0
+    return r
+state = {} if os.environ.get('WARM', '0') == '1' else None
+reps = 30
+t_all = time.perf_counter()
+for k in range(reps):
+    T("peek_forward", eng.peek_forward)
+    pred = eng.pc_trans
+    src = T("fps cano", lambda: farthest_point_sample(cano[None], nf))
+    tgt = T("fps frames", lambda: farthest_point_sample(pcs, nf))
+    cost = T("gather + cdist (reart_cdist)", lambda: cdist(index_points(pred, src.expand(B, nf)), index_points(pcs, tgt)))
+    T("  (torch.cdist, for comparison)", lambda: torch.cdist(index_points(pred, src.expand(B, nf)), index_points(pcs, tgt)))
+    assign, fb, st = T("linear_sum_assignment_batch", lambda: linear_sum_assignment_batch(cost, return_stats="full", state=state))
+    if k % 5 == 0:
+        print(f"cycle {k}: LAP mean rounds {st[:,1].mean():.0f} bids {st[:,2].mean():.0f} (max {st[:,2].max()}) cert {st[:,3].mean():.0f} fallbacks {fb}")
+    cols = T("cols to device", lambda: torch.from_numpy(np.stack([c for _, c in assign])).to(dev))
+    T("set_assignment", lambda: eng.set_assignment(src[0], tgt.gather(1, cols), 0.3))
+    T("5 iterations", lambda: eng.step(5))
+torch.cuda.synchronize()
+tot = time.perf_counter() - t_all
+for k, v in acc.items():
+    print(f"{k:32s} {v / reps * 1e3:8.2f} ms")
+print(f"{'cycle (with the syncs above)':32s} {tot / reps * 1e3:8.2f} ms")
