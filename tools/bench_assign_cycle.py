@@ -20,7 +20,7 @@ def T(name, fn):
     acc[name] = acc.get(name, 0.0) + time.perf_counter() - t0
     return r
 state = {} if os.environ.get('WARM', '0') == '1' else None
-reps = 30
+reps = int(os.environ.get('REPS', 30))
 t_all = time.perf_counter()
 for k in range(reps):
     T("peek_forward", eng.peek_forward)
