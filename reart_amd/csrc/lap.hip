@@ -186,21 +186,47 @@ __global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
             const int nu = s_cnt;
             if (nu == 0) break;
             ++st_rounds; st_bids += nu;
+            // One wave covers 1024 columns with four 16-byte loads per lane in flight; longer rows are shared by n / 1024
+            // waves whose (min, arg-min, second-min) triples one wave merges.
+            const int wmax = n >= 2048 ? (n / 1024 < NW ? n / 1024 : NW) : 1;
             if (nu == 1) {
                 // a single bidder: no conflicts are possible, so the chain (the row bids, takes the column, the displaced
                 // owner bids next, ...) is followed without rebuilding the bidder list until nobody is displaced.  The end
-                // of a phase is mostly such chains.  Every link is one row scan -- a dependent read of n costs -- so all
-                // 16 waves take a sixteenth of the row each; wave 0 merges the partial results and moves the price.
+                // of a phase is mostly such chains; every link is one row scan, a dependent read.
                 int i = ulist[0];
-                const int len = (((n + NW - 1) / NW) + 63) & ~63;
+                if (wmax == 1) {
+                    if (wv == 0) {                       // no workgroup barrier inside the chain
+                        for (;;) {
+                            double v1, v2;
+                            int j1;
+                            lap_row_top2(C + (size_t)i * n, price, n, lane, v1, j1, v2);
+                            if (!(v2 < INFINITY)) v2 = v1;
+                            const int prev = owner[j1];
+                            if (lane == 0) {
+                                price[j1] = price[j1] + (v2 - v1) + eps;
+                                owner[j1] = i; assigned[i] = j1;
+                                if (prev >= 0) assigned[prev] = -1;
+                            }
+                            ++st_bids;
+                            if (prev < 0) break;
+                            i = prev;
+                        }
+                    }
+                    __syncthreads();
+                    continue;
+                }
+                const int len = (((n + wmax - 1) / wmax) + 63) & ~63;
                 for (;;) {
                     double v1, v2;
                     int j1;
-                    lap_row_top2_range(C + (size_t)i * n, price, min(n, wv * len), min(n, (wv + 1) * len), lane, v1, j1, v2);
-                    if (lane == 0) { s_pv1[wv] = v1; s_pv2[wv] = v2; s_pj1[wv] = j1; }
+                    if (wv < wmax) {
+                        lap_row_top2_range(C + (size_t)i * n, price, min(n, wv * len), min(n, (wv + 1) * len), lane, v1, j1, v2);
+                        if (lane == 0) { s_pv1[wv] = v1; s_pv2[wv] = v2; s_pj1[wv] = j1; }
+                    }
                     __syncthreads();
                     if (wv == 0) {
-                        v1 = s_pv1[lane & (NW - 1)]; v2 = s_pv2[lane & (NW - 1)]; j1 = s_pj1[lane & (NW - 1)];
+                        v1 = INFINITY; v2 = INFINITY; j1 = 0x7fffffff;
+                        if (lane < wmax) { v1 = s_pv1[lane]; v2 = s_pv2[lane]; j1 = s_pj1[lane]; }
 #pragma unroll
                         for (int o = NW / 2; o >= 1; o >>= 1)
                             lap_merge_top2(__shfl_xor(v1, o, 64), __shfl_xor(j1, o, 64), __shfl_xor(v2, o, 64), v1, j1, v2);
@@ -220,10 +246,10 @@ __global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
                 }
                 continue;
             }
-            if (nu * 2 <= NW) {
-                // few bidders: several waves per row (a power of two), merged by one thread per row
+            if (nu * 2 <= NW && wmax > 1) {
+                // few bidders on long rows: several waves per row (a power of two), merged by one thread per row
                 int wpr = 2;
-                while (wpr * 2 * nu <= NW) wpr *= 2;
+                while (wpr * 2 * nu <= NW && wpr * 2 <= wmax) wpr *= 2;
                 const int g = wv / wpr, seg = wv % wpr;
                 const int len = (((n + wpr - 1) / wpr) + 63) & ~63;
                 if (g < nu) {
