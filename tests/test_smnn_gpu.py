@@ -82,7 +82,9 @@ def test_run_robot_end_of_run_files_and_kinematic_from_base_result(dev, tmp_path
     txt = next((tmp_path / "base").rglob("result.txt")).read_text()
     assert "total_err" in txt and "ass_err" in txt and "cd_err" in txt
     if P > 1:
+        # BASELINE.json config 5: kinematic projection with the assignment loss on, downsample 2
         model = main(build_parser().parse_args(base + ["--model", "kinematic", "--base_result_path", str(res_path),
+                                                       "--use_assign_loss", "--assign_iter", "10", "--downsample", "2",
                                                        "--n_iter", "40", "--save_root", str(tmp_path / "kin")]))
         ck = torch.load(next((tmp_path / "kin").rglob("model.pth.tar")), weights_only=False)
         assert {"state_dict", "tau", "cano_idx", "seg_part", "cano_pc", "edge_index", "paths_to_base", "reverse_topo"} <= set(ck)
