@@ -281,3 +281,17 @@ def test_part_fps_cuda_tie_rule_and_small_part_error(dev):
     seg[:5] = 3
     with pytest.raises(ValueError, match="part id 3 too small, only 5 points"):
         gu.fps_sample_cano(T_(grid, dev), T_(seg, dev), T_(np.array([0, 3]), dev), num_fps=20)
+
+
+def test_screw_edge_cases_match_the_reference(dev):
+    """transform_to_dq -> dq_to_screw of the reference on edge cases (fixture screw_edge_*): identity, pure
+    translation, rotation by pi, sub-threshold rotation, flipped axis, large rotation -- through reart_screw_fit."""
+    from reart_amd.utils import graph_utils as gu
+
+    rel = T_(G["screw_edge_T"], dev)[None]                     # [T=1, E=7, 4, 4]
+    sc = gu.screw_fit(rel, want=("screw",))["screw"][0].cpu().numpy()
+    close(sc[:, 0:3], G["screw_edge_l"], atol=1e-6)
+    close(sc[:, 6], G["screw_edge_theta"], atol=1e-6)
+    close(sc[:, 7], G["screw_edge_d"], atol=1e-6)
+    rot = np.abs(G["screw_edge_theta"]) > 1e-5                 # elsewhere the reference's moment is amplified rounding noise
+    close(sc[rot, 3:6], G["screw_edge_m"][rot], atol=1e-6)

@@ -93,3 +93,16 @@ def test_energies():
     comp = np.concatenate([pred[:2], cano[None], pred[2:]])
     close(S.group_temporal_err(comp, ns), G["group_err"], 1e-8)
     close(S.ass_err(pred[:1], G["pc_list"][:1]), G["ass_err_frame0"], 1e-9)      # one 4096 x 4096 assignment
+
+
+def test_screw_edge_cases():
+    """identity, pure translation, rotation by pi, sub-threshold rotation, axis flipped towards (1,1,1), large rotation.
+    For the no-rotation rows the reference's moment is 0.5 * (t x l + l x (t x l) / tan(5e-7)): rounding noise of t x l
+    amplified 2e6 times -- compared only where there is a rotation."""
+    l, m, th, d = S.transform_to_screw(G["screw_edge_T"])
+    close(l, G["screw_edge_l"])
+    close(th, G["screw_edge_theta"])
+    close(d, G["screw_edge_d"])
+    rot = np.abs(G["screw_edge_theta"]) > 1e-5
+    assert rot.tolist() == [False, False, False, False, True, True, True]
+    close(m[rot], G["screw_edge_m"][rot])
