@@ -261,7 +261,31 @@ def main():
                 tail.extract_structure(seg0, trans0, eng.cano)                   # warm-up (lazy module / kernel load)
                 (seg_s, trans_s, conn_s), ms_struct = _timed(lambda: tail.extract_structure(seg0, trans0, eng.cano))
                 en, ms_energy = _timed(lambda: tail.energy_terms(eng.cano, eng.pc_list, seg_s, trans_s, conn_s, cano_idx))
-                end_of_run = {"structure_ms": round(ms_struct, 3), "energy_ms": round(ms_energy, 3),
+                cpu_tail = None
+                if not args.no_cpu_baseline and world == 1:
+                    # the same two stages on the host: the oracle's numpy restatement of the structure extraction and,
+                    # for the energy, ONE of the T-1 assignments with scipy (what the reference calls); bounded sample
+                    from oracle import structure as S_
+                    from reart_amd.utils.lap import cdist as cdist_
+
+                    seg_np, tr_np, cano_np = seg0.cpu().numpy(), trans0.detach().cpu().numpy(), eng.cano.cpu().numpy()
+                    t_ = time.perf_counter()
+                    dn_ = S_.denoise_seg_label(seg_np, cano_np, 20)
+                    mg_ = S_.merging_wrapper(dn_, tr_np, cano_np, 3e-2, 2)
+                    S_.extract_kinematic(mg_, tr_np, S_.mst_wrapper(mg_, tr_np, cano_np))
+                    cpu_struct = 1e3 * (time.perf_counter() - t_)
+                    from reart_amd.utils.model_utils import compute_pc_transform as cpt_
+                    import oracle as O_
+
+                    c1 = cdist_(cpt_(eng.cano, trans_s, seg_s)[:1], eng.pc_list[:1]).cpu().numpy()
+                    t_ = time.perf_counter()
+                    O_.linear_sum_assignment(c1)
+                    cpu_lap = 1e3 * (time.perf_counter() - t_)
+                    cpu_tail = {"structure_ms": round(cpu_struct, 1), "assignment_ms_per_matrix": round(cpu_lap, 1),
+                                "matrices": int(eng.pc_list.shape[0]), "kind": "port",
+                                "sample": "oracle (numpy, C k-NN) structure extraction once; scipy.optimize."
+                                          "linear_sum_assignment on 1 of the T-1 matrices of 4096 x 4096 (serial)"}
+                end_of_run = {"structure_ms": round(ms_struct, 3), "energy_ms": round(ms_energy, 3), "cpu_baseline": cpu_tail,
                               "parts": int(trans_s.shape[1]), "total_err": round(en["total_err"], 6),
                               "ass_err": round(en["ass_err"], 6), "screw_err": round(en["screw_err"], 6),
                               "group_err": round(en["group_err"], 6),

@@ -99,11 +99,11 @@ def compute_spatial_cost(cano_part_fps_list, chamfer_dist=None, return_index=Fal
 
 
 def compute_joint_cost(part_fps_list, joint_connection, edge_pair_indices):
-    """utils/graph_utils.py:87-100: squared distance of the chosen point pair of every edge, per frame."""
-    e = torch.arange(joint_connection.shape[0], device=part_fps_list.device)
-    j0 = part_fps_list[..., joint_connection[:, 0], :, :][..., e, edge_pair_indices[:, 0], :]
-    j1 = part_fps_list[..., joint_connection[:, 1], :, :][..., e, edge_pair_indices[:, 1], :]
-    return ((j0 - j1) ** 2).sum(dim=-1)
+    """utils/graph_utils.py:87-100: squared distance between the chosen FPS point of part ``joint_connection[e, 0]``
+    and that of part ``joint_connection[e, 1]``, per frame.  part_fps_list [T,P,F,3] (or [P,F,3]) -> [T,E] (or [E])."""
+    a = part_fps_list[..., joint_connection[:, 0], edge_pair_indices[:, 0], :]
+    b = part_fps_list[..., joint_connection[:, 1], edge_pair_indices[:, 1], :]
+    return (a - b).square().sum(dim=-1)
 
 
 def _part_counts(cano_part):
