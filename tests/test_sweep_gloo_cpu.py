@@ -34,7 +34,11 @@ def _runner(spec):
         out = orc.step(-np.log(rng.exponential(size=(cano.shape[0], P))).astype(np.float32))
     if spec.get("fail"):
         raise RuntimeError("injected failure")
-    return dict(recon=out["recon"], flow=0.0, total=out["total"], iterations=3)
+    res = dict(recon=out["recon"], flow=0.0, total=out["total"], iterations=3)
+    if spec.get("with_energy"):   # the end-of-run energy terms travel in the same record (run_robot.py:306-321)
+        res.update(parts=4, ass_err=0.1 * (1 + spec["cano_idx"]), screw_err=0.01, group_err=0.02, cd_err=0.5)
+        res["total_err"] = res["ass_err"] + res["screw_err"] + res["group_err"]
+    return res
 
 
 def _worker(rank, world, port, q):
@@ -70,3 +74,17 @@ def test_sweep_two_ranks_gloo():
     # same instance on either rank gives the same energy as a single-process run
     single = _runner(dict(cano_idx=0))
     assert abs(single["total"] - rec0[0, 4]) <= 1e-5 * abs(single["total"])
+
+
+def test_records_with_energy_pick_the_lowest_energy():
+    """Single process: 16-float records, energies decide the winner (README.md:60), NaN-energy instances lose."""
+    from reart_amd import sweep
+
+    instances = [dict(cano_idx=2, with_energy=True), dict(cano_idx=0, with_energy=True), dict(cano_idx=1, fail=True),
+                 dict(cano_idx=3, with_energy=True)]
+    rec, best = sweep.run_sweep(instances, _runner, torch.device("cpu"))
+    rec = rec.numpy()
+    assert rec.shape == (4, sweep.RECORD) and best == 1
+    np.testing.assert_allclose(rec[[0, 1, 3], sweep.E_TOTAL], [0.33, 0.13, 0.43], rtol=1e-6)
+    np.testing.assert_allclose(rec[1, 7:13], [4, 0.13, 0.1, 0.01, 0.02, 0.5], rtol=1e-6)
+    assert np.isnan(rec[2, sweep.E_TOTAL]) and rec[2, 6] == 1
