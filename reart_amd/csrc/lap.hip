@@ -162,30 +162,45 @@ __global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
         ++st_phases;
         // a phase keeps the prices and every pair that already satisfies the new, tighter epsilon-complementary
         // slackness  c_i,s(i) + p_s(i) <= min_k (c_ik + p_k) + eps ; the other rows are released and bid again
-        if (st_phases > 1) {
+        // The scan that finds the rows to release also is their first bid of the phase (prices do not move in between):
+        // the released rows bid right here and the first round below starts at its resolution step.
+        const bool pre_bid = st_phases > 1;
+        if (pre_bid) {
+            if (tid == 0) s_cnt = 0;
+            __syncthreads();
             for (int i = wv; i < n; i += NW) {
                 double v1, v2;
                 int j1;
                 lap_row_top2(C + (size_t)i * n, price, n, lane, v1, j1, v2);
                 if (lane == 0) {
                     const int j = assigned[i];
-                    if ((double)C[(size_t)i * n + j] + price[j] > v1 + eps) pbobj[i] = -1; else pbobj[i] = j;
+                    if ((double)C[(size_t)i * n + j] + price[j] > v1 + eps) {
+                        owner[j] = -1; assigned[i] = -1;
+                        if (!(v2 < INFINITY)) v2 = v1;
+                        const double bid = price[j1] + (v2 - v1) + eps;
+                        pbobj[i] = j1; pbval[i] = bid;
+                        atomicMax(&bidval[j1], lap_key(bid));
+                        ulist[atomicAdd(&s_cnt, 1)] = i;
+                    }
                 }
             }
-            __syncthreads();
-            for (int i = tid; i < n; i += LAP_BS)
-                if (pbobj[i] < 0) { owner[assigned[i]] = -1; assigned[i] = -1; }
         }
         __syncthreads();
+        bool first = pre_bid;
         for (;;) {
-            if (tid == 0) s_cnt = 0;
-            __syncthreads();
-            for (int i = tid; i < n; i += LAP_BS)
-                if (assigned[i] < 0) ulist[atomicAdd(&s_cnt, 1)] = i;
-            __syncthreads();
+            if (!first) {
+                if (tid == 0) s_cnt = 0;
+                __syncthreads();
+                for (int i = tid; i < n; i += LAP_BS)
+                    if (assigned[i] < 0) ulist[atomicAdd(&s_cnt, 1)] = i;
+                __syncthreads();
+            }
             const int nu = s_cnt;
             if (nu == 0) break;
             ++st_rounds; st_bids += nu;
+            const bool skip_bids = first;      // the phase's first round: the bids were placed by the scan above
+            first = false;
+            if (!skip_bids) {
             // One wave covers 1024 columns with four 16-byte loads per lane in flight; longer rows are shared by n / 1024
             // waves whose (min, arg-min, second-min) triples one wave merges.
             const int wmax = n >= 2048 ? (n / 1024 < NW ? n / 1024 : NW) : 1;
@@ -282,6 +297,7 @@ __global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
                     pbobj[i] = j1; pbval[i] = bid;
                     atomicMax(&bidval[j1], lap_key(bid));
                 }
+            }
             }
             __syncthreads();
             for (int u = tid; u < nu; u += LAP_BS) {
