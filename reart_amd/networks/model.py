@@ -114,8 +114,9 @@ class KinematicModel(nn.Module):
     Same constructor keywords and parameter names as the reference (its checkpoints load with
     ``strict=True``): ``axis_list`` [E,3], ``moment_list`` [E,3], ``theta_list`` [T-1,E] and the
     optional ``distance_list``.  forward = k-NN label transfer (utils/model_utils.py:41-51) +
-    fused FK kernel + hard-label rigid apply.  Root motion (``root_trans``: SAPIEN / real scans
-    only, run_real.py / run_sapien.py) is not built."""
+    fused FK kernel + hard-label rigid apply.  Root motion (``root_trans`` / ``load_root_trans``, the SAPIEN / real-scan
+    variant, networks/model.py:113-120,153-158) is a per-frame rigid transform composed after the kernels (a [T-1,3,3]
+    Gram-Schmidt and one batched multiply in PyTorch, differentiable w.r.t. ``root_6d`` / ``root_t``)."""
 
     def __init__(self, pose_len, seg_part, cano_pc, knn, **kwargs):
         super().__init__()
@@ -133,8 +134,14 @@ class KinematicModel(nn.Module):
         self.reverse_topo = kwargs["reverse_topo"]
         E = len(self.edge_index)
         assert self.num_parts == E + 1  # P = E + 1
-        if "root_trans" in kwargs or kwargs.get("load_root_trans"):
-            raise NotImplementedError("root motion is only used by run_real.py / run_sapien.py (out of scope)")
+        if "root_trans" in kwargs:
+            from ..screw_se3 import matrix_to_rotation_6d
+
+            self.root_6d = nn.Parameter(matrix_to_rotation_6d(kwargs["root_trans"][:, :3, :3]).float(), requires_grad=True)
+            self.root_t = nn.Parameter(kwargs["root_trans"][:, :3, 3].clone().float(), requires_grad=True)
+        elif kwargs.get("load_root_trans"):
+            self.root_6d = nn.Parameter(torch.tensor([[1.0, 0, 0, 0, 1, 0]]).repeat((pose_len, 1)), requires_grad=True)
+            self.root_t = nn.Parameter(torch.zeros(pose_len, 3), requires_grad=True)
         for name, shape in (("axis_list", (E, 3)), ("moment_list", (E, 3)), ("theta_list", (pose_len, E))):
             init = kwargs[name] if name in kwargs else torch.zeros(shape)
             setattr(self, name, nn.Parameter(init.clone().float(), requires_grad=True))
@@ -166,4 +173,14 @@ class KinematicModel(nn.Module):
         parent, edge_of, order = self._tree(input_pc.device)
         pc_trans_list, trans_list = _FK.apply(input_pc, seg_part, self.axis_list, self.moment_list, theta, dist,
                                               parent, edge_of, order)
+        if hasattr(self, "root_6d") and hasattr(self, "root_t"):     # networks/model.py:153-158
+            a1, a2 = self.root_6d[:, :3], self.root_6d[:, 3:]
+            b1 = torch.nn.functional.normalize(a1, dim=-1)
+            b2 = torch.nn.functional.normalize(a2 - (b1 * a2).sum(-1, keepdim=True) * b1, dim=-1)
+            R = torch.stack((b1, b2, torch.cross(b1, b2, dim=-1)), dim=-2)                       # [T-1,3,3]
+            pc_trans_list = torch.matmul(pc_trans_list, R.transpose(1, 2)) + self.root_t[:, None, :]
+            with torch.no_grad():
+                root = torch.zeros((R.shape[0], 4, 4), dtype=R.dtype, device=R.device)
+                root[:, :3, :3], root[:, :3, 3], root[:, 3, 3] = R, self.root_t, 1.0
+                trans_list = torch.matmul(root[:, None], trans_list)
         return pc_trans_list, seg_part, trans_list
