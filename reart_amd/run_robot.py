@@ -19,10 +19,10 @@ What is built: the loop itself.
     the model-selection energy (assignment, screw and group errors), ``result.pkl`` / ``result.txt`` /
     ``model.pth.tar`` with the reference's keys; ``--model kinematic --base_result_path result.pkl`` builds the
     joint tree from a base result (``run_robot.py:101-124``).
-What is NOT built (SURVEY.md section 8 out of scope): visualisation (gif / html), the GT-graph tree edit distance
-(``apted``), inverse-kinematics retargeting; ground-truth metrics are printed when the sample carries ground truth.
+What is NOT built (SURVEY.md section 8 out of scope): visualisation (gif / html) and the GT-graph tree edit distance
+(``apted``); ground-truth metrics and the retargeting error (``ik``) are reported when the sequence carries them.
 
-Data: ``--seq_path`` with the reference's pickle layout (``dataset/dataset_robot.py``), or
+Data: ``--seq_path`` with the reference's pickle layout (``reart_amd.dataset.Sequence`` = ``dataset/dataset_robot.py``), or
 ``--synthetic`` for the generated articulated sequence of ``reart_amd/synthetic.py``.
 """
 import argparse
@@ -46,22 +46,10 @@ from reart_amd.utils.model_utils import tau_cosine
 
 
 def load_sequence(seq_path, num_points, cano_idx):
-    """Restates dataset/dataset_robot.py:9-100 for what the loop needs (clouds only):
-    state_0.pkl plus one state_i.pkl per pose_i.pkl, each a (points [n,3], part ids [n]) pair."""
-    pose_files = sorted(glob.glob(os.path.join(seq_path, "pose_*.pkl")),
-                        key=lambda f: int(os.path.basename(f).split(".")[0].split("_")[-1]))
-    ids = [0] + [int(os.path.basename(f).split(".")[0].split("_")[-1]) for f in pose_files]
-    clouds, parts = [], []
-    for i in ids:
-        with open(os.path.join(seq_path, f"state_{i}.pkl"), "rb") as f:
-            state = pickle.load(f)
-        pc, part = (state["pc"], state["part"]) if isinstance(state, dict) else state[:2]
-        clouds.append(np.asarray(pc)[:num_points])
-        parts.append(np.asarray(part)[:num_points])
-    complete = np.stack(clouds).astype("float32")
-    cano = complete[cano_idx]
-    pc_list = np.concatenate([complete[:cano_idx], complete[cano_idx + 1:]], axis=0)
-    return dict(cano_pc=cano, pc_list=pc_list, complete_pc_list=complete, gt_cano_part=parts[cano_idx])
+    """The reference's sample dictionary (dataset/dataset_robot.py:9-100) through the mirror loader."""
+    from reart_amd.dataset import Sequence
+
+    return Sequence(seq_path, num_points=num_points, cano_idx=cano_idx)[0]
 
 
 def synthetic_sequence(num_points, cano_idx, frames, with_flow):
@@ -83,10 +71,14 @@ def main(args):
     if not torch.cuda.is_available():
         raise SystemExit("reart_amd runs on an AMD GPU only (no CPU fallback)")
     device = torch.device("cuda")
+    dataset = None
     if args.synthetic:
         sample = synthetic_sequence(args.num_points, args.cano_idx, args.synthetic_frames, args.use_flow_loss)
     else:
-        sample = load_sequence(args.seq_path, args.num_points, args.cano_idx)
+        from reart_amd.dataset import Sequence
+
+        dataset = Sequence(args.seq_path, num_points=args.num_points, cano_idx=args.cano_idx)
+        sample = dataset[0]
     cano_pc = torch.from_numpy(sample["cano_pc"]).float().to(device)
     pc_list = torch.from_numpy(sample["pc_list"]).float().to(device)
     save_dir = os.path.join(args.save_root, os.path.basename(args.seq_path.rstrip("/")) or "synthetic")
@@ -273,12 +265,12 @@ def main(args):
             i += 1
     if args.evaluate:
         snapshot(0, {})
-    finish(args, model, cano_pc, pc_list, sample, save_dir, tau_func(cur_iter=n_iter))
+    finish(args, model, cano_pc, pc_list, sample, save_dir, tau_func(cur_iter=n_iter), dataset)
     print("all done!")
     return model
 
 
-def finish(args, model, cano_pc, pc_list, sample, save_dir, tau):
+def finish(args, model, cano_pc, pc_list, sample, save_dir, tau, dataset=None):
     """run_robot.py:227-356: structure, energies, result files (the reference's file names and keys)."""
     from reart_amd import tail
     from reart_amd.utils.kinematic_utils import edge_index2edges
@@ -310,7 +302,14 @@ def finish(args, model, cano_pc, pc_list, sample, save_dir, tau):
         print(f"Seg eval: RI: {metrics['ri']:.3f}")
     if "recon_err" in metrics:
         print(f"Recon eval: recon: {metrics['recon_err']:.3f}")
+    retarget_err = 9999      # run_robot.py:287-291: retargeting to the sequence's novel poses (kinematic model only)
+    if isinstance(model, KinematicModel) and dataset is not None and len(dataset.novel_pose_list):
+        from reart_amd.utils.kinematic_utils import ik
+
+        retarget_err = ik(dataset, model, device, verbose=False, vis=False)
+    print("Retarget error: {:.3f}".format(retarget_err))
     with open(os.path.join(save_dir, "result.txt"), "w") as f_result:
+        f_result.write(f"retarget_err: {retarget_err:.3f}\n")
         for k in ("recon_err", "epe", "acc5", "acc10", "angle", "ri", "cd_err"):
             if k in metrics:
                 f_result.write(f"{k}: {metrics[k]:.3f}\n")

@@ -81,6 +81,15 @@ def make_sequence(T=20, n_parts=8, pts_per_part=512, seed=2, n_ref=3000, with_fl
     complete = ((allp - centre) * scale).astype(np.float32)
     part = np.repeat(np.arange(n_parts), pts_per_part).astype(np.int64)
     out = dict(complete=complete, part=part, scale=scale)
+
+    def world(t):   # part-local coordinates -> the scaled, centred frame of `complete`, as 4x4 per part
+        Rw, tw = poses(t)
+        W = np.tile(np.eye(4), (n_parts, 1, 1))
+        for e in range(n_parts):
+            W[e, :3, :3], W[e, :3, 3] = scale * Rw[e], scale * (tw[e] - centre)
+        return W
+
+    out["world"] = world
     if with_flow:
         ref_loc, ref_flow = [], []
         for t in range(T - 1):
@@ -97,3 +106,26 @@ def make_sequence(T=20, n_parts=8, pts_per_part=512, seed=2, n_ref=3000, with_fl
 def split_canonical(complete, cano_idx):
     """-> (cano_pc [N,3], pc_list [T-1,N,3]) as reference dataset_robot.Sequence does (:88-89)."""
     return complete[cano_idx], np.concatenate([complete[:cano_idx], complete[cano_idx + 1:]], axis=0)
+
+
+def export_sequence(path, T=6, n_parts=4, pts_per_part=256, seed=2, n_novel=2):
+    """Write a generated sequence in the reference's on-disk layout (dataset/dataset_robot.py:9-45, utils/dataset_utils.py
+    :15-26): ``state_i.pkl`` = {pc, part_id} for i = 0..T-1, ``pose_i.pkl`` = {part: 4x4 motion of the part from state 0
+    to state i} for i >= 1, ``novel_pose_k.pkl`` = the same for poses between the frames.  -> the make_sequence dict."""
+    import os
+    import pickle
+
+    seq = make_sequence(T=T, n_parts=n_parts, pts_per_part=pts_per_part, seed=seed, with_flow=False)
+    os.makedirs(path, exist_ok=True)
+    W0 = seq["world"](0)
+    rel = lambda t: {int(e): seq["world"](t)[e] @ np.linalg.inv(W0[e]) for e in range(n_parts)}
+    for t in range(T):
+        with open(os.path.join(path, f"state_{t}.pkl"), "wb") as f:
+            pickle.dump({"pc": seq["complete"][t].astype(np.float64), "part_id": seq["part"].copy()}, f)
+        if t:
+            with open(os.path.join(path, f"pose_{t}.pkl"), "wb") as f:
+                pickle.dump(rel(t), f)
+    for k in range(n_novel):
+        with open(os.path.join(path, f"novel_pose_{k}.pkl"), "wb") as f:
+            pickle.dump(rel(k + 1.5), f)
+    return seq

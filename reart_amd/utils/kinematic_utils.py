@@ -236,3 +236,56 @@ def screw_fit_per_edge_costs(trans_list, pairs):
 def edge_index2edges(edge_index):
     """utils/kinematic_utils.py:142-149."""
     return [[int(v) for v in name.split("_")] for name in edge_index.keys()]
+
+
+def ik(dataset, model, device, verbose=True, vis=True, save_dir=None, **ikargs):
+    """Retargeting error (utils/kinematic_utils.py:200-266): for every novel pose of the sequence fit the model's
+    free motion parameters (one ``theta`` row for a KinematicModel, one 6D / translation proposal per part for a
+    BaseModel) to ONE point per ground-truth part with Adam(amsgrad, lr 0.1, 200 iterations), then measure how far
+    the whole canonical cloud lands from its ground-truth novel position (mean Euclidean distance, x100).
+    ``dataset``: an object with ``[0]`` -> sample, ``pose_list``, ``cano_idx``, ``novel_pose_list`` (the mirror
+    ``reart_amd.dataset.Sequence`` or the reference's).  ``vis`` / ``save_dir`` are accepted; nothing is drawn."""
+    from ..networks.model import BaseModel
+    from .dataset_utils import sparse_sample_novel_state
+
+    sample = dataset[0]
+    cano_pose = dataset.pose_list[dataset.cano_idx]
+    cano_pc = torch.from_numpy(sample["cano_pc"]).to(device)
+    errs = []
+    for novel_pose in dataset.novel_pose_list:
+        novel = sparse_sample_novel_state(sample["cano_pc"], sample["gt_cano_part"], cano_pose, novel_pose, 1)
+        errs.append(ik_single(model, cano_pc, novel, device, verbose=verbose, **ikargs)[0])
+    return np.array(errs).mean()
+
+
+def ik_single(model, cano_pc, novel_sample, device, n_iter=200, verbose=False, **ikargs):
+    """One novel pose of ``ik`` -> (retarget error x100, fitted kwargs)."""
+    from ..networks.model import BaseModel
+
+    src = torch.from_numpy(np.asarray(novel_sample["sparse_cano_pc"])).float().to(device)
+    tgt = torch.from_numpy(np.asarray(novel_sample["sparse_novel_pc"])).float().to(device)
+    kwargs = {}
+    if isinstance(model, BaseModel):
+        kwargs["tau"] = ikargs.get("tau", 1.0)
+        kwargs["proposal_6d"] = torch.tensor([[[1.0, 0, 0, 0, 1, 0]]], device=device).repeat((1, model.num_parts, 1)).requires_grad_(True)
+        kwargs["proposal_t"] = torch.zeros((1, model.num_parts, 3), device=device).requires_grad_(True)
+        opt_list = [kwargs["proposal_6d"], kwargs["proposal_t"]]
+    else:
+        kwargs["theta_list"] = (1e-6 * torch.ones((1, model.axis_list.shape[0]), device=device)).requires_grad_(True)
+        opt_list = [kwargs["theta_list"]]
+    optimizer = torch.optim.Adam(opt_list, lr=1e-1, amsgrad=True)
+    for _ in range(n_iter):
+        pc_trans, _, _ = model(src, **kwargs)
+        loss = ((pc_trans.squeeze(0) - tgt) ** 2).sum()
+        if verbose:
+            print(f"Loss: {loss:.3f}")
+        optimizer.zero_grad()
+        loss.backward()
+        optimizer.step()
+    with torch.no_grad():
+        pc_trans, _, _ = model(cano_pc.float(), **kwargs)
+    gt = torch.from_numpy(np.asarray(novel_sample["novel_pc"])).float().to(device)
+    err = 100 * float((pc_trans.squeeze(0) - gt).pow(2).sum(-1).sqrt().mean())
+    if verbose:
+        print(f"Novel retarget err: {err:.3f}")
+    return err, kwargs

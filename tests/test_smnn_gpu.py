@@ -89,3 +89,30 @@ def test_run_robot_end_of_run_files_and_kinematic_from_base_result(dev, tmp_path
         ck = torch.load(next((tmp_path / "kin").rglob("model.pth.tar")), weights_only=False)
         assert {"state_dict", "tau", "cano_idx", "seg_part", "cano_pc", "edge_index", "paths_to_base", "reverse_topo"} <= set(ck)
         assert len(ck["edge_index"]) == P - 1 and all(torch.isfinite(p).all() for p in model.parameters())
+
+
+def test_run_robot_on_a_sequence_directory_with_ground_truth_and_retargeting(dev, tmp_path):
+    """--seq_path in the reference's on-disk layout (written by reart_amd.synthetic.export_sequence): the mirror loader,
+    ground-truth metrics in result.txt, and for the kinematic model the retargeting error to the novel poses (ik)."""
+    from reart_amd.run_robot import build_parser, main
+    from reart_amd.synthetic import export_sequence
+
+    seq_dir = str(tmp_path / "toy")
+    export_sequence(seq_dir, T=6, n_parts=4, pts_per_part=256, seed=2, n_novel=2)
+    base = ["--seq_path", seq_dir, "--num_points", "1024", "--cano_idx", "2", "--snapshot_gap", "1000"]
+    main(build_parser().parse_args(base + ["--n_iter", "2000", "--save_root", str(tmp_path / "base")]))
+    txt = next((tmp_path / "base").rglob("result.txt")).read_text()
+    for key in ("recon_err", "epe", "acc5", "ri", "cd_err", "total_err", "retarget_err: 9999"):
+        assert key in txt, (key, txt)
+    res_path = next((tmp_path / "base").rglob("result.pkl"))
+    import pickle
+
+    with open(res_path, "rb") as f:
+        res = pickle.load(f)
+    assert {"gt_flow_list", "gt_pose_list", "complete_gt_pc_list", "pred_cano_part", "joint_connection"} <= set(res)
+    if res["pred_pose_list"].shape[1] > 1:
+        main(build_parser().parse_args(base + ["--model", "kinematic", "--base_result_path", str(res_path), "--n_iter", "60",
+                                               "--save_root", str(tmp_path / "kin")]))
+        txt = next((tmp_path / "kin").rglob("result.txt")).read_text()
+        err = float([l for l in txt.splitlines() if l.startswith("retarget_err")][0].split(":")[1])
+        assert 0.0 <= err < 100.0
