@@ -8,6 +8,9 @@ collective); the only exchange is one ``all_gather`` of a fixed-size float recor
 (RCCL over xGMI when the backend is "nccl"; latency-bound: 64 B per instance), after which every
 rank can take the arg-min.
 """
+import os
+from concurrent.futures import ThreadPoolExecutor
+
 import torch
 import torch.distributed as dist
 
@@ -127,7 +130,8 @@ def run_sweep_engines(instances, make_engine, n_iter, device, per_gpu=3, chunk=1
                     with torch.cuda.stream(e[3]):
                         e[2].step(n)
                     e[4] += n
-        for inst, spec, eng, st, done in live:
+        def finish(entry):
+            inst, spec, eng, st, done = entry
             st.synchronize()
             row = eng.last_losses().cpu()
             en = None
@@ -137,6 +141,16 @@ def run_sweep_engines(instances, make_engine, n_iter, device, per_gpu=3, chunk=1
                         en = instance_energy(eng, spec)
                 except Exception:      # e.g. every part merged away: the losses still describe the instance
                     en = None
-            local[inst] = _record(inst, spec, (float(row[0]), float(row[1]), float(row[2])), done, 0, en)
+            return inst, _record(inst, spec, (float(row[0]), float(row[1]), float(row[2])), done, 0, en)
+
+        # The end of an instance is latency-bound (its assignment solves occupy T-1 compute units) and full of host
+        # round trips: the instances of a group finish side by side, each on its own stream and host thread.
+        if energy and len(live) > 1 and os.environ.get("REART_SWEEP_THREADS", "1") != "0":
+            with ThreadPoolExecutor(max_workers=len(live)) as pool:
+                finished = list(pool.map(finish, live))
+        else:
+            finished = [finish(e) for e in live]
+        for inst, rec in finished:
+            local[inst] = rec
     records = gather_records(local, len(instances), device)
     return records, best_instance(records)
