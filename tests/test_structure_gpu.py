@@ -295,3 +295,39 @@ def test_screw_edge_cases_match_the_reference(dev):
     close(sc[:, 7], G["screw_edge_d"], atol=1e-6)
     rot = np.abs(G["screw_edge_theta"]) > 1e-5                 # elsewhere the reference's moment is amplified rounding noise
     close(sc[rot, 3:6], G["screw_edge_m"][rot], atol=1e-6)
+
+
+def test_full_size_tail_vs_oracle_on_a_trained_state(dev):
+    """BASELINE size (T = 20, N = 4096, P = 20) after 1500 fused iterations on the synthetic sequence: the GPU tail
+    against the numpy oracle on the same model outputs -- labels and the undirected kinematic tree identical, cost
+    matrices and energies to rounding (edge directions may flip where cost[i,j] and cost[j,i] differ in the last bit)."""
+    import bench
+    import oracle
+    from oracle import structure as S
+    from reart_amd import tail
+    from reart_amd.utils import graph_utils as gu
+
+    eng, seq, model = bench.build_instance(dev, 20, 4096, 10, 2, n_iter=15000)
+    eng.capture(steps_per_graph=10)
+    eng.step(1500)
+    with torch.no_grad():
+        _, seg0, trans0 = model(eng.cano)
+    cano_np, seg_np, tr_np = eng.cano.cpu().numpy(), seg0.cpu().numpy(), trans0.detach().cpu().numpy()
+    seg_g, trans_g, conn_g = tail.extract_structure(seg0, trans0, eng.cano)
+    dn = S.denoise_seg_label(seg_np, cano_np, 20)
+    mg = S.merging_wrapper(dn, tr_np, cano_np, 3e-2, 2)
+    conn_o = S.mst_wrapper(mg, tr_np, cano_np)
+    seg_o, trans_o, conn_o = S.extract_kinematic(mg, tr_np, conn_o)
+    same(seg_g, seg_o)
+    und = lambda e: sorted(tuple(sorted(x)) for x in np.asarray(e).tolist())
+    assert und(conn_g.cpu().numpy()) == und(conn_o)
+    lab = np.unique(mg)
+    pairs = torch.from_numpy(np.stack([np.repeat(lab, len(lab)), np.tile(lab, len(lab))], 1)).to(dev)
+    geo_g = gu.screw_fit(trans0, pairs)["cost"][:, 2].cpu().numpy().reshape(len(lab), len(lab))
+    off = ~np.eye(len(lab), dtype=bool)
+    close(geo_g[off], S.geo_cost(tr_np, lab)[off], atol=2e-5)
+    e = tail.energy_terms(eng.cano, eng.pc_list[:1], seg_g, trans_g[:1], conn_g, 0)      # one frame: one 4096^2 assignment
+    pred = oracle.compute_pc_transform(cano_np, trans_o[:1], seg_o)
+    close(e["ass_err"], 100 * S.ass_err(pred, eng.pc_list[:1].cpu().numpy()), atol=1e-7, rtol=2e-5)
+    comp = np.concatenate([cano_np[None], pred])
+    close(e["group_err"], S.group_temporal_err(comp, seg_o), atol=1e-9, rtol=1e-5)
