@@ -71,3 +71,38 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(import|from)\s+oracle\b", src, flags=re.M), f
                 assert "liboracle" not in src, f
+
+
+def test_new_entry_points_reject_bad_arguments_without_a_gpu():
+    """Argument checks come before any device work: status codes, never exit() (SURVEY.md 8b error convention)."""
+    from reart_amd import _lib
+
+    L = _lib.lib()
+    bad = -1   # REART_ERR_INVALID_ARG
+    assert L.reart_screw_fit(None, 3, 2, None, 4, 0, None, None, None, None, None, None, None, 0, None) == bad
+    assert L.reart_part_fps(None, None, 10, None, 2, 20, 0, None, None, None) == bad
+    assert L.reart_part_pair_cost(None, None, 0, 3, 20, None, None, None, None) == bad
+    assert L.reart_group_temporal_err(None, 2, 10, None, None, 3, None, None, None) == bad
+    assert L.reart_cdist(None, None, 1, 4, 4, None, None) == bad
+    assert L.reart_cdist(None, None, 1, 70000, 4, None, None) == bad
+    assert L.reart_lap_auction(None, 1, 5000, None, None, None, None, None, 0, None) == bad      # n above 4096
+    assert L.reart_lap_workspace_bytes(3, 4096) > L.reart_lap_workspace_bytes(3, 2048) > 0
+    assert L.reart_lap_workspace_bytes(3, 4097) == 0
+    assert L.reart_screw_fit_workspace_bytes(19, 400) == 400 * 6 * 4
+    # empty problems are fine
+    assert L.reart_part_fps(1, 1, 10, 1, 0, 20, 0, 1, 1, None) == 0
+    assert L.reart_cdist(None, None, 0, 4, 4, None, None) == 0
+
+
+def test_structure_wrappers_have_no_cpu_fallback():
+    from reart_amd.utils import graph_utils as gu
+    from reart_amd.utils.lap import cdist
+    from reart_amd.utils.model_utils import compute_ass_err, compute_group_temporal_err
+
+    t = torch.eye(4).repeat(2, 3, 1, 1)
+    for call in (lambda: gu.screw_fit(t), lambda: gu.fps_sample_cano(torch.zeros(8, 3), torch.zeros(8, dtype=torch.long), torch.zeros(1, dtype=torch.long)),
+                 lambda: gu.compute_spatial_cost(torch.zeros(2, 4, 3)), lambda: cdist(torch.zeros(1, 4, 3), torch.zeros(1, 4, 3)),
+                 lambda: compute_ass_err(torch.zeros(1, 4, 3), torch.zeros(1, 4, 3)),
+                 lambda: compute_group_temporal_err(torch.zeros(2, 4, 3), torch.zeros(4, dtype=torch.long))):
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            call()
