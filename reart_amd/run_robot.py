@@ -148,7 +148,7 @@ def main(args):
         with torch.no_grad():
             pred, _, _ = model(cano_pc, tau=tau_func(cur_iter=i + 1)) if args.model == "base" else model(cano_pc)
             cd = recon_loss(pred, pc_list, chamfer_dist).item() / (2 * pred.shape[0] * pred.shape[1])
-        print(f"iteration: {i} | " + " | ".join(f"{k}: {v:.3f}" for k, v in losses.items())
+        print(f"iteration: {i} | " + " | ".join(f"{k}: {float(v.detach() if torch.is_tensor(v) else v):.3f}" for k, v in losses.items())
               + f" | mean squared NN distance: {cd:.3e}")
 
     n_iter = 1 if args.evaluate else args.n_iter
@@ -218,31 +218,31 @@ def main(args):
                                          weight_decay=args.weight_decay)
         from reart_amd.utils.lap import cdist
 
-        assign = None
+        matched = None
+        if args.use_assign_loss:
+            # run_robot.py:167-169: both FPS calls sample fixed clouds (start 0 on the reference's CUDA path): once
+            num_fps = pc_list.shape[1] // args.downsample
+            zero = torch.zeros(1, dtype=torch.long, device=device)
+            src_idx = farthest_point_sample(cano_pc[None], num_fps, start=zero).expand(pc_list.shape[0], num_fps)
+            tgt_pts = index_points(pc_list, farthest_point_sample(pc_list, num_fps, start=zero.expand(pc_list.shape[0])))
         while i < n_iter:
             kwargs = {"tau": tau_func(cur_iter=i + 1)} if args.model == "base" else {}
             pc_trans_list, seg_part, trans_list = model(cano_pc, **kwargs)
             losses, loss = {}, 0
             if args.use_assign_loss and i >= args.assign_iter:
-                if assign is None or i % args.assign_gap == 0:  # run_robot.py:165-178
-                    num_fps = pc_trans_list.shape[1] // args.downsample
-                    src_idx = farthest_point_sample(cano_pc[None], num_fps).expand(pc_trans_list.shape[0], num_fps)
-                    tgt_idx = farthest_point_sample(pc_list, num_fps)
-                    with torch.no_grad():
-                        cost = cdist(index_points(pc_trans_list, src_idx), index_points(pc_list, tgt_idx))
+                pc_src = index_points(pc_trans_list, src_idx)
+                if matched is None or i % args.assign_gap == 0:  # run_robot.py:165-178
                     # GPU auction + exact dual certificate; an uncertified matrix falls back to scipy on the host,
                     # so this is always the optimum the reference's linear_sum_assignment / parallel_lap returns
-                    assign = linear_sum_assignment_batch(cost)
-                pc_src, pc_tgt = index_points(pc_trans_list, src_idx), index_points(pc_list, tgt_idx)
-                rows = torch.cat([torch.as_tensor(r) for r, _ in assign]).to(device)
-                cols = torch.cat([torch.as_tensor(c) for _, c in assign]).to(device)
-                bidx = torch.cat([torch.full((len(r),), b) for b, (r, _) in enumerate(assign)]).to(device)
-                ass = args.lambda_assign * ((pc_src[bidx, rows] - pc_tgt[bidx, cols]) ** 2).sum(-1).sum()
-                losses["opt assignment loss"] = ass.item()
+                    assign = linear_sum_assignment_batch(cdist(pc_src.detach(), tgt_pts))
+                    cols = torch.from_numpy(np.stack([c for _, c in assign])).to(device)    # rows are 0..n-1 in order
+                    matched = tgt_pts.gather(1, cols[..., None].expand(-1, -1, 3))
+                ass = args.lambda_assign * ((pc_src - matched) ** 2).sum(-1).sum()
+                losses["opt assignment loss"] = ass
                 loss = loss + ass
             else:
                 rec = recon_loss(pc_trans_list, pc_list, chamfer_dist)
-                losses["recon Loss"] = rec.item()
+                losses["recon Loss"] = rec
                 loss = loss + rec
             if args.use_flow_loss:
                 c = args.cano_idx
@@ -254,9 +254,9 @@ def main(args):
                 fl = args.lambda_flow * flow_loss(torch.stack([b[0] for b in blended]), comp[1:] - comp[:-1],
                                                   flow_mask_list=torch.stack([b[1] for b in blended]),
                                                   robust=args.use_robust_loss)
-                losses["flow Loss"] = fl.item()
+                losses["flow Loss"] = fl
                 loss = loss + fl
-            losses["total Loss"] = float(loss.detach())
+            losses["total Loss"] = loss
             optimizer.zero_grad()
             loss.backward()
             optimizer.step()
