@@ -386,6 +386,14 @@ int reart_lap_auction(const float *cost, int B, int n, int32_t *col4row, int32_t
                       const double *price_in, double *price_out, void *workspace, size_t workspace_bytes,
                       void *stream);
 
+/* The same solve warm-started from an earlier solve of a similar batch (the loop re-solves every assign_gap
+ * iterations): on entry col4row holds that solve's assignment and price_in (required) its potentials; pairs that are
+ * still epsilon-tight under the new costs are kept.  Certified like a cold solve.  Use when the costs move smoothly
+ * (KinematicModel); with BaseModel's resampled part labels a cold solve is faster. */
+int reart_lap_auction_warm(const float *cost, int B, int n, int32_t *col4row, int32_t *certified,
+                           const double *price_in, double *price_out, void *workspace, size_t workspace_bytes,
+                           void *stream);
+
 /* Cost matrices for the above: replaces `torch.cdist(pc_src, pc_tgt)` (run_robot.py:171, utils/model_utils.py:93).
  *   a [B,n,3], b [B,m,3] -> out [B,n,m] = Euclidean distance, sqrt(((dx*dx)+(dy*dy))+(dz*dz)) in fp32. */
 int reart_cdist(const float *a, const float *b, int B, int n, int m, float *out, void *stream);

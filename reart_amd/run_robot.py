@@ -219,6 +219,8 @@ def main(args):
         from reart_amd.utils.lap import cdist
 
         matched = None
+        # the kinematic model moves the cost matrices smoothly: the previous solve's pairs and potentials start the next
+        kin_lap_state = {} if args.model == "kinematic" else None
         if args.use_assign_loss:
             # run_robot.py:167-169: both FPS calls sample fixed clouds (start 0 on the reference's CUDA path): once
             num_fps = pc_list.shape[1] // args.downsample
@@ -234,7 +236,8 @@ def main(args):
                 if matched is None or i % args.assign_gap == 0:  # run_robot.py:165-178
                     # GPU auction + exact dual certificate; an uncertified matrix falls back to scipy on the host,
                     # so this is always the optimum the reference's linear_sum_assignment / parallel_lap returns
-                    assign = linear_sum_assignment_batch(cdist(pc_src.detach(), tgt_pts))
+                    assign = linear_sum_assignment_batch(cdist(pc_src.detach(), tgt_pts), state=kin_lap_state,
+                                                         warm_assignment=kin_lap_state is not None)
                     cols = torch.from_numpy(np.stack([c for _, c in assign])).to(device)    # rows are 0..n-1 in order
                     matched = tgt_pts.gather(1, cols[..., None].expand(-1, -1, 3))
                 ass = args.lambda_assign * ((pc_src - matched) ** 2).sum(-1).sum()

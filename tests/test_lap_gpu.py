@@ -99,3 +99,26 @@ def test_cdist_matches_oracle_bitwise_and_torch(dev):
         np.testing.assert_array_equal(got.cpu().numpy(), oracle.cdist(a, b))
         ref = torch.cdist(torch.from_numpy(a).double(), torch.from_numpy(b).double()).numpy()
         np.testing.assert_allclose(got.cpu().numpy(), ref, atol=2e-7)
+
+
+def test_lap_warm_assignment_gives_the_optimum(dev):
+    """reart_lap_auction_warm: previous assignment + potentials as the start, on slightly moved, on unrelated and on
+    identical matrices -- always the certified optimum scipy returns."""
+    import oracle
+    from reart_amd.utils.lap import cdist, linear_sum_assignment_batch
+
+    rng = np.random.default_rng(8)
+    a = rng.uniform(-0.3, 0.3, (3, 600, 3)).astype(np.float32)
+    b = (a[:, rng.permutation(600)] + rng.normal(0, 0.004, (3, 600, 3))).astype(np.float32)
+    state = {}
+    for step in range(4):
+        moved = (a + 0.002 * step).astype(np.float32) if step < 3 else rng.uniform(-0.3, 0.3, (3, 600, 3)).astype(np.float32)
+        cost = cdist(torch.from_numpy(moved).to(dev), torch.from_numpy(b).to(dev))
+        out, fb = linear_sum_assignment_batch(cost, return_stats=True, state=state, warm_assignment=True)
+        ref = oracle.linear_sum_assignment(cost.cpu().numpy())
+        for k in range(3):
+            np.testing.assert_array_equal(out[k][1], ref[k][1])
+        assert fb == 0 and "cols" in state
+    out2 = linear_sum_assignment_batch(cost, state=state, warm_assignment=True)      # the same matrices again
+    for k in range(3):
+        np.testing.assert_array_equal(out2[k][1], ref[k][1])
