@@ -74,6 +74,34 @@ def cpu_baseline(seq, T, N, cano_idx, budget_s=20.0):
                       f"{el:.1f} s wall)"}
 
 
+def cpu_baseline_torch(seq, T, N, cano_idx, budget_s=10.0):
+    """The reference-style PyTorch-CPU loop body (oracle/torch_step.py: the tensor expressions the reference issues,
+    pinned to the reference's own trajectory golden) on the host cores: a bounded sample of the same workload."""
+    from oracle.torch_step import TorchRelax
+    from reart_amd.synthetic import split_canonical
+
+    cano, pcs = split_canonical(seq["complete"], cano_idx)
+    rng = np.random.default_rng(0)
+    H, P, B = 128, 20, T - 1
+    W1 = rng.uniform(-0.5, 0.5, (H, 3)).astype(np.float32)
+    b1 = rng.uniform(-0.5, 0.5, H).astype(np.float32)
+    W2 = rng.uniform(-0.08, 0.08, (P, H)).astype(np.float32)
+    p6d = np.tile(np.array([1, 0, 0, 0, 1, 0], np.float32), (B, P, 1))
+    pt = np.zeros((B, P, 3), np.float32)
+    eng = TorchRelax(cano, pcs, W1, b1, W2, p6d, pt, cano_idx, seq.get("ref_loc"), seq.get("ref_flow"))
+    eng.step()  # warm-up (thread pool, allocator)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        eng.step()
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 20:
+            break
+    return {"value": n / el, "unit": "iterations/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} iterations of the same T={T} x N={N} Chamfer+flow step (reference-style PyTorch-CPU ops: "
+                      f"conv1d / gumbel_softmax / bmm / cdist+argmin / topk / autograd / torch.optim.Adam, {el:.1f} s wall)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -83,7 +111,7 @@ def main():
     ap.add_argument("--points", type=int, default=4096)
     ap.add_argument("--no-flow", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--steps-per-graph", type=int, default=10,
+    ap.add_argument("--steps-per-graph", type=int, default=50,
                     help="iterations captured per graph (a graph launch costs ~8 us of idle GPU; the loop has no "
                          "host interaction, so several iterations replay as one graph)")
     ap.add_argument("--no-overlap", action="store_true", help="only affects the non-default search paths (brute force / grid): run their flow branch serially instead of on a second stream")
@@ -239,9 +267,10 @@ def main():
                              "note": "ALGORITHMIC flops (8 per query-target pair of the brute-force definition) over "
                                      "time; the exact box-pruned search evaluates only the pairs it cannot rule out, "
                                      "so this is work delivered, not ALU activity"}}
-        cpu = None
+        cpu = cpu_torch = None
         if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(seq, T, N, cano_idx)
+            cpu_torch = cpu_baseline_torch(seq, T, N, cano_idx)
         # secondary figure: what ends an instance (reference run_robot.py:224-330) -- structure extraction and
         # the model-selection energy on the state reached above; outside the timed region, never part of `value`
         end_of_run = None
@@ -314,6 +343,7 @@ def main():
                        "instances_per_gpu": K},
             "roofline": roof,
             "cpu_baseline": cpu,
+            "cpu_baseline_torch": cpu_torch,
             "sweep": sweep,
             "end_of_run": end_of_run,
             "phases_ms": {k: round(v, 5) for k, v in phases.items()},
@@ -322,6 +352,7 @@ def main():
         }
         print(json.dumps(out))
     if distributed:
+        dist.barrier()   # rank 0 is still timing its secondary figures: nobody tears the communicator down early
         dist.destroy_process_group()
 
 
