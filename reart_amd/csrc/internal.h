@@ -124,6 +124,7 @@ struct KnnArgs {
     int N, S, K, euclidean;
     int items0;            // work items belonging to job 0
     int items;             // total work items
+    int sparse;            // prune.hip: boxes needed by <= sparse queries of a wave take the sparse scan (set by the launcher)
 };
 
 int reart_knn_launch_slices(const KnnArgs &a, int KK, hipStream_t st);

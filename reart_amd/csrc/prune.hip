@@ -150,6 +150,7 @@ __device__ __forceinline__ void knn_pruned_body(const KnnArgs &a, const int w) {
     const float *tx_g = tx;
 
     int work = 16;   // uniform work counter of this item (prologue ~ 16 tests)
+    const int sparse_max = a.sparse;   // boxes needed by at most this many queries take the sparse scan (0: off)
     const int per = 64 * a.S;
     for (int base = 0; base < nbox; base += per) {
         // ---- coarse filter: lane l looks at box base + l*S + s
@@ -221,6 +222,53 @@ __device__ __forceinline__ void knn_pruned_body(const KnnArgs &a, const int w) {
                 thr = fminf(thr, bm[KK - 1]);
             }
         };
+        // sparse form of the scan for a box that at most PR_SPARSE of the 64 queries need (40-60 % of the scanned
+        // boxes, tools/prune_stats.py): instead of all 64 lanes walking the 16 targets for the sake of a few,
+        // 8 lanes x 2 targets (packed) evaluate ONE needing query against the box, eight such queries side by side.
+        // The needing lanes park their coordinates in LDS by their rank among the needers, row r of 8 lanes reads
+        // query r, the row minimum (same distance expression, min is order-free) goes back to its lane through one
+        // ds_bpermute.  A lane that does not need the box (lb > thr) is not updated: its minimum over this box
+        // would exceed thr and can never be (or tie with) one of its K nearest after the slice merge.
+        auto sparse_box = [&](const int bit, const unsigned long long need, const bool nd) {
+            work += 2;
+            if (KK == 1) PRUNE_STAT(2, 1);
+            const int j0 = (base + bit * a.S + s) * NN_BOX;
+            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need, 0u));
+            float *s_qc = s_tg + 64;                                     // [8][4] behind the staged box of the dense scan
+            if (nd) *(float4 *)(s_qc + 4 * rank) = make_float4(qx, qy, qz, 0.f);
+            const int u = lane & 7;
+            const float *tp = tx_g + j0 + 2 * u;
+            const f2 txv = *(const f2 *)tp, tyv = *(const f2 *)(tp + jb.Ppad), tzv = *(const f2 *)(tp + 2 * (size_t)jb.Ppad);
+            const float4 qc = *(const float4 *)(s_qc + 4 * (lane >> 3));
+            const f2 cx = {qc.x, qc.x}, cy = {qc.y, qc.y}, cz = {qc.z, qc.z};
+            const f2 dx = cx - txv, dy = cy - tyv, dz = cz - tzv;
+            const f2 d = (dx * dx + dy * dy) + dz * dz;
+            float m = fminf(d.x, d.y);
+            m = fminf(m, reart_dpp<0xB1>(m));                            // quad: targets 8h .. 8h+7 of the box
+            m = fminf(m, reart_dpp<0x4E>(m));
+            if (KK == 1) {
+                m = fminf(m, reart_dpp<0x141>(m));                       // row_half_mirror: all 16 targets
+                float r = __int_as_float(__builtin_amdgcn_ds_bpermute(rank << 5, __float_as_int(m)));
+                r = nd ? r : INFINITY;
+                if (r < bm[0]) { bm[0] = r; bb[0] = j0; }
+                thr = fminf(thr, r);
+            } else {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    float r = __int_as_float(__builtin_amdgcn_ds_bpermute((rank << 5) + (h << 4), __float_as_int(m)));
+                    r = nd ? r : INFINITY;
+#pragma unroll
+                    for (int c = KK - 1; c >= 0; --c) {
+                        const int cp = c > 0 ? c - 1 : 0;
+                        const bool lt_prev = (c > 0) && (r < bm[cp]);
+                        const bool lt_cur = r < bm[c];
+                        bm[c] = lt_prev ? bm[cp] : (lt_cur ? r : bm[c]);
+                        bb[c] = lt_prev ? bb[cp] : (lt_cur ? j0 + 8 * h : bb[c]);
+                    }
+                }
+                thr = fminf(thr, bm[KK - 1]);
+            }
+        };
         while (mask) {
             // ---- take the next PR_PF surviving boxes and put ALL their targets in flight: lane l < 48
             // loads one float of each box (192 coalesced bytes per box) through the vector memory path,
@@ -273,7 +321,12 @@ __device__ __forceinline__ void knn_pruned_body(const KnnArgs &a, const int w) {
                     if (nl) PRUNE_STAT(nl == 1 ? 4 : (nl < 4 ? 5 : (nl < 8 ? 6 : 7)), 1);
                 }
 #endif
-                if (__any(lbh <= thr)) scan_box(h ? bB : bA, slot + h);
+                const bool nd = lbh <= thr;
+                const unsigned long long need = __ballot(nd);
+                if (need) {
+                    if (sparse_max > 0 && __builtin_popcountll(need) <= sparse_max) sparse_box(h ? bB : bA, need, nd);
+                    else scan_box(h ? bB : bA, slot + h);
+                }
             }
             slot += 2;
             }
@@ -303,6 +356,13 @@ __device__ __forceinline__ void knn_pruned_body(const KnnArgs &a, const int w) {
 template <int KK>
 __global__ __launch_bounds__(NN_BS * PR_WPB) void knn_pruned_kernel(KnnArgs a) {
     knn_pruned_body<KK>(a, blockIdx.x * PR_WPB + (threadIdx.x >> 6));
+}
+
+// REART_SPARSE=n: boxes needed by at most n (0..8) queries of the wave take the sparse scan; default 8, 0 = always dense
+static int reart_prune_pick_sparse(void) {
+    const char *env = getenv("REART_SPARSE");
+    const int n = env ? atoi(env) : 8;
+    return n < 0 ? 0 : (n > 8 ? 8 : n);
 }
 
 // Both searches of one iteration in ONE launch: the K = 1 Chamfer items and the K = 3 flow items are
@@ -354,6 +414,7 @@ int reart_knn_launch_pruned_pair(const KnnArgs &k1, const KnnArgs &k3, unsigned 
     if (k1.items != 2 * k1.items0 || k3.items != k3.items0) return REART_ERR_INVALID_ARG;
     KnnPairArgs a;
     a.k1 = k1; a.k3 = k3;
+    a.k1.sparse = a.k3.sparse = reart_prune_pick_sparse();
     const int m = (k1.items / 2 < k3.items) ? k1.items / 2 : k3.items;
     a.mixed = 3 * m;
     a.ctr = counters;
@@ -372,7 +433,9 @@ int reart_knn_launch_pruned_pair(const KnnArgs &k1, const KnnArgs &k3, unsigned 
     return REART_OK;
 }
 
-int reart_knn_launch_pruned(const KnnArgs &a, int KK, hipStream_t st) {
+int reart_knn_launch_pruned(const KnnArgs &a_in, int KK, hipStream_t st) {
+    KnnArgs a = a_in;
+    a.sparse = reart_prune_pick_sparse();
     const int grid = reart_div_up(a.items, PR_WPB);
     for (int j = 0; j < 2; ++j)
         if (!a.job[j].boxes || !a.job[j].seed) return REART_ERR_INVALID_ARG;
