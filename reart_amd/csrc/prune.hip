@@ -150,7 +150,8 @@ __device__ __forceinline__ void knn_pruned_body(const KnnArgs &a, const int w) {
     const float *tx_g = tx;
 
     int work = 16;   // uniform work counter of this item (prologue ~ 16 tests)
-    const int sparse_max = a.sparse;   // boxes needed by at most this many queries take the sparse scan (0: off)
+    const int sparse_max = a.sparse < 8 ? a.sparse : 8;   // boxes needed by at most this many queries take the sparse scan (0: off)
+    const int sparse16_max = a.sparse > 8 ? a.sparse : 0;   // 9 .. 16 needers: the 16-query form
     const int per = 64 * a.S;
     for (int base = 0; base < nbox; base += per) {
         // ---- coarse filter: lane l looks at box base + l*S + s
@@ -269,6 +270,48 @@ __device__ __forceinline__ void knn_pruned_body(const KnnArgs &a, const int w) {
                 thr = fminf(thr, bm[KK - 1]);
             }
         };
+        // the same for 9..16 needing queries: 4 lanes x 4 targets per query, sixteen queries side by side
+        auto sparse16_box = [&](const int bit, const unsigned long long need, const bool nd) {
+            work += 3;
+            if (KK == 1) PRUNE_STAT(2, 1);
+            const int j0 = (base + bit * a.S + s) * NN_BOX;
+            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need, 0u));
+            float *s_qc = s_tg + 64;                                     // [16][4]
+            if (nd) *(float4 *)(s_qc + 4 * rank) = make_float4(qx, qy, qz, 0.f);
+            const int u = lane & 3;
+            const float *tp = tx_g + j0 + 4 * u;
+            const float4 txv = *(const float4 *)tp, tyv = *(const float4 *)(tp + jb.Ppad), tzv = *(const float4 *)(tp + 2 * (size_t)jb.Ppad);
+            const float4 qc = *(const float4 *)(s_qc + 4 * (lane >> 2));
+            const f2 cx = {qc.x, qc.x}, cy = {qc.y, qc.y}, cz = {qc.z, qc.z};
+            const f2 dxa = cx - f2{txv.x, txv.y}, dya = cy - f2{tyv.x, tyv.y}, dza = cz - f2{tzv.x, tzv.y};
+            const f2 dxb = cx - f2{txv.z, txv.w}, dyb = cy - f2{tyv.z, tyv.w}, dzb = cz - f2{tzv.z, tzv.w};
+            const f2 da = (dxa * dxa + dya * dya) + dza * dza;
+            const f2 db = (dxb * dxb + dyb * dyb) + dzb * dzb;
+            float m = fminf(fminf(da.x, da.y), fminf(db.x, db.y));
+            m = fminf(m, reart_dpp<0xB1>(m));                            // lanes {0,1}: targets 0..7, lanes {2,3}: 8..15
+            if (KK == 1) {
+                m = fminf(m, reart_dpp<0x4E>(m));                        // all 16 targets
+                float r = __int_as_float(__builtin_amdgcn_ds_bpermute(rank << 4, __float_as_int(m)));
+                r = nd ? r : INFINITY;
+                if (r < bm[0]) { bm[0] = r; bb[0] = j0; }
+                thr = fminf(thr, r);
+            } else {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    float r = __int_as_float(__builtin_amdgcn_ds_bpermute((rank << 4) + (h << 3), __float_as_int(m)));
+                    r = nd ? r : INFINITY;
+#pragma unroll
+                    for (int c = KK - 1; c >= 0; --c) {
+                        const int cp = c > 0 ? c - 1 : 0;
+                        const bool lt_prev = (c > 0) && (r < bm[cp]);
+                        const bool lt_cur = r < bm[c];
+                        bm[c] = lt_prev ? bm[cp] : (lt_cur ? r : bm[c]);
+                        bb[c] = lt_prev ? bb[cp] : (lt_cur ? j0 + 8 * h : bb[c]);
+                    }
+                }
+                thr = fminf(thr, bm[KK - 1]);
+            }
+        };
         while (mask) {
             // ---- take the next PR_PF surviving boxes and put ALL their targets in flight: lane l < 48
             // loads one float of each box (192 coalesced bytes per box) through the vector memory path,
@@ -324,7 +367,9 @@ __device__ __forceinline__ void knn_pruned_body(const KnnArgs &a, const int w) {
                 const bool nd = lbh <= thr;
                 const unsigned long long need = __ballot(nd);
                 if (need) {
-                    if (sparse_max > 0 && __builtin_popcountll(need) <= sparse_max) sparse_box(h ? bB : bA, need, nd);
+                    const int nneed = __builtin_popcountll(need);
+                    if (nneed <= sparse_max) sparse_box(h ? bB : bA, need, nd);
+                    else if (nneed <= sparse16_max) sparse16_box(h ? bB : bA, need, nd);
                     else scan_box(h ? bB : bA, slot + h);
                 }
             }
@@ -361,8 +406,8 @@ __global__ __launch_bounds__(NN_BS * PR_WPB) void knn_pruned_kernel(KnnArgs a) {
 // REART_SPARSE=n: boxes needed by at most n (0..8) queries of the wave take the sparse scan; default 8, 0 = always dense
 static int reart_prune_pick_sparse(void) {
     const char *env = getenv("REART_SPARSE");
-    const int n = env ? atoi(env) : 8;
-    return n < 0 ? 0 : (n > 8 ? 8 : n);
+    const int n = env ? atoi(env) : 16;
+    return n < 0 ? 0 : (n > 16 ? 16 : n);
 }
 
 // Both searches of one iteration in ONE launch: the K = 1 Chamfer items and the K = 3 flow items are
