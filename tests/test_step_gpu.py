@@ -170,8 +170,9 @@ def test_grid_search_step_is_bit_identical_to_brute_force(dev):
 
 def test_search_variants_give_identical_trajectories(dev, monkeypatch):
     """The exact searches are interchangeable IN SITU: 40 iterations of the same instance with the
-    box-pruned warm-started search (default, merged launches), the same with separate launches, the
-    per-lane variant, and cold brute force must leave bit-identical parameters and loss logs."""
+    box-pruned warm-started search (default: sparse scans, three slices, merged launches), the same with
+    separate launches, dense scans only, other sparse thresholds and slice counts, the per-lane and
+    16-query variants, and cold brute force must leave bit-identical parameters and loss logs."""
     from reart_amd.networks.model import BaseModel
     from reart_amd.relax import RelaxEngine
     from reart_amd.synthetic import make_sequence, split_canonical
@@ -181,8 +182,10 @@ def test_search_variants_give_identical_trajectories(dev, monkeypatch):
     runs = {}
     for name, env in (("pruned", {}), ("separate", {"REART_MERGE": "0"}), ("lane", {"REART_SEARCH": "lane"}),
                       ("quad", {"REART_SEARCH": "quad"}), ("quad_separate", {"REART_SEARCH": "quad", "REART_MERGE": "0"}),
-                      ("wave", {"REART_SEARCH": "wave"}), ("brute", {"REART_SEARCH": "brute"})):
-        for k in ("REART_MERGE", "REART_SEARCH"):
+                      ("wave", {"REART_SEARCH": "wave"}), ("dense", {"REART_SPARSE": "0"}), ("sparse8", {"REART_SPARSE": "8"}),
+                      ("sparse3", {"REART_SPARSE": "3"}), ("split1", {"REART_PRUNE_SPLIT": "1"}),
+                      ("split4_dense", {"REART_PRUNE_SPLIT": "4", "REART_SPARSE": "0"}), ("brute", {"REART_SEARCH": "brute"})):
+        for k in ("REART_MERGE", "REART_SEARCH", "REART_SPARSE", "REART_PRUNE_SPLIT"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -196,7 +199,7 @@ def test_search_variants_give_identical_trajectories(dev, monkeypatch):
                       model.seg_head.model[2].weight.detach().cpu().numpy().copy(), eng.seg_part.cpu().numpy())
     ref = runs["brute"]
     assert np.isfinite(ref[0]).all()
-    for name in ("pruned", "separate", "lane", "quad", "quad_separate", "wave"):
+    for name in ("pruned", "separate", "lane", "quad", "quad_separate", "wave", "dense", "sparse8", "sparse3", "split1", "split4_dense"):
         for a, b in zip(runs[name], ref):
             np.testing.assert_array_equal(a, b, err_msg=name)
 
@@ -270,3 +273,24 @@ def test_assignment_loss_step_matches_oracle(oracle, dev):
                        ("W1", model.seg_head.model[0].weight), ("b1", model.seg_head.model[0].bias)):
             got = prm.detach().cpu().numpy().reshape(orc.params[k].shape)
             np.testing.assert_allclose(got, orc.params[k], rtol=0, atol=2e-5, err_msg=f"iter {i} param {k}")
+
+
+def test_full_size_sparse_scan_equals_dense_scan_over_a_run(dev, monkeypatch):
+    """BASELINE configuration, 400 iterations (the state moves through the high-temperature phase): the
+    sparse forms of the box scan (8 and 16 queries side by side) leave exactly the loss log and parameters of
+    dense scans only."""
+    import bench
+
+    runs = {}
+    for name, env in (("sparse", {}), ("dense", {"REART_SPARSE": "0"})):
+        monkeypatch.delenv("REART_SPARSE", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng, seq, model = bench.build_instance(dev, 20, 4096, 10, seed=2)
+        eng.step(400)
+        it, log = eng.loss_log()
+        runs[name] = (log.cpu().numpy(), model.proposal_6d.detach().cpu().numpy().copy(),
+                      model.proposal_t.detach().cpu().numpy().copy(), eng.pc_trans.cpu().numpy(), eng.seg_part.cpu().numpy())
+    assert np.isfinite(runs["dense"][0]).all()
+    for a, b in zip(runs["sparse"], runs["dense"]):
+        np.testing.assert_array_equal(a, b)
