@@ -137,6 +137,7 @@ int reart_boxes_launch(const float *soa, int N, int Ppad, float *boxes, hipStrea
 // exact search with box pruning + warm start (prune.hip); partial lists only, boxes dealt round-robin to slices
 int reart_knn_launch_pruned(const KnnArgs &a, int KK, hipStream_t st);
 int reart_prune_pick_split(void);
+int reart_prune_pick_split3(void);   // slices of the K = 3 (flow) search
 // K = 1 (two jobs) and K = 3 (one job) pruned searches in one launch
 // counters: 2 zero-initialised uints for the persistent form (NULL: one workgroup per item)
 int reart_knn_launch_pruned_pair(const KnnArgs &k1, const KnnArgs &k3, unsigned int *counters, hipStream_t st);

@@ -503,6 +503,13 @@ int reart_prune_pick_split(void) {
     return S >= 1 && S <= 16 ? S : 3;
 }
 
+int reart_prune_pick_split3(void) {
+    const char *env = getenv("REART_PRUNE_SPLIT3");
+    if (!env) return reart_prune_pick_split();
+    const int S = atoi(env);
+    return S >= 1 && S <= 16 ? S : reart_prune_pick_split();
+}
+
 // ---------------------------------------------------------------------------------------------
 // Stand-alone entry: warm-started exact K-NN (K = 1 or 3) through the C ABI.
 // ---------------------------------------------------------------------------------------------

@@ -61,7 +61,7 @@ static int step_plan(const reart_relax_config *c, StepPlan *p) {
     p->S3 = 1; p->Mpad = 0;
     if (c->use_flow) {
         const long waves3 = (long)c->B * reart_div_up(c->N, NN_BS);
-        p->S3 = p->pruned >= 2 ? 1 : (p->pruned ? reart_prune_pick_split() : reart_knn_pick_split(waves3, c->M_max, 3));
+        p->S3 = p->pruned >= 2 ? 1 : (p->pruned ? reart_prune_pick_split3() : reart_knn_pick_split(waves3, c->M_max, 3));
         p->Mpad = (int)reart_align_up((size_t)reart_div_up(c->M_max, p->S3), NN_BOX) * p->S3;
     }
     p->nchunk = reart_div_up(c->N, 64);

@@ -7,7 +7,7 @@ import numpy as np, torch, bench
 from reart_amd import _lib
 eng, seq, model = bench.build_instance(torch.device("cuda:0"), 20, 4096, 10, 2)
 lib = ctypes.CDLL(_lib.LIB_PATH)
-n = 14592
+n = 10944   # items of one launch: 3 jobs x 19 frames x 64 query waves x S = 3 slices
 buf = (ctypes.c_ulonglong * (3 * n))()
 for it in (330, 3000):
     eng.step(it - int(eng.iter.item())); torch.cuda.synchronize()
