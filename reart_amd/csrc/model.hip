@@ -159,10 +159,11 @@ __global__ __launch_bounds__(64 * (((PP > 0 ? PP : 32) + FW_PG - 1) / FW_PG)) vo
     constexpr int BS = 64 * W;
     float *s_rt = smem;                                   // [B*P][12]
     float *s_wb = s_rt + 12 * (size_t)a.B * a.P;          // [H][4]  W1 row | b1
-    float *s_w2T = s_wb + 4 * (size_t)a.H;                // [H][PMAX]  W2 transposed
+    float *s_w2T = s_wb + 4 * (size_t)a.H;                // [W][H][2]  W2 of wave g's two parts, j-major: 16-byte reads give two j
     float *s_a = s_w2T + (size_t)a.H * PMAX;              // [PMAX][64]  logits, later y
     float *s_e = s_a + PMAX * FW_PTS;                     // [PMAX][64]  z, later exp(z - max)
-    float *s_hh = s_e + PMAX * FW_PTS;                    // [H][64]  hidden activations of the 64 points
+    float *s_hh = s_e + PMAX * FW_PTS;                    // [64][H + 4]  hidden activations, point-major: a lane reads four j at once
+    const int HS = a.H + 4;                               // row stride (16-byte aligned rows, lanes spread over the banks)
     const int tid = threadIdx.x, lane = tid & 63, grp = tid >> 6;
     PHASE_TS(0, 0);
     const int P = (PP > 0) ? PP : a.P;
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(64 * (((PP > 0 ? PP : 32) + FW_PG - 1) / FW_PG)) vo
         if (tid < 4 * a.H) s_wb[tid] = wbv;
         if (tid < a.H) {
 #pragma unroll
-            for (int p = 0; p < PMAX; ++p) s_w2T[tid * PMAX + p] = vw[p];
+            for (int p = 0; p < PMAX; ++p) s_w2T[((p >> 1) * a.H + tid) * 2 + (p & 1)] = p < P ? vw[p] : 0.f;
         }
     }
     for (int e = tid + BS; e < nRT; e += BS) {
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(64 * (((PP > 0 ? PP : 32) + FW_PG - 1) / FW_PG)) vo
         s_wb[e] = c < 3 ? a.W1[3 * j + c] : a.b1[j];
     }
     for (int j = tid + BS; j < a.H; j += BS)          // one hidden unit per thread: no integer division
-        for (int p = 0; p < P; ++p) s_w2T[j * PMAX + p] = a.W2[(size_t)p * a.H + j];
+        for (int p = 0; p < PMAX; ++p) s_w2T[((p >> 1) * a.H + j) * 2 + (p & 1)] = p < P ? a.W2[(size_t)p * a.H + j] : 0.f;
 
     const int n = blockIdx.x * FW_PTS + lane;
     const bool live = n < a.N;
@@ -261,19 +262,31 @@ __global__ __launch_bounds__(64 * (((PP > 0 ? PP : 32) + FW_PG - 1) / FW_PG)) vo
             acc = fmaf(wb.z, x2, acc);
             acc = acc + wb.w;
             const float h = acc > 0.f ? acc : 0.f;
-            s_hh[j * FW_PTS + lane] = h;
+            s_hh[lane * HS + j] = h;
             if (a.hT && live) a.hT[(size_t)j * a.N + n] = h;
         }
     }
     __syncthreads();
     // logits of this wave's two parts: the full ascending-j fmaf chain (the oracle's rounding order)
     float sp0 = 0.f, sp1 = 0.f;
-#pragma unroll 8
-    for (int j = 0; j < a.H; ++j) {
-        const float h = s_hh[j * FW_PTS + lane];
-        const float2 w2 = *(const float2 *)(s_w2T + j * PMAX + p0);   // p0 and PMAX are even
-        sp0 = fmaf(w2.x, h, sp0);
-        sp1 = fmaf(w2.y, h, sp1);   // in range, ignored when !has1
+    {
+        const float *hrow = s_hh + lane * HS, *wrow = s_w2T + (size_t)grp * a.H * 2;
+        int j = 0;
+        const int H4 = (a.H & 3) == 0 ? a.H : 0;   // rows are 16-byte aligned only when H is a multiple of 4
+#pragma unroll 2
+        for (; j + 4 <= H4; j += 4) {   // 16-byte LDS reads: four h of this point, two (w0, w1) pairs per read
+            const float4 h4 = *(const float4 *)(hrow + j);
+            const float4 wa = *(const float4 *)(wrow + 2 * j), wb2 = *(const float4 *)(wrow + 2 * j + 4);
+            sp0 = fmaf(wa.x, h4.x, sp0); sp1 = fmaf(wa.y, h4.x, sp1);   // sp1: ignored when !has1 (weights are 0)
+            sp0 = fmaf(wa.z, h4.y, sp0); sp1 = fmaf(wa.w, h4.y, sp1);
+            sp0 = fmaf(wb2.x, h4.z, sp0); sp1 = fmaf(wb2.y, h4.z, sp1);
+            sp0 = fmaf(wb2.z, h4.w, sp0); sp1 = fmaf(wb2.w, h4.w, sp1);
+        }
+        for (; j < a.H; ++j) {
+            const float h = hrow[j];
+            sp0 = fmaf(wrow[2 * j], h, sp0);
+            sp1 = fmaf(wrow[2 * j + 1], h, sp1);
+        }
     }
     PHASE_TS(0, 2);
     const float z0 = (sp0 + g0) / tau, z1 = has1 ? (sp1 + g1) / tau : -INFINITY;
@@ -366,7 +379,7 @@ static void launch_base_fwd(const BaseFwdArgs &a, hipStream_t st) {
     constexpr int W = (PMAX + FW_PG - 1) / FW_PG;
     const int cover = a.out_soa ? (a.Npad > a.N ? a.Npad : a.N) : a.N;
     const size_t lds = sizeof(float) * (12 * (size_t)a.B * a.P + (size_t)a.H * (4 + PMAX) + 2 * (size_t)FW_PTS * PMAX +
-                                        (size_t)a.H * FW_PTS);
+                                        (size_t)(a.H + 4) * FW_PTS);
     static bool attr_set = false;  // raise the dynamic-LDS cap once (160 KiB per CU on gfx950)
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void *)base_fwd_kernel<PP>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
@@ -377,7 +390,7 @@ static void launch_base_fwd(const BaseFwdArgs &a, hipStream_t st) {
 
 static int dispatch_base_fwd(const BaseFwdArgs &a, hipStream_t st) {
     if (a.P < 1 || a.P > 32) return REART_ERR_UNSUPPORTED;
-    if (((size_t)a.B * a.P * 12 + 2 * FW_PTS * 32 + (size_t)a.H * (36 + FW_PTS)) * sizeof(float) > 152 * 1024) return REART_ERR_UNSUPPORTED;
+    if (((size_t)a.B * a.P * 12 + 2 * FW_PTS * 32 + (size_t)a.H * (36 + FW_PTS) + 4 * FW_PTS) * sizeof(float) > 152 * 1024) return REART_ERR_UNSUPPORTED;
     switch (a.P) {
         case 20: launch_base_fwd<20>(a, st); break;
         case 10: launch_base_fwd<10>(a, st); break;
