@@ -35,7 +35,8 @@ struct BaseBwdArgs {
     const float *gpf;           // [B,N,3] d(lambda*flow)/d pred_flow or NULL
     int cano_idx;
     int N, P, B, H;
-    int nchunk;                 // ceil(N / RED_CHUNK)
+    int nchunk;                 // ceil(N / cpts)
+    int cpts;                   // points per backward workgroup: 64 or 32 (set by the launcher)
     float *partial;             // [nchunk][n_out]
     // finalize
     float *gW1, *gb1, *gW2, *g6d, *gt;

@@ -472,8 +472,11 @@ __global__ __launch_bounds__(64 * (((PP > 0 ? PP : 32) + FW_PG - 1) / FW_PG)) vo
     float *s_w2T = s_G + (size_t)a.B * RED_CHUNK * 3;// [H][PMAX]
     float *s_rt = s_w2T + (size_t)a.H * PMAX;        // [B*P][12]  [R|t] rows
     const int tid = threadIdx.x, lane = tid & 63, grp = tid >> 6, chunk = blockIdx.x;
-    const int n0 = chunk * RED_CHUNK;
-    const int cn = (a.N - n0) < RED_CHUNK ? (a.N - n0) : RED_CHUNK;
+    // a workgroup owns a.cpts (64 or 32) points; the tiles keep their 64-point layout (columns >= cn are zero), the
+    // matrix-core loops stop at cn: with 32 points twice as many workgroups each run half the reductions
+    const int n0 = chunk * a.cpts;
+    const int cn = (a.N - n0) < a.cpts ? (a.N - n0) : a.cpts;
+    const int cn16 = (cn + 15) & ~15;   // tile columns beyond cn are zero: whole blocks of 16 points keep the loops unrolled
     float *prow = a.partial + (size_t)chunk * n_out(a.P, a.H, a.B);
     PHASE_TS(1, 0);
 
@@ -588,8 +591,9 @@ __global__ __launch_bounds__(64 * (((PP > 0 ? PP : 32) + FW_PG - 1) / FW_PG)) vo
     {
         typedef float f4v __attribute__((ext_vector_type(4)));
         const int ntn = (P + 15) / 16;                       // part tiles
-        for (int tile = grp; tile < 4 * ntn; tile += W) {
-            const int mt = tile & 3, nt = tile >> 2;
+        const int mtn = (cn + 15) >> 4;                      // point tiles
+        for (int tile = grp; tile < mtn * ntn; tile += W) {
+            const int nt = tile / mtn, mt = tile - nt * mtn;
             const int nl = 16 * mt + (lane & 15), kq = lane >> 4;          // A row (point), k within the instruction
             const int pc = 16 * nt + (lane & 15);                          // B column (part)
             const bool pok = pc < P;
@@ -652,11 +656,13 @@ __global__ __launch_bounds__(64 * (((PP > 0 ? PP : 32) + FW_PG - 1) / FW_PG)) vo
         const float *ap = s_ds + (pr < P ? pr : 0) * BW_LD + kh;
         const float *bp = s_h + (jc < a.H ? jc : 0) * BW_LD + kh;
         const bool aok = pr < P, bok = jc < a.H;
-#pragma unroll 8
-        for (int kk = 0; kk < RED_CHUNK; kk += 2) {
-            const float av = aok ? ap[kk] : 0.f;
-            const float bv = bok ? bp[kk] : 0.f;
-            c = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, c, 0, 0, 0);
+        for (int kb = 0; kb < cn16; kb += 16) {
+#pragma unroll
+            for (int kk = kb; kk < kb + 16; kk += 2) {
+                const float av = aok ? ap[kk] : 0.f;
+                const float bv = bok ? bp[kk] : 0.f;
+                c = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, c, 0, 0, 0);
+            }
         }
         // C/D layout: row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5), col = lane & 31
 #pragma unroll
@@ -679,13 +685,15 @@ __global__ __launch_bounds__(64 * (((PP > 0 ? PP : 32) + FW_PG - 1) / FW_PG)) vo
         const int t = cok ? col / 12 : 0, e = cok ? col - t * 12 : 0;
         const int gr = e < 9 ? e / 3 : e - 9, xc = e < 9 ? e - 3 * (e / 3) : 0;
         const float *gcol = s_G + t * (RED_CHUNK * 3) + gr;
-#pragma unroll 8
-        for (int kk = 0; kk < RED_CHUNK; kk += 2) {
-            const int n = kk + kh;
-            const float av = (s_kn[n] == pr) ? 1.f : 0.f;
-            float bv = s_w[n] * gcol[3 * n];
-            if (e < 9) bv = bv * s_x[3 * n + xc];
-            c = __builtin_amdgcn_mfma_f32_32x32x2f32(av, cok ? bv : 0.f, c, 0, 0, 0);
+        for (int kb = 0; kb < cn16; kb += 16) {
+#pragma unroll
+            for (int kk = kb; kk < kb + 16; kk += 2) {
+                const int n = kk + kh;
+                const float av = (s_kn[n] == pr) ? 1.f : 0.f;
+                float bv = s_w[n] * gcol[3 * n];
+                if (e < 9) bv = bv * s_x[3 * n + xc];
+                c = __builtin_amdgcn_mfma_f32_32x32x2f32(av, cok ? bv : 0.f, c, 0, 0, 0);
+            }
         }
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
@@ -728,12 +736,16 @@ __global__ __launch_bounds__(64 * (((PP > 0 ? PP : 32) + FW_PG - 1) / FW_PG)) vo
         const int j = o >> 2, c = o & 3;
         float acc = 0.f;
         if (c < 3) {
-#pragma unroll 8
-            for (int i = 0; i < RED_CHUNK; ++i) acc = fmaf(s_h[j * BW_LD + i], s_x[3 * i + c], acc);
+            for (int ib = 0; ib < cn16; ib += 16) {
+#pragma unroll
+                for (int i = ib; i < ib + 16; ++i) acc = fmaf(s_h[j * BW_LD + i], s_x[3 * i + c], acc);
+            }
             prow[off_gW1(a.P, a.H) + 3 * j + c] = acc;
         } else {
-#pragma unroll 8
-            for (int i = 0; i < RED_CHUNK; ++i) acc += s_h[j * BW_LD + i];
+            for (int ib = 0; ib < cn16; ib += 16) {
+#pragma unroll
+                for (int i = ib; i < ib + 16; ++i) acc += s_h[j * BW_LD + i];
+            }
             prow[off_gb1(a.P, a.H) + j] = acc;
         }
     }
@@ -901,7 +913,7 @@ __global__ __launch_bounds__(256) void base_bwd_finalize_kernel(BaseBwdArgs a, F
 }
 
 static size_t base_bwd_ws_layout(int N, int P, int B, int H, size_t *o_rt, size_t *o_part) {
-    const int nchunk = reart_div_up(N, RED_CHUNK);
+    const int nchunk = reart_div_up(N, 16);   // room for the 16-point form (four times the partial rows of the 64-point form)
     size_t off = 0;
     *o_rt = off; off += reart_align_up(sizeof(float) * 12 * (size_t)B * P, 256);
     *o_part = off; off += reart_align_up(sizeof(float) * (size_t)nchunk * n_out(P, H, B), 256);
@@ -937,7 +949,12 @@ int reart_base_backward_ex(BaseBwdArgs a, const FinalizeAdam *adam, const StepBo
     if (!workspace || workspace_bytes < need) return REART_ERR_INVALID_ARG;
     char *ws = (char *)workspace;
     a.partial = (float *)(ws + o_part);
-    a.nchunk = reart_div_up(a.N, RED_CHUNK);
+    {   // REART_BWD_PTS=64|32|16: points per backward workgroup
+        const char *env = getenv("REART_BWD_PTS");
+        const int v = env ? atoi(env) : 32;
+        a.cpts = (v == 64 || v == 32 || v == 16) ? v : 32;
+    }
+    a.nchunk = reart_div_up(a.N, a.cpts);
     if (!a.rt_table) {
         float *table = (float *)(ws + o_rt);
         hipLaunchKernelGGL(rt_table_kernel, dim3(reart_div_up(a.B * a.P, 256)), dim3(256), 0, st, a.p6d, a.pt,

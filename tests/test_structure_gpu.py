@@ -328,6 +328,18 @@ def test_full_size_tail_vs_oracle_on_a_trained_state(dev):
     close(geo_g[off], S.geo_cost(tr_np, lab)[off], atol=2e-5)
     e = tail.energy_terms(eng.cano, eng.pc_list[:1], seg_g, trans_g[:1], conn_g, 0)      # one frame: one 4096^2 assignment
     pred = oracle.compute_pc_transform(cano_np, trans_o[:1], seg_o)
-    close(e["ass_err"], 100 * S.ass_err(pred, eng.pc_list[:1].cpu().numpy()), atol=1e-7, rtol=2e-5)
+    # (a) same cost matrix, same answer: scipy (what the reference calls) on the product's own cost matrix returns the
+    #     permutation of the GPU auction
+    from reart_amd.utils.lap import cdist as lap_cdist, linear_sum_assignment_batch
+    from reart_amd.utils.model_utils import compute_pc_transform as cpt
+    cost_g = lap_cdist(cpt(eng.cano, trans_g[:1], seg_g), eng.pc_list[:1])
+    (_, col_g), = linear_sum_assignment_batch(cost_g)
+    (_, col_s), = oracle.linear_sum_assignment(cost_g.cpu().numpy())
+    np.testing.assert_array_equal(np.asarray(col_g), np.asarray(col_s))
+    # (b) against the oracle's own pipeline, whose cost matrix is torch.cdist's (the reference's call; its matmul form
+    #     rounds differently from direct differences, so near-tied alternative matchings can be chosen): the reported
+    #     error is the mean SQUARED distance under the Euclidean-optimal matching, which such alternatives move in the
+    #     fifth digit -- north_star's 1e-4 relative is the bar here
+    close(e["ass_err"], 100 * S.ass_err(pred, eng.pc_list[:1].cpu().numpy()), atol=1e-7, rtol=1e-4)
     comp = np.concatenate([cano_np[None], pred])
     close(e["group_err"], S.group_temporal_err(comp, seg_o), atol=1e-9, rtol=1e-5)
