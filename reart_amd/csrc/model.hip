@@ -768,9 +768,13 @@ __device__ __forceinline__ void adam_update(float *p, float g, float *m, float *
 }
 
 __device__ __forceinline__ void base_bwd_finalize_body(const BaseBwdArgs &a, const FinalizeAdam &ad) {
-    const int o = blockIdx.x * 256 + threadIdx.x;
+    // Every output is summed over the partial rows by FOUR lanes, a quarter of the rows each (one batch of loads in
+    // flight per lane at 128 rows instead of four dependent batches), combined in a fixed order by two xor-shuffles.
+    const int og = blockIdx.x * 256 + threadIdx.x;
     const int nWr = a.P * a.H + 4 * a.H;                 // real weight entries
-    const int nW = (nWr + 63) & ~63;                     // pose groups start wave-aligned
+    const int nW = (4 * nWr + 63) & ~63;                 // four lanes per weight; pose groups start wave-aligned
+    const int RQ = (a.nchunk + 3) >> 2;                  // rows per quarter
+    const int o = og >> 2;                               // weight entry of this lane (first branch)
     const int no = n_out(a.P, a.H, a.B);
     float ss_seg = 0.f, ss_tr = 0.f, bc2s = 1.f;
     if (ad.enabled) {
@@ -780,25 +784,29 @@ __device__ __forceinline__ void base_bwd_finalize_body(const BaseBwdArgs &a, con
         ss_tr = (float)((double)ad.trans_lr / bc1);
         bc2s = (float)ad.bias_corr[1];
     }
-    if (o < nW) {
-        if (o >= nWr) return;
+    if (og < nW) {
+        if (o >= nWr) return;                            // whole quads leave together
         float acc = 0.f;
-        int c = 0;
-        for (; c + 32 <= a.nchunk; c += 32) {  // 32 independent loads in flight, fixed add order
+        int c = (og & 3) * RQ;
+        const int cend = c + RQ < a.nchunk ? c + RQ : a.nchunk;
+        for (; c + 32 <= cend; c += 32) {  // 32 independent loads in flight, fixed add order
             float v[32];
 #pragma unroll
             for (int u = 0; u < 32; ++u) v[u] = a.partial[(size_t)(c + u) * no + o];
 #pragma unroll
             for (int u = 0; u < 32; ++u) acc += v[u];
         }
-        for (; c + 8 <= a.nchunk; c += 8) {
+        for (; c + 8 <= cend; c += 8) {
             float v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) v[u] = a.partial[(size_t)(c + u) * no + o];
 #pragma unroll
             for (int u = 0; u < 8; ++u) acc += v[u];
         }
-        for (; c < a.nchunk; ++c) acc += a.partial[(size_t)c * no + o];
+        for (; c < cend; ++c) acc += a.partial[(size_t)c * no + o];
+        acc = acc + __shfl_xor(acc, 1, 64);              // (q0 + q1), (q2 + q3): commutative, every lane of the quad agrees
+        acc = acc + __shfl_xor(acc, 2, 64);
+        if (og & 3) return;
         // partial-row order is W2 | W1 | b1; moment order is W1 | b1 | W2
         const int nW2 = a.P * a.H, nW1 = 3 * a.H;
         if (o < nW2) {
@@ -818,23 +826,27 @@ __device__ __forceinline__ void base_bwd_finalize_body(const BaseBwdArgs &a, con
                 adam_update(ad.b1 + q, acc, ad.m + nW1 + q, ad.v + nW1 + q, ad.seg_lr, ss_seg, bc2s, ad.beta1,
                             ad.beta2, ad.eps);
         }
-    } else if (o < nW + 16 * a.B * a.P) {
-        // 16 lanes per (frame, part): lane c < 12 sums one entry of dL/d[R|t] over the chunks (all its
-        // loads in flight at once), then lane 0 gathers the 12 sums and runs the Gram-Schmidt backward
-        const int q = o - nW, e = q >> 4, c = q & 15;
+    } else if (og < nW + 64 * a.B * a.P) {
+        // one wave per (frame, part): 4 row quarters x 16 lanes; lane c < 12 of a quarter sums one entry of dL/d[R|t]
+        // over its rows (all its loads in flight at once), the quarters meet through two xor-shuffles, then every
+        // 16-lane group holds the 12 sums and runs the Gram-Schmidt backward; the first group updates the parameters
+        const int q = og - nW, e = q >> 6, tq = (q >> 4) & 3, c = q & 15;
         float acc = 0.f;
         if (c < 12) {
             const float *pr = a.partial + off_gRt(a.P, a.H) + 12 * (size_t)e + c;
-            int ch = 0;
-            for (; ch + 32 <= a.nchunk; ch += 32) {
+            int ch = tq * RQ;
+            const int chend = ch + RQ < a.nchunk ? ch + RQ : a.nchunk;
+            for (; ch + 32 <= chend; ch += 32) {
                 float v[32];
 #pragma unroll
                 for (int u = 0; u < 32; ++u) v[u] = pr[(size_t)(ch + u) * no];
 #pragma unroll
                 for (int u = 0; u < 32; ++u) acc += v[u];
             }
-            for (; ch < a.nchunk; ++ch) acc += pr[(size_t)ch * no];
+            for (; ch < chend; ++ch) acc += pr[(size_t)ch * no];
         }
+        acc = acc + __shfl_xor(acc, 16, 64);
+        acc = acc + __shfl_xor(acc, 32, 64);
         float gRt[12];
         const int lane0 = (threadIdx.x & 63) & ~15;
 #pragma unroll
@@ -842,7 +854,7 @@ __device__ __forceinline__ void base_bwd_finalize_body(const BaseBwdArgs &a, con
         // every lane of the group runs the (cheap) Gram-Schmidt backward; lane c < 6 then owns rotation
         // entry c and lanes 6..8 the translation entries: nine independent Adam updates instead of a
         // chain of nine on one lane
-        if (c >= 9) return;
+        if (c >= 9 || tq != 0) return;
         float g6[6];
         r6d_backward(a.p6d + 6 * (size_t)e, gRt, g6);
         const int base6 = 3 * a.H + a.H + a.P * a.H, baset = base6 + 6 * a.B * a.P;
@@ -977,7 +989,7 @@ int reart_base_backward_ex(BaseBwdArgs a, const FinalizeAdam *adam, const StepBo
     StepBook nobook = {};
     // weights: one thread per entry; poses: 16 lanes per (frame, part); nW is rounded up to a multiple of 64
     // inside the kernel's indexing so that a 16-lane group never straddles a wave
-    const int nfin = (int)reart_align_up((size_t)(a.P * a.H + 4 * a.H), 64) + 16 * a.B * a.P;
+    const int nfin = (int)reart_align_up((size_t)4 * (a.P * a.H + 4 * a.H), 64) + 64 * a.B * a.P;
     hipLaunchKernelGGL(base_bwd_finalize_kernel, dim3(reart_div_up(nfin, 256)), dim3(256), 0, st, a,
                        adam ? *adam : none, book ? *book : nobook);
     REART_CHECK_LAUNCH();
