@@ -151,20 +151,28 @@ __device__ __forceinline__ float gumbel_from_bits(uint32_t bits) {
 #define FW_PTS 64
 #define FW_PG 2
 
-template <int PP>
-__global__ __launch_bounds__(64 * (((PP > 0 ? PP : 32) + FW_PG - 1) / FW_PG)) void base_fwd_kernel(BaseFwdArgs a) {
+// HALF: a workgroup owns 32 points and the two halves of a wave work on different part pairs (lane = half * 32 +
+// point), so that the same chains run in W/2 waves per workgroup on twice as many workgroups (the kernel is bound by the
+// serial work of one workgroup; 256 CUs take the extra workgroups for free).  Same arithmetic per (point, part).
+template <int PP, bool HALF>
+__global__ __launch_bounds__(64 * (HALF ? (((PP > 0 ? PP : 32) + 2 * FW_PG - 1) / (2 * FW_PG)) : (((PP > 0 ? PP : 32) + FW_PG - 1) / FW_PG)))
+void base_fwd_kernel(BaseFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int PMAX = (PP > 0) ? PP : 32;
-    constexpr int W = (PMAX + FW_PG - 1) / FW_PG;
+    constexpr int W = HALF ? (PMAX + 2 * FW_PG - 1) / (2 * FW_PG) : (PMAX + FW_PG - 1) / FW_PG;   // waves
+    constexpr int NS = HALF ? 2 * W : W;                  // part-pair slices (one per wave, or per half wave)
+    constexpr int PTS = HALF ? FW_PTS / 2 : FW_PTS;       // points per workgroup
     constexpr int BS = 64 * W;
     float *s_rt = smem;                                   // [B*P][12]
     float *s_wb = s_rt + 12 * (size_t)a.B * a.P;          // [H][4]  W1 row | b1
     float *s_w2T = s_wb + 4 * (size_t)a.H;                // [W][H][2]  W2 of wave g's two parts, j-major: 16-byte reads give two j
     float *s_a = s_w2T + (size_t)a.H * PMAX;              // [PMAX][64]  logits, later y
-    float *s_e = s_a + PMAX * FW_PTS;                     // [PMAX][64]  z, later exp(z - max)
-    float *s_hh = s_e + PMAX * FW_PTS;                    // [64][H + 4]  hidden activations, point-major: a lane reads four j at once
+    float *s_e = s_a + PMAX * PTS;                        // [PMAX][PTS]  z, later exp(z - max)
+    float *s_hh = s_e + PMAX * PTS;                       // [64][H + 4]  hidden activations, point-major: a lane reads four j at once
     const int HS = a.H + 4;                               // row stride (16-byte aligned rows, lanes spread over the banks)
     const int tid = threadIdx.x, lane = tid & 63, grp = tid >> 6;
+    const int pl = HALF ? (lane & 31) : lane;             // point of this lane inside the workgroup
+    const int sid = HALF ? 2 * grp + (lane >> 5) : grp;   // part-pair slice of this lane
     PHASE_TS(0, 0);
     const int P = (PP > 0) ? PP : a.P;
     // Prologue loads: the first batch of every group (pose parameters, W1|b1, one W2 column per thread) is
@@ -230,11 +238,11 @@ __global__ __launch_bounds__(64 * (((PP > 0 ? PP : 32) + FW_PG - 1) / FW_PG)) vo
     for (int j = tid + BS; j < a.H; j += BS)          // one hidden unit per thread: no integer division
         for (int p = 0; p < PMAX; ++p) s_w2T[((p >> 1) * a.H + j) * 2 + (p & 1)] = p < P ? a.W2[(size_t)p * a.H + j] : 0.f;
 
-    const int n = blockIdx.x * FW_PTS + lane;
+    const int n = blockIdx.x * PTS + pl;
     const bool live = n < a.N;
     const int nc = live ? n : a.N - 1;
     const float x0 = a.cano[3 * (size_t)nc], x1 = a.cano[3 * (size_t)nc + 1], x2 = a.cano[3 * (size_t)nc + 2];
-    const int p0 = grp * FW_PG;
+    const int p0 = sid * FW_PG;
     const bool has1 = p0 + 1 < P;
     const float tau = a.tau_ptr ? a.tau_ptr[0] : a.tau;
     // Gumbel noise of this wave's parts (issued early: independent of the logits)
@@ -254,7 +262,7 @@ __global__ __launch_bounds__(64 * (((PP > 0 ? PP : 32) + FW_PG - 1) / FW_PG)) vo
     PHASE_TS(0, 1);
     // hidden layer once per point: wave g evaluates its slice of the H units for the 64 points
     {
-        const int jq = (a.H + W - 1) / W, j0 = grp * jq, j1 = (j0 + jq < a.H) ? j0 + jq : a.H;
+        const int jq = (a.H + NS - 1) / NS, j0 = sid * jq, j1 = (j0 + jq < a.H) ? j0 + jq : a.H;
         for (int j = j0; j < j1; ++j) {
             const float4 wb = *(const float4 *)(s_wb + 4 * j);
             float acc = wb.x * x0;
@@ -262,7 +270,7 @@ __global__ __launch_bounds__(64 * (((PP > 0 ? PP : 32) + FW_PG - 1) / FW_PG)) vo
             acc = fmaf(wb.z, x2, acc);
             acc = acc + wb.w;
             const float h = acc > 0.f ? acc : 0.f;
-            s_hh[lane * HS + j] = h;
+            s_hh[pl * HS + j] = h;
             if (a.hT && live) a.hT[(size_t)j * a.N + n] = h;
         }
     }
@@ -270,7 +278,7 @@ __global__ __launch_bounds__(64 * (((PP > 0 ? PP : 32) + FW_PG - 1) / FW_PG)) vo
     // logits of this wave's two parts: the full ascending-j fmaf chain (the oracle's rounding order)
     float sp0 = 0.f, sp1 = 0.f;
     {
-        const float *hrow = s_hh + lane * HS, *wrow = s_w2T + (size_t)grp * a.H * 2;
+        const float *hrow = s_hh + pl * HS, *wrow = s_w2T + (size_t)(sid < PMAX / 2 ? sid : PMAX / 2 - 1) * a.H * 2;
         int j = 0;
         const int H4 = (a.H & 3) == 0 ? a.H : 0;   // rows are 16-byte aligned only when H is a multiple of 4
 #pragma unroll 2
@@ -290,8 +298,8 @@ __global__ __launch_bounds__(64 * (((PP > 0 ? PP : 32) + FW_PG - 1) / FW_PG)) vo
     }
     PHASE_TS(0, 2);
     const float z0 = (sp0 + g0) / tau, z1 = has1 ? (sp1 + g1) / tau : -INFINITY;
-    if (p0 < P) { s_a[p0 * FW_PTS + lane] = sp0; s_e[p0 * FW_PTS + lane] = z0; }
-    if (has1) { s_a[(p0 + 1) * FW_PTS + lane] = sp1; s_e[(p0 + 1) * FW_PTS + lane] = z1; }
+    if (p0 < P) { s_a[p0 * PTS + pl] = sp0; s_e[p0 * PTS + pl] = z0; }
+    if (has1) { s_a[(p0 + 1) * PTS + pl] = sp1; s_e[(p0 + 1) * PTS + pl] = z1; }
     __syncthreads();
     // noise-free arg-max (networks/model.py:70, first maximum) and the softmax max
     float m = -INFINITY;
@@ -300,24 +308,24 @@ __global__ __launch_bounds__(64 * (((PP > 0 ? PP : 32) + FW_PG - 1) / FW_PG)) vo
 #pragma unroll
     for (int p = 0; p < PMAX; ++p)
         if (PP > 0 || p < P) {
-            m = fmaxf(m, s_e[p * FW_PTS + lane]);
-            if (grp == 0) {
-                const float sv = s_a[p * FW_PTS + lane];
+            m = fmaxf(m, s_e[p * PTS + pl]);
+            if (sid == 0) {
+                const float sv = s_a[p * PTS + pl];
                 if (sv > sm) { sm = sv; am = p; }
             }
         }
     __syncthreads();
     const float e0 = expf(z0 - m), e1 = has1 ? expf(z1 - m) : 0.f;
-    if (p0 < P) s_e[p0 * FW_PTS + lane] = e0;
-    if (has1) s_e[(p0 + 1) * FW_PTS + lane] = e1;
+    if (p0 < P) s_e[p0 * PTS + pl] = e0;
+    if (has1) s_e[(p0 + 1) * PTS + pl] = e1;
     __syncthreads();
     float sum = 0.f;
 #pragma unroll
     for (int p = 0; p < PMAX; ++p)
-        if (PP > 0 || p < P) sum += s_e[p * FW_PTS + lane];   // ascending part order
+        if (PP > 0 || p < P) sum += s_e[p * PTS + pl];   // ascending part order
     const float y0 = e0 / sum, y1 = e1 / sum;
-    if (p0 < P) { s_a[p0 * FW_PTS + lane] = y0; if (a.yT && live) a.yT[(size_t)p0 * a.N + n] = y0; }
-    if (has1) { s_a[(p0 + 1) * FW_PTS + lane] = y1; if (a.yT && live) a.yT[(size_t)(p0 + 1) * a.N + n] = y1; }
+    if (p0 < P) { s_a[p0 * PTS + pl] = y0; if (a.yT && live) a.yT[(size_t)p0 * a.N + n] = y0; }
+    if (has1) { s_a[(p0 + 1) * PTS + pl] = y1; if (a.yT && live) a.yT[(size_t)(p0 + 1) * a.N + n] = y1; }
     __syncthreads();
     PHASE_TS(0, 3);
     int k = 0;
@@ -325,16 +333,16 @@ __global__ __launch_bounds__(64 * (((PP > 0 ? PP : 32) + FW_PG - 1) / FW_PG)) vo
 #pragma unroll
     for (int p = 0; p < PMAX; ++p)
         if (PP > 0 || p < P) {
-            const float yv = s_a[p * FW_PTS + lane];
+            const float yv = s_a[p * PTS + pl];
             if (yv > yk) { yk = yv; k = p; }
         }
     const float w = (1.0f - yk) + yk;  // y_hard - y_soft.detach() + y_soft
-    if (live && grp == 0) {
+    if (live && sid == 0) {
         if (a.seg_part) a.seg_part[n] = am;
         if (a.hard_idx) a.hard_idx[n] = k;
     }
     PHASE_TS(0, 4);
-    for (int t = grp; t < a.B; t += W) {
+    for (int t = sid; t < a.B; t += NS) {
         float v[3];
         apply_rt(s_rt + 12 * (t * a.P + k), x0, x1, x2, v);
         v[0] = w * v[0]; v[1] = w * v[1]; v[2] = w * v[2];
@@ -348,7 +356,7 @@ __global__ __launch_bounds__(64 * (((PP > 0 ? PP : 32) + FW_PG - 1) / FW_PG)) vo
             o[a.Npad + n] = live ? v[1] : INFINITY;
             o[2 * (size_t)a.Npad + n] = live ? v[2] : INFINITY;
         }
-        if (a.boxes && blockIdx.x * FW_PTS < a.Npad) {
+        if (a.boxes && blockIdx.x * PTS < a.Npad) {
             // AABBs of this workgroup's output points of frame t, one per NN_BOX consecutive points
             // (block-skip test of the K-NN kernels)
             float lo[3], hi[3];
@@ -363,8 +371,8 @@ __global__ __launch_bounds__(64 * (((PP > 0 ? PP : 32) + FW_PG - 1) / FW_PG)) vo
                 }
                 if (hi[c] == -INFINITY) hi[c] = INFINITY;
             }
-            const int pos = blockIdx.x * FW_PTS + lane;
-            if ((lane & (NN_BOX - 1)) == 0 && pos < a.Npad) {
+            const int pos = blockIdx.x * PTS + pl;
+            if ((pl & (NN_BOX - 1)) == 0 && pos < a.Npad) {
                 float *o = a.boxes + ((size_t)t * (a.Npad / NN_BOX) + pos / NN_BOX) * 8;
                 o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = hi[0]; o[4] = hi[1]; o[5] = hi[2];
             }
@@ -373,19 +381,27 @@ __global__ __launch_bounds__(64 * (((PP > 0 ? PP : 32) + FW_PG - 1) / FW_PG)) vo
     PHASE_TS(0, 5);
 }
 
-template <int PP>
-static void launch_base_fwd(const BaseFwdArgs &a, hipStream_t st) {
+template <int PP, bool HALF>
+static void launch_base_fwd_t(const BaseFwdArgs &a, hipStream_t st) {
     constexpr int PMAX = (PP > 0) ? PP : 32;
-    constexpr int W = (PMAX + FW_PG - 1) / FW_PG;
+    constexpr int W = HALF ? (PMAX + 2 * FW_PG - 1) / (2 * FW_PG) : (PMAX + FW_PG - 1) / FW_PG;
+    constexpr int PTS = HALF ? FW_PTS / 2 : FW_PTS;
     const int cover = a.out_soa ? (a.Npad > a.N ? a.Npad : a.N) : a.N;
-    const size_t lds = sizeof(float) * (12 * (size_t)a.B * a.P + (size_t)a.H * (4 + PMAX) + 2 * (size_t)FW_PTS * PMAX +
-                                        (size_t)(a.H + 4) * FW_PTS);
+    const size_t lds = sizeof(float) * (12 * (size_t)a.B * a.P + (size_t)a.H * (4 + PMAX) + 2 * (size_t)PTS * PMAX +
+                                        (size_t)(a.H + 4) * PTS);
     static bool attr_set = false;  // raise the dynamic-LDS cap once (160 KiB per CU on gfx950)
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)base_fwd_kernel<PP>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+        (void)hipFuncSetAttribute((const void *)base_fwd_kernel<PP, HALF>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((base_fwd_kernel<PP>), dim3(reart_div_up(cover, FW_PTS)), dim3(64 * W), lds, st, a);
+    hipLaunchKernelGGL((base_fwd_kernel<PP, HALF>), dim3(reart_div_up(cover, PTS)), dim3(64 * W), lds, st, a);
+}
+// REART_FWD_PTS=64|32: points per forward workgroup (32: half waves on different part pairs)
+template <int PP>
+static void launch_base_fwd(const BaseFwdArgs &a, hipStream_t st) {
+    const char *env = getenv("REART_FWD_PTS");
+    if (env && atoi(env) == 64) launch_base_fwd_t<PP, false>(a, st);
+    else launch_base_fwd_t<PP, true>(a, st);
 }
 
 static int dispatch_base_fwd(const BaseFwdArgs &a, hipStream_t st) {
