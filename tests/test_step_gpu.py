@@ -172,7 +172,8 @@ def test_search_variants_give_identical_trajectories(dev, monkeypatch):
     """The exact searches are interchangeable IN SITU: 40 iterations of the same instance with the
     box-pruned warm-started search (default: sparse scans, three slices, merged launches), the same with
     separate launches, dense scans only, other sparse thresholds and slice counts, the per-lane and
-    16-query variants, and cold brute force must leave bit-identical parameters and loss logs."""
+    16-query variants, the 64-point forward workgroups, and cold brute force must leave bit-identical parameters and
+    loss logs."""
     from reart_amd.networks.model import BaseModel
     from reart_amd.relax import RelaxEngine
     from reart_amd.synthetic import make_sequence, split_canonical
@@ -184,8 +185,9 @@ def test_search_variants_give_identical_trajectories(dev, monkeypatch):
                       ("quad", {"REART_SEARCH": "quad"}), ("quad_separate", {"REART_SEARCH": "quad", "REART_MERGE": "0"}),
                       ("wave", {"REART_SEARCH": "wave"}), ("dense", {"REART_SPARSE": "0"}), ("sparse8", {"REART_SPARSE": "8"}),
                       ("sparse3", {"REART_SPARSE": "3"}), ("split1", {"REART_PRUNE_SPLIT": "1"}),
-                      ("split4_dense", {"REART_PRUNE_SPLIT": "4", "REART_SPARSE": "0"}), ("brute", {"REART_SEARCH": "brute"})):
-        for k in ("REART_MERGE", "REART_SEARCH", "REART_SPARSE", "REART_PRUNE_SPLIT"):
+                      ("split4_dense", {"REART_PRUNE_SPLIT": "4", "REART_SPARSE": "0"}), ("fwd64", {"REART_FWD_PTS": "64"}),
+                      ("brute", {"REART_SEARCH": "brute"})):
+        for k in ("REART_MERGE", "REART_SEARCH", "REART_SPARSE", "REART_PRUNE_SPLIT", "REART_FWD_PTS"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -199,7 +201,7 @@ def test_search_variants_give_identical_trajectories(dev, monkeypatch):
                       model.seg_head.model[2].weight.detach().cpu().numpy().copy(), eng.seg_part.cpu().numpy())
     ref = runs["brute"]
     assert np.isfinite(ref[0]).all()
-    for name in ("pruned", "separate", "lane", "quad", "quad_separate", "wave", "dense", "sparse8", "sparse3", "split1", "split4_dense"):
+    for name in ("pruned", "separate", "lane", "quad", "quad_separate", "wave", "dense", "sparse8", "sparse3", "split1", "split4_dense", "fwd64"):
         for a, b in zip(runs[name], ref):
             np.testing.assert_array_equal(a, b, err_msg=name)
 
