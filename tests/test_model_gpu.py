@@ -63,12 +63,20 @@ def test_base_model_forward_backward(oracle, dev, tag):
         close(got["gW2"], g[f"gW2_{tag}"], 2e-4)
 
 
-def test_base_model_ragged_sizes_and_determinism(oracle, dev):
-    """N not a multiple of 64, other P/B/H; two runs bit-identical (no atomics anywhere)."""
+@pytest.mark.parametrize("shape", [(333, 7, 5, 48), (70, 3, 2, 128), (1000, 10, 4, 128), (515, 8, 3, 30), (200, 32, 2, 64)])
+@pytest.mark.parametrize("env", [{}, {"REART_FWD_PTS": "64"}, {"REART_BWD_PTS": "64"}, {"REART_BWD_PTS": "16"}])
+def test_base_model_ragged_sizes_and_determinism(oracle, dev, monkeypatch, shape, env):
+    """N not a multiple of 64 / 32, other P (every template instance and the generic one) / B / H (also not a multiple
+    of 4), for every workgroup geometry of the forward (32 / 64 points) and the backward (16 / 32 / 64 points); two runs
+    bit-identical (no atomics anywhere)."""
     from reart_amd import _lib
 
+    for k in ("REART_FWD_PTS", "REART_BWD_PTS"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
     rng = np.random.default_rng(4)
-    N, P, B, H = 333, 7, 5, 48
+    N, P, B, H = shape
     cano = rng.uniform(-0.3, 0.3, (N, 3)).astype(np.float32)
     W1, b1 = rng.normal(0, 0.5, (H, 3)).astype(np.float32), rng.normal(0, 0.1, H).astype(np.float32)
     W2 = rng.normal(0, 0.3, (P, H)).astype(np.float32)
