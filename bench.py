@@ -137,7 +137,19 @@ def main():
     dev = torch.device("cuda", local_rank)
     if distributed:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=dev)  # nccl == RCCL on ROCm
+        # RCCL prints a version banner to STDOUT when the communicator comes up; this program's stdout is ONE JSON
+        # line, so stdout points at stderr while the communicator is created (init + a first collective)
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(backend="nccl", device_id=dev)  # nccl == RCCL on ROCm
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     T, N = args.frames, args.points
     use_flow = not args.no_flow
