@@ -186,16 +186,19 @@ __device__ __forceinline__ void knn_pruned_body(const KnnArgs &a, const int w) {
             }
             const float *tx = s_tg + (PR_PREFETCH ? slot * 48 : 0) - j0, *ty = tx + 16, *tz = tx + 32;
             if (KK == 1) {
-                float m = INFINITY;
+                // minimum of each half of the box: the final rescan then looks at 8 targets instead of 16
+                float mh[2] = {INFINITY, INFINITY};
 #pragma unroll
                 for (int u = 0; u < NN_BOX; u += 2) {
                     const f2 dx = qx2 - *(const f2 *)(tx + j0 + u);
                     const f2 dy = qy2 - *(const f2 *)(ty + j0 + u);
                     const f2 dz = qz2 - *(const f2 *)(tz + j0 + u);
                     const f2 d = (dx * dx + dy * dy) + dz * dz;
-                    m = fminf(fminf(m, d.x), d.y);
+                    mh[u >> 3] = fminf(fminf(mh[u >> 3], d.x), d.y);
                 }
-                if (m < bm[0]) { bm[0] = m; bb[0] = j0; }   // ascending visits: ties keep the lower box
+                const float m = fminf(mh[0], mh[1]);
+                // ascending visits: ties keep the lower box, and inside a box the lower half
+                if (m < bm[0]) { bm[0] = m; bb[0] = j0 + (mh[1] < mh[0] ? 8 : 0); }
                 thr = fminf(thr, m);
             } else {
                 constexpr int UBK = 8;
@@ -248,10 +251,11 @@ __device__ __forceinline__ void knn_pruned_body(const KnnArgs &a, const int w) {
             m = fminf(m, reart_dpp<0xB1>(m));                            // quad: targets 8h .. 8h+7 of the box
             m = fminf(m, reart_dpp<0x4E>(m));
             if (KK == 1) {
-                m = fminf(m, reart_dpp<0x141>(m));                       // row_half_mirror: all 16 targets
-                float r = __int_as_float(__builtin_amdgcn_ds_bpermute(rank << 5, __float_as_int(m)));
-                r = nd ? r : INFINITY;
-                if (r < bm[0]) { bm[0] = r; bb[0] = j0; }
+                // the two half-box minima (lanes 0..3 / 4..7 of the row) come back separately: the winner's half
+                const float r0 = __int_as_float(__builtin_amdgcn_ds_bpermute(rank << 5, __float_as_int(m)));
+                const float r1 = __int_as_float(__builtin_amdgcn_ds_bpermute((rank << 5) + 16, __float_as_int(m)));
+                const float r = nd ? fminf(r0, r1) : INFINITY;
+                if (r < bm[0]) { bm[0] = r; bb[0] = j0 + (r1 < r0 ? 8 : 0); }
                 thr = fminf(thr, r);
             } else {
 #pragma unroll
@@ -290,10 +294,10 @@ __device__ __forceinline__ void knn_pruned_body(const KnnArgs &a, const int w) {
             float m = fminf(fminf(da.x, da.y), fminf(db.x, db.y));
             m = fminf(m, reart_dpp<0xB1>(m));                            // lanes {0,1}: targets 0..7, lanes {2,3}: 8..15
             if (KK == 1) {
-                m = fminf(m, reart_dpp<0x4E>(m));                        // all 16 targets
-                float r = __int_as_float(__builtin_amdgcn_ds_bpermute(rank << 4, __float_as_int(m)));
-                r = nd ? r : INFINITY;
-                if (r < bm[0]) { bm[0] = r; bb[0] = j0; }
+                const float r0 = __int_as_float(__builtin_amdgcn_ds_bpermute(rank << 4, __float_as_int(m)));
+                const float r1 = __int_as_float(__builtin_amdgcn_ds_bpermute((rank << 4) + 8, __float_as_int(m)));
+                const float r = nd ? fminf(r0, r1) : INFINITY;
+                if (r < bm[0]) { bm[0] = r; bb[0] = j0 + (r1 < r0 ? 8 : 0); }
                 thr = fminf(thr, r);
             } else {
 #pragma unroll
@@ -379,12 +383,12 @@ __device__ __forceinline__ void knn_pruned_body(const KnnArgs &a, const int w) {
     }
 
     if (KK == 1) {
-        // exact (lowest) index inside the winning box
+        // exact (lowest) index inside the winning half box
         int bi = 0x7fffffff;
         if (bb[0] >= 0) {
             const int blk = bb[0];
 #pragma unroll
-            for (int u = NN_BOX - 1; u >= 0; --u) {
+            for (int u = NN_BOX / 2 - 1; u >= 0; --u) {
                 const float d = reart_sqdist3(qx, qy, qz, tx[blk + u], ty[blk + u], tz[blk + u]);
                 if (d == bm[0]) bi = blk + u;
             }
