@@ -64,6 +64,28 @@ extern "C" int reart_debug_item_clock(unsigned long long *out, int n) {
 }
 #endif
 
+// min / max of a lane's value with a DPP-permuted copy in ONE instruction (v_min_f32_dpp).  Written through the compiler
+// the same step is three (v_mov_b32_dpp, a canonicalising v_max v,v -- fminf of a value of unknown origin -- and the
+// v_min); the item prologue alone has 28 such steps.  Only used where EXEC is full (every source lane is live); the
+// s_nop covers the two wait states a DPP read needs after a VALU write of the same register, which the hazard
+// recogniser does not insert for inline assembly.  No signalling NaNs exist here; quiet NaNs behave like fminf / fmaxf.
+#define PR_DPP_OP(NAME, OP, CTRLTXT)                                                                              \
+    __device__ __forceinline__ float NAME(float v) {                                                              \
+        float r;                                                                                                  \
+        asm("s_nop 1\n\t" OP " %0, %1, %1 " CTRLTXT " row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v));            \
+        return r;                                                                                                 \
+    }
+PR_DPP_OP(pr_min_q1, "v_min_f32_dpp", "quad_perm:[1,0,3,2]")
+PR_DPP_OP(pr_min_q2, "v_min_f32_dpp", "quad_perm:[2,3,0,1]")
+PR_DPP_OP(pr_min_hm, "v_min_f32_dpp", "row_half_mirror")
+PR_DPP_OP(pr_min_rm, "v_min_f32_dpp", "row_mirror")
+PR_DPP_OP(pr_max_q1, "v_max_f32_dpp", "quad_perm:[1,0,3,2]")
+PR_DPP_OP(pr_max_q2, "v_max_f32_dpp", "quad_perm:[2,3,0,1]")
+PR_DPP_OP(pr_max_hm, "v_max_f32_dpp", "row_half_mirror")
+PR_DPP_OP(pr_max_rm, "v_max_f32_dpp", "row_mirror")
+__device__ __forceinline__ float pr_row16_min(float v) { return pr_min_rm(pr_min_hm(pr_min_q2(pr_min_q1(v)))); }
+__device__ __forceinline__ float pr_row16_max(float v) { return pr_max_rm(pr_max_hm(pr_max_q2(pr_max_q1(v)))); }
+
 __device__ __forceinline__ float rl(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
@@ -130,9 +152,9 @@ __device__ __forceinline__ void knn_pruned_body(const KnnArgs &a, const int w) {
     }
 
     // ---- group summaries: 4 groups of 16 lanes
-    const float gl0 = reart_row16_min(qx), gl1 = reart_row16_min(qy), gl2 = reart_row16_min(qz);
-    const float gh0 = reart_row16_max(qx), gh1 = reart_row16_max(qy), gh2 = reart_row16_max(qz);
-    const float gt = reart_row16_max(thr);
+    const float gl0 = pr_row16_min(qx), gl1 = pr_row16_min(qy), gl2 = pr_row16_min(qz);
+    const float gh0 = pr_row16_max(qx), gh1 = pr_row16_max(qy), gh2 = pr_row16_max(qz);
+    const float gt = pr_row16_max(thr);
     float G[4][7];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -248,8 +270,7 @@ __device__ __forceinline__ void knn_pruned_body(const KnnArgs &a, const int w) {
             const f2 dx = cx - txv, dy = cy - tyv, dz = cz - tzv;
             const f2 d = (dx * dx + dy * dy) + dz * dz;
             float m = fminf(d.x, d.y);
-            m = fminf(m, reart_dpp<0xB1>(m));                            // quad: targets 8h .. 8h+7 of the box
-            m = fminf(m, reart_dpp<0x4E>(m));
+            m = pr_min_q2(pr_min_q1(m));                                 // quad: targets 8h .. 8h+7 of the box
             if (KK == 1) {
                 // the two half-box minima (lanes 0..3 / 4..7 of the row) come back separately: the winner's half
                 const float r0 = __int_as_float(__builtin_amdgcn_ds_bpermute(rank << 5, __float_as_int(m)));
@@ -292,7 +313,7 @@ __device__ __forceinline__ void knn_pruned_body(const KnnArgs &a, const int w) {
             const f2 da = (dxa * dxa + dya * dya) + dza * dza;
             const f2 db = (dxb * dxb + dyb * dyb) + dzb * dzb;
             float m = fminf(fminf(da.x, da.y), fminf(db.x, db.y));
-            m = fminf(m, reart_dpp<0xB1>(m));                            // lanes {0,1}: targets 0..7, lanes {2,3}: 8..15
+            m = pr_min_q1(m);                                            // lanes {0,1}: targets 0..7, lanes {2,3}: 8..15
             if (KK == 1) {
                 const float r0 = __int_as_float(__builtin_amdgcn_ds_bpermute(rank << 4, __float_as_int(m)));
                 const float r1 = __int_as_float(__builtin_amdgcn_ds_bpermute((rank << 4) + 8, __float_as_int(m)));
