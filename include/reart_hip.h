@@ -333,7 +333,12 @@ int reart_mlp_layer(const float *X, int ldx, const int64_t *gather_idx, int K, i
 /* 3-NN inverse-distance interpolation of PointNetFeaturePropagation
  * (networks/pointnet2_utils.py:326-336): xyz1 [B,N,3], xyz2 [B,S2,3], points2 [B,S2,D] ->
  * out [B*N, ldo] columns col0 .. col0 + D (so the cat with the skip features, :338-342, is free).
- * Distances: direct difference (the reference's matmul expansion differs by ~1e-8 absolute). */
+ * Distances: the reference's matmul expansion (square_distance, :33-55) with torch's CPU rounding,
+ * d = ((-2*fma(qz,tz,fma(qy,ty,qx*tx))) + |q|^2) + |t|^2 -- bit-equal to the reference on its CPU path
+ * (tests/golden/three_interp.npz); the three smallest by (d, index).
+ * reart_three_nn alone: dist3 f32 [B,N,3], idx3 i64 [B,N,3] (= square_distance(...).sort()[:3]). */
+int reart_three_nn(const float *xyz1, const float *xyz2, int B, int N, int S2, float *dist3,
+                   int64_t *idx3, void *stream);
 size_t reart_three_interpolate_workspace_bytes(int B, int N, int S2);
 int reart_three_interpolate(const float *xyz1, const float *xyz2, const float *points2, int B,
                             int N, int S2, int D, float *out, int ldo, int col0,

@@ -196,6 +196,28 @@ def ball_query(radius, nsample, xyz, new_xyz, cuda_mode=False, want_margin=False
     return (idx, mg) if want_margin else idx
 
 
+def three_nn_expanded(xyz1, xyz2):
+    """networks/pointnet2_utils.py:33-55 + :327-328: the 3 smallest matmul-expanded squared distances
+    (stable ascending) of every xyz1 point in xyz2 -> (dists f32 [B,N,3], idx i64 [B,N,3])."""
+    xyz1, xyz2 = _f(xyz1), _f(xyz2)
+    B, N, _ = xyz1.shape
+    S = xyz2.shape[1]
+    d = np.empty((B, N, 3), np.float32)
+    i = np.empty((B, N, 3), np.int64)
+    lib().oracle_three_nn_expanded(_p(xyz1), _p(xyz2), B, N, S, _p(d), _p(i))
+    return d, i
+
+
+def three_interpolate(xyz1, xyz2, points2):
+    """networks/pointnet2_utils.py:326-336: xyz1 [B,N,3], xyz2 [B,S,3], points2 [B,S,D] -> [B,N,D]."""
+    xyz1, xyz2, points2 = _f(xyz1), _f(xyz2), _f(points2)
+    B, N, _ = xyz1.shape
+    S, D = points2.shape[1], points2.shape[2]
+    out = np.empty((B, N, D), np.float32)
+    lib().oracle_three_interpolate(_p(xyz1), _p(xyz2), _p(points2), B, N, S, D, _p(out))
+    return out
+
+
 # ---- screw.c -----------------------------------------------------------------------------
 def se3_exp_map(log_transform):
     """screw_se3/geo_utils.py:147-222 -> [n,4,4] (pytorch3d row-vector form)."""

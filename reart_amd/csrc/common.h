@@ -28,6 +28,10 @@ typedef float f2 __attribute__((ext_vector_type(2)));
         }                                                                             \
     } while (0)
 
+// Dynamic LDS a kernel may request without hipFuncSetAttribute(MaxDynamicSharedMemorySize); launches that need
+// more raise the cap at the call (a host-side attribute write, no state kept in the library).
+#define REART_LDS_DEFAULT_CAP ((size_t)48 * 1024)
+
 static inline size_t reart_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static inline int reart_div_up(int a, int b) { return (a + b - 1) / b; }
 

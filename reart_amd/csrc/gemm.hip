@@ -224,11 +224,63 @@ extern "C" int reart_mlp_layer(const float *X, int ldx, const int64_t *gather_id
 
 // ---------------------------------------------------------------------------------------
 // 3-NN inverse-distance feature interpolation of PointNetFeaturePropagation
-// (networks/pointnet2_utils.py:326-336): idx/dist = 3 nearest of xyz2 for each xyz1 point
-// (squared distance), w = 1/(d+1e-8) normalised, out = sum_k w_k points2[idx_k].
+// (networks/pointnet2_utils.py:326-336) on the reference's square_distance (:33-55):
+//     d = ((-2 * mm) + |q|^2) + |t|^2,   mm = fma(qz, tz, fma(qy, ty, qx * tx))   (torch's K = 3 matmul)
+//     |p|^2 = ((x*x) + (y*y)) + (z*z);   the 3 smallest by (d, index);   w = 1/(d + 1e-8), w /= (w0+w1)+w2
+//     out = ((p0*w0) + (p1*w1)) + p2*w2
+// The matmul expansion is part of the result: the coarse cloud is an FPS subset of the fine one, so every
+// coarse point has a query at distance "zero" = +-1e-7 of cancellation noise (negative values included) that
+// 1/(d + 1e-8) turns into the dominant weight.  Restated bit for bit by oracle_three_interpolate and pinned by
+// tests/golden/three_interp.npz (the reference's own module on this container's CPU).
 // out is written into columns [col0, col0+D) of a [B*N, ldo] matrix so that the concatenation
 // with the skip features (:338-342) needs no extra pass.
 // ---------------------------------------------------------------------------------------
+#define TNN_TILE 1024
+__global__ __launch_bounds__(256) void three_nn_expanded_kernel(const float *__restrict__ xyz1,
+                                                                const float *__restrict__ xyz2, int N, int S,
+                                                                float *__restrict__ dist3,
+                                                                int64_t *__restrict__ idx3) {
+    __shared__ float4 T[TNN_TILE];                 // x, y, z, |t|^2
+    const int b = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
+    const bool live = n < N;
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    if (live) {
+        const float *q = xyz1 + ((size_t)b * N + n) * 3;
+        qx = q[0]; qy = q[1]; qz = q[2];
+    }
+    const float sq = (qx * qx + qy * qy) + qz * qz;
+    float d0 = INFINITY, d1 = INFINITY, d2 = INFINITY;
+    int i0 = -1, i1 = -1, i2 = -1;
+    for (int s0 = 0; s0 < S; s0 += TNN_TILE) {
+        const int cnt = min(TNN_TILE, S - s0);
+        __syncthreads();
+        for (int e = threadIdx.x; e < cnt; e += 256) {
+            const float *t = xyz2 + ((size_t)b * S + s0 + e) * 3;
+            const float x = t[0], y = t[1], z = t[2];
+            T[e] = make_float4(x, y, z, (x * x + y * y) + z * z);
+        }
+        __syncthreads();
+        for (int e = 0; e < cnt; ++e) {             // wave-uniform address: LDS broadcast
+            const float4 t = T[e];
+            const float mm = fmaf(qz, t.z, fmaf(qy, t.y, qx * t.x));
+            const float d = ((-2.0f * mm) + sq) + t.w;
+            if (d < d2) {                           // strict: an equal later index never displaces
+                const int j = s0 + e;
+                if (d < d1) {
+                    d2 = d1; i2 = i1;
+                    if (d < d0) { d1 = d0; i1 = i0; d0 = d; i0 = j; }
+                    else { d1 = d; i1 = j; }
+                } else { d2 = d; i2 = j; }
+            }
+        }
+    }
+    if (live) {
+        const size_t o = ((size_t)b * N + n) * 3;
+        dist3[o] = d0; dist3[o + 1] = d1; dist3[o + 2] = d2;
+        idx3[o] = i0; idx3[o + 1] = i1; idx3[o + 2] = i2;
+    }
+}
+
 __global__ __launch_bounds__(256) void interp3_kernel(const float *__restrict__ dist,
                                                       const int64_t *__restrict__ idx,
                                                       const float *__restrict__ P2, int N, int S2, int D,
@@ -237,13 +289,12 @@ __global__ __launch_bounds__(256) void interp3_kernel(const float *__restrict__ 
     const size_t q = (size_t)b * N + r;
     float w[3];
     int id[3];
-    float ws = 0.f;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         w[k] = 1.0f / (dist[q * 3 + k] + 1e-8f);
         id[k] = (int)idx[q * 3 + k];
-        ws += w[k];
     }
+    const float ws = (w[0] + w[1]) + w[2];
 #pragma unroll
     for (int k = 0; k < 3; ++k) w[k] = w[k] / ws;
     const float *p0 = P2 + ((size_t)b * S2 + id[0]) * D;
@@ -253,10 +304,20 @@ __global__ __launch_bounds__(256) void interp3_kernel(const float *__restrict__ 
         out[q * ldo + col0 + c] = (p0[c] * w[0] + p1[c] * w[1]) + p2[c] * w[2];
 }
 
+extern "C" int reart_three_nn(const float *xyz1, const float *xyz2, int B, int N, int S2, float *dist3,
+                              int64_t *idx3, void *stream) {
+    if (B < 0 || N < 0 || S2 < 3) return REART_ERR_INVALID_ARG;
+    if (B == 0 || N == 0) return REART_OK;
+    if (!xyz1 || !xyz2 || !dist3 || !idx3) return REART_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(three_nn_expanded_kernel, dim3(reart_div_up(N, 256), B), dim3(256), 0, (hipStream_t)stream,
+                       xyz1, xyz2, N, S2, dist3, idx3);
+    REART_CHECK_LAUNCH();
+    return REART_OK;
+}
+
 extern "C" size_t reart_three_interpolate_workspace_bytes(int B, int N, int S2) {
     if (B <= 0 || N <= 0 || S2 <= 0) return 0;
-    return reart_align_up(sizeof(float) * (size_t)B * N * 3, 256) + reart_align_up(sizeof(int64_t) * (size_t)B * N * 3, 256) +
-           reart_knn_points_workspace_bytes(B, N, S2, 3);
+    return reart_align_up(sizeof(float) * (size_t)B * N * 3, 256) + reart_align_up(sizeof(int64_t) * (size_t)B * N * 3, 256);
 }
 
 extern "C" int reart_three_interpolate(const float *xyz1, const float *xyz2, const float *points2, int B,
@@ -268,12 +329,9 @@ extern "C" int reart_three_interpolate(const float *xyz1, const float *xyz2, con
     if (workspace_bytes < reart_three_interpolate_workspace_bytes(B, N, S2)) return REART_ERR_INVALID_ARG;
     char *ws = (char *)workspace;
     float *dist = (float *)ws;
-    size_t off = reart_align_up(sizeof(float) * (size_t)B * N * 3, 256);
-    int64_t *idx = (int64_t *)(ws + off);
-    off += reart_align_up(sizeof(int64_t) * (size_t)B * N * 3, 256);
+    int64_t *idx = (int64_t *)(ws + reart_align_up(sizeof(float) * (size_t)B * N * 3, 256));
     hipStream_t st = (hipStream_t)stream;
-    int rc = reart_knn_run(1, &xyz1, &xyz2, nullptr, nullptr, B, &N, &S2, 3, 0, &dist, &idx, ws + off,
-                           workspace_bytes - off, st);
+    const int rc = reart_three_nn(xyz1, xyz2, B, N, S2, dist, idx, stream);
     if (rc != REART_OK) return rc;
     hipLaunchKernelGGL(interp3_kernel, dim3(N, B), dim3(256), 0, st, dist, idx, points2, N, S2, D, out, ldo, col0);
     REART_CHECK_LAUNCH();

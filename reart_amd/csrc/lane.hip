@@ -285,13 +285,10 @@ __global__ __launch_bounds__(64 * LN_WAVES) void knn_lane_kernel(KnnArgs a) {
 template <int KK>
 static int lane_launch(const KnnArgs &a, hipStream_t st) {
     const size_t lds = sizeof(float) * (3 * LN_AX + LN_NBOX * 8) + sizeof(unsigned short) * LN_WAVES * LN_CAP * 64;
-    static bool attr_set = false;   // raise the dynamic-LDS cap once (160 KiB per CU on gfx950)
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)knn_lane_kernel<KK>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                152 * 1024) != hipSuccess)
-            return REART_ERR_LAUNCH;
-        attr_set = true;
-    }
+    if (lds > REART_LDS_DEFAULT_CAP &&
+        hipFuncSetAttribute((const void *)knn_lane_kernel<KK>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            152 * 1024) != hipSuccess)
+        return REART_ERR_LAUNCH;
     const int njobs = a.items > a.items0 ? 2 : 1;
     const int wgs = (a.job[0].nqg + LN_WAVES - 1) / LN_WAVES;
     hipLaunchKernelGGL((knn_lane_kernel<KK>), dim3(njobs * a.N * wgs), dim3(64 * LN_WAVES), lds, st, a);

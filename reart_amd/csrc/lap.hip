@@ -402,12 +402,9 @@ static int lap_launch(const float *cost, int B, int n, int32_t *col4row, int32_t
     a.stats = (int *)((char *)workspace + reart_align_up(sizeof(double) * (size_t)B * n, 256));   // diagnostics, after the potentials
     a.pbval_ws = (double *)((char *)a.stats + reart_align_up(sizeof(int) * 4 * (size_t)B, 256));
     const size_t lds = (size_t)n * ((n <= LAP_NLDS ? 3 : 2) * 8 + 5 * 4);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)lap_auction_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)
-            return REART_ERR_LAUNCH;
-        attr_set = true;
-    }
+    if (lds > REART_LDS_DEFAULT_CAP &&
+        hipFuncSetAttribute((const void *)lap_auction_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)
+        return REART_ERR_LAUNCH;
     hipLaunchKernelGGL(lap_auction_kernel, dim3(B), dim3(LAP_BS), lds, (hipStream_t)stream, a);
     REART_CHECK_LAUNCH();
     return REART_OK;

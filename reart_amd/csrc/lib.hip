@@ -1,7 +1,7 @@
 // reart_amd/csrc/lib.hip -- library-level probes of libreart_hip.so (no device work).
 #include "common.h"
 
-extern "C" int reart_version(void) { return 100; }
+extern "C" int reart_version(void) { return 200; }
 
 extern "C" int reart_device_count(void) {
     int n = 0;

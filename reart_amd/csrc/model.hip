@@ -389,11 +389,8 @@ static void launch_base_fwd_t(const BaseFwdArgs &a, hipStream_t st) {
     const int cover = a.out_soa ? (a.Npad > a.N ? a.Npad : a.N) : a.N;
     const size_t lds = sizeof(float) * (12 * (size_t)a.B * a.P + (size_t)a.H * (4 + PMAX) + 2 * (size_t)PTS * PMAX +
                                         (size_t)(a.H + 4) * PTS);
-    static bool attr_set = false;  // raise the dynamic-LDS cap once (160 KiB per CU on gfx950)
-    if (!attr_set) {
+    if (lds > REART_LDS_DEFAULT_CAP)   // stateless: raise the dynamic-LDS cap whenever the launch needs it (160 KiB per CU on gfx950)
         (void)hipFuncSetAttribute((const void *)base_fwd_kernel<PP, HALF>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
-        attr_set = true;
-    }
     hipLaunchKernelGGL((base_fwd_kernel<PP, HALF>), dim3(reart_div_up(cover, PTS)), dim3(64 * W), lds, st, a);
 }
 // REART_FWD_PTS=64|32: points per forward workgroup (32: half waves on different part pairs)
@@ -956,13 +953,10 @@ extern "C" size_t reart_base_backward_workspace_bytes(int N, int P, int B, int H
 
 template <int PP>
 static int launch_bwd_block(const BaseBwdArgs &a, size_t lds, hipStream_t st) {
-    static bool attr_set = false;  // raise the dynamic-LDS cap once (160 KiB per CU on gfx950)
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)base_bwd_block_kernel<PP>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)
-            return REART_ERR_LAUNCH;
-        attr_set = true;
-    }
+    if (lds > REART_LDS_DEFAULT_CAP &&
+        hipFuncSetAttribute((const void *)base_bwd_block_kernel<PP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            152 * 1024) != hipSuccess)
+        return REART_ERR_LAUNCH;
     constexpr int W = (((PP > 0) ? PP : 32) + FW_PG - 1) / FW_PG;
     hipLaunchKernelGGL((base_bwd_block_kernel<PP>), dim3(a.nchunk), dim3(64 * W), lds, st, a);
     return REART_OK;

@@ -101,15 +101,10 @@ template <int IPT>
 static int fps_launch(const float *xyz, int B, int N, int M, const int *start, int cuda_mode,
                       int *idx32, int64_t *idx64, hipStream_t st) {
     const size_t lds = sizeof(float) * 3 * (size_t)N;
-    static bool attr0 = false, attr1 = false;
-    if (lds > 48 * 1024) {
-        bool &flag = cuda_mode ? attr1 : attr0;
-        if (!flag) {
-            const void *fn = cuda_mode ? (const void *)fps_kernel<IPT, true> : (const void *)fps_kernel<IPT, false>;
-            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)
-                return REART_ERR_LAUNCH;
-            flag = true;
-        }
+    if (lds > REART_LDS_DEFAULT_CAP) {   // stateless: no function-static "done once" flags in the library
+        const void *fn = cuda_mode ? (const void *)fps_kernel<IPT, true> : (const void *)fps_kernel<IPT, false>;
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)
+            return REART_ERR_LAUNCH;
     }
     if (cuda_mode)
         hipLaunchKernelGGL((fps_kernel<IPT, true>), dim3(B), dim3(FPS_BS), lds, st, xyz, N, M, start,
@@ -155,6 +150,7 @@ __global__ __launch_bounds__(BQ_BS) void ball_query_kernel(const float *__restri
     if (s >= S) return;
     const float *q = new_xyz + 3 * ((size_t)b * S + s);
     const float qx = q[0], qy = q[1], qz = q[2];
+    const float sq = (qx * qx + qy * qy) + qz * qz;
     const float *p = xyz + (size_t)b * N * 3;
     const size_t obase = ((size_t)b * S + s) * nsample;
     int cnt = 0, first = -1;
@@ -163,7 +159,17 @@ __global__ __launch_bounds__(BQ_BS) void ball_query_kernel(const float *__restri
     for (int k0 = 0; k0 < N && cnt < nsample; k0 += 64) {
         const int k = k0 + lane;
         float d = INFINITY;
-        if (k < N) d = reart_sqdist3(qx, qy, qz, p[3 * k], p[3 * k + 1], p[3 * k + 2]);
+        if (k < N) {
+            const float px = p[3 * k], py = p[3 * k + 1], pz = p[3 * k + 2];
+            if (CUDA_MODE) {
+                d = reart_sqdist3(qx, qy, qz, px, py, pz);               // ball_query_gpu.cu:30-33
+            } else {
+                // square_distance(new_xyz, xyz) of the CPU fallback (networks/pointnet2_utils.py:33-55,126):
+                // the matmul expansion with torch's CPU rounding, bit for bit (oracle/pointnet.c)
+                const float mm = fmaf(qz, pz, fmaf(qy, py, qx * px));
+                d = ((-2.0f * mm) + sq) + ((px * px + py * py) + pz * pz);
+            }
+        }
         if (!CUDA_MODE && d < nd) { nd = d; ni = k; }
         const bool hit = CUDA_MODE ? (d < r2) : (d <= r2);
         const unsigned long long m = __ballot(hit);

@@ -379,12 +379,9 @@ extern "C" int reart_part_fps(const float *cano, const int64_t *seg, int N, cons
     if (Ps == 0) return REART_OK;
     const size_t lds = (size_t)N * 8;
     if (lds > 150 * 1024) return REART_ERR_UNSUPPORTED;
-    static bool attr = false;
-    if (lds > 48 * 1024 && !attr) {
-        if (hipFuncSetAttribute((const void *)part_fps_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)
-            return REART_ERR_LAUNCH;
-        attr = true;
-    }
+    if (lds > REART_LDS_DEFAULT_CAP &&
+        hipFuncSetAttribute((const void *)part_fps_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)
+        return REART_ERR_LAUNCH;
     hipLaunchKernelGGL(part_fps_kernel, dim3(Ps), dim3(PF_BS), lds, (hipStream_t)stream, cano, seg, N, labels, num_fps,
                        cuda_mode, idx, count);
     REART_CHECK_LAUNCH();

@@ -76,7 +76,7 @@ class _SAMsg(nn.Module):
             self.bn_blocks.append(bns)
         self.out_channels = sum(m[-1] for m in mlp_list)
 
-    def run(self, xyz, feats, start=None, cuda_mode=False):
+    def run(self, xyz, feats, start=None, cuda_mode=None):
         """xyz [B,N,3], feats [B,N,D] (channel-last) -> new_xyz [B,S,3], new_feats [B,S,sum C]."""
         B, N, _ = xyz.shape
         S = self.npoint
@@ -183,9 +183,10 @@ class PointNet2Msg2(nn.Module):
         self.bn1 = nn.BatchNorm1d(out_dim)
 
     @torch.no_grad()
-    def forward(self, xyz, fps_start=None, cuda_mode=False):
-        """``fps_start`` = (start1 [B], start2 [B]) injects the FPS start indices (the reference's CPU
-        fallback draws them from torch's RNG); ``cuda_mode`` selects the CUDA-kernel sampling rules."""
+    def forward(self, xyz, fps_start=None, cuda_mode=None):
+        """``cuda_mode`` None follows ``pointnet2_utils.CUDA`` (True: the rules of a GPU run of the reference);
+        ``cuda_mode=False`` selects the CPU-fallback rules, for which ``fps_start`` = (start1 [B], start2 [B])
+        injects the FPS start indices the reference draws from torch's RNG."""
         if self.training:
             raise RuntimeError("PointNet2Msg2 is inference-only here (call .eval()); the reference freezes it")
         _lib.require_gpu(xyz)

@@ -1,14 +1,25 @@
 """Host-side mirror of the sampling / grouping functions of the reference's
 ``networks/pointnet2_utils.py`` over the HIP kernels (``reart_fps``, ``reart_ball_query``).
 
-Semantics default to the reference's CPU-fallback rules (what runs when its CUDA extension is not
-importable -- BASELINE's "reference CPU/PyTorch path"): FPS arg-max = first maximum; ball query
-keeps ``d2 <= r^2`` in index order and pads with the nearest point.  ``cuda_mode=True`` selects the
-rules of the vendored CUDA kernels instead (FPS tree tie rule, ``d2 < r^2``, pad with first hit).
+The reference picks its sampling rules with a module-level switch (``CUDA``, networks/pointnet2_utils.py:7-12:
+true whenever a GPU is present) -- mirrored here as ``CUDA = True``, because this package only runs on a GPU:
+  * ``CUDA`` rules (default): the vendored CUDA kernels -- FPS starts at index 0 with the block-tree tie rule
+    (sampling_gpu.cu:93-209), ball query keeps ``d2 < r*r`` on coordinate differences and pads with the first hit
+    (ball_query_gpu.cu:9-45);
+  * CPU-fallback rules (``cuda_mode=False`` per call, or ``pointnet2_utils.CUDA = False``): FPS starts at a
+    ``torch.randint`` draw, arg-max = first maximum (:88-99); ball query keeps ``d2 <= r^2`` on the matmul-expanded
+    ``square_distance`` and pads with the nearest point (:102-140) -- BASELINE's "reference CPU/PyTorch path", the
+    rules the CPU-generated golden vectors follow.
 """
 import torch
 
 from .. import _lib
+
+CUDA = True   # networks/pointnet2_utils.py:7-12
+
+
+def _rules(cuda_mode):
+    return CUDA if cuda_mode is None else bool(cuda_mode)
 
 
 def index_points(points, idx):
@@ -19,13 +30,14 @@ def index_points(points, idx):
     return out.reshape(*idx.shape, points.shape[-1])
 
 
-def farthest_point_sample(xyz, npoint, start=None, cuda_mode=False):
+def farthest_point_sample(xyz, npoint, start=None, cuda_mode=None):
     """xyz [B,N,3] -> int64 [B,npoint] (networks/pointnet2_utils.py:74-99).
 
     ``start`` [B]: first index of every cloud.  The reference's CPU fallback draws it with
     ``torch.randint`` from the global generator (:90) -- reproduced here when ``start`` is None and
     ``cuda_mode`` is False; its CUDA kernel always starts at 0 (sampling_gpu.cu:113)."""
     _lib.require_gpu(xyz)
+    cuda_mode = _rules(cuda_mode)
     xyz = xyz.contiguous().float()
     B, N, _ = xyz.shape
     if start is None and not cuda_mode:
@@ -38,9 +50,10 @@ def farthest_point_sample(xyz, npoint, start=None, cuda_mode=False):
     return idx
 
 
-def query_ball_point(radius, nsample, xyz, new_xyz, cuda_mode=False):
+def query_ball_point(radius, nsample, xyz, new_xyz, cuda_mode=None):
     """xyz [B,N,3], new_xyz [B,S,3] -> int64 [B,S,nsample] (networks/pointnet2_utils.py:102-140)."""
     _lib.require_gpu(xyz, new_xyz)
+    cuda_mode = _rules(cuda_mode)
     xyz, new_xyz = xyz.contiguous().float(), new_xyz.contiguous().float()
     B, N, _ = xyz.shape
     S = new_xyz.shape[1]

@@ -66,10 +66,15 @@ def _pair_cost(cano_fps, frame_fps=None):
 
 
 # ------------------------------------------------------------------------------------ reference interface
-def fps_sample_cano(cano_pc, cano_part, uni_label, num_fps=20, cuda_mode=False):
+def fps_sample_cano(cano_pc, cano_part, uni_label, num_fps=20, cuda_mode=None):
     """utils/graph_utils.py:37-52: farthest point sampling inside every part of ``uni_label`` (one launch).
-    -> (points [P,num_fps,3], indices into cano_pc [P,num_fps]).  Raises ValueError for a part below num_fps."""
+    -> (points [P,num_fps,3], indices into cano_pc [P,num_fps]).  Raises ValueError for a part below num_fps.
+    Sampling rules: ``cuda_mode`` None follows ``networks.pointnet2_utils.CUDA`` (both start at the part's first
+    member here; the CPU fallback's random start is pinned to 0 as in the fixtures)."""
+    from ..networks import pointnet2_utils as _pn2
+
     _lib.require_gpu(cano_pc, cano_part)
+    cuda_mode = _pn2._rules(cuda_mode)
     cano = cano_pc.detach().contiguous().float()
     seg = cano_part.contiguous().long()
     lab = torch.as_tensor(uni_label, device=cano.device).long().contiguous()

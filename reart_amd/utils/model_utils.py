@@ -42,13 +42,27 @@ def compute_pc_transform(cano_pc, pose_list, cano_part):
     return out
 
 
+def _row_mode(values):
+    """torch.mode(values, dim=1)[0] with the CPU rule spelled out: the most frequent value of each row,
+    ties -> the smallest value (the device implementation of torch.mode does not promise a tie rule).
+    values [n, k] integer labels; k is small (1 / 3 / 20)."""
+    counts = (values[:, :, None] == values[:, None, :]).sum(dim=2)                      # [n, k]
+    best = counts.max(dim=1, keepdim=True).values
+    big = torch.iinfo(values.dtype).max
+    return torch.where(counts == best, values, torch.full_like(values, big)).min(dim=1).values
+
+
 def knn_query(query_pc, src_pc, src_input, knn):
-    """Label / feature transfer from the k nearest source points (utils/model_utils.py:41-51)."""
+    """Label / feature transfer from the k nearest source points (utils/model_utils.py:41-51).
+    1-D ``src_input`` (labels): per-query mode over the k neighbours.  2-D ``src_input`` [n_src, C]: mean over
+    the k neighbours -- the reference reshapes by ``src_input.shape[0]``, i.e. that branch requires as many
+    queries as source points, and raises otherwise; so does this."""
+    _lib.require_gpu(query_pc, src_pc, src_input)
     _, idx = knn(ref=src_pc.unsqueeze(0), query=query_pc.unsqueeze(0))  # [1, nq, k]
     idx = idx.squeeze(0).reshape(-1)
     if src_input.dim() == 2:
-        return src_input[idx].reshape(-1, knn.k, src_input.shape[1]).mean(dim=1)
-    return torch.mode(src_input[idx].reshape(-1, knn.k), dim=1)[0]
+        return src_input[idx].reshape(src_input.shape[0], knn.k, src_input.shape[1]).mean(dim=1)
+    return _row_mode(src_input[idx].reshape(-1, knn.k))
 
 
 # ---------------------------------------------------------------------------------------------------------

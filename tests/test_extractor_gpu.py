@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("cpu_rules")]   # goldens follow the CPU-fallback rules
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
@@ -74,7 +74,7 @@ def test_extractor_matches_reference(dev):
     assert tuple(feat.shape) == (2, 64, 1024)
     ref = g["feat"]
     err = np.abs(feat.cpu().numpy() - ref)
-    # 3-NN weights use direct-difference distances (reference: matmul expansion, +-1e-8 noise on
-    # coincident points): 1e-3 of the feature scale
-    assert err.max() <= 2e-3 * np.abs(ref).max(), (err.max(), np.abs(ref).max())
-    assert err.mean() <= 1e-4 * np.abs(ref).mean()
+    # ball-query membership and the 3-NN weights are the reference's bit for bit (matmul-expanded distances with
+    # torch's CPU rounding); what is left is fp32 accumulation order (MFMA tiles vs the reference's sgemm)
+    assert err.max() <= 2e-4 * np.abs(ref).max(), (err.max(), np.abs(ref).max())
+    assert err.mean() <= 2e-5 * np.abs(ref).mean(), (err.mean(), np.abs(ref).mean())

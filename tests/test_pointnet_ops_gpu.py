@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("cpu_rules")]   # goldens follow the CPU-fallback rules
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 

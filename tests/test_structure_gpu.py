@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("cpu_rules")]   # goldens follow the CPU-fallback rules
 
 G = np.load(os.path.join(os.path.dirname(__file__), "golden", "structure.npz"))
 
