@@ -70,6 +70,8 @@ def main(args):
     random.seed(args.manual_seed)
     if not torch.cuda.is_available():
         raise SystemExit("reart_amd runs on an AMD GPU only (no CPU fallback)")
+    if args.evaluate and args.resume is None:
+        raise ValueError("need model path to evaluate!")      # run_robot.py:86-87
     device = torch.device("cuda")
     dataset = None
     if args.synthetic:
@@ -81,7 +83,9 @@ def main(args):
         sample = dataset[0]
     cano_pc = torch.from_numpy(sample["cano_pc"]).float().to(device)
     pc_list = torch.from_numpy(sample["pc_list"]).float().to(device)
-    save_dir = os.path.join(args.save_root, os.path.basename(args.seq_path.rstrip("/")) or "synthetic")
+    # --synthetic never shares a directory with a real sequence (seq_path keeps its default then)
+    save_dir = os.path.join(args.save_root, "synthetic" if args.synthetic
+                            else (os.path.basename(args.seq_path.rstrip("/")) or "sequence"))
     os.makedirs(save_dir, exist_ok=True)
 
     pc_ref_list = flow_ref_list = None
