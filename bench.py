@@ -28,7 +28,7 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 vector peak (counts FMA as 2)
 
 
-def build_instance(dev, T, N, cano_idx, seed, use_flow=True, n_iter=15000, use_grid=False, overlap=True):
+def build_instance(dev, T, N, cano_idx, seed, use_flow=True, n_iter=15000, use_grid=False, overlap=True, profile=False):
     from reart_amd.networks.model import BaseModel
     from reart_amd.relax import RelaxEngine
     from reart_amd.synthetic import make_sequence, split_canonical
@@ -41,7 +41,7 @@ def build_instance(dev, T, N, cano_idx, seed, use_flow=True, n_iter=15000, use_g
     refs = [t(r) for r in seq["ref_loc"]] if use_flow else None
     flows = [t(f) for f in seq["ref_flow"]] if use_flow else None
     eng = RelaxEngine(t(cano), t(pcs), model, cano_idx, refs, flows, n_iter=n_iter, seed=seed, use_grid=use_grid,
-                      overlap_flow=overlap)
+                      overlap_flow=overlap, profile=profile)
     return eng, seq, model
 
 
@@ -102,8 +102,127 @@ def cpu_baseline_torch(seq, T, N, cano_idx, budget_s=10.0):
                       f"conv1d / gumbel_softmax / bmm / cdist+argmin / topk / autograd / torch.optim.Adam, {el:.1f} s wall)"}
 
 
+def bench_kinematic(args, dev, rank, world, distributed, barrier):
+    """BASELINE.json configs[4] as the reference runs it (README.md:125): kinematic projection from a relaxation result,
+    `--model kinematic --use_flow_loss --use_assign_loss --assign_iter 0 --downsample 2 --assign_gap 1`, at the synthetic
+    T x N of the headline.  One step = one iteration of run_robot.py:154-221 in that mode: forward kinematics of every
+    frame, FPS subsets, (T-1) cost matrices of (N/2)^2, their OPTIMAL assignments (re-solved every iteration), assignment
+    + flow loss, backward, Adam.  Returns the dict rank 0 prints."""
+    from reart_amd import run_robot as rr
+    from reart_amd import tail
+
+    T, N = args.frames, args.points
+    cano_idx = (T // 2 + rank) % T
+    eng, seq, model = build_instance(dev, T, N, cano_idx, seed=2 + rank, use_flow=True)
+    eng.capture(steps_per_graph=50)
+    eng.step(args.base_iters)                       # the relaxation result the projection starts from (untimed)
+    torch.cuda.synchronize()
+    cano, pcs = eng.caller_clouds()
+    with torch.no_grad():
+        _, seg0, trans0 = model(cano)
+    seg_s, trans_s, conn_s = tail.extract_structure(seg0, trans0, cano)
+    result = {"pred_cano_part": seg_s.cpu().numpy(), "pred_pose_list": trans_s.cpu().numpy(),
+              "joint_connection": conn_s.cpu().numpy().tolist(), "cano_idx": cano_idx}
+    a = rr.build_parser().parse_args(["--model", "kinematic", "--use_flow_loss", "--use_assign_loss", "--assign_iter", "0",
+                                      "--downsample", str(args.downsample), "--assign_gap", str(args.assign_gap),
+                                      "--cano_idx", str(cano_idx), "--n_iter", "15000"])
+    kin = rr.build_kinematic_from_base(result, cano, pcs, a).to(dev)
+    t_ = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    refs, flows = [t_(r) for r in seq["ref_loc"]], [t_(f) for f in seq["ref_flow"]]
+    loop = rr.OperatorLoop(a, kin, cano, pcs, refs, flows)
+    it = 0
+    for _ in range(args.warmup):
+        loop.iteration(it); it += 1
+    barrier()
+    solves0 = loop.lap_solves
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses = loop.iteration(it); it += 1
+    barrier()
+    el = time.perf_counter() - t0
+    if distributed:
+        import torch.distributed as dist
+        tt = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+    if rank != 0:
+        return None
+    # dominant kernel: the assignment re-solve of (T-1) matrices; timed on the launch stream with HIP events, same state
+    from reart_amd.networks.pointnet2_utils import index_points
+    from reart_amd.utils.lap import cdist, linear_sum_assignment_batch
+    with torch.no_grad():
+        pc_trans, _, _ = kin(cano)
+        cost = cdist(index_points(pc_trans, loop.src_idx), loop.tgt_pts)
+    n = cost.shape[1]
+    reps = 5
+    ev0.record()
+    for _ in range(reps):
+        _, _, st = linear_sum_assignment_batch(cost, return_stats="full", state=loop.lap_state, warm_assignment=True)
+    ev1.record()
+    torch.cuda.synchronize()
+    lap_ms = ev0.elapsed_time(ev1) / reps
+    state_cold = {}
+    ev0.record()
+    linear_sum_assignment_batch(cost, state=state_cold, warm_assignment=True)      # cold: epsilon-scaling auction
+    ev1.record()
+    torch.cuda.synchronize()
+    lap_cold_ms = ev0.elapsed_time(ev1)
+    lap_bytes = cost.numel() * 4
+    roof = {"bound": "hbm", "achieved": round(lap_bytes / (lap_ms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(lap_bytes / (lap_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
+            "kernel": "lap_jv_kernel (re-solve of the T-1 assignment problems from the previous optimum: shortest augmenting "
+                      "paths + exact dual certificate), one workgroup per matrix",
+            "kernel_ms": round(lap_ms, 4), "algorithmic_bytes": lap_bytes,
+            "cold_solve_ms": round(lap_cold_ms, 3),
+            "note": "algorithmic bytes = every cost matrix read once; the solve is a chain of dependent row reads (one per "
+                    "Dijkstra step) on T-1 of 256 compute units, i.e. latency bound by construction; kernel_ms: HIP "
+                    "events on the launch stream around 5 re-solves at the state reached after the timed region "
+                    "(includes the certificate passes and the host's copy of the result); cold_solve_ms: the "
+                    "epsilon-scaling auction from scratch on the same matrices"}
+    cpu = None
+    if not args.no_cpu_baseline and world == 1:
+        import oracle
+        cost_h = cost.cpu().numpy()
+        pa, pb = index_points(pc_trans, loop.src_idx).cpu(), loop.tgt_pts.cpu()
+        t1 = time.perf_counter()
+        c_cpu = torch.cdist(pa, pb).numpy()
+        oracle.parallel_lap(c_cpu, nproc=len(c_cpu))
+        el_cpu = time.perf_counter() - t1
+        cpu = {"value": round(1.0 / el_cpu, 4), "unit": "iterations/s", "cores": min(len(cost_h), os.cpu_count() or 1),
+               "kind": "reference",
+               "sample": f"ONE iteration's assignment refresh as the reference computes it (run_robot.py:165-176 with "
+                         f"--use_nproc): torch.cdist on the host + scipy.optimize.linear_sum_assignment for the {len(cost_h)} "
+                         f"matrices of {n} x {n} on a pool of {len(cost_h)} processes (utils/model_utils.py:85-89), "
+                         f"{el_cpu:.1f} s wall; forward kinematics, losses, autograd and Adam (< 1 % of the reference's "
+                         f"iteration) are not included, so this is an upper bound of the CPU path's rate"}
+    return {
+        "metric": "kinematic-projection iterations/sec", "value": round(world * args.steps / el, 3), "unit": "iterations/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * el / args.steps, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (assignment potentials f64)",
+        "data": "synthetic",
+        "config": {"workload": f"kinematic projection (BASELINE configs[4], README.md:125): model=kinematic, flow + "
+                               f"assignment loss, assign_iter=0, downsample={args.downsample}, assign_gap={args.assign_gap}; "
+                               f"synthetic T={T} x N={N}, {T - 1} assignment problems of {n} x {n} per refresh, joint tree from a "
+                               f"{args.base_iters}-iteration relaxation result", "frames": T, "points": N,
+                   "parts": int(trans_s.shape[1]), "assign_gap": args.assign_gap, "downsample": args.downsample,
+                   "lap_solves_in_timed_region": loop.lap_solves - solves0 - 0,
+                   "parallelism": f"instances x{world}"},
+        "roofline": roof, "cpu_baseline": cpu,
+        "lap_stats_last": {"rows_released": st[:, 0].tolist(), "rows_searched": st[:, 1].tolist(),
+                           "dijkstra_steps": st[:, 2].tolist(), "certificate_rounds": st[:, 3].tolist()},
+        "final_losses": {k: float(v.detach()) for k, v in losses.items()},
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="relax", choices=["relax", "kinematic", "extractor"],
+                    help="relax (default): BASELINE configs[1], the headline; kinematic: configs[4] (README.md:125); "
+                         "extractor: the one-time PointNet++ correspondence extractor of configs[2]")
+    ap.add_argument("--base-iters", type=int, default=2000, help="kinematic: iterations of the relaxation the projection starts from")
+    ap.add_argument("--assign-gap", type=int, default=1)
+    ap.add_argument("--downsample", type=int, default=2)
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1500)
     ap.add_argument("--warmup", type=int, default=150)
@@ -151,6 +270,31 @@ def main():
             os.dup2(saved_fd, 1)
             os.close(saved_fd)
 
+    def barrier():
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.config == "kinematic":
+        if args.steps == 1500 and args.warmup == 150:      # the relax defaults: this config's iterations are ~100x longer
+            args.steps, args.warmup = 100, 10
+        out = bench_kinematic(args, dev, rank, world, distributed, barrier)
+        if rank == 0:
+            print(json.dumps(out))
+        if distributed:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    if args.config == "extractor":
+        out = bench_extractor(args, dev)
+        if rank == 0:
+            print(json.dumps(out))
+        if distributed:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
     T, N = args.frames, args.points
     use_flow = not args.no_flow
     # independent instances: rank r optimises canonical index (T//2 + r) % T (README: the
@@ -158,12 +302,16 @@ def main():
     cano_idx = (T // 2 + rank) % T
     K = max(1, args.instances_per_gpu)
     engines, streams = [], []
+    # a graph never holds more iterations than the timed region: a short driver run (--steps 20) still replays graphs
+    spg = 1 if args.no_graph else max(1, min(args.steps_per_graph, args.steps))
     for k in range(K):
         st = torch.cuda.Stream(device=dev) if K > 1 else torch.cuda.current_stream(dev)
         with torch.cuda.stream(st):
+            # profile=True: the search launch of every iteration leaves device-side stamps (2 stores per workgroup and
+            # one extra workgroup in the consumer launch) -- this is how kernel_ms is measured INSIDE the timed region
             e_, seq, model = build_instance(dev, T, N, (cano_idx + k) % T, seed=2 + rank + 101 * k, use_flow=use_flow,
-                                            use_grid=args.grid, overlap=not args.no_overlap)
-            used = 0 if args.no_graph else e_.capture(steps_per_graph=max(1, args.steps_per_graph))
+                                            use_grid=args.grid, overlap=not args.no_overlap, profile=(k == 0))
+            used = 0 if args.no_graph else e_.capture(steps_per_graph=spg)
             e_.step(max(args.warmup - used, 0))
         engines.append(e_)
         streams.append(st)
@@ -173,24 +321,30 @@ def main():
         if K == 1:
             eng.step(n)
             return
-        spg = 1 if args.no_graph else max(1, args.steps_per_graph)
         chunks = [spg] * (n // spg) + ([n % spg] if n % spg else [])
         for c in chunks:  # round-robin in whole graphs so that the instances interleave on the device
             for e_, st in zip(engines, streams):
                 with torch.cuda.stream(st):
                     e_.step(c)
 
-    def barrier():
-        torch.cuda.synchronize()
-        if distributed:
-            dist.barrier()
-        torch.cuda.synchronize()
-
+    barrier()
+    prof = None
+    try:
+        eng.search_profile(reset=True)         # the accumulators cover exactly the timed region
+    except Exception:                          # non-default search path (grid / brute force): no device-side profile
+        pass
+    for e_ in engines:
+        e_.graph_replays = e_.eager_steps = 0
     barrier()
     t0 = time.perf_counter()
     run_steps(args.steps)
     barrier()
     el = time.perf_counter() - t0
+    try:
+        prof = eng.search_profile()
+    except Exception:
+        prof = None
+    replays, eager = eng.graph_replays, eng.eager_steps
     if distributed:
         tt = torch.tensor([el], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -207,11 +361,10 @@ def main():
             with torch.cuda.stream(st):
                 e_, _, _ = build_instance(dev, T, N, (cano_idx + 1 + k) % T, seed=1000 + rank + 101 * k, use_flow=use_flow,
                                           use_grid=args.grid, overlap=not args.no_overlap)
-                used = 0 if args.no_graph else e_.capture(steps_per_graph=max(1, args.steps_per_graph))
+                used = 0 if args.no_graph else e_.capture(steps_per_graph=spg)
                 e_.step(max(args.warmup - used, 0))
             sw_eng.append(e_)
             sw_st.append(st)
-        spg = 1 if args.no_graph else max(1, args.steps_per_graph)
         chunks = [spg] * (args.steps // spg) + ([args.steps % spg] if args.steps % spg else [])
         barrier()
         t1 = time.perf_counter()
@@ -226,8 +379,10 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el_s = float(tt.item())
         sweep = {"instances_per_gpu": Ks, "value": round(world * Ks * args.steps / el_s, 3), "unit": "iterations/s",
-                 "note": "aggregate over all GPUs of Ks concurrent independent instances per GPU (separate streams); "
-                         "`value` above is one instance per GPU"}
+                 "per_gpu": round(Ks * args.steps / el_s, 3), "n_gpus": world,
+                 "note": "aggregate over all GPUs of Ks concurrent independent instances per GPU (separate streams, "
+                         "round-robin graph replays); `value` above is one instance per GPU; per_gpu = value / n_gpus is "
+                         "the figure that should stay flat as ranks are added (instances share nothing)"}
         del sw_eng
     losses = eng.last_losses()
     # gather of the final energies only (the reference's sweep picks argmin total energy)
@@ -255,30 +410,42 @@ def main():
             nn_bytes += B * (N * 12 + M * 12 + N * 3 * (4 + 8))
             nn_flops += B * N * M * 8
             kname = "knn_pruned_pair_kernel (Chamfer K=1 both directions + flow K=3, one launch)"
+        nn_pairs = nn_flops // 8
         roof = None
-        if phases:
-            try:   # back-to-back launches of the search alone between two HIP events on the launch stream
-                k_ms, how = eng.search_ms(20), "mean of 20 back-to-back launches of the search kernel between two HIP events on the launch stream, at the optimisation state reached after the timed region"
-            except RuntimeError:
-                k_ms, how = phases["chamfer_nn"], "HIP events around the launch in eager serial steps after the timed region"
-                if use_flow:
-                    k_ms += phases["flow_knn3"]
+        if prof is not None and prof["launches"] > 0:
+            # Measured INSIDE the timed region, in every iteration (graph replays included): per launch, the span from the
+            # first workgroup's start to the last workgroup's end on the GPU's constant-rate clock, and the
+            # query-target distance evaluations the launch actually executed (dense + sparse scans, seeds, rescans).
+            k_ms = 1e3 * prof["seconds"] / prof["launches"]
             t_nn = k_ms * 1e-3
-            ach = nn_bytes / t_nn / 1e9
+            executed = prof["pairs"] / prof["launches"]
+            ach = executed * 8 / t_nn / 1e12
             traffic = None
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc_search.json")
+            pmc = os.path.join(ROOT, "profiles", "r02_pmc_search.json")
             if os.path.exists(pmc) and use_flow:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            roof = {"bound": "hbm", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": traffic,
-                    "kernel": kname, "kernel_ms": round(k_ms, 5), "algorithmic_bytes": nn_bytes,
-                    "note": "the search is fp32-VALU bound by construction (>900 flop/B), see `valu`; kernel_ms: " + how,
-                    "valu": {"achieved": round(nn_flops / t_nn / 1e12, 3), "peak": FP32_PEAK_TFLOPS,
-                             "unit": "TFLOP/s", "frac": round(nn_flops / t_nn / 1e12 / FP32_PEAK_TFLOPS, 4),
-                             "flops": nn_flops,
-                             "note": "ALGORITHMIC flops (8 per query-target pair of the brute-force definition) over "
-                                     "time; the exact box-pruned search evaluates only the pairs it cannot rule out, "
-                                     "so this is work delivered, not ALU activity"}}
+                pj = json.load(open(pmc))
+                traffic = {"bytes_per_launch": pj.get("hbm_bytes_per_launch"),
+                           "source": "static: profiles/r02_pmc_search.json (rocprofv3 --pmc passes of this command, "
+                                     "corrected per MI355X_MICROARCH.md); not measured in this run"}
+            roof = {"bound": "valu", "achieved": round(ach, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / FP32_PEAK_TFLOPS, 4), "traffic": traffic,
+                    "kernel": "knn_group_kernel (" + kname.split("(", 1)[1],
+                    "kernel_ms": round(k_ms, 5), "launches_measured": prof["launches"],
+                    "executed_pairs_per_launch": round(executed, 1), "flop_per_pair": 8,
+                    "algorithmic_pairs_per_launch": nn_pairs,
+                    "algorithmic_speedup": round(nn_pairs / executed, 3),
+                    "hbm": {"achieved": round(nn_bytes / t_nn / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(nn_bytes / t_nn / 1e9 / HBM_PEAK_GBS, 6), "algorithmic_bytes": nn_bytes,
+                            "note": "algorithmic bytes of the brute-force definition over the kernel time: <= 4 % by "
+                                    "construction, HBM is not what bounds an exact nearest-neighbour search"},
+                    "note": "achieved = executed distance evaluations x 8 flop / kernel time against the fp32 vector peak "
+                            "(157.3 TFLOP/s counts an FMA as 2; the distance contract forbids FMA contraction, so 8 "
+                            "flop = 8 issue slots).  The exact box-pruned search skips the pairs it can rule out: "
+                            "algorithmic_speedup = brute-force pairs / executed pairs is credit for the algorithm, not "
+                            "ALU activity.  kernel_ms and executed pairs are device-side measurements of every launch "
+                            "in the timed region (profile stamps, reart_relax_profile); rocprofv3 --kernel-trace "
+                            "--stats of `bench.py --sweep-instances 0 --no-tail --no-cpu-baseline` covers the same "
+                            "launches plus warm-up (profiles/)"}
         cpu = cpu_torch = None
         if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(seq, T, N, cano_idx)
@@ -351,7 +518,8 @@ def main():
                                    + ("+flow loss (k=3 blend, 3000 refs/pair)" if use_flow else " only")
                                    + ", full iteration fwd+loss+bwd+Adam, one instance per GPU",
                        "frames": T, "points": N, "parts": 20, "flow": use_flow,
-                       "graph": not args.no_graph, "steps_per_graph": (0 if args.no_graph else max(1, args.steps_per_graph)), "grid_search_static_targets": args.grid, "parallelism": f"instances x{world}" + (f" x{K} per GPU" if K > 1 else ""),
+                       "graph": not args.no_graph, "steps_per_graph": (0 if args.no_graph else spg),
+                       "graph_replays": replays, "eager_steps": eager, "grid_search_static_targets": args.grid, "parallelism": f"instances x{world}" + (f" x{K} per GPU" if K > 1 else ""),
                        "instances_per_gpu": K},
             "roofline": roof,
             "cpu_baseline": cpu,

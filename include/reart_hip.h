@@ -198,6 +198,24 @@ typedef struct reart_relax_config {
                              /*    i >= assign_iter): lambda_assign * sum |x_src - y_assigned|^2 over   */
                              /*    the pairs of `assign_map`                                            */
     float lambda_assign;     /* --lambda_assign                                           */
+    float weight_decay;      /* --weight_decay: torch.optim.Adam's L2 form g += wd * p (run_robot.py:146-148) */
+    /* Tuning and measurement switches.  0 = the library default everywhere.  The library reads NO environment
+     * variable in any call path: the caller decides once per instance (reart_amd/relax.py maps REART_* variables
+     * to these fields when an engine is built), so the ranks of a job cannot diverge mid-run. */
+    int search_mode;         /* 0: exact box-pruned warm-started search (default); 1: cold brute force (same results) */
+    int tune_slices;         /* waves (box slices) per search workgroup, 1..4 (default 3)  */
+    int tune_slices_flow;    /* the same for the K = 3 flow search (default: tune_slices)  */
+    int tune_sparse;         /* boxes needed by <= n queries of a wave go through the (query, box) queue instead of a  */
+                             /* 64-lane scan: 1..64 (default 40), < 0: dense scans only                                */
+    int tune_fwd_pts;        /* points per forward workgroup: 64 | 32 (default 32)         */
+    int tune_bwd_pts;        /* points per backward workgroup: 64 | 32 | 16 (default 32)   */
+    int tune_reorder;        /* < 0: keep the static launch order of the search items      */
+    int tune_cloud;          /* < 0: never copy the target cloud of a search workgroup into LDS (the cloud-resident form */
+                             /* is the default whenever the clouds fit: N <= ~7000 points)                              */
+    int tune_xcd;            /* > 0: every XCD runs one contiguous eighth of the (frame, query group) pairs (a run of */
+                             /* frames per L2) instead of every 8th pair; measured slower: frames differ 10x in work  */
+    int profile;             /* 1: the search launch of every iteration records per-workgroup wall-clock stamps and  */
+                             /*    its executed distance evaluations, reduced on the device (reart_relax_profile)    */
 } reart_relax_config;
 
 typedef struct reart_relax_buffers {
@@ -234,7 +252,7 @@ int reart_relax_prepare(const reart_relax_config *cfg, const reart_relax_buffers
  * the transformed clouds of iteration i to compute the assignment used in iteration i. */
 int reart_relax_forward(const reart_relax_config *cfg, const reart_relax_buffers *bufs,
                         void *workspace, size_t workspace_bytes, void *stream);
-/* enqueue one iteration (5 launches in the default configuration, no host sync) */
+/* enqueue one iteration (5 launches in the default configuration, no host sync, no environment lookups) */
 int reart_relax_step(const reart_relax_config *cfg, const reart_relax_buffers *bufs,
                      void *workspace, size_t workspace_bytes, void *stream);
 /* measurement aid: the same sequence with hipEvents between phases on `stream`; synchronises
@@ -247,12 +265,13 @@ int reart_relax_step(const reart_relax_config *cfg, const reart_relax_buffers *b
 #define REART_RELAX_PHASES 8
 int reart_relax_step_timed(const reart_relax_config *cfg, const reart_relax_buffers *bufs,
                            void *workspace, size_t workspace_bytes, void *stream, float *h_ms);
-/* measurement aid: average milliseconds of the search launch alone (both Chamfer directions + flow
- * K=3 in one kernel) at the current optimisation state: forward once, then `reps` back-to-back search
- * launches between two events on `stream`.  Modifies no parameter, counter or seed; synchronises.
- * REART_ERR_UNSUPPORTED outside the default configuration (pruned searches with the flow loss). */
-int reart_relax_search_ms(const reart_relax_config *cfg, const reart_relax_buffers *bufs,
-                          void *workspace, size_t workspace_bytes, void *stream, int reps, float *h_ms);
+/* measurement aid (cfg->profile = 1, default search path with the flow loss): the search launch of every
+ * reart_relax_step -- eager or replayed from a graph -- leaves per-workgroup wall-clock stamps that the consumer
+ * launch reduces on the device.  h_out[0] = launches since the last reset, [1] = their summed duration in seconds
+ * (first workgroup start to last workgroup end, constant-rate clock), [2] = query-target distance evaluations they
+ * executed, [3] = the clock rate in Hz.  Synchronises `stream`; reset != 0 clears the accumulators. */
+int reart_relax_profile(const reart_relax_config *cfg, void *workspace, size_t workspace_bytes, void *stream,
+                        double *h_out, int reset);
 
 /* ------------------------------------------------------------------------ */
 /* PointNet++ sampling / grouping (the live kernels of pointnet2_cuda)       */
@@ -398,6 +417,15 @@ int reart_lap_auction(const float *cost, int B, int n, int32_t *col4row, int32_t
 int reart_lap_auction_warm(const float *cost, int B, int n, int32_t *col4row, int32_t *certified,
                            const double *price_in, double *price_out, void *workspace, size_t workspace_bytes,
                            void *stream);
+
+/* Re-solve of a slowly moving batch (the kinematic projection, README.md:125: --assign_gap=1 re-solves its T-1 matrices
+ * after every Adam step, run_robot.py:165-178): shortest augmenting paths (Jonker-Volgenant) started from the previous
+ * solve's assignment (col4row on entry) and potentials (price_in, required) -- pairs that still attain their row's
+ * minimum are kept, every other row costs one Dijkstra search over the reduced costs.  Same outputs, same exact
+ * certificate as reart_lap_auction; the first solve of a sequence comes from reart_lap_auction. */
+int reart_lap_resolve(const float *cost, int B, int n, int32_t *col4row, int32_t *certified,
+                      const double *price_in, double *price_out, void *workspace, size_t workspace_bytes,
+                      void *stream);
 
 /* Cost matrices for the above: replaces `torch.cdist(pc_src, pc_tgt)` (run_robot.py:171, utils/model_utils.py:93).
  *   a [B,n,3], b [B,m,3] -> out [B,n,m] = Euclidean distance, sqrt(((dx*dx)+(dy*dy))+(dz*dz)) in fp32. */

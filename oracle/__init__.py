@@ -259,6 +259,17 @@ def linear_sum_assignment(cost):
     return [_lsa(np.asarray(c)) for c in np.asarray(cost)]
 
 
+def parallel_lap(cost, nproc):
+    """utils/model_utils.py:85-89 (`--use_nproc`, README.md:117,125): the reference ships the (T-1) matrices to a pool of
+    `nproc = len(cost)` processes, one scipy solve each.  cost [B,n,n] -> list of (row_ind, col_ind)."""
+    from multiprocessing import Pool
+
+    from scipy.optimize import linear_sum_assignment as _lsa
+
+    with Pool(processes=nproc) as pool:
+        return pool.starmap_async(_lsa, zip(np.asarray(cost))).get()
+
+
 def match_smnn(desc1, desc2, th=0.9):
     """Mutual second-nearest-neighbour ratio matching (reference utils/flow_utils.py:7-100: cdist -> topk(2) -> ratio
     test in both directions -> mutual filter, sorted by the desc1 index) -> (pairs [M,2] int64, ratio [M] = the larger

@@ -21,6 +21,7 @@ struct BaseFwdArgs {
     int *hard_idx;              // [N] nullable
     float *rt_table;            // [B*P][12] nullable: [R|t] rows for the backward's scalar loads
     float *boxes;               // [B][Npad/64][8] nullable: AABB of every 64 output points per frame
+    int pts;                    // points per forward workgroup: 64 or 32 (0: the default, 32)
 };
 
 struct BaseBwdArgs {
@@ -36,7 +37,7 @@ struct BaseBwdArgs {
     int cano_idx;
     int N, P, B, H;
     int nchunk;                 // ceil(N / cpts)
-    int cpts;                   // points per backward workgroup: 64 or 32 (set by the launcher)
+    int cpts;                   // points per backward workgroup: 64, 32 or 16 (0: the default, 32)
     float *partial;             // [nchunk][n_out]
     // finalize
     float *gW1, *gb1, *gW2, *g6d, *gt;
@@ -51,6 +52,7 @@ struct FinalizeAdam {
     float *W1, *b1, *W2, *p6d, *pt;   // parameters (updated in place)
     float *m, *v;                     // moments, order W1|b1|W2|p6d|pt
     float seg_lr, trans_lr, beta1, beta2, eps;
+    float weight_decay;               // torch.optim.Adam's L2 form: g += weight_decay * p
     const int64_t *step_ptr;
     const double *bias_corr;          // device [2]: 1 - beta1^step, sqrt(1 - beta2^step) of the coming step
 };
@@ -107,12 +109,12 @@ struct KnnJob {
     const int *qmap;       // nullable per-batch query frame index into q
     const int *tlen;       // nullable per-batch target count (ragged SoA rows, stride Ppad)
     const float *boxes;    // nullable [N][Ppad/NN_BOX][8]: AABB (lo xyz, hi xyz, pad) of every NN_BOX targets
-    const int *seed;       // pruned search only: [N][P1][KK] candidate neighbour indices (warm start)
+    const int *seed;       // pruned search only: [N][P1][KK] candidate neighbour indices (warm start); K = 1: may alias pi
     const int *border;     // pruned search only, nullable: [N * nqg] (batch, query group) pair = b * nqg + g handled at
-                           // launch position k (heavy pairs first: the items of a launch are dealt in order, late
-                           // heavy items make a long tail)
-    unsigned int *cost;    // pruned search only, nullable: [items of this job] work done by each item (boxes tested
-                           // and scanned, launch order), input of the next launch's order
+                           // launch position k.  Position k runs on XCD k / ceil(G/8); inside an XCD's chunk heavy pairs
+                           // come first (the items of a launch are dealt in order, late heavy items make a long tail)
+    unsigned int *cost;    // pruned search only, nullable: [N * nqg] work done for the pair at each launch position
+                           // (boxes tested and scanned, all waves), input of the next launch's order
     int P1, P2, Ppad, L;   // Ppad = S*L, L % NN_UB == 0
     int nqg;               // ceil(P1/64)
     float *pd;             // partial dists [S][N][P1][KK]   (S > 1)
@@ -125,7 +127,6 @@ struct KnnArgs {
     int N, S, K, euclidean;
     int items0;            // work items belonging to job 0
     int items;             // total work items
-    int sparse;            // prune.hip: boxes needed by <= sparse queries of a wave take the sparse scan (set by the launcher)
 };
 
 int reart_knn_launch_slices(const KnnArgs &a, int KK, hipStream_t st);
@@ -135,19 +136,43 @@ int reart_knn_pick_split(long waves, int P2, int K);
 #define NN_BOX 16   // targets per bounding box of the block-skip test (16, 32 or 64; measured 4545 / 4438 / 4321 it/s)
 #endif
 int reart_boxes_launch(const float *soa, int N, int Ppad, float *boxes, hipStream_t st);
-// exact search with box pruning + warm start (prune.hip); partial lists only, boxes dealt round-robin to slices
-int reart_knn_launch_pruned(const KnnArgs &a, int KK, hipStream_t st);
-int reart_prune_pick_split(void);
-int reart_prune_pick_split3(void);   // slices of the K = 3 (flow) search
-// K = 1 (two jobs) and K = 3 (one job) pruned searches in one launch
-// counters: 2 zero-initialised uints for the persistent form (NULL: one workgroup per item)
-int reart_knn_launch_pruned_pair(const KnnArgs &k1, const KnnArgs &k3, unsigned int *counters, hipStream_t st);
-// exact pruned search, one wave = 16 queries x 4 box slots (quad.hip); a.S must be 1 and
-// items0 = N * ceil(P1 / 16) per job
-int reart_knn_launch_quad(const KnnArgs &a, int KK, hipStream_t st);
-int reart_knn_launch_quad_pair(const KnnArgs &k1, const KnnArgs &k3, hipStream_t st);
-// exact search with per-query candidate lists, target cloud staged in LDS (lane.hip); a.S must be 1
-int reart_knn_launch_lane(const KnnArgs &a, int KK, hipStream_t st);
+// exact search with box pruning + warm start (prune.hip): ONE launch for up to two K = 1 jobs (the Chamfer
+// directions) and one K = 3 job (the flow search); one workgroup per (job, batch, query group), S waves each
+struct SearchArgs {
+    KnnJob k1[2]; int n1;          // K = 1 jobs (0, 1 or 2); results pd / pi [B][P1] (pi int32: also the next seed)
+    KnnJob k3;    int n3;          // K = 3 job (0 or 1); results pd / pi [B][P1][3]: the three best 8-target BLOCKS
+                                   // (block minimum, first index), rescanned with the exact key by the consumer
+    int G;                         // (batch, query group) pairs per job = B * nqg (the same for every job)
+    int per;                       // pairs per XCD chunk = ceil(G / 8) (set by the launcher)
+    int S1, S3;                    // waves per workgroup of a K = 1 / K = 3 item (1..4)
+    int sparse;                    // boxes needed by <= sparse queries of a wave go through the (query, box) queue (0: dense only)
+    int interleave;                // 0: XCD x runs the positions [x*per, (x+1)*per) (a run of frames per L2); 1: positions
+                                   // x, x+8, ... (every XCD sees every frame: balanced whatever the frames cost)
+    int cloud_resident;            // 1: when the target clouds fit in LDS, one workgroup of 16 waves per (job, batch, 16
+                                   // query groups) with the cloud copied into LDS (knn_cloud_kernel); S1 / S3 then unused
+    int k_nqg;                     // query groups per batch (set by the launcher)
+    unsigned long long *prof;      // nullable: [grid][2] wall-clock stamps of every workgroup (start, end)
+    unsigned int *prof_pairs;      //           [grid] distance evaluations executed by the workgroup
+};
+int reart_search_launch(const SearchArgs &a, hipStream_t st);
+int reart_search_grid(int n1, int n3, int G);   // workgroups of that launch (an upper bound for both forms)
+int reart_search_grid_cloud(int n1, int n3, int G, int nqg);
+int reart_search_workgroups(const SearchArgs &a);   // of the form reart_search_launch will pick for `a`
+
+#ifdef __HIPCC__
+// branch-free insertion of key (d, j) into an ascending top-3 list ordered by (distance, index)
+__device__ __forceinline__ void reart_top3_insert(float (&kd)[3], int (&ki)[3], float d, int j) {
+    const bool l0 = (d < kd[0]) | ((d == kd[0]) & (j < ki[0]));
+    const bool l1 = (d < kd[1]) | ((d == kd[1]) & (j < ki[1]));
+    const bool l2 = (d < kd[2]) | ((d == kd[2]) & (j < ki[2]));
+    kd[2] = l1 ? kd[1] : (l2 ? d : kd[2]);
+    ki[2] = l1 ? ki[1] : (l2 ? j : ki[2]);
+    kd[1] = l0 ? kd[0] : (l1 ? d : kd[1]);
+    ki[1] = l0 ? ki[0] : (l1 ? j : ki[1]);
+    kd[0] = l0 ? d : kd[0];
+    ki[0] = l0 ? j : ki[0];
+}
+#endif
 
 // ---- exact grid search over static target sets (grid.hip) -----------------------------------
 struct GridBuildArgs {

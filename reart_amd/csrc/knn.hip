@@ -311,14 +311,9 @@ static int knn_round_k(int K) {
 // K > 1 restarts its sorted list in every slice (each restart re-runs the insertion path for
 // the first ~64*K*ln targets), so it wants fewer, longer slices than K = 1.
 static int knn_pick_split(long waves, int P2, int K) {
-    const char *env = getenv(K > 1 ? "REART_KNN_SPLIT" : "REART_NN_SPLIT");
     int S = 1;
-    if (env && atoi(env) > 0) {
-        S = atoi(env);
-    } else {
-        const long want = 8192;  // measured: K = 3 also prefers many short slices (S=8: 82 us, S=4: 90, S=2: 106)
-        while (waves * S < want && S < 16) S *= 2;
-    }
+    const long want = 8192;  // measured: K = 3 also prefers many short slices (S=8: 82 us, S=4: 90, S=2: 106)
+    while (waves * S < want && S < 16) S *= 2;
     while (S > 1 && reart_div_up(P2, S) < 128) S /= 2;  // keep slices meaningful
     return S < 1 ? 1 : S;
 }

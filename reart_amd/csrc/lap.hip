@@ -393,11 +393,9 @@ static int lap_launch(const float *cost, int B, int n, int32_t *col4row, int32_t
     a.warm_assign = warm_assign;
     a.max_rounds_cert = 4 * n;
     {   // tuning knobs (defaults measured on the loop's matrices)
-        const char *e0 = getenv("REART_LAP_EPS0"), *th = getenv("REART_LAP_THETA"), *ef = getenv("REART_LAP_EPSF");
-        const char *ew = getenv("REART_LAP_EPS0_WARM");
-        a.eps0 = price_in ? (ew ? atof(ew) : (warm_assign ? 1e-2 : 1e-3)) : (e0 ? atof(e0) : 0.125);
-        a.theta_inv = 1.0 / (th ? atof(th) : 6.0);
-        a.eps_final = ef ? atof(ef) : 1e-11;
+        a.eps0 = price_in ? (warm_assign ? 1e-2 : 1e-3) : 0.125;
+        a.theta_inv = 1.0 / 6.0;
+        a.eps_final = 1e-11;
     }
     a.stats = (int *)((char *)workspace + reart_align_up(sizeof(double) * (size_t)B * n, 256));   // diagnostics, after the potentials
     a.pbval_ws = (double *)((char *)a.stats + reart_align_up(sizeof(int) * 4 * (size_t)B, 256));
@@ -425,6 +423,266 @@ extern "C" int reart_lap_auction_warm(const float *cost, int B, int n, int32_t *
                                       void *stream) {
     if (!price_in) return REART_ERR_INVALID_ARG;
     return lap_launch(cost, B, n, col4row, certified, price_in, price_out, 1, workspace, workspace_bytes, stream);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Re-solve of a SLOWLY MOVING problem: shortest augmenting paths from the previous solve's assignment and potentials
+// (the kinematic projection re-solves its (T-1) matrices every assign_gap iterations, run_robot.py:165-178, and one Adam
+// step moves the costs by ~1e-3: README.md:125 runs it with --assign_gap=1).
+//
+// With prices p (column potentials of the previous solve) the row potentials are u_i = min_k (c_ik + p_k): dual feasible
+// by construction.  A previous pair (i, s(i)) is kept when s(i) still attains that minimum (within `keep_tol`); a freed
+// row takes its arg-min column when that is unowned (lowest row wins); every row still free then gets ONE Dijkstra
+// search over reduced costs r_ik = c_ik + p_k - u_i (Jonker-Volgenant augmentation): columns are labelled with their
+// shortest distance, the closest unlabelled column is fixed, its owner's row is relaxed, until an unowned column is
+// reached; potentials move by (mu - d_j) on the fixed columns and the path is flipped.  The whole workgroup runs one
+// search: thread t owns the columns t, t + 1024, ... (labels in registers), the arg-min is one wave reduction + 16
+// values in LDS, the relaxation one coalesced row read.  A search costs a few dependent row reads when the old
+// potentials are nearly right -- against the tens of thousands of bids the auction needs from the same start.
+// The result is certified exactly like the auction's (same Jacobi rounds on the potentials).
+// ------------------------------------------------------------------------------------------------------------
+#define JV_CPT 4   // columns per thread: n <= 4096
+struct JvArgs {
+    const float *cost; int B, n;
+    int *col4row;              // in: previous assignment (or -1), out: the optimum
+    int *certified;
+    const double *price_in;    // previous potentials (prices, the auction's sign convention)
+    double *price_out;
+    int max_rounds_cert;
+    int *stats;                // nullable [B][4]: freed rows, rows left after the greedy step, Dijkstra steps, certificate rounds
+    double keep_tol;           // fraction of the largest cost
+};
+
+__global__ __launch_bounds__(LAP_BS) void lap_jv_kernel(JvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lsm[];
+    const int n = a.n, b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    constexpr int NW = LAP_BS / 64;
+    double *price = (double *)lsm;            // [n]
+    double *u = price + n;                    // [n] row potentials
+    int *owner = (int *)(u + n);              // [n] column -> row
+    int *assigned = owner + n;                // [n] row -> column
+    int *pred = assigned + n;                 // [n] column -> row it was reached from
+    int *flist = pred + n;                    // [n] free rows / arg-min columns
+    __shared__ double s_rv[2][NW];
+    __shared__ int s_rj[2][NW];
+    __shared__ double s_red[NW];
+    __shared__ int s_cnt, s_flag;
+    const float *C = a.cost + (size_t)b * n * n;
+
+    double mx = 0.0;
+    for (size_t e = tid; e < (size_t)n * n; e += LAP_BS) mx = fmax(mx, (double)C[e]);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+    if (lane == 0) s_red[wv] = mx;
+    for (int j = tid; j < n; j += LAP_BS) {
+        price[j] = a.price_in ? a.price_in[(size_t)b * n + j] : 0.0;
+        owner[j] = -1;
+        const int c = a.col4row[(size_t)b * n + j];
+        assigned[j] = (c >= 0 && c < n) ? c : -1;
+    }
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    mx = 0.0;
+    for (int w = 0; w < NW; ++w) mx = fmax(mx, s_red[w]);
+    if (!(mx > 0.0)) mx = 1.0;
+    const double keep_tol = mx * a.keep_tol;
+    // previous pairs: a repeated column keeps its lowest row
+    for (int i = tid; i < n; i += LAP_BS)
+        if (assigned[i] >= 0) atomicMin((unsigned int *)&owner[assigned[i]], (unsigned int)i);   // -1 = 0xffffffff: empty
+    __syncthreads();
+    for (int i = tid; i < n; i += LAP_BS)
+        if (assigned[i] >= 0 && owner[assigned[i]] != i) assigned[i] = -1;
+    __syncthreads();
+    // row potentials under the old prices; pairs that lost their arg-min are released
+    for (int i = wv; i < n; i += NW) {
+        double v1, v2;
+        int j1;
+        lap_row_top2(C + (size_t)i * n, price, n, lane, v1, j1, v2);
+        if (lane == 0) {
+            const int j = assigned[i];
+            u[i] = v1; flist[i] = j1;
+            if (j >= 0) {
+                const double cur = (double)C[(size_t)i * n + j] + price[j];
+                if (cur - v1 > keep_tol) { assigned[i] = -1; owner[j] = -1; }
+                else u[i] = cur;                      // the kept pair is tight by definition
+            }
+        }
+    }
+    __syncthreads();
+    int st_freed = 0, st_left = 0, st_steps = 0, st_cert = 0;
+    // greedy: a free row takes its arg-min column when nobody owns it (lowest row wins)
+    for (int i = tid; i < n; i += LAP_BS)
+        if (assigned[i] < 0) atomicAdd(&s_cnt, 1);
+    for (int j = tid; j < n; j += LAP_BS) pred[j] = 0x7fffffff;
+    __syncthreads();
+    st_freed = s_cnt;
+    for (int i = tid; i < n; i += LAP_BS)
+        if (assigned[i] < 0 && owner[flist[i]] < 0) atomicMin(&pred[flist[i]], i);
+    __syncthreads();
+    for (int i = tid; i < n; i += LAP_BS)
+        if (assigned[i] < 0 && owner[flist[i]] < 0 && pred[flist[i]] == i) assigned[i] = flist[i];
+    __syncthreads();
+    for (int i = tid; i < n; i += LAP_BS)
+        if (assigned[i] >= 0) owner[assigned[i]] = i;
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    // the rows still free, in ascending order (deterministic)
+    for (int i0 = 0; i0 < n; i0 += LAP_BS) {
+        const int i = i0 + tid;
+        const bool fr = i < n && assigned[i] < 0;
+        const unsigned long long m = __ballot(fr);
+        if (lane == 0) s_rj[0][wv] = __builtin_popcountll(m);
+        __syncthreads();
+        int off = s_cnt;
+        for (int w = 0; w < wv; ++w) off += s_rj[0][w];
+        if (fr) flist[off + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = i;
+        __syncthreads();
+        if (tid == 0) { int t = 0; for (int w = 0; w < NW; ++w) t += s_rj[0][w]; s_cnt += t; }
+        __syncthreads();
+    }
+    const int nfree = s_cnt;
+    st_left = nfree;
+
+    // ---- one shortest augmenting path per free row
+    bool solved = true;
+    for (int f = 0; f < nfree; ++f) {
+        const int i0 = flist[f];
+        double d[JV_CPT];
+        unsigned scanned = 0u;
+        {
+            const double ui = u[i0];
+            const float *row = C + (size_t)i0 * n;
+#pragma unroll
+            for (int k = 0; k < JV_CPT; ++k) {
+                const int j = tid + k * LAP_BS;
+                d[k] = j < n ? ((double)row[j] + price[j]) - ui : INFINITY;
+                if (j < n) pred[j] = i0;
+                if (j >= n) scanned |= 1u << k;
+            }
+        }
+        double mu = 0.0;
+        int sink = -1;
+        for (int it = 0; ; ++it) {
+            // closest unlabelled column: (distance, index) minimum over the workgroup
+            double bv = INFINITY;
+            int bj = 0x7fffffff;
+#pragma unroll
+            for (int k = 0; k < JV_CPT; ++k)
+                if (!((scanned >> k) & 1u) && d[k] < bv) { bv = d[k]; bj = tid + k * LAP_BS; }
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                const double ov = __shfl_xor(bv, o, 64);
+                const int oj = __shfl_xor(bj, o, 64);
+                if (ov < bv || (ov == bv && oj < bj)) { bv = ov; bj = oj; }
+            }
+            const int par = it & 1;
+            if (lane == 0) { s_rv[par][wv] = bv; s_rj[par][wv] = bj; }
+            __syncthreads();
+            bv = s_rv[par][0]; bj = s_rj[par][0];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) {
+                const double ov = s_rv[par][w];
+                const int oj = s_rj[par][w];
+                if (ov < bv || (ov == bv && oj < bj)) { bv = ov; bj = oj; }
+            }
+            ++st_steps;
+            mu = bv;
+            const int jstar = bj;
+            if (jstar == 0x7fffffff || !(bv < INFINITY)) break;   // only with non-finite costs: the matrix is reported uncertified
+            if ((jstar & (LAP_BS - 1)) == tid) scanned |= 1u << (jstar / LAP_BS);
+            const int i = owner[jstar];
+            if (i < 0) { sink = jstar; break; }
+            const double ui = u[i];
+            const float *row = C + (size_t)i * n;
+#pragma unroll
+            for (int k = 0; k < JV_CPT; ++k) {
+                const int j = tid + k * LAP_BS;
+                if (!((scanned >> k) & 1u)) {
+                    const double nd = mu + (((double)row[j] + price[j]) - ui);
+                    if (nd < d[k]) { d[k] = nd; pred[j] = i; }
+                }
+            }
+        }
+        if (sink < 0) { solved = false; break; }
+        // potentials: fixed columns (all labelled ones except the sink) and their rows
+#pragma unroll
+        for (int k = 0; k < JV_CPT; ++k) {
+            const int j = tid + k * LAP_BS;
+            if (j < n && ((scanned >> k) & 1u) && j != sink) {
+                const double delta = mu - d[k];
+                price[j] += delta;
+                u[owner[j]] += delta;
+            }
+        }
+        if (tid == 0) u[i0] += mu;
+        __syncthreads();
+        if (tid == 0 && sink >= 0) {                           // flip the path
+            int j = sink;
+            for (;;) {
+                const int i = pred[j];
+                const int jn = assigned[i];
+                assigned[i] = j; owner[j] = i;
+                if (i == i0) break;
+                j = jn;
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- certificate (the auction's): Jacobi rounds on the potentials until every assigned column is an exact arg-min
+    double *dd = price;
+    double *pb = u;                            // scratch: the row potentials are not needed any more
+    const double tol = mx * 1e-13;
+    int certified = 0;
+    for (int round = 0; solved && round < a.max_rounds_cert; ++round) {
+        if (tid == 0) s_flag = 0;
+        ++st_cert;
+        __syncthreads();
+        for (int i = wv; i < n; i += NW) {
+            double v1, v2;
+            int j1;
+            lap_row_top2(C + (size_t)i * n, dd, n, lane, v1, j1, v2);
+            if (lane == 0) {
+                const int j = assigned[i];
+                const double cur = (double)C[(size_t)i * n + j] + dd[j];
+                pb[i] = (cur - v1 > tol) ? v1 - (double)C[(size_t)i * n + j] : dd[j];
+                if (cur - v1 > tol) s_flag = 1;
+            }
+        }
+        __syncthreads();
+        const int changed = s_flag;
+        for (int i = tid; i < n; i += LAP_BS) dd[assigned[i]] = pb[i];
+        __syncthreads();
+        if (!changed) { certified = 1; break; }
+    }
+    for (int i = tid; i < n; i += LAP_BS) a.col4row[(size_t)b * n + i] = assigned[i];
+    if (a.price_out)
+        for (int j = tid; j < n; j += LAP_BS) a.price_out[(size_t)b * n + j] = dd[j];
+    if (tid == 0) a.certified[b] = certified;
+    if (tid == 0 && a.stats) { int *o = a.stats + 4 * b; o[0] = st_freed; o[1] = st_left; o[2] = st_steps; o[3] = st_cert; }
+}
+
+// Re-solve from the assignment in col4row and the potentials in price_in (both from an earlier solve of a similar batch,
+// reart_lap_auction* or this function); same outputs and the same certificate as reart_lap_auction.
+extern "C" int reart_lap_resolve(const float *cost, int B, int n, int32_t *col4row, int32_t *certified,
+                                 const double *price_in, double *price_out, void *workspace, size_t workspace_bytes,
+                                 void *stream) {
+    if (B < 0 || n < 1 || n > LAP_NMAX || n > JV_CPT * LAP_BS) return REART_ERR_INVALID_ARG;
+    if (B == 0) return REART_OK;
+    if (!cost || !col4row || !certified || !price_in) return REART_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < reart_lap_workspace_bytes(B, n)) return REART_ERR_INVALID_ARG;
+    JvArgs a = {};
+    a.cost = cost; a.B = B; a.n = n; a.col4row = col4row; a.certified = certified; a.price_in = price_in;
+    a.price_out = price_out ? price_out : (double *)workspace;
+    a.max_rounds_cert = 4 * n; a.keep_tol = 1e-12;
+    a.stats = (int *)((char *)workspace + reart_align_up(sizeof(double) * (size_t)B * n, 256));
+    const size_t lds = (size_t)n * (2 * 8 + 4 * 4);
+    if (lds > REART_LDS_DEFAULT_CAP &&
+        hipFuncSetAttribute((const void *)lap_jv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)
+        return REART_ERR_LAUNCH;
+    hipLaunchKernelGGL(lap_jv_kernel, dim3(B), dim3(LAP_BS), lds, (hipStream_t)stream, a);
+    REART_CHECK_LAUNCH();
+    return REART_OK;
 }
 
 // ------------------------------------------------------------------------------------------------------------

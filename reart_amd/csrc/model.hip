@@ -393,11 +393,10 @@ static void launch_base_fwd_t(const BaseFwdArgs &a, hipStream_t st) {
         (void)hipFuncSetAttribute((const void *)base_fwd_kernel<PP, HALF>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
     hipLaunchKernelGGL((base_fwd_kernel<PP, HALF>), dim3(reart_div_up(cover, PTS)), dim3(64 * W), lds, st, a);
 }
-// REART_FWD_PTS=64|32: points per forward workgroup (32: half waves on different part pairs)
+// a.pts = 64 | 32: points per forward workgroup (32, the default: half waves on different part pairs)
 template <int PP>
 static void launch_base_fwd(const BaseFwdArgs &a, hipStream_t st) {
-    const char *env = getenv("REART_FWD_PTS");
-    if (env && atoi(env) == 64) launch_base_fwd_t<PP, false>(a, st);
+    if (a.pts == 64) launch_base_fwd_t<PP, false>(a, st);
     else launch_base_fwd_t<PP, true>(a, st);
 }
 
@@ -770,8 +769,9 @@ __global__ __launch_bounds__(64 * (((PP > 0 ? PP : 32) + FW_PG - 1) / FW_PG)) vo
 
 __device__ __forceinline__ void adam_update(float *p, float g, float *m, float *v, float lr,
                                             float step_size_base, float bc2s, float beta1, float beta2,
-                                            float eps) {
+                                            float eps, float weight_decay = 0.f) {
     (void)lr;
+    if (weight_decay != 0.f) g = g + weight_decay * (*p);   // torch.optim.Adam: grad.add(param, alpha=weight_decay)
     float mm = *m, vv = *v;
     mm = mm + (g - mm) * (1.0f - beta1);
     vv = vv * beta2 + ((1.0f - beta2) * g) * g;
@@ -826,18 +826,18 @@ __device__ __forceinline__ void base_bwd_finalize_body(const BaseBwdArgs &a, con
             a.gW2[o] = acc;
             if (ad.enabled)
                 adam_update(ad.W2 + o, acc, ad.m + nW1 + a.H + o, ad.v + nW1 + a.H + o, ad.seg_lr, ss_seg, bc2s,
-                            ad.beta1, ad.beta2, ad.eps);
+                            ad.beta1, ad.beta2, ad.eps, ad.weight_decay);
         } else if (o < nW2 + nW1) {
             const int q = o - nW2;
             a.gW1[q] = acc;
             if (ad.enabled)
-                adam_update(ad.W1 + q, acc, ad.m + q, ad.v + q, ad.seg_lr, ss_seg, bc2s, ad.beta1, ad.beta2, ad.eps);
+                adam_update(ad.W1 + q, acc, ad.m + q, ad.v + q, ad.seg_lr, ss_seg, bc2s, ad.beta1, ad.beta2, ad.eps, ad.weight_decay);
         } else {
             const int q = o - nW2 - nW1;
             a.gb1[q] = acc;
             if (ad.enabled)
                 adam_update(ad.b1 + q, acc, ad.m + nW1 + q, ad.v + nW1 + q, ad.seg_lr, ss_seg, bc2s, ad.beta1,
-                            ad.beta2, ad.eps);
+                            ad.beta2, ad.eps, ad.weight_decay);
         }
     } else if (og < nW + 64 * a.B * a.P) {
         // one wave per (frame, part): 4 row quarters x 16 lanes; lane c < 12 of a quarter sums one entry of dL/d[R|t]
@@ -878,14 +878,14 @@ __device__ __forceinline__ void base_bwd_finalize_body(const BaseBwdArgs &a, con
             a.g6d[6 * (size_t)e + c] = g;
             if (ad.enabled)
                 adam_update(ad.p6d + 6 * (size_t)e + c, g, ad.m + base6 + 6 * e + c, ad.v + base6 + 6 * e + c,
-                            ad.trans_lr, ss_tr, bc2s, ad.beta1, ad.beta2, ad.eps);
+                            ad.trans_lr, ss_tr, bc2s, ad.beta1, ad.beta2, ad.eps, ad.weight_decay);
         } else {
             const int k = c - 6;
             const float g = k == 0 ? gRt[9] : (k == 1 ? gRt[10] : gRt[11]);
             a.gt[3 * (size_t)e + k] = g;
             if (ad.enabled)
                 adam_update(ad.pt + 3 * (size_t)e + k, g, ad.m + baset + 3 * e + k, ad.v + baset + 3 * e + k,
-                            ad.trans_lr, ss_tr, bc2s, ad.beta1, ad.beta2, ad.eps);
+                            ad.trans_lr, ss_tr, bc2s, ad.beta1, ad.beta2, ad.eps, ad.weight_decay);
         }
     }
 }
@@ -971,11 +971,7 @@ int reart_base_backward_ex(BaseBwdArgs a, const FinalizeAdam *adam, const StepBo
     if (!workspace || workspace_bytes < need) return REART_ERR_INVALID_ARG;
     char *ws = (char *)workspace;
     a.partial = (float *)(ws + o_part);
-    {   // REART_BWD_PTS=64|32|16: points per backward workgroup
-        const char *env = getenv("REART_BWD_PTS");
-        const int v = env ? atoi(env) : 32;
-        a.cpts = (v == 64 || v == 32 || v == 16) ? v : 32;
-    }
+    a.cpts = (a.cpts == 64 || a.cpts == 32 || a.cpts == 16) ? a.cpts : 32;   // points per backward workgroup
     a.nchunk = reart_div_up(a.N, a.cpts);
     if (!a.rt_table) {
         float *table = (float *)(ws + o_rt);

@@ -6,8 +6,8 @@
 // Same answer, bit for bit, as the brute-force kernels of knn.hip (same distance expression,
 // strict '<', ties -> lowest index); what changes is how many targets are looked at.
 //
-//   * Clouds are stored in Morton order (host side, relax.py), so 16 consecutive targets form a
-//     compact box and the 64 queries of a wave are neighbours.
+//   * Clouds are stored in the leaf order of a balanced k-d tree (host side, relax.kd_order), so 16
+//     consecutive targets form a compact box and the 64 queries of a wave are neighbours.
 //   * Warm start: the neighbour indices of the PREVIOUS iteration (any valid indices would do)
 //     give each query an upper bound thr on its K-th neighbour distance before anything is
 //     scanned:  thr = max_k d(q, t[seed_k])  over K distinct seeds.
@@ -27,22 +27,30 @@
 // and fp32 subtraction, multiplication and addition are monotone, so lb <= d(q,t) for every
 // target t inside the box (and the box-to-box bound is <= the point-to-box bound of every query
 // of the group).  A box is dropped only when lb > thr strictly; a target that beats or TIES the
-// current K-th candidate has d <= thr and therefore sits in a box that is scanned.  Boxes are
-// dealt to the S slices round-robin; the consumer merges slice results by the full (d, index) key.
+// current K-th candidate has d <= thr and therefore sits in a box that is scanned.
+//
+// Launch shape.  One WORKGROUP per (job, batch b, query group g of 64): its S waves take the boxes
+// round-robin (slice s = boxes base + lane*S + s), keep their candidates in registers, meet once in LDS,
+// and wave 0 merges them by the full (distance, index) key, does the ONE exact rescan of the winning half
+// box and writes ONE record per query -- no per-slice partial lists in memory, nothing for the consumer to
+// merge.  The K = 1 record (int32 index) is also the next iteration's warm-start seed, in place.
+// Workgroup L runs on XCD L % 8: every XCD owns a contiguous eighth of the (batch, group) pairs of each job,
+// i.e. 2-3 consecutive frames, so a cloud is fetched into ONE L2 instead of eight; inside its eighth the
+// pairs are launched heaviest first (counting sort of last iteration's work counts, step.hip).
 #include "common.h"
 #include "internal.h"
 #include <math.h>
 #include <string.h>
 
 typedef float f2 __attribute__((ext_vector_type(2)));
-#define PR_WPB 1   // waves per workgroup (independent work items, no barrier); measured: 4 is slower (a
-                   // workgroup's slots are held until its slowest wave ends)
-#define PR_PF 8    // boxes whose targets are prefetched together
-#ifndef PR_PREFETCH
-#define PR_PREFETCH 0   // 1: fetch the targets of every surviving box PR_PF at a time, before the precise tests.  0: fetch a
-                        // box's targets when it is scanned -- fewer instructions and no loads for the 60 % of the boxes
-                        // the precise test rejects; with 4 waves per SIMD the exposed latency is covered (56 -> 53 us)
-#endif
+#define PR_SMAX 4       // most waves (box slices) per search workgroup
+#define PR_PF 1
+#define PR_PREFETCH 0   // a box's targets are fetched when it is scanned (prefetching every coarse survivor eight at a
+                        // time was measured: more instructions, loads for the 60 % of the boxes the precise test
+                        // rejects, no gain -- the branch is kept compiled out for reference)
+#define PR_QCAP 768     // entries of a wave's (query, box) queue
+// LDS per wave: staged box of a dense scan [64 floats] | the wave's queries [64][4] | result slots [3][64] u64 | queue
+#define PR_LDS_WAVE_BYTES (64 * 4 + 64 * 16 + 3 * 64 * 8 + PR_QCAP * 4)
 
 #ifdef REART_PRUNE_STATS   // diagnostic build only (tools/prune_stats.py): how much the filters let through
 __device__ unsigned long long g_prune_stats[8];
@@ -55,13 +63,22 @@ extern "C" int reart_debug_prune_stats(unsigned long long *out, int reset) {
 #else
 #define PRUNE_STAT(k, v) do { } while (0)
 #endif
-#ifdef REART_ITEM_CLOCK   // diagnostic build only (tools/item_clock.py): wave lifetime of every work item
-// (start, end in s_memtime ticks, XCC id) of the last pair launch, items in launch order
-__device__ unsigned long long g_item_clock[3 * 16384];
-extern "C" int reart_debug_item_clock(unsigned long long *out, int n) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_item_clock), sizeof(unsigned long long) * 3 * (n < 16384 ? n : 16384)) == hipSuccess
-               ? REART_OK : REART_ERR_LAUNCH;
+#ifdef REART_PRUNE_PHASE   // diagnostic build only (tools/phase_prof.py; make -C reart_amd/csrc phase)
+// phase clocks of the search waves (s_memtime ticks summed over waves): 0 prologue (seeds, group summaries), 1 coarse
+// filter, 2 precise tests, 3 dense scans, 4 queue appends, 5 queue drains, 6 barrier wait + merge + rescan, 7 waves
+__device__ unsigned long long g_prune_phase[8];
+extern "C" int reart_debug_prune_phase(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prune_phase), sizeof(g_prune_phase)) != hipSuccess) return REART_ERR_LAUNCH;
+    if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prune_phase), z, sizeof(z)); }
+    return REART_OK;
 }
+#define PH_DECL unsigned long long ph_t = __builtin_amdgcn_s_memtime(), ph_acc[7] = {0, 0, 0, 0, 0, 0, 0}
+#define PH(k) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); ph_acc[k] += n_ - ph_t; ph_t = n_; } while (0)
+#define PH_FLUSH(from, to) do { if ((threadIdx.x & 63) == 0) for (int k_ = from; k_ <= to; ++k_) atomicAdd(&g_prune_phase[k_], ph_acc[k_]); } while (0)
+#else
+#define PH_DECL do { } while (0)
+#define PH(k) do { } while (0)
+#define PH_FLUSH(from, to) do { } while (0)
 #endif
 
 // min / max of a lane's value with a DPP-permuted copy in ONE instruction (v_min_f32_dpp).  Written through the compiler
@@ -98,23 +115,21 @@ __device__ __forceinline__ float box_lb(float lo0, float lo1, float lo2, float h
     return (ex * ex + ey * ey) + ez * ez;
 }
 
-// KK = 1: partial (distance, exact index) per slice.  KK = 3: partial top-3 BLOCKS of 8 targets
-// (block minimum, first index of the block), rescanned by the consumer (flow_blend_kernel).
-template <int KK>
-__device__ __forceinline__ void knn_pruned_body(const KnnArgs &a, const int w) {
-    // Work per item varies (it depends on how tight the warm start is), and the working set fits
-    // every XCD's L2: no XCD-contiguous remap here -- consecutive items go to different XCDs and
-    // the two jobs alternate, so every XCD gets the same mix of light and heavy items.
-    if (w >= a.items) return;
-    const bool two = a.items > a.items0;
-    const int jsel = two ? (w & 1) : 0;
-    const KnnJob jb = a.job[jsel];
-    const int wl = two ? (w >> 1) : w;
-    const int s = wl % a.S;                      // slices of one query group are neighbours
-    const int gpos = wl / a.S;                                   // launch position of the (batch, query group) pair
-    const int grp = jb.border ? jb.border[gpos] : gpos;
-    const int b = grp / jb.nqg, g = grp - b * jb.nqg;
+// One WAVE of a search workgroup: the 64 queries of group g of batch b against the boxes of slice s (boxes
+// base + lane * S + s of every round).  Leaves, per lane (= query): KK = 1 the smallest distance found and the
+// half box (8 targets) that holds it; KK = 3 the three best 8-target blocks by (minimum, first index).
+// `pairs` counts the query-target distance evaluations the wave executed (lanes x targets, dense and sparse forms).
+// LDSV: `cloud` / `boxes_p` point at a copy of the batch's target cloud (SoA rows of `cstride` floats) and of its boxes in
+// LDS (knn_cloud_kernel); otherwise at the global images.  QCAP: entries of the wave's queue.
+template <int KK, bool LDSV, int QCAP>
+__device__ __forceinline__ void knn_pruned_wave(const KnnJob &jb, const int S, const int sparse, const int b, const int g,
+                                                const int s, const float *cloud, const int cstride, const float *boxes_p,
+                                                float *s_tg, float *s_qc, unsigned int *s_q,
+                                                unsigned long long *s_key, float &qx_o, float &qy_o, float &qz_o,
+                                                float (&bm)[KK], int (&bb)[KK], int &work_o, unsigned int &pairs_o) {
+    struct { int S, sparse; } a = {S, sparse};
     const int lane = threadIdx.x & 63;
+    PH_DECL;
 
     const int i = g * NN_BS + lane;
     const int ic = i < jb.P1 ? i : jb.P1 - 1;
@@ -123,12 +138,12 @@ __device__ __forceinline__ void knn_pruned_body(const KnnArgs &a, const int w) {
     const float qx = qp[0], qy = qp[1], qz = qp[2];
     const f2 qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
 
-    const float *tx = jb.tsoa + (size_t)b * 3 * jb.Ppad;
-    const float *ty = tx + jb.Ppad;
-    const float *tz = ty + jb.Ppad;
+    const float *tx = cloud;
+    const float *ty = tx + cstride;
+    const float *tz = ty + cstride;
     const int n2 = jb.tlen ? jb.tlen[b] : jb.P2;
     const int nbox = (n2 + NN_BOX - 1) / NN_BOX;
-    const float *bx = jb.boxes + (size_t)b * (jb.Ppad / NN_BOX) * 8;
+    const float *bx = boxes_p;
 
     // ---- warm start
     float thr = 0.f;
@@ -163,18 +178,95 @@ __device__ __forceinline__ void knn_pruned_body(const KnnArgs &a, const int w) {
         G[q][6] = rl(gt, 16 * q);
     }
 
-    float bm[KK];
-    int bb[KK];
 #pragma unroll
     for (int k = 0; k < KK; ++k) { bm[k] = INFINITY; bb[k] = -1; }
-    __shared__ __attribute__((aligned(16))) float s_tg_all[PR_WPB * PR_PF * 48];
-    float *s_tg = s_tg_all + (threadIdx.x >> 6) * (PR_PF * 48);
     const float *tx_g = tx;
+    unsigned int pairs = 64u * KK;            // the seeds
 
     int work = 16;   // uniform work counter of this item (prologue ~ 16 tests)
-    const int sparse_max = a.sparse < 8 ? a.sparse : 8;   // boxes needed by at most this many queries take the sparse scan (0: off)
-    const int sparse16_max = a.sparse > 8 ? a.sparse : 0;   // 9 .. 16 needers: the 16-query form
+    const int queue_max = a.sparse;   // boxes needed by at most this many queries go through the (query, box) queue (0: off)
+    int qcnt = 0;                     // entries in the wave's queue (uniform)
+    // the wave's queries, parked once for the drain steps (a lane then evaluates ANOTHER lane's query)
+    ((float4 *)s_qc)[lane] = make_float4(qx, qy, qz, 0.f);
+    if (KK == 1) s_key[lane] = ~0ull;
+    else { s_key[lane] = ~0ull; s_key[64 + lane] = ~0ull; s_key[128 + lane] = ~0ull; }
+    // Drain: 64 entries per step, one per lane.  The lane's 16 targets come straight from the SoA rows (three 64-byte
+    // lines per lane); the distance expression is the contract's.  K = 1: the (minimum, half box) of the entry meets the
+    // query's other entries in an LDS atomic minimum on the 64-bit key (distance bits, block start) -- distances are
+    // non-negative, so the integer order is the (distance, index) order and the result does not depend on the order of
+    // arrival.  K = 3: both half-box minima go through three such minima in a row, the loser of each level moving on to
+    // the next: the three slots end as the three smallest keys, again whatever the order.  Afterwards every lane folds
+    // its query's slots into its registers (and its bound) and clears them.
+    auto drain_queue = [&]() {
+        for (int e0 = 0; e0 < qcnt; e0 += 64) {
+            work += 6;
+            const int e = e0 + lane;
+            const bool valid = e < qcnt;
+            const unsigned ent = s_q[valid ? e : e0];
+            const int ql = (int)(ent & 63u), j0 = (int)(ent >> 6) * NN_BOX;
+            pairs += (unsigned)__builtin_popcountll(__ballot(valid)) * NN_BOX;
+            const float4 qc = ((const float4 *)s_qc)[ql];
+            const float *tp = tx_g + j0;
+            float4 X[4], Y[4], Z[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                X[u] = *(const float4 *)(tp + 4 * u);
+                Y[u] = *(const float4 *)(tp + cstride + 4 * u);
+                Z[u] = *(const float4 *)(tp + 2 * cstride + 4 * u);
+            }
+            const f2 cx = {qc.x, qc.x}, cy = {qc.y, qc.y}, cz = {qc.z, qc.z};
+            float mh[2] = {INFINITY, INFINITY};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const f2 dxa = cx - f2{X[u].x, X[u].y}, dya = cy - f2{Y[u].x, Y[u].y}, dza = cz - f2{Z[u].x, Z[u].y};
+                const f2 dxb = cx - f2{X[u].z, X[u].w}, dyb = cy - f2{Y[u].z, Y[u].w}, dzb = cz - f2{Z[u].z, Z[u].w};
+                const f2 da = (dxa * dxa + dya * dya) + dza * dza;
+                const f2 db = (dxb * dxb + dyb * dyb) + dzb * dzb;
+                mh[u >> 1] = fminf(fminf(mh[u >> 1], fminf(da.x, da.y)), fminf(db.x, db.y));
+            }
+            if (KK == 1) {
+                const float m = fminf(mh[0], mh[1]);
+                const unsigned long long key = ((unsigned long long)__float_as_uint(m) << 32) | (unsigned)(j0 + (mh[1] < mh[0] ? 8 : 0));
+                if (valid) atomicMin(&s_key[ql], key);
+            } else if (valid) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    unsigned long long key = ((unsigned long long)__float_as_uint(mh[h]) << 32) | (unsigned)(j0 + 8 * h);
+#pragma unroll
+                    for (int lv = 0; lv < 3; ++lv) {
+                        const unsigned long long old = atomicMin(&s_key[64 * lv + ql], key);
+                        key = old > key ? old : key;
+                    }
+                }
+            }
+        }
+        qcnt = 0;
+        // fold the slots of this lane's own query into its registers
+        if (KK == 1) {
+            const unsigned long long k = s_key[lane];
+            const float m = __uint_as_float((unsigned)(k >> 32));
+            const int blk = (int)(unsigned)k;
+            if (k != ~0ull && ((m < bm[0]) || (m == bm[0] && blk < bb[0]))) { bm[0] = m; bb[0] = blk; }
+            thr = fminf(thr, bm[0]);
+            s_key[lane] = ~0ull;
+        } else {
+            float kd[3];
+            int ki[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { kd[c] = bm[c]; ki[c] = bb[c] >= 0 ? bb[c] : 0x7fffffff; }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const unsigned long long k = s_key[64 * c + lane];
+                s_key[64 * c + lane] = ~0ull;
+                if (k != ~0ull) reart_top3_insert(kd, ki, __uint_as_float((unsigned)(k >> 32)), (int)(unsigned)k);
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { bm[c] = kd[c]; bb[c] = ki[c] == 0x7fffffff ? -1 : ki[c]; }
+            thr = fminf(thr, bm[KK - 1]);
+        }
+    };
     const int per = 64 * a.S;
+    PH(0);
     for (int base = 0; base < nbox; base += per) {
         // ---- coarse filter: lane l looks at box base + l*S + s
         const int bid = base + lane * a.S + s;
@@ -191,22 +283,26 @@ __device__ __forceinline__ void knn_pruned_body(const KnnArgs &a, const int w) {
             }
         }
         unsigned long long mask = __ballot(pass);
+        PH(1);
         PRUNE_STAT(KK == 1 ? 0 : 3, 0);                                  // coarse rounds (K = 1)
         if (KK == 1) PRUNE_STAT(1, __builtin_popcountll(mask));          // boxes passing the coarse filter
         if (KK == 1) PRUNE_STAT(3, __builtin_popcountll(__ballot(thr == INFINITY)));  // lanes without a bound
         // scan of one box: the brute-force inner loop of knn.hip on its 16 targets
         auto scan_box = [&](const int bit, const int slot) {
             work += 5;                                                   // a scan costs about five tests
+            pairs += 64u * NN_BOX;
             if (KK == 1) PRUNE_STAT(2, 1);                               // boxes scanned
             const int j0 = (base + bit * a.S + s) * NN_BOX;
             // the box's 16 targets were staged in LDS slot `slot` (x[16] | y[16] | z[16]); all lanes read
             // the same addresses (broadcast) -- the operands of the packed ops are VGPR pairs
-            if (!PR_PREFETCH) {
+            if (!PR_PREFETCH && !LDSV) {
                 const int l = lane < 48 ? lane : 47;
-                const float v = tx_g[(size_t)(l >> 4) * jb.Ppad + j0 + (l & 15)];
+                const float v = tx_g[(size_t)(l >> 4) * cstride + j0 + (l & 15)];
                 if (lane < 48) s_tg[lane] = v;
             }
-            const float *tx = s_tg + (PR_PREFETCH ? slot * 48 : 0) - j0, *ty = tx + 16, *tz = tx + 32;
+            // LDSV: the cloud itself is in LDS -- the broadcast reads go straight to it
+            const float *tx = LDSV ? tx_g : s_tg + (PR_PREFETCH ? slot * 48 : 0) - j0;
+            const float *ty = tx + (LDSV ? cstride : 16), *tz = ty + (LDSV ? cstride : 16);
             if (KK == 1) {
                 // minimum of each half of the box: the final rescan then looks at 8 targets instead of 16
                 float mh[2] = {INFINITY, INFINITY};
@@ -248,94 +344,19 @@ __device__ __forceinline__ void knn_pruned_body(const KnnArgs &a, const int w) {
                 thr = fminf(thr, bm[KK - 1]);
             }
         };
-        // sparse form of the scan for a box that at most PR_SPARSE of the 64 queries need (40-60 % of the scanned
-        // boxes, tools/prune_stats.py): instead of all 64 lanes walking the 16 targets for the sake of a few,
-        // 8 lanes x 2 targets (packed) evaluate ONE needing query against the box, eight such queries side by side.
-        // The needing lanes park their coordinates in LDS by their rank among the needers, row r of 8 lanes reads
-        // query r, the row minimum (same distance expression, min is order-free) goes back to its lane through one
-        // ds_bpermute.  A lane that does not need the box (lb > thr) is not updated: its minimum over this box
-        // would exceed thr and can never be (or tie with) one of its K nearest after the slice merge.
-        auto sparse_box = [&](const int bit, const unsigned long long need, const bool nd) {
-            work += 2;
+        // (query, box) work queue.  Most scanned boxes are needed by a FEW of the wave's 64 queries (one to three is
+        // typical: noisy points with large bounds drive the per-wave union), so walking a box with all 64 lanes for
+        // their sake wastes the wave.  Such a box is not scanned here: every needing lane appends (box, lane) to the
+        // wave's queue in LDS -- its rank among the needers (mbcnt of the ballot) is its slot -- and the queue is
+        // drained 64 entries at a time with ONE entry per lane (drain_queue below): every lane then evaluates one
+        // query against the 16 targets of one box, whatever mix of queries and boxes the entries hold.
+        auto enqueue_box = [&](const int bit, const unsigned long long need, const bool nd, const int nneed) {
+            work += 1;
             if (KK == 1) PRUNE_STAT(2, 1);
-            const int j0 = (base + bit * a.S + s) * NN_BOX;
+            const int bid = base + bit * a.S + s;
             const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need, 0u));
-            float *s_qc = s_tg + 64;                                     // [8][4] behind the staged box of the dense scan
-            if (nd) *(float4 *)(s_qc + 4 * rank) = make_float4(qx, qy, qz, 0.f);
-            const int u = lane & 7;
-            const float *tp = tx_g + j0 + 2 * u;
-            const f2 txv = *(const f2 *)tp, tyv = *(const f2 *)(tp + jb.Ppad), tzv = *(const f2 *)(tp + 2 * (size_t)jb.Ppad);
-            const float4 qc = *(const float4 *)(s_qc + 4 * (lane >> 3));
-            const f2 cx = {qc.x, qc.x}, cy = {qc.y, qc.y}, cz = {qc.z, qc.z};
-            const f2 dx = cx - txv, dy = cy - tyv, dz = cz - tzv;
-            const f2 d = (dx * dx + dy * dy) + dz * dz;
-            float m = fminf(d.x, d.y);
-            m = pr_min_q2(pr_min_q1(m));                                 // quad: targets 8h .. 8h+7 of the box
-            if (KK == 1) {
-                // the two half-box minima (lanes 0..3 / 4..7 of the row) come back separately: the winner's half
-                const float r0 = __int_as_float(__builtin_amdgcn_ds_bpermute(rank << 5, __float_as_int(m)));
-                const float r1 = __int_as_float(__builtin_amdgcn_ds_bpermute((rank << 5) + 16, __float_as_int(m)));
-                const float r = nd ? fminf(r0, r1) : INFINITY;
-                if (r < bm[0]) { bm[0] = r; bb[0] = j0 + (r1 < r0 ? 8 : 0); }
-                thr = fminf(thr, r);
-            } else {
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    float r = __int_as_float(__builtin_amdgcn_ds_bpermute((rank << 5) + (h << 4), __float_as_int(m)));
-                    r = nd ? r : INFINITY;
-#pragma unroll
-                    for (int c = KK - 1; c >= 0; --c) {
-                        const int cp = c > 0 ? c - 1 : 0;
-                        const bool lt_prev = (c > 0) && (r < bm[cp]);
-                        const bool lt_cur = r < bm[c];
-                        bm[c] = lt_prev ? bm[cp] : (lt_cur ? r : bm[c]);
-                        bb[c] = lt_prev ? bb[cp] : (lt_cur ? j0 + 8 * h : bb[c]);
-                    }
-                }
-                thr = fminf(thr, bm[KK - 1]);
-            }
-        };
-        // the same for 9..16 needing queries: 4 lanes x 4 targets per query, sixteen queries side by side
-        auto sparse16_box = [&](const int bit, const unsigned long long need, const bool nd) {
-            work += 3;
-            if (KK == 1) PRUNE_STAT(2, 1);
-            const int j0 = (base + bit * a.S + s) * NN_BOX;
-            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need, 0u));
-            float *s_qc = s_tg + 64;                                     // [16][4]
-            if (nd) *(float4 *)(s_qc + 4 * rank) = make_float4(qx, qy, qz, 0.f);
-            const int u = lane & 3;
-            const float *tp = tx_g + j0 + 4 * u;
-            const float4 txv = *(const float4 *)tp, tyv = *(const float4 *)(tp + jb.Ppad), tzv = *(const float4 *)(tp + 2 * (size_t)jb.Ppad);
-            const float4 qc = *(const float4 *)(s_qc + 4 * (lane >> 2));
-            const f2 cx = {qc.x, qc.x}, cy = {qc.y, qc.y}, cz = {qc.z, qc.z};
-            const f2 dxa = cx - f2{txv.x, txv.y}, dya = cy - f2{tyv.x, tyv.y}, dza = cz - f2{tzv.x, tzv.y};
-            const f2 dxb = cx - f2{txv.z, txv.w}, dyb = cy - f2{tyv.z, tyv.w}, dzb = cz - f2{tzv.z, tzv.w};
-            const f2 da = (dxa * dxa + dya * dya) + dza * dza;
-            const f2 db = (dxb * dxb + dyb * dyb) + dzb * dzb;
-            float m = fminf(fminf(da.x, da.y), fminf(db.x, db.y));
-            m = pr_min_q1(m);                                            // lanes {0,1}: targets 0..7, lanes {2,3}: 8..15
-            if (KK == 1) {
-                const float r0 = __int_as_float(__builtin_amdgcn_ds_bpermute(rank << 4, __float_as_int(m)));
-                const float r1 = __int_as_float(__builtin_amdgcn_ds_bpermute((rank << 4) + 8, __float_as_int(m)));
-                const float r = nd ? fminf(r0, r1) : INFINITY;
-                if (r < bm[0]) { bm[0] = r; bb[0] = j0 + (r1 < r0 ? 8 : 0); }
-                thr = fminf(thr, r);
-            } else {
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    float r = __int_as_float(__builtin_amdgcn_ds_bpermute((rank << 4) + (h << 3), __float_as_int(m)));
-                    r = nd ? r : INFINITY;
-#pragma unroll
-                    for (int c = KK - 1; c >= 0; --c) {
-                        const int cp = c > 0 ? c - 1 : 0;
-                        const bool lt_prev = (c > 0) && (r < bm[cp]);
-                        const bool lt_cur = r < bm[c];
-                        bm[c] = lt_prev ? bm[cp] : (lt_cur ? r : bm[c]);
-                        bb[c] = lt_prev ? bb[cp] : (lt_cur ? j0 + 8 * h : bb[c]);
-                    }
-                }
-                thr = fminf(thr, bm[KK - 1]);
-            }
+            if (nd) s_q[qcnt + rank] = ((unsigned)bid << 6) | (unsigned)lane;
+            qcnt += nneed;
         };
         while (mask) {
             // ---- take the next PR_PF surviving boxes and put ALL their targets in flight: lane l < 48
@@ -380,6 +401,7 @@ __device__ __forceinline__ void knn_pruned_body(const KnnArgs &a, const int w) {
             const f2 e2 = {fmaxf(fmaxf(a2.x, c2.x), 0.f), fmaxf(fmaxf(a2.y, c2.y), 0.f)};
             const f2 lb = (e0 * e0 + e1 * e1) + e2 * e2;
             work += 2;
+            PH(2);
 #pragma unroll 1   // one copy of the scan code (two copies cost 30 VGPRs of occupancy)
             for (int h = 0; h < (hasB ? 2 : 1); ++h) {
                 const float lbh = h ? lb.y : lb.x;
@@ -393,9 +415,14 @@ __device__ __forceinline__ void knn_pruned_body(const KnnArgs &a, const int w) {
                 const unsigned long long need = __ballot(nd);
                 if (need) {
                     const int nneed = __builtin_popcountll(need);
-                    if (nneed <= sparse_max) sparse_box(h ? bB : bA, need, nd);
-                    else if (nneed <= sparse16_max) sparse16_box(h ? bB : bA, need, nd);
-                    else scan_box(h ? bB : bA, slot + h);
+                    if (nneed <= queue_max) {
+                        enqueue_box(h ? bB : bA, need, nd, nneed);
+                        PH(4);
+                        if (qcnt > QCAP - 64) { drain_queue(); PH(5); }   // uniform: qcnt is a wave-wide count
+                    } else {
+                        scan_box(h ? bB : bA, slot + h);
+                        PH(3);
+                    }
                 }
             }
             slot += 2;
@@ -403,137 +430,281 @@ __device__ __forceinline__ void knn_pruned_body(const KnnArgs &a, const int w) {
         }
     }
 
-    if (KK == 1) {
-        // exact (lowest) index inside the winning half box
+    PH(2);
+    if (qcnt > 0) drain_queue();
+    PH(5);
+    PH_FLUSH(0, 5);
+    qx_o = qx; qy_o = qy; qz_o = qz;
+    work_o = work; pairs_o = pairs;
+}
+
+
+// ------------------------------------------------------------------------------------------------------------
+// The search launch: up to two K = 1 jobs (the Chamfer directions) and one K = 3 job (the flow search);
+// SearchArgs is declared in internal.h.
+__global__ __launch_bounds__(64 * PR_SMAX) void knn_group_kernel(SearchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];      // blockDim.x / 64 x PR_LDS_WAVE_BYTES
+    __shared__ float s_m[PR_SMAX][3][64];
+    __shared__ int s_b[PR_SMAX][3][64];
+    __shared__ unsigned int s_wk[PR_SMAX][2];
+    const int L = blockIdx.x, x = L & 7, r = L >> 3;
+    const int s = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    unsigned long long t0 = 0ull;
+    if (a.prof && threadIdx.x == 0) t0 = wall_clock64();
+    // XCD-local item r: two K = 1 items alternate with one K = 3 item while both kinds last
+    const int items1 = a.n1 * a.per, items3 = a.n3 * a.per;
+    const int mixed = (a.n1 == 2 && a.n3) ? 3 * a.per : 0;
+    int kind, idx;
+    if (r < mixed) {
+        const int q = r / 3, rr = r - 3 * q;
+        kind = rr < 2 ? 1 : 3;
+        idx = rr < 2 ? 2 * q + rr : q;
+    } else {
+        const int d1 = mixed ? 2 * a.per : 0, d3 = mixed ? a.per : 0;
+        const int v = r - mixed, left1 = items1 - d1;
+        kind = v < left1 ? 1 : 3;
+        idx = v < left1 ? d1 + v : d3 + (v - left1);
+    }
+    const int j = kind == 1 ? (a.n1 == 2 ? (idx & 1) : 0) : 0;
+    const int p = kind == 1 ? (a.n1 == 2 ? (idx >> 1) : idx) : idx;
+    const int pos = a.interleave ? p * 8 + x : x * a.per + p;   // launch position: XCD x owns a contiguous chunk, or every 8th
+    const bool live = p < a.per && pos < a.G && (kind == 1 ? idx < items1 : idx < items3);
+    if (!live) {                                                        // padding of the last chunk (uniform per workgroup)
+        if (a.prof && threadIdx.x == 0) { a.prof[2 * (size_t)L] = t0; a.prof[2 * (size_t)L + 1] = t0; a.prof_pairs[L] = 0u; }
+        return;
+    }
+    const KnnJob &jb = kind == 1 ? a.k1[j] : a.k3;
+    const int S = kind == 1 ? a.S1 : a.S3;
+    const int grp = jb.border ? jb.border[pos] : pos;
+    const int b = grp / jb.nqg, g = grp - b * jb.nqg;
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    float bm[3] = {INFINITY, INFINITY, INFINITY};
+    int bb[3] = {-1, -1, -1};
+    int work = 0;
+    unsigned int pairs = 0u;
+    if (s < S) {
+        unsigned char *wl = s_dyn + (size_t)s * PR_LDS_WAVE_BYTES;
+        float *s_tg = (float *)wl;
+        float *s_qc = (float *)(wl + 64 * 4);
+        unsigned long long *s_key = (unsigned long long *)(wl + 64 * 4 + 64 * 16);
+        unsigned int *s_q = (unsigned int *)(wl + 64 * 4 + 64 * 16 + 3 * 64 * 8);
+        const float *cloud = jb.tsoa + (size_t)b * 3 * jb.Ppad;
+        const float *boxes_p = jb.boxes + (size_t)b * (jb.Ppad / NN_BOX) * 8;
+        if (kind == 1) {
+            float m1[1]; int b1[1];
+            knn_pruned_wave<1, false, PR_QCAP>(jb, S, a.sparse, b, g, s, cloud, jb.Ppad, boxes_p, s_tg, s_qc, s_q, s_key,
+                                               qx, qy, qz, m1, b1, work, pairs);
+            bm[0] = m1[0]; bb[0] = b1[0];
+        } else {
+            knn_pruned_wave<3, false, PR_QCAP>(jb, S, a.sparse, b, g, s, cloud, jb.Ppad, boxes_p, s_tg, s_qc, s_q, s_key,
+                                               qx, qy, qz, bm, bb, work, pairs);
+        }
+        if (s > 0) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { s_m[s][k][lane] = bm[k]; s_b[s][k][lane] = bb[k]; }
+            if (lane == 0) { s_wk[s][0] = (unsigned int)work; s_wk[s][1] = pairs; }
+        }
+    }
+#ifdef REART_PRUNE_PHASE
+    const unsigned long long tb0 = __builtin_amdgcn_s_memtime();
+#endif
+    if (blockDim.x > 64) __syncthreads();
+#ifdef REART_PRUNE_PHASE
+    if (lane == 0) { atomicAdd(&g_prune_phase[6], __builtin_amdgcn_s_memtime() - tb0); atomicAdd(&g_prune_phase[7], 1ull); }
+#endif
+    if (s != 0) return;
+    // ---- wave 0: merge the slices' candidates by (minimum, first index): distinct slices hold distinct boxes, so the
+    // lower block start is the lower index
+    for (int t = 1; t < S; ++t) { work += (int)s_wk[t][0]; pairs += s_wk[t][1]; }
+    const int i = g * NN_BS + lane;
+    const float *tx = jb.tsoa + (size_t)b * 3 * jb.Ppad, *ty = tx + jb.Ppad, *tz = ty + jb.Ppad;
+    if (kind == 1) {
+        float m = bm[0];
+        int blk = bb[0];
+        for (int t = 1; t < S; ++t) {
+            const float mt = s_m[t][0][lane];
+            const int bt = s_b[t][0][lane];
+            const bool take = bt >= 0 && ((mt < m) || (mt == m && (blk < 0 || bt < blk)));
+            m = take ? mt : m; blk = take ? bt : blk;
+        }
+        // exact (lowest) index inside the winning half box: ONE rescan per query
         int bi = 0x7fffffff;
-        if (bb[0] >= 0) {
-            const int blk = bb[0];
+        if (blk >= 0) {
 #pragma unroll
             for (int u = NN_BOX / 2 - 1; u >= 0; --u) {
                 const float d = reart_sqdist3(qx, qy, qz, tx[blk + u], ty[blk + u], tz[blk + u]);
-                if (d == bm[0]) bi = blk + u;
+                if (d == m) bi = blk + u;
             }
         }
-        bb[0] = bi;
-    }
-    if (jb.cost && lane == 0) jb.cost[wl] = (unsigned int)work;
-    if (i >= jb.P1) return;
-    const size_t o = (((size_t)s * a.N + b) * jb.P1 + i) * KK;
+        pairs += 64u * (NN_BOX / 2);
+        if (i < jb.P1) {
+            const size_t o = (size_t)b * jb.P1 + i;
+            jb.pd[o] = m; jb.pi[o] = bi;
+        }
+    } else {
+        float kd[3] = {INFINITY, INFINITY, INFINITY};
+        int ki[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff};
 #pragma unroll
-    for (int k = 0; k < KK; ++k) { jb.pd[o + k] = bm[k]; jb.pi[o + k] = bb[k]; }
-}
-
-template <int KK>
-__global__ __launch_bounds__(NN_BS * PR_WPB) void knn_pruned_kernel(KnnArgs a) {
-    knn_pruned_body<KK>(a, blockIdx.x * PR_WPB + (threadIdx.x >> 6));
-}
-
-// REART_SPARSE=n: boxes needed by at most n (0..8) queries of the wave take the sparse scan; default 8, 0 = always dense
-static int reart_prune_pick_sparse(void) {
-    const char *env = getenv("REART_SPARSE");
-    const int n = env ? atoi(env) : 16;
-    return n < 0 ? 0 : (n > 16 ? 16 : n);
-}
-
-// Both searches of one iteration in ONE launch: the K = 1 Chamfer items and the K = 3 flow items are
-// independent, and a single dispatch lets them share the chip without the cross-queue fork / join of
-// two streams (measured ~6-12 us per dependency edge in a replayed graph).  Two K = 1 items alternate
-// with one K = 3 item while both kinds last.
-struct KnnPairArgs { KnnArgs k1, k3; int mixed; unsigned int *ctr; };   // mixed = 3 * min(items1 / 2, items3)
-__device__ __forceinline__ void knn_pruned_pair_item(const KnnPairArgs &a, const int w) {
-    // item kind and index first, then ONE call site per body (each inlined copy is ~1 k instructions)
-    int kind, idx;
-    if (w < a.mixed) {
-        const int q = w / 3, r = w - 3 * q;
-        kind = r < 2 ? 1 : 3;
-        idx = r < 2 ? 2 * q + r : q;
-    } else {
-        const int d1 = 2 * (a.mixed / 3), d3 = a.mixed / 3;   // items already dealt
-        const int v = w - a.mixed, left1 = a.k1.items - d1;
-        kind = v < left1 ? 1 : 3;
-        idx = v < left1 ? d1 + v : d3 + (v - left1);
-        if (kind == 3 && idx >= a.k3.items) return;
+        for (int k = 0; k < 3; ++k) reart_top3_insert(kd, ki, bm[k], bb[k] >= 0 ? bb[k] : 0x7fffffff);
+        for (int t = 1; t < S; ++t) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int bt = s_b[t][k][lane];
+                reart_top3_insert(kd, ki, s_m[t][k][lane], bt >= 0 ? bt : 0x7fffffff);
+            }
+        }
+        if (i < jb.P1) {
+            const size_t o = ((size_t)b * jb.P1 + i) * 3;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { jb.pd[o + k] = kd[k]; jb.pi[o + k] = kd[k] < INFINITY ? ki[k] : -1; }
+        }
     }
-    if (kind == 1) knn_pruned_body<1>(a.k1, idx);
-    else knn_pruned_body<3>(a.k3, idx);
-}
-__global__ __launch_bounds__(NN_BS * PR_WPB) void knn_pruned_pair_kernel(KnnPairArgs a) {
-#ifdef REART_ITEM_CLOCK
-    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-#endif
-    knn_pruned_pair_item(a, blockIdx.x * PR_WPB + (threadIdx.x >> 6));
-#ifdef REART_ITEM_CLOCK
-    if (threadIdx.x == 0 && blockIdx.x < 16384) {
-        g_item_clock[3 * blockIdx.x] = t0;
-        g_item_clock[3 * blockIdx.x + 1] = __builtin_amdgcn_s_memtime();
-        g_item_clock[3 * blockIdx.x + 2] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 0xf;   // HW_REG_XCC_ID
+    if (lane == 0) {
+        if (jb.cost) jb.cost[pos] = (unsigned int)work;
+        if (a.prof) {
+            a.prof[2 * (size_t)L] = t0; a.prof[2 * (size_t)L + 1] = wall_clock64();
+            a.prof_pairs[L] = pairs;
+        }
     }
-#endif
-}
-// Persistent form: a fixed number of one-wave workgroups (a few per SIMD) each take every
-// gridDim.x-th work item.  (Drawing items from one device counter was tried: ~15 k atomics on one
-// address serialise at the memory side and tripled the kernel time.)
-__global__ __launch_bounds__(NN_BS) void knn_pruned_pair_persistent_kernel(KnnPairArgs a) {
-    const int total = a.k1.items + a.k3.items;
-    for (int w = blockIdx.x; w < total; w += gridDim.x) knn_pruned_pair_item(a, w);
 }
 
-int reart_knn_launch_pruned_pair(const KnnArgs &k1, const KnnArgs &k3, unsigned int *counters, hipStream_t st) {
-    for (int j = 0; j < 2; ++j)
-        if (!k1.job[j].boxes || !k1.job[j].seed || !k3.job[j].boxes || !k3.job[j].seed) return REART_ERR_INVALID_ARG;
-    if (k1.items != 2 * k1.items0 || k3.items != k3.items0) return REART_ERR_INVALID_ARG;
-    KnnPairArgs a;
-    a.k1 = k1; a.k3 = k3;
-    a.k1.sparse = a.k3.sparse = reart_prune_pick_sparse();
-    const int m = (k1.items / 2 < k3.items) ? k1.items / 2 : k3.items;
-    a.mixed = 3 * m;
-    a.ctr = counters;
-    const char *pe = getenv("REART_PERSIST");
-    // persistent waves per SIMD; 0 (default) = one workgroup per item.  Measured equal at 7 per SIMD and
-    // slower below: the launch is bound by its arithmetic, not by the rate at which workgroups start.
-    const int wps = pe ? atoi(pe) : 0;
-    if (counters && wps > 0) {
-        int nwg = 256 * 4 * wps;
-        if (nwg > k1.items + k3.items) nwg = k1.items + k3.items;
-        hipLaunchKernelGGL(knn_pruned_pair_persistent_kernel, dim3(nwg), dim3(NN_BS), 0, st, a);
-    } else {
-        hipLaunchKernelGGL(knn_pruned_pair_kernel, dim3(reart_div_up(k1.items + k3.items, PR_WPB)), dim3(NN_BS * PR_WPB), 0, st, a);
+// ------------------------------------------------------------------------------------------------------------
+// Cloud-resident form of the same search.  Measured on the kernel above (tools/phase_prof.py): a search wave is a CHAIN
+// of dependent memory round trips -- seeds -> seed targets -> boxes -> (per scanned box / per drain step) targets ->
+// rescan -- and spends its life waiting for them, not computing.  A target cloud of the loop is 48 KB (4096 points,
+// SoA) + 8 KB of boxes: it fits in LDS.  Here one workgroup of PC_WAVES waves copies the cloud and the boxes of ITS
+// (job, batch) into LDS once (coalesced 16-byte loads), and every wave then runs one whole query group (all boxes: no
+// slices, no merge, no barrier at the end) with every target / box read served by LDS.  What is left of the chain in
+// global memory: the query, its seeds, and the record written at the end.
+// Falls back to knn_group_kernel when a cloud does not fit (reart_search_launch decides).
+#define PC_WAVES 16
+#define PC_QCAP 256
+#define PC_WAVE_BYTES (64 * 16 + 3 * 64 * 8 + PC_QCAP * 4)      // the wave's queries | result slots | queue
+__global__ __launch_bounds__(64 * PC_WAVES) void knn_cloud_kernel(SearchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    const int L = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    unsigned long long t0 = 0ull;
+    if (a.prof && threadIdx.x == 0) t0 = wall_clock64();
+    // workgroup -> (job, batch, block of PC_WAVES query groups); jobs innermost so that neighbours differ in kind
+    const int njobs = a.n1 + a.n3;
+    const int jsel = L % njobs;
+    const int rest = L / njobs;
+    const int B = a.G / a.k_nqg;
+    const int b = rest % B, blk = rest / B;
+    const int kind = jsel < a.n1 ? 1 : 3;
+    const KnnJob &jb = kind == 1 ? a.k1[jsel] : a.k3;
+    // ---- stage the batch's target cloud and boxes
+    const int Ppad = jb.Ppad, nboxp = Ppad / NN_BOX;
+    float *cl = (float *)s_dyn;                                   // [3][Ppad]
+    float *bxs = cl + 3 * (size_t)Ppad;                           // [nboxp][8]
+    {
+        const float4 *src = (const float4 *)(jb.tsoa + (size_t)b * 3 * Ppad);
+        float4 *dst = (float4 *)cl;
+        const int n4 = 3 * Ppad / 4;
+        for (int e = threadIdx.x; e < n4; e += 64 * PC_WAVES) dst[e] = src[e];
+        const float4 *sb = (const float4 *)(jb.boxes + (size_t)b * nboxp * 8);
+        float4 *db = (float4 *)bxs;
+        for (int e = threadIdx.x; e < 2 * nboxp; e += 64 * PC_WAVES) db[e] = sb[e];
     }
+    __syncthreads();
+    const int g = blk * PC_WAVES + w;
+    unsigned int pairs = 0u;
+    int work = 0;
+    if (g < jb.nqg) {
+        unsigned char *wl = s_dyn + (size_t)(3 * Ppad + 8 * nboxp) * 4 + (size_t)w * PC_WAVE_BYTES;
+        float *s_qc = (float *)wl;
+        unsigned long long *s_key = (unsigned long long *)(wl + 64 * 16);
+        unsigned int *s_q = (unsigned int *)(wl + 64 * 16 + 3 * 64 * 8);
+        float qx, qy, qz;
+        float bm[3] = {INFINITY, INFINITY, INFINITY};
+        int bb[3] = {-1, -1, -1};
+        if (kind == 1) {
+            float m1[1]; int b1[1];
+            knn_pruned_wave<1, true, PC_QCAP>(jb, 1, a.sparse, b, g, 0, cl, Ppad, bxs, nullptr, s_qc, s_q, s_key, qx, qy, qz,
+                                              m1, b1, work, pairs);
+            bm[0] = m1[0]; bb[0] = b1[0];
+        } else {
+            knn_pruned_wave<3, true, PC_QCAP>(jb, 1, a.sparse, b, g, 0, cl, Ppad, bxs, nullptr, s_qc, s_q, s_key, qx, qy, qz,
+                                              bm, bb, work, pairs);
+        }
+        const int i = g * NN_BS + lane;
+        if (kind == 1) {
+            // exact (lowest) index inside the winning half box
+            int bi = 0x7fffffff;
+            if (bb[0] >= 0) {
+                const float *tx = cl, *ty = cl + Ppad, *tz = cl + 2 * (size_t)Ppad;
+#pragma unroll
+                for (int u = NN_BOX / 2 - 1; u >= 0; --u) {
+                    const float d = reart_sqdist3(qx, qy, qz, tx[bb[0] + u], ty[bb[0] + u], tz[bb[0] + u]);
+                    if (d == bm[0]) bi = bb[0] + u;
+                }
+            }
+            pairs += 64u * (NN_BOX / 2);
+            if (i < jb.P1) {
+                const size_t o = (size_t)b * jb.P1 + i;
+                jb.pd[o] = bm[0]; jb.pi[o] = bi;
+            }
+        } else if (i < jb.P1) {
+            const size_t o = ((size_t)b * jb.P1 + i) * 3;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { jb.pd[o + k] = bm[k]; jb.pi[o + k] = bm[k] < INFINITY ? bb[k] : -1; }
+        }
+        if (lane == 0 && jb.cost) jb.cost[b * jb.nqg + g] = (unsigned int)work;
+    }
+    if (a.prof) {
+        __shared__ unsigned int s_pairs[PC_WAVES];
+        if (lane == 0) s_pairs[w] = pairs;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned int tot = 0u;
+            for (int k = 0; k < PC_WAVES; ++k) tot += s_pairs[k];
+            a.prof[2 * (size_t)L] = t0; a.prof[2 * (size_t)L + 1] = wall_clock64();
+            a.prof_pairs[L] = tot;
+        }
+    }
+}
+
+// LDS bytes of the cloud-resident form for the largest target cloud of the launch; 0 = does not fit
+static size_t search_cloud_lds(const SearchArgs &a) {
+    int Ppad = 0;
+    for (int j = 0; j < a.n1; ++j) Ppad = a.k1[j].Ppad > Ppad ? a.k1[j].Ppad : Ppad;
+    if (a.n3) Ppad = a.k3.Ppad > Ppad ? a.k3.Ppad : Ppad;
+    const size_t need = (size_t)(3 * Ppad + 8 * (Ppad / NN_BOX)) * 4 + (size_t)PC_WAVES * PC_WAVE_BYTES + 256;
+    return need <= 152 * 1024 ? need : 0;
+}
+
+int reart_search_launch(const SearchArgs &a_in, hipStream_t st) {
+    SearchArgs a = a_in;
+    if (a.n1 < 0 || a.n1 > 2 || a.n3 < 0 || a.n3 > 1 || a.n1 + a.n3 == 0 || a.G < 1) return REART_ERR_INVALID_ARG;
+    if ((a.n1 && (a.S1 < 1 || a.S1 > PR_SMAX)) || (a.n3 && (a.S3 < 1 || a.S3 > PR_SMAX))) return REART_ERR_INVALID_ARG;
+    for (int j = 0; j < a.n1; ++j)
+        if (!a.k1[j].boxes || !a.k1[j].seed || !a.k1[j].pd || !a.k1[j].pi) return REART_ERR_INVALID_ARG;
+    if (a.n3 && (!a.k3.boxes || !a.k3.seed || !a.k3.pd || !a.k3.pi)) return REART_ERR_INVALID_ARG;
+    a.per = reart_div_up(a.G, 8);
+    a.k_nqg = a.n1 ? a.k1[0].nqg : a.k3.nqg;
+    const size_t cl_lds = a.cloud_resident ? search_cloud_lds(a) : 0;
+    if (cl_lds) {
+        if (hipFuncSetAttribute((const void *)knn_cloud_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)
+            return REART_ERR_LAUNCH;
+        hipLaunchKernelGGL(knn_cloud_kernel, dim3(reart_search_grid_cloud(a.n1, a.n3, a.G, a.k_nqg)), dim3(64 * PC_WAVES),
+                           cl_lds, st, a);
+        REART_CHECK_LAUNCH();
+        return REART_OK;
+    }
+    const int S = (a.n1 ? a.S1 : 0) > (a.n3 ? a.S3 : 0) ? a.S1 : a.S3;
+    const size_t lds = (size_t)S * PR_LDS_WAVE_BYTES;
+    hipLaunchKernelGGL(knn_group_kernel, dim3(reart_search_grid(a.n1, a.n3, a.G)), dim3(64 * S), lds, st, a);
     REART_CHECK_LAUNCH();
     return REART_OK;
 }
-
-int reart_knn_launch_pruned(const KnnArgs &a_in, int KK, hipStream_t st) {
-    KnnArgs a = a_in;
-    a.sparse = reart_prune_pick_sparse();
-    const int grid = reart_div_up(a.items, PR_WPB);
-    for (int j = 0; j < 2; ++j)
-        if (!a.job[j].boxes || !a.job[j].seed) return REART_ERR_INVALID_ARG;
-    if (a.items != a.items0 && a.items != 2 * a.items0) return REART_ERR_INVALID_ARG;   // the two jobs alternate
-    switch (KK) {
-        case 1: hipLaunchKernelGGL((knn_pruned_kernel<1>), dim3(grid), dim3(NN_BS * PR_WPB), 0, st, a); break;
-        case 3: hipLaunchKernelGGL((knn_pruned_kernel<3>), dim3(grid), dim3(NN_BS * PR_WPB), 0, st, a); break;
-        default: return REART_ERR_UNSUPPORTED;
-    }
-    REART_CHECK_LAUNCH();
-    return REART_OK;
+// workgroups the launch of `a` will have (the form is chosen exactly as in reart_search_launch)
+int reart_search_workgroups(const SearchArgs &a) {
+    const int nqg = a.n1 ? a.k1[0].nqg : a.k3.nqg;
+    if (a.cloud_resident && search_cloud_lds(a)) return reart_search_grid_cloud(a.n1, a.n3, a.G, nqg);
+    return reart_search_grid(a.n1, a.n3, a.G);
 }
-
-// split for the pruned search: the per-item work is small and uneven, a few slices even it out.  Every slice repeats
-// the item prologue and the final rescan, so fewer slices retire fewer instructions; measured with the sparse scan
-// (9.79 / 9.95 / 9.87 k it/s for S = 4 / 3 / 2; S = 8: 8.7 k)
-int reart_prune_pick_split(void) {
-    const char *env = getenv("REART_PRUNE_SPLIT");
-    const int S = env ? atoi(env) : 3;
-    return S >= 1 && S <= 16 ? S : 3;
-}
-
-int reart_prune_pick_split3(void) {
-    const char *env = getenv("REART_PRUNE_SPLIT3");
-    if (!env) return reart_prune_pick_split();
-    const int S = atoi(env);
-    return S >= 1 && S <= 16 ? S : reart_prune_pick_split();
-}
+int reart_search_grid(int n1, int n3, int G) { return 8 * (n1 + n3) * reart_div_up(G, 8); }
+int reart_search_grid_cloud(int n1, int n3, int G, int nqg) { return (n1 + n3) * (G / nqg) * reart_div_up(nqg, PC_WAVES); }
 
 // ---------------------------------------------------------------------------------------------
 // Stand-alone entry: warm-started exact K-NN (K = 1 or 3) through the C ABI.
@@ -559,12 +730,13 @@ __global__ __launch_bounds__(256) void knn_warm_finish_kernel(KnnArgs a) {
             ki[s] = lp ? ki[sp] : (lc ? j : ki[s]);
         }
     };
-    for (int s = 0; s < a.S; ++s) {
-        const size_t o = (((size_t)s * a.N + b) * jb.P1 + i) * KK;
+    {
+        const size_t o = ((size_t)b * jb.P1 + i) * KK;                   // one merged record per query
 #pragma unroll
         for (int k = 0; k < KK; ++k) {
             const float d = jb.pd[o + k];
-            insert(d, d < INFINITY ? jb.pi[o + k] : 0x7fffffff);
+            const int q = jb.pi[o + k];
+            insert(d, (d < INFINITY && q >= 0) ? q : 0x7fffffff);
         }
     }
     if (KK > 1) {
@@ -599,15 +771,14 @@ __global__ __launch_bounds__(256) void knn_warm_finish_kernel(KnnArgs a) {
 struct WarmPlan { int S, Ppad; size_t o_soa, o_box, o_pd, o_pi, total; };
 static int warm_plan(int N, int P1, int P2, int K, WarmPlan *p) {
     if (N < 0 || P1 < 0 || P2 < 0 || (K != 1 && K != 3)) return REART_ERR_INVALID_ARG;
-    const char *mode = getenv("REART_SEARCH");
-    p->S = (mode && !strcmp(mode, "quad")) ? 1 : reart_prune_pick_split();   // quad.hip leaves one record per query
-    while (p->S > 1 && reart_div_up(P2, p->S) < 64) p->S /= 2;
+    p->S = 3;                                                             // waves per search workgroup
+    while (p->S > 1 && reart_div_up(P2, p->S) < 64) p->S -= 1;
     p->Ppad = (int)reart_align_up((size_t)(P2 > 0 ? P2 : 1), NN_BOX);
     size_t off = 0;
     p->o_soa = off; off += reart_align_up(sizeof(float) * 3 * (size_t)N * p->Ppad, 256);
     p->o_box = off; off += reart_align_up(sizeof(float) * 8 * (size_t)N * (p->Ppad / NN_BOX), 256);
-    p->o_pd = off; off += reart_align_up(sizeof(float) * (size_t)p->S * N * P1 * K, 256);
-    p->o_pi = off; off += reart_align_up(sizeof(int) * (size_t)p->S * N * P1 * K, 256);
+    p->o_pd = off; off += reart_align_up(sizeof(float) * (size_t)N * P1 * K, 256);
+    p->o_pi = off; off += reart_align_up(sizeof(int) * (size_t)N * P1 * K, 256);
     p->total = off;
     return REART_OK;
 }
@@ -644,10 +815,10 @@ extern "C" int reart_knn_points_idx_warm(const float *p1, const float *p2, int N
     jb.seed = seed; jb.P1 = P1; jb.P2 = P2; jb.Ppad = p.Ppad; jb.L = 0; jb.nqg = reart_div_up(P1, NN_BS);
     jb.pd = (float *)(ws + p.o_pd); jb.pi = (int *)(ws + p.o_pi); jb.dists = dists; jb.idx = idx;
     a.job[1] = jb;
-    const char *mode = getenv("REART_SEARCH");
-    const bool quad = mode && !strcmp(mode, "quad");
-    a.items0 = quad ? N * reart_div_up(P1, 16) : N * jb.nqg * p.S; a.items = a.items0;
-    rc = quad ? reart_knn_launch_quad(a, K, st) : reart_knn_launch_pruned(a, K, st);
+    SearchArgs sr = {};
+    sr.G = N * jb.nqg; sr.S1 = sr.S3 = p.S; sr.sparse = 40;
+    if (K == 1) { sr.k1[0] = jb; sr.n1 = 1; } else { sr.k3 = jb; sr.n3 = 1; }
+    rc = reart_search_launch(sr, st);
     if (rc != REART_OK) return rc;
     const dim3 fg(reart_div_up(P1, 256), N);
     if (K == 1) hipLaunchKernelGGL((knn_warm_finish_kernel<1>), fg, dim3(256), 0, st, a);

@@ -25,10 +25,13 @@ struct StepPlan {
     size_t o_bc;              // Adam bias corrections of the coming step (double[2])
     size_t o_ticket;          // last-workgroup ticket of the finalize kernel (zero between launches)
     size_t o_boxY, o_boxX, o_boxR;  // AABBs of every NN_BOX targets (block-skip test)
-    int pruned;               // box-pruned, warm-started search (prune.hip) instead of the slice kernels
-    size_t o_seed0, o_seed1, o_seed3;  // last iteration's neighbour indices: x->y [B,N], y->x [B,N], flow [B,N,3]
-    size_t o_border;          // [3][B * nqg] launch order of the (frame, query group) pairs of the three search jobs: heaviest first
-    size_t o_cost;            // per-item work counts of the last search launch (3 jobs)
+    int pruned;               // box-pruned, warm-started search (prune.hip) instead of the brute-force slice kernels
+    int W1, W3;               // pruned: waves (box slices) per search workgroup, K = 1 / K = 3
+    int sparse;               // pruned: sparse-scan limit
+    size_t o_seed3;           // last iteration's flow neighbour indices [B,N,3] (the Chamfer seeds are the K = 1 records themselves)
+    size_t o_border;          // [3][B * nqg] launch order of the (frame, query group) pairs of the three search jobs
+    size_t o_cost;            // [3][B * nqg] work counts of the last search launch, by launch position
+    size_t o_prof, o_prof_pairs, o_prof_acc;   // cfg.profile: per-workgroup stamps of the search launch and their accumulators
     size_t o_gridY, o_gridR;  // exact-search grids over pc_list and the flow reference sets
     int gstrideY, gstrideR;
     size_t bwd_bytes, total;
@@ -49,19 +52,20 @@ static int step_plan(const reart_relax_config *c, StepPlan *p) {
     if (c->N <= 0 || c->P <= 0 || c->P > 32 || c->B <= 0 || c->H <= 0) return REART_ERR_INVALID_ARG;
     if (c->use_flow && (c->flow_k != 3 || c->M_max < 3)) return REART_ERR_UNSUPPORTED;
     const long waves1 = 2L * c->B * reart_div_up(c->N, NN_BS);
-    // 1: per-wave pruning (prune.hip, default); 2: per-lane candidate lists (lane.hip, REART_SEARCH=lane: fewer
-    // distance evaluations but divergent and latency bound -- slower, kept as an experiment); 0: brute force
-    const char *mode = getenv("REART_SEARCH");
-    p->pruned = (c->use_boxes && !c->use_grid) ? ((mode && !strcmp(mode, "lane")) ? 2 : 1) : 0;
-    if (mode && !strcmp(mode, "brute")) p->pruned = 0;   // cold brute-force slices (A/B and in-situ parity checks)
-    if (p->pruned == 1 && mode && !strcmp(mode, "quad")) p->pruned = 3;   // 16 queries x 4 box slots per wave (quad.hip)
-    p->S1 = p->pruned >= 2 ? 1 : (p->pruned ? reart_prune_pick_split() : reart_knn_pick_split(waves1, c->N, 1));
+    // 1: exact box-pruned, warm-started search (prune.hip, default); 0: cold brute-force slices (search_mode 1, the
+    // grid variant, or clouds that are not spatially sorted) -- same results, A/B and in-situ parity checks
+    p->pruned = (c->use_boxes && !c->use_grid && c->search_mode != 1) ? 1 : 0;
+    // pruned: ONE record per query (S = 1 in the consumers); the box slices are the waves of a search workgroup
+    p->W1 = (c->tune_slices >= 1 && c->tune_slices <= 4) ? c->tune_slices : 3;
+    p->W3 = (c->tune_slices_flow >= 1 && c->tune_slices_flow <= 4) ? c->tune_slices_flow : p->W1;
+    p->sparse = c->tune_sparse < 0 ? 0 : (c->tune_sparse == 0 ? 40 : (c->tune_sparse > 64 ? 64 : c->tune_sparse));
+    p->S1 = p->pruned ? 1 : reart_knn_pick_split(waves1, c->N, 1);
     p->L1 = (int)reart_align_up((size_t)reart_div_up(c->N, p->S1), NN_BOX);
     p->Npad = p->L1 * p->S1;
     p->S3 = 1; p->Mpad = 0;
     if (c->use_flow) {
         const long waves3 = (long)c->B * reart_div_up(c->N, NN_BS);
-        p->S3 = p->pruned >= 2 ? 1 : (p->pruned ? reart_prune_pick_split3() : reart_knn_pick_split(waves3, c->M_max, 3));
+        p->S3 = p->pruned ? 1 : reart_knn_pick_split(waves3, c->M_max, 3);
         p->Mpad = (int)reart_align_up((size_t)reart_div_up(c->M_max, p->S3), NN_BOX) * p->S3;
     }
     p->nchunk = reart_div_up(c->N, 64);
@@ -96,11 +100,14 @@ static int step_plan(const reart_relax_config *c, StepPlan *p) {
     p->o_boxY = take(off, sizeof(float) * 8 * (size_t)c->B * (p->Npad / NN_BOX));
     p->o_boxX = take(off, sizeof(float) * 8 * (size_t)c->B * (p->Npad / NN_BOX));
     p->o_boxR = take(off, sizeof(float) * 8 * (size_t)c->B * (p->Mpad / NN_BOX + 1));
-    p->o_seed0 = take(off, p->pruned ? sizeof(int) * BN : 0);
-    p->o_seed1 = take(off, p->pruned ? sizeof(int) * BN : 0);
     p->o_seed3 = take(off, (p->pruned && c->use_flow) ? sizeof(int) * BN * 3 : 0);
-    p->o_border = take(off, sizeof(int) * 3 * (size_t)c->B * reart_div_up(c->N, NN_BS));
-    p->o_cost = take(off, sizeof(unsigned int) * 3 * (size_t)c->B * reart_div_up(c->N, NN_BS) * 16);
+    const size_t G = (size_t)c->B * reart_div_up(c->N, NN_BS);
+    p->o_border = take(off, sizeof(int) * 3 * G);
+    p->o_cost = take(off, sizeof(unsigned int) * 3 * G);
+    const size_t nprof = (c->profile && p->pruned) ? (size_t)reart_search_grid(2, 1, (int)G) : 0;
+    p->o_prof = take(off, sizeof(unsigned long long) * 2 * nprof);
+    p->o_prof_pairs = take(off, sizeof(unsigned int) * nprof);
+    p->o_prof_acc = take(off, sizeof(unsigned long long) * 4);
     p->gstrideY = (int)reart_align_up((size_t)c->N, 64);
     p->gstrideR = (int)reart_align_up((size_t)(c->M_max > 0 ? c->M_max : 1), 64);
     p->o_gridY = take(off, c->use_grid ? reart_grid_bytes(c->B, p->gstrideY) : 0);
@@ -144,27 +151,12 @@ __global__ void relax_init_kernel(reart_relax_config c, const int *__restrict__ 
         fx_bits[0] = bits > 39 ? 39 : (bits < 0 ? 0 : bits);
     }
     if (t < c.B) {
-        // Launch order of the search items: frames far from the canonical frame move most, have the largest
-        // neighbour distances and therefore the most candidate boxes -- they go first, so that the launch does not
-        // end on its heaviest items.  Rank by distance (descending), ties by index.
+        // Launch order of the search items: position k = pair k (frame-major), so that every XCD's eighth of the
+        // positions is a run of consecutive frames; the consumer launch re-sorts every eighth by measured work.
         {
-            const int fc = t < c.cano_idx ? t : t + 1;                 // complete-sequence index of pc_list[t]
-            const int dt = fc > c.cano_idx ? fc - c.cano_idx : c.cano_idx - fc;
-            const int d3 = t >= c.cano_idx ? t - c.cano_idx : c.cano_idx - 1 - t;   // pair t = frames t, t+1
-            int r1 = 0, r3 = 0;
-            for (int o = 0; o < c.B; ++o) {
-                const int fo = o < c.cano_idx ? o : o + 1;
-                const int dox = fo > c.cano_idx ? fo - c.cano_idx : c.cano_idx - fo;
-                const int do3 = o >= c.cano_idx ? o - c.cano_idx : c.cano_idx - 1 - o;
-                r1 += (dox > dt || (dox == dt && o < t)) ? 1 : 0;
-                r3 += (do3 > d3 || (do3 == d3 && o < t)) ? 1 : 0;
-            }
             const int nqg = (c.N + NN_BS - 1) / NN_BS, ng = c.B * nqg;
-            for (int g = 0; g < nqg; ++g) {
-                border[r1 * nqg + g] = t * nqg + g;
-                border[ng + r1 * nqg + g] = t * nqg + g;
-                border[2 * ng + r3 * nqg + g] = t * nqg + g;
-            }
+            for (int g = 0; g < nqg; ++g)
+                for (int j = 0; j < 3; ++j) border[j * ng + t * nqg + g] = t * nqg + g;
         }
         // flow pair f (complete frames f -> f+1) queries complete frame f (run_robot.py:196):
         // complete frame f is pc_trans[f] before the canonical index, the canonical cloud at it,
@@ -221,9 +213,10 @@ extern "C" int reart_relax_prepare(const reart_relax_config *cfg, const reart_re
                        (int *)(ws + p.o_fx), (double *)(ws + p.o_bc),
                        (p.pruned && cfg->use_flow) ? (int *)(ws + p.o_seed3) : nullptr, (int *)(ws + p.o_border));
     if (hipMemsetAsync(ws + p.o_ticket, 0, 4 * sizeof(unsigned int), st) != hipSuccess) return REART_ERR_LAUNCH;
-    if (p.pruned) {  // warm start of the first Chamfer search: index 0 (any valid index)
-        if (hipMemsetAsync(ws + p.o_seed0, 0, sizeof(int) * (size_t)cfg->B * cfg->N, st) != hipSuccess) return REART_ERR_LAUNCH;
-        if (hipMemsetAsync(ws + p.o_seed1, 0, sizeof(int) * (size_t)cfg->B * cfg->N, st) != hipSuccess) return REART_ERR_LAUNCH;
+    if (hipMemsetAsync(ws + p.o_prof_acc, 0, 4 * sizeof(unsigned long long), st) != hipSuccess) return REART_ERR_LAUNCH;
+    if (p.pruned) {  // warm start of the first Chamfer search: index 0 (any valid index); the K = 1 records are the seeds
+        if (hipMemsetAsync(ws + p.o_pi0, 0, sizeof(int) * (size_t)cfg->B * cfg->N, st) != hipSuccess) return REART_ERR_LAUNCH;
+        if (hipMemsetAsync(ws + p.o_pi1, 0, sizeof(int) * (size_t)cfg->B * cfg->N, st) != hipSuccess) return REART_ERR_LAUNCH;
     }
     rc = reart_boxes_launch((const float *)(ws + p.o_ysoa), cfg->B, p.Npad, (float *)(ws + p.o_boxY), st);
     if (rc != REART_OK) return rc;
@@ -282,19 +275,6 @@ __device__ __forceinline__ float huber1s_grad(float x) {
     return fabsf(x) <= 1.0f ? x : (x > 0.f ? 1.0f : -1.0f);
 }
 
-// branch-free insertion of key (d, j) into an ascending top-3 list ordered by (distance, index)
-__device__ __forceinline__ void top3_insert(float (&kd)[3], int (&ki)[3], float d, int j) {
-    const bool l0 = (d < kd[0]) | ((d == kd[0]) & (j < ki[0]));
-    const bool l1 = (d < kd[1]) | ((d == kd[1]) & (j < ki[1]));
-    const bool l2 = (d < kd[2]) | ((d == kd[2]) & (j < ki[2]));
-    kd[2] = l1 ? kd[1] : (l2 ? d : kd[2]);
-    ki[2] = l1 ? ki[1] : (l2 ? j : ki[2]);
-    kd[1] = l0 ? kd[0] : (l1 ? d : kd[1]);
-    ki[1] = l0 ? ki[0] : (l1 ? j : ki[1]);
-    kd[0] = l0 ? d : kd[0];
-    ki[0] = l0 ? j : ki[0];
-}
-
 template <bool ONE, int FBS>   // ONE: S <= 4 -- every partial of a query is loaded before the first compare
 __device__ __forceinline__ void flow_blend_body(const FlowArgs &a, const int bx, const int f, const int nbx) {
     __shared__ double s_red[FBS / REART_WAVE];
@@ -325,7 +305,7 @@ __device__ __forceinline__ void flow_blend_body(const FlowArgs &a, const int bx,
             for (int u = 0; u < 4; ++u)
 #pragma unroll
                 for (int k = 0; k < 3; ++k)   // (INF, x) never enters: INF < INF is false and ids of real entries are smaller
-                    top3_insert(kd, ki, e[u][k], e[u][k] < INFINITY ? q[u][k] : 0x7fffffff);
+                    reart_top3_insert(kd, ki, e[u][k], e[u][k] < INFINITY ? q[u][k] : 0x7fffffff);
         }
         if (a.blocks) {
             // kd/ki are the 3 best blocks over all slices (by minimum, then index); the 3 nearest
@@ -358,7 +338,7 @@ __device__ __forceinline__ void flow_blend_body(const FlowArgs &a, const int bx,
                     const float pz = c == 0 ? vz.x : (c == 1 ? vz.y : (c == 2 ? vz.z : vz.w));
                     float d = reart_sqdist3(qx, qy, qz, px, py, pz);
                     if (bb[cb] < 0) d = INFINITY;
-                    top3_insert(kd, ki, d, d < INFINITY ? bb[cb] + u : 0x7fffffff);
+                    reart_top3_insert(kd, ki, d, d < INFINITY ? bb[cb] + u : 0x7fffffff);
                 }
             }
         }
@@ -570,18 +550,22 @@ __global__ __launch_bounds__(FLOW_BS) void flow_blend_kernel(FlowArgs a) {
 // workgroup of the consumer launch sums them per frame (integer sums: deterministic) and ranks the frames,
 // heaviest first.
 struct OrderArgs {
-    const unsigned int *cost[3];   // per job: x -> y, y -> x, flow; [groups * S] work counts in the CURRENT launch order
+    const unsigned int *cost[3];   // per job: x -> y, y -> x, flow; [groups] work counts by launch position (CURRENT order)
     int *border[3];                // per job: launch position -> (frame, query group) pair (read, then rewritten)
-    int S[3];                      // items (slices) per pair
     int groups;                    // B * nqg pairs per job
+    int per;                       // positions per XCD chunk = ceil(groups / 8): chunk x = positions [x*per, (x+1)*per);
+                                   // per >= groups: one chunk (interleaved launch order: a global sort)
+    // cfg.profile: reduction of the search launch's per-workgroup stamps
+    const unsigned long long *prof; const unsigned int *prof_pairs; unsigned long long *prof_acc; int nprof;
 };
 #define ORD_MAX 4                  // pairs per thread: groups <= ORD_MAX * CG_BS, otherwise the order is left alone
-// one workgroup per job: counting sort of the pairs by their work of the iteration that just ran, heaviest first
+// One workgroup per job: inside every XCD chunk, counting sort of the pairs by their work of the iteration that just
+// ran, heaviest first.  A pair never leaves its chunk (= its XCD: the frames an L2 holds stay the same).
 __device__ __forceinline__ void order_body(const OrderArgs &o, const int j) {
-    __shared__ unsigned int s_hist[256];
+    __shared__ unsigned int s_hist[8 * 256];
     const int tid = threadIdx.x;
     if (!o.cost[j] || o.groups > ORD_MAX * CG_BS) return;
-    for (int e = tid; e < 256; e += CG_BS) s_hist[e] = 0u;
+    for (int e = tid; e < 8 * 256; e += CG_BS) s_hist[e] = 0u;
     __syncthreads();
     int old[ORD_MAX], bucket[ORD_MAX];
 #pragma unroll
@@ -589,31 +573,54 @@ __device__ __forceinline__ void order_body(const OrderArgs &o, const int j) {
         const int k = tid + u * CG_BS;
         old[u] = 0; bucket[u] = -1;
         if (k < o.groups) {
-            unsigned int c = 0u;
-            for (int s = 0; s < o.S[j]; ++s) c += o.cost[j][(size_t)k * o.S[j] + s];
+            const unsigned int c = o.cost[j][k] >> 5;
             old[u] = o.border[j][k];
-            c >>= 3;
-            bucket[u] = 255 - (int)(c < 255u ? c : 255u);        // heaviest pairs in the first buckets
+            bucket[u] = (k / o.per) * 256 + 255 - (int)(c < 255u ? c : 255u);   // heaviest pairs in the chunk's first buckets
             atomicAdd(&s_hist[bucket[u]], 1u);
         }
     }
     __syncthreads();
-    if (tid == 0) {   // exclusive prefix of 256 counters
-        unsigned int run = 0u;
-        for (int e = 0; e < 256; ++e) { const unsigned int c = s_hist[e]; s_hist[e] = run; run += c; }
+    if (tid < 8) {   // exclusive prefix of the chunk's 256 counters, starting at the chunk's first position
+        unsigned int run = (unsigned int)(tid * o.per);
+        for (int e = tid * 256; e < tid * 256 + 256; ++e) { const unsigned int c = s_hist[e]; s_hist[e] = run; run += c; }
     }
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < ORD_MAX; ++u)
         if (bucket[u] >= 0) o.border[j][atomicAdd(&s_hist[bucket[u]], 1u)] = old[u];
 }
-struct PostArgs { FlowArgs fl; CGradArgs cg; OrderArgs od; int nfx, nflow, ncx, nwork; };
+// cfg.profile: duration of the search launch that just ran = last workgroup end - first workgroup start (constant-rate
+// wall clock), and the distance evaluations it executed; accumulated on the device, read by reart_relax_profile
+__device__ __forceinline__ void prof_body(const OrderArgs &o) {
+    __shared__ unsigned long long s_lo[CG_BS / 64], s_hi[CG_BS / 64], s_sum[CG_BS / 64];
+    const int tid = threadIdx.x;
+    unsigned long long lo = ~0ull, hi = 0ull, sum = 0ull;
+    for (int k = tid; k < o.nprof; k += CG_BS) {
+        const unsigned long long a = o.prof[2 * (size_t)k], b = o.prof[2 * (size_t)k + 1];
+        lo = a < lo ? a : lo; hi = b > hi ? b : hi; sum += o.prof_pairs[k];
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const unsigned long long l2 = __shfl_xor(lo, off, 64), h2 = __shfl_xor(hi, off, 64), s2 = __shfl_xor(sum, off, 64);
+        lo = l2 < lo ? l2 : lo; hi = h2 > hi ? h2 : hi; sum += s2;
+    }
+    if ((tid & 63) == 0) { s_lo[tid >> 6] = lo; s_hi[tid >> 6] = hi; s_sum[tid >> 6] = sum; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < CG_BS / 64; ++w) {
+            lo = s_lo[w] < lo ? s_lo[w] : lo; hi = s_hi[w] > hi ? s_hi[w] : hi; sum += s_sum[w];
+        }
+        o.prof_acc[0] += 1ull; o.prof_acc[1] += hi - lo; o.prof_acc[2] += sum;
+    }
+}
+struct PostArgs { FlowArgs fl; CGradArgs cg; OrderArgs od; int nfx, nflow, ncx, nwork, norder; };
 template <bool ONE>
 __global__ __launch_bounds__(CG_BS) void post_kernel(PostArgs a) {
     const int w = blockIdx.x;
     if (w < a.nflow) flow_blend_body<ONE, CG_BS>(a.fl, w % a.nfx, w / a.nfx, a.nfx);
     else if (w < a.nwork) chamfer_grad_body<ONE>(a.cg, (w - a.nflow) % a.ncx, (w - a.nflow) / a.ncx, a.ncx);
-    else order_body(a.od, w - a.nwork);
+    else if (w < a.nwork + a.norder) order_body(a.od, w - a.nwork);
+    else prof_body(a.od);
 }
 
 // ------------------------------------------------------------------------------ assignment loss
@@ -661,11 +668,9 @@ __global__ __launch_bounds__(CG_BS) void assign_grad_kernel(AssignArgs a) {
 // ------------------------------------------------------------------------------ the step
 #define MARK(k) do { if (ev) (void)hipEventRecord(ev[k], st); } while (0)
 
-// search_reps > 0: measurement of the search launch alone -- forward once, then the search launch
-// `search_reps` times between ev[0] and ev[1] (its inputs do not change between repetitions), nothing else.
 static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buffers *bufs,
                            void *workspace, size_t workspace_bytes, void *stream, hipEvent_t *ev,
-                           int search_reps = 0, bool forward_only = false) {
+                           bool forward_only = false) {
     StepPlan p;
     if (!cfg || !bufs) return REART_ERR_INVALID_ARG;
     int rc = step_plan(cfg, &p);
@@ -690,66 +695,100 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
     fa.hard_idx = (int *)(ws + p.o_hard);
     fa.rt_table = (float *)(ws + p.o_rt);
     fa.boxes = c.use_boxes ? (float *)(ws + p.o_boxX) : nullptr;
-    if (!search_reps) MARK(0);
+    fa.pts = c.tune_fwd_pts;
+    MARK(0);
     rc = reart_base_forward_ex(fa, st);
     if (rc != REART_OK) return rc;
-    if (!search_reps) MARK(1);
+    MARK(1);
     if (forward_only) return REART_OK;
     if (c.use_assign && !bufs->assign_map) return REART_ERR_INVALID_ARG;
 
-    // Fork: the flow branch depends only on the forward output, like the Chamfer search; with an
-    // auxiliary stream it runs concurrently (its latency-bound blend then hides under the search).
-    // merged: both searches in one launch and both of their consumers in one launch (single stream, no
-    // fork / join).  Otherwise (brute force / grid / per-lane variants): separate launches, the flow
-    // branch on the auxiliary stream when the caller provides one.  The timed variant is always separate.
-    const char *mg = getenv("REART_MERGE");
-    const bool merged = c.use_flow && (p.pruned == 1 || p.pruned == 3) && !c.use_grid && !(mg && mg[0] == '0') &&
-                        !c.use_assign;   // assignment loss: flow search and blend as separate launches, no Chamfer search
-    const bool forked = !merged && !ev && bufs->aux_stream && bufs->ev_fork && bufs->ev_join && c.use_flow;
+    const int nqg = reart_div_up(N, NN_BS);
+    const int *qmap = (const int *)(ws + p.o_qmap);
+    // job descriptions: K = 1 x -> y (0), y -> x (1); K = 3 flow
+    KnnArgs ka = {};
+    ka.N = B; ka.S = p.S1; ka.K = 1; ka.euclidean = 0;
+    for (int j = 0; j < 2; ++j) {
+        KnnJob &kj = ka.job[j];
+        kj.q = j == 0 ? bufs->pc_trans : bufs->pc_list;
+        kj.tsoa = (const float *)(ws + (j == 0 ? p.o_ysoa : p.o_xsoa));
+        kj.P1 = N; kj.P2 = N; kj.Ppad = p.Npad; kj.L = p.L1; kj.nqg = nqg;
+        kj.pd = (float *)(ws + (j == 0 ? p.o_pd0 : p.o_pd1));
+        kj.pi = (int *)(ws + (j == 0 ? p.o_pi0 : p.o_pi1));
+        kj.boxes = c.use_boxes ? (const float *)(ws + (j == 0 ? p.o_boxY : p.o_boxX)) : nullptr;
+        kj.seed = p.pruned ? kj.pi : nullptr;            // last iteration's record is this iteration's seed (in place)
+        kj.border = (const int *)(ws + p.o_border) + (size_t)j * B * nqg;
+        kj.cost = p.pruned ? (unsigned int *)(ws + p.o_cost) + (size_t)j * B * nqg : nullptr;
+    }
+    ka.items0 = B * nqg * p.S1; ka.items = 2 * ka.items0;
+    KnnArgs k3 = {};
+    if (c.use_flow) {
+        k3.N = B; k3.S = p.S3; k3.K = 3; k3.euclidean = 0;
+        KnnJob &kj = k3.job[0];
+        kj.q = bufs->pc_trans; kj.q_alt = bufs->cano; kj.qmap = qmap;
+        kj.tsoa = (const float *)(ws + p.o_rsoa); kj.tlen = (const int *)(ws + p.o_rlen);
+        kj.boxes = c.use_boxes ? (const float *)(ws + p.o_boxR) : nullptr;
+        kj.P1 = N; kj.P2 = c.M_max; kj.Ppad = p.Mpad; kj.L = p.Mpad / p.S3; kj.nqg = nqg;
+        kj.pd = (float *)(ws + p.o_pd3); kj.pi = (int *)(ws + p.o_pi3);
+        kj.seed = p.pruned ? (const int *)(ws + p.o_seed3) : nullptr;
+        kj.border = (const int *)(ws + p.o_border) + 2 * (size_t)B * nqg;
+        kj.cost = p.pruned ? (unsigned int *)(ws + p.o_cost) + 2 * (size_t)B * nqg : nullptr;
+        k3.job[1] = kj;
+        k3.items0 = B * nqg * p.S3; k3.items = k3.items0;
+    }
+    // consumers' argument blocks
+    int S3 = p.S3, S0 = p.S1, nfp = 0;
+    FlowArgs fl = {};
+    const bool chamfer = !c.use_assign;
+    // merged: Chamfer + flow on the pruned path -- ONE search launch, ONE consumer launch
+    const bool merged = p.pruned && c.use_flow && chamfer;
+    // Brute-force / grid variants keep their separate launches; with an auxiliary stream from the caller their
+    // flow branch runs beside the Chamfer search (fork / join).  The timed variant is always serial.
+    const bool forked = !p.pruned && !ev && bufs->aux_stream && bufs->ev_fork && bufs->ev_join && c.use_flow;
     hipStream_t fst = forked ? (hipStream_t)bufs->aux_stream : st;
     if (forked) {
         if (hipEventRecord((hipEvent_t)bufs->ev_fork, st) != hipSuccess) return REART_ERR_LAUNCH;
         if (hipStreamWaitEvent(fst, (hipEvent_t)bufs->ev_fork, 0) != hipSuccess) return REART_ERR_LAUNCH;
     }
-    // 3-4. flow: k=3 search of every complete frame in its reference set + blend + loss grad
-    int nfp = 0;
-    KnnArgs k3 = {};
-    FlowArgs fl = {};
-    if (c.use_flow) {
-        const int *qmap = (const int *)(ws + p.o_qmap);
-        int S3 = p.S3;
-        if (c.use_grid) {
-            GridBuildArgs gr = {};
-            reart_grid_layout(ws + p.o_gridR, B, p.gstrideR, &gr);
-            GridQueryArgs gq = {};
-            gq.q = bufs->pc_trans; gq.q_alt = bufs->cano; gq.qmap = qmap; gq.nq = N; gq.E = B; gq.stride = p.gstrideR;
-            gq.gx = gr.gx; gq.gy = gr.gy; gq.gz = gr.gz; gq.gorig = gr.gorig; gq.cell_start = gr.cell_start;
-            gq.meta = gr.meta; gq.od = (float *)(ws + p.o_pd3); gq.oi = (int *)(ws + p.o_pi3);
-            rc = reart_grid_query_launch(gq, 3, fst);
-            if (rc != REART_OK) return rc;
-            S3 = 1;
-        } else {
-            k3.N = B; k3.S = p.S3; k3.K = 3; k3.euclidean = 0;
-            KnnJob &kj = k3.job[0];
-            kj.q = bufs->pc_trans; kj.q_alt = bufs->cano; kj.qmap = qmap;
-            kj.tsoa = (const float *)(ws + p.o_rsoa); kj.tlen = (const int *)(ws + p.o_rlen);
-            kj.boxes = c.use_boxes ? (const float *)(ws + p.o_boxR) : nullptr;
-            kj.P1 = N; kj.P2 = c.M_max; kj.Ppad = p.Mpad; kj.L = p.Mpad / p.S3; kj.nqg = reart_div_up(N, NN_BS);
-            kj.pd = (float *)(ws + p.o_pd3); kj.pi = (int *)(ws + p.o_pi3);
-            k3.job[1] = kj;
-            k3.items0 = p.pruned == 3 ? B * reart_div_up(N, 16) : B * kj.nqg * p.S3;
-            k3.items = k3.items0;
-            kj.seed = p.pruned ? (const int *)(ws + p.o_seed3) : nullptr;
-            kj.border = (const int *)(ws + p.o_border) + 2 * (size_t)B * kj.nqg;
-            kj.cost = p.pruned == 1 ? (unsigned int *)(ws + p.o_cost) + 2 * (size_t)B * kj.nqg * 16 : nullptr;
-            k3.job[1] = kj;
-            if (!merged) {
-                rc = p.pruned == 3 ? reart_knn_launch_quad(k3, 3, fst) : p.pruned == 2 ? reart_knn_launch_lane(k3, 3, fst)
-                                   : (p.pruned ? reart_knn_launch_pruned(k3, 3, fst) : reart_knn_launch_slices(k3, 3, fst));
-                if (rc != REART_OK) return rc;
-            }
+
+    // 2. the searches
+    int search_wgs = 0;
+    bool search_static_order = false;
+    if (p.pruned) {
+        SearchArgs sa = {};
+        sa.G = B * nqg; sa.S1 = p.W1; sa.S3 = p.W3; sa.sparse = p.sparse; sa.interleave = c.tune_xcd > 0 ? 0 : 1;
+        sa.cloud_resident = c.tune_cloud >= 0 ? 1 : 0;
+        if (chamfer) { sa.k1[0] = ka.job[0]; sa.k1[1] = ka.job[1]; sa.n1 = 2; }
+        if (c.use_flow) { sa.k3 = k3.job[0]; sa.n3 = 1; }
+        if (c.profile && merged) {
+            sa.prof = (unsigned long long *)(ws + p.o_prof); sa.prof_pairs = (unsigned int *)(ws + p.o_prof_pairs);
         }
-        if (!search_reps) MARK(2);
+        if (sa.n1 + sa.n3 > 0) {
+            search_wgs = reart_search_workgroups(sa);
+            search_static_order = search_wgs != reart_search_grid(sa.n1, sa.n3, sa.G);   // cloud-resident form: fixed order
+            rc = reart_search_launch(sa, st);
+            if (rc != REART_OK) return rc;
+        }
+    } else {
+        if (c.use_flow) {
+            if (c.use_grid) {
+                GridBuildArgs gr = {};
+                reart_grid_layout(ws + p.o_gridR, B, p.gstrideR, &gr);
+                GridQueryArgs gq = {};
+                gq.q = bufs->pc_trans; gq.q_alt = bufs->cano; gq.qmap = qmap; gq.nq = N; gq.E = B; gq.stride = p.gstrideR;
+                gq.gx = gr.gx; gq.gy = gr.gy; gq.gz = gr.gz; gq.gorig = gr.gorig; gq.cell_start = gr.cell_start;
+                gq.meta = gr.meta; gq.od = (float *)(ws + p.o_pd3); gq.oi = (int *)(ws + p.o_pi3);
+                rc = reart_grid_query_launch(gq, 3, fst);
+                S3 = 1;
+            } else {
+                rc = reart_knn_launch_slices(k3, 3, fst);
+            }
+            if (rc != REART_OK) return rc;
+        }
+    }
+    MARK(2);
+    // 3. flow consumer (separate launch unless merged): top-3 merge / rescan, blend, flow-loss term + gradient
+    if (c.use_flow) {
         fl.pd = (const float *)(ws + p.o_pd3); fl.pi = (const int *)(ws + p.o_pi3); fl.ref_flow = bufs->ref_flow;
         fl.ref_off = bufs->ref_off; fl.qmap = qmap; fl.X = bufs->pc_trans; fl.cano = bufs->cano; fl.N = N; fl.B = B;
         fl.blocks = c.use_grid ? 0 : 1; fl.rsoa = (const float *)(ws + p.o_rsoa); fl.Mpad = p.Mpad;
@@ -762,16 +801,14 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
         if (!merged) {
             if (fl.S <= 4) hipLaunchKernelGGL(flow_blend_kernel<true>, fg, dim3(FLOW_BS), 0, fst, fl);
             else hipLaunchKernelGGL(flow_blend_kernel<false>, fg, dim3(FLOW_BS), 0, fst, fl);
+            REART_CHECK_LAUNCH();
         }
     }
-
     if (forked && hipEventRecord((hipEvent_t)bufs->ev_join, fst) != hipSuccess) return REART_ERR_LAUNCH;
-    if (!c.use_flow && !search_reps) MARK(2);
-    if (!search_reps) MARK(3);
+    MARK(3);
 
     if (c.use_assign) {
         // assignment loss instead of the Chamfer loss: no search, the pairs come from the caller's assign_map
-        if (search_reps) return REART_ERR_UNSUPPORTED;
         MARK(4);
         AssignArgs aa = {};
         aa.X = bufs->pc_trans; aa.Y = bufs->pc_list; aa.map = bufs->assign_map; aa.N = N; aa.B = B;
@@ -779,98 +816,60 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
         hipLaunchKernelGGL(assign_grad_kernel, dim3(reart_div_up(N, CG_BS), B), dim3(CG_BS), 0, st, aa);
         REART_CHECK_LAUNCH();
     } else {
-    // 2. Chamfer (utils/chamfer.py:78-94).  pc_list never changes: with use_grid the direction
-    // pc_trans -> pc_list goes through its pre-built exact grid, and only pc_list -> pc_trans (moving
-    // targets) is searched by brute force; without it both directions share one brute-force launch.
-    KnnArgs ka = {};
-    ka.N = B; ka.S = p.S1; ka.K = 1; ka.euclidean = 0;
-    for (int j = 0; j < 2; ++j) {
-        KnnJob &kj = ka.job[j];
-        kj.q = j == 0 ? bufs->pc_trans : bufs->pc_list;
-        kj.tsoa = (const float *)(ws + (j == 0 ? p.o_ysoa : p.o_xsoa));
-        kj.P1 = N; kj.P2 = N; kj.Ppad = p.Npad; kj.L = p.L1; kj.nqg = reart_div_up(N, NN_BS);
-        kj.pd = (float *)(ws + (j == 0 ? p.o_pd0 : p.o_pd1));
-        kj.pi = (int *)(ws + (j == 0 ? p.o_pi0 : p.o_pi1));
-        kj.boxes = c.use_boxes ? (const float *)(ws + (j == 0 ? p.o_boxY : p.o_boxX)) : nullptr;
-        kj.seed = p.pruned ? (const int *)(ws + (j == 0 ? p.o_seed0 : p.o_seed1)) : nullptr;
-        kj.border = (const int *)(ws + p.o_border) + (size_t)j * B * kj.nqg;
-        kj.cost = p.pruned == 1 ? (unsigned int *)(ws + p.o_cost) + (size_t)j * B * kj.nqg * 16 : nullptr;
-    }
-    int S0 = p.S1;
-    if (c.use_grid) {
-        GridBuildArgs gy = {};
-        reart_grid_layout(ws + p.o_gridY, B, p.gstrideY, &gy);
-        GridQueryArgs gq = {};
-        gq.q = bufs->pc_trans; gq.nq = N; gq.E = B; gq.stride = p.gstrideY; gq.gx = gy.gx; gq.gy = gy.gy; gq.gz = gy.gz;
-        gq.gorig = gy.gorig; gq.cell_start = gy.cell_start; gq.meta = gy.meta;
-        gq.od = (float *)(ws + p.o_pd0); gq.oi = (int *)(ws + p.o_pi0);
-        rc = reart_grid_query_launch(gq, 1, st);
-        if (rc != REART_OK) return rc;
-        S0 = 1;
-        ka.job[0] = ka.job[1];
-        ka.items0 = B * ka.job[0].nqg * p.S1;
-        ka.items = ka.items0;
-    } else {
-        ka.items0 = p.pruned == 3 ? B * reart_div_up(N, 16) : B * ka.job[0].nqg * p.S1;
-        ka.items = 2 * ka.items0;
-    }
-    if (search_reps) {
-        if (!merged) return REART_ERR_UNSUPPORTED;
-        // two untimed launches first: the host gets ahead of the device (each launch takes the host a few
-        // microseconds, the kernel tens), so the timed launches run back to back.  (A one-wave spin kernel
-        // as a host-side head start was tried and rejected: the chip drops its clock while it spins.)
-        for (int r = 0; r < 2; ++r) {
-            rc = p.pruned == 3 ? reart_knn_launch_quad_pair(ka, k3, st)
-                               : reart_knn_launch_pruned_pair(ka, k3, (unsigned int *)(ws + p.o_ticket) + 2, st);
+        // Chamfer (utils/chamfer.py:78-94) on the brute-force paths.  pc_list never changes: with use_grid the
+        // direction pc_trans -> pc_list goes through its pre-built exact grid, and only pc_list -> pc_trans (moving
+        // targets) is searched by brute force; without it both directions share one brute-force launch.
+        if (!p.pruned) {
+            if (c.use_grid) {
+                GridBuildArgs gy = {};
+                reart_grid_layout(ws + p.o_gridY, B, p.gstrideY, &gy);
+                GridQueryArgs gq = {};
+                gq.q = bufs->pc_trans; gq.nq = N; gq.E = B; gq.stride = p.gstrideY; gq.gx = gy.gx; gq.gy = gy.gy; gq.gz = gy.gz;
+                gq.gorig = gy.gorig; gq.cell_start = gy.cell_start; gq.meta = gy.meta;
+                gq.od = (float *)(ws + p.o_pd0); gq.oi = (int *)(ws + p.o_pi0);
+                rc = reart_grid_query_launch(gq, 1, st);
+                if (rc != REART_OK) return rc;
+                S0 = 1;
+                ka.job[0] = ka.job[1];
+                ka.items = ka.items0;
+            }
+            rc = reart_knn_launch_slices(ka, 1, st);
             if (rc != REART_OK) return rc;
         }
-        (void)hipEventRecord(ev[0], st);
-        for (int r = 0; r < search_reps; ++r) {
-            rc = p.pruned == 3 ? reart_knn_launch_quad_pair(ka, k3, st)
-                               : reart_knn_launch_pruned_pair(ka, k3, (unsigned int *)(ws + p.o_ticket) + 2, st);
-            if (rc != REART_OK) return rc;
-        }
-        (void)hipEventRecord(ev[1], st);
-        return REART_OK;
-    }
-    if (merged) rc = p.pruned == 3 ? reart_knn_launch_quad_pair(ka, k3, st)
-                               : reart_knn_launch_pruned_pair(ka, k3, (unsigned int *)(ws + p.o_ticket) + 2, st);
-    else rc = p.pruned == 3 ? reart_knn_launch_quad(ka, 1, st) : p.pruned == 2 ? reart_knn_launch_lane(ka, 1, st)
-                            : (p.pruned ? reart_knn_launch_pruned(ka, 1, st) : reart_knn_launch_slices(ka, 1, st));
-    if (rc != REART_OK) return rc;
-
-    MARK(4);
-
-    // 5. merge + recon loss + direct gradient term + fixed-point scatter (fully parallel)
-    CGradArgs cg = {};
-    cg.X = bufs->pc_trans; cg.Y = bufs->pc_list;
-    cg.pd0 = (const float *)(ws + p.o_pd0); cg.pi0 = (const int *)(ws + p.o_pi0);
-    cg.pd1 = (const float *)(ws + p.o_pd1); cg.pi1 = (const int *)(ws + p.o_pi1);
-    cg.fx_bits = (const int *)(ws + p.o_fx);
-    cg.N = N; cg.B = B; cg.S0 = S0; cg.S1 = p.S1; cg.G = G;
-    cg.loss_part = (double *)(ws + p.o_floss);
-    cg.seed0 = p.pruned ? (int *)(ws + p.o_seed0) : nullptr;
-    cg.seed1 = p.pruned ? (int *)(ws + p.o_seed1) : nullptr;
-    const int ncg = reart_div_up(N, CG_RANGE);
-    if (merged) {
-        PostArgs pa;
-        pa.fl = fl; pa.cg = cg; pa.nfx = reart_div_up(N, CG_BS); pa.nflow = pa.nfx * B; pa.ncx = ncg;
-        pa.nwork = pa.nflow + ncg * B;
-        const char *ro = getenv("REART_REORDER");
-        const bool reorder = p.pruned == 1 && p.S1 <= 16 && p.S3 <= 16 && !(ro && ro[0] == '0');
-        for (int j = 0; j < 3; ++j) {
-            const KnnJob &kj = j < 2 ? ka.job[j] : k3.job[0];
-            pa.od.cost[j] = reorder ? kj.cost : nullptr;
-            pa.od.border[j] = (int *)(ws + p.o_border) + (size_t)j * B * kj.nqg;
-            pa.od.S[j] = j < 2 ? p.S1 : p.S3;
-        }
-        pa.od.groups = B * ka.job[0].nqg;
-        const int nblk = pa.nwork + (reorder ? 3 : 0);
-        if (cg.S0 <= 4 && cg.S1 <= 4 && fl.S <= 4) hipLaunchKernelGGL(post_kernel<true>, dim3(nblk), dim3(CG_BS), 0, st, pa);
-        else hipLaunchKernelGGL(post_kernel<false>, dim3(nblk), dim3(CG_BS), 0, st, pa);
-    } else if (cg.S0 <= 4 && cg.S1 <= 4) hipLaunchKernelGGL(chamfer_grad_kernel<true>, dim3(ncg, B), dim3(CG_BS), 0, st, cg);
-    else hipLaunchKernelGGL(chamfer_grad_kernel<false>, dim3(ncg, B), dim3(CG_BS), 0, st, cg);
-    REART_CHECK_LAUNCH();
+        MARK(4);
+        // merge + recon loss + direct gradient term + fixed-point scatter (fully parallel)
+        CGradArgs cg = {};
+        cg.X = bufs->pc_trans; cg.Y = bufs->pc_list;
+        cg.pd0 = (const float *)(ws + p.o_pd0); cg.pi0 = (const int *)(ws + p.o_pi0);
+        cg.pd1 = (const float *)(ws + p.o_pd1); cg.pi1 = (const int *)(ws + p.o_pi1);
+        cg.fx_bits = (const int *)(ws + p.o_fx);
+        cg.N = N; cg.B = B; cg.S0 = S0; cg.S1 = p.S1; cg.G = G;
+        cg.loss_part = (double *)(ws + p.o_floss);
+        const int ncg = reart_div_up(N, CG_RANGE);
+        if (merged) {
+            PostArgs pa = {};
+            pa.fl = fl; pa.cg = cg; pa.nfx = reart_div_up(N, CG_BS); pa.nflow = pa.nfx * B; pa.ncx = ncg;
+            pa.nwork = pa.nflow + ncg * B;
+            const bool reorder = c.tune_reorder >= 0 && !search_static_order;
+            for (int j = 0; j < 3; ++j) {
+                const KnnJob &kj = j < 2 ? ka.job[j] : k3.job[0];
+                pa.od.cost[j] = reorder ? kj.cost : nullptr;
+                pa.od.border[j] = (int *)(ws + p.o_border) + (size_t)j * B * nqg;
+            }
+            pa.od.groups = B * nqg; pa.od.per = c.tune_xcd > 0 ? reart_div_up(B * nqg, 8) : B * nqg;
+            pa.norder = reorder ? 3 : 0;
+            int nblk = pa.nwork + pa.norder;
+            if (c.profile) {
+                pa.od.prof = (const unsigned long long *)(ws + p.o_prof);
+                pa.od.prof_pairs = (const unsigned int *)(ws + p.o_prof_pairs);
+                pa.od.prof_acc = (unsigned long long *)(ws + p.o_prof_acc);
+                pa.od.nprof = search_wgs;
+                nblk += 1;
+            }
+            hipLaunchKernelGGL(post_kernel<true>, dim3(nblk), dim3(CG_BS), 0, st, pa);
+        } else if (cg.S0 <= 4 && cg.S1 <= 4) hipLaunchKernelGGL(chamfer_grad_kernel<true>, dim3(ncg, B), dim3(CG_BS), 0, st, cg);
+        else hipLaunchKernelGGL(chamfer_grad_kernel<false>, dim3(ncg, B), dim3(CG_BS), 0, st, cg);
+        REART_CHECK_LAUNCH();
     }
     MARK(5);
 
@@ -884,11 +883,13 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
     ba.hard_idx = fa.hard_idx; ba.tau_ptr = bufs->tau; ba.tau = 1.0f; ba.G = G; ba.rt_table = fa.rt_table;
     ba.cano_idx = c.cano_idx;
     ba.gpf = c.use_flow ? (const float *)(ws + p.o_gpf) : nullptr;
+    ba.cpts = c.tune_bwd_pts;
     ba.N = N; ba.P = P; ba.B = B; ba.H = H; ba.gW1 = gW1; ba.gb1 = gb1; ba.gW2 = gW2; ba.g6d = g6d; ba.gt = gt;
     FinalizeAdam ad = {};
     ad.enabled = 1; ad.W1 = bufs->W1; ad.b1 = bufs->b1; ad.W2 = bufs->W2; ad.p6d = bufs->p6d; ad.pt = bufs->pt;
     ad.m = bufs->adam_m; ad.v = bufs->adam_v; ad.seg_lr = c.seg_lr; ad.trans_lr = c.trans_lr;
     ad.beta1 = c.beta1; ad.beta2 = c.beta2; ad.eps = c.eps; ad.step_ptr = bufs->iter;
+    ad.weight_decay = c.weight_decay;
     ad.bias_corr = (const double *)(ws + p.o_bc);
     // loss log, iter++, next tau and bias corrections: last workgroup of the finalize kernel
     const int ncgp = reart_div_up(N, CG_RANGE);
@@ -937,29 +938,33 @@ extern "C" int reart_relax_step_timed(const reart_relax_config *cfg, const reart
     return rc;
 }
 
-// Average duration of the search launch (knn_pruned_pair_kernel: Chamfer K = 1 both directions + flow
-// K = 3) at the CURRENT state of the optimisation: the forward is run once, then the search `reps` times
-// back to back between two events on `stream`.  Parameters, counters and seeds are not modified.
-// Only for the default fused configuration (merged launches); synchronises.
-extern "C" int reart_relax_search_ms(const reart_relax_config *cfg, const reart_relax_buffers *bufs,
-                                     void *workspace, size_t workspace_bytes, void *stream, int reps,
-                                     float *h_ms) {
-    if (!h_ms || reps < 1) return REART_ERR_INVALID_ARG;
-    hipEvent_t ev[2];
-    for (int k = 0; k < 2; ++k)
-        if (hipEventCreate(&ev[k]) != hipSuccess) return REART_ERR_LAUNCH;
-    int rc = relax_step_impl(cfg, bufs, workspace, workspace_bytes, stream, ev, reps);
-    if (rc == REART_OK) {
-        float ms = 0.f;
-        if (hipEventSynchronize(ev[1]) != hipSuccess || hipEventElapsedTime(&ms, ev[0], ev[1]) != hipSuccess)
-            rc = REART_ERR_LAUNCH;
-        *h_ms = ms / (float)reps;
-    }
-    for (int k = 0; k < 2; ++k) (void)hipEventDestroy(ev[k]);
-    return rc;
+// cfg.profile: the search launch of every iteration leaves per-workgroup wall-clock stamps, reduced on the device by
+// the consumer launch (prof_body).  h_out[0] launches, [1] summed duration in SECONDS (last workgroup end - first
+// workgroup start, constant-rate clock), [2] distance evaluations executed, [3] the clock rate in Hz.  Synchronises
+// the stream; reset != 0 zeroes the accumulators afterwards.
+extern "C" int reart_relax_profile(const reart_relax_config *cfg, void *workspace, size_t workspace_bytes,
+                                   void *stream, double *h_out, int reset) {
+    StepPlan p;
+    if (!cfg || !h_out) return REART_ERR_INVALID_ARG;
+    int rc = step_plan(cfg, &p);
+    if (rc != REART_OK) return rc;
+    if (!workspace || workspace_bytes < p.total) return REART_ERR_INVALID_ARG;
+    if (!cfg->profile || !p.pruned) return REART_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long acc[4] = {0, 0, 0, 0};
+    if (hipMemcpyAsync(acc, (char *)workspace + p.o_prof_acc, sizeof(acc), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+        return REART_ERR_LAUNCH;
+    int dev = 0, khz = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0)
+        return REART_ERR_LAUNCH;
+    const double hz = 1e3 * (double)khz;
+    h_out[0] = (double)acc[0]; h_out[1] = (double)acc[1] / hz; h_out[2] = (double)acc[2]; h_out[3] = hz;
+    if (reset && hipMemsetAsync((char *)workspace + p.o_prof_acc, 0, sizeof(acc), st) != hipSuccess) return REART_ERR_LAUNCH;
+    return REART_OK;
 }
 
 extern "C" int reart_relax_forward(const reart_relax_config *cfg, const reart_relax_buffers *bufs,
                                    void *workspace, size_t workspace_bytes, void *stream) {
-    return relax_step_impl(cfg, bufs, workspace, workspace_bytes, stream, nullptr, 0, true);
+    return relax_step_impl(cfg, bufs, workspace, workspace_bytes, stream, nullptr, true);
 }

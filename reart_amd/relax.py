@@ -18,7 +18,34 @@ class RelaxConfig(ctypes.Structure):
                [(n, c_float) for n in ("lambda_flow", "smooth_weight", "trans_lr", "seg_lr", "beta1", "beta2", "eps",
                                        "start_tau", "end_tau", "fixed_tau")] + [("seed", ctypes.c_uint64),
                                                                                  ("use_grid", c_int), ("use_boxes", c_int),
-                                                                                 ("use_assign", c_int), ("lambda_assign", c_float)]
+                                                                                 ("use_assign", c_int), ("lambda_assign", c_float),
+                                                                                 ("weight_decay", c_float)] + \
+               [(n, c_int) for n in ("search_mode", "tune_slices", "tune_slices_flow", "tune_sparse", "tune_fwd_pts",
+                                     "tune_bwd_pts", "tune_reorder", "tune_cloud", "tune_xcd", "profile")]
+
+
+def tuning_from_env(env=None):
+    """Experiment switches of the library, read ONCE per engine on the host (the library itself never looks at the
+    environment): REART_SEARCH=brute, REART_PRUNE_SPLIT / REART_PRUNE_SPLIT3 (waves per search workgroup, 1..4),
+    REART_SPARSE (0 = dense scans only, 1..16), REART_FWD_PTS (64|32), REART_BWD_PTS (64|32|16), REART_REORDER=0, REART_CLOUD=0 (search targets from global memory instead of an LDS copy), REART_XCD=1 (one run of frames per XCD)."""
+    env = os.environ if env is None else env
+    geti = lambda k: int(env[k]) if env.get(k, "") != "" else None
+    t = {}
+    if env.get("REART_SEARCH") == "brute":
+        t["search_mode"] = 1
+    for key, field in (("REART_PRUNE_SPLIT", "tune_slices"), ("REART_PRUNE_SPLIT3", "tune_slices_flow"),
+                       ("REART_FWD_PTS", "tune_fwd_pts"), ("REART_BWD_PTS", "tune_bwd_pts")):
+        if geti(key) is not None:
+            t[field] = geti(key)
+    if geti("REART_SPARSE") is not None:
+        t["tune_sparse"] = -1 if geti("REART_SPARSE") <= 0 else geti("REART_SPARSE")
+    if env.get("REART_REORDER") == "0":
+        t["tune_reorder"] = -1
+    if env.get("REART_CLOUD") == "0":
+        t["tune_cloud"] = -1
+    if env.get("REART_XCD") == "1":
+        t["tune_xcd"] = 1
+    return t
 
 
 class RelaxBuffers(ctypes.Structure):
@@ -85,9 +112,9 @@ def _lib_fns():
         L.reart_relax_step_timed.restype = c_int
         L.reart_relax_step_timed.argtypes = [ctypes.POINTER(RelaxConfig), ctypes.POINTER(RelaxBuffers), c_void_p,
                                              ctypes.c_size_t, c_void_p, ctypes.POINTER(c_float)]
-        L.reart_relax_search_ms.restype = c_int
-        L.reart_relax_search_ms.argtypes = [ctypes.POINTER(RelaxConfig), ctypes.POINTER(RelaxBuffers), c_void_p,
-                                            ctypes.c_size_t, c_void_p, c_int, ctypes.POINTER(c_float)]
+        L.reart_relax_profile.restype = c_int
+        L.reart_relax_profile.argtypes = [ctypes.POINTER(RelaxConfig), c_void_p, ctypes.c_size_t, c_void_p,
+                                          ctypes.POINTER(ctypes.c_double), c_int]
         _L = L
     return _L
 
@@ -104,7 +131,7 @@ class RelaxEngine:
     def __init__(self, cano_pc, pc_list, model, cano_idx, pc_ref_list=None, flow_ref_list=None, n_iter=15000,
                  start_tau=5.0, end_tau=1.0, trans_lr=1e-2, seg_lr=1e-3, lambda_flow=1.0, use_robust_loss=False,
                  smooth_weight=1e-2, fixed_tau=0.0, seed=2, ring=1024, knn_squared=False, start_iter=0, use_grid=False,
-                 overlap_flow=True, spatial_sort=True):
+                 overlap_flow=True, spatial_sort=True, weight_decay=0.0, profile=False, tuning=None):
         _lib.require_gpu(cano_pc, pc_list)
         dev = cano_pc.device
         self.device, self.model = dev, model
@@ -161,7 +188,10 @@ class RelaxEngine:
                                M_max=max(lens), M_total=sum(lens), n_iter=n_iter, ring=ring, lambda_flow=lambda_flow,
                                smooth_weight=smooth_weight, trans_lr=trans_lr, seg_lr=seg_lr, beta1=0.9, beta2=0.999,
                                eps=1e-8, start_tau=start_tau, end_tau=end_tau, fixed_tau=fixed_tau, seed=seed,
-                               use_grid=int(bool(use_grid)), use_boxes=int(bool(spatial_sort)))
+                               use_grid=int(bool(use_grid)), use_boxes=int(bool(spatial_sort)),
+                               weight_decay=float(weight_decay), profile=int(bool(profile)))
+        for k, v in (tuning_from_env() if tuning is None else tuning).items():
+            setattr(self.cfg, k, int(v))
         L = _lib_fns()
         nbytes = L.reart_relax_workspace_bytes(ctypes.byref(self.cfg))
         if nbytes == 0:
@@ -169,6 +199,7 @@ class RelaxEngine:
         self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         self._graph = None
         self._bufs = None
+        self.graph_replays = self.eager_steps = 0
         # fork/join resources for running the flow branch beside the Chamfer search (caller-owned)
         self._aux = None
         if use_flow and overlap_flow:
@@ -204,6 +235,17 @@ class RelaxEngine:
     def seg_part(self):
         """[N] arg-max part of the noise-free logits (last iteration), in the caller's point order."""
         return self._seg_part if self._perm is None else self._seg_part[self._inv]
+
+    def caller_clouds(self):
+        """(cano_pc [N,3], pc_list [T-1,N,3]) in the CALLER's point order (the engine stores every cloud in the leaf
+        order of its own k-d tree).  Anything that depends on point order -- per-part FPS, tie rules of the structure
+        tail and of the linear assignment -- must see these, not ``self.cano`` / ``self.pc_list``."""
+        if self._perm is None:
+            return self.cano, self.pc_list
+        B, N = self._perm_frames.shape
+        inv_f = torch.empty_like(self._perm_frames)
+        inv_f.scatter_(1, self._perm_frames, torch.arange(N, device=self.device).expand(B, N))
+        return self.cano[self._inv], torch.gather(self.pc_list, 1, inv_f[..., None].expand(-1, -1, 3))
 
     def set_gumbel(self, noise):
         """Inject the Gumbel noise [N,P] used by every following step (tests); None = in-kernel Philox."""
@@ -261,13 +303,16 @@ class RelaxEngine:
         return 1  # iterations consumed by the warm-up
 
     def step(self, n=1):
-        """Enqueue n iterations (asynchronous; no host sync)."""
+        """Enqueue n iterations (asynchronous; no host sync).  Counts what it did in ``graph_replays`` /
+        ``eager_steps`` (the remainder of n over the captured graph's length runs eagerly: same launches, same results)."""
         if self._graph is not None:
             for _ in range(n // self._steps_per_graph):
                 self._graph.replay()
-            n %= self._steps_per_graph   # the remainder runs eagerly (same launches, same results)
+            self.graph_replays += n // self._steps_per_graph
+            n %= self._steps_per_graph
         for _ in range(n):
             self._enqueue()
+        self.eager_steps += n
 
     PHASES = ("forward", "flow_knn3", "flow_blend", "chamfer_nn", "chamfer_grad", "backward", "adam", "bookkeep")
 
@@ -281,14 +326,15 @@ class RelaxEngine:
             _lib.check(rc, "reart_relax_step_timed")
         return {k: acc[i] / n for i, k in enumerate(self.PHASES)}
 
-    def search_ms(self, reps=20):
-        """Average milliseconds of the search launch alone (both Chamfer directions + flow K=3 in one
-        kernel) at the current state; ``reps`` back-to-back launches between two events.  Synchronises."""
-        ms = c_float(0.0)
-        rc = _lib_fns().reart_relax_search_ms(ctypes.byref(self.cfg), ctypes.byref(self._bufs), _lib.ptr(self.workspace),
-                                              self.workspace.numel(), _lib.stream(), int(reps), ctypes.byref(ms))
-        _lib.check(rc, "reart_relax_search_ms")
-        return float(ms.value)
+    def search_profile(self, reset=False):
+        """``profile=True`` engines: what the search launches did since the last reset, measured on the device in every
+        iteration (eager or graph replay) -> dict(launches, seconds, pairs, clock_hz); seconds = sum over launches of
+        (last workgroup end - first workgroup start).  Synchronises."""
+        out = (ctypes.c_double * 4)()
+        rc = _lib_fns().reart_relax_profile(ctypes.byref(self.cfg), _lib.ptr(self.workspace), self.workspace.numel(),
+                                            _lib.stream(), out, int(bool(reset)))
+        _lib.check(rc, "reart_relax_profile")
+        return {"launches": int(out[0]), "seconds": float(out[1]), "pairs": int(out[2]), "clock_hz": float(out[3])}
 
     def loss_log(self):
         """(iterations done, tensor [min(iter, ring), 4]: recon, lambda*flow, total, tau); syncs."""

@@ -63,6 +63,101 @@ def synthetic_sequence(num_points, cano_idx, frames, with_flow):
     return out
 
 
+class OperatorLoop:
+    """The reference's loop body (run_robot.py:154-221) over the HIP operators with PyTorch autograd and
+    ``torch.optim.Adam``: the path of ``--model kinematic`` (and of a base model outside the fused engine).
+    ``iteration(i)`` runs iteration i -- forward, assignment (re-solved on the GPU every ``assign_gap`` iterations) or
+    Chamfer loss, optional flow loss, backward, Adam -- and returns the loss dictionary of tensors (no host sync)."""
+
+    def __init__(self, args, model, cano_pc, pc_list, pc_ref_list=None, flow_ref_list=None, tau_func=None):
+        self.args, self.model, self.cano_pc, self.pc_list = args, model, cano_pc, pc_list
+        self.pc_ref_list, self.flow_ref_list, self.tau_func = pc_ref_list, flow_ref_list, tau_func
+        device = cano_pc.device
+        if args.model == "base":
+            seg_params = [p for p in model.seg_head.parameters() if p.requires_grad]
+            self.optimizer = torch.optim.Adam([{"params": [model.proposal_6d, model.proposal_t], "lr": args.trans_lr},
+                                               {"params": seg_params, "lr": args.seg_lr}], lr=1e-3,
+                                              weight_decay=args.weight_decay)
+        else:
+            self.optimizer = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=args.trans_lr,
+                                              weight_decay=args.weight_decay)
+        self.chamfer_dist = ChamferDistance()
+        self.knn_flow = KNN(k=3, transpose_mode=True)
+        self.matched = None
+        # the kinematic model moves the cost matrices smoothly: the previous solve's pairs and potentials start the next
+        # (shortest augmenting paths, reart_lap_resolve); the base model's resampled labels make them jump: cold solves
+        self.lap_state = {} if args.model == "kinematic" else None
+        self.lap_solves = 0
+        if args.use_assign_loss:
+            # run_robot.py:167-169: both FPS calls sample fixed clouds (start 0 on the reference's CUDA path): once
+            num_fps = pc_list.shape[1] // args.downsample
+            zero = torch.zeros(1, dtype=torch.long, device=device)
+            self.src_idx = farthest_point_sample(cano_pc[None], num_fps, start=zero, cuda_mode=True).expand(pc_list.shape[0], num_fps)
+            self.tgt_pts = index_points(pc_list, farthest_point_sample(pc_list, num_fps, start=zero.expand(pc_list.shape[0]),
+                                                                       cuda_mode=True))
+
+    def iteration(self, i):
+        from reart_amd.utils.lap import cdist, linear_sum_assignment_batch
+
+        args, model, cano_pc, pc_list = self.args, self.model, self.cano_pc, self.pc_list
+        kwargs = {"tau": self.tau_func(cur_iter=i + 1)} if args.model == "base" else {}
+        pc_trans_list, seg_part, trans_list = model(cano_pc, **kwargs)
+        losses, loss = {}, 0
+        if args.use_assign_loss and i >= args.assign_iter:
+            pc_src = index_points(pc_trans_list, self.src_idx)
+            if self.matched is None or i % args.assign_gap == 0:  # run_robot.py:165-178
+                # certified optimum on the GPU; an uncertified matrix falls back to scipy on the host, so this is
+                # always the assignment the reference's linear_sum_assignment / parallel_lap returns
+                assign = linear_sum_assignment_batch(cdist(pc_src.detach(), self.tgt_pts), state=self.lap_state,
+                                                     warm_assignment=self.lap_state is not None)
+                self.lap_solves += 1
+                cols = torch.from_numpy(np.stack([c for _, c in assign])).to(cano_pc.device)    # rows are 0..n-1 in order
+                self.matched = self.tgt_pts.gather(1, cols[..., None].expand(-1, -1, 3))
+            ass = args.lambda_assign * ((pc_src - self.matched) ** 2).sum(-1).sum()
+            losses["opt assignment loss"] = ass
+            loss = loss + ass
+        else:
+            rec = recon_loss(pc_trans_list, pc_list, self.chamfer_dist)
+            losses["recon Loss"] = rec
+            loss = loss + rec
+        if args.use_flow_loss:
+            c = args.cano_idx
+            with torch.no_grad():
+                comp = torch.cat((pc_trans_list[:c], cano_pc[None], pc_trans_list[c:]), dim=0)
+                blended = [blend_anchor_motion(q, r, f, self.knn_flow, return_mask=True)
+                           for q, r, f in zip(comp[:-1], self.pc_ref_list, self.flow_ref_list)]
+            comp = torch.cat((pc_trans_list[:c], cano_pc[None], pc_trans_list[c:]), dim=0)
+            fl = args.lambda_flow * flow_loss(torch.stack([b[0] for b in blended]), comp[1:] - comp[:-1],
+                                              flow_mask_list=torch.stack([b[1] for b in blended]),
+                                              robust=args.use_robust_loss)
+            losses["flow Loss"] = fl
+            loss = loss + fl
+        losses["total Loss"] = loss
+        self.optimizer.zero_grad()
+        loss.backward()
+        self.optimizer.step()
+        return losses
+
+
+def build_kinematic_from_base(result, cano_pc, pc_list, args):
+    """run_robot.py:101-124: KinematicModel from a base result (dict with pred_cano_part, pred_pose_list and, when the
+    base run already extracted it, joint_connection)."""
+    from reart_amd import tail
+
+    device = cano_pc.device
+    seg_part = torch.from_numpy(np.asarray(result["pred_cano_part"])).long().to(device)
+    trans_list = torch.from_numpy(np.asarray(result["pred_pose_list"])).float().to(device)
+    if "joint_connection" in result:
+        joint_connection = torch.from_numpy(np.array(result["joint_connection"])).long().to(device)
+    else:
+        seg_part, trans_list, joint_connection = tail.extract_structure(
+            seg_part, trans_list, cano_pc, merge_thr=args.merge_thr, cano_dist_thr=args.cano_dist_thr,
+            lambda_joint=args.lambda_joint, min_num=0)
+    new_seg, kin_kwargs = tail.kinematic_init(seg_part, trans_list, joint_connection)
+    return KinematicModel(pose_len=pc_list.shape[0], seg_part=new_seg, cano_pc=cano_pc,
+                          knn=KNN(k=1, transpose_mode=True), **kin_kwargs)
+
+
 def main(args):
     torch.cuda.manual_seed_all(args.manual_seed)
     torch.manual_seed(args.manual_seed)
@@ -120,23 +215,11 @@ def main(args):
     else:
         if args.resume is None:  # run_robot.py:101-124: joint tree from a base result
             assert args.base_result_path is not None, "--model kinematic needs --base_result_path or --resume"
-            from reart_amd import tail
-
             with open(args.base_result_path, "rb") as f:
                 result = pickle.load(f)
             print(f"load base result from {args.base_result_path}")
             assert args.cano_idx == result["cano_idx"]
-            seg_part = torch.from_numpy(np.asarray(result["pred_cano_part"])).long().to(device)
-            trans_list = torch.from_numpy(np.asarray(result["pred_pose_list"])).float().to(device)
-            if "joint_connection" in result:
-                joint_connection = torch.from_numpy(np.array(result["joint_connection"])).long().to(device)
-            else:
-                seg_part, trans_list, joint_connection = tail.extract_structure(
-                    seg_part, trans_list, cano_pc, merge_thr=args.merge_thr, cano_dist_thr=args.cano_dist_thr,
-                    lambda_joint=args.lambda_joint, min_num=0)
-            new_seg, kin_kwargs = tail.kinematic_init(seg_part, trans_list, joint_connection)
-            model = KinematicModel(pose_len=pc_list.shape[0], seg_part=new_seg, cano_pc=cano_pc,
-                                   knn=KNN(k=1, transpose_mode=True), **kin_kwargs)
+            model = build_kinematic_from_base(result, cano_pc, pc_list, args)
         else:
             ckpt = torch.load(args.resume[0], map_location=device, weights_only=False)
             model = KinematicModel(pose_len=pc_list.shape[0], seg_part=ckpt["seg_part"].to(device),
@@ -163,7 +246,7 @@ def main(args):
         eng = RelaxEngine(cano_pc, pc_list, model, args.cano_idx, pc_ref_list, flow_ref_list, n_iter=args.n_iter,
                           start_tau=args.start_tau, end_tau=args.end_tau, trans_lr=args.trans_lr, seg_lr=args.seg_lr,
                           lambda_flow=args.lambda_flow, use_robust_loss=args.use_robust_loss, fixed_tau=fixed_tau,
-                          seed=args.manual_seed)
+                          seed=args.manual_seed, weight_decay=args.weight_decay)
         if fused_until > 0:
             i += eng.capture()
         while i < fused_until:
@@ -187,8 +270,8 @@ def main(args):
             # Both FPS calls of run_robot.py:167-169 sample fixed clouds; the reference's CUDA FPS starts at index 0, so
             # they return the same indices at every refresh: computed once.
             zero = torch.zeros(1, dtype=torch.long, device=device)
-            src_idx = farthest_point_sample(cano_pc[None], num_fps, start=zero)                  # [1, n]
-            tgt_idx = farthest_point_sample(pc_list, num_fps, start=zero.expand(B_))             # [B, n]
+            src_idx = farthest_point_sample(cano_pc[None], num_fps, start=zero, cuda_mode=True)                  # [1, n]
+            tgt_idx = farthest_point_sample(pc_list, num_fps, start=zero.expand(B_), cuda_mode=True)             # [B, n]
             tgt_pts = index_points(pc_list, tgt_idx)
             while i < n_iter:
                 if not have or i % args.assign_gap == 0:
@@ -210,63 +293,9 @@ def main(args):
                     snapshot(i - 1, {"opt assignment loss": row[0], "flow Loss": row[1], "total Loss": row[2]})
     # ---- phase 2 (kinematic model; base model without the engine): the reference's loop with HIP operators
     if i < n_iter and not args.evaluate:
-        from reart_amd.utils.lap import linear_sum_assignment_batch
-
-        if args.model == "base":
-            seg_params = [p for p in model.seg_head.parameters() if p.requires_grad]
-            optimizer = torch.optim.Adam([{"params": [model.proposal_6d, model.proposal_t], "lr": args.trans_lr},
-                                          {"params": seg_params, "lr": args.seg_lr}], lr=1e-3,
-                                         weight_decay=args.weight_decay)
-        else:
-            optimizer = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=args.trans_lr,
-                                         weight_decay=args.weight_decay)
-        from reart_amd.utils.lap import cdist
-
-        matched = None
-        # the kinematic model moves the cost matrices smoothly: the previous solve's pairs and potentials start the next
-        kin_lap_state = {} if args.model == "kinematic" else None
-        if args.use_assign_loss:
-            # run_robot.py:167-169: both FPS calls sample fixed clouds (start 0 on the reference's CUDA path): once
-            num_fps = pc_list.shape[1] // args.downsample
-            zero = torch.zeros(1, dtype=torch.long, device=device)
-            src_idx = farthest_point_sample(cano_pc[None], num_fps, start=zero).expand(pc_list.shape[0], num_fps)
-            tgt_pts = index_points(pc_list, farthest_point_sample(pc_list, num_fps, start=zero.expand(pc_list.shape[0])))
+        loop = OperatorLoop(args, model, cano_pc, pc_list, pc_ref_list, flow_ref_list, tau_func)
         while i < n_iter:
-            kwargs = {"tau": tau_func(cur_iter=i + 1)} if args.model == "base" else {}
-            pc_trans_list, seg_part, trans_list = model(cano_pc, **kwargs)
-            losses, loss = {}, 0
-            if args.use_assign_loss and i >= args.assign_iter:
-                pc_src = index_points(pc_trans_list, src_idx)
-                if matched is None or i % args.assign_gap == 0:  # run_robot.py:165-178
-                    # GPU auction + exact dual certificate; an uncertified matrix falls back to scipy on the host,
-                    # so this is always the optimum the reference's linear_sum_assignment / parallel_lap returns
-                    assign = linear_sum_assignment_batch(cdist(pc_src.detach(), tgt_pts), state=kin_lap_state,
-                                                         warm_assignment=kin_lap_state is not None)
-                    cols = torch.from_numpy(np.stack([c for _, c in assign])).to(device)    # rows are 0..n-1 in order
-                    matched = tgt_pts.gather(1, cols[..., None].expand(-1, -1, 3))
-                ass = args.lambda_assign * ((pc_src - matched) ** 2).sum(-1).sum()
-                losses["opt assignment loss"] = ass
-                loss = loss + ass
-            else:
-                rec = recon_loss(pc_trans_list, pc_list, chamfer_dist)
-                losses["recon Loss"] = rec
-                loss = loss + rec
-            if args.use_flow_loss:
-                c = args.cano_idx
-                with torch.no_grad():
-                    comp = torch.cat((pc_trans_list[:c], cano_pc[None], pc_trans_list[c:]), dim=0)
-                    blended = [blend_anchor_motion(q, r, f, knn_flow, return_mask=True)
-                               for q, r, f in zip(comp[:-1], pc_ref_list, flow_ref_list)]
-                comp = torch.cat((pc_trans_list[:c], cano_pc[None], pc_trans_list[c:]), dim=0)
-                fl = args.lambda_flow * flow_loss(torch.stack([b[0] for b in blended]), comp[1:] - comp[:-1],
-                                                  flow_mask_list=torch.stack([b[1] for b in blended]),
-                                                  robust=args.use_robust_loss)
-                losses["flow Loss"] = fl
-                loss = loss + fl
-            losses["total Loss"] = loss
-            optimizer.zero_grad()
-            loss.backward()
-            optimizer.step()
+            losses = loop.iteration(i)
             if i % args.snapshot_gap == 0 or i == n_iter - 1:
                 snapshot(i, losses)
             i += 1

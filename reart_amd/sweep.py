@@ -46,7 +46,10 @@ def instance_energy(eng, spec, **thresholds):
     """Structure + model-selection energy of a finished engine (reart_amd.tail) -> dict for the record."""
     from . import tail
 
-    res = tail.finish_instance(eng.model, eng.cano, eng.pc_list, int(spec.get("cano_idx", eng.cfg.cano_idx)), **thresholds)
+    # caller-order clouds: the tail depends on point order (per-part FPS starts, FPS / assignment tie rules), so the
+    # energy that picks the winning cano_idx is the value run_robot.finish computes for the same instance
+    cano, pcs = eng.caller_clouds()
+    res = tail.finish_instance(eng.model, cano, pcs, int(spec.get("cano_idx", eng.cfg.cano_idx)), **thresholds)
     res["parts"] = int(res["trans_list"].shape[1])
     return res
 

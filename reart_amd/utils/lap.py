@@ -21,14 +21,16 @@ def cdist(a, b):
     return out
 
 
-def linear_sum_assignment_batch(cost, return_stats=False, state=None, warm_assignment=False):
+def linear_sum_assignment_batch(cost, return_stats=False, state=None, warm_assignment=False, method="paths"):
     """cost [B,n,n] float32 CUDA tensor (square) -> list of (row_ind, col_ind) int64 numpy arrays, like
     ``[scipy.optimize.linear_sum_assignment(c) for c in cost]`` (rows in ascending order).
     ``state``: a dict kept by the caller between calls on slowly changing matrices (the loop re-solves every
     ``assign_gap`` iterations); it carries the column potentials of the previous solve as a warm start.
     ``warm_assignment=True`` (with ``state``) also carries the previous assignment and keeps the pairs that are still
     tight (``reart_lap_auction_warm``): faster when the matrices move smoothly (KinematicModel), slower when they
-    jump (BaseModel's resampled labels) -- there, and by default, solve cold (``state=None``)."""
+    jump (BaseModel's resampled labels) -- there, and by default, solve cold (``state=None``).
+    ``method`` of the warm re-solve: "paths" = shortest augmenting paths from the previous assignment and potentials
+    (``reart_lap_resolve``), "auction" = the warm-started auction (``reart_lap_auction_warm``)."""
     _lib.require_gpu(cost)
     if cost.dim() != 3 or cost.shape[1] != cost.shape[2]:
         raise ValueError("linear_sum_assignment_batch expects square matrices [B,n,n]")
@@ -56,7 +58,9 @@ def linear_sum_assignment_batch(cost, return_stats=False, state=None, warm_assig
         keep = bool(warm_assignment and warm and state.get("cols") is not None and tuple(state["cols"].shape) == (B, n))
         if keep:
             col.copy_(state["cols"])
-    solve = L.reart_lap_auction_warm if (state is not None and keep) else L.reart_lap_auction
+    solve = L.reart_lap_auction
+    if state is not None and keep:
+        solve = L.reart_lap_resolve if method == "paths" else L.reart_lap_auction_warm
     rc = solve(_lib.ptr(cost), B, n, _lib.ptr(col), _lib.ptr(cert),
                _lib.ptr(prices) if (state is not None and warm) else None,
                _lib.ptr(prices) if state is not None else None, _lib.ptr(ws), ws.numel(), _lib.stream())

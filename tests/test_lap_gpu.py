@@ -101,9 +101,10 @@ def test_cdist_matches_oracle_bitwise_and_torch(dev):
         np.testing.assert_allclose(got.cpu().numpy(), ref, atol=2e-7)
 
 
-def test_lap_warm_assignment_gives_the_optimum(dev):
-    """reart_lap_auction_warm: previous assignment + potentials as the start, on slightly moved, on unrelated and on
-    identical matrices -- always the certified optimum scipy returns."""
+@pytest.mark.parametrize("method", ["paths", "auction"])
+def test_lap_warm_assignment_gives_the_optimum(dev, method):
+    """reart_lap_resolve (shortest augmenting paths) / reart_lap_auction_warm: previous assignment + potentials as the
+    start, on slightly moved, on unrelated and on identical matrices -- always the certified optimum scipy returns."""
     import oracle
     from reart_amd.utils.lap import cdist, linear_sum_assignment_batch
 
@@ -114,11 +115,44 @@ def test_lap_warm_assignment_gives_the_optimum(dev):
     for step in range(4):
         moved = (a + 0.002 * step).astype(np.float32) if step < 3 else rng.uniform(-0.3, 0.3, (3, 600, 3)).astype(np.float32)
         cost = cdist(torch.from_numpy(moved).to(dev), torch.from_numpy(b).to(dev))
-        out, fb = linear_sum_assignment_batch(cost, return_stats=True, state=state, warm_assignment=True)
+        out, fb = linear_sum_assignment_batch(cost, return_stats=True, state=state, warm_assignment=True, method=method)
         ref = oracle.linear_sum_assignment(cost.cpu().numpy())
         for k in range(3):
             np.testing.assert_array_equal(out[k][1], ref[k][1])
         assert fb == 0 and "cols" in state
-    out2 = linear_sum_assignment_batch(cost, state=state, warm_assignment=True)      # the same matrices again
+    out2 = linear_sum_assignment_batch(cost, state=state, warm_assignment=True, method=method)      # the same matrices again
     for k in range(3):
         np.testing.assert_array_equal(out2[k][1], ref[k][1])
+
+
+@pytest.mark.parametrize("n", [3, 70, 1025, 2500])
+def test_lap_resolve_sizes_and_garbage_starts(dev, n):
+    """reart_lap_resolve at sizes that are not multiples of the workgroup, from the previous optimum, from a scrambled
+    assignment with repeated and missing columns, and from useless potentials: the certified optimum every time."""
+    import oracle
+    from reart_amd.utils.lap import cdist, linear_sum_assignment_batch
+
+    rng = np.random.default_rng(n)
+    a = rng.uniform(-0.3, 0.3, (2, n, 3)).astype(np.float32)
+    b = (a[:, rng.permutation(n)] + rng.normal(0, 0.004, (2, n, 3))).astype(np.float32)
+    state = {}
+    cost = cdist(torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev))
+    linear_sum_assignment_batch(cost, state=state, warm_assignment=True)                       # cold auction fills the state
+    for step in range(3):
+        a = (a + rng.normal(0, 0.001, a.shape)).astype(np.float32)
+        cost = cdist(torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev))
+        if step == 1:      # scrambled start: repeated, missing and out-of-range columns
+            bad = torch.from_numpy(rng.integers(-2, n + 2, (2, n)).astype(np.int32)).to(dev)
+            state["cols"].copy_(bad)
+        if step == 2:      # useless potentials
+            state["prices"].copy_(torch.from_numpy(rng.uniform(0, 5, (2, n))).to(dev))
+        out, fb, st = linear_sum_assignment_batch(cost, return_stats="full", state=state, warm_assignment=True)
+        ref = oracle.linear_sum_assignment(cost.cpu().numpy())
+        assert fb == 0
+        for k in range(2):
+            c = cost[k].cpu().numpy().astype(np.float64)
+            ours, best = c[out[k][0], out[k][1]].sum(), c[ref[k][0], ref[k][1]].sum()
+            assert abs(ours - best) <= 1e-9 * max(1.0, abs(best))
+            np.testing.assert_array_equal(out[k][1], ref[k][1])
+        if step == 0 and n >= 70:
+            assert (st[:, 1] < n).all()          # the previous optimum is a useful start: not every row is searched again

@@ -168,12 +168,12 @@ def test_grid_search_step_is_bit_identical_to_brute_force(dev):
         np.testing.assert_array_equal(a, b)
 
 
-def test_search_variants_give_identical_trajectories(dev, monkeypatch):
+def test_search_variants_give_identical_trajectories(dev):
     """The exact searches are interchangeable IN SITU: 40 iterations of the same instance with the
-    box-pruned warm-started search (default: sparse scans, three slices, merged launches), the same with
-    separate launches, dense scans only, other sparse thresholds and slice counts, the per-lane and
-    16-query variants, the 64-point forward workgroups, and cold brute force must leave bit-identical parameters and
-    loss logs."""
+    box-pruned warm-started search (default: sparse scans, three waves per search workgroup, XCD chunks re-sorted by
+    measured work), the same with dense scans only, other sparse thresholds, 1 / 2 / 4 waves per workgroup, the static
+    launch order, the profiling stamps switched on, the other workgroup geometries of the forward and the backward, and
+    cold brute force must leave bit-identical parameters and loss logs."""
     from reart_amd.networks.model import BaseModel
     from reart_amd.relax import RelaxEngine
     from reart_amd.synthetic import make_sequence, split_canonical
@@ -181,29 +181,34 @@ def test_search_variants_give_identical_trajectories(dev, monkeypatch):
     seq = make_sequence(T=6, n_parts=4, pts_per_part=300, seed=3, n_ref=700, with_flow=True)
     cano, pcs = split_canonical(seq["complete"], 2)
     runs = {}
-    for name, env in (("pruned", {}), ("separate", {"REART_MERGE": "0"}), ("lane", {"REART_SEARCH": "lane"}),
-                      ("quad", {"REART_SEARCH": "quad"}), ("quad_separate", {"REART_SEARCH": "quad", "REART_MERGE": "0"}),
-                      ("wave", {"REART_SEARCH": "wave"}), ("dense", {"REART_SPARSE": "0"}), ("sparse8", {"REART_SPARSE": "8"}),
-                      ("sparse3", {"REART_SPARSE": "3"}), ("split1", {"REART_PRUNE_SPLIT": "1"}),
-                      ("split4_dense", {"REART_PRUNE_SPLIT": "4", "REART_SPARSE": "0"}), ("fwd64", {"REART_FWD_PTS": "64"}),
-                      ("brute", {"REART_SEARCH": "brute"})):
-        for k in ("REART_MERGE", "REART_SEARCH", "REART_SPARSE", "REART_PRUNE_SPLIT", "REART_FWD_PTS"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
+    variants = (("pruned", {}), ("global_targets", {"tune_cloud": -1}), ("global_dense", {"tune_cloud": -1, "tune_sparse": -1}), ("dense", {"tune_sparse": -1}), ("sparse8", {"tune_sparse": 8}),
+                ("sparse3", {"tune_sparse": 3}), ("queue64", {"tune_sparse": 64}), ("split1", {"tune_slices": 1, "tune_cloud": -1}), ("split2_flow4", {"tune_slices": 2, "tune_slices_flow": 4, "tune_cloud": -1}),
+                ("split4_dense", {"tune_slices": 4, "tune_sparse": -1, "tune_cloud": -1}), ("static_order", {"tune_reorder": -1, "tune_cloud": -1}),
+                ("xcd_chunks", {"tune_xcd": 1, "tune_cloud": -1}), ("profiled", {"profile": 1}), ("fwd64", {"tune_fwd_pts": 64}),
+                ("brute", {"search_mode": 1}), ("bwd64", {"tune_bwd_pts": 64}), ("bwd16", {"tune_bwd_pts": 16}))
+    for name, tuning in variants:
         torch.manual_seed(0)
         model = BaseModel(num_parts=12, pose_len=5).to(dev)
         eng = RelaxEngine(t(cano, dev), t(pcs, dev), model, 2, [t(r, dev) for r in seq["ref_loc"]],
-                          [t(f, dev) for f in seq["ref_flow"]], n_iter=200)
+                          [t(f, dev) for f in seq["ref_flow"]], n_iter=200, tuning=tuning)
         eng.step(40)
         it, log = eng.loss_log()
         runs[name] = (log.cpu().numpy(), model.proposal_6d.detach().cpu().numpy().copy(),
                       model.seg_head.model[2].weight.detach().cpu().numpy().copy(), eng.seg_part.cpu().numpy())
+        if name == "profiled":
+            prof = eng.search_profile(reset=True)
+            brute_pairs = 5 * (2 * 1200 * 1200 + 1200 * 700)          # what a brute-force search evaluates per launch
+            assert prof["launches"] == 40 and 0 < prof["seconds"] < 40 * 5e-3
+            assert 40 * 3 * 5 * 1200 < prof["pairs"] < 2 * 40 * brute_pairs  # more than the seeds; bounded by (padded) brute force
+            assert eng.search_profile()["launches"] == 0
     ref = runs["brute"]
     assert np.isfinite(ref[0]).all()
-    for name in ("pruned", "separate", "lane", "quad", "quad_separate", "wave", "dense", "sparse8", "sparse3", "split1", "split4_dense", "fwd64"):
+    for name, _ in variants:
         for a, b in zip(runs[name], ref):
-            np.testing.assert_array_equal(a, b, err_msg=name)
+            if name.startswith("bwd"):   # other partial-sum chunks in the backward: same sums in another order
+                np.testing.assert_allclose(a, b, rtol=2e-5, atol=2e-6, err_msg=name)
+            else:
+                np.testing.assert_array_equal(a, b, err_msg=name)
 
 
 def test_full_size_pruned_equals_brute_force(dev, monkeypatch):

@@ -63,3 +63,14 @@ def test_sweep_records_carry_the_reference_energy(dev):
     solo = sweep.instance_energy(eng, instances[1])
     np.testing.assert_allclose(rec[1, 8:12], [solo["total_err"], solo["ass_err"], solo["screw_err"], solo["group_err"]], rtol=1e-6)
     assert rec[1, 7] == solo["parts"]
+    # the energy is computed on the CALLER's point order (the engine stores k-d order; the tail depends on point order):
+    # it is the value the stand-alone tail gives on the original clouds
+    from reart_amd import tail
+
+    cano, pcs = split_canonical(seq["complete"], 2)
+    direct = tail.finish_instance(eng.model, t(cano), t(pcs), 2)
+    for k in ("total_err", "ass_err", "screw_err", "group_err"):
+        assert direct[k] == solo[k], k
+    c2, p2 = eng.caller_clouds()
+    np.testing.assert_array_equal(c2.cpu().numpy(), cano)
+    np.testing.assert_array_equal(p2.cpu().numpy(), pcs)

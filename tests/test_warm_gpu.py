@@ -8,14 +8,6 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["wave", "quad"], autouse=True)
-def search_variant(request, monkeypatch):
-    """Every test runs for both work shapes of the pruned search (prune.hip: 64 queries x 1 box per wave,
-    quad.hip: 16 queries x 4 boxes)."""
-    monkeypatch.setenv("REART_SEARCH", request.param)
-    return request.param
-
-
 def _check(oracle, dev, a, b, K, seed):
     from reart_amd.chamferdist_C import knn_points_idx_warm
 
