@@ -102,6 +102,85 @@ def cpu_baseline_torch(seq, T, N, cano_idx, budget_s=10.0):
                       f"conv1d / gumbel_softmax / bmm / cdist+argmin / topk / autograd / torch.optim.Adam, {el:.1f} s wall)"}
 
 
+def extractor_flops(N, out_dim=64):
+    """Useful multiply-add flops (x2) of ONE PointNet2Msg2 forward on a cloud of N points: every 1x1 conv of
+    networks/feature_extractor.py:19-29 over the rows it is applied to (no tile padding counted)."""
+    def stack(rows, cin, widths):
+        f = 0
+        for w in widths:
+            f += 2 * rows * cin * w
+            cin = w
+        return f
+    f = 0
+    for K, widths in ((32, (32, 32, 64)), (64, (64, 64, 128)), (128, (64, 96, 128))):      # sa1: 512 centres, in = 3 + 3
+        f += stack(512 * K, 6, widths)
+    for K, widths in ((64, (128, 128, 256)), (128, (128, 196, 256))):                      # sa2: 128 centres, in = 320 + 3
+        f += stack(128 * K, 323, widths)
+    f += stack(128, 515, (256, 512, 1024))                                                 # sa3: group all
+    f += stack(128, 1536, (256, 256))                                                      # fp3
+    f += stack(512, 576, (256, 128))                                                       # fp2
+    f += stack(N, 134, (128, 128))                                                         # fp1
+    f += 2 * N * 128 * out_dim                                                             # conv1
+    return f
+
+
+def bench_extractor(args, dev):
+    """The one-time correspondence extractor of BASELINE configs[2] at the loop's size: PointNet2Msg2 on the 2(T-1)
+    clouds of N points that compute_corr_list_filter feeds it (utils/flow_utils.py:123-124).  One step = one forward of
+    all clouds.  Weights: seeded (corr_model.pth.tar is not shipped), same as the parity goldens."""
+    from reart_amd.networks.feature_extractor import PointNet2Msg2
+    from reart_amd.synthetic import make_sequence
+    from tests.golden.make_golden_extractor import extractor_state
+
+    T, N = args.frames, args.points
+    seq = make_sequence(T=T, n_parts=8, pts_per_part=N // 8, seed=2, with_flow=False)
+    pts = torch.from_numpy(seq["complete"]).to(dev)
+    pts = pts - pts.mean(dim=1, keepdim=True)
+    pts = pts / pts.norm(dim=-1).max()
+    xyz = torch.cat([pts[:-1], pts[1:]]).permute(0, 2, 1).contiguous()      # [2(T-1), 3, N]
+    model = PointNet2Msg2(64)
+    model.load_state_dict(extractor_state(model))
+    model = model.to(dev).eval()
+    B = xyz.shape[0]
+    steps = args.steps if args.steps != 1500 else 20
+    warm = args.warmup if args.warmup != 150 else 3
+    for _ in range(warm):
+        f = model(xyz)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(steps):
+        f = model(xyz)
+    ev1.record()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    ms = ev0.elapsed_time(ev1) / steps
+    flops = extractor_flops(N) * B
+    ach = flops / (ms * 1e-3) / 1e12
+    # no CPU leg for this config: the oracle restates the extractor's sampling / interpolation operators, not its conv
+    # stacks, and the reference itself cannot travel to the GPU box.  Measured in the build container instead
+    # (tests/golden/make_golden_parity2.py runs the reference's own PointNet2Msg2 on a 4096-point cloud): see DESIGN.md.
+    cpu = None
+    return {
+        "metric": "correspondence-extractor clouds/sec", "value": round(B * steps / el, 2), "unit": "clouds/s", "n_gpus": 1,
+        "steps": steps, "warmup": warm, "ms_per_step": round(1e3 * el / steps, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32 (fp32 MFMA, exact f32)", "data": "synthetic",
+        "config": {"workload": f"PointNet2Msg2 forward (FPS, ball query, gather-fused 1x1-conv stacks + max-pool on the fp32 "
+                               f"matrix cores, 3-NN interpolation) on {B} clouds of {N} points = the one-time descriptor "
+                               f"extraction of a T={T} sequence (utils/flow_utils.py:123-124); seeded weights",
+                   "clouds": B, "points": N, "sampling_rules": "CUDA (pointnet2_utils.CUDA = True)"},
+        "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(ach / FP32_PEAK_TFLOPS, 4), "traffic": None,
+                     "kernel": "mlp_gemm_kernel<NB> (all 1x1-conv layers; v_mfma_f32_32x32x2_f32)",
+                     "kernel_ms": round(ms, 4), "useful_flops": flops,
+                     "note": "useful flops of every conv layer (no tile padding) over the WHOLE forward's device time "
+                             "(HIP events on the launch stream, FPS / ball query / interpolation included), against the "
+                             "fp32 MFMA peak of MI355X_MICROARCH.md (157.3 TFLOP/s)"},
+        "cpu_baseline": cpu, "finite": bool(torch.isfinite(f).all()),
+    }
+
+
 def bench_kinematic(args, dev, rank, world, distributed, barrier):
     """BASELINE.json configs[4] as the reference runs it (README.md:125): kinematic projection from a relaxation result,
     `--model kinematic --use_flow_loss --use_assign_loss --assign_iter 0 --downsample 2 --assign_gap 1`, at the synthetic
@@ -210,7 +289,8 @@ def bench_kinematic(args, dev, rank, world, distributed, barrier):
                    "parallelism": f"instances x{world}"},
         "roofline": roof, "cpu_baseline": cpu,
         "lap_stats_last": {"rows_released": st[:, 0].tolist(), "rows_searched": st[:, 1].tolist(),
-                           "dijkstra_steps": st[:, 2].tolist(), "certificate_rounds": st[:, 3].tolist()},
+                           "dijkstra_steps": st[:, 2].tolist(), "row_reduction_steps": (st[:, 3] >> 8).tolist(),
+                           "certificate_rounds": (st[:, 3] & 255).tolist()},
         "final_losses": {k: float(v.detach()) for k, v in losses.items()},
     }
 
@@ -431,6 +511,7 @@ def main():
                     "frac": round(ach / FP32_PEAK_TFLOPS, 4), "traffic": traffic,
                     "kernel": "knn_group_kernel (" + kname.split("(", 1)[1],
                     "kernel_ms": round(k_ms, 5), "launches_measured": prof["launches"],
+                    "workgroup_busy_ms": round(1e3 * prof["workgroup_seconds"] / prof["launches"], 4),
                     "executed_pairs_per_launch": round(executed, 1), "flop_per_pair": 8,
                     "algorithmic_pairs_per_launch": nn_pairs,
                     "algorithmic_speedup": round(nn_pairs / executed, 3),

@@ -206,12 +206,14 @@ typedef struct reart_relax_config {
     int tune_slices;         /* waves (box slices) per search workgroup, 1..4 (default 3)  */
     int tune_slices_flow;    /* the same for the K = 3 flow search (default: tune_slices)  */
     int tune_sparse;         /* boxes needed by <= n queries of a wave go through the (query, box) queue instead of a  */
-                             /* 64-lane scan: 1..64 (default 40), < 0: dense scans only                                */
+                             /* 64-lane scan: 1..64 (default 20), < 0: dense scans only                                */
     int tune_fwd_pts;        /* points per forward workgroup: 64 | 32 (default 32)         */
     int tune_bwd_pts;        /* points per backward workgroup: 64 | 32 | 16 (default 32)   */
     int tune_reorder;        /* < 0: keep the static launch order of the search items      */
-    int tune_cloud;          /* < 0: never copy the target cloud of a search workgroup into LDS (the cloud-resident form */
-                             /* is the default whenever the clouds fit: N <= ~7000 points)                              */
+    int tune_cloud;          /* 1 | 2 | 4 | 8: cloud-resident form of the search (16-wave workgroups that copy their target   */
+                             /* cloud into LDS, that many box slices per query group; clouds up to ~7000 points).  Exact and  */
+                             /* tested, but measured slower than the default (targets from L2): the launch is bound by       */
+                             /* instruction issue, not by the latency the LDS copy removes                                  */
     int tune_xcd;            /* > 0: every XCD runs one contiguous eighth of the (frame, query group) pairs (a run of */
                              /* frames per L2) instead of every 8th pair; measured slower: frames differ 10x in work  */
     int profile;             /* 1: the search launch of every iteration records per-workgroup wall-clock stamps and  */
@@ -269,7 +271,8 @@ int reart_relax_step_timed(const reart_relax_config *cfg, const reart_relax_buff
  * reart_relax_step -- eager or replayed from a graph -- leaves per-workgroup wall-clock stamps that the consumer
  * launch reduces on the device.  h_out[0] = launches since the last reset, [1] = their summed duration in seconds
  * (first workgroup start to last workgroup end, constant-rate clock), [2] = query-target distance evaluations they
- * executed, [3] = the clock rate in Hz.  Synchronises `stream`; reset != 0 clears the accumulators. */
+ * executed, [3] = the clock rate in Hz, [4] = the summed lifetimes of the launches' workgroups in seconds.
+ * h_out holds 5 doubles.  Synchronises `stream`; reset != 0 clears the accumulators. */
 int reart_relax_profile(const reart_relax_config *cfg, void *workspace, size_t workspace_bytes, void *stream,
                         double *h_out, int reset);
 

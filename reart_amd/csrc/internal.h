@@ -150,13 +150,14 @@ struct SearchArgs {
                                    // x, x+8, ... (every XCD sees every frame: balanced whatever the frames cost)
     int cloud_resident;            // 1: when the target clouds fit in LDS, one workgroup of 16 waves per (job, batch, 16
                                    // query groups) with the cloud copied into LDS (knn_cloud_kernel); S1 / S3 then unused
+    int cloud_slices;              // cloud-resident form: box slices per query group, 1 | 2 | 4 | 8 (0: the default, 4)
     int k_nqg;                     // query groups per batch (set by the launcher)
     unsigned long long *prof;      // nullable: [grid][2] wall-clock stamps of every workgroup (start, end)
     unsigned int *prof_pairs;      //           [grid] distance evaluations executed by the workgroup
 };
 int reart_search_launch(const SearchArgs &a, hipStream_t st);
 int reart_search_grid(int n1, int n3, int G);   // workgroups of that launch (an upper bound for both forms)
-int reart_search_grid_cloud(int n1, int n3, int G, int nqg);
+int reart_search_grid_cloud(int n1, int n3, int G, int nqg, int slices);
 int reart_search_workgroups(const SearchArgs &a);   // of the form reart_search_launch will pick for `a`
 
 #ifdef __HIPCC__

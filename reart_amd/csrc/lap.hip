@@ -109,6 +109,23 @@ __device__ __forceinline__ void lap_merge_top2(double ov1, int oj1, double ov2, 
     j1 = take ? oj1 : j1;
 }
 
+// largest entry seen by this thread of the workgroup's matrix: 16-byte loads, eight in flight per thread (one pass
+// over n*n floats; a scalar strided loop here cost more than the certificate pass)
+__device__ __forceinline__ float lap_matrix_max(const float *__restrict__ C, size_t total, int tid) {
+    float m = 0.f;
+    const size_t n4 = ((((uintptr_t)C) & 15) == 0) ? total / 4 : 0;
+    const float4 *C4 = (const float4 *)C;
+    for (size_t e0 = tid; e0 < n4; e0 += (size_t)LAP_BS * 8) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = C4[e0 + (size_t)u * LAP_BS < n4 ? e0 + (size_t)u * LAP_BS : e0];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) m = fmaxf(m, fmaxf(fmaxf(v[u].x, v[u].y), fmaxf(v[u].z, v[u].w)));
+    }
+    for (size_t e = 4 * n4 + tid; e < total; e += LAP_BS) m = fmaxf(m, C[e]);
+    return m;
+}
+
 __global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lsm[];
     const int n = a.n, b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -128,8 +145,7 @@ __global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
     const float *C = a.cost + (size_t)b * n * n;
 
     // largest cost
-    double mx = 0.0;
-    for (size_t e = tid; e < (size_t)n * n; e += LAP_BS) mx = fmax(mx, (double)C[e]);
+    double mx = (double)lap_matrix_max(C, (size_t)n * n, tid);
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
     if (lane == 0) s_red[wv] = mx;
@@ -449,7 +465,8 @@ struct JvArgs {
     const double *price_in;    // previous potentials (prices, the auction's sign convention)
     double *price_out;
     int max_rounds_cert;
-    int *stats;                // nullable [B][4]: freed rows, rows left after the greedy step, Dijkstra steps, certificate rounds
+    int *stats;                // nullable [B][4]: released rows, rows left for the path search, Dijkstra steps, certificate rounds
+                               // + 256 * row-reduction steps
     double keep_tol;           // fraction of the largest cost
 };
 
@@ -469,8 +486,7 @@ __global__ __launch_bounds__(LAP_BS) void lap_jv_kernel(JvArgs a) {
     __shared__ int s_cnt, s_flag;
     const float *C = a.cost + (size_t)b * n * n;
 
-    double mx = 0.0;
-    for (size_t e = tid; e < (size_t)n * n; e += LAP_BS) mx = fmax(mx, (double)C[e]);
+    double mx = (double)lap_matrix_max(C, (size_t)n * n, tid);
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
     if (lane == 0) s_red[wv] = mx;
@@ -540,8 +556,54 @@ __global__ __launch_bounds__(LAP_BS) void lap_jv_kernel(JvArgs a) {
         if (tid == 0) { int t = 0; for (int w = 0; w < NW; ++w) t += s_rj[0][w]; s_cnt += t; }
         __syncthreads();
     }
-    const int nfree = s_cnt;
+    int nfree = s_cnt;
+    // ---- augmenting row reduction (Jonker-Volgenant): a free row takes its cheapest column at once and pays for it --
+    // the column's price rises by the gap to the row's second-cheapest column, which keeps every dual constraint and
+    // makes the new pair tight -- and the row it displaces is handled next.  One row scan per step, no search: most of
+    // the rows a small change of the costs has released settle here.  Exact ties and the rows left when the step budget
+    // runs out go to the path search below.  (One wave: the chain is sequential; LDS traffic of a wave is in order.)
+    if (wv == 0 && nfree > 0) {
+        int ncur = nfree, budget = 8 * nfree + 64;
+        int *next = pred;                                   // not needed before the path search
+        for (int pass = 0; pass < 2 && ncur > 0; ++pass) {
+            int nnext = 0;
+            for (int k = 0; k < ncur; ++k) {
+                int i = flist[k];
+                for (;;) {
+                    double v1, v2;
+                    int j1;
+                    lap_row_top2(C + (size_t)i * n, price, n, lane, v1, j1, v2);
+                    const int i0 = owner[j1];
+                    const bool tie = !(v1 < v2);
+                    if (budget-- <= 0 || (tie && i0 >= 0)) {
+                        if (lane == 0) { next[nnext] = i; u[i] = v1; }
+                        ++nnext;
+                        break;
+                    }
+                    if (lane == 0) {
+                        if (!tie) price[j1] += v2 - v1;
+                        u[i] = tie ? v1 : v2;
+                        assigned[i] = j1; owner[j1] = i;
+                        if (i0 >= 0) assigned[i0] = -1;
+                    }
+                    __threadfence_block();
+                    ++st_steps;
+                    if (i0 < 0) break;
+                    i = i0;
+                }
+            }
+            __threadfence_block();
+            for (int k = lane; k < nnext; k += 64) flist[k] = next[k];
+            __threadfence_block();
+            ncur = nnext;
+        }
+        if (lane == 0) s_cnt = ncur;
+    }
+    __syncthreads();
+    nfree = s_cnt;
     st_left = nfree;
+    const int st_arr = st_steps;
+    st_steps = 0;
 
     // ---- one shortest augmenting path per free row
     bool solved = true;
@@ -592,13 +654,17 @@ __global__ __launch_bounds__(LAP_BS) void lap_jv_kernel(JvArgs a) {
             if ((jstar & (LAP_BS - 1)) == tid) scanned |= 1u << (jstar / LAP_BS);
             const int i = owner[jstar];
             if (i < 0) { sink = jstar; break; }
-            const double ui = u[i];
+            // the step's ONE dependent global read: every column's cost in that row, all loads in flight together
             const float *row = C + (size_t)i * n;
+            float rc[JV_CPT];
+#pragma unroll
+            for (int k = 0; k < JV_CPT; ++k) rc[k] = row[tid + k * LAP_BS < n ? tid + k * LAP_BS : tid];
+            const double ui = u[i];
 #pragma unroll
             for (int k = 0; k < JV_CPT; ++k) {
                 const int j = tid + k * LAP_BS;
                 if (!((scanned >> k) & 1u)) {
-                    const double nd = mu + (((double)row[j] + price[j]) - ui);
+                    const double nd = mu + (((double)rc[k] + price[j]) - ui);
                     if (nd < d[k]) { d[k] = nd; pred[j] = i; }
                 }
             }
@@ -659,7 +725,7 @@ __global__ __launch_bounds__(LAP_BS) void lap_jv_kernel(JvArgs a) {
     if (a.price_out)
         for (int j = tid; j < n; j += LAP_BS) a.price_out[(size_t)b * n + j] = dd[j];
     if (tid == 0) a.certified[b] = certified;
-    if (tid == 0 && a.stats) { int *o = a.stats + 4 * b; o[0] = st_freed; o[1] = st_left; o[2] = st_steps; o[3] = st_cert; }
+    if (tid == 0 && a.stats) { int *o = a.stats + 4 * b; o[0] = st_freed; o[1] = st_left; o[2] = st_steps; o[3] = st_cert + (st_arr << 8); }
 }
 
 // Re-solve from the assignment in col4row and the potentials in price_in (both from an earlier solve of a similar batch,

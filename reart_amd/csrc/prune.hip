@@ -447,10 +447,13 @@ __global__ __launch_bounds__(64 * PR_SMAX) void knn_group_kernel(SearchArgs a) {
     __shared__ float s_m[PR_SMAX][3][64];
     __shared__ int s_b[PR_SMAX][3][64];
     __shared__ unsigned int s_wk[PR_SMAX][2];
+    __shared__ unsigned int s_ticket;
+    __shared__ unsigned long long s_t0;
+    if (threadIdx.x == 0) { s_ticket = 0u; s_t0 = a.prof ? wall_clock64() : 0ull; }
+    __syncthreads();                        // at the start, where all waves of the workgroup arrive together
     const int L = blockIdx.x, x = L & 7, r = L >> 3;
     const int s = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    unsigned long long t0 = 0ull;
-    if (a.prof && threadIdx.x == 0) t0 = wall_clock64();
+    const unsigned long long t0 = s_t0;
     // XCD-local item r: two K = 1 items alternate with one K = 3 item while both kinds last
     const int items1 = a.n1 * a.per, items3 = a.n3 * a.per;
     const int mixed = (a.n1 == 2 && a.n3) ? 3 * a.per : 0;
@@ -475,6 +478,7 @@ __global__ __launch_bounds__(64 * PR_SMAX) void knn_group_kernel(SearchArgs a) {
     }
     const KnnJob &jb = kind == 1 ? a.k1[j] : a.k3;
     const int S = kind == 1 ? a.S1 : a.S3;
+    if (s >= S) return;                                                 // the other kind of item uses more waves
     const int grp = jb.border ? jb.border[pos] : pos;
     const int b = grp / jb.nqg, g = grp - b * jb.nqg;
     float qx = 0.f, qy = 0.f, qz = 0.f;
@@ -482,7 +486,7 @@ __global__ __launch_bounds__(64 * PR_SMAX) void knn_group_kernel(SearchArgs a) {
     int bb[3] = {-1, -1, -1};
     int work = 0;
     unsigned int pairs = 0u;
-    if (s < S) {
+    {
         unsigned char *wl = s_dyn + (size_t)s * PR_LDS_WAVE_BYTES;
         float *s_tg = (float *)wl;
         float *s_qc = (float *)(wl + 64 * 4);
@@ -499,23 +503,30 @@ __global__ __launch_bounds__(64 * PR_SMAX) void knn_group_kernel(SearchArgs a) {
             knn_pruned_wave<3, false, PR_QCAP>(jb, S, a.sparse, b, g, s, cloud, jb.Ppad, boxes_p, s_tg, s_qc, s_q, s_key,
                                                qx, qy, qz, bm, bb, work, pairs);
         }
-        if (s > 0) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) { s_m[s][k][lane] = bm[k]; s_b[s][k][lane] = bb[k]; }
-            if (lane == 0) { s_wk[s][0] = (unsigned int)work; s_wk[s][1] = pairs; }
-        }
     }
+    // ---- the LAST wave to finish merges (no barrier: a wave that is done leaves at once and frees its slot; measured with
+    // a barrier here, 17 % of a wave's life was waiting for its slowest sibling).  Every wave parks its candidates, then
+    // takes a ticket; LDS operations of a wave complete in order, so the ticket holder S-1 sees all of them.
+    if (S > 1) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { s_m[s][k][lane] = bm[k]; s_b[s][k][lane] = bb[k]; }
+        if (lane == 0) { s_wk[s][0] = (unsigned int)work; s_wk[s][1] = pairs; }
+        __threadfence_block();
+        int ticket = 0;
+        if (lane == 0) ticket = (int)atomicAdd(&s_ticket, 1u);
+        ticket = __builtin_amdgcn_readfirstlane(ticket);
 #ifdef REART_PRUNE_PHASE
-    const unsigned long long tb0 = __builtin_amdgcn_s_memtime();
+        if (lane == 0) atomicAdd(&g_prune_phase[7], 1ull);
 #endif
-    if (blockDim.x > 64) __syncthreads();
-#ifdef REART_PRUNE_PHASE
-    if (lane == 0) { atomicAdd(&g_prune_phase[6], __builtin_amdgcn_s_memtime() - tb0); atomicAdd(&g_prune_phase[7], 1ull); }
-#endif
-    if (s != 0) return;
-    // ---- wave 0: merge the slices' candidates by (minimum, first index): distinct slices hold distinct boxes, so the
-    // lower block start is the lower index
-    for (int t = 1; t < S; ++t) { work += (int)s_wk[t][0]; pairs += s_wk[t][1]; }
+        if (ticket != S - 1) return;
+        __threadfence_block();
+        work = 0; pairs = 0u;
+        for (int t = 0; t < S; ++t) { work += (int)s_wk[t][0]; pairs += s_wk[t][1]; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { bm[k] = s_m[0][k][lane]; bb[k] = s_b[0][k][lane]; }
+    }
+    // ---- merge the slices' candidates by (minimum, first index): distinct slices hold distinct boxes, so the lower block
+    // start is the lower index
     const int i = g * NN_BS + lane;
     const float *tx = jb.tsoa + (size_t)b * 3 * jb.Ppad, *ty = tx + jb.Ppad, *tz = ty + jb.Ppad;
     if (kind == 1) {
@@ -573,9 +584,10 @@ __global__ __launch_bounds__(64 * PR_SMAX) void knn_group_kernel(SearchArgs a) {
 // of dependent memory round trips -- seeds -> seed targets -> boxes -> (per scanned box / per drain step) targets ->
 // rescan -- and spends its life waiting for them, not computing.  A target cloud of the loop is 48 KB (4096 points,
 // SoA) + 8 KB of boxes: it fits in LDS.  Here one workgroup of PC_WAVES waves copies the cloud and the boxes of ITS
-// (job, batch) into LDS once (coalesced 16-byte loads), and every wave then runs one whole query group (all boxes: no
-// slices, no merge, no barrier at the end) with every target / box read served by LDS.  What is left of the chain in
-// global memory: the query, its seeds, and the record written at the end.
+// (job, batch) into LDS once (coalesced 16-byte loads); its waves are PC_WAVES / S query groups x S box slices, every
+// target / box read is served by LDS, the slices of a group meet in LDS as 64-bit (distance, block) keys and the
+// slice-0 wave merges them, rescans once and writes the record.  What is left of the chain in global memory: the
+// query, its seeds, and the record written at the end.
 // Falls back to knn_group_kernel when a cloud does not fit (reart_search_launch decides).
 #define PC_WAVES 16
 #define PC_QCAP 256
@@ -593,6 +605,7 @@ __global__ __launch_bounds__(64 * PC_WAVES) void knn_cloud_kernel(SearchArgs a) 
     const int b = rest % B, blk = rest / B;
     const int kind = jsel < a.n1 ? 1 : 3;
     const KnnJob &jb = kind == 1 ? a.k1[jsel] : a.k3;
+    const int S = a.cloud_slices, gpw = PC_WAVES / S;             // slices per group, groups per workgroup
     // ---- stage the batch's target cloud and boxes
     const int Ppad = jb.Ppad, nboxp = Ppad / NN_BOX;
     float *cl = (float *)s_dyn;                                   // [3][Ppad]
@@ -607,25 +620,59 @@ __global__ __launch_bounds__(64 * PC_WAVES) void knn_cloud_kernel(SearchArgs a) 
         for (int e = threadIdx.x; e < 2 * nboxp; e += 64 * PC_WAVES) db[e] = sb[e];
     }
     __syncthreads();
-    const int g = blk * PC_WAVES + w;
+    const int g = blk * gpw + w / S, sl = w % S;
     unsigned int pairs = 0u;
     int work = 0;
+    unsigned char *wbase = s_dyn + (size_t)(3 * Ppad + 8 * nboxp) * 4;
+    unsigned long long *s_key = (unsigned long long *)(wbase + (size_t)w * PC_WAVE_BYTES + 64 * 16);
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    float bm[3] = {INFINITY, INFINITY, INFINITY};
+    int bb[3] = {-1, -1, -1};
     if (g < jb.nqg) {
-        unsigned char *wl = s_dyn + (size_t)(3 * Ppad + 8 * nboxp) * 4 + (size_t)w * PC_WAVE_BYTES;
+        unsigned char *wl = wbase + (size_t)w * PC_WAVE_BYTES;
         float *s_qc = (float *)wl;
-        unsigned long long *s_key = (unsigned long long *)(wl + 64 * 16);
         unsigned int *s_q = (unsigned int *)(wl + 64 * 16 + 3 * 64 * 8);
-        float qx, qy, qz;
-        float bm[3] = {INFINITY, INFINITY, INFINITY};
-        int bb[3] = {-1, -1, -1};
         if (kind == 1) {
             float m1[1]; int b1[1];
-            knn_pruned_wave<1, true, PC_QCAP>(jb, 1, a.sparse, b, g, 0, cl, Ppad, bxs, nullptr, s_qc, s_q, s_key, qx, qy, qz,
+            knn_pruned_wave<1, true, PC_QCAP>(jb, S, a.sparse, b, g, sl, cl, Ppad, bxs, nullptr, s_qc, s_q, s_key, qx, qy, qz,
                                               m1, b1, work, pairs);
             bm[0] = m1[0]; bb[0] = b1[0];
         } else {
-            knn_pruned_wave<3, true, PC_QCAP>(jb, 1, a.sparse, b, g, 0, cl, Ppad, bxs, nullptr, s_qc, s_q, s_key, qx, qy, qz,
+            knn_pruned_wave<3, true, PC_QCAP>(jb, S, a.sparse, b, g, sl, cl, Ppad, bxs, nullptr, s_qc, s_q, s_key, qx, qy, qz,
                                               bm, bb, work, pairs);
+        }
+        if (S > 1 && sl > 0) {
+            // the slice's candidates as (distance bits, block) keys in its own (now idle) result slots
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                s_key[64 * k + lane] = bb[k] >= 0 ? (((unsigned long long)__float_as_uint(bm[k]) << 32) | (unsigned)bb[k]) : ~0ull;
+            if (lane == 0) { s_key[192] = (unsigned long long)(unsigned)work; s_key[193] = (unsigned long long)pairs; }   // queue area
+        }
+    }
+    if (S > 1) __syncthreads();
+    if (g < jb.nqg && sl == 0) {
+        // ---- slice 0 merges its group's slices by the full (distance, block) key: distinct slices hold distinct boxes
+        for (int t = 1; t < S; ++t) {
+            const unsigned long long *ok = (const unsigned long long *)(wbase + (size_t)(w + t) * PC_WAVE_BYTES + 64 * 16);
+            work += (int)(unsigned)ok[192]; pairs += (unsigned)ok[193];
+            if (kind == 1) {
+                const unsigned long long k = ok[lane];
+                const float m = __uint_as_float((unsigned)(k >> 32));
+                const int bt = (int)(unsigned)k;
+                if (k != ~0ull && ((m < bm[0]) || (m == bm[0] && (bb[0] < 0 || bt < bb[0])))) { bm[0] = m; bb[0] = bt; }
+            } else {
+                float kd[3];
+                int ki[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { kd[c] = bm[c]; ki[c] = bb[c] >= 0 ? bb[c] : 0x7fffffff; }
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const unsigned long long k = ok[64 * c + lane];
+                    if (k != ~0ull) reart_top3_insert(kd, ki, __uint_as_float((unsigned)(k >> 32)), (int)(unsigned)k);
+                }
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { bm[c] = kd[c]; bb[c] = ki[c] == 0x7fffffff ? -1 : ki[c]; }
+            }
         }
         const int i = g * NN_BS + lane;
         if (kind == 1) {
@@ -650,6 +697,8 @@ __global__ __launch_bounds__(64 * PC_WAVES) void knn_cloud_kernel(SearchArgs a) 
             for (int k = 0; k < 3; ++k) { jb.pd[o + k] = bm[k]; jb.pi[o + k] = bm[k] < INFINITY ? bb[k] : -1; }
         }
         if (lane == 0 && jb.cost) jb.cost[b * jb.nqg + g] = (unsigned int)work;
+    } else {
+        pairs = 0u;                       // counted by the group's slice-0 wave
     }
     if (a.prof) {
         __shared__ unsigned int s_pairs[PC_WAVES];
@@ -683,10 +732,11 @@ int reart_search_launch(const SearchArgs &a_in, hipStream_t st) {
     a.per = reart_div_up(a.G, 8);
     a.k_nqg = a.n1 ? a.k1[0].nqg : a.k3.nqg;
     const size_t cl_lds = a.cloud_resident ? search_cloud_lds(a) : 0;
+    a.cloud_slices = (a.cloud_slices == 1 || a.cloud_slices == 2 || a.cloud_slices == 4 || a.cloud_slices == 8) ? a.cloud_slices : 4;
     if (cl_lds) {
         if (hipFuncSetAttribute((const void *)knn_cloud_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)
             return REART_ERR_LAUNCH;
-        hipLaunchKernelGGL(knn_cloud_kernel, dim3(reart_search_grid_cloud(a.n1, a.n3, a.G, a.k_nqg)), dim3(64 * PC_WAVES),
+        hipLaunchKernelGGL(knn_cloud_kernel, dim3(reart_search_grid_cloud(a.n1, a.n3, a.G, a.k_nqg, a.cloud_slices)), dim3(64 * PC_WAVES),
                            cl_lds, st, a);
         REART_CHECK_LAUNCH();
         return REART_OK;
@@ -700,11 +750,14 @@ int reart_search_launch(const SearchArgs &a_in, hipStream_t st) {
 // workgroups the launch of `a` will have (the form is chosen exactly as in reart_search_launch)
 int reart_search_workgroups(const SearchArgs &a) {
     const int nqg = a.n1 ? a.k1[0].nqg : a.k3.nqg;
-    if (a.cloud_resident && search_cloud_lds(a)) return reart_search_grid_cloud(a.n1, a.n3, a.G, nqg);
+    const int cs = (a.cloud_slices == 1 || a.cloud_slices == 2 || a.cloud_slices == 4 || a.cloud_slices == 8) ? a.cloud_slices : 4;
+    if (a.cloud_resident && search_cloud_lds(a)) return reart_search_grid_cloud(a.n1, a.n3, a.G, nqg, cs);
     return reart_search_grid(a.n1, a.n3, a.G);
 }
 int reart_search_grid(int n1, int n3, int G) { return 8 * (n1 + n3) * reart_div_up(G, 8); }
-int reart_search_grid_cloud(int n1, int n3, int G, int nqg) { return (n1 + n3) * (G / nqg) * reart_div_up(nqg, PC_WAVES); }
+int reart_search_grid_cloud(int n1, int n3, int G, int nqg, int slices) {
+    return (n1 + n3) * (G / nqg) * reart_div_up(nqg, PC_WAVES / slices);
+}
 
 // ---------------------------------------------------------------------------------------------
 // Stand-alone entry: warm-started exact K-NN (K = 1 or 3) through the C ABI.

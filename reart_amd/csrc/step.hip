@@ -58,7 +58,7 @@ static int step_plan(const reart_relax_config *c, StepPlan *p) {
     // pruned: ONE record per query (S = 1 in the consumers); the box slices are the waves of a search workgroup
     p->W1 = (c->tune_slices >= 1 && c->tune_slices <= 4) ? c->tune_slices : 3;
     p->W3 = (c->tune_slices_flow >= 1 && c->tune_slices_flow <= 4) ? c->tune_slices_flow : p->W1;
-    p->sparse = c->tune_sparse < 0 ? 0 : (c->tune_sparse == 0 ? 40 : (c->tune_sparse > 64 ? 64 : c->tune_sparse));
+    p->sparse = c->tune_sparse < 0 ? 0 : (c->tune_sparse == 0 ? 20 : (c->tune_sparse > 64 ? 64 : c->tune_sparse));
     p->S1 = p->pruned ? 1 : reart_knn_pick_split(waves1, c->N, 1);
     p->L1 = (int)reart_align_up((size_t)reart_div_up(c->N, p->S1), NN_BOX);
     p->Npad = p->L1 * p->S1;
@@ -592,25 +592,26 @@ __device__ __forceinline__ void order_body(const OrderArgs &o, const int j) {
 // cfg.profile: duration of the search launch that just ran = last workgroup end - first workgroup start (constant-rate
 // wall clock), and the distance evaluations it executed; accumulated on the device, read by reart_relax_profile
 __device__ __forceinline__ void prof_body(const OrderArgs &o) {
-    __shared__ unsigned long long s_lo[CG_BS / 64], s_hi[CG_BS / 64], s_sum[CG_BS / 64];
+    __shared__ unsigned long long s_lo[CG_BS / 64], s_hi[CG_BS / 64], s_sum[CG_BS / 64], s_busy[CG_BS / 64];
     const int tid = threadIdx.x;
-    unsigned long long lo = ~0ull, hi = 0ull, sum = 0ull;
+    unsigned long long lo = ~0ull, hi = 0ull, sum = 0ull, busy = 0ull;
     for (int k = tid; k < o.nprof; k += CG_BS) {
         const unsigned long long a = o.prof[2 * (size_t)k], b = o.prof[2 * (size_t)k + 1];
-        lo = a < lo ? a : lo; hi = b > hi ? b : hi; sum += o.prof_pairs[k];
+        lo = a < lo ? a : lo; hi = b > hi ? b : hi; sum += o.prof_pairs[k]; busy += b - a;
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
         const unsigned long long l2 = __shfl_xor(lo, off, 64), h2 = __shfl_xor(hi, off, 64), s2 = __shfl_xor(sum, off, 64);
-        lo = l2 < lo ? l2 : lo; hi = h2 > hi ? h2 : hi; sum += s2;
+        const unsigned long long b2 = __shfl_xor(busy, off, 64);
+        lo = l2 < lo ? l2 : lo; hi = h2 > hi ? h2 : hi; sum += s2; busy += b2;
     }
-    if ((tid & 63) == 0) { s_lo[tid >> 6] = lo; s_hi[tid >> 6] = hi; s_sum[tid >> 6] = sum; }
+    if ((tid & 63) == 0) { s_lo[tid >> 6] = lo; s_hi[tid >> 6] = hi; s_sum[tid >> 6] = sum; s_busy[tid >> 6] = busy; }
     __syncthreads();
     if (tid == 0) {
         for (int w = 1; w < CG_BS / 64; ++w) {
-            lo = s_lo[w] < lo ? s_lo[w] : lo; hi = s_hi[w] > hi ? s_hi[w] : hi; sum += s_sum[w];
+            lo = s_lo[w] < lo ? s_lo[w] : lo; hi = s_hi[w] > hi ? s_hi[w] : hi; sum += s_sum[w]; busy += s_busy[w];
         }
-        o.prof_acc[0] += 1ull; o.prof_acc[1] += hi - lo; o.prof_acc[2] += sum;
+        o.prof_acc[0] += 1ull; o.prof_acc[1] += hi - lo; o.prof_acc[2] += sum; o.prof_acc[3] += busy;
     }
 }
 struct PostArgs { FlowArgs fl; CGradArgs cg; OrderArgs od; int nfx, nflow, ncx, nwork, norder; };
@@ -757,7 +758,7 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
     if (p.pruned) {
         SearchArgs sa = {};
         sa.G = B * nqg; sa.S1 = p.W1; sa.S3 = p.W3; sa.sparse = p.sparse; sa.interleave = c.tune_xcd > 0 ? 0 : 1;
-        sa.cloud_resident = c.tune_cloud >= 0 ? 1 : 0;
+        sa.cloud_resident = c.tune_cloud > 0 ? 1 : 0; sa.cloud_slices = c.tune_cloud > 0 ? c.tune_cloud : 0;
         if (chamfer) { sa.k1[0] = ka.job[0]; sa.k1[1] = ka.job[1]; sa.n1 = 2; }
         if (c.use_flow) { sa.k3 = k3.job[0]; sa.n3 = 1; }
         if (c.profile && merged) {
@@ -940,7 +941,9 @@ extern "C" int reart_relax_step_timed(const reart_relax_config *cfg, const reart
 
 // cfg.profile: the search launch of every iteration leaves per-workgroup wall-clock stamps, reduced on the device by
 // the consumer launch (prof_body).  h_out[0] launches, [1] summed duration in SECONDS (last workgroup end - first
-// workgroup start, constant-rate clock), [2] distance evaluations executed, [3] the clock rate in Hz.  Synchronises
+// workgroup start, constant-rate clock), [2] distance evaluations executed, [3] the clock rate in Hz, [4] the summed
+// lifetimes of all search workgroups in seconds (divided by the launches and the workgroup slots of the chip: the
+// duration a perfectly balanced launch would have).  Synchronises
 // the stream; reset != 0 zeroes the accumulators afterwards.
 extern "C" int reart_relax_profile(const reart_relax_config *cfg, void *workspace, size_t workspace_bytes,
                                    void *stream, double *h_out, int reset) {
@@ -960,6 +963,7 @@ extern "C" int reart_relax_profile(const reart_relax_config *cfg, void *workspac
         return REART_ERR_LAUNCH;
     const double hz = 1e3 * (double)khz;
     h_out[0] = (double)acc[0]; h_out[1] = (double)acc[1] / hz; h_out[2] = (double)acc[2]; h_out[3] = hz;
+    h_out[4] = (double)acc[3] / hz;
     if (reset && hipMemsetAsync((char *)workspace + p.o_prof_acc, 0, sizeof(acc), st) != hipSuccess) return REART_ERR_LAUNCH;
     return REART_OK;
 }

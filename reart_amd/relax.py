@@ -27,7 +27,7 @@ class RelaxConfig(ctypes.Structure):
 def tuning_from_env(env=None):
     """Experiment switches of the library, read ONCE per engine on the host (the library itself never looks at the
     environment): REART_SEARCH=brute, REART_PRUNE_SPLIT / REART_PRUNE_SPLIT3 (waves per search workgroup, 1..4),
-    REART_SPARSE (0 = dense scans only, 1..16), REART_FWD_PTS (64|32), REART_BWD_PTS (64|32|16), REART_REORDER=0, REART_CLOUD=0 (search targets from global memory instead of an LDS copy), REART_XCD=1 (one run of frames per XCD)."""
+    REART_SPARSE (0 = dense scans only, 1..16), REART_FWD_PTS (64|32), REART_BWD_PTS (64|32|16), REART_REORDER=0, REART_CLOUD=1|2|4|8 (cloud-resident search: targets from an LDS copy, that many box slices per query group), REART_XCD=1 (one run of frames per XCD)."""
     env = os.environ if env is None else env
     geti = lambda k: int(env[k]) if env.get(k, "") != "" else None
     t = {}
@@ -41,8 +41,8 @@ def tuning_from_env(env=None):
         t["tune_sparse"] = -1 if geti("REART_SPARSE") <= 0 else geti("REART_SPARSE")
     if env.get("REART_REORDER") == "0":
         t["tune_reorder"] = -1
-    if env.get("REART_CLOUD") == "0":
-        t["tune_cloud"] = -1
+    if geti("REART_CLOUD") is not None:
+        t["tune_cloud"] = max(0, geti("REART_CLOUD"))
     if env.get("REART_XCD") == "1":
         t["tune_xcd"] = 1
     return t
@@ -330,11 +330,12 @@ class RelaxEngine:
         """``profile=True`` engines: what the search launches did since the last reset, measured on the device in every
         iteration (eager or graph replay) -> dict(launches, seconds, pairs, clock_hz); seconds = sum over launches of
         (last workgroup end - first workgroup start).  Synchronises."""
-        out = (ctypes.c_double * 4)()
+        out = (ctypes.c_double * 5)()
         rc = _lib_fns().reart_relax_profile(ctypes.byref(self.cfg), _lib.ptr(self.workspace), self.workspace.numel(),
                                             _lib.stream(), out, int(bool(reset)))
         _lib.check(rc, "reart_relax_profile")
-        return {"launches": int(out[0]), "seconds": float(out[1]), "pairs": int(out[2]), "clock_hz": float(out[3])}
+        return {"launches": int(out[0]), "seconds": float(out[1]), "pairs": int(out[2]), "clock_hz": float(out[3]),
+                "workgroup_seconds": float(out[4])}
 
     def loss_log(self):
         """(iterations done, tensor [min(iter, ring), 4]: recon, lambda*flow, total, tau); syncs."""

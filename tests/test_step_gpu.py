@@ -181,10 +181,11 @@ def test_search_variants_give_identical_trajectories(dev):
     seq = make_sequence(T=6, n_parts=4, pts_per_part=300, seed=3, n_ref=700, with_flow=True)
     cano, pcs = split_canonical(seq["complete"], 2)
     runs = {}
-    variants = (("pruned", {}), ("global_targets", {"tune_cloud": -1}), ("global_dense", {"tune_cloud": -1, "tune_sparse": -1}), ("dense", {"tune_sparse": -1}), ("sparse8", {"tune_sparse": 8}),
-                ("sparse3", {"tune_sparse": 3}), ("queue64", {"tune_sparse": 64}), ("split1", {"tune_slices": 1, "tune_cloud": -1}), ("split2_flow4", {"tune_slices": 2, "tune_slices_flow": 4, "tune_cloud": -1}),
-                ("split4_dense", {"tune_slices": 4, "tune_sparse": -1, "tune_cloud": -1}), ("static_order", {"tune_reorder": -1, "tune_cloud": -1}),
-                ("xcd_chunks", {"tune_xcd": 1, "tune_cloud": -1}), ("profiled", {"profile": 1}), ("fwd64", {"tune_fwd_pts": 64}),
+    variants = (("pruned", {}), ("cloud1", {"tune_cloud": 1}), ("cloud2_dense", {"tune_cloud": 2, "tune_sparse": -1}), ("cloud8", {"tune_cloud": 8}),
+                ("global_targets", {"tune_cloud": 0}), ("global_dense", {"tune_cloud": 0, "tune_sparse": -1}), ("dense", {"tune_sparse": -1}), ("sparse8", {"tune_sparse": 8}),
+                ("sparse3", {"tune_sparse": 3}), ("queue64", {"tune_sparse": 64}), ("split1", {"tune_slices": 1, "tune_cloud": 0}), ("split2_flow4", {"tune_slices": 2, "tune_slices_flow": 4, "tune_cloud": 0}),
+                ("split4_dense", {"tune_slices": 4, "tune_sparse": -1, "tune_cloud": 0}), ("static_order", {"tune_reorder": -1, "tune_cloud": 0}),
+                ("xcd_chunks", {"tune_xcd": 1, "tune_cloud": 0}), ("profiled", {"profile": 1}), ("fwd64", {"tune_fwd_pts": 64}),
                 ("brute", {"search_mode": 1}), ("bwd64", {"tune_bwd_pts": 64}), ("bwd16", {"tune_bwd_pts": 16}))
     for name, tuning in variants:
         torch.manual_seed(0)
