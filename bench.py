@@ -205,7 +205,9 @@ def bench_kinematic(args, dev, rank, world, distributed, barrier):
     a = rr.build_parser().parse_args(["--model", "kinematic", "--use_flow_loss", "--use_assign_loss", "--assign_iter", "0",
                                       "--downsample", str(args.downsample), "--assign_gap", str(args.assign_gap),
                                       "--cano_idx", str(cano_idx), "--n_iter", "15000"])
-    kin = rr.build_kinematic_from_base(result, cano, pcs, a).to(dev)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):     # build_graph prints like the reference does; stdout is ONE JSON line
+        kin = rr.build_kinematic_from_base(result, cano, pcs, a).to(dev)
     t_ = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
     refs, flows = [t_(r) for r in seq["ref_loc"]], [t_(f) for f in seq["ref_flow"]]
     loop = rr.OperatorLoop(a, kin, cano, pcs, refs, flows)

@@ -203,7 +203,7 @@ typedef struct reart_relax_config {
      * variable in any call path: the caller decides once per instance (reart_amd/relax.py maps REART_* variables
      * to these fields when an engine is built), so the ranks of a job cannot diverge mid-run. */
     int search_mode;         /* 0: exact box-pruned warm-started search (default); 1: cold brute force (same results) */
-    int tune_slices;         /* waves (box slices) per search workgroup, 1..4 (default 3)  */
+    int tune_slices;         /* waves (box slices) per search workgroup, 1..4 (default 4)  */
     int tune_slices_flow;    /* the same for the K = 3 flow search (default: tune_slices)  */
     int tune_sparse;         /* boxes needed by <= n queries of a wave go through the (query, box) queue instead of a  */
                              /* 64-lane scan: 1..64 (default 20), < 0: dense scans only                                */
@@ -429,6 +429,14 @@ int reart_lap_auction_warm(const float *cost, int B, int n, int32_t *col4row, in
 int reart_lap_resolve(const float *cost, int B, int n, int32_t *col4row, int32_t *certified,
                       const double *price_in, double *price_out, void *workspace, size_t workspace_bytes,
                       void *stream);
+
+/* The same re-solve for Euclidean costs between two point sets, without a cost matrix: src, tgt [B,n,3], n <= 2048;
+ * c_ij is the value reart_cdist(src, tgt) would hold (same fp32 expression), recomputed from LDS copies of both sets
+ * wherever the solver needs a cost -- a path-search step then reads no memory beyond LDS.  Result identical to
+ * reart_lap_resolve on reart_cdist's matrix. */
+int reart_lap_resolve_points(const float *src, const float *tgt, int B, int n, int32_t *col4row,
+                             int32_t *certified, const double *price_in, double *price_out, void *workspace,
+                             size_t workspace_bytes, void *stream);
 
 /* Cost matrices for the above: replaces `torch.cdist(pc_src, pc_tgt)` (run_robot.py:171, utils/model_utils.py:93).
  *   a [B,n,3], b [B,m,3] -> out [B,n,m] = Euclidean distance, sqrt(((dx*dx)+(dy*dy))+(dz*dz)) in fp32. */

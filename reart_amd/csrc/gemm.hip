@@ -18,8 +18,10 @@
 #include <math.h>
 
 #define GM_BM 128
-#define GM_BK 16   // measured: 32 is slower (8.3 vs 6.7 ms for the extractor: the Cin = 6 layers pad twice as far, fewer resident waves)
-#define GM_LDA (GM_BK + 1)   // +1: column reads by 32 lanes hit 32 different banks
+// K step per layer (template parameter BK): 8 for the Cin = 6 first layers (they pad to the step), 32 for wide layers
+// (half the barriers per flop), 16 otherwise.  One step for all was measured: 32 everywhere is slower than 16 everywhere
+// (8.3 vs 6.7 ms for the extractor: the Cin = 6 layers pad twice as far).
+// LDA = BK + 1: column reads by 32 lanes hit 32 different banks
 
 typedef float f16v __attribute__((ext_vector_type(16)));
 
@@ -73,9 +75,10 @@ __device__ __forceinline__ float gemm_load_a(const GemmArgs &a, const ARow &w, i
 // NB = number of 32-column accumulators per wave: the workgroup tile is 128 rows x 32 NB columns.  The
 // layers pick the NB that wastes the fewest columns (Cout = 32 -> 1, 64 -> 2, 96 -> 3); wider layers use
 // NB = 2 (NB = 4 reuses the A fragment four times but halves the resident waves: measured slower).
-template <int NB>
+template <int NB, int BK>
 __global__ __launch_bounds__(256) void mlp_gemm_kernel(GemmArgs a) {
     constexpr int BN = 32 * NB, LDB = BN + 4;
+    constexpr int GM_BK = BK, GM_LDA = BK + 1;
     __shared__ float As[GM_BM * GM_LDA];
     __shared__ float Bs[GM_BK * LDB];
     __shared__ float Pm[4][BN];
@@ -211,13 +214,18 @@ extern "C" int reart_mlp_layer(const float *X, int ldx, const int64_t *gather_id
     a.xyz_first = xyz_first; a.Wt = Wt; a.bias = bias; a.rows = rows; a.Cin = Cin; a.Cout = Cout; a.relu = relu;
     a.pool_k = pool_k; a.Y = Y; a.ldy = ldy; a.ycol0 = ycol0;
     const int NB = Cout <= 32 ? 1 : (Cout <= 64 ? 2 : (Cout <= 96 ? 3 : 2));   // measured: NB = 4 for wide layers is slower (7.5 vs 6.7 ms)
+    const int BK = Cin <= 8 ? 8 : 16;   // measured: 32 for the wide layers is slower (7.76 vs 6.72 ms for the extractor)
     const dim3 grid(reart_div_up(rows, GM_BM), reart_div_up(Cout, 32 * NB));
+    hipStream_t st = (hipStream_t)stream;
+#define GM_LAUNCH(NBv, BKv) hipLaunchKernelGGL((mlp_gemm_kernel<NBv, BKv>), grid, dim3(256), 0, st, a)
+#define GM_PICK(NBv) do { if (BK == 8) GM_LAUNCH(NBv, 8); else if (BK == 32) GM_LAUNCH(NBv, 32); else GM_LAUNCH(NBv, 16); } while (0)
     switch (NB) {
-        case 1: hipLaunchKernelGGL(mlp_gemm_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a); break;
-        case 2: hipLaunchKernelGGL(mlp_gemm_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, a); break;
-        case 3: hipLaunchKernelGGL(mlp_gemm_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, a); break;
-        default: hipLaunchKernelGGL(mlp_gemm_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, a); break;
+        case 1: GM_PICK(1); break;
+        case 2: GM_PICK(2); break;
+        default: GM_PICK(3); break;
     }
+#undef GM_PICK
+#undef GM_LAUNCH
     REART_CHECK_LAUNCH();
     return REART_OK;
 }

@@ -111,18 +111,19 @@ __device__ __forceinline__ void lap_merge_top2(double ov1, int oj1, double ov2, 
 
 // largest entry seen by this thread of the workgroup's matrix: 16-byte loads, eight in flight per thread (one pass
 // over n*n floats; a scalar strided loop here cost more than the certificate pass)
+template <int BS>
 __device__ __forceinline__ float lap_matrix_max(const float *__restrict__ C, size_t total, int tid) {
     float m = 0.f;
     const size_t n4 = ((((uintptr_t)C) & 15) == 0) ? total / 4 : 0;
     const float4 *C4 = (const float4 *)C;
-    for (size_t e0 = tid; e0 < n4; e0 += (size_t)LAP_BS * 8) {
+    for (size_t e0 = tid; e0 < n4; e0 += (size_t)BS * 8) {
         float4 v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = C4[e0 + (size_t)u * LAP_BS < n4 ? e0 + (size_t)u * LAP_BS : e0];
+        for (int u = 0; u < 8; ++u) v[u] = C4[e0 + (size_t)u * BS < n4 ? e0 + (size_t)u * BS : e0];
 #pragma unroll
         for (int u = 0; u < 8; ++u) m = fmaxf(m, fmaxf(fmaxf(v[u].x, v[u].y), fmaxf(v[u].z, v[u].w)));
     }
-    for (size_t e = 4 * n4 + tid; e < total; e += LAP_BS) m = fmaxf(m, C[e]);
+    for (size_t e = 4 * n4 + tid; e < total; e += BS) m = fmaxf(m, C[e]);
     return m;
 }
 
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
     const float *C = a.cost + (size_t)b * n * n;
 
     // largest cost
-    double mx = (double)lap_matrix_max(C, (size_t)n * n, tid);
+    double mx = (double)lap_matrix_max<LAP_BS>(C, (size_t)n * n, tid);
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
     if (lane == 0) s_red[wv] = mx;
@@ -457,7 +458,10 @@ extern "C" int reart_lap_auction_warm(const float *cost, int B, int n, int32_t *
 // potentials are nearly right -- against the tens of thousands of bids the auction needs from the same start.
 // The result is certified exactly like the auction's (same Jacobi rounds on the potentials).
 // ------------------------------------------------------------------------------------------------------------
-#define JV_CPT 4   // columns per thread: n <= 4096
+// BS threads per workgroup (one matrix each); JV_CPT = 4096 / BS columns per thread.  Fewer waves make a Dijkstra step
+// cheaper (the arg-min meets in fewer LDS slots, the barrier joins fewer waves) but the row-scan passes slower.
+#define JV_PTS_NMAX 2048   // points form: both point sets + the solver state must fit in LDS
+#define JV_PTS_BS 512
 struct JvArgs {
     const float *cost; int B, n;
     int *col4row;              // in: previous assignment (or -1), out: the optimum
@@ -468,29 +472,88 @@ struct JvArgs {
     int *stats;                // nullable [B][4]: released rows, rows left for the path search, Dijkstra steps, certificate rounds
                                // + 256 * row-reduction steps
     double keep_tol;           // fraction of the largest cost
+    // PTS form: no cost matrix; c_ij = sqrt(((dx*dx)+(dy*dy))+(dz*dz)) of src point i and tgt point j, the expression of
+    // reart_cdist, evaluated where it is needed from copies of both point sets in LDS
+    const float *src, *tgt;    // [B][n][3]
 };
 
-__global__ __launch_bounds__(LAP_BS) void lap_jv_kernel(JvArgs a) {
+// smallest (value, column) and second smallest value of c_ij + p_j over the columns of row i, costs from the points
+__device__ __forceinline__ void lap_row_top2_pts(float ax, float ay, float az, const float *__restrict__ tx,
+                                                 const float *__restrict__ ty, const float *__restrict__ tz,
+                                                 const double *__restrict__ p, int n, int lane, double &v1, int &j1, double &v2) {
+    v1 = INFINITY; v2 = INFINITY; j1 = 0x7fffffff;
+    for (int j0 = lane; j0 < n; j0 += 64 * 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + 64 * u;
+            if (j < n) {
+                const double v = (double)sqrtf(reart_sqdist3(ax, ay, az, tx[j], ty[j], tz[j])) + p[j];
+                if (v < v1) { v2 = v1; v1 = v; j1 = j; }
+                else if (v < v2) v2 = v;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const double ov1 = __shfl_xor(v1, o, 64), ov2 = __shfl_xor(v2, o, 64);
+        const int oj1 = __shfl_xor(j1, o, 64);
+        const bool take = (ov1 < v1) || (ov1 == v1 && oj1 < j1);
+        const double lose = take ? v1 : ov1;
+        v2 = fmin(fmin(v2, ov2), lose);
+        v1 = take ? ov1 : v1;
+        j1 = take ? oj1 : j1;
+    }
+}
+
+template <int BS, bool PTS>
+__global__ __launch_bounds__(BS) void lap_jv_kernel(JvArgs a) {
+    constexpr int JV_CPT = (PTS ? JV_PTS_NMAX : LAP_NMAX) / BS;
     extern __shared__ __attribute__((aligned(16))) unsigned char lsm[];
     const int n = a.n, b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    constexpr int NW = LAP_BS / 64;
+    constexpr int NW = BS / 64;
     double *price = (double *)lsm;            // [n]
     double *u = price + n;                    // [n] row potentials
     int *owner = (int *)(u + n);              // [n] column -> row
     int *assigned = owner + n;                // [n] row -> column
     int *pred = assigned + n;                 // [n] column -> row it was reached from
     int *flist = pred + n;                    // [n] free rows / arg-min columns
+    float *psx = (float *)(flist + n);        // PTS: src x|y|z [3][n], tgt x|y|z [3][n]
+    float *psy = psx + n, *psz = psy + n, *ptx = psz + n, *pty = ptx + n, *ptz = pty + n;
     __shared__ double s_rv[2][NW];
     __shared__ int s_rj[2][NW];
     __shared__ double s_red[NW];
     __shared__ int s_cnt, s_flag;
-    const float *C = a.cost + (size_t)b * n * n;
+    const float *C = PTS ? nullptr : a.cost + (size_t)b * n * n;
+    // c_ij for any (i, j), and the row scan, through one interface
+    auto cost_at = [&](int i, int j) -> float {
+        return PTS ? sqrtf(reart_sqdist3(psx[i], psy[i], psz[i], ptx[j], pty[j], ptz[j])) : C[(size_t)i * n + j];
+    };
+    auto row_top2 = [&](int i, const double *pr, double &v1, int &j1, double &v2) {
+        if (PTS) lap_row_top2_pts(psx[i], psy[i], psz[i], ptx, pty, ptz, pr, n, lane, v1, j1, v2);
+        else lap_row_top2(C + (size_t)i * n, pr, n, lane, v1, j1, v2);
+    };
 
-    double mx = (double)lap_matrix_max(C, (size_t)n * n, tid);
+    double mx;
+    if (PTS) {
+        // both point sets into LDS; the tolerances only need the scale of the costs: the diagonal of the clouds' box
+        float lo = INFINITY, hi = -INFINITY;
+        const float *S_ = a.src + (size_t)b * n * 3, *T_ = a.tgt + (size_t)b * n * 3;
+        for (int e = tid; e < 3 * n; e += BS) {
+            const float sv = S_[e], tv = T_[e];
+            (e % 3 == 0 ? psx : (e % 3 == 1 ? psy : psz))[e / 3] = sv;
+            (e % 3 == 0 ? ptx : (e % 3 == 1 ? pty : ptz))[e / 3] = tv;
+            lo = fminf(lo, fminf(sv, tv)); hi = fmaxf(hi, fmaxf(sv, tv));
+        }
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+        for (int o = 32; o >= 1; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o, 64)); hi = fmaxf(hi, __shfl_xor(hi, o, 64)); }
+        mx = 1.7320508 * (double)(hi - lo);
+    } else {
+        mx = (double)lap_matrix_max<BS>(C, (size_t)n * n, tid);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+    }
     if (lane == 0) s_red[wv] = mx;
-    for (int j = tid; j < n; j += LAP_BS) {
+    for (int j = tid; j < n; j += BS) {
         price[j] = a.price_in ? a.price_in[(size_t)b * n + j] : 0.0;
         owner[j] = -1;
         const int c = a.col4row[(size_t)b * n + j];
@@ -503,22 +566,22 @@ __global__ __launch_bounds__(LAP_BS) void lap_jv_kernel(JvArgs a) {
     if (!(mx > 0.0)) mx = 1.0;
     const double keep_tol = mx * a.keep_tol;
     // previous pairs: a repeated column keeps its lowest row
-    for (int i = tid; i < n; i += LAP_BS)
+    for (int i = tid; i < n; i += BS)
         if (assigned[i] >= 0) atomicMin((unsigned int *)&owner[assigned[i]], (unsigned int)i);   // -1 = 0xffffffff: empty
     __syncthreads();
-    for (int i = tid; i < n; i += LAP_BS)
+    for (int i = tid; i < n; i += BS)
         if (assigned[i] >= 0 && owner[assigned[i]] != i) assigned[i] = -1;
     __syncthreads();
     // row potentials under the old prices; pairs that lost their arg-min are released
     for (int i = wv; i < n; i += NW) {
         double v1, v2;
         int j1;
-        lap_row_top2(C + (size_t)i * n, price, n, lane, v1, j1, v2);
+        row_top2(i, price, v1, j1, v2);
         if (lane == 0) {
             const int j = assigned[i];
             u[i] = v1; flist[i] = j1;
             if (j >= 0) {
-                const double cur = (double)C[(size_t)i * n + j] + price[j];
+                const double cur = (double)cost_at(i, j) + price[j];
                 if (cur - v1 > keep_tol) { assigned[i] = -1; owner[j] = -1; }
                 else u[i] = cur;                      // the kept pair is tight by definition
             }
@@ -527,23 +590,23 @@ __global__ __launch_bounds__(LAP_BS) void lap_jv_kernel(JvArgs a) {
     __syncthreads();
     int st_freed = 0, st_left = 0, st_steps = 0, st_cert = 0;
     // greedy: a free row takes its arg-min column when nobody owns it (lowest row wins)
-    for (int i = tid; i < n; i += LAP_BS)
+    for (int i = tid; i < n; i += BS)
         if (assigned[i] < 0) atomicAdd(&s_cnt, 1);
-    for (int j = tid; j < n; j += LAP_BS) pred[j] = 0x7fffffff;
+    for (int j = tid; j < n; j += BS) pred[j] = 0x7fffffff;
     __syncthreads();
     st_freed = s_cnt;
-    for (int i = tid; i < n; i += LAP_BS)
+    for (int i = tid; i < n; i += BS)
         if (assigned[i] < 0 && owner[flist[i]] < 0) atomicMin(&pred[flist[i]], i);
     __syncthreads();
-    for (int i = tid; i < n; i += LAP_BS)
+    for (int i = tid; i < n; i += BS)
         if (assigned[i] < 0 && owner[flist[i]] < 0 && pred[flist[i]] == i) assigned[i] = flist[i];
     __syncthreads();
-    for (int i = tid; i < n; i += LAP_BS)
+    for (int i = tid; i < n; i += BS)
         if (assigned[i] >= 0) owner[assigned[i]] = i;
     if (tid == 0) s_cnt = 0;
     __syncthreads();
     // the rows still free, in ascending order (deterministic)
-    for (int i0 = 0; i0 < n; i0 += LAP_BS) {
+    for (int i0 = 0; i0 < n; i0 += BS) {
         const int i = i0 + tid;
         const bool fr = i < n && assigned[i] < 0;
         const unsigned long long m = __ballot(fr);
@@ -572,7 +635,7 @@ __global__ __launch_bounds__(LAP_BS) void lap_jv_kernel(JvArgs a) {
                 for (;;) {
                     double v1, v2;
                     int j1;
-                    lap_row_top2(C + (size_t)i * n, price, n, lane, v1, j1, v2);
+                    row_top2(i, price, v1, j1, v2);
                     const int i0 = owner[j1];
                     const bool tie = !(v1 < v2);
                     if (budget-- <= 0 || (tie && i0 >= 0)) {
@@ -606,6 +669,23 @@ __global__ __launch_bounds__(LAP_BS) void lap_jv_kernel(JvArgs a) {
     st_steps = 0;
 
     // ---- one shortest augmenting path per free row
+    float tcx[JV_CPT], tcy[JV_CPT], tcz[JV_CPT];       // PTS: this thread's columns (target points), in registers
+#pragma unroll
+    for (int k = 0; k < JV_CPT; ++k) {
+        const int j = tid + k * BS < n ? tid + k * BS : 0;
+        tcx[k] = PTS ? ptx[j] : 0.f; tcy[k] = PTS ? pty[j] : 0.f; tcz[k] = PTS ? ptz[j] : 0.f;
+    }
+    auto row_costs = [&](int i, float (&rc)[JV_CPT]) {
+        if (PTS) {
+            const float ax = psx[i], ay = psy[i], az = psz[i];
+#pragma unroll
+            for (int k = 0; k < JV_CPT; ++k) rc[k] = sqrtf(reart_sqdist3(ax, ay, az, tcx[k], tcy[k], tcz[k]));
+        } else {
+            const float *row = C + (size_t)i * n;
+#pragma unroll
+            for (int k = 0; k < JV_CPT; ++k) rc[k] = row[tid + k * BS < n ? tid + k * BS : 0];
+        }
+    };
     bool solved = true;
     for (int f = 0; f < nfree; ++f) {
         const int i0 = flist[f];
@@ -613,11 +693,12 @@ __global__ __launch_bounds__(LAP_BS) void lap_jv_kernel(JvArgs a) {
         unsigned scanned = 0u;
         {
             const double ui = u[i0];
-            const float *row = C + (size_t)i0 * n;
+            float rc0[JV_CPT];
+            row_costs(i0, rc0);
 #pragma unroll
             for (int k = 0; k < JV_CPT; ++k) {
-                const int j = tid + k * LAP_BS;
-                d[k] = j < n ? ((double)row[j] + price[j]) - ui : INFINITY;
+                const int j = tid + k * BS;
+                d[k] = j < n ? ((double)rc0[k] + price[j]) - ui : INFINITY;
                 if (j < n) pred[j] = i0;
                 if (j >= n) scanned |= 1u << k;
             }
@@ -630,7 +711,7 @@ __global__ __launch_bounds__(LAP_BS) void lap_jv_kernel(JvArgs a) {
             int bj = 0x7fffffff;
 #pragma unroll
             for (int k = 0; k < JV_CPT; ++k)
-                if (!((scanned >> k) & 1u) && d[k] < bv) { bv = d[k]; bj = tid + k * LAP_BS; }
+                if (!((scanned >> k) & 1u) && d[k] < bv) { bv = d[k]; bj = tid + k * BS; }
 #pragma unroll
             for (int o = 32; o >= 1; o >>= 1) {
                 const double ov = __shfl_xor(bv, o, 64);
@@ -651,18 +732,17 @@ __global__ __launch_bounds__(LAP_BS) void lap_jv_kernel(JvArgs a) {
             mu = bv;
             const int jstar = bj;
             if (jstar == 0x7fffffff || !(bv < INFINITY)) break;   // only with non-finite costs: the matrix is reported uncertified
-            if ((jstar & (LAP_BS - 1)) == tid) scanned |= 1u << (jstar / LAP_BS);
+            if ((jstar & (BS - 1)) == tid) scanned |= 1u << (jstar / BS);
             const int i = owner[jstar];
             if (i < 0) { sink = jstar; break; }
-            // the step's ONE dependent global read: every column's cost in that row, all loads in flight together
-            const float *row = C + (size_t)i * n;
+            // the step's costs: every column of this thread in row i (matrix form: the ONE dependent global read of
+            // the step, all loads in flight together; points form: no memory beyond LDS at all)
             float rc[JV_CPT];
-#pragma unroll
-            for (int k = 0; k < JV_CPT; ++k) rc[k] = row[tid + k * LAP_BS < n ? tid + k * LAP_BS : tid];
+            row_costs(i, rc);
             const double ui = u[i];
 #pragma unroll
             for (int k = 0; k < JV_CPT; ++k) {
-                const int j = tid + k * LAP_BS;
+                const int j = tid + k * BS;
                 if (!((scanned >> k) & 1u)) {
                     const double nd = mu + (((double)rc[k] + price[j]) - ui);
                     if (nd < d[k]) { d[k] = nd; pred[j] = i; }
@@ -673,7 +753,7 @@ __global__ __launch_bounds__(LAP_BS) void lap_jv_kernel(JvArgs a) {
         // potentials: fixed columns (all labelled ones except the sink) and their rows
 #pragma unroll
         for (int k = 0; k < JV_CPT; ++k) {
-            const int j = tid + k * LAP_BS;
+            const int j = tid + k * BS;
             if (j < n && ((scanned >> k) & 1u) && j != sink) {
                 const double delta = mu - d[k];
                 price[j] += delta;
@@ -707,48 +787,69 @@ __global__ __launch_bounds__(LAP_BS) void lap_jv_kernel(JvArgs a) {
         for (int i = wv; i < n; i += NW) {
             double v1, v2;
             int j1;
-            lap_row_top2(C + (size_t)i * n, dd, n, lane, v1, j1, v2);
+            row_top2(i, dd, v1, j1, v2);
             if (lane == 0) {
                 const int j = assigned[i];
-                const double cur = (double)C[(size_t)i * n + j] + dd[j];
-                pb[i] = (cur - v1 > tol) ? v1 - (double)C[(size_t)i * n + j] : dd[j];
+                const double cur = (double)cost_at(i, j) + dd[j];
+                pb[i] = (cur - v1 > tol) ? v1 - (double)cost_at(i, j) : dd[j];
                 if (cur - v1 > tol) s_flag = 1;
             }
         }
         __syncthreads();
         const int changed = s_flag;
-        for (int i = tid; i < n; i += LAP_BS) dd[assigned[i]] = pb[i];
+        for (int i = tid; i < n; i += BS) dd[assigned[i]] = pb[i];
         __syncthreads();
         if (!changed) { certified = 1; break; }
     }
-    for (int i = tid; i < n; i += LAP_BS) a.col4row[(size_t)b * n + i] = assigned[i];
+    for (int i = tid; i < n; i += BS) a.col4row[(size_t)b * n + i] = assigned[i];
     if (a.price_out)
-        for (int j = tid; j < n; j += LAP_BS) a.price_out[(size_t)b * n + j] = dd[j];
+        for (int j = tid; j < n; j += BS) a.price_out[(size_t)b * n + j] = dd[j];
     if (tid == 0) a.certified[b] = certified;
     if (tid == 0 && a.stats) { int *o = a.stats + 4 * b; o[0] = st_freed; o[1] = st_left; o[2] = st_steps; o[3] = st_cert + (st_arr << 8); }
 }
 
 // Re-solve from the assignment in col4row and the potentials in price_in (both from an earlier solve of a similar batch,
-// reart_lap_auction* or this function); same outputs and the same certificate as reart_lap_auction.
+// reart_lap_auction* or these functions); same outputs and the same certificate as reart_lap_auction.
+template <bool PTS>
+static int jv_launch(JvArgs a, void *workspace, size_t workspace_bytes, void *stream) {
+    if (a.B < 0 || a.n < 1 || a.n > (PTS ? JV_PTS_NMAX : LAP_NMAX)) return REART_ERR_INVALID_ARG;
+    if (a.B == 0) return REART_OK;
+    if (!a.col4row || !a.certified || !a.price_in) return REART_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < reart_lap_workspace_bytes(a.B, a.n)) return REART_ERR_INVALID_ARG;
+    if (!a.price_out) a.price_out = (double *)workspace;
+    a.max_rounds_cert = 4 * a.n; a.keep_tol = 1e-12;
+    a.stats = (int *)((char *)workspace + reart_align_up(sizeof(double) * (size_t)a.B * a.n, 256));
+    const size_t lds = (size_t)a.n * (2 * 8 + 4 * 4 + (PTS ? 6 * 4 : 0));
+    constexpr int JVBS = PTS ? JV_PTS_BS : 256;
+    if (lds > REART_LDS_DEFAULT_CAP &&
+        hipFuncSetAttribute((const void *)lap_jv_kernel<JVBS, PTS>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)
+        return REART_ERR_LAUNCH;
+    hipLaunchKernelGGL((lap_jv_kernel<JVBS, PTS>), dim3(a.B), dim3(JVBS), lds, (hipStream_t)stream, a);
+    REART_CHECK_LAUNCH();
+    return REART_OK;
+}
+
 extern "C" int reart_lap_resolve(const float *cost, int B, int n, int32_t *col4row, int32_t *certified,
                                  const double *price_in, double *price_out, void *workspace, size_t workspace_bytes,
                                  void *stream) {
-    if (B < 0 || n < 1 || n > LAP_NMAX || n > JV_CPT * LAP_BS) return REART_ERR_INVALID_ARG;
-    if (B == 0) return REART_OK;
-    if (!cost || !col4row || !certified || !price_in) return REART_ERR_INVALID_ARG;
-    if (!workspace || workspace_bytes < reart_lap_workspace_bytes(B, n)) return REART_ERR_INVALID_ARG;
+    if (!cost && B > 0) return REART_ERR_INVALID_ARG;
     JvArgs a = {};
-    a.cost = cost; a.B = B; a.n = n; a.col4row = col4row; a.certified = certified; a.price_in = price_in;
-    a.price_out = price_out ? price_out : (double *)workspace;
-    a.max_rounds_cert = 4 * n; a.keep_tol = 1e-12;
-    a.stats = (int *)((char *)workspace + reart_align_up(sizeof(double) * (size_t)B * n, 256));
-    const size_t lds = (size_t)n * (2 * 8 + 4 * 4);
-    if (lds > REART_LDS_DEFAULT_CAP &&
-        hipFuncSetAttribute((const void *)lap_jv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)
-        return REART_ERR_LAUNCH;
-    hipLaunchKernelGGL(lap_jv_kernel, dim3(B), dim3(LAP_BS), lds, (hipStream_t)stream, a);
-    REART_CHECK_LAUNCH();
-    return REART_OK;
+    a.cost = cost; a.B = B; a.n = n; a.col4row = col4row; a.certified = certified; a.price_in = price_in; a.price_out = price_out;
+    return jv_launch<false>(a, workspace, workspace_bytes, stream);
+}
+
+// The same re-solve for Euclidean costs between two point sets WITHOUT a cost matrix: c_ij = the value reart_cdist(src,
+// tgt) would hold, bit for bit, recomputed from copies of both sets in LDS wherever a cost is needed -- a Dijkstra step
+// then touches no memory beyond LDS (with a matrix it is one dependent 4n-byte row read from HBM: the matrices of a batch
+// do not fit any cache).  n <= 2048 (both sets + the solver state in 160 KB of LDS).
+extern "C" int reart_lap_resolve_points(const float *src, const float *tgt, int B, int n, int32_t *col4row,
+                                        int32_t *certified, const double *price_in, double *price_out, void *workspace,
+                                        size_t workspace_bytes, void *stream) {
+    if ((!src || !tgt) && B > 0) return REART_ERR_INVALID_ARG;
+    JvArgs a = {};
+    a.src = src; a.tgt = tgt; a.B = B; a.n = n; a.col4row = col4row; a.certified = certified; a.price_in = price_in;
+    a.price_out = price_out;
+    return jv_launch<true>(a, workspace, workspace_bytes, stream);
 }
 
 // ------------------------------------------------------------------------------------------------------------

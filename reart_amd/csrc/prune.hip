@@ -207,22 +207,29 @@ __device__ __forceinline__ void knn_pruned_wave(const KnnJob &jb, const int S, c
             pairs += (unsigned)__builtin_popcountll(__ballot(valid)) * NN_BOX;
             const float4 qc = ((const float4 *)s_qc)[ql];
             const float *tp = tx_g + j0;
-            float4 X[4], Y[4], Z[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                X[u] = *(const float4 *)(tp + 4 * u);
-                Y[u] = *(const float4 *)(tp + cstride + 4 * u);
-                Z[u] = *(const float4 *)(tp + 2 * cstride + 4 * u);
-            }
             const f2 cx = {qc.x, qc.x}, cy = {qc.y, qc.y}, cz = {qc.z, qc.z};
             float mh[2] = {INFINITY, INFINITY};
+            // one half box (8 targets: six 16-byte loads) at a time: the twelve loads of a whole box in flight cost 24 more
+            // VGPRs than the rest of the kernel needs, i.e. a resident wave per SIMD
+#pragma unroll 1
+            for (int hf = 0; hf < 2; ++hf) {
+                float4 X[2], Y[2], Z[2];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const f2 dxa = cx - f2{X[u].x, X[u].y}, dya = cy - f2{Y[u].x, Y[u].y}, dza = cz - f2{Z[u].x, Z[u].y};
-                const f2 dxb = cx - f2{X[u].z, X[u].w}, dyb = cy - f2{Y[u].z, Y[u].w}, dzb = cz - f2{Z[u].z, Z[u].w};
-                const f2 da = (dxa * dxa + dya * dya) + dza * dza;
-                const f2 db = (dxb * dxb + dyb * dyb) + dzb * dzb;
-                mh[u >> 1] = fminf(fminf(mh[u >> 1], fminf(da.x, da.y)), fminf(db.x, db.y));
+                for (int u = 0; u < 2; ++u) {
+                    X[u] = *(const float4 *)(tp + 8 * hf + 4 * u);
+                    Y[u] = *(const float4 *)(tp + cstride + 8 * hf + 4 * u);
+                    Z[u] = *(const float4 *)(tp + 2 * cstride + 8 * hf + 4 * u);
+                }
+                float m = INFINITY;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const f2 dxa = cx - f2{X[u].x, X[u].y}, dya = cy - f2{Y[u].x, Y[u].y}, dza = cz - f2{Z[u].x, Z[u].y};
+                    const f2 dxb = cx - f2{X[u].z, X[u].w}, dyb = cy - f2{Y[u].z, Y[u].w}, dzb = cz - f2{Z[u].z, Z[u].w};
+                    const f2 da = (dxa * dxa + dya * dya) + dza * dza;
+                    const f2 db = (dxb * dxb + dyb * dyb) + dzb * dzb;
+                    m = fminf(fminf(m, fminf(da.x, da.y)), fminf(db.x, db.y));
+                }
+                if (hf == 0) mh[0] = m; else mh[1] = m;
             }
             if (KK == 1) {
                 const float m = fminf(mh[0], mh[1]);
@@ -824,7 +831,7 @@ __global__ __launch_bounds__(256) void knn_warm_finish_kernel(KnnArgs a) {
 struct WarmPlan { int S, Ppad; size_t o_soa, o_box, o_pd, o_pi, total; };
 static int warm_plan(int N, int P1, int P2, int K, WarmPlan *p) {
     if (N < 0 || P1 < 0 || P2 < 0 || (K != 1 && K != 3)) return REART_ERR_INVALID_ARG;
-    p->S = 3;                                                             // waves per search workgroup
+    p->S = 4;                                                             // waves per search workgroup
     while (p->S > 1 && reart_div_up(P2, p->S) < 64) p->S -= 1;
     p->Ppad = (int)reart_align_up((size_t)(P2 > 0 ? P2 : 1), NN_BOX);
     size_t off = 0;

@@ -97,7 +97,7 @@ class OperatorLoop:
                                                                        cuda_mode=True))
 
     def iteration(self, i):
-        from reart_amd.utils.lap import cdist, linear_sum_assignment_batch
+        from reart_amd.utils.lap import cdist, linear_sum_assignment_batch, linear_sum_assignment_points
 
         args, model, cano_pc, pc_list = self.args, self.model, self.cano_pc, self.pc_list
         kwargs = {"tau": self.tau_func(cur_iter=i + 1)} if args.model == "base" else {}
@@ -108,8 +108,10 @@ class OperatorLoop:
             if self.matched is None or i % args.assign_gap == 0:  # run_robot.py:165-178
                 # certified optimum on the GPU; an uncertified matrix falls back to scipy on the host, so this is
                 # always the assignment the reference's linear_sum_assignment / parallel_lap returns
-                assign = linear_sum_assignment_batch(cdist(pc_src.detach(), self.tgt_pts), state=self.lap_state,
-                                                     warm_assignment=self.lap_state is not None)
+                if self.lap_state is not None:      # slowly moving problems: re-solve from the previous optimum
+                    assign = linear_sum_assignment_points(pc_src.detach(), self.tgt_pts, self.lap_state)
+                else:
+                    assign = linear_sum_assignment_batch(cdist(pc_src.detach(), self.tgt_pts))
                 self.lap_solves += 1
                 cols = torch.from_numpy(np.stack([c for _, c in assign])).to(cano_pc.device)    # rows are 0..n-1 in order
                 self.matched = self.tgt_pts.gather(1, cols[..., None].expand(-1, -1, 3))

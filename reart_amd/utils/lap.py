@@ -83,3 +83,46 @@ def linear_sum_assignment_batch(cost, return_stats=False, state=None, warm_assig
         st = ws[off:off + 16 * B].view(torch.int32).reshape(B, 4).cpu().numpy()
         return out, fallbacks, st
     return (out, fallbacks) if return_stats else out
+
+
+POINTS_NMAX = 2048   # reart_lap_resolve_points keeps both point sets and the solver state in LDS
+
+
+def linear_sum_assignment_points(src, tgt, state, return_stats=False):
+    """Optimal assignment for the Euclidean costs ``cdist(src, tgt)`` of two point batches [B,n,3] in a loop that
+    re-solves slowly moving problems (the kinematic projection, run_robot.py:165-178 with ``--assign_gap 1``).  ``state`` is
+    a dict the caller keeps between calls.  First call (or n > 2048): the cost matrices are built and solved like
+    ``linear_sum_assignment_batch(cdist(src, tgt), state=state, warm_assignment=True)``.  Later calls with n <= 2048 never
+    build a matrix: ``reart_lap_resolve_points`` re-solves from the previous optimum with the costs recomputed from the
+    points inside the kernel (bit-equal to ``cdist``'s values), certificate included.  Same return value."""
+    _lib.require_gpu(src, tgt)
+    src, tgt = src.detach().contiguous().float(), tgt.detach().contiguous().float()
+    B, n, _ = src.shape
+    warm = (state.get("prices") is not None and state.get("cols") is not None and tuple(state["prices"].shape) == (B, n)
+            and tuple(state["cols"].shape) == (B, n) and state["prices"].device == src.device)
+    if not warm or n > POINTS_NMAX:
+        return linear_sum_assignment_batch(cdist(src, tgt), return_stats=return_stats, state=state, warm_assignment=True)
+    L = _lib.lib()
+    col, prices = state["cols"].clone(), state["prices"]
+    cert = torch.empty((B,), dtype=torch.int32, device=src.device)
+    ws = _lib.workspace(L.reart_lap_workspace_bytes(B, n), src.device)
+    rc = L.reart_lap_resolve_points(_lib.ptr(src), _lib.ptr(tgt), B, n, _lib.ptr(col), _lib.ptr(cert), _lib.ptr(prices),
+                                    _lib.ptr(prices), _lib.ptr(ws), ws.numel(), _lib.stream())
+    _lib.check(rc, "reart_lap_resolve_points")
+    state["cols"] = col
+    col_h, cert_h = col.cpu().numpy().astype(np.int64), cert.cpu().numpy()
+    rows = np.arange(n, dtype=np.int64)
+    out, fallbacks = [], 0
+    for b in range(B):
+        if cert_h[b]:
+            out.append((rows, col_h[b]))
+        else:  # certificate did not close: exact host solve for this matrix
+            from scipy.optimize import linear_sum_assignment
+
+            fallbacks += 1
+            out.append(linear_sum_assignment(cdist(src[b:b + 1], tgt[b:b + 1])[0].cpu().numpy()))
+    if return_stats == "full":
+        off = ((8 * B * n + 255) // 256) * 256
+        st = ws[off:off + 16 * B].view(torch.int32).reshape(B, 4).cpu().numpy()
+        return out, fallbacks, st
+    return (out, fallbacks) if return_stats else out

@@ -156,3 +156,30 @@ def test_lap_resolve_sizes_and_garbage_starts(dev, n):
             np.testing.assert_array_equal(out[k][1], ref[k][1])
         if step == 0 and n >= 70:
             assert (st[:, 1] < n).all()          # the previous optimum is a useful start: not every row is searched again
+
+
+@pytest.mark.parametrize("n", [5, 130, 1024, 2048])
+def test_lap_resolve_points_equals_the_matrix_form(dev, n):
+    """reart_lap_resolve_points (costs recomputed from the points in LDS, no matrix): over a sequence of slowly moving
+    sources it returns the permutation scipy finds on cdist's matrix, and exactly what the matrix form returns."""
+    import oracle
+    from reart_amd.utils.lap import cdist, linear_sum_assignment_batch, linear_sum_assignment_points
+
+    rng = np.random.default_rng(100 + n)
+    a = rng.uniform(-0.3, 0.3, (3, n, 3)).astype(np.float32)
+    b = (a[:, rng.permutation(n)] + rng.normal(0, 0.004, (3, n, 3))).astype(np.float32)
+    tb = torch.from_numpy(b).to(dev)
+    st_pts, st_mat = {}, {}
+    for step in range(4):
+        ta = torch.from_numpy(a).to(dev)
+        out_p, fb_p, stats = linear_sum_assignment_points(ta, tb, st_pts, return_stats="full")
+        cost = cdist(ta, tb)
+        out_m = linear_sum_assignment_batch(cost, state=st_mat, warm_assignment=True)
+        ref = oracle.linear_sum_assignment(cost.cpu().numpy())
+        assert fb_p == 0
+        for k in range(3):
+            np.testing.assert_array_equal(out_p[k][1], ref[k][1])
+            np.testing.assert_array_equal(out_p[k][1], out_m[k][1])
+        if step > 0 and n >= 130:
+            assert (stats[:, 1] < n).all()
+        a = (a + rng.normal(0, 0.0015, a.shape)).astype(np.float32)

@@ -6,7 +6,7 @@ import numpy as np, torch
 import bench
 from reart_amd import run_robot as rr, tail
 from reart_amd.networks.pointnet2_utils import index_points
-from reart_amd.utils.lap import cdist, linear_sum_assignment_batch
+from reart_amd.utils.lap import cdist, linear_sum_assignment_batch, linear_sum_assignment_points
 
 dev = torch.device("cuda:0")
 T, N, cano_idx = 20, 4096, 10
@@ -32,7 +32,7 @@ for i in range(10, 30):
     pc_trans = out[0]
     (pc_src, ms) = T_(lambda: index_points(pc_trans, loop.src_idx)); acc["index"] = acc.get("index", 0) + ms
     (cost, ms) = T_(lambda: cdist(pc_src.detach(), loop.tgt_pts)); acc["cdist"] = acc.get("cdist", 0) + ms
-    (res, ms) = T_(lambda: linear_sum_assignment_batch(cost, return_stats="full", state=loop.lap_state, warm_assignment=True)); acc["lap"] = acc.get("lap", 0) + ms
+    (res, ms) = T_(lambda: linear_sum_assignment_points(pc_src.detach(), loop.tgt_pts, loop.lap_state, return_stats="full")); acc["lap (points form)"] = acc.get("lap (points form)", 0) + ms
     st = res[2]
     (_, ms) = T_(lambda: loop.iteration(i)); acc["whole iteration (incl. its own lap)"] = acc.get("whole iteration (incl. its own lap)", 0) + ms
     if i % 5 == 0:
