@@ -17,7 +17,7 @@ def tau_cosine(cur_iter, max_iter, end_temp, start_temp):
 class RelaxOracle:
     def __init__(self, cano, pc_list, W1, b1, W2, p6d, pt, cano_idx, refs=None, ref_flows=None,
                  lambda_flow=1.0, robust=False, smooth_weight=1e-2, trans_lr=1e-2, seg_lr=1e-3,
-                 n_iter=15000, start_tau=5.0, end_tau=1.0, euclidean=True):
+                 n_iter=15000, start_tau=5.0, end_tau=1.0, euclidean=True, weight_decay=0.0):
         f = lambda a: np.array(a, dtype=np.float32, copy=True, order="C")
         self.cano, self.pc_list = f(cano), f(pc_list)
         self.params = dict(W1=f(W1), b1=f(b1), W2=f(W2), p6d=f(p6d), pt=f(pt))
@@ -27,6 +27,7 @@ class RelaxOracle:
         self.lambda_flow, self.robust, self.smooth = lambda_flow, robust, smooth_weight
         self.lr = dict(W1=seg_lr, b1=seg_lr, W2=seg_lr, p6d=trans_lr, pt=trans_lr)
         self.n_iter, self.start_tau, self.end_tau, self.euclidean = n_iter, start_tau, end_tau, euclidean
+        self.weight_decay = np.float32(weight_decay)     # torch.optim.Adam(weight_decay=...): grad += wd * param (run_robot.py:146-148)
         self.it = 0
 
     def step(self, gumbel, tau=None, assign=None):
@@ -77,6 +78,9 @@ class RelaxOracle:
         g = base_backward(self.cano, p["W1"], p["b1"], p["W2"], p["p6d"], p["pt"], fw["y_soft"], fw["hard_idx"], tau, G)
         self.it += 1
         for k, gk in (("W1", "gW1"), ("b1", "gb1"), ("W2", "gW2"), ("p6d", "g6d"), ("pt", "gt")):
-            adam(p[k].reshape(-1), g[gk].reshape(-1), self.m[k].reshape(-1), self.v[k].reshape(-1), self.it, self.lr[k])
+            gr = g[gk].reshape(-1)
+            if self.weight_decay != 0:
+                gr = (gr + self.weight_decay * p[k].reshape(-1)).astype(np.float32)
+            adam(p[k].reshape(-1), gr, self.m[k].reshape(-1), self.v[k].reshape(-1), self.it, self.lr[k])
         return dict(recon=recon, flow=flow, total=recon + flow, tau=tau, pc_trans=X, G=G, grads=g,
                     seg_part=fw["seg_part"], hard_idx=fw["hard_idx"])

@@ -461,7 +461,9 @@ extern "C" int reart_lap_auction_warm(const float *cost, int B, int n, int32_t *
 // BS threads per workgroup (one matrix each); JV_CPT = 4096 / BS columns per thread.  Fewer waves make a Dijkstra step
 // cheaper (the arg-min meets in fewer LDS slots, the barrier joins fewer waves) but the row-scan passes slower.
 #define JV_PTS_NMAX 2048   // points form: both point sets + the solver state must fit in LDS
+#ifndef JV_PTS_BS
 #define JV_PTS_BS 512
+#endif
 struct JvArgs {
     const float *cost; int B, n;
     int *col4row;              // in: previous assignment (or -1), out: the optimum

@@ -88,6 +88,7 @@ class OperatorLoop:
         # (shortest augmenting paths, reart_lap_resolve); the base model's resampled labels make them jump: cold solves
         self.lap_state = {} if args.model == "kinematic" else None
         self.lap_solves = 0
+        self.lap_events = None      # set to [] to collect a (start, end) torch.cuda.Event pair around every re-solve
         if args.use_assign_loss:
             # run_robot.py:167-169: both FPS calls sample fixed clouds (start 0 on the reference's CUDA path): once
             num_fps = pc_list.shape[1] // args.downsample
@@ -108,10 +109,17 @@ class OperatorLoop:
             if self.matched is None or i % args.assign_gap == 0:  # run_robot.py:165-178
                 # certified optimum on the GPU; an uncertified matrix falls back to scipy on the host, so this is
                 # always the assignment the reference's linear_sum_assignment / parallel_lap returns
+                if self.lap_events is not None:
+                    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    ev[0].record()
                 if self.lap_state is not None:      # slowly moving problems: re-solve from the previous optimum
-                    assign = linear_sum_assignment_points(pc_src.detach(), self.tgt_pts, self.lap_state)
+                    assign, _, self.lap_stats = linear_sum_assignment_points(pc_src.detach(), self.tgt_pts, self.lap_state,
+                                                                             return_stats="full")
                 else:
                     assign = linear_sum_assignment_batch(cdist(pc_src.detach(), self.tgt_pts))
+                if self.lap_events is not None:
+                    ev[1].record()
+                    self.lap_events.append(ev)
                 self.lap_solves += 1
                 cols = torch.from_numpy(np.stack([c for _, c in assign])).to(cano_pc.device)    # rows are 0..n-1 in order
                 self.matched = self.tgt_pts.gather(1, cols[..., None].expand(-1, -1, 3))

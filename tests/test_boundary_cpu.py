@@ -106,3 +106,22 @@ def test_structure_wrappers_have_no_cpu_fallback():
                  lambda: compute_group_temporal_err(torch.zeros(2, 4, 3), torch.zeros(4, dtype=torch.long))):
         with pytest.raises(RuntimeError, match="no CPU fallback"):
             call()
+
+
+def test_relax_config_struct_matches_the_header():
+    """The ctypes mirror of reart_relax_config lists the header's fields in the header's order with the header's types
+    (a silent mismatch would shift every tuning field)."""
+    import ctypes
+    import re
+
+    from reart_amd.relax import RelaxConfig
+
+    hdr = open(os.path.join(ROOT, "include", "reart_hip.h")).read()
+    body = hdr[hdr.index("typedef struct reart_relax_config {"):hdr.index("} reart_relax_config;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for typ, names in re.findall(r"\b(int|float|uint64_t)\s+([a-zA-Z_0-9,\s]+);", body):
+        for nm in names.split(","):
+            fields.append((nm.strip(), typ))
+    ctype = {"int": ctypes.c_int, "float": ctypes.c_float, "uint64_t": ctypes.c_uint64}
+    assert [(n, ctype[t]) for n, t in fields] == list(RelaxConfig._fields_)

@@ -302,3 +302,36 @@ def test_full_size_sparse_scan_equals_dense_scan_over_a_run(dev, monkeypatch):
     assert np.isfinite(runs["dense"][0]).all()
     for a, b in zip(runs["sparse"], runs["dense"]):
         np.testing.assert_array_equal(a, b)
+
+
+def test_weight_decay_matches_oracle(oracle, dev):
+    """--weight_decay (torch.optim.Adam's L2 form, run_robot.py:146-148) on the fused engine: three iterations against the
+    oracle's Adam with grad += wd * param; and it changes the trajectory."""
+    from oracle.step import RelaxOracle
+    from reart_amd.relax import RelaxEngine
+
+    rng = np.random.default_rng(5)
+    N, P, B, H, cano_idx, wd = 200, 8, 3, 128, 1, 0.05
+    cano = rng.uniform(-0.3, 0.3, (N, 3)).astype(np.float32)
+    pcs = (cano[None] + rng.normal(0, 0.02, (B, N, 3))).astype(np.float32)
+    W1, b1 = rng.normal(0, 0.6, (H, 3)).astype(np.float32), rng.normal(0, 0.1, H).astype(np.float32)
+    W2 = rng.normal(0, 0.2, (P, H)).astype(np.float32)
+    p6d = (np.tile(np.array([1, 0, 0, 0, 1, 0], np.float32), (B, P, 1)) + rng.normal(0, 0.05, (B, P, 6))).astype(np.float32)
+    pt = rng.normal(0, 0.01, (B, P, 3)).astype(np.float32)
+    finals = {}
+    for decay in (wd, 0.0):
+        orc = RelaxOracle(cano, pcs, W1, b1, W2, p6d, pt, cano_idx, n_iter=50, weight_decay=decay)
+        model = _make_model(dev, P, B, W1, b1, W2, p6d, pt)
+        eng = RelaxEngine(t(cano, dev), t(pcs, dev), model, cano_idx, n_iter=50, weight_decay=decay)
+        nrng = np.random.default_rng(9)
+        for i in range(3):
+            noise = -np.log(nrng.exponential(size=(N, P))).astype(np.float32)
+            orc.step(noise)
+            eng.set_gumbel(t(noise, dev))
+            eng.step()
+        for k, prm in (("p6d", model.proposal_6d), ("pt", model.proposal_t), ("W2", model.seg_head.model[2].weight),
+                       ("W1", model.seg_head.model[0].weight), ("b1", model.seg_head.model[0].bias)):
+            got = prm.detach().cpu().numpy().reshape(orc.params[k].shape)
+            np.testing.assert_allclose(got, orc.params[k], rtol=0, atol=2e-5, err_msg=f"wd {decay} param {k}")
+        finals[decay] = model.seg_head.model[2].weight.detach().cpu().numpy().copy()
+    assert np.abs(finals[wd] - finals[0.0]).max() > 1e-5
