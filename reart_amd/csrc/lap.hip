@@ -507,6 +507,22 @@ __device__ __forceinline__ void lap_row_top2_pts(float ax, float ay, float az, c
     }
 }
 
+#ifdef REART_PRUNE_PHASE   // diagnostic build only (make -C reart_amd/csrc phase): s_memtime ticks of the path-search loop
+__device__ unsigned long long g_jv_phase[8];
+extern "C" int reart_debug_jv_phase(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_jv_phase), sizeof(g_jv_phase)) != hipSuccess) return REART_ERR_LAUNCH;
+    if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_jv_phase), z, sizeof(z)); }
+    return REART_OK;
+}
+#define JPH_DECL unsigned long long jph_t = __builtin_amdgcn_s_memtime(), jph[6] = {0, 0, 0, 0, 0, 0}
+#define JPH(k) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); jph[k] += n_ - jph_t; jph_t = n_; } while (0)
+#define JPH_FLUSH() do { if (threadIdx.x == 0) for (int k_ = 0; k_ < 6; ++k_) atomicAdd(&g_jv_phase[k_], jph[k_]); } while (0)
+#else
+#define JPH_DECL do { } while (0)
+#define JPH(k) do { } while (0)
+#define JPH_FLUSH() do { } while (0)
+#endif
+
 template <int BS, bool PTS>
 __global__ __launch_bounds__(BS) void lap_jv_kernel(JvArgs a) {
     constexpr int JV_CPT = (PTS ? JV_PTS_NMAX : LAP_NMAX) / BS;
@@ -670,6 +686,7 @@ __global__ __launch_bounds__(BS) void lap_jv_kernel(JvArgs a) {
     const int st_arr = st_steps;
     st_steps = 0;
 
+    JPH_DECL;
     // ---- one shortest augmenting path per free row
     float tcx[JV_CPT], tcy[JV_CPT], tcz[JV_CPT];       // PTS: this thread's columns (target points), in registers
 #pragma unroll
@@ -707,6 +724,7 @@ __global__ __launch_bounds__(BS) void lap_jv_kernel(JvArgs a) {
         }
         double mu = 0.0;
         int sink = -1;
+        JPH(5);
         for (int it = 0; ; ++it) {
             // closest unlabelled column: (distance, index) minimum over the workgroup
             double bv = INFINITY;
@@ -722,7 +740,9 @@ __global__ __launch_bounds__(BS) void lap_jv_kernel(JvArgs a) {
             }
             const int par = it & 1;
             if (lane == 0) { s_rv[par][wv] = bv; s_rj[par][wv] = bj; }
+            JPH(0);
             __syncthreads();
+            JPH(1);
             bv = s_rv[par][0]; bj = s_rj[par][0];
 #pragma unroll
             for (int w = 1; w < NW; ++w) {
@@ -733,6 +753,7 @@ __global__ __launch_bounds__(BS) void lap_jv_kernel(JvArgs a) {
             ++st_steps;
             mu = bv;
             const int jstar = bj;
+            JPH(2);
             if (jstar == 0x7fffffff || !(bv < INFINITY)) break;   // only with non-finite costs: the matrix is reported uncertified
             if ((jstar & (BS - 1)) == tid) scanned |= 1u << (jstar / BS);
             const int i = owner[jstar];
@@ -750,6 +771,7 @@ __global__ __launch_bounds__(BS) void lap_jv_kernel(JvArgs a) {
                     if (nd < d[k]) { d[k] = nd; pred[j] = i; }
                 }
             }
+            JPH(3);
         }
         if (sink < 0) { solved = false; break; }
         // potentials: fixed columns (all labelled ones except the sink) and their rows
@@ -777,6 +799,8 @@ __global__ __launch_bounds__(BS) void lap_jv_kernel(JvArgs a) {
         __syncthreads();
     }
 
+    JPH(4);
+    JPH_FLUSH();
     // ---- certificate (the auction's): Jacobi rounds on the potentials until every assigned column is an exact arg-min
     double *dd = price;
     double *pb = u;                            // scratch: the row potentials are not needed any more

@@ -580,9 +580,22 @@ __device__ __forceinline__ void order_body(const OrderArgs &o, const int j) {
         }
     }
     __syncthreads();
-    if (tid < 8) {   // exclusive prefix of the chunk's 256 counters, starting at the chunk's first position
-        unsigned int run = (unsigned int)(tid * o.per);
-        for (int e = tid * 256; e < tid * 256 + 256; ++e) { const unsigned int c = s_hist[e]; s_hist[e] = run; run += c; }
+    // exclusive prefix of every chunk's 256 counters, starting at the chunk's first position: each chunk by 64 lanes (four
+    // counters per lane + a wave scan) instead of a serial walk by one thread per chunk
+    for (int c0 = (tid >> 6); c0 < 8; c0 += CG_BS / 64) {
+        const int l = tid & 63;
+        unsigned int v[4], sum = 0u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[k] = s_hist[c0 * 256 + 4 * l + k]; sum += v[k]; }
+        unsigned int incl = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned int t = __shfl_up(incl, off, 64);
+            if (l >= off) incl += t;
+        }
+        unsigned int run = (unsigned int)(c0 * o.per) + (incl - sum);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { s_hist[c0 * 256 + 4 * l + k] = run; run += v[k]; }
     }
     __syncthreads();
 #pragma unroll

@@ -39,3 +39,14 @@ for i in range(10, 30):
         print("lap stats: released", st[:, 0].mean(), "left for paths", st[:, 1].mean(), "dijkstra steps", st[:, 2].mean(), "max", st[:, 2].max(), "ARR steps", (st[:, 3] >> 8).mean(), "cert", (st[:, 3] & 255).mean())
 for k, v in acc.items():
     print(f"{k:40s} {v / 20:8.3f} ms")
+
+import ctypes
+from reart_amd import _lib
+lib = ctypes.CDLL(_lib.LIB_PATH)
+if hasattr(lib, "reart_debug_jv_phase"):
+    buf = (ctypes.c_ulonglong * 8)()
+    lib.reart_debug_jv_phase(buf, 0)
+    v = list(buf); tot = sum(v[:6])
+    names = ["local + wave arg-min", "barrier wait", "merge of the waves' minima", "row costs + relaxation", "dual update + path flip", "search set-up"]
+    for n_, x in zip(names, v[:6]):
+        print(f"   {n_:30s} {100 * x / max(tot, 1):5.1f} %")
