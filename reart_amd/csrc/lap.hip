@@ -460,6 +460,7 @@ extern "C" int reart_lap_auction_warm(const float *cost, int B, int n, int32_t *
 // ------------------------------------------------------------------------------------------------------------
 // BS threads per workgroup (one matrix each); JV_CPT = 4096 / BS columns per thread.  Fewer waves make a Dijkstra step
 // cheaper (the arg-min meets in fewer LDS slots, the barrier joins fewer waves) but the row-scan passes slower.
+#define JV_OWNED (1 << 30)  // tie key of the path search's arg-min: owned columns after unowned ones
 #define JV_PTS_NMAX 2048   // points form: both point sets + the solver state must fit in LDS
 #ifndef JV_PTS_BS
 #define JV_PTS_BS 512
@@ -710,6 +711,12 @@ __global__ __launch_bounds__(BS) void lap_jv_kernel(JvArgs a) {
         const int i0 = flist[f];
         double d[JV_CPT];
         unsigned scanned = 0u;
+        // this thread's unowned columns: among columns at the SAME smallest distance an unowned one ends the search at once
+        // (any column at the minimum is a valid Dijkstra pick), so the arg-min's tie key puts them first
+        unsigned freecol = 0u;
+#pragma unroll
+        for (int k = 0; k < JV_CPT; ++k)
+            if (tid + k * BS < n && owner[tid + k * BS] < 0) freecol |= 1u << k;
         {
             const double ui = u[i0];
             float rc0[JV_CPT];
@@ -731,7 +738,10 @@ __global__ __launch_bounds__(BS) void lap_jv_kernel(JvArgs a) {
             int bj = 0x7fffffff;
 #pragma unroll
             for (int k = 0; k < JV_CPT; ++k)
-                if (!((scanned >> k) & 1u) && d[k] < bv) { bv = d[k]; bj = tid + k * BS; }
+                if (!((scanned >> k) & 1u)) {
+                    const int key = (tid + k * BS) | (((freecol >> k) & 1u) ? 0 : JV_OWNED);
+                    if (d[k] < bv || (d[k] == bv && key < bj)) { bv = d[k]; bj = key; }
+                }
 #pragma unroll
             for (int o = 32; o >= 1; o >>= 1) {
                 const double ov = __shfl_xor(bv, o, 64);
@@ -752,7 +762,7 @@ __global__ __launch_bounds__(BS) void lap_jv_kernel(JvArgs a) {
             }
             ++st_steps;
             mu = bv;
-            const int jstar = bj;
+            const int jstar = bj == 0x7fffffff ? bj : (bj & ~JV_OWNED);
             JPH(2);
             if (jstar == 0x7fffffff || !(bv < INFINITY)) break;   // only with non-finite costs: the matrix is reported uncertified
             if ((jstar & (BS - 1)) == tid) scanned |= 1u << (jstar / BS);
