@@ -210,7 +210,7 @@ def bench_kinematic(args, dev, rank, world, distributed, barrier):
         kin = rr.build_kinematic_from_base(result, cano, pcs, a).to(dev)
     t_ = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
     refs, flows = [t_(r) for r in seq["ref_loc"]], [t_(f) for f in seq["ref_flow"]]
-    loop = rr.OperatorLoop(a, kin, cano, pcs, refs, flows)
+    loop = rr.make_projection_loop(a, kin, cano, pcs, refs, flows)      # the autograd-free KinematicEngine for this command
     it = 0
     for _ in range(args.warmup):
         loop.iteration(it); it += 1
@@ -234,11 +234,12 @@ def bench_kinematic(args, dev, rank, world, distributed, barrier):
     # launch stream around every solve (kernel + certificate + the host's copy of the result)
     from reart_amd.networks.pointnet2_utils import index_points
     from reart_amd.utils.lap import cdist, linear_sum_assignment_batch
+    src_idx_b = loop.src_idx if loop.src_idx.dim() == 2 else loop.src_idx[None].expand(pcs.shape[0], -1)
     lap_ms = sum(e0.elapsed_time(e1) for e0, e1 in loop.lap_events) / max(len(loop.lap_events), 1)
     st = loop.lap_stats
     with torch.no_grad():
         pc_trans, _, _ = kin(cano)
-        cost = cdist(index_points(pc_trans, loop.src_idx), loop.tgt_pts)
+        cost = cdist(index_points(pc_trans, src_idx_b), loop.tgt_pts)
     n = cost.shape[1]
     ev0.record()
     linear_sum_assignment_batch(cost, state={}, warm_assignment=True)      # cold: epsilon-scaling auction on the matrices
@@ -263,7 +264,7 @@ def bench_kinematic(args, dev, rank, world, distributed, barrier):
     if not args.no_cpu_baseline and world == 1:
         import oracle
         cost_h = cost.cpu().numpy()
-        pa, pb = index_points(pc_trans, loop.src_idx).cpu(), loop.tgt_pts.cpu()
+        pa, pb = index_points(pc_trans, src_idx_b).cpu(), loop.tgt_pts.cpu()
         t1 = time.perf_counter()
         c_cpu = torch.cdist(pa, pb).numpy()
         oracle.parallel_lap(c_cpu, nproc=len(c_cpu))
@@ -286,7 +287,8 @@ def bench_kinematic(args, dev, rank, world, distributed, barrier):
                                f"{args.base_iters}-iteration relaxation result", "frames": T, "points": N,
                    "parts": int(trans_s.shape[1]), "assign_gap": args.assign_gap, "downsample": args.downsample,
                    "lap_solves_in_timed_region": loop.lap_solves - solves0 - 0,
-                   "parallelism": f"instances x{world}"},
+                   "parallelism": f"instances x{world}",
+                   "loop": type(loop).__name__},
         "roofline": roof, "cpu_baseline": cpu,
         "lap_stats_last": {"rows_released": st[:, 0].tolist(), "rows_searched": st[:, 1].tolist(),
                            "dijkstra_steps": st[:, 2].tolist(), "row_reduction_steps": (st[:, 3] >> 8).tolist(),

@@ -1,0 +1,194 @@
+"""Kinematic projection loop without autograd: the reference's loop body (run_robot.py:154-221) for ``--model kinematic``
+(networks/model.py:137-166, utils/kinematic_utils.py:151-198) as a fixed sequence of operator calls on the launch
+stream -- forward kinematics + rigid apply, assignment re-solve, assignment / flow gradients, the hand-derived FK backward
+and Adam (``reart_adam_step``) on the model's own parameter tensors, in place.  ``run_robot.OperatorLoop`` is the same
+iteration through PyTorch autograd and ``torch.optim.Adam``; ``tests/test_kinematic_engine_gpu.py`` holds the two together.
+
+What an iteration costs the host here: a dozen ctypes calls and, when the assignment is refreshed, the copy of its result.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from .networks.pointnet2_utils import farthest_point_sample, index_points
+from .utils.flow_utils import blend_anchor_motion
+from .utils.kinematic_utils import _effective_joint_values
+
+
+class KinematicEngine:
+    """State of one kinematic projection on one GPU.
+
+    ``model``: a ``KinematicModel`` without root motion whose ``axis_list`` / ``moment_list`` / ``theta_list`` (and
+    ``distance_list``) are optimised IN PLACE; ``cano_pc`` [N,3], ``pc_list`` [T-1,N,3]; ``pc_ref_list`` / ``flow_ref_list``:
+    the flow references of run_robot.py:81-84 or None.  Hyper-parameters carry the reference's flag names
+    (run_robot.py:362-420): ``trans_lr`` (Adam lr of every kinematic parameter, :150-151), ``weight_decay``,
+    ``use_assign_loss`` / ``assign_iter`` / ``assign_gap`` / ``downsample`` / ``lambda_assign``, ``lambda_flow``,
+    ``use_robust_loss``.  Without the assignment loss (or before ``assign_iter``) the Chamfer loss needs autograd-free
+    nearest-neighbour gradients that this engine does not carry: use ``OperatorLoop`` there.
+    """
+
+    def __init__(self, model, cano_pc, pc_list, cano_idx, pc_ref_list=None, flow_ref_list=None, trans_lr=1e-2,
+                 weight_decay=0.0, assign_iter=0, assign_gap=5, downsample=4, lambda_assign=3e-1, lambda_flow=1.0,
+                 use_robust_loss=False, smooth_weight=1e-2, knn_squared=False):
+        _lib.require_gpu(cano_pc, pc_list)
+        if hasattr(model, "root_6d"):
+            raise NotImplementedError("root motion (run_real / run_sapien variant) goes through OperatorLoop")
+        if model.joint_type_list is not None:
+            raise NotImplementedError("mixed joint types go through OperatorLoop")
+        self.model, self.dev = model, cano_pc.device
+        self.cano = cano_pc.contiguous().float()
+        self.pc_list = pc_list.contiguous().float()
+        self.cano_idx = int(cano_idx)
+        self.B, self.N = self.pc_list.shape[:2]
+        self.lr, self.wd = float(trans_lr), float(weight_decay)
+        self.assign_iter, self.assign_gap, self.lambda_assign = int(assign_iter), int(assign_gap), float(lambda_assign)
+        self.lambda_flow, self.robust, self.smooth = float(lambda_flow), bool(use_robust_loss), float(smooth_weight)
+        self.euclid = 0 if knn_squared else 1
+        self.refs = None
+        if pc_ref_list is not None:
+            self.refs = [(r.reshape(-1, 3).contiguous().float(), f.reshape(-1, 3).contiguous().float())
+                         for r, f in zip(pc_ref_list, flow_ref_list)]
+            assert len(self.refs) == self.B
+        with torch.no_grad():
+            self.part = model.seg_forward(self.cano).contiguous().long()      # fixed: label transfer from the model's own cloud
+        self.parent, self.edge_of, self.order = model._tree(self.dev)
+        self.P = int(self.parent.shape[0])
+        # parameters in the order torch.optim.Adam would see them (model.parameters())
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        for p in self.params:
+            assert p.is_cuda and p.is_contiguous() and p.dtype == torch.float32
+        self.m = [torch.zeros_like(p) for p in self.params]
+        self.v = [torch.zeros_like(p) for p in self.params]
+        self.grads = {id(p): torch.zeros_like(p) for p in self.params}
+        self.step_count = 0
+        # run_robot.py:167-169: both FPS calls sample fixed clouds (start 0 on the reference's CUDA path): once
+        num_fps = self.N // int(downsample)
+        zero = torch.zeros(1, dtype=torch.long, device=self.dev)
+        self.src_idx = farthest_point_sample(self.cano[None], num_fps, start=zero, cuda_mode=True)[0]          # [n]
+        tgt_idx = farthest_point_sample(self.pc_list, num_fps, start=zero.expand(self.B), cuda_mode=True)
+        self.tgt_pts = index_points(self.pc_list, tgt_idx).contiguous()                                         # [B,n,3]
+        self.matched = None
+        self.lap_state = {}
+        self.lap_solves = 0
+        self.lap_events = None
+        self.lap_stats = None
+        self.trans = torch.empty((self.B, self.P, 4, 4), dtype=torch.float32, device=self.dev)
+        self.pc_trans = torch.empty((self.B, self.N, 3), dtype=torch.float32, device=self.dev)
+        self.G = torch.zeros((self.B, self.N, 3), dtype=torch.float32, device=self.dev)
+        self.losses = {}
+
+    # ---- pieces -----------------------------------------------------------------------------------------------------
+    def _joint_values(self):
+        m = self.model
+        dist = m.distance_list if hasattr(m, "distance_list") else None
+        return _effective_joint_values(m.theta_list, dist, m.joint_type_list)
+
+    def forward(self):
+        """pc_trans [T-1,N,3] and trans_list of the current parameters (no graph kept)."""
+        L = _lib.lib()
+        m = self.model
+        theta, dist = self._joint_values()
+        B, E = theta.shape
+        rc = L.reart_fk_forward(_lib.ptr(self.parent), _lib.ptr(self.edge_of), _lib.ptr(self.order), self.P,
+                                _lib.ptr(m.axis_list), _lib.ptr(m.moment_list), _lib.ptr(theta), _lib.ptr(dist), B, E,
+                                _lib.ptr(self.trans), _lib.stream())
+        _lib.check(rc, "reart_fk_forward")
+        rc = L.reart_compute_pc_transform(_lib.ptr(self.cano), _lib.ptr(self.trans), _lib.ptr(self.part), self.N, self.P,
+                                          B, _lib.ptr(self.pc_trans), _lib.stream())
+        _lib.check(rc, "reart_compute_pc_transform")
+        return self.pc_trans
+
+    def _backward(self):
+        """dL/d pc_trans (self.G) -> gradients of axis / moment / theta (/ distance)."""
+        L = _lib.lib()
+        m = self.model
+        theta, dist = self._joint_values()
+        B, E = theta.shape
+        g_axis, g_moment, g_theta = self.grads[id(m.axis_list)], self.grads[id(m.moment_list)], self.grads[id(m.theta_list)]
+        g_dist = self.grads[id(m.distance_list)] if hasattr(m, "distance_list") else None
+        ws = _lib.workspace(L.reart_fk_backward_workspace_bytes(self.P, B, E), self.dev)
+        rc = L.reart_fk_backward(_lib.ptr(self.cano), _lib.ptr(self.part), _lib.ptr(self.G), self.N, _lib.ptr(self.parent),
+                                 _lib.ptr(self.edge_of), _lib.ptr(self.order), self.P, _lib.ptr(m.axis_list),
+                                 _lib.ptr(m.moment_list), _lib.ptr(theta), _lib.ptr(dist), B, E, _lib.ptr(self.trans),
+                                 _lib.ptr(g_axis), _lib.ptr(g_moment), _lib.ptr(g_theta), _lib.ptr(g_dist), _lib.ptr(ws),
+                                 ws.numel(), _lib.stream())
+        _lib.check(rc, "reart_fk_backward")
+
+    def _adam(self):
+        L = _lib.lib()
+        self.step_count += 1
+        for p, m_, v_ in zip(self.params, self.m, self.v):
+            g = self.grads[id(p)]
+            if self.wd != 0.0:
+                g = g + self.wd * p.detach()          # torch.optim.Adam's L2 form
+            rc = L.reart_adam_step(_lib.ptr(p), _lib.ptr(g), _lib.ptr(m_), _lib.ptr(v_), p.numel(), self.step_count,
+                                   self.lr, 0.9, 0.999, 1e-8, _lib.stream())
+            _lib.check(rc, "reart_adam_step")
+
+    def _flow_terms(self):
+        """lambda_flow * flow_loss and its gradient added to self.G (run_robot.py:194-209)."""
+        from .networks.loss import _FlowLoss  # the operator below it is reart_flow_loss
+
+        L = _lib.lib()
+        c = self.cano_idx
+        comp = torch.cat((self.pc_trans[:c], self.cano[None], self.pc_trans[c:]), dim=0)          # [T,N,3]
+        gt = torch.empty((self.B, self.N, 3), dtype=torch.float32, device=self.dev)
+        mask = torch.empty((self.B, self.N), dtype=torch.bool, device=self.dev)
+        for f, (r, fl) in enumerate(self.refs):
+            ws = _lib.workspace(L.reart_blend_anchor_motion_workspace_bytes(self.N, r.shape[0], 3), self.dev)
+            rc = L.reart_blend_anchor_motion(_lib.ptr(comp[f]), _lib.ptr(r), _lib.ptr(fl), self.N, r.shape[0], 3, self.euclid,
+                                             _lib.ptr(gt[f]), _lib.ptr(mask[f]), _lib.ptr(ws), ws.numel(), _lib.stream())
+            _lib.check(rc, "reart_blend_anchor_motion")
+        pred = (comp[1:] - comp[:-1]).contiguous()
+        loss = torch.empty((), dtype=torch.float32, device=self.dev)
+        gp = torch.empty_like(pred)
+        ws = _lib.workspace(L.reart_flow_loss_workspace_bytes(), self.dev)
+        rc = L.reart_flow_loss(_lib.ptr(gt), _lib.ptr(pred), _lib.ptr(mask), self.B, self.N, int(self.robust), self.smooth,
+                               _lib.ptr(loss), _lib.ptr(gp), _lib.ptr(ws), ws.numel(), _lib.stream())
+        _lib.check(rc, "reart_flow_loss")
+        gp = gp * self.lambda_flow
+        # pred = comp[1:] - comp[:-1]: +gp to frame f+1, -gp to frame f; the canonical frame takes no gradient
+        gc = torch.zeros_like(comp)
+        gc[1:] += gp
+        gc[:-1] -= gp
+        self.G += torch.cat((gc[:c], gc[c + 1:]), dim=0)
+        return loss * self.lambda_flow
+
+    # ---- the iteration ----------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def iteration(self, i):
+        """Iteration i of run_robot.py:154-221 in the assignment-loss branch; returns the loss dictionary (device tensors)."""
+        from .utils.lap import linear_sum_assignment_points
+
+        if i < self.assign_iter:
+            raise NotImplementedError("the Chamfer branch of the kinematic loop runs through OperatorLoop")
+        self.forward()
+        pc_src = self.pc_trans[:, self.src_idx]                                                   # [B,n,3]
+        if self.matched is None or i % self.assign_gap == 0:                                      # run_robot.py:165-178
+            if self.lap_events is not None:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
+            assign, _, self.lap_stats = linear_sum_assignment_points(pc_src, self.tgt_pts, self.lap_state, return_stats="full")
+            self.lap_solves += 1
+            cols = torch.from_numpy(np.stack([c for _, c in assign])).to(self.dev)
+            self.matched = self.tgt_pts.gather(1, cols[..., None].expand(-1, -1, 3))
+            if self.lap_events is not None:
+                ev[1].record()
+                self.lap_events.append(ev)
+        diff = pc_src - self.matched
+        ass = self.lambda_assign * (diff * diff).sum()                                            # run_robot.py:181-184
+        self.G.zero_()
+        self.G[:, self.src_idx] = (2.0 * self.lambda_assign) * diff
+        losses = {"opt assignment loss": ass}
+        total = ass
+        if self.refs is not None:
+            fl = self._flow_terms()
+            losses["flow Loss"] = fl
+            total = total + fl
+        losses["total Loss"] = total
+        self._backward()
+        self._adam()
+        self.losses = losses
+        return losses

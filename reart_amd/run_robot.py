@@ -149,6 +149,23 @@ class OperatorLoop:
         return losses
 
 
+def make_projection_loop(args, model, cano_pc, pc_list, pc_ref_list=None, flow_ref_list=None, tau_func=None):
+    """The loop object for phase 2: the autograd-free ``KinematicEngine`` for the kinematic projection as the reference's
+    README runs it (``--model kinematic --use_assign_loss --assign_iter 0``, revolute joints, no root motion); every
+    other combination -- Chamfer iterations before ``assign_iter``, root motion, mixed joint types, the base model outside
+    the fused engine -- goes through ``OperatorLoop`` (PyTorch autograd + torch.optim.Adam over the same operators)."""
+    if (args.model == "kinematic" and args.use_assign_loss and args.assign_iter == 0 and not hasattr(model, "root_6d")
+            and model.joint_type_list is None):
+        from reart_amd.kinematic_engine import KinematicEngine
+
+        return KinematicEngine(model, cano_pc, pc_list, args.cano_idx, pc_ref_list if args.use_flow_loss else None,
+                               flow_ref_list if args.use_flow_loss else None, trans_lr=args.trans_lr,
+                               weight_decay=args.weight_decay, assign_iter=0, assign_gap=args.assign_gap,
+                               downsample=args.downsample, lambda_assign=args.lambda_assign, lambda_flow=args.lambda_flow,
+                               use_robust_loss=args.use_robust_loss)
+    return OperatorLoop(args, model, cano_pc, pc_list, pc_ref_list, flow_ref_list, tau_func)
+
+
 def build_kinematic_from_base(result, cano_pc, pc_list, args):
     """run_robot.py:101-124: KinematicModel from a base result (dict with pred_cano_part, pred_pose_list and, when the
     base run already extracted it, joint_connection)."""
@@ -303,7 +320,7 @@ def main(args):
                     snapshot(i - 1, {"opt assignment loss": row[0], "flow Loss": row[1], "total Loss": row[2]})
     # ---- phase 2 (kinematic model; base model without the engine): the reference's loop with HIP operators
     if i < n_iter and not args.evaluate:
-        loop = OperatorLoop(args, model, cano_pc, pc_list, pc_ref_list, flow_ref_list, tau_func)
+        loop = make_projection_loop(args, model, cano_pc, pc_list, pc_ref_list, flow_ref_list, tau_func)
         while i < n_iter:
             losses = loop.iteration(i)
             if i % args.snapshot_gap == 0 or i == n_iter - 1:
