@@ -483,13 +483,14 @@ struct JvArgs {
 // smallest (value, column) and second smallest value of c_ij + p_j over the columns of row i, costs from the points
 __device__ __forceinline__ void lap_row_top2_pts(float ax, float ay, float az, const float *__restrict__ tx,
                                                  const float *__restrict__ ty, const float *__restrict__ tz,
-                                                 const double *__restrict__ p, int n, int lane, double &v1, int &j1, double &v2) {
+                                                 const double *__restrict__ p, int jb, int je, int lane, double &v1, int &j1,
+                                                 double &v2) {
     v1 = INFINITY; v2 = INFINITY; j1 = 0x7fffffff;
-    for (int j0 = lane; j0 < n; j0 += 64 * 4) {
+    for (int j0 = jb + lane; j0 < je; j0 += 64 * 4) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int j = j0 + 64 * u;
-            if (j < n) {
+            if (j < je) {
                 const double v = (double)sqrtf(reart_sqdist3(ax, ay, az, tx[j], ty[j], tz[j])) + p[j];
                 if (v < v1) { v2 = v1; v1 = v; j1 = j; }
                 else if (v < v2) v2 = v;
@@ -548,8 +549,27 @@ __global__ __launch_bounds__(BS) void lap_jv_kernel(JvArgs a) {
         return PTS ? sqrtf(reart_sqdist3(psx[i], psy[i], psz[i], ptx[j], pty[j], ptz[j])) : C[(size_t)i * n + j];
     };
     auto row_top2 = [&](int i, const double *pr, double &v1, int &j1, double &v2) {
-        if (PTS) lap_row_top2_pts(psx[i], psy[i], psz[i], ptx, pty, ptz, pr, n, lane, v1, j1, v2);
+        if (PTS) lap_row_top2_pts(psx[i], psy[i], psz[i], ptx, pty, ptz, pr, 0, n, lane, v1, j1, v2);
         else lap_row_top2(C + (size_t)i * n, pr, n, lane, v1, j1, v2);
+    };
+    // the same triple with the row's columns split over the workgroup's waves, and the row that owns the winning column;
+    // every thread gets them.  The owner is read BEFORE the barrier (by the wave that proposes the column), so the
+    // caller may rewrite owner[] right after the call; a second barrier must follow before the next call.
+    __shared__ double s_pv1[NW], s_pv2[NW];
+    __shared__ int s_pj1[NW], s_pi0[NW];
+    auto row_top2_block = [&](int i, const double *pr, double &v1, int &j1, double &v2, int &i0) {
+        const int len = (((n + NW - 1) / NW) + 3) & ~3, jb = min(n, wv * len), je = min(n, (wv + 1) * len);
+        if (PTS) lap_row_top2_pts(psx[i], psy[i], psz[i], ptx, pty, ptz, pr, jb, je, lane, v1, j1, v2);
+        else lap_row_top2_range(C + (size_t)i * n, pr, jb, je, lane, v1, j1, v2);
+        if (lane == 0) { s_pv1[wv] = v1; s_pj1[wv] = j1; s_pv2[wv] = v2; s_pi0[wv] = j1 < n ? owner[j1] : -1; }
+        __syncthreads();
+        v1 = s_pv1[0]; j1 = s_pj1[0]; v2 = s_pv2[0]; i0 = s_pi0[0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) {
+            const int before = j1;
+            lap_merge_top2(s_pv1[w], s_pj1[w], s_pv2[w], v1, j1, v2);
+            i0 = j1 != before ? s_pi0[w] : i0;
+        }
     };
 
     double mx;
@@ -643,9 +663,9 @@ __global__ __launch_bounds__(BS) void lap_jv_kernel(JvArgs a) {
     // the column's price rises by the gap to the row's second-cheapest column, which keeps every dual constraint and
     // makes the new pair tight -- and the row it displaces is handled next.  One row scan per step, no search: most of
     // the rows a small change of the costs has released settle here.  Exact ties and the rows left when the step budget
-    // runs out go to the path search below.  (One wave: the chain is sequential; LDS traffic of a wave is in order.)
-    if (wv == 0 && nfree > 0) {
-        int ncur = nfree, budget = 8 * nfree + 64;
+    // runs out go to the path search below.  The chain is sequential; each row scan is split over the waves.
+    {
+        int ncur = nfree, budget = 8 * nfree + 64;          // uniform over the workgroup: every thread follows the chain
         int *next = pred;                                   // not needed before the path search
         for (int pass = 0; pass < 2 && ncur > 0; ++pass) {
             int nnext = 0;
@@ -654,32 +674,31 @@ __global__ __launch_bounds__(BS) void lap_jv_kernel(JvArgs a) {
                 for (;;) {
                     double v1, v2;
                     int j1;
-                    row_top2(i, price, v1, j1, v2);
-                    const int i0 = owner[j1];
+                    int i0;
+                    row_top2_block(i, price, v1, j1, v2, i0);
                     const bool tie = !(v1 < v2);
-                    if (budget-- <= 0 || (tie && i0 >= 0)) {
-                        if (lane == 0) { next[nnext] = i; u[i] = v1; }
-                        ++nnext;
-                        break;
+                    const bool stop = budget-- <= 0 || (tie && i0 >= 0);
+                    if (tid == 0) {
+                        if (stop) { next[nnext] = i; u[i] = v1; }
+                        else {
+                            if (!tie) price[j1] += v2 - v1;
+                            u[i] = tie ? v1 : v2;
+                            assigned[i] = j1; owner[j1] = i;
+                            if (i0 >= 0) assigned[i0] = -1;
+                        }
                     }
-                    if (lane == 0) {
-                        if (!tie) price[j1] += v2 - v1;
-                        u[i] = tie ? v1 : v2;
-                        assigned[i] = j1; owner[j1] = i;
-                        if (i0 >= 0) assigned[i0] = -1;
-                    }
-                    __threadfence_block();
+                    __syncthreads();
+                    if (stop) { ++nnext; break; }
                     ++st_steps;
                     if (i0 < 0) break;
                     i = i0;
                 }
             }
-            __threadfence_block();
-            for (int k = lane; k < nnext; k += 64) flist[k] = next[k];
-            __threadfence_block();
+            for (int k = tid; k < nnext; k += BS) flist[k] = next[k];
+            __syncthreads();
             ncur = nnext;
         }
-        if (lane == 0) s_cnt = ncur;
+        if (tid == 0) s_cnt = ncur;
     }
     __syncthreads();
     nfree = s_cnt;
