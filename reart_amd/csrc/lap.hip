@@ -22,6 +22,18 @@
 
 #define LAP_BS 1024
 #define LAP_NMAX 4096
+// lap_auction_kernel: from phase LAP_SEARCH_PHASE on, the last LAP_SEARCH_NU free rows of a phase get one augmenting-path
+// search each instead of a bidding chain.  Measured on the tail's 19 x 4096^2 problems (tools/lap_cold.py): the early
+// phases' chains are long (up to 12 k links) but they are the price war that settles the duals -- cut short by a search
+// (which raises the prices by the least possible amount) the NEXT phase pays with 3-5x the rounds; from the 7th phase
+// on (eps <= 3e-6 of the largest cost) nothing is left to settle, the search is simply the shorter way to place the last
+// row, and its tighter prices halve the certificate's rounds (36 -> 19): 440 -> 395 ms.
+#ifndef LAP_SEARCH_PHASE
+#define LAP_SEARCH_PHASE 7
+#endif
+#ifndef LAP_SEARCH_NU
+#define LAP_SEARCH_NU 1
+#endif
 #define LAP_NLDS 2048   // up to here the rows' bids live in LDS too; above, in the workspace (36 B of LDS per row/column)
 
 struct LapArgs {
@@ -127,6 +139,40 @@ __device__ __forceinline__ float lap_matrix_max(const float *__restrict__ C, siz
     return m;
 }
 
+#ifdef REART_PRUNE_PHASE   // diagnostic build only (make -C reart_amd/csrc phase): s_memtime ticks of the path-search loop
+// [workgroup (first 32)][phase]: 0..5 the path search (arg-min | barrier | merge | row costs | flip | set-up), 6 = everything
+// before the row reduction, 7 = the row reduction, 8 = certificate + outputs
+__device__ unsigned long long g_jv_phase[32 * 10];
+extern "C" int reart_debug_jv_phase(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_jv_phase), sizeof(g_jv_phase)) != hipSuccess) return REART_ERR_LAUNCH;
+    if (reset) { static unsigned long long z[32 * 10]; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_jv_phase), z, sizeof(z)); }
+    return REART_OK;
+}
+__device__ unsigned long long g_auc_phase[32 * 10];   // the auction's: see tools/lap_cold.py for the phase names
+extern "C" int reart_debug_auction_phase(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_auc_phase), sizeof(g_auc_phase)) != hipSuccess) return REART_ERR_LAUNCH;
+    if (reset) { static unsigned long long z[32 * 10]; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_auc_phase), z, sizeof(z)); }
+    return REART_OK;
+}
+__device__ int g_auc_trace[32 * 4];   // workgroup 0, per phase: released rows | rounds | bids | search steps
+extern "C" int reart_debug_auction_trace(int *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_auc_trace), sizeof(g_auc_trace)) == hipSuccess ? REART_OK : REART_ERR_LAUNCH;
+}
+#define APH_TRACE(ph, slot, val) do { if (threadIdx.x == 0 && blockIdx.x == 0 && (ph) < 32) g_auc_trace[(ph) * 4 + (slot)] = (val); } while (0)
+#define APH_FLUSH() do { if (threadIdx.x == 0 && blockIdx.x < 32) for (int k_ = 0; k_ < 10; ++k_) g_auc_phase[blockIdx.x * 10 + k_] += jph[k_]; } while (0)
+#define JPH_COUNT(k, v) do { jph[k] += (v); } while (0)
+#define JPH_DECL unsigned long long jph_t = __builtin_amdgcn_s_memtime(), jph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define JPH(k) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); jph[k] += n_ - jph_t; jph_t = n_; } while (0)
+#define JPH_FLUSH() do { if (threadIdx.x == 0 && blockIdx.x < 32) for (int k_ = 0; k_ < 10; ++k_) g_jv_phase[blockIdx.x * 10 + k_] += jph[k_]; } while (0)
+#else
+#define JPH_DECL do { } while (0)
+#define JPH(k) do { } while (0)
+#define JPH_FLUSH() do { } while (0)
+#define APH_FLUSH() do { } while (0)
+#define APH_TRACE(ph, slot, val) do { } while (0)
+#define JPH_COUNT(k, v) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lsm[];
     const int n = a.n, b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -144,6 +190,7 @@ __global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
     __shared__ double s_red[NW], s_red2[NW], s_pv1[NW], s_pv2[NW];
     __shared__ int s_pj1[NW];
     const float *C = a.cost + (size_t)b * n * n;
+    JPH_DECL;
 
     // largest cost
     double mx = (double)lap_matrix_max<LAP_BS>(C, (size_t)n * n, tid);
@@ -189,6 +236,103 @@ __global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
     const double eps_final = mx * a.eps_final;
 
     int st_phases = 0, st_rounds = 0, st_bids = 0, st_cert = 0;
+    // The last free rows of a phase: one shortest augmenting path each instead of a bidding chain.  A lone bidder raises
+    // one price by its bid increment, the displaced row bids next, and so on until an unowned column is hit: thousands of
+    // dependent row scans per phase, most of them on the same few columns (a price war).  The path search finds where
+    // that walk must end and by how much every price on the way must rise in ONE sweep: Dijkstra from the free row over
+    //     r'_ik = c_ik + p_k - (c_i,s(i) + p_s(i)) + eps   (>= 0 by epsilon-complementary slackness; 0 back along a pair)
+    // fixes the closest column, relaxes its owner's row, until the closest column is unowned; prices of the fixed
+    // columns rise by (mu - d_j) and the pairs along the path are flipped.  Every pair still satisfies epsilon-CS
+    // afterwards (each row's new column is its exact arg-min), which is all the next phase and the certificate rely on.
+    // Thread t holds the labels of the columns t, t + 1024, ... in registers; a step is one coalesced row read and one
+    // workgroup arg-min (the same loop as lap_jv_kernel's, with the eps offset).
+    constexpr int CPT = LAP_NMAX / LAP_BS;
+    __shared__ double s_rv[2][NW];
+    __shared__ int s_rj[2][NW];
+    auto eps_search = [&](int i0, double eps) -> int {
+        int *pred = pbobj;                       // a row's bid column: only live inside a bidding round
+        double d[CPT];
+        unsigned scanned = 0u, freecol = 0u;
+        {
+            const float *row = C + (size_t)i0 * n;
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) {
+                const int j = tid + k * LAP_BS;
+                d[k] = j < n ? (double)row[j] + price[j] : INFINITY;
+                if (j < n) { pred[j] = i0; if (owner[j] < 0) freecol |= 1u << k; }
+                else scanned |= 1u << k;
+            }
+        }
+        double mu = 0.0;
+        int sink = -1, steps = 0;
+        for (int it = 0; ; ++it) {
+            double bv = INFINITY;
+            int bj = 0x7fffffff;
+#pragma unroll
+            for (int k = 0; k < CPT; ++k)
+                if (!((scanned >> k) & 1u)) {
+                    const int key = (tid + k * LAP_BS) | (((freecol >> k) & 1u) ? 0 : (1 << 30));   // unowned columns first
+                    if (d[k] < bv || (d[k] == bv && key < bj)) { bv = d[k]; bj = key; }
+                }
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                const double ov = __shfl_xor(bv, o, 64);
+                const int oj = __shfl_xor(bj, o, 64);
+                if (ov < bv || (ov == bv && oj < bj)) { bv = ov; bj = oj; }
+            }
+            const int par = it & 1;
+            if (lane == 0) { s_rv[par][wv] = bv; s_rj[par][wv] = bj; }
+            __syncthreads();
+            bv = s_rv[par][0]; bj = s_rj[par][0];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) {
+                const double ov = s_rv[par][w];
+                const int oj = s_rj[par][w];
+                if (ov < bv || (ov == bv && oj < bj)) { bv = ov; bj = oj; }
+            }
+            ++steps;
+            mu = bv;
+            if (bj == 0x7fffffff || !(bv < INFINITY)) break;          // non-finite costs only
+            const int jstar = bj & ~(1 << 30);
+            if ((jstar & (LAP_BS - 1)) == tid) scanned |= 1u << (jstar / LAP_BS);
+            const int i = owner[jstar];
+            if (i < 0) { sink = jstar; break; }
+            const float *row = C + (size_t)i * n;
+            float rc[CPT];
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) rc[k] = row[tid + k * LAP_BS < n ? tid + k * LAP_BS : 0];
+            const double base = mu - ((double)row[jstar] + price[jstar]) + eps;
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) {
+                const int j = tid + k * LAP_BS;
+                if (!((scanned >> k) & 1u)) {
+                    const double nd = base + ((double)rc[k] + price[j]);
+                    if (nd < d[k]) { d[k] = nd; pred[j] = i; }
+                }
+            }
+        }
+        __syncthreads();                         // every thread has read the prices it needs
+        if (sink >= 0) {
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) {
+                const int j = tid + k * LAP_BS;
+                if (j < n && ((scanned >> k) & 1u) && j != sink) price[j] += mu - d[k];
+            }
+            if (tid == 0) {
+                int j = sink;
+                for (;;) {
+                    const int i = pred[j];
+                    const int jn = assigned[i];
+                    assigned[i] = j; owner[j] = i;
+                    if (i == i0) break;
+                    j = jn;
+                }
+            }
+        }
+        __syncthreads();
+        return sink >= 0 ? steps : -steps - 1;
+    };
+    JPH(0);
     for (double eps = mx * a.eps0; ; eps = fmax(eps * a.theta_inv, eps_final)) {
         ++st_phases;
         // a phase keeps the prices and every pair that already satisfies the new, tighter epsilon-complementary
@@ -218,6 +362,10 @@ __global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
             }
         }
         __syncthreads();
+        JPH(1);
+        [[maybe_unused]] const int tr_rounds0 = st_rounds, tr_bids0 = st_bids;
+        [[maybe_unused]] int tr_search = 0;
+        APH_TRACE(st_phases - 1, 0, pre_bid ? s_cnt : n);
         bool first = pre_bid;
         for (;;) {
             if (!first) {
@@ -228,6 +376,7 @@ __global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
                 __syncthreads();
             }
             const int nu = s_cnt;
+            JPH(2);
             if (nu == 0) break;
             ++st_rounds; st_bids += nu;
             const bool skip_bids = first;      // the phase's first round: the bids were placed by the scan above
@@ -236,11 +385,25 @@ __global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
             // One wave covers 1024 columns with four 16-byte loads per lane in flight; longer rows are shared by n / 1024
             // waves whose (min, arg-min, second-min) triples one wave merges.
             const int wmax = n >= 2048 ? (n / 1024 < NW ? n / 1024 : NW) : 1;
+            if (nu <= LAP_SEARCH_NU && st_phases >= LAP_SEARCH_PHASE) {
+                JPH_COUNT(7, nu);
+                int done = 0;
+                for (; done < nu; ++done) {
+                    const int r = eps_search(ulist[done], eps);
+                    st_bids += r >= 0 ? r : -r - 1;
+                    JPH_COUNT(8, r >= 0 ? r : -r - 1);
+                    tr_search += r >= 0 ? r : -r - 1;
+                    if (r < 0) break;            // non-finite costs: leave the row to the bids below
+                }
+                JPH(4);
+                if (done > 0) continue;          // the list is rebuilt (empty unless a search gave up)
+            }
             if (nu == 1) {
                 // a single bidder: no conflicts are possible, so the chain (the row bids, takes the column, the displaced
                 // owner bids next, ...) is followed without rebuilding the bidder list until nobody is displaced.  The end
                 // of a phase is mostly such chains; every link is one row scan, a dependent read.
                 int i = ulist[0];
+                [[maybe_unused]] const int st_bids0 = st_bids;
                 if (wmax == 1) {
                     if (wv == 0) {                       // no workgroup barrier inside the chain
                         for (;;) {
@@ -260,6 +423,9 @@ __global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
                         }
                     }
                     __syncthreads();
+                    JPH(4);
+                    JPH_COUNT(8, st_bids - st_bids0);
+                    tr_search += st_bids - st_bids0;
                     continue;
                 }
                 const int len = (((n + wmax - 1) / wmax) + 63) & ~63;
@@ -291,6 +457,9 @@ __global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
                     i = s_next;
                     if (i < 0) break;
                 }
+                JPH(4);
+                JPH_COUNT(8, st_bids - st_bids0);
+                tr_search += st_bids - st_bids0;
                 continue;
             }
             if (nu * 2 <= NW && wmax > 1) {
@@ -332,6 +501,7 @@ __global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
             }
             }
             __syncthreads();
+            JPH(3);
             for (int u = tid; u < nu; u += LAP_BS) {
                 const int i = ulist[u], j = pbobj[i];
                 if (lap_key(pbval[i]) == bidval[j]) atomicMin(&bidder[j], i);
@@ -349,7 +519,11 @@ __global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
                 bidval[j] = 0ull;
             }
             __syncthreads();
+            JPH(5);
         }
+        APH_TRACE(st_phases - 1, 1, st_rounds - tr_rounds0);
+        APH_TRACE(st_phases - 1, 2, st_bids - tr_bids0);
+        APH_TRACE(st_phases - 1, 3, tr_search);
         if (eps <= eps_final) break;
         __syncthreads();
     }
@@ -384,6 +558,8 @@ __global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
     if (a.price_out)
         for (int j = tid; j < n; j += LAP_BS) a.price_out[(size_t)b * n + j] = d[j];
     if (tid == 0) a.certified[b] = certified;
+    JPH(6);
+    APH_FLUSH();
     if (tid == 0 && a.stats) { int *o = a.stats + 4 * b; o[0] = st_phases; o[1] = st_rounds; o[2] = st_bids; o[3] = st_cert; }
 }
 
@@ -465,6 +641,9 @@ extern "C" int reart_lap_auction_warm(const float *cost, int B, int n, int32_t *
 #ifndef JV_PTS_BS
 #define JV_PTS_BS 512
 #endif
+#ifndef JV_ARR_BUDGET
+#define JV_ARR_BUDGET 8    // row-reduction steps allowed per free row before the rest goes to the path search
+#endif
 struct JvArgs {
     const float *cost; int B, n;
     int *col4row;              // in: previous assignment (or -1), out: the optimum
@@ -509,21 +688,6 @@ __device__ __forceinline__ void lap_row_top2_pts(float ax, float ay, float az, c
     }
 }
 
-#ifdef REART_PRUNE_PHASE   // diagnostic build only (make -C reart_amd/csrc phase): s_memtime ticks of the path-search loop
-__device__ unsigned long long g_jv_phase[8];
-extern "C" int reart_debug_jv_phase(unsigned long long *out, int reset) {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_jv_phase), sizeof(g_jv_phase)) != hipSuccess) return REART_ERR_LAUNCH;
-    if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_jv_phase), z, sizeof(z)); }
-    return REART_OK;
-}
-#define JPH_DECL unsigned long long jph_t = __builtin_amdgcn_s_memtime(), jph[6] = {0, 0, 0, 0, 0, 0}
-#define JPH(k) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); jph[k] += n_ - jph_t; jph_t = n_; } while (0)
-#define JPH_FLUSH() do { if (threadIdx.x == 0) for (int k_ = 0; k_ < 6; ++k_) atomicAdd(&g_jv_phase[k_], jph[k_]); } while (0)
-#else
-#define JPH_DECL do { } while (0)
-#define JPH(k) do { } while (0)
-#define JPH_FLUSH() do { } while (0)
-#endif
 
 template <int BS, bool PTS>
 __global__ __launch_bounds__(BS) void lap_jv_kernel(JvArgs a) {
@@ -572,6 +736,7 @@ __global__ __launch_bounds__(BS) void lap_jv_kernel(JvArgs a) {
         }
     };
 
+    JPH_DECL;
     double mx;
     if (PTS) {
         // both point sets into LDS; the tolerances only need the scale of the costs: the diagonal of the clouds' box
@@ -659,13 +824,14 @@ __global__ __launch_bounds__(BS) void lap_jv_kernel(JvArgs a) {
         __syncthreads();
     }
     int nfree = s_cnt;
+    JPH(6);
     // ---- augmenting row reduction (Jonker-Volgenant): a free row takes its cheapest column at once and pays for it --
     // the column's price rises by the gap to the row's second-cheapest column, which keeps every dual constraint and
     // makes the new pair tight -- and the row it displaces is handled next.  One row scan per step, no search: most of
     // the rows a small change of the costs has released settle here.  Exact ties and the rows left when the step budget
     // runs out go to the path search below.  The chain is sequential; each row scan is split over the waves.
     {
-        int ncur = nfree, budget = 8 * nfree + 64;          // uniform over the workgroup: every thread follows the chain
+        int ncur = nfree, budget = JV_ARR_BUDGET * nfree + 64;          // uniform over the workgroup: every thread follows the chain
         int *next = pred;                                   // not needed before the path search
         for (int pass = 0; pass < 2 && ncur > 0; ++pass) {
             int nnext = 0;
@@ -706,7 +872,7 @@ __global__ __launch_bounds__(BS) void lap_jv_kernel(JvArgs a) {
     const int st_arr = st_steps;
     st_steps = 0;
 
-    JPH_DECL;
+    JPH(7);
     // ---- one shortest augmenting path per free row
     float tcx[JV_CPT], tcy[JV_CPT], tcz[JV_CPT];       // PTS: this thread's columns (target points), in registers
 #pragma unroll
@@ -829,7 +995,6 @@ __global__ __launch_bounds__(BS) void lap_jv_kernel(JvArgs a) {
     }
 
     JPH(4);
-    JPH_FLUSH();
     // ---- certificate (the auction's): Jacobi rounds on the potentials until every assigned column is an exact arg-min
     double *dd = price;
     double *pb = u;                            // scratch: the row potentials are not needed any more
@@ -860,6 +1025,8 @@ __global__ __launch_bounds__(BS) void lap_jv_kernel(JvArgs a) {
     if (a.price_out)
         for (int j = tid; j < n; j += BS) a.price_out[(size_t)b * n + j] = dd[j];
     if (tid == 0) a.certified[b] = certified;
+    JPH(8);
+    JPH_FLUSH();
     if (tid == 0 && a.stats) { int *o = a.stats + 4 * b; o[0] = st_freed; o[1] = st_left; o[2] = st_steps; o[3] = st_cert + (st_arr << 8); }
 }
 

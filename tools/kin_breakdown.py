@@ -21,13 +21,19 @@ a = rr.build_parser().parse_args(["--model", "kinematic", "--use_flow_loss", "--
 kin = rr.build_kinematic_from_base(result, cano, pcs, a).to(dev)
 t_ = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
 loop = rr.OperatorLoop(a, kin, cano, pcs, [t_(r) for r in seq["ref_loc"]], [t_(f) for f in seq["ref_flow"]])
-for i in range(10):
+WARM = int(os.environ.get("KIN_WARM", "90"))
+for i in range(WARM):
     loop.iteration(i)
 torch.cuda.synchronize()
+import ctypes
+from reart_amd import _lib
+lib = ctypes.CDLL(_lib.LIB_PATH)
+if hasattr(lib, "reart_debug_jv_phase"):
+    lib.reart_debug_jv_phase((ctypes.c_ulonglong * 320)(), 1)
 def T_(fn):
     torch.cuda.synchronize(); t0 = time.perf_counter(); r = fn(); torch.cuda.synchronize(); return r, 1e3 * (time.perf_counter() - t0)
 acc = {}
-for i in range(10, 30):
+for i in range(WARM, WARM + 20):
     (out, ms) = T_(lambda: kin(cano)); acc["forward"] = acc.get("forward", 0) + ms
     pc_trans = out[0]
     (pc_src, ms) = T_(lambda: index_points(pc_trans, loop.src_idx)); acc["index"] = acc.get("index", 0) + ms
@@ -44,9 +50,12 @@ import ctypes
 from reart_amd import _lib
 lib = ctypes.CDLL(_lib.LIB_PATH)
 if hasattr(lib, "reart_debug_jv_phase"):
-    buf = (ctypes.c_ulonglong * 8)()
+    buf = (ctypes.c_ulonglong * 320)()
     lib.reart_debug_jv_phase(buf, 0)
-    v = list(buf); tot = sum(v[:6])
-    names = ["local + wave arg-min", "barrier wait", "merge of the waves' minima", "row costs + relaxation", "dual update + path flip", "search set-up"]
-    for n_, x in zip(names, v[:6]):
-        print(f"   {n_:30s} {100 * x / max(tot, 1):5.1f} %")
+    v = np.array(list(buf), dtype=np.float64).reshape(32, 10)[:19]
+    names = ["search: local + wave arg-min", "search: barrier wait", "search: merge of the waves' minima", "search: row costs + relaxation",
+             "search: dual update + path flip", "search: set-up per free row", "before the row reduction", "row reduction", "certificate + outputs", "-"]
+    slow = int(v.sum(1).argmax())
+    print("s_memtime ticks (100 MHz): share over all workgroups | of the slowest workgroup (%d: %.1f ms over all launches)" % (slow, v[slow].sum() / 1e5))
+    for k, n_ in enumerate(names[:9]):
+        print(f"   {n_:36s} {100 * v[:, k].sum() / v.sum():5.1f} %   {100 * v[slow, k] / v[slow].sum():5.1f} %")
