@@ -565,8 +565,11 @@ __global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
 
 extern "C" size_t reart_lap_workspace_bytes(int B, int n) {
     if (B < 0 || n < 1 || n > LAP_NMAX) return 0;
-    return reart_align_up(sizeof(double) * (size_t)B * n, 256) + reart_align_up(sizeof(int) * 4 * (size_t)B, 256) +
-           (n > LAP_NLDS ? reart_align_up(sizeof(double) * (size_t)B * n, 256) : 0);
+    // potentials | diagnostics [B][4] | row bids (n > LAP_NLDS; always reserved) | the re-solve's pass results: v1, cur [B][n] f64,
+    // j1 [B][n] i32, scale [B] f64, cert_bad [B] i32
+    return reart_align_up(sizeof(double) * (size_t)B * n, 256) * 4 + reart_align_up(sizeof(int) * 4 * (size_t)B, 256) +
+           reart_align_up(sizeof(int) * (size_t)B * n, 256) + reart_align_up(sizeof(double) * (size_t)B, 256) +
+           reart_align_up(sizeof(int) * (size_t)B, 256);
 }
 
 // cost [B,n,n] fp32 (row-major: rows = sources), n <= 4096.  col4row [B,n] i32: column assigned to each row
@@ -641,6 +644,7 @@ extern "C" int reart_lap_auction_warm(const float *cost, int B, int n, int32_t *
 #ifndef JV_PTS_BS
 #define JV_PTS_BS 512
 #endif
+#define JV_SPLIT_NMIN 512   // from here on the two full passes of a re-solve run as their own whole-chip launches
 #ifndef JV_ARR_BUDGET
 #define JV_ARR_BUDGET 8    // row-reduction steps allowed per free row before the rest goes to the path search
 #endif
@@ -657,6 +661,12 @@ struct JvArgs {
     // PTS form: no cost matrix; c_ij = sqrt(((dx*dx)+(dy*dy))+(dz*dz)) of src point i and tgt point j, the expression of
     // reart_cdist, evaluated where it is needed from copies of both point sets in LDS
     const float *src, *tgt;    // [B][n][3]
+    // three-launch form (jv_launch): the two full passes over the costs run on the whole chip, the sequential part in between
+    double *pre_v1, *pre_cur;  // [B][n] per row: min_k (c_ik + p_k) and c_i,s(i) + p_s(i) under the incoming prices / assignment
+    int *pre_j1;               // [B][n] the arg-min column
+    double *scale;             // [B] the cost scale the tolerances are fractions of
+    int *cert_bad;             // [B] set by the certificate pass when a row's column is not its arg-min
+    int pass_mode;             // lap_jv_pass_kernel: 0 = row potentials of the start, 1 = first certificate round
 };
 
 // smallest (value, column) and second smallest value of c_ij + p_j over the columns of row i, costs from the points
@@ -689,7 +699,10 @@ __device__ __forceinline__ void lap_row_top2_pts(float ax, float ay, float az, c
 }
 
 
-template <int BS, bool PTS>
+// MODE 0: the whole re-solve in one launch.  MODE 1: the sequential part only -- row potentials come from lap_jv_pass_kernel
+// (pre_*), the certificate is left to the next two launches (certified[b] = 2: pending).  MODE 2: certificate of a pending
+// matrix whose first round (lap_jv_pass_kernel, pass_mode 1) found a violation: the Jacobi rounds from the solve's prices.
+template <int BS, bool PTS, int MODE>
 __global__ __launch_bounds__(BS) void lap_jv_kernel(JvArgs a) {
     constexpr int JV_CPT = (PTS ? JV_PTS_NMAX : LAP_NMAX) / BS;
     extern __shared__ __attribute__((aligned(16))) unsigned char lsm[];
@@ -751,10 +764,16 @@ __global__ __launch_bounds__(BS) void lap_jv_kernel(JvArgs a) {
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o, 64)); hi = fmaxf(hi, __shfl_xor(hi, o, 64)); }
         mx = 1.7320508 * (double)(hi - lo);
+    } else if (MODE == 2) {
+        mx = a.scale[b];
     } else {
         mx = (double)lap_matrix_max<BS>(C, (size_t)n * n, tid);
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+    }
+    if (MODE == 2 && (a.certified[b] != 2 || !a.cert_bad[b])) {        // uniform: nothing pending, or the first round was clean
+        if (tid == 0 && a.certified[b] == 2) a.certified[b] = 1;
+        return;
     }
     if (lane == 0) s_red[wv] = mx;
     for (int j = tid; j < n; j += BS) {
@@ -769,6 +788,9 @@ __global__ __launch_bounds__(BS) void lap_jv_kernel(JvArgs a) {
     for (int w = 0; w < NW; ++w) mx = fmax(mx, s_red[w]);
     if (!(mx > 0.0)) mx = 1.0;
     const double keep_tol = mx * a.keep_tol;
+    int st_freed = 0, st_left = 0, st_steps = 0, st_cert = 0, st_arr = 0;
+    bool solved = true;
+    if (MODE != 2) {
     // previous pairs: a repeated column keeps its lowest row
     for (int i = tid; i < n; i += BS)
         if (assigned[i] >= 0) atomicMin((unsigned int *)&owner[assigned[i]], (unsigned int)i);   // -1 = 0xffffffff: empty
@@ -777,6 +799,18 @@ __global__ __launch_bounds__(BS) void lap_jv_kernel(JvArgs a) {
         if (assigned[i] >= 0 && owner[assigned[i]] != i) assigned[i] = -1;
     __syncthreads();
     // row potentials under the old prices; pairs that lost their arg-min are released
+    if (MODE == 1) {
+        for (int i = tid; i < n; i += BS) {
+            const double v1 = a.pre_v1[(size_t)b * n + i];
+            const int j = assigned[i];
+            u[i] = v1; flist[i] = a.pre_j1[(size_t)b * n + i];
+            if (j >= 0) {
+                const double cur = a.pre_cur[(size_t)b * n + i];          // of the column col4row named: still the row's
+                if (cur - v1 > keep_tol) { assigned[i] = -1; owner[j] = -1; }
+                else u[i] = cur;
+            }
+        }
+    } else
     for (int i = wv; i < n; i += NW) {
         double v1, v2;
         int j1;
@@ -792,7 +826,6 @@ __global__ __launch_bounds__(BS) void lap_jv_kernel(JvArgs a) {
         }
     }
     __syncthreads();
-    int st_freed = 0, st_left = 0, st_steps = 0, st_cert = 0;
     // greedy: a free row takes its arg-min column when nobody owns it (lowest row wins)
     for (int i = tid; i < n; i += BS)
         if (assigned[i] < 0) atomicAdd(&s_cnt, 1);
@@ -869,7 +902,7 @@ __global__ __launch_bounds__(BS) void lap_jv_kernel(JvArgs a) {
     __syncthreads();
     nfree = s_cnt;
     st_left = nfree;
-    const int st_arr = st_steps;
+    st_arr = st_steps;
     st_steps = 0;
 
     JPH(7);
@@ -891,7 +924,6 @@ __global__ __launch_bounds__(BS) void lap_jv_kernel(JvArgs a) {
             for (int k = 0; k < JV_CPT; ++k) rc[k] = row[tid + k * BS < n ? tid + k * BS : 0];
         }
     };
-    bool solved = true;
     for (int f = 0; f < nfree; ++f) {
         const int i0 = flist[f];
         double d[JV_CPT];
@@ -995,12 +1027,13 @@ __global__ __launch_bounds__(BS) void lap_jv_kernel(JvArgs a) {
     }
 
     JPH(4);
+    }   // MODE != 2
     // ---- certificate (the auction's): Jacobi rounds on the potentials until every assigned column is an exact arg-min
     double *dd = price;
     double *pb = u;                            // scratch: the row potentials are not needed any more
     const double tol = mx * 1e-13;
     int certified = 0;
-    for (int round = 0; solved && round < a.max_rounds_cert; ++round) {
+    for (int round = 0; MODE != 1 && solved && round < a.max_rounds_cert; ++round) {
         if (tid == 0) s_flag = 0;
         ++st_cert;
         __syncthreads();
@@ -1024,10 +1057,56 @@ __global__ __launch_bounds__(BS) void lap_jv_kernel(JvArgs a) {
     for (int i = tid; i < n; i += BS) a.col4row[(size_t)b * n + i] = assigned[i];
     if (a.price_out)
         for (int j = tid; j < n; j += BS) a.price_out[(size_t)b * n + j] = dd[j];
-    if (tid == 0) a.certified[b] = certified;
+    if (tid == 0) a.certified[b] = MODE == 1 ? (solved ? 2 : 0) : certified;
+    if (MODE == 1 && tid == 0) { a.scale[b] = mx; a.cert_bad[b] = 0; }
     JPH(8);
     JPH_FLUSH();
-    if (tid == 0 && a.stats) { int *o = a.stats + 4 * b; o[0] = st_freed; o[1] = st_left; o[2] = st_steps; o[3] = st_cert + (st_arr << 8); }
+    if (tid == 0 && a.stats) {
+        int *o = a.stats + 4 * b;
+        if (MODE == 2) o[3] += st_cert;          // on top of the first round the pass kernel ran
+        else { o[0] = st_freed; o[1] = st_left; o[2] = st_steps; o[3] = (MODE == 1 ? 1 : st_cert) + (st_arr << 8); }
+    }
+}
+
+// The two full passes over the costs of a re-solve -- every row's (min, arg-min) of c_ik + p_k, before (row potentials:
+// which previous pairs are still tight) and after (first certificate round) the sequential part -- on the whole chip:
+// gridDim.y workgroups per matrix, one wave per row.  The sequential part runs one workgroup per matrix (T-1 = 19 of 256
+// compute units), where each pass cost 8 % of the kernel.  Same scan functions, so the same bits as the one-launch form.
+#define JV_PASS_BS 256
+template <bool PTS>
+__global__ __launch_bounds__(JV_PASS_BS) void lap_jv_pass_kernel(JvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lsm[];
+    const int n = a.n, b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (a.pass_mode == 1 && a.certified[b] != 2) return;
+    double *price = (double *)lsm;
+    float *ptx = (float *)(price + n), *pty = ptx + n, *ptz = pty + n;
+    const double *pin = a.pass_mode == 0 ? a.price_in : a.price_out;
+    const float *S_ = PTS ? a.src + (size_t)b * n * 3 : nullptr, *T_ = PTS ? a.tgt + (size_t)b * n * 3 : nullptr;
+    const float *C = PTS ? nullptr : a.cost + (size_t)b * n * n;
+    for (int j = tid; j < n; j += JV_PASS_BS) {
+        price[j] = pin ? pin[(size_t)b * n + j] : 0.0;
+        if (PTS) { ptx[j] = T_[3 * j]; pty[j] = T_[3 * j + 1]; ptz[j] = T_[3 * j + 2]; }
+    }
+    __syncthreads();
+    const double tol = a.pass_mode == 1 ? a.scale[b] * 1e-13 : 0.0;
+    for (int i = blockIdx.y * (JV_PASS_BS / 64) + wv; i < n; i += gridDim.y * (JV_PASS_BS / 64)) {
+        double v1, v2;
+        int j1;
+        float ax = 0.f, ay = 0.f, az = 0.f;
+        if (PTS) {
+            ax = S_[3 * i]; ay = S_[3 * i + 1]; az = S_[3 * i + 2];
+            lap_row_top2_pts(ax, ay, az, ptx, pty, ptz, price, 0, n, lane, v1, j1, v2);
+        } else lap_row_top2(C + (size_t)i * n, price, n, lane, v1, j1, v2);
+        if (lane == 0) {
+            const int c = a.col4row[(size_t)b * n + i];
+            const bool has = c >= 0 && c < n;
+            double cur = 0.0;
+            if (has) cur = (double)(PTS ? sqrtf(reart_sqdist3(ax, ay, az, ptx[c], pty[c], ptz[c])) : C[(size_t)i * n + c]) + price[c];
+            if (a.pass_mode == 0) {
+                a.pre_v1[(size_t)b * n + i] = v1; a.pre_j1[(size_t)b * n + i] = j1; a.pre_cur[(size_t)b * n + i] = cur;
+            } else if (!has || cur - v1 > tol) atomicOr(&a.cert_bad[b], 1);
+        }
+    }
 }
 
 // Re-solve from the assignment in col4row and the potentials in price_in (both from an earlier solve of a similar batch,
@@ -1044,9 +1123,38 @@ static int jv_launch(JvArgs a, void *workspace, size_t workspace_bytes, void *st
     const size_t lds = (size_t)a.n * (2 * 8 + 4 * 4 + (PTS ? 6 * 4 : 0));
     constexpr int JVBS = PTS ? JV_PTS_BS : 256;
     if (lds > REART_LDS_DEFAULT_CAP &&
-        hipFuncSetAttribute((const void *)lap_jv_kernel<JVBS, PTS>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)
+        (hipFuncSetAttribute((const void *)lap_jv_kernel<JVBS, PTS, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess ||
+         hipFuncSetAttribute((const void *)lap_jv_kernel<JVBS, PTS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess ||
+         hipFuncSetAttribute((const void *)lap_jv_kernel<JVBS, PTS, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess))
         return REART_ERR_LAUNCH;
-    hipLaunchKernelGGL((lap_jv_kernel<JVBS, PTS>), dim3(a.B), dim3(JVBS), lds, (hipStream_t)stream, a);
+    if (a.n < JV_SPLIT_NMIN) {      // small problems: one launch, the passes are a few microseconds
+        hipLaunchKernelGGL((lap_jv_kernel<JVBS, PTS, 0>), dim3(a.B), dim3(JVBS), lds, (hipStream_t)stream, a);
+        REART_CHECK_LAUNCH();
+        return REART_OK;
+    }
+    {
+        const size_t bn = reart_align_up(sizeof(double) * (size_t)a.B * a.n, 256);
+        char *w = (char *)a.stats + reart_align_up(sizeof(int) * 4 * (size_t)a.B, 256) + bn;      // past the auction's row bids
+        a.pre_v1 = (double *)w; w += bn;
+        a.pre_cur = (double *)w; w += bn;
+        a.pre_j1 = (int *)w; w += reart_align_up(sizeof(int) * (size_t)a.B * a.n, 256);
+        a.scale = (double *)w; w += reart_align_up(sizeof(double) * (size_t)a.B, 256);
+        a.cert_bad = (int *)w;
+    }
+    int per = (2 * 256 + a.B - 1) / a.B;                       // workgroups per matrix: two per compute unit over the batch
+    const int per_max = (a.n + JV_PASS_BS / 64 - 1) / (JV_PASS_BS / 64);
+    per = per < 1 ? 1 : (per > per_max ? per_max : per);
+    const size_t lds_pass = (size_t)a.n * (8 + (PTS ? 12 : 0));
+    a.pass_mode = 0;
+    hipLaunchKernelGGL((lap_jv_pass_kernel<PTS>), dim3(a.B, per), dim3(JV_PASS_BS), lds_pass, (hipStream_t)stream, a);
+    REART_CHECK_LAUNCH();
+    hipLaunchKernelGGL((lap_jv_kernel<JVBS, PTS, 1>), dim3(a.B), dim3(JVBS), lds, (hipStream_t)stream, a);
+    REART_CHECK_LAUNCH();
+    a.pass_mode = 1;
+    hipLaunchKernelGGL((lap_jv_pass_kernel<PTS>), dim3(a.B, per), dim3(JV_PASS_BS), lds_pass, (hipStream_t)stream, a);
+    REART_CHECK_LAUNCH();
+    a.price_in = a.price_out;                                  // the certificate continues from the solve's potentials
+    hipLaunchKernelGGL((lap_jv_kernel<JVBS, PTS, 2>), dim3(a.B), dim3(JVBS), lds, (hipStream_t)stream, a);
     REART_CHECK_LAUNCH();
     return REART_OK;
 }
