@@ -78,6 +78,41 @@ __device__ __forceinline__ float reart_row16_max(float v) {
     return v;
 }
 
+// Full-wave butterfly without LDS: the value a lane's partner holds at each of the six steps of an xor-butterfly
+// reduction.  Steps 0,1: quad permutes (xor 1, xor 2); steps 2,3: half-row / row mirror, which pair the same GROUPS as
+// xor 4 / xor 8 -- equivalent once the groups of 4 / 8 lanes are uniform, i.e. in a reduction with a symmetric combine
+// that runs the steps in this order; steps 4,5: gfx950's v_permlane16_swap / v_permlane32_swap (exact xor 16 / xor 32).
+// One or two VALU instructions per 32-bit word and step; all 64 lanes must be active.
+typedef unsigned reart_v2u __attribute__((ext_vector_type(2)));
+template <int STEP>
+__device__ __forceinline__ int reart_bfly(int v) {
+    if (STEP == 0) return __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, true);
+    if (STEP == 1) return __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, true);
+    if (STEP == 2) return __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, true);
+    if (STEP == 3) return __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, true);
+    if (STEP == 4) {
+        const reart_v2u r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+        return (int)((threadIdx.x & 16) ? r.x : r.y);
+    }
+    const reart_v2u r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+    return (int)((threadIdx.x & 32) ? r.x : r.y);
+}
+template <int STEP>
+__device__ __forceinline__ double reart_bfly_d(double v) {
+    return __hiloint2double(reart_bfly<STEP>(__double2hiint(v)), reart_bfly<STEP>(__double2loint(v)));
+}
+// (smallest value, its lowest index) over the wave, every lane gets it
+template <int STEP>
+__device__ __forceinline__ void reart_argmin_step(double &v, int &j) {
+    const double ov = reart_bfly_d<STEP>(v);
+    const int oj = reart_bfly<STEP>(j);
+    if (ov < v || (ov == v && oj < j)) { v = ov; j = oj; }
+}
+__device__ __forceinline__ void reart_wave_argmin_d(double &v, int &j) {
+    reart_argmin_step<0>(v, j); reart_argmin_step<1>(v, j); reart_argmin_step<2>(v, j);
+    reart_argmin_step<3>(v, j); reart_argmin_step<4>(v, j); reart_argmin_step<5>(v, j);
+}
+
 // XCD-aware remap of a linear workgroup id (cdna guide T1): the dispatcher places
 // workgroup L on XCD L % 8; give each XCD a contiguous chunk of work items so that
 // neighbours (same batch / same target slice) share one L2.  Returns -1 for the

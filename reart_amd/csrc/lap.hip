@@ -52,6 +52,25 @@ struct LapArgs {
 
 __device__ __forceinline__ unsigned long long lap_key(double v) { return (unsigned long long)__double_as_longlong(v); }  // v >= 0
 
+// the waves' merge of per-lane (min, arg-min, second min [, payload of the arg-min]) triples: LDS-free butterfly
+template <int STEP>
+__device__ __forceinline__ void lap_top2_step(double &v1, int &j1, double &v2, int &pay) {
+    const double ov1 = reart_bfly_d<STEP>(v1), ov2 = reart_bfly_d<STEP>(v2);
+    const int oj1 = reart_bfly<STEP>(j1), op = reart_bfly<STEP>(pay);
+    const bool take = (ov1 < v1) || (ov1 == v1 && oj1 < j1);
+    const double lose = take ? v1 : ov1;           // the larger of the two minima
+    v2 = fmin(fmin(v2, ov2), lose);
+    v1 = take ? ov1 : v1; j1 = take ? oj1 : j1; pay = take ? op : pay;
+}
+__device__ __forceinline__ void lap_wave_top2(double &v1, int &j1, double &v2, int &pay) {
+    lap_top2_step<0>(v1, j1, v2, pay); lap_top2_step<1>(v1, j1, v2, pay); lap_top2_step<2>(v1, j1, v2, pay);
+    lap_top2_step<3>(v1, j1, v2, pay); lap_top2_step<4>(v1, j1, v2, pay); lap_top2_step<5>(v1, j1, v2, pay);
+}
+__device__ __forceinline__ void lap_wave_top2(double &v1, int &j1, double &v2) {
+    int pay = 0;
+    lap_wave_top2(v1, j1, v2, pay);
+}
+
 // smallest (value, column) and second smallest value of row i under prices p over the columns [jb, je); all lanes
 // get the result (an empty range gives +inf).  Exact selections only, so any split of a row into ranges followed by
 // lap_merge_top2 gives the same triple as one scan of the whole row.
@@ -96,16 +115,7 @@ __device__ __forceinline__ void lap_row_top2_range(const float *__restrict__ row
             }
         }
     }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-        const double ov1 = __shfl_xor(v1, o, 64), ov2 = __shfl_xor(v2, o, 64);
-        const int oj1 = __shfl_xor(j1, o, 64);
-        const bool take = (ov1 < v1) || (ov1 == v1 && oj1 < j1);
-        const double lose = take ? v1 : ov1;           // the larger of the two minima
-        v2 = fmin(fmin(v2, ov2), lose);
-        v1 = take ? ov1 : v1;
-        j1 = take ? oj1 : j1;
-    }
+    lap_wave_top2(v1, j1, v2);
 }
 
 __device__ __forceinline__ void lap_row_top2(const float *__restrict__ row, const double *__restrict__ p, int n, int lane,
@@ -274,22 +284,15 @@ __global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
                     const int key = (tid + k * LAP_BS) | (((freecol >> k) & 1u) ? 0 : (1 << 30));   // unowned columns first
                     if (d[k] < bv || (d[k] == bv && key < bj)) { bv = d[k]; bj = key; }
                 }
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) {
-                const double ov = __shfl_xor(bv, o, 64);
-                const int oj = __shfl_xor(bj, o, 64);
-                if (ov < bv || (ov == bv && oj < bj)) { bv = ov; bj = oj; }
-            }
+            reart_wave_argmin_d(bv, bj);
             const int par = it & 1;
             if (lane == 0) { s_rv[par][wv] = bv; s_rj[par][wv] = bj; }
             __syncthreads();
-            bv = s_rv[par][0]; bj = s_rj[par][0];
-#pragma unroll
-            for (int w = 1; w < NW; ++w) {
-                const double ov = s_rv[par][w];
-                const int oj = s_rj[par][w];
-                if (ov < bv || (ov == bv && oj < bj)) { bv = ov; bj = oj; }
-            }
+            // the waves' minima meet in the first NW <= 16 lanes of every wave: four butterfly steps, then a broadcast
+            bv = lane < NW ? s_rv[par][lane] : INFINITY; bj = lane < NW ? s_rj[par][lane] : 0x7fffffff;
+            reart_argmin_step<0>(bv, bj); reart_argmin_step<1>(bv, bj); reart_argmin_step<2>(bv, bj); reart_argmin_step<3>(bv, bj);
+            bv = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(bv)), __builtin_amdgcn_readfirstlane(__double2loint(bv)));
+            bj = __builtin_amdgcn_readfirstlane(bj);
             ++steps;
             mu = bv;
             if (bj == 0x7fffffff || !(bv < INFINITY)) break;          // non-finite costs only
@@ -686,16 +689,7 @@ __device__ __forceinline__ void lap_row_top2_pts(float ax, float ay, float az, c
             }
         }
     }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-        const double ov1 = __shfl_xor(v1, o, 64), ov2 = __shfl_xor(v2, o, 64);
-        const int oj1 = __shfl_xor(j1, o, 64);
-        const bool take = (ov1 < v1) || (ov1 == v1 && oj1 < j1);
-        const double lose = take ? v1 : ov1;
-        v2 = fmin(fmin(v2, ov2), lose);
-        v1 = take ? ov1 : v1;
-        j1 = take ? oj1 : j1;
-    }
+    lap_wave_top2(v1, j1, v2);
 }
 
 
@@ -729,25 +723,8 @@ __global__ __launch_bounds__(BS) void lap_jv_kernel(JvArgs a) {
         if (PTS) lap_row_top2_pts(psx[i], psy[i], psz[i], ptx, pty, ptz, pr, 0, n, lane, v1, j1, v2);
         else lap_row_top2(C + (size_t)i * n, pr, n, lane, v1, j1, v2);
     };
-    // the same triple with the row's columns split over the workgroup's waves, and the row that owns the winning column;
-    // every thread gets them.  The owner is read BEFORE the barrier (by the wave that proposes the column), so the
-    // caller may rewrite owner[] right after the call; a second barrier must follow before the next call.
-    __shared__ double s_pv1[NW], s_pv2[NW];
-    __shared__ int s_pj1[NW], s_pi0[NW];
-    auto row_top2_block = [&](int i, const double *pr, double &v1, int &j1, double &v2, int &i0) {
-        const int len = (((n + NW - 1) / NW) + 3) & ~3, jb = min(n, wv * len), je = min(n, (wv + 1) * len);
-        if (PTS) lap_row_top2_pts(psx[i], psy[i], psz[i], ptx, pty, ptz, pr, jb, je, lane, v1, j1, v2);
-        else lap_row_top2_range(C + (size_t)i * n, pr, jb, je, lane, v1, j1, v2);
-        if (lane == 0) { s_pv1[wv] = v1; s_pj1[wv] = j1; s_pv2[wv] = v2; s_pi0[wv] = j1 < n ? owner[j1] : -1; }
-        __syncthreads();
-        v1 = s_pv1[0]; j1 = s_pj1[0]; v2 = s_pv2[0]; i0 = s_pi0[0];
-#pragma unroll
-        for (int w = 1; w < NW; ++w) {
-            const int before = j1;
-            lap_merge_top2(s_pv1[w], s_pj1[w], s_pv2[w], v1, j1, v2);
-            i0 = j1 != before ? s_pi0[w] : i0;
-        }
-    };
+    __shared__ double s_av1[2][NW], s_av2[2][NW];
+    __shared__ int s_aj1[2][NW], s_ai0[2][NW];
 
     JPH_DECL;
     double mx;
@@ -862,51 +839,7 @@ __global__ __launch_bounds__(BS) void lap_jv_kernel(JvArgs a) {
     // the column's price rises by the gap to the row's second-cheapest column, which keeps every dual constraint and
     // makes the new pair tight -- and the row it displaces is handled next.  One row scan per step, no search: most of
     // the rows a small change of the costs has released settle here.  Exact ties and the rows left when the step budget
-    // runs out go to the path search below.  The chain is sequential; each row scan is split over the waves.
-    {
-        int ncur = nfree, budget = JV_ARR_BUDGET * nfree + 64;          // uniform over the workgroup: every thread follows the chain
-        int *next = pred;                                   // not needed before the path search
-        for (int pass = 0; pass < 2 && ncur > 0; ++pass) {
-            int nnext = 0;
-            for (int k = 0; k < ncur; ++k) {
-                int i = flist[k];
-                for (;;) {
-                    double v1, v2;
-                    int j1;
-                    int i0;
-                    row_top2_block(i, price, v1, j1, v2, i0);
-                    const bool tie = !(v1 < v2);
-                    const bool stop = budget-- <= 0 || (tie && i0 >= 0);
-                    if (tid == 0) {
-                        if (stop) { next[nnext] = i; u[i] = v1; }
-                        else {
-                            if (!tie) price[j1] += v2 - v1;
-                            u[i] = tie ? v1 : v2;
-                            assigned[i] = j1; owner[j1] = i;
-                            if (i0 >= 0) assigned[i0] = -1;
-                        }
-                    }
-                    __syncthreads();
-                    if (stop) { ++nnext; break; }
-                    ++st_steps;
-                    if (i0 < 0) break;
-                    i = i0;
-                }
-            }
-            for (int k = tid; k < nnext; k += BS) flist[k] = next[k];
-            __syncthreads();
-            ncur = nnext;
-        }
-        if (tid == 0) s_cnt = ncur;
-    }
-    __syncthreads();
-    nfree = s_cnt;
-    st_left = nfree;
-    st_arr = st_steps;
-    st_steps = 0;
-
-    JPH(7);
-    // ---- one shortest augmenting path per free row
+    // runs out go to the path search below.  The chain is sequential.
     float tcx[JV_CPT], tcy[JV_CPT], tcz[JV_CPT];       // PTS: this thread's columns (target points), in registers
 #pragma unroll
     for (int k = 0; k < JV_CPT; ++k) {
@@ -924,6 +857,88 @@ __global__ __launch_bounds__(BS) void lap_jv_kernel(JvArgs a) {
             for (int k = 0; k < JV_CPT; ++k) rc[k] = row[tid + k * BS < n ? tid + k * BS : 0];
         }
     };
+    {
+        // thread t holds the columns t, t + BS, ... : coordinates (or the row read), prices and owners in registers.  A
+        // step is the row's costs in every thread, a (min, arg-min, second min) reduction that carries the arg-min's owner
+        // along, ONE barrier (the waves' triples meet in double-buffered LDS slots), and the update by the arg-min's thread.
+        double pr[JV_CPT];
+        int own[JV_CPT];
+#pragma unroll
+        for (int k = 0; k < JV_CPT; ++k) {
+            const int j = tid + k * BS;
+            pr[k] = j < n ? price[j] : INFINITY;
+            own[k] = j < n ? owner[j] : -1;
+        }
+        int ncur = nfree, budget = JV_ARR_BUDGET * nfree + 64;          // uniform over the workgroup: every thread follows the chain
+        int *next = pred;                                   // not needed before the path search
+        int par = 0;
+        for (int pass = 0; pass < 2 && ncur > 0; ++pass) {
+            int nnext = 0;
+            for (int k0 = 0; k0 < ncur; ++k0) {
+                int i = flist[k0];
+                for (;;) {
+                    float rc[JV_CPT];
+                    row_costs(i, rc);
+                    double v1 = INFINITY, v2 = INFINITY;
+                    int j1 = 0x7fffffff, i0 = -1;
+#pragma unroll
+                    for (int k = 0; k < JV_CPT; ++k) {
+                        const double v = (double)rc[k] + pr[k];              // +inf beyond n
+                        if (v < v1) { v2 = v1; v1 = v; j1 = tid + k * BS; i0 = own[k]; }
+                        else if (v < v2) v2 = v;
+                    }
+                    lap_wave_top2(v1, j1, v2, i0);
+                    if (lane == 0) { s_av1[par][wv] = v1; s_av2[par][wv] = v2; s_aj1[par][wv] = j1; s_ai0[par][wv] = i0; }
+                    __syncthreads();
+                    v1 = lane < NW ? s_av1[par][lane] : INFINITY; v2 = lane < NW ? s_av2[par][lane] : INFINITY;
+                    j1 = lane < NW ? s_aj1[par][lane] : 0x7fffffff; i0 = lane < NW ? s_ai0[par][lane] : -1;
+                    lap_top2_step<0>(v1, j1, v2, i0); lap_top2_step<1>(v1, j1, v2, i0);
+                    lap_top2_step<2>(v1, j1, v2, i0); lap_top2_step<3>(v1, j1, v2, i0);
+                    v1 = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v1)), __builtin_amdgcn_readfirstlane(__double2loint(v1)));
+                    v2 = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v2)), __builtin_amdgcn_readfirstlane(__double2loint(v2)));
+                    j1 = __builtin_amdgcn_readfirstlane(j1); i0 = __builtin_amdgcn_readfirstlane(i0);
+                    par ^= 1;
+                    const bool tie = !(v1 < v2);
+                    const bool stop = budget-- <= 0 || (tie && i0 >= 0);
+                    if (stop) {
+                        if (tid == 0) { next[nnext] = i; u[i] = v1; }
+                        ++nnext;
+                        break;
+                    }
+                    if ((j1 & (BS - 1)) == tid) {                            // the arg-min's thread
+                        const int kk = j1 / BS;
+#pragma unroll
+                        for (int k = 0; k < JV_CPT; ++k)
+                            if (k == kk) { if (!tie) pr[k] += v2 - v1; own[k] = i; }
+                        u[i] = tie ? v1 : v2;
+                        assigned[i] = j1;
+                        if (i0 >= 0) assigned[i0] = -1;
+                    }
+                    ++st_steps;
+                    if (i0 < 0) break;
+                    i = i0;
+                }
+            }
+            __syncthreads();
+            for (int k = tid; k < nnext; k += BS) flist[k] = next[k];
+            __syncthreads();
+            ncur = nnext;
+        }
+#pragma unroll
+        for (int k = 0; k < JV_CPT; ++k) {
+            const int j = tid + k * BS;
+            if (j < n) { price[j] = pr[k]; owner[j] = own[k]; }
+        }
+        if (tid == 0) s_cnt = ncur;
+    }
+    __syncthreads();
+    nfree = s_cnt;
+    st_left = nfree;
+    st_arr = st_steps;
+    st_steps = 0;
+
+    JPH(7);
+    // ---- one shortest augmenting path per free row
     for (int f = 0; f < nfree; ++f) {
         const int i0 = flist[f];
         double d[JV_CPT];
@@ -959,24 +974,17 @@ __global__ __launch_bounds__(BS) void lap_jv_kernel(JvArgs a) {
                     const int key = (tid + k * BS) | (((freecol >> k) & 1u) ? 0 : JV_OWNED);
                     if (d[k] < bv || (d[k] == bv && key < bj)) { bv = d[k]; bj = key; }
                 }
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) {
-                const double ov = __shfl_xor(bv, o, 64);
-                const int oj = __shfl_xor(bj, o, 64);
-                if (ov < bv || (ov == bv && oj < bj)) { bv = ov; bj = oj; }
-            }
+            reart_wave_argmin_d(bv, bj);
             const int par = it & 1;
             if (lane == 0) { s_rv[par][wv] = bv; s_rj[par][wv] = bj; }
             JPH(0);
             __syncthreads();
             JPH(1);
-            bv = s_rv[par][0]; bj = s_rj[par][0];
-#pragma unroll
-            for (int w = 1; w < NW; ++w) {
-                const double ov = s_rv[par][w];
-                const int oj = s_rj[par][w];
-                if (ov < bv || (ov == bv && oj < bj)) { bv = ov; bj = oj; }
-            }
+            // the waves' minima meet in the first NW <= 16 lanes of every wave: four butterfly steps, then a broadcast
+            bv = lane < NW ? s_rv[par][lane] : INFINITY; bj = lane < NW ? s_rj[par][lane] : 0x7fffffff;
+            reart_argmin_step<0>(bv, bj); reart_argmin_step<1>(bv, bj); reart_argmin_step<2>(bv, bj); reart_argmin_step<3>(bv, bj);
+            bv = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(bv)), __builtin_amdgcn_readfirstlane(__double2loint(bv)));
+            bj = __builtin_amdgcn_readfirstlane(bj);
             ++st_steps;
             mu = bv;
             const int jstar = bj == 0x7fffffff ? bj : (bj & ~JV_OWNED);
