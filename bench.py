@@ -322,6 +322,9 @@ def main():
                     help="sweep mode: K independent instances share each GPU on separate streams (secondary figure; "
                          "the headline is K=1)")
     ap.add_argument("--no-tail", action="store_true", help="skip the end-of-run structure / energy timing (secondary figure)")
+    ap.add_argument("--sweep-mode", choices=("batch", "streams"), default="streams",
+                    help="how the sweep's instances share a GPU: batch = shared launches (reart_relax_step_batch), streams = one "
+                         "stream per instance")
     ap.add_argument("--sweep-instances", type=int, default=3,
                     help="after the headline (one instance per GPU) also time this many concurrent instances per GPU on "
                          "separate streams and report the aggregate as `sweep` (0 = skip)")
@@ -435,7 +438,35 @@ def main():
     # independent instances on a GPU; their launches interleave on separate streams and fill the issue slots
     # a single latency-bound instance leaves idle
     sweep = None
-    if K == 1 and args.sweep_instances > 1:
+    if K == 1 and args.sweep_instances > 1 and args.sweep_mode == "batch":
+        # the instances advance in SHARED launches (reart_relax_step_batch): every kernel of the iteration runs once with
+        # one argument block per instance
+        from reart_amd.relax import RelaxBatch
+
+        Ks = args.sweep_instances
+        sw_eng = [build_instance(dev, T, N, (cano_idx + 1 + k) % T, seed=1000 + rank + 101 * k, use_flow=use_flow,
+                                 use_grid=args.grid, overlap=not args.no_overlap)[0] for k in range(Ks)]
+        batch = RelaxBatch(sw_eng)
+        used = 0 if args.no_graph else batch.capture(steps_per_graph=spg)
+        batch.step(max(args.warmup - used, 0))
+        barrier()
+        t1 = time.perf_counter()
+        batch.step(args.steps)
+        barrier()
+        el_s = time.perf_counter() - t1
+        if distributed:
+            tt = torch.tensor([el_s], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el_s = float(tt.item())
+        sweep = {"instances_per_gpu": Ks, "value": round(world * Ks * args.steps / el_s, 3), "unit": "iterations/s",
+                 "per_gpu": round(Ks * args.steps / el_s, 3), "n_gpus": world, "mode": "batch",
+                 "graph_replays": batch.graph_replays, "eager_steps": batch.eager_steps,
+                 "note": "aggregate over all GPUs of Ks independent instances per GPU advancing in shared launches "
+                         "(reart_relax_step_batch: each kernel of the iteration once, one argument block per instance); `value` "
+                         "above is one instance per GPU; per_gpu = value / n_gpus is the figure that should stay flat as ranks "
+                         "are added (instances share nothing)"}
+        del sw_eng, batch
+    elif K == 1 and args.sweep_instances > 1:
         Ks = args.sweep_instances
         sw_eng, sw_st = [], []
         for k in range(Ks):
@@ -461,7 +492,7 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el_s = float(tt.item())
         sweep = {"instances_per_gpu": Ks, "value": round(world * Ks * args.steps / el_s, 3), "unit": "iterations/s",
-                 "per_gpu": round(Ks * args.steps / el_s, 3), "n_gpus": world,
+                 "per_gpu": round(Ks * args.steps / el_s, 3), "n_gpus": world, "mode": "streams",
                  "note": "aggregate over all GPUs of Ks concurrent independent instances per GPU (separate streams, "
                          "round-robin graph replays); `value` above is one instance per GPU; per_gpu = value / n_gpus is "
                          "the figure that should stay flat as ranks are added (instances share nothing)"}

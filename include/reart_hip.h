@@ -257,6 +257,16 @@ int reart_relax_forward(const reart_relax_config *cfg, const reart_relax_buffers
 /* enqueue one iteration (5 launches in the default configuration, no host sync, no environment lookups) */
 int reart_relax_step(const reart_relax_config *cfg, const reart_relax_buffers *bufs,
                      void *workspace, size_t workspace_bytes, void *stream);
+/* K independent instances of ONE shape (same N, B, P, H, M_max and switches in every cfgs[k]; clouds, parameters,
+ * canonical index, seed and learning rates are each instance's own) advance one iteration in the five launches of a
+ * single instance: every kernel runs once with K argument blocks, instance k on row k of its grid.  cfgs / bufs are
+ * arrays of K, workspaces[k] is instance k's workspace (each prepared with reart_relax_prepare).  Each instance
+ * computes exactly what reart_relax_step computes for it.  This is how a sweep over canonical frames
+ * (/root/reference/README.md:60, run_robot.py: one process per cano_idx) fills the chip: one instance occupies a fraction
+ * of the 256 compute units and is a chain of dependent launches.  Default iteration only (box-pruned search,
+ * Chamfer + flow loss), 1 <= K <= 6; REART_ERR_UNSUPPORTED / REART_ERR_INVALID_ARG otherwise. */
+int reart_relax_step_batch(const reart_relax_config *cfgs, const reart_relax_buffers *bufs, void *const *workspaces,
+                           size_t workspace_bytes, int K, void *stream);
 /* measurement aid: the same sequence with hipEvents between phases on `stream`; synchronises
  * and ADDS per-phase milliseconds to the HOST array h_ms[REART_RELAX_PHASES]:
  * 0 forward, 1 flow K=3 search, 2 flow blend, 3 Chamfer K=1 search, 4 Chamfer merge + gradient,

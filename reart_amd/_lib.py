@@ -71,6 +71,7 @@ PROTOTYPES = {
     "reart_relax_workspace_bytes": (c_size_t, None),
     "reart_relax_prepare": (c_int, None),
     "reart_relax_step": (c_int, None),
+    "reart_relax_step_batch": (c_int, None),
     "reart_relax_forward": (c_int, None),
     "reart_relax_step_timed": (c_int, None),
     "reart_relax_profile": (c_int, None),

@@ -46,7 +46,20 @@ struct BaseBwdArgs {
 struct AdamSeg { float *p; const float *g; float *m; float *v; int n; float lr; };
 struct AdamArgs { AdamSeg seg[8]; int nseg; float beta1, beta2, eps; const int64_t *step_ptr; int step; };
 
+// Several independent instances of one shape in ONE launch (relax batch): the kernels of the fused step take their
+// argument block K times and pick theirs by blockIdx.y.  6 blocks of the largest (SearchArgs) stay within the 4 KB
+// kernel-argument segment with room for the runtime's hidden arguments.
+#define REART_BATCH_MAX 6
+template <class A>
+struct Batched { A a[REART_BATCH_MAX]; };
+template <class A>
+static inline Batched<A> reart_batched(const A *a, int K) {
+    Batched<A> b = {};
+    for (int k = 0; k < K && k < REART_BATCH_MAX; ++k) b.a[k] = a[k];
+    return b;
+}
 int reart_base_forward_ex(const BaseFwdArgs &a, hipStream_t st);
+int reart_base_forward_batch(const BaseFwdArgs *a, int K, hipStream_t st);          // same shapes, K <= REART_BATCH_MAX
 struct FinalizeAdam {
     int enabled;
     float *W1, *b1, *W2, *p6d, *pt;   // parameters (updated in place)
@@ -69,6 +82,8 @@ struct StepBook {
     int ring, n_iter;
     float lambda_flow, fixed_tau, end_tau, start_tau, beta1, beta2;
 };
+int reart_base_backward_batch(const BaseBwdArgs *args, const FinalizeAdam *adam, const StepBook *book, void *const *workspaces,
+                              size_t workspace_bytes, int K, hipStream_t st);
 int reart_base_backward_ex(BaseBwdArgs a, const FinalizeAdam *adam, const StepBook *book, void *workspace,
                            size_t workspace_bytes, hipStream_t st);
 #ifdef __HIPCC__
@@ -156,6 +171,7 @@ struct SearchArgs {
     unsigned int *prof_pairs;      //           [grid] distance evaluations executed by the workgroup
 };
 int reart_search_launch(const SearchArgs &a, hipStream_t st);
+int reart_search_launch_batch(const SearchArgs *a, int K, hipStream_t st);          // group form only, same shapes
 int reart_search_grid(int n1, int n3, int G);   // workgroups of that launch (an upper bound for both forms)
 int reart_search_grid_cloud(int n1, int n3, int G, int nqg, int slices);
 int reart_search_workgroups(const SearchArgs &a);   // of the form reart_search_launch will pick for `a`

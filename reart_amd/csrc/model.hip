@@ -154,9 +154,10 @@ __device__ __forceinline__ float gumbel_from_bits(uint32_t bits) {
 // HALF: a workgroup owns 32 points and the two halves of a wave work on different part pairs (lane = half * 32 +
 // point), so that the same chains run in W/2 waves per workgroup on twice as many workgroups (the kernel is bound by the
 // serial work of one workgroup; 256 CUs take the extra workgroups for free).  Same arithmetic per (point, part).
-template <int PP, bool HALF>
+template <int PP, bool HALF, bool BATCH>
 __global__ __launch_bounds__(64 * (HALF ? (((PP > 0 ? PP : 32) + 2 * FW_PG - 1) / (2 * FW_PG)) : (((PP > 0 ? PP : 32) + FW_PG - 1) / FW_PG)))
-void base_fwd_kernel(BaseFwdArgs a) {
+void base_fwd_kernel(Batched<BaseFwdArgs> ab) {
+    const BaseFwdArgs &a = ab.a[BATCH ? blockIdx.y : 0];      // a single instance reads its block at a fixed offset
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int PMAX = (PP > 0) ? PP : 32;
     constexpr int W = HALF ? (PMAX + 2 * FW_PG - 1) / (2 * FW_PG) : (PMAX + FW_PG - 1) / FW_PG;   // waves
@@ -382,32 +383,42 @@ void base_fwd_kernel(BaseFwdArgs a) {
 }
 
 template <int PP, bool HALF>
-static void launch_base_fwd_t(const BaseFwdArgs &a, hipStream_t st) {
+static void launch_base_fwd_t(const BaseFwdArgs *ak, int K, hipStream_t st) {
+    const BaseFwdArgs &a = ak[0];
     constexpr int PMAX = (PP > 0) ? PP : 32;
     constexpr int W = HALF ? (PMAX + 2 * FW_PG - 1) / (2 * FW_PG) : (PMAX + FW_PG - 1) / FW_PG;
     constexpr int PTS = HALF ? FW_PTS / 2 : FW_PTS;
     const int cover = a.out_soa ? (a.Npad > a.N ? a.Npad : a.N) : a.N;
     const size_t lds = sizeof(float) * (12 * (size_t)a.B * a.P + (size_t)a.H * (4 + PMAX) + 2 * (size_t)PTS * PMAX +
                                         (size_t)(a.H + 4) * PTS);
-    if (lds > REART_LDS_DEFAULT_CAP)   // stateless: raise the dynamic-LDS cap whenever the launch needs it (160 KiB per CU on gfx950)
-        (void)hipFuncSetAttribute((const void *)base_fwd_kernel<PP, HALF>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
-    hipLaunchKernelGGL((base_fwd_kernel<PP, HALF>), dim3(reart_div_up(cover, PTS)), dim3(64 * W), lds, st, a);
+    if (lds > REART_LDS_DEFAULT_CAP) {  // stateless: raise the dynamic-LDS cap whenever the launch needs it (160 KiB per CU on gfx950)
+        (void)hipFuncSetAttribute((const void *)base_fwd_kernel<PP, HALF, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+        (void)hipFuncSetAttribute((const void *)base_fwd_kernel<PP, HALF, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+    }
+    if (K == 1) hipLaunchKernelGGL((base_fwd_kernel<PP, HALF, false>), dim3(reart_div_up(cover, PTS)), dim3(64 * W), lds, st, reart_batched(ak, 1));
+    else hipLaunchKernelGGL((base_fwd_kernel<PP, HALF, true>), dim3(reart_div_up(cover, PTS), K), dim3(64 * W), lds, st, reart_batched(ak, K));
 }
 // a.pts = 64 | 32: points per forward workgroup (32, the default: half waves on different part pairs)
 template <int PP>
-static void launch_base_fwd(const BaseFwdArgs &a, hipStream_t st) {
-    if (a.pts == 64) launch_base_fwd_t<PP, false>(a, st);
-    else launch_base_fwd_t<PP, true>(a, st);
+static void launch_base_fwd(const BaseFwdArgs *a, int K, hipStream_t st) {
+    if (a[0].pts == 64) launch_base_fwd_t<PP, false>(a, K, st);
+    else launch_base_fwd_t<PP, true>(a, K, st);
 }
 
-static int dispatch_base_fwd(const BaseFwdArgs &a, hipStream_t st) {
+static int dispatch_base_fwd(const BaseFwdArgs *ak, int K, hipStream_t st) {
+    if (K < 1 || K > REART_BATCH_MAX) return REART_ERR_INVALID_ARG;
+    const BaseFwdArgs &a = ak[0];
+    for (int k = 1; k < K; ++k)      // one launch geometry for all
+        if (ak[k].N != a.N || ak[k].P != a.P || ak[k].B != a.B || ak[k].H != a.H || ak[k].Npad != a.Npad || ak[k].pts != a.pts ||
+            !ak[k].out_soa != !a.out_soa)
+            return REART_ERR_INVALID_ARG;
     if (a.P < 1 || a.P > 32) return REART_ERR_UNSUPPORTED;
     if (((size_t)a.B * a.P * 12 + 2 * FW_PTS * 32 + (size_t)a.H * (36 + FW_PTS) + 4 * FW_PTS) * sizeof(float) > 152 * 1024) return REART_ERR_UNSUPPORTED;
     switch (a.P) {
-        case 20: launch_base_fwd<20>(a, st); break;
-        case 10: launch_base_fwd<10>(a, st); break;
-        case 8: launch_base_fwd<8>(a, st); break;
-        default: launch_base_fwd<0>(a, st); break;
+        case 20: launch_base_fwd<20>(ak, K, st); break;
+        case 10: launch_base_fwd<10>(ak, K, st); break;
+        case 8: launch_base_fwd<8>(ak, K, st); break;
+        default: launch_base_fwd<0>(ak, K, st); break;
     }
     REART_CHECK_LAUNCH();
     return REART_OK;
@@ -427,11 +438,12 @@ extern "C" int reart_base_forward(const float *cano, int N, int P, int B, const 
     a.gumbel = gumbel; a.tau = tau; a.N = N; a.P = P; a.B = B; a.H = H; a.Npad = 0;
     a.out = out; a.seg_part = seg_part; a.trans_list = trans_list; a.yT = yT; a.hT = hT;
     a.hard_idx = hard_idx;
-    return dispatch_base_fwd(a, (hipStream_t)stream);
+    return dispatch_base_fwd(&a, 1, (hipStream_t)stream);
 }
 
 // entry used by the fused step (step.hip)
-int reart_base_forward_ex(const BaseFwdArgs &a, hipStream_t st) { return dispatch_base_fwd(a, st); }
+int reart_base_forward_ex(const BaseFwdArgs &a, hipStream_t st) { return dispatch_base_fwd(&a, 1, st); }
+int reart_base_forward_batch(const BaseFwdArgs *a, int K, hipStream_t st) { return dispatch_base_fwd(a, K, st); }
 
 // ------------------------------------------------------------------------------- backward
 // layout of one partial row / of the reduced gradient vector
@@ -468,8 +480,9 @@ __global__ __launch_bounds__(256) void rt_table_kernel(const float *__restrict__
 //      with a register accumulator -- no LDS read-modify-write chain, no atomics.
 #define BW_LD (RED_CHUNK + 1)
 
-template <int PP>
-__global__ __launch_bounds__(64 * (((PP > 0 ? PP : 32) + FW_PG - 1) / FW_PG)) void base_bwd_block_kernel(BaseBwdArgs a) {
+template <int PP, bool BATCH>
+__global__ __launch_bounds__(64 * (((PP > 0 ? PP : 32) + FW_PG - 1) / FW_PG)) void base_bwd_block_kernel(Batched<BaseBwdArgs> ab) {
+    const BaseBwdArgs &a = ab.a[BATCH ? blockIdx.y : 0];
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int PMAX = (PP > 0) ? PP : 32;
     constexpr int W = (PMAX + FW_PG - 1) / FW_PG;
@@ -890,7 +903,11 @@ __device__ __forceinline__ void base_bwd_finalize_body(const BaseBwdArgs &a, con
     }
 }
 
-__global__ __launch_bounds__(256) void base_bwd_finalize_kernel(BaseBwdArgs a, FinalizeAdam ad, StepBook bk) {
+template <bool BATCH>
+__global__ __launch_bounds__(256) void base_bwd_finalize_kernel(Batched<BaseBwdArgs> ab, Batched<FinalizeAdam> adb, Batched<StepBook> bkb) {
+    const BaseBwdArgs &a = ab.a[BATCH ? blockIdx.y : 0];
+    const FinalizeAdam &ad = adb.a[BATCH ? blockIdx.y : 0];
+    const StepBook &bk = bkb.a[BATCH ? blockIdx.y : 0];
     // Bookkeeping is done by the LAST workgroup to finish (ticket): by then every other workgroup has
     // consumed this iteration's counters.  Every workgroup prepares it speculatively up front -- the
     // loss partials are loaded and the next temperature / bias corrections computed while the main
@@ -952,54 +969,74 @@ extern "C" size_t reart_base_backward_workspace_bytes(int N, int P, int B, int H
 }
 
 template <int PP>
-static int launch_bwd_block(const BaseBwdArgs &a, size_t lds, hipStream_t st) {
+static int launch_bwd_block(const BaseBwdArgs *ak, int K, size_t lds, hipStream_t st) {
     if (lds > REART_LDS_DEFAULT_CAP &&
-        hipFuncSetAttribute((const void *)base_bwd_block_kernel<PP>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            152 * 1024) != hipSuccess)
+        (hipFuncSetAttribute((const void *)base_bwd_block_kernel<PP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess ||
+         hipFuncSetAttribute((const void *)base_bwd_block_kernel<PP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess))
         return REART_ERR_LAUNCH;
     constexpr int W = (((PP > 0) ? PP : 32) + FW_PG - 1) / FW_PG;
-    hipLaunchKernelGGL((base_bwd_block_kernel<PP>), dim3(a.nchunk), dim3(64 * W), lds, st, a);
+    if (K == 1) hipLaunchKernelGGL((base_bwd_block_kernel<PP, false>), dim3(ak[0].nchunk), dim3(64 * W), lds, st, reart_batched(ak, 1));
+    else hipLaunchKernelGGL((base_bwd_block_kernel<PP, true>), dim3(ak[0].nchunk, K), dim3(64 * W), lds, st, reart_batched(ak, K));
     return REART_OK;
 }
 
-// a.rt_table == NULL: the table is built into the workspace first (one extra tiny launch)
-int reart_base_backward_ex(BaseBwdArgs a, const FinalizeAdam *adam, const StepBook *book, void *workspace,
-                           size_t workspace_bytes, hipStream_t st) {
-    if (a.P > 32) return REART_ERR_UNSUPPORTED;
+// K instances of one shape (K = 1: the plain entry); workspaces[k] is instance k's backward workspace.
+// a.rt_table == NULL: the table is built into the workspace first (one extra tiny launch per instance)
+int reart_base_backward_batch(const BaseBwdArgs *args, const FinalizeAdam *adam, const StepBook *book, void *const *workspaces,
+                              size_t workspace_bytes, int K, hipStream_t st) {
+    if (K < 1 || K > REART_BATCH_MAX) return REART_ERR_INVALID_ARG;
+    BaseBwdArgs ak[REART_BATCH_MAX];
+    for (int k = 0; k < K; ++k) ak[k] = args[k];
+    const BaseBwdArgs &a0 = ak[0];
+    if (a0.P > 32) return REART_ERR_UNSUPPORTED;
     size_t o_rt, o_part;
-    const size_t need = base_bwd_ws_layout(a.N, a.P, a.B, a.H, &o_rt, &o_part);
-    if (!workspace || workspace_bytes < need) return REART_ERR_INVALID_ARG;
-    char *ws = (char *)workspace;
-    a.partial = (float *)(ws + o_part);
-    a.cpts = (a.cpts == 64 || a.cpts == 32 || a.cpts == 16) ? a.cpts : 32;   // points per backward workgroup
-    a.nchunk = reart_div_up(a.N, a.cpts);
-    if (!a.rt_table) {
-        float *table = (float *)(ws + o_rt);
-        hipLaunchKernelGGL(rt_table_kernel, dim3(reart_div_up(a.B * a.P, 256)), dim3(256), 0, st, a.p6d, a.pt,
-                           a.B * a.P, table);
-        a.rt_table = table;
+    const size_t need = base_bwd_ws_layout(a0.N, a0.P, a0.B, a0.H, &o_rt, &o_part);
+    if (!workspaces || workspace_bytes < need) return REART_ERR_INVALID_ARG;
+    for (int k = 0; k < K; ++k) {
+        BaseBwdArgs &a = ak[k];
+        a.cpts = (a.cpts == 64 || a.cpts == 32 || a.cpts == 16) ? a.cpts : 32;   // points per backward workgroup
+        a.nchunk = reart_div_up(a.N, a.cpts);
+        if (a.N != a0.N || a.P != a0.P || a.B != a0.B || a.H != a0.H || a.cpts != a0.cpts || !workspaces[k]) return REART_ERR_INVALID_ARG;
+        char *ws = (char *)workspaces[k];
+        a.partial = (float *)(ws + o_part);
+        if (!a.rt_table) {
+            float *table = (float *)(ws + o_rt);
+            hipLaunchKernelGGL(rt_table_kernel, dim3(reart_div_up(a.B * a.P, 256)), dim3(256), 0, st, a.p6d, a.pt,
+                               a.B * a.P, table);
+            a.rt_table = table;
+        }
     }
-    const int PMAX = (a.P == 20 || a.P == 10 || a.P == 8) ? a.P : 32;
-    const size_t lds = sizeof(float) * ((size_t)(a.H + PMAX) * BW_LD + RED_CHUNK * 5 + PMAX + 4 +
-                                        (size_t)a.B * RED_CHUNK * 3 + (size_t)a.H * PMAX + 12 * (size_t)a.B * a.P);
+    const int PMAX = (a0.P == 20 || a0.P == 10 || a0.P == 8) ? a0.P : 32;
+    const size_t lds = sizeof(float) * ((size_t)(a0.H + PMAX) * BW_LD + RED_CHUNK * 5 + PMAX + 4 +
+                                        (size_t)a0.B * RED_CHUNK * 3 + (size_t)a0.H * PMAX + 12 * (size_t)a0.B * a0.P);
     if (lds > 152 * 1024) return REART_ERR_UNSUPPORTED;
     int rc;
-    switch (a.P) {
-        case 20: rc = launch_bwd_block<20>(a, lds, st); break;
-        case 10: rc = launch_bwd_block<10>(a, lds, st); break;
-        case 8: rc = launch_bwd_block<8>(a, lds, st); break;
-        default: rc = launch_bwd_block<0>(a, lds, st); break;
+    switch (a0.P) {
+        case 20: rc = launch_bwd_block<20>(ak, K, lds, st); break;
+        case 10: rc = launch_bwd_block<10>(ak, K, lds, st); break;
+        case 8: rc = launch_bwd_block<8>(ak, K, lds, st); break;
+        default: rc = launch_bwd_block<0>(ak, K, lds, st); break;
     }
     if (rc != REART_OK) return rc;
-    FinalizeAdam none = {};
-    StepBook nobook = {};
+    Batched<FinalizeAdam> adb = {};
+    Batched<StepBook> bkb = {};
+    for (int k = 0; k < K; ++k) {
+        if (adam) adb.a[k] = adam[k];
+        if (book) bkb.a[k] = book[k];
+    }
     // weights: one thread per entry; poses: 16 lanes per (frame, part); nW is rounded up to a multiple of 64
     // inside the kernel's indexing so that a 16-lane group never straddles a wave
-    const int nfin = (int)reart_align_up((size_t)4 * (a.P * a.H + 4 * a.H), 64) + 64 * a.B * a.P;
-    hipLaunchKernelGGL(base_bwd_finalize_kernel, dim3(reart_div_up(nfin, 256)), dim3(256), 0, st, a,
-                       adam ? *adam : none, book ? *book : nobook);
+    const int nfin = (int)reart_align_up((size_t)4 * (a0.P * a0.H + 4 * a0.H), 64) + 64 * a0.B * a0.P;
+    if (K == 1) hipLaunchKernelGGL(base_bwd_finalize_kernel<false>, dim3(reart_div_up(nfin, 256)), dim3(256), 0, st, reart_batched(ak, 1), adb, bkb);
+    else hipLaunchKernelGGL(base_bwd_finalize_kernel<true>, dim3(reart_div_up(nfin, 256), K), dim3(256), 0, st, reart_batched(ak, K), adb, bkb);
     REART_CHECK_LAUNCH();
     return REART_OK;
+}
+
+int reart_base_backward_ex(BaseBwdArgs a, const FinalizeAdam *adam, const StepBook *book, void *workspace,
+                           size_t workspace_bytes, hipStream_t st) {
+    void *w[1] = {workspace};
+    return reart_base_backward_batch(&a, adam, book, w, workspace_bytes, 1, st);
 }
 
 extern "C" int reart_base_backward(const float *cano, int N, int P, int B, const float *W1,

@@ -449,7 +449,10 @@ __device__ __forceinline__ void knn_pruned_wave(const KnnJob &jb, const int S, c
 // ------------------------------------------------------------------------------------------------------------
 // The search launch: up to two K = 1 jobs (the Chamfer directions) and one K = 3 job (the flow search);
 // SearchArgs is declared in internal.h.
-__global__ __launch_bounds__(64 * PR_SMAX) void knn_group_kernel(SearchArgs a) {
+template <bool BATCH>
+__global__ __launch_bounds__(64 * PR_SMAX) void knn_group_kernel(Batched<SearchArgs> ab) {
+    // instance of a batch (gridDim.x is a multiple of 8: blockIdx.x & 7 is still the XCD); a single one reads at a fixed offset
+    const SearchArgs &a = ab.a[BATCH ? blockIdx.y : 0];
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];      // blockDim.x / 64 x PR_LDS_WAVE_BYTES
     __shared__ float s_m[PR_SMAX][3][64];
     __shared__ int s_b[PR_SMAX][3][64];
@@ -729,8 +732,7 @@ static size_t search_cloud_lds(const SearchArgs &a) {
     return need <= 152 * 1024 ? need : 0;
 }
 
-int reart_search_launch(const SearchArgs &a_in, hipStream_t st) {
-    SearchArgs a = a_in;
+static int search_check(SearchArgs &a) {
     if (a.n1 < 0 || a.n1 > 2 || a.n3 < 0 || a.n3 > 1 || a.n1 + a.n3 == 0 || a.G < 1) return REART_ERR_INVALID_ARG;
     if ((a.n1 && (a.S1 < 1 || a.S1 > PR_SMAX)) || (a.n3 && (a.S3 < 1 || a.S3 > PR_SMAX))) return REART_ERR_INVALID_ARG;
     for (int j = 0; j < a.n1; ++j)
@@ -738,6 +740,13 @@ int reart_search_launch(const SearchArgs &a_in, hipStream_t st) {
     if (a.n3 && (!a.k3.boxes || !a.k3.seed || !a.k3.pd || !a.k3.pi)) return REART_ERR_INVALID_ARG;
     a.per = reart_div_up(a.G, 8);
     a.k_nqg = a.n1 ? a.k1[0].nqg : a.k3.nqg;
+    return REART_OK;
+}
+
+int reart_search_launch(const SearchArgs &a_in, hipStream_t st) {
+    SearchArgs a = a_in;
+    const int rc = search_check(a);
+    if (rc != REART_OK) return rc;
     const size_t cl_lds = a.cloud_resident ? search_cloud_lds(a) : 0;
     a.cloud_slices = (a.cloud_slices == 1 || a.cloud_slices == 2 || a.cloud_slices == 4 || a.cloud_slices == 8) ? a.cloud_slices : 4;
     if (cl_lds) {
@@ -748,9 +757,24 @@ int reart_search_launch(const SearchArgs &a_in, hipStream_t st) {
         REART_CHECK_LAUNCH();
         return REART_OK;
     }
+    return reart_search_launch_batch(&a, 1, st);
+}
+// K searches of one geometry in one launch (group form): instance k is the grid's row k
+int reart_search_launch_batch(const SearchArgs *ak, int K, hipStream_t st) {
+    if (K < 1 || K > REART_BATCH_MAX) return REART_ERR_INVALID_ARG;
+    Batched<SearchArgs> ab = {};
+    for (int k = 0; k < K; ++k) {
+        ab.a[k] = ak[k];
+        const int rc = search_check(ab.a[k]);
+        if (rc != REART_OK) return rc;
+        const SearchArgs &a = ab.a[k], &a0 = ab.a[0];
+        if (a.n1 != a0.n1 || a.n3 != a0.n3 || a.G != a0.G || a.S1 != a0.S1 || a.S3 != a0.S3) return REART_ERR_INVALID_ARG;
+    }
+    const SearchArgs &a = ab.a[0];
     const int S = (a.n1 ? a.S1 : 0) > (a.n3 ? a.S3 : 0) ? a.S1 : a.S3;
     const size_t lds = (size_t)S * PR_LDS_WAVE_BYTES;
-    hipLaunchKernelGGL(knn_group_kernel, dim3(reart_search_grid(a.n1, a.n3, a.G)), dim3(64 * S), lds, st, a);
+    if (K == 1) hipLaunchKernelGGL(knn_group_kernel<false>, dim3(reart_search_grid(a.n1, a.n3, a.G)), dim3(64 * S), lds, st, ab);
+    else hipLaunchKernelGGL(knn_group_kernel<true>, dim3(reart_search_grid(a.n1, a.n3, a.G), K), dim3(64 * S), lds, st, ab);
     REART_CHECK_LAUNCH();
     return REART_OK;
 }

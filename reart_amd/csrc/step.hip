@@ -628,8 +628,9 @@ __device__ __forceinline__ void prof_body(const OrderArgs &o) {
     }
 }
 struct PostArgs { FlowArgs fl; CGradArgs cg; OrderArgs od; int nfx, nflow, ncx, nwork, norder; };
-template <bool ONE>
-__global__ __launch_bounds__(CG_BS) void post_kernel(PostArgs a) {
+template <bool ONE, bool BATCH>
+__global__ __launch_bounds__(CG_BS) void post_kernel(Batched<PostArgs> ab) {
+    const PostArgs &a = ab.a[BATCH ? blockIdx.y : 0];
     const int w = blockIdx.x;
     if (w < a.nflow) flow_blend_body<ONE, CG_BS>(a.fl, w % a.nfx, w / a.nfx, a.nfx);
     else if (w < a.nwork) chamfer_grad_body<ONE>(a.cg, (w - a.nflow) % a.ncx, (w - a.nflow) / a.ncx, a.ncx);
@@ -682,9 +683,16 @@ __global__ __launch_bounds__(CG_BS) void assign_grad_kernel(AssignArgs a) {
 // ------------------------------------------------------------------------------ the step
 #define MARK(k) do { if (ev) (void)hipEventRecord(ev[k], st); } while (0)
 
+// the four launches of the default iteration (box-pruned search, Chamfer + flow) as argument blocks: what
+// reart_relax_step_batch collects from every instance before it launches each kernel once for all of them
+struct StepLaunch {
+    BaseFwdArgs fa; SearchArgs sa; PostArgs pa; int post_blocks;
+    BaseBwdArgs ba; FinalizeAdam ad; StepBook bk; void *ws_bwd; size_t bwd_bytes;
+};
+
 static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buffers *bufs,
                            void *workspace, size_t workspace_bytes, void *stream, hipEvent_t *ev,
-                           bool forward_only = false) {
+                           bool forward_only = false, StepLaunch *collect = nullptr) {
     StepPlan p;
     if (!cfg || !bufs) return REART_ERR_INVALID_ARG;
     int rc = step_plan(cfg, &p);
@@ -711,8 +719,11 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
     fa.boxes = c.use_boxes ? (float *)(ws + p.o_boxX) : nullptr;
     fa.pts = c.tune_fwd_pts;
     MARK(0);
-    rc = reart_base_forward_ex(fa, st);
-    if (rc != REART_OK) return rc;
+    if (collect) collect->fa = fa;
+    else {
+        rc = reart_base_forward_ex(fa, st);
+        if (rc != REART_OK) return rc;
+    }
     MARK(1);
     if (forward_only) return REART_OK;
     if (c.use_assign && !bufs->assign_map) return REART_ERR_INVALID_ARG;
@@ -756,6 +767,7 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
     const bool chamfer = !c.use_assign;
     // merged: Chamfer + flow on the pruned path -- ONE search launch, ONE consumer launch
     const bool merged = p.pruned && c.use_flow && chamfer;
+    if (collect && !merged) return REART_ERR_UNSUPPORTED;
     // Brute-force / grid variants keep their separate launches; with an auxiliary stream from the caller their
     // flow branch runs beside the Chamfer search (fork / join).  The timed variant is always serial.
     const bool forked = !p.pruned && !ev && bufs->aux_stream && bufs->ev_fork && bufs->ev_join && c.use_flow;
@@ -780,8 +792,13 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
         if (sa.n1 + sa.n3 > 0) {
             search_wgs = reart_search_workgroups(sa);
             search_static_order = search_wgs != reart_search_grid(sa.n1, sa.n3, sa.G);   // cloud-resident form: fixed order
-            rc = reart_search_launch(sa, st);
-            if (rc != REART_OK) return rc;
+            if (collect) {
+                if (search_static_order) return REART_ERR_UNSUPPORTED;
+                collect->sa = sa;
+            } else {
+                rc = reart_search_launch(sa, st);
+                if (rc != REART_OK) return rc;
+            }
         }
     } else {
         if (c.use_flow) {
@@ -880,7 +897,8 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
                 pa.od.nprof = search_wgs;
                 nblk += 1;
             }
-            hipLaunchKernelGGL(post_kernel<true>, dim3(nblk), dim3(CG_BS), 0, st, pa);
+            if (collect) { collect->pa = pa; collect->post_blocks = nblk; }
+            else hipLaunchKernelGGL((post_kernel<true, false>), dim3(nblk), dim3(CG_BS), 0, st, reart_batched(&pa, 1));
         } else if (cg.S0 <= 4 && cg.S1 <= 4) hipLaunchKernelGGL(chamfer_grad_kernel<true>, dim3(ncg, B), dim3(CG_BS), 0, st, cg);
         else hipLaunchKernelGGL(chamfer_grad_kernel<false>, dim3(ncg, B), dim3(CG_BS), 0, st, cg);
         REART_CHECK_LAUNCH();
@@ -914,6 +932,10 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
     bk.ticket = (unsigned int *)(ws + p.o_ticket);
     bk.ring = c.ring; bk.n_iter = c.n_iter; bk.lambda_flow = c.lambda_flow; bk.fixed_tau = c.fixed_tau;
     bk.end_tau = c.end_tau; bk.start_tau = c.start_tau; bk.beta1 = c.beta1; bk.beta2 = c.beta2;
+    if (collect) {
+        collect->ba = ba; collect->ad = ad; collect->bk = bk; collect->ws_bwd = ws + p.o_bwd; collect->bwd_bytes = p.bwd_bytes;
+        return REART_OK;
+    }
     rc = reart_base_backward_ex(ba, &ad, &bk, ws + p.o_bwd, p.bwd_bytes, st);
     if (rc != REART_OK) return rc;
     MARK(6);
@@ -925,6 +947,44 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
 extern "C" int reart_relax_step(const reart_relax_config *cfg, const reart_relax_buffers *bufs,
                                 void *workspace, size_t workspace_bytes, void *stream) {
     return relax_step_impl(cfg, bufs, workspace, workspace_bytes, stream, nullptr);
+}
+
+// K independent instances of ONE shape (same N, B, P, H, M_max and switches; poses, clouds, canonical index, seeds and
+// learning rates are each instance's own) advance one iteration in the launches of a single instance: every kernel of the
+// iteration runs once with K argument blocks, instance k on the grid's row k.  One instance leaves most of the chip idle
+// (64-608 workgroups per launch on 256 compute units, and the iteration is a chain of five dependent launches): a sweep
+// over canonical frames (README.md:60) fills it this way instead of with K streams that the hardware queues interleave
+// as they please.  Each instance computes exactly what reart_relax_step computes for it.  Default iteration only
+// (box-pruned search, Chamfer + flow); K <= 6.
+extern "C" int reart_relax_step_batch(const reart_relax_config *cfgs, const reart_relax_buffers *bufs, void *const *workspaces,
+                                      size_t workspace_bytes, int K, void *stream) {
+    if (!cfgs || !bufs || !workspaces || K < 1 || K > REART_BATCH_MAX) return REART_ERR_INVALID_ARG;
+    static_assert(sizeof(Batched<SearchArgs>) <= 3584, "kernel-argument segment");
+    StepLaunch L[REART_BATCH_MAX];
+    for (int k = 0; k < K; ++k) {
+        const int rc = relax_step_impl(&cfgs[k], &bufs[k], workspaces[k], workspace_bytes, stream, nullptr, false, &L[k]);
+        if (rc != REART_OK) return rc;
+        if (L[k].post_blocks != L[0].post_blocks || L[k].bwd_bytes != L[0].bwd_bytes) return REART_ERR_INVALID_ARG;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    BaseFwdArgs fa[REART_BATCH_MAX];
+    SearchArgs sa[REART_BATCH_MAX];
+    Batched<PostArgs> pa = {};
+    BaseBwdArgs ba[REART_BATCH_MAX];
+    FinalizeAdam ad[REART_BATCH_MAX];
+    StepBook bk[REART_BATCH_MAX];
+    void *wb[REART_BATCH_MAX];
+    for (int k = 0; k < K; ++k) {
+        fa[k] = L[k].fa; sa[k] = L[k].sa; pa.a[k] = L[k].pa; ba[k] = L[k].ba; ad[k] = L[k].ad; bk[k] = L[k].bk; wb[k] = L[k].ws_bwd;
+    }
+    int rc = reart_base_forward_batch(fa, K, st);
+    if (rc != REART_OK) return rc;
+    rc = reart_search_launch_batch(sa, K, st);
+    if (rc != REART_OK) return rc;
+    if (K == 1) hipLaunchKernelGGL((post_kernel<true, false>), dim3(L[0].post_blocks), dim3(CG_BS), 0, st, pa);
+    else hipLaunchKernelGGL((post_kernel<true, true>), dim3(L[0].post_blocks, K), dim3(CG_BS), 0, st, pa);
+    REART_CHECK_LAUNCH();
+    return reart_base_backward_batch(ba, ad, bk, wb, L[0].bwd_bytes, K, st);
 }
 
 // Same launch sequence with a hipEvent between phases, recorded on `stream`; synchronises the

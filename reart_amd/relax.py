@@ -112,6 +112,9 @@ def _lib_fns():
         L.reart_relax_step_timed.restype = c_int
         L.reart_relax_step_timed.argtypes = [ctypes.POINTER(RelaxConfig), ctypes.POINTER(RelaxBuffers), c_void_p,
                                              ctypes.c_size_t, c_void_p, ctypes.POINTER(c_float)]
+        L.reart_relax_step_batch.restype = c_int
+        L.reart_relax_step_batch.argtypes = [ctypes.POINTER(RelaxConfig), ctypes.POINTER(RelaxBuffers), ctypes.POINTER(c_void_p),
+                                             ctypes.c_size_t, c_int, c_void_p]
         L.reart_relax_profile.restype = c_int
         L.reart_relax_profile.argtypes = [ctypes.POINTER(RelaxConfig), c_void_p, ctypes.c_size_t, c_void_p,
                                           ctypes.POINTER(ctypes.c_double), c_int]
@@ -346,3 +349,54 @@ class RelaxEngine:
     def last_losses(self):
         it = int(self.iter.item())
         return self.losses[(it - 1) % self.ring].clone()
+
+
+class RelaxBatch:
+    """Up to ``MAX`` engines of ONE shape stepping together: every kernel of the iteration is launched once for all of them
+    (``reart_relax_step_batch``), each engine computing exactly what its own ``step()`` would.  The sweep over canonical
+    frames (README.md:60) runs its instances this way -- one instance leaves most of the 256 compute units idle.
+    The engines keep their own state; read results from them as usual."""
+
+    MAX = 6
+
+    def __init__(self, engines):
+        engines = list(engines)
+        if not 1 <= len(engines) <= self.MAX:
+            raise ValueError(f"RelaxBatch takes 1..{self.MAX} engines")
+        nb = {e.workspace.numel() for e in engines}
+        if len(nb) != 1:
+            raise ValueError("RelaxBatch: the engines must share one shape")
+        self.engines = engines
+        K = len(engines)
+        self._cfgs = (RelaxConfig * K)(*[e.cfg for e in engines])
+        self._bufs = (RelaxBuffers * K)(*[e._bufs for e in engines])
+        self._ws = (c_void_p * K)(*[e.workspace.data_ptr() for e in engines])
+        self._nbytes = nb.pop()
+        self._graph = None
+        self.graph_replays = self.eager_steps = 0
+
+    def _enqueue(self):
+        rc = _lib_fns().reart_relax_step_batch(self._cfgs, self._bufs, self._ws, self._nbytes, len(self.engines), _lib.stream())
+        _lib.check(rc, "reart_relax_step_batch")
+
+    def capture(self, steps_per_graph=1):
+        """Capture ``steps_per_graph`` iterations of all engines into one graph; ``step()`` then replays it."""
+        self._enqueue()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(steps_per_graph):
+                self._enqueue()
+        self._graph, self._steps_per_graph = g, steps_per_graph
+        return 1
+
+    def step(self, n=1):
+        """n iterations of every engine (asynchronous)."""
+        if self._graph is not None:
+            for _ in range(n // self._steps_per_graph):
+                self._graph.replay()
+            self.graph_replays += n // self._steps_per_graph
+            n %= self._steps_per_graph
+        for _ in range(n):
+            self._enqueue()
+        self.eager_steps += n

@@ -335,3 +335,51 @@ def test_weight_decay_matches_oracle(oracle, dev):
             np.testing.assert_allclose(got, orc.params[k], rtol=0, atol=2e-5, err_msg=f"wd {decay} param {k}")
         finals[decay] = model.seg_head.model[2].weight.detach().cpu().numpy().copy()
     assert np.abs(finals[wd] - finals[0.0]).max() > 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K", [1, 3, 6])
+def test_batched_instances_equal_separate_engines(dev, K):
+    """reart_relax_step_batch: K instances of one shape (their own canonical frame, clouds, parameters, seeds) stepping in
+    shared launches -- eagerly and replayed from one graph -- leave bit for bit what K separate engines leave."""
+    from reart_amd.networks.model import BaseModel
+    from reart_amd.relax import RelaxBatch, RelaxEngine
+    from reart_amd.synthetic import make_sequence, split_canonical
+
+    seq = make_sequence(T=6, n_parts=4, pts_per_part=300, seed=5, n_ref=700, with_flow=True)
+
+    def build():
+        out = []
+        for k in range(K):
+            ci = k % 6
+            cano, pcs = split_canonical(seq["complete"], ci)
+            torch.manual_seed(10 + k)
+            model = BaseModel(num_parts=12, pose_len=5).to(dev)
+            refs = [t(r, dev) for r in seq["ref_loc"]], [t(f, dev) for f in seq["ref_flow"]]
+            out.append((RelaxEngine(t(cano, dev), t(pcs, dev), model, ci, refs[0], refs[1], n_iter=200, seed=100 + k), model))
+        return out
+
+    def state(eng, model):
+        it, log = eng.loss_log()
+        return (log.cpu().numpy(), model.proposal_6d.detach().cpu().numpy().copy(), model.proposal_t.detach().cpu().numpy().copy(),
+                model.seg_head.model[2].weight.detach().cpu().numpy().copy(), eng.pc_trans.cpu().numpy(), eng.seg_part.cpu().numpy())
+
+    solo = build()
+    for eng, _ in solo:
+        eng.step(36)
+    batched = build()
+    batch = RelaxBatch([e for e, _ in batched])
+    batch.step(11)                       # eager
+    batch.capture(steps_per_graph=4)     # +1 (warm-up)
+    batch.step(24)                       # 6 replays
+    assert batch.graph_replays == 6 and batch.eager_steps == 11
+    torch.cuda.synchronize()
+    for (e0, m0), (e1, m1) in zip(solo, batched):
+        a, b = state(e0, m0), state(e1, m1)
+        assert np.isfinite(a[0]).all() and a[0].shape == b[0].shape
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x, y)
+    if K > 1:    # the instances really are different problems
+        assert not np.array_equal(state(*solo[0])[1], state(*solo[1])[1])
+    with pytest.raises(ValueError):
+        RelaxBatch([])
