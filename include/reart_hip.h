@@ -435,7 +435,10 @@ int reart_lap_auction_warm(const float *cost, int B, int n, int32_t *col4row, in
  * after every Adam step, run_robot.py:165-178): shortest augmenting paths (Jonker-Volgenant) started from the previous
  * solve's assignment (col4row on entry) and potentials (price_in, required) -- pairs that still attain their row's
  * minimum are kept, every other row costs one Dijkstra search over the reduced costs.  Same outputs, same exact
- * certificate as reart_lap_auction; the first solve of a sequence comes from reart_lap_auction. */
+ * certificate as reart_lap_auction; the first solve of a sequence comes from reart_lap_auction.  For n >= 512 the call is
+ * four launches on `stream`: the rows' (min, arg-min) under the incoming potentials on the whole chip, the sequential
+ * part with one workgroup per matrix, the first certificate round on the whole chip, and the remaining certificate
+ * rounds for a matrix that needs them (normally none); the intermediate arrays live in `workspace`. */
 int reart_lap_resolve(const float *cost, int B, int n, int32_t *col4row, int32_t *certified,
                       const double *price_in, double *price_out, void *workspace, size_t workspace_bytes,
                       void *stream);
