@@ -363,13 +363,9 @@ void base_fwd_kernel(Batched<BaseFwdArgs> ab) {
             float lo[3], hi[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                lo[c] = live ? v[c] : INFINITY;
-                hi[c] = live ? v[c] : -INFINITY;
-#pragma unroll
-                for (int o = NN_BOX / 2; o >= 1; o >>= 1) {
-                    lo[c] = fminf(lo[c], __shfl_xor(lo[c], o, 64));
-                    hi[c] = fmaxf(hi[c], __shfl_xor(hi[c], o, 64));
-                }
+                static_assert(NN_BOX == 16, "a box is one DPP row");
+                lo[c] = reart_row16_min(live ? v[c] : INFINITY);        // four DPP steps each, no LDS crossbar; a row lies inside
+                hi[c] = reart_row16_max(live ? v[c] : -INFINITY);       // one half wave, so its lanes are active together
                 if (hi[c] == -INFINITY) hi[c] = INFINITY;
             }
             const int pos = blockIdx.x * PTS + pl;
