@@ -299,7 +299,7 @@ class RelaxEngine:
         self._enqueue()  # warm-up outside capture (lazy module load)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):   # other threads (an RCCL watchdog) may touch the runtime
             for _ in range(steps_per_graph):
                 self._enqueue()
         self._graph, self._steps_per_graph = g, steps_per_graph
@@ -384,7 +384,7 @@ class RelaxBatch:
         self._enqueue()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):   # other threads (an RCCL watchdog) may touch the runtime
             for _ in range(steps_per_graph):
                 self._enqueue()
         self._graph, self._steps_per_graph = g, steps_per_graph
