@@ -99,7 +99,7 @@ def run_sweep(instances, run_instance, device):
     return records, best_instance(records)
 
 
-def run_sweep_engines(instances, make_engine, n_iter, device, per_gpu=3, chunk=100, energy=False):
+def run_sweep_engines(instances, make_engine, n_iter, device, per_gpu=3, chunk=100, energy=False, mode="streams"):
     """Sweep of fused-loop instances with ``per_gpu`` of them in flight per GPU.
 
     One instance of the relaxation loop is a chain of short, latency-bound launches that leaves
@@ -108,7 +108,12 @@ def run_sweep_engines(instances, make_engine, n_iter, device, per_gpu=3, chunk=1
     prepared ``reart_amd.relax.RelaxEngine`` (its tensors live on ``device``); this rank's instances
     are optimised ``per_gpu`` at a time, stepped round-robin in graph replays of ``chunk``
     iterations.  ``energy=True`` finishes every instance with the reference's structure extraction and energy terms
-    (``instance_energy``), which then decide the winner.  Returns (records [n, RECORD], best index) like ``run_sweep``."""
+    (``instance_energy``), which then decide the winner.  ``mode="batch"``: the instances of a group (same shape; up to
+    ``RelaxBatch.MAX``) advance in SHARED launches (``reart_relax_step_batch``) instead of on one stream each -- the same
+    results, and an aggregate rate that does not depend on how the runtime maps streams to hardware queues.
+    Returns (records [n, RECORD], best index) like ``run_sweep``."""
+    if mode not in ("streams", "batch"):
+        raise ValueError("mode is 'streams' or 'batch'")
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     mine = shard(len(instances), rank, world)
@@ -122,11 +127,24 @@ def run_sweep_engines(instances, make_engine, n_iter, device, per_gpu=3, chunk=1
             try:
                 with torch.cuda.stream(st):
                     eng = make_engine(spec)
-                    done = eng.capture(steps_per_graph=min(chunk, n_iter))
+                    done = eng.capture(steps_per_graph=min(chunk, n_iter)) if mode == "streams" else 0
                 live.append([inst, spec, eng, st, done])
             except Exception:  # a failed instance is reported (NaN energy), it does not kill the job
                 local[inst] = _record(inst, spec, failed=1)
-        while any(e[4] < n_iter for e in live):
+        if mode == "batch" and live:
+            from .relax import RelaxBatch
+
+            for e in live:
+                e[3].synchronize()                       # the engines were prepared on their own streams
+            for b0 in range(0, len(live), RelaxBatch.MAX):
+                part = live[b0:b0 + RelaxBatch.MAX]
+                batch = RelaxBatch([e[2] for e in part])
+                used = batch.capture(steps_per_graph=min(chunk, n_iter - 1)) if n_iter > 1 else 0
+                batch.step(n_iter - used)
+                for e in part:
+                    e[4] = n_iter
+            torch.cuda.current_stream(device).synchronize()
+        while any(e[4] < n_iter for e in live):          # streams: round-robin graph replays (nothing left to do after a batch)
             for e in live:
                 if e[4] < n_iter:
                     n = min(chunk, n_iter - e[4])

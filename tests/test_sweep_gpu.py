@@ -7,7 +7,8 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def test_concurrent_instances_match_solo_runs(dev):
+@pytest.mark.parametrize("mode", ["streams", "batch"])
+def test_concurrent_instances_match_solo_runs(dev, mode):
     from reart_amd.networks.model import BaseModel
     from reart_amd.relax import RelaxEngine
     from reart_amd.sweep import run_sweep_engines
@@ -24,7 +25,7 @@ def test_concurrent_instances_match_solo_runs(dev):
                            [t(f) for f in seq["ref_flow"]], n_iter=60, seed=7 + spec["cano_idx"])
 
     instances = [{"cano_idx": c} for c in range(5)]
-    rec, best = run_sweep_engines(instances, make_engine, 60, dev, per_gpu=3, chunk=20)
+    rec, best = run_sweep_engines(instances, make_engine, 60, dev, per_gpu=3, chunk=20, mode=mode)
     rec = rec.cpu().numpy()
     assert np.isfinite(rec[:, 2:5]).all() and (rec[:, 5] == 60).all()
     for c in range(5):
