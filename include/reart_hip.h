@@ -423,6 +423,14 @@ int reart_lap_auction(const float *cost, int B, int n, int32_t *col4row, int32_t
                       const double *price_in, double *price_out, void *workspace, size_t workspace_bytes,
                       void *stream);
 
+/* The same solve for Euclidean costs between two point sets: cost must be reart_cdist(src, tgt) (src, tgt [B,n,3]) -- what
+ * /root/reference/utils/model_utils.py:92-104 (compute_ass_err) and run_robot.py:170-176 build with torch.cdist.  The long
+ * single-bidder chains at the end of every phase then recompute their rows from the points instead of reading them
+ * (a dependent row read per link otherwise).  Result and potentials identical to reart_lap_auction on the same matrix. */
+int reart_lap_auction_points(const float *cost, const float *src, const float *tgt, int B, int n, int32_t *col4row,
+                             int32_t *certified, const double *price_in, double *price_out, void *workspace,
+                             size_t workspace_bytes, void *stream);
+
 /* The same solve warm-started from an earlier solve of a similar batch (the loop re-solves every assign_gap
  * iterations): on entry col4row holds that solve's assignment and price_in (required) its potentials; pairs that are
  * still epsilon-tight under the new costs are kept.  Certified like a cold solve.  Use when the costs move smoothly

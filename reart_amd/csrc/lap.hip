@@ -28,6 +28,9 @@
 // (which raises the prices by the least possible amount) the NEXT phase pays with 3-5x the rounds; from the 7th phase
 // on (eps <= 3e-6 of the largest cost) nothing is left to settle, the search is simply the shorter way to place the last
 // row, and its tighter prices halve the certificate's rounds (36 -> 19): 440 -> 395 ms.
+#ifndef LAP_CW
+#define LAP_CW 8            // waves that compute in the points form of a single-bidder chain (of LAP_BS / 64 = 16)
+#endif
 #ifndef LAP_SEARCH_PHASE
 #define LAP_SEARCH_PHASE 7
 #endif
@@ -48,6 +51,9 @@ struct LapArgs {
     double eps0, theta_inv, eps_final;   // first epsilon and final epsilon as fractions of the largest cost, 1 / scaling factor
     const double *price_in; // nullable [B][n]: potentials of an earlier, similar problem (warm start)
     int warm_assign;        // with price_in: col4row holds that problem's assignment; pairs that still satisfy eps-CS are kept
+    // nullable [B][n][3]: the point sets whose Euclidean distances `cost` holds (cost == reart_cdist(src, tgt), bit for bit).
+    // With them a single-bidder chain recomputes its rows from the points instead of reading them (lap_auction_kernel).
+    const float *src, *tgt;
 };
 
 __device__ __forceinline__ unsigned long long lap_key(double v) { return (unsigned long long)__double_as_longlong(v); }  // v >= 0
@@ -69,6 +75,30 @@ __device__ __forceinline__ void lap_wave_top2(double &v1, int &j1, double &v2, i
 __device__ __forceinline__ void lap_wave_top2(double &v1, int &j1, double &v2) {
     int pay = 0;
     lap_wave_top2(v1, j1, v2, pay);
+}
+// The same results with a third of the instructions when the minimum is attained by ONE lane (the normal case in fp64):
+// the minimum alone by a butterfly, its column / payload read from the lane that holds it, the second minimum by another
+// butterfly.  An exact tie (or a wave without candidates) takes the full butterfly: the lowest column wins either way.
+__device__ __forceinline__ double lap_wave_min_d(double v) {
+    v = fmin(v, reart_bfly_d<0>(v)); v = fmin(v, reart_bfly_d<1>(v)); v = fmin(v, reart_bfly_d<2>(v));
+    v = fmin(v, reart_bfly_d<3>(v)); v = fmin(v, reart_bfly_d<4>(v)); v = fmin(v, reart_bfly_d<5>(v));
+    return v;
+}
+__device__ __forceinline__ void lap_wave_top2_fast(double &v1, int &j1, double &v2, int &pay) {
+    const double m = lap_wave_min_d(v1);
+    const unsigned long long at = __ballot(v1 == m);
+    if (__builtin_popcountll(at) == 1) {
+        const int wl = __ffsll((long long)at) - 1;
+        const double c = lap_wave_min_d((int)(threadIdx.x & 63) == wl ? v2 : v1);
+        j1 = __builtin_amdgcn_readlane(j1, wl); pay = __builtin_amdgcn_readlane(pay, wl);
+        v1 = m; v2 = c;
+    } else lap_wave_top2(v1, j1, v2, pay);
+}
+__device__ __forceinline__ void lap_wave_argmin_fast(double &v, int &j) {
+    const double m = lap_wave_min_d(v);
+    const unsigned long long at = __ballot(v == m);
+    if (__builtin_popcountll(at) == 1) { j = __builtin_amdgcn_readlane(j, __ffsll((long long)at) - 1); v = m; }
+    else reart_wave_argmin_d(v, j);
 }
 
 // smallest (value, column) and second smallest value of row i under prices p over the columns [jb, je); all lanes
@@ -259,6 +289,8 @@ __global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
     constexpr int CPT = LAP_NMAX / LAP_BS;
     __shared__ double s_rv[2][NW];
     __shared__ int s_rj[2][NW];
+    __shared__ double s_cv1[2][NW], s_cv2[2][NW];
+    __shared__ int s_cj1[2][NW], s_ci0[2][NW];
     auto eps_search = [&](int i0, double eps) -> int {
         int *pred = pbobj;                       // a row's bid column: only live inside a bidding round
         double d[CPT];
@@ -284,13 +316,13 @@ __global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
                     const int key = (tid + k * LAP_BS) | (((freecol >> k) & 1u) ? 0 : (1 << 30));   // unowned columns first
                     if (d[k] < bv || (d[k] == bv && key < bj)) { bv = d[k]; bj = key; }
                 }
-            reart_wave_argmin_d(bv, bj);
+            lap_wave_argmin_fast(bv, bj);
             const int par = it & 1;
             if (lane == 0) { s_rv[par][wv] = bv; s_rj[par][wv] = bj; }
             __syncthreads();
             // the waves' minima meet in the first NW <= 16 lanes of every wave: four butterfly steps, then a broadcast
             bv = lane < NW ? s_rv[par][lane] : INFINITY; bj = lane < NW ? s_rj[par][lane] : 0x7fffffff;
-            reart_argmin_step<0>(bv, bj); reart_argmin_step<1>(bv, bj); reart_argmin_step<2>(bv, bj); reart_argmin_step<3>(bv, bj);
+            lap_wave_argmin_fast(bv, bj);
             bv = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(bv)), __builtin_amdgcn_readfirstlane(__double2loint(bv)));
             bj = __builtin_amdgcn_readfirstlane(bj);
             ++steps;
@@ -407,6 +439,84 @@ __global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
                 // of a phase is mostly such chains; every link is one row scan, a dependent read.
                 int i = ulist[0];
                 [[maybe_unused]] const int st_bids0 = st_bids;
+                if (a.src && a.tgt) {
+                    // Points form: the chain's rows are recomputed, not read.  Every link of the matrix form is a dependent
+                    // row read (3.2 us at n = 4096; a phase's last row walks thousands of links).  Here the source points
+                    // are staged once per chain into LDS arrays that are idle between rounds (pbobj | ulist | bidder);
+                    // LAP_CW of the 16 waves each keep the target points, prices and owners of n / (64 LAP_CW) columns
+                    // per lane in registers (with all 16 waves a link is bound by the VALU work of its reductions: 3.0 us).
+                    // A link: the row's distances (reart_cdist's expression: the same bits as the matrix), the wave's
+                    // minimum by an fp64 butterfly, the arg-min's column / owner read from the ONE lane that holds the
+                    // minimum (exact ties take the full (min, arg-min, second-min) butterfly instead), the second minimum by
+                    // another butterfly, ONE barrier, the same meeting of the waves' results in the first lanes of every
+                    // wave, the update by the arg-min's thread.  Same bids, prices and assignment as the matrix form.
+                    constexpr int CTH = 64 * LAP_CW, CPC = LAP_NMAX / CTH;
+                    float *sx = (float *)pbobj, *sy = (float *)ulist, *sz = (float *)bidder;
+                    const float *S3 = a.src + (size_t)b * n * 3, *T3 = a.tgt + (size_t)b * n * 3;
+                    __syncthreads();                                         // everyone has read ulist[0]
+                    for (int r = tid; r < n; r += LAP_BS) { sx[r] = S3[3 * r]; sy[r] = S3[3 * r + 1]; sz[r] = S3[3 * r + 2]; }
+                    const bool act = wv < LAP_CW;
+                    float tcx[CPC], tcy[CPC], tcz[CPC];
+                    double pr[CPC];
+                    int own[CPC];
+#pragma unroll
+                    for (int k = 0; k < CPC; ++k) {
+                        const int j = tid + k * CTH;
+                        const bool ok = act && j < n;
+                        tcx[k] = ok ? T3[3 * j] : 0.f; tcy[k] = ok ? T3[3 * j + 1] : 0.f; tcz[k] = ok ? T3[3 * j + 2] : 0.f;
+                        pr[k] = ok ? price[j] : INFINITY;
+                        own[k] = ok ? owner[j] : -1;
+                    }
+                    __syncthreads();
+                    int par = 0;
+                    for (;;) {
+                        double v1 = INFINITY, v2 = INFINITY;
+                        int j1 = 0x7fffffff, i0 = -1;
+                        if (act) {
+                            const float ax = sx[i], ay = sy[i], az = sz[i];
+#pragma unroll
+                            for (int k = 0; k < CPC; ++k) {
+                                const double v = (double)sqrtf(reart_sqdist3(ax, ay, az, tcx[k], tcy[k], tcz[k])) + pr[k];
+                                if (v < v1) { v2 = v1; v1 = v; j1 = tid + k * CTH; i0 = own[k]; }
+                                else if (v < v2) v2 = v;
+                            }
+                            lap_wave_top2_fast(v1, j1, v2, i0);
+                            if (lane == 0) { s_cv1[par][wv] = v1; s_cv2[par][wv] = v2; s_cj1[par][wv] = j1; s_ci0[par][wv] = i0; }
+                        }
+                        __syncthreads();
+                        v1 = lane < LAP_CW ? s_cv1[par][lane] : INFINITY; v2 = lane < LAP_CW ? s_cv2[par][lane] : INFINITY;
+                        j1 = lane < LAP_CW ? s_cj1[par][lane] : 0x7fffffff; i0 = lane < LAP_CW ? s_ci0[par][lane] : -1;
+                        lap_wave_top2_fast(v1, j1, v2, i0);
+                        v1 = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v1)), __builtin_amdgcn_readfirstlane(__double2loint(v1)));
+                        v2 = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v2)), __builtin_amdgcn_readfirstlane(__double2loint(v2)));
+                        j1 = __builtin_amdgcn_readfirstlane(j1); i0 = __builtin_amdgcn_readfirstlane(i0);
+                        par ^= 1;
+                        if (!(v2 < INFINITY)) v2 = v1;
+                        if (act && (j1 & (CTH - 1)) == tid) {                // the arg-min's thread
+                            const int kk = j1 / CTH;
+#pragma unroll
+                            for (int k = 0; k < CPC; ++k)
+                                if (k == kk) { pr[k] = pr[k] + (v2 - v1) + eps; own[k] = i; }
+                            assigned[i] = j1;
+                            if (i0 >= 0) assigned[i0] = -1;
+                        }
+                        ++st_bids;
+                        if (i0 < 0) break;
+                        i = i0;
+                    }
+                    __syncthreads();                                         // the last reads of the staged points
+#pragma unroll
+                    for (int k = 0; k < CPC; ++k) {
+                        const int j = tid + k * CTH;
+                        if (act && j < n) { price[j] = pr[k]; owner[j] = own[k]; }
+                    }
+                    for (int j = tid; j < n; j += LAP_BS) bidder[j] = 0x7fffffff;        // its resting value between rounds
+                    __syncthreads();
+                    JPH(4);
+                    JPH_COUNT(8, st_bids - st_bids0);
+                    tr_search += st_bids - st_bids0;
+                    continue;
+                }
                 if (wmax == 1) {
                     if (wv == 0) {                       // no workgroup barrier inside the chain
                         for (;;) {
@@ -581,7 +691,8 @@ extern "C" size_t reart_lap_workspace_bytes(int B, int n) {
 // an earlier, similar batch (the loop re-solves slowly moving matrices) -- the auction then starts from them
 // with a small epsilon; price_out (nullable, [B,n] f64) receives this batch's potentials (may alias price_in).
 static int lap_launch(const float *cost, int B, int n, int32_t *col4row, int32_t *certified, const double *price_in,
-                      double *price_out, int warm_assign, void *workspace, size_t workspace_bytes, void *stream) {
+                      double *price_out, int warm_assign, void *workspace, size_t workspace_bytes, void *stream,
+                      const float *src = nullptr, const float *tgt = nullptr) {
     if (B < 0 || n < 1 || n > LAP_NMAX) return REART_ERR_INVALID_ARG;
     if (B == 0) return REART_OK;
     if (!cost || !col4row || !certified) return REART_ERR_INVALID_ARG;
@@ -590,6 +701,7 @@ static int lap_launch(const float *cost, int B, int n, int32_t *col4row, int32_t
     a.cost = cost; a.B = B; a.n = n; a.col4row = col4row; a.certified = certified;
     a.price_out = price_out ? price_out : (double *)workspace; a.price_in = price_in;
     a.warm_assign = warm_assign;
+    a.src = src; a.tgt = tgt;
     a.max_rounds_cert = 4 * n;
     {   // tuning knobs (defaults measured on the loop's matrices)
         a.eps0 = price_in ? (warm_assign ? 1e-2 : 1e-3) : 0.125;
@@ -611,6 +723,17 @@ extern "C" int reart_lap_auction(const float *cost, int B, int n, int32_t *col4r
                                  const double *price_in, double *price_out, void *workspace, size_t workspace_bytes,
                                  void *stream) {
     return lap_launch(cost, B, n, col4row, certified, price_in, price_out, 0, workspace, workspace_bytes, stream);
+}
+
+// The same solve when the costs are Euclidean distances between two point sets: cost == reart_cdist(src, tgt) (src, tgt
+// [B,n,3]).  The matrix still serves the bulk of the bidding (a row scan of a matrix is one load and eight instructions
+// per element, recomputing it is twenty-five); the long single-bidder chains at the end of every phase recompute their
+// rows from the points and read no memory.  Result and potentials identical to reart_lap_auction on the same matrix.
+extern "C" int reart_lap_auction_points(const float *cost, const float *src, const float *tgt, int B, int n, int32_t *col4row,
+                                        int32_t *certified, const double *price_in, double *price_out, void *workspace,
+                                        size_t workspace_bytes, void *stream) {
+    if (B > 0 && (!src || !tgt)) return REART_ERR_INVALID_ARG;
+    return lap_launch(cost, B, n, col4row, certified, price_in, price_out, 0, workspace, workspace_bytes, stream, src, tgt);
 }
 
 // Warm start from an earlier solve of a SIMILAR batch: col4row holds that solve's assignment on entry, price_in its
@@ -887,13 +1010,12 @@ __global__ __launch_bounds__(BS) void lap_jv_kernel(JvArgs a) {
                         if (v < v1) { v2 = v1; v1 = v; j1 = tid + k * BS; i0 = own[k]; }
                         else if (v < v2) v2 = v;
                     }
-                    lap_wave_top2(v1, j1, v2, i0);
+                    lap_wave_top2_fast(v1, j1, v2, i0);
                     if (lane == 0) { s_av1[par][wv] = v1; s_av2[par][wv] = v2; s_aj1[par][wv] = j1; s_ai0[par][wv] = i0; }
                     __syncthreads();
                     v1 = lane < NW ? s_av1[par][lane] : INFINITY; v2 = lane < NW ? s_av2[par][lane] : INFINITY;
                     j1 = lane < NW ? s_aj1[par][lane] : 0x7fffffff; i0 = lane < NW ? s_ai0[par][lane] : -1;
-                    lap_top2_step<0>(v1, j1, v2, i0); lap_top2_step<1>(v1, j1, v2, i0);
-                    lap_top2_step<2>(v1, j1, v2, i0); lap_top2_step<3>(v1, j1, v2, i0);
+                    lap_wave_top2_fast(v1, j1, v2, i0);
                     v1 = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v1)), __builtin_amdgcn_readfirstlane(__double2loint(v1)));
                     v2 = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v2)), __builtin_amdgcn_readfirstlane(__double2loint(v2)));
                     j1 = __builtin_amdgcn_readfirstlane(j1); i0 = __builtin_amdgcn_readfirstlane(i0);
@@ -974,7 +1096,7 @@ __global__ __launch_bounds__(BS) void lap_jv_kernel(JvArgs a) {
                     const int key = (tid + k * BS) | (((freecol >> k) & 1u) ? 0 : JV_OWNED);
                     if (d[k] < bv || (d[k] == bv && key < bj)) { bv = d[k]; bj = key; }
                 }
-            reart_wave_argmin_d(bv, bj);
+            lap_wave_argmin_fast(bv, bj);
             const int par = it & 1;
             if (lane == 0) { s_rv[par][wv] = bv; s_rj[par][wv] = bj; }
             JPH(0);
@@ -982,7 +1104,7 @@ __global__ __launch_bounds__(BS) void lap_jv_kernel(JvArgs a) {
             JPH(1);
             // the waves' minima meet in the first NW <= 16 lanes of every wave: four butterfly steps, then a broadcast
             bv = lane < NW ? s_rv[par][lane] : INFINITY; bj = lane < NW ? s_rj[par][lane] : 0x7fffffff;
-            reart_argmin_step<0>(bv, bj); reart_argmin_step<1>(bv, bj); reart_argmin_step<2>(bv, bj); reart_argmin_step<3>(bv, bj);
+            lap_wave_argmin_fast(bv, bj);
             bv = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(bv)), __builtin_amdgcn_readfirstlane(__double2loint(bv)));
             bj = __builtin_amdgcn_readfirstlane(bj);
             ++st_steps;

@@ -21,7 +21,7 @@ def cdist(a, b):
     return out
 
 
-def linear_sum_assignment_batch(cost, return_stats=False, state=None, warm_assignment=False, method="paths"):
+def linear_sum_assignment_batch(cost, return_stats=False, state=None, warm_assignment=False, method="paths", points=None):
     """cost [B,n,n] float32 CUDA tensor (square) -> list of (row_ind, col_ind) int64 numpy arrays, like
     ``[scipy.optimize.linear_sum_assignment(c) for c in cost]`` (rows in ascending order).
     ``state``: a dict kept by the caller between calls on slowly changing matrices (the loop re-solves every
@@ -30,7 +30,9 @@ def linear_sum_assignment_batch(cost, return_stats=False, state=None, warm_assig
     tight (``reart_lap_auction_warm``): faster when the matrices move smoothly (KinematicModel), slower when they
     jump (BaseModel's resampled labels) -- there, and by default, solve cold (``state=None``).
     ``method`` of the warm re-solve: "paths" = shortest augmenting paths from the previous assignment and potentials
-    (``reart_lap_resolve``), "auction" = the warm-started auction (``reart_lap_auction_warm``)."""
+    (``reart_lap_resolve``), "auction" = the warm-started auction (``reart_lap_auction_warm``).
+    ``points=(src, tgt)`` ([B,n,3] each) when ``cost`` is ``cdist(src, tgt)``: a cold solve then recomputes the rows of its
+    long single-bidder chains from the points instead of reading them (``reart_lap_auction_points``; same result)."""
     _lib.require_gpu(cost)
     if cost.dim() != 3 or cost.shape[1] != cost.shape[2]:
         raise ValueError("linear_sum_assignment_batch expects square matrices [B,n,n]")
@@ -61,9 +63,16 @@ def linear_sum_assignment_batch(cost, return_stats=False, state=None, warm_assig
     solve = L.reart_lap_auction
     if state is not None and keep:
         solve = L.reart_lap_resolve if method == "paths" else L.reart_lap_auction_warm
-    rc = solve(_lib.ptr(cost), B, n, _lib.ptr(col), _lib.ptr(cert),
-               _lib.ptr(prices) if (state is not None and warm) else None,
-               _lib.ptr(prices) if state is not None else None, _lib.ptr(ws), ws.numel(), _lib.stream())
+    tail_args = (B, n, _lib.ptr(col), _lib.ptr(cert), _lib.ptr(prices) if (state is not None and warm) else None,
+                 _lib.ptr(prices) if state is not None else None, _lib.ptr(ws), ws.numel(), _lib.stream())
+    if points is not None and solve is L.reart_lap_auction:
+        src, tgt = (p.detach().float().contiguous() for p in points)
+        if tuple(src.shape) != (B, n, 3) or tuple(tgt.shape) != (B, n, 3):
+            raise ValueError("points = (src, tgt), both [B,n,3], with cost = cdist(src, tgt)")
+        _lib.require_gpu(src, tgt)
+        rc = L.reart_lap_auction_points(_lib.ptr(cost), _lib.ptr(src), _lib.ptr(tgt), *tail_args)
+    else:
+        rc = solve(_lib.ptr(cost), *tail_args)
     _lib.check(rc, "reart_lap_auction")
     if state is not None and warm_assignment:
         state["cols"] = col.clone()
@@ -101,7 +110,8 @@ def linear_sum_assignment_points(src, tgt, state, return_stats=False):
     warm = (state.get("prices") is not None and state.get("cols") is not None and tuple(state["prices"].shape) == (B, n)
             and tuple(state["cols"].shape) == (B, n) and state["prices"].device == src.device)
     if not warm or n > POINTS_NMAX:
-        return linear_sum_assignment_batch(cdist(src, tgt), return_stats=return_stats, state=state, warm_assignment=True)
+        return linear_sum_assignment_batch(cdist(src, tgt), return_stats=return_stats, state=state, warm_assignment=True,
+                                           points=(src, tgt))
     L = _lib.lib()
     col, prices = state["cols"].clone(), state["prices"]
     cert = torch.empty((B,), dtype=torch.int32, device=src.device)

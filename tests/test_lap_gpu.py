@@ -183,3 +183,32 @@ def test_lap_resolve_points_equals_the_matrix_form(dev, n):
         if step > 0 and n >= 130:
             assert (stats[:, 1] < n).all()
         a = (a + rng.normal(0, 0.0015, a.shape)).astype(np.float32)
+
+
+@pytest.mark.parametrize("n", [7, 600, 2048, 4096])
+def test_auction_with_points_is_the_matrix_auction(dev, n):
+    """reart_lap_auction_points: the single-bidder chains recompute their rows from the points -- the same assignment AND the
+    same potentials, bit for bit, as the matrix form on cdist's matrix; the optimum scipy finds."""
+    import oracle
+    from reart_amd.utils.lap import cdist, linear_sum_assignment_batch
+
+    rng = np.random.default_rng(300 + n)
+    B = 2
+    a = rng.uniform(-0.3, 0.3, (B, n, 3)).astype(np.float32)
+    b = (a[:, rng.permutation(n)] + rng.normal(0, 0.01, (B, n, 3))).astype(np.float32)
+    ta, tb = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+    cost = cdist(ta, tb)
+    st_m, st_p = {}, {}
+    out_m, fb_m, stats_m = linear_sum_assignment_batch(cost, return_stats="full", state=st_m)
+    out_p, fb_p, stats_p = linear_sum_assignment_batch(cost, return_stats="full", state=st_p, points=(ta, tb))
+    assert fb_m == 0 and fb_p == 0
+    np.testing.assert_array_equal(stats_m, stats_p)                      # phases, rounds, bids, certificate rounds
+    np.testing.assert_array_equal(st_m["prices"].cpu().numpy(), st_p["prices"].cpu().numpy())
+    for k in range(B):
+        np.testing.assert_array_equal(out_m[k][1], out_p[k][1])
+    if n <= 2048:
+        ref = oracle.linear_sum_assignment(cost.cpu().numpy())
+        for k in range(B):
+            np.testing.assert_array_equal(out_p[k][1], ref[k][1])
+    with pytest.raises(ValueError):
+        linear_sum_assignment_batch(cost, points=(ta[:, :-1], tb))

@@ -20,12 +20,14 @@ lib = ctypes.CDLL(_lib.LIB_PATH)
 names = ["matrix max + init", "phase start: release scan = first bids", "free-row list", "bids (2+ bidders)", "single-bidder chains",
          "resolution", "certificate + outputs"]
 for n in (4096, 2048):
-    cost = cdist(pred[:, :n].contiguous(), pcs[:, :n].contiguous())
+    pa, pb = pred[:, :n].contiguous(), pcs[:, :n].contiguous()
+    cost = cdist(pa, pb)
+    use_points = os.environ.get("LAP_POINTS", "1") != "0"
     for rep in range(2):
         if hasattr(lib, "reart_debug_auction_phase"):
             lib.reart_debug_auction_phase((ctypes.c_ulonglong * 320)(), 1)
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        out, fb, st = linear_sum_assignment_batch(cost, return_stats="full")
+        out, fb, st = linear_sum_assignment_batch(cost, return_stats="full", points=(pa, pb) if use_points else None)
         torch.cuda.synchronize(); ms = 1e3 * (time.perf_counter() - t0)
     print(f"n={n}: {ms:.1f} ms, fallbacks {fb}; per matrix: phases {st[:,0].mean():.1f}, rounds {st[:,1].mean():.0f} (max {st[:,1].max()}), "
           f"bids {st[:,2].mean():.0f} (max {st[:,2].max()}), bids/round {st[:,2].sum()/st[:,1].sum():.1f}, certificate rounds {st[:,3].mean():.1f}")
