@@ -58,6 +58,20 @@ struct LapArgs {
 
 __device__ __forceinline__ unsigned long long lap_key(double v) { return (unsigned long long)__double_as_longlong(v); }  // v >= 0
 
+// one more candidate for a lane's running (min, arg-min, second min): seven instructions (v_min / v_max on fp64 pairs) where
+// the compare-and-select form takes eleven -- the row scans are bound by exactly these.  A tie keeps the earlier column.
+__device__ __forceinline__ void lap_top2_push(double v, int j, double &v1, int &j1, double &v2) {
+    v2 = fmin(v2, fmax(v1, v));
+    j1 = v < v1 ? j : j1;
+    v1 = fmin(v1, v);
+}
+__device__ __forceinline__ void lap_top2_push(double v, int j, int pay, double &v1, int &j1, double &v2, int &p1) {
+    v2 = fmin(v2, fmax(v1, v));
+    const bool lt = v < v1;
+    j1 = lt ? j : j1; p1 = lt ? pay : p1;
+    v1 = fmin(v1, v);
+}
+
 // the waves' merge of per-lane (min, arg-min, second min [, payload of the arg-min]) triples: LDS-free butterfly
 template <int STEP>
 __device__ __forceinline__ void lap_top2_step(double &v1, int &j1, double &v2, int &pay) {
@@ -122,9 +136,7 @@ __device__ __forceinline__ void lap_row_top2_range(const float *__restrict__ row
                     const float rr[4] = {r[u].x, r[u].y, r[u].z, r[u].w};
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        const double v = (double)rr[c] + p[j + c];
-                        if (v < v1) { v2 = v1; v1 = v; j1 = j + c; }
-                        else if (v < v2) v2 = v;
+                        lap_top2_push((double)rr[c] + p[j + c], j + c, v1, j1, v2);
                     }
                 }
             }
@@ -139,13 +151,37 @@ __device__ __forceinline__ void lap_row_top2_range(const float *__restrict__ row
         for (int u = 0; u < 8; ++u) {
             const int j = j0 + 64 * u;
             if (j < je) {
-                const double v = (double)r[u] + p[j];
-                if (v < v1) { v2 = v1; v1 = v; j1 = j; }
-                else if (v < v2) v2 = v;
+                lap_top2_push((double)r[u] + p[j], j, v1, j1, v2);
             }
         }
     }
     lap_wave_top2(v1, j1, v2);
+}
+
+// the row's minimum of c_ik + p_k alone (the certificate needs nothing else): a third of the instructions of the
+// (min, arg-min, second-min) scan, which bound the one-workgroup pass (10 VALU instructions per element)
+__device__ __forceinline__ double lap_row_min(const float *__restrict__ row, const double *__restrict__ p, int n, int lane) {
+    double m = INFINITY;
+    int jb = 0;
+    if ((((uintptr_t)row) & 15) == 0) {
+        const int n4 = n & ~3;
+        for (int j0 = 4 * lane; j0 < n4; j0 += 256 * 8) {
+            float4 r[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) r[u] = *(const float4 *)(row + (j0 + 256 * u < n4 ? j0 + 256 * u : 0));
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + 256 * u;
+                if (j < n4) {
+                    m = fmin(m, fmin(fmin((double)r[u].x + p[j], (double)r[u].y + p[j + 1]),
+                                     fmin((double)r[u].z + p[j + 2], (double)r[u].w + p[j + 3])));
+                }
+            }
+        }
+        jb = n4;
+    }
+    for (int j = jb + lane; j < n; j += 64) m = fmin(m, (double)row[j] + p[j]);
+    return lap_wave_min_d(m);
 }
 
 __device__ __forceinline__ void lap_row_top2(const float *__restrict__ row, const double *__restrict__ p, int n, int lane,
@@ -476,9 +512,8 @@ __global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
                             const float ax = sx[i], ay = sy[i], az = sz[i];
 #pragma unroll
                             for (int k = 0; k < CPC; ++k) {
-                                const double v = (double)sqrtf(reart_sqdist3(ax, ay, az, tcx[k], tcy[k], tcz[k])) + pr[k];
-                                if (v < v1) { v2 = v1; v1 = v; j1 = tid + k * CTH; i0 = own[k]; }
-                                else if (v < v2) v2 = v;
+                                lap_top2_push((double)sqrtf(reart_sqdist3(ax, ay, az, tcx[k], tcy[k], tcz[k])) + pr[k], tid + k * CTH, own[k],
+                                              v1, j1, v2, i0);
                             }
                             lap_wave_top2_fast(v1, j1, v2, i0);
                             if (lane == 0) { s_cv1[par][wv] = v1; s_cv2[par][wv] = v2; s_cj1[par][wv] = j1; s_ci0[par][wv] = i0; }
@@ -651,9 +686,7 @@ __global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
         __syncthreads();
         // Jacobi round: m_i = min_k (c_ik + d_k) with the old d; new d_sigma(i) = m_i - c_i,sigma(i)
         for (int i = wv; i < n; i += NW) {
-            double v1, v2;
-            int j1;
-            lap_row_top2(C + (size_t)i * n, d, n, lane, v1, j1, v2);
+            const double v1 = lap_row_min(C + (size_t)i * n, d, n, lane);
             if (lane == 0) {
                 const int j = assigned[i];
                 const double cur = (double)C[(size_t)i * n + j] + d[j];
@@ -806,9 +839,7 @@ __device__ __forceinline__ void lap_row_top2_pts(float ax, float ay, float az, c
         for (int u = 0; u < 4; ++u) {
             const int j = j0 + 64 * u;
             if (j < je) {
-                const double v = (double)sqrtf(reart_sqdist3(ax, ay, az, tx[j], ty[j], tz[j])) + p[j];
-                if (v < v1) { v2 = v1; v1 = v; j1 = j; }
-                else if (v < v2) v2 = v;
+                lap_top2_push((double)sqrtf(reart_sqdist3(ax, ay, az, tx[j], ty[j], tz[j])) + p[j], j, v1, j1, v2);
             }
         }
     }
@@ -1006,9 +1037,7 @@ __global__ __launch_bounds__(BS) void lap_jv_kernel(JvArgs a) {
                     int j1 = 0x7fffffff, i0 = -1;
 #pragma unroll
                     for (int k = 0; k < JV_CPT; ++k) {
-                        const double v = (double)rc[k] + pr[k];              // +inf beyond n
-                        if (v < v1) { v2 = v1; v1 = v; j1 = tid + k * BS; i0 = own[k]; }
-                        else if (v < v2) v2 = v;
+                        lap_top2_push((double)rc[k] + pr[k], tid + k * BS, own[k], v1, j1, v2, i0);   // +inf beyond n
                     }
                     lap_wave_top2_fast(v1, j1, v2, i0);
                     if (lane == 0) { s_av1[par][wv] = v1; s_av2[par][wv] = v2; s_aj1[par][wv] = j1; s_ai0[par][wv] = i0; }
