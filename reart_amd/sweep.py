@@ -99,7 +99,8 @@ def run_sweep(instances, run_instance, device):
     return records, best_instance(records)
 
 
-def run_sweep_engines(instances, make_engine, n_iter, device, per_gpu=3, chunk=100, energy=False, mode="streams"):
+def run_sweep_engines(instances, make_engine, n_iter, device, per_gpu=3, chunk=100, energy=False, mode="streams",
+                      overlap_tails=True):
     """Sweep of fused-loop instances with ``per_gpu`` of them in flight per GPU.
 
     One instance of the relaxation loop is a chain of short, latency-bound launches that leaves
@@ -118,6 +119,8 @@ def run_sweep_engines(instances, make_engine, n_iter, device, per_gpu=3, chunk=1
     rank = dist.get_rank() if dist.is_initialized() else 0
     mine = shard(len(instances), rank, world)
     local = {}
+    threads = os.environ.get("REART_SWEEP_THREADS", "1") != "0"
+    pool, pending = None, []
     for g0 in range(0, len(mine), per_gpu):
         group = mine[g0:g0 + per_gpu]
         live = []
@@ -164,14 +167,26 @@ def run_sweep_engines(instances, make_engine, n_iter, device, per_gpu=3, chunk=1
                     en = None
             return inst, _record(inst, spec, (float(row[0]), float(row[1]), float(row[2])), done, 0, en)
 
-        # The end of an instance is latency-bound (its assignment solves occupy T-1 compute units) and full of host
-        # round trips: the instances of a group finish side by side, each on its own stream and host thread.
-        if energy and len(live) > 1 and os.environ.get("REART_SWEEP_THREADS", "1") != "0":
-            with ThreadPoolExecutor(max_workers=len(live)) as pool:
-                finished = list(pool.map(finish, live))
+        # The end of an instance is latency-bound (its assignment solves occupy T-1 of the 256 compute units) and full of
+        # host round trips: the instances of a group finish side by side, each on its own stream and host thread -- and
+        # (overlap_tails) while the NEXT group already optimises: the tails leave nine tenths of the chip idle.
+        if energy and threads:
+            if pool is None:
+                pool = ThreadPoolExecutor(max_workers=2 * max(per_gpu, 1))
+            futures = [pool.submit(finish, e) for e in live]
+            if overlap_tails:
+                pending.extend(futures)
+            else:
+                for f in futures:
+                    inst, rec = f.result()
+                    local[inst] = rec
         else:
-            finished = [finish(e) for e in live]
-        for inst, rec in finished:
-            local[inst] = rec
+            for inst, rec in (finish(e) for e in live):
+                local[inst] = rec
+    for f in pending:
+        inst, rec = f.result()
+        local[inst] = rec
+    if pool is not None:
+        pool.shutdown()
     records = gather_records(local, len(instances), device)
     return records, best_instance(records)

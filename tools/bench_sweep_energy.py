@@ -14,9 +14,9 @@ def make_engine(spec):
     return eng
 inst = [{"cano_idx": c} for c in (3, 6, 9, 12, 15, 18)]
 sweep.run_sweep_engines(inst[:3], make_engine, 200, dev, per_gpu=3, chunk=100, energy=True)   # warm-up
-for energy in (False, True):
+for energy, overlap in ((False, False), (True, False), (True, True)):
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    rec, best = sweep.run_sweep_engines(inst, make_engine, iters, dev, per_gpu=3, chunk=100, energy=energy)
+    rec, best = sweep.run_sweep_engines(inst, make_engine, iters, dev, per_gpu=3, chunk=100, energy=energy, overlap_tails=overlap)
     torch.cuda.synchronize()
-    print(f"energy={energy}: {time.perf_counter() - t0:.2f} s for {len(inst)} instances x {iters} iterations; best cano_idx {inst[best]['cano_idx']}"
+    print(f"energy={energy} overlap_tails={overlap}: {time.perf_counter() - t0:.2f} s for {len(inst)} instances x {iters} iterations; best cano_idx {inst[best]['cano_idx']}"
           + (f"; total_err {rec[:, sweep.E_TOTAL].cpu().numpy().round(4).tolist()}" if energy else ""))
