@@ -475,7 +475,7 @@ __global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
                 // of a phase is mostly such chains; every link is one row scan, a dependent read.
                 int i = ulist[0];
                 [[maybe_unused]] const int st_bids0 = st_bids;
-                if (a.src && a.tgt) {
+                if (a.src && a.tgt && wmax > 1) {       // n >= 2048; below, one wave walks the chain without any barrier (faster: measured)
                     // Points form: the chain's rows are recomputed, not read.  Every link of the matrix form is a dependent
                     // row read (3.2 us at n = 4096; a phase's last row walks thousands of links).  Here the source points
                     // are staged once per chain into LDS arrays that are idle between rounds (pbobj | ulist | bidder);

@@ -19,7 +19,7 @@ from reart_amd import _lib
 lib = ctypes.CDLL(_lib.LIB_PATH)
 names = ["matrix max + init", "phase start: release scan = first bids", "free-row list", "bids (2+ bidders)", "single-bidder chains",
          "resolution", "certificate + outputs"]
-for n in (4096, 2048):
+for n in [int(x) for x in os.environ.get("LAP_NS", "4096,2048").split(",")]:
     pa, pb = pred[:, :n].contiguous(), pcs[:, :n].contiguous()
     cost = cdist(pa, pb)
     use_points = os.environ.get("LAP_POINTS", "1") != "0"
