@@ -108,6 +108,51 @@ __device__ __forceinline__ void lap_wave_top2_fast(double &v1, int &j1, double &
         v1 = m; v2 = c;
     } else lap_wave_top2(v1, j1, v2, pay);
 }
+// the same for values that live in the first 2^LG lanes only (the waves' results meeting after a barrier; the other lanes
+// hold +inf): LG butterfly steps instead of six; every lane gets the result
+template <int LG>
+__device__ __forceinline__ double lap_lanes_min_d(double v) {
+    v = fmin(v, reart_bfly_d<0>(v));
+    if (LG > 1) v = fmin(v, reart_bfly_d<1>(v));
+    if (LG > 2) v = fmin(v, reart_bfly_d<2>(v));
+    if (LG > 3) v = fmin(v, reart_bfly_d<3>(v));
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+template <int LG>
+__device__ __forceinline__ void lap_lanes_top2(double &v1, int &j1, double &v2, int &pay) {
+    const int lane = threadIdx.x & 63;
+    const double m = lap_lanes_min_d<LG>(v1);
+    const unsigned long long at = __ballot(lane < (1 << LG) && v1 == m);
+    if (__builtin_popcountll(at) == 1) {
+        const int wl = __ffsll((long long)at) - 1;
+        const double c = lap_lanes_min_d<LG>(lane == wl ? v2 : v1);
+        j1 = __builtin_amdgcn_readlane(j1, wl); pay = __builtin_amdgcn_readlane(pay, wl);
+        v1 = m; v2 = c;
+    } else {
+        lap_top2_step<0>(v1, j1, v2, pay);
+        if (LG > 1) lap_top2_step<1>(v1, j1, v2, pay);
+        if (LG > 2) lap_top2_step<2>(v1, j1, v2, pay);
+        if (LG > 3) lap_top2_step<3>(v1, j1, v2, pay);
+        v1 = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v1)), __builtin_amdgcn_readfirstlane(__double2loint(v1)));
+        v2 = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v2)), __builtin_amdgcn_readfirstlane(__double2loint(v2)));
+        j1 = __builtin_amdgcn_readfirstlane(j1); pay = __builtin_amdgcn_readfirstlane(pay);
+    }
+}
+template <int LG>
+__device__ __forceinline__ void lap_lanes_argmin(double &v, int &j) {
+    const int lane = threadIdx.x & 63;
+    const double m = lap_lanes_min_d<LG>(v);
+    const unsigned long long at = __ballot(lane < (1 << LG) && v == m);
+    if (__builtin_popcountll(at) == 1) { j = __builtin_amdgcn_readlane(j, __ffsll((long long)at) - 1); v = m; }
+    else {
+        reart_argmin_step<0>(v, j);
+        if (LG > 1) reart_argmin_step<1>(v, j);
+        if (LG > 2) reart_argmin_step<2>(v, j);
+        if (LG > 3) reart_argmin_step<3>(v, j);
+        v = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+        j = __builtin_amdgcn_readfirstlane(j);
+    }
+}
 __device__ __forceinline__ void lap_wave_argmin_fast(double &v, int &j) {
     const double m = lap_wave_min_d(v);
     const unsigned long long at = __ballot(v == m);
@@ -358,9 +403,7 @@ __global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
             __syncthreads();
             // the waves' minima meet in the first NW <= 16 lanes of every wave: four butterfly steps, then a broadcast
             bv = lane < NW ? s_rv[par][lane] : INFINITY; bj = lane < NW ? s_rj[par][lane] : 0x7fffffff;
-            lap_wave_argmin_fast(bv, bj);
-            bv = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(bv)), __builtin_amdgcn_readfirstlane(__double2loint(bv)));
-            bj = __builtin_amdgcn_readfirstlane(bj);
+            lap_lanes_argmin<(NW <= 2 ? 1 : (NW <= 4 ? 2 : (NW <= 8 ? 3 : 4)))>(bv, bj);
             ++steps;
             mu = bv;
             if (bj == 0x7fffffff || !(bv < INFINITY)) break;          // non-finite costs only
@@ -521,10 +564,8 @@ __global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
                         __syncthreads();
                         v1 = lane < LAP_CW ? s_cv1[par][lane] : INFINITY; v2 = lane < LAP_CW ? s_cv2[par][lane] : INFINITY;
                         j1 = lane < LAP_CW ? s_cj1[par][lane] : 0x7fffffff; i0 = lane < LAP_CW ? s_ci0[par][lane] : -1;
-                        lap_wave_top2_fast(v1, j1, v2, i0);
-                        v1 = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v1)), __builtin_amdgcn_readfirstlane(__double2loint(v1)));
-                        v2 = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v2)), __builtin_amdgcn_readfirstlane(__double2loint(v2)));
-                        j1 = __builtin_amdgcn_readfirstlane(j1); i0 = __builtin_amdgcn_readfirstlane(i0);
+                        static_assert(LAP_CW == 4 || LAP_CW == 8 || LAP_CW == 16, "a power of two of computing waves");
+                        lap_lanes_top2<(LAP_CW == 4 ? 2 : (LAP_CW == 8 ? 3 : 4))>(v1, j1, v2, i0);
                         par ^= 1;
                         if (!(v2 < INFINITY)) v2 = v1;
                         if (act && (j1 & (CTH - 1)) == tid) {                // the arg-min's thread
@@ -1044,10 +1085,7 @@ __global__ __launch_bounds__(BS) void lap_jv_kernel(JvArgs a) {
                     __syncthreads();
                     v1 = lane < NW ? s_av1[par][lane] : INFINITY; v2 = lane < NW ? s_av2[par][lane] : INFINITY;
                     j1 = lane < NW ? s_aj1[par][lane] : 0x7fffffff; i0 = lane < NW ? s_ai0[par][lane] : -1;
-                    lap_wave_top2_fast(v1, j1, v2, i0);
-                    v1 = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v1)), __builtin_amdgcn_readfirstlane(__double2loint(v1)));
-                    v2 = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v2)), __builtin_amdgcn_readfirstlane(__double2loint(v2)));
-                    j1 = __builtin_amdgcn_readfirstlane(j1); i0 = __builtin_amdgcn_readfirstlane(i0);
+                    lap_lanes_top2<(NW <= 2 ? 1 : (NW <= 4 ? 2 : (NW <= 8 ? 3 : 4)))>(v1, j1, v2, i0);
                     par ^= 1;
                     const bool tie = !(v1 < v2);
                     const bool stop = budget-- <= 0 || (tie && i0 >= 0);
@@ -1133,9 +1171,7 @@ __global__ __launch_bounds__(BS) void lap_jv_kernel(JvArgs a) {
             JPH(1);
             // the waves' minima meet in the first NW <= 16 lanes of every wave: four butterfly steps, then a broadcast
             bv = lane < NW ? s_rv[par][lane] : INFINITY; bj = lane < NW ? s_rj[par][lane] : 0x7fffffff;
-            lap_wave_argmin_fast(bv, bj);
-            bv = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(bv)), __builtin_amdgcn_readfirstlane(__double2loint(bv)));
-            bj = __builtin_amdgcn_readfirstlane(bj);
+            lap_lanes_argmin<(NW <= 2 ? 1 : (NW <= 4 ? 2 : (NW <= 8 ? 3 : 4)))>(bv, bj);
             ++st_steps;
             mu = bv;
             const int jstar = bj == 0x7fffffff ? bj : (bj & ~JV_OWNED);
