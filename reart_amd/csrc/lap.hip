@@ -200,7 +200,8 @@ __device__ __forceinline__ void lap_row_top2_range(const float *__restrict__ row
             }
         }
     }
-    lap_wave_top2(v1, j1, v2);
+    int pay = 0;
+    lap_wave_top2_fast(v1, j1, v2, pay);
 }
 
 // the row's minimum of c_ik + p_k alone (the certificate needs nothing else): a third of the instructions of the
@@ -884,7 +885,8 @@ __device__ __forceinline__ void lap_row_top2_pts(float ax, float ay, float az, c
             }
         }
     }
-    lap_wave_top2(v1, j1, v2);
+    int pay = 0;
+    lap_wave_top2_fast(v1, j1, v2, pay);
 }
 
 
