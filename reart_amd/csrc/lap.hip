@@ -565,8 +565,8 @@ __global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
                         __syncthreads();
                         v1 = lane < LAP_CW ? s_cv1[par][lane] : INFINITY; v2 = lane < LAP_CW ? s_cv2[par][lane] : INFINITY;
                         j1 = lane < LAP_CW ? s_cj1[par][lane] : 0x7fffffff; i0 = lane < LAP_CW ? s_ci0[par][lane] : -1;
-                        static_assert(LAP_CW == 4 || LAP_CW == 8 || LAP_CW == 16, "a power of two of computing waves");
-                        lap_lanes_top2<(LAP_CW == 4 ? 2 : (LAP_CW == 8 ? 3 : 4))>(v1, j1, v2, i0);
+                        static_assert(LAP_CW == 8 || LAP_CW == 16, "8 (measured best) or all 16 waves compute");
+                        lap_lanes_top2<(LAP_CW == 8 ? 3 : 4)>(v1, j1, v2, i0);
                         par ^= 1;
                         if (!(v2 < INFINITY)) v2 = v1;
                         if (act && (j1 & (CTH - 1)) == tid) {                // the arg-min's thread
