@@ -28,6 +28,12 @@
 // (which raises the prices by the least possible amount) the NEXT phase pays with 3-5x the rounds; from the 7th phase
 // on (eps <= 3e-6 of the largest cost) nothing is left to settle, the search is simply the shorter way to place the last
 // row, and its tighter prices halve the certificate's rounds (36 -> 19): 440 -> 395 ms.
+#ifndef LAP_EPS0
+#define LAP_EPS0 0.125      // first epsilon of a cold solve, as a fraction of the largest cost
+#endif
+#ifndef LAP_THETA
+#define LAP_THETA 6.0       // epsilon shrinks by this factor from phase to phase
+#endif
 #ifndef LAP_CW
 #define LAP_CW 8            // waves that compute in the points form of a single-bidder chain (of LAP_BS / 64 = 16)
 #endif
@@ -779,8 +785,8 @@ static int lap_launch(const float *cost, int B, int n, int32_t *col4row, int32_t
     a.src = src; a.tgt = tgt;
     a.max_rounds_cert = 4 * n;
     {   // tuning knobs (defaults measured on the loop's matrices)
-        a.eps0 = price_in ? (warm_assign ? 1e-2 : 1e-3) : 0.125;
-        a.theta_inv = 1.0 / 6.0;
+        a.eps0 = price_in ? (warm_assign ? 1e-2 : 1e-3) : LAP_EPS0;
+        a.theta_inv = 1.0 / LAP_THETA;
         a.eps_final = 1e-11;
     }
     a.stats = (int *)((char *)workspace + reart_align_up(sizeof(double) * (size_t)B * n, 256));   // diagnostics, after the potentials
