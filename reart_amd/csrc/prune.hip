@@ -50,7 +50,13 @@ typedef float f2 __attribute__((ext_vector_type(2)));
                         // rejects, no gain -- the branch is kept compiled out for reference)
 #define PR_QCAP 768     // entries of a wave's (query, box) queue
 // LDS per wave: staged box of a dense scan [64 floats] | the wave's queries [64][4] | result slots [3][64] u64 | queue
-#define PR_LDS_WAVE_BYTES (64 * 4 + 64 * 16 + 3 * 64 * 8 + PR_QCAP * 4)
+// PR_BOXLDS 1: the precise filter reads a surviving box's bounds back from LDS (broadcast ds_read, the LDS pipe is idle) instead of
+// twelve v_readlane per box pair on the VALU, which bounds this kernel: 45.0 -> 43.6 us per launch.  The 1.5 KB come out of the
+// queue's space (768 -> 384 entries); with LDS of their own (2) a workgroup less fits a compute unit: 48.6 us.  0: readlanes.
+#ifndef PR_BOXLDS
+#define PR_BOXLDS 1
+#endif
+#define PR_LDS_WAVE_BYTES (64 * 4 + 64 * 16 + 3 * 64 * 8 + PR_QCAP * 4 + (PR_BOXLDS == 2 ? 64 * 6 * 4 : 0))
 
 #ifdef REART_PRUNE_STATS   // diagnostic build only (tools/prune_stats.py): how much the filters let through
 __device__ unsigned long long g_prune_stats[8];
@@ -124,7 +130,7 @@ __device__ __forceinline__ float box_lb(float lo0, float lo1, float lo2, float h
 template <int KK, bool LDSV, int QCAP>
 __device__ __forceinline__ void knn_pruned_wave(const KnnJob &jb, const int S, const int sparse, const int b, const int g,
                                                 const int s, const float *cloud, const int cstride, const float *boxes_p,
-                                                float *s_tg, float *s_qc, unsigned int *s_q,
+                                                float *s_tg, float *s_qc, unsigned int *s_q, float *s_bb,
                                                 unsigned long long *s_key, float &qx_o, float &qy_o, float &qz_o,
                                                 float (&bm)[KK], int (&bb)[KK], int &work_o, unsigned int &pairs_o) {
     struct { int S, sparse; } a = {S, sparse};
@@ -283,6 +289,10 @@ __device__ __forceinline__ void knn_pruned_wave(const KnnJob &jb, const int S, c
             const float4 A = *(const float4 *)(bx + (size_t)bid * 8);
             const float4 Bv = *(const float4 *)(bx + (size_t)bid * 8 + 4);
             lo0 = A.x; lo1 = A.y; lo2 = A.z; hi0 = A.w; hi1 = Bv.x; hi2 = Bv.y;
+            if (s_bb) {        // the precise filter reads a surviving box's bounds back as LDS broadcasts (not VALU readlanes)
+                float *o = s_bb + 6 * lane;
+                o[0] = lo0; o[1] = lo1; o[2] = lo2; o[3] = hi0; o[4] = hi1; o[5] = hi2;
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float lb = box_lb(lo0, lo1, lo2, hi0, hi1, hi2, G[q][0], G[q][1], G[q][2], G[q][3], G[q][4], G[q][5]);
@@ -400,8 +410,15 @@ __device__ __forceinline__ void knn_pruned_wave(const KnnJob &jb, const int S, c
             const bool hasB = cm != 0;
             const int bB = hasB ? __builtin_ctzll(cm) : bA;
             if (hasB) cm &= cm - 1;
-            const f2 L0 = {rl(lo0, bA), rl(lo0, bB)}, L1 = {rl(lo1, bA), rl(lo1, bB)}, L2 = {rl(lo2, bA), rl(lo2, bB)};
-            const f2 H0 = {rl(hi0, bA), rl(hi0, bB)}, H1 = {rl(hi1, bA), rl(hi1, bB)}, H2 = {rl(hi2, bA), rl(hi2, bB)};
+            f2 L0, L1, L2, H0, H1, H2;
+            if (s_bb) {
+                const float *pA = s_bb + 6 * bA, *pB = s_bb + 6 * bB;
+                L0 = f2{pA[0], pB[0]}; L1 = f2{pA[1], pB[1]}; L2 = f2{pA[2], pB[2]};
+                H0 = f2{pA[3], pB[3]}; H1 = f2{pA[4], pB[4]}; H2 = f2{pA[5], pB[5]};
+            } else {
+                L0 = f2{rl(lo0, bA), rl(lo0, bB)}; L1 = f2{rl(lo1, bA), rl(lo1, bB)}; L2 = f2{rl(lo2, bA), rl(lo2, bB)};
+                H0 = f2{rl(hi0, bA), rl(hi0, bB)}; H1 = f2{rl(hi1, bA), rl(hi1, bB)}; H2 = f2{rl(hi2, bA), rl(hi2, bB)};
+            }
             const f2 a0 = L0 - qx2, c0 = qx2 - H0, a1 = L1 - qy2, c1 = qy2 - H1, a2 = L2 - qz2, c2 = qz2 - H2;
             const f2 e0 = {fmaxf(fmaxf(a0.x, c0.x), 0.f), fmaxf(fmaxf(a0.y, c0.y), 0.f)};
             const f2 e1 = {fmaxf(fmaxf(a1.x, c1.x), 0.f), fmaxf(fmaxf(a1.y, c1.y), 0.f)};
@@ -454,8 +471,10 @@ __global__ __launch_bounds__(64 * PR_SMAX) void knn_group_kernel(Batched<SearchA
     // instance of a batch (gridDim.x is a multiple of 8: blockIdx.x & 7 is still the XCD); a single one reads at a fixed offset
     const SearchArgs &a = ab.a[BATCH ? blockIdx.y : 0];
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];      // blockDim.x / 64 x PR_LDS_WAVE_BYTES
-    __shared__ float s_m[PR_SMAX][3][64];
-    __shared__ int s_b[PR_SMAX][3][64];
+    // where wave t parks its candidates for the merge: its own result slots (s_key, 3 x 64 x 8 bytes), dead once its search
+    // is over -- as static arrays they cost 6 KB per workgroup, i.e. the sixth resident workgroup of a compute unit
+#define PARK_M(t) ((float *)(s_dyn + (size_t)(t) * PR_LDS_WAVE_BYTES + 64 * 4 + 64 * 16))
+#define PARK_B(t) ((int *)(s_dyn + (size_t)(t) * PR_LDS_WAVE_BYTES + 64 * 4 + 64 * 16 + 3 * 64 * 4))
     __shared__ unsigned int s_wk[PR_SMAX][2];
     __shared__ unsigned int s_ticket;
     __shared__ unsigned long long s_t0;
@@ -502,15 +521,26 @@ __global__ __launch_bounds__(64 * PR_SMAX) void knn_group_kernel(Batched<SearchA
         float *s_qc = (float *)(wl + 64 * 4);
         unsigned long long *s_key = (unsigned long long *)(wl + 64 * 4 + 64 * 16);
         unsigned int *s_q = (unsigned int *)(wl + 64 * 4 + 64 * 16 + 3 * 64 * 8);
+#if PR_BOXLDS == 1          // the bounds of a coarse round's 64 boxes take the first 384 entries of the queue's space
+        float *s_bb = (float *)s_q;
+        s_q += 384;
+        constexpr int QC = PR_QCAP - 384;
+#elif PR_BOXLDS == 2        // ... or 1.5 KB of their own behind the queue
+        float *s_bb = (float *)(s_q + PR_QCAP);
+        constexpr int QC = PR_QCAP;
+#else
+        float *s_bb = nullptr;
+        constexpr int QC = PR_QCAP;
+#endif
         const float *cloud = jb.tsoa + (size_t)b * 3 * jb.Ppad;
         const float *boxes_p = jb.boxes + (size_t)b * (jb.Ppad / NN_BOX) * 8;
         if (kind == 1) {
             float m1[1]; int b1[1];
-            knn_pruned_wave<1, false, PR_QCAP>(jb, S, a.sparse, b, g, s, cloud, jb.Ppad, boxes_p, s_tg, s_qc, s_q, s_key,
+            knn_pruned_wave<1, false, QC>(jb, S, a.sparse, b, g, s, cloud, jb.Ppad, boxes_p, s_tg, s_qc, s_q, s_bb, s_key,
                                                qx, qy, qz, m1, b1, work, pairs);
             bm[0] = m1[0]; bb[0] = b1[0];
         } else {
-            knn_pruned_wave<3, false, PR_QCAP>(jb, S, a.sparse, b, g, s, cloud, jb.Ppad, boxes_p, s_tg, s_qc, s_q, s_key,
+            knn_pruned_wave<3, false, QC>(jb, S, a.sparse, b, g, s, cloud, jb.Ppad, boxes_p, s_tg, s_qc, s_q, s_bb, s_key,
                                                qx, qy, qz, bm, bb, work, pairs);
         }
     }
@@ -519,7 +549,7 @@ __global__ __launch_bounds__(64 * PR_SMAX) void knn_group_kernel(Batched<SearchA
     // takes a ticket; LDS operations of a wave complete in order, so the ticket holder S-1 sees all of them.
     if (S > 1) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { s_m[s][k][lane] = bm[k]; s_b[s][k][lane] = bb[k]; }
+        for (int k = 0; k < 3; ++k) { PARK_M(s)[k * 64 + lane] = bm[k]; PARK_B(s)[k * 64 + lane] = bb[k]; }
         if (lane == 0) { s_wk[s][0] = (unsigned int)work; s_wk[s][1] = pairs; }
         __threadfence_block();
         int ticket = 0;
@@ -533,7 +563,7 @@ __global__ __launch_bounds__(64 * PR_SMAX) void knn_group_kernel(Batched<SearchA
         work = 0; pairs = 0u;
         for (int t = 0; t < S; ++t) { work += (int)s_wk[t][0]; pairs += s_wk[t][1]; }
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { bm[k] = s_m[0][k][lane]; bb[k] = s_b[0][k][lane]; }
+        for (int k = 0; k < 3; ++k) { bm[k] = PARK_M(0)[k * 64 + lane]; bb[k] = PARK_B(0)[k * 64 + lane]; }
     }
     // ---- merge the slices' candidates by (minimum, first index): distinct slices hold distinct boxes, so the lower block
     // start is the lower index
@@ -543,8 +573,8 @@ __global__ __launch_bounds__(64 * PR_SMAX) void knn_group_kernel(Batched<SearchA
         float m = bm[0];
         int blk = bb[0];
         for (int t = 1; t < S; ++t) {
-            const float mt = s_m[t][0][lane];
-            const int bt = s_b[t][0][lane];
+            const float mt = PARK_M(t)[lane];
+            const int bt = PARK_B(t)[lane];
             const bool take = bt >= 0 && ((mt < m) || (mt == m && (blk < 0 || bt < blk)));
             m = take ? mt : m; blk = take ? bt : blk;
         }
@@ -570,8 +600,8 @@ __global__ __launch_bounds__(64 * PR_SMAX) void knn_group_kernel(Batched<SearchA
         for (int t = 1; t < S; ++t) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                const int bt = s_b[t][k][lane];
-                reart_top3_insert(kd, ki, s_m[t][k][lane], bt >= 0 ? bt : 0x7fffffff);
+                const int bt = PARK_B(t)[k * 64 + lane];
+                reart_top3_insert(kd, ki, PARK_M(t)[k * 64 + lane], bt >= 0 ? bt : 0x7fffffff);
             }
         }
         if (i < jb.P1) {
@@ -644,11 +674,11 @@ __global__ __launch_bounds__(64 * PC_WAVES) void knn_cloud_kernel(SearchArgs a) 
         unsigned int *s_q = (unsigned int *)(wl + 64 * 16 + 3 * 64 * 8);
         if (kind == 1) {
             float m1[1]; int b1[1];
-            knn_pruned_wave<1, true, PC_QCAP>(jb, S, a.sparse, b, g, sl, cl, Ppad, bxs, nullptr, s_qc, s_q, s_key, qx, qy, qz,
+            knn_pruned_wave<1, true, PC_QCAP>(jb, S, a.sparse, b, g, sl, cl, Ppad, bxs, nullptr, s_qc, s_q, nullptr, s_key, qx, qy, qz,
                                               m1, b1, work, pairs);
             bm[0] = m1[0]; bb[0] = b1[0];
         } else {
-            knn_pruned_wave<3, true, PC_QCAP>(jb, S, a.sparse, b, g, sl, cl, Ppad, bxs, nullptr, s_qc, s_q, s_key, qx, qy, qz,
+            knn_pruned_wave<3, true, PC_QCAP>(jb, S, a.sparse, b, g, sl, cl, Ppad, bxs, nullptr, s_qc, s_q, nullptr, s_key, qx, qy, qz,
                                               bm, bb, work, pairs);
         }
         if (S > 1 && sl > 0) {
