@@ -203,7 +203,7 @@ typedef struct reart_relax_config {
      * variable in any call path: the caller decides once per instance (reart_amd/relax.py maps REART_* variables
      * to these fields when an engine is built), so the ranks of a job cannot diverge mid-run. */
     int search_mode;         /* 0: exact box-pruned warm-started search (default); 1: cold brute force (same results) */
-    int tune_slices;         /* waves (box slices) per search workgroup, 1..4 (default 4)  */
+    int tune_slices;         /* waves (box slices) per search workgroup, 1..4 (default 3)  */
     int tune_slices_flow;    /* the same for the K = 3 flow search (default: tune_slices)  */
     int tune_sparse;         /* boxes needed by <= n queries of a wave go through the (query, box) queue instead of a  */
                              /* 64-lane scan: 1..64 (default 20), < 0: dense scans only                                */

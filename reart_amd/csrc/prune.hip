@@ -48,7 +48,12 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #define PR_PREFETCH 0   // a box's targets are fetched when it is scanned (prefetching every coarse survivor eight at a
                         // time was measured: more instructions, loads for the 60 % of the boxes the precise test
                         // rejects, no gain -- the branch is kept compiled out for reference)
-#define PR_QCAP 768     // entries of a wave's (query, box) queue
+#ifndef PR_QCAP
+#define PR_QCAP 768     // entries of a wave's (query, box) queue (the first 384 hold box bounds: PR_BOXLDS)
+#endif
+#ifndef PR_WPE
+#define PR_WPE 1         // minimum waves per SIMD the compiler must allow for (register budget)
+#endif
 // LDS per wave: staged box of a dense scan [64 floats] | the wave's queries [64][4] | result slots [3][64] u64 | queue
 // PR_BOXLDS 1: the precise filter reads a surviving box's bounds back from LDS (broadcast ds_read, the LDS pipe is idle) instead of
 // twelve v_readlane per box pair on the VALU, which bounds this kernel: 45.0 -> 43.6 us per launch.  The 1.5 KB come out of the
@@ -467,7 +472,7 @@ __device__ __forceinline__ void knn_pruned_wave(const KnnJob &jb, const int S, c
 // The search launch: up to two K = 1 jobs (the Chamfer directions) and one K = 3 job (the flow search);
 // SearchArgs is declared in internal.h.
 template <bool BATCH>
-__global__ __launch_bounds__(64 * PR_SMAX) void knn_group_kernel(Batched<SearchArgs> ab) {
+__global__ __launch_bounds__(64 * PR_SMAX, PR_WPE) void knn_group_kernel(Batched<SearchArgs> ab) {
     // instance of a batch (gridDim.x is a multiple of 8: blockIdx.x & 7 is still the XCD); a single one reads at a fixed offset
     const SearchArgs &a = ab.a[BATCH ? blockIdx.y : 0];
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];      // blockDim.x / 64 x PR_LDS_WAVE_BYTES

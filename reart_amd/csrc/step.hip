@@ -56,7 +56,7 @@ static int step_plan(const reart_relax_config *c, StepPlan *p) {
     // grid variant, or clouds that are not spatially sorted) -- same results, A/B and in-situ parity checks
     p->pruned = (c->use_boxes && !c->use_grid && c->search_mode != 1) ? 1 : 0;
     // pruned: ONE record per query (S = 1 in the consumers); the box slices are the waves of a search workgroup
-    p->W1 = (c->tune_slices >= 1 && c->tune_slices <= 4) ? c->tune_slices : 4;
+    p->W1 = (c->tune_slices >= 1 && c->tune_slices <= 4) ? c->tune_slices : 3;
     p->W3 = (c->tune_slices_flow >= 1 && c->tune_slices_flow <= 4) ? c->tune_slices_flow : p->W1;
     p->sparse = c->tune_sparse < 0 ? 0 : (c->tune_sparse == 0 ? 20 : (c->tune_sparse > 64 ? 64 : c->tune_sparse));
     p->S1 = p->pruned ? 1 : reart_knn_pick_split(waves1, c->N, 1);
