@@ -132,7 +132,7 @@ __device__ __forceinline__ float box_lb(float lo0, float lo1, float lo2, float h
 // `pairs` counts the query-target distance evaluations the wave executed (lanes x targets, dense and sparse forms).
 // LDSV: `cloud` / `boxes_p` point at a copy of the batch's target cloud (SoA rows of `cstride` floats) and of its boxes in
 // LDS (knn_cloud_kernel); otherwise at the global images.  QCAP: entries of the wave's queue.
-template <int KK, bool LDSV, int QCAP>
+template <int KK, bool LDSV, int QCAP, bool BOXL>
 __device__ __forceinline__ void knn_pruned_wave(const KnnJob &jb, const int S, const int sparse, const int b, const int g,
                                                 const int s, const float *cloud, const int cstride, const float *boxes_p,
                                                 float *s_tg, float *s_qc, unsigned int *s_q, float *s_bb,
@@ -294,7 +294,7 @@ __device__ __forceinline__ void knn_pruned_wave(const KnnJob &jb, const int S, c
             const float4 A = *(const float4 *)(bx + (size_t)bid * 8);
             const float4 Bv = *(const float4 *)(bx + (size_t)bid * 8 + 4);
             lo0 = A.x; lo1 = A.y; lo2 = A.z; hi0 = A.w; hi1 = Bv.x; hi2 = Bv.y;
-            if (s_bb) {        // the precise filter reads a surviving box's bounds back as LDS broadcasts (not VALU readlanes)
+            if (BOXL) {        // the precise filter reads a surviving box's bounds back as LDS broadcasts (not VALU readlanes)
                 float *o = s_bb + 6 * lane;
                 o[0] = lo0; o[1] = lo1; o[2] = lo2; o[3] = hi0; o[4] = hi1; o[5] = hi2;
             }
@@ -416,7 +416,7 @@ __device__ __forceinline__ void knn_pruned_wave(const KnnJob &jb, const int S, c
             const int bB = hasB ? __builtin_ctzll(cm) : bA;
             if (hasB) cm &= cm - 1;
             f2 L0, L1, L2, H0, H1, H2;
-            if (s_bb) {
+            if (BOXL) {
                 const float *pA = s_bb + 6 * bA, *pB = s_bb + 6 * bB;
                 L0 = f2{pA[0], pB[0]}; L1 = f2{pA[1], pB[1]}; L2 = f2{pA[2], pB[2]};
                 H0 = f2{pA[3], pB[3]}; H1 = f2{pA[4], pB[4]}; H2 = f2{pA[5], pB[5]};
@@ -541,11 +541,11 @@ __global__ __launch_bounds__(64 * PR_SMAX, PR_WPE) void knn_group_kernel(Batched
         const float *boxes_p = jb.boxes + (size_t)b * (jb.Ppad / NN_BOX) * 8;
         if (kind == 1) {
             float m1[1]; int b1[1];
-            knn_pruned_wave<1, false, QC>(jb, S, a.sparse, b, g, s, cloud, jb.Ppad, boxes_p, s_tg, s_qc, s_q, s_bb, s_key,
+            knn_pruned_wave<1, false, QC, PR_BOXLDS != 0>(jb, S, a.sparse, b, g, s, cloud, jb.Ppad, boxes_p, s_tg, s_qc, s_q, s_bb, s_key,
                                                qx, qy, qz, m1, b1, work, pairs);
             bm[0] = m1[0]; bb[0] = b1[0];
         } else {
-            knn_pruned_wave<3, false, QC>(jb, S, a.sparse, b, g, s, cloud, jb.Ppad, boxes_p, s_tg, s_qc, s_q, s_bb, s_key,
+            knn_pruned_wave<3, false, QC, PR_BOXLDS != 0>(jb, S, a.sparse, b, g, s, cloud, jb.Ppad, boxes_p, s_tg, s_qc, s_q, s_bb, s_key,
                                                qx, qy, qz, bm, bb, work, pairs);
         }
     }
@@ -679,11 +679,11 @@ __global__ __launch_bounds__(64 * PC_WAVES) void knn_cloud_kernel(SearchArgs a) 
         unsigned int *s_q = (unsigned int *)(wl + 64 * 16 + 3 * 64 * 8);
         if (kind == 1) {
             float m1[1]; int b1[1];
-            knn_pruned_wave<1, true, PC_QCAP>(jb, S, a.sparse, b, g, sl, cl, Ppad, bxs, nullptr, s_qc, s_q, nullptr, s_key, qx, qy, qz,
+            knn_pruned_wave<1, true, PC_QCAP, false>(jb, S, a.sparse, b, g, sl, cl, Ppad, bxs, nullptr, s_qc, s_q, nullptr, s_key, qx, qy, qz,
                                               m1, b1, work, pairs);
             bm[0] = m1[0]; bb[0] = b1[0];
         } else {
-            knn_pruned_wave<3, true, PC_QCAP>(jb, S, a.sparse, b, g, sl, cl, Ppad, bxs, nullptr, s_qc, s_q, nullptr, s_key, qx, qy, qz,
+            knn_pruned_wave<3, true, PC_QCAP, false>(jb, S, a.sparse, b, g, sl, cl, Ppad, bxs, nullptr, s_qc, s_q, nullptr, s_key, qx, qy, qz,
                                               bm, bb, work, pairs);
         }
         if (S > 1 && sl > 0) {
