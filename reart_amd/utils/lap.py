@@ -21,7 +21,11 @@ def cdist(a, b):
     return out
 
 
-def linear_sum_assignment_batch(cost, return_stats=False, state=None, warm_assignment=False, method="paths", points=None):
+RACERS = 5   # epsilon schedules raced per matrix by ``race=True`` (reart_lap_auction_race)
+
+
+def linear_sum_assignment_batch(cost, return_stats=False, state=None, warm_assignment=False, method="paths", points=None,
+                                race=False):
     """cost [B,n,n] float32 CUDA tensor (square) -> list of (row_ind, col_ind) int64 numpy arrays, like
     ``[scipy.optimize.linear_sum_assignment(c) for c in cost]`` (rows in ascending order).
     ``state``: a dict kept by the caller between calls on slowly changing matrices (the loop re-solves every
@@ -32,7 +36,10 @@ def linear_sum_assignment_batch(cost, return_stats=False, state=None, warm_assig
     ``method`` of the warm re-solve: "paths" = shortest augmenting paths from the previous assignment and potentials
     (``reart_lap_resolve``), "auction" = the warm-started auction (``reart_lap_auction_warm``).
     ``points=(src, tgt)`` ([B,n,3] each) when ``cost`` is ``cdist(src, tgt)``: a cold solve then recomputes the rows of its
-    long single-bidder chains from the points instead of reading them (``reart_lap_auction_points``; same result)."""
+    long single-bidder chains from the points instead of reading them (``reart_lap_auction_points``; same result).
+    ``race=True`` (cold solves): five workgroups per matrix race with different epsilon schedules on otherwise idle compute
+    units and the first certified one publishes (``reart_lap_auction_race``): the same optimal assignment 20 % sooner; the
+    potentials kept in ``state`` are the winner's (valid, but not reproducible run to run)."""
     _lib.require_gpu(cost)
     if cost.dim() != 3 or cost.shape[1] != cost.shape[2]:
         raise ValueError("linear_sum_assignment_batch expects square matrices [B,n,n]")
@@ -49,8 +56,7 @@ def linear_sum_assignment_batch(cost, return_stats=False, state=None, warm_assig
         if return_stats == "full":
             return out, B, np.zeros((B, 4), np.int32)
         return (out, B) if return_stats else out
-    ws = _lib.workspace(nbytes, cost.device)
-    prices = None
+    prices, warm, keep = None, False, False
     if state is not None:
         prices = state.get("prices")
         warm = prices is not None and tuple(prices.shape) == (B, n) and prices.device == cost.device
@@ -63,9 +69,19 @@ def linear_sum_assignment_batch(cost, return_stats=False, state=None, warm_assig
     solve = L.reart_lap_auction
     if state is not None and keep:
         solve = L.reart_lap_resolve if method == "paths" else L.reart_lap_auction_warm
+    racing = bool(race) and solve is L.reart_lap_auction and not warm          # cold solves only
+    ws = _lib.workspace(L.reart_lap_race_workspace_bytes(B, n, RACERS) if racing else nbytes, cost.device)
     tail_args = (B, n, _lib.ptr(col), _lib.ptr(cert), _lib.ptr(prices) if (state is not None and warm) else None,
                  _lib.ptr(prices) if state is not None else None, _lib.ptr(ws), ws.numel(), _lib.stream())
-    if points is not None and solve is L.reart_lap_auction:
+    if racing:
+        src = tgt = None
+        if points is not None:
+            src, tgt = (p.detach().float().contiguous() for p in points)
+            if tuple(src.shape) != (B, n, 3) or tuple(tgt.shape) != (B, n, 3):
+                raise ValueError("points = (src, tgt), both [B,n,3], with cost = cdist(src, tgt)")
+        rc = L.reart_lap_auction_race(_lib.ptr(cost), _lib.ptr(src), _lib.ptr(tgt), B, n, RACERS, _lib.ptr(col), _lib.ptr(cert),
+                                      _lib.ptr(prices) if state is not None else None, _lib.ptr(ws), ws.numel(), _lib.stream())
+    elif points is not None and solve is L.reart_lap_auction:
         src, tgt = (p.detach().float().contiguous() for p in points)
         if tuple(src.shape) != (B, n, 3) or tuple(tgt.shape) != (B, n, 3):
             raise ValueError("points = (src, tgt), both [B,n,3], with cost = cdist(src, tgt)")
@@ -111,7 +127,7 @@ def linear_sum_assignment_points(src, tgt, state, return_stats=False):
             and tuple(state["cols"].shape) == (B, n) and state["prices"].device == src.device)
     if not warm or n > POINTS_NMAX:
         return linear_sum_assignment_batch(cdist(src, tgt), return_stats=return_stats, state=state, warm_assignment=True,
-                                           points=(src, tgt))
+                                           points=(src, tgt), race=True)
     L = _lib.lib()
     col, prices = state["cols"].clone(), state["prices"]
     cert = torch.empty((B,), dtype=torch.int32, device=src.device)

@@ -83,7 +83,7 @@ def compute_ass_err(pc_trans_list, pc_list, use_nproc=True):
     _lib.require_gpu(pc_trans_list, pc_list)
     with torch.no_grad():
         cost = cdist(pc_trans_list, pc_list)
-        cols = torch.from_numpy(np.stack([c for _, c in linear_sum_assignment_batch(cost, points=(pc_trans_list, pc_list))])).to(pc_list.device)
+        cols = torch.from_numpy(np.stack([c for _, c in linear_sum_assignment_batch(cost, points=(pc_trans_list, pc_list), race=True)])).to(pc_list.device)
         matched = torch.gather(pc_list, 1, cols[..., None].expand(-1, -1, 3))
         return ((pc_trans_list - matched) ** 2).sum(dim=-1).mean()
 

@@ -212,3 +212,35 @@ def test_auction_with_points_is_the_matrix_auction(dev, n):
             np.testing.assert_array_equal(out_p[k][1], ref[k][1])
     with pytest.raises(ValueError):
         linear_sum_assignment_batch(cost, points=(ta[:, :-1], tb))
+
+
+@pytest.mark.parametrize("n", [7, 600, 1024, 2048, 4096])
+def test_raced_auction_returns_the_optimum(dev, n):
+    """reart_lap_auction_race: five epsilon schedules per matrix race on idle compute units, the first certified one
+    publishes.  Whoever wins, the assignment is the matrix auction's (= scipy's) and every matrix is certified."""
+    import oracle
+    from reart_amd.utils.lap import cdist, linear_sum_assignment_batch
+
+    rng = np.random.default_rng(400 + n)
+    B = 3
+    a = rng.uniform(-0.3, 0.3, (B, n, 3)).astype(np.float32)
+    b = (a[:, rng.permutation(n)] + rng.normal(0, 0.01, (B, n, 3))).astype(np.float32)
+    ta, tb = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+    cost = cdist(ta, tb)
+    plain = linear_sum_assignment_batch(cost)
+    for rep in range(3):
+        for pts in (None, (ta, tb)):
+            st = {}
+            out, fb, stats = linear_sum_assignment_batch(cost, return_stats="full", state=st, points=pts, race=True)
+            assert fb == 0
+            for k in range(B):
+                np.testing.assert_array_equal(out[k][1], plain[k][1])
+            assert ((stats[:, 0] >> 16) < 5).all() and ((stats[:, 0] & 0xffff) > 0).all()      # the winning racer, its phases
+            # the winner's potentials are valid duals: a re-solve from them keeps every pair
+            out2 = linear_sum_assignment_batch(cost, state=st, warm_assignment=True)
+            for k in range(B):
+                np.testing.assert_array_equal(out2[k][1], plain[k][1])
+    if n <= 2048:
+        ref = oracle.linear_sum_assignment(cost.cpu().numpy())
+        for k in range(B):
+            np.testing.assert_array_equal(plain[k][1], ref[k][1])

@@ -23,13 +23,14 @@ for n in [int(x) for x in os.environ.get("LAP_NS", "4096,2048").split(",")]:
     pa, pb = pred[:, :n].contiguous(), pcs[:, :n].contiguous()
     cost = cdist(pa, pb)
     use_points = os.environ.get("LAP_POINTS", "1") != "0"
+    race = os.environ.get("LAP_RACE", "0") == "1"
     for rep in range(2):
         if hasattr(lib, "reart_debug_auction_phase"):
             lib.reart_debug_auction_phase((ctypes.c_ulonglong * 320)(), 1)
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        out, fb, st = linear_sum_assignment_batch(cost, return_stats="full", points=(pa, pb) if use_points else None)
+        out, fb, st = linear_sum_assignment_batch(cost, return_stats="full", points=(pa, pb) if use_points else None, race=race)
         torch.cuda.synchronize(); ms = 1e3 * (time.perf_counter() - t0)
-    print(f"n={n}: {ms:.1f} ms, fallbacks {fb}; per matrix: phases {st[:,0].mean():.1f}, rounds {st[:,1].mean():.0f} (max {st[:,1].max()}), "
+    print(f"n={n}: {ms:.1f} ms, fallbacks {fb}; per matrix: phases {(st[:,0] & 0xffff).mean():.1f}, rounds {st[:,1].mean():.0f} (max {st[:,1].max()}), "
           f"bids {st[:,2].mean():.0f} (max {st[:,2].max()}), bids/round {st[:,2].sum()/st[:,1].sum():.1f}, certificate rounds {st[:,3].mean():.1f}")
     if hasattr(lib, "reart_debug_auction_phase"):
         buf = (ctypes.c_ulonglong * 320)()
