@@ -275,9 +275,11 @@ class RelaxEngine:
         tgt = tgt_idx.to(self.device).long().reshape(B, -1)
         if self._perm is not None:   # caller order -> internal storage order
             src = self._inv[src]
-            inv_f = torch.empty_like(self._perm_frames)
-            inv_f.scatter_(1, self._perm_frames, torch.arange(N, device=self.device).expand(B, N))
-            tgt = inv_f.gather(1, tgt)
+            if getattr(self, "_inv_frames", None) is None:      # fixed for the engine's life: built on first use
+                inv_f = torch.empty_like(self._perm_frames)
+                inv_f.scatter_(1, self._perm_frames, torch.arange(N, device=self.device).expand(B, N))
+                self._inv_frames = inv_f
+            tgt = self._inv_frames.gather(1, tgt)
         self._assign_map.fill_(-1)
         self._assign_map[:, src] = tgt.to(torch.int32)
         if not self.cfg.use_assign or self.cfg.lambda_assign != lambda_assign:
