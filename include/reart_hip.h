@@ -431,7 +431,7 @@ int reart_lap_auction_points(const float *cost, const float *src, const float *t
                              int32_t *certified, const double *price_in, double *price_out, void *workspace,
                              size_t workspace_bytes, void *stream);
 
-/* A cold solve as a RACE over epsilon schedules: `racers` (1..5) workgroups per matrix run the auction with different
+/* A cold solve as a RACE over epsilon schedules: `racers` (1..8) workgroups per matrix run the auction with different
  * (first epsilon, shrink factor) pairs on compute units that would otherwise idle (T-1 = 19 matrices on 256 units); the first
  * racer whose certificate closes publishes its result, the others stop at their next look at the flag.  The fastest schedule
  * depends on the matrix: over five schedules the slowest matrix of a batch is done 20 % earlier than under the best single
