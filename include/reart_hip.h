@@ -444,6 +444,14 @@ int reart_lap_auction_race(const float *cost, const float *src, const float *tgt
                            int32_t *col4row, int32_t *certified, double *price_out, void *workspace,
                            size_t workspace_bytes, void *stream);
 
+/* The race with WARM racers in the field: price_in / col4row_in are the potentials and the assignment an earlier solve of a
+ * similar batch returned; up to three of the `racers` (2..8) start from them, the others cold.  A loop that re-solves every
+ * few iterations (run_robot.py:165-178) need not know whether its matrices moved little -- a warm racer is then done in a
+ * fraction of a cold solve -- or jumped (a cold one wins).  price_out != price_in, col4row != col4row_in. */
+int reart_lap_auction_race_warm(const float *cost, const float *src, const float *tgt, int B, int n, int racers,
+                                const int32_t *col4row_in, const double *price_in, int32_t *col4row, int32_t *certified,
+                                double *price_out, void *workspace, size_t workspace_bytes, void *stream);
+
 /* The same solve warm-started from an earlier solve of a similar batch (the loop re-solves every assign_gap
  * iterations): on entry col4row holds that solve's assignment and price_in (required) its potentials; pairs that are
  * still epsilon-tight under the new costs are kept.  Certified like a cold solve.  Use when the costs move smoothly

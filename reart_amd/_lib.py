@@ -60,6 +60,7 @@ PROTOTYPES = {
     "reart_lap_auction_points": (c_int, [P, P, P, c_int, c_int, P, P, P, P, P, c_size_t, P]),
     "reart_lap_race_workspace_bytes": (c_size_t, [c_int] * 3),
     "reart_lap_auction_race": (c_int, [P, P, P, c_int, c_int, c_int, P, P, P, P, c_size_t, P]),
+    "reart_lap_auction_race_warm": (c_int, [P, P, P, c_int, c_int, c_int, P, P, P, P, P, P, c_size_t, P]),
     "reart_lap_resolve": (c_int, [P, c_int, c_int, P, P, P, P, P, c_size_t, P]),
     "reart_lap_resolve_points": (c_int, [P, P, c_int, c_int, P, P, P, P, P, c_size_t, P]),
     "reart_cdist": (c_int, [P, P, c_int, c_int, c_int, P, P]),

@@ -63,13 +63,20 @@ struct LapArgs {
     // race (reart_lap_auction_race): gridDim.y workgroups solve the SAME matrix with different epsilon schedules on compute
     // units that would idle; the first to finish certified publishes its result, the others stop when they see `done`.
     int *done;             // nullable [B]: 0 until a racer has published matrix b
+    int warm_racers;       // the last `warm_racers` of gridDim.y start from price_in / col_in (c_lap_race_warm)
+    const int *col_in;     // race: the earlier assignment the warm racers read (col4row is the winner's output)
 };
 
 // epsilon schedules of the racers (first epsilon as a fraction of the largest cost, shrink factor); racer 0 is the default
 #define LAP_SEARCH_ABORTED (-2147483647 - 1)
-#define LAP_RACE_MAX 8      // measured with 5 / 8 / 12 racers: 4096^2 189 / 190 / 195 ms, 2048^2 73 / 64 / 66 ms, 1024^2 24.6 / 24.7 / 23.2 ms
+#define LAP_RACE_MAX 8      // measured with 5 / 8 / 12 cold racers: 4096^2 189 / 190 / 195 ms, 2048^2 73 / 64 / 66 ms, 1024^2 24.6 / 24.7 / 23.2 ms
 __constant__ double c_lap_race[LAP_RACE_MAX][2] = {{LAP_EPS0, LAP_THETA}, {0.125, 4.0}, {0.03, 6.0}, {0.01, 4.0}, {0.06, 5.0},
                                                     {0.25, 6.0}, {0.125, 8.0}, {0.06, 4.0}};
+// With the potentials (and assignment) of an earlier, similar batch the LAST racers start warm: (first epsilon, shrink factor,
+// 1 = potentials only, 2 = potentials + assignment).  Whether a warm start pays depends on how far the matrices moved, which
+// the caller cannot know (the base model's resampled labels make them jump, a settled optimisation does not): racing decides.
+#define LAP_RACE_WARM 3
+__constant__ double c_lap_race_warm[LAP_RACE_WARM][3] = {{1e-2, 6.0, 2.0}, {1e-3, 6.0, 2.0}, {1e-3, 6.0, 1.0}};
 
 __device__ __forceinline__ unsigned long long lap_key(double v) { return (unsigned long long)__double_as_longlong(v); }  // v >= 0
 
@@ -340,29 +347,33 @@ __global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
     for (int o = 32; o >= 1; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
     if (lane == 0) s_red[wv] = mx;
     // warm start: potentials of an earlier problem, shifted to be non-negative (bids are ordered as unsigned keys)
+    const int warm_slot = (int)blockIdx.y - ((int)gridDim.y - a.warm_racers);          // >= 0: this racer starts warm
+    const int warm_mode = a.done ? (warm_slot >= 0 ? (int)c_lap_race_warm[warm_slot][2] : 0) : (a.price_in ? (a.warm_assign ? 2 : 1) : 0);
+    const double *price_in = warm_mode ? a.price_in : nullptr;
     double pmin = 0.0;
-    if (a.price_in) {
+    if (price_in) {
         pmin = INFINITY;
-        for (int j = tid; j < n; j += LAP_BS) pmin = fmin(pmin, a.price_in[(size_t)b * n + j]);
+        for (int j = tid; j < n; j += LAP_BS) pmin = fmin(pmin, price_in[(size_t)b * n + j]);
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) pmin = fmin(pmin, __shfl_xor(pmin, o, 64));
         if (lane == 0) s_red2[wv] = pmin;
     }
     __syncthreads();
-    if (a.price_in) {
+    if (price_in) {
         pmin = INFINITY;
         for (int w = 0; w < NW; ++w) pmin = fmin(pmin, s_red2[w]);
     }
     __syncthreads();
     for (int j = tid; j < n; j += LAP_BS) {
-        price[j] = a.price_in ? a.price_in[(size_t)b * n + j] - pmin : 0.0;
+        price[j] = price_in ? price_in[(size_t)b * n + j] - pmin : 0.0;
         owner[j] = -1; assigned[j] = -1; bidval[j] = 0ull; bidder[j] = 0x7fffffff;
     }
     __syncthreads();
-    const bool warm_assign = a.price_in && a.warm_assign;
+    const bool warm_assign = warm_mode == 2;
     if (warm_assign) {
+        const int *cin = a.col_in ? a.col_in : a.col4row;
         for (int i = tid; i < n; i += LAP_BS) {
-            const int j = a.col4row[(size_t)b * n + i];
+            const int j = cin[(size_t)b * n + i];
             if (j >= 0 && j < n) { assigned[i] = j; owner[j] = i; }
         }
         __syncthreads();
@@ -470,7 +481,8 @@ __global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
         return sink >= 0 ? steps : -steps - 1;
     };
     JPH(0);
-    const double eps0 = race ? c_lap_race[racer][0] : a.eps0, theta_inv = race ? 1.0 / c_lap_race[racer][1] : a.theta_inv;
+    const double eps0 = !race ? a.eps0 : (warm_slot >= 0 ? c_lap_race_warm[warm_slot][0] : c_lap_race[racer][0]);
+    const double theta_inv = !race ? a.theta_inv : 1.0 / (warm_slot >= 0 ? c_lap_race_warm[warm_slot][1] : c_lap_race[racer][1]);
     for (double eps = mx * eps0; ; eps = fmax(eps * theta_inv, eps_final)) {
         ++st_phases;
         // a phase keeps the prices and every pair that already satisfies the new, tighter epsilon-complementary
@@ -813,7 +825,7 @@ extern "C" size_t reart_lap_workspace_bytes(int B, int n) {
 // with a small epsilon; price_out (nullable, [B,n] f64) receives this batch's potentials (may alias price_in).
 static int lap_launch(const float *cost, int B, int n, int32_t *col4row, int32_t *certified, const double *price_in,
                       double *price_out, int warm_assign, void *workspace, size_t workspace_bytes, void *stream,
-                      const float *src = nullptr, const float *tgt = nullptr, int racers = 1) {
+                      const float *src = nullptr, const float *tgt = nullptr, int racers = 1, const int32_t *col_in = nullptr) {
     if (B < 0 || n < 1 || n > LAP_NMAX) return REART_ERR_INVALID_ARG;
     if (B == 0) return REART_OK;
     if (!cost || !col4row || !certified) return REART_ERR_INVALID_ARG;
@@ -836,7 +848,12 @@ static int lap_launch(const float *cost, int B, int n, int32_t *col4row, int32_t
         hipFuncSetAttribute((const void *)lap_auction_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)
         return REART_ERR_LAUNCH;
     if (racers > 1) {
-        if (racers > LAP_RACE_MAX || price_in) return REART_ERR_INVALID_ARG;
+        if (racers > LAP_RACE_MAX) return REART_ERR_INVALID_ARG;
+        // with the potentials (and assignment) of an earlier batch the last racers start warm; price_out / col4row must not be
+        // those inputs (the winner writes them while slower racers may still be reading)
+        a.warm_racers = price_in ? (racers - 1 < LAP_RACE_WARM ? racers - 1 : LAP_RACE_WARM) : 0;
+        if (a.warm_racers && (price_in == a.price_out || col_in == col4row || !col_in)) return REART_ERR_INVALID_ARG;
+        a.col_in = col_in;
         if (workspace_bytes < reart_lap_race_workspace_bytes(B, n, racers)) return REART_ERR_INVALID_ARG;
         char *w = (char *)workspace + reart_lap_workspace_bytes(B, n);
         a.pbval_ws = (double *)w;                                             // [racers][B][n]
@@ -861,6 +878,20 @@ extern "C" int reart_lap_auction_race(const float *cost, const float *src, const
                                       size_t workspace_bytes, void *stream) {
     if ((src == nullptr) != (tgt == nullptr) || racers < 1) return REART_ERR_INVALID_ARG;
     return lap_launch(cost, B, n, col4row, certified, nullptr, price_out, 0, workspace, workspace_bytes, stream, src, tgt, racers);
+}
+
+// The race with WARM racers among the field: price_in / col4row_in are the potentials and the assignment of an earlier solve
+// of a similar batch (reart_lap_auction* outputs); up to three of the racers start from them (potentials + assignment at
+// two first epsilons, potentials alone), the others cold.  A loop that re-solves every few iterations does not have to know
+// whether its matrices moved little (a warm racer is done in a fraction of a cold solve) or jumped (a cold one wins).
+// price_out != price_in and col4row != col4row_in.
+extern "C" int reart_lap_auction_race_warm(const float *cost, const float *src, const float *tgt, int B, int n, int racers,
+                                           const int32_t *col4row_in, const double *price_in, int32_t *col4row,
+                                           int32_t *certified, double *price_out, void *workspace, size_t workspace_bytes,
+                                           void *stream) {
+    if ((src == nullptr) != (tgt == nullptr) || racers < 2 || !price_in || !col4row_in || !price_out) return REART_ERR_INVALID_ARG;
+    return lap_launch(cost, B, n, col4row, certified, price_in, price_out, 1, workspace, workspace_bytes, stream, src, tgt, racers,
+                      col4row_in);
 }
 
 extern "C" int reart_lap_auction(const float *cost, int B, int n, int32_t *col4row, int32_t *certified,

@@ -299,14 +299,18 @@ def main(args):
             zero = torch.zeros(1, dtype=torch.long, device=device)
             src_idx = farthest_point_sample(cano_pc[None], num_fps, start=zero, cuda_mode=True)                  # [1, n]
             tgt_idx = farthest_point_sample(pc_list, num_fps, start=zero.expand(B_), cuda_mode=True)             # [B, n]
-            tgt_pts = index_points(pc_list, tgt_idx)
+            tgt_pts = index_points(pc_list, tgt_idx).contiguous()
+            lap_state = {}
             while i < n_iter:
                 if not have or i % args.assign_gap == 0:
                     eng.peek_forward()
-                    cost = cdist(index_points(eng.pc_trans, src_idx.expand(B_, num_fps)), tgt_pts)
-                    # cold start every time: the potentials of the previous solve make the auction slower here (the
-                    # assignment phase moves the matrices; measured 214 ms warm vs 56 ms cold per 19 x 1024^2)
-                    assign = linear_sum_assignment_batch(cost, race=True)    # five epsilon schedules race on idle compute units
+                    src_pts = index_points(eng.pc_trans, src_idx.expand(B_, num_fps)).contiguous()
+                    cost = cdist(src_pts, tgt_pts)
+                    # A race on compute units that would idle (reart_lap_auction_race_warm): five epsilon schedules from
+                    # scratch and three racers from the previous refresh's potentials and assignment; the first certified
+                    # one publishes.  (The assignment phase moves the matrices: a plain warm start alone was measured
+                    # SLOWER than a cold solve, 35 vs 27 ms per 19 x 1024^2; in the race a warm racer wins where it can.)
+                    assign = linear_sum_assignment_batch(cost, points=(src_pts, tgt_pts), race="warm", state=lap_state)
                     cols = torch.from_numpy(np.stack([c for _, c in assign])).to(device)       # rows are 0..n-1
                     eng.set_assignment(src_idx[0], tgt_idx.gather(1, cols), args.lambda_assign)
                     have = True

@@ -39,7 +39,9 @@ def linear_sum_assignment_batch(cost, return_stats=False, state=None, warm_assig
     long single-bidder chains from the points instead of reading them (``reart_lap_auction_points``; same result).
     ``race=True`` (cold solves): five workgroups per matrix race with different epsilon schedules on otherwise idle compute
     units and the first certified one publishes (``reart_lap_auction_race``): the same optimal assignment 20 % sooner; the
-    potentials kept in ``state`` are the winner's (valid, but not reproducible run to run)."""
+    potentials kept in ``state`` are the winner's (valid, but not reproducible run to run).  ``race="warm"`` with a ``state``
+    kept between calls: from the second call on three more racers start from the previous potentials and assignment
+    (``reart_lap_auction_race_warm``) -- a loop need not know whether its matrices moved little or jumped."""
     _lib.require_gpu(cost)
     if cost.dim() != 3 or cost.shape[1] != cost.shape[2]:
         raise ValueError("linear_sum_assignment_batch expects square matrices [B,n,n]")
@@ -69,8 +71,13 @@ def linear_sum_assignment_batch(cost, return_stats=False, state=None, warm_assig
     solve = L.reart_lap_auction
     if state is not None and keep:
         solve = L.reart_lap_resolve if method == "paths" else L.reart_lap_auction_warm
-    racing = bool(race) and solve is L.reart_lap_auction and not warm          # cold solves only
-    ws = _lib.workspace(L.reart_lap_race_workspace_bytes(B, n, RACERS) if racing else nbytes, cost.device)
+    racing = bool(race) and solve is L.reart_lap_auction
+    # race="warm": with the potentials and assignment of the previous call in ``state`` three more racers start from them
+    race_warm = racing and race == "warm" and warm and state.get("cols") is not None and tuple(state["cols"].shape) == (B, n)
+    if racing and warm and not race_warm:
+        racing = False                                                         # warm potentials only: the plain warm auction
+    n_racers = RACERS + 3 if race_warm else RACERS
+    ws = _lib.workspace(L.reart_lap_race_workspace_bytes(B, n, n_racers) if racing else nbytes, cost.device)
     tail_args = (B, n, _lib.ptr(col), _lib.ptr(cert), _lib.ptr(prices) if (state is not None and warm) else None,
                  _lib.ptr(prices) if state is not None else None, _lib.ptr(ws), ws.numel(), _lib.stream())
     if racing:
@@ -79,8 +86,15 @@ def linear_sum_assignment_batch(cost, return_stats=False, state=None, warm_assig
             src, tgt = (p.detach().float().contiguous() for p in points)
             if tuple(src.shape) != (B, n, 3) or tuple(tgt.shape) != (B, n, 3):
                 raise ValueError("points = (src, tgt), both [B,n,3], with cost = cdist(src, tgt)")
-        rc = L.reart_lap_auction_race(_lib.ptr(cost), _lib.ptr(src), _lib.ptr(tgt), B, n, RACERS, _lib.ptr(col), _lib.ptr(cert),
-                                      _lib.ptr(prices) if state is not None else None, _lib.ptr(ws), ws.numel(), _lib.stream())
+        if race_warm:
+            new_prices = torch.empty_like(prices)
+            rc = L.reart_lap_auction_race_warm(_lib.ptr(cost), _lib.ptr(src), _lib.ptr(tgt), B, n, n_racers, _lib.ptr(state["cols"]),
+                                               _lib.ptr(prices), _lib.ptr(col), _lib.ptr(cert), _lib.ptr(new_prices), _lib.ptr(ws),
+                                               ws.numel(), _lib.stream())
+            state["prices"] = new_prices
+        else:
+            rc = L.reart_lap_auction_race(_lib.ptr(cost), _lib.ptr(src), _lib.ptr(tgt), B, n, RACERS, _lib.ptr(col), _lib.ptr(cert),
+                                          _lib.ptr(prices) if state is not None else None, _lib.ptr(ws), ws.numel(), _lib.stream())
     elif points is not None and solve is L.reart_lap_auction:
         src, tgt = (p.detach().float().contiguous() for p in points)
         if tuple(src.shape) != (B, n, 3) or tuple(tgt.shape) != (B, n, 3):
@@ -90,7 +104,7 @@ def linear_sum_assignment_batch(cost, return_stats=False, state=None, warm_assig
     else:
         rc = solve(_lib.ptr(cost), *tail_args)
     _lib.check(rc, "reart_lap_auction")
-    if state is not None and warm_assignment:
+    if state is not None and (warm_assignment or race == "warm"):
         state["cols"] = col.clone()
     col_h, cert_h = col.cpu().numpy().astype(np.int64), cert.cpu().numpy()
     rows = np.arange(n, dtype=np.int64)

@@ -244,3 +244,26 @@ def test_raced_auction_returns_the_optimum(dev, n):
         ref = oracle.linear_sum_assignment(cost.cpu().numpy())
         for k in range(B):
             np.testing.assert_array_equal(plain[k][1], ref[k][1])
+
+
+def test_race_with_warm_racers_over_a_moving_sequence(dev):
+    """race="warm": from the second call on three racers start from the previous potentials and assignment.  Slowly moving
+    problems, then a jump: every solve returns the plain auction's assignment, certified."""
+    from reart_amd.utils.lap import cdist, linear_sum_assignment_batch
+
+    rng = np.random.default_rng(77)
+    B, n = 3, 700
+    a = rng.uniform(-0.3, 0.3, (B, n, 3)).astype(np.float32)
+    b = (a[:, rng.permutation(n)] + rng.normal(0, 0.01, (B, n, 3))).astype(np.float32)
+    tb = torch.from_numpy(b).to(dev)
+    st = {}
+    for step in range(6):
+        ta = torch.from_numpy(a).to(dev)
+        cost = cdist(ta, tb)
+        out, fb, stats = linear_sum_assignment_batch(cost, return_stats="full", state=st, points=(ta, tb), race="warm")
+        plain = linear_sum_assignment_batch(cost)
+        assert fb == 0
+        for k in range(B):
+            np.testing.assert_array_equal(out[k][1], plain[k][1])
+        assert ((stats[:, 0] >> 16) < 8).all()
+        a = (a + rng.normal(0, 0.002 if step != 3 else 0.05, a.shape)).astype(np.float32)      # step 3: the problems jump

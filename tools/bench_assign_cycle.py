@@ -19,7 +19,7 @@ def T(name, fn):
     torch.cuda.synchronize(); t0 = time.perf_counter(); r = fn(); torch.cuda.synchronize()
     acc[name] = acc.get(name, 0.0) + time.perf_counter() - t0
     return r
-WARM = os.environ.get('WARM', '0')      # 0: cold solves, 1: warm potentials, 2: re-solve from the previous optimum (paths), 3: points form of 2
+WARM = os.environ.get('WARM', '0')      # 4: race with warm racers, 0: cold solves, 1: warm potentials, 2: re-solve from the previous optimum (paths), 3: points form of 2
 state = {} if WARM != '0' else None
 reps = int(os.environ.get('REPS', 30))
 t_all = time.perf_counter()
@@ -35,7 +35,7 @@ for k in range(reps):
         pa, pb = index_points(pred, src.expand(B, nf)).contiguous(), index_points(pcs, tgt).contiguous()
         assign, fb, st = T("linear_sum_assignment_batch", lambda: linear_sum_assignment_points(pa, pb, state, return_stats="full"))
     else:
-        assign, fb, st = T("linear_sum_assignment_batch", lambda: linear_sum_assignment_batch(cost, return_stats="full", state=state, warm_assignment=WARM == '2', race=os.environ.get('RACE', '1') == '1'))
+        assign, fb, st = T("linear_sum_assignment_batch", lambda: linear_sum_assignment_batch(cost, return_stats="full", state=state, warm_assignment=WARM == '2', race=('warm' if WARM == '4' else os.environ.get('RACE', '1') == '1')))
     if k % 5 == 0:
         print(f"cycle {k}: LAP mean rounds {st[:,1].mean():.0f} bids {st[:,2].mean():.0f} (max {st[:,2].max()}) cert {st[:,3].mean():.0f} fallbacks {fb}")
     cols = T("cols to device", lambda: torch.from_numpy(np.stack([c for _, c in assign])).to(dev))
