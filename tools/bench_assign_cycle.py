@@ -30,7 +30,12 @@ for k in range(reps):
     tgt = T("fps frames", lambda: farthest_point_sample(pcs, nf))
     cost = T("gather + cdist (reart_cdist)", lambda: cdist(index_points(pred, src.expand(B, nf)), index_points(pcs, tgt)))
     T("  (torch.cdist, for comparison)", lambda: torch.cdist(index_points(pred, src.expand(B, nf)), index_points(pcs, tgt)))
-    if WARM == '3':
+    if WARM == '5':      # Jonker-Volgenant from scratch in the points form: no previous assignment, zero potentials
+        from reart_amd.utils.lap import linear_sum_assignment_points
+        pa, pb = index_points(pred, src.expand(B, nf)).contiguous(), index_points(pcs, tgt).contiguous()
+        jv = {"prices": torch.zeros((B, nf), dtype=torch.float64, device=dev), "cols": torch.full((B, nf), -1, dtype=torch.int32, device=dev)}
+        assign, fb, st = T("linear_sum_assignment_batch", lambda: linear_sum_assignment_points(pa, pb, jv, return_stats="full"))
+    elif WARM == '3':
         from reart_amd.utils.lap import linear_sum_assignment_points
         pa, pb = index_points(pred, src.expand(B, nf)).contiguous(), index_points(pcs, tgt).contiguous()
         assign, fb, st = T("linear_sum_assignment_batch", lambda: linear_sum_assignment_points(pa, pb, state, return_stats="full"))
