@@ -51,6 +51,9 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #ifndef PR_QCAP
 #define PR_QCAP 768     // entries of a wave's (query, box) queue (the first 384 hold box bounds: PR_BOXLDS)
 #endif
+#ifndef PR_COARSE_PACKED
+#define PR_COARSE_PACKED 1
+#endif
 #ifndef PR_WPE
 #define PR_WPE 1         // minimum waves per SIMD the compiler must allow for (register budget)
 #endif
@@ -298,11 +301,26 @@ __device__ __forceinline__ void knn_pruned_wave(const KnnJob &jb, const int S, c
                 float *o = s_bb + 6 * lane;
                 o[0] = lo0; o[1] = lo1; o[2] = lo2; o[3] = hi0; o[4] = hi1; o[5] = hi2;
             }
+#if PR_COARSE_PACKED   // two query sub-groups per packed instruction (same operation order per sub-group as box_lb)
+            const f2 bl0 = {lo0, lo0}, bl1 = {lo1, lo1}, bl2 = {lo2, lo2}, bh0 = {hi0, hi0}, bh1 = {hi1, hi1}, bh2 = {hi2, hi2};
+#pragma unroll
+            for (int q = 0; q < 4; q += 2) {
+                const f2 ql0 = {G[q][0], G[q + 1][0]}, ql1 = {G[q][1], G[q + 1][1]}, ql2 = {G[q][2], G[q + 1][2]};
+                const f2 qh0 = {G[q][3], G[q + 1][3]}, qh1 = {G[q][4], G[q + 1][4]}, qh2 = {G[q][5], G[q + 1][5]};
+                const f2 a0 = bl0 - qh0, c0 = ql0 - bh0, a1 = bl1 - qh1, c1 = ql1 - bh1, a2 = bl2 - qh2, c2 = ql2 - bh2;
+                const f2 e0 = {fmaxf(fmaxf(a0.x, c0.x), 0.f), fmaxf(fmaxf(a0.y, c0.y), 0.f)};
+                const f2 e1 = {fmaxf(fmaxf(a1.x, c1.x), 0.f), fmaxf(fmaxf(a1.y, c1.y), 0.f)};
+                const f2 e2 = {fmaxf(fmaxf(a2.x, c2.x), 0.f), fmaxf(fmaxf(a2.y, c2.y), 0.f)};
+                const f2 lb = (e0 * e0 + e1 * e1) + e2 * e2;
+                pass = pass || (lb.x <= G[q][6]) || (lb.y <= G[q + 1][6]);
+            }
+#else
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float lb = box_lb(lo0, lo1, lo2, hi0, hi1, hi2, G[q][0], G[q][1], G[q][2], G[q][3], G[q][4], G[q][5]);
                 pass = pass || (lb <= G[q][6]);
             }
+#endif
         }
         unsigned long long mask = __ballot(pass);
         PH(1);
