@@ -325,12 +325,12 @@ def main():
                     help="sweep mode: K independent instances share each GPU on separate streams (secondary figure; "
                          "the headline is K=1)")
     ap.add_argument("--no-tail", action="store_true", help="skip the end-of-run structure / energy timing (secondary figure)")
-    ap.add_argument("--sweep-mode", choices=("batch", "streams"), default="streams",
+    ap.add_argument("--sweep-mode", choices=("batch", "streams"), default="batch",
                     help="how the sweep's instances share a GPU: batch = shared launches (reart_relax_step_batch), streams = one "
                          "stream per instance")
-    ap.add_argument("--sweep-instances", type=int, default=3,
-                    help="after the headline (one instance per GPU) also time this many concurrent instances per GPU on "
-                         "separate streams and report the aggregate as `sweep` (0 = skip)")
+    ap.add_argument("--sweep-instances", type=int, default=6,
+                    help="after the headline (one instance per GPU) also time this many concurrent instances per GPU "
+                         "(--sweep-mode) and report the aggregate as `sweep` (0 = skip)")
     ap.add_argument("--profile-steps", type=int, default=20, help="eager steps timed per phase with HIP events")
     args = ap.parse_args()
 
