@@ -431,7 +431,7 @@ int reart_lap_auction_points(const float *cost, const float *src, const float *t
                              int32_t *certified, const double *price_in, double *price_out, void *workspace,
                              size_t workspace_bytes, void *stream);
 
-/* A cold solve as a RACE over epsilon schedules: `racers` (1..8) workgroups per matrix run the auction with different
+/* A cold solve as a RACE over epsilon schedules: `racers` (1..13) workgroups per matrix run the auction with different
  * (first epsilon, shrink factor) pairs on compute units that would otherwise idle (T-1 = 19 matrices on 256 units); the first
  * racer whose certificate closes publishes its result, the others stop at their next look at the flag.  The fastest schedule
  * depends on the matrix: over five schedules the slowest matrix of a batch is done 20 % earlier than under the best single
@@ -445,7 +445,7 @@ int reart_lap_auction_race(const float *cost, const float *src, const float *tgt
                            size_t workspace_bytes, void *stream);
 
 /* The race with WARM racers in the field: price_in / col4row_in are the potentials and the assignment an earlier solve of a
- * similar batch returned; up to three of the `racers` (2..8) start from them, the others cold.  A loop that re-solves every
+ * similar batch returned; up to three of the `racers` (2..16, at most 13 of them cold) start from them, the others cold.  A loop that re-solves every
  * few iterations (run_robot.py:165-178) need not know whether its matrices moved little -- a warm racer is then done in a
  * fraction of a cold solve -- or jumped (a cold one wins).  price_out != price_in, col4row != col4row_in. */
 int reart_lap_auction_race_warm(const float *cost, const float *src, const float *tgt, int B, int n, int racers,

@@ -69,9 +69,11 @@ struct LapArgs {
 
 // epsilon schedules of the racers (first epsilon as a fraction of the largest cost, shrink factor); racer 0 is the default
 #define LAP_SEARCH_ABORTED (-2147483647 - 1)
-#define LAP_RACE_MAX 8      // measured with 5 / 8 / 12 cold racers: 4096^2 189 / 190 / 195 ms, 2048^2 73 / 64 / 66 ms, 1024^2 24.6 / 24.7 / 23.2 ms
-__constant__ double c_lap_race[LAP_RACE_MAX][2] = {{LAP_EPS0, LAP_THETA}, {0.125, 4.0}, {0.03, 6.0}, {0.01, 4.0}, {0.06, 5.0},
-                                                    {0.25, 6.0}, {0.125, 8.0}, {0.06, 4.0}};
+#define LAP_RACE_COLD 13    // measured with 5 / 8 / 12 cold racers: 4096^2 189 / 190 / 195 ms, 2048^2 73 / 64 / 66 ms, 1024^2 24.6 / 24.7 / 23.2 ms
+#define LAP_RACE_MAX 16     // cold + warm racers of one launch
+__constant__ double c_lap_race[LAP_RACE_COLD][2] = {{LAP_EPS0, LAP_THETA}, {0.125, 4.0}, {0.03, 6.0}, {0.01, 4.0}, {0.06, 5.0},
+                                                     {0.25, 6.0}, {0.125, 8.0}, {0.06, 4.0}, {0.02, 6.0}, {0.03, 5.0},
+                                                     {0.5, 5.0}, {0.015, 5.0}, {0.125, 5.0}};
 // With the potentials (and assignment) of an earlier, similar batch the LAST racers start warm: (first epsilon, shrink factor,
 // 1 = potentials only, 2 = potentials + assignment).  Whether a warm start pays depends on how far the matrices moved, which
 // the caller cannot know (the base model's resampled labels make them jump, a settled optimisation does not): racing decides.
@@ -852,6 +854,7 @@ static int lap_launch(const float *cost, int B, int n, int32_t *col4row, int32_t
         // with the potentials (and assignment) of an earlier batch the last racers start warm; price_out / col4row must not be
         // those inputs (the winner writes them while slower racers may still be reading)
         a.warm_racers = price_in ? (racers - 1 < LAP_RACE_WARM ? racers - 1 : LAP_RACE_WARM) : 0;
+        if (racers - a.warm_racers > LAP_RACE_COLD) return REART_ERR_INVALID_ARG;
         if (a.warm_racers && (price_in == a.price_out || col_in == col4row || !col_in)) return REART_ERR_INVALID_ARG;
         a.col_in = col_in;
         if (workspace_bytes < reart_lap_race_workspace_bytes(B, n, racers)) return REART_ERR_INVALID_ARG;

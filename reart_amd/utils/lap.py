@@ -21,7 +21,17 @@ def cdist(a, b):
     return out
 
 
-RACERS = 5   # epsilon schedules raced per matrix by ``race=True`` (reart_lap_auction_race)
+RACERS = 5   # epsilon schedules raced per matrix by ``race=True`` (reart_lap_auction_race) at n = 4096
+
+
+def _racers(B, n, warm):
+    """(cold racers, all racers) per matrix: the chip has 256 compute units and a racer is one workgroup.  Up to 2048 columns
+    more schedules keep paying (12: -6 % at 1024^2, -10 % at 2048^2 against 5); at 4096^2 the racers' matrix reads start to
+    contend (+3 %).  ``warm``: three of the racers start from the previous potentials / assignment."""
+    if n > 2048:
+        return RACERS, RACERS + (3 if warm else 0)
+    total = max(RACERS, min(15 if warm else 12, 256 // max(B, 1)))
+    return (max(total - 3, 2), total) if warm else (total, total)
 
 
 def linear_sum_assignment_batch(cost, return_stats=False, state=None, warm_assignment=False, method="paths", points=None,
@@ -76,7 +86,7 @@ def linear_sum_assignment_batch(cost, return_stats=False, state=None, warm_assig
     race_warm = racing and race == "warm" and warm and state.get("cols") is not None and tuple(state["cols"].shape) == (B, n)
     if racing and warm and not race_warm:
         racing = False                                                         # warm potentials only: the plain warm auction
-    n_racers = RACERS + 3 if race_warm else RACERS
+    n_cold, n_racers = _racers(B, n, race_warm)
     ws = _lib.workspace(L.reart_lap_race_workspace_bytes(B, n, n_racers) if racing else nbytes, cost.device)
     tail_args = (B, n, _lib.ptr(col), _lib.ptr(cert), _lib.ptr(prices) if (state is not None and warm) else None,
                  _lib.ptr(prices) if state is not None else None, _lib.ptr(ws), ws.numel(), _lib.stream())
@@ -93,7 +103,7 @@ def linear_sum_assignment_batch(cost, return_stats=False, state=None, warm_assig
                                                ws.numel(), _lib.stream())
             state["prices"] = new_prices
         else:
-            rc = L.reart_lap_auction_race(_lib.ptr(cost), _lib.ptr(src), _lib.ptr(tgt), B, n, RACERS, _lib.ptr(col), _lib.ptr(cert),
+            rc = L.reart_lap_auction_race(_lib.ptr(cost), _lib.ptr(src), _lib.ptr(tgt), B, n, n_cold, _lib.ptr(col), _lib.ptr(cert),
                                           _lib.ptr(prices) if state is not None else None, _lib.ptr(ws), ws.numel(), _lib.stream())
     elif points is not None and solve is L.reart_lap_auction:
         src, tgt = (p.detach().float().contiguous() for p in points)

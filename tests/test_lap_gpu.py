@@ -235,7 +235,7 @@ def test_raced_auction_returns_the_optimum(dev, n):
             assert fb == 0
             for k in range(B):
                 np.testing.assert_array_equal(out[k][1], plain[k][1])
-            assert ((stats[:, 0] >> 16) < 5).all() and ((stats[:, 0] & 0xffff) > 0).all()      # the winning racer, its phases
+            assert ((stats[:, 0] >> 16) < 13).all() and ((stats[:, 0] & 0xffff) > 0).all()     # the winning racer, its phases
             # the winner's potentials are valid duals: a re-solve from them keeps every pair
             out2 = linear_sum_assignment_batch(cost, state=st, warm_assignment=True)
             for k in range(B):
@@ -265,5 +265,5 @@ def test_race_with_warm_racers_over_a_moving_sequence(dev):
         assert fb == 0
         for k in range(B):
             np.testing.assert_array_equal(out[k][1], plain[k][1])
-        assert ((stats[:, 0] >> 16) < 8).all()
+        assert ((stats[:, 0] >> 16) < 16).all()
         a = (a + rng.normal(0, 0.002 if step != 3 else 0.05, a.shape)).astype(np.float32)      # step 3: the problems jump
