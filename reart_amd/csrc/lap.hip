@@ -338,8 +338,8 @@ __global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
     __shared__ int s_pj1[NW];
     const float *C = a.cost + (size_t)b * n * n;
     JPH_DECL;
-    // a race is over for this workgroup once another racer has published the matrix (volatile: the flag lives in L2)
-    auto lost = [&]() -> int { return a.done ? *(volatile int *)(a.done + b) : 0; };
+    // a race is over for this workgroup once another racer has published the matrix (device-scope atomic load: the flag lives in L2)
+    auto lost = [&]() -> int { return a.done ? __hip_atomic_load(a.done + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0; };
     const bool race = a.done != nullptr && gridDim.y > 1;
     if (tid == 0) s_abort = 0;
 
