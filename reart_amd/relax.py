@@ -378,6 +378,8 @@ class RelaxBatch:
         self.graph_replays = self.eager_steps = 0
 
     def _enqueue(self):
+        if any(e.cfg.use_assign for e in self.engines):
+            raise RuntimeError("RelaxBatch steps the default iteration (Chamfer + flow); an engine was switched to the assignment loss")
         rc = _lib_fns().reart_relax_step_batch(self._cfgs, self._bufs, self._ws, self._nbytes, len(self.engines), _lib.stream())
         _lib.check(rc, "reart_relax_step_batch")
 
