@@ -43,3 +43,17 @@ def test_fold_equals_conv_followed_by_eval_batchnorm_and_follows_parameter_chang
     conv.weight = nn.Parameter(conv.weight.detach() * 0.5)
     Wt5, _ = _fold(conv, bn)
     np.testing.assert_allclose(Wt5.numpy(), Wt3.numpy(), rtol=1e-6, atol=1e-7)
+
+
+def test_racer_counts_fit_the_chip():
+    """reart_amd.utils.lap._racers: (cold, all) workgroups per matrix of a raced assignment solve -- never more than 256
+    workgroups below 4096 columns, five cold racers at 4096, three warm ones when a previous solution is available."""
+    from reart_amd.utils.lap import _racers, RACERS
+
+    assert _racers(19, 4096, False) == (RACERS, RACERS) and _racers(19, 4096, True) == (RACERS, RACERS + 3)
+    for B in (1, 9, 19, 40, 100):
+        for n in (64, 1024, 2048):
+            cold, total = _racers(B, n, False)
+            assert cold == total and RACERS <= total <= 12 and (total == RACERS or B * total <= 256)
+            cold, total = _racers(B, n, True)
+            assert total - cold == 3 and cold >= 2 and total <= 15 and (total == RACERS or B * total <= 256)
