@@ -21,6 +21,31 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+
+def _launch_module():
+    """reart_amd/launch.py loaded by path: the parent of a self-launched job imports neither torch nor the package."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("_reart_launch", os.path.join(ROOT, "reart_amd", "launch.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _requested_gpus(argv):
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            return int(argv[i + 1])
+        if a.startswith("--gpus="):
+            return int(a.split("=", 1)[1])
+    return 1
+
+
+if __name__ == "__main__" and _requested_gpus(sys.argv[1:]) > 1 and "RANK" not in os.environ:
+    # `python bench.py --gpus N` with no launcher around it: start the N ranks (one per GPU, RCCL) BEFORE anything in this
+    # process touches the GPU, relay rank 0's JSON line, fail loudly if the ranks fail or the line is not an N-GPU line
+    sys.exit(_launch_module().self_launch(os.path.abspath(__file__), sys.argv[1:], _requested_gpus(sys.argv[1:])))
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
@@ -334,12 +359,15 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=20, help="eager steps timed per phase with HIP events")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = _launch_module().check_world(args.gpus)      # --gpus N must be an N-rank job (or self-launched above)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = "RANK" in os.environ  # launched by torch.distributed.run (also with a single rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU (this node shows {torch.cuda.device_count()}); "
+                         f"--gpus {args.gpus} needs {args.gpus} GPUs on one node")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if distributed:

@@ -1,0 +1,80 @@
+"""One process per GPU: the launch half of the multi-GPU path.
+
+A command that is started WITHOUT ``RANK`` in its environment and asked for N > 1 GPUs starts N ranks of itself under
+``python -m torch.distributed.run`` (one rank per GPU, rendezvous on 127.0.0.1) and relays rank 0's standard output.
+The parent never touches the GPU: it must decide and spawn before any HIP call (a process that has initialised the
+GPU must not be replaced or forked into ranks), so this module imports nothing from torch."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def under_launcher(env=None):
+    """True when this process is one rank of a torch.distributed.run job."""
+    env = os.environ if env is None else env
+    return "RANK" in env and "WORLD_SIZE" in env
+
+
+def torchrun_command(script, argv, nproc, port=None, module=False):
+    """The exact command the round driver uses for N > 1 (and the one this module spawns).  ``module=True``: ``script`` is
+    a module name (``-m``)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(nproc)}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port if port is not None else free_port()),
+            *(["-m"] if module else []), script, *argv]
+
+
+def check_world(requested, env=None):
+    """A rank's view: the job must have as many ranks as ``--gpus`` asked for.  Raises SystemExit otherwise -- a line that
+    says n_gpus = 1 for a request of 8 is worse than no line."""
+    env = os.environ if env is None else env
+    world = int(env.get("WORLD_SIZE", "1"))
+    if int(requested) != world:
+        raise SystemExit(f"--gpus {requested} but the job has WORLD_SIZE={world} rank(s): start it with "
+                         f"`python -m torch.distributed.run --nproc-per-node {requested} ...` or let the command launch "
+                         f"its own ranks (no RANK in the environment)")
+    return world
+
+
+def self_launch(script, argv, nproc, expect_json_key="n_gpus", timeout=None, module=False):
+    """Start ``nproc`` ranks of ``script argv`` and wait.  stdout of the ranks is captured; the LAST line that parses as a
+    JSON object is printed (rank 0 prints exactly one), everything else goes to stderr.  Exit status: the launcher's, or 3
+    when no JSON line came back, or 4 when the line's ``expect_json_key`` differs from ``nproc``."""
+    cmd = torchrun_command(script, argv, nproc, module=module)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // max(1, int(nproc)))))
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, timeout=timeout)
+    line = None
+    for raw in proc.stdout.decode(errors="replace").splitlines():
+        s = raw.strip()
+        if s.startswith("{") and s.endswith("}"):
+            try:
+                json.loads(s)
+                line = s
+                continue
+            except ValueError:
+                pass
+        if s:
+            print(raw, file=sys.stderr)
+    if proc.returncode != 0:
+        print(f"launch of {nproc} ranks failed (exit {proc.returncode}): {' '.join(cmd)}", file=sys.stderr)
+        return proc.returncode
+    if line is None:
+        print("the ranks printed no JSON line", file=sys.stderr)
+        return 3
+    if expect_json_key is not None and json.loads(line).get(expect_json_key) != int(nproc):
+        print(f"asked for {nproc} GPUs, the line reports {expect_json_key}={json.loads(line).get(expect_json_key)}",
+              file=sys.stderr)
+        return 4
+    print(line)
+    return 0

@@ -368,18 +368,38 @@ class RelaxBatch:
         nb = {e.workspace.numel() for e in engines}
         if len(nb) != 1:
             raise ValueError("RelaxBatch: the engines must share one shape")
+        # the shared launches take their grid and their code path from instance 0: every engine must agree on everything
+        # that decides either (two shapes can need the same workspace size)
+        for f in self.SAME:
+            vals = {getattr(e.cfg, f) for e in engines}
+            if len(vals) != 1:
+                raise ValueError(f"RelaxBatch: the engines differ in cfg.{f} ({sorted(vals)})")
+        if len({e.device for e in engines}) != 1:
+            raise ValueError("RelaxBatch: the engines live on different devices")
         self.engines = engines
-        K = len(engines)
-        self._cfgs = (RelaxConfig * K)(*[e.cfg for e in engines])
-        self._bufs = (RelaxBuffers * K)(*[e._bufs for e in engines])
-        self._ws = (c_void_p * K)(*[e.workspace.data_ptr() for e in engines])
         self._nbytes = nb.pop()
         self._graph = None
         self.graph_replays = self.eager_steps = 0
+        self._refresh()
+
+    # shape and switch fields of reart_relax_config that every engine of a batch must share
+    SAME = ("N", "P", "B", "H", "M_max", "use_flow", "robust", "euclidean", "flow_k", "use_grid", "use_boxes", "use_assign",
+            "search_mode", "tune_slices", "tune_slices_flow", "tune_sparse", "tune_fwd_pts", "tune_bwd_pts", "tune_reorder",
+            "tune_cloud", "tune_xcd")
+
+    def _refresh(self):
+        """The argument blocks are VALUES: re-read them from the engines (an engine may have been given new noise, new
+        buffers or another loss since the batch was built).  A captured graph keeps the values it was captured with, like
+        an engine's own graph does."""
+        K = len(self.engines)
+        self._cfgs = (RelaxConfig * K)(*[e.cfg for e in self.engines])
+        self._bufs = (RelaxBuffers * K)(*[e._bufs for e in self.engines])
+        self._ws = (c_void_p * K)(*[e.workspace.data_ptr() for e in self.engines])
 
     def _enqueue(self):
         if any(e.cfg.use_assign for e in self.engines):
             raise RuntimeError("RelaxBatch steps the default iteration (Chamfer + flow); an engine was switched to the assignment loss")
+        self._refresh()
         rc = _lib_fns().reart_relax_step_batch(self._cfgs, self._bufs, self._ws, self._nbytes, len(self.engines), _lib.stream())
         _lib.check(rc, "reart_relax_step_batch")
 

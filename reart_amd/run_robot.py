@@ -52,15 +52,35 @@ def load_sequence(seq_path, num_points, cano_idx):
     return Sequence(seq_path, num_points=num_points, cano_idx=cano_idx)[0]
 
 
-def synthetic_sequence(num_points, cano_idx, frames, with_flow):
+def synthetic_sequence(num_points, cano_idx, frames, with_flow, seed=2):
     from reart_amd.synthetic import make_sequence, split_canonical
 
-    seq = make_sequence(T=frames, n_parts=8, pts_per_part=num_points // 8, seed=2, with_flow=with_flow)
+    seq = make_sequence(T=frames, n_parts=8, pts_per_part=num_points // 8, seed=seed, with_flow=with_flow)
     cano, pc_list = split_canonical(seq["complete"], cano_idx)
     out = dict(cano_pc=cano, pc_list=pc_list, complete_pc_list=seq["complete"], gt_cano_part=seq["part"])
     if with_flow:
         out.update(ref_loc=seq["ref_loc"], ref_flow=seq["ref_flow"])
     return out
+
+
+def flow_references(args, sample, device, seq_path=None):
+    """The flow branch's reference sets (run_robot.py:64-84) -> (pc_ref_list, flow_ref_list), lists of [M_i,3] tensors:
+    the generator's own references for a synthetic sample, otherwise descriptors -> SMNN matches -> reference flows."""
+    if "ref_loc" in sample:  # synthetic references (true motion + noise)
+        return ([torch.from_numpy(r).to(device) for r in sample["ref_loc"]],
+                [torch.from_numpy(f).to(device) for f in sample["ref_flow"]])
+    from reart_amd.networks.feature_extractor import get_extractor
+    from reart_amd.utils.dataset_utils import load_normalize_dict
+    from reart_amd.utils.flow_utils import compute_corr_list_filter, normalize_pc_list
+
+    extractor = get_extractor(args)
+    info = load_normalize_dict(args.normalize_file)[os.path.basename(seq_path.rstrip("/"))]
+    centroid = torch.from_numpy(info["centroid"]).float().to(device)
+    complete = torch.from_numpy(sample["complete_pc_list"]).float().to(device)
+    norm = normalize_pc_list(complete, centroid, info["scale"].item())
+    src_list, tgt_list = compute_corr_list_filter(norm, extractor, None, matching="smnn")
+    return ([complete[i][s] for i, s in enumerate(src_list)],
+            [complete[i + 1][t] - complete[i][s] for i, (s, t) in enumerate(zip(src_list, tgt_list))])
 
 
 class OperatorLoop:
@@ -212,22 +232,7 @@ def main(args):
 
     pc_ref_list = flow_ref_list = None
     if args.use_flow_loss:
-        if "ref_loc" in sample:  # synthetic references (true motion + noise)
-            pc_ref_list = [torch.from_numpy(r).to(device) for r in sample["ref_loc"]]
-            flow_ref_list = [torch.from_numpy(f).to(device) for f in sample["ref_flow"]]
-        else:  # run_robot.py:64-84: descriptors -> SMNN matches -> reference flows
-            from reart_amd.networks.feature_extractor import get_extractor
-            from reart_amd.utils.flow_utils import compute_corr_list_filter, normalize_pc_list
-            from reart_amd.utils.dataset_utils import load_normalize_dict
-
-            extractor = get_extractor(args)
-            info = load_normalize_dict(args.normalize_file)[os.path.basename(args.seq_path.rstrip("/"))]
-            centroid = torch.from_numpy(info["centroid"]).float().to(device)
-            complete = torch.from_numpy(sample["complete_pc_list"]).float().to(device)
-            norm = normalize_pc_list(complete, centroid, info["scale"].item())
-            src_list, tgt_list = compute_corr_list_filter(norm, extractor, None, matching="smnn")
-            pc_ref_list = [complete[i][s] for i, s in enumerate(src_list)]
-            flow_ref_list = [complete[i + 1][t] - complete[i][s] for i, (s, t) in enumerate(zip(src_list, tgt_list))]
+        pc_ref_list, flow_ref_list = flow_references(args, sample, device, args.seq_path)
 
     tau_func = functools.partial(tau_cosine, max_iter=args.n_iter, end_temp=args.end_tau, start_temp=args.start_tau)
     fixed_tau = 0.0

@@ -100,7 +100,7 @@ def run_sweep(instances, run_instance, device):
 
 
 def run_sweep_engines(instances, make_engine, n_iter, device, per_gpu=3, chunk=100, energy=False, mode="streams",
-                      overlap_tails=True):
+                      overlap_tails=True, on_finish=None):
     """Sweep of fused-loop instances with ``per_gpu`` of them in flight per GPU.
 
     One instance of the relaxation loop is a chain of short, latency-bound launches that leaves
@@ -112,7 +112,10 @@ def run_sweep_engines(instances, make_engine, n_iter, device, per_gpu=3, chunk=1
     (``instance_energy``), which then decide the winner.  ``mode="batch"``: the instances of a group (same shape; up to
     ``RelaxBatch.MAX``) advance in SHARED launches (``reart_relax_step_batch``) instead of on one stream each -- the same
     results, and an aggregate rate that does not depend on how the runtime maps streams to hardware queues.
-    Returns (records [n, RECORD], best index) like ``run_sweep``."""
+    A group whose engines the shared launches cannot take (different shapes or switches, a loss branch the batched entry
+    does not implement) falls back to the streams path for that group; it never aborts the sweep.
+    ``on_finish(inst, spec, engine, energy dict or None)`` is called once per finished instance (the command line writes
+    the instance's result files there).  Returns (records [n, RECORD], best index) like ``run_sweep``."""
     if mode not in ("streams", "batch"):
         raise ValueError("mode is 'streams' or 'batch'")
     world = dist.get_world_size() if dist.is_initialized() else 1
@@ -141,11 +144,28 @@ def run_sweep_engines(instances, make_engine, n_iter, device, per_gpu=3, chunk=1
                 e[3].synchronize()                       # the engines were prepared on their own streams
             for b0 in range(0, len(live), RelaxBatch.MAX):
                 part = live[b0:b0 + RelaxBatch.MAX]
-                batch = RelaxBatch([e[2] for e in part])
-                used = batch.capture(steps_per_graph=min(chunk, n_iter - 1)) if n_iter > 1 else 0
-                batch.step(n_iter - used)
-                for e in part:
-                    e[4] = n_iter
+                try:
+                    batch = RelaxBatch([e[2] for e in part])     # refuses engines that do not share shape and switches
+                    # capture() runs its first step eagerly: an engine the batched entry does not implement
+                    # (REART_ERR_UNSUPPORTED) shows up there, before a capture is open, and the group takes the streams
+                    # path below instead
+                    used = batch.capture(steps_per_graph=min(chunk, n_iter - 1)) if n_iter > 1 else 0
+                    batch.step(n_iter - used)
+                    for e in part:
+                        e[4] = n_iter
+                except Exception as exc:
+                    started = {int(e[2].iter.item()) for e in part}
+                    if started != {0}:          # the shared launches already advanced somebody: not restartable here
+                        for e in part:
+                            local[e[0]] = _record(e[0], e[1], failed=1)
+                        live = [e for e in live if e not in part]
+                    else:
+                        import warnings
+
+                        warnings.warn(f"sweep: batch of {len(part)} instances falls back to streams ({type(exc).__name__}: {exc})")
+                        for e in part:
+                            with torch.cuda.stream(e[3]):
+                                e[4] = e[2].capture(steps_per_graph=min(chunk, n_iter))
             torch.cuda.current_stream(device).synchronize()
         while any(e[4] < n_iter for e in live):          # streams: round-robin graph replays (nothing left to do after a batch)
             for e in live:
@@ -165,6 +185,8 @@ def run_sweep_engines(instances, make_engine, n_iter, device, per_gpu=3, chunk=1
                         en = instance_energy(eng, spec)
                 except Exception:      # e.g. every part merged away: the losses still describe the instance
                     en = None
+            if on_finish is not None:
+                on_finish(inst, spec, eng, en)
             return inst, _record(inst, spec, (float(row[0]), float(row[1]), float(row[2])), done, 0, en)
 
         # The end of an instance is latency-bound (its assignment solves occupy T-1 of the 256 compute units) and full of
@@ -190,3 +212,249 @@ def run_sweep_engines(instances, make_engine, n_iter, device, per_gpu=3, chunk=1
         pool.shutdown()
     records = gather_records(local, len(instances), device)
     return records, best_instance(records)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Command line: BASELINE.json configs[3] -- "all robot categories x cano_idx sweep sharded across 8 MI355X".
+#
+#   python -m reart_amd.sweep --seq_root data/robot --cano all --n_iter 15000 --energy --gpus 8 --save_root exp/sweep
+#
+# The reference has no sweep driver: it is run once per (sequence, cano_idx) by hand (`main(args)`, run_robot.py:35-358) and
+# "the canonical frame index is selected by the lowest energy" (README.md:58-60) from the printed energies
+# (run_robot.py:306-321).  This is that procedure as one job: enumerate, shard round-robin over the ranks, optimise, gather
+# one 16-float record per instance, take the arg-min per sequence, keep the winner's result files.
+
+def list_sequences(seq_root, names=None):
+    """Sequence directories under ``seq_root`` in the reference's layout (``state_0.pkl`` + ``pose_i.pkl``,
+    dataset/dataset_robot.py:14-22) -> [(name, path, number of frames)], sorted by name."""
+    import glob
+
+    out = []
+    for d in sorted(os.listdir(seq_root)):
+        path = os.path.join(seq_root, d)
+        if names and d not in names:
+            continue
+        if os.path.isdir(path) and os.path.exists(os.path.join(path, "state_0.pkl")):
+            out.append((d, path, 1 + len(glob.glob(os.path.join(path, "pose_*.pkl")))))
+    if names:
+        missing = sorted(set(names) - {n for n, _, _ in out})
+        if missing:
+            raise FileNotFoundError(f"no sequence directory for {missing} under {seq_root}")
+    return out
+
+
+def enumerate_instances(sequences, cano="all"):
+    """[(name, path, T)] x canonical indices -> instance specs in a fixed order (sequence-major): every rank enumerates
+    the same list, so the round-robin shard needs no communication."""
+    out = []
+    for name, path, T in sequences:
+        idxs = range(T) if cano == "all" else [int(c) for c in str(cano).split(",")]
+        for c in idxs:
+            if not 0 <= c < T:
+                raise ValueError(f"cano_idx {c} outside the {T} frames of {name}")
+            out.append({"seq": name, "seq_path": path, "cano_idx": int(c), "frames": T})
+    return out
+
+
+def winners(instances, records):
+    """Per sequence: the instance with the lowest total energy (the final loss when no energies were computed) ->
+    {sequence name: index into ``instances``}; a sequence whose instances all failed maps to None."""
+    rec = torch.as_tensor(records).float().cpu()
+    out = {}
+    for name in dict.fromkeys(s["seq"] for s in instances):
+        ids = [i for i, s in enumerate(instances) if s["seq"] == name]
+        sub = rec[ids]
+        ok = ~torch.isnan(sub[:, E_TOTAL] if not torch.isnan(sub[:, E_TOTAL]).all() else sub[:, 4])
+        out[name] = ids[best_instance(sub)] if bool(ok.any()) else None
+    return out
+
+
+def build_cli():
+    import argparse
+
+    p = argparse.ArgumentParser(prog="python -m reart_amd.sweep", description="(sequence x cano_idx) sweep, one rank per GPU")
+    p.add_argument("--seq_root", default="data/robot", help="directory holding one sub-directory per sequence / category")
+    p.add_argument("--seqs", default="", help="comma-separated sub-directory names (default: all)")
+    p.add_argument("--cano", default="all", help="'all' or comma-separated canonical frame indices")
+    p.add_argument("--synthetic", type=int, default=0, metavar="K", help="K generated sequences instead of --seq_root")
+    p.add_argument("--synthetic_frames", type=int, default=20)
+    p.add_argument("--gpus", type=int, default=1, help="ranks to start when not already under torch.distributed.run")
+    p.add_argument("--per_gpu", type=int, default=3, help="instances in flight per GPU")
+    p.add_argument("--mode", choices=("streams", "batch"), default="streams")
+    p.add_argument("--energy", action="store_true", help="end every instance with structure extraction + energy (run_robot.py:224-321)")
+    p.add_argument("--save_root", default="exp/sweep")
+    p.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
+    # the per-instance flags of run_robot.py:362-420, same names and defaults
+    p.add_argument("--manual_seed", default=2, type=int)
+    p.add_argument("--num_points", default=4096, type=int)
+    p.add_argument("--num_parts", default=20, type=int)
+    p.add_argument("--n_iter", default=15000, type=int)
+    p.add_argument("--start_tau", default=5, type=float)
+    p.add_argument("--end_tau", default=1, type=float)
+    p.add_argument("--seg_lr", default=1e-3, type=float)
+    p.add_argument("--trans_lr", default=1e-2, type=float)
+    p.add_argument("--weight_decay", default=0, type=float)
+    p.add_argument("--use_flow_loss", action="store_true")
+    p.add_argument("--use_robust_loss", action="store_true")
+    p.add_argument("--lambda_flow", default=1, type=float)
+    p.add_argument("--corr_model_path", default="pretrained/corr_model.pth.tar")
+    p.add_argument("--normalize_file", default="data/category_normalize_scale.pkl", type=str)
+    return p
+
+
+def _engine_factory(args, device, samples):
+    """make_engine(spec) for run_sweep_engines: one BaseModel + RelaxEngine per instance, exactly what
+    ``run_robot.main`` builds for ``--model base`` (run_robot.py:91-98, 145-151)."""
+    from .networks.model import BaseModel
+    from .relax import RelaxEngine
+    from . import run_robot as rr
+
+    def make_engine(spec):
+        if spec.get("synthetic") is not None:
+            sample = rr.synthetic_sequence(args.num_points, spec["cano_idx"], spec["frames"], args.use_flow_loss,
+                                           seed=spec["synthetic"])
+        else:
+            sample = rr.load_sequence(spec["seq_path"], args.num_points, spec["cano_idx"])
+        cano = torch.from_numpy(sample["cano_pc"]).float().to(device)
+        pcs = torch.from_numpy(sample["pc_list"]).float().to(device)
+        refs = flows = None
+        if args.use_flow_loss:
+            refs, flows = rr.flow_references(args, sample, device, spec.get("seq_path"))
+        torch.manual_seed(args.manual_seed)                   # run_robot.py:36-41: every run seeds the seg-head init alike
+        model = BaseModel(num_parts=args.num_parts, pose_len=pcs.shape[0]).to(device)
+        samples[spec["id"]] = sample
+        return RelaxEngine(cano, pcs, model, spec["cano_idx"], refs, flows, n_iter=args.n_iter, start_tau=args.start_tau,
+                           end_tau=args.end_tau, trans_lr=args.trans_lr, seg_lr=args.seg_lr, lambda_flow=args.lambda_flow,
+                           use_robust_loss=args.use_robust_loss, seed=args.manual_seed, weight_decay=args.weight_decay)
+
+    return make_engine
+
+
+def instance_dir(save_root, spec):
+    return os.path.join(save_root, spec["seq"], f"cano_{spec['cano_idx']}")
+
+
+def save_instance(save_root, spec, result, sample=None, model=None, tau=None):
+    """result.pkl (+ model.pth.tar) of one instance with the reference's keys (run_robot.py:333-356)."""
+    import pickle
+
+    import numpy as np
+
+    d = instance_dir(save_root, spec)
+    os.makedirs(d, exist_ok=True)
+    to_np = lambda x: x.detach().cpu().numpy() if torch.is_tensor(x) else np.asarray(x)
+    out = {"pred_cano_part": to_np(result["seg_part"]), "pred_pose_list": to_np(result["trans_list"]),
+           "cano_idx": int(spec["cano_idx"]), "joint_connection": to_np(result["joint_connection"]).tolist()}
+    if sample is not None:
+        out.update(sample)
+    with open(os.path.join(d, "result.pkl"), "wb") as f:
+        pickle.dump(out, f)
+    if model is not None:
+        torch.save({"state_dict": model.state_dict(), "tau": tau, "cano_idx": int(spec["cano_idx"])},
+                   os.path.join(d, "model.pth.tar"))
+    return d
+
+
+def main(argv=None, runner=None):
+    """The sweep job.  ``runner(spec) -> dict`` replaces the GPU engine per instance (tests run the CPU oracle through it
+    under gloo); the product path (``runner is None``) needs a GPU per rank and raises without one."""
+    import json
+    import shutil
+    import sys
+
+    from . import launch
+
+    args = build_cli().parse_args(argv)
+    if args.gpus > 1 and not launch.under_launcher():
+        # N ranks of this module, started before anything here has touched the GPU
+        return launch.self_launch("reart_amd.sweep", list(sys.argv[1:] if argv is None else argv), args.gpus, module=True)
+    world = launch.check_world(args.gpus) if launch.under_launcher() else 1
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if runner is None:
+        if not torch.cuda.is_available():
+            raise SystemExit("reart_amd.sweep needs an MI355X per rank: the HIP path has no CPU fallback")
+        if local_rank >= torch.cuda.device_count():
+            raise SystemExit(f"rank {rank}: no GPU {local_rank} on this node ({torch.cuda.device_count()} visible)")
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+    else:
+        device = torch.device("cpu")
+    if launch.under_launcher() and not dist.is_initialized():
+        backend = args.backend or ("nccl" if device.type == "cuda" else "gloo")
+        kw = {"device_id": device} if backend == "nccl" else {}
+        dist.init_process_group(backend=backend, **kw)
+
+    if args.synthetic:
+        sequences = [(f"synthetic_{k}", None, args.synthetic_frames) for k in range(args.synthetic)]
+    else:
+        names = [s for s in args.seqs.split(",") if s]
+        sequences = list_sequences(args.seq_root, names or None)
+    if not sequences:
+        raise SystemExit(f"no sequences under {args.seq_root}")
+    instances = enumerate_instances(sequences, args.cano)
+    for i, s in enumerate(instances):
+        s["id"] = i
+        if args.synthetic:
+            s["synthetic"] = 2 + int(s["seq"].split("_")[1])
+    os.makedirs(args.save_root, exist_ok=True)
+
+    if runner is not None:
+        def run_and_save(spec):
+            res = runner(spec)
+            if "seg_part" in res:
+                save_instance(args.save_root, spec, res)
+            return res
+
+        records, _ = run_sweep(instances, run_and_save, device)
+    else:
+        samples = {}
+        make_engine = _engine_factory(args, device, samples)
+
+        def on_finish(inst, spec, eng, en):
+            if en is not None:
+                save_instance(args.save_root, spec, en, samples.get(inst), eng.model, float(eng.tau.item()))
+            samples.pop(inst, None)
+
+        records, _ = run_sweep_engines(instances, make_engine, args.n_iter, device, per_gpu=args.per_gpu,
+                                       chunk=min(100, args.n_iter), energy=args.energy, mode=args.mode, on_finish=on_finish)
+    records = records.cpu()
+    win = winners(instances, records)
+    if dist.is_initialized():
+        dist.barrier()                      # every rank's result files are on disk before rank 0 copies the winners
+    if rank == 0:
+        fields = ["instance", "cano_idx", "recon_loss", "flow_loss", "total_loss", "iterations", "failed", "parts",
+                  "total_err", "ass_err", "screw_err", "group_err", "cd_err"]
+        table = {}
+        for name in win:
+            rows = []
+            for i, s in enumerate(instances):
+                if s["seq"] != name:
+                    continue
+                row = {k: (None if bool(torch.isnan(records[i, j])) else float(records[i, j])) for j, k in enumerate(fields)}
+                row["rank"] = i % world
+                rows.append(row)
+            w = win[name]
+            table[name] = {"winner_cano_idx": None if w is None else instances[w]["cano_idx"],
+                           "winner_instance": w, "selected_by": "total_err" if args.energy or runner is not None else "total_loss",
+                           "instances": rows}
+            if w is not None:
+                src = os.path.join(instance_dir(args.save_root, instances[w]), "result.pkl")
+                if os.path.exists(src):     # the winner's files, where a single run of the reference would have put them
+                    shutil.copyfile(src, os.path.join(args.save_root, name, "result.pkl"))
+                    mp = os.path.join(instance_dir(args.save_root, instances[w]), "model.pth.tar")
+                    if os.path.exists(mp):
+                        shutil.copyfile(mp, os.path.join(args.save_root, name, "model.pth.tar"))
+        with open(os.path.join(args.save_root, "sweep.json"), "w") as f:
+            json.dump({"world_size": world, "n_instances": len(instances), "n_iter": args.n_iter, "energy": bool(args.energy),
+                       "sequences": table}, f, indent=1)
+        print(json.dumps({"sweep": os.path.join(args.save_root, "sweep.json"), "n_gpus": world, "instances": len(instances),
+                          "winners": {k: v["winner_cano_idx"] for k, v in table.items()}}))
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

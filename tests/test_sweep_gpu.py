@@ -75,3 +75,48 @@ def test_sweep_records_carry_the_reference_energy(dev):
     c2, p2 = eng.caller_clouds()
     np.testing.assert_array_equal(c2.cpu().numpy(), cano)
     np.testing.assert_array_equal(p2.cpu().numpy(), pcs)
+
+
+def test_sweep_command_line_one_rank(dev, tmp_path):
+    """python -m reart_amd.sweep on a sequence directory in the reference's layout (tests/golden/seq_tiny, 4 frames): every
+    cano_idx is optimised by the fused engine, ends with the reference's energy, and the lowest total energy wins
+    (README.md:58-60); result files carry the reference's keys (run_robot.py:333-356)."""
+    import json
+    import os
+    import pickle
+
+    from reart_amd import sweep
+
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    rc = sweep.main(["--seq_root", root, "--seqs", "seq_tiny", "--cano", "all", "--n_iter", "300", "--energy", "--num_points", "80",
+                     "--num_parts", "6", "--per_gpu", "2", "--save_root", str(tmp_path)])
+    assert rc == 0
+    sw = json.load(open(tmp_path / "sweep.json"))
+    seq = sw["sequences"]["seq_tiny"]
+    rows = seq["instances"]
+    assert sw["world_size"] == 1 and [r["cano_idx"] for r in rows] == [0, 1, 2, 3]
+    assert all(r["iterations"] == 300 and r["failed"] == 0 and np.isfinite(r["total_loss"]) for r in rows)
+    en = [r["total_err"] for r in rows]
+    assert all(e is not None for e in en), en
+    w = int(np.argmin(en))
+    assert seq["winner_cano_idx"] == w and seq["selected_by"] == "total_err"
+    for r in rows:
+        assert abs(r["total_err"] - (r["ass_err"] + r["screw_err"] + r["group_err"])) <= 1e-5 * abs(r["total_err"])
+    res = pickle.load(open(tmp_path / "seq_tiny" / "result.pkl", "rb"))
+    assert res["cano_idx"] == w and res["pred_cano_part"].shape == (80,) and res["pred_pose_list"].shape[0] == 3
+    assert set(res) >= {"pred_cano_part", "pred_pose_list", "cano_idx", "joint_connection", "cano_pc", "pc_list"}
+    ck = torch.load(tmp_path / "seq_tiny" / "model.pth.tar", weights_only=False)
+    assert set(ck) >= {"state_dict", "tau", "cano_idx"} and ck["cano_idx"] == w
+    # a solo run of the winner ends with the same energy the sweep recorded
+    from reart_amd.networks.model import BaseModel
+    from reart_amd.relax import RelaxEngine
+    from reart_amd import run_robot as rr
+
+    sample = rr.load_sequence(os.path.join(root, "seq_tiny"), 80, w)
+    torch.manual_seed(2)
+    model = BaseModel(num_parts=6, pose_len=3).to(dev)
+    eng = RelaxEngine(torch.from_numpy(sample["cano_pc"]).float().to(dev), torch.from_numpy(sample["pc_list"]).float().to(dev),
+                      model, w, n_iter=300, seed=2)
+    eng.step(300)
+    solo = sweep.instance_energy(eng, {"cano_idx": w})
+    assert abs(solo["total_err"] - rows[w]["total_err"]) <= 1e-6 * abs(solo["total_err"])
