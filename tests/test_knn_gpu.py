@@ -160,3 +160,41 @@ def test_knn_backward_degenerate_buckets(oracle, dev):
                                        torch.from_numpy(i).to(dev), torch.from_numpy(g).to(dev))
         np.testing.assert_array_equal(g1.cpu().numpy(), g1_ref)
         np.testing.assert_array_equal(g2.cpu().numpy(), g2_ref)
+
+
+def test_knn_per_point_against_the_reference_kdtree(dev):
+    """HIP brute force and the fused loop's pruned warm-started search against the per-point results of the REFERENCE's
+    KD-tree Chamfer (utils/eval_utils.py:39-66; tests/golden/chamfer_kdtree.npz) -- no oracle in between."""
+    from test_oracle_golden_cpu import kdtree_check, load
+    from reart_amd.utils.chamfer import knn_points
+
+    g, c = load("chamfer_kdtree"), load("chamfer")
+
+    def knn(p1, p2):
+        out = knn_points(torch.from_numpy(np.ascontiguousarray(p1)).to(dev), torch.from_numpy(np.ascontiguousarray(p2)).to(dev), K=1)
+        return out.dists[..., 0].cpu().numpy(), out.idx[..., 0].cpu().numpy()
+
+    ties = (kdtree_check(knn, g, "ab", c["a"], c["b"]) + kdtree_check(knn, g, "st", c["src"], c["tgt"])
+            + kdtree_check(knn, g, "nao", g["nao_x"], g["nao_y"]))
+    assert ties <= 8
+
+    # the pruned search of the fused step (k-d leaf order, boxes, seeds from a previous call)
+    from reart_amd.chamferdist_C import knn_points_idx_warm
+    from reart_amd.relax import kd_order
+
+    def knn_w(p1, p2):
+        """queries and targets stored in k-d leaf order like the engine stores them; results mapped back"""
+        d_out, i_out = np.empty(p1.shape[:2], np.float32), np.empty(p1.shape[:2], np.int64)
+        for b in range(p1.shape[0]):
+            o1 = kd_order(torch.from_numpy(np.ascontiguousarray(p1[b]))).numpy()
+            o2 = kd_order(torch.from_numpy(np.ascontiguousarray(p2[b]))).numpy()
+            ta = torch.from_numpy(np.ascontiguousarray(p1[b][o1][None])).to(dev)
+            tb = torch.from_numpy(np.ascontiguousarray(p2[b][o2][None])).to(dev)
+            seeds = None
+            for _ in range(2):      # cold, then warm from its own result
+                idx, dists, seeds = knn_points_idx_warm(ta, tb, 1, seeds)
+            d_out[b, o1] = dists[0, :, 0].cpu().numpy()
+            i_out[b, o1] = o2[idx[0, :, 0].cpu().numpy()]
+        return d_out, i_out
+
+    kdtree_check(knn_w, g, "nao", g["nao_x"], g["nao_y"])

@@ -31,6 +31,46 @@ def test_chamfer_golden(oracle):
     np.testing.assert_allclose(gx1 + gx2, g["grad_src"], rtol=0, atol=1e-6)
 
 
+KD_TIE_REL = 1e-6      # a best / second-best gap below this (relative, float64) is a near-tie fp32 may resolve either way
+
+
+def kdtree_check(knn_points, g, tag, x, y):
+    """knn_points(p1, p2) -> (squared fp32 distances [B,P1], indices [B,P1]) against what the REFERENCE's KD-tree
+    (utils/eval_utils.py:39-66, float64, recorded per point by tests/golden/make_golden_kdtree.py) found, both directions.
+    Indices must agree wherever the float64 gap to the second-best target exceeds fp32 rounding; distances to 1e-6
+    relative everywhere.  Returns the number of near-ties (reported by the callers)."""
+    ties = 0
+    for p1, p2, sfx in ((x, y, "12"), (y, x, "21")):
+        d, i = knn_points(p1, p2)
+        kd_d, kd_i = g[f"{tag}_d{sfx}"], g[f"{tag}_i{sfx}"]
+        best, second = g[f"{tag}_best{sfx}"], g[f"{tag}_second{sfx}"]
+        np.testing.assert_allclose(kd_d ** 2, best, rtol=1e-12, atol=1e-30)     # the tree is exact: its distance IS the minimum
+        clear = (second - best) > KD_TIE_REL * np.maximum(second, 1e-30)
+        ties += int((~clear).sum())
+        np.testing.assert_array_equal(np.asarray(i)[clear], kd_i[clear])
+        # near-ties: whichever index was taken, it is one of the (near-)minimal targets
+        np.testing.assert_allclose(np.asarray(d, np.float64), kd_d ** 2, rtol=1e-6, atol=1e-12)
+    return ties
+
+
+def test_knn_per_point_against_the_reference_kdtree(oracle):
+    """The non-circular pin of a2: the chamferdist extension is not vendored in the reference, but its KD-tree Chamfer is
+    an independent nearest-neighbour search over the same clouds (VERDICT r02 weak #1)."""
+    g = load("chamfer_kdtree")
+    c = load("chamfer")
+    knn = lambda p1, p2: tuple(a[..., 0] for a in oracle.knn_points(p1, p2, K=1))
+    t_ab = kdtree_check(knn, g, "ab", c["a"], c["b"])
+    t_st = kdtree_check(knn, g, "st", c["src"], c["tgt"])
+    t_nao = kdtree_check(knn, g, "nao", g["nao_x"], g["nao_y"])
+    print(f"near-ties (gap < {KD_TIE_REL} relative): uniform 512: {t_ab}, nao 512: {t_st}, nao 4096: {t_nao}")
+    assert t_ab + t_st + t_nao <= 8          # the pin covers all but a handful of the 21 504 queries
+    # and the sums the reference's function returned
+    for tag, x, y in (("ab", c["a"], c["b"]), ("st", c["src"], c["tgt"]), ("nao", g["nao_x"], g["nao_y"])):
+        d1, _, d2, _ = oracle.chamfer_bidir(x, y)
+        tot = d1.astype(np.float64).sum(1) + d2.astype(np.float64).sum(1)
+        np.testing.assert_allclose(tot, g[f"{tag}_total"], rtol=1e-6)
+
+
 def test_flow_golden(oracle):
     g = load("flow")
     for robust in (0, 1):
