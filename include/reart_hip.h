@@ -134,6 +134,13 @@ int reart_base_forward(const float *cano, int N, int P, int B,
                        float *out, int64_t *seg_part, float *trans_list,
                        float *yT, float *hT, int32_t *hard_idx, void *stream);
 
+/* The noise F.gumbel_softmax(logits, tau, hard=True) adds (networks/model.py:44: -log(Exp(1)) samples from torch's
+ * generator) as the fused step draws it IN the forward kernel when reart_relax_buffers.gumbel is NULL: a Philox4x32-10
+ * stream keyed by `seed`, counter (point, part / 4, iteration).  out [N,P] = exactly the samples iteration `iter` of an
+ * engine with that seed uses, so the production path can be checked (distribution, independence) and replayed
+ * (inject `out` as `gumbel`: same bits).  */
+int reart_gumbel_noise(uint64_t seed, int64_t iter, int N, int P, float *out, void *stream);
+
 /* Backward of the above (the reference relies on autograd): G = dL/d out [B,N,3] ->
  * gradients of W1, b1, W2, proposal_6d [B,P,6], proposal_t [B,P,3].  Deterministic
  * (fixed-order chunked reductions, no atomics). */

@@ -33,6 +33,7 @@ PROTOTYPES = {
     "reart_flow_loss_workspace_bytes": (c_size_t, []),
     "reart_flow_loss": (c_int, [P, P, P, c_int, c_int, c_int, c_float, P, P, P, c_size_t, P]),
     "reart_base_forward": (c_int, [P, c_int, c_int, c_int, P, P, P, c_int, P, P, P, c_float, P, P, P, P, P, P, P]),
+    "reart_gumbel_noise": (c_int, [ctypes.c_uint64, ctypes.c_int64, c_int, c_int, P, P]),
     "reart_base_backward_workspace_bytes": (c_size_t, [c_int] * 4),
     "reart_base_backward": (c_int, [P, c_int, c_int, c_int, P, P, P, c_int, P, P, P, P, P, c_float, P,
                                     P, P, P, P, P, P, c_size_t, P]),

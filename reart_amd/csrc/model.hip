@@ -437,6 +437,31 @@ extern "C" int reart_base_forward(const float *cano, int N, int P, int B, const 
     return dispatch_base_fwd(&a, 1, (hipStream_t)stream);
 }
 
+// The production noise stream, exported: out[n][p] = the Gumbel sample the forward kernel draws for (point n, part p) in
+// iteration `iter` of an engine seeded with `seed` -- the same philox4x32 call (counter = n, p / 4, iter; key = seed; word
+// p % 4) and the same gumbel_from_bits, so injecting `out` into the forward reproduces the in-kernel path bit for bit.
+__global__ __launch_bounds__(256) void gumbel_noise_kernel(uint64_t seed, uint64_t it, int N, int P, float *__restrict__ out) {
+    const int Q = (P + 3) >> 2;
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (size_t)N * Q) return;
+    const int n = (int)(e / Q), q = (int)(e % Q);
+    uint32_t r[4];
+    philox4x32((uint32_t)n, (uint32_t)q, (uint32_t)it, (uint32_t)(it >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), r);
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+        if (4 * q + w < P) out[(size_t)n * P + 4 * q + w] = gumbel_from_bits(r[w]);
+}
+
+extern "C" int reart_gumbel_noise(uint64_t seed, int64_t iter, int N, int P, float *out, void *stream) {
+    if (N < 0 || P < 1 || iter < 0) return REART_ERR_INVALID_ARG;
+    if (N == 0) return REART_OK;
+    if (!out) return REART_ERR_INVALID_ARG;
+    const size_t total = (size_t)N * ((P + 3) >> 2);
+    gumbel_noise_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(seed, (uint64_t)iter, N, P, out);
+    REART_CHECK_LAUNCH();
+    return REART_OK;
+}
+
 // entry used by the fused step (step.hip)
 int reart_base_forward_ex(const BaseFwdArgs &a, hipStream_t st) { return dispatch_base_fwd(&a, 1, st); }
 int reart_base_forward_batch(const BaseFwdArgs *a, int K, hipStream_t st) { return dispatch_base_fwd(a, K, st); }

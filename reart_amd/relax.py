@@ -122,6 +122,17 @@ def _lib_fns():
     return _L
 
 
+def gumbel_noise(seed, iteration, N, P, device):
+    """[N,P] Gumbel samples exactly as the fused step draws them in its forward kernel for iteration ``iteration`` of an
+    engine seeded with ``seed`` (``reart_gumbel_noise``; the stand-in for the draw inside F.gumbel_softmax,
+    networks/model.py:44).  Row n belongs to the engine's n-th STORED point (k-d leaf order when ``spatial_sort``)."""
+    out = torch.empty((N, P), dtype=torch.float32, device=device)
+    with torch.cuda.device(device):
+        rc = _lib.lib().reart_gumbel_noise(int(seed), int(iteration), N, P, _lib.ptr(out), _lib.stream())
+    _lib.check(rc, "reart_gumbel_noise")
+    return out
+
+
 class RelaxEngine:
     """State of one optimisation instance on one GPU.
 

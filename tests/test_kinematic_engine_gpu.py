@@ -65,3 +65,57 @@ def test_engine_equals_the_autograd_loop(dev, with_flow, gap, wd):
             np.testing.assert_allclose(getattr(m_eng, name).detach().cpu().numpy(), getattr(m_ref, name).detach().cpu().numpy(),
                                        rtol=0, atol=2e-6, err_msg=f"iteration {i} {name}")
     assert eng.lap_solves == loop.lap_solves
+
+
+def test_config5_literal_against_the_oracle_loop(oracle, dev):
+    """BASELINE.json configs[4] as README.md:125 runs it -- `--model kinematic --use_flow_loss --use_assign_loss
+    --assign_iter 0 --downsample 2 --assign_gap 1` on the reference's demo sequence (nao, 9 x 4096 points) from its shipped
+    kinematic-2 checkpoint -- three iterations of KinematicEngine against the ORACLE-side loop (oracle/kinematic_step.py:
+    torch-CPU fk with autograd pinned to the reference's golden, oracle FPS / cdist / blend / flow loss, scipy's
+    linear_sum_assignment as the reference calls it, oracle Adam).  Nothing of the product is on the checker's side."""
+    import os as _os
+
+    from oracle.kinematic_step import KinematicOracle
+    from reart_amd import run_robot as rr
+    from reart_amd.kinematic_engine import KinematicEngine
+
+    k, s = np.load(os.path.join(G, "kinematic.npz")), np.load(os.path.join(G, "structure.npz"))
+    np.testing.assert_array_equal(k["cano_pc"], s["cano"])            # the checkpoint's cloud IS the sequence's frame 2
+    B, N = s["pc_list"].shape[:2]
+    rng = np.random.default_rng(0)
+    # flow references: 3000 ground-truth correspondences per frame pair (the SMNN matches need the unshipped extractor weights)
+    sel = [rng.permutation(N)[:3000] for _ in range(B)]
+    refs = [s["complete_gt_pc_list"][f][x] for f, x in enumerate(sel)]
+    flows = [s["gt_flow_list"][f][x] for f, x in enumerate(sel)]
+    orc = KinematicOracle(k["cano_pc"], s["pc_list"], k["seg_part"], k["parent"], k["edge_of_part"], k["order"], k["axis"],
+                          k["moment"], k["theta"], 2, refs, flows, downsample=2, assign_gap=1,
+                          nproc=min(B, _os.cpu_count() or 1))
+    cano, pcs = t(k["cano_pc"], dev), t(s["pc_list"], dev)
+    a = rr.build_parser().parse_args(["--model", "kinematic", "--use_flow_loss", "--use_assign_loss", "--assign_iter", "0",
+                                      "--downsample", "2", "--assign_gap", "1", "--cano_idx", "2"])
+    model = _model(dev, k, cano)
+    eng = rr.make_projection_loop(a, model, cano, pcs, [t(r, dev) for r in refs], [t(f, dev) for f in flows])
+    assert isinstance(eng, KinematicEngine)
+    np.testing.assert_array_equal(eng.src_idx.cpu().numpy().ravel(), orc.src_idx.numpy())
+    np.testing.assert_array_equal(eng.tgt_pts.cpu().numpy(), orc.tgt_pts.numpy())
+    names = ("axis_list", "moment_list", "theta_list")
+    solid = [np.ones(p.shape, bool) for p in orc.params]
+    for i in range(3):
+        lo, pc_o = orc.iteration(i)
+        le = eng.iteration(i)
+        np.testing.assert_allclose(eng.pc_trans.cpu().numpy(), pc_o, rtol=0, atol=2e-6, err_msg=f"iteration {i} forward")
+        # the optimal assignment of every frame: the same permutation scipy returns on the oracle's cost matrices
+        np.testing.assert_array_equal(eng.matched.cpu().numpy(), orc.matched.numpy(), err_msg=f"iteration {i} assignment")
+        for key in lo:
+            assert abs(float(le[key]) - lo[key]) <= 1e-4 * abs(lo[key]), (i, key, float(le[key]), lo[key])
+        for j, name in enumerate(names):
+            g_o = orc.grads[j]
+            g_e = eng.grads[id(getattr(model, name))].cpu().numpy()
+            np.testing.assert_allclose(g_e, g_o, rtol=0, atol=1e-4 * np.abs(g_o).max(), err_msg=f"iteration {i} d/d{name}")
+            # Adam's first steps move a parameter by lr * g / (|g| + eps): an entry whose gradient is rounding noise may go
+            # either way, so the parameters are compared where the gradient is well above the noise in every iteration
+            solid[j] &= np.abs(g_o) > 1e-2 * np.abs(g_o).max()
+            p_e, p_o = getattr(model, name).detach().cpu().numpy(), orc.params[j].detach().numpy()
+            np.testing.assert_allclose(p_e[solid[j]], p_o[solid[j]], rtol=0, atol=2e-5, err_msg=f"iteration {i} {name}")
+    assert sum(int(m.sum()) for m in solid) >= 0.3 * sum(m.size for m in solid)
+    assert eng.lap_solves == orc.lap_solves == 3

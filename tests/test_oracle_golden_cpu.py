@@ -124,6 +124,31 @@ def test_known_answers(oracle):
     assert abs(float(g["cd_kin_x100"]) - 0.013050) < 5e-7
 
 
+def test_kinematic_oracle_golden(oracle):
+    """oracle/kinematic_step.py (torch restatement of the screw / SE(3) / fk chain with autograd) against the reference's
+    KinematicModel on its shipped kinematic-2 checkpoint: forward transforms, moved points, and the reference's autograd
+    gradients of sum(out * G)."""
+    import torch
+
+    from oracle import kinematic_step as ks
+
+    k = load("kinematic")
+    axis, moment, theta = (torch.tensor(k[n], requires_grad=True) for n in ("axis", "moment", "theta"))
+    trans = ks.fk(k["parent"], k["edge_of_part"], k["order"], axis, moment, theta)
+    np.testing.assert_allclose(trans.detach().numpy(), k["trans"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(trans.detach().numpy(), oracle.fk(k["parent"], k["edge_of_part"], k["order"], k["axis"], k["moment"],
+                                                                 k["theta"]), rtol=0, atol=1e-6)
+    out = ks.apply_parts(torch.from_numpy(k["input_pc"]), trans, torch.from_numpy(k["seg"]))
+    np.testing.assert_allclose(out.detach().numpy(), k["out"], rtol=0, atol=1e-6)
+    (out * torch.from_numpy(k["G"])).sum().backward()
+    for got, name in ((axis.grad, "g_axis"), (moment.grad, "g_moment"), (theta.grad, "g_theta")):
+        np.testing.assert_allclose(got.numpy(), k[name], rtol=0, atol=2e-5 * np.abs(k[name]).max(), err_msg=name)
+    # theta edge cases of SURVEY A8: below the squared-norm clamp, the 1e-6 placeholder (NOT the no-rotation branch), pi
+    g = load("se3")
+    T = ks.screw_to_transform(*(torch.from_numpy(g[n]) for n in ("l", "m", "theta", "d")))
+    np.testing.assert_allclose(T.numpy(), g["T"], rtol=0, atol=2e-6)
+
+
 def test_adam_matches_torch(oracle):
     import torch
 
