@@ -500,7 +500,9 @@ int reart_cdist(const float *a, const float *b, int B, int n, int m, float *out,
  * directions and the mutual filter, without the [N1,N2] distance matrix.
  *   desc1 [E,N1,64], desc2 [E,N2,64] (point-major rows);  keep [E,N1] u8 = 1 where point i of desc1
  *   has a mutual match; tgt [E,N1] i64 = its nearest descriptor in desc2 (valid where keep).
- *   The matches of pair e, sorted by source index, are {(i, tgt[e,i]) : keep[e,i]}. */
+ *   The matches of pair e, sorted by source index, are {(i, tgt[e,i]) : keep[e,i]}.
+ *   th < 0 skips the ratio test: plain mutual nearest neighbours = the reference's matching="mnn" branch
+ *   (k = 1 KNN in both directions + find_mutual_correspondences, utils/flow_utils.py:102-113, 126-137). */
 size_t reart_match_smnn_workspace_bytes(int E, int N1, int N2);
 int reart_match_smnn(const float *desc1, const float *desc2, int E, int N1, int N2, int D, float th,
                      uint8_t *keep, int64_t *tgt, void *workspace, size_t workspace_bytes, void *stream);

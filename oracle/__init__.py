@@ -13,7 +13,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
+# REART_ORACLE_LIB: another build of the same sources (the sanitizer build, `make -C oracle asan`)
+LIB_PATH = os.environ.get("REART_ORACLE_LIB") or os.path.join(_HERE, "_build", "liboracle.so")
 
 _lib = None
 

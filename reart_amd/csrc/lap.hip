@@ -334,6 +334,11 @@ __global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
     int *pbobj = bidder + n;                                        // [n] row's bid column
     int *ulist = pbobj + n;                                         // [n] unassigned rows
     __shared__ int s_cnt, s_flag, s_next, s_abort;
+    // Loops with ONE barrier per step publish the race's abort decision through a slot per step parity: thread 0 writes slot
+    // (step & 1) before the barrier, every wave reads that slot after it, and the slot is not written again before the barrier
+    // of step + 1 -- which no wave passes without having read.  (A single word rewritten by thread 0 for the next step could be
+    // seen early by a slow wave, which would then leave one barrier before its siblings.)
+    __shared__ int s_abp[2];
     __shared__ double s_red[NW], s_red2[NW], s_pv1[NW], s_pv2[NW];
     __shared__ int s_pj1[NW];
     const float *C = a.cost + (size_t)b * n * n;
@@ -341,7 +346,7 @@ __global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
     // a race is over for this workgroup once another racer has published the matrix (device-scope atomic load: the flag lives in L2)
     auto lost = [&]() -> int { return a.done ? __hip_atomic_load(a.done + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0; };
     const bool race = a.done != nullptr && gridDim.y > 1;
-    if (tid == 0) s_abort = 0;
+    if (tid == 0) { s_abort = 0; s_abp[0] = 0; s_abp[1] = 0; }
 
     // largest cost
     double mx = (double)lap_matrix_max<LAP_BS>(C, (size_t)n * n, tid);
@@ -434,9 +439,9 @@ __global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
             lap_wave_argmin_fast(bv, bj);
             const int par = it & 1;
             if (lane == 0) { s_rv[par][wv] = bv; s_rj[par][wv] = bj; }
-            if (race && tid == 0 && (it & 63) == 0) s_abort = lost();
+            if (race && tid == 0) s_abp[par] = ((it & 63) == 0) ? lost() : s_abp[par ^ 1];
             __syncthreads();
-            if (s_abort) return LAP_SEARCH_ABORTED;
+            if (race && s_abp[par]) return LAP_SEARCH_ABORTED;
             // the waves' minima meet in the first NW <= 16 lanes of every wave: four butterfly steps, then a broadcast
             bv = lane < NW ? s_rv[par][lane] : INFINITY; bj = lane < NW ? s_rj[par][lane] : 0x7fffffff;
             lap_lanes_argmin<(NW <= 2 ? 1 : (NW <= 4 ? 2 : (NW <= 8 ? 3 : 4)))>(bv, bj);
@@ -601,9 +606,9 @@ __global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
                             lap_wave_top2_fast(v1, j1, v2, i0);
                             if (lane == 0) { s_cv1[par][wv] = v1; s_cv2[par][wv] = v2; s_cj1[par][wv] = j1; s_ci0[par][wv] = i0; }
                         }
-                        if (race && tid == 0 && (st_bids & 31) == 0) s_abort = lost();
+                        if (race && tid == 0) s_abp[par] = ((st_bids & 31) == 0) ? lost() : s_abp[par ^ 1];
                         __syncthreads();
-                        if (s_abort) return;
+                        if (race && s_abp[par]) return;
                         v1 = lane < LAP_CW ? s_cv1[par][lane] : INFINITY; v2 = lane < LAP_CW ? s_cv2[par][lane] : INFINITY;
                         j1 = lane < LAP_CW ? s_cj1[par][lane] : 0x7fffffff; i0 = lane < LAP_CW ? s_ci0[par][lane] : -1;
                         static_assert(LAP_CW == 8 || LAP_CW == 16, "8 (measured best) or all 16 waves compute");

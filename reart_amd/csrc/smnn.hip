@@ -58,7 +58,8 @@ __global__ __launch_bounds__(256) void smnn_kernel(const float *__restrict__ dA,
     const size_t b = (size_t)e * NB + j;
     const float ra = sqrtf(dA[2 * a]) / sqrtf(dA[2 * a + 1]);   // vals[:,0] / vals[:,1] of Euclidean distances
     const float rb = sqrtf(dB[2 * b]) / sqrtf(dB[2 * b + 1]);
-    const bool ok = (ra <= th) && (rb <= th) && (iB[b] == i);
+    // th < 0: no ratio test -- plain mutual nearest neighbours (matching="mnn", flow_utils.py:102-113, 126-137)
+    const bool ok = (th < 0.f || ((ra <= th) && (rb <= th))) && (iB[b] == i);
     keep[a] = ok ? 1 : 0;
     tgt[a] = j;
 }
@@ -72,7 +73,8 @@ extern "C" size_t reart_match_smnn_workspace_bytes(int E, int NA, int NB) {
 extern "C" int reart_match_smnn(const float *desc1, const float *desc2, int E, int N1, int N2, int D, float th,
                                 uint8_t *keep, int64_t *tgt, void *workspace, size_t workspace_bytes,
                                 void *stream) {
-    if (E < 0 || N1 < 2 || N2 < 2) return REART_ERR_INVALID_ARG;   // the reference raises below 2 descriptors
+    if (E < 0 || N1 < 1 || N2 < 1) return REART_ERR_INVALID_ARG;
+    if (th >= 0.f && (N1 < 2 || N2 < 2)) return REART_ERR_INVALID_ARG;   // the ratio test needs a second neighbour (the reference raises)
     if (D != SM_D) return REART_ERR_UNSUPPORTED;
     if (E == 0) return REART_OK;
     if (!desc1 || !desc2 || !keep || !tgt || !workspace) return REART_ERR_INVALID_ARG;

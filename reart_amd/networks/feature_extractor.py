@@ -18,15 +18,18 @@ from .pointnet2_utils import farthest_point_sample, index_points, query_ball_poi
 def _fold(conv, bn):
     """eval-mode BN folded into the 1x1 conv -> (Wt [Cin, Cout] contiguous, bias [Cout]).  The folded pair is kept on the
     conv module until one of the six tensors it was made from changes (in-place updates and ``load_state_dict`` bump
-    ``_version``; a re-assigned tensor has another ``data_ptr``): nine tiny launches per layer and forward otherwise,
-    a sixth of the extractor's device time."""
+    ``_version``; a re-assigned tensor is another object): nine tiny launches per layer and forward otherwise,
+    a sixth of the extractor's device time.  The entry holds references to its source tensors, so an address cannot be
+    recycled under it.  NOT seen: writes through ``.data`` (``p.data.copy_()``, ``p.data.mul_()`` -- they bypass the
+    version counter); after such an update call ``PointNet2Msg2.invalidate_fold()`` (``.train()``, ``.to()`` / ``.cuda()``
+    / ``.float()`` and ``load_state_dict`` on the extractor do it themselves)."""
     src = (conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var)
-    key = tuple((t.data_ptr(), t._version) if t is not None else None for t in src) + (bn.eps,)
+    key = tuple((id(t), t.data_ptr(), t._version) if t is not None else None for t in src) + (bn.eps,)
     hit = getattr(conv, "_reart_folded", None)
     if hit is not None and hit[0] == key:
         return hit[1], hit[2]
     Wt, bf = _fold_now(conv, bn)
-    conv._reart_folded = (key, Wt, bf)
+    conv._reart_folded = (key, Wt, bf, src)          # src: keeps the keyed tensors (and their addresses) alive
     return Wt, bf
 
 
@@ -195,6 +198,25 @@ class PointNet2Msg2(nn.Module):
         self.fp1 = _FP(134, [128, 128])
         self.conv1 = nn.Conv1d(128, out_dim, 1)
         self.bn1 = nn.BatchNorm1d(out_dim)
+
+    def invalidate_fold(self):
+        """Drop every cached BatchNorm fold (see ``_fold``): needed by hand only after writes through ``.data``."""
+        for m in self.modules():
+            if hasattr(m, "_reart_folded"):
+                del m._reart_folded
+        return self
+
+    def train(self, mode=True):
+        self.invalidate_fold()
+        return super().train(mode)
+
+    def _apply(self, fn, *args, **kwargs):         # .to() / .cuda() / .float() / .half()
+        self.invalidate_fold()
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self.invalidate_fold()
+        return super().load_state_dict(*args, **kwargs)
 
     @torch.no_grad()
     def forward(self, xyz, fps_start=None, cuda_mode=None):

@@ -25,6 +25,14 @@ def blend_anchor_motion(query_loc, reference_loc, reference_flow, knn, return_ma
     return (flow, mask) if return_mask else flow
 
 
+@torch.no_grad()
+def find_mutual_correspondences(nns01, nns10):
+    """utils/flow_utils.py:102-113: the pairs (i, nns01[i]) whose target points back at i."""
+    idx0 = torch.arange(len(nns01), device=nns10.device)
+    keep = nns10[nns01] == idx0
+    return idx0[keep], nns01[keep]
+
+
 def normalize_pc_list(pc_list, centroid, scale):
     """utils/flow_utils.py:173-175."""
     return (pc_list - centroid) * scale
@@ -64,11 +72,13 @@ def compute_corr_list_filter(norm_pc_list, feature_extractor, knn=None, matching
     [:-1] and [1:], then per pair the mutual SMNN matches.  norm_pc_list [T,N,3] ->
     (corrs_src_list, corrs_tgt_list): ragged index lists per consecutive frame pair.
     Every frame's descriptors are computed once (the reference evaluates interior frames twice)."""
-    if matching != "smnn":
-        raise NotImplementedError("only the reference's default matching='smnn' is built (run_robot.py:80)")
+    if matching not in ("smnn", "mnn"):
+        raise ValueError("matching is 'smnn' (the reference's default, run_robot.py:80) or 'mnn'")
     feats = feature_extractor(norm_pc_list.transpose(1, 2).contiguous())   # [T,64,N]
     feats = feats.permute(0, 2, 1).contiguous()                            # point-major rows
-    keep, tgt = _smnn_batched(feats[:-1], feats[1:], 0.9)
+    # "mnn" (utils/flow_utils.py:126-137): nearest descriptor in both directions + the mutual filter, no ratio test --
+    # the same two top-2 passes with the test switched off (th < 0); ``knn`` is not needed (the reference's k = 1 KNN)
+    keep, tgt = _smnn_batched(feats[:-1], feats[1:], 0.9 if matching == "smnn" else -1.0)
     src_list, tgt_list = [], []
     for e in range(keep.shape[0]):
         src = torch.nonzero(keep[e], as_tuple=False)[:, 0]

@@ -49,7 +49,9 @@ def linear_sum_assignment_batch(cost, return_stats=False, state=None, warm_assig
     long single-bidder chains from the points instead of reading them (``reart_lap_auction_points``; same result).
     ``race=True`` (cold solves): five workgroups per matrix race with different epsilon schedules on otherwise idle compute
     units and the first certified one publishes (``reart_lap_auction_race``): the same optimal assignment 20 % sooner; the
-    potentials kept in ``state`` are the winner's (valid, but not reproducible run to run).  ``race="warm"`` with a ``state``
+    potentials kept in ``state`` are the winner's (valid, but not reproducible run to run; when a matrix has several optimal
+    assignments of exactly the same cost, which of them is returned may also differ from run to run -- the winner's).
+    ``race="warm"`` with a ``state``
     kept between calls: from the second call on three more racers start from the previous potentials and assignment
     (``reart_lap_auction_race_warm``) -- a loop need not know whether its matrices moved little or jumped."""
     _lib.require_gpu(cost)
@@ -58,8 +60,18 @@ def linear_sum_assignment_batch(cost, return_stats=False, state=None, warm_assig
     cost = cost.detach().float().contiguous()
     B, n, _ = cost.shape
     L = _lib.lib()
-    col = torch.empty((B, n), dtype=torch.int32, device=cost.device)
-    cert = torch.empty((B,), dtype=torch.int32, device=cost.device)
+    src = tgt = None
+    if points is not None:      # validated for every branch that may hand the pointers to a kernel
+        src, tgt = (p.detach().float().contiguous() for p in points)
+        _lib.require_gpu(src, tgt)
+        if tuple(src.shape) != (B, n, 3) or tuple(tgt.shape) != (B, n, 3):
+            raise ValueError("points = (src, tgt), both [B,n,3], with cost = cdist(src, tgt)")
+        if src.device != cost.device or tgt.device != cost.device:
+            raise ValueError("points and cost live on different devices")
+    # defined outputs whatever the kernels write: a racing launch whose racers all miss the certificate writes nothing for
+    # that matrix (it is solved on the host below)
+    col = torch.full((B, n), -1, dtype=torch.int32, device=cost.device)
+    cert = torch.zeros((B,), dtype=torch.int32, device=cost.device)
     nbytes = L.reart_lap_workspace_bytes(B, n)
     if nbytes == 0:   # n > 4096: beyond the kernel's LDS state -- the reference's host solver
         from scipy.optimize import linear_sum_assignment
@@ -73,7 +85,7 @@ def linear_sum_assignment_batch(cost, return_stats=False, state=None, warm_assig
         prices = state.get("prices")
         warm = prices is not None and tuple(prices.shape) == (B, n) and prices.device == cost.device
         if not warm:
-            prices = torch.empty((B, n), dtype=torch.float64, device=cost.device)
+            prices = torch.zeros((B, n), dtype=torch.float64, device=cost.device)
         state["prices"] = prices
         keep = bool(warm_assignment and warm and state.get("cols") is not None and tuple(state["cols"].shape) == (B, n))
         if keep:
@@ -88,16 +100,14 @@ def linear_sum_assignment_batch(cost, return_stats=False, state=None, warm_assig
         racing = False                                                         # warm potentials only: the plain warm auction
     n_cold, n_racers = _racers(B, n, race_warm)
     ws = _lib.workspace(L.reart_lap_race_workspace_bytes(B, n, n_racers) if racing else nbytes, cost.device)
+    if return_stats == "full":      # the statistics of a matrix nobody certified in a race are never written: report zeros
+        off = ((8 * B * n + 255) // 256) * 256
+        ws[off:off + 16 * B].zero_()
     tail_args = (B, n, _lib.ptr(col), _lib.ptr(cert), _lib.ptr(prices) if (state is not None and warm) else None,
                  _lib.ptr(prices) if state is not None else None, _lib.ptr(ws), ws.numel(), _lib.stream())
     if racing:
-        src = tgt = None
-        if points is not None:
-            src, tgt = (p.detach().float().contiguous() for p in points)
-            if tuple(src.shape) != (B, n, 3) or tuple(tgt.shape) != (B, n, 3):
-                raise ValueError("points = (src, tgt), both [B,n,3], with cost = cdist(src, tgt)")
         if race_warm:
-            new_prices = torch.empty_like(prices)
+            new_prices = torch.zeros_like(prices)
             rc = L.reart_lap_auction_race_warm(_lib.ptr(cost), _lib.ptr(src), _lib.ptr(tgt), B, n, n_racers, _lib.ptr(state["cols"]),
                                                _lib.ptr(prices), _lib.ptr(col), _lib.ptr(cert), _lib.ptr(new_prices), _lib.ptr(ws),
                                                ws.numel(), _lib.stream())
@@ -106,16 +116,10 @@ def linear_sum_assignment_batch(cost, return_stats=False, state=None, warm_assig
             rc = L.reart_lap_auction_race(_lib.ptr(cost), _lib.ptr(src), _lib.ptr(tgt), B, n, n_cold, _lib.ptr(col), _lib.ptr(cert),
                                           _lib.ptr(prices) if state is not None else None, _lib.ptr(ws), ws.numel(), _lib.stream())
     elif points is not None and solve is L.reart_lap_auction:
-        src, tgt = (p.detach().float().contiguous() for p in points)
-        if tuple(src.shape) != (B, n, 3) or tuple(tgt.shape) != (B, n, 3):
-            raise ValueError("points = (src, tgt), both [B,n,3], with cost = cdist(src, tgt)")
-        _lib.require_gpu(src, tgt)
         rc = L.reart_lap_auction_points(_lib.ptr(cost), _lib.ptr(src), _lib.ptr(tgt), *tail_args)
     else:
         rc = solve(_lib.ptr(cost), *tail_args)
     _lib.check(rc, "reart_lap_auction")
-    if state is not None and (warm_assignment or race == "warm"):
-        state["cols"] = col.clone()
     col_h, cert_h = col.cpu().numpy().astype(np.int64), cert.cpu().numpy()
     rows = np.arange(n, dtype=np.int64)
     out, fallbacks = [], 0
@@ -127,11 +131,23 @@ def linear_sum_assignment_batch(cost, return_stats=False, state=None, warm_assig
 
             fallbacks += 1
             out.append(linear_sum_assignment(cost[b].cpu().numpy()))
+            _forget_uncertified(state, col, b, out[-1][1])
+    if state is not None and (warm_assignment or race == "warm"):
+        state["cols"] = col.clone()
     if return_stats == "full":   # per matrix: phases, auction rounds, bids, certificate rounds
         off = ((8 * B * n + 255) // 256) * 256
         st = ws[off:off + 16 * B].view(torch.int32).reshape(B, 4).cpu().numpy()
         return out, fallbacks, st
     return (out, fallbacks) if return_stats else out
+
+
+def _forget_uncertified(state, col, b, host_cols):
+    """Matrix b was solved on the host: what the kernel left for it (an uncertified assignment and potentials, or nothing
+    at all after a lost race) must not start the next solve.  The kept assignment becomes the host's optimum and the
+    potentials of that matrix are zeroed -- the next call starts cold for it (useless potentials are legal input)."""
+    col[b] = torch.from_numpy(np.asarray(host_cols)).to(device=col.device, dtype=col.dtype)
+    if state is not None and state.get("prices") is not None:
+        state["prices"][b].zero_()
 
 
 POINTS_NMAX = 2048   # reart_lap_resolve_points keeps both point sets and the solver state in LDS
@@ -171,6 +187,7 @@ def linear_sum_assignment_points(src, tgt, state, return_stats=False):
 
             fallbacks += 1
             out.append(linear_sum_assignment(cdist(src[b:b + 1], tgt[b:b + 1])[0].cpu().numpy()))
+            _forget_uncertified(state, state["cols"], b, out[-1][1])
     if return_stats == "full":
         off = ((8 * B * n + 255) // 256) * 256
         st = ws[off:off + 16 * B].view(torch.int32).reshape(B, 4).cpu().numpy()

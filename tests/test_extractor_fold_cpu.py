@@ -45,6 +45,29 @@ def test_fold_equals_conv_followed_by_eval_batchnorm_and_follows_parameter_chang
     np.testing.assert_allclose(Wt5.numpy(), Wt3.numpy(), rtol=1e-6, atol=1e-7)
 
 
+def test_fold_cache_is_dropped_by_the_module_level_hooks():
+    """Writes through .data bypass the version counter: invalidate_fold() -- which .train(), .to() and
+    load_state_dict() call themselves -- drops the cached folds."""
+    from reart_amd.networks.feature_extractor import PointNet2Msg2, _fold
+
+    torch.manual_seed(1)
+    net = PointNet2Msg2(8).eval()
+    Wt, _ = _fold(net.conv1, net.bn1)
+    assert _fold(net.conv1, net.bn1)[0] is Wt
+    net.conv1.weight.data.mul_(2.0)                      # invisible to the key ...
+    assert _fold(net.conv1, net.bn1)[0] is Wt
+    net.invalidate_fold()                                # ... until the cache is dropped
+    Wt2, _ = _fold(net.conv1, net.bn1)
+    np.testing.assert_allclose(Wt2.numpy(), 2.0 * Wt.numpy(), rtol=1e-6, atol=1e-7)
+    for action in (lambda: net.train() and net.eval(), lambda: net.double().float(), lambda: net.load_state_dict(net.state_dict())):
+        _fold(net.conv1, net.bn1)
+        assert hasattr(net.conv1, "_reart_folded")
+        action()
+        assert not hasattr(net.conv1, "_reart_folded")
+    # the entry keeps its source tensors alive: a freed parameter's address cannot be handed to a new one under the key
+    assert _fold(net.conv1, net.bn1) and net.conv1._reart_folded[3][0] is net.conv1.weight
+
+
 def test_racer_counts_fit_the_chip():
     """reart_amd.utils.lap._racers: (cold, all) workgroups per matrix of a raced assignment solve -- never more than 256
     workgroups below 4096 columns, five cold racers at 4096, three warm ones when a previous solution is available."""

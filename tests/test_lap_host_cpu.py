@@ -1,0 +1,124 @@
+"""Host logic of reart_amd.utils.lap around the GPU solver (no GPU, no compute): what happens when the kernels do NOT
+certify a matrix.  The library is replaced by a fake whose solver entry points return success and write nothing -- exactly
+what a racing launch leaves behind for a matrix on which every racer missed the certificate (lap.hip: nobody publishes)."""
+import numpy as np
+import pytest
+import torch
+
+
+class _FakeLib:
+    """reart_lap_* entry points that succeed without touching their outputs; optionally certifies some matrices with a
+    given assignment (written through the raw pointers like the kernel would)."""
+
+    def __init__(self, B, n, certify=None):
+        self.B, self.n, self.certify, self.calls = B, n, certify or {}, []
+        # like a ctypes library, attribute access returns the SAME function object every time (lap.py compares them by identity)
+        for name in [k for k in dir(type(self)) if k.startswith("reart_")]:
+            setattr(self, name, getattr(self, name))
+
+    def reart_lap_workspace_bytes(self, B, n):
+        return 8 * B * n + 4096 + 16 * B + 8 * B * n
+
+    def reart_lap_race_workspace_bytes(self, B, n, racers):
+        return self.reart_lap_workspace_bytes(B, n) * racers
+
+    def _solve(self, name, col_ptr, cert_ptr):
+        import ctypes
+
+        self.calls.append(name)
+        for b, cols in self.certify.items():
+            ctypes.memmove(col_ptr.value + 4 * b * self.n, np.asarray(cols, np.int32).ctypes.data, 4 * self.n)
+            ctypes.memmove(cert_ptr.value + 4 * b, np.asarray([1], np.int32).ctypes.data, 4)
+        return 0
+
+    def reart_lap_auction(self, cost, B, n, col, cert, pin, pout, ws, nws, st):
+        return self._solve("auction", col, cert)
+
+    def reart_lap_auction_race(self, cost, src, tgt, B, n, racers, col, cert, pout, ws, nws, st):
+        return self._solve("race", col, cert)
+
+    def reart_lap_auction_race_warm(self, cost, src, tgt, B, n, racers, cin, pin, col, cert, pout, ws, nws, st):
+        return self._solve("race_warm", col, cert)
+
+    def reart_lap_auction_warm(self, *a):
+        return self._solve("warm", a[3], a[4])
+
+    def reart_lap_resolve(self, *a):
+        return self._solve("resolve", a[3], a[4])
+
+    def reart_lap_auction_points(self, cost, src, tgt, B, n, col, cert, pin, pout, ws, nws, st):
+        return self._solve("points", col, cert)
+
+    def reart_status_string(self, rc):
+        return b"ok"
+
+
+@pytest.fixture
+def fake(monkeypatch):
+    from reart_amd import _lib
+
+    def install(B, n, certify=None):
+        f = _FakeLib(B, n, certify)
+        monkeypatch.setattr(_lib, "lib", lambda: f)
+        monkeypatch.setattr(_lib, "require_gpu", lambda *t: None)
+        monkeypatch.setattr(_lib, "stream", lambda: None)
+        monkeypatch.setattr(_lib, "workspace", lambda nbytes, device: torch.full((max(int(nbytes), 1),), 0xAB, dtype=torch.uint8))
+        return f
+
+    return install
+
+
+def _optimal(cost):
+    from scipy.optimize import linear_sum_assignment
+
+    return [linear_sum_assignment(c)[1] for c in cost.numpy()]
+
+
+@pytest.mark.parametrize("race", [True, "warm", False])
+def test_uncertified_matrices_are_solved_on_the_host_and_leave_no_garbage(fake, race):
+    from reart_amd.utils import lap
+
+    B, n = 3, 12
+    rng = np.random.default_rng(0)
+    cost = torch.from_numpy(rng.uniform(0, 1, (B, n, n)).astype(np.float32))
+    want = _optimal(cost)
+    f = fake(B, n, certify={1: want[1]})                   # the kernels certify matrix 1 only
+    state = {}
+    out, fallbacks, stats = lap.linear_sum_assignment_batch(cost, return_stats="full", state=state, race=race)
+    assert fallbacks == 2 and f.calls[0] in ("race", "auction")
+    for b in range(B):                                     # always the optimum scipy returns
+        np.testing.assert_array_equal(out[b][0], np.arange(n))
+        np.testing.assert_array_equal(out[b][1], want[b])
+    assert (stats == 0).all()                              # no statistics were written: zeros, not the buffer's old bytes
+    # what is kept for the next call: finite, defined -- zero potentials for the matrices the host solved
+    assert torch.isfinite(state["prices"]).all()
+    assert (state["prices"][0] == 0).all() and (state["prices"][2] == 0).all()
+    if race == "warm":
+        np.testing.assert_array_equal(state["cols"].numpy(), np.stack(want))      # the host's optimum, not uninitialised memory
+        # second call: the warm racers start from that state
+        out2 = lap.linear_sum_assignment_batch(cost, state=state, race="warm")
+        assert f.calls[-1] == "race_warm"
+        for b in range(B):
+            np.testing.assert_array_equal(out2[b][1], want[b])
+        assert torch.isfinite(state["prices"]).all()
+        np.testing.assert_array_equal(state["cols"].numpy(), np.stack(want))
+
+
+def test_points_are_validated_in_every_branch(fake):
+    from reart_amd.utils import lap
+
+    B, n = 2, 8
+    cost = torch.rand(B, n, n)
+    fake(B, n)
+    with pytest.raises(ValueError):
+        lap.linear_sum_assignment_batch(cost, points=(torch.rand(B, n - 1, 3), torch.rand(B, n, 3)), race=True)
+    with pytest.raises(ValueError):
+        lap.linear_sum_assignment_batch(cost, points=(torch.rand(B, n, 3), torch.rand(B, n, 2)), race=False)
+
+
+def test_racing_branch_requires_gpu_points():
+    """The real require_gpu: host tensors never reach a kernel as pointers."""
+    from reart_amd.utils import lap
+
+    with pytest.raises(RuntimeError):
+        lap.linear_sum_assignment_batch(torch.rand(1, 4, 4), race=True)

@@ -116,3 +116,31 @@ def test_run_robot_on_a_sequence_directory_with_ground_truth_and_retargeting(dev
         txt = next((tmp_path / "kin").rglob("result.txt")).read_text()
         err = float([l for l in txt.splitlines() if l.startswith("retarget_err")][0].split(":")[1])
         assert 0.0 <= err < 100.0
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_mnn_matching_vs_reference_golden(dev, tag):
+    """matching="mnn" of compute_corr_list_filter (utils/flow_utils.py:126-137) against the reference's own function
+    (tests/golden/mnn.npz: its k = 1 KNN both ways + find_mutual_correspondences on the smnn.npz descriptors)."""
+    import os
+
+    from reart_amd.utils.flow_utils import compute_corr_list_filter, find_mutual_correspondences
+
+    G = os.path.join(os.path.dirname(__file__), "golden")
+    g, m = np.load(os.path.join(G, "smnn.npz")), np.load(os.path.join(G, "mnn.npz"))
+    n = int(m[f"n_{tag}"])
+    assert float(m[f"gap_{tag}"]) > 1e-4        # no near-tie between a best and second-best descriptor: well defined in fp32
+    frames = torch.stack([torch.from_numpy(g[f"d1_{tag}"][:n]), torch.from_numpy(g[f"d2_{tag}"][:n])]).to(dev)
+    extractor = lambda x: frames.transpose(1, 2).contiguous()            # [T, 64, N] like PointNet2Msg2
+    src, tgt = compute_corr_list_filter(torch.zeros(2, n, 3, device=dev), extractor, None, matching="mnn")
+    assert len(src) == 1
+    np.testing.assert_array_equal(src[0].cpu().numpy(), m[f"src_{tag}"])
+    np.testing.assert_array_equal(tgt[0].cpu().numpy(), m[f"tgt_{tag}"])
+    # the helper of the same name
+    nn01 = torch.cdist(frames[0], frames[1]).argmin(1)
+    nn10 = torch.cdist(frames[1], frames[0]).argmin(1)
+    s2, t2 = find_mutual_correspondences(nn01, nn10)
+    np.testing.assert_array_equal(s2.cpu().numpy(), m[f"src_{tag}"])
+    np.testing.assert_array_equal(t2.cpu().numpy(), m[f"tgt_{tag}"])
+    with pytest.raises(ValueError):
+        compute_corr_list_filter(torch.zeros(2, n, 3, device=dev), extractor, None, matching="other")
