@@ -479,6 +479,13 @@ int reart_lap_resolve(const float *cost, int B, int n, int32_t *col4row, int32_t
                       const double *price_in, double *price_out, void *workspace, size_t workspace_bytes,
                       void *stream);
 
+/* Measurement aid for the latency roofline of reart_lap_resolve_points (no reference counterpart): B workgroups run
+ * `steps` path-search steps of the re-solve stripped to what cannot be removed -- the workgroup-wide (distance, column)
+ * arg-min over n <= 2048 labels held in registers and its one barrier, with the solver's own primitives -- and
+ * *h_us_per_step (HOST pointer) receives the slowest workgroup's microseconds per step on the GPU's constant-rate
+ * clock.  A re-solve of S sequential steps cannot take less than S x this.  Synchronises `stream`.  workspace: 16 B bytes. */
+int reart_lap_step_floor(int B, int n, int steps, void *workspace, size_t workspace_bytes, double *h_us_per_step, void *stream);
+
 /* The same re-solve for Euclidean costs between two point sets, without a cost matrix: src, tgt [B,n,3], n <= 2048;
  * c_ij is the value reart_cdist(src, tgt) would hold (same fp32 expression), recomputed from LDS copies of both sets
  * wherever the solver needs a cost -- a path-search step then reads no memory beyond LDS.  Result identical to

@@ -1488,6 +1488,78 @@ extern "C" int reart_lap_resolve_points(const float *src, const float *tgt, int 
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Measurement aid (bench.py's latency roofline of the re-solve, tools/lap_floor.py): the FLOOR of one path-search step of
+// lap_jv_kernel<512, points, .> -- what is left of a Dijkstra step when its costs are free: every thread's minimum over its
+// JV_PTS_NMAX / 512 = 4 labels in registers, the wave arg-min (lap_wave_argmin_fast), one LDS slot per wave, ONE barrier,
+// the meeting of the waves' results in the first lanes (lap_lanes_argmin), the winner's thread marking its column.  The
+// same primitives in the same order as the loop above, nothing else: no row costs, no square roots, no relaxation.  A
+// re-solve is a sequential chain of such steps per problem, so steps x this floor bounds its duration from below.
+template <int BS>
+__global__ __launch_bounds__(BS) void lap_step_floor_kernel(int n, int steps, unsigned long long *__restrict__ ticks,
+                                                            double *__restrict__ sink) {
+    constexpr int NW = BS / 64, CPT = JV_PTS_NMAX / BS;
+    __shared__ double s_rv[2][NW];
+    __shared__ int s_rj[2][NW];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    double d[CPT];
+    unsigned scanned = 0u;
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+        const unsigned j = (unsigned)(tid + k * BS);
+        unsigned h = (j + 1u + 7919u * blockIdx.x) * 2654435761u;           // distinct pseudo-random positive labels
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        d[k] = (int)j < n ? 1.0 + (double)h * (1.0 / 4294967296.0) : INFINITY;
+        if ((int)j >= n) scanned |= 1u << k;
+    }
+    const unsigned dead = scanned;
+    double acc = 0.0;
+    __syncthreads();
+    const unsigned long long t0 = wall_clock64();
+    for (int it = 0; it < steps; ++it) {
+        double bv = INFINITY;
+        int bj = 0x7fffffff;
+#pragma unroll
+        for (int k = 0; k < CPT; ++k)
+            if (!((scanned >> k) & 1u)) {
+                const int key = tid + k * BS;
+                if (d[k] < bv || (d[k] == bv && key < bj)) { bv = d[k]; bj = key; }
+            }
+        lap_wave_argmin_fast(bv, bj);
+        const int par = it & 1;
+        if (lane == 0) { s_rv[par][wv] = bv; s_rj[par][wv] = bj; }
+        __syncthreads();
+        bv = lane < NW ? s_rv[par][lane] : INFINITY; bj = lane < NW ? s_rj[par][lane] : 0x7fffffff;
+        lap_lanes_argmin<(NW <= 2 ? 1 : (NW <= 4 ? 2 : (NW <= 8 ? 3 : 4)))>(bv, bj);
+        if (bj == 0x7fffffff) { scanned = dead; continue; }                 // every column labelled: start over
+        acc += bv;
+        if ((bj & (BS - 1)) == tid) scanned |= 1u << (bj / BS);
+    }
+    const unsigned long long t1 = wall_clock64();
+    if (tid == 0) { ticks[blockIdx.x] = t1 - t0; sink[blockIdx.x] = acc; }
+}
+
+extern "C" int reart_lap_step_floor(int B, int n, int steps, void *workspace, size_t workspace_bytes, double *h_us_per_step,
+                                    void *stream) {
+    if (B < 1 || B > 4096 || n < 1 || n > JV_PTS_NMAX || steps < 1 || !h_us_per_step) return REART_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < 16 * (size_t)B) return REART_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long *ticks = (unsigned long long *)workspace;
+    hipLaunchKernelGGL(lap_step_floor_kernel<512>, dim3(B), dim3(512), 0, st, n, steps, ticks, (double *)(ticks + B));
+    REART_CHECK_LAUNCH();
+    unsigned long long h[4096];
+    if (hipMemcpyAsync(h, ticks, sizeof(unsigned long long) * B, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+        return REART_ERR_LAUNCH;
+    int dev = 0, khz = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0)
+        return REART_ERR_LAUNCH;
+    unsigned long long worst = 0;
+    for (int b = 0; b < B; ++b) worst = h[b] > worst ? h[b] : worst;
+    *h_us_per_step = (double)worst / (1e3 * (double)khz) * 1e6 / (double)steps;    // slowest workgroup, like the solve
+    return REART_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Cost matrices of the assignment loss / assignment error: Euclidean distances between two batches of points
 // (`torch.cdist(pc_src, pc_tgt)` at run_robot.py:171 and utils/model_utils.py:93).  Direct differences in fp32,
 // ((dx*dx)+(dy*dy))+(dz*dz) then sqrt -- the library-wide distance contract -- and one pass over the output, which is

@@ -62,6 +62,7 @@ class KinematicEngine:
         self.m = [torch.zeros_like(p) for p in self.params]
         self.v = [torch.zeros_like(p) for p in self.params]
         self.grads = {id(p): torch.zeros_like(p) for p in self.params}
+        self.lap_steps_log = []
         self.step_count = 0
         # run_robot.py:167-169: both FPS calls sample fixed clouds (start 0 on the reference's CUDA path): once
         num_fps = self.N // int(downsample)
@@ -172,6 +173,10 @@ class KinematicEngine:
                 ev[0].record()
             assign, _, self.lap_stats = linear_sum_assignment_points(pc_src, self.tgt_pts, self.lap_state, return_stats="full")
             self.lap_solves += 1
+            # sequential steps of this solve (path search + row reduction) per problem: slowest problem, mean -- the
+            # latency roofline of bench.py multiplies them by the measured floor of one step
+            seq = self.lap_stats[:, 2].astype(np.int64) + (self.lap_stats[:, 3].astype(np.int64) >> 8)
+            self.lap_steps_log.append((int(seq.max()), float(seq.mean())))
             cols = torch.from_numpy(np.stack([c for _, c in assign])).to(self.dev)
             self.matched = self.tgt_pts.gather(1, cols[..., None].expand(-1, -1, 3))
             if self.lap_events is not None:

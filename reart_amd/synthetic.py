@@ -129,3 +129,29 @@ def export_sequence(path, T=6, n_parts=4, pts_per_part=256, seed=2, n_novel=2):
         with open(os.path.join(path, f"novel_pose_{k}.pkl"), "wb") as f:
             pickle.dump(rel(k + 1.5), f)
     return seq
+
+
+def extractor_state(model, seed=11):
+    """Deterministic weights for every parameter / buffer of a PointNet2Msg2-shaped module: the reference does not ship
+    ``corr_model.pth.tar`` (feature_extractor.py:62-86), so the extractor benchmark and the parity fixtures run on these
+    seeded weights (He-style scale keeps the activations O(1) through the 12 conv stacks)."""
+    import torch
+
+    rng = np.random.default_rng(seed)
+    sd = {}
+    for k, v in model.state_dict().items():
+        shape = tuple(v.shape)
+        if k.endswith("num_batches_tracked"):
+            sd[k] = torch.tensor(1, dtype=torch.long)
+        elif k.endswith("running_var"):
+            sd[k] = torch.from_numpy(rng.uniform(0.5, 1.5, shape).astype(np.float32))
+        elif k.endswith("running_mean"):
+            sd[k] = torch.from_numpy(rng.normal(0, 0.1, shape).astype(np.float32))
+        elif "bn" in k and k.endswith("weight"):
+            sd[k] = torch.from_numpy(rng.uniform(0.8, 1.2, shape).astype(np.float32))
+        elif k.endswith("bias"):
+            sd[k] = torch.from_numpy(rng.normal(0, 0.05, shape).astype(np.float32))
+        else:  # conv weight [out, in, 1(,1)]: He-style scale keeps activations O(1)
+            fan_in = shape[1]
+            sd[k] = torch.from_numpy(rng.normal(0, np.sqrt(2.0 / fan_in), shape).astype(np.float32))
+    return sd

@@ -2,7 +2,7 @@
 """Golden vectors for the PointNet++ correspondence extractor (G9): the REFERENCE's PointNet2Msg2
 (networks/feature_extractor.py:10-49, CPU fallbacks for FPS / ball query) with seeded random
 weights (corr_model.pth.tar is not shipped) on a 1024-point nao cloud.  The weights are NOT stored:
-tests regenerate them from the same numpy seed with `extractor_state(seed)` below.
+tests regenerate them from the same numpy seed with `reart_amd.synthetic.extractor_state`.
 
     python tests/golden/make_golden_extractor.py
 """
@@ -18,26 +18,7 @@ REF = os.environ.get("REART_REFERENCE", "/root/reference")
 sys.path.insert(0, ROOT)
 
 
-def extractor_state(model, seed=11):
-    """Deterministic weights for every parameter / buffer of a PointNet2Msg2-shaped module."""
-    rng = np.random.default_rng(seed)
-    sd = {}
-    for k, v in model.state_dict().items():
-        shape = tuple(v.shape)
-        if k.endswith("num_batches_tracked"):
-            sd[k] = torch.tensor(1, dtype=torch.long)
-        elif k.endswith("running_var"):
-            sd[k] = torch.from_numpy(rng.uniform(0.5, 1.5, shape).astype(np.float32))
-        elif k.endswith("running_mean"):
-            sd[k] = torch.from_numpy(rng.normal(0, 0.1, shape).astype(np.float32))
-        elif "bn" in k and k.endswith("weight"):
-            sd[k] = torch.from_numpy(rng.uniform(0.8, 1.2, shape).astype(np.float32))
-        elif k.endswith("bias"):
-            sd[k] = torch.from_numpy(rng.normal(0, 0.05, shape).astype(np.float32))
-        else:  # conv weight [out, in, 1(,1)]: He-style scale keeps activations O(1)
-            fan_in = shape[1]
-            sd[k] = torch.from_numpy(rng.normal(0, np.sqrt(2.0 / fan_in), shape).astype(np.float32))
-    return sd
+from reart_amd.synthetic import extractor_state  # noqa: E402  (seeded weights: corr_model.pth.tar is not shipped)
 
 
 def main():

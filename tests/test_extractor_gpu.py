@@ -55,7 +55,7 @@ def test_mlp_layer_vs_torch(dev):
 
 def test_extractor_matches_reference(dev):
     from reart_amd.networks.feature_extractor import PointNet2Msg2
-    from tests.golden.make_golden_extractor import extractor_state
+    from reart_amd.synthetic import extractor_state
 
     g = np.load(os.path.join(G, "extractor.npz"))
     model = PointNet2Msg2(out_dim=64)

@@ -165,6 +165,10 @@ def test_knn_backward_degenerate_buckets(oracle, dev):
 def test_knn_per_point_against_the_reference_kdtree(dev):
     """HIP brute force and the fused loop's pruned warm-started search against the per-point results of the REFERENCE's
     KD-tree Chamfer (utils/eval_utils.py:39-66; tests/golden/chamfer_kdtree.npz) -- no oracle in between."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from test_oracle_golden_cpu import kdtree_check, load
     from reart_amd.utils.chamfer import knn_points
 

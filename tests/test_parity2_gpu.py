@@ -116,9 +116,12 @@ def test_row_mode_matches_torch_cpu(dev):
         np.testing.assert_array_equal(_row_mode(t(v, dev)).cpu().numpy(), torch.mode(torch.from_numpy(v), dim=1)[0].numpy())
 
 
+EXTRACTOR_TOL = 2e-4      # of the descriptors' scale (north_star: fp32 within 1e-4 relative); the measured error is printed
+
+
 def _extractor(dev):
     from reart_amd.networks.feature_extractor import PointNet2Msg2
-    from tests.golden.make_golden_extractor import extractor_state
+    from reart_amd.synthetic import extractor_state
 
     model = PointNet2Msg2(out_dim=64)
     model.load_state_dict(extractor_state(model), strict=True)
@@ -142,7 +145,11 @@ def test_extractor_4096_reference_golden(dev):
     ref = g["feat"]
     assert feat.shape == (1, 64, 4096)
     err = np.abs(feat - ref)
-    assert err.max() <= 2e-4 * np.abs(ref).max(), (err.max(), np.abs(ref).max())
+    l2e = np.abs(l2.permute(0, 2, 1).cpu().numpy() - g["l2_points"])
+    print(f"\n[a9 @ N=4096, CPU rules] descriptor error: max {err.max():.3e} = {err.max() / np.abs(ref).max():.3e} of the scale "
+          f"({np.abs(ref).max():.3f}), mean {err.mean():.3e} = {err.mean() / np.abs(ref).mean():.3e} of the mean magnitude; "
+          f"sa2 output: max {l2e.max():.3e} of scale {np.abs(g['l2_points']).max():.3f}")
+    assert err.max() <= EXTRACTOR_TOL * np.abs(ref).max(), (err.max(), np.abs(ref).max())
     assert err.mean() <= 2e-5 * np.abs(ref).mean()
     # CUDA sampling rules (what the reference computes on a GPU): start 0, d2 < r2, padded with the first hit
     feat_c = model(xyz).cpu().numpy()            # the package default: pointnet2_utils.CUDA = True
@@ -150,7 +157,9 @@ def test_extractor_4096_reference_golden(dev):
     np.testing.assert_array_equal(l1c.permute(0, 2, 1).cpu().numpy(), g["cuda_l1_xyz"])
     ref = g["cuda_feat"]
     err = np.abs(feat_c - ref)
-    assert err.max() <= 2e-4 * np.abs(ref).max(), (err.max(), np.abs(ref).max())
+    print(f"[a9 @ N=4096, CUDA rules] descriptor error: max {err.max():.3e} = {err.max() / np.abs(ref).max():.3e} of the scale, "
+          f"mean {err.mean():.3e} = {err.mean() / np.abs(ref).mean():.3e} of the mean magnitude")
+    assert err.max() <= EXTRACTOR_TOL * np.abs(ref).max(), (err.max(), np.abs(ref).max())
     assert not np.array_equal(g["cuda_feat"], g["feat"])
 
 

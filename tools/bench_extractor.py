@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from reart_amd.networks.feature_extractor import PointNet2Msg2
 from reart_amd.synthetic import make_sequence
-from tests.golden.make_golden_extractor import extractor_state
+from reart_amd.synthetic import extractor_state
 
 dev = torch.device("cuda:0")
 seq = make_sequence(T=20, with_flow=False)
