@@ -161,6 +161,7 @@ struct SearchArgs {
     int per;                       // pairs per XCD chunk = ceil(G / 8) (set by the launcher)
     int S1, S3;                    // waves per workgroup of a K = 1 / K = 3 item (1..4)
     int sparse;                    // boxes needed by <= sparse queries of a wave go through the (query, box) queue (0: dense only)
+    int share;                     // 1: every lane's bound also takes the seeds of the 15 other lanes of its row (neighbour seeds)
     int interleave;                // 0: XCD x runs the positions [x*per, (x+1)*per) (a run of frames per L2); 1: positions
                                    // x, x+8, ... (every XCD sees every frame: balanced whatever the frames cost)
     int cloud_resident;            // 1: when the target clouds fit in LDS, one workgroup of 16 waves per (job, batch, 16

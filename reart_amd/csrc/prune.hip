@@ -34,9 +34,20 @@
 // and wave 0 merges them by the full (distance, index) key, does the ONE exact rescan of the winning half
 // box and writes ONE record per query -- no per-slice partial lists in memory, nothing for the consumer to
 // merge.  The K = 1 record (int32 index) is also the next iteration's warm-start seed, in place.
-// Workgroup L runs on XCD L % 8: every XCD owns a contiguous eighth of the (batch, group) pairs of each job,
-// i.e. 2-3 consecutive frames, so a cloud is fetched into ONE L2 instead of eight; inside its eighth the
-// pairs are launched heaviest first (counting sort of last iteration's work counts, step.hip).
+// Launch positions are dealt to the XCDs round-robin (workgroup L runs on XCD L % 8 and takes every 8th (batch, group)
+// pair: every XCD sees every frame, which balances the chip whatever the frames cost; a contiguous run of frames per
+// XCD -- `interleave = 0`, tune_xcd -- was measured slower: frames differ 10x in work), heaviest pairs first (counting
+// sort of last iteration's work counts, step.hip).
+//
+//   * Neighbour seeds (round 3).  A lane's own seed is a poor bound exactly when it matters: every iteration a fifth of
+//     the points re-sample their part label and jump (queries of the x -> y search, targets of the y -> x search), their
+//     old neighbour is then far away, and those lanes -- 23 % of them -- used to produce 78 % of all (query, box)
+//     pairs.  But the 16 lanes of a row are neighbours on the canonical shape, and the lanes that landed next to a
+//     jumped point hold seeds next to ITS new neighbour.  So the lanes of a row park their seed targets in LDS and
+//     every lane takes  thr = min over the row's lanes l' of  max_k d(q, t[seed_{l',k}])  -- any K distinct targets
+//     bound the K-th neighbour distance, whoever found them.  Measured on dumped states (tools/sim_filter.py):
+//     (query, box) pairs per wave 675 -> 194 (x -> y), 1219 -> 508 (y -> x), 983 -> 305 (flow); boxes some lane needs
+//     76 -> 34; coarse survivors 112 -> 70.
 #include "common.h"
 #include "internal.h"
 #include <math.h>
@@ -135,10 +146,12 @@ __device__ __forceinline__ float box_lb(float lo0, float lo1, float lo2, float h
 // `pairs` counts the query-target distance evaluations the wave executed (lanes x targets, dense and sparse forms).
 // LDSV: `cloud` / `boxes_p` point at a copy of the batch's target cloud (SoA rows of `cstride` floats) and of its boxes in
 // LDS (knn_cloud_kernel); otherwise at the global images.  QCAP: entries of the wave's queue.
+// share: neighbour seeds (parked in the queue's space, which is free until the first coarse round: s_bb | s_q when BOXL,
+// s_q otherwise; skipped when that space is too small for KK x 3 x 64 floats).
 template <int KK, bool LDSV, int QCAP, bool BOXL>
 __device__ __forceinline__ void knn_pruned_wave(const KnnJob &jb, const int S, const int sparse, const int b, const int g,
                                                 const int s, const float *cloud, const int cstride, const float *boxes_p,
-                                                float *s_tg, float *s_qc, unsigned int *s_q, float *s_bb,
+                                                float *s_tg, float *s_qc, unsigned int *s_q, float *s_bb, const int share,
                                                 unsigned long long *s_key, float &qx_o, float &qy_o, float &qz_o,
                                                 float (&bm)[KK], int (&bb)[KK], int &work_o, unsigned int &pairs_o) {
     struct { int S, sparse; } a = {S, sparse};
@@ -172,12 +185,44 @@ __device__ __forceinline__ void knn_pruned_wave(const KnnJob &jb, const int S, c
 #pragma unroll
             for (int k2 = 0; k2 < k; ++k2) ok = ok && sj[k] != sj[k2];
         }
+        constexpr bool SCR_JOINT = BOXL && PR_BOXLDS == 1;       // s_bb | s_q contiguous
+        constexpr bool SCR_FITS = (QCAP + (SCR_JOINT ? 384 : 0)) >= KK * 3 * 64;
+        if (SCR_FITS && share) {
+            // ---- neighbour seeds: the K seed targets of every lane of this row of 16 (the lane's own among them), two lanes
+            // per packed step.  A lane without usable seeds parks +inf (its candidates bound nothing -- but it still takes its
+            // neighbours' bound); LDS operations of a wave complete in order, and every lane reads only its own row.
+            float *s_scr = SCR_JOINT ? s_bb : (float *)s_q;
 #pragma unroll
-        for (int k = 0; k < KK; ++k) {
-            const int j = ok ? sj[k] : 0;
-            thr = fmaxf(thr, reart_sqdist3(qx, qy, qz, tx[j], ty[j], tz[j]));
+            for (int k = 0; k < KK; ++k) {
+                const int j = ok ? sj[k] : 0;
+                s_scr[(3 * k + 0) * 64 + lane] = ok ? tx[j] : INFINITY;
+                s_scr[(3 * k + 1) * 64 + lane] = ok ? ty[j] : INFINITY;
+                s_scr[(3 * k + 2) * 64 + lane] = ok ? tz[j] : INFINITY;
+            }
+            thr = INFINITY;
+            const float *row = s_scr + (lane & 48);
+#pragma unroll 1      // rolled: unrolled, the 72 LDS loads of a K = 3 item in flight cost 25 VGPRs, i.e. two resident waves per SIMD
+            for (int c = 0; c < 16; c += 2) {
+                f2 far = {0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < KK; ++k) {
+                    const f2 dx = qx2 - *(const f2 *)(row + (3 * k + 0) * 64 + c);
+                    const f2 dy = qy2 - *(const f2 *)(row + (3 * k + 1) * 64 + c);
+                    const f2 dz = qz2 - *(const f2 *)(row + (3 * k + 2) * 64 + c);
+                    const f2 d = (dx * dx + dy * dy) + dz * dz;
+                    far = f2{fmaxf(far.x, d.x), fmaxf(far.y, d.y)};
+                }
+                thr = fminf(thr, fminf(far.x, far.y));
+            }
+            if (!(thr >= 0.f)) thr = INFINITY;      // NaN query
+        } else {
+#pragma unroll
+            for (int k = 0; k < KK; ++k) {
+                const int j = ok ? sj[k] : 0;
+                thr = fmaxf(thr, reart_sqdist3(qx, qy, qz, tx[j], ty[j], tz[j]));
+            }
+            if (!ok || !(thr >= 0.f)) thr = INFINITY;   // unusable seeds / NaN: no pruning for this lane
         }
-        if (!ok || !(thr >= 0.f)) thr = INFINITY;   // unusable seeds / NaN: no pruning for this lane
     }
 
     // ---- group summaries: 4 groups of 16 lanes
@@ -195,9 +240,11 @@ __device__ __forceinline__ void knn_pruned_wave(const KnnJob &jb, const int S, c
 #pragma unroll
     for (int k = 0; k < KK; ++k) { bm[k] = INFINITY; bb[k] = -1; }
     const float *tx_g = tx;
-    unsigned int pairs = 64u * KK;            // the seeds
+    // ONE uniform counter for both statistics (a scalar register less, one s_add per event): bits 0..19 the distance
+    // evaluations (< 2^20 per wave), bits 20..31 the work count that orders the next launch (a heuristic: overflow is harmless)
+#define PR_WORK(w) ((unsigned)(w) << 20)
+    unsigned int wp = PR_WORK(16) | (64u * KK * (share ? 17u : 1u));   // prologue ~ 16 tests; the seeds (the row's 16 lanes)
 
-    int work = 16;   // uniform work counter of this item (prologue ~ 16 tests)
     const int queue_max = a.sparse;   // boxes needed by at most this many queries go through the (query, box) queue (0: off)
     int qcnt = 0;                     // entries in the wave's queue (uniform)
     // the wave's queries, parked once for the drain steps (a lane then evaluates ANOTHER lane's query)
@@ -213,14 +260,16 @@ __device__ __forceinline__ void knn_pruned_wave(const KnnJob &jb, const int S, c
     // its query's slots into its registers (and its bound) and clears them.
     auto drain_queue = [&]() {
         for (int e0 = 0; e0 < qcnt; e0 += 64) {
-            work += 6;
+            wp += PR_WORK(6);
             const int e = e0 + lane;
             const bool valid = e < qcnt;
             const unsigned ent = s_q[valid ? e : e0];
             const int ql = (int)(ent & 63u), j0 = (int)(ent >> 6) * NN_BOX;
-            pairs += (unsigned)__builtin_popcountll(__ballot(valid)) * NN_BOX;
+            wp += (unsigned)__builtin_popcountll(__ballot(valid)) * NN_BOX;
             const float4 qc = ((const float4 *)s_qc)[ql];
-            const float *tp = tx_g + j0;
+            // rows addressed as (wave-uniform base) + (32-bit lane offset): the scalar-base form of global_load keeps three
+            // 64-bit lane pointers (and their adds) out of the VGPRs
+            const float *rx = tx_g, *ry = tx_g + cstride, *rz = tx_g + 2 * (size_t)cstride;
             const f2 cx = {qc.x, qc.x}, cy = {qc.y, qc.y}, cz = {qc.z, qc.z};
             float mh[2] = {INFINITY, INFINITY};
             // one half box (8 targets: six 16-byte loads) at a time: the twelve loads of a whole box in flight cost 24 more
@@ -230,9 +279,10 @@ __device__ __forceinline__ void knn_pruned_wave(const KnnJob &jb, const int S, c
                 float4 X[2], Y[2], Z[2];
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    X[u] = *(const float4 *)(tp + 8 * hf + 4 * u);
-                    Y[u] = *(const float4 *)(tp + cstride + 8 * hf + 4 * u);
-                    Z[u] = *(const float4 *)(tp + 2 * cstride + 8 * hf + 4 * u);
+                    const unsigned ob = 4u * ((unsigned)j0 + 8u * hf + 4u * u);          // BYTE offset: zext(ob) is the address form
+                    X[u] = *(const float4 *)((const char *)rx + ob);
+                    Y[u] = *(const float4 *)((const char *)ry + ob);
+                    Z[u] = *(const float4 *)((const char *)rz + ob);
                 }
                 float m = INFINITY;
 #pragma unroll
@@ -329,8 +379,7 @@ __device__ __forceinline__ void knn_pruned_wave(const KnnJob &jb, const int S, c
         if (KK == 1) PRUNE_STAT(3, __builtin_popcountll(__ballot(thr == INFINITY)));  // lanes without a bound
         // scan of one box: the brute-force inner loop of knn.hip on its 16 targets
         auto scan_box = [&](const int bit, const int slot) {
-            work += 5;                                                   // a scan costs about five tests
-            pairs += 64u * NN_BOX;
+            wp += PR_WORK(5) | (64u * NN_BOX);                           // a scan costs about five tests
             if (KK == 1) PRUNE_STAT(2, 1);                               // boxes scanned
             const int j0 = (base + bit * a.S + s) * NN_BOX;
             // the box's 16 targets were staged in LDS slot `slot` (x[16] | y[16] | z[16]); all lanes read
@@ -391,7 +440,7 @@ __device__ __forceinline__ void knn_pruned_wave(const KnnJob &jb, const int S, c
         // drained 64 entries at a time with ONE entry per lane (drain_queue below): every lane then evaluates one
         // query against the 16 targets of one box, whatever mix of queries and boxes the entries hold.
         auto enqueue_box = [&](const int bit, const unsigned long long need, const bool nd, const int nneed) {
-            work += 1;
+            wp += PR_WORK(1);
             if (KK == 1) PRUNE_STAT(2, 1);
             const int bid = base + bit * a.S + s;
             const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need, 0u));
@@ -447,7 +496,7 @@ __device__ __forceinline__ void knn_pruned_wave(const KnnJob &jb, const int S, c
             const f2 e1 = {fmaxf(fmaxf(a1.x, c1.x), 0.f), fmaxf(fmaxf(a1.y, c1.y), 0.f)};
             const f2 e2 = {fmaxf(fmaxf(a2.x, c2.x), 0.f), fmaxf(fmaxf(a2.y, c2.y), 0.f)};
             const f2 lb = (e0 * e0 + e1 * e1) + e2 * e2;
-            work += 2;
+            wp += PR_WORK(2);
             PH(2);
 #pragma unroll 1   // one copy of the scan code (two copies cost 30 VGPRs of occupancy)
             for (int h = 0; h < (hasB ? 2 : 1); ++h) {
@@ -482,7 +531,7 @@ __device__ __forceinline__ void knn_pruned_wave(const KnnJob &jb, const int S, c
     PH(5);
     PH_FLUSH(0, 5);
     qx_o = qx; qy_o = qy; qz_o = qz;
-    work_o = work; pairs_o = pairs;
+    work_o = (int)(wp >> 20); pairs_o = wp & 0xFFFFFu;
 }
 
 
@@ -544,6 +593,7 @@ __global__ __launch_bounds__(64 * PR_SMAX, PR_WPE) void knn_group_kernel(Batched
         float *s_qc = (float *)(wl + 64 * 4);
         unsigned long long *s_key = (unsigned long long *)(wl + 64 * 4 + 64 * 16);
         unsigned int *s_q = (unsigned int *)(wl + 64 * 4 + 64 * 16 + 3 * 64 * 8);
+        static_assert(PR_QCAP >= 3 * 3 * 64, "neighbour seeds of a K = 3 item: 9 x 64 floats in the queue's space");
 #if PR_BOXLDS == 1          // the bounds of a coarse round's 64 boxes take the first 384 entries of the queue's space
         float *s_bb = (float *)s_q;
         s_q += 384;
@@ -559,11 +609,11 @@ __global__ __launch_bounds__(64 * PR_SMAX, PR_WPE) void knn_group_kernel(Batched
         const float *boxes_p = jb.boxes + (size_t)b * (jb.Ppad / NN_BOX) * 8;
         if (kind == 1) {
             float m1[1]; int b1[1];
-            knn_pruned_wave<1, false, QC, PR_BOXLDS != 0>(jb, S, a.sparse, b, g, s, cloud, jb.Ppad, boxes_p, s_tg, s_qc, s_q, s_bb, s_key,
+            knn_pruned_wave<1, false, QC, PR_BOXLDS != 0>(jb, S, a.sparse, b, g, s, cloud, jb.Ppad, boxes_p, s_tg, s_qc, s_q, s_bb, a.share, s_key,
                                                qx, qy, qz, m1, b1, work, pairs);
             bm[0] = m1[0]; bb[0] = b1[0];
         } else {
-            knn_pruned_wave<3, false, QC, PR_BOXLDS != 0>(jb, S, a.sparse, b, g, s, cloud, jb.Ppad, boxes_p, s_tg, s_qc, s_q, s_bb, s_key,
+            knn_pruned_wave<3, false, QC, PR_BOXLDS != 0>(jb, S, a.sparse, b, g, s, cloud, jb.Ppad, boxes_p, s_tg, s_qc, s_q, s_bb, a.share, s_key,
                                                qx, qy, qz, bm, bb, work, pairs);
         }
     }
@@ -697,11 +747,11 @@ __global__ __launch_bounds__(64 * PC_WAVES) void knn_cloud_kernel(SearchArgs a) 
         unsigned int *s_q = (unsigned int *)(wl + 64 * 16 + 3 * 64 * 8);
         if (kind == 1) {
             float m1[1]; int b1[1];
-            knn_pruned_wave<1, true, PC_QCAP, false>(jb, S, a.sparse, b, g, sl, cl, Ppad, bxs, nullptr, s_qc, s_q, nullptr, s_key, qx, qy, qz,
+            knn_pruned_wave<1, true, PC_QCAP, false>(jb, S, a.sparse, b, g, sl, cl, Ppad, bxs, nullptr, s_qc, s_q, nullptr, a.share, s_key, qx, qy, qz,
                                               m1, b1, work, pairs);
             bm[0] = m1[0]; bb[0] = b1[0];
         } else {
-            knn_pruned_wave<3, true, PC_QCAP, false>(jb, S, a.sparse, b, g, sl, cl, Ppad, bxs, nullptr, s_qc, s_q, nullptr, s_key, qx, qy, qz,
+            knn_pruned_wave<3, true, PC_QCAP, false>(jb, S, a.sparse, b, g, sl, cl, Ppad, bxs, nullptr, s_qc, s_q, nullptr, a.share, s_key, qx, qy, qz,
                                               bm, bb, work, pairs);
         }
         if (S > 1 && sl > 0) {
@@ -953,7 +1003,7 @@ extern "C" int reart_knn_points_idx_warm(const float *p1, const float *p2, int N
     jb.pd = (float *)(ws + p.o_pd); jb.pi = (int *)(ws + p.o_pi); jb.dists = dists; jb.idx = idx;
     a.job[1] = jb;
     SearchArgs sr = {};
-    sr.G = N * jb.nqg; sr.S1 = sr.S3 = p.S; sr.sparse = 40;
+    sr.G = N * jb.nqg; sr.S1 = sr.S3 = p.S; sr.sparse = 40; sr.share = 1;
     if (K == 1) { sr.k1[0] = jb; sr.n1 = 1; } else { sr.k3 = jb; sr.n3 = 1; }
     rc = reart_search_launch(sr, st);
     if (rc != REART_OK) return rc;

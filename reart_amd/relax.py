@@ -21,7 +21,7 @@ class RelaxConfig(ctypes.Structure):
                                                                                  ("use_assign", c_int), ("lambda_assign", c_float),
                                                                                  ("weight_decay", c_float)] + \
                [(n, c_int) for n in ("search_mode", "tune_slices", "tune_slices_flow", "tune_sparse", "tune_fwd_pts",
-                                     "tune_bwd_pts", "tune_reorder", "tune_cloud", "tune_xcd", "profile")]
+                                     "tune_bwd_pts", "tune_reorder", "tune_cloud", "tune_xcd", "profile", "tune_share")]
 
 
 def tuning_from_env(env=None):
@@ -45,6 +45,8 @@ def tuning_from_env(env=None):
         t["tune_cloud"] = max(0, geti("REART_CLOUD"))
     if env.get("REART_XCD") == "1":
         t["tune_xcd"] = 1
+    if env.get("REART_SHARE") == "0":
+        t["tune_share"] = -1
     return t
 
 
@@ -396,7 +398,7 @@ class RelaxBatch:
     # shape and switch fields of reart_relax_config that every engine of a batch must share
     SAME = ("N", "P", "B", "H", "M_max", "use_flow", "robust", "euclidean", "flow_k", "use_grid", "use_boxes", "use_assign",
             "search_mode", "tune_slices", "tune_slices_flow", "tune_sparse", "tune_fwd_pts", "tune_bwd_pts", "tune_reorder",
-            "tune_cloud", "tune_xcd")
+            "tune_cloud", "tune_xcd", "tune_share")
 
     def _refresh(self):
         """The argument blocks are VALUES: re-read them from the engines (an engine may have been given new noise, new

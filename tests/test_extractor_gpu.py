@@ -76,5 +76,6 @@ def test_extractor_matches_reference(dev):
     err = np.abs(feat.cpu().numpy() - ref)
     # ball-query membership and the 3-NN weights are the reference's bit for bit (matmul-expanded distances with
     # torch's CPU rounding); what is left is fp32 accumulation order (MFMA tiles vs the reference's sgemm)
-    assert err.max() <= 2e-4 * np.abs(ref).max(), (err.max(), np.abs(ref).max())
-    assert err.mean() <= 2e-5 * np.abs(ref).mean(), (err.mean(), np.abs(ref).mean())
+    print(f"\n[a9 @ N=1024] descriptor error: max {err.max() / np.abs(ref).max():.3e} of the scale, mean {err.mean() / np.abs(ref).mean():.3e} of the mean magnitude")
+    assert err.max() <= 2e-5 * np.abs(ref).max(), (err.max(), np.abs(ref).max())
+    assert err.mean() <= 5e-6 * np.abs(ref).mean(), (err.mean(), np.abs(ref).mean())

@@ -116,7 +116,7 @@ def test_row_mode_matches_torch_cpu(dev):
         np.testing.assert_array_equal(_row_mode(t(v, dev)).cpu().numpy(), torch.mode(torch.from_numpy(v), dim=1)[0].numpy())
 
 
-EXTRACTOR_TOL = 2e-4      # of the descriptors' scale (north_star: fp32 within 1e-4 relative); the measured error is printed
+EXTRACTOR_TOL = 1e-5      # of the descriptors' scale (north_star: fp32 within 1e-4 relative); measured on MI355X: 1.6e-6 (printed below)
 
 
 def _extractor(dev):
@@ -130,7 +130,7 @@ def _extractor(dev):
 
 def test_extractor_4096_reference_golden(dev):
     """The BASELINE extractor shape (flow_utils.py:123-124: clouds of 4096 points) against the reference's own
-    PointNet2Msg2: sampled coordinates bit-equal, descriptors within 2e-4 of their scale (fp32 MFMA accumulation
+    PointNet2Msg2: sampled coordinates bit-equal, descriptors within 1e-5 of their scale (measured 1.6e-6) (fp32 MFMA accumulation
     order vs the reference's sgemm; the 3-NN weights are the reference's bit for bit)."""
     g = np.load(os.path.join(G, "extractor_4096.npz"))
     model = _extractor(dev)
@@ -150,7 +150,7 @@ def test_extractor_4096_reference_golden(dev):
           f"({np.abs(ref).max():.3f}), mean {err.mean():.3e} = {err.mean() / np.abs(ref).mean():.3e} of the mean magnitude; "
           f"sa2 output: max {l2e.max():.3e} of scale {np.abs(g['l2_points']).max():.3f}")
     assert err.max() <= EXTRACTOR_TOL * np.abs(ref).max(), (err.max(), np.abs(ref).max())
-    assert err.mean() <= 2e-5 * np.abs(ref).mean()
+    assert err.mean() <= 5e-6 * np.abs(ref).mean()
     # CUDA sampling rules (what the reference computes on a GPU): start 0, d2 < r2, padded with the first hit
     feat_c = model(xyz).cpu().numpy()            # the package default: pointnet2_utils.CUDA = True
     l1c, _ = model.sa1.run(pts, pts)

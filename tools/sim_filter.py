@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Offline model of the search filter's WORK on a dumped state (tools/dump_state.py): how many tests the present
+decomposition executes and what alternatives would.  numpy; float32 bounds like the kernel's.
+    python tools/sim_filter.py gpurun_out/state.npz 300"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+def nn_brute(q, t):
+    d = ((q[:, None, :] - t[None]) ** 2).sum(-1)
+    return d.argmin(1), d.min(1)
+
+def boxes_of(t):                      # [n,3] -> lo, hi [n/16,3]
+    n = t.shape[0]; nb = (n + 15) // 16
+    pad = np.full((nb * 16, 3), np.nan, np.float32); pad[:n] = t
+    g = pad.reshape(nb, 16, 3)
+    return np.nanmin(g, 1), np.nanmax(g, 1)
+
+def lb_pt_box(q, lo, hi):             # [m,3] x [nb,3] -> [m,nb]
+    e = np.maximum(np.maximum(lo[None] - q[:, None], q[:, None] - hi[None]), 0)
+    return (e ** 2).sum(-1)
+
+def lb_box_box(qlo, qhi, lo, hi):
+    e = np.maximum(np.maximum(lo[None] - qhi[:, None], qlo[:, None] - hi[None]), 0)
+    return (e ** 2).sum(-1)
+
+def analyse(Q, Qprev, T, Tprev, name, K=1):
+    """one job: queries Q [B,N,3] (previous positions Qprev), targets T [B,M,3] (Tprev)."""
+    acc = {}
+    def add(k, v): acc[k] = acc.get(k, 0) + v
+    B = Q.shape[0]
+    for b in range(B):
+        q, t = Q[b], T[b]
+        dprev = ((Qprev[b][:, None, :] - Tprev[b][None]) ** 2).sum(-1)
+        seed = np.argsort(dprev, 1)[:, :K]
+        dcur = ((q[:, None, :] - t[None]) ** 2).sum(-1)
+        thr0 = np.take_along_axis(dcur, seed, 1).max(1)            # initial bound
+        thr1 = np.sort(dcur, 1)[:, K - 1]                          # final bound (true K-th distance)
+        lo, hi = boxes_of(t)
+        nb = lo.shape[0]
+        lbp = lb_pt_box(q, lo, hi)                                 # [N, nb]
+        need0 = lbp <= thr0[:, None]                               # needed under the initial bound
+        need1 = lbp <= thr1[:, None]
+        N = q.shape[0]
+        for g in range(0, N, 64):
+            sl = slice(g, g + 64)
+            add("waves", 1)
+            # present: 4 sub-group AABBs with the sub-group's largest thr
+            sub_pass = np.zeros((4, nb), bool)
+            for s4 in range(4):
+                ss = slice(g + 16 * s4, g + 16 * s4 + 16)
+                lbb = lb_box_box(q[ss].min(0)[None], q[ss].max(0)[None], lo, hi)[0]
+                sub_pass[s4] = lbb <= thr0[ss].max()
+            coarse = sub_pass.any(0)
+            add("coarse_survivors", coarse.sum())
+            add("sub_survivors_sum", sub_pass.sum())
+            add("sub_survivors_max", sub_pass.sum(1).max())
+            un0 = need0[sl].any(0); un1 = need1[sl].any(0)
+            add("union_initial", un0.sum()); add("union_final", un1.sum())
+            add("entries_initial", need0[sl].sum()); add("entries_final", need1[sl].sum())
+            # per sub-group: boxes some lane of the sub-group needs
+            add("sub_union_sum", sum(need0[g + 16 * s4:g + 16 * s4 + 16].any(0).sum() for s4 in range(4)))
+            add("sub_union_max", max(need0[g + 16 * s4:g + 16 * s4 + 16].any(0).sum() for s4 in range(4)))
+            add("lane_max", need0[sl].sum(1).max())
+            # 8-lane groups
+            add("oct_survivors_sum", sum((lb_box_box(q[g + 8 * o:g + 8 * o + 8].min(0)[None], q[g + 8 * o:g + 8 * o + 8].max(0)[None], lo, hi)[0]
+                                          <= thr0[g + 8 * o:g + 8 * o + 8].max()).sum() for o in range(8)))
+            # super-boxes of 8 boxes (128 targets): per-lane precise on 32 super-boxes
+            slo = lo.reshape(-1, 8, 3).min(1) if nb % 8 == 0 else None
+            if slo is not None:
+                shi = hi.reshape(-1, 8, 3).max(1)
+                sneed = lb_pt_box(q[sl], slo, shi) <= thr0[sl, None]
+                add("super_union", sneed.any(0).sum()); add("super_entries", sneed.sum())
+    w = acc.pop("waves")
+    print(f"{name}: {w} waves; per wave:", {k: round(v / w, 1) for k, v in acc.items()})
+    return acc
+
+def main():
+    path, it = sys.argv[1], sys.argv[2]
+    d = np.load(path)
+    cur, prev, pcs, cano = d[f"cur_{it}"], d[f"prev_{it}"], d["pc_list"], d["cano"]
+    frames = [int(f) for f in (sys.argv[3].split(",") if len(sys.argv) > 3 else range(cur.shape[0]))]
+    analyse(cur[frames], prev[frames], pcs[frames], pcs[frames], "x->y (queries move, static targets)")
+    analyse(pcs[frames], pcs[frames], cur[frames], prev[frames], "y->x (static queries, targets move)")
+    c = int(d["cano_idx"]); off = d["ref_off"]
+    comp = np.concatenate([cur[:c], cano[None], cur[c:]]); compp = np.concatenate([prev[:c], cano[None], prev[c:]])
+    for f in frames[:4]:
+        r = d["ref_loc"][off[f]:off[f + 1]]
+        analyse(comp[f][None], compp[f][None], r[None], r[None], f"flow K=3 frame {f}", K=3)
+
+main()
