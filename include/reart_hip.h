@@ -226,7 +226,8 @@ typedef struct reart_relax_config {
     int profile;             /* 1: the search launch of every iteration records per-workgroup wall-clock stamps and  */
                              /*    its executed distance evaluations, reduced on the device (reart_relax_profile)    */
     int tune_share;          /* < 0: a query's search bound comes from its own seeds only; default: also from the    */
-                             /*    seeds of the 15 neighbouring queries of its row (same results, fewer boxes)       */
+                             /*    seeds of the 15 neighbouring queries of its row (same results, fewer boxes), the  */
+                             /*    candidates split over the waves of the search workgroup; 1: every wave all of them */
 } reart_relax_config;
 
 typedef struct reart_relax_buffers {

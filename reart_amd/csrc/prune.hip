@@ -66,7 +66,8 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #define PR_COARSE_PACKED 1
 #endif
 #ifndef PR_WPE
-#define PR_WPE 1         // minimum waves per SIMD the compiler must allow for (register budget)
+#define PR_WPE 6         // waves per SIMD the compiler must allow for (register budget: 85 -> 80 VGPRs; the kernel sits at the
+                         // edge -- 78 under this bound, 82 without it, no spills either way -- and the sixth wave is worth 7 %)
 #endif
 // LDS per wave: staged box of a dense scan [64 floats] | the wave's queries [64][4] | result slots [3][64] u64 | queue
 // PR_BOXLDS 1: the precise filter reads a surviving box's bounds back from LDS (broadcast ds_read, the LDS pipe is idle) instead of
@@ -105,6 +106,8 @@ extern "C" int reart_debug_prune_phase(unsigned long long *out, int reset) {
 #define PH(k) do { } while (0)
 #define PH_FLUSH(from, to) do { } while (0)
 #endif
+
+#define PR_WORK(w) ((unsigned)(w) << 20)   // the work count lives in bits 20..31 of a wave's statistics counter, the pairs below
 
 // min / max of a lane's value with a DPP-permuted copy in ONE instruction (v_min_f32_dpp).  Written through the compiler
 // the same step is three (v_mov_b32_dpp, a canonicalising v_max v,v -- fminf of a value of unknown origin -- and the
@@ -151,7 +154,7 @@ __device__ __forceinline__ float box_lb(float lo0, float lo1, float lo2, float h
 template <int KK, bool LDSV, int QCAP, bool BOXL>
 __device__ __forceinline__ void knn_pruned_wave(const KnnJob &jb, const int S, const int sparse, const int b, const int g,
                                                 const int s, const float *cloud, const int cstride, const float *boxes_p,
-                                                float *s_tg, float *s_qc, unsigned int *s_q, float *s_bb, const int share,
+                                                float *s_tg, float *s_qc, unsigned int *s_q, float *s_bb, const int share, float *s_xthr,
                                                 unsigned long long *s_key, float &qx_o, float &qy_o, float &qz_o,
                                                 float (&bm)[KK], int (&bb)[KK], int &work_o, unsigned int &pairs_o) {
     struct { int S, sparse; } a = {S, sparse};
@@ -174,6 +177,7 @@ __device__ __forceinline__ void knn_pruned_wave(const KnnJob &jb, const int S, c
 
     // ---- warm start
     float thr = 0.f;
+    unsigned int wp = 0u;             // statistics counter, see PR_WORK below
     {
         const int *sd = jb.seed + ((size_t)b * jb.P1 + ic) * KK;
         int sj[KK];
@@ -201,8 +205,14 @@ __device__ __forceinline__ void knn_pruned_wave(const KnnJob &jb, const int S, c
             }
             thr = INFINITY;
             const float *row = s_scr + (lane & 48);
+            // s_xthr (the workgroup's exchange array [S][64]): the S waves of the workgroup hold the same 64 queries, so each
+            // evaluates every S-th candidate pair and the partial bounds meet after ONE barrier (at the start of the waves'
+            // lives, where they still run side by side); without it every wave evaluates all 16 candidates
+            const bool split = s_xthr != nullptr && a.S > 1;
+            const int c0 = split ? 2 * s : 0, cstep = split ? 2 * a.S : 2;
+            wp = 64u * KK * 2u * (unsigned)((16 - c0 + cstep - 1) / cstep);   // the seed candidates this wave evaluates
 #pragma unroll 1      // rolled: unrolled, the 72 LDS loads of a K = 3 item in flight cost 25 VGPRs, i.e. two resident waves per SIMD
-            for (int c = 0; c < 16; c += 2) {
+            for (int c = c0; c < 16; c += cstep) {
                 f2 far = {0.f, 0.f};
 #pragma unroll
                 for (int k = 0; k < KK; ++k) {
@@ -214,6 +224,11 @@ __device__ __forceinline__ void knn_pruned_wave(const KnnJob &jb, const int S, c
                 }
                 thr = fminf(thr, fminf(far.x, far.y));
             }
+            if (split) {
+                s_xthr[64 * s + lane] = thr;
+                __syncthreads();                     // every live wave of the workgroup runs this prologue (waves >= S have left)
+                for (int t = 0; t < a.S; ++t) thr = fminf(thr, s_xthr[64 * t + lane]);
+            }
             if (!(thr >= 0.f)) thr = INFINITY;      // NaN query
         } else {
 #pragma unroll
@@ -221,6 +236,7 @@ __device__ __forceinline__ void knn_pruned_wave(const KnnJob &jb, const int S, c
                 const int j = ok ? sj[k] : 0;
                 thr = fmaxf(thr, reart_sqdist3(qx, qy, qz, tx[j], ty[j], tz[j]));
             }
+            wp = 64u * KK;
             if (!ok || !(thr >= 0.f)) thr = INFINITY;   // unusable seeds / NaN: no pruning for this lane
         }
     }
@@ -242,8 +258,7 @@ __device__ __forceinline__ void knn_pruned_wave(const KnnJob &jb, const int S, c
     const float *tx_g = tx;
     // ONE uniform counter for both statistics (a scalar register less, one s_add per event): bits 0..19 the distance
     // evaluations (< 2^20 per wave), bits 20..31 the work count that orders the next launch (a heuristic: overflow is harmless)
-#define PR_WORK(w) ((unsigned)(w) << 20)
-    unsigned int wp = PR_WORK(16) | (64u * KK * (share ? 17u : 1u));   // prologue ~ 16 tests; the seeds (the row's 16 lanes)
+    wp |= PR_WORK(16);                                                   // prologue ~ 16 tests
 
     const int queue_max = a.sparse;   // boxes needed by at most this many queries go through the (query, box) queue (0: off)
     int qcnt = 0;                     // entries in the wave's queue (uniform)
@@ -548,6 +563,7 @@ __global__ __launch_bounds__(64 * PR_SMAX, PR_WPE) void knn_group_kernel(Batched
 #define PARK_M(t) ((float *)(s_dyn + (size_t)(t) * PR_LDS_WAVE_BYTES + 64 * 4 + 64 * 16))
 #define PARK_B(t) ((int *)(s_dyn + (size_t)(t) * PR_LDS_WAVE_BYTES + 64 * 4 + 64 * 16 + 3 * 64 * 4))
     __shared__ unsigned int s_wk[PR_SMAX][2];
+    __shared__ float s_xthr[PR_SMAX][64];   // the waves' partial neighbour-seed bounds (written once, read after one barrier)
     __shared__ unsigned int s_ticket;
     __shared__ unsigned long long s_t0;
     if (threadIdx.x == 0) { s_ticket = 0u; s_t0 = a.prof ? wall_clock64() : 0ull; }
@@ -609,11 +625,11 @@ __global__ __launch_bounds__(64 * PR_SMAX, PR_WPE) void knn_group_kernel(Batched
         const float *boxes_p = jb.boxes + (size_t)b * (jb.Ppad / NN_BOX) * 8;
         if (kind == 1) {
             float m1[1]; int b1[1];
-            knn_pruned_wave<1, false, QC, PR_BOXLDS != 0>(jb, S, a.sparse, b, g, s, cloud, jb.Ppad, boxes_p, s_tg, s_qc, s_q, s_bb, a.share, s_key,
+            knn_pruned_wave<1, false, QC, PR_BOXLDS != 0>(jb, S, a.sparse, b, g, s, cloud, jb.Ppad, boxes_p, s_tg, s_qc, s_q, s_bb, a.share, a.share > 1 ? &s_xthr[0][0] : nullptr, s_key,
                                                qx, qy, qz, m1, b1, work, pairs);
             bm[0] = m1[0]; bb[0] = b1[0];
         } else {
-            knn_pruned_wave<3, false, QC, PR_BOXLDS != 0>(jb, S, a.sparse, b, g, s, cloud, jb.Ppad, boxes_p, s_tg, s_qc, s_q, s_bb, a.share, s_key,
+            knn_pruned_wave<3, false, QC, PR_BOXLDS != 0>(jb, S, a.sparse, b, g, s, cloud, jb.Ppad, boxes_p, s_tg, s_qc, s_q, s_bb, a.share, a.share > 1 ? &s_xthr[0][0] : nullptr, s_key,
                                                qx, qy, qz, bm, bb, work, pairs);
         }
     }
@@ -747,11 +763,11 @@ __global__ __launch_bounds__(64 * PC_WAVES) void knn_cloud_kernel(SearchArgs a) 
         unsigned int *s_q = (unsigned int *)(wl + 64 * 16 + 3 * 64 * 8);
         if (kind == 1) {
             float m1[1]; int b1[1];
-            knn_pruned_wave<1, true, PC_QCAP, false>(jb, S, a.sparse, b, g, sl, cl, Ppad, bxs, nullptr, s_qc, s_q, nullptr, a.share, s_key, qx, qy, qz,
+            knn_pruned_wave<1, true, PC_QCAP, false>(jb, S, a.sparse, b, g, sl, cl, Ppad, bxs, nullptr, s_qc, s_q, nullptr, a.share, nullptr, s_key, qx, qy, qz,
                                               m1, b1, work, pairs);
             bm[0] = m1[0]; bb[0] = b1[0];
         } else {
-            knn_pruned_wave<3, true, PC_QCAP, false>(jb, S, a.sparse, b, g, sl, cl, Ppad, bxs, nullptr, s_qc, s_q, nullptr, a.share, s_key, qx, qy, qz,
+            knn_pruned_wave<3, true, PC_QCAP, false>(jb, S, a.sparse, b, g, sl, cl, Ppad, bxs, nullptr, s_qc, s_q, nullptr, a.share, nullptr, s_key, qx, qy, qz,
                                               bm, bb, work, pairs);
         }
         if (S > 1 && sl > 0) {
@@ -1003,7 +1019,7 @@ extern "C" int reart_knn_points_idx_warm(const float *p1, const float *p2, int N
     jb.pd = (float *)(ws + p.o_pd); jb.pi = (int *)(ws + p.o_pi); jb.dists = dists; jb.idx = idx;
     a.job[1] = jb;
     SearchArgs sr = {};
-    sr.G = N * jb.nqg; sr.S1 = sr.S3 = p.S; sr.sparse = 40; sr.share = 1;
+    sr.G = N * jb.nqg; sr.S1 = sr.S3 = p.S; sr.sparse = 40; sr.share = 2;
     if (K == 1) { sr.k1[0] = jb; sr.n1 = 1; } else { sr.k3 = jb; sr.n3 = 1; }
     rc = reart_search_launch(sr, st);
     if (rc != REART_OK) return rc;

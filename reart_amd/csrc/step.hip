@@ -782,7 +782,7 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
     bool search_static_order = false;
     if (p.pruned) {
         SearchArgs sa = {};
-        sa.G = B * nqg; sa.S1 = p.W1; sa.S3 = p.W3; sa.sparse = p.sparse; sa.share = c.tune_share < 0 ? 0 : 1; sa.interleave = c.tune_xcd > 0 ? 0 : 1;
+        sa.G = B * nqg; sa.S1 = p.W1; sa.S3 = p.W3; sa.sparse = p.sparse; sa.share = c.tune_share < 0 ? 0 : (c.tune_share == 1 ? 1 : 2); sa.interleave = c.tune_xcd > 0 ? 0 : 1;
         sa.cloud_resident = c.tune_cloud > 0 ? 1 : 0; sa.cloud_slices = c.tune_cloud > 0 ? c.tune_cloud : 0;
         if (chamfer) { sa.k1[0] = ka.job[0]; sa.k1[1] = ka.job[1]; sa.n1 = 2; }
         if (c.use_flow) { sa.k3 = k3.job[0]; sa.n3 = 1; }

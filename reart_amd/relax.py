@@ -45,8 +45,8 @@ def tuning_from_env(env=None):
         t["tune_cloud"] = max(0, geti("REART_CLOUD"))
     if env.get("REART_XCD") == "1":
         t["tune_xcd"] = 1
-    if env.get("REART_SHARE") == "0":
-        t["tune_share"] = -1
+    if env.get("REART_SHARE") in ("0", "1"):        # 0: own seeds only; 1: neighbour seeds, every wave all candidates
+        t["tune_share"] = -1 if env["REART_SHARE"] == "0" else 1
     return t
 
 

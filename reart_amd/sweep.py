@@ -54,6 +54,50 @@ def instance_energy(eng, spec, **thresholds):
     return res
 
 
+class _CaptureGate:
+    """Graph capture on one thread and GPU work (allocation, frees, synchronisation) on others do not mix: on this stack a
+    tensor freed by a worker thread while the main thread had a capture open ended the process (segmentation fault), even
+    in thread-local capture mode.  The tails of finished instances therefore run as READERS of this gate and every capture
+    as its one WRITER: replays and eager launches overlap the tails as before, a capture waits for the tails in flight."""
+
+    def __init__(self):
+        import threading
+
+        self._cv, self._readers, self._writer = threading.Condition(), 0, False
+
+    def tail(self):
+        gate = self
+
+        class _R:
+            def __enter__(self):
+                with gate._cv:
+                    while gate._writer:
+                        gate._cv.wait()
+                    gate._readers += 1
+
+            def __exit__(self, *exc):
+                with gate._cv:
+                    gate._readers -= 1
+                    gate._cv.notify_all()
+        return _R()
+
+    def capture(self):
+        gate = self
+
+        class _W:
+            def __enter__(self):
+                with gate._cv:
+                    while gate._writer or gate._readers:
+                        gate._cv.wait()
+                    gate._writer = True
+
+            def __exit__(self, *exc):
+                with gate._cv:
+                    gate._writer = False
+                    gate._cv.notify_all()
+        return _W()
+
+
 def shard(n_instances, rank, world):
     """Static round-robin assignment: instance i runs on rank i % world."""
     return list(range(rank, n_instances, world))
@@ -124,6 +168,7 @@ def run_sweep_engines(instances, make_engine, n_iter, device, per_gpu=3, chunk=1
     local = {}
     threads = os.environ.get("REART_SWEEP_THREADS", "1") != "0"
     pool, pending = None, []
+    gate = _CaptureGate()
     for g0 in range(0, len(mine), per_gpu):
         group = mine[g0:g0 + per_gpu]
         live = []
@@ -133,7 +178,10 @@ def run_sweep_engines(instances, make_engine, n_iter, device, per_gpu=3, chunk=1
             try:
                 with torch.cuda.stream(st):
                     eng = make_engine(spec)
-                    done = eng.capture(steps_per_graph=min(chunk, n_iter)) if mode == "streams" else 0
+                    done = 0
+                    if mode == "streams":
+                        with gate.capture():
+                            done = eng.capture(steps_per_graph=min(chunk, n_iter))
                 live.append([inst, spec, eng, st, done])
             except Exception:  # a failed instance is reported (NaN energy), it does not kill the job
                 local[inst] = _record(inst, spec, failed=1)
@@ -149,7 +197,10 @@ def run_sweep_engines(instances, make_engine, n_iter, device, per_gpu=3, chunk=1
                     # capture() runs its first step eagerly: an engine the batched entry does not implement
                     # (REART_ERR_UNSUPPORTED) shows up there, before a capture is open, and the group takes the streams
                     # path below instead
-                    used = batch.capture(steps_per_graph=min(chunk, n_iter - 1)) if n_iter > 1 else 0
+                    used = 0
+                    if n_iter > 1:
+                        with gate.capture():
+                            used = batch.capture(steps_per_graph=min(chunk, n_iter - 1))
                     batch.step(n_iter - used)
                     for e in part:
                         e[4] = n_iter
@@ -164,7 +215,7 @@ def run_sweep_engines(instances, make_engine, n_iter, device, per_gpu=3, chunk=1
 
                         warnings.warn(f"sweep: batch of {len(part)} instances falls back to streams ({type(exc).__name__}: {exc})")
                         for e in part:
-                            with torch.cuda.stream(e[3]):
+                            with torch.cuda.stream(e[3]), gate.capture():
                                 e[4] = e[2].capture(steps_per_graph=min(chunk, n_iter))
             torch.cuda.current_stream(device).synchronize()
         while any(e[4] < n_iter for e in live):          # streams: round-robin graph replays (nothing left to do after a batch)
@@ -175,6 +226,10 @@ def run_sweep_engines(instances, make_engine, n_iter, device, per_gpu=3, chunk=1
                         e[2].step(n)
                     e[4] += n
         def finish(entry):
+            with gate.tail():
+                return _finish(entry)
+
+        def _finish(entry):
             inst, spec, eng, st, done = entry
             st.synchronize()
             row = eng.last_losses().cpu()
@@ -183,8 +238,13 @@ def run_sweep_engines(instances, make_engine, n_iter, device, per_gpu=3, chunk=1
                 try:
                     with torch.cuda.stream(st):
                         en = instance_energy(eng, spec)
-                except Exception:      # e.g. every part merged away: the losses still describe the instance
+                except Exception as exc:      # e.g. every part merged away: the losses still describe the instance
+                    import sys
+                    import traceback
+
                     en = None
+                    print(f"sweep: instance {inst} ({spec}) has no energy: {type(exc).__name__}: {exc}\n"
+                          + "".join(traceback.format_exception(type(exc), exc, exc.__traceback__)[-3:]), file=sys.stderr)
             if on_finish is not None:
                 on_finish(inst, spec, eng, en)
             return inst, _record(inst, spec, (float(row[0]), float(row[1]), float(row[2])), done, 0, en)
