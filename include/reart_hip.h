@@ -213,7 +213,7 @@ typedef struct reart_relax_config {
     int tune_slices;         /* waves (box slices) per search workgroup, 1..4 (default 3)  */
     int tune_slices_flow;    /* the same for the K = 3 flow search (default: tune_slices)  */
     int tune_sparse;         /* boxes needed by <= n queries of a wave go through the (query, box) queue instead of a  */
-                             /* 64-lane scan: 1..64 (default 20), < 0: dense scans only                                */
+                             /* 64-lane scan: 1..64 (default 40), < 0: dense scans only                                */
     int tune_fwd_pts;        /* points per forward workgroup: 64 | 32 (default 32)         */
     int tune_bwd_pts;        /* points per backward workgroup: 64 | 32 | 16 (default 32)   */
     int tune_reorder;        /* < 0: keep the static launch order of the search items      */

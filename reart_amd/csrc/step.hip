@@ -58,7 +58,7 @@ static int step_plan(const reart_relax_config *c, StepPlan *p) {
     // pruned: ONE record per query (S = 1 in the consumers); the box slices are the waves of a search workgroup
     p->W1 = (c->tune_slices >= 1 && c->tune_slices <= 4) ? c->tune_slices : 3;
     p->W3 = (c->tune_slices_flow >= 1 && c->tune_slices_flow <= 4) ? c->tune_slices_flow : p->W1;
-    p->sparse = c->tune_sparse < 0 ? 0 : (c->tune_sparse == 0 ? 20 : (c->tune_sparse > 64 ? 64 : c->tune_sparse));
+    p->sparse = c->tune_sparse < 0 ? 0 : (c->tune_sparse == 0 ? 40 : (c->tune_sparse > 64 ? 64 : c->tune_sparse));
     p->S1 = p->pruned ? 1 : reart_knn_pick_split(waves1, c->N, 1);
     p->L1 = (int)reart_align_up((size_t)reart_div_up(c->N, p->S1), NN_BOX);
     p->Npad = p->L1 * p->S1;
