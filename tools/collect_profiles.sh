@@ -1,31 +1,29 @@
 #!/bin/bash
-# Round-2 measurement evidence, collected on the GPU box (gpurun): the bench lines, rocprofv3 kernel stats of the bench
-# commands and the counter passes of the search kernel.  Outputs under gpurun_out/prof2/ (copied into profiles/ afterwards).
+# Measurement evidence of a round, collected on the GPU box (gpurun): the bench lines, rocprofv3 kernel stats of the bench
+# commands and the counter passes of the search kernel.  Outputs under gpurun_out/prof3/ (copied into profiles/ afterwards).
 # Every command runs under `timeout`: a hang must not take the box.
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
-O=gpurun_out/prof2
+O=gpurun_out/prof3
 rm -rf $O; mkdir -p $O
-CLEAN="--sweep-instances 0 --no-tail --no-cpu-baseline"
+CLEAN="--sweep-instances 0 --no-tail --no-cpu-baseline --no-secondary"
 # 0. the plain bench lines (no profiler)
-timeout 600 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
+timeout 900 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
 timeout 600 python3 bench.py --config kinematic > $O/bench_kinematic.json 2> $O/bench_kinematic.err
 timeout 300 python3 bench.py --config extractor > $O/bench_extractor.json 2> $O/bench_extractor.err
-timeout 300 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_driver_args.json 2> $O/bench_driver_args.err
+timeout 300 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > $O/bench_driver_args.json 2> $O/bench_driver_args.err
 # 1. kernel stats of the clean headline command (every launch belongs to the measured instance)
 timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $O/stats_clean -- python3 bench.py $CLEAN > $O/bench_clean_under_rocprof.json 2> $O/stats_clean.err
-# 2. kernel stats of the DEFAULT command (sweep, tail and CPU baselines included; the three sweep streams serialise under the tracer)
-timeout 900 rocprofv3 --kernel-trace --stats -f csv -d $O/stats_default -- python3 bench.py > $O/bench_default_under_rocprof.json 2> $O/stats_default.err
-# 3. counter passes (separate runs, --kernel-trace only), eager launches so that every dispatch is visible
+# 2. counter passes (separate runs, --kernel-trace only), eager launches so that every dispatch is visible
 for C in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_SALU SQ_INSTS_LDS; do
   timeout 600 rocprofv3 --kernel-trace --pmc $C -f csv -d $O/pmc_$C -- python3 bench.py --steps 300 --warmup 150 --no-graph --profile-steps 0 $CLEAN > $O/pmc_$C.json 2> $O/pmc_$C.err
 done
-# 4. the other two configs
+# 3. the other two configs
 timeout 900 rocprofv3 --kernel-trace --stats -f csv -d $O/stats_kinematic -- python3 bench.py --config kinematic --no-cpu-baseline > $O/bench_kinematic_under_rocprof.json 2> $O/stats_kinematic.err
-timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $O/stats_extractor -- python3 bench.py --config extractor > $O/bench_extractor_under_rocprof.json 2> $O/stats_extractor.err
+timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $O/stats_extractor -- python3 bench.py --config extractor --no-cpu-baseline > $O/bench_extractor_under_rocprof.json 2> $O/stats_extractor.err
 # summaries
-for d in stats_clean stats_default stats_kinematic stats_extractor; do
+for d in stats_clean stats_kinematic stats_extractor; do
   f=$(find $O/$d -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/$d.kernel_stats.csv
 done
 for C in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_SALU SQ_INSTS_LDS; do
