@@ -653,11 +653,11 @@ def main():
             executed = prof["pairs"] / prof["launches"]
             ach = executed * 8 / t_nn / 1e12
             traffic = None
-            pmc = os.path.join(ROOT, "profiles", "r02_pmc_search.json")
+            pmc = os.path.join(ROOT, "profiles", "r03_pmc_search.json")
             if os.path.exists(pmc) and use_flow:
                 pj = json.load(open(pmc))
                 traffic = {"bytes_per_launch": pj.get("hbm_bytes_per_launch"),
-                           "source": "static: profiles/r02_pmc_search.json (rocprofv3 --pmc passes of this command, "
+                           "source": "static: profiles/r03_pmc_search.json (rocprofv3 --pmc passes of this command, "
                                      "corrected per MI355X_MICROARCH.md); not measured in this run"}
             roof = {"bound": "valu", "achieved": round(ach, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / FP32_PEAK_TFLOPS, 4), "traffic": traffic,

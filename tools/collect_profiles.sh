@@ -8,6 +8,12 @@ export TMPDIR=/tmp
 O=gpurun_out/prof3
 rm -rf $O; mkdir -p $O
 CLEAN="--sweep-instances 0 --no-tail --no-cpu-baseline --no-secondary"
+# gpurun boxes differ: about one in ten runs the search launch 35 % slower than the others (every other kernel the same, four
+# times the fabric traffic on its counters).  The profile set is collected on a box of the common kind; the odd kind is
+# reported and skipped (exit 7) so that the call can simply be repeated.
+KMS=$(timeout 300 python3 bench.py --steps 300 --warmup 150 $CLEAN --profile-steps 0 2>/dev/null | python3 -c "import json,sys; print(json.loads(sys.stdin.read())['roofline']['kernel_ms'])")
+echo "probe: search launch $KMS ms"
+if python3 -c "import sys; sys.exit(0 if float('$KMS') > 0.038 else 1)"; then echo "slow-search box: profile set not collected"; exit 7; fi
 # 0. the plain bench lines (no profiler)
 timeout 900 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
 timeout 600 python3 bench.py --config kinematic > $O/bench_kinematic.json 2> $O/bench_kinematic.err
