@@ -372,6 +372,17 @@ int reart_mlp_layer(const float *X, int ldx, const int64_t *gather_idx, int K, i
                     const float *Wt, const float *bias, int rows, int Cin, int Cout, int relu,
                     int pool_k, float *Y, int ldy, int ycol0, void *stream);
 
+/* Three such layers in ONE launch for a scale of the first set-abstraction level (PointNetSetAbstractionMsg,
+ * networks/pointnet2_utils.py:257-295): gathered input [F (3) | Q - C] (6 columns) -> C1 -> C2 -> C3 (each with bias and
+ * ReLU) -> max over the K rows of a group; the activations between the layers never leave the compute unit (LDS).
+ * Same arguments as the gathered form of reart_mlp_layer (D = 3, xyz_first = 0, pool_k = K); rows = B*S*K.
+ * Bit-identical to three reart_mlp_layer calls.  Built for the extractor's three scales, (C1, C2, C3, K) =
+ * (32, 32, 64, 32), (64, 64, 128, 64), (64, 96, 128, 128) (networks/feature_extractor.py:19-21); anything else returns
+ * REART_ERR_UNSUPPORTED (call the layers one by one). */
+int reart_mlp_chain3(const int64_t *gather_idx, int K, int S, int Npts, const float *F, const float *Q, const float *C,
+                     const float *W1t, const float *b1, int C1, const float *W2t, const float *b2, int C2,
+                     const float *W3t, const float *b3, int C3, int rows, float *Y, int ldy, int ycol0, void *stream);
+
 /* 3-NN inverse-distance interpolation of PointNetFeaturePropagation
  * (networks/pointnet2_utils.py:326-336): xyz1 [B,N,3], xyz2 [B,S2,3], points2 [B,S2,D] ->
  * out [B*N, ldo] columns col0 .. col0 + D (so the cat with the skip features, :338-342, is free).

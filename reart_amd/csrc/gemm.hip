@@ -231,6 +231,185 @@ extern "C" int reart_mlp_layer(const float *X, int ldx, const int64_t *gather_id
 }
 
 // ---------------------------------------------------------------------------------------
+// Three layers in ONE launch for the first set-abstraction level (PointNetSetAbstractionMsg of sa1,
+// networks/pointnet2_utils.py:257-295 with networks/feature_extractor.py:19-21: grouped [features(3) | xyz - centre(3)]
+// -> C1 -> C2 -> C3 -> max over the K samples of a group).  Layer by layer the two narrow layers of every scale were bound
+// by memory, not by the matrix cores: their activations ([B S K, C] floats, 0.6 .. 1.2 GB per scale at T = 20) were
+// written by one launch and read back by the next at 3-4 TB/s.  Here a wave keeps its 32 rows through all three layers:
+//   * the weights of the three layers live in LDS for the lifetime of a (persistent) workgroup, which loops over row tiles;
+//   * layer 1 (K = 6) takes its A fragments straight from the gather; its output goes through the wave's PRIVATE
+//     32 x C activation tile in LDS -- from the accumulator layout (row = f(register, lane / 32), column = lane % 32) to
+//     the A-fragment layout (row = lane % 32, k = lane / 32) -- and feeds layer 2, whose output takes the same way into
+//     layer 3; no barrier between the layers (LDS operations of a wave complete in order);
+//   * the epilogue of layer 3 is the single-layer kernel's: bias, ReLU, max over the wave's rows, the waves of a group
+//     meet in LDS.
+// Every accumulator sees its k in the same ascending order through the same instruction as in mlp_gemm_kernel (whose
+// K padding only adds exact zeros), so the result equals the three-launch path BIT FOR BIT (tests/test_extractor_gpu.py).
+// LDS strides: weights C + 4 (as in mlp_gemm_kernel), activations C + 2 (= 2 mod 4: the 32 rows of a fragment fall on 32
+// distinct even banks, its second k on the odd ones).
+struct Chain3Args {
+    const int64_t *idx; int K, S, Npts;
+    const float *F, *Q, *C;           // features [B*Npts,3], xyz [B*Npts,3], centres [B*S,3]
+    const float *W1, *b1, *W2, *b2, *W3, *b3;   // transposed weights [Cin,Cout], biases
+    int rows;
+    float *Y; int ldy, ycol0;
+};
+__host__ __device__ constexpr int chain_ldb(int c) { return c + 4; }   // like mlp_gemm_kernel's B tile
+__host__ __device__ constexpr int chain_lda(int c) { return c + 2; }   // = 2 (mod 4): 32 rows on 32 distinct even banks, k + 1 on the odd ones
+
+template <int NB, int LDB>
+__device__ __forceinline__ void chain_layer(const float *__restrict__ Hw, int lda, const float *__restrict__ Ws, int Cin, f16v (&acc)[NB],
+                                            int lane) {
+    const int kh = lane >> 5, lr = lane & 31;
+#pragma unroll 4
+    for (int kk = 0; kk < Cin; kk += 2) {
+        const float av = Hw[lr * lda + kk + kh];
+#pragma unroll
+        for (int n = 0; n < NB; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Ws[(kk + kh) * LDB + 32 * n + lr], acc[n], 0, 0, 0);
+    }
+}
+// bias + ReLU of an accumulator tile, written into the wave's activation tile in A-fragment order
+template <int NB>
+__device__ __forceinline__ void chain_store(float *__restrict__ Hw, int lda, const float *__restrict__ bias, const f16v (&acc)[NB], int lane) {
+    const int kh = lane >> 5, lr = lane & 31;
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+        const float bv = bias[32 * n + lr];
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int row = (reg & 3) + 8 * (reg >> 2) + 4 * kh;
+            const float v = acc[n][reg] + bv;
+            Hw[row * lda + 32 * n + lr] = v > 0.f ? v : 0.f;
+        }
+    }
+}
+
+template <int C1, int C2, int C3, int PK>
+__global__ __launch_bounds__(256) void mlp_chain3_kernel(Chain3Args a) {
+    constexpr int NB1 = C1 / 32, NB2 = C2 / 32, NB3 = C3 / 32;
+    constexpr int LDW1 = chain_ldb(C1), LDW2 = chain_ldb(C2), LDW3 = chain_ldb(C3);
+    constexpr int LDA = chain_lda(C1 > C2 ? C1 : C2);
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *W1s = sm;                       // [6][LDW1]
+    float *W2s = W1s + 6 * LDW1;           // [C1][LDW2]
+    float *W3s = W2s + C1 * LDW2;          // [C2][LDW3]
+    float *Bs = W3s + C2 * LDW3;           // b1 | b2 | b3
+    float *H = Bs + (C1 + C2 + C3);        // [4][32][LDA]
+    float *Pm = H + 4 * 32 * LDA;          // [4][C3]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, kh = lane >> 5, lr = lane & 31;
+    for (int e = tid; e < 6 * C1; e += 256) W1s[(e / C1) * LDW1 + e % C1] = a.W1[e];
+    for (int e = tid; e < C1 * C2; e += 256) W2s[(e / C2) * LDW2 + e % C2] = a.W2[e];
+    for (int e = tid; e < C2 * C3; e += 256) W3s[(e / C3) * LDW3 + e % C3] = a.W3[e];
+    for (int e = tid; e < C1; e += 256) Bs[e] = a.b1[e];
+    for (int e = tid; e < C2; e += 256) Bs[C1 + e] = a.b2[e];
+    for (int e = tid; e < C3; e += 256) Bs[C1 + C2 + e] = a.b3[e];
+    __syncthreads();
+    float *Hw = H + wv * 32 * LDA;
+    const int ntiles = (a.rows + GM_BM - 1) / GM_BM;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int row0 = tile * GM_BM, r = row0 + wv * 32 + lr;
+        const bool live = row0 + wv * 32 < a.rows;          // rows % 32 == 0: a wave's rows are all inside or all outside
+        float mx[NB3];
+#pragma unroll
+        for (int n = 0; n < NB3; ++n) mx[n] = -INFINITY;
+        if (live) {
+            // ---- layer 1: A fragments from the gather, row r = [F(3) | Q - C(3)], this lane's k = kh, 2 + kh, 4 + kh
+            const int bb = r / (a.S * a.K);
+            const size_t prow = (size_t)bb * a.Npts + (size_t)a.idx[r];
+            const float *f = a.F + prow * 3, *q = a.Q + prow * 3, *c = a.C + (size_t)(r / a.K) * 3;
+            const float x0 = f[0], x1 = f[1], x2 = f[2], x3 = q[0] - c[0], x4 = q[1] - c[1], x5 = q[2] - c[2];
+            const float xa[3] = {kh ? x1 : x0, kh ? x3 : x2, kh ? x5 : x4};
+            {
+                f16v acc[NB1];
+#pragma unroll
+                for (int n = 0; n < NB1; ++n)
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) acc[n][g] = 0.f;
+#pragma unroll
+                for (int s3 = 0; s3 < 3; ++s3)
+#pragma unroll
+                    for (int n = 0; n < NB1; ++n)
+                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[s3], W1s[(2 * s3 + kh) * LDW1 + 32 * n + lr], acc[n], 0, 0, 0);
+                chain_store<NB1>(Hw, LDA, Bs, acc, lane);
+            }
+            {   // ---- layer 2
+                f16v acc[NB2];
+#pragma unroll
+                for (int n = 0; n < NB2; ++n)
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) acc[n][g] = 0.f;
+                chain_layer<NB2, LDW2>(Hw, LDA, W2s, C1, acc, lane);
+                chain_store<NB2>(Hw, LDA, Bs + C1, acc, lane);
+            }
+            {   // ---- layer 3 + bias + ReLU + max over the wave's 32 rows
+                f16v acc[NB3];
+#pragma unroll
+                for (int n = 0; n < NB3; ++n)
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) acc[n][g] = 0.f;
+                chain_layer<NB3, LDW3>(Hw, LDA, W3s, C2, acc, lane);
+#pragma unroll
+                for (int n = 0; n < NB3; ++n) {
+                    const float bv = Bs[C1 + C2 + 32 * n + lr];
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const float v = acc[n][reg] + bv;
+                        mx[n] = fmaxf(mx[n], v > 0.f ? v : 0.f);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < NB3; ++n) {
+            mx[n] = fmaxf(mx[n], __shfl_xor(mx[n], 32, 64));
+            if (lane < 32) Pm[wv * C3 + 32 * n + lane] = mx[n];
+        }
+        __syncthreads();
+        constexpr int wpg = PK / 32, groups = 4 / wpg;         // waves per pooled group: 1, 2 or 4
+        for (int e = tid; e < groups * C3; e += 256) {
+            const int g = e / C3, cc = e % C3;
+            float m = -INFINITY;
+#pragma unroll
+            for (int w = 0; w < wpg; ++w) m = fmaxf(m, Pm[(g * wpg + w) * C3 + cc]);
+            if (row0 + g * PK < a.rows) a.Y[(size_t)((row0 + g * PK) / PK) * a.ldy + a.ycol0 + cc] = m;
+        }
+        __syncthreads();                                       // Pm is rewritten by the next tile
+    }
+}
+
+template <int C1, int C2, int C3, int PK>
+static int chain3_launch(const Chain3Args &a, hipStream_t st) {
+    constexpr size_t lds = sizeof(float) * (6 * chain_ldb(C1) + C1 * chain_ldb(C2) + C2 * chain_ldb(C3) + (C1 + C2 + C3) +
+                                            4 * 32 * chain_lda(C1 > C2 ? C1 : C2) + 4 * C3);
+    static_assert(lds <= 152 * 1024, "chain3: weights + activation tiles must fit the LDS of one compute unit");
+    if (lds > REART_LDS_DEFAULT_CAP &&
+        hipFuncSetAttribute((const void *)mlp_chain3_kernel<C1, C2, C3, PK>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)
+        return REART_ERR_LAUNCH;
+    const int ntiles = reart_div_up(a.rows, GM_BM);
+    const int wgs = (int)(160 * 1024 / (lds + 1024));          // workgroups one compute unit holds (LDS bound)
+    const int grid = ntiles < 256 * wgs ? ntiles : 256 * wgs;   // persistent: every workgroup loads the weights once
+    hipLaunchKernelGGL((mlp_chain3_kernel<C1, C2, C3, PK>), dim3(grid), dim3(256), lds, st, a);
+    REART_CHECK_LAUNCH();
+    return REART_OK;
+}
+
+extern "C" int reart_mlp_chain3(const int64_t *gather_idx, int K, int S, int Npts, const float *F, const float *Q, const float *C,
+                                const float *W1t, const float *b1, int C1, const float *W2t, const float *b2, int C2,
+                                const float *W3t, const float *b3, int C3, int rows, float *Y, int ldy, int ycol0, void *stream) {
+    if (rows < 0 || K < 1 || S < 1 || Npts < 1) return REART_ERR_INVALID_ARG;
+    if (rows == 0) return REART_OK;
+    if (!gather_idx || !F || !Q || !C || !W1t || !b1 || !W2t || !b2 || !W3t || !b3 || !Y) return REART_ERR_INVALID_ARG;
+    if (ycol0 < 0 || ldy < ycol0 + C3 || rows % K != 0) return REART_ERR_INVALID_ARG;
+    Chain3Args a = {gather_idx, K, S, Npts, F, Q, C, W1t, b1, W2t, b2, W3t, b3, rows, Y, ldy, ycol0};
+    hipStream_t st = (hipStream_t)stream;
+    // the three scales of the extractor's sa1 (networks/feature_extractor.py:19-21)
+    if (C1 == 32 && C2 == 32 && C3 == 64 && K == 32) return chain3_launch<32, 32, 64, 32>(a, st);
+    if (C1 == 64 && C2 == 64 && C3 == 128 && K == 64) return chain3_launch<64, 64, 128, 64>(a, st);
+    if (C1 == 64 && C2 == 96 && C3 == 128 && K == 128) return chain3_launch<64, 96, 128, 128>(a, st);
+    return REART_ERR_UNSUPPORTED;
+}
+
+// ---------------------------------------------------------------------------------------
 // 3-NN inverse-distance feature interpolation of PointNetFeaturePropagation
 // (networks/pointnet2_utils.py:326-336) on the reference's square_distance (:33-55):
 //     d = ((-2 * mm) + |q|^2) + |t|^2,   mm = fma(qz, tz, fma(qy, ty, qx * tx))   (torch's K = 3 matmul)

@@ -948,6 +948,17 @@ extern "C" int reart_lap_auction_warm(const float *cost, int B, int n, int32_t *
 // ------------------------------------------------------------------------------------------------------------
 // BS threads per workgroup (one matrix each); JV_CPT = 4096 / BS columns per thread.  Fewer waves make a Dijkstra step
 // cheaper (the arg-min meets in fewer LDS slots, the barrier joins fewer waves) but the row-scan passes slower.
+// order in which the free rows of a re-solve are taken (experiment: -DJV_ORDER_MODE=1 descending, 2 from the middle outwards)
+#ifndef JV_ORDER_MODE
+#define JV_ORDER_MODE 0
+#endif
+#if JV_ORDER_MODE == 1
+#define JV_ORDER(k, n) ((n) - 1 - (k))
+#elif JV_ORDER_MODE == 2
+#define JV_ORDER(k, n) (((k) & 1) ? (n) / 2 + ((k) + 1) / 2 < (n) ? (n) / 2 + ((k) + 1) / 2 : (n) - 1 - (k) / 2 : ((n) / 2 - (k) / 2 >= 0 ? (n) / 2 - (k) / 2 : (k)))
+#else
+#define JV_ORDER(k, n) (k)
+#endif
 #define JV_OWNED (1 << 30)  // tie key of the path search's arg-min: owned columns after unowned ones
 #define JV_PTS_NMAX 2048   // points form: both point sets + the solver state must fit in LDS
 #ifndef JV_PTS_BS
@@ -1180,7 +1191,7 @@ __global__ __launch_bounds__(BS) void lap_jv_kernel(JvArgs a) {
         for (int pass = 0; pass < 2 && ncur > 0; ++pass) {
             int nnext = 0;
             for (int k0 = 0; k0 < ncur; ++k0) {
-                int i = flist[k0];
+                int i = flist[JV_ORDER(k0, ncur)];
                 for (;;) {
                     float rc[JV_CPT];
                     row_costs(i, rc);
@@ -1239,7 +1250,7 @@ __global__ __launch_bounds__(BS) void lap_jv_kernel(JvArgs a) {
     JPH(7);
     // ---- one shortest augmenting path per free row
     for (int f = 0; f < nfree; ++f) {
-        const int i0 = flist[f];
+        const int i0 = flist[JV_ORDER(f, nfree)];
         double d[JV_CPT];
         unsigned scanned = 0u;
         // this thread's unowned columns: among columns at the SAME smallest distance an unowned one ends the search at once

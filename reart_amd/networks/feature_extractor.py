@@ -65,6 +65,23 @@ def mlp_layer(X, Wt, bias, relu=True, pool_k=0, out=None, out_col=0, gather=None
     return out
 
 
+CHAIN3 = {(32, 32, 64, 32), (64, 64, 128, 64), (64, 96, 128, 128)}    # (C1, C2, C3, nsample) built into reart_mlp_chain3
+FUSE_CHAIN = True      # False: every layer its own launch (the same bits; tests compare the two)
+
+
+def mlp_chain3(folded, gather, out, out_col):
+    """Three gathered 1x1-conv layers + max over the group in ONE launch (reart_mlp_chain3): ``folded`` = [(Wt, bias)] x 3,
+    ``gather`` as for ``mlp_layer`` with 3 feature columns; the result lands in out[:, out_col:out_col + C3]."""
+    L = _lib.lib()
+    (W1, b1), (W2, b2), (W3, b3) = folded
+    B, S, K = gather["idx"].shape
+    rc = L.reart_mlp_chain3(_lib.ptr(gather["idx"]), K, S, gather["Npts"], _lib.ptr(gather["F"]), _lib.ptr(gather["Q"]),
+                            _lib.ptr(gather["C"]), _lib.ptr(W1), _lib.ptr(b1), W1.shape[1], _lib.ptr(W2), _lib.ptr(b2), W2.shape[1],
+                            _lib.ptr(W3), _lib.ptr(b3), W3.shape[1], B * S * K, _lib.ptr(out), out.shape[1], out_col, _lib.stream())
+    _lib.check(rc, "reart_mlp_chain3")
+    return out
+
+
 def three_interpolate(xyz1, xyz2, points2, out, out_col):
     """PointNetFeaturePropagation's 3-NN interpolation written into out[:, out_col:out_col+D]."""
     L = _lib.lib()
@@ -107,6 +124,13 @@ class _SAMsg(nn.Module):
             idx = query_ball_point(radius, K, xyz, new_xyz, cuda_mode=cuda_mode)
             h = None
             n_layers = len(self.conv_blocks[i])
+            widths = tuple(c.weight.shape[0] for c in self.conv_blocks[i])
+            if FUSE_CHAIN and n_layers == 3 and F.shape[1] == 3 and widths + (K,) in CHAIN3:
+                # sa1: the activations between the three layers stay in LDS (one launch per scale instead of three)
+                folded = [_fold(conv, bn) for conv, bn in zip(self.conv_blocks[i], self.bn_blocks[i])]
+                mlp_chain3(folded, dict(idx=idx, F=F, Q=Q, C=new_xyz.reshape(B * S, 3), Npts=N), out, col)
+                col += widths[-1]
+                continue
             for j, (conv, bn) in enumerate(zip(self.conv_blocks[i], self.bn_blocks[i])):
                 Wt, b = _fold(conv, bn)
                 last = j == n_layers - 1

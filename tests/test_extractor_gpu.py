@@ -79,3 +79,57 @@ def test_extractor_matches_reference(dev):
     print(f"\n[a9 @ N=1024] descriptor error: max {err.max() / np.abs(ref).max():.3e} of the scale, mean {err.mean() / np.abs(ref).mean():.3e} of the mean magnitude")
     assert err.max() <= 2e-5 * np.abs(ref).max(), (err.max(), np.abs(ref).max())
     assert err.mean() <= 5e-6 * np.abs(ref).mean(), (err.mean(), np.abs(ref).mean())
+
+
+def test_fused_sa1_chain_equals_the_three_launch_path(dev):
+    """reart_mlp_chain3 (three layers + pooling in one launch, activations in LDS) against three reart_mlp_layer launches:
+    every accumulator sees the same k order through the same MFMA instruction, so the outputs are equal BIT FOR BIT --
+    for each of the extractor's three sa1 scales, full and ragged tile counts."""
+    from reart_amd.networks import feature_extractor as fe
+
+    rng = np.random.default_rng(5)
+    for (C1, C2, C3, K), (B, S, Npts) in (((32, 32, 64, 32), (2, 37, 300)), ((64, 64, 128, 64), (3, 21, 257)),
+                                         ((64, 96, 128, 128), (2, 9, 400)), ((64, 96, 128, 128), (5, 64, 1024))):
+        F = rng.normal(size=(B * Npts, 3)).astype(np.float32)
+        C = rng.normal(size=(B * S, 3)).astype(np.float32)
+        idx = rng.integers(0, Npts, (B, S, K))
+        folded = []
+        cin = 6
+        for cout in (C1, C2, C3):
+            folded.append((t((rng.normal(size=(cin, cout)) * np.sqrt(2.0 / cin)).astype(np.float32), dev),
+                           t(rng.normal(0, 0.1, cout).astype(np.float32), dev)))
+            cin = cout
+        g = dict(idx=t(idx, dev), F=t(F, dev), Q=t(F, dev), C=t(C, dev), Npts=Npts, xyz_first=0)
+        h = fe.mlp_layer(None, *folded[0], gather=g)
+        h = fe.mlp_layer(h, *folded[1])
+        ref = torch.full((B * S, C3 + 7), -3.0, device=dev)
+        fe.mlp_layer(h, *folded[2], pool_k=K, out=ref, out_col=5)
+        got = torch.full((B * S, C3 + 7), -3.0, device=dev)
+        fe.mlp_chain3(folded, g, got, 5)
+        assert torch.equal(got, ref), (C1, C2, C3, K, float((got - ref).abs().max()))
+        # against float64 on the host as well
+        X = np.concatenate([F.reshape(B, Npts, 3)[np.arange(B)[:, None, None], idx],
+                            F.reshape(B, Npts, 3)[np.arange(B)[:, None, None], idx] - C.reshape(B, S, 1, 3)], -1).reshape(-1, 6).astype(np.float64)
+        for W, bvec in folded:
+            X = np.maximum(X @ W.cpu().numpy().astype(np.float64) + bvec.cpu().numpy(), 0)
+        want = X.reshape(B * S, K, C3).max(1)
+        np.testing.assert_allclose(got[:, 5:5 + C3].cpu().numpy(), want, rtol=2e-5, atol=2e-5 * np.abs(want).max())
+
+
+def test_extractor_same_bits_with_and_without_the_fused_chain(dev):
+    from reart_amd.networks import feature_extractor as fe
+    from reart_amd.synthetic import extractor_state
+
+    g = np.load(os.path.join(G, "extractor.npz"))
+    model = fe.PointNet2Msg2(out_dim=64)
+    model.load_state_dict(extractor_state(model), strict=True)
+    model = model.to(dev).eval()
+    xyz = t(g["xyz"], dev)
+    starts = (t(g["start1"], dev), t(g["start2"], dev))
+    fused = model(xyz, fps_start=starts)
+    fe.FUSE_CHAIN = False
+    try:
+        plain = model(xyz, fps_start=starts)
+    finally:
+        fe.FUSE_CHAIN = True
+    assert torch.equal(fused, plain)
