@@ -18,6 +18,9 @@
 #include <math.h>
 
 #define GM_BM 128
+#ifndef GM_NB4_GATHER
+#define GM_NB4_GATHER 0     // 1: four accumulators per wave for the gathered 323 -> 128 layers (measured: 5.69 vs 5.57 ms per forward)
+#endif
 // K step per layer (template parameter BK): 8 for the Cin = 6 first layers (they pad to the step), 32 for wide layers
 // (half the barriers per flop), 16 otherwise.  One step for all was measured: 32 everywhere is slower than 16 everywhere
 // (8.3 vs 6.7 ms for the extractor: the Cin = 6 layers pad twice as far).
@@ -213,7 +216,9 @@ extern "C" int reart_mlp_layer(const float *X, int ldx, const int64_t *gather_id
     a.X = X; a.ldx = ldx; a.idx = gather_idx; a.K = K; a.S = S; a.Npts = Npts; a.F = F; a.D = D; a.Q = Q; a.C = C;
     a.xyz_first = xyz_first; a.Wt = Wt; a.bias = bias; a.rows = rows; a.Cin = Cin; a.Cout = Cout; a.relu = relu;
     a.pool_k = pool_k; a.Y = Y; a.ldy = ldy; a.ycol0 = ycol0;
-    const int NB = Cout <= 32 ? 1 : (Cout <= 64 ? 2 : (Cout <= 96 ? 3 : 2));   // measured: NB = 4 for wide layers is slower (7.5 vs 6.7 ms)
+    // measured: NB = 4 for ALL wide layers is slower (7.5 vs 6.7 ms: half the resident waves), and for the gathered wide-K
+    // first layers of sa2 (323 -> 128, whose A tile NB = 2 stages twice) alone as well (GM_NB4_GATHER: 5.69 vs 5.57 ms)
+    const int NB = Cout <= 32 ? 1 : (Cout <= 64 ? 2 : (Cout <= 96 ? 3 : ((gather_idx && Cin > 128 && Cout % 128 == 0 && GM_NB4_GATHER) ? 4 : 2)));
     const int BK = Cin <= 8 ? 8 : 16;   // measured: 32 for the wide layers is slower (7.76 vs 6.72 ms for the extractor)
     const dim3 grid(reart_div_up(rows, GM_BM), reart_div_up(Cout, 32 * NB));
     hipStream_t st = (hipStream_t)stream;
@@ -222,6 +227,7 @@ extern "C" int reart_mlp_layer(const float *X, int ldx, const int64_t *gather_id
     switch (NB) {
         case 1: GM_PICK(1); break;
         case 2: GM_PICK(2); break;
+        case 4: GM_PICK(4); break;
         default: GM_PICK(3); break;
     }
 #undef GM_PICK
