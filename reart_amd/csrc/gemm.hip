@@ -18,6 +18,9 @@
 #include <math.h>
 
 #define GM_BM 128
+#ifndef GM_NB7
+#define GM_NB7 1
+#endif
 #ifndef GM_NB4_GATHER
 #define GM_NB4_GATHER 0     // 1: four accumulators per wave for the gathered 323 -> 128 layers (measured: 5.69 vs 5.57 ms per forward)
 #endif
@@ -218,7 +221,10 @@ extern "C" int reart_mlp_layer(const float *X, int ldx, const int64_t *gather_id
     a.pool_k = pool_k; a.Y = Y; a.ldy = ldy; a.ycol0 = ycol0;
     // measured: NB = 4 for ALL wide layers is slower (7.5 vs 6.7 ms: half the resident waves), and for the gathered wide-K
     // first layers of sa2 (323 -> 128, whose A tile NB = 2 stages twice) alone as well (GM_NB4_GATHER: 5.69 vs 5.57 ms)
-    const int NB = Cout <= 32 ? 1 : (Cout <= 64 ? 2 : (Cout <= 96 ? 3 : ((gather_idx && Cin > 128 && Cout % 128 == 0 && GM_NB4_GATHER) ? 4 : 2)));
+    // Cout = 196 (sa2's 128 -> 196): four 64-column blocks compute 256 columns for 196; ONE block of seven 32-column
+    // accumulators computes 224 and stages the A tile once
+    const int NB = Cout <= 32 ? 1 : (Cout <= 64 ? 2 : (Cout <= 96 ? 3 : ((Cout > 192 && Cout <= 224 && GM_NB7) ? 7 :
+                   ((gather_idx && Cin > 128 && Cout % 128 == 0 && GM_NB4_GATHER) ? 4 : 2))));
     const int BK = Cin <= 8 ? 8 : 16;   // measured: 32 for the wide layers is slower (7.76 vs 6.72 ms for the extractor)
     const dim3 grid(reart_div_up(rows, GM_BM), reart_div_up(Cout, 32 * NB));
     hipStream_t st = (hipStream_t)stream;
@@ -228,6 +234,7 @@ extern "C" int reart_mlp_layer(const float *X, int ldx, const int64_t *gather_id
         case 1: GM_PICK(1); break;
         case 2: GM_PICK(2); break;
         case 4: GM_PICK(4); break;
+        case 7: GM_PICK(7); break;
         default: GM_PICK(3); break;
     }
 #undef GM_PICK
