@@ -65,6 +65,17 @@ def mlp_layer(X, Wt, bias, relu=True, pool_k=0, out=None, out_col=0, gather=None
     return out
 
 
+OVERLAP_SAMPLING = True      # the second level's FPS / ball queries on a side stream under the first level's GEMMs
+_SIDE = {}
+
+
+def _side_stream(device):
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]
+
+
 CHAIN3 = {(32, 32, 64, 32), (64, 64, 128, 64), (64, 96, 128, 128)}    # (C1, C2, C3, nsample) built into reart_mlp_chain3
 FUSE_CHAIN = True      # False: every layer its own launch (the same bits; tests compare the two)
 
@@ -110,18 +121,26 @@ class _SAMsg(nn.Module):
             self.bn_blocks.append(bns)
         self.out_channels = sum(m[-1] for m in mlp_list)
 
-    def run(self, xyz, feats, start=None, cuda_mode=None):
+    def sample(self, xyz, start=None, cuda_mode=None):
+        """The part of the level that depends on COORDINATES only: farthest point sampling and the ball queries of every
+        scale -> (new_xyz [B,S,3], [idx [B,S,K] per scale]).  The caller may run it ahead of the previous level's
+        feature stacks (another stream)."""
+        fps = farthest_point_sample(xyz, self.npoint, start=start, cuda_mode=cuda_mode)
+        new_xyz = index_points(xyz, fps).contiguous()
+        return new_xyz, [query_ball_point(radius, K, xyz, new_xyz, cuda_mode=cuda_mode)
+                         for radius, K in zip(self.radius_list, self.nsample_list)]
+
+    def run(self, xyz, feats, start=None, cuda_mode=None, sampled=None):
         """xyz [B,N,3], feats [B,N,D] (channel-last) -> new_xyz [B,S,3], new_feats [B,S,sum C]."""
         B, N, _ = xyz.shape
         S = self.npoint
-        fps = farthest_point_sample(xyz, S, start=start, cuda_mode=cuda_mode)
-        new_xyz = index_points(xyz, fps).contiguous()
+        new_xyz, idx_list = sampled if sampled is not None else self.sample(xyz, start=start, cuda_mode=cuda_mode)
         out = torch.empty((B * S, self.out_channels), dtype=torch.float32, device=xyz.device)
         col = 0
         Q = xyz.reshape(B * N, 3)
         F = feats.reshape(B * N, -1).contiguous()
         for i, (radius, K) in enumerate(zip(self.radius_list, self.nsample_list)):
-            idx = query_ball_point(radius, K, xyz, new_xyz, cuda_mode=cuda_mode)
+            idx = idx_list[i]
             h = None
             n_layers = len(self.conv_blocks[i])
             widths = tuple(c.weight.shape[0] for c in self.conv_blocks[i])
@@ -253,8 +272,21 @@ class PointNet2Msg2(nn.Module):
         B, _, N = xyz.shape
         pts = xyz.permute(0, 2, 1).contiguous().float()  # [B,N,3]
         s1, s2 = fps_start if fps_start is not None else (None, None)
-        l1_xyz, l1 = self.sa1.run(pts, pts, start=s1, cuda_mode=cuda_mode)           # [B,512,3], [B,512,320]
-        l2_xyz, l2 = self.sa2.run(l1_xyz, l1, start=s2, cuda_mode=cuda_mode)         # [B,128,3], [B,128,512]
+        samp1 = self.sa1.sample(pts, start=s1, cuda_mode=cuda_mode)
+        samp2 = None
+        if OVERLAP_SAMPLING:
+            # the second level's sampling (FPS 512 -> 128: a latency chain on B workgroups; its ball queries) needs the first
+            # level's coordinates only: it runs on a side stream under the first level's feature stacks
+            main, side = torch.cuda.current_stream(xyz.device), _side_stream(xyz.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                samp2 = self.sa2.sample(samp1[0], start=s2, cuda_mode=cuda_mode)
+                for t_ in (samp2[0], *samp2[1]):
+                    t_.record_stream(main)           # allocated on the side stream, consumed on the main one
+        l1_xyz, l1 = self.sa1.run(pts, pts, sampled=samp1)                           # [B,512,3], [B,512,320]
+        if samp2 is not None:
+            main.wait_stream(side)
+        l2_xyz, l2 = self.sa2.run(l1_xyz, l1, start=s2, cuda_mode=cuda_mode, sampled=samp2)   # [B,128,3], [B,128,512]
         l3 = self.sa3.run(l2_xyz, l2)                                                # [B,1024]
         l2n = self.fp3.run(l2_xyz, l2_xyz[:, :1], l2, l3[:, None, :])                # [B,128,256]
         l1n = self.fp2.run(l1_xyz, l2_xyz, l1, l2n)                                  # [B,512,128]

@@ -133,3 +133,12 @@ def test_extractor_same_bits_with_and_without_the_fused_chain(dev):
     finally:
         fe.FUSE_CHAIN = True
     assert torch.equal(fused, plain)
+    # and with the second level's sampling on the main stream instead of the side stream
+    fe.OVERLAP_SAMPLING = False
+    try:
+        serial = model(xyz, fps_start=starts)
+    finally:
+        fe.OVERLAP_SAMPLING = True
+    assert torch.equal(fused, serial)
+    for _ in range(3):                       # repeated forwards: the side stream's tensors are recycled safely
+        assert torch.equal(model(xyz, fps_start=starts), fused)
