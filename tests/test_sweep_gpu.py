@@ -120,3 +120,25 @@ def test_sweep_command_line_one_rank(dev, tmp_path):
     eng.step(300)
     solo = sweep.instance_energy(eng, {"cano_idx": w})
     assert abs(solo["total_err"] - rows[w]["total_err"]) <= 1e-6 * abs(solo["total_err"])
+
+
+def test_sweep_command_line_synthetic_batch_with_flow(dev, tmp_path):
+    """Two generated sequences x all canonical frames, flow loss on, the default shared-launch mode (groups of six, the last
+    group smaller): every instance finishes, one winner per sequence."""
+    import json
+
+    from reart_amd import sweep
+
+    rc = sweep.main(["--synthetic", "2", "--synthetic_frames", "5", "--num_points", "512", "--cano", "all", "--n_iter", "150",
+                     "--use_flow_loss", "--energy", "--save_root", str(tmp_path)])
+    assert rc == 0
+    sw = json.load(open(tmp_path / "sweep.json"))
+    assert sw["n_instances"] == 10 and set(sw["sequences"]) == {"synthetic_0", "synthetic_1"}
+    for name, seq in sw["sequences"].items():
+        rows = seq["instances"]
+        assert [r["cano_idx"] for r in rows] == [0, 1, 2, 3, 4]
+        assert all(r["iterations"] == 150 and r["failed"] == 0 and np.isfinite(r["total_loss"]) and r["flow_loss"] > 0 for r in rows)
+        have = [r for r in rows if r["total_err"] is not None]
+        assert have, "no instance of the sequence produced an energy"
+        assert seq["winner_cano_idx"] == min(have, key=lambda r: r["total_err"])["cano_idx"]
+        assert (tmp_path / name / "result.pkl").exists()
