@@ -149,6 +149,27 @@ def test_kinematic_oracle_golden(oracle):
     np.testing.assert_allclose(T.numpy(), g["T"], rtol=0, atol=2e-6)
 
 
+def test_extractor_oracle_golden(oracle):
+    """oracle/extractor.py (CPU restatement of PointNet2Msg2: C sampling / grouping / interpolation + one matrix product per
+    layer with the eval-mode BatchNorm folded) against the reference's own module on a 1024-point nao cloud with the seeded
+    weights (extractor.npz): sampled coordinates bit-equal, features to float32 round-off."""
+    from oracle import extractor as ox
+    from reart_amd.networks.feature_extractor import PointNet2Msg2
+    from reart_amd.synthetic import extractor_state
+
+    g = load("extractor")
+    sd = {k: v.numpy() for k, v in extractor_state(PointNet2Msg2(64)).items()}
+    feat, mid = ox.forward(sd, g["xyz"], fps_start=(g["start1"], g["start2"]), cuda_mode=False, intermediates=True)
+    np.testing.assert_array_equal(np.transpose(mid["l1_xyz"], (0, 2, 1)), g["l1_xyz"])
+    np.testing.assert_array_equal(np.transpose(mid["l2_xyz"], (0, 2, 1)), g["l2_xyz"])
+    np.testing.assert_allclose(np.transpose(mid["l1_points"], (0, 2, 1)), g["l1_points"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(np.transpose(mid["l2_points"], (0, 2, 1)), g["l2_points"], rtol=1e-4, atol=1e-5)
+    ref = g["feat"]
+    err = np.abs(feat - ref)
+    print(f"oracle extractor vs reference: max {err.max() / np.abs(ref).max():.3e} of the scale, mean {err.mean() / np.abs(ref).mean():.3e}")
+    assert err.max() <= 1e-5 * np.abs(ref).max() and err.mean() <= 5e-6 * np.abs(ref).mean()
+
+
 def test_adam_matches_torch(oracle):
     import torch
 
