@@ -149,48 +149,6 @@ def extractor_flops(N, out_dim=64):
     return f
 
 
-def cpu_baseline_extractor(N, out_dim=64, budget_s=8.0):
-    """The 1x1-conv stacks of ONE PointNet2Msg2 forward (networks/feature_extractor.py:19-29, pointnet2_utils.py:257-295) on
-    the host: the same layer shapes as extractor_flops, random operands, torch.mm + bias + ReLU + group max."""
-    rng = torch.Generator().manual_seed(0)
-
-    def stack(rows, cin, widths, pool):
-        x = torch.randn((rows, cin), generator=rng)
-        ws = []
-        for w in widths:
-            ws.append((torch.randn((cin, w), generator=rng) * (2.0 / cin) ** 0.5, torch.zeros(w)))
-            cin = w
-        return x, ws, pool
-
-    stacks = [stack(512 * K, 6, widths, K) for K, widths in ((32, (32, 32, 64)), (64, (64, 64, 128)), (128, (64, 96, 128)))]
-    stacks += [stack(128 * K, 323, widths, K) for K, widths in ((64, (128, 128, 256)), (128, (128, 196, 256)))]
-    stacks += [stack(128, 515, (256, 512, 1024), 128), stack(128, 1536, (256, 256), 0), stack(512, 576, (256, 128), 0),
-               stack(N, 134, (128, 128, out_dim), 0)]
-
-    def forward():
-        for x, ws, pool in stacks:
-            h = x
-            for w, b in ws:
-                h = torch.relu(h @ w + b)
-            if pool:
-                h = h.reshape(-1, pool, h.shape[1]).amax(dim=1)
-        return h
-
-    with torch.no_grad():
-        forward()
-        n, t0 = 0, time.perf_counter()
-        while True:
-            forward()
-            n += 1
-            el = time.perf_counter() - t0
-            if el > budget_s or n >= 20:
-                break
-    return {"value": round(n / el, 3), "unit": "clouds/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} x the 1x1-conv stacks of ONE {N}-point cloud (every layer's fp32 matrix product over its grouped "
-                      f"rows + bias + ReLU + group max, torch on the host, {el:.1f} s wall); FPS, ball query, gathers and "
-                      f"interpolation not included: an upper bound of the CPU path's rate"}
-
-
 def bench_extractor(args, dev):
     """The one-time correspondence extractor of BASELINE configs[2] at the loop's size: PointNet2Msg2 on the 2(T-1)
     clouds of N points that compute_corr_list_filter feeds it (utils/flow_utils.py:123-124).  One step = one forward of
