@@ -169,8 +169,20 @@ def run_sweep_engines(instances, make_engine, n_iter, device, per_gpu=3, chunk=1
     threads = os.environ.get("REART_SWEEP_THREADS", "1") != "0"
     pool, pending = None, []
     gate = _CaptureGate()
-    for g0 in range(0, len(mine), per_gpu):
-        group = mine[g0:g0 + per_gpu]
+    # groups of (nearly) equal size, none larger than per_gpu: 20 instances at 6 per GPU run as 5 + 5 + 5 + 5, not 6 + 6 + 6 + 2
+    # (a short last group leaves the chip to two instances: 18 k instead of 22 k it/s for its share)
+    n_groups = (len(mine) + per_gpu - 1) // per_gpu if mine else 0
+    size = (len(mine) + n_groups - 1) // n_groups if n_groups else 0
+    groups = [mine[g0:g0 + size] for g0 in range(0, len(mine), size)] if size else []
+
+    # A group goes through four stages, and the loop below runs them so that the GPU always has a group's iterations queued:
+    #   build    host work (loading / generating the sequence, k-d orders) + the engines' set-up launches on their own streams
+    #   capture  graphs of `chunk` iterations (shared launches: one per part of <= RelaxBatch.MAX engines); synchronises the device
+    #   enqueue  every iteration of the group, asynchronously (graph replays); an event marks the end
+    #   tails    structure + energy + result files per instance, on host threads
+    # build(g+1) runs on the host while the GPU steps group g; capture(g+1) comes BEFORE the tails of group g are started
+    # (captures and tails never overlap, _CaptureGate), so those tails then run under the iterations of group g+1.
+    def build(group):
         live = []
         for inst in group:
             spec = instances[inst]
@@ -178,80 +190,101 @@ def run_sweep_engines(instances, make_engine, n_iter, device, per_gpu=3, chunk=1
             try:
                 with torch.cuda.stream(st):
                     eng = make_engine(spec)
-                    done = 0
-                    if mode == "streams":
-                        with gate.capture():
-                            done = eng.capture(steps_per_graph=min(chunk, n_iter))
-                live.append([inst, spec, eng, st, done])
+                live.append([inst, spec, eng, st, 0, None])           # [.., iterations queued, event after the last one]
             except Exception:  # a failed instance is reported (NaN energy), it does not kill the job
                 local[inst] = _record(inst, spec, failed=1)
+        return live
+
+    def capture(live):
+        """-> plan: list of (RelaxBatch, its entries, iterations its capture already ran) for the shared launches; entries not
+        covered by a batch carry their own graph (streams)."""
+        plan = []
+        solo = list(live)
         if mode == "batch" and live:
             from .relax import RelaxBatch
 
             for e in live:
                 e[3].synchronize()                       # the engines were prepared on their own streams
+            solo = []
             for b0 in range(0, len(live), RelaxBatch.MAX):
                 part = live[b0:b0 + RelaxBatch.MAX]
                 try:
                     batch = RelaxBatch([e[2] for e in part])     # refuses engines that do not share shape and switches
                     # capture() runs its first step eagerly: an engine the batched entry does not implement
-                    # (REART_ERR_UNSUPPORTED) shows up there, before a capture is open, and the group takes the streams
-                    # path below instead
+                    # (REART_ERR_UNSUPPORTED) shows up there, before a capture is open, and the part takes the streams path
                     used = 0
                     if n_iter > 1:
                         with gate.capture():
                             used = batch.capture(steps_per_graph=min(chunk, n_iter - 1))
-                    batch.step(n_iter - used)
-                    for e in part:
-                        e[4] = n_iter
+                    plan.append((batch, part, used))
                 except Exception as exc:
                     started = {int(e[2].iter.item()) for e in part}
                     if started != {0}:          # the shared launches already advanced somebody: not restartable here
                         for e in part:
                             local[e[0]] = _record(e[0], e[1], failed=1)
-                        live = [e for e in live if e not in part]
+                            live.remove(e)
                     else:
                         import warnings
 
                         warnings.warn(f"sweep: batch of {len(part)} instances falls back to streams ({type(exc).__name__}: {exc})")
-                        for e in part:
-                            with torch.cuda.stream(e[3]), gate.capture():
-                                e[4] = e[2].capture(steps_per_graph=min(chunk, n_iter))
-            torch.cuda.current_stream(device).synchronize()
-        while any(e[4] < n_iter for e in live):          # streams: round-robin graph replays (nothing left to do after a batch)
-            for e in live:
+                        solo.extend(part)
+        for e in solo:
+            with torch.cuda.stream(e[3]), gate.capture():
+                e[4] = e[2].capture(steps_per_graph=min(chunk, n_iter))
+        return plan
+
+    def enqueue(live, plan):
+        batched = set()
+        for batch, part, used in plan:
+            batch.step(n_iter - used)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(device))
+            for e in part:
+                e[4], e[5] = n_iter, ev
+                batched.add(id(e))
+        rest = [e for e in live if id(e) not in batched]
+        while any(e[4] < n_iter for e in rest):          # streams: round-robin graph replays
+            for e in rest:
                 if e[4] < n_iter:
                     n = min(chunk, n_iter - e[4])
                     with torch.cuda.stream(e[3]):
                         e[2].step(n)
                     e[4] += n
-        def finish(entry):
-            with gate.tail():
-                return _finish(entry)
+        for e in rest:
+            e[5] = torch.cuda.Event()
+            e[5].record(e[3])
 
-        def _finish(entry):
-            inst, spec, eng, st, done = entry
-            st.synchronize()
+    def finish(entry):
+        with gate.tail():
+            return _finish(entry)
+
+    def _finish(entry):
+        inst, spec, eng, st, done, ev = entry
+        ev.synchronize()                                  # the instance's last iteration (its own stream or the batch's)
+        st.wait_event(ev)
+        with torch.cuda.stream(st):
             row = eng.last_losses().cpu()
-            en = None
-            if energy:
-                try:
-                    with torch.cuda.stream(st):
-                        en = instance_energy(eng, spec)
-                except Exception as exc:      # e.g. every part merged away: the losses still describe the instance
-                    import sys
-                    import traceback
+        en = None
+        if energy:
+            try:
+                with torch.cuda.stream(st):
+                    en = instance_energy(eng, spec)
+            except Exception as exc:      # e.g. every part merged away: the losses still describe the instance
+                import sys
+                import traceback
 
-                    en = None
-                    print(f"sweep: instance {inst} ({spec}) has no energy: {type(exc).__name__}: {exc}\n"
-                          + "".join(traceback.format_exception(type(exc), exc, exc.__traceback__)[-3:]), file=sys.stderr)
-            if on_finish is not None:
-                on_finish(inst, spec, eng, en)
-            return inst, _record(inst, spec, (float(row[0]), float(row[1]), float(row[2])), done, 0, en)
+                en = None
+                print(f"sweep: instance {inst} ({spec}) has no energy: {type(exc).__name__}: {exc}\n"
+                      + "".join(traceback.format_exception(type(exc), exc, exc.__traceback__)[-3:]), file=sys.stderr)
+        if on_finish is not None:
+            on_finish(inst, spec, eng, en)
+        return inst, _record(inst, spec, (float(row[0]), float(row[1]), float(row[2])), done, 0, en)
 
+    def tails(live):
         # The end of an instance is latency-bound (its assignment solves occupy T-1 of the 256 compute units) and full of
         # host round trips: the instances of a group finish side by side, each on its own stream and host thread -- and
-        # (overlap_tails) while the NEXT group already optimises: the tails leave nine tenths of the chip idle.
+        # (overlap_tails) under the next group's iterations.
+        nonlocal pool
         if energy and threads:
             if pool is None:
                 pool = ThreadPoolExecutor(max_workers=2 * max(per_gpu, 1))
@@ -265,11 +298,39 @@ def run_sweep_engines(instances, make_engine, n_iter, device, per_gpu=3, chunk=1
         else:
             for inst, rec in (finish(e) for e in live):
                 local[inst] = rec
+
+    import time
+
+    stages = {"build_s": 0.0, "capture_s": 0.0, "drain_s": 0.0, "groups": len(groups)}   # host seconds per stage (this rank)
+
+    def timed(key, fn, *a):
+        t_ = time.perf_counter()
+        r_ = fn(*a)
+        stages[key] += time.perf_counter() - t_
+        return r_
+
+    cur = timed("build_s", build, groups[0]) if groups else []
+    enqueue(cur, timed("capture_s", capture, cur))
+    for gi in range(len(groups)):
+        nxt = timed("build_s", build, groups[gi + 1]) if gi + 1 < len(groups) else None      # host work under the GPU's stepping of `cur`
+        nplan = timed("capture_s", capture, nxt) if nxt is not None else None   # waits for the tails in flight and for `cur`'s iterations
+        if nxt is not None and not (energy and threads):
+            enqueue(nxt, nplan)                                             # inline tails: keep the GPU busy while the host reads results
+            tails(cur)
+        else:
+            tails(cur)
+            if nxt is not None:
+                enqueue(nxt, nplan)
+        cur = nxt
+    t_ = time.perf_counter()
     for f in pending:
         inst, rec = f.result()
         local[inst] = rec
     if pool is not None:
         pool.shutdown()
+    torch.cuda.synchronize(device)
+    stages["drain_s"] = time.perf_counter() - t_          # what is left after the last group was queued: its iterations and tails
+    run_sweep_engines.last_stages = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in stages.items()}
     records = gather_records(local, len(instances), device)
     return records, best_instance(records)
 
@@ -427,6 +488,9 @@ def main(argv=None, runner=None):
 
     from . import launch
 
+    import time
+
+    t_start = time.perf_counter()
     args = build_cli().parse_args(argv)
     if args.gpus > 1 and not launch.under_launcher():
         # N ranks of this module, started before anything here has touched the GPU
@@ -508,10 +572,15 @@ def main(argv=None, runner=None):
                     mp = os.path.join(instance_dir(args.save_root, instances[w]), "model.pth.tar")
                     if os.path.exists(mp):
                         shutil.copyfile(mp, os.path.join(args.save_root, name, "model.pth.tar"))
+        wall = time.perf_counter() - t_start          # this rank's wall clock from argument parsing to the winners (after the gather)
+        rate = len(instances) * args.n_iter / wall
         with open(os.path.join(args.save_root, "sweep.json"), "w") as f:
             json.dump({"world_size": world, "n_instances": len(instances), "n_iter": args.n_iter, "energy": bool(args.energy),
-                       "sequences": table}, f, indent=1)
+                       "wall_s": round(wall, 3), "iterations_per_s": round(rate, 1),
+                       "rank0_stages": getattr(run_sweep_engines, "last_stages", None), "sequences": table}, f, indent=1)
         print(json.dumps({"sweep": os.path.join(args.save_root, "sweep.json"), "n_gpus": world, "instances": len(instances),
+                          "wall_s": round(wall, 3), "iterations_per_s": round(rate, 1),
+                          "rank0_stages": getattr(run_sweep_engines, "last_stages", None),
                           "winners": {k: v["winner_cano_idx"] for k, v in table.items()}}))
     if dist.is_initialized():
         dist.barrier()
