@@ -976,6 +976,14 @@ extern "C" int reart_relax_step_batch(const reart_relax_config *cfgs, const rear
     void *wb[REART_BATCH_MAX];
     for (int k = 0; k < K; ++k) {
         fa[k] = L[k].fa; sa[k] = L[k].sa; pa.a[k] = L[k].pa; ba[k] = L[k].ba; ad[k] = L[k].ad; bk[k] = L[k].bk; wb[k] = L[k].ws_bwd;
+        // Box slices per search workgroup: ONE instance wants three waves per workgroup (its launch is only a few wave
+        // lifetimes long: shorter waves, more of them in flight); with K instances in the launch the chip is full anyway and
+        // the launch is bound by the instructions it issues, of which every extra wave of a workgroup repeats the prologue and
+        // the coarse rounds: measured for K = 6, aggregate it/s: 3 slices 22.7 k, 2 slices 23.8 k, 1 slice 24.5 k (K = 2: best with 2).  Same
+        // results whatever the count; an explicit tune_slices is kept.
+        const int auto_s = K >= 3 ? 1 : (K == 2 ? 2 : 3);      // measured grid (K x slices): profiles/r03_search_ab_runs.txt
+        if (cfgs[k].tune_slices == 0) sa[k].S1 = auto_s;
+        if (cfgs[k].tune_slices_flow == 0) sa[k].S3 = cfgs[k].tune_slices == 0 ? auto_s : sa[k].S1;
     }
     int rc = reart_base_forward_batch(fa, K, st);
     if (rc != REART_OK) return rc;

@@ -402,7 +402,7 @@ def build_cli():
     p.add_argument("--gpus", type=int, default=1, help="ranks to start when not already under torch.distributed.run")
     p.add_argument("--per_gpu", type=int, default=6, help="instances in flight per GPU")
     p.add_argument("--mode", choices=("streams", "batch"), default="batch",
-                   help="batch (default): the instances of a group advance in shared launches (22.6 k it/s per GPU for six at "
+                   help="batch (default): the instances of a group advance in shared launches (24.5 k it/s per GPU for six at "
                         "T=20 x N=4096 against 12.3 k for one); streams: one stream per instance (a group the shared launches "
                         "cannot take -- mixed shapes -- falls back to it by itself)")
     p.add_argument("--energy", action="store_true", help="end every instance with structure extraction + energy (run_robot.py:224-321)")
