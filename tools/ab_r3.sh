@@ -1,5 +1,5 @@
-for k in 2 3 4 6; do for s in 1 2 3; do
-  REART_PRUNE_SPLIT=$s REART_PRUNE_SPLIT3=$s timeout 300 python bench.py --no-cpu-baseline --no-tail --no-secondary --profile-steps 0 --sweep-instances $k --steps 600 2>/dev/null | python -c "
+for env in "X=1" "REART_SPARSE=20" "REART_SPARSE=64" "REART_SHARE=0" "REART_FWD_PTS=64" "REART_BWD_PTS=64"; do
+  env $env timeout 300 python bench.py --no-cpu-baseline --no-tail --no-secondary --profile-steps 0 --sweep-instances 6 2>/dev/null | python -c "
 import json,sys
-d=json.loads(sys.stdin.read()); print('K', d['sweep']['instances_per_gpu'], 'S', $s, 'sweep', d['sweep']['value'])"
-done; done
+d=json.loads(sys.stdin.read()); print('$env', 'single', d['value'], 'sweep', d['sweep']['value'])"
+done
