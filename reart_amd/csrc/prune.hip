@@ -60,7 +60,8 @@ typedef float f2 __attribute__((ext_vector_type(2)));
                         // time was measured: more instructions, loads for the 60 % of the boxes the precise test
                         // rejects, no gain -- the branch is kept compiled out for reference)
 #ifndef PR_QCAP
-#define PR_QCAP 768     // entries of a wave's (query, box) queue (the first 384 hold box bounds: PR_BOXLDS)
+#define PR_QCAP 640     // words of a wave's queue space: the first 384 hold box bounds (PR_BOXLDS), 256 (query, box) entries (768: one
+                        // workgroup less per compute unit, 32.9 vs 32.3 us; 512: drains too small and too many, 33.7 us)
 #endif
 #ifndef PR_COARSE_PACKED
 #define PR_COARSE_PACKED 1
@@ -189,13 +190,15 @@ __device__ __forceinline__ void knn_pruned_wave(const KnnJob &jb, const int S, c
 #pragma unroll
             for (int k2 = 0; k2 < k; ++k2) ok = ok && sj[k] != sj[k2];
         }
+        // scratch for the neighbour seeds: the result slots (s_key, 384 floats, initialised after this block) and the queue's
+        // space behind them (box bounds | queue) are contiguous and idle until the first coarse round
         constexpr bool SCR_JOINT = BOXL && PR_BOXLDS == 1;       // s_bb | s_q contiguous
-        constexpr bool SCR_FITS = (QCAP + (SCR_JOINT ? 384 : 0)) >= KK * 3 * 64;
+        constexpr bool SCR_FITS = (384 + QCAP + (SCR_JOINT ? 384 : 0)) >= KK * 3 * 64;
         if (SCR_FITS && share) {
             // ---- neighbour seeds: the K seed targets of every lane of this row of 16 (the lane's own among them), two lanes
             // per packed step.  A lane without usable seeds parks +inf (its candidates bound nothing -- but it still takes its
             // neighbours' bound); LDS operations of a wave complete in order, and every lane reads only its own row.
-            float *s_scr = SCR_JOINT ? s_bb : (float *)s_q;
+            float *s_scr = (float *)s_key;
 #pragma unroll
             for (int k = 0; k < KK; ++k) {
                 const int j = ok ? sj[k] : 0;
@@ -609,7 +612,8 @@ __global__ __launch_bounds__(64 * PR_SMAX, PR_WPE) void knn_group_kernel(Batched
         float *s_qc = (float *)(wl + 64 * 4);
         unsigned long long *s_key = (unsigned long long *)(wl + 64 * 4 + 64 * 16);
         unsigned int *s_q = (unsigned int *)(wl + 64 * 4 + 64 * 16 + 3 * 64 * 8);
-        static_assert(PR_QCAP >= 3 * 3 * 64, "neighbour seeds of a K = 3 item: 9 x 64 floats in the queue's space");
+        static_assert(384 + PR_QCAP >= 3 * 3 * 64, "neighbour seeds of a K = 3 item: 9 x 64 floats in the result slots + the queue's space");
+        static_assert(PR_QCAP >= 384 + 128, "box bounds of a coarse round + at least two drain steps of queue");
 #if PR_BOXLDS == 1          // the bounds of a coarse round's 64 boxes take the first 384 entries of the queue's space
         float *s_bb = (float *)s_q;
         s_q += 384;
