@@ -1,0 +1,47 @@
+"""The bench command lines themselves (short runs): the JSON contract of every configuration -- one line on stdout, the
+metric / config / roofline / cpu_baseline keys the driver and the judge read."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*argv, timeout=600):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], capture_output=True, timeout=timeout, cwd=ROOT)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1, lines                     # exactly ONE line on stdout
+    return json.loads(lines[0])
+
+
+def test_headline_line_contract(dev):
+    d = _run("--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-secondary", "--no-tail", "--sweep-instances", "0")
+    assert d["metric"] == "relaxation-loop iterations/sec" and d["unit"] == "iterations/s" and d["n_gpus"] == 1
+    assert d["steps"] == 20 and d["warmup"] == 5 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert abs(d["ms_per_step"] * d["value"] - 1e3) < 1.0 and d["value"] > 1000
+    c = d["config"]
+    assert c["frames"] == 20 and c["points"] == 4096 and c["flow"] is True and c["eager_steps"] == 0 and c["graph_replays"] >= 1
+    r = d["roofline"]
+    assert r["bound"] == "valu" and 0 < r["frac"] < 1 and r["kernel_ms"] < d["ms_per_step"]
+    assert r["algorithmic"]["frac"] > r["frac"] and r["hbm"]["frac"] < 0.2 and r["executed_pairs_per_launch"] < r["algorithmic_pairs_per_launch"]
+
+
+def test_nao_config_line(dev):
+    """BASELINE configs[2] on the reference's demo sequence (data inside tests/golden/structure.npz), shortened."""
+    d = _run("--config", "nao", "--steps", "400", "--no-cpu-baseline")
+    assert d["metric"] == "relaxation-loop iterations/sec" and d["config"]["frames"] == 10 and d["config"]["points"] == 4096
+    assert d["steps"] + d["warmup"] == 400 and d["value"] > 1000 and d["config"]["eager_steps"] < 50
+    assert len(d["config"]["matches_per_pair"]) == 9 and all(v == v for v in d["final_losses"])
+    assert d["roofline"]["launches_measured"] == d["steps"]
+
+
+def test_extractor_config_line(dev):
+    d = _run("--config", "extractor", "--steps", "3", "--warmup", "1", "--no-cpu-baseline")
+    assert d["unit"] == "clouds/s" and d["config"]["clouds"] == 38 and d["roofline"]["bound"] == "mfma" and d["finite"] is True
+    assert 0.1 < d["roofline"]["frac"] < 1
