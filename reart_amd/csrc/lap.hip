@@ -948,17 +948,19 @@ extern "C" int reart_lap_auction_warm(const float *cost, int B, int n, int32_t *
 // ------------------------------------------------------------------------------------------------------------
 // BS threads per workgroup (one matrix each); JV_CPT = 4096 / BS columns per thread.  Fewer waves make a Dijkstra step
 // cheaper (the arg-min meets in fewer LDS slots, the barrier joins fewer waves) but the row-scan passes slower.
-// order in which the free rows of a re-solve are taken (experiment: -DJV_ORDER_MODE=1 descending, 2 from the middle outwards)
-#ifndef JV_ORDER_MODE
-#define JV_ORDER_MODE 0
-#endif
-#if JV_ORDER_MODE == 1
-#define JV_ORDER(k, n) ((n) - 1 - (k))
-#elif JV_ORDER_MODE == 2
-#define JV_ORDER(k, n) (((k) & 1) ? (n) / 2 + ((k) + 1) / 2 < (n) ? (n) / 2 + ((k) + 1) / 2 : (n) - 1 - (k) / 2 : ((n) / 2 - (k) / 2 >= 0 ? (n) / 2 - (k) / 2 : (k)))
-#else
-#define JV_ORDER(k, n) (k)
-#endif
+// Racing re-solve (reart_lap_resolve_points_race): gridDim.y workgroups per matrix run the SAME exact algorithm from the same
+// start and differ only in the order in which they take the free rows (and in how long they stay in the row reduction
+// before handing the rest to the path search) -- the number of sequential steps of a re-solve varies by +-18 % with that
+// order, the first racer to finish publishes and the others leave at their next step.  Racer 0 is the plain solver
+// (ascending rows), 1 takes them descending, the others in a fixed pseudo-random order k -> k * prime mod count.
+#define JV_RACE_MAX 12
+__device__ const int jv_race_prime[JV_RACE_MAX] = {0, 0, 4099, 4111, 4127, 4129, 4133, 4139, 4153, 4157, 4159, 4177};
+__device__ const int jv_race_budget[JV_RACE_MAX] = {8, 8, 8, 8, 3, 8, 20, 8, 8, 3, 8, 20};
+__device__ __forceinline__ int jv_order(int k, int cnt, int racer) {
+    if (racer == 0) return k;
+    if (racer == 1) return cnt - 1 - k;
+    return (int)(((unsigned)k * (unsigned)(jv_race_prime[racer] % cnt)) % (unsigned)cnt);   // the primes exceed every count: a permutation
+}
 #define JV_OWNED (1 << 30)  // tie key of the path search's arg-min: owned columns after unowned ones
 #define JV_PTS_NMAX 2048   // points form: both point sets + the solver state must fit in LDS
 #ifndef JV_PTS_BS
@@ -987,6 +989,11 @@ struct JvArgs {
     double *scale;             // [B] the cost scale the tolerances are fractions of
     int *cert_bad;             // [B] set by the certificate pass when a row's column is not its arg-min
     int pass_mode;             // lap_jv_pass_kernel: 0 = row potentials of the start, 1 = first certificate round
+    // racing form (MODE 1, gridDim.y racers per matrix): the racers read the start from copies (col4row / price_out are
+    // written by the winner while others may still be loading) and meet in done[b] (0 = nobody has finished)
+    int *done;
+    const int *col_start;
+    const double *price_start;
 };
 
 // smallest (value, column) and second smallest value of c_ij + p_j over the columns of row i, costs from the points
@@ -1031,6 +1038,10 @@ __global__ __launch_bounds__(BS) void lap_jv_kernel(JvArgs a) {
     __shared__ double s_red[NW];
     __shared__ int s_cnt, s_flag;
     const float *C = PTS ? nullptr : a.cost + (size_t)b * n * n;
+    const bool race = MODE == 1 && a.done != nullptr;
+    const int racer = race ? (int)blockIdx.y : 0;
+    __shared__ int s_lost[2];                  // race: "another racer has published", double-buffered like the steps' slots
+    auto lost = [&]() -> int { return __hip_atomic_load(a.done + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     // c_ij for any (i, j), and the row scan, through one interface
     auto cost_at = [&](int i, int j) -> float {
         return PTS ? sqrtf(reart_sqdist3(psx[i], psy[i], psz[i], ptx[j], pty[j], ptz[j])) : C[(size_t)i * n + j];
@@ -1070,12 +1081,12 @@ __global__ __launch_bounds__(BS) void lap_jv_kernel(JvArgs a) {
     }
     if (lane == 0) s_red[wv] = mx;
     for (int j = tid; j < n; j += BS) {
-        price[j] = a.price_in ? a.price_in[(size_t)b * n + j] : 0.0;
+        price[j] = race ? a.price_start[(size_t)b * n + j] : (a.price_in ? a.price_in[(size_t)b * n + j] : 0.0);
         owner[j] = -1;
-        const int c = a.col4row[(size_t)b * n + j];
+        const int c = (race ? a.col_start : a.col4row)[(size_t)b * n + j];
         assigned[j] = (c >= 0 && c < n) ? c : -1;
     }
-    if (tid == 0) s_cnt = 0;
+    if (tid == 0) { s_cnt = 0; s_lost[0] = 0; s_lost[1] = 0; }
     __syncthreads();
     mx = 0.0;
     for (int w = 0; w < NW; ++w) mx = fmax(mx, s_red[w]);
@@ -1185,13 +1196,13 @@ __global__ __launch_bounds__(BS) void lap_jv_kernel(JvArgs a) {
             pr[k] = j < n ? price[j] : INFINITY;
             own[k] = j < n ? owner[j] : -1;
         }
-        int ncur = nfree, budget = JV_ARR_BUDGET * nfree + 64;          // uniform over the workgroup: every thread follows the chain
+        int ncur = nfree, budget = (race ? jv_race_budget[racer] : JV_ARR_BUDGET) * nfree + 64;          // uniform over the workgroup: every thread follows the chain
         int *next = pred;                                   // not needed before the path search
         int par = 0;
         for (int pass = 0; pass < 2 && ncur > 0; ++pass) {
             int nnext = 0;
             for (int k0 = 0; k0 < ncur; ++k0) {
-                int i = flist[JV_ORDER(k0, ncur)];
+                int i = flist[jv_order(k0, ncur, racer)];
                 for (;;) {
                     float rc[JV_CPT];
                     row_costs(i, rc);
@@ -1203,7 +1214,9 @@ __global__ __launch_bounds__(BS) void lap_jv_kernel(JvArgs a) {
                     }
                     lap_wave_top2_fast(v1, j1, v2, i0);
                     if (lane == 0) { s_av1[par][wv] = v1; s_av2[par][wv] = v2; s_aj1[par][wv] = j1; s_ai0[par][wv] = i0; }
+                    if (race && tid == 0) s_lost[par] = (budget & 15) == 0 ? lost() : s_lost[par ^ 1];
                     __syncthreads();
+                    if (race && s_lost[par]) return;                        // uniform: everybody reads the step's slot
                     v1 = lane < NW ? s_av1[par][lane] : INFINITY; v2 = lane < NW ? s_av2[par][lane] : INFINITY;
                     j1 = lane < NW ? s_aj1[par][lane] : 0x7fffffff; i0 = lane < NW ? s_ai0[par][lane] : -1;
                     lap_lanes_top2<(NW <= 2 ? 1 : (NW <= 4 ? 2 : (NW <= 8 ? 3 : 4)))>(v1, j1, v2, i0);
@@ -1250,7 +1263,7 @@ __global__ __launch_bounds__(BS) void lap_jv_kernel(JvArgs a) {
     JPH(7);
     // ---- one shortest augmenting path per free row
     for (int f = 0; f < nfree; ++f) {
-        const int i0 = flist[JV_ORDER(f, nfree)];
+        const int i0 = flist[jv_order(f, nfree, racer)];
         double d[JV_CPT];
         unsigned scanned = 0u;
         // this thread's unowned columns: among columns at the SAME smallest distance an unowned one ends the search at once
@@ -1287,9 +1300,11 @@ __global__ __launch_bounds__(BS) void lap_jv_kernel(JvArgs a) {
             lap_wave_argmin_fast(bv, bj);
             const int par = it & 1;
             if (lane == 0) { s_rv[par][wv] = bv; s_rj[par][wv] = bj; }
+            if (race && tid == 0) s_lost[par] = (it & 15) == 0 ? lost() : s_lost[par ^ 1];
             JPH(0);
             __syncthreads();
             JPH(1);
+            if (race && s_lost[par]) return;
             // the waves' minima meet in the first NW <= 16 lanes of every wave: four butterfly steps, then a broadcast
             bv = lane < NW ? s_rv[par][lane] : INFINITY; bj = lane < NW ? s_rj[par][lane] : 0x7fffffff;
             lap_lanes_argmin<(NW <= 2 ? 1 : (NW <= 4 ? 2 : (NW <= 8 ? 3 : 4)))>(bv, bj);
@@ -1343,6 +1358,11 @@ __global__ __launch_bounds__(BS) void lap_jv_kernel(JvArgs a) {
     }
 
     JPH(4);
+    if (race) {                                // first to finish publishes; everybody else has nothing to add
+        if (tid == 0) s_flag = atomicCAS(a.done + b, 0, racer + 1) == 0;
+        __syncthreads();
+        if (!s_flag) return;
+    }
     }   // MODE != 2
     // ---- certificate (the auction's): Jacobi rounds on the potentials until every assigned column is an exact arg-min
     double *dd = price;
@@ -1380,7 +1400,7 @@ __global__ __launch_bounds__(BS) void lap_jv_kernel(JvArgs a) {
     if (tid == 0 && a.stats) {
         int *o = a.stats + 4 * b;
         if (MODE == 2) o[3] += st_cert;          // on top of the first round the pass kernel ran
-        else { o[0] = st_freed; o[1] = st_left; o[2] = st_steps; o[3] = (MODE == 1 ? 1 : st_cert) + (st_arr << 8); }
+        else { o[0] = st_freed + (racer << 16); o[1] = st_left; o[2] = st_steps; o[3] = (MODE == 1 ? 1 : st_cert) + (st_arr << 8); }
     }
 }
 
@@ -1428,11 +1448,14 @@ __global__ __launch_bounds__(JV_PASS_BS) void lap_jv_pass_kernel(JvArgs a) {
 // Re-solve from the assignment in col4row and the potentials in price_in (both from an earlier solve of a similar batch,
 // reart_lap_auction* or these functions); same outputs and the same certificate as reart_lap_auction.
 template <bool PTS>
-static int jv_launch(JvArgs a, void *workspace, size_t workspace_bytes, void *stream) {
+static int jv_launch(JvArgs a, void *workspace, size_t workspace_bytes, void *stream, int racers = 1) {
     if (a.B < 0 || a.n < 1 || a.n > (PTS ? JV_PTS_NMAX : LAP_NMAX)) return REART_ERR_INVALID_ARG;
+    if (racers < 1 || racers > JV_RACE_MAX) return REART_ERR_INVALID_ARG;
     if (a.B == 0) return REART_OK;
     if (!a.col4row || !a.certified || !a.price_in) return REART_ERR_INVALID_ARG;
-    if (!workspace || workspace_bytes < reart_lap_workspace_bytes(a.B, a.n)) return REART_ERR_INVALID_ARG;
+    if (a.n < JV_SPLIT_NMIN) racers = 1;       // one launch does everything there: nothing worth racing
+    if (!workspace || workspace_bytes < (racers > 1 ? reart_lap_race_workspace_bytes(a.B, a.n, racers) : reart_lap_workspace_bytes(a.B, a.n)))
+        return REART_ERR_INVALID_ARG;
     if (!a.price_out) a.price_out = (double *)workspace;
     a.max_rounds_cert = 4 * a.n; a.keep_tol = 1e-12;
     a.stats = (int *)((char *)workspace + reart_align_up(sizeof(double) * (size_t)a.B * a.n, 256));
@@ -1464,8 +1487,23 @@ static int jv_launch(JvArgs a, void *workspace, size_t workspace_bytes, void *st
     a.pass_mode = 0;
     hipLaunchKernelGGL((lap_jv_pass_kernel<PTS>), dim3(a.B, per), dim3(JV_PASS_BS), lds_pass, (hipStream_t)stream, a);
     REART_CHECK_LAUNCH();
-    hipLaunchKernelGGL((lap_jv_kernel<JVBS, PTS, 1>), dim3(a.B), dim3(JVBS), lds, (hipStream_t)stream, a);
+    if (racers > 1) {
+        // the racers' common start: copies of the assignment and the potentials (the winner overwrites the originals while
+        // a late racer may still be loading), and the flags they meet in -- in the race layout's per-racer arrays
+        const size_t bn = reart_align_up(sizeof(double) * (size_t)a.B * a.n, 256);
+        char *w = (char *)workspace + reart_lap_workspace_bytes(a.B, a.n);
+        double *pc = (double *)w;
+        int *cc = (int *)(w + bn);
+        a.done = (int *)(w + bn * (size_t)racers);
+        if (hipMemcpyAsync(pc, a.price_in, sizeof(double) * (size_t)a.B * a.n, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess ||
+            hipMemcpyAsync(cc, a.col4row, sizeof(int) * (size_t)a.B * a.n, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess ||
+            hipMemsetAsync(a.done, 0, sizeof(int) * (size_t)a.B, (hipStream_t)stream) != hipSuccess)
+            return REART_ERR_LAUNCH;
+        a.price_start = pc; a.col_start = cc;
+    }
+    hipLaunchKernelGGL((lap_jv_kernel<JVBS, PTS, 1>), dim3(a.B, racers), dim3(JVBS), lds, (hipStream_t)stream, a);
     REART_CHECK_LAUNCH();
+    a.done = nullptr;
     a.pass_mode = 1;
     hipLaunchKernelGGL((lap_jv_pass_kernel<PTS>), dim3(a.B, per), dim3(JV_PASS_BS), lds_pass, (hipStream_t)stream, a);
     REART_CHECK_LAUNCH();
@@ -1496,6 +1534,21 @@ extern "C" int reart_lap_resolve_points(const float *src, const float *tgt, int 
     a.src = src; a.tgt = tgt; a.B = B; a.n = n; a.col4row = col4row; a.certified = certified; a.price_in = price_in;
     a.price_out = price_out;
     return jv_launch<true>(a, workspace, workspace_bytes, stream);
+}
+
+// reart_lap_resolve_points with `racers` (2..12) workgroups per problem on otherwise idle compute units: the same exact
+// algorithm taking the free rows in different orders, first to finish publishes (see jv_order).  The assignment is the
+// optimum either way; the potentials (and, among optima of exactly equal cost, the assignment) are the winner's, so they
+// are not reproducible run to run.  workspace: reart_lap_race_workspace_bytes(B, n, racers).  n < 512: the plain re-solve.
+extern "C" int reart_lap_resolve_points_race(const float *src, const float *tgt, int B, int n, int racers, int32_t *col4row,
+                                             int32_t *certified, const double *price_in, double *price_out, void *workspace,
+                                             size_t workspace_bytes, void *stream) {
+    if ((!src || !tgt) && B > 0) return REART_ERR_INVALID_ARG;
+    if (racers < 2) return REART_ERR_INVALID_ARG;
+    JvArgs a = {};
+    a.src = src; a.tgt = tgt; a.B = B; a.n = n; a.col4row = col4row; a.certified = certified; a.price_in = price_in;
+    a.price_out = price_out;
+    return jv_launch<true>(a, workspace, workspace_bytes, stream, racers);
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -2,6 +2,8 @@
 utils/model_utils.py:85-103): ``[linear_sum_assignment(c) for c in cost]`` / ``parallel_lap(cost, nproc)``
 on the GPU (``reart_lap_auction``: epsilon-scaling auction + exact dual certificate).  A matrix whose
 certificate does not close is solved with scipy on the host, so the result is always an optimal assignment."""
+import os
+
 import numpy as np
 import torch
 
@@ -151,15 +153,29 @@ def _forget_uncertified(state, col, b, host_cols):
 
 
 POINTS_NMAX = 2048   # reart_lap_resolve_points keeps both point sets and the solver state in LDS
+# free-row orders raced per problem by linear_sum_assignment_points (reart_lap_resolve_points_race); REART_RESOLVE_RACERS=1: none
+RESOLVE_RACERS = int(os.environ.get("REART_RESOLVE_RACERS", "8"))
 
 
-def linear_sum_assignment_points(src, tgt, state, return_stats=False):
+def _resolve_racers(B, n, race=True):
+    """Workgroups per problem of a re-solve: a racer holds a compute unit's LDS, the chip has 256; below 512 columns the
+    re-solve is one short launch and is not raced."""
+    if not race or n < 512:
+        return 1
+    r = min(RESOLVE_RACERS, 256 // max(B, 1))
+    return r if r >= 2 else 1
+
+
+def linear_sum_assignment_points(src, tgt, state, return_stats=False, race=True):
     """Optimal assignment for the Euclidean costs ``cdist(src, tgt)`` of two point batches [B,n,3] in a loop that
     re-solves slowly moving problems (the kinematic projection, run_robot.py:165-178 with ``--assign_gap 1``).  ``state`` is
     a dict the caller keeps between calls.  First call (or n > 2048): the cost matrices are built and solved like
     ``linear_sum_assignment_batch(cdist(src, tgt), state=state, warm_assignment=True)``.  Later calls with n <= 2048 never
     build a matrix: ``reart_lap_resolve_points`` re-solves from the previous optimum with the costs recomputed from the
-    points inside the kernel (bit-equal to ``cdist``'s values), certificate included.  Same return value."""
+    points inside the kernel (bit-equal to ``cdist``'s values), certificate included.  Same return value.
+    ``race`` (default on): idle compute units run the same re-solve with the free rows taken in other orders and the first
+    to finish publishes (``reart_lap_resolve_points_race``) -- the same optimum sooner; as with the cold race, the potentials
+    kept in ``state`` are the winner's."""
     _lib.require_gpu(src, tgt)
     src, tgt = src.detach().contiguous().float(), tgt.detach().contiguous().float()
     B, n, _ = src.shape
@@ -171,9 +187,15 @@ def linear_sum_assignment_points(src, tgt, state, return_stats=False):
     L = _lib.lib()
     col, prices = state["cols"].clone(), state["prices"]
     cert = torch.empty((B,), dtype=torch.int32, device=src.device)
-    ws = _lib.workspace(L.reart_lap_workspace_bytes(B, n), src.device)
-    rc = L.reart_lap_resolve_points(_lib.ptr(src), _lib.ptr(tgt), B, n, _lib.ptr(col), _lib.ptr(cert), _lib.ptr(prices),
-                                    _lib.ptr(prices), _lib.ptr(ws), ws.numel(), _lib.stream())
+    racers = _resolve_racers(B, n, race)
+    if racers > 1:
+        ws = _lib.workspace(L.reart_lap_race_workspace_bytes(B, n, racers), src.device)
+        rc = L.reart_lap_resolve_points_race(_lib.ptr(src), _lib.ptr(tgt), B, n, racers, _lib.ptr(col), _lib.ptr(cert),
+                                             _lib.ptr(prices), _lib.ptr(prices), _lib.ptr(ws), ws.numel(), _lib.stream())
+    else:
+        ws = _lib.workspace(L.reart_lap_workspace_bytes(B, n), src.device)
+        rc = L.reart_lap_resolve_points(_lib.ptr(src), _lib.ptr(tgt), B, n, _lib.ptr(col), _lib.ptr(cert), _lib.ptr(prices),
+                                        _lib.ptr(prices), _lib.ptr(ws), ws.numel(), _lib.stream())
     _lib.check(rc, "reart_lap_resolve_points")
     state["cols"] = col
     col_h, cert_h = col.cpu().numpy().astype(np.int64), cert.cpu().numpy()

@@ -185,6 +185,38 @@ def test_lap_resolve_points_equals_the_matrix_form(dev, n):
         a = (a + rng.normal(0, 0.0015, a.shape)).astype(np.float32)
 
 
+@pytest.mark.parametrize("n,B", [(512, 3), (1024, 19), (2048, 19), (2048, 40)])
+def test_lap_resolve_points_race_is_the_plain_resolve(dev, n, B):
+    """reart_lap_resolve_points_race (free-row orders raced on idle compute units): over a sequence of moving sources the raced
+    re-solve returns the assignment of the plain one (= scipy's on cdist's matrix), every problem certified, the winner
+    recorded; the potentials it leaves start the next re-solve as well as the plain solver's own."""
+    import oracle
+    from reart_amd.utils.lap import _resolve_racers, cdist, linear_sum_assignment_points
+
+    rng = np.random.default_rng(700 + n + B)
+    a = rng.uniform(-0.3, 0.3, (B, n, 3)).astype(np.float32)
+    b = (a[:, rng.permutation(n)] + rng.normal(0, 0.004, (B, n, 3))).astype(np.float32)
+    tb = torch.from_numpy(b).to(dev)
+    st_race, st_plain = {}, {}
+    racers = _resolve_racers(B, n)
+    assert racers == min(8, 256 // B)
+    for step in range(5):
+        ta = torch.from_numpy(a).to(dev)
+        out_r, fb_r, stats = linear_sum_assignment_points(ta, tb, st_race, return_stats="full", race=True)
+        out_p, fb_p, stats_p = linear_sum_assignment_points(ta, tb, st_plain, return_stats="full", race=False)
+        assert fb_r == 0 and fb_p == 0
+        for k in range(B):
+            np.testing.assert_array_equal(out_r[k][1], out_p[k][1])
+        if step in (1, 4):
+            ref = oracle.linear_sum_assignment(cdist(ta[:2], tb[:2]).cpu().numpy())
+            for k in range(2):
+                np.testing.assert_array_equal(out_r[k][1], ref[k][1])
+        if step > 0:
+            assert ((stats[:, 0] >> 16) < racers).all() and ((stats[:, 0] >> 16) >= 0).all()
+            assert ((stats_p[:, 0] >> 16) == 0).all()
+        a = (a + rng.normal(0, 0.0015, a.shape)).astype(np.float32)
+
+
 @pytest.mark.parametrize("n", [7, 600, 2048, 4096])
 def test_auction_with_points_is_the_matrix_auction(dev, n):
     """reart_lap_auction_points: the single-bidder chains recompute their rows from the points -- the same assignment AND the
