@@ -353,7 +353,8 @@ def bench_kinematic(args, dev, rank, world, distributed, barrier):
                    "parallelism": f"instances x{world}",
                    "loop": type(loop).__name__},
         "roofline": roof, "cpu_baseline": cpu,
-        "lap_stats_last": {"rows_released": (st[:, 0] & 0xffff).tolist(), "winning_racer": (st[:, 0] >> 16).tolist(), "rows_searched": st[:, 1].tolist(),
+        "lap_stats_last": {"rows_released": (st[:, 0] & 0xffff).tolist(), "winning_racer": (st[:, 0] >> 16).tolist(),
+                           "wins_per_racer": getattr(loop, "lap_winners", np.zeros(1)).tolist(), "rows_searched": st[:, 1].tolist(),
                            "dijkstra_steps": st[:, 2].tolist(), "row_reduction_steps": (st[:, 3] >> 8).tolist(),
                            "certificate_rounds": (st[:, 3] & 255).tolist()},
         "final_losses": {k: float(v.detach()) for k, v in losses.items()},

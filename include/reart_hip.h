@@ -508,11 +508,10 @@ int reart_lap_resolve_points(const float *src, const float *tgt, int B, int n, i
                              int32_t *certified, const double *price_in, double *price_out, void *workspace,
                              size_t workspace_bytes, void *stream);
 
-/* reart_lap_resolve_points with `racers` (2..12) workgroups per problem on otherwise idle compute units (a re-solve keeps
+/* reart_lap_resolve_points with `racers` (2..13) workgroups per problem on otherwise idle compute units (a re-solve keeps
  * one workgroup per problem busy: 19 of 256 compute units at README.md:125's 20 frames).  Every racer runs the same exact
  * algorithm from the same start and differs only in the order in which it takes the free rows (ascending, descending,
- * fixed pseudo-random permutations) and in its row-reduction budget; the first to finish publishes, the others leave at
- * their next step.  The assignment is the optimum either way; the potentials written to price_out -- and, between optima
+ * fixed pseudo-random permutations); the first to finish publishes, the others leave at their next step.  The assignment is the optimum either way; the potentials written to price_out -- and, between optima
  * of exactly equal cost, the assignment -- are the winner's, so not reproducible run to run.  stats[b][0] carries the
  * winning racer in bits 16+.  workspace: reart_lap_race_workspace_bytes(B, n, racers).  n < 512 runs the plain re-solve. */
 int reart_lap_resolve_points_race(const float *src, const float *tgt, int B, int n, int racers, int32_t *col4row,

@@ -949,13 +949,11 @@ extern "C" int reart_lap_auction_warm(const float *cost, int B, int n, int32_t *
 // BS threads per workgroup (one matrix each); JV_CPT = 4096 / BS columns per thread.  Fewer waves make a Dijkstra step
 // cheaper (the arg-min meets in fewer LDS slots, the barrier joins fewer waves) but the row-scan passes slower.
 // Racing re-solve (reart_lap_resolve_points_race): gridDim.y workgroups per matrix run the SAME exact algorithm from the same
-// start and differ only in the order in which they take the free rows (and in how long they stay in the row reduction
-// before handing the rest to the path search) -- the number of sequential steps of a re-solve varies by +-18 % with that
+// start and differ only in the order in which they take the free rows -- the number of sequential steps of a re-solve varies by +-18 % with that
 // order, the first racer to finish publishes and the others leave at their next step.  Racer 0 is the plain solver
 // (ascending rows), 1 takes them descending, the others in a fixed pseudo-random order k -> k * prime mod count.
-#define JV_RACE_MAX 12
-__device__ const int jv_race_prime[JV_RACE_MAX] = {0, 0, 4099, 4111, 4127, 4129, 4133, 4139, 4153, 4157, 4159, 4177};
-__device__ const int jv_race_budget[JV_RACE_MAX] = {8, 8, 8, 8, 3, 8, 20, 8, 8, 3, 8, 20};
+#define JV_RACE_MAX 13
+__device__ const int jv_race_prime[JV_RACE_MAX] = {0, 0, 4099, 4111, 4127, 4129, 4133, 4139, 4153, 4157, 4159, 4177, 4201};
 __device__ __forceinline__ int jv_order(int k, int cnt, int racer) {
     if (racer == 0) return k;
     if (racer == 1) return cnt - 1 - k;
@@ -1196,7 +1194,7 @@ __global__ __launch_bounds__(BS) void lap_jv_kernel(JvArgs a) {
             pr[k] = j < n ? price[j] : INFINITY;
             own[k] = j < n ? owner[j] : -1;
         }
-        int ncur = nfree, budget = (race ? jv_race_budget[racer] : JV_ARR_BUDGET) * nfree + 64;          // uniform over the workgroup: every thread follows the chain
+        int ncur = nfree, budget = JV_ARR_BUDGET * nfree + 64;          // uniform over the workgroup: every thread follows the chain
         int *next = pred;                                   // not needed before the path search
         int par = 0;
         for (int pass = 0; pass < 2 && ncur > 0; ++pass) {
@@ -1536,7 +1534,7 @@ extern "C" int reart_lap_resolve_points(const float *src, const float *tgt, int 
     return jv_launch<true>(a, workspace, workspace_bytes, stream);
 }
 
-// reart_lap_resolve_points with `racers` (2..12) workgroups per problem on otherwise idle compute units: the same exact
+// reart_lap_resolve_points with `racers` (2..13) workgroups per problem on otherwise idle compute units: the same exact
 // algorithm taking the free rows in different orders, first to finish publishes (see jv_order).  The assignment is the
 // optimum either way; the potentials (and, among optima of exactly equal cost, the assignment) are the winner's, so they
 // are not reproducible run to run.  workspace: reart_lap_race_workspace_bytes(B, n, racers).  n < 512: the plain re-solve.

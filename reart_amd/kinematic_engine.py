@@ -75,6 +75,7 @@ class KinematicEngine:
         self.lap_solves = 0
         self.lap_events = None
         self.lap_stats = None
+        self.lap_winners = np.zeros(16, np.int64)
         self.trans = torch.empty((self.B, self.P, 4, 4), dtype=torch.float32, device=self.dev)
         self.pc_trans = torch.empty((self.B, self.N, 3), dtype=torch.float32, device=self.dev)
         self.G = torch.zeros((self.B, self.N, 3), dtype=torch.float32, device=self.dev)
@@ -177,6 +178,7 @@ class KinematicEngine:
             # latency roofline of bench.py multiplies them by the measured floor of one step
             seq = self.lap_stats[:, 2].astype(np.int64) + (self.lap_stats[:, 3].astype(np.int64) >> 8)
             self.lap_steps_log.append((int(seq.max()), float(seq.mean())))
+            self.lap_winners += np.bincount(self.lap_stats[:, 0] >> 16, minlength=16)[:16]         # raced re-solves: who finished first
             cols = torch.from_numpy(np.stack([c for _, c in assign])).to(self.dev)
             self.matched = self.tgt_pts.gather(1, cols[..., None].expand(-1, -1, 3))
             if self.lap_events is not None:

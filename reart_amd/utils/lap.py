@@ -154,7 +154,7 @@ def _forget_uncertified(state, col, b, host_cols):
 
 POINTS_NMAX = 2048   # reart_lap_resolve_points keeps both point sets and the solver state in LDS
 # free-row orders raced per problem by linear_sum_assignment_points (reart_lap_resolve_points_race); REART_RESOLVE_RACERS=1: none
-RESOLVE_RACERS = int(os.environ.get("REART_RESOLVE_RACERS", "8"))
+RESOLVE_RACERS = int(os.environ.get("REART_RESOLVE_RACERS", "13"))
 
 
 def _resolve_racers(B, n, race=True):

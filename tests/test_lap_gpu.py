@@ -199,7 +199,7 @@ def test_lap_resolve_points_race_is_the_plain_resolve(dev, n, B):
     tb = torch.from_numpy(b).to(dev)
     st_race, st_plain = {}, {}
     racers = _resolve_racers(B, n)
-    assert racers == min(8, 256 // B)
+    assert racers == min(13, 256 // B)
     for step in range(5):
         ta = torch.from_numpy(a).to(dev)
         out_r, fb_r, stats = linear_sum_assignment_points(ta, tb, st_race, return_stats="full", race=True)
