@@ -12,44 +12,66 @@
 #include <math.h>
 
 // ---------------------------------------------------------------------------------------
-// FPS: one 1024-thread workgroup per cloud; points and running min-distances live in
-// registers (IPT per thread), the cloud's coordinates in LDS for the broadcast read of the
-// current farthest point; per round ONE barrier: wave arg-max by shuffles, 16 wave winners
-// through a double-buffered LDS slot, every wave reduces the 16 again redundantly.
-// The op is inherently sequential in npoint (latency bound): ~1 us per round.
+// FPS: one workgroup per cloud (256 threads up to 1024 points, 512 above); points and running min-distances live in
+// registers (pairs of points per thread: the distance update runs on packed fp32), the cloud's coordinates in LDS for
+// the broadcast read of the current farthest point.  The op is a chain of npoint dependent rounds, so a round is built
+// to be short rather than wide -- per round ONE barrier and no data-dependent branch:
+//   every thread   running min-distances of its points, their maximum (values only)
+//   every wave     maximum over the wave (six DPP steps), then the smallest tie KEY among the points that attain it
+//                  (six more); one (value, key) slot per wave, double buffered
+//   after barrier  every wave merges the slots again redundantly (log2(waves) DPP steps for the value, the same for the
+//                  key among the slots that attain it)
+// The key encodes the reference's choice between equal distances, so exact ties need no slow path:
+//   CUDA rule (sampling_gpu.cu's tree arg-max): lowest thread id of the CUDA block, then lowest index -> (k & mask) << 16 | k
+//   CPU rule (torch.max(...)[1]): first maximum -> k
 // ---------------------------------------------------------------------------------------
-#define FPS_BS 1024
+typedef float reart_f2 __attribute__((ext_vector_type(2)));
 
-struct FpsKey { float v; int i; };
-
-template <bool CUDA_MODE>
-__device__ __forceinline__ bool fps_better(float v2, int i2, float v, int i, int bsmask) {
-    if (v2 > v) return true;
-    if (v2 < v) return false;
-    if (CUDA_MODE) {  // tree arg-max of the CUDA kernel: lowest thread id, then lowest index
-        const int t2 = i2 & bsmask, t = i & bsmask;
-        return (t2 < t) || (t2 == t && i2 < i);
-    }
-    return i2 < i;    // torch.max(...)[1]: first maximum
+// Distances are sums of squares (>= +0) and the padding is -inf: on such values the order of the floats is the order of
+// their bit patterns as signed integers, so the maxima run on v_max_i32 with the DPP operand folded in (fmaxf would add a
+// canonicalising instruction per operand).
+template <int STEPS>
+__device__ __forceinline__ int fps_lanes_max(int v) {
+    v = max(v, reart_bfly<0>(v));
+    if (STEPS > 1) v = max(v, reart_bfly<1>(v));
+    if (STEPS > 2) v = max(v, reart_bfly<2>(v));
+    if (STEPS > 3) v = max(v, reart_bfly<3>(v));
+    if (STEPS > 4) v = max(v, reart_bfly<4>(v));
+    if (STEPS > 5) v = max(v, reart_bfly<5>(v));
+    return v;
+}
+template <int STEPS>
+__device__ __forceinline__ int fps_lanes_min(int v) {
+    v = min(v, reart_bfly<0>(v));
+    if (STEPS > 1) v = min(v, reart_bfly<1>(v));
+    if (STEPS > 2) v = min(v, reart_bfly<2>(v));
+    if (STEPS > 3) v = min(v, reart_bfly<3>(v));
+    if (STEPS > 4) v = min(v, reart_bfly<4>(v));
+    if (STEPS > 5) v = min(v, reart_bfly<5>(v));
+    return v;
 }
 
-template <int IPT, bool CUDA_MODE>
-__global__ __launch_bounds__(FPS_BS) void fps_kernel(const float *__restrict__ xyz, int N, int M,
-                                                     const int *__restrict__ start, int bsmask,
-                                                     int *__restrict__ idx32, int64_t *__restrict__ idx64) {
+// BS threads, NP pairs of points per thread: thread t holds the points t + u * BS, u < 2 NP
+template <int BS, int NP, bool CUDA_MODE>
+__global__ __launch_bounds__(BS) void fps_kernel(const float *__restrict__ xyz, int N, int M,
+                                                 const int *__restrict__ start, int bsmask,
+                                                 int *__restrict__ idx32, int64_t *__restrict__ idx64) {
     extern __shared__ __attribute__((aligned(16))) float s_xyz[];  // [N][3]
-    __shared__ float s_v[2][FPS_BS / 64];
-    __shared__ int s_i[2][FPS_BS / 64];
+    constexpr int NW = BS / 64, LG = NW <= 4 ? 2 : (NW <= 8 ? 3 : 4);
+    static_assert(NW == 4 || NW == 8 || NW == 16, "the slots' merge walks 2, 3 or 4 butterfly steps");
+    __shared__ int s_v[2][NW], s_k[2][NW];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const float *p = xyz + (size_t)b * N * 3;
-    for (int e = tid; e < 3 * N; e += FPS_BS) s_xyz[e] = p[e];
-    float px[IPT], py[IPT], pz[IPT], dm[IPT];
+    for (int e = tid; e < 3 * N; e += BS) s_xyz[e] = p[e];
+    reart_f2 px[NP], py[NP], pz[NP], dm[NP];
+    int key[2 * NP];
 #pragma unroll
-    for (int u = 0; u < IPT; ++u) {
-        const int k = tid + u * FPS_BS;
+    for (int u = 0; u < 2 * NP; ++u) {
+        const int k = tid + u * BS;
         const bool ok = k < N;
-        px[u] = ok ? p[3 * k] : 0.f; py[u] = ok ? p[3 * k + 1] : 0.f; pz[u] = ok ? p[3 * k + 2] : 0.f;
-        dm[u] = ok ? 1e10f : -INFINITY;  // padding can never win the arg-max
+        px[u >> 1][u & 1] = ok ? p[3 * k] : 0.f; py[u >> 1][u & 1] = ok ? p[3 * k + 1] : 0.f; pz[u >> 1][u & 1] = ok ? p[3 * k + 2] : 0.f;
+        dm[u >> 1][u & 1] = ok ? 1e10f : -INFINITY;  // padding can never win the arg-max
+        key[u] = CUDA_MODE ? (((k & bsmask) << 16) | k) : k;
     }
     int far = start ? start[b] : 0;
     __syncthreads();
@@ -60,33 +82,28 @@ __global__ __launch_bounds__(FPS_BS) void fps_kernel(const float *__restrict__ x
         }
         if (it == M - 1) break;
         const float fx = s_xyz[3 * far], fy = s_xyz[3 * far + 1], fz = s_xyz[3 * far + 2];
-        float bv = -INFINITY;
-        int bi = 0x7fffffff;
+        const reart_f2 fx2 = {fx, fx}, fy2 = {fy, fy}, fz2 = {fz, fz};
+        int bv = (int)0xff800000;                                          // -inf
 #pragma unroll
-        for (int u = 0; u < IPT; ++u) {
-            const float d = reart_sqdist3(px[u], py[u], pz[u], fx, fy, fz);
-            dm[u] = d < dm[u] ? d : dm[u];
-            const int k = tid + u * FPS_BS;
-            if (fps_better<CUDA_MODE>(dm[u], k, bv, bi, bsmask)) { bv = dm[u]; bi = k; }
+        for (int u = 0; u < NP; ++u) {
+            const reart_f2 dx = px[u] - fx2, dy = py[u] - fy2, dz = pz[u] - fz2;
+            const reart_f2 d = (dx * dx + dy * dy) + dz * dz;              // reart_sqdist3, two points at a time
+            dm[u].x = d.x < dm[u].x ? d.x : dm[u].x;
+            dm[u].y = d.y < dm[u].y ? d.y : dm[u].y;
+            bv = max(max(bv, __float_as_int(dm[u].x)), __float_as_int(dm[u].y));
         }
+        const int wmax = fps_lanes_max<6>(bv);
+        int bk = 0x7fffffff;
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-            const float v2 = __shfl_xor(bv, o, 64);
-            const int i2 = __shfl_xor(bi, o, 64);
-            if (fps_better<CUDA_MODE>(v2, i2, bv, bi, bsmask)) { bv = v2; bi = i2; }
-        }
+        for (int u = 0; u < 2 * NP; ++u) bk = min(bk, __float_as_int(dm[u >> 1][u & 1]) == wmax ? key[u] : 0x7fffffff);
+        bk = fps_lanes_min<6>(bk);
         const int buf = it & 1;
-        if (lane == 0) { s_v[buf][wv] = bv; s_i[buf][wv] = bi; }
+        if (lane == 0) { s_v[buf][wv] = wmax; s_k[buf][wv] = bk; }
         __syncthreads();
-        bv = s_v[buf][lane & (FPS_BS / 64 - 1)];
-        bi = s_i[buf][lane & (FPS_BS / 64 - 1)];
-#pragma unroll
-        for (int o = FPS_BS / 128; o >= 1; o >>= 1) {
-            const float v2 = __shfl_xor(bv, o, 64);
-            const int i2 = __shfl_xor(bi, o, 64);
-            if (fps_better<CUDA_MODE>(v2, i2, bv, bi, bsmask)) { bv = v2; bi = i2; }
-        }
-        far = bi;
+        const int v = s_v[buf][lane & (NW - 1)];
+        const int k = s_k[buf][lane & (NW - 1)];
+        const int gmax = fps_lanes_max<LG>(v);
+        far = __builtin_amdgcn_readfirstlane(fps_lanes_min<LG>(v == gmax ? k : 0x7fffffff)) & 0xffff;
     }
 }
 
@@ -97,25 +114,28 @@ static int fps_block_mask(int N) {  // opt_n_threads(N) - 1 (cuda_utils.h:10-14)
     return p - 1;
 }
 
-template <int IPT>
+template <int BS, int NP>
 static int fps_launch(const float *xyz, int B, int N, int M, const int *start, int cuda_mode,
                       int *idx32, int64_t *idx64, hipStream_t st) {
     const size_t lds = sizeof(float) * 3 * (size_t)N;
     if (lds > REART_LDS_DEFAULT_CAP) {   // stateless: no function-static "done once" flags in the library
-        const void *fn = cuda_mode ? (const void *)fps_kernel<IPT, true> : (const void *)fps_kernel<IPT, false>;
+        const void *fn = cuda_mode ? (const void *)fps_kernel<BS, NP, true> : (const void *)fps_kernel<BS, NP, false>;
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)
             return REART_ERR_LAUNCH;
     }
     if (cuda_mode)
-        hipLaunchKernelGGL((fps_kernel<IPT, true>), dim3(B), dim3(FPS_BS), lds, st, xyz, N, M, start,
+        hipLaunchKernelGGL((fps_kernel<BS, NP, true>), dim3(B), dim3(BS), lds, st, xyz, N, M, start,
                            fps_block_mask(N), idx32, idx64);
     else
-        hipLaunchKernelGGL((fps_kernel<IPT, false>), dim3(B), dim3(FPS_BS), lds, st, xyz, N, M, start,
+        hipLaunchKernelGGL((fps_kernel<BS, NP, false>), dim3(B), dim3(BS), lds, st, xyz, N, M, start,
                            fps_block_mask(N), idx32, idx64);
     REART_CHECK_LAUNCH();
     return REART_OK;
 }
 
+#ifndef FPS_BS_BIG
+#define FPS_BS_BIG 512     // threads per cloud above 1024 points
+#endif
 extern "C" int reart_fps(const float *xyz, int B, int N, int npoint, const int32_t *start,
                          int cuda_mode, int32_t *idx32, int64_t *idx64, void *stream) {
     if (B < 0 || N < 1 || npoint < 0) return REART_ERR_INVALID_ARG;
@@ -123,12 +143,13 @@ extern "C" int reart_fps(const float *xyz, int B, int N, int npoint, const int32
     if (!xyz || (!idx32 && !idx64)) return REART_ERR_INVALID_ARG;
     if (N > 12288) return REART_ERR_UNSUPPORTED;  // cloud must fit in LDS (12 B/point)
     hipStream_t st = (hipStream_t)stream;
-    const int ipt = reart_div_up(N, FPS_BS);
-    if (ipt <= 1) return fps_launch<1>(xyz, B, N, npoint, start, cuda_mode, idx32, idx64, st);
-    if (ipt <= 2) return fps_launch<2>(xyz, B, N, npoint, start, cuda_mode, idx32, idx64, st);
-    if (ipt <= 4) return fps_launch<4>(xyz, B, N, npoint, start, cuda_mode, idx32, idx64, st);
-    if (ipt <= 8) return fps_launch<8>(xyz, B, N, npoint, start, cuda_mode, idx32, idx64, st);
-    return fps_launch<12>(xyz, B, N, npoint, start, cuda_mode, idx32, idx64, st);
+    if (N <= 512) return fps_launch<256, 1>(xyz, B, N, npoint, start, cuda_mode, idx32, idx64, st);
+    if (N <= 1024) return fps_launch<256, 2>(xyz, B, N, npoint, start, cuda_mode, idx32, idx64, st);
+    const int pairs = reart_div_up(N, 2 * FPS_BS_BIG);
+    if (pairs <= 2) return fps_launch<FPS_BS_BIG, 2>(xyz, B, N, npoint, start, cuda_mode, idx32, idx64, st);
+    if (pairs <= 4) return fps_launch<FPS_BS_BIG, 4>(xyz, B, N, npoint, start, cuda_mode, idx32, idx64, st);
+    if (pairs <= 8) return fps_launch<FPS_BS_BIG, 8>(xyz, B, N, npoint, start, cuda_mode, idx32, idx64, st);
+    return fps_launch<FPS_BS_BIG, 12 * 512 / FPS_BS_BIG>(xyz, B, N, npoint, start, cuda_mode, idx32, idx64, st);
 }
 
 // ---------------------------------------------------------------------------------------
