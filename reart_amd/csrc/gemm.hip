@@ -423,6 +423,256 @@ extern "C" int reart_mlp_chain3(const int64_t *gather_idx, int K, int S, int Npt
 }
 
 // ---------------------------------------------------------------------------------------
+// The same fusion for the SECOND set-abstraction level (sa2, networks/feature_extractor.py:22-23: grouped
+// [features(320) | xyz - centre(3)] -> 128 -> 128 | 196 -> 256 -> max over the K samples): its weights (up to 200 KB a layer)
+// do not fit LDS next to the activations, so they stream through it in 16-row slabs like mlp_gemm_kernel's B tile (double
+// buffered: one barrier per slab) while a wave's 32 rows stay in its private activation tile from layer to layer.
+// Layer by layer the middle activations of the K = 128 scale ([622 592, 128] and [622 592, 196] floats at T = 20: 0.8 GB)
+// were written and read back, and the 128 -> 196 layer ran at a third of the matrix cores' rate (seven accumulators, a
+// 100 KB store per workgroup).  Here one workgroup owns 128 rows (one group of K = 128 samples, or two of K = 64) through all
+// three layers with every output column in registers: 4, then 4 or 7, then 8 accumulators per wave.
+// The k order of every accumulator is mlp_gemm_kernel's (ascending, slabs of 16), so the bits are the layer-by-layer path's.
+struct ChainWideArgs {
+    const int64_t *idx; int K, S, Npts;
+    const float *F; int D;            // features [B*Npts, D], D % 4 == 0
+    const float *Q, *C;               // xyz [B*Npts,3], centres [B*S,3]
+    const float *W1, *b1, *W2, *b2, *W3, *b3;   // transposed weights [D+3, C1], [C1, C2], [C2, C3], biases
+    int rows;                         // % 128 == 0
+    float *Y; int ldy, ycol0;
+};
+#define CW_BK 16
+#define CW_LDAS (CW_BK + 1)
+template <int NBp> struct CwSlab {
+    static constexpr int BN = 32 * NBp, LDB = BN + 4, NBF = CW_BK * BN / 4, BPT = (NBF + 255) / 256;
+};
+// rows [k0, k0 + 16) of a transposed weight matrix [Cin, Cout] (Cout % 4 == 0), zero beyond either edge
+template <int NBp>
+__device__ __forceinline__ void cw_load_b(const float *__restrict__ W, int Cin, int Cout, int k0, int tid, float4 (&bw)[CwSlab<NBp>::BPT]) {
+    typedef CwSlab<NBp> SL;
+#pragma unroll
+    for (int h = 0; h < SL::BPT; ++h) {
+        const int f = tid + 256 * h, k = k0 + f / (SL::BN / 4), cc = (f % (SL::BN / 4)) * 4;
+        float4 w = {0.f, 0.f, 0.f, 0.f};
+        if (f < SL::NBF && k < Cin && cc < Cout) w = *(const float4 *)(W + (size_t)k * Cout + cc);
+        bw[h] = w;
+    }
+}
+template <int NBp>
+__device__ __forceinline__ void cw_store_b(float *__restrict__ Bs, int tid, const float4 (&bw)[CwSlab<NBp>::BPT]) {
+    typedef CwSlab<NBp> SL;
+#pragma unroll
+    for (int h = 0; h < SL::BPT; ++h) {
+        const int f = tid + 256 * h;
+        if (f < SL::NBF) *(float4 *)(Bs + (f / (SL::BN / 4)) * SL::LDB + (f % (SL::BN / 4)) * 4) = bw[h];
+    }
+}
+// The MFMAs of one slab: A value of step kk at ap[kk * astride], B values at bp[kk * LDB + 32 n].  One wave per SIMD is
+// resident (the tiles fill the LDS), so nothing but the wave's own instruction stream hides the LDS latency: the
+// fragments of step kk + 2 are fetched into a second register set before the matrix cores get step kk.
+template <int NBp>
+__device__ __forceinline__ void cw_frag(const float *__restrict__ ap, const float *__restrict__ bp, float &av, float (&bv)[NBp]) {
+    av = *ap;
+#pragma unroll
+    for (int n = 0; n < NBp; ++n) bv[n] = bp[32 * n];
+}
+template <int NBp>
+__device__ __forceinline__ void cw_slab_mfma(const float *__restrict__ ap, const float *__restrict__ bp, int kn, f16v (&acc)[NBp]) {
+    // kn < 16 (the last slab of a layer whose Cin is no multiple of 16): the slab's rows beyond Cin are zero and the A
+    // values there are replaced by zero (the tile has no such columns) -- mlp_gemm_kernel's K padding, the same bits
+    constexpr int LDB = CwSlab<NBp>::LDB;
+    const int kh = (threadIdx.x >> 5) & 1;
+    float a0, a1, b0[NBp], b1[NBp];
+    cw_frag<NBp>(ap, bp, a0, b0);
+    // sched_barrier: the compiler's scheduler otherwise sinks every LDS read next to its MFMA (fewer live registers) and the
+    // wave then waits out the LDS latency once per pair of MFMAs
+#pragma unroll
+    for (int kk = 0; kk < CW_BK; kk += 4) {
+        cw_frag<NBp>(ap + (kk + 2), bp + (kk + 2) * LDB, a1, b1);
+        a0 = kk + kh < kn ? a0 : 0.f;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int n = 0; n < NBp; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0[n], acc[n], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kk + 4 < CW_BK) cw_frag<NBp>(ap + (kk + 4), bp + (kk + 4) * LDB, a0, b0);
+        a1 = kk + 2 + kh < kn ? a1 : 0.f;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int n = 0; n < NBp; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1[n], acc[n], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+// one layer whose A operand is the wave's activation tile: Cin of its columns against the slabs of W [Cin, Cout]
+template <int NBp>
+__device__ __forceinline__ void cw_layer(const float *__restrict__ Hw, int lda, const float *__restrict__ W, int Cin, int Cout,
+                                         float *__restrict__ Bs2, int &buf, f16v (&acc)[NBp], int tid, int lane) {
+    typedef CwSlab<NBp> SL;
+    const int kh = lane >> 5, lr = lane & 31;
+    float4 bw[SL::BPT];
+    cw_load_b<NBp>(W, Cin, Cout, 0, tid, bw);
+    for (int k0 = 0; k0 < Cin; k0 += CW_BK, buf ^= 1) {
+        float *Bs = Bs2 + buf * (CW_BK * CwSlab<8>::LDB);
+        cw_store_b<NBp>(Bs, tid, bw);
+        __syncthreads();
+        if (k0 + CW_BK < Cin) cw_load_b<NBp>(W, Cin, Cout, k0 + CW_BK, tid, bw);
+        const int kn = Cin - k0 < CW_BK ? Cin - k0 : CW_BK;
+        cw_slab_mfma<NBp>(Hw + lr * lda + k0 + kh, Bs + kh * SL::LDB + lr, kn, acc);
+    }
+}
+// bias + ReLU of an accumulator tile into the wave's activation tile, columns < Cout only
+template <int NBp>
+__device__ __forceinline__ void cw_store(float *__restrict__ Hw, int lda, const float *__restrict__ bias, int Cout, const f16v (&acc)[NBp], int lane) {
+    const int kh = lane >> 5, lr = lane & 31;
+#pragma unroll
+    for (int n = 0; n < NBp; ++n) {
+        const int cn = 32 * n + lr;
+        if (cn < Cout) {
+            const float bv = bias[cn];
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int row = (reg & 3) + 8 * (reg >> 2) + 4 * kh;
+                const float v = acc[n][reg] + bv;
+                Hw[row * lda + cn] = v > 0.f ? v : 0.f;
+            }
+        }
+    }
+}
+
+template <int C1, int C2, int C3, int PK>
+__global__ __launch_bounds__(256) void mlp_chain_wide_kernel(ChainWideArgs a) {
+    constexpr int NB1 = C1 / 32, NB2 = (C2 + 31) / 32, NB3 = C3 / 32;
+    static_assert(C1 % 32 == 0 && C3 % 32 == 0 && C2 % 4 == 0 && NB1 <= 8 && NB2 <= 8 && NB3 <= 8, "chain_wide: widths");
+    constexpr int LDA = chain_lda(C1 > C2 ? C1 : C2);
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *Bs2 = sm;                                   // [2][16][260]: weight slabs
+    float *H = Bs2 + 2 * CW_BK * CwSlab<8>::LDB;       // [4][32][LDA]: the waves' activation tiles
+    float *As2 = H;                                    // [2][128][17]: the gathered A slabs of layer 1 live in the (not yet used) tiles
+    float *Pm = H + 4 * 32 * LDA;                      // [4][C3]
+    static_assert(2 * GM_BM * CW_LDAS <= 4 * 32 * LDA, "chain_wide: the gather slabs alias the activation tiles");
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, kh = lane >> 5, lr = lane & 31;
+    float *Hw = H + wv * 32 * LDA;
+    const int row0 = blockIdx.x * GM_BM;
+    // kernel arguments into locals: a lambda that captured the argument struct by reference kept it in scratch, and every
+    // pointer loaded back from there had lost its address space (flat loads count against the LDS counter too)
+    const int D = a.D, Cin1 = D + 3;
+    const float *const W1 = a.W1, *const W2 = a.W2, *const W3 = a.W3, *const b1 = a.b1, *const b2 = a.b2, *const b3 = a.b3;
+    int buf = 0;
+    {   // ---- layer 1: A from the gather (mlp_gemm_kernel's staging: thread <- 8 consecutive k of one row)
+        const int ar = tid >> 1, ak = (tid & 1) * 8, r = row0 + ar;
+        const size_t prow = (size_t)(r / (a.S * a.K)) * a.Npts + (size_t)a.idx[r];
+        const float *f = a.F + prow * a.D, *q = a.Q + prow * 3, *c = a.C + (size_t)(r / a.K) * 3;
+        // the row's last three columns, xyz - centre, as bit patterns: the slab that holds them is put together with masks
+        // (a chain of selects over run-time values became a table in scratch, and the pointers kept next to it went flat)
+        const int x0 = __float_as_int(q[0] - c[0]), x1 = __float_as_int(q[1] - c[1]), x2 = __float_as_int(q[2] - c[2]);
+        auto load_a = [=](int k0, float (&v)[8]) __attribute__((always_inline)) {
+            const int k = k0 + ak;
+            if (k + 8 <= D) {
+                const float4 p0 = *(const float4 *)(f + k), p1 = *(const float4 *)(f + k + 4);
+                v[0] = p0.x; v[1] = p0.y; v[2] = p0.z; v[3] = p0.w; v[4] = p1.x; v[5] = p1.y; v[6] = p1.z; v[7] = p1.w;
+            } else {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int kx = k + u - D;
+                    const int fv = __float_as_int(f[kx < 0 ? k + u : D - 1]);          // a valid address either way
+                    v[u] = __int_as_float((fv & -(int)(kx < 0)) | (x0 & -(int)(kx == 0)) | (x1 & -(int)(kx == 1)) | (x2 & -(int)(kx == 2)));
+                }
+            }
+        };
+        f16v acc[NB1];
+#pragma unroll
+        for (int n = 0; n < NB1; ++n)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[n][g] = 0.f;
+        typedef CwSlab<NB1> SL;
+        float av8[8];
+        float4 bw[SL::BPT];
+        load_a(0, av8);
+        cw_load_b<NB1>(W1, Cin1, C1, 0, tid, bw);
+        for (int k0 = 0; k0 < Cin1; k0 += CW_BK, buf ^= 1) {
+            float *As = As2 + buf * (GM_BM * CW_LDAS), *Bs = Bs2 + buf * (CW_BK * CwSlab<8>::LDB);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) As[ar * CW_LDAS + ak + u] = av8[u];
+            cw_store_b<NB1>(Bs, tid, bw);
+            __syncthreads();
+            if (k0 + CW_BK < Cin1) { load_a(k0 + CW_BK, av8); cw_load_b<NB1>(W1, Cin1, C1, k0 + CW_BK, tid, bw); }
+            cw_slab_mfma<NB1>(As + (wv * 32 + lr) * CW_LDAS + kh, Bs + kh * SL::LDB + lr, CW_BK, acc);
+        }
+        __syncthreads();                               // the gather slabs share the tiles' space: everybody has read them
+        cw_store<NB1>(Hw, LDA, b1, C1, acc, lane);
+    }
+    {   // ---- layer 2
+        f16v acc[NB2];
+#pragma unroll
+        for (int n = 0; n < NB2; ++n)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[n][g] = 0.f;
+        cw_layer<NB2>(Hw, LDA, W2, C1, C2, Bs2, buf, acc, tid, lane);
+        cw_store<NB2>(Hw, LDA, b2, C2, acc, lane);   // the wave's own tile, after its own last read of it
+    }
+    float mx[NB3];
+    {   // ---- layer 3 + bias + ReLU + max over the wave's 32 rows
+        f16v acc[NB3];
+#pragma unroll
+        for (int n = 0; n < NB3; ++n)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[n][g] = 0.f;
+        cw_layer<NB3>(Hw, LDA, W3, C2, C3, Bs2, buf, acc, tid, lane);
+#pragma unroll
+        for (int n = 0; n < NB3; ++n) {
+            const float bv = b3[32 * n + lr];
+            mx[n] = -INFINITY;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const float v = acc[n][reg] + bv;
+                mx[n] = fmaxf(mx[n], v > 0.f ? v : 0.f);
+            }
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < NB3; ++n) {
+        mx[n] = fmaxf(mx[n], __shfl_xor(mx[n], 32, 64));
+        if (lane < 32) Pm[wv * C3 + 32 * n + lane] = mx[n];
+    }
+    __syncthreads();
+    constexpr int wpg = PK / 32, groups = 4 / wpg;             // waves per pooled group: 2 or 4
+    for (int e = tid; e < groups * C3; e += 256) {
+        const int g = e / C3, cc = e % C3;
+        float m = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < wpg; ++w) m = fmaxf(m, Pm[(g * wpg + w) * C3 + cc]);
+        a.Y[(size_t)((row0 + g * PK) / PK) * a.ldy + a.ycol0 + cc] = m;
+    }
+}
+
+template <int C1, int C2, int C3, int PK>
+static int chain_wide_launch(const ChainWideArgs &a, hipStream_t st) {
+    constexpr size_t lds = sizeof(float) * (2 * CW_BK * CwSlab<8>::LDB + 4 * 32 * chain_lda(C1 > C2 ? C1 : C2) + 4 * C3);
+    static_assert(lds <= 152 * 1024, "chain_wide: weight slabs + activation tiles must fit the LDS of one compute unit");
+    if (lds > REART_LDS_DEFAULT_CAP &&
+        hipFuncSetAttribute((const void *)mlp_chain_wide_kernel<C1, C2, C3, PK>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)
+        return REART_ERR_LAUNCH;
+    hipLaunchKernelGGL((mlp_chain_wide_kernel<C1, C2, C3, PK>), dim3(a.rows / GM_BM), dim3(256), lds, st, a);
+    REART_CHECK_LAUNCH();
+    return REART_OK;
+}
+
+extern "C" int reart_mlp_chain3_wide(const int64_t *gather_idx, int K, int S, int Npts, const float *F, int D, const float *Q,
+                                     const float *C, const float *W1t, const float *b1, int C1, const float *W2t, const float *b2,
+                                     int C2, const float *W3t, const float *b3, int C3, int rows, float *Y, int ldy, int ycol0,
+                                     void *stream) {
+    if (rows < 0 || K < 1 || S < 1 || Npts < 1 || D < 4) return REART_ERR_INVALID_ARG;
+    if (rows == 0) return REART_OK;
+    if (!gather_idx || !F || !Q || !C || !W1t || !b1 || !W2t || !b2 || !W3t || !b3 || !Y) return REART_ERR_INVALID_ARG;
+    if (ycol0 < 0 || ldy < ycol0 + C3 || rows % K != 0) return REART_ERR_INVALID_ARG;
+    if (rows % GM_BM != 0 || D % 4 != 0 || (((size_t)F) & 15) != 0) return REART_ERR_UNSUPPORTED;
+    ChainWideArgs a = {gather_idx, K, S, Npts, F, D, Q, C, W1t, b1, W2t, b2, W3t, b3, rows, Y, ldy, ycol0};
+    hipStream_t st = (hipStream_t)stream;
+    // the two scales of the extractor's sa2 (networks/feature_extractor.py:22-23)
+    if (C1 == 128 && C2 == 128 && C3 == 256 && K == 64) return chain_wide_launch<128, 128, 256, 64>(a, st);
+    if (C1 == 128 && C2 == 196 && C3 == 256 && K == 128) return chain_wide_launch<128, 196, 256, 128>(a, st);
+    return REART_ERR_UNSUPPORTED;
+}
+
+// ---------------------------------------------------------------------------------------
 // 3-NN inverse-distance feature interpolation of PointNetFeaturePropagation
 // (networks/pointnet2_utils.py:326-336) on the reference's square_distance (:33-55):
 //     d = ((-2 * mm) + |q|^2) + |t|^2,   mm = fma(qz, tz, fma(qy, ty, qx * tx))   (torch's K = 3 matmul)

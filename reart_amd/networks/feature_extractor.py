@@ -77,6 +77,7 @@ def _side_stream(device):
 
 
 CHAIN3 = {(32, 32, 64, 32), (64, 64, 128, 64), (64, 96, 128, 128)}    # (C1, C2, C3, nsample) built into reart_mlp_chain3
+CHAIN3_WIDE = {(128, 128, 256, 64), (128, 196, 256, 128)}             # sa2's scales, built into reart_mlp_chain3_wide
 FUSE_CHAIN = True      # False: every layer its own launch (the same bits; tests compare the two)
 
 
@@ -90,6 +91,21 @@ def mlp_chain3(folded, gather, out, out_col):
                             _lib.ptr(gather["C"]), _lib.ptr(W1), _lib.ptr(b1), W1.shape[1], _lib.ptr(W2), _lib.ptr(b2), W2.shape[1],
                             _lib.ptr(W3), _lib.ptr(b3), W3.shape[1], B * S * K, _lib.ptr(out), out.shape[1], out_col, _lib.stream())
     _lib.check(rc, "reart_mlp_chain3")
+    return out
+
+
+def mlp_chain3_wide(folded, gather, out, out_col):
+    """The same for a scale with D (% 4 == 0) feature columns and wide layers (reart_mlp_chain3_wide: the weights stream
+    through LDS, a workgroup carries 128 rows through the three layers)."""
+    L = _lib.lib()
+    (W1, b1), (W2, b2), (W3, b3) = folded
+    B, S, K = gather["idx"].shape
+    F = gather["F"]
+    rc = L.reart_mlp_chain3_wide(_lib.ptr(gather["idx"]), K, S, gather["Npts"], _lib.ptr(F), F.shape[1], _lib.ptr(gather["Q"]),
+                                 _lib.ptr(gather["C"]), _lib.ptr(W1), _lib.ptr(b1), W1.shape[1], _lib.ptr(W2), _lib.ptr(b2),
+                                 W2.shape[1], _lib.ptr(W3), _lib.ptr(b3), W3.shape[1], B * S * K, _lib.ptr(out), out.shape[1], out_col,
+                                 _lib.stream())
+    _lib.check(rc, "reart_mlp_chain3_wide")
     return out
 
 
@@ -148,6 +164,13 @@ class _SAMsg(nn.Module):
                 # sa1: the activations between the three layers stay in LDS (one launch per scale instead of three)
                 folded = [_fold(conv, bn) for conv, bn in zip(self.conv_blocks[i], self.bn_blocks[i])]
                 mlp_chain3(folded, dict(idx=idx, F=F, Q=Q, C=new_xyz.reshape(B * S, 3), Npts=N), out, col)
+                col += widths[-1]
+                continue
+            if (FUSE_CHAIN and n_layers == 3 and widths + (K,) in CHAIN3_WIDE and F.shape[1] % 4 == 0 and (B * S * K) % 128 == 0
+                    and F.data_ptr() % 16 == 0):
+                # sa2: the same with the weights streamed through LDS
+                folded = [_fold(conv, bn) for conv, bn in zip(self.conv_blocks[i], self.bn_blocks[i])]
+                mlp_chain3_wide(folded, dict(idx=idx, F=F, Q=Q, C=new_xyz.reshape(B * S, 3), Npts=N), out, col)
                 col += widths[-1]
                 continue
             for j, (conv, bn) in enumerate(zip(self.conv_blocks[i], self.bn_blocks[i])):

@@ -116,6 +116,41 @@ def test_fused_sa1_chain_equals_the_three_launch_path(dev):
         np.testing.assert_allclose(got[:, 5:5 + C3].cpu().numpy(), want, rtol=2e-5, atol=2e-5 * np.abs(want).max())
 
 
+def test_fused_sa2_chain_equals_the_three_launch_path(dev):
+    """reart_mlp_chain3_wide (sa2's scales: 323 -> 128 -> 128 | 196 -> 256, weights streamed through LDS) against three
+    reart_mlp_layer launches: the same bits; and float64 on the host."""
+    from reart_amd.networks import feature_extractor as fe
+
+    rng = np.random.default_rng(6)
+    for (C1, C2, C3, K), (B, S, Npts, D) in (((128, 128, 256, 64), (2, 6, 70, 320)), ((128, 196, 256, 128), (3, 5, 200, 320)),
+                                            ((128, 196, 256, 128), (2, 128, 512, 320)), ((128, 128, 256, 64), (1, 2, 64, 8))):
+        F = rng.normal(size=(B * Npts, D)).astype(np.float32)
+        Q = rng.normal(size=(B * Npts, 3)).astype(np.float32)
+        C = rng.normal(size=(B * S, 3)).astype(np.float32)
+        idx = rng.integers(0, Npts, (B, S, K))
+        folded = []
+        cin = D + 3
+        for cout in (C1, C2, C3):
+            folded.append((t((rng.normal(size=(cin, cout)) * np.sqrt(2.0 / cin)).astype(np.float32), dev),
+                           t(rng.normal(0, 0.1, cout).astype(np.float32), dev)))
+            cin = cout
+        g = dict(idx=t(idx, dev), F=t(F, dev), Q=t(Q, dev), C=t(C, dev), Npts=Npts, xyz_first=0)
+        h = fe.mlp_layer(None, *folded[0], gather=g)
+        h = fe.mlp_layer(h, *folded[1])
+        ref = torch.full((B * S, C3 + 7), -3.0, device=dev)
+        fe.mlp_layer(h, *folded[2], pool_k=K, out=ref, out_col=5)
+        got = torch.full((B * S, C3 + 7), -3.0, device=dev)
+        fe.mlp_chain3_wide(folded, g, got, 5)
+        assert torch.equal(got, ref), (C1, C2, C3, K, float((got - ref).abs().max()))
+        Fg = F.reshape(B, Npts, D)[np.arange(B)[:, None, None], idx]
+        Qg = Q.reshape(B, Npts, 3)[np.arange(B)[:, None, None], idx] - C.reshape(B, S, 1, 3)
+        X = np.concatenate([Fg, Qg], -1).reshape(-1, D + 3).astype(np.float64)
+        for W, bvec in folded:
+            X = np.maximum(X @ W.cpu().numpy().astype(np.float64) + bvec.cpu().numpy(), 0)
+        want = X.reshape(B * S, K, C3).max(1)
+        np.testing.assert_allclose(got[:, 5:5 + C3].cpu().numpy(), want, rtol=5e-5, atol=5e-5 * np.abs(want).max())
+
+
 def test_extractor_same_bits_with_and_without_the_fused_chain(dev):
     from reart_amd.networks import feature_extractor as fe
     from reart_amd.synthetic import extractor_state
