@@ -268,7 +268,7 @@ struct Chain3Args {
     float *Y; int ldy, ycol0;
 };
 __host__ __device__ constexpr int chain_ldb(int c) { return c + 4; }   // like mlp_gemm_kernel's B tile
-__host__ __device__ constexpr int chain_lda(int c) { return c + 2; }   // = 2 (mod 4): 32 rows on 32 distinct even banks, k + 1 on the odd ones
+__host__ __device__ constexpr int chain_lda(int c) { return c + 2; }   // (measured in mlp_chain_wide_kernel: an odd stride, conflict-free for ds_read_b32's 32 banks, is 1 % slower)
 
 template <int NB, int LDB>
 __device__ __forceinline__ void chain_layer(const float *__restrict__ Hw, int lda, const float *__restrict__ Ws, int Cin, f16v (&acc)[NB],
@@ -441,19 +441,30 @@ struct ChainWideArgs {
     float *Y; int ldy, ycol0;
 };
 #define CW_BK 16
+#ifndef CW_SCHED
+#define CW_SCHED 1
+#endif
+#if CW_SCHED
+#define CW_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define CW_SCHED_FENCE() ((void)0)
+#endif
 #define CW_LDAS (CW_BK + 1)
 template <int NBp> struct CwSlab {
     static constexpr int BN = 32 * NBp, LDB = BN + 4, NBF = CW_BK * BN / 4, BPT = (NBF + 255) / 256;
 };
-// rows [k0, k0 + 16) of a transposed weight matrix [Cin, Cout] (Cout % 4 == 0), zero beyond either edge
+// rows [k0, k0 + 16) of a transposed weight matrix [Cin, Cout] (Cout % 4 == 0).  No zero padding and no branches: beyond
+// either edge the address is clamped to the last row / the last four columns.  A row beyond Cin only ever meets an A value
+// of exactly zero (the gather slabs and cw_slab_mfma see to that) and a column beyond Cout is never stored, so what is
+// loaded there does not reach a result (a finite weight times zero adds a zero of either sign to the accumulator).
 template <int NBp>
 __device__ __forceinline__ void cw_load_b(const float *__restrict__ W, int Cin, int Cout, int k0, int tid, float4 (&bw)[CwSlab<NBp>::BPT]) {
     typedef CwSlab<NBp> SL;
 #pragma unroll
     for (int h = 0; h < SL::BPT; ++h) {
-        const int f = tid + 256 * h, k = k0 + f / (SL::BN / 4), cc = (f % (SL::BN / 4)) * 4;
-        float4 w = {0.f, 0.f, 0.f, 0.f};
-        if (f < SL::NBF && k < Cin && cc < Cout) w = *(const float4 *)(W + (size_t)k * Cout + cc);
+        const int f = tid + 256 * h < SL::NBF ? tid + 256 * h : SL::NBF - 1;
+        const int k = min(k0 + f / (SL::BN / 4), Cin - 1), cc = min((f % (SL::BN / 4)) * 4, Cout - 4);
+        const float4 w = *(const float4 *)(W + (size_t)k * Cout + cc);      // (assigning the load straight to bw[h] kept the array in scratch)
         bw[h] = w;
     }
 }
@@ -475,47 +486,66 @@ __device__ __forceinline__ void cw_frag(const float *__restrict__ ap, const floa
 #pragma unroll
     for (int n = 0; n < NBp; ++n) bv[n] = bp[32 * n];
 }
+// In two parts, so that the caller can issue its global loads for the next slab once the matrix cores have their first
+// group: the loads' address arithmetic then runs in the shadow of the MFMAs instead of between the barrier and the first of
+// them.  (Passing the loads in as a lambda sent the registers they fill through scratch.)
+// kn < 16 (the last slab of a layer whose Cin is no multiple of 16): the A values beyond Cin are replaced by zero (the tile
+// has no such columns) -- mlp_gemm_kernel's K padding, the same bits.
+// sched_barrier: the compiler's scheduler otherwise sinks every LDS read next to its MFMA (fewer live registers) and the
+// wave then waits out the LDS latency once per pair of MFMAs.
+template <int NBp> struct CwFrags { float a0, a1, b0[NBp], b1[NBp]; };
 template <int NBp>
-__device__ __forceinline__ void cw_slab_mfma(const float *__restrict__ ap, const float *__restrict__ bp, int kn, f16v (&acc)[NBp]) {
-    // kn < 16 (the last slab of a layer whose Cin is no multiple of 16): the slab's rows beyond Cin are zero and the A
-    // values there are replaced by zero (the tile has no such columns) -- mlp_gemm_kernel's K padding, the same bits
+__device__ __forceinline__ void cw_slab_head(const float *__restrict__ ap, const float *__restrict__ bp, int kn, f16v (&acc)[NBp], CwFrags<NBp> &r) {
     constexpr int LDB = CwSlab<NBp>::LDB;
     const int kh = (threadIdx.x >> 5) & 1;
-    float a0, a1, b0[NBp], b1[NBp];
-    cw_frag<NBp>(ap, bp, a0, b0);
-    // sched_barrier: the compiler's scheduler otherwise sinks every LDS read next to its MFMA (fewer live registers) and the
-    // wave then waits out the LDS latency once per pair of MFMAs
+    cw_frag<NBp>(ap, bp, r.a0, r.b0);
+    cw_frag<NBp>(ap + 2, bp + 2 * LDB, r.a1, r.b1);
+    r.a0 = kh < kn ? r.a0 : 0.f;
+    CW_SCHED_FENCE();
+#pragma unroll
+    for (int n = 0; n < NBp; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(r.a0, r.b0[n], acc[n], 0, 0, 0);
+    CW_SCHED_FENCE();
+}
+template <int NBp>
+__device__ __forceinline__ void cw_slab_tail(const float *__restrict__ ap, const float *__restrict__ bp, int kn, f16v (&acc)[NBp], CwFrags<NBp> &r) {
+    constexpr int LDB = CwSlab<NBp>::LDB;
+    const int kh = (threadIdx.x >> 5) & 1;
+    CW_SCHED_FENCE();
 #pragma unroll
     for (int kk = 0; kk < CW_BK; kk += 4) {
-        cw_frag<NBp>(ap + (kk + 2), bp + (kk + 2) * LDB, a1, b1);
-        a0 = kk + kh < kn ? a0 : 0.f;
-        __builtin_amdgcn_sched_barrier(0);
+        if (kk > 0) {
+            cw_frag<NBp>(ap + (kk + 2), bp + (kk + 2) * LDB, r.a1, r.b1);
+            r.a0 = kk + kh < kn ? r.a0 : 0.f;
+            CW_SCHED_FENCE();
 #pragma unroll
-        for (int n = 0; n < NBp; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0[n], acc[n], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (kk + 4 < CW_BK) cw_frag<NBp>(ap + (kk + 4), bp + (kk + 4) * LDB, a0, b0);
-        a1 = kk + 2 + kh < kn ? a1 : 0.f;
-        __builtin_amdgcn_sched_barrier(0);
+            for (int n = 0; n < NBp; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(r.a0, r.b0[n], acc[n], 0, 0, 0);
+            CW_SCHED_FENCE();
+        }
+        if (kk + 4 < CW_BK) cw_frag<NBp>(ap + (kk + 4), bp + (kk + 4) * LDB, r.a0, r.b0);
+        r.a1 = kk + 2 + kh < kn ? r.a1 : 0.f;
+        CW_SCHED_FENCE();
 #pragma unroll
-        for (int n = 0; n < NBp; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1[n], acc[n], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int n = 0; n < NBp; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(r.a1, r.b1[n], acc[n], 0, 0, 0);
+        CW_SCHED_FENCE();
     }
 }
 // one layer whose A operand is the wave's activation tile: Cin of its columns against the slabs of W [Cin, Cout]
+// (bw: the layer's first slab, fetched by the caller while the previous layer was still on the matrix cores)
 template <int NBp>
 __device__ __forceinline__ void cw_layer(const float *__restrict__ Hw, int lda, const float *__restrict__ W, int Cin, int Cout,
-                                         float *__restrict__ Bs2, int &buf, f16v (&acc)[NBp], int tid, int lane) {
+                                         float *__restrict__ Bs2, int &buf, f16v (&acc)[NBp], int tid, int lane,
+                                         float4 (&bw)[CwSlab<NBp>::BPT]) {
     typedef CwSlab<NBp> SL;
     const int kh = lane >> 5, lr = lane & 31;
-    float4 bw[SL::BPT];
-    cw_load_b<NBp>(W, Cin, Cout, 0, tid, bw);
     for (int k0 = 0; k0 < Cin; k0 += CW_BK, buf ^= 1) {
         float *Bs = Bs2 + buf * (CW_BK * CwSlab<8>::LDB);
         cw_store_b<NBp>(Bs, tid, bw);
         __syncthreads();
-        if (k0 + CW_BK < Cin) cw_load_b<NBp>(W, Cin, Cout, k0 + CW_BK, tid, bw);
         const int kn = Cin - k0 < CW_BK ? Cin - k0 : CW_BK;
-        cw_slab_mfma<NBp>(Hw + lr * lda + k0 + kh, Bs + kh * SL::LDB + lr, kn, acc);
+        CwFrags<NBp> fr;
+        cw_slab_head<NBp>(Hw + lr * lda + k0 + kh, Bs + kh * SL::LDB + lr, kn, acc, fr);
+        if (k0 + CW_BK < Cin) cw_load_b<NBp>(W, Cin, Cout, k0 + CW_BK, tid, bw);
+        cw_slab_tail<NBp>(Hw + lr * lda + k0 + kh, Bs + kh * SL::LDB + lr, kn, acc, fr);
     }
 }
 // bias + ReLU of an accumulator tile into the wave's activation tile, columns < Cout only
@@ -556,6 +586,11 @@ __global__ __launch_bounds__(256) void mlp_chain_wide_kernel(ChainWideArgs a) {
     const int D = a.D, Cin1 = D + 3;
     const float *const W1 = a.W1, *const W2 = a.W2, *const W3 = a.W3, *const b1 = a.b1, *const b2 = a.b2, *const b3 = a.b3;
     int buf = 0;
+    float4 bw2[CwSlab<NB2>::BPT], bw3[CwSlab<NB3>::BPT];
+#ifndef CW_XPHASE
+#define CW_XPHASE 1
+#endif
+    if (CW_XPHASE) cw_load_b<NB2>(W2, C1, C2, 0, tid, bw2);           // layer 2's first slab waits in registers through layer 1
     {   // ---- layer 1: A from the gather (mlp_gemm_kernel's staging: thread <- 8 consecutive k of one row)
         const int ar = tid >> 1, ak = (tid & 1) * 8, r = row0 + ar;
         const size_t prow = (size_t)(r / (a.S * a.K)) * a.Npts + (size_t)a.idx[r];
@@ -583,19 +618,34 @@ __global__ __launch_bounds__(256) void mlp_chain_wide_kernel(ChainWideArgs a) {
 #pragma unroll
             for (int g = 0; g < 16; ++g) acc[n][g] = 0.f;
         typedef CwSlab<NB1> SL;
-        float av8[8];
+        // The gathered rows come from all over a cloud's feature matrix (25 MB at T = 20: beyond L2), and with one workgroup
+        // per compute unit nobody else hides that latency: a slab keeps the matrix cores busy for 2048 cycles, a row takes
+        // longer to arrive.  Three slabs of rows are in flight (three register sets, the loop unrolled over them).
+        float av0[8], av1[8], av2[8];
         float4 bw[SL::BPT];
-        load_a(0, av8);
+        load_a(0, av0);
+        load_a(CW_BK, av1);                            // (beyond Cin1 a set is simply never stored)
+        load_a(2 * CW_BK, av2);
         cw_load_b<NB1>(W1, Cin1, C1, 0, tid, bw);
-        for (int k0 = 0; k0 < Cin1; k0 += CW_BK, buf ^= 1) {
-            float *As = As2 + buf * (GM_BM * CW_LDAS), *Bs = Bs2 + buf * (CW_BK * CwSlab<8>::LDB);
-#pragma unroll
-            for (int u = 0; u < 8; ++u) As[ar * CW_LDAS + ak + u] = av8[u];
-            cw_store_b<NB1>(Bs, tid, bw);
-            __syncthreads();
-            if (k0 + CW_BK < Cin1) { load_a(k0 + CW_BK, av8); cw_load_b<NB1>(W1, Cin1, C1, k0 + CW_BK, tid, bw); }
-            cw_slab_mfma<NB1>(As + (wv * 32 + lr) * CW_LDAS + kh, Bs + kh * SL::LDB + lr, CW_BK, acc);
+#define CW_GATHER_SLAB(K0, AV)                                                                                              \
+        if ((K0) < Cin1) {                                                                                                   \
+            float *As = As2 + buf * (GM_BM * CW_LDAS), *Bs = Bs2 + buf * (CW_BK * CwSlab<8>::LDB);                           \
+            _Pragma("unroll") for (int u = 0; u < 8; ++u) As[ar * CW_LDAS + ak + u] = AV[u];                                 \
+            cw_store_b<NB1>(Bs, tid, bw);                                                                                    \
+            __syncthreads();                                                                                                 \
+            CwFrags<NB1> fr;                                                                                                 \
+            cw_slab_head<NB1>(As + (wv * 32 + lr) * CW_LDAS + kh, Bs + kh * SL::LDB + lr, CW_BK, acc, fr);                   \
+            if ((K0) + 3 * CW_BK < Cin1) load_a((K0) + 3 * CW_BK, AV);                                                       \
+            if ((K0) + CW_BK < Cin1) cw_load_b<NB1>(W1, Cin1, C1, (K0) + CW_BK, tid, bw);                                    \
+            cw_slab_tail<NB1>(As + (wv * 32 + lr) * CW_LDAS + kh, Bs + kh * SL::LDB + lr, CW_BK, acc, fr);                   \
+            buf ^= 1;                                                                                                        \
         }
+        for (int k0 = 0; k0 < Cin1; k0 += 3 * CW_BK) {
+            CW_GATHER_SLAB(k0, av0)
+            CW_GATHER_SLAB(k0 + CW_BK, av1)
+            CW_GATHER_SLAB(k0 + 2 * CW_BK, av2)
+        }
+#undef CW_GATHER_SLAB
         __syncthreads();                               // the gather slabs share the tiles' space: everybody has read them
         cw_store<NB1>(Hw, LDA, b1, C1, acc, lane);
     }
@@ -605,7 +655,9 @@ __global__ __launch_bounds__(256) void mlp_chain_wide_kernel(ChainWideArgs a) {
         for (int n = 0; n < NB2; ++n)
 #pragma unroll
             for (int g = 0; g < 16; ++g) acc[n][g] = 0.f;
-        cw_layer<NB2>(Hw, LDA, W2, C1, C2, Bs2, buf, acc, tid, lane);
+        if (!CW_XPHASE) cw_load_b<NB2>(W2, C1, C2, 0, tid, bw2);
+        if (CW_XPHASE) cw_load_b<NB3>(W3, C2, C3, 0, tid, bw3);
+        cw_layer<NB2>(Hw, LDA, W2, C1, C2, Bs2, buf, acc, tid, lane, bw2);
         cw_store<NB2>(Hw, LDA, b2, C2, acc, lane);   // the wave's own tile, after its own last read of it
     }
     float mx[NB3];
@@ -615,7 +667,8 @@ __global__ __launch_bounds__(256) void mlp_chain_wide_kernel(ChainWideArgs a) {
         for (int n = 0; n < NB3; ++n)
 #pragma unroll
             for (int g = 0; g < 16; ++g) acc[n][g] = 0.f;
-        cw_layer<NB3>(Hw, LDA, W3, C2, C3, Bs2, buf, acc, tid, lane);
+        if (!CW_XPHASE) cw_load_b<NB3>(W3, C2, C3, 0, tid, bw3);
+        cw_layer<NB3>(Hw, LDA, W3, C2, C3, Bs2, buf, acc, tid, lane, bw3);
 #pragma unroll
         for (int n = 0; n < NB3; ++n) {
             const float bv = b3[32 * n + lr];
