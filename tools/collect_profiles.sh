@@ -28,6 +28,11 @@ done
 # 3. the other two configs
 timeout 900 rocprofv3 --kernel-trace --stats -f csv -d $O/stats_kinematic -- python3 bench.py --config kinematic --no-cpu-baseline > $O/bench_kinematic_under_rocprof.json 2> $O/stats_kinematic.err
 timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $O/stats_extractor -- python3 bench.py --config extractor --no-cpu-baseline > $O/bench_extractor_under_rocprof.json 2> $O/stats_extractor.err
+# 4. matrix-core counters of the extractor's dense kernels
+bash tools/pmc_extractor.sh > $O/pmc_extractor.log 2>&1
+python3 tools/pmc_extractor_json.py gpurun_out/pmc_ext > $O/pmc_extractor_mfma.json 2> $O/pmc_extractor_json.err
+# 5. the nao line (BASELINE configs[2])
+timeout 300 python3 bench.py --config nao > $O/bench_nao.json 2> $O/bench_nao.err
 # summaries
 for d in stats_clean stats_kinematic stats_extractor; do
   f=$(find $O/$d -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/$d.kernel_stats.csv
