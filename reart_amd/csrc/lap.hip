@@ -959,6 +959,7 @@ __device__ __forceinline__ int jv_order(int k, int cnt, int racer) {
     if (racer == 1) return cnt - 1 - k;
     return (int)(((unsigned)k * (unsigned)(jv_race_prime[racer] % cnt)) % (unsigned)cnt);   // the primes exceed every count: a permutation
 }
+typedef float jv_f2 __attribute__((ext_vector_type(2)));
 #define JV_OWNED (1 << 30)  // tie key of the path search's arg-min: owned columns after unowned ones
 #define JV_PTS_NMAX 2048   // points form: both point sets + the solver state must fit in LDS
 #ifndef JV_PTS_BS
@@ -1165,17 +1166,25 @@ __global__ __launch_bounds__(BS) void lap_jv_kernel(JvArgs a) {
     // makes the new pair tight -- and the row it displaces is handled next.  One row scan per step, no search: most of
     // the rows a small change of the costs has released settle here.  Exact ties and the rows left when the step budget
     // runs out go to the path search below.  The chain is sequential.
-    float tcx[JV_CPT], tcy[JV_CPT], tcz[JV_CPT];       // PTS: this thread's columns (target points), in registers
+    // PTS: this thread's columns (target points) in registers, two per packed-fp32 operand: a step is bound by the
+    // instructions its waves issue (two waves per SIMD, ~50 per column), and reart_sqdist3 on pairs halves its share
+    static_assert(JV_CPT % 2 == 0, "columns per thread come in pairs");
+    jv_f2 tcx[JV_CPT / 2], tcy[JV_CPT / 2], tcz[JV_CPT / 2];
 #pragma unroll
     for (int k = 0; k < JV_CPT; ++k) {
         const int j = tid + k * BS < n ? tid + k * BS : 0;
-        tcx[k] = PTS ? ptx[j] : 0.f; tcy[k] = PTS ? pty[j] : 0.f; tcz[k] = PTS ? ptz[j] : 0.f;
+        tcx[k >> 1][k & 1] = PTS ? ptx[j] : 0.f; tcy[k >> 1][k & 1] = PTS ? pty[j] : 0.f; tcz[k >> 1][k & 1] = PTS ? ptz[j] : 0.f;
     }
     auto row_costs = [&](int i, float (&rc)[JV_CPT]) {
         if (PTS) {
             const float ax = psx[i], ay = psy[i], az = psz[i];
+            const jv_f2 ax2 = {ax, ax}, ay2 = {ay, ay}, az2 = {az, az};
 #pragma unroll
-            for (int k = 0; k < JV_CPT; ++k) rc[k] = sqrtf(reart_sqdist3(ax, ay, az, tcx[k], tcy[k], tcz[k]));
+            for (int k = 0; k < JV_CPT / 2; ++k) {
+                const jv_f2 dx = ax2 - tcx[k], dy = ay2 - tcy[k], dz = az2 - tcz[k];
+                const jv_f2 sq = (dx * dx + dy * dy) + dz * dz;               // reart_sqdist3, two columns at a time
+                rc[2 * k] = sqrtf(sq.x); rc[2 * k + 1] = sqrtf(sq.y);
+            }
         } else {
             const float *row = C + (size_t)i * n;
 #pragma unroll
@@ -1260,6 +1269,11 @@ __global__ __launch_bounds__(BS) void lap_jv_kernel(JvArgs a) {
 
     JPH(7);
     // ---- one shortest augmenting path per free row
+    // The prices of this thread's columns stay in registers through all searches (LDS keeps a copy for the certificate):
+    // read from LDS inside the step each one was a latency the step waited out.
+    double pj[JV_CPT];
+#pragma unroll
+    for (int k = 0; k < JV_CPT; ++k) pj[k] = tid + k * BS < n ? price[tid + k * BS] : 0.0;
     for (int f = 0; f < nfree; ++f) {
         const int i0 = flist[jv_order(f, nfree, racer)];
         double d[JV_CPT];
@@ -1277,7 +1291,7 @@ __global__ __launch_bounds__(BS) void lap_jv_kernel(JvArgs a) {
 #pragma unroll
             for (int k = 0; k < JV_CPT; ++k) {
                 const int j = tid + k * BS;
-                d[k] = j < n ? ((double)rc0[k] + price[j]) - ui : INFINITY;
+                d[k] = j < n ? ((double)rc0[k] + pj[k]) - ui : INFINITY;
                 if (j < n) pred[j] = i0;
                 if (j >= n) scanned |= 1u << k;
             }
@@ -1315,17 +1329,18 @@ __global__ __launch_bounds__(BS) void lap_jv_kernel(JvArgs a) {
             const int i = owner[jstar];
             if (i < 0) { sink = jstar; break; }
             // the step's costs: every column of this thread in row i (matrix form: the ONE dependent global read of
-            // the step, all loads in flight together; points form: no memory beyond LDS at all)
+            // the step, all loads in flight together; points form: no memory beyond LDS at all).  All columns are
+            // evaluated, labelled ones included (a search labels ~ 7 % of them), and the relaxation is a select: the
+            // thread's columns advance together instead of one conditional block after the other
             float rc[JV_CPT];
             row_costs(i, rc);
             const double ui = u[i];
 #pragma unroll
             for (int k = 0; k < JV_CPT; ++k) {
-                const int j = tid + k * BS;
-                if (!((scanned >> k) & 1u)) {
-                    const double nd = mu + (((double)rc[k] + price[j]) - ui);
-                    if (nd < d[k]) { d[k] = nd; pred[j] = i; }
-                }
+                const double nd = mu + (((double)rc[k] + pj[k]) - ui);
+                const bool better = !((scanned >> k) & 1u) && nd < d[k];
+                d[k] = better ? nd : d[k];
+                if (better) pred[tid + k * BS] = i;
             }
             JPH(3);
         }
@@ -1336,7 +1351,8 @@ __global__ __launch_bounds__(BS) void lap_jv_kernel(JvArgs a) {
             const int j = tid + k * BS;
             if (j < n && ((scanned >> k) & 1u) && j != sink) {
                 const double delta = mu - d[k];
-                price[j] += delta;
+                pj[k] += delta;
+                price[j] = pj[k];
                 u[owner[j]] += delta;
             }
         }

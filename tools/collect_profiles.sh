@@ -13,7 +13,12 @@ CLEAN="--sweep-instances 0 --no-tail --no-cpu-baseline --no-secondary"
 # reported and skipped (exit 7) so that the call can simply be repeated.
 KMS=$(timeout 300 python3 bench.py --steps 300 --warmup 150 $CLEAN --profile-steps 0 2>/dev/null | python3 -c "import json,sys; print(json.loads(sys.stdin.read())['roofline']['kernel_ms'])")
 echo "probe: search launch $KMS ms"
-if python3 -c "import sys; sys.exit(0 if float('$KMS') > 0.038 else 1)"; then echo "slow-search box: profile set not collected"; exit 7; fi
+if python3 -c "import sys; sys.exit(0 if float('$KMS') > 0.038 else 1)"; then
+  echo "slow-search box: profile set not collected"
+  # what is different about this box?  (kept next to the profiles when it happens: gpurun_out/slowbox_diag.txt)
+  { date; rocm-smi --showcomputepartition --showmemorypartition --showclocks --showperflevel --showpower 2>&1; rocminfo 2>&1 | grep -i -E "xnack|Compute Unit|Max Clock|Cacheline|L2|L3|Marketing|Coherent|Memory Properties" | sort | uniq -c; env | grep -E "^(HSA|HIP|ROC|GPU|AMD)" ; } > gpurun_out/slowbox_diag.txt 2>&1
+  exit 7
+fi
 # 0. the plain bench lines (no profiler)
 timeout 900 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
 timeout 600 python3 bench.py --config kinematic > $O/bench_kinematic.json 2> $O/bench_kinematic.err
