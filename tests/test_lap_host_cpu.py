@@ -122,3 +122,17 @@ def test_racing_branch_requires_gpu_points():
 
     with pytest.raises(RuntimeError):
         lap.linear_sum_assignment_batch(torch.rand(1, 4, 4), race=True)
+
+
+def test_resolve_racer_count():
+    """Host policy of the raced re-solve: a racer is one workgroup holding a compute unit's LDS, the chip has 256; short
+    problems (one launch) and batches that leave no idle unit are not raced."""
+    from reart_amd.utils import lap
+
+    assert lap._resolve_racers(19, 2048) == min(lap.RESOLVE_RACERS, 13)
+    assert lap._resolve_racers(19, 2048, race=False) == 1
+    assert lap._resolve_racers(19, 511) == 1
+    assert lap._resolve_racers(100, 1024) == 2
+    assert lap._resolve_racers(129, 1024) == 1
+    assert lap._resolve_racers(1, 2048) == lap.RESOLVE_RACERS
+    assert 2 <= lap.RESOLVE_RACERS <= 13 or lap.RESOLVE_RACERS == 1

@@ -33,7 +33,8 @@ def test_fps_and_ball_query_reference_golden(dev):
 
 
 @pytest.mark.parametrize("cuda_mode", [False, True])
-@pytest.mark.parametrize("N,M", [(1, 1), (70, 70), (1000, 33), (4096, 1024), (5000, 64)])
+@pytest.mark.parametrize("N,M", [(1, 1), (70, 70), (300, 50), (512, 128), (513, 40), (1000, 33), (1025, 30), (2049, 20), (4096, 1024),
+                                 (5000, 64), (8192, 16), (12288, 12)])      # every (threads, points per thread) instantiation
 def test_fps_vs_oracle(oracle, dev, cuda_mode, N, M):
     from reart_amd.networks.pointnet2_utils import farthest_point_sample
 
@@ -46,6 +47,23 @@ def test_fps_vs_oracle(oracle, dev, cuda_mode, N, M):
     ref = oracle.fps(xyz, M, start=start, cuda_mode=cuda_mode)
     got = farthest_point_sample(t(xyz, dev), M, start=t(start, dev), cuda_mode=cuda_mode)
     np.testing.assert_array_equal(got.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("cuda_mode", [False, True])
+def test_fps_all_ties(oracle, dev, cuda_mode):
+    """Every distance equal (coincident points; a two-value lattice): the whole sequence is decided by the reference's tie
+    rule -- lowest thread of the CUDA block then lowest index, or first maximum -- which the kernel carries as a key."""
+    from reart_amd.networks.pointnet2_utils import farthest_point_sample
+
+    rng = np.random.default_rng(77)
+    for N, M in ((640, 40), (4096, 24)):
+        xyz = np.zeros((3, N, 3), np.float32)
+        xyz[1] = rng.integers(0, 2, (N, 3)).astype(np.float32)            # the corners of a cube, many copies of each
+        xyz[2, ::3] = 1.0
+        start = np.array([0, N - 1, N // 2], np.int32)
+        ref = oracle.fps(xyz, M, start=start, cuda_mode=cuda_mode)
+        got = farthest_point_sample(t(xyz, dev), M, start=t(start, dev), cuda_mode=cuda_mode)
+        np.testing.assert_array_equal(got.cpu().numpy(), ref)
 
 
 @pytest.mark.parametrize("cuda_mode", [False, True])
