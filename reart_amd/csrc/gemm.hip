@@ -444,6 +444,27 @@ struct ChainWideArgs {
 #ifndef CW_SCHED
 #define CW_SCHED 1
 #endif
+// diagnostic build (-DCW_CLOCK): where a wave of mlp_chain_wide_kernel spends its cycles (tools/cw_clock.py)
+#ifdef CW_CLOCK
+__device__ unsigned long long cw_clock_acc[16];
+#define CW_T(v) const long long v = clock64()
+struct CwClk { long long v[10]; };
+#define CW_CLK_ARG , CwClk &clk
+#define CW_CLK_PASS , clk
+#define CW_ADD(i, d) (clk.v[i] += (d))
+#define CW_FLUSH(i, d) do { if ((threadIdx.x & 63) == 0) atomicAdd(&cw_clock_acc[i], (unsigned long long)(d)); } while (0)
+extern "C" int reart_debug_cw_clock(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(cw_clock_acc), sizeof(cw_clock_acc)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(cw_clock_acc), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#else
+#define CW_T(v) ((void)0)
+#define CW_ADD(i, d) ((void)0)
+#define CW_FLUSH(i, d) ((void)0)
+#define CW_CLK_ARG
+#define CW_CLK_PASS
+#endif
 #if CW_SCHED
 #define CW_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #else
@@ -494,39 +515,41 @@ __device__ __forceinline__ void cw_frag(const float *__restrict__ ap, const floa
 // sched_barrier: the compiler's scheduler otherwise sinks every LDS read next to its MFMA (fewer live registers) and the
 // wave then waits out the LDS latency once per pair of MFMAs.
 template <int NBp> struct CwFrags { float a0, a1, b0[NBp], b1[NBp]; };
+// one k-step of a slab: the first MFMA of the group goes out, THEN the LDS reads of the next step are issued (the compiler
+// waits with lgkmcnt(0) before a group, i.e. also for reads issued just ahead of it: issued behind the group's first MFMA
+// they have the rest of the group -- 192 cycles with four accumulators, 448 with eight -- to arrive)
+template <int NBp>
+__device__ __forceinline__ void cw_kstep(float a, const float (&b)[NBp], f16v (&acc)[NBp], const float *__restrict__ ap_next,
+                                         const float *__restrict__ bp_next, bool fetch, float &a_next, float (&b_next)[NBp]) {
+    CW_SCHED_FENCE();
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[0], acc[0], 0, 0, 0);
+    CW_SCHED_FENCE();
+    if (fetch) cw_frag<NBp>(ap_next, bp_next, a_next, b_next);
+    CW_SCHED_FENCE();
+#pragma unroll
+    for (int n = 1; n < NBp; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[n], acc[n], 0, 0, 0);
+    CW_SCHED_FENCE();
+}
 template <int NBp>
 __device__ __forceinline__ void cw_slab_head(const float *__restrict__ ap, const float *__restrict__ bp, int kn, f16v (&acc)[NBp], CwFrags<NBp> &r) {
     constexpr int LDB = CwSlab<NBp>::LDB;
     const int kh = (threadIdx.x >> 5) & 1;
     cw_frag<NBp>(ap, bp, r.a0, r.b0);
-    cw_frag<NBp>(ap + 2, bp + 2 * LDB, r.a1, r.b1);
     r.a0 = kh < kn ? r.a0 : 0.f;
-    CW_SCHED_FENCE();
-#pragma unroll
-    for (int n = 0; n < NBp; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(r.a0, r.b0[n], acc[n], 0, 0, 0);
-    CW_SCHED_FENCE();
+    cw_kstep<NBp>(r.a0, r.b0, acc, ap + 2, bp + 2 * LDB, true, r.a1, r.b1);
 }
 template <int NBp>
 __device__ __forceinline__ void cw_slab_tail(const float *__restrict__ ap, const float *__restrict__ bp, int kn, f16v (&acc)[NBp], CwFrags<NBp> &r) {
     constexpr int LDB = CwSlab<NBp>::LDB;
     const int kh = (threadIdx.x >> 5) & 1;
-    CW_SCHED_FENCE();
 #pragma unroll
-    for (int kk = 0; kk < CW_BK; kk += 4) {
-        if (kk > 0) {
-            cw_frag<NBp>(ap + (kk + 2), bp + (kk + 2) * LDB, r.a1, r.b1);
-            r.a0 = kk + kh < kn ? r.a0 : 0.f;
-            CW_SCHED_FENCE();
-#pragma unroll
-            for (int n = 0; n < NBp; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(r.a0, r.b0[n], acc[n], 0, 0, 0);
-            CW_SCHED_FENCE();
+    for (int kk = 2; kk < CW_BK; kk += 4) {
+        r.a1 = kk + kh < kn ? r.a1 : 0.f;
+        cw_kstep<NBp>(r.a1, r.b1, acc, ap + (kk + 2), bp + (kk + 2) * LDB, kk + 2 < CW_BK, r.a0, r.b0);
+        if (kk + 2 < CW_BK) {
+            r.a0 = kk + 2 + kh < kn ? r.a0 : 0.f;
+            cw_kstep<NBp>(r.a0, r.b0, acc, ap + (kk + 4), bp + (kk + 4) * LDB, kk + 4 < CW_BK, r.a1, r.b1);
         }
-        if (kk + 4 < CW_BK) cw_frag<NBp>(ap + (kk + 4), bp + (kk + 4) * LDB, r.a0, r.b0);
-        r.a1 = kk + 2 + kh < kn ? r.a1 : 0.f;
-        CW_SCHED_FENCE();
-#pragma unroll
-        for (int n = 0; n < NBp; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(r.a1, r.b1[n], acc[n], 0, 0, 0);
-        CW_SCHED_FENCE();
     }
 }
 // one layer whose A operand is the wave's activation tile: Cin of its columns against the slabs of W [Cin, Cout]
@@ -534,18 +557,24 @@ __device__ __forceinline__ void cw_slab_tail(const float *__restrict__ ap, const
 template <int NBp>
 __device__ __forceinline__ void cw_layer(const float *__restrict__ Hw, int lda, const float *__restrict__ W, int Cin, int Cout,
                                          float *__restrict__ Bs2, int &buf, f16v (&acc)[NBp], int tid, int lane,
-                                         float4 (&bw)[CwSlab<NBp>::BPT]) {
+                                         float4 (&bw)[CwSlab<NBp>::BPT] CW_CLK_ARG) {
     typedef CwSlab<NBp> SL;
     const int kh = lane >> 5, lr = lane & 31;
     for (int k0 = 0; k0 < Cin; k0 += CW_BK, buf ^= 1) {
         float *Bs = Bs2 + buf * (CW_BK * CwSlab<8>::LDB);
+        CW_T(t0);
         cw_store_b<NBp>(Bs, tid, bw);
+        CW_T(t1);
         __syncthreads();
+        CW_T(t2);
         const int kn = Cin - k0 < CW_BK ? Cin - k0 : CW_BK;
         CwFrags<NBp> fr;
         cw_slab_head<NBp>(Hw + lr * lda + k0 + kh, Bs + kh * SL::LDB + lr, kn, acc, fr);
+        CW_T(t3);
         if (k0 + CW_BK < Cin) cw_load_b<NBp>(W, Cin, Cout, k0 + CW_BK, tid, bw);
         cw_slab_tail<NBp>(Hw + lr * lda + k0 + kh, Bs + kh * SL::LDB + lr, kn, acc, fr);
+        CW_T(t4);
+        CW_ADD(0, t1 - t0); CW_ADD(1, t2 - t1); CW_ADD(2, t3 - t2); CW_ADD(3, t4 - t3); CW_ADD(4, 1);
     }
 }
 // bias + ReLU of an accumulator tile into the wave's activation tile, columns < Cout only
@@ -580,6 +609,10 @@ __global__ __launch_bounds__(256) void mlp_chain_wide_kernel(ChainWideArgs a) {
     static_assert(2 * GM_BM * CW_LDAS <= 4 * 32 * LDA, "chain_wide: the gather slabs alias the activation tiles");
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, kh = lane >> 5, lr = lane & 31;
     float *Hw = H + wv * 32 * LDA;
+    CW_T(tk0);
+#ifdef CW_CLOCK
+    CwClk clk = {{0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
+#endif
     const int row0 = blockIdx.x * GM_BM;
     // kernel arguments into locals: a lambda that captured the argument struct by reference kept it in scratch, and every
     // pointer loaded back from there had lost its address space (flat loads count against the LDS counter too)
@@ -630,14 +663,20 @@ __global__ __launch_bounds__(256) void mlp_chain_wide_kernel(ChainWideArgs a) {
 #define CW_GATHER_SLAB(K0, AV)                                                                                              \
         if ((K0) < Cin1) {                                                                                                   \
             float *As = As2 + buf * (GM_BM * CW_LDAS), *Bs = Bs2 + buf * (CW_BK * CwSlab<8>::LDB);                           \
+            CW_T(g0);                                                                                                        \
             _Pragma("unroll") for (int u = 0; u < 8; ++u) As[ar * CW_LDAS + ak + u] = AV[u];                                 \
             cw_store_b<NB1>(Bs, tid, bw);                                                                                    \
+            CW_T(g1);                                                                                                        \
             __syncthreads();                                                                                                 \
+            CW_T(g2);                                                                                                        \
             CwFrags<NB1> fr;                                                                                                 \
             cw_slab_head<NB1>(As + (wv * 32 + lr) * CW_LDAS + kh, Bs + kh * SL::LDB + lr, CW_BK, acc, fr);                   \
+            CW_T(g3);                                                                                                        \
             if ((K0) + 3 * CW_BK < Cin1) load_a((K0) + 3 * CW_BK, AV);                                                       \
             if ((K0) + CW_BK < Cin1) cw_load_b<NB1>(W1, Cin1, C1, (K0) + CW_BK, tid, bw);                                    \
             cw_slab_tail<NB1>(As + (wv * 32 + lr) * CW_LDAS + kh, Bs + kh * SL::LDB + lr, CW_BK, acc, fr);                   \
+            CW_T(g4);                                                                                                        \
+            CW_ADD(5, g1 - g0); CW_ADD(6, g2 - g1); CW_ADD(7, g3 - g2); CW_ADD(8, g4 - g3); CW_ADD(9, 1);                    \
             buf ^= 1;                                                                                                        \
         }
         for (int k0 = 0; k0 < Cin1; k0 += 3 * CW_BK) {
@@ -657,7 +696,7 @@ __global__ __launch_bounds__(256) void mlp_chain_wide_kernel(ChainWideArgs a) {
             for (int g = 0; g < 16; ++g) acc[n][g] = 0.f;
         if (!CW_XPHASE) cw_load_b<NB2>(W2, C1, C2, 0, tid, bw2);
         if (CW_XPHASE) cw_load_b<NB3>(W3, C2, C3, 0, tid, bw3);
-        cw_layer<NB2>(Hw, LDA, W2, C1, C2, Bs2, buf, acc, tid, lane, bw2);
+        cw_layer<NB2>(Hw, LDA, W2, C1, C2, Bs2, buf, acc, tid, lane, bw2 CW_CLK_PASS);
         cw_store<NB2>(Hw, LDA, b2, C2, acc, lane);   // the wave's own tile, after its own last read of it
     }
     float mx[NB3];
@@ -668,7 +707,7 @@ __global__ __launch_bounds__(256) void mlp_chain_wide_kernel(ChainWideArgs a) {
 #pragma unroll
             for (int g = 0; g < 16; ++g) acc[n][g] = 0.f;
         if (!CW_XPHASE) cw_load_b<NB3>(W3, C2, C3, 0, tid, bw3);
-        cw_layer<NB3>(Hw, LDA, W3, C2, C3, Bs2, buf, acc, tid, lane, bw3);
+        cw_layer<NB3>(Hw, LDA, W3, C2, C3, Bs2, buf, acc, tid, lane, bw3 CW_CLK_PASS);
 #pragma unroll
         for (int n = 0; n < NB3; ++n) {
             const float bv = b3[32 * n + lr];
@@ -694,6 +733,12 @@ __global__ __launch_bounds__(256) void mlp_chain_wide_kernel(ChainWideArgs a) {
         for (int w = 0; w < wpg; ++w) m = fmaxf(m, Pm[(g * wpg + w) * C3 + cc]);
         a.Y[(size_t)((row0 + g * PK) / PK) * a.ldy + a.ycol0 + cc] = m;
     }
+    CW_T(tk1);
+#ifdef CW_CLOCK
+    for (int i = 0; i < 5; ++i) CW_FLUSH(i, clk.v[i]);
+    for (int i = 5; i < 10; ++i) CW_FLUSH(i + 3, clk.v[i]);
+#endif
+    CW_FLUSH(5, tk1 - tk0); CW_FLUSH(6, 1);
 }
 
 template <int C1, int C2, int C3, int PK>

@@ -2,7 +2,9 @@
 """Does the ORDER in which a re-solve takes its free rows change its step count?  Runs the kinematic projection of
 bench.py --config kinematic and logs every solve's per-problem sequential steps; run once per library variant
 (REART_LIB=...libreart_hip_o1.so = descending order) on ONE box and compare: the assignments are the unique optima, so both
-runs see the same problems.   python tools/lap_order_exp.py out.npy"""
+runs see the same problems.   python tools/lap_order_exp.py out.npy
+(The variants were builds with a compile-time order switch; since then the order is the racer's index at run time,
+reart_lap_resolve_points_race -- REART_RESOLVE_RACERS=1 runs the plain ascending order.)"""
 import os, sys, json, subprocess
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, contextlib
