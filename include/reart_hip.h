@@ -386,12 +386,15 @@ int reart_mlp_chain3(const int64_t *gather_idx, int K, int S, int Npts, const fl
 /* The same fusion for a scale of the SECOND set-abstraction level: gathered input [F (D) | Q - C] (D + 3 columns, D % 4 == 0,
  * F 16-byte aligned) -> C1 -> C2 -> C3 -> max over the K rows of a group.  The weights stream through LDS in 16-row slabs,
  * a workgroup carries 128 rows through all three layers (rows % 128 == 0).  Bit-identical to three reart_mlp_layer calls.
+ * workspace (16-byte aligned, reart_mlp_chain3_wide_workspace_bytes(D, C1, C2, C3)): every call first writes an image of
+ * the three weight matrices there in the order the matrix cores' B fragments are read (one small launch).
  * Built for (C1, C2, C3, K) = (128, 128, 256, 64), (128, 196, 256, 128) (networks/feature_extractor.py:22-23); anything
  * else returns REART_ERR_UNSUPPORTED. */
+size_t reart_mlp_chain3_wide_workspace_bytes(int D, int C1, int C2, int C3);
 int reart_mlp_chain3_wide(const int64_t *gather_idx, int K, int S, int Npts, const float *F, int D, const float *Q,
                           const float *C, const float *W1t, const float *b1, int C1, const float *W2t, const float *b2,
                           int C2, const float *W3t, const float *b3, int C3, int rows, float *Y, int ldy, int ycol0,
-                          void *stream);
+                          void *workspace, size_t workspace_bytes, void *stream);
 
 /* 3-NN inverse-distance interpolation of PointNetFeaturePropagation
  * (networks/pointnet2_utils.py:326-336): xyz1 [B,N,3], xyz2 [B,S2,3], points2 [B,S2,D] ->

@@ -49,8 +49,9 @@ PROTOTYPES = {
     "reart_mlp_layer": (c_int, [P, c_int, P, c_int, c_int, c_int, P, c_int, P, P, c_int, P, P, c_int, c_int, c_int,
                                 c_int, c_int, P, c_int, c_int, P]),
     "reart_mlp_chain3": (c_int, [P, c_int, c_int, c_int, P, P, P, P, P, c_int, P, P, c_int, P, P, c_int, c_int, P, c_int, c_int, P]),
+    "reart_mlp_chain3_wide_workspace_bytes": (c_size_t, [c_int] * 4),
     "reart_mlp_chain3_wide": (c_int, [P, c_int, c_int, c_int, P, c_int, P, P, P, P, c_int, P, P, c_int, P, P, c_int, c_int, P, c_int,
-                                      c_int, P]),
+                                      c_int, P, c_size_t, P]),
     "reart_three_nn": (c_int, [P, P, c_int, c_int, c_int, P, P, P]),
     "reart_three_interpolate_workspace_bytes": (c_size_t, [c_int] * 3),
     "reart_three_interpolate": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, c_int, c_int, P, c_size_t, P]),

@@ -471,21 +471,43 @@ extern "C" int reart_debug_cw_clock(unsigned long long *out, int reset) {
 #define CW_SCHED_FENCE() ((void)0)
 #endif
 #define CW_LDAS (CW_BK + 1)
+// Weight slabs in LDS: the B fragment of lane (k-half kh, column lr) for step kk is the NB values W[kk + kh][32 n + lr],
+// n = 0 .. NB-1.  They are stored next to each other ([k][lr][n], S = 4 or 8 floats per (k, lr)) so that ONE or TWO 16-byte
+// LDS reads fetch them -- with the row-major slab ([k][column]) it took NB / 2 ds_read2_b32, and the instructions a wave
+// issues between its MFMAs are what idles the matrix cores (tools/ubench_mfma.hip: 64 cycles per MFMA from registers, 92 -
+// 102 with a fragment read per accumulator).  The weights come in that order from an image of the matrix (cw_image_kernel,
+// once per call), so the slab's global -> LDS copy is a straight 16-byte copy.  LDS stride per (k, lr): 12 floats for S = 8
+// (the 16-lane groups of ds_read_b128 then cover the 64 banks exactly), 4 for S = 4.
 template <int NBp> struct CwSlab {
-    static constexpr int BN = 32 * NBp, LDB = BN + 4, NBF = CW_BK * BN / 4, BPT = (NBF + 255) / 256;
+    static constexpr int S = NBp <= 4 ? 4 : 8, SL = S == 8 ? 12 : 4;
+    static constexpr int KSTR = 32 * SL;                       // floats per k row in LDS
+    static constexpr int NBF = CW_BK * 32 * S / 4, BPT = (NBF + 255) / 256;
 };
-// rows [k0, k0 + 16) of a transposed weight matrix [Cin, Cout] (Cout % 4 == 0).  No zero padding and no branches: beyond
-// either edge the address is clamped to the last row / the last four columns.  A row beyond Cin only ever meets an A value
-// of exactly zero (the gather slabs and cw_slab_mfma see to that) and a column beyond Cout is never stored, so what is
-// loaded there does not reach a result (a finite weight times zero adds a zero of either sign to the accumulator).
+#define CW_SLAB_FLOATS (CW_BK * 32 * 12)
+// image of a transposed weight matrix W [Cin, Cout]: img[k][lr][n] = W[k][32 n + lr] (zero beyond Cout), n < S
+__global__ __launch_bounds__(256) void cw_image_kernel(const float *__restrict__ W1, int Cin1, int Cout1, int S1, float *__restrict__ img1,
+                                                       const float *__restrict__ W2, int Cin2, int Cout2, int S2, float *__restrict__ img2,
+                                                       const float *__restrict__ W3, int Cin3, int Cout3, int S3, float *__restrict__ img3) {
+    const float *W = blockIdx.y == 0 ? W1 : (blockIdx.y == 1 ? W2 : W3);
+    float *img = blockIdx.y == 0 ? img1 : (blockIdx.y == 1 ? img2 : img3);
+    const int Cin = blockIdx.y == 0 ? Cin1 : (blockIdx.y == 1 ? Cin2 : Cin3), Cout = blockIdx.y == 0 ? Cout1 : (blockIdx.y == 1 ? Cout2 : Cout3);
+    const int S = blockIdx.y == 0 ? S1 : (blockIdx.y == 1 ? S2 : S3);
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < Cin * 32 * S; e += gridDim.x * 256) {
+        const int k = e / (32 * S), lr = (e / S) & 31, n = e % S, col = 32 * n + lr;
+        img[e] = col < Cout ? W[(size_t)k * Cout + col] : 0.f;
+    }
+}
+// rows [k0, k0 + 16) of a weight image.  No branches: beyond Cin the address is clamped to the last row -- such a row only
+// ever meets an A value of exactly zero (the gather slabs and cw_slab_* see to that), so what is loaded there does not reach
+// a result (a finite weight times zero adds a zero of either sign to the accumulator).
 template <int NBp>
-__device__ __forceinline__ void cw_load_b(const float *__restrict__ W, int Cin, int Cout, int k0, int tid, float4 (&bw)[CwSlab<NBp>::BPT]) {
+__device__ __forceinline__ void cw_load_b(const float *__restrict__ img, int Cin, int k0, int tid, float4 (&bw)[CwSlab<NBp>::BPT]) {
     typedef CwSlab<NBp> SL;
 #pragma unroll
     for (int h = 0; h < SL::BPT; ++h) {
         const int f = tid + 256 * h < SL::NBF ? tid + 256 * h : SL::NBF - 1;
-        const int k = min(k0 + f / (SL::BN / 4), Cin - 1), cc = min((f % (SL::BN / 4)) * 4, Cout - 4);
-        const float4 w = *(const float4 *)(W + (size_t)k * Cout + cc);      // (assigning the load straight to bw[h] kept the array in scratch)
+        const int k = min(k0 + f / (8 * SL::S), Cin - 1), off = f % (8 * SL::S);
+        const float4 w = *(const float4 *)(img + ((size_t)k * 32 * SL::S + 4 * off));      // (assigning the load straight to bw[h] kept the array in scratch)
         bw[h] = w;
     }
 }
@@ -494,26 +516,25 @@ __device__ __forceinline__ void cw_store_b(float *__restrict__ Bs, int tid, cons
     typedef CwSlab<NBp> SL;
 #pragma unroll
     for (int h = 0; h < SL::BPT; ++h) {
-        const int f = tid + 256 * h;
-        if (f < SL::NBF) *(float4 *)(Bs + (f / (SL::BN / 4)) * SL::LDB + (f % (SL::BN / 4)) * 4) = bw[h];
+        const int f = tid + 256 * h, k = f / (8 * SL::S), rem = f % (8 * SL::S), lr = rem / (SL::S / 4), q = rem % (SL::S / 4);
+        if (f < SL::NBF) *(float4 *)(Bs + (k * 32 + lr) * SL::SL + 4 * q) = bw[h];
     }
 }
-// The MFMAs of one slab: A value of step kk at ap[kk * astride], B values at bp[kk * LDB + 32 n].  One wave per SIMD is
-// resident (the tiles fill the LDS), so nothing but the wave's own instruction stream hides the LDS latency: the
-// fragments of step kk + 2 are fetched into a second register set before the matrix cores get step kk.
+// The MFMAs of one slab: A value of step kk at ap[kk], B values at bp[kk * KSTR + n].  One wave per SIMD is resident (the
+// tiles fill the LDS), so nothing but the wave's own instruction stream hides the LDS latency: the fragments of step kk + 2
+// are fetched into a second register set while the matrix cores have step kk.
 template <int NBp>
 __device__ __forceinline__ void cw_frag(const float *__restrict__ ap, const float *__restrict__ bp, float &av, float (&bv)[NBp]) {
     av = *ap;
 #pragma unroll
-    for (int n = 0; n < NBp; ++n) bv[n] = bp[32 * n];
+    for (int q = 0; q < CwSlab<NBp>::S / 4; ++q) {
+        const float4 v = *(const float4 *)(bp + 4 * q);
+        if (4 * q < NBp) bv[4 * q] = v.x;
+        if (4 * q + 1 < NBp) bv[4 * q + 1] = v.y;
+        if (4 * q + 2 < NBp) bv[4 * q + 2] = v.z;
+        if (4 * q + 3 < NBp) bv[4 * q + 3] = v.w;
+    }
 }
-// In two parts, so that the caller can issue its global loads for the next slab once the matrix cores have their first
-// group: the loads' address arithmetic then runs in the shadow of the MFMAs instead of between the barrier and the first of
-// them.  (Passing the loads in as a lambda sent the registers they fill through scratch.)
-// kn < 16 (the last slab of a layer whose Cin is no multiple of 16): the A values beyond Cin are replaced by zero (the tile
-// has no such columns) -- mlp_gemm_kernel's K padding, the same bits.
-// sched_barrier: the compiler's scheduler otherwise sinks every LDS read next to its MFMA (fewer live registers) and the
-// wave then waits out the LDS latency once per pair of MFMAs.
 template <int NBp> struct CwFrags { float a0, a1, b0[NBp], b1[NBp]; };
 // one k-step of a slab: the first MFMA of the group goes out, THEN the LDS reads of the next step are issued (the compiler
 // waits with lgkmcnt(0) before a group, i.e. also for reads issued just ahead of it: issued behind the group's first MFMA
@@ -532,7 +553,7 @@ __device__ __forceinline__ void cw_kstep(float a, const float (&b)[NBp], f16v (&
 }
 template <int NBp>
 __device__ __forceinline__ void cw_slab_head(const float *__restrict__ ap, const float *__restrict__ bp, int kn, f16v (&acc)[NBp], CwFrags<NBp> &r) {
-    constexpr int LDB = CwSlab<NBp>::LDB;
+    constexpr int LDB = CwSlab<NBp>::KSTR;
     const int kh = (threadIdx.x >> 5) & 1;
     cw_frag<NBp>(ap, bp, r.a0, r.b0);
     r.a0 = kh < kn ? r.a0 : 0.f;
@@ -540,7 +561,7 @@ __device__ __forceinline__ void cw_slab_head(const float *__restrict__ ap, const
 }
 template <int NBp>
 __device__ __forceinline__ void cw_slab_tail(const float *__restrict__ ap, const float *__restrict__ bp, int kn, f16v (&acc)[NBp], CwFrags<NBp> &r) {
-    constexpr int LDB = CwSlab<NBp>::LDB;
+    constexpr int LDB = CwSlab<NBp>::KSTR;
     const int kh = (threadIdx.x >> 5) & 1;
 #pragma unroll
     for (int kk = 2; kk < CW_BK; kk += 4) {
@@ -561,7 +582,7 @@ __device__ __forceinline__ void cw_layer(const float *__restrict__ Hw, int lda, 
     typedef CwSlab<NBp> SL;
     const int kh = lane >> 5, lr = lane & 31;
     for (int k0 = 0; k0 < Cin; k0 += CW_BK, buf ^= 1) {
-        float *Bs = Bs2 + buf * (CW_BK * CwSlab<8>::LDB);
+        float *Bs = Bs2 + buf * CW_SLAB_FLOATS;
         CW_T(t0);
         cw_store_b<NBp>(Bs, tid, bw);
         CW_T(t1);
@@ -569,10 +590,10 @@ __device__ __forceinline__ void cw_layer(const float *__restrict__ Hw, int lda, 
         CW_T(t2);
         const int kn = Cin - k0 < CW_BK ? Cin - k0 : CW_BK;
         CwFrags<NBp> fr;
-        cw_slab_head<NBp>(Hw + lr * lda + k0 + kh, Bs + kh * SL::LDB + lr, kn, acc, fr);
+        cw_slab_head<NBp>(Hw + lr * lda + k0 + kh, Bs + (kh * 32 + lr) * SL::SL, kn, acc, fr);
         CW_T(t3);
-        if (k0 + CW_BK < Cin) cw_load_b<NBp>(W, Cin, Cout, k0 + CW_BK, tid, bw);
-        cw_slab_tail<NBp>(Hw + lr * lda + k0 + kh, Bs + kh * SL::LDB + lr, kn, acc, fr);
+        if (k0 + CW_BK < Cin) cw_load_b<NBp>(W, Cin, k0 + CW_BK, tid, bw);
+        cw_slab_tail<NBp>(Hw + lr * lda + k0 + kh, Bs + (kh * 32 + lr) * SL::SL, kn, acc, fr);
         CW_T(t4);
         CW_ADD(0, t1 - t0); CW_ADD(1, t2 - t1); CW_ADD(2, t3 - t2); CW_ADD(3, t4 - t3); CW_ADD(4, 1);
     }
@@ -602,8 +623,8 @@ __global__ __launch_bounds__(256) void mlp_chain_wide_kernel(ChainWideArgs a) {
     static_assert(C1 % 32 == 0 && C3 % 32 == 0 && C2 % 4 == 0 && NB1 <= 8 && NB2 <= 8 && NB3 <= 8, "chain_wide: widths");
     constexpr int LDA = chain_lda(C1 > C2 ? C1 : C2);
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float *Bs2 = sm;                                   // [2][16][260]: weight slabs
-    float *H = Bs2 + 2 * CW_BK * CwSlab<8>::LDB;       // [4][32][LDA]: the waves' activation tiles
+    float *Bs2 = sm;                                   // [2][16][32][12]: weight slabs
+    float *H = Bs2 + 2 * CW_SLAB_FLOATS;               // [4][32][LDA]: the waves' activation tiles
     float *As2 = H;                                    // [2][128][17]: the gathered A slabs of layer 1 live in the (not yet used) tiles
     float *Pm = H + 4 * 32 * LDA;                      // [4][C3]
     static_assert(2 * GM_BM * CW_LDAS <= 4 * 32 * LDA, "chain_wide: the gather slabs alias the activation tiles");
@@ -623,7 +644,7 @@ __global__ __launch_bounds__(256) void mlp_chain_wide_kernel(ChainWideArgs a) {
 #ifndef CW_XPHASE
 #define CW_XPHASE 1
 #endif
-    if (CW_XPHASE) cw_load_b<NB2>(W2, C1, C2, 0, tid, bw2);           // layer 2's first slab waits in registers through layer 1
+    if (CW_XPHASE) cw_load_b<NB2>(W2, C1, 0, tid, bw2);           // layer 2's first slab waits in registers through layer 1
     {   // ---- layer 1: A from the gather (mlp_gemm_kernel's staging: thread <- 8 consecutive k of one row)
         const int ar = tid >> 1, ak = (tid & 1) * 8, r = row0 + ar;
         const size_t prow = (size_t)(r / (a.S * a.K)) * a.Npts + (size_t)a.idx[r];
@@ -659,10 +680,10 @@ __global__ __launch_bounds__(256) void mlp_chain_wide_kernel(ChainWideArgs a) {
         load_a(0, av0);
         load_a(CW_BK, av1);                            // (beyond Cin1 a set is simply never stored)
         load_a(2 * CW_BK, av2);
-        cw_load_b<NB1>(W1, Cin1, C1, 0, tid, bw);
+        cw_load_b<NB1>(W1, Cin1, 0, tid, bw);
 #define CW_GATHER_SLAB(K0, AV)                                                                                              \
         if ((K0) < Cin1) {                                                                                                   \
-            float *As = As2 + buf * (GM_BM * CW_LDAS), *Bs = Bs2 + buf * (CW_BK * CwSlab<8>::LDB);                           \
+            float *As = As2 + buf * (GM_BM * CW_LDAS), *Bs = Bs2 + buf * CW_SLAB_FLOATS;                                     \
             CW_T(g0);                                                                                                        \
             _Pragma("unroll") for (int u = 0; u < 8; ++u) As[ar * CW_LDAS + ak + u] = AV[u];                                 \
             cw_store_b<NB1>(Bs, tid, bw);                                                                                    \
@@ -670,11 +691,11 @@ __global__ __launch_bounds__(256) void mlp_chain_wide_kernel(ChainWideArgs a) {
             __syncthreads();                                                                                                 \
             CW_T(g2);                                                                                                        \
             CwFrags<NB1> fr;                                                                                                 \
-            cw_slab_head<NB1>(As + (wv * 32 + lr) * CW_LDAS + kh, Bs + kh * SL::LDB + lr, CW_BK, acc, fr);                   \
+            cw_slab_head<NB1>(As + (wv * 32 + lr) * CW_LDAS + kh, Bs + (kh * 32 + lr) * SL::SL, CW_BK, acc, fr);             \
             CW_T(g3);                                                                                                        \
             if ((K0) + 3 * CW_BK < Cin1) load_a((K0) + 3 * CW_BK, AV);                                                       \
-            if ((K0) + CW_BK < Cin1) cw_load_b<NB1>(W1, Cin1, C1, (K0) + CW_BK, tid, bw);                                    \
-            cw_slab_tail<NB1>(As + (wv * 32 + lr) * CW_LDAS + kh, Bs + kh * SL::LDB + lr, CW_BK, acc, fr);                   \
+            if ((K0) + CW_BK < Cin1) cw_load_b<NB1>(W1, Cin1, (K0) + CW_BK, tid, bw);                                        \
+            cw_slab_tail<NB1>(As + (wv * 32 + lr) * CW_LDAS + kh, Bs + (kh * 32 + lr) * SL::SL, CW_BK, acc, fr);             \
             CW_T(g4);                                                                                                        \
             CW_ADD(5, g1 - g0); CW_ADD(6, g2 - g1); CW_ADD(7, g3 - g2); CW_ADD(8, g4 - g3); CW_ADD(9, 1);                    \
             buf ^= 1;                                                                                                        \
@@ -694,8 +715,8 @@ __global__ __launch_bounds__(256) void mlp_chain_wide_kernel(ChainWideArgs a) {
         for (int n = 0; n < NB2; ++n)
 #pragma unroll
             for (int g = 0; g < 16; ++g) acc[n][g] = 0.f;
-        if (!CW_XPHASE) cw_load_b<NB2>(W2, C1, C2, 0, tid, bw2);
-        if (CW_XPHASE) cw_load_b<NB3>(W3, C2, C3, 0, tid, bw3);
+        if (!CW_XPHASE) cw_load_b<NB2>(W2, C1, 0, tid, bw2);
+        if (CW_XPHASE) cw_load_b<NB3>(W3, C2, 0, tid, bw3);
         cw_layer<NB2>(Hw, LDA, W2, C1, C2, Bs2, buf, acc, tid, lane, bw2 CW_CLK_PASS);
         cw_store<NB2>(Hw, LDA, b2, C2, acc, lane);   // the wave's own tile, after its own last read of it
     }
@@ -706,7 +727,7 @@ __global__ __launch_bounds__(256) void mlp_chain_wide_kernel(ChainWideArgs a) {
         for (int n = 0; n < NB3; ++n)
 #pragma unroll
             for (int g = 0; g < 16; ++g) acc[n][g] = 0.f;
-        if (!CW_XPHASE) cw_load_b<NB3>(W3, C2, C3, 0, tid, bw3);
+        if (!CW_XPHASE) cw_load_b<NB3>(W3, C2, 0, tid, bw3);
         cw_layer<NB3>(Hw, LDA, W3, C2, C3, Bs2, buf, acc, tid, lane, bw3 CW_CLK_PASS);
 #pragma unroll
         for (int n = 0; n < NB3; ++n) {
@@ -741,13 +762,26 @@ __global__ __launch_bounds__(256) void mlp_chain_wide_kernel(ChainWideArgs a) {
     CW_FLUSH(5, tk1 - tk0); CW_FLUSH(6, 1);
 }
 
+static size_t cw_image_floats(int Cin, int Cout) { return (size_t)Cin * 32 * (Cout <= 128 ? 4 : 8); }
+extern "C" size_t reart_mlp_chain3_wide_workspace_bytes(int D, int C1, int C2, int C3) {
+    if (D < 1 || C1 < 1 || C2 < 1 || C3 < 1 || C1 > 256 || C2 > 256 || C3 > 256) return 0;
+    return sizeof(float) * (reart_align_up(cw_image_floats(D + 3, C1), 64) + reart_align_up(cw_image_floats(C1, C2), 64) +
+                            reart_align_up(cw_image_floats(C2, C3), 64));
+}
+
 template <int C1, int C2, int C3, int PK>
-static int chain_wide_launch(const ChainWideArgs &a, hipStream_t st) {
-    constexpr size_t lds = sizeof(float) * (2 * CW_BK * CwSlab<8>::LDB + 4 * 32 * chain_lda(C1 > C2 ? C1 : C2) + 4 * C3);
+static int chain_wide_launch(ChainWideArgs a, float *ws, hipStream_t st) {
+    constexpr size_t lds = sizeof(float) * (2 * CW_SLAB_FLOATS + 4 * 32 * chain_lda(C1 > C2 ? C1 : C2) + 4 * C3);
     static_assert(lds <= 152 * 1024, "chain_wide: weight slabs + activation tiles must fit the LDS of one compute unit");
     if (lds > REART_LDS_DEFAULT_CAP &&
         hipFuncSetAttribute((const void *)mlp_chain_wide_kernel<C1, C2, C3, PK>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)
         return REART_ERR_LAUNCH;
+    // the three weight images (B fragments contiguous per lane), then the layers on them
+    constexpr int S1 = CwSlab<C1 / 32>::S, S2 = CwSlab<(C2 + 31) / 32>::S, S3 = CwSlab<C3 / 32>::S;
+    float *img1 = ws, *img2 = img1 + reart_align_up(cw_image_floats(a.D + 3, C1), 64), *img3 = img2 + reart_align_up(cw_image_floats(C1, C2), 64);
+    hipLaunchKernelGGL(cw_image_kernel, dim3(64, 3), dim3(256), 0, st, a.W1, a.D + 3, C1, S1, img1, a.W2, C1, C2, S2, img2, a.W3, C2, C3, S3, img3);
+    REART_CHECK_LAUNCH();
+    a.W1 = img1; a.W2 = img2; a.W3 = img3;
     hipLaunchKernelGGL((mlp_chain_wide_kernel<C1, C2, C3, PK>), dim3(a.rows / GM_BM), dim3(256), lds, st, a);
     REART_CHECK_LAUNCH();
     return REART_OK;
@@ -756,18 +790,20 @@ static int chain_wide_launch(const ChainWideArgs &a, hipStream_t st) {
 extern "C" int reart_mlp_chain3_wide(const int64_t *gather_idx, int K, int S, int Npts, const float *F, int D, const float *Q,
                                      const float *C, const float *W1t, const float *b1, int C1, const float *W2t, const float *b2,
                                      int C2, const float *W3t, const float *b3, int C3, int rows, float *Y, int ldy, int ycol0,
-                                     void *stream) {
+                                     void *workspace, size_t workspace_bytes, void *stream) {
     if (rows < 0 || K < 1 || S < 1 || Npts < 1 || D < 4) return REART_ERR_INVALID_ARG;
     if (rows == 0) return REART_OK;
     if (!gather_idx || !F || !Q || !C || !W1t || !b1 || !W2t || !b2 || !W3t || !b3 || !Y) return REART_ERR_INVALID_ARG;
     if (ycol0 < 0 || ldy < ycol0 + C3 || rows % K != 0) return REART_ERR_INVALID_ARG;
     if (rows % GM_BM != 0 || D % 4 != 0 || (((size_t)F) & 15) != 0) return REART_ERR_UNSUPPORTED;
+    const bool known = (C1 == 128 && C2 == 128 && C3 == 256 && K == 64) || (C1 == 128 && C2 == 196 && C3 == 256 && K == 128);
+    if (!known) return REART_ERR_UNSUPPORTED;
+    if (!workspace || (((size_t)workspace) & 15) != 0 || workspace_bytes < reart_mlp_chain3_wide_workspace_bytes(D, C1, C2, C3)) return REART_ERR_INVALID_ARG;
     ChainWideArgs a = {gather_idx, K, S, Npts, F, D, Q, C, W1t, b1, W2t, b2, W3t, b3, rows, Y, ldy, ycol0};
     hipStream_t st = (hipStream_t)stream;
     // the two scales of the extractor's sa2 (networks/feature_extractor.py:22-23)
-    if (C1 == 128 && C2 == 128 && C3 == 256 && K == 64) return chain_wide_launch<128, 128, 256, 64>(a, st);
-    if (C1 == 128 && C2 == 196 && C3 == 256 && K == 128) return chain_wide_launch<128, 196, 256, 128>(a, st);
-    return REART_ERR_UNSUPPORTED;
+    if (K == 64) return chain_wide_launch<128, 128, 256, 64>(a, (float *)workspace, st);
+    return chain_wide_launch<128, 196, 256, 128>(a, (float *)workspace, st);
 }
 
 // ---------------------------------------------------------------------------------------

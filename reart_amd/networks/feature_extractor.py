@@ -101,10 +101,11 @@ def mlp_chain3_wide(folded, gather, out, out_col):
     (W1, b1), (W2, b2), (W3, b3) = folded
     B, S, K = gather["idx"].shape
     F = gather["F"]
+    ws = _lib.workspace(L.reart_mlp_chain3_wide_workspace_bytes(F.shape[1], W1.shape[1], W2.shape[1], W3.shape[1]), F.device)
     rc = L.reart_mlp_chain3_wide(_lib.ptr(gather["idx"]), K, S, gather["Npts"], _lib.ptr(F), F.shape[1], _lib.ptr(gather["Q"]),
                                  _lib.ptr(gather["C"]), _lib.ptr(W1), _lib.ptr(b1), W1.shape[1], _lib.ptr(W2), _lib.ptr(b2),
                                  W2.shape[1], _lib.ptr(W3), _lib.ptr(b3), W3.shape[1], B * S * K, _lib.ptr(out), out.shape[1], out_col,
-                                 _lib.stream())
+                                 _lib.ptr(ws), ws.numel(), _lib.stream())
     _lib.check(rc, "reart_mlp_chain3_wide")
     return out
 
