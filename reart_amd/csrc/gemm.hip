@@ -270,15 +270,34 @@ struct Chain3Args {
 __host__ __device__ constexpr int chain_ldb(int c) { return c + 4; }   // like mlp_gemm_kernel's B tile
 __host__ __device__ constexpr int chain_lda(int c) { return c + 2; }   // (measured in mlp_chain_wide_kernel: an odd stride, conflict-free for ds_read_b32's 32 banks, is 1 % slower)
 
-template <int NB, int LDB>
-__device__ __forceinline__ void chain_layer(const float *__restrict__ Hw, int lda, const float *__restrict__ Ws, int Cin, f16v (&acc)[NB],
-                                            int lane) {
+// Weights in LDS as B-fragment images: [k][lr][S] with S = 1, 2 or 4 floats (the NB values W[k][32 n + lr] of one lane next
+// to each other), so one LDS read of 4, 8 or 16 bytes fetches a step's B operands (see mlp_chain_wide_kernel: the
+// instructions issued between MFMAs are what idles the matrix cores with one wave per SIMD).
+__host__ __device__ constexpr int chain_s(int nb) { return nb <= 1 ? 1 : (nb == 2 ? 2 : 4); }
+template <int NB>
+__device__ __forceinline__ void chain_bfrag(const float *__restrict__ bp, float (&b)[NB]) {
+    if (NB == 1) b[0] = bp[0];
+    else if (NB == 2) { const float2 v = *(const float2 *)bp; b[0] = v.x; b[1] = v.y; }
+    else {
+        const float4 v = *(const float4 *)bp;
+        b[0] = v.x; b[1] = v.y; b[2] = v.z;
+        if (NB > 3) b[3] = v.w;
+    }
+}
+// (The loop is left to the compiler's scheduler: with two to four accumulators a group of MFMAs is too short for the
+// hand-fenced two-stage pipeline of mlp_chain_wide_kernel, which was measured slower here, 939 vs 874 us.)
+template <int NB, int CIN>
+__device__ __forceinline__ void chain_layer(const float *__restrict__ Hw, int lda, const float *__restrict__ Wimg, f16v (&acc)[NB], int lane) {
+    constexpr int S = chain_s(NB), KSTR = 32 * S;
     const int kh = lane >> 5, lr = lane & 31;
+    const float *ap = Hw + lr * lda + kh, *bp = Wimg + (kh * 32 + lr) * S;
 #pragma unroll 4
-    for (int kk = 0; kk < Cin; kk += 2) {
-        const float av = Hw[lr * lda + kk + kh];
+    for (int kk = 0; kk < CIN; kk += 2) {
+        const float av = ap[kk];
+        float b[NB];
+        chain_bfrag<NB>(bp + kk * KSTR, b);
 #pragma unroll
-        for (int n = 0; n < NB; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Ws[(kk + kh) * LDB + 32 * n + lr], acc[n], 0, 0, 0);
+        for (int n = 0; n < NB; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[n], acc[n], 0, 0, 0);
     }
 }
 // bias + ReLU of an accumulator tile, written into the wave's activation tile in A-fragment order
@@ -300,19 +319,25 @@ __device__ __forceinline__ void chain_store(float *__restrict__ Hw, int lda, con
 template <int C1, int C2, int C3, int PK>
 __global__ __launch_bounds__(256) void mlp_chain3_kernel(Chain3Args a) {
     constexpr int NB1 = C1 / 32, NB2 = C2 / 32, NB3 = C3 / 32;
-    constexpr int LDW1 = chain_ldb(C1), LDW2 = chain_ldb(C2), LDW3 = chain_ldb(C3);
+    constexpr int LDW1 = chain_ldb(C1), S2 = chain_s(NB2), S3 = chain_s(NB3);
     constexpr int LDA = chain_lda(C1 > C2 ? C1 : C2);
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float *W1s = sm;                       // [6][LDW1]
-    float *W2s = W1s + 6 * LDW1;           // [C1][LDW2]
-    float *W3s = W2s + C1 * LDW2;          // [C2][LDW3]
-    float *Bs = W3s + C2 * LDW3;           // b1 | b2 | b3
+    float *W2s = sm;                       // [C1][32][S2]: B-fragment image of W2
+    float *W3s = W2s + C1 * 32 * S2;       // [C2][32][S3]
+    float *W1s = W3s + C2 * 32 * S3;       // [6][LDW1]
+    float *Bs = W1s + 6 * LDW1;            // b1 | b2 | b3
     float *H = Bs + (C1 + C2 + C3);        // [4][32][LDA]
     float *Pm = H + 4 * 32 * LDA;          // [4][C3]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, kh = lane >> 5, lr = lane & 31;
     for (int e = tid; e < 6 * C1; e += 256) W1s[(e / C1) * LDW1 + e % C1] = a.W1[e];
-    for (int e = tid; e < C1 * C2; e += 256) W2s[(e / C2) * LDW2 + e % C2] = a.W2[e];
-    for (int e = tid; e < C2 * C3; e += 256) W3s[(e / C3) * LDW3 + e % C3] = a.W3[e];
+    for (int e = tid; e < C1 * 32 * S2; e += 256) {                      // image element (k, lr, n) <- W2[k][32 n + lr]
+        const int k = e / (32 * S2), lr2 = (e / S2) & 31, n = e % S2;
+        W2s[e] = n < NB2 ? a.W2[k * C2 + 32 * n + lr2] : 0.f;
+    }
+    for (int e = tid; e < C2 * 32 * S3; e += 256) {
+        const int k = e / (32 * S3), lr2 = (e / S3) & 31, n = e % S3;
+        W3s[e] = n < NB3 ? a.W3[k * C3 + 32 * n + lr2] : 0.f;
+    }
     for (int e = tid; e < C1; e += 256) Bs[e] = a.b1[e];
     for (int e = tid; e < C2; e += 256) Bs[C1 + e] = a.b2[e];
     for (int e = tid; e < C3; e += 256) Bs[C1 + C2 + e] = a.b3[e];
@@ -351,7 +376,7 @@ __global__ __launch_bounds__(256) void mlp_chain3_kernel(Chain3Args a) {
                 for (int n = 0; n < NB2; ++n)
 #pragma unroll
                     for (int g = 0; g < 16; ++g) acc[n][g] = 0.f;
-                chain_layer<NB2, LDW2>(Hw, LDA, W2s, C1, acc, lane);
+                chain_layer<NB2, C1>(Hw, LDA, W2s, acc, lane);
                 chain_store<NB2>(Hw, LDA, Bs + C1, acc, lane);
             }
             {   // ---- layer 3 + bias + ReLU + max over the wave's 32 rows
@@ -360,7 +385,7 @@ __global__ __launch_bounds__(256) void mlp_chain3_kernel(Chain3Args a) {
                 for (int n = 0; n < NB3; ++n)
 #pragma unroll
                     for (int g = 0; g < 16; ++g) acc[n][g] = 0.f;
-                chain_layer<NB3, LDW3>(Hw, LDA, W3s, C2, acc, lane);
+                chain_layer<NB3, C2>(Hw, LDA, W3s, acc, lane);
 #pragma unroll
                 for (int n = 0; n < NB3; ++n) {
                     const float bv = Bs[C1 + C2 + 32 * n + lr];
@@ -392,7 +417,7 @@ __global__ __launch_bounds__(256) void mlp_chain3_kernel(Chain3Args a) {
 
 template <int C1, int C2, int C3, int PK>
 static int chain3_launch(const Chain3Args &a, hipStream_t st) {
-    constexpr size_t lds = sizeof(float) * (6 * chain_ldb(C1) + C1 * chain_ldb(C2) + C2 * chain_ldb(C3) + (C1 + C2 + C3) +
+    constexpr size_t lds = sizeof(float) * (6 * chain_ldb(C1) + C1 * 32 * chain_s(C2 / 32) + C2 * 32 * chain_s(C3 / 32) + (C1 + C2 + C3) +
                                             4 * 32 * chain_lda(C1 > C2 ? C1 : C2) + 4 * C3);
     static_assert(lds <= 152 * 1024, "chain3: weights + activation tiles must fit the LDS of one compute unit");
     if (lds > REART_LDS_DEFAULT_CAP &&
