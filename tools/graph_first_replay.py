@@ -17,6 +17,14 @@ if len(sys.argv) > 1 and sys.argv[1] == "upload":
     rc = hip.hipGraphUpload(ctypes.c_void_p(eng._graph.raw_cuda_graph_exec()), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
     print("hipGraphUpload rc", rc)
+if len(sys.argv) > 1 and sys.argv[1] == "spin":
+    # keep the GPU busy for ~100 ms right before the first replay: does the clock state matter?
+    x = torch.randn(4096, 4096, device=dev)
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.1:
+        y = x @ x
+    torch.cuda.synchronize()
+    del x, y
 for i in range(6):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
