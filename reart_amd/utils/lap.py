@@ -186,8 +186,12 @@ def linear_sum_assignment_points(src, tgt, state, return_stats=False, race=True)
                                            points=(src, tgt), race=True)
     L = _lib.lib()
     col, prices = state["cols"].clone(), state["prices"]
-    cert = torch.empty((B,), dtype=torch.int32, device=src.device)
+    cert = torch.zeros((B,), dtype=torch.int32, device=src.device)    # defined whatever the kernels write: 0 = solve on the host
     racers = _resolve_racers(B, n, race)
+    if return_stats == "full":      # the statistics region of the workspace (shared with other calls): zeros unless written
+        nb = L.reart_lap_race_workspace_bytes(B, n, racers) if racers > 1 else L.reart_lap_workspace_bytes(B, n)
+        off = ((8 * B * n + 255) // 256) * 256
+        _lib.workspace(nb, src.device)[off:off + 16 * B].zero_()
     if racers > 1:
         ws = _lib.workspace(L.reart_lap_race_workspace_bytes(B, n, racers), src.device)
         rc = L.reart_lap_resolve_points_race(_lib.ptr(src), _lib.ptr(tgt), B, n, racers, _lib.ptr(col), _lib.ptr(cert),
