@@ -20,7 +20,9 @@
 #include "internal.h"
 #include <math.h>
 
+#ifndef LAP_BS
 #define LAP_BS 1024
+#endif
 #define LAP_NMAX 4096
 // lap_auction_kernel: from phase LAP_SEARCH_PHASE on, the last LAP_SEARCH_NU free rows of a phase get one augmenting-path
 // search each instead of a bidding chain.  Measured on the tail's 19 x 4096^2 problems (tools/lap_cold.py): the early
