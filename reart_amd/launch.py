@@ -46,27 +46,60 @@ def check_world(requested, env=None):
 
 
 def self_launch(script, argv, nproc, expect_json_key="n_gpus", timeout=None, module=False):
-    """Start ``nproc`` ranks of ``script argv`` and wait.  stdout of the ranks is captured; the LAST line that parses as a
-    JSON object is printed (rank 0 prints exactly one), everything else goes to stderr.  Exit status: the launcher's, or 3
-    when no JSON line came back, or 4 when the line's ``expect_json_key`` differs from ``nproc``."""
+    """Start ``nproc`` ranks of ``script argv`` and wait.  The ranks' stdout is read line by line AS IT ARRIVES: a line that
+    parses as a JSON object is kept (rank 0 prints exactly one; the last one is printed at the end), every other line goes
+    to stderr at once -- progress is visible while the job runs and a hung rendezvous shows what was printed before it.
+    The launcher runs in its own session: on ``timeout`` (seconds) or an interrupt the whole process group is killed, so no
+    rank is left holding a GPU.  Exit status: the launcher's, 124 after a timeout, 3 when no JSON line came back, 4 when
+    the line's ``expect_json_key`` differs from ``nproc``."""
+    import signal
+    import threading
+
     cmd = torchrun_command(script, argv, nproc, module=module)
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // max(1, int(nproc)))))
-    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, timeout=timeout)
-    line = None
-    for raw in proc.stdout.decode(errors="replace").splitlines():
-        s = raw.strip()
-        if s.startswith("{") and s.endswith("}"):
-            try:
-                json.loads(s)
-                line = s
-                continue
-            except ValueError:
-                pass
-        if s:
-            print(raw, file=sys.stderr)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, start_new_session=True)
+    found = []
+
+    def pump():
+        for raw in iter(proc.stdout.readline, b""):
+            text = raw.decode(errors="replace").rstrip("\n")
+            s = text.strip()
+            if s.startswith("{") and s.endswith("}"):
+                try:
+                    json.loads(s)
+                    found.append(s)
+                    continue
+                except ValueError:
+                    pass
+            if s:
+                print(text, file=sys.stderr, flush=True)
+
+    def kill_group():
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)          # start_new_session: the launcher's pid is its group's id
+        except ProcessLookupError:
+            pass
+
+    reader = threading.Thread(target=pump, daemon=True)
+    reader.start()
+    try:
+        proc.wait(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        kill_group()
+        proc.wait()
+        reader.join(timeout=5)
+        print(f"launch of {nproc} ranks timed out after {timeout} s (process group killed): {' '.join(cmd)}", file=sys.stderr)
+        return 124
+    except BaseException:
+        kill_group()
+        proc.wait()
+        raise
+    reader.join(timeout=30)
+    line = found[-1] if found else None
     if proc.returncode != 0:
+        kill_group()                                      # a rank that outlived a failed launcher
         print(f"launch of {nproc} ranks failed (exit {proc.returncode}): {' '.join(cmd)}", file=sys.stderr)
         return proc.returncode
     if line is None:

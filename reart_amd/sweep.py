@@ -103,14 +103,51 @@ def shard(n_instances, rank, world):
     return list(range(rank, n_instances, world))
 
 
-def gather_records(local, n_instances, device):
+def instance_cost(spec):
+    """Relative cost of one instance for the longest-first deal: frames x points^2 (the all-pairs searches dominate an
+    iteration; SURVEY.md 8e "longest-first greedy by T*N^2").  Specs without the fields cost 1."""
+    if "cost" in spec:
+        return float(spec["cost"])
+    n = float(spec.get("points", 1) or 1)
+    return float(spec.get("frames", 1) or 1) * n * n
+
+
+def deal(instances, world, policy="round_robin"):
+    """-> list over ranks of the instance ids each rank owns.  Every rank computes the same deal from the same list, so no
+    communication is needed.  ``round_robin``: instance i on rank i % world (right for equal instances: a cano_idx sweep of
+    one sequence).  ``lpt``: longest processing time first -- instances sorted by ``instance_cost`` (ties: lower id), each
+    to the rank with the least load so far (ties: lower rank); for sequence sets with different frame counts / sizes it
+    bounds the slowest rank by 4/3 of the optimum where round-robin can be off by the largest instance per round."""
+    n = len(instances)
+    if policy == "round_robin":
+        return [shard(n, r, world) for r in range(world)]
+    if policy != "lpt":
+        raise ValueError("policy is 'round_robin' or 'lpt'")
+    cost = [instance_cost(s) for s in instances]
+    load, out = [0.0] * world, [[] for _ in range(world)]
+    for i in sorted(range(n), key=lambda i: (-cost[i], i)):
+        r = min(range(world), key=lambda r: (load[r], r))
+        out[r].append(i)
+        load[r] += cost[i]
+    return out
+
+
+def owner_of(plan):
+    """{instance id: rank} of a deal."""
+    return {i: r for r, ids in enumerate(plan) for i in ids}
+
+
+def gather_records(local, n_instances, device, plan=None):
     """local: {instance id: 1-D float tensor [RECORD]} of this rank -> [n_instances, RECORD] on every
-    rank, ordered by instance id.  Uses all_gather on padded per-rank blocks (equal message size)."""
+    rank, ordered by instance id.  Uses all_gather on padded per-rank blocks (equal message size).  ``plan``: the deal
+    (``deal``) the ranks ran under; round-robin when omitted."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
-    per = (n_instances + world - 1) // world
+    if plan is None:
+        plan = [shard(n_instances, r, world) for r in range(world)]
+    per = max([len(ids) for ids in plan] + [1])
     block = torch.full((per, RECORD), float("nan"), dtype=torch.float32, device=device)
-    for slot, inst in enumerate(shard(n_instances, rank, world)):
+    for slot, inst in enumerate(plan[rank]):
         block[slot] = local[inst].to(device=device, dtype=torch.float32)
     if world > 1:
         blocks = [torch.empty_like(block) for _ in range(world)]
@@ -119,19 +156,20 @@ def gather_records(local, n_instances, device):
         blocks = [block]
     out = torch.empty((n_instances, RECORD), dtype=torch.float32, device=device)
     for r in range(world):
-        for slot, inst in enumerate(shard(n_instances, r, world)):
+        for slot, inst in enumerate(plan[r]):
             out[inst] = blocks[r][slot]
     return out
 
 
-def run_sweep(instances, run_instance, device):
+def run_sweep(instances, run_instance, device, policy="round_robin"):
     """instances: list of dicts (at least ``cano_idx``); ``run_instance(spec) -> dict(recon, flow,
-    total, iterations)`` optimises one instance on this rank's GPU.  Returns (records
-    [n, RECORD], index of the lowest-energy instance)."""
+    total, iterations)`` optimises one instance on this rank's GPU.  ``policy``: how instances are dealt to ranks
+    (``deal``).  Returns (records [n, RECORD], index of the lowest-energy instance)."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
+    plan = deal(instances, world, policy)
     local = {}
-    for inst in shard(len(instances), rank, world):
+    for inst in plan[rank]:
         spec = instances[inst]
         try:
             res = run_instance(spec)
@@ -139,12 +177,12 @@ def run_sweep(instances, run_instance, device):
                                   res if "total_err" in res else None)
         except Exception:  # a failed instance is reported (NaN energy), it does not kill the job
             local[inst] = _record(inst, spec, failed=1)
-    records = gather_records(local, len(instances), device)
+    records = gather_records(local, len(instances), device, plan)
     return records, best_instance(records)
 
 
 def run_sweep_engines(instances, make_engine, n_iter, device, per_gpu=3, chunk=100, energy=False, mode="streams",
-                      overlap_tails=True, on_finish=None):
+                      overlap_tails=True, on_finish=None, policy="round_robin"):
     """Sweep of fused-loop instances with ``per_gpu`` of them in flight per GPU.
 
     One instance of the relaxation loop is a chain of short, latency-bound launches that leaves
@@ -164,7 +202,8 @@ def run_sweep_engines(instances, make_engine, n_iter, device, per_gpu=3, chunk=1
         raise ValueError("mode is 'streams' or 'batch'")
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
-    mine = shard(len(instances), rank, world)
+    plan_ranks = deal(instances, world, policy)
+    mine = plan_ranks[rank]
     local = {}
     threads = os.environ.get("REART_SWEEP_THREADS", "1") != "0"
     pool, pending = None, []
@@ -206,8 +245,9 @@ def run_sweep_engines(instances, make_engine, n_iter, device, per_gpu=3, chunk=1
             for e in live:
                 e[3].synchronize()                       # the engines were prepared on their own streams
             solo = []
-            for b0 in range(0, len(live), RelaxBatch.MAX):
-                part = live[b0:b0 + RelaxBatch.MAX]
+            dead = []                                     # entries whose shared launches failed after advancing somebody
+            # the parts are cut ONCE from a snapshot: `live` itself is only edited after the loop
+            for part in [live[b0:b0 + RelaxBatch.MAX] for b0 in range(0, len(live), RelaxBatch.MAX)]:
                 try:
                     batch = RelaxBatch([e[2] for e in part])     # refuses engines that do not share shape and switches
                     # capture() runs its first step eagerly: an engine the batched entry does not implement
@@ -222,15 +262,24 @@ def run_sweep_engines(instances, make_engine, n_iter, device, per_gpu=3, chunk=1
                     if started != {0}:          # the shared launches already advanced somebody: not restartable here
                         for e in part:
                             local[e[0]] = _record(e[0], e[1], failed=1)
-                            live.remove(e)
+                            dead.append(e)
                     else:
                         import warnings
 
                         warnings.warn(f"sweep: batch of {len(part)} instances falls back to streams ({type(exc).__name__}: {exc})")
                         solo.extend(part)
+            for e in dead:
+                live.remove(e)
         for e in solo:
-            with torch.cuda.stream(e[3]), gate.capture():
-                e[4] = e[2].capture(steps_per_graph=min(chunk, n_iter))
+            try:
+                with torch.cuda.stream(e[3]), gate.capture():
+                    e[4] = e[2].capture(steps_per_graph=min(chunk, n_iter))
+            except Exception as exc:  # a failed capture is this instance's failure (NaN energy), never the sweep's
+                import sys
+
+                print(f"sweep: instance {e[0]} ({e[1]}) failed in graph capture: {type(exc).__name__}: {exc}", file=sys.stderr)
+                local[e[0]] = _record(e[0], e[1], failed=1)
+                live.remove(e)
         return plan
 
     def enqueue(live, plan):
@@ -277,7 +326,12 @@ def run_sweep_engines(instances, make_engine, n_iter, device, per_gpu=3, chunk=1
                 print(f"sweep: instance {inst} ({spec}) has no energy: {type(exc).__name__}: {exc}\n"
                       + "".join(traceback.format_exception(type(exc), exc, exc.__traceback__)[-3:]), file=sys.stderr)
         if on_finish is not None:
-            on_finish(inst, spec, eng, en)
+            try:
+                on_finish(inst, spec, eng, en)
+            except Exception as exc:      # disk full, pickling error ...: the record still counts, the job goes on
+                import sys
+
+                print(f"sweep: on_finish of instance {inst} ({spec}) raised {type(exc).__name__}: {exc}", file=sys.stderr)
         return inst, _record(inst, spec, (float(row[0]), float(row[1]), float(row[2])), done, 0, en)
 
     def tails(live):
@@ -331,7 +385,7 @@ def run_sweep_engines(instances, make_engine, n_iter, device, per_gpu=3, chunk=1
     torch.cuda.synchronize(device)
     stages["drain_s"] = time.perf_counter() - t_          # what is left after the last group was queued: its iterations and tails
     run_sweep_engines.last_stages = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in stages.items()}
-    records = gather_records(local, len(instances), device)
+    records = gather_records(local, len(instances), device, plan_ranks)
     return records, best_instance(records)
 
 
@@ -408,6 +462,9 @@ def build_cli():
     p.add_argument("--energy", action="store_true", help="end every instance with structure extraction + energy (run_robot.py:224-321)")
     p.add_argument("--save_root", default="exp/sweep")
     p.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
+    p.add_argument("--shard", choices=("round_robin", "lpt"), default="round_robin",
+                   help="how instances are dealt to ranks: round_robin (instance i on rank i %% world) or lpt = longest first by "
+                        "frames x points^2 onto the least loaded rank (sequence sets of unequal length)")
     # the per-instance flags of run_robot.py:362-420, same names and defaults
     p.add_argument("--manual_seed", default=2, type=int)
     p.add_argument("--num_points", default=4096, type=int)
@@ -433,6 +490,16 @@ def _engine_factory(args, device, samples):
     from .relax import RelaxEngine
     from . import run_robot as rr
 
+    ref_cache = {}        # sequence -> (pc_ref_list, flow_ref_list): they depend on the sequence only, not on cano_idx
+
+    def references(spec, sample):
+        key = spec.get("seq_path") or ("synthetic", spec.get("synthetic"))
+        if spec.get("synthetic") is not None:      # the generator's own references travel with the sample
+            return rr.flow_references(args, sample, device, None)
+        if key not in ref_cache:
+            ref_cache[key] = rr.flow_references(args, sample, device, spec.get("seq_path"))
+        return ref_cache[key]
+
     def make_engine(spec):
         if spec.get("synthetic") is not None:
             sample = rr.synthetic_sequence(args.num_points, spec["cano_idx"], spec["frames"], args.use_flow_loss,
@@ -443,7 +510,7 @@ def _engine_factory(args, device, samples):
         pcs = torch.from_numpy(sample["pc_list"]).float().to(device)
         refs = flows = None
         if args.use_flow_loss:
-            refs, flows = rr.flow_references(args, sample, device, spec.get("seq_path"))
+            refs, flows = references(spec, sample)
         torch.manual_seed(args.manual_seed)                   # run_robot.py:36-41: every run seeds the seg-head init alike
         model = BaseModel(num_parts=args.num_parts, pose_len=pcs.shape[0]).to(device)
         samples[spec["id"]] = sample
@@ -452,6 +519,12 @@ def _engine_factory(args, device, samples):
                            use_robust_loss=args.use_robust_loss, seed=args.manual_seed, weight_decay=args.weight_decay)
 
     return make_engine
+
+
+def _engine_poses(eng):
+    """[T-1, P, 4, 4] poses of a finished engine's model (BaseModel.forward's third output, networks/model.py:39-70)."""
+    with torch.no_grad():
+        return eng.model(eng.caller_clouds()[0])[2].detach()
 
 
 def instance_dir(save_root, spec):
@@ -522,6 +595,7 @@ def main(argv=None, runner=None):
     instances = enumerate_instances(sequences, args.cano)
     for i, s in enumerate(instances):
         s["id"] = i
+        s["points"] = args.num_points
         if args.synthetic:
             s["synthetic"] = 2 + int(s["seq"].split("_")[1])
     os.makedirs(args.save_root, exist_ok=True)
@@ -533,20 +607,37 @@ def main(argv=None, runner=None):
                 save_instance(args.save_root, spec, res)
             return res
 
-        records, _ = run_sweep(instances, run_and_save, device)
+        records, _ = run_sweep(instances, run_and_save, device, policy=args.shard)
     else:
         samples = {}
         make_engine = _engine_factory(args, device, samples)
 
         def on_finish(inst, spec, eng, en):
-            if en is not None:
+            # run_robot.py:333-356 saves result.pkl + model.pth.tar for EVERY optimisation run: without the energy tail (or
+            # when it raised for this instance) the files carry the engine's own labels and poses, unmerged
+            try:
+                if en is None:
+                    ident = torch.arange(eng.model.num_parts if hasattr(eng.model, "num_parts") else 0)
+                    en = {"seg_part": eng.seg_part, "trans_list": _engine_poses(eng), "joint_connection": ident.new_zeros((0, 2))}
                 save_instance(args.save_root, spec, en, samples.get(inst), eng.model, float(eng.tau.item()))
-            samples.pop(inst, None)
+            finally:
+                samples.pop(inst, None)
 
         records, _ = run_sweep_engines(instances, make_engine, args.n_iter, device, per_gpu=args.per_gpu,
-                                       chunk=min(100, args.n_iter), energy=args.energy, mode=args.mode, on_finish=on_finish)
+                                       chunk=min(100, args.n_iter), energy=args.energy, mode=args.mode, on_finish=on_finish,
+                                       policy=args.shard)
     records = records.cpu()
     win = winners(instances, records)
+    owner = owner_of(deal(instances, world, args.shard))
+    backend = dist.get_backend() if dist.is_initialized() else None
+    # who ran what: every rank reports its device; rank 0 writes the table (one small object gather, outside the data path)
+    me = {"rank": rank, "device": str(device), "instances": [i for i, r in owner.items() if r == rank],
+          "cano_idx": [instances[i]["cano_idx"] for i, r in owner.items() if r == rank]}
+    if dist.is_initialized():
+        ranks_info = [None] * world
+        dist.all_gather_object(ranks_info, me)
+    else:
+        ranks_info = [me]
     if dist.is_initialized():
         dist.barrier()                      # every rank's result files are on disk before rank 0 copies the winners
     if rank == 0:
@@ -559,7 +650,7 @@ def main(argv=None, runner=None):
                 if s["seq"] != name:
                     continue
                 row = {k: (None if bool(torch.isnan(records[i, j])) else float(records[i, j])) for j, k in enumerate(fields)}
-                row["rank"] = i % world
+                row["rank"] = owner[i]
                 rows.append(row)
             w = win[name]
             table[name] = {"winner_cano_idx": None if w is None else instances[w]["cano_idx"],
@@ -575,10 +666,14 @@ def main(argv=None, runner=None):
         wall = time.perf_counter() - t_start          # this rank's wall clock from argument parsing to the winners (after the gather)
         rate = len(instances) * args.n_iter / wall
         with open(os.path.join(args.save_root, "sweep.json"), "w") as f:
-            json.dump({"world_size": world, "n_instances": len(instances), "n_iter": args.n_iter, "energy": bool(args.energy),
+            json.dump({"world_size": world, "rccl_world": dist.get_world_size() if dist.is_initialized() else 1,
+                       "backend": backend, "shard": args.shard, "ranks": ranks_info,
+                       "n_instances": len(instances), "n_iter": args.n_iter, "energy": bool(args.energy),
                        "wall_s": round(wall, 3), "iterations_per_s": round(rate, 1),
                        "rank0_stages": getattr(run_sweep_engines, "last_stages", None), "sequences": table}, f, indent=1)
-        print(json.dumps({"sweep": os.path.join(args.save_root, "sweep.json"), "n_gpus": world, "instances": len(instances),
+        print(json.dumps({"sweep": os.path.join(args.save_root, "sweep.json"), "n_gpus": world,
+                          "rccl_world": dist.get_world_size() if dist.is_initialized() else 1, "backend": backend,
+                          "shard": args.shard, "ranks": ranks_info, "instances": len(instances),
                           "wall_s": round(wall, 3), "iterations_per_s": round(rate, 1),
                           "rank0_stages": getattr(run_sweep_engines, "last_stages", None),
                           "winners": {k: v["winner_cano_idx"] for k, v in table.items()}}))

@@ -29,7 +29,7 @@ def _compare(cost_np, dev, expect_same_perm=True):
 def test_lap_random_matrices(dev, n):
     rng = np.random.default_rng(n)
     cost = rng.uniform(0.0, 1.0, (3, n, n)).astype(np.float32)
-    _compare(cost, dev)
+    assert _compare(cost, dev) == 0          # certified on the GPU: no matrix went to the host solver
 
 
 def test_lap_above_the_lds_resident_size(dev):
@@ -60,8 +60,8 @@ def test_lap_ties(dev):
     base = rng.uniform(0, 1, (1, 40, 40)).astype(np.float32)
     cost = np.concatenate([base, base], axis=1)           # 80 x 40 -> make square by duplicating columns too
     cost = np.concatenate([cost, cost], axis=2)
-    _compare(cost, dev, expect_same_perm=False)
-    _compare(np.zeros((2, 17, 17), np.float32), dev, expect_same_perm=False)
+    assert _compare(cost, dev, expect_same_perm=False) == 0      # the certificate closes on exact ties too
+    assert _compare(np.zeros((2, 17, 17), np.float32), dev, expect_same_perm=False) == 0
 
 
 def test_lap_warm_start_same_result(dev):
@@ -77,7 +77,8 @@ def test_lap_warm_start_same_result(dev):
     for k in range(3):
         moved = pts + rng.normal(0, 0.01 * k, pts.shape).astype(np.float32)
         cost = torch.cdist(torch.from_numpy(moved), torch.from_numpy(pts[::-1].copy())).numpy().astype(np.float32)
-        out = linear_sum_assignment_batch(torch.from_numpy(cost).to(dev), state=state)
+        out, fallbacks = linear_sum_assignment_batch(torch.from_numpy(cost).to(dev), state=state, return_stats=True)
+        assert fallbacks == 0                # the GPU's own certified result, not the host solver's
         for b, (r, c) in enumerate(out):
             rr, cc = linear_sum_assignment(cost[b])
             np.testing.assert_array_equal(c, cc)
