@@ -531,6 +531,18 @@ int reart_lap_resolve_points_race(const float *src, const float *tgt, int B, int
                                   int32_t *certified, const double *price_in, double *price_out, void *workspace,
                                   size_t workspace_bytes, void *stream);
 
+/* reart_lap_resolve_points[_race] with one search per WAVE (csrc/lap_mw.hip): the free rows a refresh leaves (run_robot.py:164-187
+ * re-solves every assign_gap iterations) are mostly independent of each other, so every wave of a problem's workgroup follows
+ * its own free row -- row-reduction chain, then a shortest augmenting path -- on columns it holds in registers, and commits
+ * under a workgroup lock after checking that the columns it is about to write are still as it saw them.  512 <= n <= 1024
+ * (REART_ERR_UNSUPPORTED otherwise: call reart_lap_resolve_points_race).  racers >= 1 workgroups per problem (free rows taken
+ * in different orders); workspace: reart_lap_race_workspace_bytes(B, n, racers).  Outputs, certificate and the caveat on the
+ * potentials as reart_lap_resolve_points_race; stats[b] = released rows (+ winner << 16), rows left for the path searches |
+ * commit conflicts << 16, path-search steps, 1 + 256 * row-reduction steps. */
+int reart_lap_resolve_points_mw(const float *src, const float *tgt, int B, int n, int racers, int32_t *col4row,
+                                int32_t *certified, const double *price_in, double *price_out, void *workspace,
+                                size_t workspace_bytes, void *stream);
+
 /* Cost matrices for the above: replaces `torch.cdist(pc_src, pc_tgt)` (run_robot.py:171, utils/model_utils.py:93).
  *   a [B,n,3], b [B,m,3] -> out [B,n,m] = Euclidean distance, sqrt(((dx*dx)+(dy*dy))+(dz*dz)) in fp32. */
 int reart_cdist(const float *a, const float *b, int B, int n, int m, float *out, void *stream);

@@ -18,12 +18,12 @@
 // integer atomics on ordered keys (max bid, then lowest row).
 #include "common.h"
 #include "internal.h"
+#include "lap_dev.h"
 #include <math.h>
 
 #ifndef LAP_BS
 #define LAP_BS 1024
 #endif
-#define LAP_NMAX 4096
 // lap_auction_kernel: from phase LAP_SEARCH_PHASE on, the last LAP_SEARCH_NU free rows of a phase get one augmenting-path
 // search each instead of a bidding chain.  Measured on the tail's 19 x 4096^2 problems (tools/lap_cold.py): the early
 // phases' chains are long (up to 12 k links) but they are the price war that settles the duals -- cut short by a search
@@ -82,109 +82,6 @@ __constant__ double c_lap_race[LAP_RACE_COLD][2] = {{LAP_EPS0, LAP_THETA}, {0.12
 #define LAP_RACE_WARM 3
 __constant__ double c_lap_race_warm[LAP_RACE_WARM][3] = {{1e-2, 6.0, 2.0}, {1e-3, 6.0, 2.0}, {1e-3, 6.0, 1.0}};
 
-__device__ __forceinline__ unsigned long long lap_key(double v) { return (unsigned long long)__double_as_longlong(v); }  // v >= 0
-
-// one more candidate for a lane's running (min, arg-min, second min): seven instructions (v_min / v_max on fp64 pairs) where
-// the compare-and-select form takes eleven -- the row scans are bound by exactly these.  A tie keeps the earlier column.
-__device__ __forceinline__ void lap_top2_push(double v, int j, double &v1, int &j1, double &v2) {
-    v2 = fmin(v2, fmax(v1, v));
-    j1 = v < v1 ? j : j1;
-    v1 = fmin(v1, v);
-}
-__device__ __forceinline__ void lap_top2_push(double v, int j, int pay, double &v1, int &j1, double &v2, int &p1) {
-    v2 = fmin(v2, fmax(v1, v));
-    const bool lt = v < v1;
-    j1 = lt ? j : j1; p1 = lt ? pay : p1;
-    v1 = fmin(v1, v);
-}
-
-// the waves' merge of per-lane (min, arg-min, second min [, payload of the arg-min]) triples: LDS-free butterfly
-template <int STEP>
-__device__ __forceinline__ void lap_top2_step(double &v1, int &j1, double &v2, int &pay) {
-    const double ov1 = reart_bfly_d<STEP>(v1), ov2 = reart_bfly_d<STEP>(v2);
-    const int oj1 = reart_bfly<STEP>(j1), op = reart_bfly<STEP>(pay);
-    const bool take = (ov1 < v1) || (ov1 == v1 && oj1 < j1);
-    const double lose = take ? v1 : ov1;           // the larger of the two minima
-    v2 = fmin(fmin(v2, ov2), lose);
-    v1 = take ? ov1 : v1; j1 = take ? oj1 : j1; pay = take ? op : pay;
-}
-__device__ __forceinline__ void lap_wave_top2(double &v1, int &j1, double &v2, int &pay) {
-    lap_top2_step<0>(v1, j1, v2, pay); lap_top2_step<1>(v1, j1, v2, pay); lap_top2_step<2>(v1, j1, v2, pay);
-    lap_top2_step<3>(v1, j1, v2, pay); lap_top2_step<4>(v1, j1, v2, pay); lap_top2_step<5>(v1, j1, v2, pay);
-}
-__device__ __forceinline__ void lap_wave_top2(double &v1, int &j1, double &v2) {
-    int pay = 0;
-    lap_wave_top2(v1, j1, v2, pay);
-}
-// The same results with a third of the instructions when the minimum is attained by ONE lane (the normal case in fp64):
-// the minimum alone by a butterfly, its column / payload read from the lane that holds it, the second minimum by another
-// butterfly.  An exact tie (or a wave without candidates) takes the full butterfly: the lowest column wins either way.
-__device__ __forceinline__ double lap_wave_min_d(double v) {
-    v = fmin(v, reart_bfly_d<0>(v)); v = fmin(v, reart_bfly_d<1>(v)); v = fmin(v, reart_bfly_d<2>(v));
-    v = fmin(v, reart_bfly_d<3>(v)); v = fmin(v, reart_bfly_d<4>(v)); v = fmin(v, reart_bfly_d<5>(v));
-    return v;
-}
-__device__ __forceinline__ void lap_wave_top2_fast(double &v1, int &j1, double &v2, int &pay) {
-    const double m = lap_wave_min_d(v1);
-    const unsigned long long at = __ballot(v1 == m);
-    if (__builtin_popcountll(at) == 1) {
-        const int wl = __ffsll((long long)at) - 1;
-        const double c = lap_wave_min_d((int)(threadIdx.x & 63) == wl ? v2 : v1);
-        j1 = __builtin_amdgcn_readlane(j1, wl); pay = __builtin_amdgcn_readlane(pay, wl);
-        v1 = m; v2 = c;
-    } else lap_wave_top2(v1, j1, v2, pay);
-}
-// the same for values that live in the first 2^LG lanes only (the waves' results meeting after a barrier; the other lanes
-// hold +inf): LG butterfly steps instead of six; every lane gets the result
-template <int LG>
-__device__ __forceinline__ double lap_lanes_min_d(double v) {
-    v = fmin(v, reart_bfly_d<0>(v));
-    if (LG > 1) v = fmin(v, reart_bfly_d<1>(v));
-    if (LG > 2) v = fmin(v, reart_bfly_d<2>(v));
-    if (LG > 3) v = fmin(v, reart_bfly_d<3>(v));
-    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
-}
-template <int LG>
-__device__ __forceinline__ void lap_lanes_top2(double &v1, int &j1, double &v2, int &pay) {
-    const int lane = threadIdx.x & 63;
-    const double m = lap_lanes_min_d<LG>(v1);
-    const unsigned long long at = __ballot(lane < (1 << LG) && v1 == m);
-    if (__builtin_popcountll(at) == 1) {
-        const int wl = __ffsll((long long)at) - 1;
-        const double c = lap_lanes_min_d<LG>(lane == wl ? v2 : v1);
-        j1 = __builtin_amdgcn_readlane(j1, wl); pay = __builtin_amdgcn_readlane(pay, wl);
-        v1 = m; v2 = c;
-    } else {
-        lap_top2_step<0>(v1, j1, v2, pay);
-        if (LG > 1) lap_top2_step<1>(v1, j1, v2, pay);
-        if (LG > 2) lap_top2_step<2>(v1, j1, v2, pay);
-        if (LG > 3) lap_top2_step<3>(v1, j1, v2, pay);
-        v1 = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v1)), __builtin_amdgcn_readfirstlane(__double2loint(v1)));
-        v2 = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v2)), __builtin_amdgcn_readfirstlane(__double2loint(v2)));
-        j1 = __builtin_amdgcn_readfirstlane(j1); pay = __builtin_amdgcn_readfirstlane(pay);
-    }
-}
-template <int LG>
-__device__ __forceinline__ void lap_lanes_argmin(double &v, int &j) {
-    const int lane = threadIdx.x & 63;
-    const double m = lap_lanes_min_d<LG>(v);
-    const unsigned long long at = __ballot(lane < (1 << LG) && v == m);
-    if (__builtin_popcountll(at) == 1) { j = __builtin_amdgcn_readlane(j, __ffsll((long long)at) - 1); v = m; }
-    else {
-        reart_argmin_step<0>(v, j);
-        if (LG > 1) reart_argmin_step<1>(v, j);
-        if (LG > 2) reart_argmin_step<2>(v, j);
-        if (LG > 3) reart_argmin_step<3>(v, j);
-        v = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
-        j = __builtin_amdgcn_readfirstlane(j);
-    }
-}
-__device__ __forceinline__ void lap_wave_argmin_fast(double &v, int &j) {
-    const double m = lap_wave_min_d(v);
-    const unsigned long long at = __ballot(v == m);
-    if (__builtin_popcountll(at) == 1) { j = __builtin_amdgcn_readlane(j, __ffsll((long long)at) - 1); v = m; }
-    else reart_wave_argmin_d(v, j);
-}
 
 // smallest (value, column) and second smallest value of row i under prices p over the columns [jb, je); all lanes
 // get the result (an empty range gives +inf).  Exact selections only, so any split of a row into ranges followed by
@@ -296,6 +193,15 @@ extern "C" int reart_debug_jv_phase(unsigned long long *out, int reset) {
     if (reset) { static unsigned long long z[32 * 10]; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_jv_phase), z, sizeof(z)); }
     return REART_OK;
 }
+// path-search lengths of lap_jv_kernel (racer 0 of every problem): [log2 bin of the steps][searches | steps]
+__device__ unsigned long long g_jv_hist[16 * 2];
+extern "C" int reart_debug_jv_hist(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_jv_hist), sizeof(g_jv_hist)) != hipSuccess) return REART_ERR_LAUNCH;
+    if (reset) { static unsigned long long z[16 * 2]; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_jv_hist), z, sizeof(z)); }
+    return REART_OK;
+}
+#define JPH_HIST(steps_) do { if (threadIdx.x == 0 && blockIdx.y == 0) { int b_ = 0; while ((1 << b_) < (steps_) && b_ < 15) ++b_; \
+    atomicAdd(&g_jv_hist[2 * b_], 1ull); atomicAdd(&g_jv_hist[2 * b_ + 1], (unsigned long long)(steps_)); } } while (0)
 __device__ unsigned long long g_auc_phase[32 * 10];   // the auction's: see tools/lap_cold.py for the phase names
 extern "C" int reart_debug_auction_phase(unsigned long long *out, int reset) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_auc_phase), sizeof(g_auc_phase)) != hipSuccess) return REART_ERR_LAUNCH;
@@ -319,6 +225,7 @@ extern "C" int reart_debug_auction_trace(int *out) {
 #define APH_FLUSH() do { } while (0)
 #define APH_TRACE(ph, slot, val) do { } while (0)
 #define JPH_COUNT(k, v) do { } while (0)
+#define JPH_HIST(steps_) do { } while (0)
 #endif
 
 __global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
@@ -954,48 +861,6 @@ extern "C" int reart_lap_auction_warm(const float *cost, int B, int n, int32_t *
 // start and differ only in the order in which they take the free rows -- the number of sequential steps of a re-solve varies by +-18 % with that
 // order, the first racer to finish publishes and the others leave at their next step.  Racer 0 is the plain solver
 // (ascending rows), 1 takes them descending, the others in a fixed pseudo-random order k -> k * prime mod count.
-#define JV_RACE_MAX 13
-__device__ const int jv_race_prime[JV_RACE_MAX] = {0, 0, 4099, 4111, 4127, 4129, 4133, 4139, 4153, 4157, 4159, 4177, 4201};
-__device__ __forceinline__ int jv_order(int k, int cnt, int racer) {
-    if (racer == 0) return k;
-    if (racer == 1) return cnt - 1 - k;
-    return (int)(((unsigned)k * (unsigned)(jv_race_prime[racer] % cnt)) % (unsigned)cnt);   // the primes exceed every count: a permutation
-}
-typedef float jv_f2 __attribute__((ext_vector_type(2)));
-#define JV_OWNED (1 << 30)  // tie key of the path search's arg-min: owned columns after unowned ones
-#define JV_PTS_NMAX 2048   // points form: both point sets + the solver state must fit in LDS
-#ifndef JV_PTS_BS
-#define JV_PTS_BS 512
-#endif
-#define JV_SPLIT_NMIN 512   // from here on the two full passes of a re-solve run as their own whole-chip launches
-#ifndef JV_ARR_BUDGET
-#define JV_ARR_BUDGET 8    // row-reduction steps allowed per free row before the rest goes to the path search
-#endif
-struct JvArgs {
-    const float *cost; int B, n;
-    int *col4row;              // in: previous assignment (or -1), out: the optimum
-    int *certified;
-    const double *price_in;    // previous potentials (prices, the auction's sign convention)
-    double *price_out;
-    int max_rounds_cert;
-    int *stats;                // nullable [B][4]: released rows, rows left for the path search, Dijkstra steps, certificate rounds
-                               // + 256 * row-reduction steps
-    double keep_tol;           // fraction of the largest cost
-    // PTS form: no cost matrix; c_ij = sqrt(((dx*dx)+(dy*dy))+(dz*dz)) of src point i and tgt point j, the expression of
-    // reart_cdist, evaluated where it is needed from copies of both point sets in LDS
-    const float *src, *tgt;    // [B][n][3]
-    // three-launch form (jv_launch): the two full passes over the costs run on the whole chip, the sequential part in between
-    double *pre_v1, *pre_cur;  // [B][n] per row: min_k (c_ik + p_k) and c_i,s(i) + p_s(i) under the incoming prices / assignment
-    int *pre_j1;               // [B][n] the arg-min column
-    double *scale;             // [B] the cost scale the tolerances are fractions of
-    int *cert_bad;             // [B] set by the certificate pass when a row's column is not its arg-min
-    int pass_mode;             // lap_jv_pass_kernel: 0 = row potentials of the start, 1 = first certificate round
-    // racing form (MODE 1, gridDim.y racers per matrix): the racers read the start from copies (col4row / price_out are
-    // written by the winner while others may still be loading) and meet in done[b] (0 = nobody has finished)
-    int *done;
-    const int *col_start;
-    const double *price_start;
-};
 
 // smallest (value, column) and second smallest value of c_ij + p_j over the columns of row i, costs from the points
 __device__ __forceinline__ void lap_row_top2_pts(float ax, float ay, float az, const float *__restrict__ tx,
@@ -1300,6 +1165,7 @@ __global__ __launch_bounds__(BS) void lap_jv_kernel(JvArgs a) {
         }
         double mu = 0.0;
         int sink = -1;
+        [[maybe_unused]] const int hist0_ = st_steps;
         JPH(5);
         for (int it = 0; ; ++it) {
             // closest unlabelled column: (distance, index) minimum over the workgroup
@@ -1347,6 +1213,7 @@ __global__ __launch_bounds__(BS) void lap_jv_kernel(JvArgs a) {
             JPH(3);
         }
         if (sink < 0) { solved = false; break; }
+        JPH_HIST(st_steps - hist0_);
         // potentials: fixed columns (all labelled ones except the sink) and their rows
 #pragma unroll
         for (int k = 0; k < JV_CPT; ++k) {
@@ -1464,11 +1331,12 @@ __global__ __launch_bounds__(JV_PASS_BS) void lap_jv_pass_kernel(JvArgs a) {
 // Re-solve from the assignment in col4row and the potentials in price_in (both from an earlier solve of a similar batch,
 // reart_lap_auction* or these functions); same outputs and the same certificate as reart_lap_auction.
 template <bool PTS>
-static int jv_launch(JvArgs a, void *workspace, size_t workspace_bytes, void *stream, int racers = 1) {
+static int jv_launch(JvArgs a, void *workspace, size_t workspace_bytes, void *stream, int racers = 1, bool per_wave = false) {
     if (a.B < 0 || a.n < 1 || a.n > (PTS ? JV_PTS_NMAX : LAP_NMAX)) return REART_ERR_INVALID_ARG;
     if (racers < 1 || racers > JV_RACE_MAX) return REART_ERR_INVALID_ARG;
     if (a.B == 0) return REART_OK;
     if (!a.col4row || !a.certified || !a.price_in) return REART_ERR_INVALID_ARG;
+    if (per_wave && (!PTS || a.n < JV_SPLIT_NMIN || a.n > reart_internal_jvmw_nmax())) return REART_ERR_UNSUPPORTED;
     if (a.n < JV_SPLIT_NMIN) racers = 1;       // one launch does everything there: nothing worth racing
     if (!workspace || workspace_bytes < (racers > 1 ? reart_lap_race_workspace_bytes(a.B, a.n, racers) : reart_lap_workspace_bytes(a.B, a.n)))
         return REART_ERR_INVALID_ARG;
@@ -1517,8 +1385,13 @@ static int jv_launch(JvArgs a, void *workspace, size_t workspace_bytes, void *st
             return REART_ERR_LAUNCH;
         a.price_start = pc; a.col_start = cc;
     }
-    hipLaunchKernelGGL((lap_jv_kernel<JVBS, PTS, 1>), dim3(a.B, racers), dim3(JVBS), lds, (hipStream_t)stream, a);
-    REART_CHECK_LAUNCH();
+    if (per_wave) {                             // lap_mw.hip: one search per wave instead of one per workgroup
+        const int rc = reart_internal_jvmw_launch(a, racers, (hipStream_t)stream);
+        if (rc != REART_OK) return rc;
+    } else {
+        hipLaunchKernelGGL((lap_jv_kernel<JVBS, PTS, 1>), dim3(a.B, racers), dim3(JVBS), lds, (hipStream_t)stream, a);
+        REART_CHECK_LAUNCH();
+    }
     a.done = nullptr;
     a.pass_mode = 1;
     hipLaunchKernelGGL((lap_jv_pass_kernel<PTS>), dim3(a.B, per), dim3(JV_PASS_BS), lds_pass, (hipStream_t)stream, a);
@@ -1565,6 +1438,26 @@ extern "C" int reart_lap_resolve_points_race(const float *src, const float *tgt,
     a.src = src; a.tgt = tgt; a.B = B; a.n = n; a.col4row = col4row; a.certified = certified; a.price_in = price_in;
     a.price_out = price_out;
     return jv_launch<true>(a, workspace, workspace_bytes, stream, racers);
+}
+
+// reart_lap_resolve_points[_race] with the sequential part run by lap_mw.hip: every WAVE of a problem's workgroup follows its
+// own free row (row-reduction chain, then shortest augmenting path) on the columns it holds in registers, and commits under
+// a workgroup lock after checking that the columns it is about to write are as it saw them.  512 <= n <= 1024
+// (REART_ERR_UNSUPPORTED otherwise: use reart_lap_resolve_points_race).  racers >= 1 workgroups per problem (1: no race;
+// workspace reart_lap_race_workspace_bytes(B, n, racers) either way).  Same outputs and certificate; like the raced
+// solves the potentials (and, among optima of exactly equal cost, the assignment) depend on timing.  stats [B][4] in the
+// workspace: released rows (+ winner << 16), rows left for the path search | conflicts << 16, path-search steps,
+// 1 + 256 * row-reduction steps.
+extern "C" int reart_lap_resolve_points_mw(const float *src, const float *tgt, int B, int n, int racers, int32_t *col4row,
+                                           int32_t *certified, const double *price_in, double *price_out, void *workspace,
+                                           size_t workspace_bytes, void *stream) {
+    if ((!src || !tgt) && B > 0) return REART_ERR_INVALID_ARG;
+    if (racers < 1) return REART_ERR_INVALID_ARG;
+    if (workspace_bytes < reart_lap_race_workspace_bytes(B, n, racers)) return REART_ERR_INVALID_ARG;
+    JvArgs a = {};
+    a.src = src; a.tgt = tgt; a.B = B; a.n = n; a.col4row = col4row; a.certified = certified; a.price_in = price_in;
+    a.price_out = price_out;
+    return jv_launch<true>(a, workspace, workspace_bytes, stream, racers, true);
 }
 
 // ------------------------------------------------------------------------------------------------------------

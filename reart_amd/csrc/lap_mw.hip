@@ -1,0 +1,387 @@
+// reart_amd/csrc/lap_mw.hip -- the sequential part of a points-form re-solve (lap.hip: lap_jv_kernel<., true, 1>) with the
+// ROW REDUCTION RUN ONE CHAIN PER WAVE (reference: the assignment refresh of run_robot.py:164-187 -- scipy's
+// linear_sum_assignment on (T-1) matrices cdist(pc_src, pc_tgt), utils/model_utils.py:85-103 -- every assign_gap iterations).
+//
+// What the one-row-at-a-time form measured (tools/exp_assign_phase.py, 9 x 1024^2 of the base recipe): a refresh frees
+// ~380 rows, the augmenting row reduction settles all but 55-90 of them in ~2 000-2 500 steps, those take one shortest
+// augmenting path each, 3 000-6 000 Dijkstra steps per problem -- every step a workgroup-wide reduction + barrier.
+// Row-reduction chains from different free rows are independent of each other, so here every wave follows its OWN chain:
+//   * a wave holds all n <= 64 * CPL columns (CPL target points per lane) in registers; a step is CPL distances per lane
+//     and ONE wave reduction -- no barrier;
+//   * the shared state (prices, owners, assignment) lives in LDS and is written only under a lock by the wave that
+//     COMMITS a step.  Nothing else synchronises the waves: a wave reads the prices whenever it likes.
+// Why unsynchronised reads are safe: prices only ever RISE (a step raises its column by v2 - v1 >= 0) and a column never
+// loses its owner.  A step that saw a stale (lower) price of a column it did NOT choose underestimated that column --
+// which lost the comparison anyway -- and pays at most the gap it would be allowed to pay now: every dual constraint
+// still holds and the new pair is tight.  What must not have changed is what the step writes: under the lock the wave
+// compares the chosen column's (price, owner) with the values its decision used; a difference and the row is scanned again.
+// The remaining rows' path searches then run with the whole workgroup on one search (they are NOT independent: measured,
+// see below).  The optimum is the optimum in whatever order the rows are settled; the potentials depend on the
+// interleaving, so -- like the raced solves -- they are valid duals that are not reproducible from run to run.  The exact
+// certificate of the re-solve (lap_jv_pass_kernel + lap_jv_kernel<., ., 2>) runs afterwards unchanged.
+#include "common.h"
+#include "internal.h"
+#include "lap_dev.h"
+
+#ifndef MW_NW
+#define MW_NW 8              // waves per workgroup = searches in flight per problem (two per SIMD: 256 VGPRs each)
+#endif
+#define MW_CHECK 16          // a search looks at the race flag and at its labelled columns every MW_CHECK steps
+
+#ifdef REART_PRUNE_PHASE   // diagnostic build only (make -C reart_amd/csrc phase; tools/exp_mw.py)
+// per workgroup (first 64): 0 set-up | 1 row-reduction phase | 2 path-search phase (wall ticks of wave 0) | 3, 4 ticks the waves
+// spent inside those phases' work loops (summed over waves) | 5 ticks waiting for the lock | 6 path-search steps thrown away |
+// 7 path-search steps in all | 8 searches started | 9 longest search (steps)
+__device__ unsigned long long g_mw_phase[64 * 10];
+extern "C" int reart_debug_mw_phase(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mw_phase), sizeof(g_mw_phase)) != hipSuccess) return REART_ERR_LAUNCH;
+    if (reset) { static unsigned long long z[64 * 10]; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_mw_phase), z, sizeof(z)); }
+    return REART_OK;
+}
+#define MWP_ADD(k, v) do { if (lane == 0 && blockIdx.y == 0 && blockIdx.x < 64) atomicAdd(&g_mw_phase[blockIdx.x * 10 + (k)], (unsigned long long)(v)); } while (0)
+#define MWP_MAX(k, v) do { if (lane == 0 && blockIdx.y == 0 && blockIdx.x < 64) atomicMax(&g_mw_phase[blockIdx.x * 10 + (k)], (unsigned long long)(v)); } while (0)
+#define MWP_NOW() wall_clock64()
+#else
+#define MWP_ADD(k, v) do { } while (0)
+#define MWP_MAX(k, v) do { } while (0)
+#define MWP_NOW() 0ull
+#endif
+
+struct MwShared {
+    int lock, qhead, nnext, budget, abort_, flag, unsolved;
+    int steps, arr, conflicts;
+};
+
+__device__ __forceinline__ void mw_lock(int *lock) {
+    if ((threadIdx.x & 63) == 0) {
+        for (;;) {
+            int expected = 0;
+            if (__hip_atomic_compare_exchange_strong(lock, &expected, 1, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");      // every lane's reads of the state come after the lock
+}
+__device__ __forceinline__ void mw_unlock(int *lock) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // every lane's writes are in LDS before the lock opens
+    if ((threadIdx.x & 63) == 0) __hip_atomic_store(lock, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ int mw_flag(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ int mw_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// this lane's CPL costs of row (ax, ay, az): reart_cdist's expression, two columns per packed-fp32 operand
+template <int CPL>
+__device__ __forceinline__ void mw_row_costs(float ax, float ay, float az, const jv_f2 (&tcx)[CPL / 2], const jv_f2 (&tcy)[CPL / 2],
+                                             const jv_f2 (&tcz)[CPL / 2], float (&rc)[CPL]) {
+    const jv_f2 ax2 = {ax, ax}, ay2 = {ay, ay}, az2 = {az, az};
+#pragma unroll
+    for (int k = 0; k < CPL / 2; ++k) {
+        const jv_f2 dx = ax2 - tcx[k], dy = ay2 - tcy[k], dz = az2 - tcz[k];
+        const jv_f2 sq = (dx * dx + dy * dy) + dz * dz;
+        rc[2 * k] = sqrtf(sq.x); rc[2 * k + 1] = sqrtf(sq.y);
+    }
+}
+
+// Column j = 64 k + lane is slot k of lane `lane` in every wave.
+template <int CPL>
+__global__ __launch_bounds__(64 * MW_NW) void lap_jvmw_kernel(JvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lsm[];
+    constexpr int BS = 64 * MW_NW;
+    const int n = a.n, b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    double *price = (double *)lsm;                                      // [n]
+    int *owner = (int *)(price + n);                                    // [n] column -> row
+    int *assigned = owner + n;                                          // [n] row -> column
+    int *flist = assigned + n;                                          // [n] free rows
+    int *next = flist + n;                                              // [n] rows left for the path search
+    float *psx = (float *)(next + n), *psy = psx + n, *psz = psy + n;   // source points
+    float *ptx = psz + n, *pty = ptx + n, *ptz = pty + n;               // target points (wave-uniform reads of one column)
+    __shared__ MwShared sh;
+    __shared__ double s_red[MW_NW];
+    __shared__ int s_cw[MW_NW];
+    const bool race = a.done != nullptr;
+    const int racer = race ? (int)blockIdx.y : 0;
+    [[maybe_unused]] const unsigned long long tp0_ = MWP_NOW();
+    auto lost = [&]() -> int { return __hip_atomic_load(a.done + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+
+    // ---- the problem into LDS / registers
+    double mx;
+    {
+        float lo = INFINITY, hi = -INFINITY;
+        const float *S_ = a.src + (size_t)b * n * 3, *T_ = a.tgt + (size_t)b * n * 3;
+        for (int e = tid; e < 3 * n; e += BS) {
+            const float sv = S_[e], tv = T_[e];
+            (e % 3 == 0 ? psx : (e % 3 == 1 ? psy : psz))[e / 3] = sv;
+            (e % 3 == 0 ? ptx : (e % 3 == 1 ? pty : ptz))[e / 3] = tv;
+            lo = fminf(lo, fminf(sv, tv)); hi = fmaxf(hi, fmaxf(sv, tv));
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o, 64)); hi = fmaxf(hi, __shfl_xor(hi, o, 64)); }
+        mx = 1.7320508 * (double)(hi - lo);      // the scale of the costs (the tolerances are fractions of it), as lap_jv_kernel's
+    }
+    if (lane == 0) s_red[wv] = mx;
+    for (int j = tid; j < n; j += BS) {
+        price[j] = race ? a.price_start[(size_t)b * n + j] : (a.price_in ? a.price_in[(size_t)b * n + j] : 0.0);
+        owner[j] = -1;
+        const int c = (race ? a.col_start : a.col4row)[(size_t)b * n + j];
+        assigned[j] = (c >= 0 && c < n) ? c : -1;
+        next[j] = 0x7fffffff;
+    }
+    if (tid == 0) { sh.lock = 0; sh.qhead = 0; sh.nnext = 0; sh.abort_ = 0; sh.flag = 0; sh.unsolved = 0; sh.steps = 0; sh.arr = 0; sh.conflicts = 0; }
+    __syncthreads();
+    mx = 0.0;
+    for (int w = 0; w < MW_NW; ++w) mx = fmax(mx, s_red[w]);
+    if (!(mx > 0.0)) mx = 1.0;
+    const double keep_tol = mx * a.keep_tol;
+    jv_f2 tcx[CPL / 2], tcy[CPL / 2], tcz[CPL / 2];
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+        const int j = 64 * k + lane < n ? 64 * k + lane : 0;
+        tcx[k >> 1][k & 1] = ptx[j]; tcy[k >> 1][k & 1] = pty[j]; tcz[k >> 1][k & 1] = ptz[j];
+    }
+    // previous pairs: a repeated column keeps its lowest row
+    for (int i = tid; i < n; i += BS)
+        if (assigned[i] >= 0) atomicMin((unsigned int *)&owner[assigned[i]], (unsigned int)i);   // -1 = 0xffffffff: empty
+    __syncthreads();
+    for (int i = tid; i < n; i += BS)
+        if (assigned[i] >= 0 && owner[assigned[i]] != i) assigned[i] = -1;
+    __syncthreads();
+    // pairs that lost their arg-min under the old prices are released (row minima from lap_jv_pass_kernel); a kept pair counts
+    // as tight: a row's potential is never stored here, it IS c_i,s(i) + p_s(i)
+    for (int i = tid; i < n; i += BS) {
+        const int j = assigned[i];
+        flist[i] = a.pre_j1[(size_t)b * n + i];
+        if (j >= 0 && a.pre_cur[(size_t)b * n + i] - a.pre_v1[(size_t)b * n + i] > keep_tol) { assigned[i] = -1; owner[j] = -1; }
+    }
+    __syncthreads();
+    // greedy: a free row takes its arg-min column when nobody owns it (lowest row wins)
+    for (int i = tid; i < n; i += BS)
+        if (assigned[i] < 0) { atomicAdd(&sh.flag, 1); if (owner[flist[i]] < 0) atomicMin(&next[flist[i]], i); }
+    __syncthreads();
+    const int st_freed = sh.flag;
+    for (int i = tid; i < n; i += BS)
+        if (assigned[i] < 0 && owner[flist[i]] < 0 && next[flist[i]] == i) assigned[i] = flist[i];
+    __syncthreads();
+    for (int i = tid; i < n; i += BS)
+        if (assigned[i] >= 0) owner[assigned[i]] = i;
+    if (tid == 0) sh.flag = 0;
+    __syncthreads();
+    // the rows still free, ascending
+    for (int i0 = 0; i0 < n; i0 += BS) {
+        const int i = i0 + tid;
+        const bool fr = i < n && assigned[i] < 0;
+        const unsigned long long m = __ballot(fr);
+        if (lane == 0) s_cw[wv] = __builtin_popcountll(m);
+        __syncthreads();
+        int off = sh.flag;
+        for (int w = 0; w < wv; ++w) off += s_cw[w];
+        if (fr) flist[off + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = i;
+        __syncthreads();
+        if (tid == 0) { int t = 0; for (int w = 0; w < MW_NW; ++w) t += s_cw[w]; sh.flag += t; }
+        __syncthreads();
+    }
+    const int nfree = sh.flag;
+    if (tid == 0) sh.budget = JV_ARR_BUDGET * nfree + 64;
+    __syncthreads();
+
+    int my_steps = 0, my_arr = 0, my_conf = 0;
+    [[maybe_unused]] unsigned long long tp_ = MWP_NOW();
+    if (wv == 0) MWP_ADD(0, tp_ - tp0_);
+    // ---- augmenting row reduction, one chain per wave: the row takes its cheapest column and pays the gap to its second
+    // cheapest (the pair is tight, every other constraint still holds), the row it displaces goes on in the same wave
+    for (bool go = true; go;) {
+        int q = 0;
+        if (lane == 0) q = atomicAdd(&sh.qhead, 1);
+        q = mw_uniform(q);
+        if (q >= nfree) break;
+        int i = flist[jv_order(q, nfree, racer)];
+        for (;;) {
+            if (mw_flag(&sh.abort_)) { go = false; break; }
+            const float ax = psx[i], ay = psy[i], az = psz[i];
+            float rc[CPL];
+            mw_row_costs<CPL>(ax, ay, az, tcx, tcy, tcz, rc);
+            double v1 = INFINITY, v2 = INFINITY;
+            int j1 = 0x7fffffff, pay = 0;
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) {
+                const int j = 64 * k + lane;
+                lap_top2_push((double)rc[k] + (j < n ? price[j] : INFINITY), j, v1, j1, v2);
+            }
+            lap_wave_top2_fast(v1, j1, v2, pay);
+            if (!(v1 < INFINITY)) { if (lane == 0) sh.unsolved = 1; go = false; break; }       // non-finite costs
+            // what the decision rests on: the arg-min column's price and owner (wave-uniform reads)
+            const double pj1 = price[j1];
+            const int own = owner[j1];
+            const bool consistent = (double)sqrtf(reart_sqdist3(ax, ay, az, ptx[j1], pty[j1], ptz[j1])) + pj1 == v1;
+            const bool tie = !(v1 < v2);
+            int bud = 0;
+            if (lane == 0) bud = atomicSub(&sh.budget, 1);
+            bud = mw_uniform(bud);
+            if (bud <= 0 || (tie && own >= 0)) {                // out of budget / an exact tie on an owned column: path search
+                if (lane == 0) next[atomicAdd(&sh.nnext, 1)] = i;
+                break;
+            }
+            { [[maybe_unused]] const unsigned long long tl_ = MWP_NOW(); mw_lock(&sh.lock); MWP_ADD(5, MWP_NOW() - tl_); }
+            const bool ok = consistent && price[j1] == pj1 && owner[j1] == own;
+            if (ok && lane == 0) {
+                if (!tie) price[j1] = pj1 + (v2 - v1);
+                owner[j1] = i; assigned[i] = j1;
+                if (own >= 0) assigned[own] = -1;
+            }
+            mw_unlock(&sh.lock);
+            if (!ok) { ++my_conf; continue; }
+            ++my_arr;
+            if (race && (my_arr & (MW_CHECK - 1)) == 0 && lane == 0 && lost()) sh.abort_ = 1;
+            if (own < 0) break;
+            i = own;
+        }
+    }
+    MWP_ADD(3, MWP_NOW() - tp_);
+    __syncthreads();
+    if (wv == 0) MWP_ADD(1, MWP_NOW() - tp_);
+    tp_ = MWP_NOW();
+    const int nleft = sh.nnext;
+    if (tid == 0) sh.qhead = 0;
+    __syncthreads();
+
+    // ---- one shortest augmenting path per remaining row, the whole workgroup on one search (thread t owns the columns
+    // t, t + BS, ...: labels, predecessors and prices in registers; a step is one workgroup arg-min + ONE barrier).  Searches
+    // per wave were built and measured first (profiles/r04_lap_per_wave_search_variant.hip.txt): the row reduction's chains
+    // are independent, the searches are not -- 5 % of them label > 500 of the 1024 columns and hold 45 % of all steps, any
+    // commit elsewhere invalidates them, and a wave alone takes 1.7 us per step.
+    constexpr int CPT = CPL >= MW_NW ? CPL / MW_NW : 1;   // n <= 64 CPL <= BS * CPT
+    static_assert(CPT >= 1, "a thread owns at least one column");
+    float qx[CPT], qy[CPT], qz[CPT];
+    double pj[CPT];
+    unsigned deadq = 0u;
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+        const int j = tid + k * BS;
+        const int jj = j < n ? j : 0;
+        qx[k] = ptx[jj]; qy[k] = pty[jj]; qz[k] = ptz[jj];
+        pj[k] = j < n ? price[j] : INFINITY;
+        if (j >= n) deadq |= 1u << k;
+    }
+    int *cpred = flist;                                   // the free-row list is spent: column -> row it was reached from
+    // (Also measured: rounds that settle several columns -- every wave's closest column a candidate, candidates relaxed from
+    // ahead of their turn, the sorted ready prefix settled together, profiles/r04_lap_speculative_rounds_variant.hip.txt.
+    // Exact, 1.6 columns per round, but a round cost 2.6 us against 1.27 us per step: the step is bound by the instructions
+    // its waves issue -- 35 per column and relaxation, the correctly rounded square root among them --, not by latencies
+    // that extra relaxations could hide.)
+    __shared__ double s_rv[2][MW_NW];
+    __shared__ int s_rj[2][MW_NW], s_lostp[2];
+    if (tid == 0) { s_lostp[0] = 0; s_lostp[1] = 0; }
+    bool aborted = mw_flag(&sh.abort_) != 0, unsolved = mw_flag(&sh.unsolved) != 0;     // uniform: read after the barrier
+    for (int f = 0; f < nleft && !aborted && !unsolved; ++f) {
+        const int i0 = next[jv_order(f, nleft, racer)];
+        double d[CPT];
+        unsigned scanned = deadq, freecol = 0u;
+        {
+            const float ax = psx[i0], ay = psy[i0], az = psz[i0];
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) {
+                const int j = tid + k * BS;
+                d[k] = (double)sqrtf(reart_sqdist3(ax, ay, az, qx[k], qy[k], qz[k])) + pj[k];       // labels up to the row's potential
+                if (j < n) { cpred[j] = i0; if (owner[j] < 0) freecol |= 1u << k; }
+            }
+        }
+        double mu = 0.0;
+        int sink = -1;
+        for (int it = 0; ; ++it) {
+            double bv = INFINITY;
+            int bj = 0x7fffffff;
+#pragma unroll
+            for (int k = 0; k < CPT; ++k)
+                if (!((scanned >> k) & 1u)) {
+                    const int key = (tid + k * BS) | (((freecol >> k) & 1u) ? 0 : JV_OWNED);       // unowned columns first among ties
+                    if (d[k] < bv || (d[k] == bv && key < bj)) { bv = d[k]; bj = key; }
+                }
+            lap_wave_argmin_fast(bv, bj);
+            const int par = it & 1;
+            if (lane == 0) { s_rv[par][wv] = bv; s_rj[par][wv] = bj; }
+            if (race && tid == 0) s_lostp[par] = (it & (MW_CHECK - 1)) == 0 ? lost() : s_lostp[par ^ 1];
+            __syncthreads();
+            if (race && s_lostp[par]) { aborted = true; break; }            // uniform: everybody reads the step's slot
+            bv = lane < MW_NW ? s_rv[par][lane] : INFINITY; bj = lane < MW_NW ? s_rj[par][lane] : 0x7fffffff;
+            lap_lanes_argmin<(MW_NW <= 2 ? 1 : (MW_NW <= 4 ? 2 : (MW_NW <= 8 ? 3 : 4)))>(bv, bj);
+            ++my_steps;
+            mu = bv;
+            if (bj == 0x7fffffff || !(bv < INFINITY)) { unsolved = true; break; }          // non-finite costs only
+            const int jstar = bj & ~JV_OWNED;
+            if ((jstar & (BS - 1)) == tid) scanned |= 1u << (jstar / BS);
+            const int i = owner[jstar];
+            if (i < 0) { sink = jstar; break; }
+            const float ax = psx[i], ay = psy[i], az = psz[i];
+            // row i's potential is the cost of its own pair (tight by construction)
+            const double h = (double)sqrtf(reart_sqdist3(ax, ay, az, ptx[jstar], pty[jstar], ptz[jstar])) + price[jstar];
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) {
+                const double nd = mu + (((double)sqrtf(reart_sqdist3(ax, ay, az, qx[k], qy[k], qz[k])) + pj[k]) - h);
+                const bool better = !((scanned >> k) & 1u) && nd < d[k];
+                d[k] = better ? nd : d[k];
+                if (better) cpred[tid + k * BS] = i;
+            }
+        }
+        if (aborted || unsolved) break;
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            const int j = tid + k * BS;
+            if ((((scanned & ~deadq) >> k) & 1u) && j != sink) { pj[k] += mu - d[k]; price[j] = pj[k]; }
+        }
+        __syncthreads();
+        if (tid == 0) {                                    // flip the path
+            int j = sink;
+            for (;;) {
+                const int i = cpred[j];
+                const int jn = assigned[i];
+                assigned[i] = j; owner[j] = i;
+                if (i == i0) break;
+                j = jn;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0 && aborted) sh.abort_ = 1;
+    if (tid == 0 && unsolved) sh.unsolved = 1;
+    if (wv != 0) my_steps = 0;                             // every wave counted the same steps
+    MWP_ADD(4, MWP_NOW() - tp_);
+    if (lane == 0) { atomicAdd(&sh.steps, my_steps); atomicAdd(&sh.arr, my_arr); atomicAdd(&sh.conflicts, my_conf); }
+    __syncthreads();
+    if (wv == 0) MWP_ADD(2, MWP_NOW() - tp_);
+    if (mw_flag(&sh.abort_)) return;                    // uniform after the barrier: another racer has published
+    if (race) {
+        if (tid == 0) sh.flag = atomicCAS(a.done + b, 0, racer + 1) == 0;
+        __syncthreads();
+        if (!sh.flag) return;
+    }
+    const bool solved = !sh.unsolved;
+    for (int i = tid; i < n; i += BS) a.col4row[(size_t)b * n + i] = assigned[i];
+    if (a.price_out)
+        for (int j = tid; j < n; j += BS) a.price_out[(size_t)b * n + j] = price[j];
+    if (tid == 0) {
+        a.certified[b] = solved ? 2 : 0;                // 2 = pending: the certificate launches follow
+        a.scale[b] = mx; a.cert_bad[b] = 0;
+        if (a.stats) {
+            int *o = a.stats + 4 * b;
+            o[0] = st_freed + (racer << 16); o[1] = nleft | (sh.conflicts << 16); o[2] = sh.steps; o[3] = 1 + (sh.arr << 8);
+        }
+    }
+}
+
+int reart_internal_jvmw_nmax() { return 64 * 16; }
+
+template <int CPL>
+static int mw_launch(const JvArgs &a, int racers, hipStream_t stream) {
+    const size_t lds = (size_t)a.n * (8 + 4 * 4 + 6 * 4);
+    if (lds > REART_LDS_DEFAULT_CAP &&
+        hipFuncSetAttribute((const void *)lap_jvmw_kernel<CPL>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)
+        return REART_ERR_LAUNCH;
+    hipLaunchKernelGGL((lap_jvmw_kernel<CPL>), dim3(a.B, racers), dim3(64 * MW_NW), lds, stream, a);
+    REART_CHECK_LAUNCH();
+    return REART_OK;
+}
+
+int reart_internal_jvmw_launch(const JvArgs &a, int racers, hipStream_t stream) {
+    if (a.n < 1 || a.n > reart_internal_jvmw_nmax() || !a.src || !a.tgt || !a.pre_v1) return REART_ERR_UNSUPPORTED;
+    if (a.n <= 512) return mw_launch<8>(a, racers, stream);
+    return mw_launch<16>(a, racers, stream);
+}

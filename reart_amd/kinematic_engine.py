@@ -72,7 +72,7 @@ class KinematicEngine:
         self.tgt_pts = index_points(self.pc_list, tgt_idx).contiguous()                                         # [B,n,3]
         self.matched = None
         self.lap_state = {}
-        self.lap_solves = 0
+        self.lap_solves = self.lap_fallbacks = 0
         self.lap_events = None
         self.lap_stats = None
         self.lap_winners = np.zeros(16, np.int64)
@@ -172,13 +172,14 @@ class KinematicEngine:
             if self.lap_events is not None:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 ev[0].record()
-            assign, _, self.lap_stats = linear_sum_assignment_points(pc_src, self.tgt_pts, self.lap_state, return_stats="full")
+            assign, fb, self.lap_stats = linear_sum_assignment_points(pc_src, self.tgt_pts, self.lap_state, return_stats="full")
             self.lap_solves += 1
+            self.lap_fallbacks += fb
             # sequential steps of this solve (path search + row reduction) per problem: slowest problem, mean -- the
             # latency roofline of bench.py multiplies them by the measured floor of one step
             seq = self.lap_stats[:, 2].astype(np.int64) + (self.lap_stats[:, 3].astype(np.int64) >> 8)
             self.lap_steps_log.append((int(seq.max()), float(seq.mean())))
-            self.lap_winners += np.bincount(self.lap_stats[:, 0] >> 16, minlength=16)[:16]         # raced re-solves: who finished first
+            self.lap_winners += np.bincount((self.lap_stats[:, 0] >> 16) & 15, minlength=16)[:16]         # raced re-solves: who finished first
             cols = torch.from_numpy(np.stack([c for _, c in assign])).to(self.dev)
             self.matched = self.tgt_pts.gather(1, cols[..., None].expand(-1, -1, 3))
             if self.lap_events is not None:

@@ -83,6 +83,78 @@ def flow_references(args, sample, device, seq_path=None):
             [complete[i + 1][t] - complete[i][s] for i, (s, t) in enumerate(zip(src_list, tgt_list))])
 
 
+class AssignmentPhase:
+    """The base model's assignment-loss phase (run_robot.py:164-187) on the fused ``RelaxEngine``.  Every ``assign_gap``
+    iterations: forward of the coming iteration (``peek_forward``: the temperature and noise the step will use) -> the sampled
+    source points (FPS of the canonical cloud, run_robot.py:167) -> optimal assignment to the sampled target points
+    (``cdist`` + ``linear_sum_assignment`` in the reference, :170-176) -> the pairs go to the engine, which then runs the
+    iterations up to the next refresh from a captured graph without touching the host.
+    Both FPS calls of the reference sample fixed clouds from a fixed start (its CUDA FPS starts at index 0): computed once.
+    The first refresh is a cold solve (raced auction + exact certificate); every later one re-solves from the previous
+    optimum and potentials (``linear_sum_assignment_points``: shortest augmenting paths, the row reduction one chain per
+    wave, costs recomputed from the points, same certificate).  ``fallbacks`` counts matrices that went to the host solver."""
+
+    def __init__(self, eng, cano_pc, pc_list, downsample, assign_gap, lambda_assign):
+        self.eng, self.gap, self.lam = eng, int(assign_gap), float(lambda_assign)
+        device = cano_pc.device
+        self.B, N = pc_list.shape[0], pc_list.shape[1]
+        self.n = N // downsample
+        zero = torch.zeros(1, dtype=torch.long, device=device)
+        self.src_idx = farthest_point_sample(cano_pc[None], self.n, start=zero, cuda_mode=True)                      # [1, n]
+        self.tgt_idx = farthest_point_sample(pc_list, self.n, start=zero.expand(self.B), cuda_mode=True)             # [B, n]
+        self.tgt_pts = index_points(pc_list, self.tgt_idx).contiguous()
+        self.lap_state = {}
+        self.refreshes = self.fallbacks = 0
+        self.events = None          # set to [] to collect a (start, end) torch.cuda.Event pair around every solve
+        self._have = False
+
+    def refresh(self):
+        from reart_amd.utils.lap import linear_sum_assignment_points
+
+        eng = self.eng
+        eng.peek_forward()
+        src_pts = index_points(eng.pc_trans, self.src_idx.expand(self.B, self.n)).contiguous()
+        if self.events is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        cols, fb = linear_sum_assignment_points(src_pts, self.tgt_pts, self.lap_state, device_cols=True)
+        if self.events is not None:
+            ev[1].record()
+            self.events.append(ev)
+        self.fallbacks += fb
+        self.refreshes += 1
+        first = not eng.cfg.use_assign
+        eng.set_assignment(self.src_idx[0], self.tgt_idx.gather(1, cols), self.lam)
+        self._have = True
+        return first
+
+    def run(self, i, n_iter, snapshot_gap=0, on_snapshot=None):
+        """Iterations i .. n_iter-1 -> n_iter.  ``on_snapshot(k)`` after iteration k-1 whenever k % snapshot_gap == 0 or k == n_iter."""
+        eng = self.eng
+        while i < n_iter:
+            if not self._have or i % self.gap == 0:
+                if self.refresh() and n_iter - i > 1:
+                    # the engine's mode changed (its graph was dropped): one eager iteration, then a graph of the iterations
+                    # between two refreshes
+                    i += eng.capture(steps_per_graph=max(1, self.gap - 1)) if self.gap > 1 else 0
+            nxt = (i // self.gap + 1) * self.gap                                       # next refresh
+            snap = (i // snapshot_gap + 1) * snapshot_gap if snapshot_gap else n_iter
+            chunk = max(1, min(nxt, snap, n_iter) - i)
+            eng.step(chunk)
+            i += chunk
+            if on_snapshot is not None and (i == n_iter or (snapshot_gap and i % snapshot_gap == 0)):
+                on_snapshot(i)
+        return i
+
+    def report(self):
+        out = {"assign_refreshes": self.refreshes, "lap_fallbacks": self.fallbacks}
+        if self.events:
+            torch.cuda.synchronize()
+            ms = [a.elapsed_time(b) for a, b in self.events]
+            out.update(ms_per_solve=sum(ms[1:]) / max(len(ms) - 1, 1), first_solve_ms=ms[0])
+        return out
+
+
 class OperatorLoop:
     """The reference's loop body (run_robot.py:154-221) over the HIP operators with PyTorch autograd and
     ``torch.optim.Adam``: the path of ``--model kinematic`` (and of a base model outside the fused engine).
@@ -107,7 +179,7 @@ class OperatorLoop:
         # the kinematic model moves the cost matrices smoothly: the previous solve's pairs and potentials start the next
         # (shortest augmenting paths, reart_lap_resolve); the base model's resampled labels make them jump: cold solves
         self.lap_state = {} if args.model == "kinematic" else None
-        self.lap_solves = 0
+        self.lap_solves = self.lap_fallbacks = 0
         self.lap_events = None      # set to [] to collect a (start, end) torch.cuda.Event pair around every re-solve
         if args.use_assign_loss:
             # run_robot.py:167-169: both FPS calls sample fixed clouds (start 0 on the reference's CUDA path): once
@@ -133,14 +205,16 @@ class OperatorLoop:
                     ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                     ev[0].record()
                 if self.lap_state is not None:      # slowly moving problems: re-solve from the previous optimum
-                    assign, _, self.lap_stats = linear_sum_assignment_points(pc_src.detach(), self.tgt_pts, self.lap_state,
-                                                                             return_stats="full")
+                    assign, fb, self.lap_stats = linear_sum_assignment_points(pc_src.detach(), self.tgt_pts, self.lap_state,
+                                                                              return_stats="full")
                 else:
-                    assign = linear_sum_assignment_batch(cdist(pc_src.detach(), self.tgt_pts), points=(pc_src.detach(), self.tgt_pts), race=True)
+                    assign, fb = linear_sum_assignment_batch(cdist(pc_src.detach(), self.tgt_pts), points=(pc_src.detach(), self.tgt_pts),
+                                                             race=True, return_stats=True)
                 if self.lap_events is not None:
                     ev[1].record()
                     self.lap_events.append(ev)
                 self.lap_solves += 1
+                self.lap_fallbacks += fb
                 cols = torch.from_numpy(np.stack([c for _, c in assign])).to(cano_pc.device)    # rows are 0..n-1 in order
                 self.matched = self.tgt_pts.gather(1, cols[..., None].expand(-1, -1, 3))
             ass = args.lambda_assign * ((pc_src - self.matched) ** 2).sum(-1).sum()
@@ -272,6 +346,7 @@ def main(args):
 
     n_iter = 1 if args.evaluate else args.n_iter
     i = 0
+    lap_report = None       # assignment problems solved in the loop / how many of them went to the host solver
     # ---- phase 1: fused engine (base model, Chamfer [+ flow]) until the assignment loss takes over
     fused_until = n_iter if not args.use_assign_loss else min(args.assign_iter, n_iter)
     if args.model == "base" and not args.evaluate:
@@ -287,46 +362,17 @@ def main(args):
             i += chunk
             row = eng.last_losses().cpu().numpy()
             snapshot(i - 1, {"recon Loss": row[0], "flow Loss": row[1], "total Loss": row[2]})
-        # ---- phase 2 (base model): assignment loss on the same engine (run_robot.py:164-187).  Every
-        # assign_gap iterations: forward of the coming iteration -> FPS of both sides -> Euclidean cost matrices ->
-        # linear assignment (GPU auction + exact certificate) -> the pairs go to the engine, which then runs
-        # the iterations up to the next refresh without touching the host.
+        # ---- phase 2 (base model): assignment loss on the same engine (run_robot.py:164-187)
         if i < n_iter and args.use_assign_loss:
-            from reart_amd.utils.lap import linear_sum_assignment_batch
+            phase = AssignmentPhase(eng, cano_pc, pc_list, args.downsample, args.assign_gap, args.lambda_assign)
 
-            from reart_amd.utils.lap import cdist
+            def on_snapshot(k):
+                row = eng.last_losses().cpu().numpy()
+                snapshot(k - 1, {"opt assignment loss": row[0], "flow Loss": row[1], "total Loss": row[2]})
 
-            have = False
-            B_, N_ = pc_list.shape[0], pc_list.shape[1]
-            num_fps = N_ // args.downsample
-            # Both FPS calls of run_robot.py:167-169 sample fixed clouds; the reference's CUDA FPS starts at index 0, so
-            # they return the same indices at every refresh: computed once.
-            zero = torch.zeros(1, dtype=torch.long, device=device)
-            src_idx = farthest_point_sample(cano_pc[None], num_fps, start=zero, cuda_mode=True)                  # [1, n]
-            tgt_idx = farthest_point_sample(pc_list, num_fps, start=zero.expand(B_), cuda_mode=True)             # [B, n]
-            tgt_pts = index_points(pc_list, tgt_idx).contiguous()
-            lap_state = {}
-            while i < n_iter:
-                if not have or i % args.assign_gap == 0:
-                    eng.peek_forward()
-                    src_pts = index_points(eng.pc_trans, src_idx.expand(B_, num_fps)).contiguous()
-                    cost = cdist(src_pts, tgt_pts)
-                    # A race on compute units that would idle (reart_lap_auction_race_warm): five epsilon schedules from
-                    # scratch and three racers from the previous refresh's potentials and assignment; the first certified
-                    # one publishes.  (The assignment phase moves the matrices: a plain warm start alone was measured
-                    # SLOWER than a cold solve, 35 vs 27 ms per 19 x 1024^2; in the race a warm racer wins where it can.)
-                    assign = linear_sum_assignment_batch(cost, points=(src_pts, tgt_pts), race="warm", state=lap_state)
-                    cols = torch.from_numpy(np.stack([c for _, c in assign])).to(device)       # rows are 0..n-1
-                    eng.set_assignment(src_idx[0], tgt_idx.gather(1, cols), args.lambda_assign)
-                    have = True
-                nxt = (i // args.assign_gap + 1) * args.assign_gap                              # next refresh
-                snap = (i // args.snapshot_gap + 1) * args.snapshot_gap
-                chunk = max(1, min(nxt, snap, n_iter) - i)
-                eng.step(chunk)
-                i += chunk
-                if i % args.snapshot_gap == 0 or i == n_iter:
-                    row = eng.last_losses().cpu().numpy()
-                    snapshot(i - 1, {"opt assignment loss": row[0], "flow Loss": row[1], "total Loss": row[2]})
+            i = phase.run(i, n_iter, args.snapshot_gap, on_snapshot)
+            lap_report = phase.report()
+            print(f"assignment phase: {lap_report['assign_refreshes']} refreshes, {lap_report['lap_fallbacks']} host fallbacks")
     # ---- phase 2 (kinematic model; base model without the engine): the reference's loop with HIP operators
     if i < n_iter and not args.evaluate:
         loop = make_projection_loop(args, model, cano_pc, pc_list, pc_ref_list, flow_ref_list, tau_func)
@@ -335,14 +381,16 @@ def main(args):
             if i % args.snapshot_gap == 0 or i == n_iter - 1:
                 snapshot(i, losses)
             i += 1
+        if args.use_assign_loss:
+            lap_report = {"assign_refreshes": loop.lap_solves, "lap_fallbacks": loop.lap_fallbacks}
     if args.evaluate:
         snapshot(0, {})
-    finish(args, model, cano_pc, pc_list, sample, save_dir, tau_func(cur_iter=n_iter), dataset)
+    finish(args, model, cano_pc, pc_list, sample, save_dir, tau_func(cur_iter=n_iter), dataset, lap_report)
     print("all done!")
     return model
 
 
-def finish(args, model, cano_pc, pc_list, sample, save_dir, tau, dataset=None):
+def finish(args, model, cano_pc, pc_list, sample, save_dir, tau, dataset=None, lap_report=None):
     """run_robot.py:227-356: structure, energies, result files (the reference's file names and keys)."""
     from reart_amd import tail
     from reart_amd.utils.kinematic_utils import edge_index2edges
@@ -392,6 +440,9 @@ def finish(args, model, cano_pc, pc_list, sample, save_dir, tau, dataset=None):
                 print(f"{k}: {energy[k]:.3f}")
                 f_result.write(f"{k}: {energy[k]:.3f}\n")
             print(f"cd_err: {metrics['cd_err']:.3f}")
+        if lap_report is not None:      # additions: how many assignment problems of the loop went to the host solver (0 = none)
+            for k in ("assign_refreshes", "lap_fallbacks"):
+                f_result.write(f"{k}: {lap_report[k]}\n")
     if args.evaluate:
         return
     save_dict = {"pred_cano_part": seg_part.cpu().numpy(), "pred_pose_list": trans_list.cpu().numpy(),

@@ -157,6 +157,11 @@ POINTS_NMAX = 2048   # reart_lap_resolve_points keeps both point sets and the so
 RESOLVE_RACERS = int(os.environ.get("REART_RESOLVE_RACERS", "13"))
 
 
+# one search per wave (reart_lap_resolve_points_mw, csrc/lap_mw.hip) where its waves hold a whole problem in registers
+MW_NMIN, MW_NMAX = 512, 1024
+RESOLVE_PER_WAVE = os.environ.get("REART_RESOLVE_MW", "1") != "0"
+
+
 def _resolve_racers(B, n, race=True):
     """Workgroups per problem of a re-solve: a racer holds a compute unit's LDS, the chip has 256; below 512 columns the
     re-solve is one short launch and is not raced."""
@@ -166,7 +171,7 @@ def _resolve_racers(B, n, race=True):
     return r if r >= 2 else 1
 
 
-def linear_sum_assignment_points(src, tgt, state, return_stats=False, race=True):
+def linear_sum_assignment_points(src, tgt, state, return_stats=False, race=True, per_wave=None, device_cols=False):
     """Optimal assignment for the Euclidean costs ``cdist(src, tgt)`` of two point batches [B,n,3] in a loop that
     re-solves slowly moving problems (the kinematic projection, run_robot.py:165-178 with ``--assign_gap 1``).  ``state`` is
     a dict the caller keeps between calls.  First call (or n > 2048): the cost matrices are built and solved like
@@ -175,15 +180,24 @@ def linear_sum_assignment_points(src, tgt, state, return_stats=False, race=True)
     points inside the kernel (bit-equal to ``cdist``'s values), certificate included.  Same return value.
     ``race`` (default on): idle compute units run the same re-solve with the free rows taken in other orders and the first
     to finish publishes (``reart_lap_resolve_points_race``) -- the same optimum sooner; as with the cold race, the potentials
-    kept in ``state`` are the winner's."""
+    kept in ``state`` are the winner's.
+    ``per_wave`` (default: on for 512 <= n <= 1024): every wave of a problem's workgroup follows its own free row and commits
+    under a lock (``reart_lap_resolve_points_mw``) instead of the whole workgroup following one row at a time: same optimum,
+    timing-dependent potentials (like a race).
+    ``device_cols=True``: returns ``(cols, fallbacks)`` with ``cols`` the [B,n] int64 DEVICE tensor of assigned columns (rows
+    are 0..n-1) instead of the host lists -- a loop that feeds the pairs back to the GPU (``RelaxEngine.set_assignment``) then
+    only reads the B certificate flags on the host."""
     _lib.require_gpu(src, tgt)
     src, tgt = src.detach().contiguous().float(), tgt.detach().contiguous().float()
     B, n, _ = src.shape
     warm = (state.get("prices") is not None and state.get("cols") is not None and tuple(state["prices"].shape) == (B, n)
             and tuple(state["cols"].shape) == (B, n) and state["prices"].device == src.device)
     if not warm or n > POINTS_NMAX:
-        return linear_sum_assignment_batch(cdist(src, tgt), return_stats=return_stats, state=state, warm_assignment=True,
-                                           points=(src, tgt), race=True)
+        res = linear_sum_assignment_batch(cdist(src, tgt), return_stats=(return_stats or device_cols), state=state,
+                                          warm_assignment=True, points=(src, tgt), race=True)
+        if device_cols:      # state["cols"] holds the certified (or host-solved) assignment
+            return state["cols"].long(), res[1]
+        return res
     L = _lib.lib()
     col, prices = state["cols"].clone(), state["prices"]
     cert = torch.zeros((B,), dtype=torch.int32, device=src.device)    # defined whatever the kernels write: 0 = solve on the host
@@ -192,7 +206,13 @@ def linear_sum_assignment_points(src, tgt, state, return_stats=False, race=True)
         nb = L.reart_lap_race_workspace_bytes(B, n, racers) if racers > 1 else L.reart_lap_workspace_bytes(B, n)
         off = ((8 * B * n + 255) // 256) * 256
         _lib.workspace(nb, src.device)[off:off + 16 * B].zero_()
-    if racers > 1:
+    if per_wave is None:
+        per_wave = RESOLVE_PER_WAVE
+    if per_wave and MW_NMIN <= n <= MW_NMAX:
+        ws = _lib.workspace(L.reart_lap_race_workspace_bytes(B, n, racers), src.device)
+        rc = L.reart_lap_resolve_points_mw(_lib.ptr(src), _lib.ptr(tgt), B, n, racers, _lib.ptr(col), _lib.ptr(cert),
+                                           _lib.ptr(prices), _lib.ptr(prices), _lib.ptr(ws), ws.numel(), _lib.stream())
+    elif racers > 1:
         ws = _lib.workspace(L.reart_lap_race_workspace_bytes(B, n, racers), src.device)
         rc = L.reart_lap_resolve_points_race(_lib.ptr(src), _lib.ptr(tgt), B, n, racers, _lib.ptr(col), _lib.ptr(cert),
                                              _lib.ptr(prices), _lib.ptr(prices), _lib.ptr(ws), ws.numel(), _lib.stream())
@@ -202,20 +222,27 @@ def linear_sum_assignment_points(src, tgt, state, return_stats=False, race=True)
                                         _lib.ptr(prices), _lib.ptr(ws), ws.numel(), _lib.stream())
     _lib.check(rc, "reart_lap_resolve_points")
     state["cols"] = col
-    col_h, cert_h = col.cpu().numpy().astype(np.int64), cert.cpu().numpy()
+    cert_h = cert.cpu().numpy()
+    col_h = None if device_cols else col.cpu().numpy().astype(np.int64)
     rows = np.arange(n, dtype=np.int64)
     out, fallbacks = [], 0
     for b in range(B):
         if cert_h[b]:
-            out.append((rows, col_h[b]))
+            if not device_cols:
+                out.append((rows, col_h[b]))
         else:  # certificate did not close: exact host solve for this matrix
             from scipy.optimize import linear_sum_assignment
 
             fallbacks += 1
             out.append(linear_sum_assignment(cdist(src[b:b + 1], tgt[b:b + 1])[0].cpu().numpy()))
             _forget_uncertified(state, state["cols"], b, out[-1][1])
+    if device_cols:
+        return state["cols"].long(), fallbacks
     if return_stats == "full":
         off = ((8 * B * n + 255) // 256) * 256
-        st = ws[off:off + 16 * B].view(torch.int32).reshape(B, 4).cpu().numpy()
+        st = ws[off:off + 16 * B].view(torch.int32).reshape(B, 4).cpu().numpy().copy()
+        if per_wave and MW_NMIN <= n <= MW_NMAX:      # the per-wave row reduction reports its redone steps in the upper half
+            state["commit_conflicts"] = st[:, 1] >> 16
+            st[:, 1] &= 0xffff
         return out, fallbacks, st
     return (out, fallbacks) if return_stats else out

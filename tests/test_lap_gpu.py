@@ -300,3 +300,38 @@ def test_race_with_warm_racers_over_a_moving_sequence(dev):
             np.testing.assert_array_equal(out[k][1], plain[k][1])
         assert ((stats[:, 0] >> 16) < 16).all()
         a = (a + rng.normal(0, 0.002 if step != 3 else 0.05, a.shape)).astype(np.float32)      # step 3: the problems jump
+
+
+@pytest.mark.parametrize("n,racers", [(1024, None), (600, None), (512, 1), (1024, 1)])
+def test_resolve_per_wave_gives_the_optimum(dev, n, racers):
+    """reart_lap_resolve_points_mw (one search per wave, optimistic commits): a sequence of moved problems, each re-solved
+    from the previous optimum -- smoothly moved, partly scrambled (rows that jump, like the base model's resampled labels),
+    identical -- always the certified optimum scipy returns, never through the host solver."""
+    import oracle
+    from reart_amd.utils import lap
+
+    rng = np.random.default_rng(n)
+    B = 3
+    tgt = rng.uniform(-0.3, 0.3, (B, n, 3)).astype(np.float32)
+    src = (tgt[:, rng.permutation(n)] + rng.normal(0, 0.01, (B, n, 3))).astype(np.float32)
+    state = {}
+    old = lap.RESOLVE_RACERS
+    try:
+        if racers is not None:
+            lap.RESOLVE_RACERS = racers
+        for k in range(5):
+            if k == 2:                      # a fifth of the rows jump somewhere else
+                jump = rng.permutation(n)[: n // 5]
+                src[:, jump] = rng.uniform(-0.3, 0.3, (B, len(jump), 3)).astype(np.float32)
+            elif k != 4:                    # k == 4: the same problem again
+                src = (src + rng.normal(0, 0.002, src.shape)).astype(np.float32)
+            s, t = torch.from_numpy(src).to(dev), torch.from_numpy(tgt).to(dev)
+            out, fb, st = lap.linear_sum_assignment_points(s, t, state, return_stats="full", per_wave=True)
+            assert fb == 0
+            ref = oracle.linear_sum_assignment(oracle.cdist(src, tgt))
+            for b, (r, c) in enumerate(out):
+                np.testing.assert_array_equal(c, ref[b][1])
+            if k == 4:
+                assert (st[:, 0] & 0xffff).max() == 0       # nothing released: the previous optimum is still one
+    finally:
+        lap.RESOLVE_RACERS = old

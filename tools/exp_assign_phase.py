@@ -41,7 +41,7 @@ def timed(fn):
 
 
 state, jv_state, prev_pts, prev_cols, k = {}, None, None, None, 0
-print("refresh iter | moved>5mm moved>2cm | cols changed | cold ms | warm-race ms | jv re-solve ms (freed left steps) | winners")
+print("refresh iter | moved>5mm moved>2cm | cols changed | cold ms | warm-race ms | jv re-solve ms (freed left steps) | per-wave re-solve | winners")
 while i < n_iter:
     eng.peek_forward()
     src_pts = index_points(eng.pc_trans, src.expand(B, nf)).contiguous()
@@ -50,16 +50,20 @@ while i < n_iter:
     if sample:
         _, t_cold = timed(lambda: linear_sum_assignment_batch(cost, points=(src_pts, tgt_pts), race=True))
         js = {"prices": jv_state["prices"].clone(), "cols": jv_state["cols"].clone()}
-        (a_jv, fb_jv, st_jv), t_jv = timed(lambda: linear_sum_assignment_points(src_pts, tgt_pts, js, return_stats="full"))
+        (a_jv, fb_jv, st_jv), t_jv = timed(lambda: linear_sum_assignment_points(src_pts, tgt_pts, js, return_stats="full", per_wave=False))
+        jm = {"prices": jv_state["prices"].clone(), "cols": jv_state["cols"].clone()}
+        (a_mw, fb_mw, st_mw), t_mw = timed(lambda: linear_sum_assignment_points(src_pts, tgt_pts, jm, return_stats="full", per_wave=True))
     (assign, fb, st), t_warm = timed(lambda: linear_sum_assignment_batch(cost, points=(src_pts, tgt_pts), race="warm", state=state,
                                                                           return_stats="full"))
     cols_np = np.stack([c for _, c in assign])
     if sample:
         d = (src_pts - prev_pts).norm(dim=-1)
-        same = all(np.array_equal(a[1], c) for a, c in zip(a_jv, cols_np))
+        same = all(np.array_equal(a[1], c) for a, c in zip(a_jv, cols_np)) and all(np.array_equal(a[1], c) for a, c in zip(a_mw, cols_np))
         print(f"{k:5d} {i:6d} | {(d > 0.005).sum().item() / B:7.1f} {(d > 0.02).sum().item() / B:7.1f} | "
               f"{(cols_np != prev_cols).sum() / B:7.1f} | {t_cold:7.2f} | {t_warm:7.2f} | {t_jv:7.2f} "
               f"({(st_jv[:, 0] & 0xffff).mean():.0f} {st_jv[:, 1].mean():.0f} {st_jv[:, 2].mean():.0f} max {st_jv[:, 2].max()}) | "
+              f"mw {t_mw:6.2f} (left {st_mw[:, 1].mean():.0f} steps {st_mw[:, 2].mean():.0f} max {st_mw[:, 2].max()} arr {(st_mw[:, 3] >> 8).mean():.0f} "
+              f"conf {jm.get('commit_conflicts', np.zeros(1)).mean():.0f}) fb {fb_mw} | "
               f"{(st[:, 0] >> 16).tolist()} fb {fb} {fb_jv} same {same}", flush=True)
     jv_state = {"prices": state["prices"].clone(), "cols": state["cols"].clone()}
     prev_pts, prev_cols = src_pts, cols_np

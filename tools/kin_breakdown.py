@@ -42,7 +42,7 @@ for i in range(WARM, WARM + 20):
     st = res[2]
     (_, ms) = T_(lambda: loop.iteration(i)); acc["whole iteration (incl. its own lap)"] = acc.get("whole iteration (incl. its own lap)", 0) + ms
     if i % 5 == 0:
-        print("lap stats: released", st[:, 0].mean(), "left for paths", st[:, 1].mean(), "dijkstra steps", st[:, 2].mean(), "max", st[:, 2].max(), "ARR steps", (st[:, 3] >> 8).mean(), "cert", (st[:, 3] & 255).mean())
+        print("lap stats: released", (st[:, 0] & 0xffff).mean(), "left for paths", st[:, 1].mean(), "dijkstra steps", st[:, 2].mean(), "max", st[:, 2].max(), "ARR steps", (st[:, 3] >> 8).mean(), "cert", (st[:, 3] & 255).mean())
 for k, v in acc.items():
     print(f"{k:40s} {v / 20:8.3f} ms")
 

@@ -35,24 +35,16 @@ i = eng.capture(steps_per_graph=10)
 first = assign_iter if use_assign else n_iter
 eng.step(first - i); i = first
 if use_assign:
-    # the assignment phase as reart_amd/run_robot.py runs it: both FPS calls sample fixed clouds (once), the costs come from
-    # reart_cdist, every refresh is a cold solve with five epsilon schedules racing (reart_lap_auction_race)
-    from reart_amd.utils.lap import cdist
-    B, N = pcs.shape[:2]; nf = N // 4
-    src = farthest_point_sample(cano[None], nf); tgt = farthest_point_sample(pcs, nf)
-    tgt_pts = index_points(pcs, tgt).contiguous()
-    t_lap = 0.0; lap_state = {}; race = 'warm' if os.environ.get('LAP_WARM', '1') == '1' else True
-    while i < n_iter:
-        eng.peek_forward()
-        src_pts = index_points(eng.pc_trans, src.expand(B, nf)).contiguous()
-        cost = cdist(src_pts, tgt_pts)
-        torch.cuda.synchronize(); t1 = time.perf_counter()
-        assign = linear_sum_assignment_batch(cost, points=(src_pts, tgt_pts), race=race, state=lap_state if race == 'warm' else None)
-        t_lap += time.perf_counter() - t1
-        cols = torch.from_numpy(np.stack([c for _, c in assign])).to(dev)
-        eng.set_assignment(src[0], tgt.gather(1, cols), 0.3)
-        eng.step(5); i += 5
-    print(f"assignment phase: {(n_iter - first) // 5} refreshes, {t_lap:.2f} s in the solver")
+    # the assignment phase exactly as reart_amd/run_robot.py runs it
+    from reart_amd.run_robot import AssignmentPhase
+    phase = AssignmentPhase(eng, cano, pcs, 4, 5, 0.3)
+    phase.events = []
+    torch.cuda.synchronize(); t1 = time.perf_counter()
+    i = phase.run(i, n_iter)
+    torch.cuda.synchronize(); t_phase = time.perf_counter() - t1
+    rep = phase.report()
+    print(f"assignment phase: {rep['assign_refreshes']} refreshes in {t_phase:.2f} s, {rep['ms_per_solve']:.2f} ms per solve "
+          f"(first {rep['first_solve_ms']:.1f} ms), host fallbacks {rep['lap_fallbacks']}")
 torch.cuda.synchronize(); t_opt = time.perf_counter() - t0
 sample = dict(gt_flow_list=g["gt_flow_list"], gt_cano_part=g["gt_cano_part"], complete_gt_pc_list=g["complete_gt_pc_list"])
 t0 = time.perf_counter()
