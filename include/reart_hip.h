@@ -273,8 +273,10 @@ int reart_relax_step(const reart_relax_config *cfg, const reart_relax_buffers *b
  * arrays of K, workspaces[k] is instance k's workspace (each prepared with reart_relax_prepare).  Each instance
  * computes exactly what reart_relax_step computes for it.  This is how a sweep over canonical frames
  * (/root/reference/README.md:60, run_robot.py: one process per cano_idx) fills the chip: one instance occupies a fraction
- * of the 256 compute units and is a chain of dependent launches.  Default iteration only (box-pruned search,
- * Chamfer + flow loss), 1 <= K <= 6; REART_ERR_UNSUPPORTED / REART_ERR_INVALID_ARG otherwise. */
+ * of the 256 compute units and is a chain of dependent launches.  Box-pruned search paths: Chamfer + flow loss (five
+ * launches), Chamfer only, and the assignment loss with or without flow (run_robot.py:164-192: the pairs in each
+ * instance's assign_map); every instance in the same mode, 1 <= K <= 6; REART_ERR_UNSUPPORTED / REART_ERR_INVALID_ARG
+ * otherwise. */
 int reart_relax_step_batch(const reart_relax_config *cfgs, const reart_relax_buffers *bufs, void *const *workspaces,
                            size_t workspace_bytes, int K, void *stream);
 /* measurement aid: the same sequence with hipEvents between phases on `stream`; synchronises

@@ -26,6 +26,13 @@
 #ifndef MW_NW
 #define MW_NW 8              // waves per workgroup = searches in flight per problem (two per SIMD: 256 VGPRs each)
 #endif
+// row-reduction steps allowed per free row before the rest goes to the path searches.  A chain step here costs a third of a
+// search step (0.4 us against 1.3-1.5 us), so the budget is four times the one-row-at-a-time solver's: measured per refresh of
+// the base recipe (9 x 1024^2, raced), budget 8 / 16 / 32 / 64: 10.5 / 10.1 / 9.7 / 10.7 ms -- rows left 50-100 / 15-55 / 5-25 /
+// 2-13, of which the last few need searches of hundreds of steps whatever the budget.
+#ifndef MW_ARR_BUDGET
+#define MW_ARR_BUDGET 32
+#endif
 #define MW_CHECK 16          // a search looks at the race flag and at its labelled columns every MW_CHECK steps
 
 #ifdef REART_PRUNE_PHASE   // diagnostic build only (make -C reart_amd/csrc phase; tools/exp_mw.py)
@@ -180,7 +187,7 @@ __global__ __launch_bounds__(64 * MW_NW) void lap_jvmw_kernel(JvArgs a) {
         __syncthreads();
     }
     const int nfree = sh.flag;
-    if (tid == 0) sh.budget = JV_ARR_BUDGET * nfree + 64;
+    if (tid == 0) sh.budget = MW_ARR_BUDGET * nfree + 64;
     __syncthreads();
 
     int my_steps = 0, my_arr = 0, my_conf = 0;

@@ -543,6 +543,15 @@ template <bool ONE>
 __global__ __launch_bounds__(FLOW_BS) void flow_blend_kernel(FlowArgs a) {
     flow_blend_body<ONE, FLOW_BS>(a, blockIdx.x, blockIdx.y, gridDim.x);
 }
+// the same consumers for K instances in one launch (reart_relax_step_batch): instance k on the grid's plane z = k
+template <bool ONE>
+__global__ __launch_bounds__(CG_BS) void chamfer_grad_batch_kernel(Batched<CGradArgs> ab) {
+    chamfer_grad_body<ONE>(ab.a[blockIdx.z], blockIdx.x, blockIdx.y, gridDim.x);
+}
+template <bool ONE>
+__global__ __launch_bounds__(FLOW_BS) void flow_blend_batch_kernel(Batched<FlowArgs> ab) {
+    flow_blend_body<ONE, FLOW_BS>(ab.a[blockIdx.z], blockIdx.x, blockIdx.y, gridDim.x);
+}
 // Both consumers of the searches in ONE launch (same reason as knn_pruned_pair_kernel): workgroups
 // [0, nflow) blend the flow of (frame pair, 1024 points), the rest reduce the Chamfer gradient.
 // Launch order of the next search: the items of a launch are dealt in order, so a launch that ends on its
@@ -649,9 +658,9 @@ struct AssignArgs {
     float *G;                // [B,N,3]
     double *loss_part;       // [B][gridDim.x]
 };
-__global__ __launch_bounds__(CG_BS) void assign_grad_kernel(AssignArgs a) {
+__device__ __forceinline__ void assign_grad_body(const AssignArgs &a, int bx, int b, int gx) {
     __shared__ double s_red[CG_BS / REART_WAVE];
-    const int b = blockIdx.y, i = blockIdx.x * CG_BS + threadIdx.x, tid = threadIdx.x;
+    const int i = bx * CG_BS + threadIdx.x, tid = threadIdx.x;
     double term = 0.0;
     if (i < a.N) {
         const size_t o = (size_t)b * a.N + i;
@@ -676,8 +685,12 @@ __global__ __launch_bounds__(CG_BS) void assign_grad_kernel(AssignArgs a) {
     if (tid == 0) {
         double t = 0.0;
         for (int w = 0; w < CG_BS / REART_WAVE; ++w) t += s_red[w];
-        a.loss_part[(size_t)b * gridDim.x + blockIdx.x] = t * (double)a.lambda;
+        a.loss_part[(size_t)b * gx + bx] = t * (double)a.lambda;
     }
+}
+__global__ __launch_bounds__(CG_BS) void assign_grad_kernel(AssignArgs a) { assign_grad_body(a, blockIdx.x, blockIdx.y, gridDim.x); }
+__global__ __launch_bounds__(CG_BS) void assign_grad_batch_kernel(Batched<AssignArgs> ab) {
+    assign_grad_body(ab.a[blockIdx.z], blockIdx.x, blockIdx.y, gridDim.x);
 }
 
 // ------------------------------------------------------------------------------ the step
@@ -688,6 +701,9 @@ __global__ __launch_bounds__(CG_BS) void assign_grad_kernel(AssignArgs a) {
 struct StepLaunch {
     BaseFwdArgs fa; SearchArgs sa; PostArgs pa; int post_blocks;
     BaseBwdArgs ba; FinalizeAdam ad; StepBook bk; void *ws_bwd; size_t bwd_bytes;
+    // the unmerged iterations (Chamfer only; assignment loss [+ flow]): separate consumers after the search
+    int merged, has_search, has_fl, has_aa, has_cg, fgx, fgy, ncg, nB;
+    FlowArgs fl; AssignArgs aa; CGradArgs cg;
 };
 
 static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buffers *bufs,
@@ -767,7 +783,11 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
     const bool chamfer = !c.use_assign;
     // merged: Chamfer + flow on the pruned path -- ONE search launch, ONE consumer launch
     const bool merged = p.pruned && c.use_flow && chamfer;
-    if (collect && !merged) return REART_ERR_UNSUPPORTED;
+    if (collect && !p.pruned) return REART_ERR_UNSUPPORTED;         // the brute-force / grid variants launch as they go
+    if (collect) {
+        collect->merged = merged ? 1 : 0; collect->has_search = collect->has_fl = collect->has_aa = collect->has_cg = 0;
+        collect->nB = B;
+    }
     // Brute-force / grid variants keep their separate launches; with an auxiliary stream from the caller their
     // flow branch runs beside the Chamfer search (fork / join).  The timed variant is always serial.
     const bool forked = !p.pruned && !ev && bufs->aux_stream && bufs->ev_fork && bufs->ev_join && c.use_flow;
@@ -794,7 +814,7 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
             search_static_order = search_wgs != reart_search_grid(sa.n1, sa.n3, sa.G);   // cloud-resident form: fixed order
             if (collect) {
                 if (search_static_order) return REART_ERR_UNSUPPORTED;
-                collect->sa = sa;
+                collect->sa = sa; collect->has_search = 1;
             } else {
                 rc = reart_search_launch(sa, st);
                 if (rc != REART_OK) return rc;
@@ -829,7 +849,10 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
         fl.seed_out = p.pruned ? (int *)(ws + p.o_seed3) : nullptr;
         const dim3 fg(reart_div_up(N, merged ? CG_BS : FLOW_BS), B);
         nfp = fg.x * fg.y;
-        if (!merged) {
+        if (!merged && collect) {
+            if (fl.S > 4) return REART_ERR_UNSUPPORTED;
+            collect->fl = fl; collect->fgx = fg.x; collect->fgy = fg.y; collect->has_fl = 1;
+        } else if (!merged) {
             if (fl.S <= 4) hipLaunchKernelGGL(flow_blend_kernel<true>, fg, dim3(FLOW_BS), 0, fst, fl);
             else hipLaunchKernelGGL(flow_blend_kernel<false>, fg, dim3(FLOW_BS), 0, fst, fl);
             REART_CHECK_LAUNCH();
@@ -844,8 +867,11 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
         AssignArgs aa = {};
         aa.X = bufs->pc_trans; aa.Y = bufs->pc_list; aa.map = bufs->assign_map; aa.N = N; aa.B = B;
         aa.lambda = c.lambda_assign; aa.G = G; aa.loss_part = (double *)(ws + p.o_floss);
-        hipLaunchKernelGGL(assign_grad_kernel, dim3(reart_div_up(N, CG_BS), B), dim3(CG_BS), 0, st, aa);
-        REART_CHECK_LAUNCH();
+        if (collect) { collect->aa = aa; collect->has_aa = 1; }
+        else {
+            hipLaunchKernelGGL(assign_grad_kernel, dim3(reart_div_up(N, CG_BS), B), dim3(CG_BS), 0, st, aa);
+            REART_CHECK_LAUNCH();
+        }
     } else {
         // Chamfer (utils/chamfer.py:78-94) on the brute-force paths.  pc_list never changes: with use_grid the
         // direction pc_trans -> pc_list goes through its pre-built exact grid, and only pc_list -> pc_trans (moving
@@ -899,6 +925,9 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
             }
             if (collect) { collect->pa = pa; collect->post_blocks = nblk; }
             else hipLaunchKernelGGL((post_kernel<true, false>), dim3(nblk), dim3(CG_BS), 0, st, reart_batched(&pa, 1));
+        } else if (collect) {
+            if (cg.S0 > 4 || cg.S1 > 4) return REART_ERR_UNSUPPORTED;
+            collect->cg = cg; collect->ncg = ncg; collect->has_cg = 1;
         } else if (cg.S0 <= 4 && cg.S1 <= 4) hipLaunchKernelGGL(chamfer_grad_kernel<true>, dim3(ncg, B), dim3(CG_BS), 0, st, cg);
         else hipLaunchKernelGGL(chamfer_grad_kernel<false>, dim3(ncg, B), dim3(CG_BS), 0, st, cg);
         REART_CHECK_LAUNCH();
@@ -954,8 +983,9 @@ extern "C" int reart_relax_step(const reart_relax_config *cfg, const reart_relax
 // iteration runs once with K argument blocks, instance k on the grid's row k.  One instance leaves most of the chip idle
 // (64-608 workgroups per launch on 256 compute units, and the iteration is a chain of five dependent launches): a sweep
 // over canonical frames (README.md:60) fills it this way instead of with K streams that the hardware queues interleave
-// as they please.  Each instance computes exactly what reart_relax_step computes for it.  Default iteration only
-// (box-pruned search, Chamfer + flow); K <= 6.
+// as they please.  Each instance computes exactly what reart_relax_step computes for it.  Box-pruned search paths: the
+// merged Chamfer + flow iteration, Chamfer only, and the assignment loss with or without flow (the second phase of the
+// README recipe, run_robot.py:164-192); K <= 6.
 extern "C" int reart_relax_step_batch(const reart_relax_config *cfgs, const reart_relax_buffers *bufs, void *const *workspaces,
                                       size_t workspace_bytes, int K, void *stream) {
     if (!cfgs || !bufs || !workspaces || K < 1 || K > REART_BATCH_MAX) return REART_ERR_INVALID_ARG;
@@ -964,7 +994,13 @@ extern "C" int reart_relax_step_batch(const reart_relax_config *cfgs, const rear
     for (int k = 0; k < K; ++k) {
         const int rc = relax_step_impl(&cfgs[k], &bufs[k], workspaces[k], workspace_bytes, stream, nullptr, false, &L[k]);
         if (rc != REART_OK) return rc;
-        if (L[k].post_blocks != L[0].post_blocks || L[k].bwd_bytes != L[0].bwd_bytes) return REART_ERR_INVALID_ARG;
+        if (L[k].bwd_bytes != L[0].bwd_bytes || L[k].merged != L[0].merged || L[k].has_search != L[0].has_search ||
+            L[k].has_fl != L[0].has_fl || L[k].has_aa != L[0].has_aa || L[k].has_cg != L[0].has_cg || L[k].nB != L[0].nB)
+            return REART_ERR_INVALID_ARG;
+        if (L[0].merged && L[k].post_blocks != L[0].post_blocks) return REART_ERR_INVALID_ARG;
+        if (L[0].has_fl && (L[k].fgx != L[0].fgx || L[k].fgy != L[0].fgy)) return REART_ERR_INVALID_ARG;
+        if (L[0].has_cg && L[k].ncg != L[0].ncg) return REART_ERR_INVALID_ARG;
+        if (L[0].has_aa && L[k].aa.N != L[0].aa.N) return REART_ERR_INVALID_ARG;
     }
     hipStream_t st = (hipStream_t)stream;
     BaseFwdArgs fa[REART_BATCH_MAX];
@@ -987,11 +1023,36 @@ extern "C" int reart_relax_step_batch(const reart_relax_config *cfgs, const rear
     }
     int rc = reart_base_forward_batch(fa, K, st);
     if (rc != REART_OK) return rc;
-    rc = reart_search_launch_batch(sa, K, st);
-    if (rc != REART_OK) return rc;
-    if (K == 1) hipLaunchKernelGGL((post_kernel<true, false>), dim3(L[0].post_blocks), dim3(CG_BS), 0, st, pa);
-    else hipLaunchKernelGGL((post_kernel<true, true>), dim3(L[0].post_blocks, K), dim3(CG_BS), 0, st, pa);
-    REART_CHECK_LAUNCH();
+    if (L[0].has_search) {
+        rc = reart_search_launch_batch(sa, K, st);
+        if (rc != REART_OK) return rc;
+    }
+    if (L[0].merged) {
+        if (K == 1) hipLaunchKernelGGL((post_kernel<true, false>), dim3(L[0].post_blocks), dim3(CG_BS), 0, st, pa);
+        else hipLaunchKernelGGL((post_kernel<true, true>), dim3(L[0].post_blocks, K), dim3(CG_BS), 0, st, pa);
+        REART_CHECK_LAUNCH();
+    } else {
+        // the unmerged iterations: Chamfer only (search + its consumer), assignment loss (the caller's pairs) [+ flow: its
+        // search + consumer] -- the same separate consumers reart_relax_step launches, once for all K instances
+        if (L[0].has_fl) {
+            Batched<FlowArgs> fb = {};
+            for (int k = 0; k < K; ++k) fb.a[k] = L[k].fl;
+            hipLaunchKernelGGL(flow_blend_batch_kernel<true>, dim3(L[0].fgx, L[0].fgy, K), dim3(FLOW_BS), 0, st, fb);
+            REART_CHECK_LAUNCH();
+        }
+        if (L[0].has_aa) {
+            Batched<AssignArgs> ab = {};
+            for (int k = 0; k < K; ++k) ab.a[k] = L[k].aa;
+            hipLaunchKernelGGL(assign_grad_batch_kernel, dim3(reart_div_up(L[0].aa.N, CG_BS), L[0].nB, K), dim3(CG_BS), 0, st, ab);
+            REART_CHECK_LAUNCH();
+        }
+        if (L[0].has_cg) {
+            Batched<CGradArgs> cb = {};
+            for (int k = 0; k < K; ++k) cb.a[k] = L[k].cg;
+            hipLaunchKernelGGL(chamfer_grad_batch_kernel<true>, dim3(L[0].ncg, L[0].nB, K), dim3(CG_BS), 0, st, cb);
+            REART_CHECK_LAUNCH();
+        }
+    }
     return reart_base_backward_batch(ba, ad, bk, wb, L[0].bwd_bytes, K, st);
 }
 

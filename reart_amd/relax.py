@@ -410,8 +410,8 @@ class RelaxBatch:
         self._ws = (c_void_p * K)(*[e.workspace.data_ptr() for e in self.engines])
 
     def _enqueue(self):
-        if any(e.cfg.use_assign for e in self.engines):
-            raise RuntimeError("RelaxBatch steps the default iteration (Chamfer + flow); an engine was switched to the assignment loss")
+        if len({(e.cfg.use_assign, e.cfg.use_flow) for e in self.engines}) != 1:
+            raise RuntimeError("RelaxBatch: the engines must be in the same loss mode (all Chamfer or all assignment loss)")
         self._refresh()
         rc = _lib_fns().reart_relax_step_batch(self._cfgs, self._bufs, self._ws, self._nbytes, len(self.engines), _lib.stream())
         _lib.check(rc, "reart_relax_step_batch")

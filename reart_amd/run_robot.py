@@ -106,6 +106,8 @@ class AssignmentPhase:
         self.lap_state = {}
         self.refreshes = self.fallbacks = 0
         self.events = None          # set to [] to collect a (start, end) torch.cuda.Event pair around every solve
+        self.collect_stats = False  # True: the solver's per-problem statistics of every refresh are read (B x 4 ints) into stats_log
+        self.stats_log = []         # per refresh: (path-search steps of the slowest problem, their mean, mean row-reduction steps)
         self._have = False
 
     def refresh(self):
@@ -117,7 +119,11 @@ class AssignmentPhase:
         if self.events is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        cols, fb = linear_sum_assignment_points(src_pts, self.tgt_pts, self.lap_state, device_cols=True)
+        if self.collect_stats:
+            cols, fb, st = linear_sum_assignment_points(src_pts, self.tgt_pts, self.lap_state, device_cols=True, return_stats="full")
+            self.stats_log.append((int(st[:, 2].max()), float(st[:, 2].mean()), float((st[:, 3] >> 8).mean())))
+        else:
+            cols, fb = linear_sum_assignment_points(src_pts, self.tgt_pts, self.lap_state, device_cols=True)
         if self.events is not None:
             ev[1].record()
             self.events.append(ev)

@@ -40,7 +40,8 @@ def energy_terms(cano_pc, pc_list, seg_part, trans_list, joint_connection, cano_
     screw_err = float(gu.compute_screw_cost(trans_list, joint_connection)) if joint_connection.numel() else 0.0
     complete = torch.cat((pred_pc_list[:cano_idx], cano_pc[None], pred_pc_list[cano_idx:]), dim=0)
     group_err = float(compute_group_temporal_err(complete, seg_part))
-    return dict(ass_err=ass_err, screw_err=screw_err, group_err=group_err, total_err=ass_err + screw_err + group_err)
+    return dict(ass_err=ass_err, screw_err=screw_err, group_err=group_err, total_err=ass_err + screw_err + group_err,
+                lap_fallbacks=getattr(compute_ass_err, "last_fallbacks", 0))     # assignment problems solved on the host: 0 = none
 
 
 def snapshot_metrics(cano_pc, pc_list, seg_part, trans_list, cano_idx, sample=None):

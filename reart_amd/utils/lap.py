@@ -196,7 +196,7 @@ def linear_sum_assignment_points(src, tgt, state, return_stats=False, race=True,
         res = linear_sum_assignment_batch(cdist(src, tgt), return_stats=(return_stats or device_cols), state=state,
                                           warm_assignment=True, points=(src, tgt), race=True)
         if device_cols:      # state["cols"] holds the certified (or host-solved) assignment
-            return state["cols"].long(), res[1]
+            return (state["cols"].long(), res[1], res[2]) if return_stats == "full" else (state["cols"].long(), res[1])
         return res
     L = _lib.lib()
     col, prices = state["cols"].clone(), state["prices"]
@@ -236,7 +236,7 @@ def linear_sum_assignment_points(src, tgt, state, return_stats=False, race=True,
             fallbacks += 1
             out.append(linear_sum_assignment(cdist(src[b:b + 1], tgt[b:b + 1])[0].cpu().numpy()))
             _forget_uncertified(state, state["cols"], b, out[-1][1])
-    if device_cols:
+    if device_cols and return_stats != "full":
         return state["cols"].long(), fallbacks
     if return_stats == "full":
         off = ((8 * B * n + 255) // 256) * 256
@@ -244,5 +244,5 @@ def linear_sum_assignment_points(src, tgt, state, return_stats=False, race=True,
         if per_wave and MW_NMIN <= n <= MW_NMAX:      # the per-wave row reduction reports its redone steps in the upper half
             state["commit_conflicts"] = st[:, 1] >> 16
             st[:, 1] &= 0xffff
-        return out, fallbacks, st
+        return (state["cols"].long() if device_cols else out), fallbacks, st
     return (out, fallbacks) if return_stats else out

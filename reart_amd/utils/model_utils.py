@@ -83,7 +83,9 @@ def compute_ass_err(pc_trans_list, pc_list, use_nproc=True):
     _lib.require_gpu(pc_trans_list, pc_list)
     with torch.no_grad():
         cost = cdist(pc_trans_list, pc_list)
-        cols = torch.from_numpy(np.stack([c for _, c in linear_sum_assignment_batch(cost, points=(pc_trans_list, pc_list), race=True)])).to(pc_list.device)
+        assign, fallbacks = linear_sum_assignment_batch(cost, points=(pc_trans_list, pc_list), race=True, return_stats=True)
+        compute_ass_err.last_fallbacks = int(fallbacks)        # matrices of this call that went to the host solver (0 = none)
+        cols = torch.from_numpy(np.stack([c for _, c in assign])).to(pc_list.device)
         matched = torch.gather(pc_list, 1, cols[..., None].expand(-1, -1, 3))
         return ((pc_trans_list - matched) ** 2).sum(dim=-1).mean()
 

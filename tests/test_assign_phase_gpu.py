@@ -1,0 +1,75 @@
+"""The base model's assignment-loss phase (run_robot.py:164-187) of the README recipe (README.md:116: --use_flow_loss
+--use_assign_loss --downsample 4, assign_gap 5) at the reference's demo size, against an ORACLE-side loop: oracle forward /
+FPS / cdist, scipy's linear_sum_assignment as the reference calls it, the oracle's iteration with those pairs.  Nothing of
+the product is on the checker's side."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def test_base_recipe_assignment_phase_against_the_oracle_loop(oracle, dev):
+    """nao (9 x 4096 points, cano_idx 2) from the reference's shipped base-2 state: 11 iterations of the assignment phase
+    with refreshes at iterations 0, 5 and 10 -- `AssignmentPhase.refresh` (production: in-kernel Gumbel noise, GPU FPS,
+    cold raced auction then per-wave re-solves, device-side pairs) + `RelaxEngine.step`, against RelaxOracle with the
+    exported noise stream.  Sampled indices and the optimal permutations equal, no host fallback, losses 1e-5, clouds 5e-7."""
+    from oracle.step import RelaxOracle, tau_cosine
+    from reart_amd.networks.model import BaseModel
+    from reart_amd.relax import RelaxEngine, gumbel_noise
+    from reart_amd.run_robot import AssignmentPhase
+
+    s, w = np.load(os.path.join(G, "structure.npz")), np.load(os.path.join(G, "base_model.npz"))
+    cano, pcs, c = s["cano"], s["pc_list"], int(s["cano_idx"])
+    B, N, P, ds, gap, lam, n_iter, seed = pcs.shape[0], pcs.shape[1], 20, 4, 5, 0.3, 15000, 5
+    rng = np.random.default_rng(0)
+    sel = [rng.permutation(N)[:3000] for _ in range(B)]
+    refs = [s["complete_gt_pc_list"][f][x] for f, x in enumerate(sel)]
+    flows = [s["gt_flow_list"][f][x] for f, x in enumerate(sel)]
+    orc = RelaxOracle(cano, pcs, w["W1"], w["b1"], w["W2"], w["p6d"], w["pt"], c, refs, flows, n_iter=n_iter)
+    model = BaseModel(num_parts=P, pose_len=B).to(dev)
+    with torch.no_grad():
+        model.seg_head.model[0].weight.copy_(t(w["W1"], dev)[:, :, None])
+        model.seg_head.model[0].bias.copy_(t(w["b1"], dev))
+        model.seg_head.model[2].weight.copy_(t(w["W2"], dev)[:, :, None])
+        model.proposal_6d.copy_(t(w["p6d"], dev))
+        model.proposal_t.copy_(t(w["pt"], dev))
+    eng = RelaxEngine(t(cano, dev), t(pcs, dev), model, c, [t(r, dev) for r in refs], [t(f, dev) for f in flows], n_iter=n_iter, seed=seed)
+    phase = AssignmentPhase(eng, t(cano, dev), t(pcs, dev), ds, gap, lam)
+    n = N // ds
+    # run_robot.py:167-169: both sides sampled by FPS (the CUDA kernel's rules, start 0)
+    src_o = oracle.fps(cano[None], n, start=np.zeros(1, np.int64), cuda_mode=True)[0]
+    tgt_o = oracle.fps(pcs, n, start=np.zeros(B, np.int64), cuda_mode=True)
+    np.testing.assert_array_equal(phase.src_idx.cpu().numpy()[0], src_o)
+    np.testing.assert_array_equal(phase.tgt_idx.cpu().numpy(), tgt_o)
+    tgt_pts_o = np.stack([pcs[b][tgt_o[b]] for b in range(B)])
+    assign = None
+    for i in range(2 * gap + 1):
+        stored = gumbel_noise(seed, i, N, P, dev)                       # the noise the production forward draws for iteration i
+        noise = torch.empty_like(stored)
+        noise[eng._perm] = stored                                        # rows in the caller's point order
+        noise = noise.cpu().numpy()
+        if i % gap == 0:
+            p = orc.params
+            tau = float(np.float32(tau_cosine(orc.it + 1, n_iter, 1.0, 5.0)))
+            X = oracle.base_forward(orc.cano, p["W1"], p["b1"], p["W2"], p["p6d"], p["pt"], noise, tau)["out"]
+            cost = oracle.cdist(np.ascontiguousarray(X[:, src_o]), tgt_pts_o)
+            cols_o = np.stack([cc for _, cc in oracle.linear_sum_assignment(cost)])          # scipy, like the reference
+            assign = (src_o, np.take_along_axis(tgt_o, cols_o, axis=1), lam)
+            phase.refresh()
+            np.testing.assert_array_equal(phase.lap_state["cols"].cpu().numpy(), cols_o, err_msg=f"refresh at iteration {i}")
+            assert phase.fallbacks == 0
+        ref = orc.step(noise, assign=assign)
+        eng.step()
+        row = eng.last_losses().cpu().numpy()
+        assert abs(row[0] - ref["recon"]) <= 1e-5 * abs(ref["recon"]), (i, row, ref["recon"])
+        assert abs(row[1] - ref["flow"]) <= 1e-5 * abs(ref["flow"]) + 1e-9, (i, row, ref["flow"])
+        np.testing.assert_allclose(eng.pc_trans.cpu().numpy(), ref["pc_trans"], rtol=0, atol=5e-7, err_msg=f"iteration {i}")
+    assert phase.refreshes == 3 and phase.fallbacks == 0

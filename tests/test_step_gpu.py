@@ -383,3 +383,61 @@ def test_batched_instances_equal_separate_engines(dev, K):
         assert not np.array_equal(state(*solo[0])[1], state(*solo[1])[1])
     with pytest.raises(ValueError):
         RelaxBatch([])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["chamfer_only", "assign_flow", "assign_only"])
+def test_batched_instances_in_the_unmerged_modes(dev, mode):
+    """reart_relax_step_batch beyond the merged Chamfer + flow iteration: Chamfer only, and the assignment loss (pairs set
+    with set_assignment, refreshed once on the way) with and without the flow loss -- the second phase of the README recipe
+    (run_robot.py:164-192).  Three instances in shared launches, eager and replayed, bit for bit what separate engines leave."""
+    from reart_amd.networks.model import BaseModel
+    from reart_amd.relax import RelaxBatch, RelaxEngine
+    from reart_amd.synthetic import make_sequence, split_canonical
+
+    K, flow = 3, mode == "assign_flow"
+    seq = make_sequence(T=6, n_parts=4, pts_per_part=300, seed=5, n_ref=700, with_flow=True)
+    N = seq["complete"].shape[1]
+    rng = np.random.default_rng(7)
+    pairs = [[(rng.permutation(N)[:256], np.stack([rng.permutation(N)[:256] for _ in range(5)])) for _ in range(2)] for _ in range(K)]
+
+    def build():
+        out = []
+        for k in range(K):
+            cano, pcs = split_canonical(seq["complete"], k)
+            torch.manual_seed(10 + k)
+            model = BaseModel(num_parts=12, pose_len=5).to(dev)
+            refs = ([t(r, dev) for r in seq["ref_loc"]], [t(f, dev) for f in seq["ref_flow"]]) if flow else (None, None)
+            out.append((RelaxEngine(t(cano, dev), t(pcs, dev), model, k, refs[0], refs[1], n_iter=200, seed=100 + k), model))
+        return out
+
+    def assign(engines, r):
+        if mode != "chamfer_only":
+            for k, (e, _) in enumerate(engines):
+                e.set_assignment(torch.from_numpy(pairs[k][r][0]), torch.from_numpy(pairs[k][r][1]), 0.3)
+
+    def state(eng, model):
+        it, log = eng.loss_log()
+        return (log.cpu().numpy(), model.proposal_6d.detach().cpu().numpy().copy(), model.proposal_t.detach().cpu().numpy().copy(),
+                model.seg_head.model[2].weight.detach().cpu().numpy().copy(), eng.pc_trans.cpu().numpy(), eng.seg_part.cpu().numpy())
+
+    solo = build()
+    assign(solo, 0)
+    for e, _ in solo:
+        e.step(8)
+    assign(solo, 1)
+    for e, _ in solo:
+        e.step(9)
+    batched = build()
+    assign(batched, 0)
+    batch = RelaxBatch([e for e, _ in batched])
+    batch.step(8)                        # eager
+    assign(batched, 1)                   # the pairs live in each engine's buffer: a refresh needs no new batch
+    batch.capture(steps_per_graph=4)     # +1 (warm-up)
+    batch.step(8)                        # 2 replays
+    torch.cuda.synchronize()
+    for (e0, m0), (e1, m1) in zip(solo, batched):
+        a, b = state(e0, m0), state(e1, m1)
+        assert np.isfinite(a[0]).all()
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x, y)

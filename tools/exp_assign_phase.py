@@ -13,7 +13,8 @@ from reart_amd.relax import RelaxEngine
 from reart_amd.utils.lap import cdist, linear_sum_assignment_batch, linear_sum_assignment_points
 
 dev = torch.device("cuda:0")
-g = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "structure.npz"))
+from reart_amd.data import load_nao_demo
+g = load_nao_demo()
 t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 cano, pcs, cano_idx = t(g["cano"]), t(g["pc_list"]), int(g["cano_idx"])
 n_iter, assign_iter = int(os.environ.get("ITERS", 15000)), int(os.environ.get("ASSIGN_ITER", 5000))

@@ -13,7 +13,8 @@ from reart_amd.relax import RelaxEngine
 from reart_amd.utils import lap
 
 dev = torch.device("cuda:0")
-g = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "structure.npz"))
+from reart_amd.data import load_nao_demo
+g = load_nao_demo()
 t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 cano, pcs, cano_idx = t(g["cano"]), t(g["pc_list"]), int(g["cano_idx"])
 gt_pos = t(g["complete_gt_pc_list"])

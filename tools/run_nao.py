@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """End-to-end on the reference's demo sequence (nao, 10 frames x 4096 points; clouds and ground truth travel inside
-tests/golden/structure.npz): the reference's base recipe without the flow loss (its extractor weights are not shipped)
+reart_amd/data/nao_demo.npz): the reference's base recipe without the flow loss (its extractor weights are not shipped)
 -- 15 000 iterations, assignment loss after 5 000 -- then structure extraction and the reference's metrics, next to the
 numbers the reference's own shipped base-2 checkpoint gives (same fixture)."""
 import os, sys, time
@@ -13,7 +13,8 @@ from reart_amd.relax import RelaxEngine
 from reart_amd.utils.lap import linear_sum_assignment_batch
 
 dev = torch.device("cuda:0")
-g = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "structure.npz"))
+from reart_amd.data import load_nao_demo
+g = load_nao_demo()
 t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 cano, pcs, cano_idx = t(g["cano"]), t(g["pc_list"]), int(g["cano_idx"])
 n_iter = int(os.environ.get("ITERS", 15000)); assign_iter = int(os.environ.get("ASSIGN_ITER", 5000))
@@ -53,6 +54,7 @@ torch.cuda.synchronize(); t_tail = time.perf_counter() - t0
 keys = ("total_err", "ass_err", "screw_err", "group_err", "cd_err", "epe", "acc5", "acc10", "ri", "recon_err")
 print(f"optimisation {t_opt:.2f} s ({n_iter} iterations), end of run {t_tail:.2f} s; parts {res['trans_list'].shape[1]}, tree {res['joint_connection'].tolist()}")
 print("ours     :", {k: round(float(res[k]), 4) for k in keys})
+g = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "structure.npz"))     # the reference's own numbers
 ref = dict(total_err=100 * float(g["ass_err"]) + float(g["screw_err"]) + float(g["group_err"]), ass_err=100 * float(g["ass_err"]),
            screw_err=float(g["screw_err"]), group_err=float(g["group_err"]), cd_err=float("nan"), epe=100 * float(g["epe"]),
            acc5=float(g["acc5"]), acc10=float(g["acc10"]), ri=float(g["ri"]), recon_err=float(g["recon_err"]))
