@@ -26,6 +26,7 @@ Data: ``--seq_path`` with the reference's pickle layout (``reart_amd.dataset.Seq
 ``--synthetic`` for the generated articulated sequence of ``reart_amd/synthetic.py``.
 """
 import argparse
+import contextlib
 import functools
 import glob
 import os
@@ -108,6 +109,7 @@ class AssignmentPhase:
         self.events = None          # set to [] to collect a (start, end) torch.cuda.Event pair around every solve
         self.collect_stats = False  # True: the solver's per-problem statistics of every refresh are read (B x 4 ints) into stats_log
         self.stats_log = []         # per refresh: (path-search steps of the slowest problem, their mean, mean row-reduction steps)
+        self.capture_guard = None   # a context-manager factory entered around the graph capture (the sweep's _CaptureGate)
         self._have = False
 
     def refresh(self):
@@ -142,7 +144,9 @@ class AssignmentPhase:
                 if self.refresh() and n_iter - i > 1:
                     # the engine's mode changed (its graph was dropped): one eager iteration, then a graph of the iterations
                     # between two refreshes
-                    i += eng.capture(steps_per_graph=max(1, self.gap - 1)) if self.gap > 1 else 0
+                    if self.gap > 1:
+                        with (self.capture_guard() if self.capture_guard else contextlib.nullcontext()):
+                            i += eng.capture(steps_per_graph=self.gap - 1)
             nxt = (i // self.gap + 1) * self.gap                                       # next refresh
             snap = (i // snapshot_gap + 1) * snapshot_gap if snapshot_gap else n_iter
             chunk = max(1, min(nxt, snap, n_iter) - i)
@@ -159,6 +163,57 @@ class AssignmentPhase:
             ms = [a.elapsed_time(b) for a, b in self.events]
             out.update(ms_per_solve=sum(ms[1:]) / max(len(ms) - 1, 1), first_solve_ms=ms[0])
         return out
+
+
+class AssignmentPhaseBatch:
+    """The assignment phase of K instances of one shape that step in shared launches (``RelaxBatch``; the sweep over canonical
+    frames): every refresh gathers the sampled source points of all instances and solves their K x (T-1) assignment problems
+    in ONE call -- one set of launches, every problem its own workgroup(s) --, then hands each instance its pairs; the
+    iterations between refreshes replay one graph for all instances.  Each instance ends exactly as its own
+    ``AssignmentPhase`` would (the optimal assignment does not depend on who else is in the call)."""
+
+    def __init__(self, batch, clouds, downsample, assign_gap, lambda_assign):
+        """clouds: [(cano_pc, pc_list)] per engine of ``batch``, in the caller's point order."""
+        self.batch, self.gap, self.lam = batch, int(assign_gap), float(lambda_assign)
+        self.parts = [AssignmentPhase(e, c, p, downsample, assign_gap, lambda_assign) for e, (c, p) in zip(batch.engines, clouds)]
+        if len({(ph.B, ph.n) for ph in self.parts}) != 1:
+            raise ValueError("AssignmentPhaseBatch: the instances must share one shape")
+        self.B, self.n = self.parts[0].B, self.parts[0].n
+        self.tgt_all = torch.cat([ph.tgt_pts for ph in self.parts], dim=0).contiguous()
+        self.lap_state = {}
+        self.refreshes = self.fallbacks = 0
+        self.capture_guard = None
+        self._have = False
+
+    def refresh(self):
+        from reart_amd.utils.lap import linear_sum_assignment_points
+
+        for ph in self.parts:
+            ph.eng.peek_forward()
+        src_all = torch.cat([index_points(ph.eng.pc_trans, ph.src_idx.expand(self.B, self.n)) for ph in self.parts], dim=0).contiguous()
+        cols, fb = linear_sum_assignment_points(src_all, self.tgt_all, self.lap_state, device_cols=True)
+        self.fallbacks += fb
+        self.refreshes += 1
+        first = not self.parts[0].eng.cfg.use_assign
+        for k, ph in enumerate(self.parts):
+            ph.eng.set_assignment(ph.src_idx[0], ph.tgt_idx.gather(1, cols[k * self.B:(k + 1) * self.B]), self.lam)
+        self._have = True
+        return first
+
+    def run(self, i, n_iter):
+        while i < n_iter:
+            if not self._have or i % self.gap == 0:
+                if self.refresh() and n_iter - i > 1 and self.gap > 1:
+                    with (self.capture_guard() if self.capture_guard else contextlib.nullcontext()):
+                        i += self.batch.capture(steps_per_graph=self.gap - 1)     # one eager iteration, then the graph between refreshes
+            nxt = (i // self.gap + 1) * self.gap
+            chunk = max(1, min(nxt, n_iter) - i)
+            self.batch.step(chunk)
+            i += chunk
+        return i
+
+    def report(self):
+        return {"assign_refreshes": self.refreshes, "lap_fallbacks": self.fallbacks}
 
 
 class OperatorLoop:

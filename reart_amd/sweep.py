@@ -182,7 +182,7 @@ def run_sweep(instances, run_instance, device, policy="round_robin"):
 
 
 def run_sweep_engines(instances, make_engine, n_iter, device, per_gpu=3, chunk=100, energy=False, mode="streams",
-                      overlap_tails=True, on_finish=None, policy="round_robin"):
+                      overlap_tails=True, on_finish=None, policy="round_robin", assign=None):
     """Sweep of fused-loop instances with ``per_gpu`` of them in flight per GPU.
 
     One instance of the relaxation loop is a chain of short, latency-bound launches that leaves
@@ -196,6 +196,10 @@ def run_sweep_engines(instances, make_engine, n_iter, device, per_gpu=3, chunk=1
     results, and an aggregate rate that does not depend on how the runtime maps streams to hardware queues.
     A group whose engines the shared launches cannot take (different shapes or switches, a loss branch the batched entry
     does not implement) falls back to the streams path for that group; it never aborts the sweep.
+    ``assign = dict(assign_iter, assign_gap, downsample, lambda_assign)``: the README recipe's second phase
+    (run_robot.py:164-187, ``--use_assign_loss``) -- after ``assign_iter`` iterations the Chamfer loss gives way to the
+    assignment loss, its pairs refreshed every ``assign_gap`` iterations; a batch group solves the problems of all its
+    instances in one call per refresh (``run_robot.AssignmentPhaseBatch``) and keeps stepping in shared launches.
     ``on_finish(inst, spec, engine, energy dict or None)`` is called once per finished instance (the command line writes
     the instance's result files there).  Returns (records [n, RECORD], best index) like ``run_sweep``."""
     if mode not in ("streams", "batch"):
@@ -253,9 +257,9 @@ def run_sweep_engines(instances, make_engine, n_iter, device, per_gpu=3, chunk=1
                     # capture() runs its first step eagerly: an engine the batched entry does not implement
                     # (REART_ERR_UNSUPPORTED) shows up there, before a capture is open, and the part takes the streams path
                     used = 0
-                    if n_iter > 1:
+                    if first_phase > 1:
                         with gate.capture():
-                            used = batch.capture(steps_per_graph=min(chunk, n_iter - 1))
+                            used = batch.capture(steps_per_graph=min(chunk, first_phase - 1))
                     plan.append((batch, part, used))
                 except Exception as exc:
                     started = {int(e[2].iter.item()) for e in part}
@@ -273,7 +277,7 @@ def run_sweep_engines(instances, make_engine, n_iter, device, per_gpu=3, chunk=1
         for e in solo:
             try:
                 with torch.cuda.stream(e[3]), gate.capture():
-                    e[4] = e[2].capture(steps_per_graph=min(chunk, n_iter))
+                    e[4] = e[2].capture(steps_per_graph=min(chunk, first_phase))
             except Exception as exc:  # a failed capture is this instance's failure (NaN energy), never the sweep's
                 import sys
 
@@ -282,23 +286,45 @@ def run_sweep_engines(instances, make_engine, n_iter, device, per_gpu=3, chunk=1
                 live.remove(e)
         return plan
 
+    first_phase = n_iter if assign is None else max(1, min(int(assign["assign_iter"]), n_iter))
+    lap_counts = {"assign_refreshes": 0, "lap_fallbacks": 0}
+
     def enqueue(live, plan):
         batched = set()
         for batch, part, used in plan:
-            batch.step(n_iter - used)
+            batch.step(first_phase - used)
+            if first_phase < n_iter:          # the assignment phase: host-driven (a refresh reads its certificates), shared launches
+                from .run_robot import AssignmentPhaseBatch
+
+                ph = AssignmentPhaseBatch(batch, [e[2].caller_clouds() for e in part], assign["downsample"], assign["assign_gap"],
+                                          assign["lambda_assign"])
+                ph.capture_guard = gate.capture
+                ph.run(first_phase, n_iter)
+                lap_counts["assign_refreshes"] += ph.refreshes
+                lap_counts["lap_fallbacks"] += ph.fallbacks
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(device))
             for e in part:
                 e[4], e[5] = n_iter, ev
                 batched.add(id(e))
         rest = [e for e in live if id(e) not in batched]
-        while any(e[4] < n_iter for e in rest):          # streams: round-robin graph replays
+        while any(e[4] < first_phase for e in rest):     # streams: round-robin graph replays
             for e in rest:
-                if e[4] < n_iter:
-                    n = min(chunk, n_iter - e[4])
+                if e[4] < first_phase:
+                    n = min(chunk, first_phase - e[4])
                     with torch.cuda.stream(e[3]):
                         e[2].step(n)
                     e[4] += n
+        if first_phase < n_iter:                          # streams: the assignment phase, one instance after the other
+            from .run_robot import AssignmentPhase
+
+            for e in rest:
+                with torch.cuda.stream(e[3]):
+                    ph = AssignmentPhase(e[2], *e[2].caller_clouds(), assign["downsample"], assign["assign_gap"], assign["lambda_assign"])
+                    ph.capture_guard = gate.capture
+                    e[4] = ph.run(first_phase, n_iter)
+                lap_counts["assign_refreshes"] += ph.refreshes
+                lap_counts["lap_fallbacks"] += ph.fallbacks
         for e in rest:
             e[5] = torch.cuda.Event()
             e[5].record(e[3])
@@ -384,6 +410,7 @@ def run_sweep_engines(instances, make_engine, n_iter, device, per_gpu=3, chunk=1
         pool.shutdown()
     torch.cuda.synchronize(device)
     stages["drain_s"] = time.perf_counter() - t_          # what is left after the last group was queued: its iterations and tails
+    stages.update(lap_counts)
     run_sweep_engines.last_stages = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in stages.items()}
     records = gather_records(local, len(instances), device, plan_ranks)
     return records, best_instance(records)
@@ -478,6 +505,11 @@ def build_cli():
     p.add_argument("--use_flow_loss", action="store_true")
     p.add_argument("--use_robust_loss", action="store_true")
     p.add_argument("--lambda_flow", default=1, type=float)
+    p.add_argument("--use_assign_loss", action="store_true", help="README.md:116: assignment loss after --assign_iter iterations")
+    p.add_argument("--assign_iter", default=5000, type=int)
+    p.add_argument("--assign_gap", default=5, type=int)
+    p.add_argument("--downsample", default=4, type=int)
+    p.add_argument("--lambda_assign", default=3e-1, type=float)
     p.add_argument("--corr_model_path", default="pretrained/corr_model.pth.tar")
     p.add_argument("--normalize_file", default="data/category_normalize_scale.pkl", type=str)
     return p
@@ -625,7 +657,9 @@ def main(argv=None, runner=None):
 
         records, _ = run_sweep_engines(instances, make_engine, args.n_iter, device, per_gpu=args.per_gpu,
                                        chunk=min(100, args.n_iter), energy=args.energy, mode=args.mode, on_finish=on_finish,
-                                       policy=args.shard)
+                                       policy=args.shard,
+                                       assign=dict(assign_iter=args.assign_iter, assign_gap=args.assign_gap, downsample=args.downsample,
+                                                   lambda_assign=args.lambda_assign) if args.use_assign_loss else None)
     records = records.cpu()
     win = winners(instances, records)
     owner = owner_of(deal(instances, world, args.shard))

@@ -142,3 +142,42 @@ def test_sweep_command_line_synthetic_batch_with_flow(dev, tmp_path):
         assert have, "no instance of the sequence produced an energy"
         assert seq["winner_cano_idx"] == min(have, key=lambda r: r["total_err"])["cano_idx"]
         assert (tmp_path / name / "result.pkl").exists()
+
+
+def test_sweep_command_line_readme_recipe(dev, tmp_path):
+    """The README recipe as a sweep (README.md:116: --use_flow_loss --use_assign_loss --downsample 4; here assign_iter 40 of
+    80 iterations): the five canonical frames of a generated sequence step in SHARED launches through both phases -- no
+    fall-back to streams --, every refresh solves the 5 x 4 assignment problems of 512 x 512 in one call, nothing goes to the
+    host solver, and an instance ends exactly as a solo engine driven by AssignmentPhase ends."""
+    import json
+    import warnings
+
+    from reart_amd import run_robot as rr
+    from reart_amd import sweep
+    from reart_amd.networks.model import BaseModel
+    from reart_amd.relax import RelaxEngine
+
+    argv = ["--synthetic", "1", "--synthetic_frames", "5", "--num_points", "2048", "--cano", "all", "--n_iter", "80", "--use_flow_loss",
+            "--use_assign_loss", "--assign_iter", "40", "--assign_gap", "5", "--downsample", "4", "--save_root", str(tmp_path)]
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                  # a batch group falling back to streams warns: not allowed here
+        assert sweep.main(argv) == 0
+    sw = json.load(open(tmp_path / "sweep.json"))
+    st = sw["rank0_stages"]
+    assert st["assign_refreshes"] == 8 and st["lap_fallbacks"] == 0         # one group of five: refreshes at 40, 45, ..., 75
+    rows = sw["sequences"]["synthetic_0"]["instances"]
+    assert all(r["iterations"] == 80 and r["failed"] == 0 and np.isfinite(r["total_loss"]) for r in rows)
+    # instance cano_idx 1, alone
+    args = sweep.build_cli().parse_args(argv)
+    sample = rr.synthetic_sequence(2048, 1, 5, True, seed=2)
+    cano, pcs = torch.from_numpy(sample["cano_pc"]).float().to(dev), torch.from_numpy(sample["pc_list"]).float().to(dev)
+    refs, flows = rr.flow_references(args, sample, dev, None)
+    torch.manual_seed(2)
+    model = BaseModel(num_parts=20, pose_len=4).to(dev)
+    eng = RelaxEngine(cano, pcs, model, 1, refs, flows, n_iter=80, seed=2)
+    eng.step(40)
+    ph = rr.AssignmentPhase(eng, cano, pcs, 4, 5, 0.3)
+    ph.run(40, 80)
+    row = eng.last_losses().cpu().numpy()
+    assert ph.fallbacks == 0
+    np.testing.assert_allclose([rows[1]["recon_loss"], rows[1]["flow_loss"], rows[1]["total_loss"]], row[:3], rtol=1e-6)
