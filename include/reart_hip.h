@@ -536,7 +536,7 @@ int reart_lap_resolve_points_race(const float *src, const float *tgt, int B, int
 /* reart_lap_resolve_points[_race] with one search per WAVE (csrc/lap_mw.hip): the free rows a refresh leaves (run_robot.py:164-187
  * re-solves every assign_gap iterations) are mostly independent of each other, so every wave of a problem's workgroup follows
  * its own free row -- row-reduction chain, then a shortest augmenting path -- on columns it holds in registers, and commits
- * under a workgroup lock after checking that the columns it is about to write are still as it saw them.  512 <= n <= 1024
+ * under a workgroup lock after checking that the columns it is about to write are still as it saw them.  512 <= n <= 2048
  * (REART_ERR_UNSUPPORTED otherwise: call reart_lap_resolve_points_race).  racers >= 1 workgroups per problem (free rows taken
  * in different orders); workspace: reart_lap_race_workspace_bytes(B, n, racers).  Outputs, certificate and the caveat on the
  * potentials as reart_lap_resolve_points_race; stats[b] = released rows (+ winner << 16), rows left for the path searches |

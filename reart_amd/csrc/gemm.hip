@@ -18,12 +18,6 @@
 #include <math.h>
 
 #define GM_BM 128
-#ifndef GM_NB7
-#define GM_NB7 1
-#endif
-#ifndef GM_NB4_GATHER
-#define GM_NB4_GATHER 0     // 1: four accumulators per wave for the gathered 323 -> 128 layers (measured: 5.69 vs 5.57 ms per forward)
-#endif
 // K step per layer (template parameter BK): 8 for the Cin = 6 first layers (they pad to the step), 32 for wide layers
 // (half the barriers per flop), 16 otherwise.  One step for all was measured: 32 everywhere is slower than 16 everywhere
 // (8.3 vs 6.7 ms for the extractor: the Cin = 6 layers pad twice as far).
@@ -220,11 +214,10 @@ extern "C" int reart_mlp_layer(const float *X, int ldx, const int64_t *gather_id
     a.xyz_first = xyz_first; a.Wt = Wt; a.bias = bias; a.rows = rows; a.Cin = Cin; a.Cout = Cout; a.relu = relu;
     a.pool_k = pool_k; a.Y = Y; a.ldy = ldy; a.ycol0 = ycol0;
     // measured: NB = 4 for ALL wide layers is slower (7.5 vs 6.7 ms: half the resident waves), and for the gathered wide-K
-    // first layers of sa2 (323 -> 128, whose A tile NB = 2 stages twice) alone as well (GM_NB4_GATHER: 5.69 vs 5.57 ms)
+    // first layers of sa2 (323 -> 128, whose A tile NB = 2 stages twice) alone as well (5.69 vs 5.57 ms per forward)
     // Cout = 196 (sa2's 128 -> 196): four 64-column blocks compute 256 columns for 196; ONE block of seven 32-column
     // accumulators computes 224 and stages the A tile once
-    const int NB = Cout <= 32 ? 1 : (Cout <= 64 ? 2 : (Cout <= 96 ? 3 : ((Cout > 192 && Cout <= 224 && GM_NB7) ? 7 :
-                   ((gather_idx && Cin > 128 && Cout % 128 == 0 && GM_NB4_GATHER) ? 4 : 2))));
+    const int NB = Cout <= 32 ? 1 : (Cout <= 64 ? 2 : (Cout <= 96 ? 3 : ((Cout > 192 && Cout <= 224) ? 7 : 2)));
     const int BK = Cin <= 8 ? 8 : 16;   // measured: 32 for the wide layers is slower (7.76 vs 6.72 ms for the extractor)
     const dim3 grid(reart_div_up(rows, GM_BM), reart_div_up(Cout, 32 * NB));
     hipStream_t st = (hipStream_t)stream;
@@ -466,9 +459,6 @@ struct ChainWideArgs {
     float *Y; int ldy, ycol0;
 };
 #define CW_BK 16
-#ifndef CW_SCHED
-#define CW_SCHED 1
-#endif
 // diagnostic build (-DCW_CLOCK): where a wave of mlp_chain_wide_kernel spends its cycles (tools/cw_clock.py)
 #ifdef CW_CLOCK
 __device__ unsigned long long cw_clock_acc[16];
@@ -490,11 +480,7 @@ extern "C" int reart_debug_cw_clock(unsigned long long *out, int reset) {
 #define CW_CLK_ARG
 #define CW_CLK_PASS
 #endif
-#if CW_SCHED
 #define CW_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-#else
-#define CW_SCHED_FENCE() ((void)0)
-#endif
 #define CW_LDAS (CW_BK + 1)
 // Weight slabs in LDS: the B fragment of lane (k-half kh, column lr) for step kk is the NB values W[kk + kh][32 n + lr],
 // n = 0 .. NB-1.  They are stored next to each other ([k][lr][n], S = 4 or 8 floats per (k, lr)) so that ONE or TWO 16-byte
@@ -666,10 +652,7 @@ __global__ __launch_bounds__(256) void mlp_chain_wide_kernel(ChainWideArgs a) {
     const float *const W1 = a.W1, *const W2 = a.W2, *const W3 = a.W3, *const b1 = a.b1, *const b2 = a.b2, *const b3 = a.b3;
     int buf = 0;
     float4 bw2[CwSlab<NB2>::BPT], bw3[CwSlab<NB3>::BPT];
-#ifndef CW_XPHASE
-#define CW_XPHASE 1
-#endif
-    if (CW_XPHASE) cw_load_b<NB2>(W2, C1, 0, tid, bw2);           // layer 2's first slab waits in registers through layer 1
+    cw_load_b<NB2>(W2, C1, 0, tid, bw2);           // layer 2's first slab waits in registers through layer 1
     {   // ---- layer 1: A from the gather (mlp_gemm_kernel's staging: thread <- 8 consecutive k of one row)
         const int ar = tid >> 1, ak = (tid & 1) * 8, r = row0 + ar;
         const size_t prow = (size_t)(r / (a.S * a.K)) * a.Npts + (size_t)a.idx[r];
@@ -740,8 +723,7 @@ __global__ __launch_bounds__(256) void mlp_chain_wide_kernel(ChainWideArgs a) {
         for (int n = 0; n < NB2; ++n)
 #pragma unroll
             for (int g = 0; g < 16; ++g) acc[n][g] = 0.f;
-        if (!CW_XPHASE) cw_load_b<NB2>(W2, C1, 0, tid, bw2);
-        if (CW_XPHASE) cw_load_b<NB3>(W3, C2, 0, tid, bw3);
+        cw_load_b<NB3>(W3, C2, 0, tid, bw3);                      // layer 3's first slab a layer ahead, like layer 2's
         cw_layer<NB2>(Hw, LDA, W2, C1, C2, Bs2, buf, acc, tid, lane, bw2 CW_CLK_PASS);
         cw_store<NB2>(Hw, LDA, b2, C2, acc, lane);   // the wave's own tile, after its own last read of it
     }
@@ -752,7 +734,6 @@ __global__ __launch_bounds__(256) void mlp_chain_wide_kernel(ChainWideArgs a) {
         for (int n = 0; n < NB3; ++n)
 #pragma unroll
             for (int g = 0; g < 16; ++g) acc[n][g] = 0.f;
-        if (!CW_XPHASE) cw_load_b<NB3>(W3, C2, 0, tid, bw3);
         cw_layer<NB3>(Hw, LDA, W3, C2, C3, Bs2, buf, acc, tid, lane, bw3 CW_CLK_PASS);
 #pragma unroll
         for (int n = 0; n < NB3; ++n) {

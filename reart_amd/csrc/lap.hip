@@ -21,32 +21,20 @@
 #include "lap_dev.h"
 #include <math.h>
 
-#ifndef LAP_BS
 #define LAP_BS 1024
-#endif
 // lap_auction_kernel: from phase LAP_SEARCH_PHASE on, the last LAP_SEARCH_NU free rows of a phase get one augmenting-path
 // search each instead of a bidding chain.  Measured on the tail's 19 x 4096^2 problems (tools/lap_cold.py): the early
 // phases' chains are long (up to 12 k links) but they are the price war that settles the duals -- cut short by a search
 // (which raises the prices by the least possible amount) the NEXT phase pays with 3-5x the rounds; from the 7th phase
 // on (eps <= 3e-6 of the largest cost) nothing is left to settle, the search is simply the shorter way to place the last
 // row, and its tighter prices halve the certificate's rounds (36 -> 19): 440 -> 395 ms.
-#ifndef LAP_CW
 #define LAP_CW 8            // waves that compute in the points form of a single-bidder chain (of LAP_BS / 64 = 16)
-#endif
-#ifndef LAP_SEARCH_PHASE
 #define LAP_SEARCH_PHASE 7
-#endif
-#ifndef LAP_SEARCH_NU
 #define LAP_SEARCH_NU 1
-#endif
 #define LAP_NLDS 2048   // up to here the rows' bids live in LDS too; above, in the workspace (36 B of LDS per row/column)
 
-#ifndef LAP_EPS0
 #define LAP_EPS0 0.125      // first epsilon of a cold solve, as a fraction of the largest cost
-#endif
-#ifndef LAP_THETA
 #define LAP_THETA 6.0       // epsilon shrinks by this factor from phase to phase
-#endif
 struct LapArgs {
     const float *cost;     // [B][n][n]
     int B, n;
@@ -1442,7 +1430,7 @@ extern "C" int reart_lap_resolve_points_race(const float *src, const float *tgt,
 
 // reart_lap_resolve_points[_race] with the sequential part run by lap_mw.hip: every WAVE of a problem's workgroup follows its
 // own free row (row-reduction chain, then shortest augmenting path) on the columns it holds in registers, and commits under
-// a workgroup lock after checking that the columns it is about to write are as it saw them.  512 <= n <= 1024
+// a workgroup lock after checking that the columns it is about to write are as it saw them.  512 <= n <= 2048
 // (REART_ERR_UNSUPPORTED otherwise: use reart_lap_resolve_points_race).  racers >= 1 workgroups per problem (1: no race;
 // workspace reart_lap_race_workspace_bytes(B, n, racers) either way).  Same outputs and certificate; like the raced
 // solves the potentials (and, among optima of exactly equal cost, the assignment) depend on timing.  stats [B][4] in the

@@ -374,7 +374,7 @@ __global__ __launch_bounds__(64 * MW_NW) void lap_jvmw_kernel(JvArgs a) {
     }
 }
 
-int reart_internal_jvmw_nmax() { return 64 * 16; }
+int reart_internal_jvmw_nmax() { return 64 * 32; }
 
 template <int CPL>
 static int mw_launch(const JvArgs &a, int racers, hipStream_t stream) {
@@ -390,5 +390,6 @@ static int mw_launch(const JvArgs &a, int racers, hipStream_t stream) {
 int reart_internal_jvmw_launch(const JvArgs &a, int racers, hipStream_t stream) {
     if (a.n < 1 || a.n > reart_internal_jvmw_nmax() || !a.src || !a.tgt || !a.pre_v1) return REART_ERR_UNSUPPORTED;
     if (a.n <= 512) return mw_launch<8>(a, racers, stream);
-    return mw_launch<16>(a, racers, stream);
+    if (a.n <= 1024) return mw_launch<16>(a, racers, stream);
+    return mw_launch<32>(a, racers, stream);
 }

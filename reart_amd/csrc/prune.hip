@@ -55,29 +55,17 @@
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 #define PR_SMAX 4       // most waves (box slices) per search workgroup
-#define PR_PF 1
-#define PR_PREFETCH 0   // a box's targets are fetched when it is scanned (prefetching every coarse survivor eight at a
-                        // time was measured: more instructions, loads for the 60 % of the boxes the precise test
-                        // rejects, no gain -- the branch is kept compiled out for reference)
-#ifndef PR_QCAP
-#define PR_QCAP 640     // words of a wave's queue space: the first 384 hold box bounds (PR_BOXLDS), 256 (query, box) entries (768: one
+// (a box's targets are fetched when it is scanned: prefetching every coarse survivor eight at a time was measured -- more
+// instructions, loads for the 60 % of the boxes the precise test rejects, no gain; DESIGN_HISTORY.md)
+#define PR_QCAP 640     // words of a wave's queue space: the first 384 hold box bounds, 256 (query, box) entries (768: one
                         // workgroup less per compute unit, 32.9 vs 32.3 us; 512: drains too small and too many, 33.7 us)
-#endif
-#ifndef PR_COARSE_PACKED
-#define PR_COARSE_PACKED 1
-#endif
-#ifndef PR_WPE
 #define PR_WPE 6         // waves per SIMD the compiler must allow for (register budget: 85 -> 80 VGPRs; the kernel sits at the
                          // edge -- 78 under this bound, 82 without it, no spills either way -- and the sixth wave is worth 7 %)
-#endif
 // LDS per wave: staged box of a dense scan [64 floats] | the wave's queries [64][4] | result slots [3][64] u64 | queue
-// PR_BOXLDS 1: the precise filter reads a surviving box's bounds back from LDS (broadcast ds_read, the LDS pipe is idle) instead of
-// twelve v_readlane per box pair on the VALU, which bounds this kernel: 45.0 -> 43.6 us per launch.  The 1.5 KB come out of the
-// queue's space (768 -> 384 entries); with LDS of their own (2) a workgroup less fits a compute unit: 48.6 us.  0: readlanes.
-#ifndef PR_BOXLDS
-#define PR_BOXLDS 1
-#endif
-#define PR_LDS_WAVE_BYTES (64 * 4 + 64 * 16 + 3 * 64 * 8 + PR_QCAP * 4 + (PR_BOXLDS == 2 ? 64 * 6 * 4 : 0))
+// The precise filter reads a surviving box's bounds back from LDS (broadcast ds_read, the LDS pipe is idle) instead of twelve
+// v_readlane per box pair on the VALU, which bounds this kernel: 45.0 -> 43.6 us per launch.  The 1.5 KB come out of the
+// queue's space (768 -> 384 entries); with LDS of their own a workgroup less fits a compute unit: 48.6 us.
+#define PR_LDS_WAVE_BYTES (64 * 4 + 64 * 16 + 3 * 64 * 8 + PR_QCAP * 4)
 
 #ifdef REART_PRUNE_STATS   // diagnostic build only (tools/prune_stats.py): how much the filters let through
 __device__ unsigned long long g_prune_stats[8];
@@ -192,7 +180,7 @@ __device__ __forceinline__ void knn_pruned_wave(const KnnJob &jb, const int S, c
         }
         // scratch for the neighbour seeds: the result slots (s_key, 384 floats, initialised after this block) and the queue's
         // space behind them (box bounds | queue) are contiguous and idle until the first coarse round
-        constexpr bool SCR_JOINT = BOXL && PR_BOXLDS == 1;       // s_bb | s_q contiguous
+        constexpr bool SCR_JOINT = BOXL;                         // s_bb | s_q contiguous
         constexpr bool SCR_FITS = (384 + QCAP + (SCR_JOINT ? 384 : 0)) >= KK * 3 * 64;
         if (SCR_FITS && share) {
             // ---- neighbour seeds: the K seed targets of every lane of this row of 16 (the lane's own among them), two lanes
@@ -369,7 +357,7 @@ __device__ __forceinline__ void knn_pruned_wave(const KnnJob &jb, const int S, c
                 float *o = s_bb + 6 * lane;
                 o[0] = lo0; o[1] = lo1; o[2] = lo2; o[3] = hi0; o[4] = hi1; o[5] = hi2;
             }
-#if PR_COARSE_PACKED   // two query sub-groups per packed instruction (same operation order per sub-group as box_lb)
+            // two query sub-groups per packed instruction (same operation order per sub-group as box_lb)
             const f2 bl0 = {lo0, lo0}, bl1 = {lo1, lo1}, bl2 = {lo2, lo2}, bh0 = {hi0, hi0}, bh1 = {hi1, hi1}, bh2 = {hi2, hi2};
 #pragma unroll
             for (int q = 0; q < 4; q += 2) {
@@ -382,13 +370,6 @@ __device__ __forceinline__ void knn_pruned_wave(const KnnJob &jb, const int S, c
                 const f2 lb = (e0 * e0 + e1 * e1) + e2 * e2;
                 pass = pass || (lb.x <= G[q][6]) || (lb.y <= G[q + 1][6]);
             }
-#else
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float lb = box_lb(lo0, lo1, lo2, hi0, hi1, hi2, G[q][0], G[q][1], G[q][2], G[q][3], G[q][4], G[q][5]);
-                pass = pass || (lb <= G[q][6]);
-            }
-#endif
         }
         unsigned long long mask = __ballot(pass);
         PH(1);
@@ -396,19 +377,19 @@ __device__ __forceinline__ void knn_pruned_wave(const KnnJob &jb, const int S, c
         if (KK == 1) PRUNE_STAT(1, __builtin_popcountll(mask));          // boxes passing the coarse filter
         if (KK == 1) PRUNE_STAT(3, __builtin_popcountll(__ballot(thr == INFINITY)));  // lanes without a bound
         // scan of one box: the brute-force inner loop of knn.hip on its 16 targets
-        auto scan_box = [&](const int bit, const int slot) {
+        auto scan_box = [&](const int bit) {
             wp += PR_WORK(5) | (64u * NN_BOX);                           // a scan costs about five tests
             if (KK == 1) PRUNE_STAT(2, 1);                               // boxes scanned
             const int j0 = (base + bit * a.S + s) * NN_BOX;
-            // the box's 16 targets were staged in LDS slot `slot` (x[16] | y[16] | z[16]); all lanes read
+            // the box's 16 targets are staged in the wave's LDS slot (x[16] | y[16] | z[16]); all lanes read
             // the same addresses (broadcast) -- the operands of the packed ops are VGPR pairs
-            if (!PR_PREFETCH && !LDSV) {
+            if (!LDSV) {
                 const int l = lane < 48 ? lane : 47;
                 const float v = tx_g[(size_t)(l >> 4) * cstride + j0 + (l & 15)];
                 if (lane < 48) s_tg[lane] = v;
             }
             // LDSV: the cloud itself is in LDS -- the broadcast reads go straight to it
-            const float *tx = LDSV ? tx_g : s_tg + (PR_PREFETCH ? slot * 48 : 0) - j0;
+            const float *tx = LDSV ? tx_g : s_tg - j0;
             const float *ty = tx + (LDSV ? cstride : 16), *tz = ty + (LDSV ? cstride : 16);
             if (KK == 1) {
                 // minimum of each half of the box: the final rescan then looks at 8 targets instead of 16
@@ -466,34 +447,12 @@ __device__ __forceinline__ void knn_pruned_wave(const KnnJob &jb, const int S, c
             qcnt += nneed;
         };
         while (mask) {
-            // ---- take the next PR_PF surviving boxes and put ALL their targets in flight: lane l < 48
-            // loads one float of each box (192 coalesced bytes per box) through the vector memory path,
-            // then the values are parked in the wave's LDS slots.  (Targets used to come through scalar
-            // loads, s_load_dwordx16 x 3 per scanned box: one dependent scalar-cache miss chain per scan;
-            // measured 95 -> 80 us for the launch with the vector path alone, before prefetching.)
-            unsigned long long rest = PR_PREFETCH ? mask : 0ull;
-#pragma unroll
-            for (int k = 0; k < PR_PF; ++k) rest &= rest - 1;            // x & (x - 1) of 0 is 0
-            unsigned long long cm = mask & ~rest;                        // this chunk's boxes
-            mask = rest;
-            if (PR_PREFETCH) {
-                const int l = lane < 48 ? lane : 47;
-                const float *src = tx_g + (size_t)(l >> 4) * jb.Ppad + (l & 15);
-                float pv[PR_PF];
-                unsigned long long t = cm;
-#pragma unroll
-                for (int k = 0; k < PR_PF; ++k) {
-                    const int bit = t ? __builtin_ctzll(t) : 0;          // clamped: an unused slot re-reads box `base`
-                    t &= t - 1;
-                    pv[k] = src[(base + bit * a.S + s) * NN_BOX];
-                }
-#pragma unroll
-                for (int k = 0; k < PR_PF; ++k)
-                    if (lane < 48) s_tg[k * 48 + lane] = pv[k];
-            }
+            // (Targets used to come through scalar loads, s_load_dwordx16 x 3 per scanned box: one dependent scalar-cache
+            // miss chain per scan; measured 95 -> 80 us for the launch with the vector path of scan_box alone.)
+            unsigned long long cm = mask;                                // every surviving box of the round
+            mask = 0ull;
             // ---- precise filter with the lane's current bound, two boxes per step in packed fp32 (same
             // operation order per box as box_lb; the second box is judged after the first one's scan)
-            int slot = 0;
             while (cm) {
             const int bA = __builtin_ctzll(cm);
             cm &= cm - 1;
@@ -534,12 +493,11 @@ __device__ __forceinline__ void knn_pruned_wave(const KnnJob &jb, const int S, c
                         PH(4);
                         if (qcnt > QCAP - 64) { drain_queue(); PH(5); }   // uniform: qcnt is a wave-wide count
                     } else {
-                        scan_box(h ? bB : bA, slot + h);
+                        scan_box(h ? bB : bA);
                         PH(3);
                     }
                 }
             }
-            slot += 2;
             }
         }
     }
@@ -614,26 +572,18 @@ __global__ __launch_bounds__(64 * PR_SMAX, PR_WPE) void knn_group_kernel(Batched
         unsigned int *s_q = (unsigned int *)(wl + 64 * 4 + 64 * 16 + 3 * 64 * 8);
         static_assert(384 + PR_QCAP >= 3 * 3 * 64, "neighbour seeds of a K = 3 item: 9 x 64 floats in the result slots + the queue's space");
         static_assert(PR_QCAP >= 384 + 128, "box bounds of a coarse round + at least two drain steps of queue");
-#if PR_BOXLDS == 1          // the bounds of a coarse round's 64 boxes take the first 384 entries of the queue's space
-        float *s_bb = (float *)s_q;
+        float *s_bb = (float *)s_q;          // the bounds of a coarse round's 64 boxes take the first 384 entries of the queue's space
         s_q += 384;
         constexpr int QC = PR_QCAP - 384;
-#elif PR_BOXLDS == 2        // ... or 1.5 KB of their own behind the queue
-        float *s_bb = (float *)(s_q + PR_QCAP);
-        constexpr int QC = PR_QCAP;
-#else
-        float *s_bb = nullptr;
-        constexpr int QC = PR_QCAP;
-#endif
         const float *cloud = jb.tsoa + (size_t)b * 3 * jb.Ppad;
         const float *boxes_p = jb.boxes + (size_t)b * (jb.Ppad / NN_BOX) * 8;
         if (kind == 1) {
             float m1[1]; int b1[1];
-            knn_pruned_wave<1, false, QC, PR_BOXLDS != 0>(jb, S, a.sparse, b, g, s, cloud, jb.Ppad, boxes_p, s_tg, s_qc, s_q, s_bb, a.share, a.share > 1 ? &s_xthr[0][0] : nullptr, s_key,
+            knn_pruned_wave<1, false, QC, true>(jb, S, a.sparse, b, g, s, cloud, jb.Ppad, boxes_p, s_tg, s_qc, s_q, s_bb, a.share, a.share > 1 ? &s_xthr[0][0] : nullptr, s_key,
                                                qx, qy, qz, m1, b1, work, pairs);
             bm[0] = m1[0]; bb[0] = b1[0];
         } else {
-            knn_pruned_wave<3, false, QC, PR_BOXLDS != 0>(jb, S, a.sparse, b, g, s, cloud, jb.Ppad, boxes_p, s_tg, s_qc, s_q, s_bb, a.share, a.share > 1 ? &s_xthr[0][0] : nullptr, s_key,
+            knn_pruned_wave<3, false, QC, true>(jb, S, a.sparse, b, g, s, cloud, jb.Ppad, boxes_p, s_tg, s_qc, s_q, s_bb, a.share, a.share > 1 ? &s_xthr[0][0] : nullptr, s_key,
                                                qx, qy, qz, bm, bb, work, pairs);
         }
     }

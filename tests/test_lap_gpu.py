@@ -335,3 +335,31 @@ def test_resolve_per_wave_gives_the_optimum(dev, n, racers):
                 assert (st[:, 0] & 0xffff).max() == 0       # nothing released: the previous optimum is still one
     finally:
         lap.RESOLVE_RACERS = old
+
+
+def test_resolve_per_wave_at_2048(dev):
+    """The kinematic projection's size (README.md:125: downsample 2 of 4096 points): the per-wave row reduction with 32
+    columns per lane, three re-solves of moved problems against scipy."""
+    import oracle
+    from reart_amd.utils import lap
+
+    rng = np.random.default_rng(5)
+    B, n = 2, 2048
+    tgt = rng.uniform(-0.3, 0.3, (B, n, 3)).astype(np.float32)
+    src = (tgt[:, rng.permutation(n)] + rng.normal(0, 0.005, (B, n, 3))).astype(np.float32)
+    state = {}
+    old = lap.MW_NMAX
+    lap.MW_NMAX = 2048               # opt in: the default stops at 1024 (measured slower above)
+    try:
+        outs = []
+        for k in range(3):
+            src = (src + rng.normal(0, 0.001, src.shape)).astype(np.float32)
+            outs.append((src.copy(), lap.linear_sum_assignment_points(torch.from_numpy(src).to(dev), torch.from_numpy(tgt).to(dev), state,
+                                                                       return_stats="full", per_wave=True)))
+    finally:
+        lap.MW_NMAX = old
+    for src, (out, fb, st) in outs:
+        assert fb == 0
+        ref = oracle.linear_sum_assignment(oracle.cdist(src, tgt))
+        for b, (r, c) in enumerate(out):
+            np.testing.assert_array_equal(c, ref[b][1])

@@ -1,5 +1,5 @@
 import sys, json
-for line in sys.stdin:
+for line in (open(sys.argv[1]) if len(sys.argv) > 1 else sys.stdin):
     line = line.strip()
     if line.startswith("{"):
         d = json.loads(line)
