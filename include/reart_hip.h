@@ -545,6 +545,16 @@ int reart_lap_resolve_points_mw(const float *src, const float *tgt, int B, int n
                                 int32_t *certified, const double *price_in, double *price_out, void *workspace,
                                 size_t workspace_bytes, void *stream);
 
+/* reart_lap_resolve_points_mw with every problem's row reduction spread over `arr_wgs` workgroups (1..256; csrc/lap_mw.hip:
+ * lap_mc_arr_kernel -- the chains only meet in the column they commit on, so their state lives in memory and a commit is a
+ * lock-free compare-and-swap on the column's owner), the path searches then one workgroup per problem and racer.  Three
+ * launches between the two whole-chip passes.  512 <= n <= 2048; workspace: reart_lap_mc_workspace_bytes(B, n, racers).
+ * Outputs, certificate, statistics and the caveat on the potentials as reart_lap_resolve_points_mw. */
+size_t reart_lap_mc_workspace_bytes(int B, int n, int racers);
+int reart_lap_resolve_points_mc(const float *src, const float *tgt, int B, int n, int racers, int arr_wgs, int32_t *col4row,
+                                int32_t *certified, const double *price_in, double *price_out, void *workspace,
+                                size_t workspace_bytes, void *stream);
+
 /* Cost matrices for the above: replaces `torch.cdist(pc_src, pc_tgt)` (run_robot.py:171, utils/model_utils.py:93).
  *   a [B,n,3], b [B,m,3] -> out [B,n,m] = Euclidean distance, sqrt(((dx*dx)+(dy*dy))+(dz*dz)) in fp32. */
 int reart_cdist(const float *a, const float *b, int B, int n, int m, float *out, void *stream);

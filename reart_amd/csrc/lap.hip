@@ -1318,8 +1318,20 @@ __global__ __launch_bounds__(JV_PASS_BS) void lap_jv_pass_kernel(JvArgs a) {
 
 // Re-solve from the assignment in col4row and the potentials in price_in (both from an earlier solve of a similar batch,
 // reart_lap_auction* or these functions); same outputs and the same certificate as reart_lap_auction.
+// the state arrays of the many-compute-unit row reduction, behind the race layout
+static size_t jv_mc_extra_bytes(int B, int n) {
+    return reart_align_up(sizeof(double) * (size_t)B * n, 256) + 4 * reart_align_up(sizeof(int) * (size_t)B * n, 256) +
+           reart_align_up(sizeof(int) * 8 * (size_t)B, 256);
+}
+extern "C" size_t reart_lap_mc_workspace_bytes(int B, int n, int racers) {
+    const size_t r = reart_lap_race_workspace_bytes(B, n, racers);
+    return r ? r + jv_mc_extra_bytes(B, n) : 0;
+}
+
+// per_wave: 0 = one row at a time (lap_jv_kernel), 1 = row reduction one chain per wave (lap_mw.hip), 2 = row reduction on
+// arr_wgs workgroups per problem (lap_mw.hip, three launches)
 template <bool PTS>
-static int jv_launch(JvArgs a, void *workspace, size_t workspace_bytes, void *stream, int racers = 1, bool per_wave = false) {
+static int jv_launch(JvArgs a, void *workspace, size_t workspace_bytes, void *stream, int racers = 1, int per_wave = 0, int arr_wgs = 0) {
     if (a.B < 0 || a.n < 1 || a.n > (PTS ? JV_PTS_NMAX : LAP_NMAX)) return REART_ERR_INVALID_ARG;
     if (racers < 1 || racers > JV_RACE_MAX) return REART_ERR_INVALID_ARG;
     if (a.B == 0) return REART_OK;
@@ -1373,7 +1385,16 @@ static int jv_launch(JvArgs a, void *workspace, size_t workspace_bytes, void *st
             return REART_ERR_LAUNCH;
         a.price_start = pc; a.col_start = cc;
     }
-    if (per_wave) {                             // lap_mw.hip: one search per wave instead of one per workgroup
+    if (per_wave == 2) {                        // lap_mw.hip: set-up | row reduction on arr_wgs workgroups per problem | searches
+        if (workspace_bytes < reart_lap_mc_workspace_bytes(a.B, a.n, racers)) return REART_ERR_INVALID_ARG;
+        char *w = (char *)workspace + reart_lap_race_workspace_bytes(a.B, a.n, racers);
+        const size_t bi = reart_align_up(sizeof(int) * (size_t)a.B * a.n, 256);
+        a.mc_price = (double *)w; w += reart_align_up(sizeof(double) * (size_t)a.B * a.n, 256);
+        a.mc_owner = (int *)w; w += bi; a.mc_assigned = (int *)w; w += bi; a.mc_list = (int *)w; w += bi; a.mc_next = (int *)w; w += bi;
+        a.mc_cnt = (int *)w;
+        const int rc = reart_internal_jvmc_launch(a, racers, arr_wgs, (hipStream_t)stream);
+        if (rc != REART_OK) return rc;
+    } else if (per_wave) {                      // lap_mw.hip: the row reduction one chain per wave
         const int rc = reart_internal_jvmw_launch(a, racers, (hipStream_t)stream);
         if (rc != REART_OK) return rc;
     } else {
@@ -1445,7 +1466,22 @@ extern "C" int reart_lap_resolve_points_mw(const float *src, const float *tgt, i
     JvArgs a = {};
     a.src = src; a.tgt = tgt; a.B = B; a.n = n; a.col4row = col4row; a.certified = certified; a.price_in = price_in;
     a.price_out = price_out;
-    return jv_launch<true>(a, workspace, workspace_bytes, stream, racers, true);
+    return jv_launch<true>(a, workspace, workspace_bytes, stream, racers, 1);
+}
+
+// reart_lap_resolve_points_mw with the row reduction of every problem spread over `arr_wgs` workgroups (lap_mc_arr_kernel:
+// lock-free commits on state in memory), the path searches then one workgroup per problem and racer as before.  workspace:
+// reart_lap_mc_workspace_bytes(B, n, racers).  512 <= n <= 2048.
+extern "C" int reart_lap_resolve_points_mc(const float *src, const float *tgt, int B, int n, int racers, int arr_wgs, int32_t *col4row,
+                                           int32_t *certified, const double *price_in, double *price_out, void *workspace,
+                                           size_t workspace_bytes, void *stream) {
+    if ((!src || !tgt) && B > 0) return REART_ERR_INVALID_ARG;
+    if (racers < 1 || arr_wgs < 1 || arr_wgs > 256) return REART_ERR_INVALID_ARG;
+    if (workspace_bytes < reart_lap_mc_workspace_bytes(B, n, racers)) return REART_ERR_INVALID_ARG;
+    JvArgs a = {};
+    a.src = src; a.tgt = tgt; a.B = B; a.n = n; a.col4row = col4row; a.certified = certified; a.price_in = price_in;
+    a.price_out = price_out;
+    return jv_launch<true>(a, workspace, workspace_bytes, stream, racers, 2, arr_wgs);
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -149,6 +149,10 @@ struct JvArgs {
     // racing form (MODE 1, gridDim.y racers per matrix): the racers read the start from copies (col4row / price_out are
     // written by the winner while others may still be loading) and meet in done[b] (0 = nobody has finished)
     int *done;
+    // lap_mw.hip, form with the row reduction on many compute units: the state between its three launches, in the workspace
+    double *mc_price;          // [B][n]
+    int *mc_owner, *mc_assigned, *mc_list, *mc_next;       // [B][n] each: column -> row | row -> column | free rows | rows left
+    int *mc_cnt;               // [B][8]: free rows | queue head | rows left | reduction steps | conflicts | released | unsolved
     const int *col_start;
     const double *price_start;
 };
@@ -156,4 +160,6 @@ struct JvArgs {
 // lap_mw.hip: the sequential part of a points-form re-solve with one search per WAVE (see there); same inputs and
 // outputs as lap_jv_kernel<., true, 1>.  Returns REART_ERR_UNSUPPORTED when n exceeds what its waves hold in registers.
 int reart_internal_jvmw_launch(const JvArgs &a, int racers, hipStream_t stream);
+// the same with the row reduction spread over `arr_wgs` workgroups per problem (state in a.mc_*): three launches
+int reart_internal_jvmc_launch(const JvArgs &a, int racers, int arr_wgs, hipStream_t stream);
 int reart_internal_jvmw_nmax();

@@ -90,7 +90,9 @@ __device__ __forceinline__ void mw_row_costs(float ax, float ay, float az, const
 }
 
 // Column j = 64 k + lane is slot k of lane `lane` in every wave.
-template <int CPL>
+// STAGE 0: the whole sequential part in one launch.  STAGE 1: set-up only -- the state after the release / greedy steps goes to
+// a.mc_* for lap_mc_arr_kernel.  STAGE 2: the path searches only, from the state the row reduction left in a.mc_*.
+template <int CPL, int STAGE>
 __global__ __launch_bounds__(64 * MW_NW) void lap_jvmw_kernel(JvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lsm[];
     constexpr int BS = 64 * MW_NW;
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(64 * MW_NW) void lap_jvmw_kernel(JvArgs a) {
     __shared__ MwShared sh;
     __shared__ double s_red[MW_NW];
     __shared__ int s_cw[MW_NW];
-    const bool race = a.done != nullptr;
+    const bool race = STAGE != 1 && a.done != nullptr;
     const int racer = race ? (int)blockIdx.y : 0;
     [[maybe_unused]] const unsigned long long tp0_ = MWP_NOW();
     auto lost = [&]() -> int { return __hip_atomic_load(a.done + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
@@ -127,9 +129,14 @@ __global__ __launch_bounds__(64 * MW_NW) void lap_jvmw_kernel(JvArgs a) {
     }
     if (lane == 0) s_red[wv] = mx;
     for (int j = tid; j < n; j += BS) {
-        price[j] = race ? a.price_start[(size_t)b * n + j] : (a.price_in ? a.price_in[(size_t)b * n + j] : 0.0);
+        if (STAGE == 2) {
+            price[j] = a.mc_price[(size_t)b * n + j]; owner[j] = a.mc_owner[(size_t)b * n + j];
+            assigned[j] = a.mc_assigned[(size_t)b * n + j]; next[j] = a.mc_next[(size_t)b * n + j];
+            continue;
+        }
+        price[j] = (race && STAGE == 0) ? a.price_start[(size_t)b * n + j] : (a.price_in ? a.price_in[(size_t)b * n + j] : 0.0);
         owner[j] = -1;
-        const int c = (race ? a.col_start : a.col4row)[(size_t)b * n + j];
+        const int c = ((race && STAGE == 0) ? a.col_start : a.col4row)[(size_t)b * n + j];
         assigned[j] = (c >= 0 && c < n) ? c : -1;
         next[j] = 0x7fffffff;
     }
@@ -138,6 +145,7 @@ __global__ __launch_bounds__(64 * MW_NW) void lap_jvmw_kernel(JvArgs a) {
     mx = 0.0;
     for (int w = 0; w < MW_NW; ++w) mx = fmax(mx, s_red[w]);
     if (!(mx > 0.0)) mx = 1.0;
+    if (STAGE == 2) mx = a.scale[b];
     const double keep_tol = mx * a.keep_tol;
     jv_f2 tcx[CPL / 2], tcy[CPL / 2], tcz[CPL / 2];
 #pragma unroll
@@ -145,6 +153,10 @@ __global__ __launch_bounds__(64 * MW_NW) void lap_jvmw_kernel(JvArgs a) {
         const int j = 64 * k + lane < n ? 64 * k + lane : 0;
         tcx[k >> 1][k & 1] = ptx[j]; tcy[k >> 1][k & 1] = pty[j]; tcz[k >> 1][k & 1] = ptz[j];
     }
+    int st_freed = 0, nleft = 0;
+    int my_steps = 0, my_arr = 0, my_conf = 0;
+    [[maybe_unused]] unsigned long long tp_ = MWP_NOW();
+    if (STAGE != 2) {
     // previous pairs: a repeated column keeps its lowest row
     for (int i = tid; i < n; i += BS)
         if (assigned[i] >= 0) atomicMin((unsigned int *)&owner[assigned[i]], (unsigned int)i);   // -1 = 0xffffffff: empty
@@ -164,7 +176,7 @@ __global__ __launch_bounds__(64 * MW_NW) void lap_jvmw_kernel(JvArgs a) {
     for (int i = tid; i < n; i += BS)
         if (assigned[i] < 0) { atomicAdd(&sh.flag, 1); if (owner[flist[i]] < 0) atomicMin(&next[flist[i]], i); }
     __syncthreads();
-    const int st_freed = sh.flag;
+    st_freed = sh.flag;
     for (int i = tid; i < n; i += BS)
         if (assigned[i] < 0 && owner[flist[i]] < 0 && next[flist[i]] == i) assigned[i] = flist[i];
     __syncthreads();
@@ -190,8 +202,19 @@ __global__ __launch_bounds__(64 * MW_NW) void lap_jvmw_kernel(JvArgs a) {
     if (tid == 0) sh.budget = MW_ARR_BUDGET * nfree + 64;
     __syncthreads();
 
-    int my_steps = 0, my_arr = 0, my_conf = 0;
-    [[maybe_unused]] unsigned long long tp_ = MWP_NOW();
+    if (STAGE == 1) {                                   // hand the state to lap_mc_arr_kernel
+        for (int j = tid; j < n; j += BS) {
+            a.mc_price[(size_t)b * n + j] = price[j]; a.mc_owner[(size_t)b * n + j] = owner[j];
+            a.mc_assigned[(size_t)b * n + j] = assigned[j]; a.mc_list[(size_t)b * n + j] = flist[j];
+        }
+        if (tid == 0) {
+            int *c = a.mc_cnt + 8 * b;
+            c[0] = nfree; c[1] = 0; c[2] = 0; c[3] = 0; c[4] = 0; c[5] = st_freed; c[6] = 0;
+            a.scale[b] = mx;
+        }
+        return;
+    }
+    tp_ = MWP_NOW();
     if (wv == 0) MWP_ADD(0, tp_ - tp0_);
     // ---- augmenting row reduction, one chain per wave: the row takes its cheapest column and pays the gap to its second
     // cheapest (the pair is tight, every other constraint still holds), the row it displaces goes on in the same wave
@@ -246,9 +269,15 @@ __global__ __launch_bounds__(64 * MW_NW) void lap_jvmw_kernel(JvArgs a) {
     __syncthreads();
     if (wv == 0) MWP_ADD(1, MWP_NOW() - tp_);
     tp_ = MWP_NOW();
-    const int nleft = sh.nnext;
+    nleft = sh.nnext;
     if (tid == 0) sh.qhead = 0;
     __syncthreads();
+    } else {                                            // STAGE 2: what the row reduction on the other compute units left
+        const int *c = a.mc_cnt + 8 * b;
+        nleft = c[2]; st_freed = c[5];
+        if (tid == 0) { sh.arr = c[3]; sh.conflicts = c[4]; sh.unsolved = c[6]; }
+        __syncthreads();
+    }
 
     // ---- one shortest augmenting path per remaining row, the whole workgroup on one search (thread t owns the columns
     // t, t + BS, ...: labels, predecessors and prices in registers; a step is one workgroup arg-min + ONE barrier).  Searches
@@ -374,15 +403,105 @@ __global__ __launch_bounds__(64 * MW_NW) void lap_jvmw_kernel(JvArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The row reduction of ONE problem on MANY compute units (lap_mc_arr_kernel, between the set-up and the search launches of
+// reart_internal_jvmc_launch).  Chains only meet in the column they commit on, so nothing ties them to one workgroup's LDS:
+// the state lives in memory, every wave of gridDim.x workgroups per problem follows a chain, and a commit is lock-free --
+//   1. owner[j] : seen -> LOCKED by compare-and-swap (fails if somebody else has committed on j since the wave looked);
+//   2. price[j] still the value the decision used?  (otherwise owner[j] <- seen again, and the row is scanned again);
+//   3. price[j] += v2 - v1, assigned[i] <- j, assigned[displaced row] <- -1;  4. owner[j] <- i (release).
+// All reads and writes of the shared state are device-scope atomics (no cached copy can go stale, and the workgroups of a
+// problem may sit on different XCDs); that a wave works with prices which other waves are raising meanwhile is harmless for
+// the reason given at the top of this file.  A chain gives up after MW_MC_CHAIN steps or at an exact tie on an owned column and
+// leaves its row for the path searches.
+// measured on the base recipe's refreshes (9 x 1024^2, 13 racers for the searches, same box; one-workgroup form 9.4-10.3 ms):
+// chains of 64 / 256 / 1024 steps on 8 workgroups per problem 7.5-8.1 / 7.1-8.0 / 8.5-9.0 ms (a chain is sequential: 5 us per
+// step alone), 16 or 28 workgroups no better than 8 (more commits collide).
+#ifndef MW_MC_CHAIN
+#define MW_MC_CHAIN 256
+#endif
+#define MW_LOCKED (-2)
+template <int CPL>
+__global__ __launch_bounds__(64 * MW_NW) void lap_mc_arr_kernel(JvArgs a) {
+    const int n = a.n, b = blockIdx.y, lane = threadIdx.x & 63;
+    double *price = a.mc_price + (size_t)b * n;
+    int *owner = a.mc_owner + (size_t)b * n, *assigned = a.mc_assigned + (size_t)b * n, *next = a.mc_next + (size_t)b * n;
+    const int *flist = a.mc_list + (size_t)b * n;
+    int *cnt = a.mc_cnt + 8 * b;
+    const float *S_ = a.src + (size_t)b * n * 3, *T_ = a.tgt + (size_t)b * n * 3;
+    const int nfree = cnt[0];
+    jv_f2 tcx[CPL / 2], tcy[CPL / 2], tcz[CPL / 2];
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+        const int j = 64 * k + lane < n ? 64 * k + lane : 0;
+        tcx[k >> 1][k & 1] = T_[3 * j]; tcy[k >> 1][k & 1] = T_[3 * j + 1]; tcz[k >> 1][k & 1] = T_[3 * j + 2];
+    }
+    auto ld_i = [](const int *p) -> int { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto ld_d = [](const double *p) -> double { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    int my_arr = 0, my_conf = 0;
+    for (;;) {
+        int q = 0;
+        if (lane == 0) q = __hip_atomic_fetch_add(&cnt[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        q = mw_uniform(q);
+        if (q >= nfree) break;
+        int i = flist[q];
+        for (int budget = MW_MC_CHAIN; ; ) {
+            const float ax = S_[3 * i], ay = S_[3 * i + 1], az = S_[3 * i + 2];
+            float rc[CPL];
+            mw_row_costs<CPL>(ax, ay, az, tcx, tcy, tcz, rc);
+            double v1 = INFINITY, v2 = INFINITY;
+            int j1 = 0x7fffffff, pay = 0;
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) {
+                const int j = 64 * k + lane;
+                lap_top2_push((double)rc[k] + (j < n ? ld_d(price + j) : INFINITY), j, v1, j1, v2);
+            }
+            lap_wave_top2_fast(v1, j1, v2, pay);
+            if (!(v1 < INFINITY)) { if (lane == 0) __hip_atomic_store(&cnt[6], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            const double pj1 = ld_d(price + j1);
+            const int own = ld_i(owner + j1);
+            const bool consistent = own != MW_LOCKED &&
+                                    (double)sqrtf(reart_sqdist3(ax, ay, az, T_[3 * j1], T_[3 * j1 + 1], T_[3 * j1 + 2])) + pj1 == v1;
+            const bool tie = !(v1 < v2);
+            if (consistent && (--budget < 0 || (tie && own >= 0))) {           // out of budget / an exact tie on an owned column
+                if (lane == 0) next[__hip_atomic_fetch_add(&cnt[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = i;
+                break;
+            }
+            int ok = 0;
+            if (consistent && lane == 0) {
+                int seen = own;
+                if (__hip_atomic_compare_exchange_strong(owner + j1, &seen, MW_LOCKED, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    if (ld_d(price + j1) == pj1) {
+                        if (!tie) __hip_atomic_store(price + j1, pj1 + (v2 - v1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(assigned + i, j1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (own >= 0) __hip_atomic_store(assigned + own, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(owner + j1, i, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                        ok = 1;
+                    } else __hip_atomic_store(owner + j1, own, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            ok = mw_uniform(ok);
+            if (!ok) { ++my_conf; continue; }
+            ++my_arr;
+            if (own < 0) break;
+            i = own;
+        }
+    }
+    if (lane == 0) {
+        __hip_atomic_fetch_add(&cnt[3], my_arr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&cnt[4], my_conf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 int reart_internal_jvmw_nmax() { return 64 * 32; }
 
 template <int CPL>
 static int mw_launch(const JvArgs &a, int racers, hipStream_t stream) {
     const size_t lds = (size_t)a.n * (8 + 4 * 4 + 6 * 4);
     if (lds > REART_LDS_DEFAULT_CAP &&
-        hipFuncSetAttribute((const void *)lap_jvmw_kernel<CPL>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)
+        hipFuncSetAttribute((const void *)lap_jvmw_kernel<CPL, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)
         return REART_ERR_LAUNCH;
-    hipLaunchKernelGGL((lap_jvmw_kernel<CPL>), dim3(a.B, racers), dim3(64 * MW_NW), lds, stream, a);
+    hipLaunchKernelGGL((lap_jvmw_kernel<CPL, 0>), dim3(a.B, racers), dim3(64 * MW_NW), lds, stream, a);
     REART_CHECK_LAUNCH();
     return REART_OK;
 }
@@ -392,4 +511,29 @@ int reart_internal_jvmw_launch(const JvArgs &a, int racers, hipStream_t stream) 
     if (a.n <= 512) return mw_launch<8>(a, racers, stream);
     if (a.n <= 1024) return mw_launch<16>(a, racers, stream);
     return mw_launch<32>(a, racers, stream);
+}
+
+template <int CPL>
+static int mc_launch(const JvArgs &a, int racers, int arr_wgs, hipStream_t stream) {
+    const size_t lds = (size_t)a.n * (8 + 4 * 4 + 6 * 4);
+    if (lds > REART_LDS_DEFAULT_CAP &&
+        (hipFuncSetAttribute((const void *)lap_jvmw_kernel<CPL, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess ||
+         hipFuncSetAttribute((const void *)lap_jvmw_kernel<CPL, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess))
+        return REART_ERR_LAUNCH;
+    JvArgs s1 = a;
+    s1.done = nullptr;                                   // the set-up reads the caller's assignment and potentials themselves
+    hipLaunchKernelGGL((lap_jvmw_kernel<CPL, 1>), dim3(a.B), dim3(64 * MW_NW), lds, stream, s1);
+    REART_CHECK_LAUNCH();
+    hipLaunchKernelGGL((lap_mc_arr_kernel<CPL>), dim3(arr_wgs, a.B), dim3(64 * MW_NW), 0, stream, a);
+    REART_CHECK_LAUNCH();
+    hipLaunchKernelGGL((lap_jvmw_kernel<CPL, 2>), dim3(a.B, racers), dim3(64 * MW_NW), lds, stream, a);
+    REART_CHECK_LAUNCH();
+    return REART_OK;
+}
+
+int reart_internal_jvmc_launch(const JvArgs &a, int racers, int arr_wgs, hipStream_t stream) {
+    if (a.n < 1 || a.n > reart_internal_jvmw_nmax() || !a.src || !a.tgt || !a.pre_v1 || !a.mc_price || arr_wgs < 1) return REART_ERR_UNSUPPORTED;
+    if (a.n <= 512) return mc_launch<8>(a, racers, arr_wgs, stream);
+    if (a.n <= 1024) return mc_launch<16>(a, racers, arr_wgs, stream);
+    return mc_launch<32>(a, racers, arr_wgs, stream);
 }

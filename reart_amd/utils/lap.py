@@ -162,6 +162,12 @@ RESOLVE_RACERS = int(os.environ.get("REART_RESOLVE_RACERS", "13"))
 # kinematic projection's 19 x 2048^2 re-solve measured 24.5 ms against 20.4 ms, so the default stops at 1024)
 MW_NMIN, MW_NMAX = 512, int(os.environ.get("REART_RESOLVE_MW_NMAX", "1024"))
 RESOLVE_PER_WAVE = os.environ.get("REART_RESOLVE_MW", "1") != "0"
+# workgroups per problem of the row reduction on many compute units (reart_lap_resolve_points_mc); 0: the one-workgroup form
+RESOLVE_ARR_WGS = int(os.environ.get("REART_RESOLVE_ARR_WGS", "-1"))     # -1: up to eight, as many as the batch leaves room for
+
+
+def _arr_wgs(B):
+    return RESOLVE_ARR_WGS if RESOLVE_ARR_WGS >= 0 else max(1, min(8, 256 // max(B, 1)))
 
 
 def _resolve_racers(B, n, race=True):
@@ -185,7 +191,8 @@ def linear_sum_assignment_points(src, tgt, state, return_stats=False, race=True,
     kept in ``state`` are the winner's.
     ``per_wave`` (default: on for 512 <= n <= 1024; the kernel takes up to 2048): every wave of a problem's workgroup follows its own free row and commits
     under a lock (``reart_lap_resolve_points_mw``) instead of the whole workgroup following one row at a time: same optimum,
-    timing-dependent potentials (like a race).
+    timing-dependent potentials (like a race).  ``per_wave=("mc", W)``: the row reduction of every problem on W workgroups
+    (``reart_lap_resolve_points_mc``).
     ``device_cols=True``: returns ``(cols, fallbacks)`` with ``cols`` the [B,n] int64 DEVICE tensor of assigned columns (rows
     are 0..n-1) instead of the host lists -- a loop that feeds the pairs back to the GPU (``RelaxEngine.set_assignment``) then
     only reads the B certificate flags on the host."""
@@ -210,7 +217,12 @@ def linear_sum_assignment_points(src, tgt, state, return_stats=False, race=True,
         _lib.workspace(nb, src.device)[off:off + 16 * B].zero_()
     if per_wave is None:
         per_wave = RESOLVE_PER_WAVE
-    if per_wave and MW_NMIN <= n <= MW_NMAX:
+    arr_wgs = int(per_wave[1]) if isinstance(per_wave, tuple) else (_arr_wgs(B) if per_wave else 0)
+    if per_wave and MW_NMIN <= n <= MW_NMAX and arr_wgs > 0:
+        ws = _lib.workspace(L.reart_lap_mc_workspace_bytes(B, n, racers), src.device)
+        rc = L.reart_lap_resolve_points_mc(_lib.ptr(src), _lib.ptr(tgt), B, n, racers, min(arr_wgs, 256), _lib.ptr(col), _lib.ptr(cert),
+                                           _lib.ptr(prices), _lib.ptr(prices), _lib.ptr(ws), ws.numel(), _lib.stream())
+    elif per_wave and MW_NMIN <= n <= MW_NMAX:
         ws = _lib.workspace(L.reart_lap_race_workspace_bytes(B, n, racers), src.device)
         rc = L.reart_lap_resolve_points_mw(_lib.ptr(src), _lib.ptr(tgt), B, n, racers, _lib.ptr(col), _lib.ptr(cert),
                                            _lib.ptr(prices), _lib.ptr(prices), _lib.ptr(ws), ws.numel(), _lib.stream())
@@ -244,7 +256,7 @@ def linear_sum_assignment_points(src, tgt, state, return_stats=False, race=True,
         off = ((8 * B * n + 255) // 256) * 256
         st = ws[off:off + 16 * B].view(torch.int32).reshape(B, 4).cpu().numpy().copy()
         if per_wave and MW_NMIN <= n <= MW_NMAX:      # the per-wave row reduction reports its redone steps in the upper half
-            state["commit_conflicts"] = st[:, 1] >> 16
+            state["commit_conflicts"] = (st[:, 1] >> 16) & 0xffff
             st[:, 1] &= 0xffff
         return (state["cols"].long() if device_cols else out), fallbacks, st
     return (out, fallbacks) if return_stats else out

@@ -302,9 +302,11 @@ def test_race_with_warm_racers_over_a_moving_sequence(dev):
         a = (a + rng.normal(0, 0.002 if step != 3 else 0.05, a.shape)).astype(np.float32)      # step 3: the problems jump
 
 
-@pytest.mark.parametrize("n,racers", [(1024, None), (600, None), (512, 1), (1024, 1)])
-def test_resolve_per_wave_gives_the_optimum(dev, n, racers):
-    """reart_lap_resolve_points_mw (one search per wave, optimistic commits): a sequence of moved problems, each re-solved
+@pytest.mark.parametrize("n,racers,form", [(1024, None, True), (600, None, True), (512, 1, True), (1024, 1, True),
+                                            (1024, None, ("mc", 16)), (700, 1, ("mc", 3)), (1024, 2, ("mc", 28))])
+def test_resolve_per_wave_gives_the_optimum(dev, n, racers, form):
+    """reart_lap_resolve_points_mw (row reduction one chain per wave, optimistic commits) and reart_lap_resolve_points_mc (the
+    chains of a problem on several workgroups, lock-free commits on state in memory): a sequence of moved problems, each re-solved
     from the previous optimum -- smoothly moved, partly scrambled (rows that jump, like the base model's resampled labels),
     identical -- always the certified optimum scipy returns, never through the host solver."""
     import oracle
@@ -326,7 +328,7 @@ def test_resolve_per_wave_gives_the_optimum(dev, n, racers):
             elif k != 4:                    # k == 4: the same problem again
                 src = (src + rng.normal(0, 0.002, src.shape)).astype(np.float32)
             s, t = torch.from_numpy(src).to(dev), torch.from_numpy(tgt).to(dev)
-            out, fb, st = lap.linear_sum_assignment_points(s, t, state, return_stats="full", per_wave=True)
+            out, fb, st = lap.linear_sum_assignment_points(s, t, state, return_stats="full", per_wave=form)
             assert fb == 0
             ref = oracle.linear_sum_assignment(oracle.cdist(src, tgt))
             for b, (r, c) in enumerate(out):

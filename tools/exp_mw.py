@@ -42,15 +42,16 @@ for k in range(int(os.environ.get("REPS", 8))):
     if k == 0:
         out = lap.linear_sum_assignment_points(src_pts, tgt_pts, state)
     else:
-        for racers in (1, 13):
+        forms = [(13, True)] + [(13, ("mc", w)) for w in (8, 16)]
+        for racers, form in forms:
             lap.RESOLVE_RACERS = racers
             js = {"prices": state["prices"].clone(), "cols": state["cols"].clone()}
             if has_phase:
                 L.reart_debug_mw_phase(buf, 1)
             torch.cuda.synchronize(); t0 = time.perf_counter()
-            out, fb, st = lap.linear_sum_assignment_points(src_pts, tgt_pts, js, return_stats="full", per_wave=True)
+            out, fb, st = lap.linear_sum_assignment_points(src_pts, tgt_pts, js, return_stats="full", per_wave=form)
             torch.cuda.synchronize(); ms = 1e3 * (time.perf_counter() - t0)
-            line = f"refresh {k} racers {racers:2d}: {ms:6.2f} ms fb {fb} left {st[:, 1].tolist()} steps {st[:, 2].tolist()} arr {(st[:, 3] >> 8).tolist()} conf {js.get('commit_conflicts', np.zeros(1)).tolist()}"
+            line = f"refresh {k} racers {racers:2d} form {form}: {ms:6.2f} ms fb {fb} left {st[:, 1].tolist()} steps {st[:, 2].tolist()} arr {(st[:, 3] >> 8).tolist()} conf {js.get('commit_conflicts', np.zeros(1)).tolist()}"
             print(line)
             if has_phase:
                 L.reart_debug_mw_phase(buf, 0)
