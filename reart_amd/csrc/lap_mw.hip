@@ -48,7 +48,20 @@ extern "C" int reart_debug_mw_phase(unsigned long long *out, int reset) {
 #define MWP_ADD(k, v) do { if (lane == 0 && blockIdx.y == 0 && blockIdx.x < 64) atomicAdd(&g_mw_phase[blockIdx.x * 10 + (k)], (unsigned long long)(v)); } while (0)
 #define MWP_MAX(k, v) do { if (lane == 0 && blockIdx.y == 0 && blockIdx.x < 64) atomicMax(&g_mw_phase[blockIdx.x * 10 + (k)], (unsigned long long)(v)); } while (0)
 #define MWP_NOW() wall_clock64()
+// s_memtime ticks of the search step's sections, wave 0 of workgroup (0, 0): arg-min | barrier | merge | reads | relaxation
+__device__ unsigned long long g_mw_step[8];
+extern "C" int reart_debug_mw_step(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mw_step), sizeof(g_mw_step)) != hipSuccess) return REART_ERR_LAUNCH;
+    if (reset) { static unsigned long long z[8]; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_mw_step), z, sizeof(z)); }
+    return REART_OK;
+}
+#define MWS_DECL unsigned long long mws_t = __builtin_amdgcn_s_memtime(), mws[6] = {0, 0, 0, 0, 0, 0}
+#define MWS(k) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); mws[k] += n_ - mws_t; mws_t = n_; } while (0)
+#define MWS_FLUSH() do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) for (int k_ = 0; k_ < 6; ++k_) g_mw_step[k_] += mws[k_]; } while (0)
 #else
+#define MWS_DECL do { } while (0)
+#define MWS(k) do { } while (0)
+#define MWS_FLUSH() do { } while (0)
 #define MWP_ADD(k, v) do { } while (0)
 #define MWP_MAX(k, v) do { } while (0)
 #define MWP_NOW() 0ull
@@ -76,6 +89,20 @@ __device__ __forceinline__ void mw_unlock(int *lock) {
 __device__ __forceinline__ int mw_flag(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ int mw_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// sqrtf(x) for x >= 0, bit for bit: v_sqrt_f32 (within one unit in the last place) and the library's own correction -- the
+// neighbours s -/+ 1 ulp judged by the sign of their residuals -- without its range scaling for inputs below 2^-96 and its
+// class test (zero needs neither: the residuals of 0 are NaN and 0, nothing is selected); such inputs take sqrtf itself.
+// Five instructions fewer per square root on a step that is bound by the instructions it issues.
+__device__ __forceinline__ float mw_sqrt(float x) {
+    if (__builtin_expect(x < 0x1p-96f && x > 0.f, 0)) return sqrtf(x);
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float sm = __int_as_float(__float_as_int(s) - 1), sp = __int_as_float(__float_as_int(s) + 1);
+    const float rm = fmaf(-sm, s, x), rp = fmaf(-sp, s, x);
+    float r = rm <= 0.f ? sm : s;
+    r = rp > 0.f ? sp : r;
+    return r;
+}
+
 // this lane's CPL costs of row (ax, ay, az): reart_cdist's expression, two columns per packed-fp32 operand
 template <int CPL>
 __device__ __forceinline__ void mw_row_costs(float ax, float ay, float az, const jv_f2 (&tcx)[CPL / 2], const jv_f2 (&tcy)[CPL / 2],
@@ -85,7 +112,7 @@ __device__ __forceinline__ void mw_row_costs(float ax, float ay, float az, const
     for (int k = 0; k < CPL / 2; ++k) {
         const jv_f2 dx = ax2 - tcx[k], dy = ay2 - tcy[k], dz = az2 - tcz[k];
         const jv_f2 sq = (dx * dx + dy * dy) + dz * dz;
-        rc[2 * k] = sqrtf(sq.x); rc[2 * k + 1] = sqrtf(sq.y);
+        rc[2 * k] = mw_sqrt(sq.x); rc[2 * k + 1] = mw_sqrt(sq.y);
     }
 }
 
@@ -104,6 +131,7 @@ __global__ __launch_bounds__(64 * MW_NW) void lap_jvmw_kernel(JvArgs a) {
     int *next = flist + n;                                              // [n] rows left for the path search
     float *psx = (float *)(next + n), *psy = psx + n, *psz = psy + n;   // source points
     float *ptx = psz + n, *pty = ptx + n, *ptz = pty + n;               // target points (wave-uniform reads of one column)
+    double *hcol = (double *)(ptz + n);                                 // [n] searches: potential of the row that owns the column
     __shared__ MwShared sh;
     __shared__ double s_red[MW_NW];
     __shared__ int s_cw[MW_NW];
@@ -241,7 +269,7 @@ __global__ __launch_bounds__(64 * MW_NW) void lap_jvmw_kernel(JvArgs a) {
             // what the decision rests on: the arg-min column's price and owner (wave-uniform reads)
             const double pj1 = price[j1];
             const int own = owner[j1];
-            const bool consistent = (double)sqrtf(reart_sqdist3(ax, ay, az, ptx[j1], pty[j1], ptz[j1])) + pj1 == v1;
+            const bool consistent = (double)mw_sqrt(reart_sqdist3(ax, ay, az, ptx[j1], pty[j1], ptz[j1])) + pj1 == v1;
             const bool tie = !(v1 < v2);
             int bud = 0;
             if (lane == 0) bud = atomicSub(&sh.budget, 1);
@@ -297,6 +325,14 @@ __global__ __launch_bounds__(64 * MW_NW) void lap_jvmw_kernel(JvArgs a) {
         pj[k] = j < n ? price[j] : INFINITY;
         if (j >= n) deadq |= 1u << k;
     }
+    // a matched row's potential is the cost of its own pair, c_i,s(i) + p_s(i) (tight by construction): kept per COLUMN and
+    // rewritten, with the same expression the relaxations use, whenever a search has moved the column's price or owner
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+        const int j = tid + k * BS;
+        const int i = j < n ? owner[j] : -1;
+        if (i >= 0) hcol[j] = (double)mw_sqrt(reart_sqdist3(psx[i], psy[i], psz[i], qx[k], qy[k], qz[k])) + pj[k];
+    }
     int *cpred = flist;                                   // the free-row list is spent: column -> row it was reached from
     // (Also measured: rounds that settle several columns -- every wave's closest column a candidate, candidates relaxed from
     // ahead of their turn, the sorted ready prefix settled together, profiles/r04_lap_speculative_rounds_variant.hip.txt.
@@ -307,6 +343,7 @@ __global__ __launch_bounds__(64 * MW_NW) void lap_jvmw_kernel(JvArgs a) {
     __shared__ int s_rj[2][MW_NW], s_lostp[2];
     if (tid == 0) { s_lostp[0] = 0; s_lostp[1] = 0; }
     bool aborted = mw_flag(&sh.abort_) != 0, unsolved = mw_flag(&sh.unsolved) != 0;     // uniform: read after the barrier
+    MWS_DECL;
     for (int f = 0; f < nleft && !aborted && !unsolved; ++f) {
         const int i0 = next[jv_order(f, nleft, racer)];
         double d[CPT];
@@ -316,12 +353,13 @@ __global__ __launch_bounds__(64 * MW_NW) void lap_jvmw_kernel(JvArgs a) {
 #pragma unroll
             for (int k = 0; k < CPT; ++k) {
                 const int j = tid + k * BS;
-                d[k] = (double)sqrtf(reart_sqdist3(ax, ay, az, qx[k], qy[k], qz[k])) + pj[k];       // labels up to the row's potential
+                d[k] = (double)mw_sqrt(reart_sqdist3(ax, ay, az, qx[k], qy[k], qz[k])) + pj[k];     // labels up to the row's potential
                 if (j < n) { cpred[j] = i0; if (owner[j] < 0) freecol |= 1u << k; }
             }
         }
         double mu = 0.0;
         int sink = -1;
+        MWS(5);
         for (int it = 0; ; ++it) {
             double bv = INFINITY;
             int bj = 0x7fffffff;
@@ -335,27 +373,34 @@ __global__ __launch_bounds__(64 * MW_NW) void lap_jvmw_kernel(JvArgs a) {
             const int par = it & 1;
             if (lane == 0) { s_rv[par][wv] = bv; s_rj[par][wv] = bj; }
             if (race && tid == 0) s_lostp[par] = (it & (MW_CHECK - 1)) == 0 ? lost() : s_lostp[par ^ 1];
+            MWS(0);
             __syncthreads();
+            MWS(1);
             if (race && s_lostp[par]) { aborted = true; break; }            // uniform: everybody reads the step's slot
             bv = lane < MW_NW ? s_rv[par][lane] : INFINITY; bj = lane < MW_NW ? s_rj[par][lane] : 0x7fffffff;
             lap_lanes_argmin<(MW_NW <= 2 ? 1 : (MW_NW <= 4 ? 2 : (MW_NW <= 8 ? 3 : 4)))>(bv, bj);
             ++my_steps;
             mu = bv;
+            MWS(2);
             if (bj == 0x7fffffff || !(bv < INFINITY)) { unsolved = true; break; }          // non-finite costs only
             const int jstar = bj & ~JV_OWNED;
             if ((jstar & (BS - 1)) == tid) scanned |= 1u << (jstar / BS);
             const int i = owner[jstar];
             if (i < 0) { sink = jstar; break; }
             const float ax = psx[i], ay = psy[i], az = psz[i];
-            // row i's potential is the cost of its own pair (tight by construction)
-            const double h = (double)sqrtf(reart_sqdist3(ax, ay, az, ptx[jstar], pty[jstar], ptz[jstar])) + price[jstar];
+            const double h = hcol[jstar];                                  // row i's potential
+#ifdef REART_PRUNE_PHASE
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+            MWS(3);
 #pragma unroll
             for (int k = 0; k < CPT; ++k) {
-                const double nd = mu + (((double)sqrtf(reart_sqdist3(ax, ay, az, qx[k], qy[k], qz[k])) + pj[k]) - h);
+                const double nd = mu + (((double)mw_sqrt(reart_sqdist3(ax, ay, az, qx[k], qy[k], qz[k])) + pj[k]) - h);
                 const bool better = !((scanned >> k) & 1u) && nd < d[k];
                 d[k] = better ? nd : d[k];
                 if (better) cpred[tid + k * BS] = i;
             }
+            MWS(4);
         }
         if (aborted || unsolved) break;
 #pragma unroll
@@ -375,7 +420,16 @@ __global__ __launch_bounds__(64 * MW_NW) void lap_jvmw_kernel(JvArgs a) {
             }
         }
         __syncthreads();
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {                    // the labelled columns have new prices, those on the path new owners
+            const int j = tid + k * BS;
+            if (((scanned & ~deadq) >> k) & 1u) {
+                const int i = owner[j];
+                hcol[j] = (double)mw_sqrt(reart_sqdist3(psx[i], psy[i], psz[i], qx[k], qy[k], qz[k])) + pj[k];
+            }
+        }
     }
+    MWS_FLUSH();
     if (tid == 0 && aborted) sh.abort_ = 1;
     if (tid == 0 && unsolved) sh.unsolved = 1;
     if (wv != 0) my_steps = 0;                             // every wave counted the same steps
@@ -461,7 +515,7 @@ __global__ __launch_bounds__(64 * MW_NW) void lap_mc_arr_kernel(JvArgs a) {
             const double pj1 = ld_d(price + j1);
             const int own = ld_i(owner + j1);
             const bool consistent = own != MW_LOCKED &&
-                                    (double)sqrtf(reart_sqdist3(ax, ay, az, T_[3 * j1], T_[3 * j1 + 1], T_[3 * j1 + 2])) + pj1 == v1;
+                                    (double)mw_sqrt(reart_sqdist3(ax, ay, az, T_[3 * j1], T_[3 * j1 + 1], T_[3 * j1 + 2])) + pj1 == v1;
             const bool tie = !(v1 < v2);
             if (consistent && (--budget < 0 || (tie && own >= 0))) {           // out of budget / an exact tie on an owned column
                 if (lane == 0) next[__hip_atomic_fetch_add(&cnt[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = i;
@@ -497,7 +551,7 @@ int reart_internal_jvmw_nmax() { return 64 * 32; }
 
 template <int CPL>
 static int mw_launch(const JvArgs &a, int racers, hipStream_t stream) {
-    const size_t lds = (size_t)a.n * (8 + 4 * 4 + 6 * 4);
+    const size_t lds = (size_t)a.n * (8 + 4 * 4 + 6 * 4 + 8);
     if (lds > REART_LDS_DEFAULT_CAP &&
         hipFuncSetAttribute((const void *)lap_jvmw_kernel<CPL, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)
         return REART_ERR_LAUNCH;
@@ -515,7 +569,7 @@ int reart_internal_jvmw_launch(const JvArgs &a, int racers, hipStream_t stream) 
 
 template <int CPL>
 static int mc_launch(const JvArgs &a, int racers, int arr_wgs, hipStream_t stream) {
-    const size_t lds = (size_t)a.n * (8 + 4 * 4 + 6 * 4);
+    const size_t lds = (size_t)a.n * (8 + 4 * 4 + 6 * 4 + 8);
     if (lds > REART_LDS_DEFAULT_CAP &&
         (hipFuncSetAttribute((const void *)lap_jvmw_kernel<CPL, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess ||
          hipFuncSetAttribute((const void *)lap_jvmw_kernel<CPL, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess))

@@ -158,9 +158,9 @@ RESOLVE_RACERS = int(os.environ.get("REART_RESOLVE_RACERS", "13"))
 
 
 # one search per wave (reart_lap_resolve_points_mw, csrc/lap_mw.hip) where its waves hold a whole problem in registers
-# (the kernel takes n <= 2048; above 1024 -- 32 columns per lane -- its chains lose to the workgroup-wide row reduction: the
-# kinematic projection's 19 x 2048^2 re-solve measured 24.5 ms against 20.4 ms, so the default stops at 1024)
-MW_NMIN, MW_NMAX = 512, int(os.environ.get("REART_RESOLVE_MW_NMAX", "1024"))
+# (Above 1024 columns -- 32 per lane -- the chains of ONE workgroup lose to the workgroup-wide row reduction: 24.5 against
+# 20.4 ms per re-solve of the kinematic projection's 19 x 2048^2; spread over eight workgroups per problem they win: 16.6 ms.)
+MW_NMIN, MW_NMAX = 512, int(os.environ.get("REART_RESOLVE_MW_NMAX", "2048"))
 RESOLVE_PER_WAVE = os.environ.get("REART_RESOLVE_MW", "1") != "0"
 # workgroups per problem of the row reduction on many compute units (reart_lap_resolve_points_mc); 0: the one-workgroup form
 RESOLVE_ARR_WGS = int(os.environ.get("REART_RESOLVE_ARR_WGS", "-1"))     # -1: up to eight, as many as the batch leaves room for
@@ -189,7 +189,7 @@ def linear_sum_assignment_points(src, tgt, state, return_stats=False, race=True,
     ``race`` (default on): idle compute units run the same re-solve with the free rows taken in other orders and the first
     to finish publishes (``reart_lap_resolve_points_race``) -- the same optimum sooner; as with the cold race, the potentials
     kept in ``state`` are the winner's.
-    ``per_wave`` (default: on for 512 <= n <= 1024; the kernel takes up to 2048): every wave of a problem's workgroup follows its own free row and commits
+    ``per_wave`` (default: on for 512 <= n <= 2048): every wave of a problem's workgroup follows its own free row and commits
     under a lock (``reart_lap_resolve_points_mw``) instead of the whole workgroup following one row at a time: same optimum,
     timing-dependent potentials (like a race).  ``per_wave=("mc", W)``: the row reduction of every problem on W workgroups
     (``reart_lap_resolve_points_mc``).

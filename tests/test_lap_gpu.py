@@ -351,7 +351,7 @@ def test_resolve_per_wave_at_2048(dev):
     src = (tgt[:, rng.permutation(n)] + rng.normal(0, 0.005, (B, n, 3))).astype(np.float32)
     state = {}
     old = lap.MW_NMAX
-    lap.MW_NMAX = 2048               # opt in: the default stops at 1024 (measured slower above)
+    lap.MW_NMAX = 2048
     try:
         outs = []
         for k in range(3):

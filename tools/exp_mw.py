@@ -42,7 +42,7 @@ for k in range(int(os.environ.get("REPS", 8))):
     if k == 0:
         out = lap.linear_sum_assignment_points(src_pts, tgt_pts, state)
     else:
-        forms = [(13, True)] + [(13, ("mc", w)) for w in (8, 16)]
+        forms = [(1, ("mc", 8))]
         for racers, form in forms:
             lap.RESOLVE_RACERS = racers
             js = {"prices": state["prices"].clone(), "cols": state["cols"].clone()}
@@ -53,6 +53,11 @@ for k in range(int(os.environ.get("REPS", 8))):
             torch.cuda.synchronize(); ms = 1e3 * (time.perf_counter() - t0)
             line = f"refresh {k} racers {racers:2d} form {form}: {ms:6.2f} ms fb {fb} left {st[:, 1].tolist()} steps {st[:, 2].tolist()} arr {(st[:, 3] >> 8).tolist()} conf {js.get('commit_conflicts', np.zeros(1)).tolist()}"
             print(line)
+            if hasattr(L, "reart_debug_mw_step"):
+                sb = (ctypes.c_ulonglong * 8)()
+                L.reart_debug_mw_step(sb, 1)
+                tot = sum(sb[:6]) or 1
+                print("    step sections (s_memtime ticks, problem 0 wave 0; share): " + " ".join(f"{nm} {sb[q]} ({100 * sb[q] / tot:.0f}%)" for q, nm in enumerate(["argmin", "barrier", "merge", "reads", "relax", "between"])) + f" | steps {st[0, 2]} -> {tot / max(st[0, 2], 1):.0f} ticks per step")
             if has_phase:
                 L.reart_debug_mw_phase(buf, 0)
                 a = np.array(buf[:], dtype=np.float64).reshape(64, 10)[:B]
