@@ -838,6 +838,13 @@ def main():
         energies = torch.stack(gathered).cpu().numpy()
     else:
         energies = losses[None].cpu().numpy()
+    # who ran what (one small object gather, outside the timed region): the driver's first multi-GPU run should be readable
+    me = {"rank": rank, "device": str(dev), "cano_idx": int(cano_idx)}
+    if distributed:
+        ranks_info = [None] * world
+        dist.all_gather_object(ranks_info, me)
+    else:
+        ranks_info = [me]
 
     # per-phase device time of the same step (eager, HIP events on the launch stream)
     phases = eng.step_timed(args.profile_steps) if args.profile_steps > 0 else {}
@@ -968,6 +975,10 @@ def main():
             "value": round(world * K * args.steps / el, 3),
             "unit": "iterations/s",
             "n_gpus": world,
+            "per_gpu": round(K * args.steps / el, 3),
+            "rccl_world": dist.get_world_size() if distributed else 1,
+            "backend": dist.get_backend() if distributed else None,
+            "ranks": ranks_info,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(1e3 * el / args.steps, 5),

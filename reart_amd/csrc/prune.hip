@@ -220,7 +220,9 @@ __device__ __forceinline__ void knn_pruned_wave(const KnnJob &jb, const int S, c
                 __syncthreads();                     // every live wave of the workgroup runs this prologue (waves >= S have left)
                 for (int t = 0; t < a.S; ++t) thr = fminf(thr, s_xthr[64 * t + lane]);
             }
-            if (!(thr >= 0.f)) thr = INFINITY;      // NaN query
+            // a NaN query: fmaxf / fminf drop the NaN distances (fmaxf(0, NaN) = 0), so the bound would come out 0, not NaN --
+            // test the query itself and prune nothing for it (its lower bounds are NaN and fail every compare: index -1)
+            if (!(qx == qx && qy == qy && qz == qz)) thr = INFINITY;
         } else {
 #pragma unroll
             for (int k = 0; k < KK; ++k) {

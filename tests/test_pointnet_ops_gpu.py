@@ -95,8 +95,16 @@ def test_pointnet2_cuda_wrappers(oracle, dev):
     bidx = torch.zeros((2, 64, 16), dtype=torch.int32, device=dev)
     assert pc.ball_query_wrapper(2, 777, 64, 0.25, 16, t(new, dev), pts, bidx) == 1
     np.testing.assert_array_equal(bidx.cpu().numpy(), oracle.ball_query(0.25, 16, xyz, new, cuda_mode=True))
+    # three_nn_wrapper (dead in the reference, interpolate_gpu.cu:81-131): the three nearest by direct-difference squared
+    # distance = the oracle's K = 3 search
+    d3 = torch.zeros((2, 777, 3), dtype=torch.float32, device=dev)
+    i3 = torch.zeros((2, 777, 3), dtype=torch.int32, device=dev)
+    pc.three_nn_wrapper(2, 777, 64, pts, t(new, dev), d3, i3)
+    dd, ii = oracle.knn_points(xyz, new, K=3)
+    np.testing.assert_array_equal(i3.cpu().numpy(), ii)
+    np.testing.assert_array_equal(d3.cpu().numpy(), dd)
     with pytest.raises(NotImplementedError):
-        pc.three_nn_wrapper()
+        pc.three_interpolate_wrapper()
 
 
 def test_fps_full_size_properties(dev):

@@ -123,3 +123,55 @@ def test_bench_refuses_a_rank_count_that_is_not_gpus():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        env=env, capture_output=True, timeout=300)
     assert r.returncode != 0 and b"--gpus 2" in r.stderr and b"n_gpus" not in r.stdout
+
+
+def _rank4(rank, world, port, seq_root, save_root):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from reart_amd import sweep
+
+    rc = sweep.main(["--seq_root", seq_root, "--cano", "all", "--n_iter", "2", "--energy", "--gpus", str(world), "--shard", "lpt",
+                     "--save_root", save_root], runner=_oracle_runner)
+    assert rc == 0
+
+
+def test_sweep_cli_four_ranks_lpt_with_unequal_sequences(tmp_path):
+    """world 4 (gloo), two sequences of different length (4 and 2 frames: instance costs 2 : 1 by frames x points^2), dealt
+    longest first (--shard lpt): the deal is the documented one, every rank's records arrive under the right instance id
+    (unequal per-rank counts: padded blocks), each sequence gets its own winner, and the line says who ran what."""
+    import shutil
+
+    from reart_amd import sweep
+    from reart_amd.launch import free_port
+
+    root = tmp_path / "seqs"
+    shutil.copytree(os.path.join(SEQ_ROOT, "seq_tiny"), root / "seq_a")
+    (root / "seq_b").mkdir()
+    for f in ("state_0.pkl", "state_1.pkl", "pose_1.pkl"):            # a 2-frame sequence in the reference's layout
+        shutil.copy(os.path.join(SEQ_ROOT, "seq_tiny", f), root / "seq_b" / f)
+    seqs = sweep.list_sequences(str(root))
+    assert [(n, t) for n, _, t in seqs] == [("seq_a", 4), ("seq_b", 2)]
+    inst = sweep.enumerate_instances(seqs, "all")
+    for s in inst:
+        s["points"] = 4096
+    plan = sweep.deal(inst, 4, "lpt")
+    assert plan == [[0, 4], [1, 5], [2], [3]]                          # the four long instances first, one per rank; the short ones fill up
+    assert sweep.deal(inst, 4, "round_robin") == [[0, 4], [1, 5], [2], [3]]
+    assert sweep.deal(list(reversed(inst)), 4, "lpt") == [[2, 0], [3, 1], [4], [5]]   # order of enumeration does not matter to LPT
+    out = tmp_path / "out"
+    ctx = mp.get_context("spawn")
+    port = free_port()
+    procs = [ctx.Process(target=_rank4, args=(r, 4, port, str(root), str(out))) for r in range(4)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    sw = json.load(open(out / "sweep.json"))
+    assert sw["world_size"] == 4 and sw["rccl_world"] == 4 and sw["backend"] == "gloo" and sw["shard"] == "lpt"
+    assert sw["n_instances"] == 6 and [r["instances"] for r in sw["ranks"]] == plan
+    a, b = sw["sequences"]["seq_a"]["instances"], sw["sequences"]["seq_b"]["instances"]
+    assert [r["rank"] for r in a] == [0, 1, 2, 3] and [r["rank"] for r in b] == [0, 1]
+    assert [r["cano_idx"] for r in a] == [0, 1, 2, 3] and [r["cano_idx"] for r in b] == [0, 1]
+    assert a[3]["failed"] == 1 and all(r["failed"] == 0 for r in a[:3] + b)        # the injected failure is reported, nothing else lost
+    assert sw["sequences"]["seq_a"]["winner_cano_idx"] == 2 and sw["sequences"]["seq_b"]["winner_cano_idx"] == 1
