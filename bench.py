@@ -874,12 +874,20 @@ def main():
             executed = prof["pairs"] / prof["launches"]
             ach = executed * 8 / t_nn / 1e12
             traffic = None
-            pmc = os.path.join(ROOT, "profiles", "r03_pmc_search.json")
-            if os.path.exists(pmc) and use_flow:
-                pj = json.load(open(pmc))
+            pmc_file = next((f for f in (os.path.join(ROOT, "profiles", "r04_pmc_search.json"), os.path.join(ROOT, "profiles", "r03_pmc_search.json"))
+                             if os.path.exists(f)), None)
+            if use_flow and T == 20 and N == 4096 and pmc_file:
+                import hashlib
+
+                pj = json.load(open(pmc_file))
+                stamps = pj.get("measured_on_sources_sha256_16", {})
+                same = bool(stamps) and all(hashlib.sha256(open(os.path.join(ROOT, p_), "rb").read()).hexdigest()[:16] == h_
+                                            for p_, h_ in stamps.items())
                 traffic = {"bytes_per_launch": pj.get("hbm_bytes_per_launch"),
-                           "source": "static: profiles/r03_pmc_search.json (rocprofv3 --pmc passes of this command, "
-                                     "corrected per MI355X_MICROARCH.md); not measured in this run"}
+                           "source": f"{os.path.relpath(pmc_file, ROOT)}: rocprofv3 --pmc passes of this command (FETCH_SIZE + WRITE_SIZE, "
+                                     f"MI355X_MICROARCH.md); counters cannot be read inside a run, so the figure is the committed "
+                                     f"measurement, stamped with the kernel sources it was taken on",
+                           "measured_on_current_sources": same}
             box_note = None
             ref_ms = 0.0329          # profiles/r03_bench_default.json (a box of the common kind, default window)
             if use_flow and T == 20 and N == 4096 and args.steps >= 300 and k_ms > 1.25 * ref_ms:

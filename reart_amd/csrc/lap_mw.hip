@@ -103,6 +103,39 @@ __device__ __forceinline__ float mw_sqrt(float x) {
     return r;
 }
 
+// (smallest value, its lowest key) over the first 2^STEPS lanes of the wave (STEPS = 6: all of it), every lane gets the result.
+// Two butterflies on 32-bit INTEGERS instead of one on doubles: a double's bit pattern, sign-folded, orders like the number, so
+// the minimum of the high words, then of the low words among the lanes that attain it, is the minimum value -- v_min_u32 with
+// the lane permutation folded in, where the double form takes two moves and a v_min_f64 per step.  Exact ties go by the key.
+template <int STEPS>
+__device__ __forceinline__ unsigned mw_bmin(unsigned x) {
+    x = min(x, (unsigned)reart_bfly<0>((int)x));
+    if (STEPS > 1) x = min(x, (unsigned)reart_bfly<1>((int)x));
+    if (STEPS > 2) x = min(x, (unsigned)reart_bfly<2>((int)x));
+    if (STEPS > 3) x = min(x, (unsigned)reart_bfly<3>((int)x));
+    if (STEPS > 4) x = min(x, (unsigned)reart_bfly<4>((int)x));
+    if (STEPS > 5) x = min(x, (unsigned)reart_bfly<5>((int)x));
+    return STEPS < 6 ? (unsigned)__builtin_amdgcn_readfirstlane((int)x) : x;
+}
+template <int STEPS>
+__device__ __forceinline__ void mw_argmin_key(double &v, int &j) {
+    const bool in = STEPS == 6 || (int)(threadIdx.x & 63) < (1 << STEPS);
+    const int hi = __double2hiint(v), lo = __double2loint(v);
+    const unsigned sg = (unsigned)(hi >> 31);
+    const unsigned kh = in ? (unsigned)hi ^ (sg | 0x80000000u) : 0xffffffffu, kl = (unsigned)lo ^ sg;
+    const unsigned mh = mw_bmin<STEPS>(kh);
+    const unsigned ml = mw_bmin<STEPS>(kh == mh ? kl : 0xffffffffu);
+    const bool at = in && kh == mh && kl == ml;
+    unsigned long long m = __ballot(at);
+    if (__builtin_popcountll(m) > 1) {
+        const unsigned mj = mw_bmin<STEPS>(at ? (unsigned)j : 0xffffffffu);
+        m = __ballot(at && (unsigned)j == mj);
+    }
+    const int wl = m ? __ffsll((long long)m) - 1 : 0;
+    j = __builtin_amdgcn_readlane(j, wl);
+    v = __hiloint2double(__builtin_amdgcn_readlane(hi, wl), __builtin_amdgcn_readlane(lo, wl));
+}
+
 // this lane's CPL costs of row (ax, ay, az): reart_cdist's expression, two columns per packed-fp32 operand
 template <int CPL>
 __device__ __forceinline__ void mw_row_costs(float ax, float ay, float az, const jv_f2 (&tcx)[CPL / 2], const jv_f2 (&tcy)[CPL / 2],
@@ -369,7 +402,7 @@ __global__ __launch_bounds__(64 * MW_NW) void lap_jvmw_kernel(JvArgs a) {
                     const int key = (tid + k * BS) | (((freecol >> k) & 1u) ? 0 : JV_OWNED);       // unowned columns first among ties
                     if (d[k] < bv || (d[k] == bv && key < bj)) { bv = d[k]; bj = key; }
                 }
-            lap_wave_argmin_fast(bv, bj);
+            mw_argmin_key<6>(bv, bj);           // (the double-precision butterfly lap_wave_argmin_fast: 2 800-3 030 ticks per step against 2 710-2 770)
             const int par = it & 1;
             if (lane == 0) { s_rv[par][wv] = bv; s_rj[par][wv] = bj; }
             if (race && tid == 0) s_lostp[par] = (it & (MW_CHECK - 1)) == 0 ? lost() : s_lostp[par ^ 1];
@@ -378,7 +411,7 @@ __global__ __launch_bounds__(64 * MW_NW) void lap_jvmw_kernel(JvArgs a) {
             MWS(1);
             if (race && s_lostp[par]) { aborted = true; break; }            // uniform: everybody reads the step's slot
             bv = lane < MW_NW ? s_rv[par][lane] : INFINITY; bj = lane < MW_NW ? s_rj[par][lane] : 0x7fffffff;
-            lap_lanes_argmin<(MW_NW <= 2 ? 1 : (MW_NW <= 4 ? 2 : (MW_NW <= 8 ? 3 : 4)))>(bv, bj);
+            mw_argmin_key<(MW_NW <= 2 ? 1 : (MW_NW <= 4 ? 2 : (MW_NW <= 8 ? 3 : 4)))>(bv, bj);
             ++my_steps;
             mu = bv;
             MWS(2);

@@ -1,50 +1,53 @@
 #!/bin/bash
 # Measurement evidence of a round, collected on the GPU box (gpurun): the bench lines, rocprofv3 kernel stats of the bench
-# commands and the counter passes of the search kernel.  Outputs under gpurun_out/prof3/ (copied into profiles/ afterwards).
-# Every command runs under `timeout`: a hang must not take the box.
+# commands (restricted to the timed window where warm-up would be averaged in) and the counter passes of the search kernel.
+# Outputs under gpurun_out/prof4/ (the summaries are copied into profiles/ afterwards, named r04_*).
+# Every command runs under `timeout`: a hang must not take the box.  Under rocprofv3 the program itself follows `--`.
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
-O=gpurun_out/prof3
+O=gpurun_out/prof4
 rm -rf $O; mkdir -p $O
 CLEAN="--sweep-instances 0 --no-tail --no-cpu-baseline --no-secondary"
 # gpurun boxes differ: about one in ten runs the search launch 35 % slower than the others (every other kernel the same, four
-# times the fabric traffic on its counters).  The profile set is collected on a box of the common kind; the odd kind is
-# reported and skipped (exit 7) so that the call can simply be repeated.
+# times the fabric traffic on its counters).  Such a box is no longer skipped: the set is collected all the same and TAGGED
+# (slowbox.txt next to it), so that profiles/ can hold one set of each kind side by side.
 KMS=$(timeout 300 python3 bench.py --steps 300 --warmup 150 $CLEAN --profile-steps 0 2>/dev/null | python3 -c "import json,sys; print(json.loads(sys.stdin.read())['roofline']['kernel_ms'])")
-echo "probe: search launch $KMS ms"
+echo "probe: search launch $KMS ms" | tee $O/probe.txt
 if python3 -c "import sys; sys.exit(0 if float('$KMS') > 0.038 else 1)"; then
-  echo "slow-search box: profile set not collected"
-  # what is different about this box?  (kept next to the profiles when it happens: gpurun_out/slowbox_diag.txt)
-  { date; rocm-smi --showcomputepartition --showmemorypartition --showclocks --showperflevel --showpower 2>&1; rocminfo 2>&1 | grep -i -E "xnack|Compute Unit|Max Clock|Cacheline|L2|L3|Marketing|Coherent|Memory Properties" | sort | uniq -c; env | grep -E "^(HSA|HIP|ROC|GPU|AMD)" ; } > gpurun_out/slowbox_diag.txt 2>&1
-  exit 7
+  echo "slow-search box: this set is the SLOW kind" | tee $O/slowbox.txt
+  { date; rocm-smi --showcomputepartition --showmemorypartition --showclocks --showperflevel --showpower 2>&1; rocminfo 2>&1 | grep -i -E "xnack|Compute Unit|Max Clock|Cacheline|L2|L3|Marketing|Coherent|Memory Properties" | sort | uniq -c; env | grep -E "^(HSA|HIP|ROC|GPU|AMD)" ; } >> $O/slowbox.txt 2>&1
 fi
 # 0. the plain bench lines (no profiler)
 timeout 900 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
-timeout 600 python3 bench.py --config kinematic > $O/bench_kinematic.json 2> $O/bench_kinematic.err
-timeout 300 python3 bench.py --config extractor > $O/bench_extractor.json 2> $O/bench_extractor.err
 timeout 300 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > $O/bench_driver_args.json 2> $O/bench_driver_args.err
+timeout 600 python3 bench.py --config kinematic > $O/bench_kinematic.json 2> $O/bench_kinematic.err
+timeout 600 python3 bench.py --config nao_recipe > $O/bench_nao_recipe.json 2> $O/bench_nao_recipe.err
 # 1. kernel stats of the clean headline command (every launch belongs to the measured instance)
 timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $O/stats_clean -- python3 bench.py $CLEAN > $O/bench_clean_under_rocprof.json 2> $O/stats_clean.err
-# 2. counter passes (separate runs, --kernel-trace only), eager launches so that every dispatch is visible
+# 2. counter passes of the search kernel (separate runs, --kernel-trace only), eager launches so that every dispatch is visible
 for C in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_SALU SQ_INSTS_LDS; do
   timeout 600 rocprofv3 --kernel-trace --pmc $C -f csv -d $O/pmc_$C -- python3 bench.py --steps 300 --warmup 150 --no-graph --profile-steps 0 $CLEAN > $O/pmc_$C.json 2> $O/pmc_$C.err
 done
-# 3. the other two configs
-timeout 900 rocprofv3 --kernel-trace --stats -f csv -d $O/stats_kinematic -- python3 bench.py --config kinematic --no-cpu-baseline > $O/bench_kinematic_under_rocprof.json 2> $O/stats_kinematic.err
-timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $O/stats_extractor -- python3 bench.py --config extractor --no-cpu-baseline > $O/bench_extractor_under_rocprof.json 2> $O/stats_extractor.err
-# 4. matrix-core counters of the extractor's dense kernels
-bash tools/pmc_extractor.sh > $O/pmc_extractor.log 2>&1
-python3 tools/pmc_extractor_json.py gpurun_out/pmc_ext > $O/pmc_extractor_mfma.json 2> $O/pmc_extractor_json.err
-# 5. the nao line (BASELINE configs[2])
-timeout 300 python3 bench.py --config nao > $O/bench_nao.json 2> $O/bench_nao.err
+# 3. the kinematic projection and the README recipe: per-dispatch traces, statistics over the TIMED WINDOW only (the last
+#    dispatches of every kernel: the cold solve and the warm-up re-solves that precede the timed iterations stay out)
+timeout 900 rocprofv3 --kernel-trace -f csv -d $O/trace_kinematic -- python3 bench.py --config kinematic --no-cpu-baseline > $O/bench_kinematic_under_rocprof.json 2> $O/trace_kinematic.err
+f=$(find $O/trace_kinematic -name "*kernel_trace.csv" | head -1)
+[ -n "$f" ] && python3 tools/kernel_window_stats.py "$f" --last 100 > $O/kernel_stats_kinematic_window.csv
+timeout 900 rocprofv3 --kernel-trace -f csv -d $O/trace_recipe -- python3 bench.py --config nao_recipe --no-cpu-baseline > $O/bench_nao_recipe_under_rocprof.json 2> $O/trace_recipe.err
+f=$(find $O/trace_recipe -name "*kernel_trace.csv" | head -1)
+[ -n "$f" ] && python3 tools/kernel_window_stats.py "$f" --last 1999 --match lap_ > $O/kernel_stats_nao_recipe_window.csv
+# 4. the README recipe as a sweep on one GPU: 20 canonical frames of one generated sequence, both phases in shared launches
+rm -rf /tmp/sweep_recipe
+timeout 900 python3 -m reart_amd.sweep --synthetic 1 --synthetic_frames 20 --cano all --n_iter 15000 --use_flow_loss --use_assign_loss --energy --save_root /tmp/sweep_recipe > $O/sweep_recipe.line.json 2> $O/sweep_recipe.err
+cp /tmp/sweep_recipe/sweep.json $O/sweep_recipe_20x15000_energy.json 2>/dev/null
 # summaries
-for d in stats_clean stats_kinematic stats_extractor; do
-  f=$(find $O/$d -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/$d.kernel_stats.csv
-done
+f=$(find $O/stats_clean -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/kernel_stats_clean.csv
 for C in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_SALU SQ_INSTS_LDS; do
   python3 tools/pmc_sum.py $O/pmc_$C knn_group > $O/pmc_$C.txt 2>&1
 done
+# the counter summary the bench line cites, stamped with the sources it was measured on
+python3 tools/pmc_search_json.py $O > $O/pmc_search.json 2> $O/pmc_search_json.err
 # keep the merge-back small: only the summaries travel
 find $O -mindepth 1 -maxdepth 1 -type d -exec rm -rf {} +
 ls -la $O
