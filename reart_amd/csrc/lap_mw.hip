@@ -501,11 +501,12 @@ __global__ __launch_bounds__(64 * MW_NW) void lap_jvmw_kernel(JvArgs a) {
 // problem may sit on different XCDs); that a wave works with prices which other waves are raising meanwhile is harmless for
 // the reason given at the top of this file.  A chain gives up after MW_MC_CHAIN steps or at an exact tie on an owned column and
 // leaves its row for the path searches.
-// measured on the base recipe's refreshes (9 x 1024^2, 13 racers for the searches, same box; one-workgroup form 9.4-10.3 ms):
-// chains of 64 / 256 / 1024 steps on 8 workgroups per problem 7.5-8.1 / 7.1-8.0 / 8.5-9.0 ms (a chain is sequential: 5 us per
-// step alone), 16 or 28 workgroups no better than 8 (more commits collide).
+// A chain is sequential (5 us per step at n = 1024, 10 us at 2048: a round of memory-side atomics and two dependent ones), so
+// the launch lasts as long as its longest chain is allowed to.  Measured, chains of 256 / 128 / 64 steps: README recipe
+// (9 x 1024^2) 12.1 / 11.2 s / - for the whole run, kinematic projection (19 x 2048^2) 62.5 / 64.9 / 64.4 iterations/s; on 8
+// workgroups per problem (13, 16 or 28: no better -- more commits collide).  JvArgs.mc_chain overrides.
 #ifndef MW_MC_CHAIN
-#define MW_MC_CHAIN 256
+#define MW_MC_CHAIN 128
 #endif
 #define MW_LOCKED (-2)
 template <int CPL>
@@ -532,7 +533,7 @@ __global__ __launch_bounds__(64 * MW_NW) void lap_mc_arr_kernel(JvArgs a) {
         q = mw_uniform(q);
         if (q >= nfree) break;
         int i = flist[q];
-        for (int budget = MW_MC_CHAIN; ; ) {
+        for (int budget = a.mc_chain; ; ) {
             const float ax = S_[3 * i], ay = S_[3 * i + 1], az = S_[3 * i + 2];
             float rc[CPL];
             mw_row_costs<CPL>(ax, ay, az, tcx, tcy, tcz, rc);
@@ -609,9 +610,11 @@ static int mc_launch(const JvArgs &a, int racers, int arr_wgs, hipStream_t strea
         return REART_ERR_LAUNCH;
     JvArgs s1 = a;
     s1.done = nullptr;                                   // the set-up reads the caller's assignment and potentials themselves
+    JvArgs s2 = a;
+    if (s2.mc_chain <= 0) s2.mc_chain = MW_MC_CHAIN;
     hipLaunchKernelGGL((lap_jvmw_kernel<CPL, 1>), dim3(a.B), dim3(64 * MW_NW), lds, stream, s1);
     REART_CHECK_LAUNCH();
-    hipLaunchKernelGGL((lap_mc_arr_kernel<CPL>), dim3(arr_wgs, a.B), dim3(64 * MW_NW), 0, stream, a);
+    hipLaunchKernelGGL((lap_mc_arr_kernel<CPL>), dim3(arr_wgs, a.B), dim3(64 * MW_NW), 0, stream, s2);
     REART_CHECK_LAUNCH();
     hipLaunchKernelGGL((lap_jvmw_kernel<CPL, 2>), dim3(a.B, racers), dim3(64 * MW_NW), lds, stream, a);
     REART_CHECK_LAUNCH();
