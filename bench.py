@@ -309,18 +309,19 @@ def bench_kinematic(args, dev, rank, world, distributed, barrier):
     steps_total = float(st[:, 2].sum() + (st[:, 3] >> 8).sum())
     roof = {"bound": "latency", "achieved": round(bound_ms, 4), "peak": round(lap_ms, 4), "unit": "ms per re-solve (lower bound / measured)",
             "frac": round(bound_ms / lap_ms, 4) if lap_ms > 0 else None, "traffic": None,
-            "kernel": "lap_jv_kernel<512, points, 1> + two lap_jv_pass_kernel launches (re-solve of the T-1 assignment problems from "
-                      "the previous optimum: row potentials on the whole chip, then augmenting row reduction + shortest augmenting "
-                      "paths with one workgroup per problem -- both point sets and the solver state in LDS --, then the exact dual "
-                      "certificate on the whole chip)",
+            "kernel": "lap_jvmw_kernel<32, 2> (searches) + lap_mc_arr_kernel<32> + set-up + two lap_jv_pass_kernel launches (re-solve of the "
+                      "T-1 assignment problems from the previous optimum: row potentials on the whole chip, augmenting row reduction "
+                      "one chain per wave on eight workgroups per problem, shortest augmenting paths with one workgroup per problem "
+                      "and racer -- the solver state in LDS --, then the exact dual certificate on the whole chip)",
             "kernel_ms": round(lap_ms, 4), "solves_measured": len(loop.lap_events),
             "step_floor_us": round(floor_us.value, 4), "steps_slowest_problem": round(steps_max, 1), "steps_mean_problem": round(steps_mean, 1),
             "cold_solve_ms": round(lap_cold_ms, 3),
-            "note": "latency roofline: a re-solve is a sequential chain of path-search / row-reduction steps per problem on T-1 "
-                    "of the 256 compute units; step_floor_us = the workgroup-wide arg-min over the 2048 labels + its barrier with "
-                    "the solver's own primitives and nothing else (reart_lap_step_floor, measured in this run); achieved = steps "
+            "note": "latency roofline: a re-solve ends with its slowest problem's sequential chain of path-search steps (the row "
+                    "reduction's chains run 64 at a time per problem and are not part of that chain); step_floor_us = the "
+                    "workgroup-wide arg-min over the 2048 labels + its barrier with "
+                    "the solver's own primitives and nothing else (reart_lap_step_floor, measured in this run); achieved = search steps "
                     "of the slowest problem (mean over the timed solves) x floor; frac = achieved / kernel_ms -- what is above it is "
-                    "the step's cost evaluation (4 square roots per lane), relaxation and the two whole-chip passes.  The HBM view "
+                    "the step's relaxation (4 square roots per lane), the row-reduction launch and the two whole-chip passes.  The HBM view "
                     f"is meaningless here ({2 * cost.shape[0] * n * 12} algorithmic bytes per solve).  "
                     "cold_solve_ms: the epsilon-scaling auction from scratch on the same matrices (schedules racing, reart_lap_auction_race)"}
     cpu = None

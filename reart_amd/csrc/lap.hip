@@ -708,7 +708,7 @@ __global__ __launch_bounds__(LAP_BS) void lap_auction_kernel(LapArgs a) {
 extern "C" size_t reart_lap_workspace_bytes(int B, int n);
 // workspace of reart_lap_auction_race: the plain layout, one row-bid array per racer, the `done` flags
 extern "C" size_t reart_lap_race_workspace_bytes(int B, int n, int racers) {
-    if (B < 0 || n < 1 || n > LAP_NMAX || racers < 1 || racers > LAP_RACE_MAX) return 0;
+    if (B < 0 || n < 1 || n > LAP_NMAX || racers < 1 || racers > (LAP_RACE_MAX > JV_RACE_MAX ? LAP_RACE_MAX : JV_RACE_MAX)) return 0;
     return reart_lap_workspace_bytes(B, n) + reart_align_up(sizeof(double) * (size_t)B * n, 256) * (size_t)racers +
            reart_align_up(sizeof(int) * (size_t)B, 256);
 }

@@ -110,8 +110,9 @@ __device__ __forceinline__ void lap_wave_argmin_fast(double &v, int &j) {
     else reart_wave_argmin_d(v, j);
 }
 
-#define JV_RACE_MAX 13
-static __device__ const int jv_race_prime[JV_RACE_MAX] = {0, 0, 4099, 4111, 4127, 4129, 4133, 4139, 4153, 4157, 4159, 4177, 4201};
+#define JV_RACE_MAX 28
+static __device__ const int jv_race_prime[JV_RACE_MAX] = {0, 0, 4099, 4111, 4127, 4129, 4133, 4139, 4153, 4157, 4159, 4177, 4201, 4211,
+                                                          4217, 4219, 4229, 4231, 4241, 4243, 4253, 4259, 4261, 4271, 4273, 4283, 4289, 4297};
 __device__ __forceinline__ int jv_order(int k, int cnt, int racer) {
     if (racer == 0) return k;
     if (racer == 1) return cnt - 1 - k;

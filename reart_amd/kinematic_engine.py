@@ -177,7 +177,9 @@ class KinematicEngine:
             self.lap_fallbacks += fb
             # sequential steps of this solve (path search + row reduction) per problem: slowest problem, mean -- the
             # latency roofline of bench.py multiplies them by the measured floor of one step
-            seq = self.lap_stats[:, 2].astype(np.int64) + (self.lap_stats[:, 3].astype(np.int64) >> 8)
+            seq = self.lap_stats[:, 2].astype(np.int64)
+            if self.lap_state.get("resolve_form", "jv") == "jv":       # one row at a time: the row reduction's steps are sequential too
+                seq = seq + (self.lap_stats[:, 3].astype(np.int64) >> 8)
             self.lap_steps_log.append((int(seq.max()), float(seq.mean())))
             self.lap_winners += np.bincount((self.lap_stats[:, 0] >> 16) & 15, minlength=16)[:16]         # raced re-solves: who finished first
             cols = torch.from_numpy(np.stack([c for _, c in assign])).to(self.dev)

@@ -218,6 +218,8 @@ def linear_sum_assignment_points(src, tgt, state, return_stats=False, race=True,
     if per_wave is None:
         per_wave = RESOLVE_PER_WAVE
     arr_wgs = int(per_wave[1]) if isinstance(per_wave, tuple) else (_arr_wgs(B) if per_wave else 0)
+    # which form ran (statistics mean different things: the row-reduction steps of the chain forms are spread over many waves)
+    state["resolve_form"] = ("mc" if arr_wgs > 0 else "mw") if (per_wave and MW_NMIN <= n <= MW_NMAX) else "jv"
     if per_wave and MW_NMIN <= n <= MW_NMAX and arr_wgs > 0:
         ws = _lib.workspace(L.reart_lap_mc_workspace_bytes(B, n, racers), src.device)
         rc = L.reart_lap_resolve_points_mc(_lib.ptr(src), _lib.ptr(tgt), B, n, racers, min(arr_wgs, 256), _lib.ptr(col), _lib.ptr(cert),
