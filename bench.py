@@ -525,16 +525,17 @@ def bench_nao_recipe(args, dev):
                    "lap_fallbacks": rep["lap_fallbacks"]},
         "roofline": {"bound": "latency", "achieved": round(bound_ms, 4), "peak": round(solve_ms, 4),
                      "unit": "ms per re-solve (lower bound / measured)", "frac": round(bound_ms / solve_ms, 4) if solve_ms > 0 else None,
-                     "traffic": None, "kernel": "lap_jvmw_kernel<16> + two lap_jv_pass_kernel launches (re-solve of the 9 problems from "
-                     "the previous refresh's optimum: row reduction one chain per wave, then shortest augmenting paths)",
+                     "traffic": None, "kernel": "lap_jvmw_kernel<16, 2> (searches) + lap_mc_arr_kernel<16> + set-up + two lap_jv_pass_kernel launches (re-solve of "
+                     "the 9 problems from the previous refresh's optimum: row reduction one chain per wave on eight workgroups per "
+                     "problem, then shortest augmenting paths, 13 racers per problem)",
                      "kernel_ms": round(solve_ms, 4), "solves_measured": max(len(phase.events) - 1, 0),
                      "step_floor_us": round(floor_us.value, 4), "search_steps_slowest_problem": round(steps_max, 1),
                      "search_steps_mean_problem": round(float(st[:, 1].mean()) if st.size else 0.0, 1),
                      "row_reduction_steps_mean_problem": round(float(st[:, 2].mean()) if st.size else 0.0, 1),
                      "note": "latency roofline like secondary.kinematic's: a re-solve ends with its slowest problem's sequential "
                              "chain of path-search steps; floor = the workgroup-wide arg-min over the 1024 labels + its barrier "
-                             "alone (reart_lap_step_floor, measured in this run); the row reduction (8 chains in flight per "
-                             "problem) and the two whole-chip passes are on top"},
+                             "alone (reart_lap_step_floor, measured in this run); the row-reduction launch (64 chains in flight per "
+                             "problem, as long as its longest chain) and the two whole-chip passes are on top"},
         "cpu_baseline": cpu, "final_losses": [float(v) for v in eng.last_losses().cpu()[:3]],
     }
 
