@@ -61,6 +61,8 @@ def test_run_robot_driver_synthetic(dev, tmp_path):
     assert set(ck) == {"state_dict", "tau", "cano_idx"} and ck["cano_idx"] == 2
     assert {"proposal_6d", "proposal_t", "seg_head.model.0.weight", "seg_head.model.2.weight"} <= set(ck["state_dict"])
     assert all(torch.isfinite(p).all() for p in model.parameters())
+    txt = next(tmp_path.rglob("result.txt")).read_text()
+    assert "assign_refreshes: 4" in txt and "lap_fallbacks: 0" in txt        # refreshes at 40, 45, 50, 55; none solved on the host
 
 
 def test_run_robot_end_of_run_files_and_kinematic_from_base_result(dev, tmp_path):
