@@ -286,7 +286,10 @@ def run_sweep_engines(instances, make_engine, n_iter, device, per_gpu=3, chunk=1
                 live.remove(e)
         return plan
 
-    first_phase = n_iter if assign is None else max(1, min(int(assign["assign_iter"]), n_iter))
+    if assign is not None and int(assign["assign_iter"]) < 1:
+        raise ValueError("the sweep's assignment phase starts after at least one Chamfer iteration (assign_iter >= 1); "
+                         "run_robot.py handles assign_iter 0")
+    first_phase = n_iter if assign is None else min(int(assign["assign_iter"]), n_iter)
     lap_counts = {"assign_refreshes": 0, "lap_fallbacks": 0}
 
     def enqueue(live, plan):
