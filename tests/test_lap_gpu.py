@@ -303,7 +303,7 @@ def test_race_with_warm_racers_over_a_moving_sequence(dev):
 
 
 @pytest.mark.parametrize("n,racers,form", [(1024, None, True), (600, None, True), (512, 1, True), (1024, 1, True),
-                                            (1024, None, ("mc", 16)), (700, 1, ("mc", 3)), (1024, 2, ("mc", 28))])
+                                            (1024, None, ("mc", 16)), (700, 1, ("mc", 3)), (1024, 2, ("mc", 28)), (1500, 2, ("mc", 4))])
 def test_resolve_per_wave_gives_the_optimum(dev, n, racers, form):
     """reart_lap_resolve_points_mw (row reduction one chain per wave, optimistic commits) and reart_lap_resolve_points_mc (the
     chains of a problem on several workgroups, lock-free commits on state in memory): a sequence of moved problems, each re-solved
