@@ -24,6 +24,8 @@ def lb_box_box(qlo, qhi, lo, hi):
     e = np.maximum(np.maximum(lo[None] - qhi[:, None], qlo[:, None] - hi[None]), 0)
     return (e ** 2).sum(-1)
 
+ROW_BOUND = True
+
 def analyse(Q, Qprev, T, Tprev, name, K=1):
     """one job: queries Q [B,N,3] (previous positions Qprev), targets T [B,M,3] (Tprev)."""
     acc = {}
@@ -34,7 +36,12 @@ def analyse(Q, Qprev, T, Tprev, name, K=1):
         dprev = ((Qprev[b][:, None, :] - Tprev[b][None]) ** 2).sum(-1)
         seed = np.argsort(dprev, 1)[:, :K]
         dcur = ((q[:, None, :] - t[None]) ** 2).sum(-1)
-        thr0 = np.take_along_axis(dcur, seed, 1).max(1)            # initial bound
+        thr0 = np.take_along_axis(dcur, seed, 1).max(1)            # initial bound from the query's own seeds
+        if ROW_BOUND:                                              # the kernel's bound since round 3: the best of the row's 16 lanes' seeds
+            for g in range(0, q.shape[0], 16):
+                cand = seed[g:g + 16]                              # [16, K]
+                dd = dcur[g:g + 16][:, cand].max(2)                # [16 lanes, 16 donors]: K-th distance under a donor's seeds
+                thr0[g:g + 16] = dd.min(1)
         thr1 = np.sort(dcur, 1)[:, K - 1]                          # final bound (true K-th distance)
         lo, hi = boxes_of(t)
         nb = lo.shape[0]
@@ -82,6 +89,15 @@ def main():
     frames = [int(f) for f in (sys.argv[3].split(",") if len(sys.argv) > 3 else range(cur.shape[0]))]
     analyse(cur[frames], prev[frames], pcs[frames], pcs[frames], "x->y (queries move, static targets)")
     analyse(pcs[frames], pcs[frames], cur[frames], prev[frames], "y->x (static queries, targets move)")
+    if f"seg_{it}" in d:
+        # the moving targets regrouped by this iteration's sampled part (stable: canonical k-d order
+        # inside a part), so that 16 consecutive targets went through ONE transform
+        seg = d[f"seg_{it}"]
+        perm = np.argsort(seg, kind="stable")
+        print("labels present:", len(np.unique(seg)), "distinct labels per 64 consecutive points:",
+              round(float(np.mean([len(np.unique(seg[g:g + 64])) for g in range(0, len(seg), 64)])), 1),
+              "points whose label changed since the previous iteration:", int((seg != d[f"segprev_{it}"]).sum()))
+        analyse(pcs[frames], pcs[frames], cur[frames][:, perm], prev[frames][:, perm], "y->x, targets regrouped by sampled part")
     c = int(d["cano_idx"]); off = d["ref_off"]
     comp = np.concatenate([cur[:c], cano[None], cur[c:]]); compp = np.concatenate([prev[:c], cano[None], prev[c:]])
     for f in frames[:4]:
