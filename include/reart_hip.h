@@ -555,6 +555,18 @@ int reart_lap_resolve_points_mc(const float *src, const float *tgt, int B, int n
                                 int32_t *certified, const double *price_in, double *price_out, void *workspace,
                                 size_t workspace_bytes, void *stream);
 
+/* Device-side glue of an assignment refresh (run_robot.py:165-178), so that a loop which re-solves on the GPU touches the host
+ * only for the B certificate flags (csrc/assign.hip):
+ *   reart_gather_points: out[b][r] = pc[b][index[r]] -- `index_points(pc_trans_list, fps_idx)` (run_robot.py:169) for ONE sample
+ *     shared by all frames; pc [B,N,3], index [n] (0 <= index[r] < N), out [B,n,3].
+ *   reart_assign_pairs: the solved columns as the fused step's pair map (run_robot.py:177-178: `pc_tgt` gathered by the
+ *     solver's columns, paired with the sampled source points in order): assign_map[b][p] = -1 where slot_of_point[p] < 0, else
+ *     tgt_index[b][col4row[b][slot_of_point[p]]].  col4row [B,n], slot_of_point [N] (sample slot of canonical point p or -1),
+ *     tgt_index [B,n] (index of the r-th sampled target point in frame b's cloud), assign_map [B,N] (reart_relax_buffers). */
+int reart_gather_points(const float *pc, const int32_t *index, int B, int N, int n, float *out, void *stream);
+int reart_assign_pairs(const int32_t *col4row, const int32_t *slot_of_point, const int32_t *tgt_index, int B, int N, int n,
+                       int32_t *assign_map, void *stream);
+
 /* Cost matrices for the above: replaces `torch.cdist(pc_src, pc_tgt)` (run_robot.py:171, utils/model_utils.py:93).
  *   a [B,n,3], b [B,m,3] -> out [B,n,m] = Euclidean distance, sqrt(((dx*dx)+(dy*dy))+(dz*dz)) in fp32. */
 int reart_cdist(const float *a, const float *b, int B, int n, int m, float *out, void *stream);

@@ -172,7 +172,8 @@ class KinematicEngine:
             if self.lap_events is not None:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 ev[0].record()
-            assign, fb, self.lap_stats = linear_sum_assignment_points(pc_src, self.tgt_pts, self.lap_state, return_stats="full")
+            cols, fb, self.lap_stats = linear_sum_assignment_points(pc_src, self.tgt_pts, self.lap_state, return_stats="full",
+                                                                    device_cols=True)      # the columns never leave the device
             self.lap_solves += 1
             self.lap_fallbacks += fb
             # sequential steps of this solve (path search + row reduction) per problem: slowest problem, mean -- the
@@ -182,7 +183,6 @@ class KinematicEngine:
                 seq = seq + (self.lap_stats[:, 3].astype(np.int64) >> 8)
             self.lap_steps_log.append((int(seq.max()), float(seq.mean())))
             self.lap_winners += np.bincount((self.lap_stats[:, 0] >> 16) & 15, minlength=16)[:16]         # raced re-solves: who finished first
-            cols = torch.from_numpy(np.stack([c for _, c in assign])).to(self.dev)
             self.matched = self.tgt_pts.gather(1, cols[..., None].expand(-1, -1, 3))
             if self.lap_events is not None:
                 ev[1].record()

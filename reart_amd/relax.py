@@ -295,7 +295,8 @@ class RelaxEngine:
             tgt = self._inv_frames.gather(1, tgt)
         self._assign_map.fill_(-1)
         self._assign_map[:, src] = tgt.to(torch.int32)
-        if not self.cfg.use_assign or self.cfg.lambda_assign != lambda_assign:
+        lam32 = ctypes.c_float(lambda_assign).value       # the config holds fp32: compare what it would hold (0.3 != fp32(0.3))
+        if not self.cfg.use_assign or self.cfg.lambda_assign != lam32:
             self.cfg.use_assign, self.cfg.lambda_assign = 1, float(lambda_assign)
             self._graph = None
 

@@ -27,6 +27,7 @@ Data: ``--seq_path`` with the reference's pickle layout (``reart_amd.dataset.Seq
 """
 import argparse
 import contextlib
+import ctypes
 import functools
 import glob
 import os
@@ -112,11 +113,102 @@ class AssignmentPhase:
         self.capture_guard = None   # a context-manager factory entered around the graph capture (the sweep's _CaptureGate)
         self._have = False
 
+    def _native_tables(self):
+        """Index tables of the device-side refresh, in the engine's STORAGE order (built once): the stored position of every
+        sampled canonical point, the sample slot of every stored point (-1: not sampled), the stored position of every
+        sampled target point."""
+        eng, dev = self.eng, self.eng.device
+        N = eng._assign_map.shape[1]
+        src = self.src_idx[0].long()
+        tgt = self.tgt_idx.long()
+        if eng._perm is not None:
+            src = eng._inv[src]
+            if getattr(eng, "_inv_frames", None) is None:
+                inv_f = torch.empty_like(eng._perm_frames)
+                inv_f.scatter_(1, eng._perm_frames, torch.arange(N, device=dev).expand(self.B, N))
+                eng._inv_frames = inv_f
+            tgt = eng._inv_frames.gather(1, tgt)
+        slot = torch.full((N,), -1, dtype=torch.int32, device=dev)
+        slot[src] = torch.arange(self.n, dtype=torch.int32, device=dev)
+        self._src_stored, self._slot, self._tgt_stored = src.int().contiguous(), slot, tgt.int().contiguous()
+        self._src_pts = torch.empty((self.B, self.n, 3), device=dev)
+        self._cert = torch.zeros((self.B,), dtype=torch.int32, device=dev)
+        self._cert_host = torch.zeros((self.B,), dtype=torch.int32).pin_memory()
+        self._stats_host = torch.zeros((4 * self.B,), dtype=torch.int32).pin_memory()
+
+    def _refresh_on_device(self):
+        """A refresh after the first, without a host-side tensor operation: gather (reart_gather_points) -> re-solve from the
+        previous optimum in place (reart_lap_resolve_points_mc) -> pair map (reart_assign_pairs), all queued behind the
+        forward; the host waits for the B certificate flags only (an uncertified problem goes to scipy, as everywhere)."""
+        from reart_amd import _lib
+        from reart_amd.utils import lap
+
+        eng, st, L = self.eng, self.lap_state, _lib.lib()
+        B, n, N = self.B, self.n, eng._assign_map.shape[1]
+        racers, arr = lap._resolve_racers(B, n), min(lap._arr_wgs(B), 256)
+        stream = _lib.stream()
+        _lib.check(L.reart_gather_points(_lib.ptr(eng._pc_trans), _lib.ptr(self._src_stored), B, N, n, _lib.ptr(self._src_pts), stream),
+                   "reart_gather_points")
+        self._cert.zero_()
+        ws = _lib.workspace(L.reart_lap_mc_workspace_bytes(B, n, racers), eng.device)
+        cols, prices = st["cols"], st["prices"]
+        off = ((8 * B * n + 255) // 256) * 256                            # the solver's statistics: [B][4] ints behind the potentials
+        if self.collect_stats:
+            ws[off:off + 16 * B].zero_()
+        _lib.check(L.reart_lap_resolve_points_mc(_lib.ptr(self._src_pts), _lib.ptr(self.tgt_pts), B, n, racers, arr, _lib.ptr(cols),
+                                                 _lib.ptr(self._cert), _lib.ptr(prices), _lib.ptr(prices), _lib.ptr(ws), ws.numel(), stream),
+                   "reart_lap_resolve_points_mc")
+        st["resolve_form"] = "mc"
+        pairs = lambda: _lib.check(L.reart_assign_pairs(_lib.ptr(cols), _lib.ptr(self._slot), _lib.ptr(self._tgt_stored), B, N, n,
+                                                        _lib.ptr(eng._assign_map), stream), "reart_assign_pairs")
+        pairs()
+        self._cert_host.copy_(self._cert, non_blocking=True)
+        if self.collect_stats:
+            self._stats_host.copy_(ws[off:off + 16 * B].view(torch.int32), non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        if self.collect_stats:
+            sth = self._stats_host.numpy().reshape(B, 4)
+            self.stats_log.append((int(sth[:, 2].max()), float(sth[:, 2].mean()), float((sth[:, 3] >> 8).mean())))
+        fb = 0
+        for b in (self._cert_host == 0).nonzero().flatten().tolist():      # certificate did not close: exact host solve
+            from scipy.optimize import linear_sum_assignment
+
+            fb += 1
+            host = linear_sum_assignment(lap.cdist(self._src_pts[b:b + 1], self.tgt_pts[b:b + 1])[0].cpu().numpy())[1]
+            lap._forget_uncertified(st, cols, b, host)
+        if fb:
+            pairs()
+        return fb
+
+    def _device_path(self):
+        from reart_amd.utils import lap
+
+        st = self.lap_state
+        return (self.NATIVE and self.eng.cfg.use_assign and self.eng.cfg.lambda_assign == ctypes.c_float(self.lam).value
+                and st.get("cols") is not None and st.get("prices") is not None and st["cols"].dtype == torch.int32
+                and tuple(st["cols"].shape) == (self.B, self.n) and lap.RESOLVE_PER_WAVE and lap.MW_NMIN <= self.n <= lap.MW_NMAX
+                and lap._arr_wgs(self.B) > 0)
+
+    NATIVE = os.environ.get("REART_ASSIGN_NATIVE", "1") != "0"
+
     def refresh(self):
         from reart_amd.utils.lap import linear_sum_assignment_points
 
         eng = self.eng
         eng.peek_forward()
+        if self._device_path():
+            if getattr(self, "_slot", None) is None:
+                self._native_tables()
+            if self.events is not None:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
+            fb = self._refresh_on_device()
+            if self.events is not None:
+                ev[1].record()
+                self.events.append(ev)
+            self.fallbacks += fb
+            self.refreshes += 1
+            return False
         src_pts = index_points(eng.pc_trans, self.src_idx.expand(self.B, self.n)).contiguous()
         if self.events is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -190,6 +282,10 @@ class AssignmentPhaseBatch:
 
         for ph in self.parts:
             ph.eng.peek_forward()
+        if self._device_path():
+            self.fallbacks += self._refresh_on_device()
+            self.refreshes += 1
+            return False
         src_all = torch.cat([index_points(ph.eng.pc_trans, ph.src_idx.expand(self.B, self.n)) for ph in self.parts], dim=0).contiguous()
         cols, fb = linear_sum_assignment_points(src_all, self.tgt_all, self.lap_state, device_cols=True)
         self.fallbacks += fb
@@ -199,6 +295,62 @@ class AssignmentPhaseBatch:
             ph.eng.set_assignment(ph.src_idx[0], ph.tgt_idx.gather(1, cols[k * self.B:(k + 1) * self.B]), self.lam)
         self._have = True
         return first
+
+    def _device_path(self):
+        from reart_amd.utils import lap
+
+        st, K = self.lap_state, len(self.parts)
+        return (AssignmentPhase.NATIVE and all(ph.eng.cfg.use_assign and ph.eng.cfg.lambda_assign == ctypes.c_float(self.lam).value for ph in self.parts)
+                and st.get("cols") is not None and st.get("prices") is not None and st["cols"].dtype == torch.int32
+                and tuple(st["cols"].shape) == (K * self.B, self.n) and lap.RESOLVE_PER_WAVE
+                and lap.MW_NMIN <= self.n <= lap.MW_NMAX and lap._arr_wgs(K * self.B) > 0)
+
+    def _refresh_on_device(self):
+        """AssignmentPhase._refresh_on_device for the K instances of a shared launch: K gathers into one source batch, ONE
+        re-solve of the K x (T-1) problems, K pair maps; the host waits for the certificate flags only."""
+        from reart_amd import _lib
+        from reart_amd.utils import lap
+
+        st, L, K, B, n = self.lap_state, _lib.lib(), len(self.parts), self.B, self.n
+        dev = self.parts[0].eng.device
+        if getattr(self, "_src_all", None) is None:
+            for ph in self.parts:
+                ph._native_tables()
+            self._src_all = torch.empty((K * B, n, 3), device=dev)
+            self._cert = torch.zeros((K * B,), dtype=torch.int32, device=dev)
+            self._cert_host = torch.zeros((K * B,), dtype=torch.int32).pin_memory()
+        racers, arr = lap._resolve_racers(K * B, n), min(lap._arr_wgs(K * B), 256)
+        stream = _lib.stream()
+        for k, ph in enumerate(self.parts):
+            N = ph.eng._assign_map.shape[1]
+            _lib.check(L.reart_gather_points(_lib.ptr(ph.eng._pc_trans), _lib.ptr(ph._src_stored), B, N, n,
+                                             _lib.ptr(self._src_all[k * B:]), stream), "reart_gather_points")
+        self._cert.zero_()
+        ws = _lib.workspace(L.reart_lap_mc_workspace_bytes(K * B, n, racers), dev)
+        cols, prices = st["cols"], st["prices"]
+        _lib.check(L.reart_lap_resolve_points_mc(_lib.ptr(self._src_all), _lib.ptr(self.tgt_all), K * B, n, racers, arr, _lib.ptr(cols),
+                                                 _lib.ptr(self._cert), _lib.ptr(prices), _lib.ptr(prices), _lib.ptr(ws), ws.numel(), stream),
+                   "reart_lap_resolve_points_mc")
+        st["resolve_form"] = "mc"
+
+        def pairs():
+            for k, ph in enumerate(self.parts):
+                N = ph.eng._assign_map.shape[1]
+                _lib.check(L.reart_assign_pairs(_lib.ptr(cols[k * B:]), _lib.ptr(ph._slot), _lib.ptr(ph._tgt_stored), B, N, n,
+                                                _lib.ptr(ph.eng._assign_map), stream), "reart_assign_pairs")
+        pairs()
+        self._cert_host.copy_(self._cert, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        fb = 0
+        for b in (self._cert_host == 0).nonzero().flatten().tolist():
+            from scipy.optimize import linear_sum_assignment
+
+            fb += 1
+            host = linear_sum_assignment(lap.cdist(self._src_all[b:b + 1], self.tgt_all[b:b + 1])[0].cpu().numpy())[1]
+            lap._forget_uncertified(st, cols, b, host)
+        if fb:
+            pairs()
+        return fb
 
     def run(self, i, n_iter):
         while i < n_iter:
@@ -266,8 +418,8 @@ class OperatorLoop:
                     ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                     ev[0].record()
                 if self.lap_state is not None:      # slowly moving problems: re-solve from the previous optimum
-                    assign, fb, self.lap_stats = linear_sum_assignment_points(pc_src.detach(), self.tgt_pts, self.lap_state,
-                                                                              return_stats="full")
+                    cols, fb, self.lap_stats = linear_sum_assignment_points(pc_src.detach(), self.tgt_pts, self.lap_state,
+                                                                            return_stats="full", device_cols=True)
                 else:
                     assign, fb = linear_sum_assignment_batch(cdist(pc_src.detach(), self.tgt_pts), points=(pc_src.detach(), self.tgt_pts),
                                                              race=True, return_stats=True)
@@ -276,7 +428,8 @@ class OperatorLoop:
                     self.lap_events.append(ev)
                 self.lap_solves += 1
                 self.lap_fallbacks += fb
-                cols = torch.from_numpy(np.stack([c for _, c in assign])).to(cano_pc.device)    # rows are 0..n-1 in order
+                if self.lap_state is None:
+                    cols = torch.from_numpy(np.stack([c for _, c in assign])).to(cano_pc.device)    # rows are 0..n-1 in order
                 self.matched = self.tgt_pts.gather(1, cols[..., None].expand(-1, -1, 3))
             ass = args.lambda_assign * ((pc_src - self.matched) ** 2).sum(-1).sum()
             losses["opt assignment loss"] = ass

@@ -73,3 +73,59 @@ def test_base_recipe_assignment_phase_against_the_oracle_loop(oracle, dev):
         assert abs(row[1] - ref["flow"]) <= 1e-5 * abs(ref["flow"]) + 1e-9, (i, row, ref["flow"])
         np.testing.assert_allclose(eng.pc_trans.cpu().numpy(), ref["pc_trans"], rtol=0, atol=5e-7, err_msg=f"iteration {i}")
     assert phase.refreshes == 3 and phase.fallbacks == 0
+    assert phase._device_path() and phase._slot is not None        # refreshes 2 and 3 ran without host-side tensor operations
+
+
+def test_refresh_glue_entry_points(dev):
+    """reart_gather_points / reart_assign_pairs against the tensor operations they replace (index_points of the sampled
+    source points, run_robot.py:169; the pairs RelaxEngine.set_assignment writes, :177-178), through the C ABI."""
+    from reart_amd import _lib
+    from reart_amd.networks.pointnet2_utils import index_points
+
+    L, g = _lib.lib(), torch.Generator(device="cpu").manual_seed(3)
+    B, N, n = 5, 777, 130
+    pc = torch.randn((B, N, 3), generator=g).to(dev)
+    idx = torch.randperm(N, generator=g)[:n].to(dev)
+    out = torch.full((B, n, 3), float("nan"), device=dev)
+    idx32 = idx.int()                                                  # (kept alive: a temporary's memory is reused at once)
+    _lib.check(L.reart_gather_points(_lib.ptr(pc), _lib.ptr(idx32), B, N, n, _lib.ptr(out), _lib.stream()), "reart_gather_points")
+    assert torch.equal(out, index_points(pc, idx.expand(B, n)))
+    cols = torch.stack([torch.randperm(n, generator=g) for _ in range(B)]).to(dev)
+    tgt_index = torch.stack([torch.randperm(N, generator=g)[:n] for _ in range(B)]).to(dev)
+    slot = torch.full((N,), -1, dtype=torch.int32, device=dev)
+    slot[idx] = torch.arange(n, dtype=torch.int32, device=dev)
+    amap = torch.full((B, N), 12345, dtype=torch.int32, device=dev)
+    cols32, tgt32 = cols.int(), tgt_index.int()
+    _lib.check(L.reart_assign_pairs(_lib.ptr(cols32), _lib.ptr(slot), _lib.ptr(tgt32), B, N, n, _lib.ptr(amap), _lib.stream()),
+               "reart_assign_pairs")
+    want = torch.full((B, N), -1, dtype=torch.int32, device=dev)
+    want[:, idx] = tgt_index.gather(1, cols).int()
+    assert torch.equal(amap, want)
+    assert L.reart_gather_points(None, _lib.ptr(idx32), B, N, n, _lib.ptr(out), _lib.stream()) == -1
+    assert L.reart_assign_pairs(_lib.ptr(cols32), _lib.ptr(slot), _lib.ptr(tgt32), B, N, 0, _lib.ptr(amap), _lib.stream()) == -1
+
+
+def test_device_side_refresh_equals_the_tensor_path(dev):
+    """The same 16 iterations of the assignment phase (refreshes at 0, 5, 10, 15) with the refresh glue on the device and with
+    the tensor operations it replaces: the optimum is unique, so assignments, pair maps and the trajectory are identical."""
+    from reart_amd.data import load_nao_demo
+    from reart_amd.networks.model import BaseModel
+    from reart_amd.relax import RelaxEngine
+    from reart_amd.run_robot import AssignmentPhase
+
+    g = load_nao_demo()
+    cano, pcs, c = t(g["cano"], dev), t(g["pc_list"], dev), int(g["cano_idx"])
+    outs = []
+    for native in (True, False):
+        torch.manual_seed(4)
+        model = BaseModel(num_parts=20, pose_len=pcs.shape[0]).to(dev)
+        eng = RelaxEngine(cano, pcs, model, c, None, None, n_iter=15000, seed=4)
+        eng.step(40)
+        phase = AssignmentPhase(eng, cano, pcs, 4, 5, 0.3)
+        phase.NATIVE = native
+        i = phase.run(40, 56)
+        assert i == 56 and phase.refreshes == 4 and phase.fallbacks == 0
+        assert (getattr(phase, "_slot", None) is not None) == native
+        outs.append((phase.lap_state["cols"].clone(), eng._assign_map.clone(), eng.pc_trans.clone(), eng.last_losses().clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
