@@ -33,6 +33,9 @@
 #ifndef MW_ARR_BUDGET
 #define MW_ARR_BUDGET 32
 #endif
+#ifndef MW_TIGHTEN
+#define MW_TIGHTEN 1         // lower the unowned columns' prices to the matched rows' potentials before the path searches
+#endif
 #define MW_CHECK 16          // a search looks at the race flag and at its labelled columns every MW_CHECK steps
 
 #ifdef REART_PRUNE_PHASE   // diagnostic build only (make -C reart_amd/csrc phase; tools/exp_mw.py)
@@ -367,6 +370,50 @@ __global__ __launch_bounds__(64 * MW_NW) void lap_jvmw_kernel(JvArgs a) {
         if (i >= 0) hcol[j] = (double)mw_sqrt(reart_sqdist3(psx[i], psy[i], psz[i], qx[k], qy[k], qz[k])) + pj[k];
     }
     int *cpred = flist;                                   // the free-row list is spent: column -> row it was reached from
+#if MW_TIGHTEN
+    // ---- the unowned columns' prices.  A column a released row left keeps the price it had: tight for a pair that no longer
+    // exists.  Nothing constrains an unowned column's price from below except the matched rows' potentials (row i must not
+    // prefer it to its own column: c_ij + p_j >= u_i), so it is lowered until the first matched row is indifferent -- p_j -=
+    // min_i (c_ij + p_j - u_i), the expression of the relaxations.  Every dual constraint still holds, no pair changes, and a
+    // search now meets the column as soon as it has labelled that row instead of after every column cheaper than the gap.
+    if (nleft > 0 && !mw_flag(&sh.abort_) && !mw_flag(&sh.unsolved)) {
+        if (tid == 0) sh.flag = 0;
+        __syncthreads();                                  // hcol is complete
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            const int j = tid + k * BS;
+            if (j < n && owner[j] < 0) cpred[atomicAdd(&sh.flag, 1)] = j;
+        }
+        __syncthreads();
+        const int nh = sh.flag;
+        for (int hI = 0; hI < nh; ++hI) {
+            const int jh = cpred[hI];
+            const float hx = ptx[jh], hy = pty[jh], hz = ptz[jh];
+            const double ph = price[jh];
+            double m = INFINITY;
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) {
+                const int j = tid + k * BS;
+                const int i = j < n ? owner[j] : -1;
+                if (i >= 0) m = fmin(m, (((double)mw_sqrt(reart_sqdist3(psx[i], psy[i], psz[i], hx, hy, hz)) + ph) - hcol[j]));
+            }
+            m = lap_wave_min_d(m);
+            if (lane == 0) s_red[wv] = m;
+            __syncthreads();
+            m = s_red[0];
+#pragma unroll
+            for (int w = 1; w < MW_NW; ++w) m = fmin(m, s_red[w]);
+            __syncthreads();                              // s_red is rewritten by the next column
+            if (tid == 0 && m > 0.0 && m < INFINITY) price[jh] = ph - m;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            const int j = tid + k * BS;
+            if (j < n) pj[k] = price[j];
+        }
+    }
+#endif
     // (Also measured: rounds that settle several columns -- every wave's closest column a candidate, candidates relaxed from
     // ahead of their turn, the sorted ready prefix settled together, profiles/r04_lap_speculative_rounds_variant.hip.txt.
     // Exact, 1.6 columns per round, but a round cost 2.6 us against 1.27 us per step: the step is bound by the instructions
