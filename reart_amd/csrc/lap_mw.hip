@@ -36,6 +36,9 @@
 #ifndef MW_TIGHTEN
 #define MW_TIGHTEN 1         // lower the unowned columns' prices to the matched rows' potentials before the path searches
 #endif
+#ifndef MW_TIGHTEN_ARR
+#define MW_TIGHTEN_ARR 1     // ... and before the row reduction on many compute units (lap_mc_tighten_kernel)
+#endif
 #define MW_CHECK 16          // a search looks at the race flag and at its labelled columns every MW_CHECK steps
 
 #ifdef REART_PRUNE_PHASE   // diagnostic build only (make -C reart_amd/csrc phase; tools/exp_mw.py)
@@ -271,9 +274,15 @@ __global__ __launch_bounds__(64 * MW_NW) void lap_jvmw_kernel(JvArgs a) {
             a.mc_price[(size_t)b * n + j] = price[j]; a.mc_owner[(size_t)b * n + j] = owner[j];
             a.mc_assigned[(size_t)b * n + j] = assigned[j]; a.mc_list[(size_t)b * n + j] = flist[j];
         }
+        // the unowned columns, for lap_mc_tighten_kernel (the list lives where the row reduction will leave its rows: spent by then)
+        if (tid == 0) sh.flag = 0;
+        __syncthreads();
+        for (int j = tid; j < n; j += BS)
+            if (owner[j] < 0) a.mc_next[(size_t)b * n + atomicAdd(&sh.flag, 1)] = j;
+        __syncthreads();
         if (tid == 0) {
             int *c = a.mc_cnt + 8 * b;
-            c[0] = nfree; c[1] = 0; c[2] = 0; c[3] = 0; c[4] = 0; c[5] = st_freed; c[6] = 0;
+            c[0] = nfree; c[1] = 0; c[2] = 0; c[3] = 0; c[4] = 0; c[5] = st_freed; c[6] = 0; c[7] = sh.flag;
             a.scale[b] = mx;
         }
         return;
@@ -555,6 +564,44 @@ __global__ __launch_bounds__(64 * MW_NW) void lap_jvmw_kernel(JvArgs a) {
 #ifndef MW_MC_CHAIN
 #define MW_MC_CHAIN 128
 #endif
+
+// Between the set-up and the row reduction: every unowned column's price is lowered until the first MATCHED row is indifferent
+// between it and its own column (the step the searches' part of lap_jvmw_kernel explains; here for all the columns the
+// released rows left, so that a chain ends in such a column as soon as it displaces that row).  A wave per unowned column:
+// the matched rows' points and potentials (one per owned column) sit in its registers, a column is CPL distances per lane and
+// a wave minimum.  Unowned columns do not enter any row's potential, so they are independent of each other; the launch is
+// complete before the chains start, whose argument needs prices that only rise from then on.
+template <int CPL>
+__global__ __launch_bounds__(64 * MW_NW) void lap_mc_tighten_kernel(JvArgs a) {
+    const int n = a.n, b = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int nh = a.mc_cnt[8 * b + 7];
+    const int w0 = blockIdx.x * MW_NW + wv, nw = gridDim.x * MW_NW;
+    if (w0 >= nh) return;
+    double *price = a.mc_price + (size_t)b * n;
+    const int *owner = a.mc_owner + (size_t)b * n, *holes = a.mc_next + (size_t)b * n;
+    const float *S_ = a.src + (size_t)b * n * 3, *T_ = a.tgt + (size_t)b * n * 3;
+    float sx[CPL], sy[CPL], sz[CPL];
+    double u[CPL];
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+        const int j = 64 * k + lane;
+        const int i = j < n ? owner[j] : -1;
+        const int ii = i >= 0 ? i : 0, jj = j < n ? j : 0;
+        sx[k] = S_[3 * ii]; sy[k] = S_[3 * ii + 1]; sz[k] = S_[3 * ii + 2];
+        u[k] = i >= 0 ? (double)mw_sqrt(reart_sqdist3(sx[k], sy[k], sz[k], T_[3 * jj], T_[3 * jj + 1], T_[3 * jj + 2])) + price[jj] : INFINITY;
+    }
+    for (int h = w0; h < nh; h += nw) {
+        const int jh = holes[h];
+        const float hx = T_[3 * jh], hy = T_[3 * jh + 1], hz = T_[3 * jh + 2];
+        const double ph = price[jh];
+        double m = INFINITY;
+#pragma unroll
+        for (int k = 0; k < CPL; ++k)
+            if (u[k] < INFINITY) m = fmin(m, (((double)mw_sqrt(reart_sqdist3(sx[k], sy[k], sz[k], hx, hy, hz)) + ph) - u[k]));
+        m = lap_wave_min_d(m);
+        if (lane == 0 && m > 0.0 && m < INFINITY) price[jh] = ph - m;
+    }
+}
 #define MW_LOCKED (-2)
 template <int CPL>
 __global__ __launch_bounds__(64 * MW_NW) void lap_mc_arr_kernel(JvArgs a) {
@@ -661,6 +708,10 @@ static int mc_launch(const JvArgs &a, int racers, int arr_wgs, hipStream_t strea
     if (s2.mc_chain <= 0) s2.mc_chain = MW_MC_CHAIN;
     hipLaunchKernelGGL((lap_jvmw_kernel<CPL, 1>), dim3(a.B), dim3(64 * MW_NW), lds, stream, s1);
     REART_CHECK_LAUNCH();
+#if MW_TIGHTEN_ARR
+    hipLaunchKernelGGL((lap_mc_tighten_kernel<CPL>), dim3(arr_wgs, a.B), dim3(64 * MW_NW), 0, stream, s2);
+    REART_CHECK_LAUNCH();
+#endif
     hipLaunchKernelGGL((lap_mc_arr_kernel<CPL>), dim3(arr_wgs, a.B), dim3(64 * MW_NW), 0, stream, s2);
     REART_CHECK_LAUNCH();
     hipLaunchKernelGGL((lap_jvmw_kernel<CPL, 2>), dim3(a.B, racers), dim3(64 * MW_NW), lds, stream, a);
