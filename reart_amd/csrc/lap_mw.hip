@@ -627,46 +627,70 @@ __global__ __launch_bounds__(64 * MW_NW) void lap_mc_arr_kernel(JvArgs a) {
         q = mw_uniform(q);
         if (q >= nfree) break;
         int i = flist[q];
+        float ax = S_[3 * i], ay = S_[3 * i + 1], az = S_[3 * i + 2];
         for (int budget = a.mc_chain; ; ) {
-            const float ax = S_[3 * i], ay = S_[3 * i + 1], az = S_[3 * i + 2];
+            // ONE round of reads per step: every column's price and owner as they are now (stale by the time they are used:
+            // harmless, see the top of the file; what the step writes is validated under the column's lock)
+            constexpr bool OWN_TOO = CPL <= 16;          // (32 columns per lane: the owners would not fit the registers -- 332 B of scratch)
+            double pr[CPL];
+            int ow[OWN_TOO ? CPL : 1];
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) {
+                const int j = 64 * k + lane;
+                pr[k] = j < n ? ld_d(price + j) : INFINITY;
+                if (OWN_TOO) ow[k] = j < n ? ld_i(owner + j) : -1;
+            }
             float rc[CPL];
             mw_row_costs<CPL>(ax, ay, az, tcx, tcy, tcz, rc);
             double v1 = INFINITY, v2 = INFINITY;
             int j1 = 0x7fffffff, pay = 0;
 #pragma unroll
-            for (int k = 0; k < CPL; ++k) {
-                const int j = 64 * k + lane;
-                lap_top2_push((double)rc[k] + (j < n ? ld_d(price + j) : INFINITY), j, v1, j1, v2);
-            }
+            for (int k = 0; k < CPL; ++k) lap_top2_push((double)rc[k] + pr[k], 64 * k + lane, v1, j1, v2);
             lap_wave_top2_fast(v1, j1, v2, pay);
             if (!(v1 < INFINITY)) { if (lane == 0) __hip_atomic_store(&cnt[6], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-            const double pj1 = ld_d(price + j1);
-            const int own = ld_i(owner + j1);
-            const bool consistent = own != MW_LOCKED &&
-                                    (double)mw_sqrt(reart_sqdist3(ax, ay, az, T_[3 * j1], T_[3 * j1 + 1], T_[3 * j1 + 2])) + pj1 == v1;
+            // the price and owner the decision used, from the lane that holds the arg-min column (no second round of reads)
+            j1 = mw_uniform(j1);
+            double pl = 0.0;
+            int ol = -1;
+#pragma unroll
+            for (int k = 0; k < CPL; ++k)
+                if ((j1 >> 6) == k) { pl = pr[k]; if (OWN_TOO) ol = ow[k]; }
+            const double pj1 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(pl), j1 & 63),
+                                                __builtin_amdgcn_readlane(__double2loint(pl), j1 & 63));
+            const int own = OWN_TOO ? __builtin_amdgcn_readlane(ol, j1 & 63) : ld_i(owner + j1);
+            if (own == MW_LOCKED) { ++my_conf; continue; }                     // somebody is committing on it: look again
             const bool tie = !(v1 < v2);
-            if (consistent && (--budget < 0 || (tie && own >= 0))) {           // out of budget / an exact tie on an owned column
+            if (--budget < 0 || (tie && own >= 0)) {                           // out of budget / an exact tie on an owned column
                 if (lane == 0) next[__hip_atomic_fetch_add(&cnt[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = i;
                 break;
             }
+            // the displaced row's point: in flight while the commit makes its round trips
+            const int in_ = own >= 0 ? own : i;
+            const float nx = S_[3 * in_], ny = S_[3 * in_ + 1], nz = S_[3 * in_ + 2];
             int ok = 0;
-            if (consistent && lane == 0) {
+            if (lane == 0) {
                 int seen = own;
-                if (__hip_atomic_compare_exchange_strong(owner + j1, &seen, MW_LOCKED, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                // Orders, not cache maintenance: every access to the shared state is a device-scope atomic (served where all
+                // compute units meet), so the lock needs no L2 write-back / invalidate (what ACQUIRE / RELEASE at device scope
+                // cost here: buffer_inv sc1 + buffer_wbl2 sc1 per commit).  The re-read of the price issues after the swap has
+                // returned (it is control-dependent on its result); the owner is released after the wave's earlier stores have
+                // completed (s_waitcnt vmcnt(0): on gfx9 stores count there).
+                if (__hip_atomic_compare_exchange_strong(owner + j1, &seen, MW_LOCKED, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                     if (ld_d(price + j1) == pj1) {
                         if (!tie) __hip_atomic_store(price + j1, pj1 + (v2 - v1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         __hip_atomic_store(assigned + i, j1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if (own >= 0) __hip_atomic_store(assigned + own, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(owner + j1, i, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __hip_atomic_store(owner + j1, i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         ok = 1;
-                    } else __hip_atomic_store(owner + j1, own, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    } else __hip_atomic_store(owner + j1, own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
             ok = mw_uniform(ok);
             if (!ok) { ++my_conf; continue; }
             ++my_arr;
             if (own < 0) break;
-            i = own;
+            i = own; ax = nx; ay = ny; az = nz;
         }
     }
     if (lane == 0) {
@@ -712,7 +736,11 @@ static int mc_launch(const JvArgs &a, int racers, int arr_wgs, hipStream_t strea
     hipLaunchKernelGGL((lap_mc_tighten_kernel<CPL>), dim3(arr_wgs, a.B), dim3(64 * MW_NW), 0, stream, s2);
     REART_CHECK_LAUNCH();
 #endif
-    hipLaunchKernelGGL((lap_mc_arr_kernel<CPL>), dim3(arr_wgs, a.B), dim3(64 * MW_NW), 0, stream, s2);
+    // a chain step is ~1 000 instructions of ONE wave (CPL square roots, the fp64 top-2, the wave merge) and no waiting worth the
+    // name: two waves on a SIMD halve each other.  Where the chip has room the same chains run as twice the workgroups of half
+    // the waves -- a SIMD each.
+    const int split = (2 * arr_wgs * a.B <= 256) ? 2 : 1;
+    hipLaunchKernelGGL((lap_mc_arr_kernel<CPL>), dim3(arr_wgs * split, a.B), dim3(64 * MW_NW / split), 0, stream, s2);
     REART_CHECK_LAUNCH();
     hipLaunchKernelGGL((lap_jvmw_kernel<CPL, 2>), dim3(a.B, racers), dim3(64 * MW_NW), lds, stream, a);
     REART_CHECK_LAUNCH();
