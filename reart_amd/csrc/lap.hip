@@ -1320,7 +1320,7 @@ __global__ __launch_bounds__(JV_PASS_BS) void lap_jv_pass_kernel(JvArgs a) {
 // reart_lap_auction* or these functions); same outputs and the same certificate as reart_lap_auction.
 // the state arrays of the many-compute-unit row reduction, behind the race layout
 static size_t jv_mc_extra_bytes(int B, int n) {
-    return reart_align_up(sizeof(double) * (size_t)B * n, 256) + 4 * reart_align_up(sizeof(int) * (size_t)B * n, 256) +
+    return reart_align_up(sizeof(double) * (size_t)B * n, 256) + 6 * reart_align_up(sizeof(int) * (size_t)B * n, 256) +
            reart_align_up(sizeof(int) * 8 * (size_t)B, 256);
 }
 extern "C" size_t reart_lap_mc_workspace_bytes(int B, int n, int racers) {
@@ -1391,6 +1391,7 @@ static int jv_launch(JvArgs a, void *workspace, size_t workspace_bytes, void *st
         const size_t bi = reart_align_up(sizeof(int) * (size_t)a.B * a.n, 256);
         a.mc_price = (double *)w; w += reart_align_up(sizeof(double) * (size_t)a.B * a.n, 256);
         a.mc_owner = (int *)w; w += bi; a.mc_assigned = (int *)w; w += bi; a.mc_list = (int *)w; w += bi; a.mc_next = (int *)w; w += bi;
+        a.mc_tree = (int *)w; w += bi; a.mc_tpar = (int *)w; w += bi;
         a.mc_cnt = (int *)w;
         const int rc = reart_internal_jvmc_launch(a, racers, arr_wgs, (hipStream_t)stream);
         if (rc != REART_OK) return rc;

@@ -153,6 +153,7 @@ struct JvArgs {
     // lap_mw.hip, form with the row reduction on many compute units: the state between its three launches, in the workspace
     double *mc_price;          // [B][n]
     int *mc_owner, *mc_assigned, *mc_list, *mc_next;       // [B][n] each: column -> row | row -> column | free rows | rows left
+    int *mc_tree, *mc_tpar;    // [B][n] each: column -> tree (the unowned column it leads to at zero reduced cost; -1 none) | its parent column there
     int *mc_cnt;               // [B][8]: free rows | queue head | rows left | reduction steps | conflicts | released | unsolved | unowned columns
     int mc_chain;              // steps after which a chain leaves its row to the path searches
     const int *col_start;

@@ -171,6 +171,7 @@ __global__ __launch_bounds__(64 * MW_NW) void lap_jvmw_kernel(JvArgs a) {
     float *psx = (float *)(next + n), *psy = psx + n, *psz = psy + n;   // source points
     float *ptx = psz + n, *pty = ptx + n, *ptz = pty + n;               // target points (wave-uniform reads of one column)
     double *hcol = (double *)(ptz + n);                                 // [n] searches: potential of the row that owns the column
+    int *tof = (int *)(hcol + n), *tpr = tof + n;                       // [n] each: the column's tree (lap_mc_trees_kernel) | its parent there
     __shared__ MwShared sh;
     __shared__ double s_red[MW_NW];
     __shared__ int s_cw[MW_NW];
@@ -199,10 +200,11 @@ __global__ __launch_bounds__(64 * MW_NW) void lap_jvmw_kernel(JvArgs a) {
         if (STAGE == 2) {
             price[j] = a.mc_price[(size_t)b * n + j]; owner[j] = a.mc_owner[(size_t)b * n + j];
             assigned[j] = a.mc_assigned[(size_t)b * n + j]; next[j] = a.mc_next[(size_t)b * n + j];
+            tof[j] = a.mc_tree[(size_t)b * n + j]; tpr[j] = a.mc_tpar[(size_t)b * n + j];
             continue;
         }
         price[j] = (race && STAGE == 0) ? a.price_start[(size_t)b * n + j] : (a.price_in ? a.price_in[(size_t)b * n + j] : 0.0);
-        owner[j] = -1;
+        owner[j] = -1; tof[j] = -1; tpr[j] = -1;
         const int c = ((race && STAGE == 0) ? a.col_start : a.col4row)[(size_t)b * n + j];
         assigned[j] = (c >= 0 && c < n) ? c : -1;
         next[j] = 0x7fffffff;
@@ -273,6 +275,7 @@ __global__ __launch_bounds__(64 * MW_NW) void lap_jvmw_kernel(JvArgs a) {
         for (int j = tid; j < n; j += BS) {
             a.mc_price[(size_t)b * n + j] = price[j]; a.mc_owner[(size_t)b * n + j] = owner[j];
             a.mc_assigned[(size_t)b * n + j] = assigned[j]; a.mc_list[(size_t)b * n + j] = flist[j];
+            a.mc_tree[(size_t)b * n + j] = -1; a.mc_tpar[(size_t)b * n + j] = -1;
         }
         // the unowned columns, for lap_mc_tighten_kernel (the list lives where the row reduction will leave its rows: spent by then)
         if (tid == 0) sh.flag = 0;
@@ -428,6 +431,7 @@ __global__ __launch_bounds__(64 * MW_NW) void lap_jvmw_kernel(JvArgs a) {
     // Exact, 1.6 columns per round, but a round cost 2.6 us against 1.27 us per step: the step is bound by the instructions
     // its waves issue -- 35 per column and relaxation, the correctly rounded square root among them --, not by latencies
     // that extra relaxations could hide.)
+    __shared__ int s_path[64];
     __shared__ double s_rv[2][MW_NW];
     __shared__ int s_rj[2][MW_NW], s_lostp[2];
     if (tid == 0) { s_lostp[0] = 0; s_lostp[1] = 0; }
@@ -475,7 +479,11 @@ __global__ __launch_bounds__(64 * MW_NW) void lap_jvmw_kernel(JvArgs a) {
             const int jstar = bj & ~JV_OWNED;
             if ((jstar & (BS - 1)) == tid) scanned |= 1u << (jstar / BS);
             const int i = owner[jstar];
+#ifdef MW_TREE_IGNORE
             if (i < 0) { sink = jstar; break; }
+#else
+            if (i < 0 || tof[jstar] >= 0) { sink = jstar; break; }
+#endif     // unowned, or a node of a tree that leads to an unowned column at no cost
             const float ax = psx[i], ay = psy[i], az = psz[i];
             const double h = hcol[jstar];                                  // row i's potential
 #ifdef REART_PRUNE_PHASE
@@ -498,17 +506,35 @@ __global__ __launch_bounds__(64 * MW_NW) void lap_jvmw_kernel(JvArgs a) {
             if ((((scanned & ~deadq) >> k) & 1u) && j != sink) { pj[k] += mu - d[k]; price[j] = pj[k]; }
         }
         __syncthreads();
+        const int tree_hit = tof[sink];                    // the tree this search uses up (its root, when the search met the unowned column itself)
         if (tid == 0) {                                    // flip the path
-            int j = sink;
-            for (;;) {
+            if (owner[sink] >= 0) {
+                // down the tree first: every row on the way moves to its parent column (tight pairs: prices stay), the last one
+                // takes the unowned root; from the root upwards, so that no owner is overwritten before it has moved
+                int m = 0;
+                for (int c = sink; c >= 0 && m < 64; c = tpr[c]) s_path[m++] = c;
+                for (int k = m - 2; k >= 0; --k) {
+                    const int r = owner[s_path[k]], c1 = s_path[k + 1];
+                    assigned[r] = c1; owner[c1] = r;
+                    hcol[c1] = (double)mw_sqrt(reart_sqdist3(psx[r], psy[r], psz[r], ptx[c1], pty[c1], ptz[c1])) + price[c1];
+                }
+            }
+            int j = sink, guard = 0;
+            for (;; ++guard) {
                 const int i = cpred[j];
                 const int jn = assigned[i];
                 assigned[i] = j; owner[j] = i;
                 if (i == i0) break;
+                if (guard > n || jn < 0) { sh.unsolved = 1; break; }      // a broken chain must not spin: the host solves this problem
                 j = jn;
             }
         }
         __syncthreads();
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {                    // the tree is spent (its unowned column is taken)
+            const int j = tid + k * BS;
+            if (tree_hit >= 0 && j < n && tof[j] == tree_hit) tof[j] = -1;
+        }
 #pragma unroll
         for (int k = 0; k < CPT; ++k) {                    // the labelled columns have new prices, those on the path new owners
             const int j = tid + k * BS;
@@ -602,6 +628,126 @@ __global__ __launch_bounds__(64 * MW_NW) void lap_mc_tighten_kernel(JvArgs a) {
         if (lane == 0 && m > 0.0 && m < INFINITY) price[jh] = ph - m;
     }
 }
+// After the row reduction, before the path searches: for every column still unowned, the TREE of matched rows that reach it at
+// zero reduced cost, grown MW_TREE_K nodes deep.  The step of lap_mc_tighten_kernel one level up and repeated: a tree T (columns
+// with the rows that own them, rooted in the unowned column) may lower all its prices -- and with them its rows' potentials,
+// which ARE c + p of their own pairs -- by the least slack any row outside has towards a column inside:
+//     D = min over rows i not in T, columns t in T of (c_it + p_t - u_i);
+// nothing becomes infeasible (rows inside only gain slack towards the outside, rows outside keep >= 0 towards the inside), all
+// pairs stay tight, and the row that attains D now reaches the tree at no cost: it joins with its column.  This is the backward
+// Dijkstra search from the unowned column, done for all of them at once -- a wave per tree, one node per round:
+//   * per row (one per owned column: CPL slots per lane) the wave keeps M_i = min over the tree's columns of (c_it + q_t), where
+//     q_t = p_t + the tree's total shift when t joined, so that a round costs ONE distance per row (to the newest column) and the
+//     slack is (M_i - shift) - u_i;
+//   * trees compete for rows through a compare-and-swap on a.mc_tree; a tree whose nearest row belongs to another tree stops
+//     (it has shifted by that slack, which is all it may do);
+//   * a wave reads potentials that other trees are lowering meanwhile: a stale potential is a HIGHER one, the slack comes out
+//     smaller, the shift stays safe; prices are written once, when the tree is done (p_t = q_t - shift).
+// The searches (lap_jvmw_kernel<., 2>) end at the first labelled column that belongs to a live tree and walk down its parent
+// links: the path to an unowned column is known and costs nothing.  Without trees a search labels every column cheaper than the
+// last hop to ONE particular row (in a graph whose reduced costs are nearly all within rounding of zero: hundreds).
+#ifndef MW_TREE_K
+#define MW_TREE_K 12
+#endif
+template <int CPL>
+__global__ __launch_bounds__(256) void lap_mc_trees_kernel(JvArgs a) {
+    const int n = a.n, b = blockIdx.y, lane = threadIdx.x & 63;
+    const int *cnt = a.mc_cnt + 8 * b;
+    const int nh = cnt[2];                               // rows left for the searches = columns still unowned
+    const int w0 = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), nw = gridDim.x * (blockDim.x >> 6);
+    if (w0 >= nh || cnt[6]) return;
+    double *price = a.mc_price + (size_t)b * n;
+    const int *owner = a.mc_owner + (size_t)b * n;
+    int *tree = a.mc_tree + (size_t)b * n, *tpar = a.mc_tpar + (size_t)b * n;
+    const float *S_ = a.src + (size_t)b * n * 3, *T_ = a.tgt + (size_t)b * n * 3;
+    auto ld_d = [](const double *p) -> double { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto bcast_d = [](double v, int l) -> double {
+        return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+    };
+    float sx[CPL], sy[CPL], sz[CPL];
+    double u[CPL], M[CPL];
+    unsigned long long free_mask[CPL];                   // wave-uniform: the unowned columns of slot k
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+        const int j = 64 * k + lane;
+        const int i = j < n ? owner[j] : 0;
+        free_mask[k] = __ballot(j < n && i < 0);
+        const int ii = (j < n && i >= 0) ? i : 0, jj = j < n ? j : 0;
+        sx[k] = S_[3 * ii]; sy[k] = S_[3 * ii + 1]; sz[k] = S_[3 * ii + 2];
+        u[k] = (j < n && i >= 0) ? (double)mw_sqrt(reart_sqdist3(sx[k], sy[k], sz[k], T_[3 * jj], T_[3 * jj + 1], T_[3 * jj + 2])) + ld_d(price + jj)
+                                 : INFINITY;
+    }
+    for (int h = w0; h < nh; h += nw) {
+        int jh = -1;                                     // the h-th unowned column
+        {
+            int c = 0;
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) {
+                const int pc = __builtin_popcountll(free_mask[k]);
+                if (jh < 0 && h < c + pc) {
+                    unsigned long long m2 = free_mask[k];
+                    for (int t = 0; t < h - c; ++t) m2 &= m2 - 1ull;
+                    jh = 64 * k + __ffsll((long long)m2) - 1;
+                }
+                c += pc;
+            }
+        }
+        if (jh < 0) break;                               // (fewer unowned columns than rows left: non-finite costs upstream)
+        if (lane == 0) { tree[jh] = h; tpar[jh] = -1; }
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) M[k] = INFINITY;
+        double off = 0.0, mq = 0.0;
+        int mcol = -1, nm = 1;
+        unsigned mine = 0u;
+        if (lane == 0) { mcol = jh; mq = ld_d(price + jh); }
+        for (int r = 0; r < MW_TREE_K; ++r) {
+            const int tcol = __builtin_amdgcn_readlane(mcol, nm - 1);
+            const double tq = bcast_d(mq, nm - 1);
+            const float tx = T_[3 * tcol], ty = T_[3 * tcol + 1], tz = T_[3 * tcol + 2];
+            double best = INFINITY;
+            int bk = 0x7fffffff;
+#pragma unroll
+            for (int k = 0; k < CPL; ++k)
+                if (u[k] < INFINITY && !((mine >> k) & 1u)) {
+                    M[k] = fmin(M[k], (double)mw_sqrt(reart_sqdist3(sx[k], sy[k], sz[k], tx, ty, tz)) + tq);
+                    const double sl = (M[k] - off) - u[k];
+                    if (sl < best) { best = sl; bk = 64 * k + lane; }
+                }
+            lap_wave_argmin_fast(best, bk);
+            if (!(best < INFINITY)) break;
+            off += best > 0.0 ? best : 0.0;
+            bk = mw_uniform(bk);
+            int ok = 0;
+            if (lane == 0) {
+                int seen = -1;
+                ok = __hip_atomic_compare_exchange_strong(tree + bk, &seen, h, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
+            }
+            if (!mw_uniform(ok)) break;                  // the nearest row is another tree's: this one is as low as it may go
+            // the row's parent: the tree column that attains its M (the same expression, so the same value)
+            float rx = 0.f, ry = 0.f, rz = 0.f;
+#pragma unroll
+            for (int k = 0; k < CPL; ++k)
+                if ((bk >> 6) == k) { rx = sx[k]; ry = sy[k]; rz = sz[k]; }
+            rx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rx), bk & 63));      // (the builtin moves integers: bits, not values)
+            ry = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ry), bk & 63));
+            rz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rz), bk & 63));
+            double pv = INFINITY;
+            int pm = 0x7fffffff;
+            if (lane < nm) {
+                pv = (double)mw_sqrt(reart_sqdist3(rx, ry, rz, T_[3 * mcol], T_[3 * mcol + 1], T_[3 * mcol + 2])) + mq;
+                pm = mcol;
+            }
+            lap_wave_argmin_fast(pv, pm);
+            const double pnew = ld_d(price + bk);
+            if (lane == 0) tpar[bk] = pm;
+            if (lane == nm) { mcol = bk; mq = pnew + off; }
+            if (lane == (bk & 63)) mine |= 1u << (bk >> 6);
+            ++nm;
+        }
+        if (lane < nm) __hip_atomic_store(price + mcol, mq - off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 #define MW_LOCKED (-2)
 template <int CPL>
 __global__ __launch_bounds__(64 * MW_NW) void lap_mc_arr_kernel(JvArgs a) {
@@ -703,7 +849,7 @@ int reart_internal_jvmw_nmax() { return 64 * 32; }
 
 template <int CPL>
 static int mw_launch(const JvArgs &a, int racers, hipStream_t stream) {
-    const size_t lds = (size_t)a.n * (8 + 4 * 4 + 6 * 4 + 8);
+    const size_t lds = (size_t)a.n * (8 + 4 * 4 + 6 * 4 + 8 + 2 * 4);
     if (lds > REART_LDS_DEFAULT_CAP &&
         hipFuncSetAttribute((const void *)lap_jvmw_kernel<CPL, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)
         return REART_ERR_LAUNCH;
@@ -721,7 +867,7 @@ int reart_internal_jvmw_launch(const JvArgs &a, int racers, hipStream_t stream) 
 
 template <int CPL>
 static int mc_launch(const JvArgs &a, int racers, int arr_wgs, hipStream_t stream) {
-    const size_t lds = (size_t)a.n * (8 + 4 * 4 + 6 * 4 + 8);
+    const size_t lds = (size_t)a.n * (8 + 4 * 4 + 6 * 4 + 8 + 2 * 4);
     if (lds > REART_LDS_DEFAULT_CAP &&
         (hipFuncSetAttribute((const void *)lap_jvmw_kernel<CPL, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess ||
          hipFuncSetAttribute((const void *)lap_jvmw_kernel<CPL, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess))
@@ -742,6 +888,13 @@ static int mc_launch(const JvArgs &a, int racers, int arr_wgs, hipStream_t strea
     const int split = (2 * arr_wgs * a.B <= 256) ? 2 : 1;
     hipLaunchKernelGGL((lap_mc_arr_kernel<CPL>), dim3(arr_wgs * split, a.B), dim3(64 * MW_NW / split), 0, stream, s2);
     REART_CHECK_LAUNCH();
+#if MW_TREE_K > 0
+    hipLaunchKernelGGL((lap_mc_trees_kernel<CPL>), dim3(a.B * 8 <= 256 ? 8 : 4, a.B), dim3(256), 0, stream, s2);
+    REART_CHECK_LAUNCH();
+#endif
+#ifdef MW_STOP_AFTER_TREES
+    return REART_OK;
+#endif
     hipLaunchKernelGGL((lap_jvmw_kernel<CPL, 2>), dim3(a.B, racers), dim3(64 * MW_NW), lds, stream, a);
     REART_CHECK_LAUNCH();
     return REART_OK;
