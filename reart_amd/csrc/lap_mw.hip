@@ -158,10 +158,10 @@ __device__ __forceinline__ void mw_row_costs(float ax, float ay, float az, const
 // Column j = 64 k + lane is slot k of lane `lane` in every wave.
 // STAGE 0: the whole sequential part in one launch.  STAGE 1: set-up only -- the state after the release / greedy steps goes to
 // a.mc_* for lap_mc_arr_kernel.  STAGE 2: the path searches only, from the state the row reduction left in a.mc_*.
-template <int CPL, int STAGE>
-__global__ __launch_bounds__(64 * MW_NW) void lap_jvmw_kernel(JvArgs a) {
+template <int CPL, int STAGE, int NW = MW_NW>
+__global__ __launch_bounds__(64 * NW) void lap_jvmw_kernel(JvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lsm[];
-    constexpr int BS = 64 * MW_NW;
+    constexpr int BS = 64 * NW;
     const int n = a.n, b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     double *price = (double *)lsm;                                      // [n]
     int *owner = (int *)(price + n);                                    // [n] column -> row
@@ -173,8 +173,8 @@ __global__ __launch_bounds__(64 * MW_NW) void lap_jvmw_kernel(JvArgs a) {
     double *hcol = (double *)(ptz + n);                                 // [n] searches: potential of the row that owns the column
     int *tof = (int *)(hcol + n), *tpr = tof + n;                       // [n] each: the column's tree (lap_mc_trees_kernel) | its parent there
     __shared__ MwShared sh;
-    __shared__ double s_red[MW_NW];
-    __shared__ int s_cw[MW_NW];
+    __shared__ double s_red[NW];
+    __shared__ int s_cw[NW];
     const bool race = STAGE != 1 && a.done != nullptr;
     const int racer = race ? (int)blockIdx.y : 0;
     [[maybe_unused]] const unsigned long long tp0_ = MWP_NOW();
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(64 * MW_NW) void lap_jvmw_kernel(JvArgs a) {
     if (tid == 0) { sh.lock = 0; sh.qhead = 0; sh.nnext = 0; sh.abort_ = 0; sh.flag = 0; sh.unsolved = 0; sh.steps = 0; sh.arr = 0; sh.conflicts = 0; }
     __syncthreads();
     mx = 0.0;
-    for (int w = 0; w < MW_NW; ++w) mx = fmax(mx, s_red[w]);
+    for (int w = 0; w < NW; ++w) mx = fmax(mx, s_red[w]);
     if (!(mx > 0.0)) mx = 1.0;
     if (STAGE == 2) mx = a.scale[b];
     const double keep_tol = mx * a.keep_tol;
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(64 * MW_NW) void lap_jvmw_kernel(JvArgs a) {
         for (int w = 0; w < wv; ++w) off += s_cw[w];
         if (fr) flist[off + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = i;
         __syncthreads();
-        if (tid == 0) { int t = 0; for (int w = 0; w < MW_NW; ++w) t += s_cw[w]; sh.flag += t; }
+        if (tid == 0) { int t = 0; for (int w = 0; w < NW; ++w) t += s_cw[w]; sh.flag += t; }
         __syncthreads();
     }
     const int nfree = sh.flag;
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(64 * MW_NW) void lap_jvmw_kernel(JvArgs a) {
     // per wave were built and measured first (profiles/r04_lap_per_wave_search_variant.hip.txt): the row reduction's chains
     // are independent, the searches are not -- 5 % of them label > 500 of the 1024 columns and hold 45 % of all steps, any
     // commit elsewhere invalidates them, and a wave alone takes 1.7 us per step.
-    constexpr int CPT = CPL >= MW_NW ? CPL / MW_NW : 1;   // n <= 64 CPL <= BS * CPT
+    constexpr int CPT = CPL >= NW ? CPL / NW : 1;   // n <= 64 CPL <= BS * CPT
     static_assert(CPT >= 1, "a thread owns at least one column");
     float qx[CPT], qy[CPT], qz[CPT];
     double pj[CPT];
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(64 * MW_NW) void lap_jvmw_kernel(JvArgs a) {
             __syncthreads();
             m = s_red[0];
 #pragma unroll
-            for (int w = 1; w < MW_NW; ++w) m = fmin(m, s_red[w]);
+            for (int w = 1; w < NW; ++w) m = fmin(m, s_red[w]);
             __syncthreads();                              // s_red is rewritten by the next column
             if (tid == 0 && m > 0.0 && m < INFINITY) price[jh] = ph - m;
         }
@@ -432,8 +432,8 @@ __global__ __launch_bounds__(64 * MW_NW) void lap_jvmw_kernel(JvArgs a) {
     // its waves issue -- 35 per column and relaxation, the correctly rounded square root among them --, not by latencies
     // that extra relaxations could hide.)
     __shared__ int s_path[64];
-    __shared__ double s_rv[2][MW_NW];
-    __shared__ int s_rj[2][MW_NW], s_lostp[2];
+    __shared__ double s_rv[2][NW];
+    __shared__ int s_rj[2][NW], s_lostp[2];
     if (tid == 0) { s_lostp[0] = 0; s_lostp[1] = 0; }
     bool aborted = mw_flag(&sh.abort_) != 0, unsolved = mw_flag(&sh.unsolved) != 0;     // uniform: read after the barrier
     MWS_DECL;
@@ -470,8 +470,8 @@ __global__ __launch_bounds__(64 * MW_NW) void lap_jvmw_kernel(JvArgs a) {
             __syncthreads();
             MWS(1);
             if (race && s_lostp[par]) { aborted = true; break; }            // uniform: everybody reads the step's slot
-            bv = lane < MW_NW ? s_rv[par][lane] : INFINITY; bj = lane < MW_NW ? s_rj[par][lane] : 0x7fffffff;
-            mw_argmin_key<(MW_NW <= 2 ? 1 : (MW_NW <= 4 ? 2 : (MW_NW <= 8 ? 3 : 4)))>(bv, bj);
+            bv = lane < NW ? s_rv[par][lane] : INFINITY; bj = lane < NW ? s_rj[par][lane] : 0x7fffffff;
+            mw_argmin_key<(NW <= 2 ? 1 : (NW <= 4 ? 2 : (NW <= 8 ? 3 : 4)))>(bv, bj);
             ++my_steps;
             mu = bv;
             MWS(2);
@@ -895,7 +895,14 @@ static int mc_launch(const JvArgs &a, int racers, int arr_wgs, hipStream_t strea
 #ifdef MW_STOP_AFTER_TREES
     return REART_OK;
 #endif
-    hipLaunchKernelGGL((lap_jvmw_kernel<CPL, 2>), dim3(a.B, racers), dim3(64 * MW_NW), lds, stream, a);
+#ifndef MW_SNW32
+#define MW_SNW32 16          // waves of a search workgroup at 32 columns per lane (n > 1024): two columns per thread instead of four; projection 76.7 -> 79.0 it/s
+#endif
+    constexpr int SNW = CPL == 32 ? MW_SNW32 : MW_NW;
+    if (SNW != MW_NW && lds > REART_LDS_DEFAULT_CAP &&
+        hipFuncSetAttribute((const void *)lap_jvmw_kernel<CPL, 2, SNW>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)
+        return REART_ERR_LAUNCH;
+    hipLaunchKernelGGL((lap_jvmw_kernel<CPL, 2, SNW>), dim3(a.B, racers), dim3(64 * SNW), lds, stream, a);
     REART_CHECK_LAUNCH();
     return REART_OK;
 }
