@@ -774,6 +774,7 @@ __global__ __launch_bounds__(64 * MW_NW) void lap_mc_arr_kernel(JvArgs a) {
         if (q >= nfree) break;
         int i = flist[q];
         float ax = S_[3 * i], ay = S_[3 * i + 1], az = S_[3 * i + 2];
+        int spins = 0;
         for (int budget = a.mc_chain; ; ) {
             // ONE round of reads per step: every column's price and owner as they are now (stale by the time they are used:
             // harmless, see the top of the file; what the step writes is validated under the column's lock)
@@ -804,7 +805,11 @@ __global__ __launch_bounds__(64 * MW_NW) void lap_mc_arr_kernel(JvArgs a) {
             const double pj1 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(pl), j1 & 63),
                                                 __builtin_amdgcn_readlane(__double2loint(pl), j1 & 63));
             const int own = OWN_TOO ? __builtin_amdgcn_readlane(ol, j1 & 63) : ld_i(owner + j1);
-            if (own == MW_LOCKED) { ++my_conf; continue; }                     // somebody is committing on it: look again
+            if (own == MW_LOCKED && ++spins < (1 << 14)) { ++my_conf; continue; }     // somebody is committing on it: look again
+            if (own == MW_LOCKED) {                                            // (never observed; a wait must not be unbounded)
+                if (lane == 0) next[__hip_atomic_fetch_add(&cnt[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = i;
+                break;
+            }
             const bool tie = !(v1 < v2);
             if (--budget < 0 || (tie && own >= 0)) {                           // out of budget / an exact tie on an owned column
                 if (lane == 0) next[__hip_atomic_fetch_add(&cnt[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = i;
