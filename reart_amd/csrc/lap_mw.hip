@@ -651,6 +651,7 @@ __global__ __launch_bounds__(64 * MW_NW) void lap_mc_tighten_kernel(JvArgs a) {
 #endif
 template <int CPL>
 __global__ __launch_bounds__(256) void lap_mc_trees_kernel(JvArgs a) {
+    static_assert(MW_TREE_K < 63, "a tree's nodes live one per lane, and the searches' path buffer holds 64 columns");
     const int n = a.n, b = blockIdx.y, lane = threadIdx.x & 63;
     const int *cnt = a.mc_cnt + 8 * b;
     const int nh = cnt[2];                               // rows left for the searches = columns still unowned
