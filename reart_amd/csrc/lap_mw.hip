@@ -749,6 +749,113 @@ __global__ __launch_bounds__(256) void lap_mc_trees_kernel(JvArgs a) {
     }
 }
 
+// The trees of lap_mc_trees_kernel stop where they meet (a tree's nearest row belongs to its neighbour) -- and the unowned
+// columns of a re-solve cluster, so they meet at once.  Here the forest goes on growing AS ONE SET: all its columns (and their
+// rows' potentials) shift together by the least slack of an outside row, that row joins under the column it is now tight to
+// and inherits that column's ROOT (a search that reaches it walks to that unowned column; the root is what a search uses up).
+// One workgroup per problem: a thread owns the rows of its columns (M_i = min over the forest of c_it + q_t and the column
+// that attains it in registers), a round is one workgroup arg-min + one distance per row.  MW_FOREST_R rounds.
+#ifndef MW_FOREST_R
+#define MW_FOREST_R 512       // measured 0 / 48 / 128 / 256 / 512 / 1024: recipe 3.57 / 3.58 / 3.51 / 3.37 / 3.33 / 3.70 ms per refresh, projection 78.8 / 77.9 / 80.4 / 82.4 / 86.7 / 86.8 it/s
+#endif
+template <int CPL>
+__global__ __launch_bounds__(512) void lap_mc_forest_kernel(JvArgs a) {
+    constexpr int BS = 512, NW = 8, CPT = CPL / NW >= 1 ? CPL / NW : 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
+    const int n = a.n, b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int *cnt = a.mc_cnt + 8 * b;
+    if (cnt[2] <= 0 || cnt[6]) return;
+    double *gprice = a.mc_price + (size_t)b * n;
+    const int *owner = a.mc_owner + (size_t)b * n;
+    int *gtree = a.mc_tree + (size_t)b * n, *gtpar = a.mc_tpar + (size_t)b * n;
+    const float *S_ = a.src + (size_t)b * n * 3, *T_ = a.tgt + (size_t)b * n * 3;
+    double *q = (double *)fsm;                    // [n] forest columns: price + the shift when they joined
+    int *flist = (int *)(q + n);                  // [n] the forest's columns
+    int *troot = flist + n;                       // [n] column -> root (tree id) or -1
+    __shared__ int s_n, s_j[2][NW];
+    __shared__ double s_v[2][NW];
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    float sx[CPT], sy[CPT], sz[CPT];
+    double u[CPT], M[CPT], pk[CPT];
+    int Mt[CPT];
+    bool out[CPT];                                // a matched row outside the forest
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+        const int j = tid + k * BS;
+        const int jj = j < n ? j : 0;
+        const int i = j < n ? owner[j] : -1, tr = j < n ? gtree[j] : -1;
+        pk[k] = gprice[jj];
+        if (j < n) { troot[j] = tr; q[j] = pk[k]; if (tr >= 0) flist[atomicAdd(&s_n, 1)] = j; }
+        const int ii = i >= 0 ? i : 0;
+        sx[k] = S_[3 * ii]; sy[k] = S_[3 * ii + 1]; sz[k] = S_[3 * ii + 2];
+        out[k] = j < n && i >= 0 && tr < 0;
+        u[k] = out[k] ? (double)mw_sqrt(reart_sqdist3(sx[k], sy[k], sz[k], T_[3 * jj], T_[3 * jj + 1], T_[3 * jj + 2])) + pk[k] : INFINITY;
+        M[k] = INFINITY; Mt[k] = -1;
+    }
+    __syncthreads();
+    const int nf0 = s_n;
+    for (int m = 0; m < nf0; ++m) {               // M over the forest the trees left
+        const int t = flist[m];
+        const float tx = T_[3 * t], ty = T_[3 * t + 1], tz = T_[3 * t + 2];
+        const double tq = q[t];
+#pragma unroll
+        for (int k = 0; k < CPT; ++k)
+            if (out[k]) {
+                const double v = (double)mw_sqrt(reart_sqdist3(sx[k], sy[k], sz[k], tx, ty, tz)) + tq;
+                if (v < M[k]) { M[k] = v; Mt[k] = t; }
+            }
+    }
+    double off = 0.0;
+    int nf = nf0;
+    for (int r = 0; r < MW_FOREST_R; ++r) {
+        double bv = INFINITY;
+        int bj = 0x7fffffff;
+#pragma unroll
+        for (int k = 0; k < CPT; ++k)
+            if (out[k]) {
+                const double sl = (M[k] - off) - u[k];
+                if (sl < bv) { bv = sl; bj = tid + k * BS; }
+            }
+        lap_wave_argmin_fast(bv, bj);
+        const int par = r & 1;
+        if (lane == 0) { s_v[par][wv] = bv; s_j[par][wv] = bj; }
+        __syncthreads();
+        bv = lane < NW ? s_v[par][lane] : INFINITY; bj = lane < NW ? s_j[par][lane] : 0x7fffffff;
+        lap_wave_argmin_fast(bv, bj);
+        if (!(bv < INFINITY)) break;
+        off += bv > 0.0 ? bv : 0.0;
+        const int js = bj;
+        // the row of column js joins: its owner thread records parent, root and q
+        if ((js & (BS - 1)) == tid) {
+#pragma unroll
+            for (int k = 0; k < CPT; ++k)
+                if (js == tid + k * BS) {
+                    out[k] = false;
+                    troot[js] = troot[Mt[k]]; gtpar[js] = Mt[k];
+                    q[js] = pk[k] + off;
+                    flist[nf] = js;
+                }
+        }
+        ++nf;
+        __syncthreads();
+        const float tx = T_[3 * js], ty = T_[3 * js + 1], tz = T_[3 * js + 2];
+        const double tq = q[js];
+#pragma unroll
+        for (int k = 0; k < CPT; ++k)
+            if (out[k]) {
+                const double v = (double)mw_sqrt(reart_sqdist3(sx[k], sy[k], sz[k], tx, ty, tz)) + tq;
+                if (v < M[k]) { M[k] = v; Mt[k] = js; }
+            }
+    }
+    __syncthreads();
+    for (int m = tid; m < nf; m += BS) {          // the forest's prices and roots
+        const int t = flist[m];
+        gprice[t] = q[t] - off;
+        gtree[t] = troot[t];
+    }
+}
+
 #define MW_LOCKED (-2)
 template <int CPL>
 __global__ __launch_bounds__(64 * MW_NW) void lap_mc_arr_kernel(JvArgs a) {
@@ -897,6 +1004,13 @@ static int mc_launch(const JvArgs &a, int racers, int arr_wgs, hipStream_t strea
 #if MW_TREE_K > 0
     hipLaunchKernelGGL((lap_mc_trees_kernel<CPL>), dim3(a.B * 8 <= 256 ? 8 : 4, a.B), dim3(256), 0, stream, s2);
     REART_CHECK_LAUNCH();
+#endif
+#if MW_FOREST_R > 0
+    {
+        const size_t flds = (size_t)a.n * (8 + 4 + 4);
+        hipLaunchKernelGGL((lap_mc_forest_kernel<CPL>), dim3(a.B), dim3(512), flds, stream, s2);
+        REART_CHECK_LAUNCH();
+    }
 #endif
 #ifdef MW_STOP_AFTER_TREES
     return REART_OK;
