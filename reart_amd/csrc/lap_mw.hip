@@ -769,28 +769,30 @@ __global__ __launch_bounds__(512) void lap_mc_forest_kernel(JvArgs a) {
     const int *owner = a.mc_owner + (size_t)b * n;
     int *gtree = a.mc_tree + (size_t)b * n, *gtpar = a.mc_tpar + (size_t)b * n;
     const float *S_ = a.src + (size_t)b * n * 3, *T_ = a.tgt + (size_t)b * n * 3;
-    double *q = (double *)fsm;                    // [n] forest columns: price + the shift when they joined
-    int *flist = (int *)(q + n);                  // [n] the forest's columns
+    double *q = (double *)fsm;                    // [n] every column's price as the launch found it
+    double *oj = q + n;                           // [n] forest columns: the shift when they joined
+    int *flist = (int *)(oj + n);                 // [n] the forest's columns
     int *troot = flist + n;                       // [n] column -> root (tree id) or -1
     __shared__ int s_n, s_j[2][NW];
     __shared__ double s_v[2][NW];
     if (tid == 0) s_n = 0;
     __syncthreads();
     float sx[CPT], sy[CPT], sz[CPT];
-    double u[CPT], M[CPT], pk[CPT];
+    double u[CPT], M[CPT];
     int Mt[CPT];
-    bool out[CPT];                                // a matched row outside the forest
+    unsigned out = 0u;                            // bit k: a matched row outside the forest
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
         const int j = tid + k * BS;
         const int jj = j < n ? j : 0;
         const int i = j < n ? owner[j] : -1, tr = j < n ? gtree[j] : -1;
-        pk[k] = gprice[jj];
-        if (j < n) { troot[j] = tr; q[j] = pk[k]; if (tr >= 0) flist[atomicAdd(&s_n, 1)] = j; }
+        const double pk = gprice[jj];
+        if (j < n) { troot[j] = tr; q[j] = pk; oj[j] = 0.0; if (tr >= 0) flist[atomicAdd(&s_n, 1)] = j; }
         const int ii = i >= 0 ? i : 0;
         sx[k] = S_[3 * ii]; sy[k] = S_[3 * ii + 1]; sz[k] = S_[3 * ii + 2];
-        out[k] = j < n && i >= 0 && tr < 0;
-        u[k] = out[k] ? (double)mw_sqrt(reart_sqdist3(sx[k], sy[k], sz[k], T_[3 * jj], T_[3 * jj + 1], T_[3 * jj + 2])) + pk[k] : INFINITY;
+        const bool o = j < n && i >= 0 && tr < 0;
+        if (o) out |= 1u << k;
+        u[k] = o ? (double)mw_sqrt(reart_sqdist3(sx[k], sy[k], sz[k], T_[3 * jj], T_[3 * jj + 1], T_[3 * jj + 2])) + pk : INFINITY;
         M[k] = INFINITY; Mt[k] = -1;
     }
     __syncthreads();
@@ -801,49 +803,49 @@ __global__ __launch_bounds__(512) void lap_mc_forest_kernel(JvArgs a) {
         const double tq = q[t];
 #pragma unroll
         for (int k = 0; k < CPT; ++k)
-            if (out[k]) {
+            if ((out >> k) & 1u) {
                 const double v = (double)mw_sqrt(reart_sqdist3(sx[k], sy[k], sz[k], tx, ty, tz)) + tq;
                 if (v < M[k]) { M[k] = v; Mt[k] = t; }
             }
     }
     double off = 0.0;
     int nf = nf0;
+    // a round: the workgroup's arg-min of the outside rows' slacks (ordered-integer keys, as in the searches), ONE barrier,
+    // then everybody relaxes its rows against the column that joined (its price is in q, the shift is known to all)
     for (int r = 0; r < MW_FOREST_R; ++r) {
         double bv = INFINITY;
         int bj = 0x7fffffff;
 #pragma unroll
         for (int k = 0; k < CPT; ++k)
-            if (out[k]) {
+            if ((out >> k) & 1u) {
                 const double sl = (M[k] - off) - u[k];
                 if (sl < bv) { bv = sl; bj = tid + k * BS; }
             }
-        lap_wave_argmin_fast(bv, bj);
+        mw_argmin_key<6>(bv, bj);
         const int par = r & 1;
         if (lane == 0) { s_v[par][wv] = bv; s_j[par][wv] = bj; }
         __syncthreads();
         bv = lane < NW ? s_v[par][lane] : INFINITY; bj = lane < NW ? s_j[par][lane] : 0x7fffffff;
-        lap_wave_argmin_fast(bv, bj);
-        if (!(bv < INFINITY)) break;
+        mw_argmin_key<3>(bv, bj);
+        if (bj == 0x7fffffff || !(bv < INFINITY)) break;
         off += bv > 0.0 ? bv : 0.0;
         const int js = bj;
-        // the row of column js joins: its owner thread records parent, root and q
-        if ((js & (BS - 1)) == tid) {
+        if ((js & (BS - 1)) == tid) {             // the row of column js joins: parent, root, shift at joining
 #pragma unroll
             for (int k = 0; k < CPT; ++k)
                 if (js == tid + k * BS) {
-                    out[k] = false;
+                    out &= ~(1u << k);
                     troot[js] = troot[Mt[k]]; gtpar[js] = Mt[k];
-                    q[js] = pk[k] + off;
+                    oj[js] = off;
                     flist[nf] = js;
                 }
         }
         ++nf;
-        __syncthreads();
         const float tx = T_[3 * js], ty = T_[3 * js + 1], tz = T_[3 * js + 2];
-        const double tq = q[js];
+        const double tq = q[js] + off;
 #pragma unroll
         for (int k = 0; k < CPT; ++k)
-            if (out[k]) {
+            if ((out >> k) & 1u) {
                 const double v = (double)mw_sqrt(reart_sqdist3(sx[k], sy[k], sz[k], tx, ty, tz)) + tq;
                 if (v < M[k]) { M[k] = v; Mt[k] = js; }
             }
@@ -851,7 +853,7 @@ __global__ __launch_bounds__(512) void lap_mc_forest_kernel(JvArgs a) {
     __syncthreads();
     for (int m = tid; m < nf; m += BS) {          // the forest's prices and roots
         const int t = flist[m];
-        gprice[t] = q[t] - off;
+        gprice[t] = (q[t] + oj[t]) - off;
         gtree[t] = troot[t];
     }
 }
@@ -1007,7 +1009,7 @@ static int mc_launch(const JvArgs &a, int racers, int arr_wgs, hipStream_t strea
 #endif
 #if MW_FOREST_R > 0
     {
-        const size_t flds = (size_t)a.n * (8 + 4 + 4);
+        const size_t flds = (size_t)a.n * (8 + 8 + 4 + 4);
         hipLaunchKernelGGL((lap_mc_forest_kernel<CPL>), dim3(a.B), dim3(512), flds, stream, s2);
         REART_CHECK_LAUNCH();
     }
