@@ -773,6 +773,7 @@ __global__ __launch_bounds__(512) void lap_mc_forest_kernel(JvArgs a) {
     double *oj = q + n;                           // [n] forest columns: the shift when they joined
     int *flist = (int *)(oj + n);                 // [n] the forest's columns
     int *troot = flist + n;                       // [n] column -> root (tree id) or -1
+    float *ltx = (float *)(troot + n), *lty = ltx + n, *ltz = lty + n;     // [n] target points (a round reads ONE, chosen by the arg-min)
     __shared__ int s_n, s_j[2][NW];
     __shared__ double s_v[2][NW];
     if (tid == 0) s_n = 0;
@@ -787,7 +788,11 @@ __global__ __launch_bounds__(512) void lap_mc_forest_kernel(JvArgs a) {
         const int jj = j < n ? j : 0;
         const int i = j < n ? owner[j] : -1, tr = j < n ? gtree[j] : -1;
         const double pk = gprice[jj];
-        if (j < n) { troot[j] = tr; q[j] = pk; oj[j] = 0.0; if (tr >= 0) flist[atomicAdd(&s_n, 1)] = j; }
+        if (j < n) {
+            troot[j] = tr; q[j] = pk; oj[j] = 0.0;
+            ltx[j] = T_[3 * j]; lty[j] = T_[3 * j + 1]; ltz[j] = T_[3 * j + 2];
+            if (tr >= 0) flist[atomicAdd(&s_n, 1)] = j;
+        }
         const int ii = i >= 0 ? i : 0;
         sx[k] = S_[3 * ii]; sy[k] = S_[3 * ii + 1]; sz[k] = S_[3 * ii + 2];
         const bool o = j < n && i >= 0 && tr < 0;
@@ -799,7 +804,7 @@ __global__ __launch_bounds__(512) void lap_mc_forest_kernel(JvArgs a) {
     const int nf0 = s_n;
     for (int m = 0; m < nf0; ++m) {               // M over the forest the trees left
         const int t = flist[m];
-        const float tx = T_[3 * t], ty = T_[3 * t + 1], tz = T_[3 * t + 2];
+        const float tx = ltx[t], ty = lty[t], tz = ltz[t];
         const double tq = q[t];
 #pragma unroll
         for (int k = 0; k < CPT; ++k)
@@ -841,7 +846,7 @@ __global__ __launch_bounds__(512) void lap_mc_forest_kernel(JvArgs a) {
                 }
         }
         ++nf;
-        const float tx = T_[3 * js], ty = T_[3 * js + 1], tz = T_[3 * js + 2];
+        const float tx = ltx[js], ty = lty[js], tz = ltz[js];
         const double tq = q[js] + off;
 #pragma unroll
         for (int k = 0; k < CPT; ++k)
@@ -1009,7 +1014,7 @@ static int mc_launch(const JvArgs &a, int racers, int arr_wgs, hipStream_t strea
 #endif
 #if MW_FOREST_R > 0
     {
-        const size_t flds = (size_t)a.n * (8 + 8 + 4 + 4);
+        const size_t flds = (size_t)a.n * (8 + 8 + 4 + 4 + 12);
         hipLaunchKernelGGL((lap_mc_forest_kernel<CPL>), dim3(a.B), dim3(512), flds, stream, s2);
         REART_CHECK_LAUNCH();
     }
