@@ -309,17 +309,20 @@ def bench_kinematic(args, dev, rank, world, distributed, barrier):
     steps_total = float(st[:, 2].sum() + (st[:, 3] >> 8).sum())
     roof = {"bound": "latency", "achieved": round(bound_ms, 4), "peak": round(lap_ms, 4), "unit": "ms per re-solve (lower bound / measured)",
             "frac": round(bound_ms / lap_ms, 4) if lap_ms > 0 else None, "traffic": None,
-            "kernel": "lap_jvmw_kernel<32, 2> (searches) + lap_mc_arr_kernel<32> + set-up + two lap_jv_pass_kernel launches (re-solve of the "
-                      "T-1 assignment problems from the previous optimum: row potentials on the whole chip, augmenting row reduction "
-                      "one chain per wave on eight workgroups per problem, shortest augmenting paths with one workgroup per problem "
-                      "and racer -- the solver state in LDS --, then the exact dual certificate on the whole chip)",
+            "kernel": "lap_jvmw_kernel<32, 2, 16> (searches) + lap_mc_forest_kernel<32> + lap_mc_arr_kernel<32> + lap_mc_trees_kernel<32> + "
+                      "set-up + two lap_jv_pass_kernel launches (re-solve of the T-1 assignment problems from the previous optimum: row "
+                      "potentials on the whole chip, unowned columns re-priced, augmenting row reduction one chain per wave on eight "
+                      "workgroups per problem, trees / a forest of zero-cost rows behind the columns still unowned, shortest augmenting "
+                      "paths that end at the forest with one workgroup per problem and racer -- the solver state in LDS --, then the "
+                      "exact dual certificate on the whole chip)",
             "kernel_ms": round(lap_ms, 4), "solves_measured": len(loop.lap_events),
             "step_floor_us": round(floor_us.value, 4), "steps_slowest_problem": round(steps_max, 1), "steps_mean_problem": round(steps_mean, 1),
             "cold_solve_ms": round(lap_cold_ms, 3),
-            "note": "latency roofline: a re-solve ends with its slowest problem's sequential chain of path-search steps (the row "
-                    "reduction's chains run 64 at a time per problem and are not part of that chain); step_floor_us = the "
+            "note": "latency roofline: a re-solve ends with its slowest problem's sequential chain of workgroup-wide steps: the rounds "
+                    "of the backward growth and the path-search steps (the row reduction's chains run 64 at a time per problem, the "
+                    "trees a wave each: not part of that chain); step_floor_us = the "
                     "workgroup-wide arg-min over the 2048 labels + its barrier with "
-                    "the solver's own primitives and nothing else (reart_lap_step_floor, measured in this run); achieved = search steps "
+                    "the solver's own primitives and nothing else (reart_lap_step_floor, measured in this run); achieved = those steps "
                     "of the slowest problem (mean over the timed solves) x floor; frac = achieved / kernel_ms -- what is above it is "
                     "the step's relaxation (4 square roots per lane), the row-reduction launch and the two whole-chip passes.  The HBM view "
                     f"is meaningless here ({2 * cost.shape[0] * n * 12} algorithmic bytes per solve).  "
@@ -354,7 +357,7 @@ def bench_kinematic(args, dev, rank, world, distributed, barrier):
                    "parallelism": f"instances x{world}",
                    "loop": type(loop).__name__},
         "roofline": roof, "cpu_baseline": cpu,
-        "lap_stats_last": {"rows_released": (st[:, 0] & 0xffff).tolist(), "winning_racer": (st[:, 0] >> 16).tolist(),
+        "lap_stats_last": {"rows_released": (st[:, 0] & 0xffff).tolist(), "winning_racer": ((st[:, 0] >> 16) & 31).tolist(),
                            "wins_per_racer": getattr(loop, "lap_winners", np.zeros(1)).tolist(), "rows_searched": st[:, 1].tolist(),
                            "dijkstra_steps": st[:, 2].tolist(), "row_reduction_steps": (st[:, 3] >> 8).tolist(),
                            "certificate_rounds": (st[:, 3] & 255).tolist()},
@@ -483,7 +486,7 @@ def bench_nao_recipe(args, dev):
     floor_us = ctypes.c_double(0.0)
     fws = torch.empty(16 * B + 256, dtype=torch.uint8, device=dev)
     L_.check(L_.lib().reart_lap_step_floor(B, n, 20000, L_.ptr(fws), fws.numel(), ctypes.byref(floor_us), L_.stream()), "reart_lap_step_floor")
-    st = np.asarray(phase.stats_log[1:], dtype=np.float64)          # [re-solves, 3]: slowest problem's search steps, mean, row-reduction steps (mean)
+    st = np.asarray(phase.stats_log[1:], dtype=np.float64)          # [re-solves, 5]: see AssignmentPhase.stats_log
     steps_max = float(st[:, 0].mean()) if st.size else 0.0
     bound_ms = steps_max * floor_us.value * 1e-3
     solve_ms = rep.get("ms_per_solve", 0.0)
@@ -525,17 +528,21 @@ def bench_nao_recipe(args, dev):
                    "lap_fallbacks": rep["lap_fallbacks"]},
         "roofline": {"bound": "latency", "achieved": round(bound_ms, 4), "peak": round(solve_ms, 4),
                      "unit": "ms per re-solve (lower bound / measured)", "frac": round(bound_ms / solve_ms, 4) if solve_ms > 0 else None,
-                     "traffic": None, "kernel": "lap_jvmw_kernel<16, 2> (searches) + lap_mc_arr_kernel<16> + set-up + two lap_jv_pass_kernel launches (re-solve of "
-                     "the 9 problems from the previous refresh's optimum: row reduction one chain per wave on eight workgroups per "
-                     "problem, then shortest augmenting paths, 13 racers per problem)",
+                     "traffic": None, "kernel": "lap_jvmw_kernel<16, 2, 8> (searches) + lap_mc_forest_kernel<16> + lap_mc_arr_kernel<16> + lap_mc_trees_kernel<16> + "
+                     "set-up + two lap_jv_pass_kernel launches (re-solve of the 9 problems from the previous refresh's optimum: unowned "
+                     "columns re-priced, row reduction one chain per wave on eight workgroups per problem, trees / a forest of zero-cost "
+                     "rows behind the columns still unowned, then shortest augmenting paths that end at the forest, 13 racers per problem)",
                      "kernel_ms": round(solve_ms, 4), "solves_measured": max(len(phase.events) - 1, 0),
-                     "step_floor_us": round(floor_us.value, 4), "search_steps_slowest_problem": round(steps_max, 1),
+                     "step_floor_us": round(floor_us.value, 4), "sequential_steps_slowest_problem": round(steps_max, 1),
+                     "search_steps_slowest_problem": round(float(st[:, 3].mean()) if st.size else 0.0, 1),
+                     "backward_rounds_mean_problem": round(float(st[:, 4].mean()) if st.size else 0.0, 1),
                      "search_steps_mean_problem": round(float(st[:, 1].mean()) if st.size else 0.0, 1),
                      "row_reduction_steps_mean_problem": round(float(st[:, 2].mean()) if st.size else 0.0, 1),
                      "note": "latency roofline like secondary.kinematic's: a re-solve ends with its slowest problem's sequential "
-                             "chain of path-search steps; floor = the workgroup-wide arg-min over the 1024 labels + its barrier "
-                             "alone (reart_lap_step_floor, measured in this run); the row-reduction launch (64 chains in flight per "
-                             "problem, as long as its longest chain) and the two whole-chip passes are on top"},
+                             "chain of workgroup-wide steps -- the rounds of the backward growth (lap_mc_forest_kernel) and then the "
+                             "path-search steps; floor = the workgroup-wide arg-min over the 1024 labels + its barrier alone "
+                             "(reart_lap_step_floor, measured in this run); the row-reduction launch (64 chains in flight per "
+                             "problem, as long as its longest chain), the trees and the two whole-chip passes are on top"},
         "cpu_baseline": cpu, "final_losses": [float(v) for v in eng.last_losses().cpu()[:3]],
     }
 

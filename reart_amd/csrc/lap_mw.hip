@@ -350,7 +350,7 @@ __global__ __launch_bounds__(64 * NW) void lap_jvmw_kernel(JvArgs a) {
     __syncthreads();
     } else {                                            // STAGE 2: what the row reduction on the other compute units left
         const int *c = a.mc_cnt + 8 * b;
-        nleft = c[2]; st_freed = c[5];
+        nleft = c[2]; st_freed = c[5] | ((c[7] & 0x3ff) << 21);     // (c[7]: rounds of lap_mc_forest_kernel, reported next to the released rows)
         if (tid == 0) { sh.arr = c[3]; sh.conflicts = c[4]; sh.unsolved = c[6]; }
         __syncthreads();
     }
@@ -764,7 +764,7 @@ __global__ __launch_bounds__(512) void lap_mc_forest_kernel(JvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
     const int n = a.n, b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int *cnt = a.mc_cnt + 8 * b;
-    if (cnt[2] <= 0 || cnt[6]) return;
+    if (cnt[2] <= 0 || cnt[6]) { if (tid == 0) a.mc_cnt[8 * b + 7] = 0; return; }
     double *gprice = a.mc_price + (size_t)b * n;
     const int *owner = a.mc_owner + (size_t)b * n;
     int *gtree = a.mc_tree + (size_t)b * n, *gtpar = a.mc_tpar + (size_t)b * n;
@@ -855,6 +855,7 @@ __global__ __launch_bounds__(512) void lap_mc_forest_kernel(JvArgs a) {
                 if (v < M[k]) { M[k] = v; Mt[k] = js; }
             }
     }
+    if (tid == 0) a.mc_cnt[8 * b + 7] = nf - nf0; // rounds that added a row (statistics: they are sequential steps like the searches')
     __syncthreads();
     for (int m = tid; m < nf; m += BS) {          // the forest's prices and roots
         const int t = flist[m];

@@ -181,6 +181,8 @@ class KinematicEngine:
             seq = self.lap_stats[:, 2].astype(np.int64)
             if self.lap_state.get("resolve_form", "jv") == "jv":       # one row at a time: the row reduction's steps are sequential too
                 seq = seq + (self.lap_stats[:, 3].astype(np.int64) >> 8)
+            elif self.lap_state.get("backward_rounds") is not None:    # the backward growth before the searches: the same kind of step
+                seq = seq + np.asarray(self.lap_state["backward_rounds"], dtype=np.int64)
             self.lap_steps_log.append((int(seq.max()), float(seq.mean())))
             self.lap_winners += np.bincount((self.lap_stats[:, 0] >> 16) & 15, minlength=16)[:16]         # raced re-solves: who finished first
             self.matched = self.tgt_pts.gather(1, cols[..., None].expand(-1, -1, 3))

@@ -109,7 +109,8 @@ class AssignmentPhase:
         self.refreshes = self.fallbacks = 0
         self.events = None          # set to [] to collect a (start, end) torch.cuda.Event pair around every solve
         self.collect_stats = False  # True: the solver's per-problem statistics of every refresh are read (B x 4 ints) into stats_log
-        self.stats_log = []         # per refresh: (path-search steps of the slowest problem, their mean, mean row-reduction steps)
+        self.stats_log = []         # per refresh: (sequential steps of the slowest problem = search steps + backward rounds, mean search
+                                    # steps, mean row-reduction steps, most search steps, mean backward rounds)
         self.capture_guard = None   # a context-manager factory entered around the graph capture (the sweep's _CaptureGate)
         self._have = False
 
@@ -168,7 +169,9 @@ class AssignmentPhase:
         torch.cuda.current_stream().synchronize()
         if self.collect_stats:
             sth = self._stats_host.numpy().reshape(B, 4)
-            self.stats_log.append((int(sth[:, 2].max()), float(sth[:, 2].mean()), float((sth[:, 3] >> 8).mean())))
+            back = (sth[:, 0] >> 21) & 0x3ff               # rounds of the backward growth: sequential steps of the same kind
+            self.stats_log.append((int((sth[:, 2] + back).max()), float(sth[:, 2].mean()), float((sth[:, 3] >> 8).mean()),
+                                   int(sth[:, 2].max()), float(back.mean())))
         fb = 0
         for b in (self._cert_host == 0).nonzero().flatten().tolist():      # certificate did not close: exact host solve
             from scipy.optimize import linear_sum_assignment
@@ -215,7 +218,9 @@ class AssignmentPhase:
             ev[0].record()
         if self.collect_stats:
             cols, fb, st = linear_sum_assignment_points(src_pts, self.tgt_pts, self.lap_state, device_cols=True, return_stats="full")
-            self.stats_log.append((int(st[:, 2].max()), float(st[:, 2].mean()), float((st[:, 3] >> 8).mean())))
+            back = np.asarray(self.lap_state.get("backward_rounds", np.zeros(len(st), np.int64)), dtype=np.int64)
+            self.stats_log.append((int((st[:, 2] + back).max()), float(st[:, 2].mean()), float((st[:, 3] >> 8).mean()),
+                                   int(st[:, 2].max()), float(back.mean())))
         else:
             cols, fb = linear_sum_assignment_points(src_pts, self.tgt_pts, self.lap_state, device_cols=True)
         if self.events is not None:

@@ -260,5 +260,8 @@ def linear_sum_assignment_points(src, tgt, state, return_stats=False, race=True,
         if per_wave and MW_NMIN <= n <= MW_NMAX:      # the per-wave row reduction reports its redone steps in the upper half
             state["commit_conflicts"] = (st[:, 1] >> 16) & 0xffff
             st[:, 1] &= 0xffff
+            # ... and the rounds of the backward growth (lap_mc_forest_kernel: sequential workgroup-wide steps like the searches')
+            state["backward_rounds"] = (st[:, 0] >> 21) & 0x3ff
+            st[:, 0] &= 0x1fffff
         return (state["cols"].long() if device_cols else out), fallbacks, st
     return (out, fallbacks) if return_stats else out
