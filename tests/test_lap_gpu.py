@@ -335,6 +335,14 @@ def test_resolve_per_wave_gives_the_optimum(dev, n, racers, form):
                 np.testing.assert_array_equal(c, ref[b][1])
             if k == 4:
                 assert (st[:, 0] & 0xffff).max() == 0       # nothing released: the previous optimum is still one
+            if k >= 1:
+                # the statistics of the chain forms: winner below the racer count, and (many-compute-unit form) the rounds of the
+                # backward growth next to the search steps -- zero when no row was left for a search
+                assert ((st[:, 0] >> 16) < 32).all()
+                if state.get("resolve_form") == "mc":
+                    back = np.asarray(state["backward_rounds"])
+                    assert back.shape == (B,) and (back >= 0).all() and (back <= 512).all()
+                    assert ((back > 0) <= (st[:, 1] > 0)).all()
     finally:
         lap.RESOLVE_RACERS = old
 
