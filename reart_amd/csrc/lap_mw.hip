@@ -431,7 +431,6 @@ __global__ __launch_bounds__(64 * NW) void lap_jvmw_kernel(JvArgs a) {
     // Exact, 1.6 columns per round, but a round cost 2.6 us against 1.27 us per step: the step is bound by the instructions
     // its waves issue -- 35 per column and relaxation, the correctly rounded square root among them --, not by latencies
     // that extra relaxations could hide.)
-    __shared__ int s_path[64];
     __shared__ double s_rv[2][NW];
     __shared__ int s_rj[2][NW], s_lostp[2];
     if (tid == 0) { s_lostp[0] = 0; s_lostp[1] = 0; }
@@ -510,14 +509,18 @@ __global__ __launch_bounds__(64 * NW) void lap_jvmw_kernel(JvArgs a) {
         if (tid == 0) {                                    // flip the path
             if (owner[sink] >= 0) {
                 // down the tree first: every row on the way moves to its parent column (tight pairs: prices stay), the last one
-                // takes the unowned root; from the root upwards, so that no owner is overwritten before it has moved
-                int m = 0;
-                for (int c = sink; c >= 0 && m < 64; c = tpr[c]) s_path[m++] = c;
-                for (int k = m - 2; k >= 0; --k) {
-                    const int r = owner[s_path[k]], c1 = s_path[k + 1];
-                    assigned[r] = c1; owner[c1] = r;
-                    hcol[c1] = (double)mw_sqrt(reart_sqdist3(psx[r], psy[r], psz[r], ptx[c1], pty[c1], ptz[c1])) + price[c1];
-                }
+                // takes the unowned root -- from the root upwards, so that no owner is overwritten before it has moved.  The
+                // way can be hundreds of columns long (the forest grows a node per round): the parent links are reversed on the
+                // way down and followed back (the tree is spent after this search anyway).
+                int prev = -1, c = sink, guard = 0;
+                for (; c >= 0 && guard <= n; ++guard) { const int up = tpr[c]; tpr[c] = prev; prev = c; c = up; }
+                if (guard > n || owner[prev] >= 0) sh.unsolved = 1;           // (a loop or a root that is owned: never observed)
+                else
+                    for (c = prev; tpr[c] >= 0; c = tpr[c]) {
+                        const int ch = tpr[c], r = owner[ch];
+                        assigned[r] = c; owner[c] = r;
+                        hcol[c] = (double)mw_sqrt(reart_sqdist3(psx[r], psy[r], psz[r], ptx[c], pty[c], ptz[c])) + price[c];
+                    }
             }
             int j = sink, guard = 0;
             for (;; ++guard) {
@@ -651,7 +654,7 @@ __global__ __launch_bounds__(64 * MW_NW) void lap_mc_tighten_kernel(JvArgs a) {
 #endif
 template <int CPL>
 __global__ __launch_bounds__(256) void lap_mc_trees_kernel(JvArgs a) {
-    static_assert(MW_TREE_K < 63, "a tree's nodes live one per lane, and the searches' path buffer holds 64 columns");
+    static_assert(MW_TREE_K < 63, "a tree's nodes live one per lane");
     const int n = a.n, b = blockIdx.y, lane = threadIdx.x & 63;
     const int *cnt = a.mc_cnt + 8 * b;
     const int nh = cnt[2];                               // rows left for the searches = columns still unowned
