@@ -1019,6 +1019,9 @@ static int mc_launch(const JvArgs &a, int racers, int arr_wgs, hipStream_t strea
 #if MW_FOREST_R > 0
     {
         const size_t flds = (size_t)a.n * (8 + 8 + 4 + 4 + 12);
+        if (flds > REART_LDS_DEFAULT_CAP &&
+            hipFuncSetAttribute((const void *)lap_mc_forest_kernel<CPL>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)
+            return REART_ERR_LAUNCH;
         hipLaunchKernelGGL((lap_mc_forest_kernel<CPL>), dim3(a.B), dim3(512), flds, stream, s2);
         REART_CHECK_LAUNCH();
     }
