@@ -65,6 +65,7 @@ def test_engine_equals_the_autograd_loop(dev, with_flow, gap, wd):
             np.testing.assert_allclose(getattr(m_eng, name).detach().cpu().numpy(), getattr(m_ref, name).detach().cpu().numpy(),
                                        rtol=0, atol=2e-6, err_msg=f"iteration {i} {name}")
     assert eng.lap_solves == loop.lap_solves
+    assert eng.lap_fallbacks == 0 and loop.lap_fallbacks == 0          # neither loop went through the host solver
 
 
 def test_config5_literal_against_the_oracle_loop(oracle, dev):
@@ -119,3 +120,4 @@ def test_config5_literal_against_the_oracle_loop(oracle, dev):
             np.testing.assert_allclose(p_e[solid[j]], p_o[solid[j]], rtol=0, atol=2e-5, err_msg=f"iteration {i} {name}")
     assert sum(int(m.sum()) for m in solid) >= 0.3 * sum(m.size for m in solid)
     assert eng.lap_solves == orc.lap_solves == 3
+    assert eng.lap_fallbacks == 0                                     # the permutations above are the GPU solver's own

@@ -303,12 +303,15 @@ def test_race_with_warm_racers_over_a_moving_sequence(dev):
 
 
 @pytest.mark.parametrize("n,racers,form", [(1024, None, True), (600, None, True), (512, 1, True), (1024, 1, True),
-                                            (1024, None, ("mc", 16)), (700, 1, ("mc", 3)), (1024, 2, ("mc", 28)), (1500, 2, ("mc", 4))])
+                                            (1024, None, ("mc", 16)), (700, 1, ("mc", 3)), (1024, 2, ("mc", 28)), (1500, 2, ("mc", 4)),
+                                            (600, None, ("mc", 0)), (1024, None, ("mc", 0)), (1024, 1, ("mc", 0)),
+                                            (2048, 2, ("mc", 0))])
 def test_resolve_per_wave_gives_the_optimum(dev, n, racers, form):
-    """reart_lap_resolve_points_mw (row reduction one chain per wave, optimistic commits) and reart_lap_resolve_points_mc (the
-    chains of a problem on several workgroups, lock-free commits on state in memory): a sequence of moved problems, each re-solved
-    from the previous optimum -- smoothly moved, partly scrambled (rows that jump, like the base model's resampled labels),
-    identical -- always the certified optimum scipy returns, never through the host solver."""
+    """The chain forms of the re-solve.  ``form=True`` and ``("mc", W > 0)``: reart_lap_resolve_points_mc (the chains of a problem
+    on W workgroups, lock-free commits on state in memory; True = the default W).  ``("mc", 0)``: reart_lap_resolve_points_mw (the
+    row reduction one chain per wave inside the problem's ONE workgroup, optimistic commits under a lock).  A sequence of moved
+    problems, each re-solved from the previous optimum -- smoothly moved, partly scrambled (rows that jump, like the base model's
+    resampled labels), identical -- always the certified optimum scipy returns, never through the host solver."""
     import oracle
     from reart_amd.utils import lap
 
@@ -330,6 +333,9 @@ def test_resolve_per_wave_gives_the_optimum(dev, n, racers, form):
             s, t = torch.from_numpy(src).to(dev), torch.from_numpy(tgt).to(dev)
             out, fb, st = lap.linear_sum_assignment_points(s, t, state, return_stats="full", per_wave=form)
             assert fb == 0
+            if k >= 1:                      # the entry point the case names is the one that ran
+                want = "mw" if (isinstance(form, tuple) and form[1] == 0) else "mc"
+                assert state["resolve_form"] == want, (state["resolve_form"], want)
             ref = oracle.linear_sum_assignment(oracle.cdist(src, tgt))
             for b, (r, c) in enumerate(out):
                 np.testing.assert_array_equal(c, ref[b][1])
@@ -348,8 +354,8 @@ def test_resolve_per_wave_gives_the_optimum(dev, n, racers, form):
 
 
 def test_resolve_per_wave_at_2048(dev):
-    """The kinematic projection's size (README.md:125: downsample 2 of 4096 points): the per-wave row reduction with 32
-    columns per lane, three re-solves of moved problems against scipy."""
+    """The kinematic projection's size (README.md:125: downsample 2 of 4096 points): the default chain form
+    (reart_lap_resolve_points_mc, 32 columns per lane), three re-solves of moved problems against scipy."""
     import oracle
     from reart_amd.utils import lap
 
@@ -368,6 +374,7 @@ def test_resolve_per_wave_at_2048(dev):
                                                                        return_stats="full", per_wave=True)))
     finally:
         lap.MW_NMAX = old
+    assert state["resolve_form"] == "mc"
     for src, (out, fb, st) in outs:
         assert fb == 0
         ref = oracle.linear_sum_assignment(oracle.cdist(src, tgt))
@@ -375,7 +382,7 @@ def test_resolve_per_wave_at_2048(dev):
             np.testing.assert_array_equal(c, ref[b][1])
 
 
-@pytest.mark.parametrize("form", [True, ("mc", 13), ("mc", 2)])
+@pytest.mark.parametrize("form", [True, ("mc", 13), ("mc", 2), ("mc", 0)])
 def test_resolve_chain_forms_under_stress(dev, form):
     """The chain forms of the re-solve where their commits collide most: 19 problems of 1024^2 re-solved 12 times in a row while
     a third of the rows jump every time and the target clouds hold exact DUPLICATES (exact ties: a chain must leave the row to
@@ -395,6 +402,8 @@ def test_resolve_chain_forms_under_stress(dev, form):
         src[:, jump] = (tgt[:, rng.permutation(n)[: len(jump)]] + rng.normal(0, 0.02, (B, len(jump), 3))).astype(np.float32)
         out, fb, st = lap.linear_sum_assignment_points(t_(src), t_(tgt), state, return_stats="full", per_wave=form)
         assert fb == 0, (k, fb)
+        if k >= 1:
+            assert state["resolve_form"] == ("mw" if form == ("mc", 0) else "mc")
         cost = oracle.cdist(src, tgt)
         if k in (1, 6, 11):                                              # scipy on 19 x 1024^2 takes seconds: three of the twelve
             ref = oracle.linear_sum_assignment(cost)
