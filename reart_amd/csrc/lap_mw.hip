@@ -40,6 +40,18 @@
 #define MW_TIGHTEN_ARR 1     // ... and before the row reduction on many compute units (lap_mc_tighten_kernel)
 #endif
 #define MW_CHECK 16          // a search looks at the race flag and at its labelled columns every MW_CHECK steps
+// A search that has not met a sink after MW_BUCKET_AFTER one-column steps goes on in BUCKETS (see the search loop): all
+// unlabelled columns within `width` of the closest one are settled together by label-correcting rounds.
+#ifndef MW_BUCKET_AFTER
+#define MW_BUCKET_AFTER 48
+#endif
+#define MW_BK 256            // columns relaxed from per round (the rest of a bucket waits for the next round)
+#ifndef MW_BUCKET_LO
+#define MW_BUCKET_LO 8       // a bucket that closes with fewer columns than this widens the next one fourfold ...
+#endif
+#ifndef MW_BUCKET_HI
+#define MW_BUCKET_HI 48      // ... with more than this, halves it
+#endif
 
 #ifdef REART_PRUNE_PHASE   // diagnostic build only (make -C reart_amd/csrc phase; tools/exp_mw.py)
 // per workgroup (first 64): 0 set-up | 1 row-reduction phase | 2 path-search phase (wall ticks of wave 0) | 3, 4 ticks the waves
@@ -433,7 +445,17 @@ __global__ __launch_bounds__(64 * NW) void lap_jvmw_kernel(JvArgs a) {
     // that extra relaxations could hide.)
     __shared__ double s_rv[2][NW];
     __shared__ int s_rj[2][NW], s_lostp[2];
-    if (tid == 0) { s_lostp[0] = 0; s_lostp[1] = 0; }
+    // bucket rounds: the columns relaxed FROM in a round (their rows' points and potentials, their labels), two buffers; the
+    // list lengths rotate through three slots (slot r + 1 is cleared before the barrier of round r: its last reader passed
+    // the barrier of round r - 1)
+    __shared__ float s_ex[2][MW_BK], s_ey[2][MW_BK], s_ez[2][MW_BK];
+    __shared__ double s_ed[2][MW_BK], s_eh[2][MW_BK];
+    __shared__ int s_ei[2][MW_BK], s_ecnt[3];
+    __shared__ double s_bv[2][NW], s_bs[2][NW];
+    __shared__ int s_bj[2][NW], s_bsj[2][NW], s_bn[2][NW], s_blost[2];
+    if (tid == 0) { s_lostp[0] = 0; s_lostp[1] = 0; s_ecnt[0] = 0; s_ecnt[1] = 0; s_ecnt[2] = 0; }
+    double bwidth = mx * 1e-8;                            // bucket width, carried from search to search
+    int brot = 0, bpar = 0;                               // rotating slot of the list length / parity of the closing reductions
     bool aborted = mw_flag(&sh.abort_) != 0, unsolved = mw_flag(&sh.unsolved) != 0;     // uniform: read after the barrier
     MWS_DECL;
     for (int f = 0; f < nleft && !aborted && !unsolved; ++f) {
@@ -451,8 +473,10 @@ __global__ __launch_bounds__(64 * NW) void lap_jvmw_kernel(JvArgs a) {
         }
         double mu = 0.0;
         int sink = -1;
+        bool buckets = false;
         MWS(5);
         for (int it = 0; ; ++it) {
+            if (it >= MW_BUCKET_AFTER) { buckets = true; break; }
             double bv = INFINITY;
             int bj = 0x7fffffff;
 #pragma unroll
@@ -498,11 +522,141 @@ __global__ __launch_bounds__(64 * NW) void lap_jvmw_kernel(JvArgs a) {
             }
             MWS(4);
         }
+        if (buckets && !aborted && !unsolved) {
+            // ---- the search goes on in BUCKETS.  All unlabelled columns with a label below hi = (closest label) + width are
+            // settled TOGETHER: rounds relax from every bucket member whose label is new or has improved (up to MW_BK per round,
+            // one barrier per round) until no label inside the bucket moves -- label-correcting inside a bucket, label-setting
+            // from bucket to bucket (delta-stepping), so the labels below the first sink's are the shortest distances Dijkstra
+            // finds, one column per 1.2 us step.  A long search labels hundreds of columns of a nearly tight graph whose
+            // shortest-path tree is 40-100 nodes deep (tools/sim_tail.py on dumped solves): 900 steps become ~170 rounds.
+            // Reduced costs are clamped at zero inside a bucket (they are >= 0 up to rounding; a cycle of rounding-negative
+            // edges must not improve labels for ever).  A sink (unowned column, or a node of a live tree) is never relaxed
+            // from; the search ends with the closest sink of the first bucket that holds one.
+            unsigned sinkb = freecol;
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) {
+                const int j = tid + k * BS;
+                if (j < n && tof[j] >= 0) sinkb |= 1u << k;
+            }
+            unsigned pend = 0u;
+            double lo = INFINITY;
+            bool first = true;
+            for (;;) {
+                // closing reductions of the previous bucket double as the opening of this one: the closest unlabelled column
+                double bv = INFINITY;
+                int bj = 0x7fffffff;
+#pragma unroll
+                for (int k = 0; k < CPT; ++k)
+                    if (!((scanned >> k) & 1u) && d[k] < bv) { bv = d[k]; bj = tid + k * BS; }
+                if (first) {
+                    mw_argmin_key<6>(bv, bj);
+                    if (lane == 0) { s_bv[bpar][wv] = bv; s_bj[bpar][wv] = bj; }
+                    if (race && tid == 0) s_blost[bpar] = lost();
+                    __syncthreads();
+                    if (race && s_blost[bpar]) { aborted = true; break; }
+                    bv = lane < NW ? s_bv[bpar][lane] : INFINITY; bj = lane < NW ? s_bj[bpar][lane] : 0x7fffffff;
+                    mw_argmin_key<(NW <= 2 ? 1 : (NW <= 4 ? 2 : (NW <= 8 ? 3 : 4)))>(bv, bj);
+                    bpar ^= 1;
+                    ++my_steps;
+                    lo = bv;
+                    first = false;
+                }
+                if (!(lo < INFINITY)) { unsolved = true; break; }
+                const double hi = lo + bwidth;
+#pragma unroll
+                for (int k = 0; k < CPT; ++k)
+                    if (!((scanned >> k) & 1u) && (d[k] < hi || d[k] == lo)) pend |= 1u << k;
+                pend &= ~sinkb;
+                // ---- rounds
+                for (;;) {
+                    const int buf = brot & 1, slot = brot % 3;
+#pragma unroll
+                    for (int k = 0; k < CPT; ++k) {
+                        const bool want = (pend >> k) & 1u;
+                        const unsigned long long m = __ballot(want);
+                        if (m) {
+                            int base = 0;
+                            if (lane == 0) base = atomicAdd(&s_ecnt[slot], __builtin_popcountll(m));
+                            base = mw_uniform(base);
+                            const int at = base + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+                            if (want && at < MW_BK) {
+                                const int j = tid + k * BS, i = owner[j];
+                                s_ex[buf][at] = psx[i]; s_ey[buf][at] = psy[i]; s_ez[buf][at] = psz[i];
+                                s_ed[buf][at] = d[k]; s_eh[buf][at] = hcol[j]; s_ei[buf][at] = i;
+                                pend &= ~(1u << k);
+                            }
+                        }
+                    }
+                    if (tid == 0) s_ecnt[(brot + 1) % 3] = 0;
+                    __syncthreads();
+                    int ne = s_ecnt[slot];
+                    ++brot;
+                    if (ne == 0) break;                    // uniform: nobody had anything left to relax from
+                    ne = ne < MW_BK ? ne : MW_BK;
+                    ++my_steps;
+                    for (int e = 0; e < ne; ++e) {
+                        const float ax = s_ex[buf][e], ay = s_ey[buf][e], az = s_ez[buf][e];
+                        const double df = s_ed[buf][e], h = s_eh[buf][e];
+                        const int i = s_ei[buf][e];
+#pragma unroll
+                        for (int k = 0; k < CPT; ++k) {
+                            double w = ((double)mw_sqrt(reart_sqdist3(ax, ay, az, qx[k], qy[k], qz[k])) + pj[k]) - h;
+                            w = w > 0.0 ? w : 0.0;
+                            const double nd = df + w;
+                            const bool better = !((scanned >> k) & 1u) && nd < d[k];
+                            d[k] = better ? nd : d[k];
+                            if (better) { cpred[tid + k * BS] = i; if ((nd < hi || nd == lo) && !((sinkb >> k) & 1u)) pend |= 1u << k; }
+                        }
+                    }
+                }
+                // ---- the bucket is stable: its columns are settled; the closest sink among them ends the search, otherwise the
+                // closest column outside opens the next bucket (one pair of reductions for both)
+                double sv = INFINITY;
+                int sj = 0x7fffffff, nnew = 0;
+                bv = INFINITY; bj = 0x7fffffff;
+#pragma unroll
+                for (int k = 0; k < CPT; ++k) {
+                    if ((scanned >> k) & 1u) continue;
+                    if (d[k] < hi || d[k] == lo) {
+                        scanned |= 1u << k;
+                        ++nnew;
+                        if ((sinkb >> k) & 1u) {
+                            const int key = (tid + k * BS) | (((freecol >> k) & 1u) ? 0 : JV_OWNED);
+                            if (d[k] < sv || (d[k] == sv && key < sj)) { sv = d[k]; sj = key; }
+                        }
+                    } else if (d[k] < bv) { bv = d[k]; bj = tid + k * BS; }
+                }
+                mw_argmin_key<6>(sv, sj);
+                mw_argmin_key<6>(bv, bj);
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) nnew += __shfl_xor(nnew, o, 64);
+                if (lane == 0) { s_bs[bpar][wv] = sv; s_bsj[bpar][wv] = sj; s_bv[bpar][wv] = bv; s_bj[bpar][wv] = bj; s_bn[bpar][wv] = nnew; }
+                if (race && tid == 0) s_blost[bpar] = lost();
+                __syncthreads();
+                if (race && s_blost[bpar]) { aborted = true; break; }
+                sv = lane < NW ? s_bs[bpar][lane] : INFINITY; sj = lane < NW ? s_bsj[bpar][lane] : 0x7fffffff;
+                bv = lane < NW ? s_bv[bpar][lane] : INFINITY; bj = lane < NW ? s_bj[bpar][lane] : 0x7fffffff;
+                nnew = lane < NW ? s_bn[bpar][lane] : 0;
+                mw_argmin_key<(NW <= 2 ? 1 : (NW <= 4 ? 2 : (NW <= 8 ? 3 : 4)))>(sv, sj);
+                mw_argmin_key<(NW <= 2 ? 1 : (NW <= 4 ? 2 : (NW <= 8 ? 3 : 4)))>(bv, bj);
+#pragma unroll
+                for (int o = 8; o >= 1; o >>= 1) nnew += __shfl_xor(nnew, o, 64);
+                nnew = mw_uniform(nnew);
+                bpar ^= 1;
+                ++my_steps;
+                if (sj != 0x7fffffff && sv < INFINITY) { mu = sv; sink = sj & ~JV_OWNED; break; }
+                if (nnew < MW_BUCKET_LO) bwidth *= 4.0;
+                else if (nnew > MW_BUCKET_HI) bwidth *= 0.5;
+                lo = bv;
+                if (bj == 0x7fffffff) { unsolved = true; break; }
+            }
+        }
         if (aborted || unsolved) break;
 #pragma unroll
         for (int k = 0; k < CPT; ++k) {
             const int j = tid + k * BS;
-            if ((((scanned & ~deadq) >> k) & 1u) && j != sink) { pj[k] += mu - d[k]; price[j] = pj[k]; }
+            // (a bucket settles columns beyond the sink's label too: their prices stay)
+            if ((((scanned & ~deadq) >> k) & 1u) && j != sink && d[k] < mu) { pj[k] += mu - d[k]; price[j] = pj[k]; }
         }
         __syncthreads();
         const int tree_hit = tof[sink];                    // the tree this search uses up (its root, when the search met the unowned column itself)
@@ -542,8 +696,8 @@ __global__ __launch_bounds__(64 * NW) void lap_jvmw_kernel(JvArgs a) {
         for (int k = 0; k < CPT; ++k) {                    // the labelled columns have new prices, those on the path new owners
             const int j = tid + k * BS;
             if (((scanned & ~deadq) >> k) & 1u) {
-                const int i = owner[j];
-                hcol[j] = (double)mw_sqrt(reart_sqdist3(psx[i], psy[i], psz[i], qx[k], qy[k], qz[k])) + pj[k];
+                const int i = owner[j];          // (a bucket may have settled unowned columns besides the sink)
+                if (i >= 0) hcol[j] = (double)mw_sqrt(reart_sqdist3(psx[i], psy[i], psz[i], qx[k], qy[k], qz[k])) + pj[k];
             }
         }
     }
@@ -758,6 +912,9 @@ __global__ __launch_bounds__(256) void lap_mc_trees_kernel(JvArgs a) {
 // and inherits that column's ROOT (a search that reaches it walks to that unowned column; the root is what a search uses up).
 // One workgroup per problem: a thread owns the rows of its columns (M_i = min over the forest of c_it + q_t and the column
 // that attains it in registers), a round is one workgroup arg-min + one distance per row.  MW_FOREST_R rounds.
+#ifndef MW_FOREST_MIN
+#define MW_FOREST_MIN 64
+#endif
 #ifndef MW_FOREST_R
 #define MW_FOREST_R 512       // measured 0 / 48 / 128 / 256 / 512 / 1024: recipe 3.57 / 3.58 / 3.51 / 3.37 / 3.33 / 3.70 ms per refresh, projection 78.8 / 77.9 / 80.4 / 82.4 / 86.7 / 86.8 it/s
 #endif
@@ -818,9 +975,15 @@ __global__ __launch_bounds__(512) void lap_mc_forest_kernel(JvArgs a) {
     }
     double off = 0.0;
     int nf = nf0;
+#ifdef MW_FOREST_K
+    // rounds follow the problem: MW_FOREST_K per row left for the searches, within [MW_FOREST_MIN, MW_FOREST_R]
+    const int rounds = min(MW_FOREST_R, max(MW_FOREST_MIN, MW_FOREST_K * cnt[2]));
+#else
+    const int rounds = MW_FOREST_R;
+#endif
     // a round: the workgroup's arg-min of the outside rows' slacks (ordered-integer keys, as in the searches), ONE barrier,
     // then everybody relaxes its rows against the column that joined (its price is in q, the shift is known to all)
-    for (int r = 0; r < MW_FOREST_R; ++r) {
+    for (int r = 0; r < rounds; ++r) {
         double bv = INFINITY;
         int bj = 0x7fffffff;
 #pragma unroll

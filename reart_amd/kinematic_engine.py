@@ -75,7 +75,7 @@ class KinematicEngine:
         self.lap_solves = self.lap_fallbacks = 0
         self.lap_events = None
         self.lap_stats = None
-        self.lap_winners = np.zeros(16, np.int64)
+        self.lap_winners = np.zeros(32, np.int64)      # wins per racer (JV_RACE_MAX = 28 racers, 5 bits in the statistics)
         self.trans = torch.empty((self.B, self.P, 4, 4), dtype=torch.float32, device=self.dev)
         self.pc_trans = torch.empty((self.B, self.N, 3), dtype=torch.float32, device=self.dev)
         self.G = torch.zeros((self.B, self.N, 3), dtype=torch.float32, device=self.dev)
@@ -184,7 +184,7 @@ class KinematicEngine:
             elif self.lap_state.get("backward_rounds") is not None:    # the backward growth before the searches: the same kind of step
                 seq = seq + np.asarray(self.lap_state["backward_rounds"], dtype=np.int64)
             self.lap_steps_log.append((int(seq.max()), float(seq.mean())))
-            self.lap_winners += np.bincount((self.lap_stats[:, 0] >> 16) & 15, minlength=16)[:16]         # raced re-solves: who finished first
+            self.lap_winners += np.bincount((self.lap_stats[:, 0] >> 16) & 31, minlength=32)[:32]         # raced re-solves: who finished first
             self.matched = self.tgt_pts.gather(1, cols[..., None].expand(-1, -1, 3))
             if self.lap_events is not None:
                 ev[1].record()

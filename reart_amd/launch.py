@@ -19,6 +19,27 @@ def free_port():
     return port
 
 
+def descendants(pid):
+    """Every live descendant of ``pid`` (children first), from /proc: the ranks of a torch.distributed.run launcher are its
+    children but neither in its process group nor in its session."""
+    kids = {}
+    for name in os.listdir("/proc"):
+        if not name.isdigit():
+            continue
+        try:
+            with open(f"/proc/{name}/stat") as f:
+                rest = f.read().rsplit(")", 1)[1].split()     # state ppid ...
+            kids.setdefault(int(rest[1]), []).append(int(name))
+        except (OSError, IndexError, ValueError):
+            continue
+    out, todo = [], [int(pid)]
+    while todo:
+        for k in kids.get(todo.pop(), []):
+            out.append(k)
+            todo.append(k)
+    return out
+
+
 def under_launcher(env=None):
     """True when this process is one rank of a torch.distributed.run job."""
     env = os.environ if env is None else env
@@ -49,9 +70,12 @@ def self_launch(script, argv, nproc, expect_json_key="n_gpus", timeout=None, mod
     """Start ``nproc`` ranks of ``script argv`` and wait.  The ranks' stdout is read line by line AS IT ARRIVES: a line that
     parses as a JSON object is kept (rank 0 prints exactly one; the last one is printed at the end), every other line goes
     to stderr at once -- progress is visible while the job runs and a hung rendezvous shows what was printed before it.
-    The launcher runs in its own session: on ``timeout`` (seconds) or an interrupt the whole process group is killed, so no
-    rank is left holding a GPU.  Exit status: the launcher's, 124 after a timeout, 3 when no JSON line came back, 4 when
-    the line's ``expect_json_key`` differs from ``nproc``."""
+    The launcher runs in its own session: on ``timeout`` (seconds), an interrupt or a SIGTERM / SIGHUP / SIGINT sent to THIS
+    process (an outer ``timeout``, a harness kill: they signal the parent's group only, and the ranks are no longer in it)
+    the whole process group is killed, so no rank is left holding a GPU; should this process die without running a handler
+    (SIGKILL), the kernel sends the launcher SIGTERM (PR_SET_PDEATHSIG) and torch.distributed.run takes its ranks down.
+    Exit status: the launcher's, 124 after a timeout, 128 + signal after a signal, 3 when no JSON line came back, 4 when the
+    line's ``expect_json_key`` differs from ``nproc``."""
     import signal
     import threading
 
@@ -59,8 +83,27 @@ def self_launch(script, argv, nproc, expect_json_key="n_gpus", timeout=None, mod
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // max(1, int(nproc)))))
-    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, start_new_session=True)
+    def die_with_parent():                                # in the child, before exec: SIGTERM when the parent is gone
+        try:
+            import ctypes
+            ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, int(signal.SIGTERM), 0, 0, 0)      # PR_SET_PDEATHSIG = 1
+        except Exception:                                 # (no libc by that name: the handlers below still cover signals)
+            pass
+
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, start_new_session=True, preexec_fn=die_with_parent)
     found = []
+
+    class _Signalled(BaseException):
+        def __init__(self, signum):
+            self.signum = signum
+
+    def on_signal(signum, frame):
+        raise _Signalled(signum)                          # unwinds proc.wait() into the clean-up below
+
+    old_handlers = {}
+    if threading.current_thread() is threading.main_thread():       # (signal.signal is the main thread's privilege)
+        for sg in (signal.SIGTERM, signal.SIGHUP, signal.SIGINT):
+            old_handlers[sg] = signal.signal(sg, on_signal)
 
     def pump():
         for raw in iter(proc.stdout.readline, b""):
@@ -77,10 +120,25 @@ def self_launch(script, argv, nproc, expect_json_key="n_gpus", timeout=None, mod
                 print(text, file=sys.stderr, flush=True)
 
     def kill_group():
+        """torch.distributed.run starts every rank in a session of its OWN (subprocess_handler: start_new_session), so the
+        launcher's process group holds the launcher alone: SIGKILL to it would orphan the ranks with their GPUs.  The ranks
+        are found as the launcher's descendants BEFORE anything is signalled, the launcher gets SIGTERM (its handler closes
+        its workers) and a few seconds, then whatever is left -- launcher, ranks, the ranks' own process groups -- SIGKILL."""
+        victims = descendants(proc.pid)
         try:
-            os.killpg(proc.pid, signal.SIGKILL)          # start_new_session: the launcher's pid is its group's id
+            os.killpg(proc.pid, signal.SIGTERM)          # start_new_session: the launcher's pid is its group's id
         except ProcessLookupError:
             pass
+        try:
+            proc.wait(timeout=10)
+        except subprocess.TimeoutExpired:
+            pass
+        for pid in [proc.pid] + victims:
+            for kill in (os.killpg, os.kill):            # a rank leads its own group (its children with it)
+                try:
+                    kill(pid, signal.SIGKILL)
+                except (ProcessLookupError, PermissionError):
+                    pass
 
     reader = threading.Thread(target=pump, daemon=True)
     reader.start()
@@ -92,10 +150,18 @@ def self_launch(script, argv, nproc, expect_json_key="n_gpus", timeout=None, mod
         reader.join(timeout=5)
         print(f"launch of {nproc} ranks timed out after {timeout} s (process group killed): {' '.join(cmd)}", file=sys.stderr)
         return 124
+    except _Signalled as sg:
+        kill_group()
+        proc.wait()
+        print(f"launch of {nproc} ranks ended by signal {sg.signum} (process group killed)", file=sys.stderr)
+        return 128 + int(sg.signum)
     except BaseException:
         kill_group()
         proc.wait()
         raise
+    finally:
+        for sg, h in old_handlers.items():
+            signal.signal(sg, h)
     reader.join(timeout=30)
     line = found[-1] if found else None
     if proc.returncode != 0:

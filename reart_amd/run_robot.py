@@ -111,6 +111,7 @@ class AssignmentPhase:
         self.collect_stats = False  # True: the solver's per-problem statistics of every refresh are read (B x 4 ints) into stats_log
         self.stats_log = []         # per refresh: (sequential steps of the slowest problem = search steps + backward rounds, mean search
                                     # steps, mean row-reduction steps, most search steps, mean backward rounds)
+        self.stats_raw = []         # per device-side refresh: the solver's [B,4] statistics words as written (tools/exp_tail.py)
         self.capture_guard = None   # a context-manager factory entered around the graph capture (the sweep's _CaptureGate)
         self._have = False
 
@@ -169,6 +170,7 @@ class AssignmentPhase:
         torch.cuda.current_stream().synchronize()
         if self.collect_stats:
             sth = self._stats_host.numpy().reshape(B, 4)
+            self.stats_raw.append(sth.copy())
             back = (sth[:, 0] >> 21) & 0x3ff               # rounds of the backward growth: sequential steps of the same kind
             self.stats_log.append((int((sth[:, 2] + back).max()), float(sth[:, 2].mean()), float((sth[:, 3] >> 8).mean()),
                                    int(sth[:, 2].max()), float(back.mean())))

@@ -263,5 +263,6 @@ def linear_sum_assignment_points(src, tgt, state, return_stats=False, race=True,
             # ... and the rounds of the backward growth (lap_mc_forest_kernel: sequential workgroup-wide steps like the searches')
             state["backward_rounds"] = (st[:, 0] >> 21) & 0x3ff
             st[:, 0] &= 0x1fffff
+            state["winner"] = (st[:, 0] >> 16) & 31          # the racer that published (bits 16-20 of word 0; released rows below)
         return (state["cols"].long() if device_cols else out), fallbacks, st
     return (out, fallbacks) if return_stats else out
