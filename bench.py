@@ -53,6 +53,15 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 vector peak (counts FMA as 2)
 
 
+def _pcts(ms):
+    """p50 / p95 / max of per-solve milliseconds (the mean sits next to them as kernel_ms)."""
+    if not len(ms):
+        return {}
+    a = np.asarray(ms, dtype=np.float64)
+    return {"solve_ms_p50": round(float(np.percentile(a, 50)), 4), "solve_ms_p95": round(float(np.percentile(a, 95)), 4),
+            "solve_ms_max": round(float(a.max()), 4)}
+
+
 def build_instance(dev, T, N, cano_idx, seed, use_flow=True, n_iter=15000, use_grid=False, overlap=True, profile=False):
     from reart_amd.networks.model import BaseModel
     from reart_amd.relax import RelaxEngine
@@ -95,8 +104,7 @@ def cpu_baseline(seq, T, N, cano_idx, budget_s=20.0):
         if el > budget_s or n >= 20:
             break
     return {"value": n / el, "unit": "iterations/s", "cores": oracle.num_threads(), "kind": "port",
-            "sample": f"{n} iterations of the same T={T} x N={N} Chamfer+flow step (oracle C/OpenMP, "
-                      f"{el:.1f} s wall)"}
+            "sample": f"{n} iterations of the same step, oracle C/OpenMP, {el:.1f} s"}
 
 
 def cpu_baseline_torch(seq, T, N, cano_idx, budget_s=10.0):
@@ -123,8 +131,7 @@ def cpu_baseline_torch(seq, T, N, cano_idx, budget_s=10.0):
         if el > budget_s or n >= 20:
             break
     return {"value": n / el, "unit": "iterations/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} iterations of the same T={T} x N={N} Chamfer+flow step (reference-style PyTorch-CPU ops: "
-                      f"conv1d / gumbel_softmax / bmm / cdist+argmin / topk / autograd / torch.optim.Adam, {el:.1f} s wall)"}
+            "sample": f"{n} iterations of the same step, reference-style PyTorch-CPU ops, {el:.1f} s"}
 
 
 def extractor_flops(N, out_dim=64):
@@ -203,23 +210,17 @@ def bench_extractor(args, dev):
             if e_ > getattr(args, "cpu_budget", 8.0) or n_ >= 20:
                 break
         cpu = {"value": round(n_ / e_, 3), "unit": "clouds/s", "cores": max(O_.num_threads(), torch.get_num_threads()), "kind": "port",
-               "sample": f"{n_} forwards of ONE {N}-point cloud through the oracle's PointNet2Msg2 (FPS, ball queries, grouped "
-                         f"conv stacks as float32 matrix products, interpolation; {e_:.1f} s wall)"}
+               "sample": f"{n_} forwards of one {N}-point cloud, oracle PointNet2Msg2, {e_:.1f} s"}
     return {
         "metric": "correspondence-extractor clouds/sec", "value": round(B * steps / el, 2), "unit": "clouds/s", "n_gpus": 1,
         "steps": steps, "warmup": warm, "ms_per_step": round(1e3 * el / steps, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32 (fp32 MFMA, exact f32)", "data": "synthetic",
-        "config": {"workload": f"PointNet2Msg2 forward (FPS, ball query, gather-fused 1x1-conv stacks + max-pool on the fp32 "
-                               f"matrix cores, 3-NN interpolation) on {B} clouds of {N} points = the one-time descriptor "
-                               f"extraction of a T={T} sequence (utils/flow_utils.py:123-124); seeded weights",
+        "config": {"workload": f"PointNet2Msg2 forward on {B} clouds of {N} points (descriptors of a T={T} sequence)",
                    "clouds": B, "points": N, "sampling_rules": "CUDA (pointnet2_utils.CUDA = True)"},
         "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(ach / FP32_PEAK_TFLOPS, 4), "traffic": None,
-                     "kernel": "mlp_gemm_kernel<NB> (all 1x1-conv layers; v_mfma_f32_32x32x2_f32)",
-                     "kernel_ms": round(ms, 4), "useful_flops": flops,
-                     "note": "useful flops of every conv layer (no tile padding) over the WHOLE forward's device time "
-                             "(HIP events on the launch stream, FPS / ball query / interpolation included), against the "
-                             "fp32 MFMA peak of MI355X_MICROARCH.md (157.3 TFLOP/s)"},
+                     "kernel": "mlp_gemm_kernel<NB> (v_mfma_f32_32x32x2_f32), whole forward's device time",
+                     "kernel_ms": round(ms, 4), "useful_flops": flops},
         "cpu_baseline": cpu, "finite": bool(torch.isfinite(f).all()),
     }
 
@@ -279,7 +280,6 @@ def bench_kinematic(args, dev, rank, world, distributed, barrier):
     from reart_amd.utils.lap import cdist, linear_sum_assignment_batch
     src_idx_b = loop.src_idx if loop.src_idx.dim() == 2 else loop.src_idx[None].expand(pcs.shape[0], -1)
     lap_ms = sum(e0.elapsed_time(e1) for e0, e1 in loop.lap_events) / max(len(loop.lap_events), 1)
-    st = loop.lap_stats
     with torch.no_grad():
         pc_trans, _, _ = kin(cano)
         cold_src = index_points(pc_trans, src_idx_b).contiguous()
@@ -302,31 +302,22 @@ def bench_kinematic(args, dev, rank, world, distributed, barrier):
     fws = torch.empty(16 * cost.shape[0] + 256, dtype=torch.uint8, device=dev)
     L_.check(L_.lib().reart_lap_step_floor(cost.shape[0], n, 20000, L_.ptr(fws), fws.numel(), ctypes.byref(floor_us), L_.stream()),
              "reart_lap_step_floor")
-    per_solve = np.asarray(getattr(loop, "lap_steps_log", [])[-max(len(loop.lap_events), 1):], dtype=np.float64)     # [solves, 2]: slowest problem, mean
+    per_solve = np.asarray(getattr(loop, "lap_steps_log", [])[-max(len(loop.lap_events), 1):], dtype=np.float64)     # [solves, 3]: slowest problem (with backward rounds), mean, slowest problem's search steps
     steps_max = float(per_solve[:, 0].mean()) if per_solve.size else 0.0
     steps_mean = float(per_solve[:, 1].mean()) if per_solve.size else 0.0
+    steps_search = float(per_solve[:, 2].mean()) if per_solve.size and per_solve.shape[1] > 2 else steps_max
     bound_ms = steps_max * floor_us.value * 1e-3
-    steps_total = float(st[:, 2].sum() + (st[:, 3] >> 8).sum())
-    roof = {"bound": "latency", "achieved": round(bound_ms, 4), "peak": round(lap_ms, 4), "unit": "ms per re-solve (lower bound / measured)",
-            "frac": round(bound_ms / lap_ms, 4) if lap_ms > 0 else None, "traffic": None,
-            "kernel": "lap_jvmw_kernel<32, 2, 16> (searches) + lap_mc_forest_kernel<32> + lap_mc_arr_kernel<32> + lap_mc_trees_kernel<32> + "
-                      "set-up + two lap_jv_pass_kernel launches (re-solve of the T-1 assignment problems from the previous optimum: row "
-                      "potentials on the whole chip, unowned columns re-priced, augmenting row reduction one chain per wave on eight "
-                      "workgroups per problem, trees / a forest of zero-cost rows behind the columns still unowned, shortest augmenting "
-                      "paths that end at the forest with one workgroup per problem and racer -- the solver state in LDS --, then the "
-                      "exact dual certificate on the whole chip)",
-            "kernel_ms": round(lap_ms, 4), "solves_measured": len(loop.lap_events),
-            "step_floor_us": round(floor_us.value, 4), "steps_slowest_problem": round(steps_max, 1), "steps_mean_problem": round(steps_mean, 1),
-            "cold_solve_ms": round(lap_cold_ms, 3),
-            "note": "latency roofline: a re-solve ends with its slowest problem's sequential chain of workgroup-wide steps: the rounds "
-                    "of the backward growth and the path-search steps (the row reduction's chains run 64 at a time per problem, the "
-                    "trees a wave each: not part of that chain); step_floor_us = the "
-                    "workgroup-wide arg-min over the 2048 labels + its barrier with "
-                    "the solver's own primitives and nothing else (reart_lap_step_floor, measured in this run); achieved = those steps "
-                    "of the slowest problem (mean over the timed solves) x floor; frac = achieved / kernel_ms -- what is above it is "
-                    "the step's relaxation (4 square roots per lane), the row-reduction launch and the two whole-chip passes.  The HBM view "
-                    f"is meaningless here ({2 * cost.shape[0] * n * 12} algorithmic bytes per solve).  "
-                    "cold_solve_ms: the epsilon-scaling auction from scratch on the same matrices (schedules racing, reart_lap_auction_race)"}
+    solve_ms_all = [e0.elapsed_time(e1) for e0, e1 in loop.lap_events]
+    # latency roofline: sequential workgroup-wide steps of the slowest problem x the measured floor of one
+    # such step (arg-min + barrier, reart_lap_step_floor) over the measured solve; frac_search_only leaves the backward rounds out
+    roof = {"bound": "latency", "achieved": round(bound_ms, 4), "peak": round(lap_ms, 4), "unit": "ms per re-solve (floor / measured)",
+            "frac": round(bound_ms / lap_ms, 4) if lap_ms > 0 else None,
+            "frac_search_only": round(steps_search * floor_us.value * 1e-3 / lap_ms, 4) if lap_ms > 0 else None, "traffic": None,
+            "kernel": "lap_jvmw_kernel<32,2,16> + forest/arr/trees/set-up/passes (assignment re-solve)",
+            "kernel_ms": round(lap_ms, 4), "solves_measured": len(loop.lap_events), **_pcts(solve_ms_all),
+            "step_floor_us": round(floor_us.value, 4), "steps_slowest_problem": round(steps_max, 1),
+            "search_steps_slowest_problem": round(steps_search, 1), "steps_mean_problem": round(steps_mean, 1),
+            "cold_solve_ms": round(lap_cold_ms, 3)}
     cpu = None
     if not args.no_cpu_baseline and world == 1:
         import oracle
@@ -338,29 +329,19 @@ def bench_kinematic(args, dev, rank, world, distributed, barrier):
         el_cpu = time.perf_counter() - t1
         cpu = {"value": round(1.0 / el_cpu, 4), "unit": "iterations/s", "cores": min(len(cost_h), os.cpu_count() or 1),
                "kind": "reference",
-               "sample": f"ONE iteration's assignment refresh as the reference computes it (run_robot.py:165-176 with "
-                         f"--use_nproc): torch.cdist on the host + scipy.optimize.linear_sum_assignment for the {len(cost_h)} "
-                         f"matrices of {n} x {n} on a pool of {len(cost_h)} processes (utils/model_utils.py:85-89), "
-                         f"{el_cpu:.1f} s wall; forward kinematics, losses, autograd and Adam (< 1 % of the reference's "
-                         f"iteration) are not included, so this is an upper bound of the CPU path's rate"}
+               "sample": f"one refresh the reference's way: torch.cdist + scipy on {len(cost_h)} processes, {el_cpu:.1f} s"}
     return {
         "metric": "kinematic-projection iterations/sec", "value": round(world * args.steps / el, 3), "unit": "iterations/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * el / args.steps, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (assignment potentials f64)",
         "data": "synthetic",
-        "config": {"workload": f"kinematic projection (BASELINE configs[4], README.md:125): model=kinematic, flow + "
-                               f"assignment loss, assign_iter=0, downsample={args.downsample}, assign_gap={args.assign_gap}; "
-                               f"synthetic T={T} x N={N}, {T - 1} assignment problems of {n} x {n} per refresh, joint tree from a "
-                               f"{args.base_iters}-iteration relaxation result", "frames": T, "points": N,
+        "config": {"workload": f"kinematic projection (README.md:125), synthetic T={T} x N={N}, {T - 1} x {n}^2 per iteration",
+                   "frames": T, "points": N,
                    "parts": int(trans_s.shape[1]), "assign_gap": args.assign_gap, "downsample": args.downsample,
                    "lap_solves_in_timed_region": loop.lap_solves - solves0 - 0, "lap_fallbacks": int(getattr(loop, "lap_fallbacks", -1)),
                    "parallelism": f"instances x{world}",
                    "loop": type(loop).__name__},
         "roofline": roof, "cpu_baseline": cpu,
-        "lap_stats_last": {"rows_released": (st[:, 0] & 0xffff).tolist(), "winning_racer": ((st[:, 0] >> 16) & 31).tolist(),
-                           "wins_per_racer": getattr(loop, "lap_winners", np.zeros(1)).tolist(), "rows_searched": st[:, 1].tolist(),
-                           "dijkstra_steps": st[:, 2].tolist(), "row_reduction_steps": (st[:, 3] >> 8).tolist(),
-                           "certificate_rounds": (st[:, 3] & 255).tolist()},
         "final_losses": {k: float(v.detach()) for k, v in losses.items()},
     }
 
@@ -369,10 +350,10 @@ def run_secondary(args, dev, barrier):
     import copy
 
     keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "roofline", "cpu_baseline")
-    sec = {}
-    for name in ("kinematic", "extractor", "nao", "nao_recipe"):
+    sec, start = {}, {}
+    for name in ("kinematic", "extractor", "nao", "nao_recipe", "nao_projection"):
         a = copy.copy(args)
-        a.cpu_budget = 3.0                                        # bounded CPU samples: the whole default run stays within ~1 minute
+        a.cpu_budget = 3.0                                        # bounded CPU samples: the whole default run stays within minutes
         t0 = time.perf_counter()
         try:
             if name == "nao":
@@ -380,7 +361,11 @@ def run_secondary(args, dev, barrier):
                 full = bench_nao(a, dev)
             elif name == "nao_recipe":
                 a.steps = 1500                                    # = the README's 15 000 iterations with 2 000 refreshes
-                full = bench_nao_recipe(a, dev)
+                full = bench_nao_recipe(a, dev, keep=start)
+            elif name == "nao_projection":
+                # README.md:125 from the recipe's result above: a bounded sample (the first 1 500 of its 15 000 iterations, three
+                # windows); the whole run: `python bench.py --config nao_projection` (profiles/)
+                full = bench_nao_projection(a, dev, start=start or None, n_iter=1500)
             elif name == "kinematic":
                 a.steps, a.warmup = 100, 10                       # iterations 10-110 of the projection, like --config kinematic
                 full = bench_kinematic(a, dev, 0, 1, False, barrier)
@@ -388,18 +373,15 @@ def run_secondary(args, dev, barrier):
                 a.steps, a.warmup = 20, 3
                 full = bench_extractor(a, dev)
             sec[name] = {k: full[k] for k in keep if k in full}
-            sec[name]["workload"] = full["config"]["workload"]
-            if name == "nao":
-                sec[name].update({k: full["config"][k] for k in ("matches_per_pair", "pairs_with_ground_truth_references",
-                                                                 "correspondence_stage_s", "loop_s", "whole_run_s")})
-            if name == "nao_recipe":
-                sec[name].update({k: full["config"][k] for k in ("correspondence_stage_s", "chamfer_phase_s", "assignment_phase_s", "loop_s",
-                                                                 "whole_run_s", "assign_refreshes", "ms_per_refresh", "ms_per_solve",
-                                                                 "first_solve_ms", "lap_fallbacks")})
-            if name == "kinematic":
-                sec[name]["lap_fallbacks"] = full["config"].get("lap_fallbacks")
+            extra = {"nao": ("matches_per_pair", "pairs_with_ground_truth_references", "correspondence_stage_s", "loop_s", "whole_run_s"),
+                     "nao_recipe": ("correspondence_stage_s", "chamfer_phase_s", "assignment_phase_s", "loop_s", "whole_run_s",
+                                    "assign_refreshes", "ms_per_refresh", "ms_per_solve", "first_solve_ms", "lap_fallbacks", "snapshots"),
+                     "nao_projection": ("n_iter", "of", "snapshots", "iterations_per_s_by_window", "wall_s", "projected_whole_run_s",
+                                        "lap_fallbacks"),
+                     "kinematic": ("lap_fallbacks",)}.get(name, ())
+            sec[name].update({k: full["config"][k] for k in extra if k in full["config"]})
         except Exception as exc:                                  # a secondary figure never costs the headline line
-            sec[name] = {"error": f"{type(exc).__name__}: {exc}"}
+            sec[name] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
         torch.cuda.synchronize()
         sec[name]["wall_s"] = round(time.perf_counter() - t0, 2)
     return sec
@@ -443,7 +425,7 @@ def nao_correspondences(dev):
     return g, cano, pcs, c, complete, refs, flows, matches, gt_pairs, time.perf_counter() - t0
 
 
-def bench_nao_recipe(args, dev):
+def bench_nao_recipe(args, dev, keep=None):
     """The relaxation recipe the reference's README documents for this sequence (README.md:116):
     `run_robot.py --seq_path=data/robot/nao --save_root=exp --cano_idx=2 --use_flow_loss --use_nproc --use_assign_loss
     --downsample 4 --n_iter=15000` -- with the defaults assign_iter = 5000, assign_gap = 5 (run_robot.py:386,404) that is
@@ -467,19 +449,41 @@ def bench_nao_recipe(args, dev):
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     eng = RelaxEngine(cano, pcs, model, c, refs, flows, n_iter=n_iter, seed=2)
+    # the run a user starts prints a snapshot every --snapshot_gap = 100 iterations (run_robot.py:224-266: loss line + the
+    # Flow / Seg / Recon eval lines on the ground truth the sequence carries): part of the timed run
+    import functools
+    import io
+
+    from reart_amd.run_robot import SnapshotPrinter
+    from reart_amd.utils.model_utils import tau_cosine
+    snap_gap = 100
+    tau_func = functools.partial(tau_cosine, max_iter=n_iter, end_temp=1.0, start_temp=5.0)
+    sample = dict(gt_flow_list=g["gt_flow_list"], gt_cano_part=g["gt_cano_part"], complete_gt_pc_list=g["complete_gt_pc_list"])
+    snap = SnapshotPrinter(argparse.Namespace(model="base", cano_idx=c), model, cano, pcs, sample, tau_func, out=io.StringIO())
+
+    def snapshot(k, names):
+        row = eng.last_losses().cpu().numpy()
+        snap(k - 1, dict(zip(names, row[:3])))
+
     i = eng.capture(steps_per_graph=50)
-    eng.step(assign_iter - i)
-    i = assign_iter
+    while i < assign_iter:
+        chunk = min(snap_gap - i % snap_gap, assign_iter - i)
+        eng.step(chunk)
+        i += chunk
+        if i % snap_gap == 0:
+            snapshot(i, ("recon Loss", "flow Loss", "total Loss"))
     torch.cuda.synchronize()
     t_cd = time.perf_counter() - t1
     phase = AssignmentPhase(eng, cano, pcs, ds, gap, lam)
     phase.events, phase.collect_stats = [], True
     t2 = time.perf_counter()
-    phase.run(i, n_iter)
+    phase.run(i, n_iter, snap_gap, lambda k: snapshot(k, ("opt assignment loss", "flow Loss", "total Loss")))
     torch.cuda.synchronize()
     t_as = time.perf_counter() - t2
     rep = phase.report()
     n = phase.n
+    if keep is not None:                                          # the relaxation result a projection can start from
+        keep.update(model=model, cano=cano, pcs=pcs, cano_idx=c, refs=refs, flows=flows)
     # latency roofline of the refresh's solve, the re-solve's construction (see bench_kinematic): path-search steps of the
     # slowest problem x the measured floor of one workgroup-wide arg-min + barrier
     import ctypes
@@ -503,47 +507,109 @@ def bench_nao_recipe(args, dev):
         oracle.parallel_lap(c_cpu, nproc=len(c_cpu))
         el_cpu = time.perf_counter() - tc
         cpu = {"value": round(gap / el_cpu, 3), "unit": "iterations/s", "cores": min(B, os.cpu_count() or 1), "kind": "reference",
-               "sample": f"ONE assignment refresh as the reference computes it (run_robot.py:165-176 with --use_nproc): torch.cdist on "
-                         f"the host + scipy.optimize.linear_sum_assignment for the {B} matrices of {n} x {n} on a pool of {B} "
-                         f"processes (utils/model_utils.py:85-89), {el_cpu:.2f} s wall for the {gap} iterations it serves; the "
-                         f"iterations themselves are not included (see secondary.nao's cpu_baseline), so this is an upper bound "
-                         f"of the CPU path's rate in the assignment phase"}
+               "sample": f"one refresh the reference's way: torch.cdist + scipy on {B} processes, {el_cpu:.2f} s per {gap} iterations"}
     whole = t_corr + t_cd + t_as
     return {
         "metric": "relaxation-recipe iterations/sec (README.md:116)", "value": round(n_iter / whole, 2), "unit": "iterations/s",
         "n_gpus": 1, "steps": n_iter, "warmup": 0, "ms_per_step": round(1e3 * whole / n_iter, 5), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32 (assignment potentials f64)",
         "data": "reference demo sequence (nao), seeded extractor weights",
-        "config": {"workload": f"nao relaxation as README.md:116 runs it: --use_flow_loss --use_assign_loss --downsample {ds} "
-                               f"--n_iter {n_iter} (assign_iter {assign_iter}, assign_gap {gap}): descriptors + SMNN matches -> flow "
-                               f"references, {assign_iter} iterations of Chamfer + flow loss, {n_iter - assign_iter} of assignment + flow "
-                               f"loss with {rep['assign_refreshes']} refreshes of {B} optimal assignments of {n} x {n}; T={T} x N={N}, "
-                               f"P=20, cano_idx={c}",
+        "config": {"workload": f"nao relaxation as README.md:116 runs it, {rep['assign_refreshes']} refreshes of {B} x {n}^2",
                    "frames": T, "points": N, "n_iter": n_iter, "assign_iter": assign_iter, "assign_gap": gap, "downsample": ds,
                    "matches_per_pair": matches, "pairs_with_ground_truth_references": gt_pairs,
                    "correspondence_stage_s": round(t_corr, 4), "chamfer_phase_s": round(t_cd, 4), "assignment_phase_s": round(t_as, 4),
                    "loop_s": round(t_cd + t_as, 4), "whole_run_s": round(whole, 4), "assign_refreshes": rep["assign_refreshes"],
                    "ms_per_refresh": round(1e3 * t_as / max(rep["assign_refreshes"], 1), 4),
                    "ms_per_solve": round(solve_ms, 4), "first_solve_ms": round(rep.get("first_solve_ms", 0.0), 3),
-                   "lap_fallbacks": rep["lap_fallbacks"]},
+                   "lap_fallbacks": rep["lap_fallbacks"], "snapshots": snap.count, "snapshot_gap": snap_gap},
         "roofline": {"bound": "latency", "achieved": round(bound_ms, 4), "peak": round(solve_ms, 4),
-                     "unit": "ms per re-solve (lower bound / measured)", "frac": round(bound_ms / solve_ms, 4) if solve_ms > 0 else None,
-                     "traffic": None, "kernel": "lap_jvmw_kernel<16, 2, 8> (searches) + lap_mc_forest_kernel<16> + lap_mc_arr_kernel<16> + lap_mc_trees_kernel<16> + "
-                     "set-up + two lap_jv_pass_kernel launches (re-solve of the 9 problems from the previous refresh's optimum: unowned "
-                     "columns re-priced, row reduction one chain per wave on eight workgroups per problem, trees / a forest of zero-cost "
-                     "rows behind the columns still unowned, then shortest augmenting paths that end at the forest, 13 racers per problem)",
+                     "unit": "ms per re-solve (floor / measured)", "frac": round(bound_ms / solve_ms, 4) if solve_ms > 0 else None,
+                     "frac_search_only": round(float(st[:, 3].mean()) * floor_us.value * 1e-3 / solve_ms, 4) if st.size and solve_ms > 0 else None,
+                     "traffic": None, "kernel": "lap_jvmw_kernel<16,2,8> + forest/arr/trees/set-up/passes (assignment re-solve)",
                      "kernel_ms": round(solve_ms, 4), "solves_measured": max(len(phase.events) - 1, 0),
+                     **_pcts([e0.elapsed_time(e1) for e0, e1 in phase.events[1:]]),
                      "step_floor_us": round(floor_us.value, 4), "sequential_steps_slowest_problem": round(steps_max, 1),
                      "search_steps_slowest_problem": round(float(st[:, 3].mean()) if st.size else 0.0, 1),
                      "backward_rounds_mean_problem": round(float(st[:, 4].mean()) if st.size else 0.0, 1),
                      "search_steps_mean_problem": round(float(st[:, 1].mean()) if st.size else 0.0, 1),
-                     "row_reduction_steps_mean_problem": round(float(st[:, 2].mean()) if st.size else 0.0, 1),
-                     "note": "latency roofline like secondary.kinematic's: a re-solve ends with its slowest problem's sequential "
-                             "chain of workgroup-wide steps -- the rounds of the backward growth (lap_mc_forest_kernel) and then the "
-                             "path-search steps; floor = the workgroup-wide arg-min over the 1024 labels + its barrier alone "
-                             "(reart_lap_step_floor, measured in this run); the row-reduction launch (64 chains in flight per "
-                             "problem, as long as its longest chain), the trees and the two whole-chip passes are on top"},
+                     "row_reduction_steps_mean_problem": round(float(st[:, 2].mean()) if st.size else 0.0, 1)},
         "cpu_baseline": cpu, "final_losses": [float(v) for v in eng.last_losses().cpu()[:3]],
+    }
+
+
+def bench_nao_projection(args, dev, start=None, n_iter=None, windows=3):
+    """The projection recipe the reference's README documents for this sequence (README.md:125): `run_robot.py --model=kinematic
+    --use_flow_loss --use_assign_loss --assign_iter=0 --downsample=2 --assign_gap=1 --snapshot_gap=10 --base_result_path=...`
+    on nao, from the result of the relaxation recipe (README.md:116; `start`: what bench_nao_recipe kept, or that recipe is
+    run here first, untimed).  Every iteration re-solves 9 optimal assignments of 2048 x 2048 (run_robot.py:164-187) and every
+    10th prints the reference's snapshot metrics (run_robot.py:224-266).  n_iter: the default line runs a BOUNDED sample -- the
+    first `n_iter` iterations of the run, reported per window -- `--config nao_projection --steps 1500` = all 15 000."""
+    import contextlib
+    import io
+
+    from reart_amd import run_robot as rr
+    from reart_amd import tail
+
+    if start is None:
+        start = {}
+        a0 = argparse.Namespace(**vars(args))
+        a0.steps, a0.no_cpu_baseline = 1500, True
+        bench_nao_recipe(a0, dev, keep=start)
+    model, cano, pcs, c, refs, flows = (start[k] for k in ("model", "cano", "pcs", "cano_idx", "refs", "flows"))
+    total = 15000
+    n_iter = total if n_iter is None else int(n_iter)
+    with torch.no_grad():
+        _, seg0, trans0 = model(cano)
+    seg_s, trans_s, conn_s = tail.extract_structure(seg0, trans0, cano)
+    result = {"pred_cano_part": seg_s.cpu().numpy(), "pred_pose_list": trans_s.cpu().numpy(),
+              "joint_connection": conn_s.cpu().numpy().tolist(), "cano_idx": c}
+    a = rr.build_parser().parse_args(["--model", "kinematic", "--use_flow_loss", "--use_assign_loss", "--assign_iter", "0",
+                                      "--downsample", "2", "--assign_gap", "1", "--snapshot_gap", "10", "--cano_idx", str(c),
+                                      "--n_iter", str(total)])
+    with contextlib.redirect_stdout(sys.stderr):
+        kin = rr.build_kinematic_from_base(result, cano, pcs, a).to(dev)
+    loop = rr.make_projection_loop(a, kin, cano, pcs, refs, flows)
+    g = None
+    try:
+        from reart_amd.data import load_nao_demo
+        g = load_nao_demo()
+    except Exception:
+        pass
+    sample = None if g is None else dict(gt_flow_list=g["gt_flow_list"], gt_cano_part=g["gt_cano_part"],
+                                         complete_gt_pc_list=g["complete_gt_pc_list"])
+    snap = rr.SnapshotPrinter(a, kin, cano, pcs, sample, out=io.StringIO())        # the lines are produced, not shown
+    loop.lap_events = []
+    edges = [round(n_iter * k / windows) for k in range(windows + 1)]
+    marks = []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for it in range(n_iter):
+        losses = loop.iteration(it)
+        if it % a.snapshot_gap == 0 or it == n_iter - 1:
+            snap(it, losses)
+        if it + 1 in edges[1:]:
+            torch.cuda.synchronize()
+            marks.append(time.perf_counter() - t0)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    ms = [e0.elapsed_time(e1) for e0, e1 in loop.lap_events]
+    win = [round((edges[k + 1] - edges[k]) / (marks[k] - (marks[k - 1] if k else 0.0)), 2) for k in range(len(marks))]
+    lap_ms = float(np.mean(ms[1:])) if len(ms) > 1 else 0.0
+    n = loop.tgt_pts.shape[1]
+    return {
+        "metric": "kinematic-projection iterations/sec (README.md:125, nao)", "value": round(n_iter / el, 3), "unit": "iterations/s",
+        "n_gpus": 1, "steps": n_iter, "warmup": 0, "ms_per_step": round(1e3 * el / n_iter, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32 (assignment potentials f64)",
+        "data": "reference demo sequence (nao), seeded extractor weights",
+        "config": {"workload": f"nao projection as README.md:125 runs it: first {n_iter} of {total} iterations, {pcs.shape[0]} x {n}^2 per iteration",
+                   "n_iter": n_iter, "of": total, "snapshot_gap": a.snapshot_gap, "snapshots": snap.count,
+                   "iterations_per_s_by_window": win, "wall_s": round(el, 3),
+                   "projected_whole_run_s": round(el * total / n_iter, 1) if n_iter < total else round(el, 3),
+                   "lap_fallbacks": int(loop.lap_fallbacks), "parts": int(trans_s.shape[1])},
+        "roofline": {"bound": "latency", "kernel": "lap_jvmw_kernel<32,2,16> + forest/arr/trees/set-up/passes (assignment re-solve)",
+                     "kernel_ms": round(lap_ms, 4), "solves_measured": max(len(ms) - 1, 0), **_pcts(ms[1:]),
+                     "first_solve_ms": round(ms[0], 3) if ms else None, "traffic": None},
+        "cpu_baseline": None, "final_losses": {k: float(v.detach()) for k, v in losses.items()},
     }
 
 
@@ -603,15 +669,13 @@ def bench_nao(args, dev):
             if e2 > getattr(args, "cpu_budget", 8.0) or n >= 20:
                 break
         cpu = {"value": round(n / e2, 3), "unit": "iterations/s", "cores": oracle.num_threads(), "kind": "port",
-               "sample": f"{n} iterations of the same nao step (T={T} x N={N}, oracle C/OpenMP, {e2:.1f} s wall); the one-time "
-                         f"extractor is not part of it (the reference's own PointNet2Msg2 takes 4.9 s per cloud on 8 CPU threads)"}
+               "sample": f"{n} iterations of the same nao step, oracle C/OpenMP, {e2:.1f} s"}
     return {
         "metric": "relaxation-loop iterations/sec", "value": round(steps / el, 2), "unit": "iterations/s", "n_gpus": 1,
         "steps": steps, "warmup": done, "ms_per_step": round(1e3 * el / steps, 5), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "reference demo sequence (nao), seeded extractor weights",
-        "config": {"workload": f"nao relaxation, full loop (BASELINE configs[2]): PointNet2Msg2 descriptors + SMNN matches -> flow "
-                               f"references, then {n_iter} iterations of per-part rigid transforms + Chamfer + flow loss + Adam; "
-                               f"T={T} x N={N}, P=20, cano_idx={c}", "frames": T, "points": N, "n_iter": n_iter,
+        "config": {"workload": f"nao relaxation, full loop (BASELINE configs[2]): descriptors + matches + {n_iter} iterations",
+                   "frames": T, "points": N, "n_iter": n_iter,
                    "matches_per_pair": matches, "pairs_with_ground_truth_references": gt_pairs,
                    "correspondence_stage_s": round(t_corr, 4), "loop_s": round(el, 4),
                    "whole_run_s": round(t_corr + el, 4), "graph_replays": eng.graph_replays, "eager_steps": eng.eager_steps},
@@ -619,19 +683,19 @@ def bench_nao(args, dev):
                      "frac": round(ach / FP32_PEAK_TFLOPS, 4), "traffic": None, "kernel": "knn_group_kernel (as the headline's)",
                      "kernel_ms": round(k_ms, 5), "launches_measured": prof["launches"],
                      "executed_pairs_per_launch": round(executed, 1), "algorithmic_pairs_per_launch": int(nn_pairs),
-                     "algorithmic_speedup": round(nn_pairs / max(executed, 1), 3),
-                     "note": "device-side measurement of every search launch of the timed iterations (see the headline's roofline)"},
+                     "algorithmic_speedup": round(nn_pairs / max(executed, 1), 3)},
         "cpu_baseline": cpu, "final_losses": [float(v) for v in eng.last_losses().cpu()[:3]],
     }
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--config", default="relax", choices=["relax", "kinematic", "extractor", "nao", "nao_recipe"],
+    ap.add_argument("--config", default="relax", choices=["relax", "kinematic", "extractor", "nao", "nao_recipe", "nao_projection"],
                     help="relax (default): BASELINE configs[1], the headline; kinematic: configs[4] (README.md:125); "
                          "extractor: the one-time PointNet++ correspondence extractor of configs[2]; nao: configs[2] itself -- the "
                          "reference's demo sequence, descriptors + matches + 15 000 iterations (--steps N for fewer); nao_recipe: the same "
-                         "sequence as README.md:116 runs it (--use_flow_loss --use_assign_loss --downsample 4: 2 000 assignment refreshes)")
+                         "sequence as README.md:116 runs it (--use_flow_loss --use_assign_loss --downsample 4: 2 000 assignment refreshes); nao_projection: "
+                         "README.md:125 on nao from that recipe's result, all 15 000 iterations with a snapshot every 10 (--steps N for the first N)")
     ap.add_argument("--base-iters", type=int, default=2000, help="kinematic: iterations of the relaxation the projection starts from")
     ap.add_argument("--assign-gap", type=int, default=1)
     ap.add_argument("--downsample", type=int, default=2)
@@ -705,8 +769,11 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         return
-    if args.config in ("nao", "nao_recipe"):
-        out = bench_nao(args, dev) if args.config == "nao" else bench_nao_recipe(args, dev)
+    if args.config in ("nao", "nao_recipe", "nao_projection"):
+        if args.config == "nao_projection":
+            out = bench_nao_projection(args, dev, n_iter=None if args.steps == 1500 else args.steps, windows=15 if args.steps == 1500 else 3)
+        else:
+            out = bench_nao(args, dev) if args.config == "nao" else bench_nao_recipe(args, dev)
         if rank == 0:
             print(json.dumps(out))
         if distributed:
@@ -806,11 +873,7 @@ def main():
             el_s = float(tt.item())
         sweep = {"instances_per_gpu": Ks, "value": round(world * Ks * sw_steps / el_s, 3), "unit": "iterations/s",
                  "per_gpu": round(Ks * sw_steps / el_s, 3), "n_gpus": world, "mode": "batch", "steps": sw_steps, "warmup": sw_warm,
-                 "graph_replays": batch.graph_replays, "eager_steps": batch.eager_steps,
-                 "note": "aggregate over all GPUs of Ks independent instances per GPU advancing in shared launches "
-                         "(reart_relax_step_batch: each kernel of the iteration once, one argument block per instance); `value` "
-                         "above is one instance per GPU; per_gpu = value / n_gpus is the figure that should stay flat as ranks "
-                         "are added (instances share nothing)"}
+                 "graph_replays": batch.graph_replays, "eager_steps": batch.eager_steps}
         del sw_eng, batch
     elif K == 1 and args.sweep_instances > 1:
         Ks = args.sweep_instances
@@ -838,10 +901,7 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el_s = float(tt.item())
         sweep = {"instances_per_gpu": Ks, "value": round(world * Ks * args.steps / el_s, 3), "unit": "iterations/s",
-                 "per_gpu": round(Ks * args.steps / el_s, 3), "n_gpus": world, "mode": "streams",
-                 "note": "aggregate over all GPUs of Ks concurrent independent instances per GPU (separate streams, "
-                         "round-robin graph replays); `value` above is one instance per GPU; per_gpu = value / n_gpus is "
-                         "the figure that should stay flat as ranks are added (instances share nothing)"}
+                 "per_gpu": round(Ks * args.steps / el_s, 3), "n_gpus": world, "mode": "streams"}
         del sw_eng
     losses = eng.last_losses()
     # gather of the final energies only (the reference's sweep picks argmin total energy)
@@ -886,8 +946,8 @@ def main():
             t_nn = k_ms * 1e-3
             executed = prof["pairs"] / prof["launches"]
             ach = executed * 8 / t_nn / 1e12
-            traffic = None
-            pmc_file = next((f for f in (os.path.join(ROOT, "profiles", "r04_pmc_search.json"), os.path.join(ROOT, "profiles", "r03_pmc_search.json"))
+            traffic = traffic_current = None
+            pmc_file = next((f for f in (os.path.join(ROOT, "profiles", "r05_pmc_search.json"), os.path.join(ROOT, "profiles", "r04_pmc_search.json"))
                              if os.path.exists(f)), None)
             if use_flow and T == 20 and N == 4096 and pmc_file:
                 import hashlib
@@ -896,43 +956,22 @@ def main():
                 stamps = pj.get("measured_on_sources_sha256_16", {})
                 same = bool(stamps) and all(hashlib.sha256(open(os.path.join(ROOT, p_), "rb").read()).hexdigest()[:16] == h_
                                             for p_, h_ in stamps.items())
-                traffic = {"bytes_per_launch": pj.get("hbm_bytes_per_launch"),
-                           "source": f"{os.path.relpath(pmc_file, ROOT)}: rocprofv3 --pmc passes of this command (FETCH_SIZE + WRITE_SIZE, "
-                                     f"MI355X_MICROARCH.md); counters cannot be read inside a run, so the figure is the committed "
-                                     f"measurement, stamped with the kernel sources it was taken on",
-                           "measured_on_current_sources": same}
-            box_note = None
-            ref_ms = 0.0329          # profiles/r03_bench_default.json (a box of the common kind, default window)
-            if use_flow and T == 20 and N == 4096 and args.steps >= 300 and k_ms > 1.25 * ref_ms:
-                box_note = (f"this box runs the search launch in {1e3 * k_ms:.1f} us against {1e3 * ref_ms:.1f} us on the boxes the profile "
-                            "set was collected on, with every other kernel of the step at its usual time: about one gpurun box in "
-                            "ten is of that kind (four times the fabric traffic on the same launches, profiles/README.md)")
+                traffic = pj.get("hbm_bytes_per_launch")      # the committed rocprofv3 --pmc measurement (counters cannot be read inside a run)
+                traffic_current = same                          # ... taken on the kernel sources this run uses?
+            # kernel_ms and the executed pairs are device-side measurements of every launch in the timed region (profile stamps);
+            # achieved = executed pair evaluations x 8 flop (no FMA: the distance contract) / kernel time against the fp32 vector
+            # peak; the brute-force definition of SURVEY 8(d) is kept as algorithmic_* 
             roof = {"bound": "valu", "achieved": round(ach, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / FP32_PEAK_TFLOPS, 4), "traffic": traffic,
-                    "kernel": "knn_group_kernel (" + kname.split("(", 1)[1],
-                    "kernel_ms": round(k_ms, 5), "launches_measured": prof["launches"], "box_note": box_note,
+                    "frac": round(ach / FP32_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_on_current_sources": traffic_current,
+                    "kernel": "knn_group_kernel (Chamfer K=1 both directions + flow K=3, one launch)" if use_flow else "knn_group_kernel (Chamfer K=1, both directions)",
+                    "kernel_ms": round(k_ms, 5), "launches_measured": prof["launches"],
+                    "slow_box": bool(use_flow and T == 20 and N == 4096 and args.steps >= 300 and k_ms > 1.25 * 0.0329),
                     "workgroup_busy_ms": round(1e3 * prof["workgroup_seconds"] / prof["launches"], 4),
                     "executed_pairs_per_launch": round(executed, 1), "flop_per_pair": 8,
-                    "algorithmic_pairs_per_launch": nn_pairs,
-                    "algorithmic_speedup": round(nn_pairs / executed, 3),
-                    "algorithmic": {"achieved": round(nn_flops / t_nn / 1e12, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                    "frac": round(nn_flops / t_nn / 1e12 / FP32_PEAK_TFLOPS, 4), "flops_per_launch": nn_flops,
-                                    "note": "SURVEY 8(d)'s definition to the letter: the brute-force flops of the launch "
-                                            "(every query-target pair, 8 flop) over the kernel time.  Above 1 because the exact "
-                                            "search does not evaluate the pairs it can rule out; `frac` above is the executed "
-                                            "work, the figure that describes the kernel"},
-                    "hbm": {"achieved": round(nn_bytes / t_nn / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": round(nn_bytes / t_nn / 1e9 / HBM_PEAK_GBS, 6), "algorithmic_bytes": nn_bytes,
-                            "note": "algorithmic bytes of the brute-force definition over the kernel time: <= 4 % by "
-                                    "construction, HBM is not what bounds an exact nearest-neighbour search"},
-                    "note": "achieved = executed distance evaluations x 8 flop / kernel time against the fp32 vector peak "
-                            "(157.3 TFLOP/s counts an FMA as 2; the distance contract forbids FMA contraction, so 8 "
-                            "flop = 8 issue slots).  The exact box-pruned search skips the pairs it can rule out: "
-                            "algorithmic_speedup = brute-force pairs / executed pairs is credit for the algorithm, not "
-                            "ALU activity.  kernel_ms and executed pairs are device-side measurements of every launch "
-                            "in the timed region (profile stamps, reart_relax_profile); rocprofv3 --kernel-trace "
-                            "--stats of `bench.py --sweep-instances 0 --no-tail --no-cpu-baseline` covers the same "
-                            "launches plus warm-up (profiles/)"}
+                    "algorithmic_pairs_per_launch": nn_pairs, "algorithmic_speedup": round(nn_pairs / executed, 3),
+                    "algorithmic_tflops": round(nn_flops / t_nn / 1e12, 2), "algorithmic_frac": round(nn_flops / t_nn / 1e12 / FP32_PEAK_TFLOPS, 4),
+                    "hbm_gbs": round(nn_bytes / t_nn / 1e9, 3), "hbm_frac": round(nn_bytes / t_nn / 1e9 / HBM_PEAK_GBS, 6),
+                    "algorithmic_bytes": nn_bytes}
         cpu = cpu_torch = None
         if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(seq, T, N, cano_idx)
@@ -981,14 +1020,11 @@ def main():
                     cpu_lap = 1e3 * (time.perf_counter() - t_)
                     cpu_tail = {"structure_ms": round(cpu_struct, 1), "assignment_ms_per_matrix": round(cpu_lap, 1),
                                 "matrices": int(eng.pc_list.shape[0]), "kind": "port",
-                                "sample": "oracle (numpy, C k-NN) structure extraction once; scipy.optimize."
-                                          "linear_sum_assignment on 1 of the T-1 matrices of 4096 x 4096 (serial)"}
+                                "sample": "oracle structure extraction once; scipy on 1 of the T-1 matrices of 4096^2"}
                 end_of_run = {"structure_ms": round(ms_struct, 3), "energy_ms": round(ms_energy, 3), "cpu_baseline": cpu_tail,
                               "parts": int(trans_s.shape[1]), "total_err": round(en["total_err"], 6),
                               "ass_err": round(en["ass_err"], 6), "screw_err": round(en["screw_err"], 6),
-                              "group_err": round(en["group_err"], 6), "lap_fallbacks": int(en.get("lap_fallbacks", -1)),
-                              "note": "after warmup+steps iterations; energy_ms is dominated by the (T-1) optimal "
-                                      "assignments of 4096 x 4096 (GPU auction + exact certificate)"}
+                              "group_err": round(en["group_err"], 6), "lap_fallbacks": int(en.get("lap_fallbacks", -1))}
             except Exception as exc:      # a degenerate early state (e.g. every part merged) must not cost the bench line
                 end_of_run = {"error": f"{type(exc).__name__}: {exc}"}
         out = {
@@ -1008,9 +1044,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"synthetic articulated sequence T={T} x N={N}, P=20 parts, Chamfer"
-                                   + ("+flow loss (k=3 blend, 3000 refs/pair)" if use_flow else " only")
-                                   + ", full iteration fwd+loss+bwd+Adam, one instance per GPU",
+            "config": {"workload": f"synthetic T={T} x N={N}, P=20, Chamfer" + ("+flow" if use_flow else "") + ", fwd+loss+bwd+Adam, one instance per GPU",
                        "frames": T, "points": N, "parts": 20, "flow": use_flow,
                        "graph": not args.no_graph, "steps_per_graph": (0 if args.no_graph else spg),
                        "graph_replays": replays, "eager_steps": eager, "grid_search_static_targets": args.grid, "parallelism": f"instances x{world}" + (f" x{K} per GPU" if K > 1 else ""),

@@ -45,7 +45,10 @@
 #ifndef MW_BUCKET_AFTER
 #define MW_BUCKET_AFTER 48
 #endif
-#define MW_BK 256            // columns relaxed from per round (the rest of a bucket waits for the next round)
+#ifndef MW_BUCKET_W0
+#define MW_BUCKET_W0 1e-8    // first bucket width of a problem, as a fraction of the cost scale
+#endif
+#define MW_BK 192            // columns relaxed from per round (the rest of a bucket waits for the next round); 12 KB of lists: two 1024-column workgroups per compute unit
 #ifndef MW_BUCKET_LO
 #define MW_BUCKET_LO 8       // a bucket that closes with fewer columns than this widens the next one fourfold ...
 #endif
@@ -454,7 +457,10 @@ __global__ __launch_bounds__(64 * NW) void lap_jvmw_kernel(JvArgs a) {
     __shared__ double s_bv[2][NW], s_bs[2][NW];
     __shared__ int s_bj[2][NW], s_bsj[2][NW], s_bn[2][NW], s_blost[2];
     if (tid == 0) { s_lostp[0] = 0; s_lostp[1] = 0; s_ecnt[0] = 0; s_ecnt[1] = 0; s_ecnt[2] = 0; }
-    double bwidth = mx * 1e-8;                            // bucket width, carried from search to search
+    double bwidth = mx * MW_BUCKET_W0;                    // bucket width, carried from search to search
+#ifdef MW_BUCKET_STATS
+    int my_relax = 0, my_rounds = 0, my_buckets = 0;     // diagnostic build: columns relaxed from / rounds / buckets, reported in place of the commit conflicts and reduction steps
+#endif
     int brot = 0, bpar = 0;                               // rotating slot of the list length / parity of the closing reductions
     bool aborted = mw_flag(&sh.abort_) != 0, unsolved = mw_flag(&sh.unsolved) != 0;     // uniform: read after the barrier
     MWS_DECL;
@@ -541,6 +547,10 @@ __global__ __launch_bounds__(64 * NW) void lap_jvmw_kernel(JvArgs a) {
             unsigned pend = 0u;
             double lo = INFINITY;
             bool first = true;
+            const double bdelta = mx * 1e-12;
+            double rk[CPT];                                   // d - p of the unsettled columns (settled: -inf, never a candidate)
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) rk[k] = ((scanned >> k) & 1u) ? -INFINITY : d[k] - pj[k];
             for (;;) {
                 // closing reductions of the previous bucket double as the opening of this one: the closest unlabelled column
                 double bv = INFINITY;
@@ -594,18 +604,32 @@ __global__ __launch_bounds__(64 * NW) void lap_jvmw_kernel(JvArgs a) {
                     if (ne == 0) break;                    // uniform: nobody had anything left to relax from
                     ne = ne < MW_BK ? ne : MW_BK;
                     ++my_steps;
+#ifdef MW_BUCKET_STATS
+                    my_relax += ne; ++my_rounds;
+#endif
                     for (int e = 0; e < ne; ++e) {
                         const float ax = s_ex[buf][e], ay = s_ey[buf][e], az = s_ez[buf][e];
                         const double df = s_ed[buf][e], h = s_eh[buf][e];
                         const int i = s_ei[buf][e];
+                        const double g = (h - df) + bdelta;
 #pragma unroll
                         for (int k = 0; k < CPT; ++k) {
-                            double w = ((double)mw_sqrt(reart_sqdist3(ax, ay, az, qx[k], qy[k], qz[k])) + pj[k]) - h;
-                            w = w > 0.0 ? w : 0.0;
-                            const double nd = df + w;
-                            const bool better = !((scanned >> k) & 1u) && nd < d[k];
-                            d[k] = better ? nd : d[k];
-                            if (better) { cpred[tid + k * BS] = i; if ((nd < hi || nd == lo) && !((sinkb >> k) & 1u)) pend |= 1u << k; }
+                            // the label improves iff c < (d - p) + (h - df) =: T (in exact arithmetic).  Nearly no (entry, column)
+                            // pair does, and the square root is a third of the work: a pair whose squared distance exceeds T^2 by
+                            // more than every rounding on the way (bdelta: 1e-12 of the cost scale against <= 1e-15 of it;
+                            // 2^-22 against the 2^-24 of the fp32 root) is skipped; the others take the expression itself.
+                            const float sq = reart_sqdist3(ax, ay, az, qx[k], qy[k], qz[k]);
+                            const double T = rk[k] + g, Tq = T * 1.000000238418579;
+                            if (T > 0.0 && (double)sq <= Tq * Tq) {
+                                double w = ((double)mw_sqrt(sq) + pj[k]) - h;
+                                w = w > 0.0 ? w : 0.0;
+                                const double nd = df + w;
+                                if (nd < d[k]) {
+                                    d[k] = nd; rk[k] = nd - pj[k];
+                                    cpred[tid + k * BS] = i;
+                                    if ((nd < hi || nd == lo) && !((sinkb >> k) & 1u)) pend |= 1u << k;
+                                }
+                            }
                         }
                     }
                 }
@@ -619,6 +643,7 @@ __global__ __launch_bounds__(64 * NW) void lap_jvmw_kernel(JvArgs a) {
                     if ((scanned >> k) & 1u) continue;
                     if (d[k] < hi || d[k] == lo) {
                         scanned |= 1u << k;
+                        rk[k] = -INFINITY;
                         ++nnew;
                         if ((sinkb >> k) & 1u) {
                             const int key = (tid + k * BS) | (((freecol >> k) & 1u) ? 0 : JV_OWNED);
@@ -644,6 +669,9 @@ __global__ __launch_bounds__(64 * NW) void lap_jvmw_kernel(JvArgs a) {
                 nnew = mw_uniform(nnew);
                 bpar ^= 1;
                 ++my_steps;
+#ifdef MW_BUCKET_STATS
+                ++my_buckets;
+#endif
                 if (sj != 0x7fffffff && sv < INFINITY) { mu = sv; sink = sj & ~JV_OWNED; break; }
                 if (nnew < MW_BUCKET_LO) bwidth *= 4.0;
                 else if (nnew > MW_BUCKET_HI) bwidth *= 0.5;
@@ -706,6 +734,11 @@ __global__ __launch_bounds__(64 * NW) void lap_jvmw_kernel(JvArgs a) {
     if (tid == 0 && unsolved) sh.unsolved = 1;
     if (wv != 0) my_steps = 0;                             // every wave counted the same steps
     MWP_ADD(4, MWP_NOW() - tp_);
+#ifdef MW_BUCKET_STATS
+    if (tid == 0) { sh.conflicts = min(my_relax >> 4, 0xffff); sh.arr = (my_rounds & 0xfff) | (min(my_buckets, 0xfff) << 12); }
+    __syncthreads();
+    my_arr = 0; my_conf = 0;
+#endif
     if (lane == 0) { atomicAdd(&sh.steps, my_steps); atomicAdd(&sh.arr, my_arr); atomicAdd(&sh.conflicts, my_conf); }
     __syncthreads();
     if (wv == 0) MWP_ADD(2, MWP_NOW() - tp_);
@@ -1031,6 +1064,11 @@ __global__ __launch_bounds__(512) void lap_mc_forest_kernel(JvArgs a) {
 }
 
 #define MW_LOCKED (-2)
+// The commit below orders its stores with s_waitcnt vmcnt(0) instead of release semantics: an argument about gfx9 hardware
+// (stores count in vmcnt; device-scope atomics are served at the memory side), not something the HIP memory model promises.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "lap_mc_arr_kernel's commit protocol is written for gfx942 / gfx950"
+#endif
 template <int CPL>
 __global__ __launch_bounds__(64 * MW_NW) void lap_mc_arr_kernel(JvArgs a) {
     const int n = a.n, b = blockIdx.y, lane = threadIdx.x & 63;
@@ -1134,11 +1172,13 @@ __global__ __launch_bounds__(64 * MW_NW) void lap_mc_arr_kernel(JvArgs a) {
 
 int reart_internal_jvmw_nmax() { return 64 * 32; }
 
+// (dynamic LDS is raised to what the launch needs, not to a flat 152 KB: the kernel also holds ~18 KB of static LDS -- the
+// bucket rounds' lists -- and the two together must stay within the compute unit's 160 KB)
 template <int CPL>
 static int mw_launch(const JvArgs &a, int racers, hipStream_t stream) {
     const size_t lds = (size_t)a.n * (8 + 4 * 4 + 6 * 4 + 8 + 2 * 4);
     if (lds > REART_LDS_DEFAULT_CAP &&
-        hipFuncSetAttribute((const void *)lap_jvmw_kernel<CPL, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)
+        hipFuncSetAttribute((const void *)lap_jvmw_kernel<CPL, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return REART_ERR_LAUNCH;
     hipLaunchKernelGGL((lap_jvmw_kernel<CPL, 0>), dim3(a.B, racers), dim3(64 * MW_NW), lds, stream, a);
     REART_CHECK_LAUNCH();
@@ -1156,8 +1196,8 @@ template <int CPL>
 static int mc_launch(const JvArgs &a, int racers, int arr_wgs, hipStream_t stream) {
     const size_t lds = (size_t)a.n * (8 + 4 * 4 + 6 * 4 + 8 + 2 * 4);
     if (lds > REART_LDS_DEFAULT_CAP &&
-        (hipFuncSetAttribute((const void *)lap_jvmw_kernel<CPL, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess ||
-         hipFuncSetAttribute((const void *)lap_jvmw_kernel<CPL, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess))
+        (hipFuncSetAttribute((const void *)lap_jvmw_kernel<CPL, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+         hipFuncSetAttribute((const void *)lap_jvmw_kernel<CPL, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess))
         return REART_ERR_LAUNCH;
     JvArgs s1 = a;
     s1.done = nullptr;                                   // the set-up reads the caller's assignment and potentials themselves
@@ -1197,7 +1237,7 @@ static int mc_launch(const JvArgs &a, int racers, int arr_wgs, hipStream_t strea
 #endif
     constexpr int SNW = CPL == 32 ? MW_SNW32 : MW_NW;
     if (SNW != MW_NW && lds > REART_LDS_DEFAULT_CAP &&
-        hipFuncSetAttribute((const void *)lap_jvmw_kernel<CPL, 2, SNW>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)
+        hipFuncSetAttribute((const void *)lap_jvmw_kernel<CPL, 2, SNW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return REART_ERR_LAUNCH;
     hipLaunchKernelGGL((lap_jvmw_kernel<CPL, 2, SNW>), dim3(a.B, racers), dim3(64 * SNW), lds, stream, a);
     REART_CHECK_LAUNCH();

@@ -990,7 +990,7 @@ extern "C" int reart_relax_step_batch(const reart_relax_config *cfgs, const rear
                                       size_t workspace_bytes, int K, void *stream) {
     if (!cfgs || !bufs || !workspaces || K < 1 || K > REART_BATCH_MAX) return REART_ERR_INVALID_ARG;
     static_assert(sizeof(Batched<SearchArgs>) <= 3584, "kernel-argument segment");
-    StepLaunch L[REART_BATCH_MAX];
+    StepLaunch L[REART_BATCH_MAX] = {};
     for (int k = 0; k < K; ++k) {
         const int rc = relax_step_impl(&cfgs[k], &bufs[k], workspaces[k], workspace_bytes, stream, nullptr, false, &L[k]);
         if (rc != REART_OK) return rc;

@@ -179,11 +179,12 @@ class KinematicEngine:
             # sequential steps of this solve (path search + row reduction) per problem: slowest problem, mean -- the
             # latency roofline of bench.py multiplies them by the measured floor of one step
             seq = self.lap_stats[:, 2].astype(np.int64)
+            search_only = int(seq.max())
             if self.lap_state.get("resolve_form", "jv") == "jv":       # one row at a time: the row reduction's steps are sequential too
                 seq = seq + (self.lap_stats[:, 3].astype(np.int64) >> 8)
             elif self.lap_state.get("backward_rounds") is not None:    # the backward growth before the searches: the same kind of step
                 seq = seq + np.asarray(self.lap_state["backward_rounds"], dtype=np.int64)
-            self.lap_steps_log.append((int(seq.max()), float(seq.mean())))
+            self.lap_steps_log.append((int(seq.max()), float(seq.mean()), search_only))
             self.lap_winners += np.bincount((self.lap_stats[:, 0] >> 16) & 31, minlength=32)[:32]         # raced re-solves: who finished first
             self.matched = self.tgt_pts.gather(1, cols[..., None].expand(-1, -1, 3))
             if self.lap_events is not None:

@@ -426,10 +426,17 @@ class RelaxBatch:
             for _ in range(steps_per_graph):
                 self._enqueue()
         self._graph, self._steps_per_graph = g, steps_per_graph
+        self._graph_mode = self._mode()
         return 1
+
+    def _mode(self):
+        """What a captured graph has baked in besides the buffers: the loss mode of every engine."""
+        return tuple((e.cfg.use_assign, e.cfg.use_flow, e.cfg.lambda_assign) for e in self.engines)
 
     def step(self, n=1):
         """n iterations of every engine (asynchronous)."""
+        if self._graph is not None and self._graph_mode != self._mode():
+            self._graph = None          # an engine changed its loss since the capture (set_assignment): that graph is another iteration
         if self._graph is not None:
             for _ in range(n // self._steps_per_graph):
                 self._graph.replay()

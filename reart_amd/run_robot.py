@@ -246,6 +246,11 @@ class AssignmentPhase:
                     if self.gap > 1:
                         with (self.capture_guard() if self.capture_guard else contextlib.nullcontext()):
                             i += eng.capture(steps_per_graph=self.gap - 1)
+                        # the capture's eager iteration has moved i: a refresh or a snapshot may be due right here
+                        # (assign_iter % assign_gap == assign_gap - 1: run_robot.py:165 refreshes at every i % gap == 0)
+                        if on_snapshot is not None and (i == n_iter or (snapshot_gap and i % snapshot_gap == 0)):
+                            on_snapshot(i)
+                        continue
             nxt = (i // self.gap + 1) * self.gap                                       # next refresh
             snap = (i // snapshot_gap + 1) * snapshot_gap if snapshot_gap else n_iter
             chunk = max(1, min(nxt, snap, n_iter) - i)
@@ -282,9 +287,16 @@ class AssignmentPhaseBatch:
         self.lap_state = {}
         self.refreshes = self.fallbacks = 0
         self.capture_guard = None
+        self.work_guard = None      # a context-manager factory entered around every refresh (the sweep's gate, reader side)
         self._have = False
 
     def refresh(self):
+        if self.work_guard is not None:
+            with self.work_guard():
+                return self._refresh()
+        return self._refresh()
+
+    def _refresh(self):
         from reart_amd.utils.lap import linear_sum_assignment_points
 
         for ph in self.parts:
@@ -365,6 +377,7 @@ class AssignmentPhaseBatch:
                 if self.refresh() and n_iter - i > 1 and self.gap > 1:
                     with (self.capture_guard() if self.capture_guard else contextlib.nullcontext()):
                         i += self.batch.capture(steps_per_graph=self.gap - 1)     # one eager iteration, then the graph between refreshes
+                    continue                                                       # (a refresh may be due at the new i)
             nxt = (i // self.gap + 1) * self.gap
             chunk = max(1, min(nxt, n_iter) - i)
             self.batch.step(chunk)
@@ -481,6 +494,49 @@ def make_projection_loop(args, model, cano_pc, pc_list, pc_ref_list=None, flow_r
     return OperatorLoop(args, model, cano_pc, pc_list, pc_ref_list, flow_ref_list, tau_func)
 
 
+class SnapshotPrinter:
+    """What the reference prints at ``i % snapshot_gap == 0`` and at the last iteration (run_robot.py:224-266): the loss line
+    (the reference prints it every iteration, :216; here with the snapshot -- the fused loop does not meet the host in between)
+    and, when the sample carries ground truth, `Flow eval: EPE | Acc 5 | Acc 10 | Angle`, `Seg eval: RI`, `Recon eval: recon`
+    with the reference's formats and centimetre scaling.  The metrics are taken on a forward of the model as it stands after
+    iteration i (the reference uses the forward iteration i itself ran: one Adam step and one noise draw earlier).
+    ``lines`` keeps the metrics of every snapshot; ``out``: where the lines go (default stdout)."""
+
+    def __init__(self, args, model, cano_pc, pc_list, sample=None, tau_func=None, out=None):
+        self.args, self.model, self.cano_pc, self.pc_list, self.sample = args, model, cano_pc, pc_list, sample
+        self.tau_func, self.out = tau_func, out
+        self.count, self.lines = 0, []
+
+    def state(self, i):
+        with torch.no_grad():
+            if self.args.model == "base":
+                _, seg_part, trans_list = self.model(self.cano_pc, tau=self.tau_func(cur_iter=i + 1))
+            else:
+                _, seg_part, trans_list = self.model(self.cano_pc)
+        return seg_part, trans_list.detach()
+
+    def __call__(self, i, losses):
+        from reart_amd import tail
+
+        import sys
+        out = self.out if self.out is not None else sys.stdout
+        if losses:
+            print(f"iteration: {i} | " + " | ".join(f"{k}: {float(v.detach() if torch.is_tensor(v) else v):.3f}" for k, v in losses.items()),
+                  file=out)
+        seg_part, trans_list = self.state(i)
+        has_gt = self.sample is not None and any(k in self.sample for k in ("gt_flow_list", "gt_cano_part", "complete_gt_pc_list"))
+        m = tail.snapshot_metrics(self.cano_pc, self.pc_list, seg_part, trans_list, self.args.cano_idx, self.sample, chamfer=False) if has_gt else {}
+        if "epe" in m:
+            print(f"Flow eval: EPE: {m['epe']:.3f} | Acc 5: {m['acc5']:.3f} | Acc 10: {m['acc10']:.3f} | Angle: {m['angle']:.3f}", file=out)
+        if "ri" in m:
+            print(f"Seg eval: RI: {m['ri']:.3f}", file=out)
+        if "recon_err" in m:
+            print(f"Recon eval: recon: {m['recon_err']:.3f}", file=out)
+        self.count += 1
+        self.lines.append((i, m))
+        return m
+
+
 def build_kinematic_from_base(result, cano_pc, pc_list, args):
     """run_robot.py:101-124: KinematicModel from a base result (dict with pred_cano_part, pred_pose_list and, when the
     base run already extracted it, joint_connection)."""
@@ -558,12 +614,7 @@ def main(args):
     chamfer_dist = ChamferDistance()
     knn_flow = KNN(k=3, transpose_mode=True)
 
-    def snapshot(i, losses):
-        with torch.no_grad():
-            pred, _, _ = model(cano_pc, tau=tau_func(cur_iter=i + 1)) if args.model == "base" else model(cano_pc)
-            cd = recon_loss(pred, pc_list, chamfer_dist).item() / (2 * pred.shape[0] * pred.shape[1])
-        print(f"iteration: {i} | " + " | ".join(f"{k}: {float(v.detach() if torch.is_tensor(v) else v):.3f}" for k, v in losses.items())
-              + f" | mean squared NN distance: {cd:.3e}")
+    snapshot = SnapshotPrinter(args, model, cano_pc, pc_list, None if args.synthetic and "gt_flow_list" not in sample else sample, tau_func)
 
     n_iter = 1 if args.evaluate else args.n_iter
     i = 0

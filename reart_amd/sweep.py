@@ -63,7 +63,7 @@ class _CaptureGate:
     def __init__(self):
         import threading
 
-        self._cv, self._readers, self._writer = threading.Condition(), 0, False
+        self._cv, self._readers, self._writer, self._waiting = threading.Condition(), 0, False, 0
 
     def tail(self):
         gate = self
@@ -71,8 +71,8 @@ class _CaptureGate:
         class _R:
             def __enter__(self):
                 with gate._cv:
-                    while gate._writer:
-                        gate._cv.wait()
+                    while gate._writer or gate._waiting:      # a waiting capture goes first: readers that keep coming (the
+                        gate._cv.wait()                       # refreshes of concurrent groups) must not starve it
                     gate._readers += 1
 
             def __exit__(self, *exc):
@@ -87,8 +87,10 @@ class _CaptureGate:
         class _W:
             def __enter__(self):
                 with gate._cv:
+                    gate._waiting += 1
                     while gate._writer or gate._readers:
                         gate._cv.wait()
+                    gate._waiting -= 1
                     gate._writer = True
 
             def __exit__(self, *exc):
@@ -302,6 +304,7 @@ def run_sweep_engines(instances, make_engine, n_iter, device, per_gpu=3, chunk=1
                 ph = AssignmentPhaseBatch(batch, [e[2].caller_clouds() for e in part], assign["downsample"], assign["assign_gap"],
                                           assign["lambda_assign"])
                 ph.capture_guard = gate.capture
+                ph.work_guard = gate.tail if concurrent else None
                 ph.run(first_phase, n_iter)
                 lap_counts["assign_refreshes"] += ph.refreshes
                 lap_counts["lap_fallbacks"] += ph.fallbacks
@@ -392,6 +395,53 @@ def run_sweep_engines(instances, make_engine, n_iter, device, per_gpu=3, chunk=1
         stages[key] += time.perf_counter() - t_
         return r_
 
+    # The README recipe as a sweep (assign): a group's second phase is driven from the host refresh by refresh, and while its
+    # K x (T-1) assignment problems are being solved (one workgroup each, as long as the slowest of them) the rest of the chip
+    # idles -- 65 s for 20 instances when the groups took turns.  The groups are independent: here every group runs BOTH
+    # phases on a stream and a host thread of its own, all groups at once; the solves of one group overlap the solves and the
+    # iterations of the others (the solver's racers and reduction workgroups are dealt with the number of concurrent calls
+    # in mind, lap.CONCURRENT_CALLS).  Captures stay exclusive (the gate's one writer); refreshes and tails are its readers.
+    concurrent = (assign is not None and first_phase < n_iter and mode == "batch" and threads and len(groups) > 1
+                  and os.environ.get("REART_SWEEP_CONCURRENT", "1") != "0")
+    if concurrent:
+        import threading
+
+        from .utils import lap as _lap
+
+        lives = [timed("build_s", build, g) for g in groups]
+        plans = [timed("capture_s", capture, live) for live in lives]
+        if energy and pool is None:
+            pool = ThreadPoolExecutor(max_workers=2 * max(per_gpu, 1))
+        errors = []
+
+        def drive(k):
+            try:
+                st = torch.cuda.Stream(device=device)
+                st.wait_stream(torch.cuda.default_stream(device))      # the set-up and capture work of the main thread
+                with torch.cuda.stream(st):
+                    enqueue(lives[k], plans[k])
+                tails(lives[k])
+            except BaseException as exc:      # the group's instances are reported failed; the other groups go on
+                errors.append((k, exc))
+                for e in lives[k]:
+                    local.setdefault(e[0], _record(e[0], e[1], failed=1))
+
+        old_calls = _lap.CONCURRENT_CALLS
+        _lap.CONCURRENT_CALLS = len(groups)
+        try:
+            workers = [threading.Thread(target=drive, args=(k,), name=f"sweep-group-{k}") for k in range(len(groups))]
+            for w in workers:
+                w.start()
+            for w in workers:
+                w.join()
+        finally:
+            _lap.CONCURRENT_CALLS = old_calls
+        for k, exc in errors:
+            import sys
+
+            print(f"sweep: group {k} failed: {type(exc).__name__}: {exc}", file=sys.stderr)
+        stages["concurrent_groups"] = len(groups)
+        groups = []                                        # nothing left for the pipelined loop below
     cur = timed("build_s", build, groups[0]) if groups else []
     enqueue(cur, timed("capture_s", capture, cur))
     for gi in range(len(groups)):

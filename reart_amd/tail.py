@@ -44,11 +44,11 @@ def energy_terms(cano_pc, pc_list, seg_part, trans_list, joint_connection, cano_
                 lap_fallbacks=getattr(compute_ass_err, "last_fallbacks", 0))     # assignment problems solved on the host: 0 = none
 
 
-def snapshot_metrics(cano_pc, pc_list, seg_part, trans_list, cano_idx, sample=None):
-    """-> dict with cd_err always and, when ``sample`` carries the ground truth, epe / acc5 / acc10 / angle / ri /
-    recon_err (run_robot.py:245-266; centimetre scaling as there)."""
+def snapshot_metrics(cano_pc, pc_list, seg_part, trans_list, cano_idx, sample=None, chamfer=True):
+    """-> dict with cd_err (``chamfer``: the value is printed at the end of a run only, run_robot.py:316) and, when ``sample``
+    carries the ground truth, epe / acc5 / acc10 / angle / ri / recon_err (run_robot.py:245-266; centimetre scaling as there)."""
     pred = compute_pc_transform(cano_pc, trans_list, seg_part)
-    out = dict(cd_err=100 * compute_chamfer_list(pred, pc_list, reduction="mean"))
+    out = dict(cd_err=100 * compute_chamfer_list(pred, pc_list, reduction="mean")) if chamfer else {}
     if sample is None:
         return out
     dev = cano_pc.device

@@ -166,8 +166,13 @@ RESOLVE_PER_WAVE = os.environ.get("REART_RESOLVE_MW", "1") != "0"
 RESOLVE_ARR_WGS = int(os.environ.get("REART_RESOLVE_ARR_WGS", "-1"))     # -1: up to eight, as many as the batch leaves room for
 
 
+# solver calls expected to be in flight at once on the device (the sweep's concurrent groups set it): the idle compute units a
+# call hands to racers / reduction workgroups are shared among them
+CONCURRENT_CALLS = 1
+
+
 def _arr_wgs(B):
-    return RESOLVE_ARR_WGS if RESOLVE_ARR_WGS >= 0 else max(1, min(8, 256 // max(B, 1)))
+    return RESOLVE_ARR_WGS if RESOLVE_ARR_WGS >= 0 else max(1, min(8, 256 // max(B * max(CONCURRENT_CALLS, 1), 1)))
 
 
 def _resolve_racers(B, n, race=True):
@@ -175,7 +180,7 @@ def _resolve_racers(B, n, race=True):
     re-solve is one short launch and is not raced."""
     if not race or n < 512:
         return 1
-    r = min(RESOLVE_RACERS, 256 // max(B, 1))
+    r = min(RESOLVE_RACERS, 256 // max(B * max(CONCURRENT_CALLS, 1), 1))
     return r if r >= 2 else 1
 
 

@@ -129,3 +129,86 @@ def test_device_side_refresh_equals_the_tensor_path(dev):
         outs.append((phase.lap_state["cols"].clone(), eng._assign_map.clone(), eng.pc_trans.clone(), eng.last_losses().clone()))
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+def test_refresh_schedule_when_the_phase_starts_one_iteration_before_a_refresh(dev):
+    """run_robot.py:165 refreshes the pairs at the first assignment iteration AND at every i % assign_gap == 0.  With
+    assign_iter % assign_gap == assign_gap - 1 (here 4 and 5) the second refresh is due one iteration after the first -- the
+    iteration the graph capture runs eagerly.  `AssignmentPhase.run` (graph replays between refreshes) against the
+    reference's loop structure spelled out one iteration at a time: same refreshes (4, 5, 10, 15), same snapshots, the same
+    trajectory bit for bit; the shared-launch form (`AssignmentPhaseBatch`) keeps the same schedule."""
+    from reart_amd.data import load_nao_demo
+    from reart_amd.networks.model import BaseModel
+    from reart_amd.relax import RelaxBatch, RelaxEngine
+    from reart_amd.run_robot import AssignmentPhase, AssignmentPhaseBatch
+
+    g = load_nao_demo()
+    cano, pcs, c = t(g["cano"], dev), t(g["pc_list"], dev), int(g["cano_idx"])
+    start, end, gap = 4, 17, 5
+
+    def engine():
+        torch.manual_seed(4)
+        model = BaseModel(num_parts=20, pose_len=pcs.shape[0]).to(dev)
+        eng = RelaxEngine(cano, pcs, model, c, None, None, n_iter=15000, seed=4)
+        eng.step(start)
+        return eng
+
+    # the reference's structure, literally
+    eng = engine()
+    ref = AssignmentPhase(eng, cano, pcs, 4, gap, 0.3)
+    refreshed = []
+    for i in range(start, end):
+        if not ref._have or i % gap == 0:
+            ref.refresh()
+            refreshed.append(i)
+        eng.step(1)
+    assert refreshed == [4, 5, 10, 15]
+    want = (ref.lap_state["cols"].clone(), eng._assign_map.clone(), eng.pc_trans.clone(), eng.last_losses().clone())
+    # the production loop
+    eng = engine()
+    phase = AssignmentPhase(eng, cano, pcs, 4, gap, 0.3)
+    snaps = []
+    assert phase.run(start, end, snapshot_gap=5, on_snapshot=snaps.append) == end
+    assert phase.refreshes == 4 and phase.fallbacks == 0
+    assert snaps == [5, 10, 15, 17]
+    for a, b in zip(want, (phase.lap_state["cols"], eng._assign_map, eng.pc_trans, eng.last_losses())):
+        assert torch.equal(a, b)
+    # two instances in shared launches: the first of them is the instance above
+    engs = [engine(), engine()]
+    batch = RelaxBatch(engs)
+    pb = AssignmentPhaseBatch(batch, [(cano, pcs), (cano, pcs)], 4, gap, 0.3)
+    assert pb.run(start, end) == end and pb.refreshes == 4 and pb.fallbacks == 0
+    for e in engs:
+        assert torch.equal(e.pc_trans, want[2]) and torch.equal(e._assign_map, want[1])
+
+
+def test_a_batch_graph_captured_in_the_chamfer_phase_is_not_replayed_in_the_assignment_phase(dev):
+    """RelaxBatch keeps ONE graph for all its engines; when the engines switch to the assignment loss (set_assignment drops
+    their own graphs) the batch's Chamfer-phase graph must go too -- with assign_gap 1 nothing re-captures, and replaying it
+    would silently run Chamfer iterations.  Two instances, assign_gap 1: equal to the solo loop."""
+    from reart_amd.data import load_nao_demo
+    from reart_amd.networks.model import BaseModel
+    from reart_amd.relax import RelaxBatch, RelaxEngine
+    from reart_amd.run_robot import AssignmentPhase, AssignmentPhaseBatch
+
+    g = load_nao_demo()
+    cano, pcs, c = t(g["cano"], dev), t(g["pc_list"], dev), int(g["cano_idx"])
+
+    def engine():
+        torch.manual_seed(4)
+        model = BaseModel(num_parts=20, pose_len=pcs.shape[0]).to(dev)
+        return RelaxEngine(cano, pcs, model, c, None, None, n_iter=15000, seed=4)
+
+    solo = engine()
+    solo.step(3)
+    ph = AssignmentPhase(solo, cano, pcs, 4, 1, 0.3)
+    ph.run(3, 7)
+    engs = [engine(), engine()]
+    batch = RelaxBatch(engs)
+    done = batch.capture(steps_per_graph=1)                 # the Chamfer phase's graph
+    batch.step(3 - done)
+    pb = AssignmentPhaseBatch(batch, [(cano, pcs), (cano, pcs)], 4, 1, 0.3)
+    pb.run(3, 7)
+    assert pb.refreshes == ph.refreshes == 4
+    for e in engs:
+        assert torch.equal(e.pc_trans, solo.pc_trans) and torch.equal(e.last_losses(), solo.last_losses())

@@ -1,0 +1,68 @@
+"""The drop-in loop prints what the reference prints at a snapshot (run_robot.py:224-266: `Flow eval: EPE | Acc 5 | Acc 10 |
+Angle`, `Seg eval: RI`, `Recon eval: recon`, every --snapshot_gap iterations and at the last one) -- in the fused Chamfer
+phase, in the assignment phase and in the kinematic projection -- and the numbers in those lines are `tail.snapshot_metrics`
+(golden-tested against the reference's own tail: tests/golden/structure.npz) of the model's state at that iteration."""
+import re
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _lines(out):
+    flow = [tuple(float(x) for x in m) for m in re.findall(r"Flow eval: EPE: ([\d.]+) \| Acc 5: ([\d.]+) \| Acc 10: ([\d.]+) \| Angle: ([\d.]+)", out)]
+    seg = [float(x) for x in re.findall(r"Seg eval: RI: ([\d.]+)", out)]
+    rec = [float(x) for x in re.findall(r"Recon eval: recon: ([\d.]+)", out)]
+    return flow, seg, rec
+
+
+def test_snapshot_lines_of_the_drop_in_loop(dev, tmp_path, capsys):
+    from reart_amd import tail
+    from reart_amd.run_robot import SnapshotPrinter, build_parser, main
+    from reart_amd.synthetic import export_sequence
+
+    seq_dir = str(tmp_path / "toy")
+    export_sequence(seq_dir, T=6, n_parts=4, pts_per_part=256, seed=2, n_novel=0)
+    base = ["--seq_path", seq_dir, "--num_points", "1024", "--cano_idx", "2", "--snapshot_gap", "500"]
+    # base model: 1 800 fused Chamfer iterations, then 200 of the assignment phase: snapshots at the end of every fused chunk
+    # (4) and at the end of the assignment phase (1)
+    main(build_parser().parse_args(base + ["--n_iter", "2000", "--assign_iter", "1800", "--use_assign_loss", "--downsample", "4",
+                                           "--save_root", str(tmp_path / "base")]))
+    out = capsys.readouterr().out
+    flow, seg, rec = _lines(out)
+    # the snapshots of the loop + the same three lines once more from the end of the run (run_robot.py:263-266 at i == n_iter - 1)
+    n_loss = len(re.findall(r"iteration: \d+ \| recon Loss", out)) + len(re.findall(r"iteration: \d+ \| opt assignment loss", out))
+    assert n_loss == 5 and len(flow) == len(seg) == len(rec) == n_loss + 1, out
+    assert len(re.findall(r"iteration: \d+ \| opt assignment loss", out)) == 1
+    assert all(0.0 <= s <= 1.0 for s in seg) and all(r >= 0.0 for r in rec) and all(0.0 <= f[1] <= f[2] <= 1.0 for f in flow)
+    # kinematic projection from that result: the forward has no noise, so the last snapshot's lines ARE the final model's metrics
+    res_path = next((tmp_path / "base").rglob("result.pkl"))
+    import pickle
+
+    with open(res_path, "rb") as f:
+        if pickle.load(f)["pred_pose_list"].shape[1] < 2:
+            pytest.skip("the toy relaxation ended with one part: no joint tree to project onto")
+    args = build_parser().parse_args(base[:-1] + ["10", "--model", "kinematic", "--base_result_path", str(res_path), "--use_assign_loss",
+                                                  "--assign_iter", "0", "--downsample", "2", "--assign_gap", "1", "--n_iter", "31",
+                                                  "--save_root", str(tmp_path / "kin")])
+    model = main(args)
+    out = capsys.readouterr().out
+    flow, seg, rec = _lines(out)
+    assert len(flow) == len(seg) == len(rec) == 4 + 1, out            # i = 0, 10, 20, 30 (the last iteration) + the end of the run
+    from reart_amd.dataset import Sequence
+
+    sample = Sequence(seq_dir, num_points=1024, cano_idx=2)[0]
+    cano = torch.from_numpy(sample["cano_pc"]).float().to(dev)
+    pcs = torch.from_numpy(sample["pc_list"]).float().to(dev)
+    with torch.no_grad():
+        _, seg_part, trans = model(cano)
+    m = tail.snapshot_metrics(cano, pcs, seg_part, trans, 2, sample, chamfer=False)
+    # the snapshot of the last iteration (index 3) sees the model main() returns; index 4 is the end of the run's (denoised labels)
+    assert abs(flow[3][0] - m["epe"]) <= 6e-4 and abs(flow[3][1] - m["acc5"]) <= 6e-4 and abs(flow[3][3] - m["angle"]) <= 6e-4
+    assert abs(seg[3] - float(m["ri"])) <= 6e-4 and abs(rec[3] - m["recon_err"]) <= 6e-4
+    # the printer as an object: counts its snapshots and keeps the metrics
+    sp = SnapshotPrinter(args, model, cano, pcs, sample)
+    got = sp(30, {"total Loss": torch.tensor(1.0)})
+    assert sp.count == 1 and abs(got["epe"] - m["epe"]) < 1e-6 and sp.lines[0][0] == 30

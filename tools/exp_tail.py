@@ -37,6 +37,21 @@ def table(ms, raw, form_note):
     print(f"per solve, slowest problem: search steps p50 {pct(steps.max(1), 50):.0f} p95 {pct(steps.max(1), 95):.0f} max {steps.max():.0f} | "
           f"rows left p50 {pct(left.max(1), 50):.0f} p95 {pct(left.max(1), 95):.0f} max {left.max()} | rows released p50 {pct(freed.max(1), 50):.0f} "
           f"max {freed.max()} | row-reduction steps (problem mean) {arr.mean():.0f}")
+    if os.environ.get("BUCKET_STATS"):      # diagnostic build (-DMW_BUCKET_STATS): relaxations / 16 | rounds | buckets in place of conflicts / reduction steps
+        relax = 16 * ((raw[:, :, 1] >> 16) & 0xffff)
+        rounds, buckets = arr & 0xfff, (arr >> 12) & 0xfff
+        k = steps.argmax(1)
+        ar = np.arange(len(ms))
+        print(f"bucketed part, slowest problem of a solve: relaxations p50 {pct(relax[ar, k], 50):.0f} p95 {pct(relax[ar, k], 95):.0f} max {relax.max()} | "
+              f"rounds p50 {pct(rounds[ar, k], 50):.0f} p95 {pct(rounds[ar, k], 95):.0f} | buckets p50 {pct(buckets[ar, k], 50):.0f} p95 {pct(buckets[ar, k], 95):.0f} | "
+              f"totals over all problems: relaxations {relax.sum()} rounds {rounds.sum()} buckets {buckets.sum()} counted steps {steps.sum()}")
+        ok = (rounds[ar, k] < 4000) & (buckets[ar, k] < 4000) & (ms < np.percentile(ms, 99))
+        seqs = np.maximum(steps[ar, k] - rounds[ar, k] - buckets[ar, k], 0)
+        A_ = np.stack([np.ones(ok.sum()), seqs[ok], rounds[ar, k][ok], buckets[ar, k][ok], relax[ar, k][ok]], axis=1).astype(np.float64)
+        c_, *_ = np.linalg.lstsq(A_, ms[ok], rcond=None)
+        print(f"least squares over the slowest problem's counts: ms = {c_[0]:.3f} + {1e3 * c_[1]:.3f} us x one-column steps + {1e3 * c_[2]:.3f} us x rounds + "
+              f"{1e3 * c_[3]:.3f} us x buckets + {1e3 * c_[4]:.3f} us x relaxations; residual rms {(ms[ok] - A_ @ c_).std():.3f} ms; "
+              f"means: steps {seqs[ok].mean():.0f} rounds {rounds[ar, k][ok].mean():.0f} buckets {buckets[ar, k][ok].mean():.0f} relaxations {relax[ar, k][ok].mean():.0f}")
     # a linear account: ms ~ a + b * (search steps of the slowest problem)
     A = np.stack([np.ones(len(ms)), steps.max(1)], axis=1)
     coef, *_ = np.linalg.lstsq(A, ms, rcond=None)

@@ -5,6 +5,25 @@ reart_amd/data/nao_demo.npz): the reference's base recipe without the flow loss 
 numbers the reference's own shipped base-2 checkpoint gives (same fixture)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if "--projection" in sys.argv:
+    # README.md:125 literally, on nao, from the result of the README.md:116 recipe: all 15 000 iterations with a snapshot every
+    # 10, iterations/s per window of 1 000 and the whole wall time (bench.py's nao_projection leg, unbounded) -> a text report
+    import argparse, json
+    import torch
+    import bench
+    a = argparse.Namespace(steps=1500, warmup=150, no_cpu_baseline=True, cpu_budget=3.0, frames=20, points=4096)
+    t0 = time.perf_counter()
+    out = bench.bench_nao_projection(a, torch.device("cuda:0"), n_iter=None, windows=15)
+    c, r = out["config"], out["roofline"]
+    print(f"README.md:125 on nao (kinematic projection, {c['n_iter']} iterations, snapshot every {c['snapshot_gap']}: {c['snapshots']} snapshots), "
+          f"from the README.md:116 recipe's result ({c['parts']} parts)")
+    print(f"whole projection run: {c['wall_s']:.2f} s = {out['value']:.1f} iterations/s; host fallbacks {c['lap_fallbacks']}; "
+          f"recipe + projection in this process: {time.perf_counter() - t0:.1f} s")
+    print("iterations/s per window of 1 000:", " ".join(f"{v:.0f}" for v in c["iterations_per_s_by_window"]))
+    print(f"assignment re-solve (9 x 2048^2 per iteration): mean {r['kernel_ms']:.3f} ms | p50 {r['solve_ms_p50']:.3f} | p95 {r['solve_ms_p95']:.3f} | "
+          f"max {r['solve_ms_max']:.3f} | first (cold) {r['first_solve_ms']:.1f} ms")
+    print("final losses:", json.dumps(out["final_losses"]))
+    sys.exit(0)
 import numpy as np, torch
 from reart_amd import tail
 from reart_amd.networks.model import BaseModel
