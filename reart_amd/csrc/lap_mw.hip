@@ -1170,6 +1170,120 @@ __global__ __launch_bounds__(64 * MW_NW) void lap_mc_arr_kernel(JvArgs a) {
     }
 }
 
+
+// The same chains with a TEAM of TW waves per chain (one workgroup = one team).  At 32 columns per lane a wave alone spends
+// 9-10 us per step on its ~2 000 instructions (32 square roots, the fp64 top-2) -- and the launch lasts as long as the longest
+// chain is allowed to (128 steps: 1.2 ms of every re-solve of the projection's 2048 x 2048 problems).  In a team every wave
+// scans CPL / TW columns per lane, the waves' (min, arg-min, second min) meet in LDS after ONE barrier, every wave merges the
+// same TW triples (so every decision is uniform across the team without a broadcast), thread 0 commits exactly as a lone
+// wave's lane 0 does and the outcome comes back after a second barrier.  Column 64 * (TW * k + wave) + lane is slot k of a lane.
+template <int CPL, int TW>
+__global__ __launch_bounds__(64 * TW) void lap_mc_arr_team_kernel(JvArgs a) {
+    constexpr int CW = CPL / TW, LG = TW <= 2 ? 1 : (TW <= 4 ? 2 : 3);
+    static_assert(CPL % TW == 0 && CW >= 2 && CW % 2 == 0 && TW <= 8, "columns per lane of a team wave: an even number");
+    const int n = a.n, b = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double *price = a.mc_price + (size_t)b * n;
+    int *owner = a.mc_owner + (size_t)b * n, *assigned = a.mc_assigned + (size_t)b * n, *next = a.mc_next + (size_t)b * n;
+    const int *flist = a.mc_list + (size_t)b * n;
+    int *cnt = a.mc_cnt + 8 * b;
+    const float *S_ = a.src + (size_t)b * n * 3, *T_ = a.tgt + (size_t)b * n * 3;
+    const int nfree = cnt[0];
+    __shared__ double s_v1[2][TW], s_v2[2][TW], s_p[2][TW];
+    __shared__ int s_j1[2][TW], s_o[2][TW], s_q[2], s_ok[2];
+    jv_f2 tcx[CW / 2], tcy[CW / 2], tcz[CW / 2];
+    int col[CW];
+#pragma unroll
+    for (int k = 0; k < CW; ++k) {
+        col[k] = 64 * (TW * k + wv) + lane;
+        const int j = col[k] < n ? col[k] : 0;
+        tcx[k >> 1][k & 1] = T_[3 * j]; tcy[k >> 1][k & 1] = T_[3 * j + 1]; tcz[k >> 1][k & 1] = T_[3 * j + 2];
+    }
+    auto ld_i = [](const int *p) -> int { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto ld_d = [](const double *p) -> double { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    int my_arr = 0, my_conf = 0, par = 0, qpar = 0, opar = 0;
+    for (;;) {
+        if (threadIdx.x == 0) s_q[qpar] = __hip_atomic_fetch_add(&cnt[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const int q = s_q[qpar];
+        qpar ^= 1;
+        if (q >= nfree) break;
+        int i = flist[q];
+        float ax = S_[3 * i], ay = S_[3 * i + 1], az = S_[3 * i + 2];
+        int spins = 0;
+        for (int budget = a.mc_chain; ; ) {
+            double pr[CW];
+            int ow[CW];
+#pragma unroll
+            for (int k = 0; k < CW; ++k) {
+                pr[k] = col[k] < n ? ld_d(price + col[k]) : INFINITY;
+                ow[k] = col[k] < n ? ld_i(owner + col[k]) : -1;
+            }
+            float rc[CW];
+            mw_row_costs<CW>(ax, ay, az, tcx, tcy, tcz, rc);
+            double v1 = INFINITY, v2 = INFINITY;
+            int j1 = 0x7fffffff, slot = 0;
+#pragma unroll
+            for (int k = 0; k < CW; ++k) lap_top2_push((double)rc[k] + pr[k], col[k], k, v1, j1, v2, slot);
+            lap_wave_top2_fast(v1, j1, v2, slot);
+            // the price and owner the wave's candidate was judged by, from the lane that holds that column
+            j1 = mw_uniform(j1); slot = mw_uniform(slot);
+            double pl = 0.0;
+            int ol = -1;
+#pragma unroll
+            for (int k = 0; k < CW; ++k)
+                if (slot == k) { pl = pr[k]; ol = ow[k]; }
+            const int hl = j1 == 0x7fffffff ? 0 : (j1 & 63);
+            const double pw = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(pl), hl), __builtin_amdgcn_readlane(__double2loint(pl), hl));
+            const int owv = __builtin_amdgcn_readlane(ol, hl);
+            if (lane == 0) { s_v1[par][wv] = v1; s_v2[par][wv] = v2; s_j1[par][wv] = j1; s_p[par][wv] = pw; s_o[par][wv] = owv; }
+            __syncthreads();
+            v1 = lane < TW ? s_v1[par][lane] : INFINITY; v2 = lane < TW ? s_v2[par][lane] : INFINITY;
+            j1 = lane < TW ? s_j1[par][lane] : 0x7fffffff;
+            int win = lane;
+            lap_lanes_top2<LG>(v1, j1, v2, win);
+            win = win < TW ? win : 0;
+            const double pj1 = s_p[par][win];
+            const int own = s_o[par][win];
+            par ^= 1;
+            if (!(v1 < INFINITY)) { if (threadIdx.x == 0) __hip_atomic_store(&cnt[6], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            if (own == MW_LOCKED && ++spins < (1 << 14)) { ++my_conf; continue; }     // somebody is committing on it: look again
+            const bool tie = !(v1 < v2);
+            if (own == MW_LOCKED || --budget < 0 || (tie && own >= 0)) {       // (a lock that never opens: never observed) / out of budget / an exact tie on an owned column
+                if (threadIdx.x == 0) next[__hip_atomic_fetch_add(&cnt[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = i;
+                break;
+            }
+            const int in_ = own >= 0 ? own : i;
+            const float nx = S_[3 * in_], ny = S_[3 * in_ + 1], nz = S_[3 * in_ + 2];
+            if (threadIdx.x == 0) {
+                int ok = 0, seen = own;
+                // (the commit of lap_mc_arr_kernel, word for word: see there for why these orders suffice)
+                if (__hip_atomic_compare_exchange_strong(owner + j1, &seen, MW_LOCKED, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    if (ld_d(price + j1) == pj1) {
+                        if (!tie) __hip_atomic_store(price + j1, pj1 + (v2 - v1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(assigned + i, j1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (own >= 0) __hip_atomic_store(assigned + own, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __hip_atomic_store(owner + j1, i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok = 1;
+                    } else __hip_atomic_store(owner + j1, own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                s_ok[opar] = ok;
+            }
+            __syncthreads();
+            const int ok = s_ok[opar];
+            opar ^= 1;
+            if (!ok) { ++my_conf; continue; }
+            ++my_arr;
+            if (own < 0) break;
+            i = own; ax = nx; ay = ny; az = nz;
+        }
+    }
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(&cnt[3], my_arr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&cnt[4], my_conf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 int reart_internal_jvmw_nmax() { return 64 * 32; }
 
 // (dynamic LDS is raised to what the launch needs, not to a flat 152 KB: the kernel also holds ~18 KB of static LDS -- the
@@ -1213,7 +1327,15 @@ static int mc_launch(const JvArgs &a, int racers, int arr_wgs, hipStream_t strea
     // name: two waves on a SIMD halve each other.  Where the chip has room the same chains run as twice the workgroups of half
     // the waves -- a SIMD each.
     const int split = (2 * arr_wgs * a.B <= 256) ? 2 : 1;
-    hipLaunchKernelGGL((lap_mc_arr_kernel<CPL>), dim3(arr_wgs * split, a.B), dim3(64 * MW_NW / split), 0, stream, s2);
+#ifndef MW_ARR_TEAM
+#define MW_ARR_TEAM 4        // waves per chain from 16 columns per lane on (0: a wave per chain everywhere)
+#endif
+    if (MW_ARR_TEAM > 0 && CPL >= 16) {
+        // as many chains in flight per problem as the wave-per-chain form has (arr_wgs x 8), each a workgroup of its own
+        constexpr int TW = MW_ARR_TEAM > 0 ? MW_ARR_TEAM : 1;
+        hipLaunchKernelGGL((lap_mc_arr_team_kernel<(CPL >= 16 ? CPL : 16), TW>), dim3(arr_wgs * MW_NW, a.B), dim3(64 * TW), 0, stream, s2);
+    } else
+        hipLaunchKernelGGL((lap_mc_arr_kernel<CPL>), dim3(arr_wgs * split, a.B), dim3(64 * MW_NW / split), 0, stream, s2);
     REART_CHECK_LAUNCH();
 #if MW_TREE_K > 0
     hipLaunchKernelGGL((lap_mc_trees_kernel<CPL>), dim3(a.B * 8 <= 256 ? 8 : 4, a.B), dim3(256), 0, stream, s2);
