@@ -966,9 +966,9 @@ __global__ __launch_bounds__(512) void lap_mc_forest_kernel(JvArgs a) {
     double *oj = q + n;                           // [n] forest columns: the shift when they joined
     int *flist = (int *)(oj + n);                 // [n] the forest's columns
     int *troot = flist + n;                       // [n] column -> root (tree id) or -1
-    float *ltx = (float *)(troot + n), *lty = ltx + n, *ltz = lty + n;     // [n] target points (a round reads ONE, chosen by the arg-min)
-    __shared__ int s_n, s_j[2][NW];
-    __shared__ double s_v[2][NW];
+    int *jp = troot + n;                          // [n] rows that joined: jump pointer towards the root (starts as the parent)
+    float *ltx = (float *)(jp + n), *lty = ltx + n, *ltz = lty + n;       // [n] target points
+    __shared__ int s_n;
     if (tid == 0) s_n = 0;
     __syncthreads();
     float sx[CPT], sy[CPT], sz[CPT];
@@ -1009,52 +1009,141 @@ __global__ __launch_bounds__(512) void lap_mc_forest_kernel(JvArgs a) {
     double off = 0.0;
     int nf = nf0;
 #ifdef MW_FOREST_K
-    // rounds follow the problem: MW_FOREST_K per row left for the searches, within [MW_FOREST_MIN, MW_FOREST_R]
+    // rows follow the problem: MW_FOREST_K per row left for the searches, within [MW_FOREST_MIN, MW_FOREST_R]
     const int rounds = min(MW_FOREST_R, max(MW_FOREST_MIN, MW_FOREST_K * cnt[2]));
 #else
     const int rounds = MW_FOREST_R;
 #endif
-    // a round: the workgroup's arg-min of the outside rows' slacks (ordered-integer keys, as in the searches), ONE barrier,
-    // then everybody relaxes its rows against the column that joined (its price is in q, the shift is known to all)
-    for (int r = 0; r < rounds; ++r) {
-        double bv = INFINITY;
-        int bj = 0x7fffffff;
+    // The growth is a shortest-path computation like the searches' (the label of an outside row: L_i = M_i - u_i, the shift
+    // at which it becomes tight to the forest; a row that joins at shift o offers its column at q + o to everybody else) and
+    // runs in BUCKETS like them: all outside rows with a label below (closest label) + width join together, label-correcting
+    // rounds inside the bucket (a member whose label improves offers its column again), one barrier per round.  One row per
+    // round and arg-min, the first form, took 512 x 1.15 us of every re-solve.
+    __shared__ float s_fx[2][MW_BK], s_fy[2][MW_BK], s_fz[2][MW_BK];
+    __shared__ double s_fq[2][MW_BK], s_cmax[2][NW], s_cmin[2][NW];
+    __shared__ int s_fj[2][MW_BK], s_fcnt[3], s_cn[2][NW];
+    if (tid == 0) { s_fcnt[0] = 0; s_fcnt[1] = 0; s_fcnt[2] = 0; }
+    const double fdelta = a.scale[b] * 1e-12;
+    double bw = a.scale[b] * MW_BUCKET_W0, L[CPT];
+    int brot = 0, bpar = 0, seq = 0, joined = 0;
+    unsigned pend = 0u;
+    double lo = INFINITY;
 #pragma unroll
-        for (int k = 0; k < CPT; ++k)
-            if ((out >> k) & 1u) {
-                const double sl = (M[k] - off) - u[k];
-                if (sl < bv) { bv = sl; bj = tid + k * BS; }
-            }
-        mw_argmin_key<6>(bv, bj);
-        const int par = r & 1;
-        if (lane == 0) { s_v[par][wv] = bv; s_j[par][wv] = bj; }
-        __syncthreads();
-        bv = lane < NW ? s_v[par][lane] : INFINITY; bj = lane < NW ? s_j[par][lane] : 0x7fffffff;
-        mw_argmin_key<3>(bv, bj);
-        if (bj == 0x7fffffff || !(bv < INFINITY)) break;
-        off += bv > 0.0 ? bv : 0.0;
-        const int js = bj;
-        if ((js & (BS - 1)) == tid) {             // the row of column js joins: parent, root, shift at joining
-#pragma unroll
-            for (int k = 0; k < CPT; ++k)
-                if (js == tid + k * BS) {
-                    out &= ~(1u << k);
-                    troot[js] = troot[Mt[k]]; gtpar[js] = Mt[k];
-                    oj[js] = off;
-                    flist[nf] = js;
-                }
-        }
-        ++nf;
-        const float tx = ltx[js], ty = lty[js], tz = ltz[js];
-        const double tq = q[js] + off;
-#pragma unroll
-        for (int k = 0; k < CPT; ++k)
-            if ((out >> k) & 1u) {
-                const double v = (double)mw_sqrt(reart_sqdist3(sx[k], sy[k], sz[k], tx, ty, tz)) + tq;
-                if (v < M[k]) { M[k] = v; Mt[k] = js; }
-            }
+    for (int k = 0; k < CPT; ++k) {
+        L[k] = ((out >> k) & 1u) ? M[k] - u[k] : INFINITY;
+        if (!((out >> k) & 1u)) M[k] = -INFINITY;            // never a candidate of the relaxations' filter
+        lo = fmin(lo, L[k]);
     }
-    if (tid == 0) a.mc_cnt[8 * b + 7] = nf - nf0; // rounds that added a row (statistics: they are sequential steps like the searches')
+    lo = lap_wave_min_d(lo);
+    if (lane == 0) s_cmin[bpar][wv] = lo;
+    __syncthreads();                                         // (also: s_fcnt is cleared)
+    lo = s_cmin[bpar][0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) lo = fmin(lo, s_cmin[bpar][w]);
+    bpar ^= 1;
+    ++seq;
+    while (joined < rounds && lo < INFINITY) {
+        const double base = fmax(lo, off), hi = base + bw;
+#pragma unroll
+        for (int k = 0; k < CPT; ++k)
+            if (((out >> k) & 1u) && (L[k] < hi || L[k] == lo)) pend |= 1u << k;
+        for (;;) {
+            const int buf = brot & 1, slot = brot % 3;
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) {
+                const bool want = (pend >> k) & 1u;
+                const unsigned long long m = __ballot(want);
+                if (m) {
+                    int at0 = 0;
+                    if (lane == 0) at0 = atomicAdd(&s_fcnt[slot], __builtin_popcountll(m));
+                    at0 = mw_uniform(at0);
+                    const int at = at0 + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+                    if (want && at < MW_BK) {
+                        const int j = tid + k * BS;
+                        s_fx[buf][at] = ltx[j]; s_fy[buf][at] = lty[j]; s_fz[buf][at] = ltz[j];
+                        s_fq[buf][at] = q[j] + fmax(L[k], off); s_fj[buf][at] = j;
+                        pend &= ~(1u << k);
+                    }
+                }
+            }
+            if (tid == 0) s_fcnt[(brot + 1) % 3] = 0;
+            __syncthreads();
+            int ne = s_fcnt[slot];
+            ++brot;
+            if (ne == 0) break;
+            ne = ne < MW_BK ? ne : MW_BK;
+            ++seq;
+            for (int e = 0; e < ne; ++e) {
+                const float tx = s_fx[buf][e], ty = s_fy[buf][e], tz = s_fz[buf][e];
+                const double tq = s_fq[buf][e];
+                const int js = s_fj[buf][e];
+#pragma unroll
+                for (int k = 0; k < CPT; ++k) {
+                    // v = c + tq improves M iff c < M - tq: the filter of the searches' bucket rounds (square root skipped
+                    // when the squared distance exceeds the bound by more than every rounding on the way)
+                    const float sq = reart_sqdist3(sx[k], sy[k], sz[k], tx, ty, tz);
+                    const double T = (M[k] - tq) + fdelta, Tq = T * 1.000000238418579;
+                    if (T > 0.0 && (double)sq <= Tq * Tq) {
+                        const double v = (double)mw_sqrt(sq) + tq;
+                        if (v < M[k]) {
+                            const double ln = v - u[k];
+                            // a member (or a row this brings into the bucket) whose join shift got smaller offers its column again
+                            if ((ln < hi || ln == lo) && fmax(ln, off) < fmax(L[k], off)) pend |= 1u << k;
+                            M[k] = v; Mt[k] = js; L[k] = ln;
+                        }
+                    }
+                }
+            }
+        }
+        // ---- the bucket is stable: its rows join (parent = the column that attains M, shift = their label, at least the
+        // forest's shift so far); one pair of reductions: how many joined, the largest shift among them, the closest row left
+        int nnew = 0;
+        double mxo = -INFINITY, mn = INFINITY;
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            if (!((out >> k) & 1u)) continue;
+            if (L[k] < hi || L[k] == lo) {
+                const int j = tid + k * BS;
+                const double o = fmax(L[k], off);
+                out &= ~(1u << k);
+                gtpar[j] = Mt[k]; jp[j] = Mt[k]; oj[j] = o;
+                flist[atomicAdd(&s_n, 1)] = j;
+                M[k] = -INFINITY; L[k] = INFINITY;
+                mxo = fmax(mxo, o);
+                ++nnew;
+            } else mn = fmin(mn, L[k]);
+        }
+        mxo = -lap_wave_min_d(-mxo); mn = lap_wave_min_d(mn);
+#pragma unroll
+        for (int o_ = 32; o_ >= 1; o_ >>= 1) nnew += __shfl_xor(nnew, o_, 64);
+        if (lane == 0) { s_cmax[bpar][wv] = mxo; s_cmin[bpar][wv] = mn; s_cn[bpar][wv] = nnew; }
+        __syncthreads();
+        mxo = s_cmax[bpar][0]; mn = s_cmin[bpar][0]; nnew = s_cn[bpar][0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) { mxo = fmax(mxo, s_cmax[bpar][w]); mn = fmin(mn, s_cmin[bpar][w]); nnew += s_cn[bpar][w]; }
+        bpar ^= 1;
+        ++seq;
+        joined += nnew;
+        off = fmax(off, mxo);
+        lo = mn;
+        if (nnew < MW_BUCKET_LO) bw *= 4.0;
+        else if (nnew > MW_BUCKET_HI) bw *= 0.5;
+    }
+    nf = nf0 + joined;
+    // the roots of the rows that joined: their parents' (pointer jumping over the parent links; a tree's first columns carry
+    // their root from lap_mc_trees_kernel)
+    for (int it = 0; it < 16; ++it) {
+        int moved = 0;
+        for (int m = nf0 + tid; m < nf; m += BS) {
+            const int c = flist[m];
+            if (troot[c] >= 0) continue;
+            const int p = jp[c], r = troot[p];
+            if (r >= 0) troot[c] = r;
+            else { jp[c] = jp[p]; moved = 1; }
+        }
+        if (!__syncthreads_or(moved)) break;
+    }
+    if (tid == 0) a.mc_cnt[8 * b + 7] = seq < 1023 ? seq : 1023;     // sequential workgroup-wide steps of the growth (rounds + bucket reductions), reported like the searches'
     __syncthreads();
     for (int m = tid; m < nf; m += BS) {          // the forest's prices and roots
         const int t = flist[m];
@@ -1343,9 +1432,9 @@ static int mc_launch(const JvArgs &a, int racers, int arr_wgs, hipStream_t strea
 #endif
 #if MW_FOREST_R > 0
     {
-        const size_t flds = (size_t)a.n * (8 + 8 + 4 + 4 + 12);
+        const size_t flds = (size_t)a.n * (8 + 8 + 4 + 4 + 4 + 12);
         if (flds > REART_LDS_DEFAULT_CAP &&
-            hipFuncSetAttribute((const void *)lap_mc_forest_kernel<CPL>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)
+            hipFuncSetAttribute((const void *)lap_mc_forest_kernel<CPL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds) != hipSuccess)
             return REART_ERR_LAUNCH;
         hipLaunchKernelGGL((lap_mc_forest_kernel<CPL>), dim3(a.B), dim3(512), flds, stream, s2);
         REART_CHECK_LAUNCH();
