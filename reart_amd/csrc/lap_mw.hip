@@ -837,7 +837,8 @@ __global__ __launch_bounds__(64 * MW_NW) void lap_mc_tighten_kernel(JvArgs a) {
 // links: the path to an unowned column is known and costs nothing.  Without trees a search labels every column cheaper than the
 // last hop to ONE particular row (in a graph whose reduced costs are nearly all within rounding of zero: hundreds).
 #ifndef MW_TREE_K
-#define MW_TREE_K 24        // measured 6 / 12 / 24 / 40: recipe 3.71 / 3.59 / 3.56 / 3.59 ms per refresh, projection 72.1 / 75.3 / 76.7 / 77.8 it/s
+#define MW_TREE_K 12        // round 4 (one-column searches) measured 6 / 12 / 24 / 40: recipe 3.71 / 3.59 / 3.56 / 3.59 ms per refresh; round 5 (bucket rounds, the
+                            // forest in buckets) 3 / 6 / 12 / 24: recipe 2.78 / 2.70 / 2.60-2.69 / 2.79-2.81 ms, projection 174 / 176 / 178 / 176 it/s
 #endif
 template <int CPL>
 __global__ __launch_bounds__(256) void lap_mc_trees_kernel(JvArgs a) {

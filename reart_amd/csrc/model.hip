@@ -26,7 +26,9 @@ __device__ unsigned long long g_phase_ts[2][16];
 extern "C" int reart_debug_phase_clock(unsigned long long *out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_ts), sizeof(g_phase_ts)) == hipSuccess ? REART_OK : REART_ERR_LAUNCH;
 }
-#define PHASE_TS(which, k) do { if (blockIdx.x == 1 && threadIdx.x == 0) g_phase_ts[which][k] = __builtin_amdgcn_s_memtime(); } while (0)
+// (slots 12 / 13 of a row: the constant-rate 100 MHz wall clock next to the first / latest stamp -- the rate of s_memtime)
+#define PHASE_TS(which, k) do { if (blockIdx.x == 1 && threadIdx.x == 0) { g_phase_ts[which][k] = __builtin_amdgcn_s_memtime(); \
+    g_phase_ts[which][(k) == 0 ? 12 : 13] = wall_clock64(); } } while (0)
 #else
 #define PHASE_TS(which, k) do { } while (0)
 #endif
@@ -924,54 +926,66 @@ __device__ __forceinline__ void base_bwd_finalize_body(const BaseBwdArgs &a, con
     }
 }
 
+// 256 threads of column sums / pose gradients / Adam (base_bwd_finalize_body) + TWO MORE WAVES for the bookkeeping.
 template <bool BATCH>
-__global__ __launch_bounds__(256) void base_bwd_finalize_kernel(Batched<BaseBwdArgs> ab, Batched<FinalizeAdam> adb, Batched<StepBook> bkb) {
+__global__ __launch_bounds__(384) void base_bwd_finalize_kernel(Batched<BaseBwdArgs> ab, Batched<FinalizeAdam> adb, Batched<StepBook> bkb) {
     const BaseBwdArgs &a = ab.a[BATCH ? blockIdx.y : 0];
     const FinalizeAdam &ad = adb.a[BATCH ? blockIdx.y : 0];
     const StepBook &bk = bkb.a[BATCH ? blockIdx.y : 0];
     // Bookkeeping is done by the LAST workgroup to finish (ticket): by then every other workgroup has
-    // consumed this iteration's counters.  Every workgroup prepares it speculatively up front -- the
-    // loss partials are loaded and the next temperature / bias corrections computed while the main
-    // work's loads are in flight -- so that the winner only has to reduce and store.
+    // consumed this iteration's counters.  Every workgroup prepares it speculatively -- the loss partials
+    // are summed (fifth wave) and the next temperature / bias corrections computed (sixth wave: two double-
+    // precision pow, a sqrt, a cosine: 2.2 us on one lane) -- beside the four waves that run the main work
+    // (1.8 us), not in front of them (profiles/r05_small_kernel_clocks.txt); the winner only has to store.
     __shared__ int s_last;
-    __shared__ double s_r[4], s_f[4];
+    __shared__ double s_book[4];       // recon, flow (x lambda), bias corrections of the next step
+    __shared__ float s_tau;
+    __shared__ long s_it;
     const int tid = threadIdx.x;
-    double recon = 0.0, flow = 0.0, bc0 = 0.0, bc1 = 0.0;
-    float tau_next = 0.f;
-    long it = 0;
-    if (bk.enabled) {
-        // fixed assignment of terms to lanes + fixed-order tree: deterministic sums
-        for (int b = tid; b < bk.n_frame_part; b += 256) recon += bk.frame_loss[b];
-        for (int i = tid; i < bk.n_flow_part; i += 256) flow += bk.flow_part[i];
-        if (tid == 0) {
-            it = (long)bk.iter[0];
-            bc0 = 1.0 - pow((double)bk.beta1, (double)(it + 2));   // Adam step count of the next iteration
-            bc1 = sqrt(1.0 - pow((double)bk.beta2, (double)(it + 2)));
+#ifdef REART_PHASE_CLOCK
+    if (blockIdx.x == 1 && blockIdx.y == 0 && threadIdx.x == 0) { g_phase_ts[0][14] = __builtin_amdgcn_s_memtime(); g_phase_ts[0][8] = g_phase_ts[0][14]; }
+#endif
+    if (tid >= 320) {                  // sixth wave: the scalars of the next step (no memory but the iteration counter)
+        if (!bk.enabled) return;
+        if (tid == 320) {
+            const long it = (long)bk.iter[0];
+            s_it = it;
+            s_book[2] = 1.0 - pow((double)bk.beta1, (double)(it + 2));   // Adam step count of the next iteration
+            s_book[3] = sqrt(1.0 - pow((double)bk.beta2, (double)(it + 2)));
             // iteration i (0-based) uses tau_cosine(i+1, ...) (run_robot.py:157)
-            tau_next = bk.fixed_tau > 0.f ? bk.fixed_tau : reart_tau_schedule(it + 2, bk.n_iter, bk.end_tau, bk.start_tau);
+            s_tau = bk.fixed_tau > 0.f ? bk.fixed_tau : reart_tau_schedule(it + 2, bk.n_iter, bk.end_tau, bk.start_tau);
         }
-    }
-    base_bwd_finalize_body(a, ad);
+    } else if (tid >= 256) {           // fifth wave: the loss partials
+        if (!bk.enabled) return;
+        const int l = tid - 256;
+        // fixed assignment of terms to lanes + fixed-order tree: deterministic sums
+        double recon = 0.0, flow = 0.0;
+        for (int b = l; b < bk.n_frame_part; b += 64) recon += bk.frame_loss[b];
+        for (int i = l; i < bk.n_flow_part; i += 64) flow += bk.flow_part[i];
+        recon = reart_wave_sum_d(recon);
+        flow = reart_wave_sum_d(flow);
+        if (l == 0) { s_book[0] = recon; s_book[1] = flow * (double)bk.lambda_flow; }
+    } else base_bwd_finalize_body(a, ad);
+#ifdef REART_PHASE_CLOCK
+    if (blockIdx.x == 1 && blockIdx.y == 0 && threadIdx.x == 0) g_phase_ts[0][9] = __builtin_amdgcn_s_memtime();
+#endif
     if (!bk.enabled) return;
-    __syncthreads();   // every thread of this workgroup has read the counters it needs (values already used)
+    __syncthreads();   // every thread of this workgroup has read the counters it needs (values already used); s_book is written
     if (tid == 0) s_last = (atomicAdd(bk.ticket, 1u) == gridDim.x - 1) ? 1 : 0;
     __syncthreads();
-    if (!s_last) return;
-    recon = reart_wave_sum_d(recon);
-    flow = reart_wave_sum_d(flow);
-    if ((tid & 63) == 0) { s_r[tid >> 6] = recon; s_f[tid >> 6] = flow; }
-    __syncthreads();
-    if (tid != 0) return;
-    recon = (s_r[0] + s_r[1]) + (s_r[2] + s_r[3]);
-    flow = ((s_f[0] + s_f[1]) + (s_f[2] + s_f[3])) * (double)bk.lambda_flow;
+#ifdef REART_PHASE_CLOCK
+    if (blockIdx.x == 1 && blockIdx.y == 0 && threadIdx.x == 0) g_phase_ts[0][10] = __builtin_amdgcn_s_memtime();   // after the ticket's round trip
+#endif
+    if (!s_last || tid != 0) return;
+    const long it = s_it;
     if (bk.losses && bk.ring > 0) {
         float *row = bk.losses + 4 * (size_t)(it % bk.ring);
-        row[0] = (float)recon; row[1] = (float)flow; row[2] = (float)(recon + flow); row[3] = bk.tau[0];
+        row[0] = (float)s_book[0]; row[1] = (float)s_book[1]; row[2] = (float)(s_book[0] + s_book[1]); row[3] = bk.tau[0];
     }
     bk.iter[0] = it + 1;
-    bk.bias_corr[0] = bc0;
-    bk.bias_corr[1] = bc1;
-    bk.tau[0] = tau_next;
+    bk.bias_corr[0] = s_book[2];
+    bk.bias_corr[1] = s_book[3];
+    bk.tau[0] = s_tau;
     *bk.ticket = 0u;
 }
 
@@ -1048,8 +1062,8 @@ int reart_base_backward_batch(const BaseBwdArgs *args, const FinalizeAdam *adam,
     // weights: one thread per entry; poses: 16 lanes per (frame, part); nW is rounded up to a multiple of 64
     // inside the kernel's indexing so that a 16-lane group never straddles a wave
     const int nfin = (int)reart_align_up((size_t)4 * (a0.P * a0.H + 4 * a0.H), 64) + 64 * a0.B * a0.P;
-    if (K == 1) hipLaunchKernelGGL(base_bwd_finalize_kernel<false>, dim3(reart_div_up(nfin, 256)), dim3(256), 0, st, reart_batched(ak, 1), adb, bkb);
-    else hipLaunchKernelGGL(base_bwd_finalize_kernel<true>, dim3(reart_div_up(nfin, 256), K), dim3(256), 0, st, reart_batched(ak, K), adb, bkb);
+    if (K == 1) hipLaunchKernelGGL(base_bwd_finalize_kernel<false>, dim3(reart_div_up(nfin, 256)), dim3(384), 0, st, reart_batched(ak, 1), adb, bkb);
+    else hipLaunchKernelGGL(base_bwd_finalize_kernel<true>, dim3(reart_div_up(nfin, 256), K), dim3(384), 0, st, reart_batched(ak, K), adb, bkb);
     REART_CHECK_LAUNCH();
     return REART_OK;
 }

@@ -45,6 +45,10 @@ static size_t take(size_t &off, size_t bytes) {
 
 #define FLOW_BS 256    // stand-alone flow_blend_kernel; inside post_kernel the blend uses CG_BS threads
 #define CG_BS 1024
+// points (= live threads) of a flow-blend workgroup inside post_kernel.  Same-box A/B of the headline (tools/ab_headline.sh),
+// 1024 / 512 / 256: 12 560 / 12 950 / 12 520 it/s -- at 256 the blend workgroup lives 6.1 us instead of 10, but the 304 of them
+// delay the Chamfer-gradient workgroups dispatched behind them (7.1 -> 8.3 us); dispatching those first changes nothing at 512.
+#define POST_FBS 512
 #define CG_RANGE 1024   // targets x_j owned by one workgroup of chamfer_grad_kernel
 static_assert(CG_BS == CG_RANGE, "chamfer_grad_kernel: thread tid owns target r0 + tid");
 
@@ -637,14 +641,37 @@ __device__ __forceinline__ void prof_body(const OrderArgs &o) {
     }
 }
 struct PostArgs { FlowArgs fl; CGradArgs cg; OrderArgs od; int nfx, nflow, ncx, nwork, norder; };
+#ifdef REART_PHASE_CLOCK   // diagnostic build only (make stats; tools/phase_clock.py): lifetimes of one workgroup of every kind
+__device__ unsigned long long g_post_ts[8];      // flow blend | Chamfer gradient | launch order | profile: (start, end) each
+extern "C" int reart_debug_post_clock(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_post_ts), sizeof(g_post_ts)) == hipSuccess ? REART_OK : REART_ERR_LAUNCH;
+}
+#define POST_TS(k) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.y == 0) g_post_ts[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define POST_TS(k) do { } while (0)
+#endif
 template <bool ONE, bool BATCH>
 __global__ __launch_bounds__(CG_BS) void post_kernel(Batched<PostArgs> ab) {
     const PostArgs &a = ab.a[BATCH ? blockIdx.y : 0];
     const int w = blockIdx.x;
-    if (w < a.nflow) flow_blend_body<ONE, CG_BS>(a.fl, w % a.nfx, w / a.nfx, a.nfx);
-    else if (w < a.nwork) chamfer_grad_body<ONE>(a.cg, (w - a.nflow) % a.ncx, (w - a.nflow) / a.ncx, a.ncx);
-    else if (w < a.nwork + a.norder) order_body(a.od, w - a.nwork);
-    else prof_body(a.od);
+    if (w < a.nflow) {
+        if (threadIdx.x >= POST_FBS) return;
+        if (w == 1) POST_TS(0);
+        flow_blend_body<ONE, POST_FBS>(a.fl, w % a.nfx, w / a.nfx, a.nfx);
+        if (w == 1) POST_TS(1);
+    } else if (w < a.nwork) {
+        if (w == a.nflow + 1) POST_TS(2);
+        chamfer_grad_body<ONE>(a.cg, (w - a.nflow) % a.ncx, (w - a.nflow) / a.ncx, a.ncx);
+        if (w == a.nflow + 1) POST_TS(3);
+    } else if (w < a.nwork + a.norder) {
+        if (w == a.nwork) POST_TS(4);
+        order_body(a.od, w - a.nwork);
+        if (w == a.nwork) POST_TS(5);
+    } else {
+        POST_TS(6);
+        prof_body(a.od);
+        POST_TS(7);
+    }
 }
 
 // ------------------------------------------------------------------------------ assignment loss
@@ -847,7 +874,11 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
         fl.smooth = c.smooth_weight; fl.lambda = c.lambda_flow;
         fl.gpf = (float *)(ws + p.o_gpf); fl.part = (double *)(ws + p.o_fpart);
         fl.seed_out = p.pruned ? (int *)(ws + p.o_seed3) : nullptr;
-        const dim3 fg(reart_div_up(N, merged ? CG_BS : FLOW_BS), B);
+        // merged consumers (post_kernel, workgroups of CG_BS threads): a blend workgroup covers POST_FBS points with its first
+        // POST_FBS threads (the other waves leave at once: the hardware barrier counts live waves only) -- the blend is a chain
+        // of gathers, 16 waves of them on ONE compute unit queue up behind its one address unit; four times the workgroups of
+        // four waves spread them over four times the compute units
+        const dim3 fg(reart_div_up(N, merged ? POST_FBS : FLOW_BS), B);
         nfp = fg.x * fg.y;
         if (!merged && collect) {
             if (fl.S > 4) return REART_ERR_UNSUPPORTED;
@@ -905,7 +936,7 @@ static int relax_step_impl(const reart_relax_config *cfg, const reart_relax_buff
         const int ncg = reart_div_up(N, CG_RANGE);
         if (merged) {
             PostArgs pa = {};
-            pa.fl = fl; pa.cg = cg; pa.nfx = reart_div_up(N, CG_BS); pa.nflow = pa.nfx * B; pa.ncx = ncg;
+            pa.fl = fl; pa.cg = cg; pa.nfx = reart_div_up(N, POST_FBS); pa.nflow = pa.nfx * B; pa.ncx = ncg;
             pa.nwork = pa.nflow + ncg * B;
             const bool reorder = c.tune_reorder >= 0 && !search_static_order;
             for (int j = 0; j < 3; ++j) {

@@ -80,6 +80,7 @@ class KinematicEngine:
         self.pc_trans = torch.empty((self.B, self.N, 3), dtype=torch.float32, device=self.dev)
         self.G = torch.zeros((self.B, self.N, 3), dtype=torch.float32, device=self.dev)
         self.losses = {}
+        self._pc_src, self._inplace, self._g_pre, self._g_post = None, None, None, None
 
     # ---- pieces -----------------------------------------------------------------------------------------------------
     def _joint_values(self):
@@ -159,38 +160,50 @@ class KinematicEngine:
         return loss * self.lambda_flow
 
     # ---- the iteration ----------------------------------------------------------------------------------------------
-    @torch.no_grad()
-    def iteration(self, i):
-        """Iteration i of run_robot.py:154-221 in the assignment-loss branch; returns the loss dictionary (device tensors)."""
-        from .utils.lap import linear_sum_assignment_points
+    GRAPHS = True       # replay the launches around the solve from two captured graphs (False: every launch eagerly)
 
-        if i < self.assign_iter:
-            raise NotImplementedError("the Chamfer branch of the kinematic loop runs through OperatorLoop")
+    def _solve(self, pc_src):
+        """The assignment refresh (run_robot.py:165-178) -> the solver's [B,4] statistics; the optimum is in lap_state["cols"]."""
+        from .utils import lap
+
+        B, n = pc_src.shape[:2]
+        if lap.InPlaceResolve.usable(self.lap_state, B, n):
+            if self._inplace is None:
+                self._inplace = lap.InPlaceResolve(B, n, self.dev)
+            fb, raw = self._inplace(pc_src, self.tgt_pts, self.lap_state, stats=True)
+            st = raw.copy()
+            self.lap_state["commit_conflicts"] = (st[:, 1] >> 16) & 0xffff
+            st[:, 1] &= 0xffff
+            self.lap_state["backward_rounds"] = (st[:, 0] >> 21) & 0x3ff
+            st[:, 0] &= 0x1fffff
+            self.lap_state["winner"] = (st[:, 0] >> 16) & 31
+        else:       # the first solve (cold), sizes outside the chain forms: the general entry (its columns are a new tensor)
+            _, fb, st = lap.linear_sum_assignment_points(pc_src.contiguous(), self.tgt_pts, self.lap_state, return_stats="full", device_cols=True)
+            self._g_post = None                     # a graph that reads the columns must see the new tensor
+        self.lap_solves += 1
+        self.lap_fallbacks += fb
+        self.lap_stats = st
+        # sequential steps of this solve per problem (slowest, mean) and the slowest problem's search steps alone -- the latency
+        # roofline of bench.py multiplies them by the measured floor of one step
+        seq = st[:, 2].astype(np.int64)
+        search_only = int(seq.max())
+        if self.lap_state.get("resolve_form", "jv") == "jv":           # one row at a time: the row reduction's steps are sequential too
+            seq = seq + (st[:, 3].astype(np.int64) >> 8)
+        elif self.lap_state.get("backward_rounds") is not None:        # the backward growth before the searches: the same kind of step
+            seq = seq + np.asarray(self.lap_state["backward_rounds"], dtype=np.int64)
+        self.lap_steps_log.append((int(seq.max()), float(seq.mean()), search_only))
+        self.lap_winners += np.bincount((st[:, 0] >> 16) & 31, minlength=32)[:32]                  # raced re-solves: who finished first
+
+    def _pre(self):
+        """Forward of the current parameters and the sampled source points (the solver's input)."""
         self.forward()
-        pc_src = self.pc_trans[:, self.src_idx]                                                   # [B,n,3]
-        if self.matched is None or i % self.assign_gap == 0:                                      # run_robot.py:165-178
-            if self.lap_events is not None:
-                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                ev[0].record()
-            cols, fb, self.lap_stats = linear_sum_assignment_points(pc_src, self.tgt_pts, self.lap_state, return_stats="full",
-                                                                    device_cols=True)      # the columns never leave the device
-            self.lap_solves += 1
-            self.lap_fallbacks += fb
-            # sequential steps of this solve (path search + row reduction) per problem: slowest problem, mean -- the
-            # latency roofline of bench.py multiplies them by the measured floor of one step
-            seq = self.lap_stats[:, 2].astype(np.int64)
-            search_only = int(seq.max())
-            if self.lap_state.get("resolve_form", "jv") == "jv":       # one row at a time: the row reduction's steps are sequential too
-                seq = seq + (self.lap_stats[:, 3].astype(np.int64) >> 8)
-            elif self.lap_state.get("backward_rounds") is not None:    # the backward growth before the searches: the same kind of step
-                seq = seq + np.asarray(self.lap_state["backward_rounds"], dtype=np.int64)
-            self.lap_steps_log.append((int(seq.max()), float(seq.mean()), search_only))
-            self.lap_winners += np.bincount((self.lap_stats[:, 0] >> 16) & 31, minlength=32)[:32]         # raced re-solves: who finished first
-            self.matched = self.tgt_pts.gather(1, cols[..., None].expand(-1, -1, 3))
-            if self.lap_events is not None:
-                ev[1].record()
-                self.lap_events.append(ev)
-        diff = pc_src - self.matched
+        self._pc_src.copy_(self.pc_trans[:, self.src_idx])
+
+    def _post(self):
+        """Everything between the solve and Adam: matched targets, assignment (+ flow) loss, dL/d pc_trans, the FK backward."""
+        cols = self.lap_state["cols"].long()
+        self.matched = self.tgt_pts.gather(1, cols[..., None].expand(-1, -1, 3))
+        diff = self._pc_src - self.matched
         ass = self.lambda_assign * (diff * diff).sum()                                            # run_robot.py:181-184
         self.G.zero_()
         self.G[:, self.src_idx] = (2.0 * self.lambda_assign) * diff
@@ -202,6 +215,46 @@ class KinematicEngine:
             total = total + fl
         losses["total Loss"] = total
         self._backward()
-        self._adam()
         self.losses = losses
-        return losses
+
+    @staticmethod
+    def _graph(fn):
+        fn()                                        # warm-up outside the capture (lazy loads, workspace growth)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            fn()
+        return g
+
+    @torch.no_grad()
+    def iteration(self, i):
+        """Iteration i of run_robot.py:154-221 in the assignment-loss branch; returns the loss dictionary (device tensors).
+        From the third iteration on the launches before and after the solve replay from two captured graphs (the solve itself
+        and Adam, whose step count is a host value, stay eager): same launches, same results, a tenth of the host work."""
+        if i < self.assign_iter:
+            raise NotImplementedError("the Chamfer branch of the kinematic loop runs through OperatorLoop")
+        if self._pc_src is None:
+            self._pc_src = torch.empty((self.B, self.src_idx.numel(), 3), dtype=torch.float32, device=self.dev)
+        if self._g_pre is not None:
+            self._g_pre.replay()
+        else:
+            self._pre()
+            if self.GRAPHS and self.lap_solves >= 2:
+                self._g_pre = self._graph(self._pre)                      # (the warm-up inside recomputes the same forward)
+        if self.lap_state.get("cols") is None or i % self.assign_gap == 0:                       # run_robot.py:165-178
+            if self.lap_events is not None:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
+            self._solve(self._pc_src)
+            if self.lap_events is not None:
+                ev[1].record()
+                self.lap_events.append(ev)
+        if self._g_post is not None:
+            self._g_post.replay()
+        elif self.GRAPHS and self.lap_solves >= 2 and self._inplace is not None:
+            self._g_post = self._graph(self._post)                        # (warm-up + capture; the replay below does the work once more:
+            self._g_post.replay()                                         #  _post only writes buffers it fully overwrites)
+        else:
+            self._post()
+        self._adam()
+        return self.losses

@@ -271,3 +271,52 @@ def linear_sum_assignment_points(src, tgt, state, return_stats=False, race=True,
             state["winner"] = (st[:, 0] >> 16) & 31          # the racer that published (bits 16-20 of word 0; released rows below)
         return (state["cols"].long() if device_cols else out), fallbacks, st
     return (out, fallbacks) if return_stats else out
+
+
+class InPlaceResolve:
+    """The re-solve of a loop that keeps its problems on the device (run_robot.py:164-187 with the pairs fed straight back to
+    the GPU): ``state["cols"]`` (int32 [B,n]) and ``state["prices"]`` (f64 [B,n]) of an earlier solve are re-solved IN PLACE
+    for new source points (``reart_lap_resolve_points_mc``), so that launches which read them -- a captured graph included --
+    see the new optimum at the same addresses.  The host waits for the B certificate flags (and, on request, the B x 4
+    statistics words) and nothing else; an uncertified problem goes to scipy like everywhere.  ``usable(state, B, n)`` says
+    whether the state qualifies (a first call has to go through ``linear_sum_assignment_points``)."""
+
+    def __init__(self, B, n, device):
+        self.B, self.n, self.device = B, n, device
+        self.cert = torch.zeros((B,), dtype=torch.int32, device=device)
+        self.cert_host = torch.zeros((B,), dtype=torch.int32).pin_memory()
+        self.stats_host = torch.zeros((4 * B,), dtype=torch.int32).pin_memory()
+
+    @staticmethod
+    def usable(state, B, n):
+        return (RESOLVE_PER_WAVE and MW_NMIN <= n <= MW_NMAX and _arr_wgs(B) > 0 and state.get("cols") is not None
+                and state.get("prices") is not None and state["cols"].dtype == torch.int32 and tuple(state["cols"].shape) == (B, n)
+                and tuple(state["prices"].shape) == (B, n))
+
+    def __call__(self, src, tgt, state, stats=False):
+        """-> (host fallbacks, [B,4] int32 numpy statistics as the kernel wrote them or None)"""
+        L, B, n = _lib.lib(), self.B, self.n
+        racers, arr = _resolve_racers(B, n), min(_arr_wgs(B), 256)
+        stream = _lib.stream()
+        self.cert.zero_()
+        ws = _lib.workspace(L.reart_lap_mc_workspace_bytes(B, n, racers), self.device)
+        cols, prices = state["cols"], state["prices"]
+        off = ((8 * B * n + 255) // 256) * 256                            # the solver's statistics: [B][4] ints behind the potentials
+        if stats:
+            ws[off:off + 16 * B].zero_()
+        _lib.check(L.reart_lap_resolve_points_mc(_lib.ptr(src), _lib.ptr(tgt), B, n, racers, arr, _lib.ptr(cols), _lib.ptr(self.cert),
+                                                 _lib.ptr(prices), _lib.ptr(prices), _lib.ptr(ws), ws.numel(), stream),
+                   "reart_lap_resolve_points_mc")
+        state["resolve_form"] = "mc"
+        self.cert_host.copy_(self.cert, non_blocking=True)
+        if stats:
+            self.stats_host.copy_(ws[off:off + 16 * B].view(torch.int32), non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        fb = 0
+        for b in (self.cert_host == 0).nonzero().flatten().tolist():      # certificate did not close: exact host solve
+            from scipy.optimize import linear_sum_assignment
+
+            fb += 1
+            host = linear_sum_assignment(cdist(src[b:b + 1], tgt[b:b + 1])[0].cpu().numpy())[1]
+            _forget_uncertified(state, cols, b, host)
+        return fb, (self.stats_host.numpy().reshape(B, 4).copy() if stats else None)

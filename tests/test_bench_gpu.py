@@ -29,7 +29,44 @@ def test_headline_line_contract(dev):
     assert c["frames"] == 20 and c["points"] == 4096 and c["flow"] is True and c["eager_steps"] == 0 and c["graph_replays"] >= 1
     r = d["roofline"]
     assert r["bound"] == "valu" and 0 < r["frac"] < 1 and r["kernel_ms"] < d["ms_per_step"]
-    assert r["algorithmic"]["frac"] > r["frac"] and r["hbm"]["frac"] < 0.2 and r["executed_pairs_per_launch"] < r["algorithmic_pairs_per_launch"]
+    assert r["algorithmic_frac"] > r["frac"] and r["hbm_frac"] < 0.2 and r["executed_pairs_per_launch"] < r["algorithmic_pairs_per_launch"]
+    assert r["traffic"] is None or isinstance(r["traffic"], (int, float))        # a number of bytes (or null), as the contract says
+
+
+def _strings(x, path=""):
+    if isinstance(x, dict):
+        for k, v in x.items():
+            yield from _strings(v, f"{path}.{k}")
+    elif isinstance(x, list):
+        for i, v in enumerate(x):
+            yield from _strings(v, f"{path}[{i}]")
+    elif isinstance(x, str):
+        yield path, x
+
+
+def test_default_line_fits_the_drivers_record(dev):
+    """`python bench.py` with every leg (short windows): ONE line of at most 5 KB -- numbers and labels of at most 80
+    characters, no prose -- so that the tail the driver stores holds secondary.*.value, sweep.per_gpu, end_of_run, rccl_world
+    and ranks (VERDICT r04 #6); per-solve percentiles and the bounded sample of the README.md:125 projection are in it."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "100", "--warmup", "150"], capture_output=True, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1
+    assert len(lines[0]) <= 5 * 1024, len(lines[0])
+    d = json.loads(lines[0])
+    long_ = [(p_, len(s_)) for p_, s_ in _strings(d) if len(s_) > 80]
+    assert not long_, long_
+    assert d["rccl_world"] == 1 and d["ranks"][0]["rank"] == 0 and d["sweep"]["per_gpu"] > 0 and "energy_ms" in d["end_of_run"]
+    sec = d["secondary"]
+    for name in ("kinematic", "extractor", "nao", "nao_recipe", "nao_projection"):
+        assert "error" not in sec[name], sec[name]
+        assert sec[name]["value"] > 0
+    for name in ("kinematic", "nao_recipe", "nao_projection"):
+        rf = sec[name]["roofline"]
+        assert rf["solve_ms_p50"] <= rf["solve_ms_p95"] <= rf["solve_ms_max"] and sec[name]["lap_fallbacks"] == 0
+    assert 0 < sec["nao_recipe"]["roofline"]["frac_search_only"] <= sec["nao_recipe"]["roofline"]["frac"] < 1
+    assert sec["nao_recipe"]["snapshots"] == 150 and sec["nao_projection"]["snapshots"] == 151
+    assert len(sec["nao_projection"]["iterations_per_s_by_window"]) == 3
 
 
 def test_nao_config_line(dev):

@@ -121,3 +121,36 @@ def test_config5_literal_against_the_oracle_loop(oracle, dev):
     assert sum(int(m.sum()) for m in solid) >= 0.3 * sum(m.size for m in solid)
     assert eng.lap_solves == orc.lap_solves == 3
     assert eng.lap_fallbacks == 0                                     # the permutations above are the GPU solver's own
+
+
+def test_graph_replays_equal_the_eager_iterations(dev):
+    """From its third iteration on KinematicEngine replays the launches around the solve from two captured graphs and re-solves
+    the assignments in place: ten iterations of the README.md:125 configuration (downsample 2, assign_gap 1, flow loss) with
+    and without the graphs end in the same parameters, losses and assignments, bit for bit, with no host fallback."""
+    from reart_amd.kinematic_engine import KinematicEngine
+
+    k = np.load(os.path.join(G, "kinematic.npz"))
+    cano = t(k["cano_pc"], dev)
+    rng = np.random.default_rng(5)
+    B, N = 9, cano.shape[0]
+    with torch.no_grad():
+        pcs = _model(dev, k, cano)(cano)[0]
+    pcs = (pcs + t(rng.normal(0, 0.004, (B, N, 3)).astype(np.float32), dev)).contiguous()
+    pcs = torch.stack([p[torch.from_numpy(rng.permutation(N)).to(dev)] for p in pcs])
+    comp = torch.cat((pcs[:2], cano[None], pcs[2:]), dim=0)
+    sel = [torch.from_numpy(rng.permutation(N)[:300 + 7 * f]).to(dev) for f in range(B)]
+    refs = [comp[f][s] for f, s in enumerate(sel)]
+    flows = [(comp[f + 1][s] - comp[f][s]) * 0.5 for f, s in enumerate(sel)]
+    outs = []
+    for graphs in (True, False):
+        m = _model(dev, k, cano)
+        eng = KinematicEngine(m, cano, pcs, 2, refs, flows, assign_iter=0, assign_gap=1, downsample=2)
+        eng.GRAPHS = graphs
+        for i in range(10):
+            losses = eng.iteration(i)
+        assert eng.lap_solves == 10 and eng.lap_fallbacks == 0
+        assert (eng._g_pre is not None and eng._g_post is not None) == graphs
+        outs.append([getattr(m, n_).detach().clone() for n_ in ("axis_list", "moment_list", "theta_list")]
+                    + [eng.lap_state["cols"].clone(), eng.matched.clone()] + [losses[key].clone() for key in sorted(losses)])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
