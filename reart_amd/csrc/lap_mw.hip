@@ -23,38 +23,20 @@
 #include "internal.h"
 #include "lap_dev.h"
 
-#ifndef MW_NW
 #define MW_NW 8              // waves per workgroup = searches in flight per problem (two per SIMD: 256 VGPRs each)
-#endif
 // row-reduction steps allowed per free row before the rest goes to the path searches.  A chain step here costs a third of a
 // search step (0.4 us against 1.3-1.5 us), so the budget is four times the one-row-at-a-time solver's: measured per refresh of
 // the base recipe (9 x 1024^2, raced), budget 8 / 16 / 32 / 64: 10.5 / 10.1 / 9.7 / 10.7 ms -- rows left 50-100 / 15-55 / 5-25 /
 // 2-13, of which the last few need searches of hundreds of steps whatever the budget.
-#ifndef MW_ARR_BUDGET
 #define MW_ARR_BUDGET 32
-#endif
-#ifndef MW_TIGHTEN
-#define MW_TIGHTEN 1         // lower the unowned columns' prices to the matched rows' potentials before the path searches
-#endif
-#ifndef MW_TIGHTEN_ARR
-#define MW_TIGHTEN_ARR 1     // ... and before the row reduction on many compute units (lap_mc_tighten_kernel)
-#endif
 #define MW_CHECK 16          // a search looks at the race flag and at its labelled columns every MW_CHECK steps
 // A search that has not met a sink after MW_BUCKET_AFTER one-column steps goes on in BUCKETS (see the search loop): all
 // unlabelled columns within `width` of the closest one are settled together by label-correcting rounds.
-#ifndef MW_BUCKET_AFTER
 #define MW_BUCKET_AFTER 48
-#endif
-#ifndef MW_BUCKET_W0
 #define MW_BUCKET_W0 1e-8    // first bucket width of a problem, as a fraction of the cost scale
-#endif
 #define MW_BK 192            // columns relaxed from per round (the rest of a bucket waits for the next round); 12 KB of lists: two 1024-column workgroups per compute unit
-#ifndef MW_BUCKET_LO
 #define MW_BUCKET_LO 8       // a bucket that closes with fewer columns than this widens the next one fourfold ...
-#endif
-#ifndef MW_BUCKET_HI
 #define MW_BUCKET_HI 48      // ... with more than this, halves it
-#endif
 
 #ifdef REART_PRUNE_PHASE   // diagnostic build only (make -C reart_amd/csrc phase; tools/exp_mw.py)
 // per workgroup (first 64): 0 set-up | 1 row-reduction phase | 2 path-search phase (wall ticks of wave 0) | 3, 4 ticks the waves
@@ -397,7 +379,6 @@ __global__ __launch_bounds__(64 * NW) void lap_jvmw_kernel(JvArgs a) {
         if (i >= 0) hcol[j] = (double)mw_sqrt(reart_sqdist3(psx[i], psy[i], psz[i], qx[k], qy[k], qz[k])) + pj[k];
     }
     int *cpred = flist;                                   // the free-row list is spent: column -> row it was reached from
-#if MW_TIGHTEN
     // ---- the unowned columns' prices.  A column a released row left keeps the price it had: tight for a pair that no longer
     // exists.  Nothing constrains an unowned column's price from below except the matched rows' potentials (row i must not
     // prefer it to its own column: c_ij + p_j >= u_i), so it is lowered until the first matched row is indifferent -- p_j -=
@@ -440,7 +421,6 @@ __global__ __launch_bounds__(64 * NW) void lap_jvmw_kernel(JvArgs a) {
             if (j < n) pj[k] = price[j];
         }
     }
-#endif
     // (Also measured: rounds that settle several columns -- every wave's closest column a candidate, candidates relaxed from
     // ahead of their turn, the sorted ready prefix settled together, profiles/r04_lap_speculative_rounds_variant.hip.txt.
     // Exact, 1.6 columns per round, but a round cost 2.6 us against 1.27 us per step: the step is bound by the instructions
@@ -458,7 +438,7 @@ __global__ __launch_bounds__(64 * NW) void lap_jvmw_kernel(JvArgs a) {
     __shared__ int s_bj[2][NW], s_bsj[2][NW], s_bn[2][NW], s_blost[2];
     if (tid == 0) { s_lostp[0] = 0; s_lostp[1] = 0; s_ecnt[0] = 0; s_ecnt[1] = 0; s_ecnt[2] = 0; }
     double bwidth = mx * MW_BUCKET_W0;                    // bucket width, carried from search to search
-#ifdef MW_BUCKET_STATS
+#ifdef REART_PRUNE_PHASE
     int my_relax = 0, my_rounds = 0, my_buckets = 0;     // diagnostic build: columns relaxed from / rounds / buckets, reported in place of the commit conflicts and reduction steps
 #endif
     int brot = 0, bpar = 0;                               // rotating slot of the list length / parity of the closing reductions
@@ -508,11 +488,7 @@ __global__ __launch_bounds__(64 * NW) void lap_jvmw_kernel(JvArgs a) {
             const int jstar = bj & ~JV_OWNED;
             if ((jstar & (BS - 1)) == tid) scanned |= 1u << (jstar / BS);
             const int i = owner[jstar];
-#ifdef MW_TREE_IGNORE
-            if (i < 0) { sink = jstar; break; }
-#else
-            if (i < 0 || tof[jstar] >= 0) { sink = jstar; break; }
-#endif     // unowned, or a node of a tree that leads to an unowned column at no cost
+            if (i < 0 || tof[jstar] >= 0) { sink = jstar; break; }     // unowned, or a node of a tree that leads to an unowned column at no cost
             const float ax = psx[i], ay = psy[i], az = psz[i];
             const double h = hcol[jstar];                                  // row i's potential
 #ifdef REART_PRUNE_PHASE
@@ -604,7 +580,7 @@ __global__ __launch_bounds__(64 * NW) void lap_jvmw_kernel(JvArgs a) {
                     if (ne == 0) break;                    // uniform: nobody had anything left to relax from
                     ne = ne < MW_BK ? ne : MW_BK;
                     ++my_steps;
-#ifdef MW_BUCKET_STATS
+#ifdef REART_PRUNE_PHASE
                     my_relax += ne; ++my_rounds;
 #endif
                     for (int e = 0; e < ne; ++e) {
@@ -669,7 +645,7 @@ __global__ __launch_bounds__(64 * NW) void lap_jvmw_kernel(JvArgs a) {
                 nnew = mw_uniform(nnew);
                 bpar ^= 1;
                 ++my_steps;
-#ifdef MW_BUCKET_STATS
+#ifdef REART_PRUNE_PHASE
                 ++my_buckets;
 #endif
                 if (sj != 0x7fffffff && sv < INFINITY) { mu = sv; sink = sj & ~JV_OWNED; break; }
@@ -734,7 +710,7 @@ __global__ __launch_bounds__(64 * NW) void lap_jvmw_kernel(JvArgs a) {
     if (tid == 0 && unsolved) sh.unsolved = 1;
     if (wv != 0) my_steps = 0;                             // every wave counted the same steps
     MWP_ADD(4, MWP_NOW() - tp_);
-#ifdef MW_BUCKET_STATS
+#ifdef REART_PRUNE_PHASE
     if (tid == 0) { sh.conflicts = min(my_relax >> 4, 0xffff); sh.arr = (my_rounds & 0xfff) | (min(my_buckets, 0xfff) << 12); }
     __syncthreads();
     my_arr = 0; my_conf = 0;
@@ -777,9 +753,7 @@ __global__ __launch_bounds__(64 * NW) void lap_jvmw_kernel(JvArgs a) {
 // the launch lasts as long as its longest chain is allowed to.  Measured, chains of 256 / 128 / 64 steps: README recipe
 // (9 x 1024^2) 12.1 / 11.2 s / - for the whole run, kinematic projection (19 x 2048^2) 62.5 / 64.9 / 64.4 iterations/s; on 8
 // workgroups per problem (13, 16 or 28: no better -- more commits collide).  JvArgs.mc_chain overrides.
-#ifndef MW_MC_CHAIN
 #define MW_MC_CHAIN 128
-#endif
 
 // Between the set-up and the row reduction: every unowned column's price is lowered until the first MATCHED row is indifferent
 // between it and its own column (the step the searches' part of lap_jvmw_kernel explains; here for all the columns the
@@ -836,10 +810,8 @@ __global__ __launch_bounds__(64 * MW_NW) void lap_mc_tighten_kernel(JvArgs a) {
 // The searches (lap_jvmw_kernel<., 2>) end at the first labelled column that belongs to a live tree and walk down its parent
 // links: the path to an unowned column is known and costs nothing.  Without trees a search labels every column cheaper than the
 // last hop to ONE particular row (in a graph whose reduced costs are nearly all within rounding of zero: hundreds).
-#ifndef MW_TREE_K
 #define MW_TREE_K 12        // round 4 (one-column searches) measured 6 / 12 / 24 / 40: recipe 3.71 / 3.59 / 3.56 / 3.59 ms per refresh; round 5 (bucket rounds, the
                             // forest in buckets) 3 / 6 / 12 / 24: recipe 2.78 / 2.70 / 2.60-2.69 / 2.79-2.81 ms, projection 174 / 176 / 178 / 176 it/s
-#endif
 template <int CPL>
 __global__ __launch_bounds__(256) void lap_mc_trees_kernel(JvArgs a) {
     static_assert(MW_TREE_K < 63, "a tree's nodes live one per lane");
@@ -946,12 +918,7 @@ __global__ __launch_bounds__(256) void lap_mc_trees_kernel(JvArgs a) {
 // and inherits that column's ROOT (a search that reaches it walks to that unowned column; the root is what a search uses up).
 // One workgroup per problem: a thread owns the rows of its columns (M_i = min over the forest of c_it + q_t and the column
 // that attains it in registers), a round is one workgroup arg-min + one distance per row.  MW_FOREST_R rounds.
-#ifndef MW_FOREST_MIN
-#define MW_FOREST_MIN 64
-#endif
-#ifndef MW_FOREST_R
 #define MW_FOREST_R 512       // measured 0 / 48 / 128 / 256 / 512 / 1024: recipe 3.57 / 3.58 / 3.51 / 3.37 / 3.33 / 3.70 ms per refresh, projection 78.8 / 77.9 / 80.4 / 82.4 / 86.7 / 86.8 it/s
-#endif
 template <int CPL>
 __global__ __launch_bounds__(512) void lap_mc_forest_kernel(JvArgs a) {
     constexpr int BS = 512, NW = 8, CPT = CPL / NW >= 1 ? CPL / NW : 1;
@@ -1009,12 +976,7 @@ __global__ __launch_bounds__(512) void lap_mc_forest_kernel(JvArgs a) {
     }
     double off = 0.0;
     int nf = nf0;
-#ifdef MW_FOREST_K
-    // rows follow the problem: MW_FOREST_K per row left for the searches, within [MW_FOREST_MIN, MW_FOREST_R]
-    const int rounds = min(MW_FOREST_R, max(MW_FOREST_MIN, MW_FOREST_K * cnt[2]));
-#else
-    const int rounds = MW_FOREST_R;
-#endif
+    const int rounds = MW_FOREST_R;     // rows the growth stops after (measured per-problem targets, 16 / 32 / 64 per row left: no better)
     // The growth is a shortest-path computation like the searches' (the label of an outside row: L_i = M_i - u_i, the shift
     // at which it becomes tight to the forest; a row that joins at shift o offers its column at q + o to everybody else) and
     // runs in BUCKETS like them: all outside rows with a label below (closest label) + width join together, label-correcting
@@ -1409,29 +1371,22 @@ static int mc_launch(const JvArgs &a, int racers, int arr_wgs, hipStream_t strea
     if (s2.mc_chain <= 0) s2.mc_chain = MW_MC_CHAIN;
     hipLaunchKernelGGL((lap_jvmw_kernel<CPL, 1>), dim3(a.B), dim3(64 * MW_NW), lds, stream, s1);
     REART_CHECK_LAUNCH();
-#if MW_TIGHTEN_ARR
     hipLaunchKernelGGL((lap_mc_tighten_kernel<CPL>), dim3(arr_wgs, a.B), dim3(64 * MW_NW), 0, stream, s2);
     REART_CHECK_LAUNCH();
-#endif
     // a chain step is ~1 000 instructions of ONE wave (CPL square roots, the fp64 top-2, the wave merge) and no waiting worth the
     // name: two waves on a SIMD halve each other.  Where the chip has room the same chains run as twice the workgroups of half
     // the waves -- a SIMD each.
     const int split = (2 * arr_wgs * a.B <= 256) ? 2 : 1;
-#ifndef MW_ARR_TEAM
-#define MW_ARR_TEAM 4        // waves per chain from 16 columns per lane on (0: a wave per chain everywhere)
-#endif
-    if (MW_ARR_TEAM > 0 && CPL >= 16) {
-        // as many chains in flight per problem as the wave-per-chain form has (arr_wgs x 8), each a workgroup of its own
-        constexpr int TW = MW_ARR_TEAM > 0 ? MW_ARR_TEAM : 1;
+    if (CPL >= 16) {
+        // from 16 columns per lane on a TEAM of four waves per chain (measured 2 / 4 / 8: the projection's median re-solve 2.29 /
+        // 2.12 / 2.14 ms against 2.73 with a wave per chain); arr_wgs x 8 chains in flight per problem, each a workgroup of its own
+        constexpr int TW = 4;
         hipLaunchKernelGGL((lap_mc_arr_team_kernel<(CPL >= 16 ? CPL : 16), TW>), dim3(arr_wgs * MW_NW, a.B), dim3(64 * TW), 0, stream, s2);
     } else
         hipLaunchKernelGGL((lap_mc_arr_kernel<CPL>), dim3(arr_wgs * split, a.B), dim3(64 * MW_NW / split), 0, stream, s2);
     REART_CHECK_LAUNCH();
-#if MW_TREE_K > 0
     hipLaunchKernelGGL((lap_mc_trees_kernel<CPL>), dim3(a.B * 8 <= 256 ? 8 : 4, a.B), dim3(256), 0, stream, s2);
     REART_CHECK_LAUNCH();
-#endif
-#if MW_FOREST_R > 0
     {
         const size_t flds = (size_t)a.n * (8 + 8 + 4 + 4 + 4 + 12);
         if (flds > REART_LDS_DEFAULT_CAP &&
@@ -1440,13 +1395,7 @@ static int mc_launch(const JvArgs &a, int racers, int arr_wgs, hipStream_t strea
         hipLaunchKernelGGL((lap_mc_forest_kernel<CPL>), dim3(a.B), dim3(512), flds, stream, s2);
         REART_CHECK_LAUNCH();
     }
-#endif
-#ifdef MW_STOP_AFTER_TREES
-    return REART_OK;
-#endif
-#ifndef MW_SNW32
 #define MW_SNW32 16          // waves of a search workgroup at 32 columns per lane (n > 1024): two columns per thread instead of four; projection 76.7 -> 79.0 it/s
-#endif
     constexpr int SNW = CPL == 32 ? MW_SNW32 : MW_NW;
     if (SNW != MW_NW && lds > REART_LDS_DEFAULT_CAP &&
         hipFuncSetAttribute((const void *)lap_jvmw_kernel<CPL, 2, SNW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)

@@ -163,7 +163,7 @@ RESOLVE_RACERS = int(os.environ.get("REART_RESOLVE_RACERS", "13"))
 MW_NMIN, MW_NMAX = 512, int(os.environ.get("REART_RESOLVE_MW_NMAX", "2048"))
 RESOLVE_PER_WAVE = os.environ.get("REART_RESOLVE_MW", "1") != "0"
 # workgroups per problem of the row reduction on many compute units (reart_lap_resolve_points_mc); 0: the one-workgroup form
-RESOLVE_ARR_WGS = int(os.environ.get("REART_RESOLVE_ARR_WGS", "-1"))     # -1: up to eight, as many as the batch leaves room for
+RESOLVE_ARR_WGS = int(os.environ.get("REART_RESOLVE_ARR_WGS", "-1"))     # -1: up to sixteen, as many as the batch leaves room for
 
 
 # solver calls expected to be in flight at once on the device (the sweep's concurrent groups set it): the idle compute units a
@@ -172,7 +172,9 @@ CONCURRENT_CALLS = 1
 
 
 def _arr_wgs(B):
-    return RESOLVE_ARR_WGS if RESOLVE_ARR_WGS >= 0 else max(1, min(8, 256 // max(B * max(CONCURRENT_CALLS, 1), 1)))
+    # (x 8 chains each: with a team of four waves per chain -- lap_mc_arr_team_kernel -- 128 chains in flight per problem beat
+    # 64, recipe refresh 2.68 -> 2.57 ms; 224 are no better)
+    return RESOLVE_ARR_WGS if RESOLVE_ARR_WGS >= 0 else max(1, min(16, 512 // max(B * max(CONCURRENT_CALLS, 1), 1)))
 
 
 def _resolve_racers(B, n, race=True):

@@ -1,12 +1,12 @@
 #!/bin/bash
 # Measurement evidence of a round, collected on the GPU box (gpurun): the bench lines, rocprofv3 kernel stats of the bench
 # commands (restricted to the timed window where warm-up would be averaged in) and the counter passes of the search kernel.
-# Outputs under gpurun_out/prof4/ (the summaries are copied into profiles/ afterwards, named r04_*).
+# Outputs under gpurun_out/prof5/ (the summaries are copied into profiles/ afterwards, named r05_*).
 # Every command runs under `timeout`: a hang must not take the box.  Under rocprofv3 the program itself follows `--`.
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
-O=gpurun_out/prof4
+O=gpurun_out/prof5
 rm -rf $O; mkdir -p $O
 CLEAN="--sweep-instances 0 --no-tail --no-cpu-baseline --no-secondary"
 # gpurun boxes differ: about one in ten runs the search launch 35 % slower than the others (every other kernel the same, four
@@ -23,6 +23,7 @@ timeout 900 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
 timeout 300 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > $O/bench_driver_args.json 2> $O/bench_driver_args.err
 timeout 600 python3 bench.py --config kinematic > $O/bench_kinematic.json 2> $O/bench_kinematic.err
 timeout 600 python3 bench.py --config nao_recipe > $O/bench_nao_recipe.json 2> $O/bench_nao_recipe.err
+timeout 600 python3 bench.py --config nao > $O/bench_nao.json 2> $O/bench_nao.err
 # 1. kernel stats of the clean headline command (every launch belongs to the measured instance)
 timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $O/stats_clean -- python3 bench.py $CLEAN > $O/bench_clean_under_rocprof.json 2> $O/stats_clean.err
 # 2. counter passes of the search kernel (separate runs, --kernel-trace only), eager launches so that every dispatch is visible
@@ -37,7 +38,17 @@ f=$(find $O/trace_kinematic -name "*kernel_trace.csv" | head -1)
 timeout 900 rocprofv3 --kernel-trace -f csv -d $O/trace_recipe -- python3 bench.py --config nao_recipe --no-cpu-baseline > $O/bench_nao_recipe_under_rocprof.json 2> $O/trace_recipe.err
 f=$(find $O/trace_recipe -name "*kernel_trace.csv" | head -1)
 [ -n "$f" ] && python3 tools/kernel_window_stats.py "$f" --last 1999 --match lap_ > $O/kernel_stats_nao_recipe_window.csv
-# 4. the README recipe as a sweep on one GPU: 20 canonical frames of one generated sequence, both phases in shared launches
+timeout 900 rocprofv3 --kernel-trace -f csv -d $O/trace_projection -- python3 bench.py --config nao_projection --steps 1500 --no-cpu-baseline > $O/bench_nao_projection_1500_under_rocprof.json 2> $O/trace_projection.err
+f=$(find $O/trace_projection -name "*kernel_trace.csv" | head -1)
+[ -n "$f" ] && python3 tools/kernel_window_stats.py "$f" --last 1499 --match lap_ > $O/kernel_stats_nao_projection_window.csv
+# 3b. README.md:125 on nao, the whole run (15 000 iterations, a snapshot every 10), and the solve-by-solve account of both recipes
+timeout 900 python3 tools/run_nao.py --projection > $O/run_nao_projection.txt 2> $O/run_nao_projection.err
+MODE=recipe timeout 400 python3 tools/exp_tail.py 2>/dev/null | grep -v amdgpu.ids > $O/exp_tail_recipe.txt
+MODE=projection P_ITERS=3000 timeout 400 python3 tools/exp_tail.py 2>/dev/null | grep -v "amdgpu.ids\|joint types" > $O/exp_tail_projection.txt
+# 3c. workgroup lifetimes of the four small kernels of the headline step (diagnostic build: device clocks)
+make -C reart_amd/csrc stats > /dev/null 2>&1
+REART_LIB=reart_amd/csrc/libreart_hip_stats.so timeout 120 python3 tools/phase_clock.py 2>/dev/null | tail -7 > $O/small_kernel_clocks.txt
+# 4. the README recipe as a sweep on one GPU: 20 canonical frames of one generated sequence, both phases in shared launches, the groups concurrently
 rm -rf /tmp/sweep_recipe
 timeout 900 python3 -m reart_amd.sweep --synthetic 1 --synthetic_frames 20 --cano all --n_iter 15000 --use_flow_loss --use_assign_loss --energy --save_root /tmp/sweep_recipe > $O/sweep_recipe.line.json 2> $O/sweep_recipe.err
 cp /tmp/sweep_recipe/sweep.json $O/sweep_recipe_20x15000_energy.json 2>/dev/null
