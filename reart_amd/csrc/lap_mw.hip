@@ -650,7 +650,7 @@ __global__ __launch_bounds__(64 * NW) void lap_jvmw_kernel(JvArgs a) {
 #endif
                 if (sj != 0x7fffffff && sv < INFINITY) { mu = sv; sink = sj & ~JV_OWNED; break; }
                 if (nnew < MW_BUCKET_LO) bwidth *= 4.0;
-                else if (nnew > MW_BUCKET_HI) bwidth *= 0.5;
+                else if (nnew > MW_BUCKET_HI) bwidth = fmax(bwidth * 0.5, bdelta * 1e-3);      // (never down to zero: it could not grow again)
                 lo = bv;
                 if (bj == 0x7fffffff) { unsolved = true; break; }
             }
@@ -1090,7 +1090,7 @@ __global__ __launch_bounds__(512) void lap_mc_forest_kernel(JvArgs a) {
         off = fmax(off, mxo);
         lo = mn;
         if (nnew < MW_BUCKET_LO) bw *= 4.0;
-        else if (nnew > MW_BUCKET_HI) bw *= 0.5;
+        else if (nnew > MW_BUCKET_HI) bw = fmax(bw * 0.5, fdelta * 1e-3);                      // (never down to zero: it could not grow again)
     }
     nf = nf0 + joined;
     // the roots of the rows that joined: their parents' (pointer jumping over the parent links; a tree's first columns carry

@@ -415,3 +415,33 @@ def test_resolve_chain_forms_under_stress(dev, form):
         else:
             for r, c in out:
                 assert sorted(c.tolist()) == list(range(n))
+
+
+@pytest.mark.parametrize("n", [1024, 2048])
+def test_resolve_on_massively_tied_problems(dev, n):
+    """Bucket rounds and the bucketed backward growth where labels tie by the hundred: targets (and sources) drawn from 64
+    distinct points, so that every cost value occurs thousands of times and most reduced costs are exactly zero.  Four
+    re-solves of re-drawn sources: a permutation whose cost is scipy's optimum, certified on the GPU (the optimum is far
+    from unique: costs are compared, not columns)."""
+    import oracle
+    from reart_amd.utils import lap
+
+    rng = np.random.default_rng(n)
+    B = 3
+    grid = rng.uniform(-0.3, 0.3, (64, 3)).astype(np.float32)
+    tgt = grid[rng.integers(0, 64, (B, n))]
+    src = grid[rng.integers(0, 64, (B, n))]
+    state = {}
+    t_ = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    for k in range(4):
+        move = rng.permutation(n)[: n // 4]
+        src[:, move] = grid[rng.integers(0, 64, (B, len(move)))]
+        out, fb, st = lap.linear_sum_assignment_points(t_(src), t_(tgt), state, return_stats="full")
+        assert fb == 0, (k, fb)
+        cost = oracle.cdist(src, tgt)
+        ref = oracle.linear_sum_assignment(cost)
+        for b, (r, c) in enumerate(out):
+            assert sorted(c.tolist()) == list(range(n))
+            ours = cost[b][r, c].astype(np.float64).sum()
+            best = cost[b][ref[b][0], ref[b][1]].astype(np.float64).sum()
+            assert abs(ours - best) <= 1e-9 * max(best, 1.0), (k, b, ours, best)
