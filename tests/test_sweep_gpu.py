@@ -144,8 +144,11 @@ def test_sweep_command_line_synthetic_batch_with_flow(dev, tmp_path):
         assert (tmp_path / name / "result.pkl").exists()
 
 
-def test_sweep_command_line_readme_recipe(dev, tmp_path):
-    """The README recipe as a sweep (README.md:116: --use_flow_loss --use_assign_loss --downsample 4; here assign_iter 40 of
+@pytest.mark.parametrize("per_gpu", [None, 2])
+def test_sweep_command_line_readme_recipe(dev, tmp_path, per_gpu):
+    """per_gpu 2: the five instances run as THREE groups (2 + 2 + 1) that go through both phases CONCURRENTLY, each on a
+    stream and a host thread of its own (round 5) -- same results, instance by instance, as one group of five.
+    The README recipe as a sweep (README.md:116: --use_flow_loss --use_assign_loss --downsample 4; here assign_iter 40 of
     80 iterations): the five canonical frames of a generated sequence step in SHARED launches through both phases -- no
     fall-back to streams --, every refresh solves the 5 x 4 assignment problems of 512 x 512 in one call, nothing goes to the
     host solver, and an instance ends exactly as a solo engine driven by AssignmentPhase ends."""
@@ -159,12 +162,16 @@ def test_sweep_command_line_readme_recipe(dev, tmp_path):
 
     argv = ["--synthetic", "1", "--synthetic_frames", "5", "--num_points", "2048", "--cano", "all", "--n_iter", "80", "--use_flow_loss",
             "--use_assign_loss", "--assign_iter", "40", "--assign_gap", "5", "--downsample", "4", "--save_root", str(tmp_path)]
+    if per_gpu:
+        argv += ["--per_gpu", str(per_gpu)]
     with warnings.catch_warnings():
         warnings.simplefilter("error")                  # a batch group falling back to streams warns: not allowed here
         assert sweep.main(argv) == 0
     sw = json.load(open(tmp_path / "sweep.json"))
     st = sw["rank0_stages"]
-    assert st["assign_refreshes"] == 8 and st["lap_fallbacks"] == 0         # one group of five: refreshes at 40, 45, ..., 75
+    groups = 3 if per_gpu else 1
+    assert st["assign_refreshes"] == 8 * groups and st["lap_fallbacks"] == 0         # per group: refreshes at 40, 45, ..., 75
+    assert st.get("concurrent_groups", 1) == groups
     rows = sw["sequences"]["synthetic_0"]["instances"]
     assert all(r["iterations"] == 80 and r["failed"] == 0 and np.isfinite(r["total_loss"]) for r in rows)
     # instance cano_idx 1, alone
