@@ -49,6 +49,7 @@ if __name__ == "__main__" and _requested_gpus(sys.argv[1:]) > 1 and "RANK" not i
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+P_BENCH = 20             # parts of the bench model (BaseModel(num_parts=20))
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 vector peak (counts FMA as 2)
 
@@ -75,6 +76,45 @@ def _pcts(ms):
     a = np.asarray(ms, dtype=np.float64)
     return {"solve_ms_p50": round(float(np.percentile(a, 50)), 4), "solve_ms_p95": round(float(np.percentile(a, 95)), 4),
             "solve_ms_max": round(float(a.max()), 4)}
+
+
+def step_chain_floor(dev, N, B, P=20, H=128):
+    """The headline iteration's launch chain with its arithmetic removed (reart_relax_step_floor): five dependent launches with
+    the grids, block sizes and LDS footprints of the step's kernels at this configuration (rocprofv3 kernel trace) and the
+    dependent global round trips / workgroup barriers of one workgroup's chain in each (read off the kernels: forward 1 / 6,
+    search 11 / 2, consumers 3 / 3, backward 1 / 6, finalize 2 / 2), replayed from a graph like the step
+    itself -> (microseconds per iteration of the five launches, of the four small kernels' launches alone).  What is above it in
+    `ms_per_step` is the kernels' arithmetic and whatever of their chains the counts miss."""
+    import ctypes
+
+    from reart_amd import _lib as L_
+    nfin = ((4 * (P * H + 4 * H) + 63) // 64 * 64 + 64 * B * P + 255) // 256
+    shape = [N // 32, 320, 53760, 1, 6,
+             3 * B * (N // 64), 192, 17664, 11, 2,
+             B * (N // 512) + B * (N // 1024) + 4, 1024, 33792, 3, 3,
+             N // 32, 640, 65536, 1, 6,
+             nfin, 384, 512, 2, 2]
+    ws = torch.empty(65536 + 256, dtype=torch.uint8, device=dev)
+    per, reps, out = 50, 20, []
+    for sh in (shape, shape[:5] + shape[10:]):          # all five launches | the four small kernels alone (without the search)
+        arr = (ctypes.c_int * len(sh))(*sh)
+        run = lambda: L_.check(L_.lib().reart_relax_step_floor(arr, len(sh) // 5, per, L_.ptr(ws), ws.numel(), L_.stream()), "reart_relax_step_floor")
+        run()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            run()
+        for _ in range(3):
+            g.replay()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        ev0.record()
+        for _ in range(reps):
+            g.replay()
+        ev1.record()
+        torch.cuda.synchronize()
+        out.append(1e3 * ev0.elapsed_time(ev1) / (reps * per))
+    return out[0], out[1]
 
 
 def build_instance(dev, T, N, cano_idx, seed, use_flow=True, n_iter=15000, use_grid=False, overlap=True, profile=False):
@@ -993,6 +1033,14 @@ def main():
                     "algorithmic_tflops": round(nn_flops / t_nn / 1e12, 2), "algorithmic_frac": round(nn_flops / t_nn / 1e12 / FP32_PEAK_TFLOPS, 4),
                     "hbm_gbs": round(nn_bytes / t_nn / 1e9, 3), "hbm_frac": round(nn_bytes / t_nn / 1e9 / HBM_PEAK_GBS, 6),
                     "algorithmic_bytes": nn_bytes}
+            if use_flow and P_BENCH == 20:
+                try:       # the five-launch chain with free arithmetic, measured now (an aid: never costs the line)
+                    fl_us, fl_small = step_chain_floor(dev, N, B)
+                    roof["step_floor_us"] = round(fl_us, 3)
+                    roof["step_floor_small_kernels_us"] = round(fl_small, 3)
+                    roof["step_floor_frac"] = round(fl_us / (1e6 * el / args.steps), 4)
+                except Exception as exc:
+                    roof["step_floor_us"] = None
         cpu = cpu_torch = None
         if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(seq, T, N, cano_idx)

@@ -515,6 +515,15 @@ int reart_lap_resolve(const float *cost, int B, int n, int32_t *col4row, int32_t
  * clock.  A re-solve of S sequential steps cannot take less than S x this.  Synchronises `stream`.  workspace: 16 B bytes. */
 int reart_lap_step_floor(int B, int n, int steps, void *workspace, size_t workspace_bytes, double *h_us_per_step, void *stream);
 
+/* Measurement aid for the headline iteration (run_robot.py:154-221 as five dependent launches; no reference counterpart):
+ * enqueues `iters` times a chain of `nk` <= 8 launches of a kernel that does NO arithmetic.  shape [nk][5] (HOST ints): grid
+ * size, block size, dynamic LDS bytes, dependent global loads per thread (a pointer chase through `workspace`, 64 KB of it,
+ * L2-resident), workgroup barriers.  Launched with the shapes and dependent-access counts of the step's kernels, the chain's
+ * time per iteration is what those launches cost when their arithmetic is free: dispatch, drain and the latency of the
+ * dependent chain -- a floor of the five-launch iteration (bench.py reports it as roofline.step_floor_us).  Asynchronous and
+ * graph-capturable: the caller times it.  workspace: >= 64 KB + 64 B, initialised by the first call's own set-up launch. */
+int reart_relax_step_floor(const int *shape, int nk, int iters, void *workspace, size_t workspace_bytes, void *stream);
+
 /* The same re-solve for Euclidean costs between two point sets, without a cost matrix: src, tgt [B,n,3], n <= 2048;
  * c_ij is the value reart_cdist(src, tgt) would hold (same fp32 expression), recomputed from LDS copies of both sets
  * wherever the solver needs a cost -- a path-search step then reads no memory beyond LDS.  Result identical to

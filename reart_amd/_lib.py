@@ -75,6 +75,7 @@ PROTOTYPES = {
     "reart_gather_points": (c_int, [P, P, c_int, c_int, c_int, P, P]),
     "reart_assign_pairs": (c_int, [P, P, P, c_int, c_int, c_int, P, P]),
     "reart_lap_step_floor": (c_int, [c_int, c_int, c_int, P, c_size_t, ctypes.POINTER(ctypes.c_double), P]),
+    "reart_relax_step_floor": (c_int, [ctypes.POINTER(c_int), c_int, c_int, P, c_size_t, P]),
     "reart_cdist": (c_int, [P, P, c_int, c_int, c_int, P, P]),
     "reart_match_smnn_workspace_bytes": (c_size_t, [c_int] * 3),
     "reart_match_smnn": (c_int, [P, P, c_int, c_int, c_int, c_int, c_float, P, P, P, c_size_t, P]),

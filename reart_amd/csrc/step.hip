@@ -1145,3 +1145,35 @@ extern "C" int reart_relax_forward(const reart_relax_config *cfg, const reart_re
                                    void *workspace, size_t workspace_bytes, void *stream) {
     return relax_step_impl(cfg, bufs, workspace, workspace_bytes, stream, nullptr, true);
 }
+
+
+// ------------------------------------------------------------------------------ measurement aid: the launch chain's floor
+// (include/reart_hip.h: reart_relax_step_floor)
+__global__ void step_floor_init_kernel(int *chase, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) chase[i] = (int)(((unsigned)i * 40503u + 12345u) % (unsigned)n);     // a fixed scatter: every load lands on another line
+}
+__global__ void step_floor_kernel(const int *__restrict__ chase, int n, int loads, int barriers, int *sink) {
+    extern __shared__ int fl_lds[];
+    int idx = (int)((blockIdx.x * blockDim.x + threadIdx.x) % (unsigned)n);
+    for (int l = 0; l < loads; ++l) idx = chase[idx];           // dependent: the next address is the value just loaded
+    if (threadIdx.x == 0) fl_lds[0] = idx;
+    for (int b_ = 0; b_ < barriers; ++b_) __syncthreads();
+    if (idx < 0) sink[0] = fl_lds[0];                            // never true: keeps the chain alive
+}
+extern "C" int reart_relax_step_floor(const int *shape, int nk, int iters, void *workspace, size_t workspace_bytes, void *stream) {
+    const int n = 16384;                                         // 64 KB of indices
+    if (!shape || nk < 1 || nk > 8 || iters < 1 || !workspace || workspace_bytes < sizeof(int) * (size_t)n + 64) return REART_ERR_INVALID_ARG;
+    for (int k = 0; k < nk; ++k)
+        if (shape[5 * k] < 1 || shape[5 * k + 1] < 1 || shape[5 * k + 1] > 1024 || shape[5 * k + 2] < 4 || shape[5 * k + 2] > 64 * 1024 ||
+            shape[5 * k + 3] < 0 || shape[5 * k + 4] < 0) return REART_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    int *chase = (int *)workspace, *sink = chase + n;
+    hipLaunchKernelGGL(step_floor_init_kernel, dim3(n / 256), dim3(256), 0, st, chase, n);
+    for (int it = 0; it < iters; ++it)
+        for (int k = 0; k < nk; ++k)
+            hipLaunchKernelGGL(step_floor_kernel, dim3(shape[5 * k]), dim3(shape[5 * k + 1]), (size_t)shape[5 * k + 2], st, chase, n,
+                               shape[5 * k + 3], shape[5 * k + 4], sink);
+    REART_CHECK_LAUNCH();
+    return REART_OK;
+}

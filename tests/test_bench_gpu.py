@@ -31,6 +31,8 @@ def test_headline_line_contract(dev):
     assert r["bound"] == "valu" and 0 < r["frac"] < 1 and r["kernel_ms"] < d["ms_per_step"]
     assert r["algorithmic_frac"] > r["frac"] and r["hbm_frac"] < 0.2 and r["executed_pairs_per_launch"] < r["algorithmic_pairs_per_launch"]
     assert r["traffic"] is None or isinstance(r["traffic"], (int, float))        # a number of bytes (or null), as the contract says
+    # the launch chain with its arithmetic removed, measured in the run: below the step, the small kernels' share below the whole
+    assert 0 < r["step_floor_small_kernels_us"] < r["step_floor_us"] < 1e3 * d["ms_per_step"] and 0 < r["step_floor_frac"] < 1
 
 
 def _strings(x, path=""):
