@@ -506,6 +506,10 @@ class SnapshotPrinter:
         self.args, self.model, self.cano_pc, self.pc_list, self.sample = args, model, cano_pc, pc_list, sample
         self.tau_func, self.out = tau_func, out
         self.count, self.lines = 0, []
+        # the ground truth the metrics compare with, on the device once (tail.snapshot_metrics would upload it at every snapshot)
+        if sample is not None:
+            keys = ("gt_flow_list", "gt_cano_part", "complete_gt_pc_list")
+            self.sample = {k: torch.as_tensor(sample[k]).to(cano_pc.device) for k in keys if k in sample}
 
     def state(self, i):
         with torch.no_grad():

@@ -46,22 +46,30 @@ def energy_terms(cano_pc, pc_list, seg_part, trans_list, joint_connection, cano_
 
 def snapshot_metrics(cano_pc, pc_list, seg_part, trans_list, cano_idx, sample=None, chamfer=True):
     """-> dict with cd_err (``chamfer``: the value is printed at the end of a run only, run_robot.py:316) and, when ``sample``
-    carries the ground truth, epe / acc5 / acc10 / angle / ri / recon_err (run_robot.py:245-266; centimetre scaling as there)."""
+    carries the ground truth, epe / acc5 / acc10 / angle / ri / recon_err (run_robot.py:245-266; centimetre scaling as there).
+    All of it is computed on the device and read with ONE copy (a run prints hundreds of snapshots)."""
     pred = compute_pc_transform(cano_pc, trans_list, seg_part)
     out = dict(cd_err=100 * compute_chamfer_list(pred, pc_list, reduction="mean")) if chamfer else {}
     if sample is None:
         return out
     dev = cano_pc.device
     complete = torch.cat((pred[:cano_idx], cano_pc[None], pred[cano_idx:]), dim=0)
+    vals, names = [], []
     if "gt_flow_list" in sample:
         gt = torch.as_tensor(sample["gt_flow_list"]).float().to(dev)
-        epe, acc1, acc2, angle = eval_flow(complete[1:] - complete[:-1], gt, acc1_thre=0.005, acc2_thre=0.01)
-        out.update(epe=100 * epe, acc5=acc1, acc10=acc2, angle=angle)
+        vals += list(eval_flow(complete[1:] - complete[:-1], gt, acc1_thre=0.005, acc2_thre=0.01, as_tensors=True))
+        names += ["epe", "acc5", "acc10", "angle"]
     if "gt_cano_part" in sample:
-        out["ri"] = float(eval_seg(torch.as_tensor(sample["gt_cano_part"]).long().to(dev), seg_part))
+        vals.append(eval_seg(torch.as_tensor(sample["gt_cano_part"]).long().to(dev), seg_part, as_tensor=True))
+        names.append("ri")
     if "complete_gt_pc_list" in sample:
         gt = torch.as_tensor(sample["complete_gt_pc_list"]).float().to(dev)
-        out["recon_err"] = 100 * float(((complete - gt) ** 2).sum(-1).sqrt().mean(1).mean())
+        vals.append(((complete - gt) ** 2).sum(-1).sqrt().mean(1).mean())
+        names.append("recon_err")
+    if vals:
+        host = torch.stack([v.double().reshape(()) for v in vals]).cpu().tolist()
+        for k, v in zip(names, host):
+            out[k] = 100 * v if k in ("epe", "recon_err") else v
     return out
 
 

@@ -4,8 +4,9 @@ import torch
 from .chamfer import ChamferDistance
 
 
-def eval_flow(pred_flow_list, gt_flow_list, acc1_thre=0.05, acc2_thre=0.1):
-    """utils/eval_utils.py:6-22: end-point error, two accuracy levels and the angular error of [T-1,N,3] flows."""
+def eval_flow(pred_flow_list, gt_flow_list, acc1_thre=0.05, acc2_thre=0.1, as_tensors=False):
+    """utils/eval_utils.py:6-22: end-point error, two accuracy levels and the angular error of [T-1,N,3] flows.
+    ``as_tensors``: the four values as 0-d device tensors (no host sync) instead of floats."""
     pred, gt = torch.as_tensor(pred_flow_list), torch.as_tensor(gt_flow_list).to(pred_flow_list.device)
     error = torch.sqrt(((pred - gt) ** 2).sum(2) + 1e-20)
     gt_len = torch.sqrt((gt * gt).sum(2) + 1e-20)
@@ -18,14 +19,22 @@ def eval_flow(pred_flow_list, gt_flow_list, acc1_thre=0.05, acc2_thre=0.1):
     dot = (unit_gt * unit_pred).sum(2).clamp(-1 + eps, 1 - eps)
     dot = torch.where(torch.isnan(dot), torch.ones_like(dot), dot)
     angle = torch.acos(dot).mean(1).mean()
+    if as_tensors:
+        return error.mean(), acc1, acc2, angle
     return float(error.mean()), float(acc1), float(acc2), float(angle)
 
 
-def eval_seg(gt_segm, pd_segm):
+def eval_seg(gt_segm, pd_segm, as_tensor=False, num_labels=128):
     """utils/eval_utils.py:25-36: Rand index.  The reference compares two N x N co-membership matrices; the same
     count follows from the contingency table: agreeing ordered pairs = N^2 - sum_a n_a^2 - sum_b n_b^2 + 2 sum_ab n_ab^2."""
     gt, pd = gt_segm.long().reshape(-1), pd_segm.long().reshape(-1).to(gt_segm.device)
     n = gt.numel()
+    if as_tensor:      # no host sync: a fixed table of ``num_labels`` x ``num_labels`` cells (labels are part indices, far below 128)
+        s = num_labels
+        ar = torch.arange(s, device=gt.device)
+        table = (gt[:, None] == ar[None, :]).double().T @ (pd[:, None] == ar[None, :]).double()     # contingency table (no atomics)
+        agree = n * n - (table.sum(1) ** 2).sum() - (table.sum(0) ** 2).sum() + 2 * (table ** 2).sum()
+        return (agree / (n * n)).float()
     s = int(max(gt.max(), pd.max())) + 1
     table = torch.bincount(gt * s + pd, minlength=s * s).reshape(s, s).double()
     agree = n * n - (table.sum(1) ** 2).sum() - (table.sum(0) ** 2).sum() + 2 * (table ** 2).sum()
