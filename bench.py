@@ -1028,7 +1028,7 @@ def main():
                     "kernel_ms": round(k_ms, 5), "launches_measured": prof["launches"],
                     "slow_box": bool(use_flow and T == 20 and N == 4096 and args.steps >= 300 and k_ms > 1.25 * 0.0329),
                     "workgroup_busy_ms": round(1e3 * prof["workgroup_seconds"] / prof["launches"], 4),
-                    "executed_pairs_per_launch": round(executed, 1), "flop_per_pair": 8,
+                    "executed_pairs_per_launch": round(executed, 1),
                     "algorithmic_pairs_per_launch": nn_pairs, "algorithmic_speedup": round(nn_pairs / executed, 3),
                     "algorithmic_tflops": round(nn_flops / t_nn / 1e12, 2), "algorithmic_frac": round(nn_flops / t_nn / 1e12 / FP32_PEAK_TFLOPS, 4),
                     "hbm_gbs": round(nn_bytes / t_nn / 1e9, 3), "hbm_frac": round(nn_bytes / t_nn / 1e9 / HBM_PEAK_GBS, 6),
@@ -1089,7 +1089,7 @@ def main():
                     cpu_lap = 1e3 * (time.perf_counter() - t_)
                     cpu_tail = {"structure_ms": round(cpu_struct, 1), "assignment_ms_per_matrix": round(cpu_lap, 1),
                                 "matrices": int(eng.pc_list.shape[0]), "kind": "port",
-                                "sample": "oracle structure extraction once; scipy on 1 of the T-1 matrices of 4096^2"}
+                                "sample": "oracle structure once; scipy on 1 of T-1 matrices"}
                 end_of_run = {"structure_ms": round(ms_struct, 3), "energy_ms": round(ms_energy, 3), "cpu_baseline": cpu_tail,
                               "parts": int(trans_s.shape[1]), "total_err": round(en["total_err"], 6),
                               "ass_err": round(en["ass_err"], 6), "screw_err": round(en["screw_err"], 6),
@@ -1116,7 +1116,7 @@ def main():
             "config": {"workload": f"synthetic T={T} x N={N}, P=20, Chamfer" + ("+flow" if use_flow else "") + ", full iteration, one instance/GPU",
                        "frames": T, "points": N, "parts": 20, "flow": use_flow,
                        "graph": not args.no_graph, "steps_per_graph": (0 if args.no_graph else spg),
-                       "graph_replays": replays, "eager_steps": eager, "grid_search_static_targets": args.grid, "parallelism": f"instances x{world}" + (f" x{K} per GPU" if K > 1 else ""),
+                       "graph_replays": replays, "eager_steps": eager, "parallelism": f"instances x{world}" + (f" x{K} per GPU" if K > 1 else ""),
                        "instances_per_gpu": K},
             "roofline": roof,
             "cpu_baseline": cpu,

@@ -25,13 +25,13 @@ class KinematicEngine:
     the flow references of run_robot.py:81-84 or None.  Hyper-parameters carry the reference's flag names
     (run_robot.py:362-420): ``trans_lr`` (Adam lr of every kinematic parameter, :150-151), ``weight_decay``,
     ``use_assign_loss`` / ``assign_iter`` / ``assign_gap`` / ``downsample`` / ``lambda_assign``, ``lambda_flow``,
-    ``use_robust_loss``.  Without the assignment loss (or before ``assign_iter``) the Chamfer loss needs autograd-free
-    nearest-neighbour gradients that this engine does not carry: use ``OperatorLoop`` there.
+    ``use_robust_loss``.  Before ``assign_iter`` (or with ``use_assign_loss=False``) the iteration takes the Chamfer branch
+    (run_robot.py:187-190): two exact K = 1 searches and ``knn_points_backward`` for dL/d pc_trans, no autograd there either.
     """
 
     def __init__(self, model, cano_pc, pc_list, cano_idx, pc_ref_list=None, flow_ref_list=None, trans_lr=1e-2,
                  weight_decay=0.0, assign_iter=0, assign_gap=5, downsample=4, lambda_assign=3e-1, lambda_flow=1.0,
-                 use_robust_loss=False, smooth_weight=1e-2, knn_squared=False):
+                 use_robust_loss=False, smooth_weight=1e-2, knn_squared=False, use_assign_loss=True):
         _lib.require_gpu(cano_pc, pc_list)
         if hasattr(model, "root_6d"):
             raise NotImplementedError("root motion (run_real / run_sapien variant) goes through OperatorLoop")
@@ -44,6 +44,7 @@ class KinematicEngine:
         self.B, self.N = self.pc_list.shape[:2]
         self.lr, self.wd = float(trans_lr), float(weight_decay)
         self.assign_iter, self.assign_gap, self.lambda_assign = int(assign_iter), int(assign_gap), float(lambda_assign)
+        self.use_assign = bool(use_assign_loss)
         self.lambda_flow, self.robust, self.smooth = float(lambda_flow), bool(use_robust_loss), float(smooth_weight)
         self.euclid = 0 if knn_squared else 1
         self.refs = None
@@ -217,6 +218,31 @@ class KinematicEngine:
         self._backward()
         self.losses = losses
 
+    def _post_chamfer(self):
+        """The Chamfer branch (run_robot.py:187-190: recon_loss = sum of the bidirectional per-point Chamfer distance,
+        networks/loss.py:24-29) without autograd: both searches, then the gradient of each direction's distances w.r.t. the
+        predicted cloud (utils/chamfer.py:195-209 with grad_dists = 1), flow terms, FK backward."""
+        from . import chamferdist_C as _C
+
+        X, Y = self.pc_trans, self.pc_list
+        i1, d1 = _C.knn_points_idx(X, Y, None, None, 1)
+        i2, d2 = _C.knn_points_idx(Y, X, None, None, 1)
+        rec = d1.sum() + d2.sum()
+        ones = torch.ones_like(d1)
+        g1, _ = _C.knn_points_backward(X, Y, None, None, i1, ones)
+        _, g2 = _C.knn_points_backward(Y, X, None, None, i2, ones)
+        self.G.copy_(g1)
+        self.G += g2
+        losses = {"recon Loss": rec}
+        total = rec
+        if self.refs is not None:
+            fl = self._flow_terms()
+            losses["flow Loss"] = fl
+            total = total + fl
+        losses["total Loss"] = total
+        self._backward()
+        self.losses = losses
+
     @staticmethod
     def _graph(fn):
         fn()                                        # warm-up outside the capture (lazy loads, workspace growth)
@@ -231,8 +257,11 @@ class KinematicEngine:
         """Iteration i of run_robot.py:154-221 in the assignment-loss branch; returns the loss dictionary (device tensors).
         From the third iteration on the launches before and after the solve replay from two captured graphs (the solve itself
         and Adam, whose step count is a host value, stay eager): same launches, same results, a tenth of the host work."""
-        if i < self.assign_iter:
-            raise NotImplementedError("the Chamfer branch of the kinematic loop runs through OperatorLoop")
+        if not self.use_assign or i < self.assign_iter:                   # run_robot.py:187-190
+            self.forward()
+            self._post_chamfer()
+            self._adam()
+            return self.losses
         if self._pc_src is None:
             self._pc_src = torch.empty((self.B, self.src_idx.numel(), 3), dtype=torch.float32, device=self.dev)
         if self._g_pre is not None:

@@ -478,19 +478,19 @@ class OperatorLoop:
 
 
 def make_projection_loop(args, model, cano_pc, pc_list, pc_ref_list=None, flow_ref_list=None, tau_func=None):
-    """The loop object for phase 2: the autograd-free ``KinematicEngine`` for the kinematic projection as the reference's
-    README runs it (``--model kinematic --use_assign_loss --assign_iter 0``, revolute joints, no root motion); every
-    other combination -- Chamfer iterations before ``assign_iter``, root motion, mixed joint types, the base model outside
-    the fused engine -- goes through ``OperatorLoop`` (PyTorch autograd + torch.optim.Adam over the same operators)."""
-    if (args.model == "kinematic" and args.use_assign_loss and args.assign_iter == 0 and not hasattr(model, "root_6d")
-            and model.joint_type_list is None):
+    """The loop object for phase 2: the autograd-free ``KinematicEngine`` for ``--model kinematic`` with revolute joints and
+    no root motion -- the projection as the reference's README runs it (``--use_assign_loss --assign_iter 0``) and, since
+    round 5, its Chamfer branch too (iterations before ``assign_iter``, runs without ``--use_assign_loss``); root motion,
+    mixed joint types and the base model outside the fused engine go through ``OperatorLoop`` (PyTorch autograd +
+    torch.optim.Adam over the same operators)."""
+    if args.model == "kinematic" and not hasattr(model, "root_6d") and model.joint_type_list is None:
         from reart_amd.kinematic_engine import KinematicEngine
 
         return KinematicEngine(model, cano_pc, pc_list, args.cano_idx, pc_ref_list if args.use_flow_loss else None,
                                flow_ref_list if args.use_flow_loss else None, trans_lr=args.trans_lr,
-                               weight_decay=args.weight_decay, assign_iter=0, assign_gap=args.assign_gap,
+                               weight_decay=args.weight_decay, assign_iter=args.assign_iter, assign_gap=args.assign_gap,
                                downsample=args.downsample, lambda_assign=args.lambda_assign, lambda_flow=args.lambda_flow,
-                               use_robust_loss=args.use_robust_loss)
+                               use_robust_loss=args.use_robust_loss, use_assign_loss=args.use_assign_loss)
     return OperatorLoop(args, model, cano_pc, pc_list, pc_ref_list, flow_ref_list, tau_func)
 
 

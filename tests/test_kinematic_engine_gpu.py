@@ -27,10 +27,12 @@ def _model(dev, k, cano):
                           theta_list=t(k["theta"], dev)).to(dev)
 
 
-@pytest.mark.parametrize("with_flow,gap,wd", [(True, 1, 0.0), (False, 2, 0.0), (True, 2, 0.01)])
-def test_engine_equals_the_autograd_loop(dev, with_flow, gap, wd):
+@pytest.mark.parametrize("with_flow,gap,wd,assign_iter", [(True, 1, 0.0, 0), (False, 2, 0.0, 0), (True, 2, 0.01, 0), (True, 1, 0.0, 3),
+                                                          (False, 1, 0.0, 100)])
+def test_engine_equals_the_autograd_loop(dev, with_flow, gap, wd, assign_iter):
     """kinematic-2 checkpoint of the reference (golden kinematic.npz) on its own canonical cloud: six iterations of the
-    assignment (+ flow) branch; parameters after every step and all losses agree with the autograd loop."""
+    assignment (+ flow) branch -- with assign_iter 3 / 100 the first three / all of them in the Chamfer branch
+    (run_robot.py:187-190) --; parameters after every step and all losses agree with the autograd loop."""
     from reart_amd import run_robot as rr
     from reart_amd.kinematic_engine import KinematicEngine
 
@@ -48,12 +50,12 @@ def test_engine_equals_the_autograd_loop(dev, with_flow, gap, wd):
         sel = [torch.from_numpy(rng.permutation(N)[:300 + 7 * f]).to(dev) for f in range(B)]
         refs = [comp[f][s] for f, s in enumerate(sel)]
         flows = [(comp[f + 1][s] - comp[f][s]) * 0.5 for f, s in enumerate(sel)]
-    argv = ["--model", "kinematic", "--use_assign_loss", "--assign_iter", "0", "--downsample", "4", "--assign_gap", str(gap),
+    argv = ["--model", "kinematic", "--use_assign_loss", "--assign_iter", str(assign_iter), "--downsample", "4", "--assign_gap", str(gap),
             "--cano_idx", "2", "--weight_decay", str(wd)] + (["--use_flow_loss"] if with_flow else [])
     a = rr.build_parser().parse_args(argv)
     m_ref, m_eng = _model(dev, k, cano), _model(dev, k, cano)
     loop = rr.OperatorLoop(a, m_ref, cano, pcs, refs, flows)
-    eng = KinematicEngine(m_eng, cano, pcs, 2, refs, flows, trans_lr=a.trans_lr, weight_decay=wd, assign_iter=0, assign_gap=gap,
+    eng = KinematicEngine(m_eng, cano, pcs, 2, refs, flows, trans_lr=a.trans_lr, weight_decay=wd, assign_iter=assign_iter, assign_gap=gap,
                           downsample=4, lambda_assign=a.lambda_assign, lambda_flow=a.lambda_flow)
     for i in range(6):
         l_ref = loop.iteration(i)
