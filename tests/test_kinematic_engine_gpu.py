@@ -64,8 +64,17 @@ def test_engine_equals_the_autograd_loop(dev, with_flow, gap, wd, assign_iter):
             a_, b_ = float(l_ref[key].detach()), float(l_eng[key].detach())
             assert abs(a_ - b_) <= 2e-5 * abs(a_) + 1e-7, (i, key)
         for name in ("axis_list", "moment_list", "theta_list"):
+            # The Chamfer branch starts at a checkpoint that is (nearly) a minimum of the Chamfer loss: its gradients are small, the
+            # two loops sum their 9 x 4096 terms in different orders, and Adam turns rounding noise in a small gradient into
+            # lr-sized steps; once the parameters differ in the sixth digit single points switch their nearest neighbour and the
+            # gradients differ by 1e-3.  So the GRADIENTS are held to 1e-4 of their largest entry over the first three iterations
+            # (the same parameters on both sides up to rounding) and the parameters to a wider band throughout.
+            if assign_iter > 0 and i < 3:
+                g_ref = getattr(m_ref, name).grad.detach().cpu().numpy()
+                g_eng = eng.grads[id(getattr(m_eng, name))].cpu().numpy()
+                np.testing.assert_allclose(g_eng, g_ref, rtol=0, atol=1e-4 * np.abs(g_ref).max(), err_msg=f"iteration {i} d/d{name}")
             np.testing.assert_allclose(getattr(m_eng, name).detach().cpu().numpy(), getattr(m_ref, name).detach().cpu().numpy(),
-                                       rtol=0, atol=2e-6, err_msg=f"iteration {i} {name}")
+                                       rtol=0, atol=2e-6 if assign_iter == 0 else 1e-4, err_msg=f"iteration {i} {name}")
     assert eng.lap_solves == loop.lap_solves
     assert eng.lap_fallbacks == 0 and loop.lap_fallbacks == 0          # neither loop went through the host solver
 
