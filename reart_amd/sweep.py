@@ -8,6 +8,7 @@ collective); the only exchange is one ``all_gather`` of a fixed-size float recor
 (RCCL over xGMI when the backend is "nccl"; latency-bound: 64 B per instance), after which every
 rank can take the arg-min.
 """
+import contextlib
 import os
 from concurrent.futures import ThreadPoolExecutor
 
@@ -301,8 +302,9 @@ def run_sweep_engines(instances, make_engine, n_iter, device, per_gpu=3, chunk=1
             if first_phase < n_iter:          # the assignment phase: host-driven (a refresh reads its certificates), shared launches
                 from .run_robot import AssignmentPhaseBatch
 
-                ph = AssignmentPhaseBatch(batch, [e[2].caller_clouds() for e in part], assign["downsample"], assign["assign_gap"],
-                                          assign["lambda_assign"])
+                with (gate.tail() if concurrent else contextlib.nullcontext()):      # (allocates: not while another group captures)
+                    ph = AssignmentPhaseBatch(batch, [e[2].caller_clouds() for e in part], assign["downsample"], assign["assign_gap"],
+                                              assign["lambda_assign"])
                 ph.capture_guard = gate.capture
                 ph.work_guard = gate.tail if concurrent else None
                 ph.run(first_phase, n_iter)
