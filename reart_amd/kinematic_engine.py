@@ -82,6 +82,7 @@ class KinematicEngine:
         self.G = torch.zeros((self.B, self.N, 3), dtype=torch.float32, device=self.dev)
         self.losses = {}
         self._pc_src, self._inplace, self._g_pre, self._g_post = None, None, None, None
+        self._side = None
 
     # ---- pieces -----------------------------------------------------------------------------------------------------
     def _joint_values(self):
@@ -140,11 +141,21 @@ class KinematicEngine:
         comp = torch.cat((self.pc_trans[:c], self.cano[None], self.pc_trans[c:]), dim=0)          # [T,N,3]
         gt = torch.empty((self.B, self.N, 3), dtype=torch.float32, device=self.dev)
         mask = torch.empty((self.B, self.N), dtype=torch.bool, device=self.dev)
+        # the T-1 blends are independent and small (16 workgroups each, a chain of gathers): dealt to a few side streams they
+        # run side by side -- in a captured graph as parallel branches -- instead of one after the other
+        cur = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = [torch.cuda.Stream(device=self.dev) for _ in range(min(self.SIDE_STREAMS, len(self.refs)))]
+        for st in self._side:
+            st.wait_stream(cur)
         for f, (r, fl) in enumerate(self.refs):
-            ws = _lib.workspace(L.reart_blend_anchor_motion_workspace_bytes(self.N, r.shape[0], 3), self.dev)
-            rc = L.reart_blend_anchor_motion(_lib.ptr(comp[f]), _lib.ptr(r), _lib.ptr(fl), self.N, r.shape[0], 3, self.euclid,
-                                             _lib.ptr(gt[f]), _lib.ptr(mask[f]), _lib.ptr(ws), ws.numel(), _lib.stream())
-            _lib.check(rc, "reart_blend_anchor_motion")
+            with torch.cuda.stream(self._side[f % len(self._side)]):
+                ws = _lib.workspace(L.reart_blend_anchor_motion_workspace_bytes(self.N, r.shape[0], 3), self.dev)
+                rc = L.reart_blend_anchor_motion(_lib.ptr(comp[f]), _lib.ptr(r), _lib.ptr(fl), self.N, r.shape[0], 3, self.euclid,
+                                                 _lib.ptr(gt[f]), _lib.ptr(mask[f]), _lib.ptr(ws), ws.numel(), _lib.stream())
+                _lib.check(rc, "reart_blend_anchor_motion")
+        for st in self._side:
+            cur.wait_stream(st)
         pred = (comp[1:] - comp[:-1]).contiguous()
         loss = torch.empty((), dtype=torch.float32, device=self.dev)
         gp = torch.empty_like(pred)
@@ -162,6 +173,7 @@ class KinematicEngine:
 
     # ---- the iteration ----------------------------------------------------------------------------------------------
     GRAPHS = True       # replay the launches around the solve from two captured graphs (False: every launch eagerly)
+    SIDE_STREAMS = 6    # streams the per-frame flow blends of an iteration are dealt to
 
     def _solve(self, pc_src):
         """The assignment refresh (run_robot.py:165-178) -> the solver's [B,4] statistics; the optimum is in lap_state["cols"]."""
