@@ -89,6 +89,15 @@ def test_new_entry_points_reject_bad_arguments_without_a_gpu():
     assert L.reart_lap_workspace_bytes(3, 4096) > L.reart_lap_workspace_bytes(3, 2048) > 0
     assert L.reart_lap_workspace_bytes(3, 4097) == 0
     assert L.reart_screw_fit_workspace_bytes(19, 400) == 400 * 6 * 4
+    # the measurement aid of the headline's roofline: shapes are validated before anything is launched
+    import ctypes
+    shape = (ctypes.c_int * 5)(128, 320, 4096, 1, 6)
+    assert L.reart_relax_step_floor(None, 1, 1, 1, 1 << 20, None) == bad
+    assert L.reart_relax_step_floor(shape, 1, 1, None, 1 << 20, None) == bad
+    assert L.reart_relax_step_floor(shape, 9, 1, 1, 1 << 20, None) == bad                    # at most eight launches per iteration
+    assert L.reart_relax_step_floor(shape, 1, 1, 1, 1024, None) == bad                       # workspace below 64 KB
+    shape[1] = 2048
+    assert L.reart_relax_step_floor(shape, 1, 1, 1, 1 << 20, None) == bad                    # block size above 1024
     # empty problems are fine
     assert L.reart_part_fps(1, 1, 10, 1, 0, 20, 0, 1, 1, None) == 0
     assert L.reart_cdist(None, None, 0, 4, 4, None, None) == 0
