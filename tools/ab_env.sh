@@ -1,4 +1,5 @@
 #!/bin/bash
+# A/B of the engine's tuning fields (relax.tuning_from_env) on the headline iteration, ONE box, two rounds.
 run() { env "$@" timeout 200 python bench.py --no-cpu-baseline --no-secondary --sweep-instances 0 --no-tail --profile-steps 0 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); print('$*', d['value'])"; }
