@@ -32,11 +32,19 @@
 #define MW_CHECK 16          // a search looks at the race flag and at its labelled columns every MW_CHECK steps
 // A search that has not met a sink after MW_BUCKET_AFTER one-column steps goes on in BUCKETS (see the search loop): all
 // unlabelled columns within `width` of the closest one are settled together by label-correcting rounds.
-#define MW_BUCKET_AFTER 48
+#define MW_BUCKET_AFTER 24   // (replayed solves, 16 / 24 / 32 / 48: 250 / 252 / 257 / 258 ms over the recipe's slowest 24, 545 / 545 / 542 / 555 over the projection's)
 #define MW_BUCKET_W0 1e-8    // first bucket width of a problem, as a fraction of the cost scale
 #define MW_BK 192            // columns relaxed from per round (the rest of a bucket waits for the next round); 12 KB of lists: two 1024-column workgroups per compute unit
-#define MW_BUCKET_LO 8       // a bucket that closes with fewer columns than this widens the next one fourfold ...
-#define MW_BUCKET_HI 48      // ... with more than this, halves it
+// (the three below were first set by whole-loop runs, whose trajectories are chaotic: 8 / 48 / 4.0.  On DUMPED solves replayed with
+// every variant, tools/replay_tail.py, same box -- recipe slowest 24 / recipe sample 40 / projection slowest 24 / projection
+// sample 40, ms: 8, 48: 359 / 127 / 796 / 207 | 4, 24: 311 / 118 / 657 / 186 | 2, 12: 272 / 117 / 575 / 177 | 2, 8: 276 / 117 /
+// 578 / 178 | 1, 6: 288 / 146 / 602 / 205 | 16, 96: 424 / 145 / 996 / 255; widening twofold: 259 / 116 / 555 / 178.  A wide bucket
+// relaxes from its members again and again: 2.6 entries per settled column at 8 / 48, 1.4 at 2 / 12.)
+#define MW_BUCKET_LO 2       // a bucket that closes with fewer columns than this widens the next one ...
+#define MW_BUCKET_HI 12      // ... with more than this, halves it
+#define MW_BUCKET_UP 2.0
+#define MW_FOREST_LO 8       // the same thresholds for the backward growth's buckets (lap_mc_forest_kernel; fourfold)
+#define MW_FOREST_HI 48
 
 #ifdef REART_PRUNE_PHASE   // diagnostic build only (make -C reart_amd/csrc phase; tools/exp_mw.py)
 // per workgroup (first 64): 0 set-up | 1 row-reduction phase | 2 path-search phase (wall ticks of wave 0) | 3, 4 ticks the waves
@@ -138,6 +146,10 @@ __device__ __forceinline__ void mw_argmin_key(double &v, int &j) {
     j = __builtin_amdgcn_readlane(j, wl);
     v = __hiloint2double(__builtin_amdgcn_readlane(hi, wl), __builtin_amdgcn_readlane(lo, wl));
 }
+
+typedef float mw_f4 __attribute__((ext_vector_type(4)));
+// x rounded to fp32 so that the result is not below it (finite x, +inf): (float)(x (1 +- 2^-23)) >= x whatever the conversion's rounding
+__device__ __forceinline__ float mw_f32_up(double x) { return (float)(x + fabs(x) * 1.1920928955078125e-07); }
 
 // this lane's CPL costs of row (ax, ay, az): reart_cdist's expression, two columns per packed-fp32 operand
 template <int CPL>
@@ -431,8 +443,10 @@ __global__ __launch_bounds__(64 * NW) void lap_jvmw_kernel(JvArgs a) {
     // bucket rounds: the columns relaxed FROM in a round (their rows' points and potentials, their labels), two buffers; the
     // list lengths rotate through three slots (slot r + 1 is cleared before the barrier of round r: its last reader passed
     // the barrier of round r - 1)
-    __shared__ float s_ex[2][MW_BK], s_ey[2][MW_BK], s_ez[2][MW_BK];
-    __shared__ double s_ed[2][MW_BK], s_eh[2][MW_BK];
+    // (an entry's hot part is ONE 16-byte broadcast read: the row's point and g = (its potential - its label), rounded UP to fp32;
+    // the label and the potential themselves are read by the few pairs that pass the filter)
+    __shared__ __attribute__((aligned(16))) float s_e4[2][MW_BK][4];
+    __shared__ __attribute__((aligned(16))) double s_eg[2][MW_BK][2];
     __shared__ int s_ei[2][MW_BK], s_ecnt[3];
     __shared__ double s_bv[2][NW], s_bs[2][NW];
     __shared__ int s_bj[2][NW], s_bsj[2][NW], s_bn[2][NW], s_blost[2];
@@ -524,9 +538,9 @@ __global__ __launch_bounds__(64 * NW) void lap_jvmw_kernel(JvArgs a) {
             double lo = INFINITY;
             bool first = true;
             const double bdelta = mx * 1e-12;
-            double rk[CPT];                                   // d - p of the unsettled columns (settled: -inf, never a candidate)
+            float rk[CPT];                                    // d - p of the unsettled columns rounded UP to fp32 (settled: -inf, never a candidate)
 #pragma unroll
-            for (int k = 0; k < CPT; ++k) rk[k] = ((scanned >> k) & 1u) ? -INFINITY : d[k] - pj[k];
+            for (int k = 0; k < CPT; ++k) rk[k] = ((scanned >> k) & 1u) ? -INFINITY : mw_f32_up(d[k] - pj[k]);
             for (;;) {
                 // closing reductions of the previous bucket double as the opening of this one: the closest unlabelled column
                 double bv = INFINITY;
@@ -567,8 +581,10 @@ __global__ __launch_bounds__(64 * NW) void lap_jvmw_kernel(JvArgs a) {
                             const int at = base + __builtin_popcountll(m & ((1ull << lane) - 1ull));
                             if (want && at < MW_BK) {
                                 const int j = tid + k * BS, i = owner[j];
-                                s_ex[buf][at] = psx[i]; s_ey[buf][at] = psy[i]; s_ez[buf][at] = psz[i];
-                                s_ed[buf][at] = d[k]; s_eh[buf][at] = hcol[j]; s_ei[buf][at] = i;
+                                const double h = hcol[j];
+                                s_e4[buf][at][0] = psx[i]; s_e4[buf][at][1] = psy[i]; s_e4[buf][at][2] = psz[i];
+                                s_e4[buf][at][3] = mw_f32_up((h - d[k]) + bdelta);
+                                s_eg[buf][at][0] = d[k]; s_eg[buf][at][1] = h; s_ei[buf][at] = i;
                                 pend &= ~(1u << k);
                             }
                         }
@@ -583,28 +599,67 @@ __global__ __launch_bounds__(64 * NW) void lap_jvmw_kernel(JvArgs a) {
 #ifdef REART_PRUNE_PHASE
                     my_relax += ne; ++my_rounds;
 #endif
-                    for (int e = 0; e < ne; ++e) {
-                        const float ax = s_ex[buf][e], ay = s_ey[buf][e], az = s_ez[buf][e];
-                        const double df = s_ed[buf][e], h = s_eh[buf][e];
-                        const int i = s_ei[buf][e];
-                        const double g = (h - df) + bdelta;
+                    // The label of column k improves through entry e iff c < (d - p) + (h - df) =: T (in exact arithmetic).  Nearly no
+                    // (entry, column) pair does, and the square root and the double-precision sums are most of the work: a pair whose
+                    // squared distance exceeds T^2 by more than every rounding on the way is skipped -- T from the two fp32 UPPER
+                    // bounds (bdelta, 1e-12 of the cost scale, covers the <= 1e-15 of the double sums; the factor 1 + 2^-20 the
+                    // fp32 sum, the two products and the 2^-24 of the fp32 root), two columns per packed operand, two entries in
+                    // flight.  The pairs that pass take the expression itself, in the entries' order.
+                    for (int e = 0; e < ne; e += 2) {
+                        const mw_f4 E0 = *(const mw_f4 *)s_e4[buf][e];
+                        mw_f4 E1 = *(const mw_f4 *)s_e4[buf][e + 1 < MW_BK ? e + 1 : e];
+                        if (e + 1 >= ne) E1.w = -INFINITY;             // (odd count: the slot behind the list holds an older round's entry)
+                        unsigned pass0 = 0u, pass1 = 0u;
+                        if (CPT % 2 == 0) {
 #pragma unroll
-                        for (int k = 0; k < CPT; ++k) {
-                            // the label improves iff c < (d - p) + (h - df) =: T (in exact arithmetic).  Nearly no (entry, column)
-                            // pair does, and the square root is a third of the work: a pair whose squared distance exceeds T^2 by
-                            // more than every rounding on the way (bdelta: 1e-12 of the cost scale against <= 1e-15 of it;
-                            // 2^-22 against the 2^-24 of the fp32 root) is skipped; the others take the expression itself.
-                            const float sq = reart_sqdist3(ax, ay, az, qx[k], qy[k], qz[k]);
-                            const double T = rk[k] + g, Tq = T * 1.000000238418579;
-                            if (T > 0.0 && (double)sq <= Tq * Tq) {
-                                double w = ((double)mw_sqrt(sq) + pj[k]) - h;
-                                w = w > 0.0 ? w : 0.0;
-                                const double nd = df + w;
-                                if (nd < d[k]) {
-                                    d[k] = nd; rk[k] = nd - pj[k];
-                                    cpred[tid + k * BS] = i;
-                                    if ((nd < hi || nd == lo) && !((sinkb >> k) & 1u)) pend |= 1u << k;
+                            for (int k = 0; k < CPT / 2 * 2; k += 2) {
+                                const jv_f2 cx = {qx[k], qx[k + 1]}, cy = {qy[k], qy[k + 1]}, cz = {qz[k], qz[k + 1]}, r2 = {rk[k], rk[k + 1]};
+                                {
+                                    const jv_f2 ax = {E0.x, E0.x}, ay = {E0.y, E0.y}, az = {E0.z, E0.z}, g2 = {E0.w, E0.w};
+                                    const jv_f2 dx = ax - cx, dy = ay - cy, dz = az - cz;
+                                    const jv_f2 sq = (dx * dx + dy * dy) + dz * dz;
+                                    const jv_f2 T = r2 + g2, Tq = T * 1.00000095367431640625f, Q = Tq * Tq;
+                                    if (T.x > 0.0f && sq.x <= Q.x) pass0 |= 1u << k;
+                                    if (T.y > 0.0f && sq.y <= Q.y) pass0 |= 2u << k;
                                 }
+                                {
+                                    const jv_f2 ax = {E1.x, E1.x}, ay = {E1.y, E1.y}, az = {E1.z, E1.z}, g2 = {E1.w, E1.w};
+                                    const jv_f2 dx = ax - cx, dy = ay - cy, dz = az - cz;
+                                    const jv_f2 sq = (dx * dx + dy * dy) + dz * dz;
+                                    const jv_f2 T = r2 + g2, Tq = T * 1.00000095367431640625f, Q = Tq * Tq;
+                                    if (T.x > 0.0f && sq.x <= Q.x) pass1 |= 1u << k;
+                                    if (T.y > 0.0f && sq.y <= Q.y) pass1 |= 2u << k;
+                                }
+                            }
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < CPT; ++k) {
+                                const float s0 = reart_sqdist3(E0.x, E0.y, E0.z, qx[k], qy[k], qz[k]), s1 = reart_sqdist3(E1.x, E1.y, E1.z, qx[k], qy[k], qz[k]);
+                                const float T0 = rk[k] + E0.w, T1 = rk[k] + E1.w;
+                                const float q0 = T0 * 1.00000095367431640625f, q1 = T1 * 1.00000095367431640625f;
+                                if (T0 > 0.0f && s0 <= q0 * q0) pass0 |= 1u << k;
+                                if (T1 > 0.0f && s1 <= q1 * q1) pass1 |= 1u << k;
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const unsigned pass = u ? pass1 : pass0;
+                            if (pass) {
+                                const mw_f4 E = u ? E1 : E0;
+                                const double df = s_eg[buf][e + u][0], h = s_eg[buf][e + u][1];
+                                const int i = s_ei[buf][e + u];
+#pragma unroll
+                                for (int k = 0; k < CPT; ++k)
+                                    if ((pass >> k) & 1u) {
+                                        double w = ((double)mw_sqrt(reart_sqdist3(E.x, E.y, E.z, qx[k], qy[k], qz[k])) + pj[k]) - h;
+                                        w = w > 0.0 ? w : 0.0;
+                                        const double nd = df + w;
+                                        if (nd < d[k]) {
+                                            d[k] = nd; rk[k] = mw_f32_up(nd - pj[k]);
+                                            cpred[tid + k * BS] = i;
+                                            if ((nd < hi || nd == lo) && !((sinkb >> k) & 1u)) pend |= 1u << k;
+                                        }
+                                    }
                             }
                         }
                     }
@@ -649,7 +704,7 @@ __global__ __launch_bounds__(64 * NW) void lap_jvmw_kernel(JvArgs a) {
                 ++my_buckets;
 #endif
                 if (sj != 0x7fffffff && sv < INFINITY) { mu = sv; sink = sj & ~JV_OWNED; break; }
-                if (nnew < MW_BUCKET_LO) bwidth *= 4.0;
+                if (nnew < MW_BUCKET_LO) bwidth *= MW_BUCKET_UP;
                 else if (nnew > MW_BUCKET_HI) bwidth = fmax(bwidth * 0.5, bdelta * 1e-3);      // (never down to zero: it could not grow again)
                 lo = bv;
                 if (bj == 0x7fffffff) { unsolved = true; break; }
@@ -711,7 +766,7 @@ __global__ __launch_bounds__(64 * NW) void lap_jvmw_kernel(JvArgs a) {
     if (wv != 0) my_steps = 0;                             // every wave counted the same steps
     MWP_ADD(4, MWP_NOW() - tp_);
 #ifdef REART_PRUNE_PHASE
-    if (tid == 0) { sh.conflicts = min(my_relax >> 4, 0xffff); sh.arr = (my_rounds & 0xfff) | (min(my_buckets, 0xfff) << 12); }
+    if (tid == 0) { sh.conflicts = min(my_relax >> 4, 0xffff); sh.arr = min(my_rounds, 0xfff) | (min(my_buckets, 0xfff) << 12); }
     __syncthreads();
     my_arr = 0; my_conf = 0;
 #endif
@@ -1089,8 +1144,8 @@ __global__ __launch_bounds__(512) void lap_mc_forest_kernel(JvArgs a) {
         joined += nnew;
         off = fmax(off, mxo);
         lo = mn;
-        if (nnew < MW_BUCKET_LO) bw *= 4.0;
-        else if (nnew > MW_BUCKET_HI) bw = fmax(bw * 0.5, fdelta * 1e-3);                      // (never down to zero: it could not grow again)
+        if (nnew < MW_FOREST_LO) bw *= 4.0;
+        else if (nnew > MW_FOREST_HI) bw = fmax(bw * 0.5, fdelta * 1e-3);                      // (never down to zero: it could not grow again)
     }
     nf = nf0 + joined;
     // the roots of the rows that joined: their parents' (pointer jumping over the parent links; a tree's first columns carry

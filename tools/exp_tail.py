@@ -4,8 +4,9 @@ Runs the README recipe's assignment phase on the nao demo (MODE=recipe: 9 x 1024
 the kinematic projection that follows it (MODE=projection: README.md:125, 9 x 2048^2 every iteration), times every solve with
 HIP events, keeps the solver's per-problem statistics and the state every solve started from, and prints
   * percentiles of the solve time, * how the time follows the statistics, * the slowest solves with their statistics;
-DUMP=path.npz stores the inputs of the KEEP slowest solves (source points, previous columns and potentials; targets once) so
-that a solver variant can be replayed on exactly those problems (tools/replay_tail.py).
+DUMP=path.npz stores the inputs of the KEEP slowest solves and of SAMPLE solves evenly spaced over the run (source points,
+previous columns and potentials; targets once) so that a solver variant can be replayed on exactly those problems
+(tools/replay_tail.py: the loops' trajectories are chaotic, two runs of a loop never compare the same problems).
 Usage: gpurun -- 'MODE=recipe ITERS=15000 python tools/exp_tail.py'"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,6 +15,7 @@ import numpy as np, torch
 MODE = os.environ.get("MODE", "recipe")
 KEEP = int(os.environ.get("KEEP", 24))
 DUMP = os.environ.get("DUMP", "")
+SAMPLE = int(os.environ.get("SAMPLE", 0))      # DUMP also keeps this many solves evenly spaced over the run (the typical ones)
 dev = torch.device("cuda:0")
 
 
@@ -62,6 +64,8 @@ def table(ms, raw, form_note):
     order = np.argsort(-ms)[:KEEP]
     for s in order[:12]:
         print(f"  {s:6d} | {ms[s]:7.3f} | " + " ".join(f"{freed[s, b]}/{left[s, b]}/{steps[s, b]}/{back[s, b]}/{arr[s, b]}" for b in range(raw.shape[1])))
+    if SAMPLE:
+        order = np.concatenate([order, np.linspace(0, len(ms) - 1, SAMPLE).astype(np.int64)])
     return order, seq
 
 
