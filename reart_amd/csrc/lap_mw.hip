@@ -151,6 +151,13 @@ typedef float mw_f4 __attribute__((ext_vector_type(4)));
 // x rounded to fp32 so that the result is not below it (finite x, +inf): (float)(x (1 +- 2^-23)) >= x whatever the conversion's rounding
 __device__ __forceinline__ float mw_f32_up(double x) { return (float)(x + fabs(x) * 1.1920928955078125e-07); }
 
+#define MW_FILTER_K 1.00000095367431640625       // 1 + 2^-20: see the bucket rounds' filter
+// the filter's squared distance: one product and two fused multiply-adds per pair of columns (an estimate within 2^-22 of the
+// expression of the costs, which is never contracted)
+__device__ __forceinline__ jv_f2 mw_sq_estimate(jv_f2 dx, jv_f2 dy, jv_f2 dz) {
+#pragma clang fp contract(fast)
+    return dx * dx + dy * dy + dz * dz;
+}
 // this lane's CPL costs of row (ax, ay, az): reart_cdist's expression, two columns per packed-fp32 operand
 template <int CPL>
 __device__ __forceinline__ void mw_row_costs(float ax, float ay, float az, const jv_f2 (&tcx)[CPL / 2], const jv_f2 (&tcy)[CPL / 2],
@@ -538,9 +545,9 @@ __global__ __launch_bounds__(64 * NW) void lap_jvmw_kernel(JvArgs a) {
             double lo = INFINITY;
             bool first = true;
             const double bdelta = mx * 1e-12;
-            float rk[CPT];                                    // d - p of the unsettled columns rounded UP to fp32 (settled: -inf, never a candidate)
+            float rk[CPT];                                    // (d - p)(1 + 2^-20) of the unsettled columns rounded UP to fp32 (settled: -inf, never a candidate)
 #pragma unroll
-            for (int k = 0; k < CPT; ++k) rk[k] = ((scanned >> k) & 1u) ? -INFINITY : mw_f32_up(d[k] - pj[k]);
+            for (int k = 0; k < CPT; ++k) rk[k] = ((scanned >> k) & 1u) ? -INFINITY : mw_f32_up((d[k] - pj[k]) * MW_FILTER_K);
             for (;;) {
                 // closing reductions of the previous bucket double as the opening of this one: the closest unlabelled column
                 double bv = INFINITY;
@@ -583,7 +590,7 @@ __global__ __launch_bounds__(64 * NW) void lap_jvmw_kernel(JvArgs a) {
                                 const int j = tid + k * BS, i = owner[j];
                                 const double h = hcol[j];
                                 s_e4[buf][at][0] = psx[i]; s_e4[buf][at][1] = psy[i]; s_e4[buf][at][2] = psz[i];
-                                s_e4[buf][at][3] = mw_f32_up((h - d[k]) + bdelta);
+                                s_e4[buf][at][3] = mw_f32_up(((h - d[k]) + bdelta) * MW_FILTER_K);
                                 s_eg[buf][at][0] = d[k]; s_eg[buf][at][1] = h; s_ei[buf][at] = i;
                                 pend &= ~(1u << k);
                             }
@@ -601,62 +608,51 @@ __global__ __launch_bounds__(64 * NW) void lap_jvmw_kernel(JvArgs a) {
 #endif
                     // The label of column k improves through entry e iff c < (d - p) + (h - df) =: T (in exact arithmetic).  Nearly no
                     // (entry, column) pair does, and the square root and the double-precision sums are most of the work: a pair whose
-                    // squared distance exceeds T^2 by more than every rounding on the way is skipped -- T from the two fp32 UPPER
-                    // bounds (bdelta, 1e-12 of the cost scale, covers the <= 1e-15 of the double sums; the factor 1 + 2^-20 the
-                    // fp32 sum, the two products and the 2^-24 of the fp32 root), two columns per packed operand, two entries in
-                    // flight.  The pairs that pass take the expression itself, in the entries' order.
+                    // squared distance exceeds T^2 by more than every rounding on the way is skipped.  The test is all fp32, two
+                    // columns per packed operand, two entries in flight: T from two UPPER bounds (column: d - p, entry: h - df +
+                    // bdelta -- 1e-12 of the cost scale, which covers the <= 1e-15 of the double sums), both times 1 + 2^-20 (which
+                    // covers the fp32 sum, the square, the estimate's own roundings and the 2^-24 of the fp32 root); the squared
+                    // distance as an ESTIMATE with fused multiply-adds (the cost itself never is: common.h); T |T| instead of
+                    // T > 0 && T^2.  The pairs that pass take the expression itself, in the entries' order.
                     for (int e = 0; e < ne; e += 2) {
                         const mw_f4 E0 = *(const mw_f4 *)s_e4[buf][e];
                         mw_f4 E1 = *(const mw_f4 *)s_e4[buf][e + 1 < MW_BK ? e + 1 : e];
                         if (e + 1 >= ne) E1.w = -INFINITY;             // (odd count: the slot behind the list holds an older round's entry)
-                        unsigned pass0 = 0u, pass1 = 0u;
+                        float s0[CPT], s1[CPT], Q0[CPT], Q1[CPT];
                         if (CPT % 2 == 0) {
 #pragma unroll
                             for (int k = 0; k < CPT / 2 * 2; k += 2) {
                                 const jv_f2 cx = {qx[k], qx[k + 1]}, cy = {qy[k], qy[k + 1]}, cz = {qz[k], qz[k + 1]}, r2 = {rk[k], rk[k + 1]};
-                                {
-                                    const jv_f2 ax = {E0.x, E0.x}, ay = {E0.y, E0.y}, az = {E0.z, E0.z}, g2 = {E0.w, E0.w};
-                                    const jv_f2 dx = ax - cx, dy = ay - cy, dz = az - cz;
-                                    const jv_f2 sq = (dx * dx + dy * dy) + dz * dz;
-                                    const jv_f2 T = r2 + g2, Tq = T * 1.00000095367431640625f, Q = Tq * Tq;
-                                    if (T.x > 0.0f && sq.x <= Q.x) pass0 |= 1u << k;
-                                    if (T.y > 0.0f && sq.y <= Q.y) pass0 |= 2u << k;
-                                }
-                                {
-                                    const jv_f2 ax = {E1.x, E1.x}, ay = {E1.y, E1.y}, az = {E1.z, E1.z}, g2 = {E1.w, E1.w};
-                                    const jv_f2 dx = ax - cx, dy = ay - cy, dz = az - cz;
-                                    const jv_f2 sq = (dx * dx + dy * dy) + dz * dz;
-                                    const jv_f2 T = r2 + g2, Tq = T * 1.00000095367431640625f, Q = Tq * Tq;
-                                    if (T.x > 0.0f && sq.x <= Q.x) pass1 |= 1u << k;
-                                    if (T.y > 0.0f && sq.y <= Q.y) pass1 |= 2u << k;
-                                }
+                                const jv_f2 a = mw_sq_estimate(E0.x - cx, E0.y - cy, E0.z - cz), b = mw_sq_estimate(E1.x - cx, E1.y - cy, E1.z - cz);
+                                const jv_f2 T = r2 + E0.w, U = r2 + E1.w;
+                                s0[k] = a.x; s0[k + 1] = a.y; s1[k] = b.x; s1[k + 1] = b.y;
+                                Q0[k] = T.x * fabsf(T.x); Q0[k + 1] = T.y * fabsf(T.y); Q1[k] = U.x * fabsf(U.x); Q1[k + 1] = U.y * fabsf(U.y);
                             }
                         } else {
 #pragma unroll
                             for (int k = 0; k < CPT; ++k) {
-                                const float s0 = reart_sqdist3(E0.x, E0.y, E0.z, qx[k], qy[k], qz[k]), s1 = reart_sqdist3(E1.x, E1.y, E1.z, qx[k], qy[k], qz[k]);
-                                const float T0 = rk[k] + E0.w, T1 = rk[k] + E1.w;
-                                const float q0 = T0 * 1.00000095367431640625f, q1 = T1 * 1.00000095367431640625f;
-                                if (T0 > 0.0f && s0 <= q0 * q0) pass0 |= 1u << k;
-                                if (T1 > 0.0f && s1 <= q1 * q1) pass1 |= 1u << k;
+                                s0[k] = reart_sqdist3(E0.x, E0.y, E0.z, qx[k], qy[k], qz[k]); s1[k] = reart_sqdist3(E1.x, E1.y, E1.z, qx[k], qy[k], qz[k]);
+                                const float T = rk[k] + E0.w, U = rk[k] + E1.w;
+                                Q0[k] = T * fabsf(T); Q1[k] = U * fabsf(U);
                             }
                         }
+                        bool any = false;
 #pragma unroll
-                        for (int u = 0; u < 2; ++u) {
-                            const unsigned pass = u ? pass1 : pass0;
-                            if (pass) {
+                        for (int k = 0; k < CPT; ++k) any |= (s0[k] <= Q0[k]) | (s1[k] <= Q1[k]);
+                        if (any) {
+#pragma unroll
+                            for (int u = 0; u < 2; ++u) {
                                 const mw_f4 E = u ? E1 : E0;
-                                const double df = s_eg[buf][e + u][0], h = s_eg[buf][e + u][1];
-                                const int i = s_ei[buf][e + u];
 #pragma unroll
                                 for (int k = 0; k < CPT; ++k)
-                                    if ((pass >> k) & 1u) {
+                                    if (u ? s1[k] <= Q1[k] : s0[k] <= Q0[k]) {
+                                        const double df = s_eg[buf][e + u][0], h = s_eg[buf][e + u][1];
                                         double w = ((double)mw_sqrt(reart_sqdist3(E.x, E.y, E.z, qx[k], qy[k], qz[k])) + pj[k]) - h;
                                         w = w > 0.0 ? w : 0.0;
                                         const double nd = df + w;
                                         if (nd < d[k]) {
-                                            d[k] = nd; rk[k] = mw_f32_up(nd - pj[k]);
-                                            cpred[tid + k * BS] = i;
+                                            d[k] = nd; rk[k] = mw_f32_up((nd - pj[k]) * MW_FILTER_K);
+                                            cpred[tid + k * BS] = s_ei[buf][e + u];
                                             if ((nd < hi || nd == lo) && !((sinkb >> k) & 1u)) pend |= 1u << k;
                                         }
                                     }
