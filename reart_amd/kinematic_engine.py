@@ -20,8 +20,8 @@ from .utils.kinematic_utils import _effective_joint_values
 class KinematicEngine:
     """State of one kinematic projection on one GPU.
 
-    ``model``: a ``KinematicModel`` without root motion whose ``axis_list`` / ``moment_list`` / ``theta_list`` (and
-    ``distance_list``) are optimised IN PLACE; ``cano_pc`` [N,3], ``pc_list`` [T-1,N,3]; ``pc_ref_list`` / ``flow_ref_list``:
+    ``model``: a ``KinematicModel`` (any joint types; with or without root motion, networks/model.py:113-166) whose ``axis_list`` /
+    ``moment_list`` / ``theta_list`` (and ``distance_list``, ``root_6d``, ``root_t``) are optimised IN PLACE; ``cano_pc`` [N,3], ``pc_list`` [T-1,N,3]; ``pc_ref_list`` / ``flow_ref_list``:
     the flow references of run_robot.py:81-84 or None.  Hyper-parameters carry the reference's flag names
     (run_robot.py:362-420): ``trans_lr`` (Adam lr of every kinematic parameter, :150-151), ``weight_decay``,
     ``use_assign_loss`` / ``assign_iter`` / ``assign_gap`` / ``downsample`` / ``lambda_assign``, ``lambda_flow``,
@@ -33,10 +33,14 @@ class KinematicEngine:
                  weight_decay=0.0, assign_iter=0, assign_gap=5, downsample=4, lambda_assign=3e-1, lambda_flow=1.0,
                  use_robust_loss=False, smooth_weight=1e-2, knn_squared=False, use_assign_loss=True):
         _lib.require_gpu(cano_pc, pc_list)
-        if hasattr(model, "root_6d"):
-            raise NotImplementedError("root motion (run_real / run_sapien variant) goes through OperatorLoop")
+        self.root = hasattr(model, "root_6d") and hasattr(model, "root_t")      # networks/model.py:153-158
+        self._pris = None
         if model.joint_type_list is not None:
-            raise NotImplementedError("mixed joint types go through OperatorLoop")
+            # utils/kinematic_utils.py:174-186: prismatic joints run with theta = 1e-6 and their distance, revolute joints with
+            # their theta and distance = 1e-6; the masked entries take no gradient (torch.where's backward in the autograd loop)
+            if not hasattr(model, "distance_list"):
+                raise NotImplementedError("joint types without distance_list")
+            self._pris = torch.tensor([jt == "prismatic" for jt in model.joint_type_list], device=cano_pc.device)[None, :]
         self.model, self.dev = model, cano_pc.device
         self.cano = cano_pc.contiguous().float()
         self.pc_list = pc_list.contiguous().float()
@@ -80,6 +84,9 @@ class KinematicEngine:
         self.trans = torch.empty((self.B, self.P, 4, 4), dtype=torch.float32, device=self.dev)
         self.pc_trans = torch.empty((self.B, self.N, 3), dtype=torch.float32, device=self.dev)
         self.G = torch.zeros((self.B, self.N, 3), dtype=torch.float32, device=self.dev)
+        # root motion: the articulated cloud before the per-frame rigid motion, and dL/d of it
+        self.pc_fk = torch.empty_like(self.pc_trans) if self.root else self.pc_trans
+        self.G_fk = torch.empty_like(self.G) if self.root else self.G
         self.losses = {}
         self._pc_src, self._inplace, self._g_pre, self._g_post = None, None, None, None
         self._side = None
@@ -88,7 +95,11 @@ class KinematicEngine:
     def _joint_values(self):
         m = self.model
         dist = m.distance_list if hasattr(m, "distance_list") else None
-        return _effective_joint_values(m.theta_list, dist, m.joint_type_list)
+        if self._pris is None:
+            return _effective_joint_values(m.theta_list, dist, None)
+        # (the mask is built once: _effective_joint_values uploads it on every call, which a captured graph cannot hold)
+        return (torch.where(self._pris, torch.full_like(m.theta_list, 1e-6), m.theta_list).detach(),
+                torch.where(self._pris, dist, torch.full_like(dist, 1e-6)).detach())
 
     def forward(self):
         """pc_trans [T-1,N,3] and trans_list of the current parameters (no graph kept)."""
@@ -101,9 +112,50 @@ class KinematicEngine:
                                 _lib.ptr(self.trans), _lib.stream())
         _lib.check(rc, "reart_fk_forward")
         rc = L.reart_compute_pc_transform(_lib.ptr(self.cano), _lib.ptr(self.trans), _lib.ptr(self.part), self.N, self.P,
-                                          B, _lib.ptr(self.pc_trans), _lib.stream())
+                                          B, _lib.ptr(self.pc_fk), _lib.stream())
         _lib.check(rc, "reart_compute_pc_transform")
+        if self.root:                                     # networks/model.py:153-158: x R^T + t per frame
+            R = self._root_rotation()[0]
+            torch.baddbmm(m.root_t.detach()[:, None, :], self.pc_fk, R.transpose(1, 2), out=self.pc_trans)
         return self.pc_trans
+
+    def trans_list(self):
+        """The parts' transforms of the last forward, root motion included (what the model's forward returns third)."""
+        if not self.root:
+            return self.trans
+        root = torch.zeros((self.B, 4, 4), dtype=torch.float32, device=self.dev)
+        root[:, :3, :3], root[:, :3, 3], root[:, 3, 3] = self._root_rotation()[0], self.model.root_t.detach(), 1.0
+        return torch.matmul(root[:, None], self.trans)
+
+    def _root_rotation(self):
+        """R [T-1,3,3] of the 6-D parameters (Gram-Schmidt, rows b1, b2, b1 x b2) and what its backward needs."""
+        r6 = self.model.root_6d.detach()
+        a1, a2 = r6[:, :3], r6[:, 3:]
+        n1 = a1.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+        b1 = a1 / n1
+        s = (b1 * a2).sum(-1, keepdim=True)
+        v = a2 - s * b1
+        n2 = v.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+        b2 = v / n2
+        return torch.stack((b1, b2, torch.cross(b1, b2, dim=-1)), dim=-2), (a2, n1, b1, s, n2, b2)
+
+    def _root_backward(self):
+        """self.G = dL/d pc_trans -> gradients of root_6d / root_t, and self.G_fk = dL/d (the cloud before the root motion):
+        the hand-derived backward of x R^T + t and of the Gram-Schmidt step (autograd's in OperatorLoop)."""
+        m = self.model
+        R, (a2, n1, b1, s, n2, b2) = self._root_rotation()
+        self.grads[id(m.root_t)].copy_(self.G.sum(dim=1))
+        dR = torch.matmul(self.G.transpose(1, 2), self.pc_fk)           # [T-1,3,3]: rows = gradients of b1, b2, b3
+        torch.matmul(self.G, R, out=self.G_fk)
+        g1, g2, g3 = dR[:, 0], dR[:, 1], dR[:, 2]
+        g_b1 = g1 + torch.cross(b2, g3, dim=-1)                         # b3 = b1 x b2
+        g_b2 = g2 + torch.cross(g3, b1, dim=-1)
+        g_v = (g_b2 - (g_b2 * b2).sum(-1, keepdim=True) * b2) / n2      # b2 = v / |v|
+        gvb = (g_v * b1).sum(-1, keepdim=True)
+        g_a2 = g_v - gvb * b1                                           # v = a2 - (b1 . a2) b1
+        g_b1 = g_b1 - gvb * a2 - s * g_v
+        g_a1 = (g_b1 - (g_b1 * b1).sum(-1, keepdim=True) * b1) / n1     # b1 = a1 / |a1|
+        self.grads[id(m.root_6d)].copy_(torch.cat((g_a1, g_a2), dim=-1))
 
     def _backward(self):
         """dL/d pc_trans (self.G) -> gradients of axis / moment / theta (/ distance)."""
@@ -113,13 +165,18 @@ class KinematicEngine:
         B, E = theta.shape
         g_axis, g_moment, g_theta = self.grads[id(m.axis_list)], self.grads[id(m.moment_list)], self.grads[id(m.theta_list)]
         g_dist = self.grads[id(m.distance_list)] if hasattr(m, "distance_list") else None
+        if self.root:
+            self._root_backward()
         ws = _lib.workspace(L.reart_fk_backward_workspace_bytes(self.P, B, E), self.dev)
-        rc = L.reart_fk_backward(_lib.ptr(self.cano), _lib.ptr(self.part), _lib.ptr(self.G), self.N, _lib.ptr(self.parent),
+        rc = L.reart_fk_backward(_lib.ptr(self.cano), _lib.ptr(self.part), _lib.ptr(self.G_fk), self.N, _lib.ptr(self.parent),
                                  _lib.ptr(self.edge_of), _lib.ptr(self.order), self.P, _lib.ptr(m.axis_list),
                                  _lib.ptr(m.moment_list), _lib.ptr(theta), _lib.ptr(dist), B, E, _lib.ptr(self.trans),
                                  _lib.ptr(g_axis), _lib.ptr(g_moment), _lib.ptr(g_theta), _lib.ptr(g_dist), _lib.ptr(ws),
                                  ws.numel(), _lib.stream())
         _lib.check(rc, "reart_fk_backward")
+        if self._pris is not None:
+            g_theta.masked_fill_(self._pris, 0.0)
+            g_dist.masked_fill_(~self._pris, 0.0)
 
     def _adam(self):
         L = _lib.lib()

@@ -478,12 +478,12 @@ class OperatorLoop:
 
 
 def make_projection_loop(args, model, cano_pc, pc_list, pc_ref_list=None, flow_ref_list=None, tau_func=None):
-    """The loop object for phase 2: the autograd-free ``KinematicEngine`` for ``--model kinematic`` with revolute joints and
-    no root motion -- the projection as the reference's README runs it (``--use_assign_loss --assign_iter 0``) and, since
-    round 5, its Chamfer branch too (iterations before ``assign_iter``, runs without ``--use_assign_loss``); root motion,
-    mixed joint types and the base model outside the fused engine go through ``OperatorLoop`` (PyTorch autograd +
-    torch.optim.Adam over the same operators)."""
-    if args.model == "kinematic" and not hasattr(model, "root_6d") and model.joint_type_list is None:
+    """The loop object for phase 2: the autograd-free ``KinematicEngine`` for every ``--model kinematic`` run -- the projection
+    as the reference's README runs it (``--use_assign_loss --assign_iter 0``), its Chamfer branch (iterations before
+    ``assign_iter``, runs without ``--use_assign_loss``), mixed joint types and root motion (the SAPIEN / real-scan variant of
+    the model, networks/model.py:113-166); the base model outside the fused engine goes through ``OperatorLoop`` (PyTorch
+    autograd + torch.optim.Adam over the same operators), which also remains the engine's reference in the tests."""
+    if args.model == "kinematic":
         from reart_amd.kinematic_engine import KinematicEngine
 
         return KinematicEngine(model, cano_pc, pc_list, args.cano_idx, pc_ref_list if args.use_flow_loss else None,

@@ -165,3 +165,81 @@ def test_graph_replays_equal_the_eager_iterations(dev):
                     + [eng.lap_state["cols"].clone(), eng.matched.clone()] + [losses[key].clone() for key in sorted(losses)])
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+def _root_model(dev):
+    """The reference's SAPIEN / real-scan variant of the model (root motion, prismatic joints, distances) from the golden
+    tests/golden/kinematic_root.npz, as tests/test_kinematic_root_gpu.py builds it."""
+    from reart_amd.knn_cuda import KNN
+    from reart_amd.networks.model import KinematicModel
+    from reart_amd.utils.kinematic_utils import JointTree
+
+    g = np.load(os.path.join(G, "kinematic_root.npz"))
+    edges = list(zip(g["edge_child"].tolist(), g["edge_parent"].tolist()))
+    tree = JointTree([list(e) for e in edges], int(g["reverse_topo"][0]))
+    types = ["prismatic" if b else "revolute" for b in g["prismatic"]]
+    model = KinematicModel(pose_len=9, seg_part=t(g["seg_part"], dev), cano_pc=t(g["cano_pc"], dev), knn=KNN(k=1, transpose_mode=True),
+                           edge_index={f"{c}_{p}": k for k, (c, p) in enumerate(edges)}, paths_to_base=tree.paths_to_base,
+                           reverse_topo=g["reverse_topo"].tolist(), axis_list=t(g["axis"], dev), moment_list=t(g["moment"], dev),
+                           theta_list=t(g["theta"], dev), distance_list=t(g["distance"], dev), root_trans=t(g["root_trans"], dev),
+                           joint_type_list=types).to(dev)
+    return g, model
+
+
+def test_root_motion_and_joint_types_against_the_reference_golden(dev):
+    """KinematicEngine's forward and hand-derived backward for the model variant with root motion, prismatic joints and
+    distances (networks/model.py:113-166) against the reference's own class and autograd (kinematic_root.npz): forward 2e-6,
+    every gradient -- root_6d / root_t through the Gram-Schmidt step included -- 2e-4 of its largest entry."""
+    from reart_amd.kinematic_engine import KinematicEngine
+
+    g, model = _root_model(dev)
+    x = t(g["input_pc"], dev)
+    eng = KinematicEngine(model, x, x[None].expand(9, -1, -1).contiguous(), 2, downsample=4)
+    np.testing.assert_array_equal(eng.part.cpu().numpy(), g["seg"])
+    np.testing.assert_allclose(eng.forward().cpu().numpy(), g["out"], atol=2e-6)
+    np.testing.assert_allclose(eng.trans_list().cpu().numpy(), g["trans"], atol=2e-6)
+    eng.G.copy_(t(g["G"], dev))
+    eng._backward()
+    for name, key in (("axis_list", "g_axis"), ("moment_list", "g_moment"), ("theta_list", "g_theta"), ("distance_list", "g_distance"),
+                      ("root_6d", "g_root_6d"), ("root_t", "g_root_t")):
+        got, ref = eng.grads[id(getattr(model, name))].cpu().numpy(), g[key]
+        assert np.abs(got - ref).max() <= 2e-4 * max(1.0, np.abs(ref).max()), (name, np.abs(got - ref).max(), np.abs(ref).max())
+
+
+@pytest.mark.parametrize("with_flow", [True, False])
+def test_engine_with_root_motion_equals_the_autograd_loop(dev, with_flow):
+    """Six iterations of the assignment (+ flow) branch on the root-motion / mixed-joint variant: make_projection_loop hands it
+    to KinematicEngine; parameters (root_6d, root_t, distance_list included) and losses agree with OperatorLoop."""
+    from reart_amd import run_robot as rr
+    from reart_amd.kinematic_engine import KinematicEngine
+
+    g, m_eng = _root_model(dev)
+    _, m_ref = _root_model(dev)
+    cano = t(g["cano_pc"], dev)
+    rng = np.random.default_rng(5)
+    B, N = 9, cano.shape[0]
+    with torch.no_grad():
+        pcs = m_ref(cano)[0]
+    pcs = (pcs + t(rng.normal(0, 0.004, (B, N, 3)).astype(np.float32), dev)).contiguous()
+    pcs = torch.stack([p[torch.from_numpy(rng.permutation(N)).to(dev)] for p in pcs])
+    refs = flows = None
+    if with_flow:
+        comp = torch.cat((pcs[:2], cano[None], pcs[2:]), dim=0)
+        sel = [torch.from_numpy(rng.permutation(N)[:300 + 7 * f]).to(dev) for f in range(B)]
+        refs = [comp[f][s] for f, s in enumerate(sel)]
+        flows = [(comp[f + 1][s] - comp[f][s]) * 0.5 for f, s in enumerate(sel)]
+    argv = ["--model", "kinematic", "--use_assign_loss", "--assign_iter", "0", "--downsample", "4", "--assign_gap", "1",
+            "--cano_idx", "2"] + (["--use_flow_loss"] if with_flow else [])
+    a = rr.build_parser().parse_args(argv)
+    loop = rr.OperatorLoop(a, m_ref, cano, pcs, refs, flows)
+    eng = rr.make_projection_loop(a, m_eng, cano, pcs, refs, flows)
+    assert isinstance(eng, KinematicEngine) and eng.root
+    for i in range(6):
+        l_ref, l_eng = loop.iteration(i), eng.iteration(i)
+        for key in l_ref:
+            a_, b_ = float(l_ref[key].detach()), float(l_eng[key].detach())
+            assert abs(a_ - b_) <= 2e-5 * abs(a_) + 1e-7, (i, key, a_, b_)
+        for name in ("axis_list", "moment_list", "theta_list", "distance_list", "root_6d", "root_t"):
+            np.testing.assert_allclose(getattr(m_eng, name).detach().cpu().numpy(), getattr(m_ref, name).detach().cpu().numpy(),
+                                       rtol=0, atol=5e-6, err_msg=f"iteration {i} {name}")
+    assert eng.lap_fallbacks == 0 and loop.lap_fallbacks == 0
