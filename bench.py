@@ -586,7 +586,7 @@ def bench_nao_recipe(args, dev, keep=None):
         "roofline": {"bound": "latency", "achieved": round(bound_ms, 4), "peak": round(solve_ms, 4),
                      "unit": "ms per re-solve (floor / measured)", "frac": round(bound_ms / solve_ms, 4) if solve_ms > 0 else None,
                      "frac_search_only": round(float(st[:, 3].mean()) * floor_us.value * 1e-3 / solve_ms, 4) if st.size and solve_ms > 0 else None,
-                     "traffic": None, "kernel": "lap_jvmw_kernel<16,2,8> + forest/arr/trees/set-up/passes (assignment re-solve)",
+                     "traffic": None, "kernel": "lap_jvmw_kernel<16,2,16> + forest/arr/trees/set-up/passes (assignment re-solve)",
                      "kernel_ms": round(solve_ms, 4), "solves_measured": max(len(phase.events) - 1, 0),
                      **_pcts([e0.elapsed_time(e1) for e0, e1 in phase.events[1:]]),
                      "step_floor_us": round(floor_us.value, 4), "sequential_steps_slowest_problem": round(steps_max, 1),

@@ -452,7 +452,7 @@ __global__ __launch_bounds__(64 * NW) void lap_jvmw_kernel(JvArgs a) {
     // the barrier of round r - 1)
     // (an entry's hot part is ONE 16-byte broadcast read: the row's point and g = (its potential - its label), rounded UP to fp32;
     // the label and the potential themselves are read by the few pairs that pass the filter)
-    __shared__ __attribute__((aligned(16))) float s_e4[2][MW_BK][4];
+    __shared__ __attribute__((aligned(16))) float s_e4[2][MW_BK / 2][8];     // entries in PAIRS: x0 x1 y0 y1 z0 z1 g0 g1 -- packed operands as they are read
     __shared__ __attribute__((aligned(16))) double s_eg[2][MW_BK][2];
     __shared__ int s_ei[2][MW_BK], s_ecnt[3];
     __shared__ double s_bv[2][NW], s_bs[2][NW];
@@ -589,8 +589,9 @@ __global__ __launch_bounds__(64 * NW) void lap_jvmw_kernel(JvArgs a) {
                             if (want && at < MW_BK) {
                                 const int j = tid + k * BS, i = owner[j];
                                 const double h = hcol[j];
-                                s_e4[buf][at][0] = psx[i]; s_e4[buf][at][1] = psy[i]; s_e4[buf][at][2] = psz[i];
-                                s_e4[buf][at][3] = mw_f32_up(((h - d[k]) + bdelta) * MW_FILTER_K);
+                                float *rec = &s_e4[buf][at >> 1][at & 1];
+                                rec[0] = psx[i]; rec[2] = psy[i]; rec[4] = psz[i];
+                                rec[6] = mw_f32_up(((h - d[k]) + bdelta) * MW_FILTER_K);
                                 s_eg[buf][at][0] = d[k]; s_eg[buf][at][1] = h; s_ei[buf][at] = i;
                                 pend &= ~(1u << k);
                             }
@@ -613,28 +614,20 @@ __global__ __launch_bounds__(64 * NW) void lap_jvmw_kernel(JvArgs a) {
                     // bdelta -- 1e-12 of the cost scale, which covers the <= 1e-15 of the double sums), both times 1 + 2^-20 (which
                     // covers the fp32 sum, the square, the estimate's own roundings and the 2^-24 of the fp32 root); the squared
                     // distance as an ESTIMATE with fused multiply-adds (the cost itself never is: common.h); T |T| instead of
-                    // T > 0 && T^2.  The pairs that pass take the expression itself, in the entries' order.
+                    // T > 0 && T^2.  Two ENTRIES per packed operand (the lists hold them interleaved).  The pairs that pass take
+                    // the expression itself, in the entries' order.
                     for (int e = 0; e < ne; e += 2) {
-                        const mw_f4 E0 = *(const mw_f4 *)s_e4[buf][e];
-                        mw_f4 E1 = *(const mw_f4 *)s_e4[buf][e + 1 < MW_BK ? e + 1 : e];
-                        if (e + 1 >= ne) E1.w = -INFINITY;             // (odd count: the slot behind the list holds an older round's entry)
+                        const mw_f4 Exy = *(const mw_f4 *)&s_e4[buf][e >> 1][0];
+                        mw_f4 Ezg = *(const mw_f4 *)&s_e4[buf][e >> 1][4];
+                        if (e + 1 >= ne) Ezg.w = -INFINITY;            // (odd count: the record's second half holds an older round's entry)
+                        const jv_f2 ex = {Exy.x, Exy.y}, ey = {Exy.z, Exy.w}, ez = {Ezg.x, Ezg.y}, eg = {Ezg.z, Ezg.w};
                         float s0[CPT], s1[CPT], Q0[CPT], Q1[CPT];
-                        if (CPT % 2 == 0) {
 #pragma unroll
-                            for (int k = 0; k < CPT / 2 * 2; k += 2) {
-                                const jv_f2 cx = {qx[k], qx[k + 1]}, cy = {qy[k], qy[k + 1]}, cz = {qz[k], qz[k + 1]}, r2 = {rk[k], rk[k + 1]};
-                                const jv_f2 a = mw_sq_estimate(E0.x - cx, E0.y - cy, E0.z - cz), b = mw_sq_estimate(E1.x - cx, E1.y - cy, E1.z - cz);
-                                const jv_f2 T = r2 + E0.w, U = r2 + E1.w;
-                                s0[k] = a.x; s0[k + 1] = a.y; s1[k] = b.x; s1[k + 1] = b.y;
-                                Q0[k] = T.x * fabsf(T.x); Q0[k + 1] = T.y * fabsf(T.y); Q1[k] = U.x * fabsf(U.x); Q1[k + 1] = U.y * fabsf(U.y);
-                            }
-                        } else {
-#pragma unroll
-                            for (int k = 0; k < CPT; ++k) {
-                                s0[k] = reart_sqdist3(E0.x, E0.y, E0.z, qx[k], qy[k], qz[k]); s1[k] = reart_sqdist3(E1.x, E1.y, E1.z, qx[k], qy[k], qz[k]);
-                                const float T = rk[k] + E0.w, U = rk[k] + E1.w;
-                                Q0[k] = T * fabsf(T); Q1[k] = U * fabsf(U);
-                            }
+                        for (int k = 0; k < CPT; ++k) {                // the two ENTRIES are the packed pair: one form for any columns per thread
+                            const jv_f2 a = mw_sq_estimate(ex - qx[k], ey - qy[k], ez - qz[k]);
+                            const jv_f2 T = eg + rk[k];
+                            s0[k] = a.x; s1[k] = a.y;
+                            Q0[k] = T.x * fabsf(T.x); Q1[k] = T.y * fabsf(T.y);
                         }
                         bool any = false;
 #pragma unroll
@@ -642,12 +635,12 @@ __global__ __launch_bounds__(64 * NW) void lap_jvmw_kernel(JvArgs a) {
                         if (any) {
 #pragma unroll
                             for (int u = 0; u < 2; ++u) {
-                                const mw_f4 E = u ? E1 : E0;
+                                const float Ex = u ? ex.y : ex.x, Ey = u ? ey.y : ey.x, Ez = u ? ez.y : ez.x;
 #pragma unroll
                                 for (int k = 0; k < CPT; ++k)
                                     if (u ? s1[k] <= Q1[k] : s0[k] <= Q0[k]) {
                                         const double df = s_eg[buf][e + u][0], h = s_eg[buf][e + u][1];
-                                        double w = ((double)mw_sqrt(reart_sqdist3(E.x, E.y, E.z, qx[k], qy[k], qz[k])) + pj[k]) - h;
+                                        double w = ((double)mw_sqrt(reart_sqdist3(Ex, Ey, Ez, qx[k], qy[k], qz[k])) + pj[k]) - h;
                                         w = w > 0.0 ? w : 0.0;
                                         const double nd = df + w;
                                         if (nd < d[k]) {
@@ -1446,8 +1439,10 @@ static int mc_launch(const JvArgs &a, int racers, int arr_wgs, hipStream_t strea
         hipLaunchKernelGGL((lap_mc_forest_kernel<CPL>), dim3(a.B), dim3(512), flds, stream, s2);
         REART_CHECK_LAUNCH();
     }
-#define MW_SNW32 16          // waves of a search workgroup at 32 columns per lane (n > 1024): two columns per thread instead of four; projection 76.7 -> 79.0 it/s
-    constexpr int SNW = CPL == 32 ? MW_SNW32 : MW_NW;
+#define MW_SNW 16            // waves of a search workgroup from 16 columns per lane on (n > 512): two columns per thread at n = 2048 instead of four
+                             // (projection 76.7 -> 79.0 it/s, round 5), one at n = 1024 instead of two (replayed recipe solves: slowest 24 235 ->
+                             // 220 ms, sample 111 -> 108; four waves: 355) -- the rounds are bound by the instructions a SIMD issues
+    constexpr int SNW = CPL >= 16 ? MW_SNW : MW_NW;
     if (SNW != MW_NW && lds > REART_LDS_DEFAULT_CAP &&
         hipFuncSetAttribute((const void *)lap_jvmw_kernel<CPL, 2, SNW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return REART_ERR_LAUNCH;
