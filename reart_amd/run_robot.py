@@ -502,10 +502,16 @@ class SnapshotPrinter:
     iteration i (the reference uses the forward iteration i itself ran: one Adam step and one noise draw earlier).
     ``lines`` keeps the metrics of every snapshot; ``out``: where the lines go (default stdout)."""
 
-    def __init__(self, args, model, cano_pc, pc_list, sample=None, tau_func=None, out=None):
+    GRAPH = os.environ.get("REART_SNAPSHOT_GRAPH", "1") != "0"
+
+    def __init__(self, args, model, cano_pc, pc_list, sample=None, tau_func=None, out=None, graph=None):
         self.args, self.model, self.cano_pc, self.pc_list, self.sample = args, model, cano_pc, pc_list, sample
         self.tau_func, self.out = tau_func, out
         self.count, self.lines = 0, []
+        # the metrics are ~80 small launches (elementwise / reductions / one matrix product): from the third snapshot on they are
+        # ONE replay of a captured graph on copies of (seg_part, trans_list) -- README.md:125 prints 1 501 snapshots per run
+        self.graph = self.GRAPH if graph is None else bool(graph)
+        self._g = self._g_in = self._g_out = self._g_names = None
         # the ground truth the metrics compare with, on the device once (tail.snapshot_metrics would upload it at every snapshot)
         if sample is not None:
             keys = ("gt_flow_list", "gt_cano_part", "complete_gt_pc_list")
@@ -529,7 +535,7 @@ class SnapshotPrinter:
                   file=out)
         seg_part, trans_list = self.state(i)
         has_gt = self.sample is not None and any(k in self.sample for k in ("gt_flow_list", "gt_cano_part", "complete_gt_pc_list"))
-        m = tail.snapshot_metrics(self.cano_pc, self.pc_list, seg_part, trans_list, self.args.cano_idx, self.sample, chamfer=False) if has_gt else {}
+        m = self._metrics(seg_part, trans_list) if has_gt else {}
         if "epe" in m:
             print(f"Flow eval: EPE: {m['epe']:.3f} | Acc 5: {m['acc5']:.3f} | Acc 10: {m['acc10']:.3f} | Angle: {m['angle']:.3f}", file=out)
         if "ri" in m:
@@ -539,6 +545,31 @@ class SnapshotPrinter:
         self.count += 1
         self.lines.append((i, m))
         return m
+
+    def _metrics(self, seg_part, trans_list):
+        from reart_amd import tail
+
+        c = self.args.cano_idx
+        if not self.graph or self.count < 2:
+            return tail.snapshot_metrics(self.cano_pc, self.pc_list, seg_part, trans_list, c, self.sample, chamfer=False)
+        if self._g is None:
+            try:
+                self._g_in = (seg_part.clone(), trans_list.clone())
+                g = torch.cuda.CUDAGraph()
+                torch.cuda.synchronize()
+                with torch.cuda.graph(g):
+                    self._g_names, self._g_out = tail.snapshot_values(self.cano_pc, self._g_in[0], self._g_in[1], c, self.sample)
+                self._g = g
+            except Exception:           # a capture the runtime refuses: the eager form from here on
+                self.graph, self._g = False, None
+                torch.cuda.synchronize()
+                return tail.snapshot_metrics(self.cano_pc, self.pc_list, seg_part, trans_list, c, self.sample, chamfer=False)
+        if seg_part.shape != self._g_in[0].shape or trans_list.shape != self._g_in[1].shape:
+            return tail.snapshot_metrics(self.cano_pc, self.pc_list, seg_part, trans_list, c, self.sample, chamfer=False)
+        self._g_in[0].copy_(seg_part)
+        self._g_in[1].copy_(trans_list)
+        self._g.replay()
+        return tail.snapshot_scaled(self._g_names, self._g_out.cpu().tolist()) if self._g_out is not None else {}
 
 
 def build_kinematic_from_base(result, cano_pc, pc_list, args):

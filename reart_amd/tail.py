@@ -44,15 +44,11 @@ def energy_terms(cano_pc, pc_list, seg_part, trans_list, joint_connection, cano_
                 lap_fallbacks=getattr(compute_ass_err, "last_fallbacks", 0))     # assignment problems solved on the host: 0 = none
 
 
-def snapshot_metrics(cano_pc, pc_list, seg_part, trans_list, cano_idx, sample=None, chamfer=True):
-    """-> dict with cd_err (``chamfer``: the value is printed at the end of a run only, run_robot.py:316) and, when ``sample``
-    carries the ground truth, epe / acc5 / acc10 / angle / ri / recon_err (run_robot.py:245-266; centimetre scaling as there).
-    All of it is computed on the device and read with ONE copy (a run prints hundreds of snapshots)."""
-    pred = compute_pc_transform(cano_pc, trans_list, seg_part)
-    out = dict(cd_err=100 * compute_chamfer_list(pred, pc_list, reduction="mean")) if chamfer else {}
-    if sample is None:
-        return out
+def snapshot_values(cano_pc, seg_part, trans_list, cano_idx, sample):
+    """The ground-truth metrics of a snapshot as ONE device tensor: -> (names, [len(names)] float64 tensor), no host sync and no
+    data-dependent shape (a loop that prints hundreds of snapshots replays this from a captured graph: SnapshotPrinter)."""
     dev = cano_pc.device
+    pred = compute_pc_transform(cano_pc, trans_list, seg_part)
     complete = torch.cat((pred[:cano_idx], cano_pc[None], pred[cano_idx:]), dim=0)
     vals, names = [], []
     if "gt_flow_list" in sample:
@@ -66,10 +62,27 @@ def snapshot_metrics(cano_pc, pc_list, seg_part, trans_list, cano_idx, sample=No
         gt = torch.as_tensor(sample["complete_gt_pc_list"]).float().to(dev)
         vals.append(((complete - gt) ** 2).sum(-1).sqrt().mean(1).mean())
         names.append("recon_err")
-    if vals:
-        host = torch.stack([v.double().reshape(()) for v in vals]).cpu().tolist()
-        for k, v in zip(names, host):
-            out[k] = 100 * v if k in ("epe", "recon_err") else v
+    return names, (torch.stack([v.double().reshape(()) for v in vals]) if vals else None)
+
+
+def snapshot_scaled(names, host_values):
+    """run_robot.py:245-266: centimetre scaling of the end-point and reconstruction errors."""
+    return {k: 100 * v if k in ("epe", "recon_err") else v for k, v in zip(names, host_values)}
+
+
+def snapshot_metrics(cano_pc, pc_list, seg_part, trans_list, cano_idx, sample=None, chamfer=True):
+    """-> dict with cd_err (``chamfer``: the value is printed at the end of a run only, run_robot.py:316) and, when ``sample``
+    carries the ground truth, epe / acc5 / acc10 / angle / ri / recon_err (run_robot.py:245-266; centimetre scaling as there).
+    All of it is computed on the device and read with ONE copy (a run prints hundreds of snapshots)."""
+    out = {}
+    if chamfer:
+        pred = compute_pc_transform(cano_pc, trans_list, seg_part)
+        out["cd_err"] = 100 * compute_chamfer_list(pred, pc_list, reduction="mean")
+    if sample is None:
+        return out
+    names, vals = snapshot_values(cano_pc, seg_part, trans_list, cano_idx, sample)
+    if vals is not None:
+        out.update(snapshot_scaled(names, vals.cpu().tolist()))
     return out
 
 

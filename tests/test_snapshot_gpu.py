@@ -66,3 +66,42 @@ def test_snapshot_lines_of_the_drop_in_loop(dev, tmp_path, capsys):
     sp = SnapshotPrinter(args, model, cano, pcs, sample)
     got = sp(30, {"total Loss": torch.tensor(1.0)})
     assert sp.count == 1 and abs(got["epe"] - m["epe"]) < 1e-6 and sp.lines[0][0] == 30
+
+
+def test_graph_replays_of_the_metrics_equal_the_eager_form(dev):
+    """From its third snapshot on the printer replays the metrics from ONE captured graph (on copies of the labels and the
+    transforms): the values of every later snapshot equal tail.snapshot_metrics on the same state."""
+    import argparse
+    import io
+
+    import numpy as np
+    from reart_amd import tail
+    from reart_amd.run_robot import SnapshotPrinter
+
+    rng = np.random.default_rng(0)
+    N, B, P = 2048, 5, 6
+    cano = torch.from_numpy(rng.normal(size=(N, 3)).astype(np.float32)).to(dev)
+    pcs = torch.from_numpy(rng.normal(size=(B, N, 3)).astype(np.float32)).to(dev)
+    sample = dict(gt_flow_list=rng.normal(scale=0.05, size=(B, N, 3)).astype(np.float32), gt_cano_part=rng.integers(0, P, N),
+                  complete_gt_pc_list=rng.normal(size=(B + 1, N, 3)).astype(np.float32))
+
+    class Model(torch.nn.Module):                      # a model whose state the test moves between snapshots
+        def forward(self, x, **kw):
+            return None, self.seg, self.trans
+
+    def state(k):
+        r = np.random.default_rng(100 + k)
+        tr = np.tile(np.eye(4, dtype=np.float32), (B, P, 1, 1))
+        tr[:, :, :3, 3] = r.normal(scale=0.1, size=(B, P, 3))
+        return torch.from_numpy(r.integers(0, P, N)).to(dev), torch.from_numpy(tr).to(dev)
+
+    model = Model()
+    sp = SnapshotPrinter(argparse.Namespace(model="kinematic", cano_idx=2), model, cano, pcs, sample, out=io.StringIO(), graph=True)
+    for k in range(6):
+        model.seg, model.trans = state(k)
+        got = sp(k, {})
+        ref = tail.snapshot_metrics(cano, pcs, model.seg, model.trans, 2, sample, chamfer=False)
+        assert set(got) == set(ref) == {"epe", "acc5", "acc10", "angle", "ri", "recon_err"}
+        for key in ref:
+            assert got[key] == ref[key], (k, key, got[key], ref[key])
+    assert sp.graph and sp._g is not None               # the capture was taken, not refused
