@@ -45,6 +45,12 @@ f=$(find $O/trace_projection -name "*kernel_trace.csv" | head -1)
 timeout 900 python3 tools/run_nao.py --projection > $O/run_nao_projection.txt 2> $O/run_nao_projection.err
 MODE=recipe timeout 400 python3 tools/exp_tail.py 2>/dev/null | grep -v amdgpu.ids > $O/exp_tail_recipe.txt
 MODE=projection P_ITERS=3000 timeout 400 python3 tools/exp_tail.py 2>/dev/null | grep -v "amdgpu.ids\|joint types" > $O/exp_tail_projection.txt
+# 3d. the re-solve on DUMPED solves (tools/exp_tail.py DUMP=... SAMPLE=40 -> tools/_states/, not in the history: 28 MB): the SAME
+#     problems through a library built from lap_mw.hip as the round found it (libreart_hip_old.so, built here from the history:
+#     git show <round start>:reart_amd/csrc/lap_mw.hip, see tools/mk_variant.sh) and through the product library
+if [ -f reart_amd/csrc/libreart_hip_old.so ] && [ -f tools/_states/r05s_recipe.npz ]; then
+  TAGS="old base old base" timeout 900 tools/ab_tags.sh > $O/replay_tail_ab.txt 2>&1
+fi
 # 3c. workgroup lifetimes of the four small kernels of the headline step (diagnostic build: device clocks)
 make -C reart_amd/csrc stats > /dev/null 2>&1
 REART_LIB=reart_amd/csrc/libreart_hip_stats.so timeout 120 python3 tools/phase_clock.py 2>/dev/null | tail -7 > $O/small_kernel_clocks.txt
