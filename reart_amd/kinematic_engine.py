@@ -74,7 +74,11 @@ class KinematicEngine:
         zero = torch.zeros(1, dtype=torch.long, device=self.dev)
         self.src_idx = farthest_point_sample(self.cano[None], num_fps, start=zero, cuda_mode=True)[0]          # [n]
         tgt_idx = farthest_point_sample(self.pc_list, num_fps, start=zero.expand(self.B), cuda_mode=True)
-        self.tgt_pts = index_points(self.pc_list, tgt_idx).contiguous()                                         # [B,n,3]
+        # the sampled targets are the COLUMNS of every re-solve of the run: numbered along a Z-order curve (lap.spatial_order)
+        from .utils.lap import spatial_order
+        self.tgt_order = spatial_order(index_points(self.pc_list, tgt_idx))                                     # [B,n] into the FPS order
+        self.tgt_idx = tgt_idx.gather(1, self.tgt_order)
+        self.tgt_pts = index_points(self.pc_list, self.tgt_idx).contiguous()                                    # [B,n,3]
         self.matched = None
         self.lap_state = {}
         self.lap_solves = self.lap_fallbacks = 0

@@ -103,7 +103,12 @@ class AssignmentPhase:
         self.n = N // downsample
         zero = torch.zeros(1, dtype=torch.long, device=device)
         self.src_idx = farthest_point_sample(cano_pc[None], self.n, start=zero, cuda_mode=True)                      # [1, n]
-        self.tgt_idx = farthest_point_sample(pc_list, self.n, start=zero.expand(self.B), cuda_mode=True)             # [B, n]
+        tgt_fps = farthest_point_sample(pc_list, self.n, start=zero.expand(self.B), cuda_mode=True)                  # [B, n]
+        # the sampled targets are the COLUMNS of every refresh: numbered along a Z-order curve (lap.spatial_order: the searches'
+        # waves then hold neighbouring columns); the pairs a refresh returns are the same whatever the numbering
+        from reart_amd.utils.lap import spatial_order
+        self.tgt_order = spatial_order(index_points(pc_list, tgt_fps))                                               # [B, n] into the FPS order
+        self.tgt_idx = tgt_fps.gather(1, self.tgt_order)
         self.tgt_pts = index_points(pc_list, self.tgt_idx).contiguous()
         self.lap_state = {}
         self.refreshes = self.fallbacks = 0

@@ -48,7 +48,10 @@ def test_base_recipe_assignment_phase_against_the_oracle_loop(oracle, dev):
     src_o = oracle.fps(cano[None], n, start=np.zeros(1, np.int64), cuda_mode=True)[0]
     tgt_o = oracle.fps(pcs, n, start=np.zeros(B, np.int64), cuda_mode=True)
     np.testing.assert_array_equal(phase.src_idx.cpu().numpy()[0], src_o)
-    np.testing.assert_array_equal(phase.tgt_idx.cpu().numpy(), tgt_o)
+    # ... the targets then re-numbered along a Z-order curve (lap.spatial_order): a permutation of the reference's sample
+    order = phase.tgt_order.cpu().numpy()
+    np.testing.assert_array_equal(np.sort(order, axis=1), np.tile(np.arange(n), (B, 1)))
+    np.testing.assert_array_equal(phase.tgt_idx.cpu().numpy(), np.take_along_axis(tgt_o, order, axis=1))
     tgt_pts_o = np.stack([pcs[b][tgt_o[b]] for b in range(B)])
     assign = None
     for i in range(2 * gap + 1):
@@ -64,7 +67,9 @@ def test_base_recipe_assignment_phase_against_the_oracle_loop(oracle, dev):
             cols_o = np.stack([cc for _, cc in oracle.linear_sum_assignment(cost)])          # scipy, like the reference
             assign = (src_o, np.take_along_axis(tgt_o, cols_o, axis=1), lam)
             phase.refresh()
-            np.testing.assert_array_equal(phase.lap_state["cols"].cpu().numpy(), cols_o, err_msg=f"refresh at iteration {i}")
+            # (the solver's columns are in the phase's numbering: back to the reference's sample order)
+            np.testing.assert_array_equal(np.take_along_axis(order, phase.lap_state["cols"].cpu().numpy().astype(np.int64), axis=1), cols_o,
+                                          err_msg=f"refresh at iteration {i}")
             assert phase.fallbacks == 0
         ref = orc.step(noise, assign=assign)
         eng.step()

@@ -18,14 +18,50 @@ KEEP = int(os.environ.get("KEEP", 24))          # the first KEEP dumped solves a
 
 def main(path):
     g = np.load(path)
-    tgt = torch.from_numpy(g["tgt"]).to(dev).contiguous()
+    tgt_h, cols_h, prices_h = g["tgt"], g["cols"], g["prices"]
     S, B, n = g["src"].shape[:3]
+    if os.environ.get("ORDER"):
+        # experiment: the COLUMNS (targets) of every problem re-numbered -- ORDER=morton: along a Z-order curve (the 64 columns of a
+        # wave become neighbours in space), ORDER=random: shuffled; the dumped state is re-numbered with them
+        perm = np.zeros((B, n), np.int64)
+        for b in range(B):
+            if os.environ["ORDER"] == "morton":
+                q = tgt_h[b] - tgt_h[b].min(0)
+                q = np.minimum((q / max(q.max(), 1e-30) * 1023).astype(np.int64), 1023)
+                code = np.zeros(n, np.int64)
+                for bit in range(10):
+                    for ax in range(3):
+                        code |= ((q[:, ax] >> bit) & 1) << (3 * bit + ax)
+                perm[b] = np.argsort(code, kind="stable")
+            else:
+                perm[b] = np.random.default_rng(b).permutation(n)
+        inv = np.zeros_like(perm)
+        for b in range(B):
+            inv[b, perm[b]] = np.arange(n)
+        tgt_h = np.stack([tgt_h[b][perm[b]] for b in range(B)])
+        prices_h = np.stack([np.stack([prices_h[s][b][perm[b]] for b in range(B)]) for s in range(S)])
+        cols_h = np.stack([np.stack([np.where(cols_h[s][b] >= 0, inv[b][np.maximum(cols_h[s][b], 0)], -1) for b in range(B)]) for s in range(S)]).astype(np.int32)
+    src_h = g["src"]
+    if os.environ.get("ROWS"):
+        # ... and the ROWS (source points) along a Z-order curve of their positions in the first dumped solve
+        def morton(pts):
+            q = pts - pts.min(0)
+            q = np.minimum((q / max(q.max(), 1e-30) * 1023).astype(np.int64), 1023)
+            code = np.zeros(len(pts), np.int64)
+            for bit in range(10):
+                for ax in range(3):
+                    code |= ((q[:, ax] >> bit) & 1) << (3 * bit + ax)
+            return np.argsort(code, kind="stable")
+        rperm = [morton(src_h[0][b]) for b in range(B)]
+        src_h = np.stack([np.stack([src_h[s][b][rperm[b]] for b in range(B)]) for s in range(S)])
+        cols_h = np.stack([np.stack([cols_h[s][b][rperm[b]] for b in range(B)]) for s in range(S)])
+    tgt = torch.from_numpy(tgt_h).to(dev).contiguous()
     solve = lap.InPlaceResolve(B, n, dev)
     ms, steps, cost, fbs = np.zeros((S, REPS)), np.zeros((S, B), np.int64), np.zeros(S), 0
     raws = np.zeros((S, B, 4), np.int64)
     for s in range(S):
-        src = torch.from_numpy(g["src"][s]).to(dev).contiguous()
-        cols0, prices0 = torch.from_numpy(g["cols"][s]).to(dev), torch.from_numpy(g["prices"][s]).to(dev)
+        src = torch.from_numpy(src_h[s]).to(dev).contiguous()
+        cols0, prices0 = torch.from_numpy(cols_h[s]).to(dev), torch.from_numpy(prices_h[s]).to(dev)
         for r in range(REPS + 1):               # one untimed pass first
             st = {"cols": cols0.clone(), "prices": prices0.clone()}
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
