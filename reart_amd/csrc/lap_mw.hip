@@ -32,16 +32,19 @@
 #define MW_CHECK 16          // a search looks at the race flag and at its labelled columns every MW_CHECK steps
 // A search that has not met a sink after MW_BUCKET_AFTER one-column steps goes on in BUCKETS (see the search loop): all
 // unlabelled columns within `width` of the closest one are settled together by label-correcting rounds.
-#define MW_BUCKET_AFTER 24   // (replayed solves, 16 / 24 / 32 / 48: 250 / 252 / 257 / 258 ms over the recipe's slowest 24, 545 / 545 / 542 / 555 over the projection's)
+#define MW_BUCKET_AFTER 8    // (replayed solves, columns in caller order, 16 / 24 / 32 / 48: 250 / 252 / 257 / 258 ms over the recipe's slowest 24; with the
+                             // columns along a Z-order curve -- see below -- and 4-24 buckets, 4 / 8 / 12 / 24 / 40: 189 / 190 / 192 / 197 / 206)
 #define MW_BUCKET_W0 1e-8    // first bucket width of a problem, as a fraction of the cost scale
 #define MW_BK 192            // columns relaxed from per round (the rest of a bucket waits for the next round); 12 KB of lists: two 1024-column workgroups per compute unit
 // (the three below were first set by whole-loop runs, whose trajectories are chaotic: 8 / 48 / 4.0.  On DUMPED solves replayed with
 // every variant, tools/replay_tail.py, same box -- recipe slowest 24 / recipe sample 40 / projection slowest 24 / projection
 // sample 40, ms: 8, 48: 359 / 127 / 796 / 207 | 4, 24: 311 / 118 / 657 / 186 | 2, 12: 272 / 117 / 575 / 177 | 2, 8: 276 / 117 /
 // 578 / 178 | 1, 6: 288 / 146 / 602 / 205 | 16, 96: 424 / 145 / 996 / 255; widening twofold: 259 / 116 / 555 / 178.  A wide bucket
-// relaxes from its members again and again: 2.6 entries per settled column at 8 / 48, 1.4 at 2 / 12.)
-#define MW_BUCKET_LO 2       // a bucket that closes with fewer columns than this widens the next one ...
-#define MW_BUCKET_HI 12      // ... with more than this, halves it
+// relaxes from its members again and again: 2.6 entries per settled column at 8 / 48, 1.4 at 2 / 12.  Since the loops number
+// their columns along a Z-order curve (lap.spatial_order: the exact path of a relaxation runs in one or two waves, an entry is
+// cheaper) the balance sits a little wider -- 2, 12: 198 / 101 / 398 / 143 | 3, 16: 193 / 97 / 398 / 139 | 4, 24: 195 / 95 / 402 / 139.)
+#define MW_BUCKET_LO 4       // a bucket that closes with fewer columns than this widens the next one ...
+#define MW_BUCKET_HI 24      // ... with more than this, halves it
 #define MW_BUCKET_UP 2.0
 #define MW_FOREST_LO 8       // the same thresholds for the backward growth's buckets (lap_mc_forest_kernel; fourfold)
 #define MW_FOREST_HI 48
