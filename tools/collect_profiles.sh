@@ -49,7 +49,7 @@ MODE=projection P_ITERS=3000 timeout 400 python3 tools/exp_tail.py 2>/dev/null |
 #     problems through a library built from lap_mw.hip as the round found it (libreart_hip_old.so, built here from the history:
 #     git show <round start>:reart_amd/csrc/lap_mw.hip, see tools/mk_variant.sh) and through the product library
 if [ -f reart_amd/csrc/libreart_hip_old.so ] && [ -f tools/_states/r05s_recipe.npz ]; then
-  TAGS="old base old base" timeout 900 tools/ab_tags.sh > $O/replay_tail_ab.txt 2>&1
+  TAGS="old base@morton old base@morton" timeout 900 tools/ab_tags.sh > $O/replay_tail_ab.txt 2>&1
 fi
 # 3c. workgroup lifetimes of the four small kernels of the headline step (diagnostic build: device clocks)
 make -C reart_amd/csrc stats > /dev/null 2>&1
