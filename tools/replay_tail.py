@@ -25,7 +25,7 @@ def main(path):
         # wave become neighbours in space), ORDER=random: shuffled; the dumped state is re-numbered with them
         perm = np.zeros((B, n), np.int64)
         for b in range(B):
-            if os.environ["ORDER"] == "morton":
+            if os.environ["ORDER"].startswith("morton"):
                 q = tgt_h[b] - tgt_h[b].min(0)
                 q = np.minimum((q / max(q.max(), 1e-30) * 1023).astype(np.int64), 1023)
                 code = np.zeros(n, np.int64)
@@ -33,6 +33,8 @@ def main(path):
                     for ax in range(3):
                         code |= ((q[:, ax] >> bit) & 1) << (3 * bit + ax)
                 perm[b] = np.argsort(code, kind="stable")
+                if os.environ["ORDER"] == "morton2":      # two columns per thread (n = 2 x workgroup): thread t gets curve positions 2t, 2t + 1
+                    perm[b] = np.concatenate([perm[b][0::2], perm[b][1::2]])
             else:
                 perm[b] = np.random.default_rng(b).permutation(n)
         inv = np.zeros_like(perm)
