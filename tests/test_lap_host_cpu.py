@@ -136,3 +136,28 @@ def test_resolve_racer_count():
     assert lap._resolve_racers(129, 1024) == 1
     assert lap._resolve_racers(1, 2048) == lap.RESOLVE_RACERS
     assert 2 <= lap.RESOLVE_RACERS <= 13 or lap.RESOLVE_RACERS == 1
+
+
+def test_spatial_order_is_a_permutation_that_keeps_neighbours_together():
+    """lap.spatial_order (the loops number their target columns with it): per problem a permutation, the same on every call, and
+    consecutive points along it are neighbours in space (a Z-order curve) -- which is all the solver's speed needs; the optimum
+    does not depend on the numbering."""
+    import numpy as np
+    import torch
+    from reart_amd.utils.lap import spatial_order
+
+    rng = np.random.default_rng(0)
+    pts = torch.from_numpy(rng.normal(size=(3, 2048, 3)).astype(np.float32))
+    pts[2] *= 1e-3                                       # a tiny cloud is scaled to the same grid
+    order = spatial_order(pts)
+    assert order.shape == (3, 2048) and order.dtype == torch.long
+    assert torch.equal(order, spatial_order(pts))
+    for b in range(3):
+        assert torch.equal(torch.sort(order[b]).values, torch.arange(2048))
+        along = pts[b][order[b]]
+        hop = (along[1:] - along[:-1]).norm(dim=-1).mean()
+        rand = (pts[b][1:] - pts[b][:-1]).norm(dim=-1).mean()
+        assert hop < 0.25 * rand, (b, float(hop), float(rand))
+    # degenerate input: all points equal -> the identity (stable sort of equal codes)
+    same = torch.zeros((1, 16, 3))
+    assert torch.equal(spatial_order(same)[0], torch.arange(16))
