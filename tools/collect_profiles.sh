@@ -48,6 +48,11 @@ MODE=projection P_ITERS=3000 timeout 400 python3 tools/exp_tail.py 2>/dev/null |
 # 3d. the re-solve on DUMPED solves (tools/exp_tail.py DUMP=... SAMPLE=40 -> tools/_states/, not in the history: 28 MB): the SAME
 #     problems through a library built from lap_mw.hip as the round found it (libreart_hip_old.so, built here from the history:
 #     git show <round start>:reart_amd/csrc/lap_mw.hip, see tools/mk_variant.sh) and through the product library
+if [ ! -f tools/_states/r05s_recipe.npz ]; then      # (a fresh checkout: take the dumps from runs of the current code)
+  mkdir -p tools/_states
+  MODE=recipe DUMP=tools/_states/r05s_recipe.npz SAMPLE=40 timeout 400 python3 tools/exp_tail.py > /dev/null 2>&1
+  MODE=projection P_ITERS=3000 DUMP=tools/_states/r05s_proj.npz SAMPLE=40 timeout 400 python3 tools/exp_tail.py > /dev/null 2>&1
+fi
 if [ -f reart_amd/csrc/libreart_hip_old.so ] && [ -f tools/_states/r05s_recipe.npz ]; then
   TAGS="old base@morton old base@morton" timeout 900 tools/ab_tags.sh > $O/replay_tail_ab.txt 2>&1
 fi
