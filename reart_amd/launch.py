@@ -19,25 +19,45 @@ def free_port():
     return port
 
 
-def descendants(pid):
-    """Every live descendant of ``pid`` (children first), from /proc: the ranks of a torch.distributed.run launcher are its
-    children but neither in its process group nor in its session."""
-    kids = {}
+def _proc_table():
+    """pid -> (ppid, start time in clock ticks) for every process in /proc."""
+    table = {}
     for name in os.listdir("/proc"):
         if not name.isdigit():
             continue
         try:
             with open(f"/proc/{name}/stat") as f:
-                rest = f.read().rsplit(")", 1)[1].split()     # state ppid ...
-            kids.setdefault(int(rest[1]), []).append(int(name))
+                rest = f.read().rsplit(")", 1)[1].split()     # state ppid ... (field 22 = start time: index 19 here)
+            table[int(name)] = (int(rest[1]), int(rest[19]))
         except (OSError, IndexError, ValueError):
             continue
+    return table
+
+
+def descendants(pid, stamped=False):
+    """Every live descendant of ``pid`` (children first), from /proc: the ranks of a torch.distributed.run launcher are its
+    children but neither in its process group nor in its session.  ``stamped``: (pid, start time) pairs -- a pid alone may
+    be recycled by the time somebody signals it, the pair may not."""
+    table = _proc_table()
+    kids = {}
+    for child, (parent, _) in table.items():
+        kids.setdefault(parent, []).append(child)
     out, todo = [], [int(pid)]
     while todo:
         for k in kids.get(todo.pop(), []):
-            out.append(k)
+            out.append((k, table[k][1]) if stamped else k)
             todo.append(k)
     return out
+
+
+def still_same(pid, start):
+    """Is ``pid`` still the process that was started at ``start`` (clock ticks since boot)?"""
+    try:
+        with open(f"/proc/{pid}/stat") as f:
+            rest = f.read().rsplit(")", 1)[1].split()
+        return rest[0] != "Z" and int(rest[19]) == int(start)
+    except (OSError, IndexError, ValueError):
+        return False
 
 
 def under_launcher(env=None):
@@ -78,6 +98,7 @@ def self_launch(script, argv, nproc, expect_json_key="n_gpus", timeout=None, mod
     line's ``expect_json_key`` differs from ``nproc``."""
     import signal
     import threading
+    import time
 
     cmd = torchrun_command(script, argv, nproc, module=module)
     env = dict(os.environ)
@@ -90,20 +111,20 @@ def self_launch(script, argv, nproc, expect_json_key="n_gpus", timeout=None, mod
         except Exception:                                 # (no libc by that name: the handlers below still cover signals)
             pass
 
-    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, start_new_session=True, preexec_fn=die_with_parent)
     found = []
+    known = {}                                            # pid -> start time of every descendant the launcher ever had
 
     class _Signalled(BaseException):
         def __init__(self, signum):
             self.signum = signum
 
-    def on_signal(signum, frame):
-        raise _Signalled(signum)                          # unwinds proc.wait() into the clean-up below
+    state = {"cleaning": False, "pending": None}
 
-    old_handlers = {}
-    if threading.current_thread() is threading.main_thread():       # (signal.signal is the main thread's privilege)
-        for sg in (signal.SIGTERM, signal.SIGHUP, signal.SIGINT):
-            old_handlers[sg] = signal.signal(sg, on_signal)
+    def on_signal(signum, frame):
+        if state["cleaning"]:                             # a second TERM / INT while the ranks are being taken down
+            state["pending"] = signum                     # (timeout -k, a double Ctrl-C) must not abort the clean-up
+            return
+        raise _Signalled(signum)                          # unwinds the wait below into the clean-up
 
     def pump():
         for raw in iter(proc.stdout.readline, b""):
@@ -119,45 +140,97 @@ def self_launch(script, argv, nproc, expect_json_key="n_gpus", timeout=None, mod
             if s:
                 print(text, file=sys.stderr, flush=True)
 
-    def kill_group():
-        """torch.distributed.run starts every rank in a session of its OWN (subprocess_handler: start_new_session), so the
-        launcher's process group holds the launcher alone: SIGKILL to it would orphan the ranks with their GPUs.  The ranks
-        are found as the launcher's descendants BEFORE anything is signalled, the launcher gets SIGTERM (its handler closes
-        its workers) and a few seconds, then whatever is left -- launcher, ranks, the ranks' own process groups -- SIGKILL."""
-        victims = descendants(proc.pid)
-        try:
-            os.killpg(proc.pid, signal.SIGTERM)          # start_new_session: the launcher's pid is its group's id
-        except ProcessLookupError:
-            pass
-        try:
-            proc.wait(timeout=10)
-        except subprocess.TimeoutExpired:
-            pass
-        for pid in [proc.pid] + victims:
+    def snapshot():
+        """Record the launcher's descendants WHILE IT LIVES: once it is reaped its ranks are somebody else's children and
+        its pid may belong to anyone."""
+        if proc.returncode is None:
+            for pid, start in descendants(proc.pid, stamped=True):
+                known[pid] = start
+
+    def kill_ranks(sig):
+        for pid, start in list(known.items()):
+            if not still_same(pid, start):
+                known.pop(pid, None)
+                continue
             for kill in (os.killpg, os.kill):            # a rank leads its own group (its children with it)
                 try:
-                    kill(pid, signal.SIGKILL)
+                    kill(pid, sig)
                 except (ProcessLookupError, PermissionError):
                     pass
 
-    reader = threading.Thread(target=pump, daemon=True)
-    reader.start()
+    def kill_group():
+        """torch.distributed.run starts every rank in a session of its OWN (subprocess_handler: start_new_session), so the
+        launcher's process group holds the launcher alone: SIGKILL to it would orphan the ranks with their GPUs.  The ranks
+        are the descendants recorded while the launcher was alive (pid + start time: a recycled pid is never signalled);
+        a live launcher gets SIGTERM (its handler closes its workers) and a few seconds, then whatever is left -- launcher,
+        ranks, the ranks' own process groups -- SIGKILL.  A launcher that has been reaped is never signalled: its pid is
+        free."""
+        state["cleaning"] = True
+        snapshot()
+        if proc.poll() is None:
+            try:
+                os.killpg(proc.pid, signal.SIGTERM)      # start_new_session: the launcher's pid is its group's id
+            except ProcessLookupError:
+                pass
+            try:
+                proc.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                pass
+        else:
+            kill_ranks(signal.SIGTERM)
+            deadline = time.monotonic() + 5
+            while time.monotonic() < deadline and any(still_same(p, s) for p, s in known.items()):
+                time.sleep(0.1)
+        if proc.poll() is None:
+            for kill in (os.killpg, os.kill):
+                try:
+                    kill(proc.pid, signal.SIGKILL)
+                except (ProcessLookupError, PermissionError):
+                    pass
+            proc.wait()
+        kill_ranks(signal.SIGKILL)
+
+    def wait_recording(limit):
+        """proc.wait(timeout=limit) in short slices, recording the launcher's descendants between them."""
+        deadline = None if limit is None else time.monotonic() + float(limit)
+        while True:
+            snapshot()
+            left = None if deadline is None else deadline - time.monotonic()
+            if left is not None and left <= 0:
+                raise subprocess.TimeoutExpired(cmd, limit)
+            try:
+                return proc.wait(timeout=0.5 if left is None else min(0.5, left))
+            except subprocess.TimeoutExpired:
+                continue
+
+    old_handlers = {}
+    proc = reader = None
     try:
-        proc.wait(timeout=timeout)
+        if threading.current_thread() is threading.main_thread():   # (signal.signal is the main thread's privilege)
+            for sg in (signal.SIGTERM, signal.SIGHUP, signal.SIGINT):
+                old_handlers[sg] = signal.signal(sg, on_signal)
+        try:                                              # orphaned ranks become OUR children, not init's: still findable
+            import ctypes
+            ctypes.CDLL("libc.so.6", use_errno=True).prctl(36, 1, 0, 0, 0)                       # PR_SET_CHILD_SUBREAPER
+        except Exception:
+            pass
+        proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, start_new_session=True, preexec_fn=die_with_parent)
+        reader = threading.Thread(target=pump, daemon=True)
+        reader.start()
+        wait_recording(timeout)
     except subprocess.TimeoutExpired:
         kill_group()
-        proc.wait()
         reader.join(timeout=5)
         print(f"launch of {nproc} ranks timed out after {timeout} s (process group killed): {' '.join(cmd)}", file=sys.stderr)
         return 124
     except _Signalled as sg:
-        kill_group()
-        proc.wait()
+        if proc is not None:
+            kill_group()
         print(f"launch of {nproc} ranks ended by signal {sg.signum} (process group killed)", file=sys.stderr)
         return 128 + int(sg.signum)
     except BaseException:
-        kill_group()
-        proc.wait()
+        if proc is not None:
+            kill_group()
         raise
     finally:
         for sg, h in old_handlers.items():
@@ -165,7 +238,10 @@ def self_launch(script, argv, nproc, expect_json_key="n_gpus", timeout=None, mod
     reader.join(timeout=30)
     line = found[-1] if found else None
     if proc.returncode != 0:
-        kill_group()                                      # a rank that outlived a failed launcher
+        state["cleaning"] = True
+        kill_ranks(signal.SIGTERM)                        # a rank that outlived a failed launcher: recorded while it lived
+        time.sleep(0.5 if known else 0)
+        kill_ranks(signal.SIGKILL)
         print(f"launch of {nproc} ranks failed (exit {proc.returncode}): {' '.join(cmd)}", file=sys.stderr)
         return proc.returncode
     if line is None:

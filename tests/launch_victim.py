@@ -1,5 +1,7 @@
 """Helper of tests/test_launch_failures_cpu.py: one RANK of a job started by reart_amd.launch.self_launch.
   hang  DIR          every rank writes DIR/pid.<rank> and sleeps (the test signals the launcher's parent)
+  stubborn DIR      the same, but the ranks ignore SIGTERM: taking them down needs the SIGKILL stage of the clean-up
+  orphan DIR        rank 1 SIGKILLs the LAUNCHER (its parent) after a while; both ranks sleep on as orphans
   crash DIR ROOT     the sweep's command line under gloo with the oracle as runner; rank 1 dies hard (os._exit) in the
                      middle of its share while rank 0 goes on to the gather of the energies"""
 import os
@@ -17,6 +19,20 @@ def main():
     with open(os.path.join(d, f"pid.{rank}"), "w") as f:
         f.write(str(os.getpid()))
     if mode == "hang":
+        time.sleep(3600)
+        return 0
+    if mode == "stubborn":
+        import signal
+        signal.signal(signal.SIGTERM, signal.SIG_IGN)
+        with open(os.path.join(d, f"armed.{rank}"), "w") as f:
+            f.write("1")
+        time.sleep(3600)
+        return 0
+    if mode == "orphan":
+        import signal
+        time.sleep(3.0)                       # (the launching process records its launcher's descendants twice a second)
+        if rank == 1:
+            os.kill(os.getppid(), signal.SIGKILL)
         time.sleep(3600)
         return 0
     from test_sweep_cli_cpu import SEQ_ROOT, _oracle_runner

@@ -83,3 +83,69 @@ def test_a_rank_that_dies_mid_sweep_ends_the_job(tmp_path):
     pids = [int(open(tmp_path / f).read()) for f in os.listdir(tmp_path) if f.startswith("pid.")]
     assert len(pids) == 2 and _gone(pids, 30), "rank 0 was left in the gather"
     assert not (save / "sweep.json").exists()
+
+
+def _cleanup(tmp_path, drv=None):
+    if drv is not None and drv.poll() is None:
+        drv.kill()
+    for f in os.listdir(tmp_path):
+        if f.startswith("pid."):
+            try:
+                os.kill(int(open(tmp_path / f).read()), signal.SIGKILL)
+            except (ProcessLookupError, ValueError):
+                pass
+
+
+def test_a_second_signal_does_not_abort_the_clean_up(tmp_path):
+    """`timeout -k`, a harness that sends TERM and then INT, a double Ctrl-C.  The ranks ignore SIGTERM, so the
+    clean-up is still waiting for the launcher when the second signal arrives; it must go on to its SIGKILL stage."""
+    code = DRIVER.format(root=ROOT, victim=VICTIM, argv=["stubborn", str(tmp_path)], timeout=300)
+    drv = subprocess.Popen([sys.executable, "-c", code], stderr=subprocess.PIPE)
+    try:
+        pids = _wait_pids(str(tmp_path), 2, 120)
+        t0 = time.time()
+        while not all((tmp_path / f"armed.{r}").exists() for r in range(2)):
+            assert time.time() - t0 < 30
+            time.sleep(0.1)
+        drv.send_signal(signal.SIGTERM)
+        time.sleep(1.5)
+        drv.send_signal(signal.SIGINT)
+        time.sleep(0.5)
+        drv.send_signal(signal.SIGTERM)
+        rc = drv.wait(timeout=90)
+        err = drv.stderr.read().decode(errors="replace")
+        assert rc == 128 + signal.SIGTERM, (rc, err[-400:])
+        assert _gone(pids, 30), "a second signal left ranks behind"
+    finally:
+        _cleanup(tmp_path, drv)
+
+
+def test_ranks_that_outlive_a_dead_launcher_are_killed(tmp_path):
+    """once the launcher is reaped its ranks are no longer its descendants and its pid is free.  The launching
+    process records the ranks while the launcher lives (and is a child subreaper), and never signals the launcher's pid
+    afterwards."""
+    code = DRIVER.format(root=ROOT, victim=VICTIM, argv=["orphan", str(tmp_path)], timeout=300)
+    drv = subprocess.Popen([sys.executable, "-c", code], stderr=subprocess.PIPE)
+    try:
+        pids = _wait_pids(str(tmp_path), 2, 120)
+        rc = drv.wait(timeout=120)
+        err = drv.stderr.read().decode(errors="replace")
+        assert rc not in (0, 124), (rc, err[-400:])
+        assert "failed" in err
+        assert _gone(pids, 30), "orphaned ranks survived"
+    finally:
+        _cleanup(tmp_path, drv)
+
+
+def test_descendants_are_stamped_and_checked():
+    from reart_amd.launch import descendants, still_same
+    child = subprocess.Popen([sys.executable, "-c", "import time; time.sleep(30)"])
+    try:
+        mine = dict(descendants(os.getpid(), stamped=True))
+        assert child.pid in mine and child.pid in descendants(os.getpid())
+        assert still_same(child.pid, mine[child.pid])
+        assert not still_same(child.pid, mine[child.pid] + 1)          # the same pid, another process
+    finally:
+        child.kill()
+        child.wait()
+    assert not still_same(child.pid, mine[child.pid])
