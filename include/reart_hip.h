@@ -564,6 +564,21 @@ int reart_lap_resolve_points_mc(const float *src, const float *tgt, int B, int n
                                 int32_t *certified, const double *price_in, double *price_out, void *workspace,
                                 size_t workspace_bytes, void *stream);
 
+/* Is the optimum a solve returned the ONLY optimal assignment?  (csrc/ties.hip; reference: the refresh is scipy's
+ * linear_sum_assignment, a pure function of the cost matrix, run_robot.py:172-176, so a run repeats under --manual_seed,
+ * run_robot.py:37-49; the raced solvers above return SOME optimum.)  Inputs: the points of reart_lap_resolve_points, the
+ * optimum col4row [B,n] and its column potentials price [B,n] as those calls leave them; n <= 4096.  Outputs (caller-owned):
+ *   edges [B,cap,2]  (row, column) of every pair off the assignment that is tight under the potentials,
+ *                    c_ij + p_j - (c_i,s(i) + p_s(i)) <= 1e-13 x cost scale (the certificate's tolerance), costs by
+ *                    reart_cdist's expression; n_edges [B] their number (pairs beyond cap are counted, not stored);
+ *   tie [B]          0: no alternating cycle among the tight pairs -- the optimum is unique; 1: rows on or between cycles
+ *                    exist -- other optima of the same cost may (the host decides: reart_amd/utils/lap.py
+ *                    canonical_among_ties); 2: more tight pairs than the kernel holds (n_edges > cap or > 12 288);
+ *                    3: col4row is not an assignment.
+ * Two launches on `stream`, no workspace, no host synchronisation. */
+int reart_lap_ties(const float *src, const float *tgt, int B, int n, const int32_t *col4row, const double *price,
+                   int32_t *tie, int32_t *edges, int32_t *n_edges, int cap, void *stream);
+
 /* Device-side glue of an assignment refresh (run_robot.py:165-178), so that a loop which re-solves on the GPU touches the host
  * only for the B certificate flags (csrc/assign.hip):
  *   reart_gather_points: out[b][r] = pc[b][index[r]] -- `index_points(pc_trans_list, fps_idx)` (run_robot.py:169) for ONE sample

@@ -1,0 +1,179 @@
+// reart_amd/csrc/ties.hip -- is the optimal assignment a re-solve returned the ONLY optimal one?
+//
+// The reference's refresh is `scipy.optimize.linear_sum_assignment` on the cost matrix (run_robot.py:172-176,
+// utils/model_utils.py:85-103): a pure function of the matrix, so two runs under one --manual_seed (run_robot.py:37-49) are
+// the same run.  The solvers of lap.hip / lap_mw.hip race (orders of free rows, lock-free chains): all of them end in an
+// optimal assignment, but when several assignments are optimal -- two rows whose costs to each other's columns tie to the
+// last bit of the fp32 costs happen about once in a few hundred re-solves of the kinematic projection -- which one depends on
+// who won.  This file finds those cases so that the host can make the choice canonical (reart_amd/utils/lap.py:
+// canonical_among_ties).
+//
+// With optimal potentials p (columns) and u_i = c_i,s(i) + p_s(i) (rows), EVERY optimal assignment uses only tight pairs,
+// r_ij = c_ij + p_j - u_i = 0 (complementary slackness), and every perfect matching of the tight pairs is optimal: the set of
+// optima is the set of perfect matchings of the tight graph whatever optimal potentials it was drawn with.  The returned
+// optimum s is the only one iff the directed graph on rows, i -> owner(j) for every tight pair (i, j) with j != s(i), has no
+// cycle (an alternating cycle IS another perfect matching of the tight pairs).
+//   lap_tie_edges_kernel  whole chip, one wave per row: the tight pairs off the assignment, with the costs' own expression
+//                         and the certificate's tolerance (lap.hip: `cur - v1 > tol`, tol = 1e-13 of the cost scale)
+//   lap_tie_cycle_kernel  one workgroup per problem: does that graph hold a cycle?  Chains of rows with one tight pair out
+//                         of them are contracted by pointer jumping, the rows with several are peeled layer by layer
+//                         (see there).  No cycle (the normal case): tie[b] = 0.
+#include "common.h"
+#include "lap_dev.h"
+
+#define TIE_PASS_BS 256
+#define TIE_CYC_BS 1024
+#define TIE_LDS_EDGES 12288        // tight pairs one workgroup keeps in LDS (48 KB); more: tie[b] = 2, the host looks itself
+
+struct TieArgs {
+    const float *src, *tgt;        // [B][n][3]
+    int B, n;
+    const int *col4row;            // [B][n] the optimum
+    const double *price;           // [B][n] its column potentials (the solvers' sign convention: a row minimises c + p)
+    int *tie;                      // [B] out
+    int *edges;                    // [B][cap][2] out: (row, column) of every tight pair off the assignment
+    int *n_edges;                  // [B] out (may exceed cap: the pairs beyond it are not stored)
+    int cap;
+};
+
+__global__ __launch_bounds__(TIE_PASS_BS) void lap_tie_edges_kernel(TieArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lsm[];
+    const int n = a.n, b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    double *price = (double *)lsm;
+    float *ptx = (float *)(price + n), *pty = ptx + n, *ptz = pty + n;
+    __shared__ float s_lo[TIE_PASS_BS / 64], s_hi[TIE_PASS_BS / 64];
+    const float *S_ = a.src + (size_t)b * n * 3, *T_ = a.tgt + (size_t)b * n * 3;
+    // the cost scale of the solvers' tolerances (lap.hip, points form): the diagonal of the clouds' common box
+    float lo = INFINITY, hi = -INFINITY;
+    for (int e = tid; e < 3 * n; e += TIE_PASS_BS) {
+        const float sv = S_[e], tv = T_[e];
+        (e % 3 == 0 ? ptx : (e % 3 == 1 ? pty : ptz))[e / 3] = tv;
+        lo = fminf(lo, fminf(sv, tv)); hi = fmaxf(hi, fmaxf(sv, tv));
+    }
+    for (int j = tid; j < n; j += TIE_PASS_BS) price[j] = a.price[(size_t)b * n + j];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o, 64)); hi = fmaxf(hi, __shfl_xor(hi, o, 64)); }
+    if (lane == 0) { s_lo[wv] = lo; s_hi[wv] = hi; }
+    __syncthreads();
+    for (int w = 0; w < TIE_PASS_BS / 64; ++w) { lo = fminf(lo, s_lo[w]); hi = fmaxf(hi, s_hi[w]); }
+    double mx = 1.7320508 * (double)(hi - lo);
+    if (!(mx > 0.0)) mx = 1.0;
+    const double tol = mx * 1e-13;
+    int *edges = a.edges + (size_t)b * a.cap * 2;
+    for (int i = blockIdx.y * (TIE_PASS_BS / 64) + wv; i < n; i += gridDim.y * (TIE_PASS_BS / 64)) {
+        const int c = a.col4row[(size_t)b * n + i];
+        if (c < 0 || c >= n) {                                         // not an assignment: nothing to say about it
+            if (lane == 0) atomicMax(&a.tie[b], 3);
+            continue;
+        }
+        const float ax = S_[3 * i], ay = S_[3 * i + 1], az = S_[3 * i + 2];
+        const double cur = (double)sqrtf(reart_sqdist3(ax, ay, az, ptx[c], pty[c], ptz[c])) + price[c];
+        for (int j0 = 0; j0 < n; j0 += 64) {
+            const int j = j0 + lane;
+            bool hit = false;
+            if (j < n && j != c) hit = ((double)sqrtf(reart_sqdist3(ax, ay, az, ptx[j], pty[j], ptz[j])) + price[j]) - cur <= tol;
+            const unsigned long long m = __ballot(hit);
+            if (m) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&a.n_edges[b], __builtin_popcountll(m));
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (hit) {
+                    const int at = base + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+                    if (at < a.cap) { edges[2 * at] = i; edges[2 * at + 1] = j; }
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(TIE_CYC_BS) void lap_tie_cycle_kernel(TieArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lsm[];
+    const int n = a.n, b = blockIdx.x, tid = threadIdx.x;
+    if (a.tie[b] == 3) return;
+    const int E = a.n_edges[b];
+    if (E == 0) return;                                                // (tie[b] was cleared by the launch's memset)
+    if (E > a.cap || E > TIE_LDS_EDGES) { if (tid == 0) a.tie[b] = 2; return; }
+    // Does the row graph hold a cycle?  Peeling rows without a live pair out of them one layer per round takes as many rounds
+    // as the longest chain of tight pairs -- hundreds: the tight pairs are mostly what the searches' and the backward growth's
+    // trees left behind, chains by construction (measured: 0.4 ms per solve of 9 x 2048^2).  So the chains are CONTRACTED first:
+    // a row with exactly one tight pair out of it is a link (12 rounds of pointer jumping take every link to the end of its
+    // chain: a row with no pair out of it = dead, a row with several = a junction; a link that never arrives runs into a cycle
+    // of links), and only the junctions are peeled layer by layer -- a junction dies when every pair out of it leads to a dead
+    // end.  Junctions that survive the fixed point all lead to surviving junctions: a cycle.
+    int *owner = (int *)lsm;                                           // column -> row
+    int *deg = owner + n;                                              // tight pairs out of the row
+    int *ptr = deg + n;                                                // a link: where its chain has got to; an end: itself
+    int *mark = ptr + n;                                               // the last round in which a junction saw a live way out
+    unsigned *pair = (unsigned *)(mark + n);                           // (row << 16) | row the pair leads to
+    unsigned char *dead = (unsigned char *)(pair + TIE_LDS_EDGES);
+    for (int i = tid; i < n; i += TIE_CYC_BS) { owner[i] = 0xffff; deg[i] = 0; ptr[i] = i; mark[i] = -1; dead[i] = 0; }
+    __syncthreads();
+    for (int i = tid; i < n; i += TIE_CYC_BS) owner[a.col4row[(size_t)b * n + i]] = i;      // (a permutation: tie[b] != 3)
+    __syncthreads();
+    const int *edges = a.edges + (size_t)b * a.cap * 2;
+    for (int e = tid; e < E; e += TIE_CYC_BS) {
+        const int i = edges[2 * e], k = owner[edges[2 * e + 1]];
+        pair[e] = ((unsigned)i << 16) | (unsigned)k;
+        if (k != 0xffff) { atomicAdd(&deg[i], 1); ptr[i] = k; }        // (deg 1: the one way out; otherwise overwritten below)
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += TIE_CYC_BS) {
+        if (deg[i] != 1) ptr[i] = i;                                   // ends of chains: dead ends and junctions
+        dead[i] = deg[i] == 0;
+    }
+    __syncthreads();
+    int steps = 1;
+    while ((1 << steps) < n) ++steps;
+    for (int r = 0; r < steps; ++r) {                                  // ptr[i] <- ptr[ptr[i]]: ends point at themselves
+        int nx[(LAP_NMAX + TIE_CYC_BS - 1) / TIE_CYC_BS];
+        int c = 0;
+        for (int i = tid; i < n; i += TIE_CYC_BS) nx[c++] = ptr[ptr[i]];
+        __syncthreads();
+        c = 0;
+        for (int i = tid; i < n; i += TIE_CYC_BS) ptr[i] = nx[c++];
+        __syncthreads();
+    }
+    int cyc = 0;                                                       // a link whose chain has no end: a cycle of links
+    for (int i = tid; i < n; i += TIE_CYC_BS) cyc |= (deg[i] == 1 && deg[ptr[i]] == 1);
+    if (__syncthreads_or(cyc)) { if (tid == 0) a.tie[b] = 1; return; }
+    for (int round = 0; round <= n; ++round) {
+        for (int e = tid; e < E; e += TIE_CYC_BS) {
+            const int i = (int)(pair[e] >> 16), k = (int)(pair[e] & 0xffffu);
+            if (k != 0xffff && deg[i] > 1 && !dead[i] && !dead[ptr[k]]) mark[i] = round;   // (every writer writes the same value)
+        }
+        __syncthreads();
+        int died = 0;
+        for (int i = tid; i < n; i += TIE_CYC_BS)
+            if (deg[i] > 1 && !dead[i] && mark[i] != round) { dead[i] = 1; died = 1; }
+        if (!__syncthreads_or(died)) break;
+    }
+    int left = 0;
+    for (int i = tid; i < n; i += TIE_CYC_BS) left |= (deg[i] > 1 && !dead[i]);
+    if (__syncthreads_or(left) && tid == 0) a.tie[b] = 1;
+}
+
+extern "C" int reart_lap_ties(const float *src, const float *tgt, int B, int n, const int32_t *col4row, const double *price,
+                              int32_t *tie, int32_t *edges, int32_t *n_edges, int cap, void *stream) {
+    if (B < 0 || n < 1 || n > LAP_NMAX || cap < 1) return REART_ERR_INVALID_ARG;
+    if (B == 0) return REART_OK;
+    if (!src || !tgt || !col4row || !price || !tie || !edges || !n_edges) return REART_ERR_INVALID_ARG;
+    TieArgs a{src, tgt, B, n, col4row, price, tie, edges, n_edges, cap};
+    if (hipMemsetAsync(tie, 0, sizeof(int) * (size_t)B, (hipStream_t)stream) != hipSuccess ||
+        hipMemsetAsync(n_edges, 0, sizeof(int) * (size_t)B, (hipStream_t)stream) != hipSuccess)
+        return REART_ERR_LAUNCH;
+    int per = (2 * 256 + B - 1) / B;                                   // workgroups per problem: two per compute unit over the batch
+    const int per_max = (n + TIE_PASS_BS / 64 - 1) / (TIE_PASS_BS / 64);
+    per = per < 1 ? 1 : (per > per_max ? per_max : per);
+    const size_t lds_pass = (size_t)n * (8 + 12);
+    const size_t lds_cyc = (size_t)n * (4 * 4 + 1) + 4 * (size_t)TIE_LDS_EDGES + 16;
+    if ((lds_pass > REART_LDS_DEFAULT_CAP &&
+         hipFuncSetAttribute((const void *)lap_tie_edges_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pass) != hipSuccess) ||
+        (lds_cyc > REART_LDS_DEFAULT_CAP &&
+         hipFuncSetAttribute((const void *)lap_tie_cycle_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cyc) != hipSuccess))
+        return REART_ERR_LAUNCH;
+    hipLaunchKernelGGL(lap_tie_edges_kernel, dim3(B, per), dim3(TIE_PASS_BS), lds_pass, (hipStream_t)stream, a);
+    REART_CHECK_LAUNCH();
+    hipLaunchKernelGGL(lap_tie_cycle_kernel, dim3(B), dim3(TIE_CYC_BS), lds_cyc, (hipStream_t)stream, a);
+    REART_CHECK_LAUNCH();
+    return REART_OK;
+}

@@ -172,7 +172,13 @@ class AssignmentPhase:
         self._cert_host.copy_(self._cert, non_blocking=True)
         if self.collect_stats:
             self._stats_host.copy_(ws[off:off + 16 * B].view(torch.int32), non_blocking=True)
+        tb = None
+        if lap.CANONICAL_TIES:                                            # --deterministic: tied optima take the canonical one
+            tb = lap._tie_breaker(st, B, n, eng.device)
+            tb.launch(self._src_pts, self.tgt_pts, cols, prices)
         torch.cuda.current_stream().synchronize()
+        if tb is not None and tb.settle(self._src_pts, self.tgt_pts, st, skip=set((self._cert_host == 0).nonzero().flatten().tolist())):
+            pairs()
         if self.collect_stats:
             sth = self._stats_host.numpy().reshape(B, 4)
             self.stats_raw.append(sth.copy())
@@ -364,7 +370,13 @@ class AssignmentPhaseBatch:
                                                 _lib.ptr(ph.eng._assign_map), stream), "reart_assign_pairs")
         pairs()
         self._cert_host.copy_(self._cert, non_blocking=True)
+        tb = None
+        if lap.CANONICAL_TIES:
+            tb = lap._tie_breaker(st, K * B, n, dev)
+            tb.launch(self._src_all, self.tgt_all, cols, prices)
         torch.cuda.current_stream().synchronize()
+        if tb is not None and tb.settle(self._src_all, self.tgt_all, st, skip=set((self._cert_host == 0).nonzero().flatten().tolist())):
+            pairs()
         fb = 0
         for b in (self._cert_host == 0).nonzero().flatten().tolist():
             from scipy.optimize import linear_sum_assignment
@@ -446,8 +458,14 @@ class OperatorLoop:
                     cols, fb, self.lap_stats = linear_sum_assignment_points(pc_src.detach(), self.tgt_pts, self.lap_state,
                                                                             return_stats="full", device_cols=True)
                 else:
+                    from reart_amd.utils import lap as lap_
+
+                    st_ = {} if lap_.CANONICAL_TIES else None      # --deterministic: the potentials the tie check needs
                     assign, fb = linear_sum_assignment_batch(cdist(pc_src.detach(), self.tgt_pts), points=(pc_src.detach(), self.tgt_pts),
-                                                             race=True, return_stats=True)
+                                                             race=True, return_stats=True, state=st_, warm_assignment=st_ is not None)
+                    if st_ is not None and lap_.canonicalize(pc_src.detach().contiguous(), self.tgt_pts.contiguous(), st_):
+                        rows_ = np.arange(pc_src.shape[1], dtype=np.int64)
+                        assign = [(rows_, c_) for c_ in st_["cols"].cpu().numpy().astype(np.int64)]
                 if self.lap_events is not None:
                     ev[1].record()
                     self.lap_events.append(ev)
@@ -603,6 +621,10 @@ def main(args):
     random.seed(args.manual_seed)
     if not torch.cuda.is_available():
         raise SystemExit("reart_amd runs on an AMD GPU only (no CPU fallback)")
+    if getattr(args, "deterministic", False):
+        from reart_amd.utils import lap as _lap
+
+        _lap.CANONICAL_TIES = True
     if args.evaluate and args.resume is None:
         raise ValueError("need model path to evaluate!")      # run_robot.py:86-87
     device = torch.device("cuda")
@@ -809,6 +831,11 @@ def build_parser():
     # additions
     p.add_argument("--synthetic", action="store_true", help="generated articulated sequence instead of --seq_path")
     p.add_argument("--synthetic_frames", default=20, type=int)
+    p.add_argument("--deterministic", action="store_true",
+                   help="the assignment refreshes return a function of the cost matrix alone, like the reference's scipy call "
+                        "(run_robot.py:172-176): when several assignments are optimal the raced GPU solvers return whichever "
+                        "finished first; with this flag every solve is checked for ties (reart_lap_ties) and a tied problem "
+                        "takes the lexicographically smallest optimum -- two runs under one --manual_seed are then the same run")
     return p
 
 

@@ -185,7 +185,7 @@ def run_sweep(instances, run_instance, device, policy="round_robin"):
 
 
 def run_sweep_engines(instances, make_engine, n_iter, device, per_gpu=3, chunk=100, energy=False, mode="streams",
-                      overlap_tails=True, on_finish=None, policy="round_robin", assign=None):
+                      overlap_tails=True, on_finish=None, policy="round_robin", assign=None, groups_in_flight=4):
     """Sweep of fused-loop instances with ``per_gpu`` of them in flight per GPU.
 
     One instance of the relaxation loop is a chain of short, latency-bound launches that leaves
@@ -204,7 +204,9 @@ def run_sweep_engines(instances, make_engine, n_iter, device, per_gpu=3, chunk=1
     assignment loss, its pairs refreshed every ``assign_gap`` iterations; a batch group solves the problems of all its
     instances in one call per refresh (``run_robot.AssignmentPhaseBatch``) and keeps stepping in shared launches.
     ``on_finish(inst, spec, engine, energy dict or None)`` is called once per finished instance (the command line writes
-    the instance's result files there).  Returns (records [n, RECORD], best index) like ``run_sweep``."""
+    the instance's result files there).  ``groups_in_flight``: how many groups of the recipe sweep run concurrently (each
+    with its engines, graphs, a stream and a host thread); the rest are built when a slot frees up.
+    Returns (records [n, RECORD], best index) like ``run_sweep``."""
     if mode not in ("streams", "batch"):
         raise ValueError("mode is 'streams' or 'batch'")
     world = dist.get_world_size() if dist.is_initialized() else 1
@@ -379,13 +381,14 @@ def run_sweep_engines(instances, make_engine, n_iter, device, per_gpu=3, chunk=1
             futures = [pool.submit(finish, e) for e in live]
             if overlap_tails:
                 pending.extend(futures)
-            else:
-                for f in futures:
-                    inst, rec = f.result()
-                    local[inst] = rec
+                return futures
+            for f in futures:
+                inst, rec = f.result()
+                local[inst] = rec
         else:
             for inst, rec in (finish(e) for e in live):
                 local[inst] = rec
+        return None
 
     import time
 
@@ -410,28 +413,65 @@ def run_sweep_engines(instances, make_engine, n_iter, device, per_gpu=3, chunk=1
 
         from .utils import lap as _lap
 
-        lives = [timed("build_s", build, g) for g in groups]
-        plans = [timed("capture_s", capture, live) for live in lives]
+        # At most `groups_in_flight` groups hold engines, graphs and a host thread at a time (`per_gpu` bounds
+        # the instances of a GROUP; with every group of a rank resident at once nothing bounded device memory, the thread
+        # count or the solver's share of the chip).  The first wave is built and captured up front on this thread, as
+        # measured (starting a group while the next is still being built: 25.9 against 24.7 s); every later group is built
+        # and captured lazily by the worker that takes it, inside its turn -- the build as a READER of the gate (it
+        # allocates), the capture as its writer -- after that worker's previous group has finished its tails and let go of
+        # its engines.
+        bound = max(1, min(int(groups_in_flight), len(groups)))
+        first = [timed("build_s", build, g) for g in groups[:bound]]
+        ready = [(live, timed("capture_s", capture, live)) for live in first]
+        del first
+        later = list(range(bound, len(groups)))
         if energy and pool is None:
             pool = ThreadPoolExecutor(max_workers=2 * max(per_gpu, 1))
         errors = []
+        take = threading.Lock()
+        peak = {"now": 0, "max": 0}
 
         def drive(k):
-            try:
-                st = torch.cuda.Stream(device=device)
-                st.wait_stream(torch.cuda.default_stream(device))      # the set-up and capture work of the main thread
-                with torch.cuda.stream(st):
-                    enqueue(lives[k], plans[k])
-                tails(lives[k])
-            except BaseException as exc:      # the group's instances are reported failed; the other groups go on
-                errors.append((k, exc))
-                for e in lives[k]:
-                    local.setdefault(e[0], _record(e[0], e[1], failed=1))
+            live, plan = ready[k]
+            ready[k] = None
+            gi = k
+            while True:
+                try:
+                    with take:
+                        peak["now"] += 1
+                        peak["max"] = max(peak["max"], peak["now"])
+                    st = torch.cuda.Stream(device=device)
+                    st.wait_stream(torch.cuda.default_stream(device))      # the set-up and capture work of the main thread
+                    with torch.cuda.stream(st):
+                        enqueue(live, plan)
+                    for f in tails(live) or ():           # this group's tails end before the worker takes another group
+                        f.exception()
+                except BaseException as exc:      # the group's instances are reported failed; the other groups go on
+                    errors.append((gi, exc))
+                    for e in live:
+                        local.setdefault(e[0], _record(e[0], e[1], failed=1))
+                finally:
+                    with take:
+                        peak["now"] -= 1
+                live = plan = None                        # engines and graphs of the finished group go back to the allocator
+                with take:
+                    if not later:
+                        return
+                    gi = later.pop(0)
+                try:
+                    with gate.tail():
+                        live = build(groups[gi])
+                    plan = capture(live)
+                except BaseException as exc:
+                    errors.append((gi, exc))
+                    for inst in groups[gi]:
+                        local.setdefault(inst, _record(inst, instances[inst], failed=1))
+                    live, plan = [], []
 
         old_calls = _lap.CONCURRENT_CALLS
-        _lap.CONCURRENT_CALLS = len(groups)
+        _lap.CONCURRENT_CALLS = bound
         try:
-            workers = [threading.Thread(target=drive, args=(k,), name=f"sweep-group-{k}") for k in range(len(groups))]
+            workers = [threading.Thread(target=drive, args=(k,), name=f"sweep-group-{k}") for k in range(bound)]
             for w in workers:
                 w.start()
             for w in workers:
@@ -442,7 +482,8 @@ def run_sweep_engines(instances, make_engine, n_iter, device, per_gpu=3, chunk=1
             import sys
 
             print(f"sweep: group {k} failed: {type(exc).__name__}: {exc}", file=sys.stderr)
-        stages["concurrent_groups"] = len(groups)
+        stages["concurrent_groups"] = bound
+        stages["groups_in_flight_max"] = peak["max"]
         groups = []                                        # nothing left for the pipelined loop below
     cur = timed("build_s", build, groups[0]) if groups else []
     enqueue(cur, timed("capture_s", capture, cur))
@@ -537,6 +578,9 @@ def build_cli():
     p.add_argument("--synthetic_frames", type=int, default=20)
     p.add_argument("--gpus", type=int, default=1, help="ranks to start when not already under torch.distributed.run")
     p.add_argument("--per_gpu", type=int, default=6, help="instances in flight per GPU")
+    p.add_argument("--groups_in_flight", type=int, default=4,
+                   help="recipe sweep (--use_assign_loss): groups of --per_gpu instances that run concurrently on one GPU, each on a "
+                        "stream and host thread of its own; further groups are built when one finishes")
     p.add_argument("--mode", choices=("streams", "batch"), default="batch",
                    help="batch (default): the instances of a group advance in shared launches (24.5 k it/s per GPU for six at "
                         "T=20 x N=4096 against 12.3 k for one); streams: one stream per instance (a group the shared launches "
@@ -567,6 +611,8 @@ def build_cli():
     p.add_argument("--lambda_assign", default=3e-1, type=float)
     p.add_argument("--corr_model_path", default="pretrained/corr_model.pth.tar")
     p.add_argument("--normalize_file", default="data/category_normalize_scale.pkl", type=str)
+    p.add_argument("--deterministic", action="store_true",
+                   help="assignment refreshes settle tied optima canonically (run_robot.py --deterministic): a sweep repeats run to run")
     return p
 
 
@@ -665,6 +711,10 @@ def main(argv=None, runner=None):
             raise SystemExit(f"rank {rank}: no GPU {local_rank} on this node ({torch.cuda.device_count()} visible)")
         torch.cuda.set_device(local_rank)
         device = torch.device("cuda", local_rank)
+        if args.deterministic:
+            from .utils import lap as _lap
+
+            _lap.CANONICAL_TIES = True
     else:
         device = torch.device("cpu")
     if launch.under_launcher() and not dist.is_initialized():
@@ -712,7 +762,7 @@ def main(argv=None, runner=None):
 
         records, _ = run_sweep_engines(instances, make_engine, args.n_iter, device, per_gpu=args.per_gpu,
                                        chunk=min(100, args.n_iter), energy=args.energy, mode=args.mode, on_finish=on_finish,
-                                       policy=args.shard,
+                                       policy=args.shard, groups_in_flight=args.groups_in_flight,
                                        assign=dict(assign_iter=args.assign_iter, assign_gap=args.assign_gap, downsample=args.downsample,
                                                    lambda_assign=args.lambda_assign) if args.use_assign_loss else None)
     records = records.cpu()

@@ -152,6 +152,198 @@ def _forget_uncertified(state, col, b, host_cols):
         state["prices"][b].zero_()
 
 
+# --deterministic (run_robot.py): when several assignments are optimal -- exact ties of the fp32 costs, about one re-solve in a
+# few hundred of the kinematic projection -- the raced solvers return whichever the winner found; with this switch every solve
+# of the loops is followed by reart_lap_ties and a tied problem takes the lexicographically smallest optimum
+# (canonical_among_ties): the assignment becomes a function of the cost matrix alone, like the reference's scipy call
+# (run_robot.py:172-176), and a run repeats under --manual_seed (run_robot.py:37-49)
+CANONICAL_TIES = os.environ.get("REART_CANONICAL_TIES", "0") == "1"
+
+
+def _lex_min_matching(rows, allowed, cols):
+    """Lexicographically smallest perfect matching (rows ascending, each the smallest column it can get) of the bipartite
+    graph ``allowed[row] = set of columns``, starting from the perfect matching ``cols[row]``.  Rows are fixed in ascending
+    order: row r takes candidate c iff the row that holds c can then be re-matched along an alternating path through rows
+    and columns not fixed yet (Kuhn's augmenting step; the matching stays perfect throughout)."""
+    match = {int(r): int(cols[r]) for r in rows}
+    holder = {c: r for r, c in match.items()}
+    fixed_rows, fixed_cols = set(), set()
+    for r in sorted(match):
+        for c in sorted(allowed[r]):
+            if c in fixed_cols:
+                continue
+            if match[r] == c:
+                break
+            saved = (dict(match), dict(holder))
+            r2, old = holder[c], match[r]                 # r takes c: r2 loses it, r's old column becomes free
+            match[r], holder[c] = c, r
+            del holder[old], match[r2]
+            fixed_rows.add(r)
+            fixed_cols.add(c)
+            if _augment(r2, allowed, match, holder, fixed_cols):
+                break
+            fixed_rows.discard(r)
+            fixed_cols.discard(c)
+            match.clear()
+            match.update(saved[0])
+            holder.clear()
+            holder.update(saved[1])
+        fixed_rows.add(r)
+        fixed_cols.add(match[r])
+    return match
+
+
+def _augment(r0, allowed, match, holder, fixed_cols):
+    """An augmenting path for the unmatched row r0 over the columns not fixed (the rows that hold them are not fixed either);
+    edits match / holder on success.  Iterative depth-first search: components of hundreds of rows (duplicated points) must
+    not meet the interpreter's recursion limit."""
+    seen = set()
+    stack = [(r0, iter(sorted(allowed[r0])))]
+    path = []                                             # (row, column) steps taken so far
+    while stack:
+        r, it = stack[-1]
+        for c in it:
+            if c in fixed_cols or c in seen:
+                continue
+            seen.add(c)
+            r1 = holder.get(c)
+            if r1 is None:                                # a free column: flip the path
+                path.append((r, c))
+                for rr, cc in path:
+                    match[rr], holder[cc] = cc, rr
+                return True
+            path.append((r, c))
+            stack.append((r1, iter(sorted(allowed[r1]))))
+            break
+        else:
+            stack.pop()
+            if path:
+                path.pop()
+    return False
+
+
+def canonical_among_ties(cols, edges):
+    """``cols`` [n]: an optimal assignment (row -> column); ``edges`` [E,2]: every (row, column) pair off it that is tight
+    under its potentials (reart_lap_ties).  The optimal assignments are exactly the perfect matchings of the tight pairs,
+    whatever optimal potentials they were drawn with; they differ from ``cols`` along alternating cycles, i.e. inside the
+    strongly connected components of the row graph i -> owner(j).  Returns (the lexicographically smallest optimal assignment
+    -- rows in ascending order, each the smallest column some optimum gives it --, number of rows that changed): a function of
+    the SET of optima, so of the cost matrix alone."""
+    cols = np.asarray(cols, dtype=np.int64).copy()
+    n = cols.shape[0]
+    e = np.asarray(edges, dtype=np.int64).reshape(-1, 2)
+    if not len(e):
+        return cols, 0
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+
+    owner = np.empty(n, dtype=np.int64)
+    owner[cols] = np.arange(n)
+    to = owner[e[:, 1]]
+    keep = to != e[:, 0]
+    e, to = e[keep], to[keep]
+    ncomp, lab = connected_components(coo_matrix((np.ones(len(e), np.int8), (e[:, 0], to)), shape=(n, n)), directed=True,
+                                      connection="strong")
+    inside = lab[e[:, 0]] == lab[to]                       # a pair between two components is in no perfect matching
+    e = e[inside]
+    if not len(e):
+        return cols, 0
+    changed = 0
+    for comp in np.unique(lab[e[:, 0]]):
+        rows = np.nonzero(lab == comp)[0]
+        allowed = {int(r): {int(cols[r])} for r in rows}
+        for i, j in e[lab[e[:, 0]] == comp]:
+            allowed[int(i)].add(int(j))
+        best = _lex_min_matching(rows, allowed, cols)
+        for r, c in best.items():
+            if cols[r] != c:
+                cols[r] = c
+                changed += 1
+    assert np.array_equal(np.sort(cols), np.arange(n)), "canonical_among_ties: not a permutation"
+    return cols, changed
+
+
+def tight_pairs_host(src, tgt, cols, prices):
+    """reart_lap_ties' pair list for ONE problem, computed on the host from reart_cdist's matrix (the kernel's overflow path:
+    more tight pairs than it stores).  src, tgt [n,3] device tensors, cols [n], prices [n] -> [E,2] int64."""
+    c = cdist(src[None], tgt[None])[0].cpu().numpy().astype(np.float64)
+    p = prices.detach().cpu().numpy().astype(np.float64)
+    col = np.asarray(cols.detach().cpu().numpy(), dtype=np.int64)
+    both = torch.cat((src.reshape(-1), tgt.reshape(-1))).float()
+    mx = 1.7320508 * float((both.max() - both.min()).item())           # fp32 difference, as the kernels take it
+    if not mx > 0.0:
+        mx = 1.0
+    v = c + p[None, :]
+    cur = v[np.arange(len(col)), col]
+    hit = (v - cur[:, None]) <= mx * 1e-13
+    hit[np.arange(len(col)), col] = False
+    return np.argwhere(hit)
+
+
+class TieBreaker:
+    """reart_lap_ties behind a solve of B problems of n columns, and the host's canonical choice for the problems it flags.
+    ``launch`` queues the two kernels and the copy of the B flags behind the solve (no synchronisation); after the caller's
+    own synchronisation ``settle`` rewrites ``state["cols"]`` of every flagged problem IN PLACE and returns how many
+    problems changed."""
+
+    def __init__(self, B, n, device):
+        self.B, self.n, self.device, self.cap = B, n, device, 8 * n
+        self.tie = torch.zeros((B,), dtype=torch.int32, device=device)
+        self.n_edges = torch.zeros((B,), dtype=torch.int32, device=device)
+        self.edges = torch.empty((B, self.cap, 2), dtype=torch.int32, device=device)
+        self.tie_host = torch.zeros((B,), dtype=torch.int32).pin_memory()
+        self.flagged = self.changed = self.overflows = 0
+        self.log = None                                   # set to [] to keep (problem, old cols, new cols, pairs) of every change
+
+    def launch(self, src, tgt, cols, prices):
+        _lib.check(_lib.lib().reart_lap_ties(_lib.ptr(src), _lib.ptr(tgt), self.B, self.n, _lib.ptr(cols), _lib.ptr(prices),
+                                             _lib.ptr(self.tie), _lib.ptr(self.edges), _lib.ptr(self.n_edges), self.cap, _lib.stream()),
+                   "reart_lap_ties")
+        self.tie_host.copy_(self.tie, non_blocking=True)
+
+    def settle(self, src, tgt, state, skip=()):
+        """``skip``: problems whose solve did not certify (they went to the host solver)."""
+        changed = 0
+        cols, prices = state["cols"], state["prices"]
+        for b in self.tie_host.nonzero().flatten().tolist():
+            if b in skip or int(self.tie_host[b]) == 3:
+                continue
+            self.flagged += 1
+            if int(self.tie_host[b]) == 2:
+                self.overflows += 1
+                pairs = tight_pairs_host(src[b], tgt[b], cols[b], prices[b])
+            else:
+                pairs = self.edges[b, :int(self.n_edges[b].item())].cpu().numpy()
+            old = cols[b].cpu().numpy()
+            new, moved = canonical_among_ties(old, pairs)
+            if moved:
+                cols[b].copy_(torch.from_numpy(new).to(device=cols.device, dtype=cols.dtype))
+                changed += 1
+                if self.log is not None:
+                    self.log.append((b, old.copy(), new.copy(), np.asarray(pairs).copy()))
+        self.changed += changed
+        return changed
+
+
+def _tie_breaker(state, B, n, device):
+    tb = state.get("tie_breaker")
+    if tb is None or (tb.B, tb.n) != (B, n) or tb.device != device:
+        tb = state["tie_breaker"] = TieBreaker(B, n, device)
+    return tb
+
+
+def canonicalize(src, tgt, state, skip=()):
+    """One-shot form for the host-driven entries below: queue reart_lap_ties on ``state``'s optimum, wait, settle."""
+    B, n = state["cols"].shape
+    tb = _tie_breaker(state, B, n, src.device)
+    cols = state["cols"] if state["cols"].dtype == torch.int32 else state["cols"].int()
+    tb.launch(src, tgt, cols.contiguous(), state["prices"])
+    torch.cuda.current_stream().synchronize()
+    if cols is not state["cols"]:
+        state["cols"] = cols
+    return tb.settle(src, tgt, state, skip)
+
+
 POINTS_NMAX = 2048   # reart_lap_resolve_points keeps both point sets and the solver state in LDS
 # free-row orders raced per problem by linear_sum_assignment_points (reart_lap_resolve_points_race); REART_RESOLVE_RACERS=1: none
 RESOLVE_RACERS = int(os.environ.get("REART_RESOLVE_RACERS", "13"))
@@ -211,6 +403,10 @@ def linear_sum_assignment_points(src, tgt, state, return_stats=False, race=True,
     if not warm or n > POINTS_NMAX:
         res = linear_sum_assignment_batch(cdist(src, tgt), return_stats=(return_stats or device_cols), state=state,
                                           warm_assignment=True, points=(src, tgt), race=True)
+        if CANONICAL_TIES and n <= 4096 and canonicalize(src, tgt, state) and not device_cols:
+            rows_ = np.arange(n, dtype=np.int64)          # (a problem the host solved is optimal too: its ties are settled alike)
+            fixed = [(rows_, c_) for c_ in state["cols"].cpu().numpy().astype(np.int64)]
+            res = (fixed, *res[1:]) if isinstance(res, tuple) else fixed
         if device_cols:      # state["cols"] holds the certified (or host-solved) assignment
             return (state["cols"].long(), res[1], res[2]) if return_stats == "full" else (state["cols"].long(), res[1])
         return res
@@ -245,7 +441,13 @@ def linear_sum_assignment_points(src, tgt, state, return_stats=False, race=True,
                                         _lib.ptr(prices), _lib.ptr(ws), ws.numel(), _lib.stream())
     _lib.check(rc, "reart_lap_resolve_points")
     state["cols"] = col
+    tb = None
+    if CANONICAL_TIES:
+        tb = _tie_breaker(state, B, n, src.device)
+        tb.launch(src, tgt, col, prices)
     cert_h = cert.cpu().numpy()
+    if tb is not None:
+        tb.settle(src, tgt, state, skip=set(np.nonzero(cert_h == 0)[0].tolist()))
     col_h = None if device_cols else col.cpu().numpy().astype(np.int64)
     rows = np.arange(n, dtype=np.int64)
     out, fallbacks = [], 0
@@ -329,9 +531,16 @@ class InPlaceResolve:
         self.cert_host.copy_(self.cert, non_blocking=True)
         if stats:
             self.stats_host.copy_(ws[off:off + 16 * B].view(torch.int32), non_blocking=True)
+        tb = None
+        if CANONICAL_TIES:                                                # --deterministic: the tied problems, behind the solve
+            tb = _tie_breaker(state, B, n, self.device)
+            tb.launch(src, tgt, cols, prices)
         torch.cuda.current_stream().synchronize()
         fb = 0
-        for b in (self.cert_host == 0).nonzero().flatten().tolist():      # certificate did not close: exact host solve
+        bad = (self.cert_host == 0).nonzero().flatten().tolist()
+        if tb is not None:
+            tb.settle(src, tgt, state, skip=set(bad))
+        for b in bad:                                                     # certificate did not close: exact host solve
             from scipy.optimize import linear_sum_assignment
 
             fb += 1

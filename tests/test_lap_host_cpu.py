@@ -161,3 +161,40 @@ def test_spatial_order_is_a_permutation_that_keeps_neighbours_together():
     # degenerate input: all points equal -> the identity (stable sort of equal codes)
     same = torch.zeros((1, 16, 3))
     assert torch.equal(spatial_order(same)[0], torch.arange(16))
+
+
+def test_canonical_among_ties_is_the_lexicographic_minimum_of_all_optima():
+    """reart_amd.utils.lap.canonical_among_ties (the host half of --deterministic; reference: scipy's refresh is a function of
+    the cost matrix, run_robot.py:172-176): small integer matrices with many tied optima; starting from a RANDOM optimal
+    assignment and optimal potentials built for it, the result is the lexicographically smallest of all optimal permutations
+    (brute force) -- whatever the start."""
+    import itertools
+
+    from scipy.optimize import linear_sum_assignment
+
+    from reart_amd.utils.lap import canonical_among_ties
+
+    rng = np.random.default_rng(0)
+    tied = 0
+    for trial in range(1500):
+        n = int(rng.integers(2, 7))
+        C = rng.integers(0, 4, (n, n)).astype(np.float64)
+        r, c = linear_sum_assignment(C)
+        opt = C[r, c].sum()
+        opts = [p for p in itertools.permutations(range(n)) if C[np.arange(n), list(p)].sum() == opt]
+        tied += len(opts) > 1
+        start = np.array(opts[int(rng.integers(len(opts)))])
+        p = np.zeros(n)                                     # prices with c_ij + p_j >= c_i,s(i) + p_s(i): longest paths
+        for _ in range(n + 2):
+            for i in range(n):
+                for j in range(n):
+                    p[j] = max(p[j], p[start[i]] + C[i, start[i]] - C[i, j])
+        red = C + p[None, :]
+        cur = red[np.arange(n), start]
+        assert (red - cur[:, None] >= 0).all()
+        hit = (red - cur[:, None]) <= 0
+        hit[np.arange(n), start] = False
+        new, moved = canonical_among_ties(start, np.argwhere(hit))
+        assert tuple(new) == opts[0], (C, start, new, opts[0])
+        assert moved == int((new != start).sum())
+    assert tied > 300

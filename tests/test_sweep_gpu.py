@@ -144,9 +144,11 @@ def test_sweep_command_line_synthetic_batch_with_flow(dev, tmp_path):
         assert (tmp_path / name / "result.pkl").exists()
 
 
-@pytest.mark.parametrize("per_gpu", [None, 2])
-def test_sweep_command_line_readme_recipe(dev, tmp_path, per_gpu):
-    """per_gpu 2: the five instances run as THREE groups (2 + 2 + 1) that go through both phases CONCURRENTLY, each on a
+@pytest.mark.parametrize("per_gpu,in_flight", [(None, None), (2, None), (2, 2), (1, 2)])
+def test_sweep_command_line_readme_recipe(dev, tmp_path, per_gpu, in_flight):
+    """in_flight 2: more groups (3, or 5 of one instance) than may run at once -- the later groups are built and
+    captured lazily by the worker whose group has finished; never more than two in flight, same results.
+    per_gpu 2: the five instances run as THREE groups (2 + 2 + 1) that go through both phases CONCURRENTLY, each on a
     stream and a host thread of its own (round 5) -- same results, instance by instance, as one group of five.
     The README recipe as a sweep (README.md:116: --use_flow_loss --use_assign_loss --downsample 4; here assign_iter 40 of
     80 iterations): the five canonical frames of a generated sequence step in SHARED launches through both phases -- no
@@ -164,14 +166,17 @@ def test_sweep_command_line_readme_recipe(dev, tmp_path, per_gpu):
             "--use_assign_loss", "--assign_iter", "40", "--assign_gap", "5", "--downsample", "4", "--save_root", str(tmp_path)]
     if per_gpu:
         argv += ["--per_gpu", str(per_gpu)]
+    if in_flight:
+        argv += ["--groups_in_flight", str(in_flight)]
     with warnings.catch_warnings():
         warnings.simplefilter("error")                  # a batch group falling back to streams warns: not allowed here
         assert sweep.main(argv) == 0
     sw = json.load(open(tmp_path / "sweep.json"))
     st = sw["rank0_stages"]
-    groups = 3 if per_gpu else 1
+    groups = {None: 1, 2: 3, 1: 5}[per_gpu]
     assert st["assign_refreshes"] == 8 * groups and st["lap_fallbacks"] == 0         # per group: refreshes at 40, 45, ..., 75
-    assert st.get("concurrent_groups", 1) == groups
+    assert st.get("concurrent_groups", 1) == min(groups, in_flight or 4)
+    assert st.get("groups_in_flight_max", 1) <= (in_flight or 4)
     rows = sw["sequences"]["synthetic_0"]["instances"]
     assert all(r["iterations"] == 80 and r["failed"] == 0 and np.isfinite(r["total_loss"]) for r in rows)
     # instance cano_idx 1, alone
