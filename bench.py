@@ -229,8 +229,7 @@ def bench_extractor(args, dev):
     model.load_state_dict(extractor_state(model))
     model = model.to(dev).eval()
     B = xyz.shape[0]
-    steps = args.steps if args.steps != 1500 else 20
-    warm = args.warmup if args.warmup != 150 else 3
+    steps, warm = args.steps, args.warmup
     for _ in range(warm):
         f = model(xyz)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -404,7 +403,7 @@ def bench_kinematic(args, dev, rank, world, distributed, barrier):
 def run_secondary(args, dev, barrier):
     import copy
 
-    keep = ("value", "unit", "steps", "ms_per_step", "roofline", "cpu_baseline")
+    keep = ("value", "unit", "steps", "ms_per_step", "roofline", "cpu_baseline", "cpu_baseline_torch")
     sec, start = {}, {}
     for name in ("kinematic", "extractor", "nao", "nao_recipe", "nao_projection"):
         a = copy.copy(args)
@@ -412,10 +411,10 @@ def run_secondary(args, dev, barrier):
         t0 = time.perf_counter()
         try:
             if name == "nao":
-                a.steps = 1500                                    # = the full 15 000 iterations of configs[2]
+                a.steps = 15000                                   # the full 15 000 iterations of configs[2]
                 full = bench_nao(a, dev)
             elif name == "nao_recipe":
-                a.steps = 1500                                    # = the README's 15 000 iterations with 2 000 refreshes
+                a.steps = 15000                                   # the README's 15 000 iterations with 2 000 refreshes
                 full = bench_nao_recipe(a, dev, keep=start)
             elif name == "nao_projection":
                 # README.md:125 from the recipe's result above: a bounded sample (the first 1 500 of its 15 000 iterations, three
@@ -432,13 +431,16 @@ def run_secondary(args, dev, barrier):
             # metric / kernel / units are in the full line of `python bench.py --config <name>` and in DESIGN.md section 6
             if isinstance(sec[name].get("roofline"), dict):
                 sec[name]["roofline"] = {k: v for k, v in sec[name]["roofline"].items() if k not in ("kernel", "unit", "traffic")}
-            if isinstance(sec[name].get("cpu_baseline"), dict):
-                sec[name]["cpu_baseline"] = {k: v for k, v in sec[name]["cpu_baseline"].items() if k != "sample"}
+            for key in ("cpu_baseline", "cpu_baseline_torch"):
+                if isinstance(sec[name].get(key), dict):
+                    sec[name][key] = {k: v for k, v in sec[name][key].items() if k not in ("sample", "unit", "kind")}
+                elif key == "cpu_baseline_torch":
+                    sec[name].pop(key, None)
             extra = {"nao": ("matches_per_pair", "pairs_with_ground_truth_references", "correspondence_stage_s", "loop_s", "whole_run_s"),
                      "nao_recipe": ("correspondence_stage_s", "chamfer_phase_s", "assignment_phase_s", "loop_s", "whole_run_s",
                                     "assign_refreshes", "ms_per_refresh", "ms_per_solve", "first_solve_ms", "lap_fallbacks", "snapshots"),
                      "nao_projection": ("n_iter", "of", "snapshots", "iterations_per_s_by_window", "wall_s", "projected_whole_run_s",
-                                        "lap_fallbacks"),
+                                        "lap_fallbacks", "deterministic", "ties", "other_mode"),
                      "kinematic": ("lap_fallbacks",)}.get(name, ())
             sec[name].update({k: full["config"][k] for k in extra if k in full["config"]})
         except Exception as exc:                                  # a secondary figure never costs the headline line
@@ -499,7 +501,7 @@ def bench_nao_recipe(args, dev, keep=None):
     from reart_amd.run_robot import AssignmentPhase
 
     n_iter, assign_iter, gap, ds, lam = 15000, 5000, 5, 4, 0.3
-    if args.steps != 1500:                                         # a shortened run for experiments: same proportions
+    if args.steps != 15000:                                        # a shortened run for experiments: same proportions
         n_iter = max(args.steps, 30)
         assign_iter = n_iter // 3
     g, cano, pcs, c, complete, refs, flows, matches, gt_pairs, t_corr = nao_correspondences(dev)
@@ -604,7 +606,7 @@ def bench_nao_projection(args, dev, start=None, n_iter=None, windows=3):
     on nao, from the result of the relaxation recipe (README.md:116; `start`: what bench_nao_recipe kept, or that recipe is
     run here first, untimed).  Every iteration re-solves 9 optimal assignments of 2048 x 2048 (run_robot.py:164-187) and every
     10th prints the reference's snapshot metrics (run_robot.py:224-266).  n_iter: the default line runs a BOUNDED sample -- the
-    first `n_iter` iterations of the run, reported per window -- `--config nao_projection --steps 1500` = all 15 000."""
+    first `n_iter` iterations of the run, reported per window -- `--config nao_projection` without --steps = all 15 000."""
     import contextlib
     import io
 
@@ -614,7 +616,7 @@ def bench_nao_projection(args, dev, start=None, n_iter=None, windows=3):
     if start is None:
         start = {}
         a0 = argparse.Namespace(**vars(args))
-        a0.steps, a0.no_cpu_baseline = 1500, True
+        a0.steps, a0.no_cpu_baseline = 15000, True
         bench_nao_recipe(a0, dev, keep=start)
     model, cano, pcs, c, refs, flows = (start[k] for k in ("model", "cano", "pcs", "cano_idx", "refs", "flows"))
     total = 15000
@@ -627,9 +629,6 @@ def bench_nao_projection(args, dev, start=None, n_iter=None, windows=3):
     a = rr.build_parser().parse_args(["--model", "kinematic", "--use_flow_loss", "--use_assign_loss", "--assign_iter", "0",
                                       "--downsample", "2", "--assign_gap", "1", "--snapshot_gap", "10", "--cano_idx", str(c),
                                       "--n_iter", str(total)])
-    with contextlib.redirect_stdout(sys.stderr):
-        kin = rr.build_kinematic_from_base(result, cano, pcs, a).to(dev)
-    loop = rr.make_projection_loop(a, kin, cano, pcs, refs, flows)
     g = None
     try:
         from reart_amd.data import load_nao_demo
@@ -638,39 +637,102 @@ def bench_nao_projection(args, dev, start=None, n_iter=None, windows=3):
         pass
     sample = None if g is None else dict(gt_flow_list=g["gt_flow_list"], gt_cano_part=g["gt_cano_part"],
                                          complete_gt_pc_list=g["complete_gt_pc_list"])
-    snap = rr.SnapshotPrinter(a, kin, cano, pcs, sample, out=io.StringIO())        # the lines are produced, not shown
-    loop.lap_events = []
+    from reart_amd.utils import lap as lap_
     edges = [round(n_iter * k / windows) for k in range(windows + 1)]
-    marks = []
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for it in range(n_iter):
-        losses = loop.iteration(it)
-        if it % a.snapshot_gap == 0 or it == n_iter - 1:
-            snap(it, losses)
-        if it + 1 in edges[1:]:
+
+    def run_sample(deterministic):
+        """The first n_iter iterations of the run from the recipe's result, tied optima settled canonically or not."""
+        old = lap_.CANONICAL_TIES
+        lap_.CANONICAL_TIES = bool(deterministic)
+        try:
+            with contextlib.redirect_stdout(sys.stderr):
+                kin = rr.build_kinematic_from_base(result, cano, pcs, a).to(dev)
+            loop = rr.make_projection_loop(a, kin, cano, pcs, refs, flows)
+            snap = rr.SnapshotPrinter(a, kin, cano, pcs, sample, out=io.StringIO())        # the lines are produced, not shown
+            loop.lap_events = []
+            marks = []
             torch.cuda.synchronize()
-            marks.append(time.perf_counter() - t0)
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    ms = [e0.elapsed_time(e1) for e0, e1 in loop.lap_events]
+            t0 = time.perf_counter()
+            for it in range(n_iter):
+                losses = loop.iteration(it)
+                if it % a.snapshot_gap == 0 or it == n_iter - 1:
+                    snap(it, losses)
+                if it + 1 in edges[1:]:
+                    torch.cuda.synchronize()
+                    marks.append(time.perf_counter() - t0)
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            tb = loop.lap_state.get("tie_breaker")
+            return dict(loop=loop, kin=kin, snap=snap, marks=marks, el=el, losses=losses,
+                        ms=[e0.elapsed_time(e1) for e0, e1 in loop.lap_events],
+                        ties=None if tb is None else {"flagged": tb.flagged, "changed": tb.changed, "overflows": tb.overflows})
+        finally:
+            lap_.CANONICAL_TIES = old
+
+    mode = bool(getattr(args, "deterministic", lap_.CANONICAL_TIES))
+    run = run_sample(mode)
+    loop, kin, snap, marks, el, losses, ms = (run[k] for k in ("loop", "kin", "snap", "marks", "el", "losses", "ms"))
     win = [round((edges[k + 1] - edges[k]) / (marks[k] - (marks[k - 1] if k else 0.0)), 2) for k in range(len(marks))]
     lap_ms = float(np.mean(ms[1:])) if len(ms) > 1 else 0.0
     n = loop.tgt_pts.shape[1]
+    B = pcs.shape[0]
+    # latency roofline of the re-solve, as bench_kinematic builds it: the slowest problem's sequential workgroup-wide steps x the
+    # floor of one such step (arg-min + barrier) measured now, over the measured solve
+    from reart_amd import _lib as L_
+    import ctypes
+    floor_us = ctypes.c_double(0.0)
+    fws = torch.empty(16 * B + 256, dtype=torch.uint8, device=dev)
+    L_.check(L_.lib().reart_lap_step_floor(B, n, 20000, L_.ptr(fws), fws.numel(), ctypes.byref(floor_us), L_.stream()), "reart_lap_step_floor")
+    per_solve = np.asarray(getattr(loop, "lap_steps_log", [])[1:], dtype=np.float64)         # [re-solves, 3] (the cold solve left out)
+    steps_max = float(per_solve[:, 0].mean()) if per_solve.size else 0.0
+    steps_search = float(per_solve[:, 2].mean()) if per_solve.size else 0.0
+    bound_ms = steps_max * floor_us.value * 1e-3
+    # the other mode on the same bounded sample (the whole run is measured in one mode: profiles/)
+    other = None
+    if n_iter <= 3000 and not getattr(args, "one_mode", False):
+        o = run_sample(not mode)
+        o_ms = o["ms"]
+        other = {"deterministic": not mode, "value": round(n_iter / o["el"], 3), "wall_s": round(o["el"], 3),
+                 "kernel_ms": round(float(np.mean(o_ms[1:])) if len(o_ms) > 1 else 0.0, 4), **_pcts(o_ms[1:]),
+                 "lap_fallbacks": int(o["loop"].lap_fallbacks), "ties": o["ties"]}
+        del o
+    cpu = None
+    if not getattr(args, "no_cpu_baseline", False):
+        # the reference's refresh on this run's own problems (run_robot.py:164-178: torch.cdist + parallel_lap over a pool,
+        # utils/model_utils.py:85-89): ONE refresh of the 9 x 2048^2 on the host -- with --assign_gap 1 that is one iteration
+        import oracle
+        from reart_amd.networks.pointnet2_utils import index_points
+
+        with torch.no_grad():
+            pc_trans = kin(cano)[0]
+        src_idx_b = loop.src_idx if loop.src_idx.dim() == 2 else loop.src_idx[None].expand(B, -1)
+        pa, pb = index_points(pc_trans, src_idx_b).cpu(), loop.tgt_pts.cpu()
+        t1 = time.perf_counter()
+        c_cpu = torch.cdist(pa, pb).numpy()
+        oracle.parallel_lap(c_cpu, nproc=len(c_cpu))
+        el_cpu = time.perf_counter() - t1
+        cpu = {"value": round(1.0 / el_cpu, 4), "unit": "iterations/s", "cores": min(B, os.cpu_count() or 1), "kind": "reference",
+               "sample": f"one refresh the reference's way: torch.cdist + scipy on {B} processes, {el_cpu:.2f} s"}
     return {
         "metric": "kinematic-projection iterations/sec (README.md:125, nao)", "value": round(n_iter / el, 3), "unit": "iterations/s",
         "n_gpus": 1, "steps": n_iter, "warmup": 0, "ms_per_step": round(1e3 * el / n_iter, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32 (assignment potentials f64)",
         "data": "reference demo sequence (nao), seeded extractor weights",
-        "config": {"workload": f"nao projection as README.md:125 runs it: first {n_iter} of {total} iterations, {pcs.shape[0]} x {n}^2 per iteration",
+        "config": {"workload": f"nao projection as README.md:125 runs it: first {n_iter} of {total} iterations, {B} x {n}^2 per iteration",
                    "n_iter": n_iter, "of": total, "snapshot_gap": a.snapshot_gap, "snapshots": snap.count,
                    "iterations_per_s_by_window": win, "wall_s": round(el, 3),
                    "projected_whole_run_s": round(el * total / n_iter, 1) if n_iter < total else round(el, 3),
-                   "lap_fallbacks": int(loop.lap_fallbacks), "parts": int(trans_s.shape[1])},
-        "roofline": {"bound": "latency", "kernel": "lap_jvmw_kernel<32,2,16> + forest/arr/trees/set-up/passes (assignment re-solve)",
+                   "lap_fallbacks": int(loop.lap_fallbacks), "parts": int(trans_s.shape[1]),
+                   "deterministic": mode, "ties": run["ties"], "other_mode": other},
+        "roofline": {"bound": "latency", "achieved": round(bound_ms, 4), "peak": round(lap_ms, 4),
+                     "unit": "ms per re-solve (floor / measured)", "frac": round(bound_ms / lap_ms, 4) if lap_ms > 0 else None,
+                     "frac_search_only": round(steps_search * floor_us.value * 1e-3 / lap_ms, 4) if lap_ms > 0 else None,
+                     "kernel": "lap_jvmw_kernel<32,2,16> + forest/arr/trees/set-up/passes (assignment re-solve)",
                      "kernel_ms": round(lap_ms, 4), "solves_measured": max(len(ms) - 1, 0), **_pcts(ms[1:]),
+                     "step_floor_us": round(floor_us.value, 4), "steps_slowest_problem": round(steps_max, 1),
+                     "search_steps_slowest_problem": round(steps_search, 1),
                      "first_solve_ms": round(ms[0], 3) if ms else None, "traffic": None},
-        "cpu_baseline": None, "final_losses": {k: float(v.detach()) for k, v in losses.items()},
+        "cpu_baseline": cpu, "final_losses": {k: float(v.detach()) for k, v in losses.items()},
     }
 
 
@@ -685,7 +747,7 @@ def bench_nao(args, dev):
     from reart_amd.networks.model import BaseModel
     from reart_amd.relax import RelaxEngine
 
-    n_iter = 15000 if args.steps == 1500 else args.steps
+    n_iter = args.steps
     g, cano, pcs, c, complete, refs, flows, matches, gt_pairs, t_corr = nao_correspondences(dev)
     T, N = complete.shape[:2]
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
@@ -710,7 +772,7 @@ def bench_nao(args, dev):
     k_ms = 1e3 * prof["seconds"] / max(prof["launches"], 1)
     executed = prof["pairs"] / max(prof["launches"], 1)
     ach = executed * 8 / (k_ms * 1e-3) / 1e12
-    cpu = None
+    cpu = cpu_torch = None
     if not getattr(args, "no_cpu_baseline", False):
         import oracle
         from oracle.step import RelaxOracle
@@ -731,6 +793,23 @@ def bench_nao(args, dev):
                 break
         cpu = {"value": round(n / e2, 3), "unit": "iterations/s", "cores": oracle.num_threads(), "kind": "port",
                "sample": f"{n} iterations of the same nao step, oracle C/OpenMP, {e2:.1f} s"}
+        # the reference-style PyTorch-CPU loop body on the SAME nao step (networks/model.py:63-69,
+        # utils/chamfer.py:174 as torch expressions: oracle/torch_step.py), bounded like the port's sample
+        from oracle.torch_step import TorchRelax
+
+        te = TorchRelax(g["cano"], g["pc_list"], rng.uniform(-0.5, 0.5, (H, 3)).astype(np.float32),
+                        rng.uniform(-0.5, 0.5, H).astype(np.float32), rng.uniform(-0.08, 0.08, (P, H)).astype(np.float32),
+                        np.tile(np.array([1, 0, 0, 0, 1, 0], np.float32), (B, P, 1)), np.zeros((B, P, 3), np.float32), c,
+                        [r.cpu().numpy() for r in refs], [f.cpu().numpy() for f in flows])
+        te.step()
+        n3, t3 = 0, time.perf_counter()
+        while True:
+            te.step(); n3 += 1
+            e3 = time.perf_counter() - t3
+            if e3 > getattr(args, "cpu_budget", 8.0) or n3 >= 20:
+                break
+        cpu_torch = {"value": round(n3 / e3, 3), "unit": "iterations/s", "cores": torch.get_num_threads(), "kind": "port",
+                     "sample": f"{n3} iterations of the same nao step, reference-style PyTorch-CPU ops, {e3:.1f} s"}
     return {
         "metric": "relaxation-loop iterations/sec", "value": round(steps / el, 2), "unit": "iterations/s", "n_gpus": 1,
         "steps": steps, "warmup": done, "ms_per_step": round(1e3 * el / steps, 5), "higher_is_better": True, "scaling": "weak",
@@ -745,7 +824,7 @@ def bench_nao(args, dev):
                      "kernel_ms": round(k_ms, 5), "launches_measured": prof["launches"],
                      "executed_pairs_per_launch": round(executed, 1), "algorithmic_pairs_per_launch": int(nn_pairs),
                      "algorithmic_speedup": round(nn_pairs / max(executed, 1), 3)},
-        "cpu_baseline": cpu, "final_losses": [float(v) for v in eng.last_losses().cpu()[:3]],
+        "cpu_baseline": cpu, "cpu_baseline_torch": cpu_torch, "final_losses": [float(v) for v in eng.last_losses().cpu()[:3]],
     }
 
 
@@ -761,8 +840,10 @@ def main():
     ap.add_argument("--assign-gap", type=int, default=1)
     ap.add_argument("--downsample", type=int, default=2)
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1500)
-    ap.add_argument("--warmup", type=int, default=150)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed steps; default per --config: relax 1500, kinematic 100, extractor 20, nao / nao_recipe / nao_projection "
+                         "the WHOLE run (15 000 iterations)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps before; default per --config: relax 150, kinematic 10, extractor 3")
     ap.add_argument("--frames", type=int, default=20)
     ap.add_argument("--points", type=int, default=4096)
     ap.add_argument("--no-flow", action="store_true")
@@ -785,7 +866,19 @@ def main():
                     help="after the headline (one instance per GPU) also time this many concurrent instances per GPU "
                          "(--sweep-mode) and report the aggregate as `sweep` (0 = skip)")
     ap.add_argument("--profile-steps", type=int, default=20, help="eager steps timed per phase with HIP events")
+    ap.add_argument("--deterministic", dest="deterministic", action="store_true", default=True,
+                    help="(default, as in run_robot.py) assignment-bound configs: tied optima settled canonically")
+    ap.add_argument("--no-deterministic", dest="deterministic", action="store_false")
+    ap.add_argument("--one-mode", action="store_true", help="nao_projection: do not repeat the bounded sample in the other mode")
     args = ap.parse_args()
+    # an explicit --steps N always means N (1500 used to be a sentinel for "the whole run" of the nao configs)
+    args.full = args.steps is None
+    from reart_amd.utils import lap as _lap
+
+    _lap.CANONICAL_TIES = bool(args.deterministic)      # the product loops' default (run_robot.py / sweep: --deterministic)
+    d_steps, d_warm = {"relax": (1500, 150), "kinematic": (100, 10), "extractor": (20, 3)}.get(args.config, (15000, 0))
+    args.steps = d_steps if args.steps is None else args.steps
+    args.warmup = d_warm if args.warmup is None else args.warmup
 
     world = _launch_module().check_world(args.gpus)      # --gpus N must be an N-rank job (or self-launched above)
     rank = int(os.environ.get("RANK", "0"))
@@ -821,8 +914,6 @@ def main():
         torch.cuda.synchronize()
 
     if args.config == "kinematic":
-        if args.steps == 1500 and args.warmup == 150:      # the relax defaults: this config's iterations are ~100x longer
-            args.steps, args.warmup = 100, 10
         out = bench_kinematic(args, dev, rank, world, distributed, barrier)
         if rank == 0:
             print(_line(out))
@@ -832,7 +923,7 @@ def main():
         return
     if args.config in ("nao", "nao_recipe", "nao_projection"):
         if args.config == "nao_projection":
-            out = bench_nao_projection(args, dev, n_iter=None if args.steps == 1500 else args.steps, windows=15 if args.steps == 1500 else 3)
+            out = bench_nao_projection(args, dev, n_iter=None if args.full else args.steps, windows=15 if args.full else 3)
         else:
             out = bench_nao(args, dev) if args.config == "nao" else bench_nao_recipe(args, dev)
         if rank == 0:
@@ -900,6 +991,7 @@ def main():
     except Exception:
         prof = None
     replays, eager = eng.graph_replays, eng.eager_steps
+    el_local = el                                   # this rank's own clock around the timed region (the line's `value` uses the max)
     if distributed:
         tt = torch.tensor([el], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -973,7 +1065,13 @@ def main():
     else:
         energies = losses[None].cpu().numpy()
     # who ran what (one small object gather, outside the timed region): the driver's first multi-GPU run should be readable
-    me = {"rank": rank, "device": str(dev), "cano_idx": int(cano_idx)}
+    # ... and a straggler should be visible in the one line the driver keeps: every rank's own elapsed time and rate
+    me = {"rank": rank, "device": str(dev), "cano_idx": int(cano_idx), "elapsed_s": round(el_local, 5),
+          "it_per_s": round(K * args.steps / el_local, 2)}
+    try:
+        me["search_ms"] = round(1e3 * prof["seconds"] / prof["launches"], 5) if prof and prof["launches"] else None
+    except Exception:
+        me["search_ms"] = None
     if distributed:
         ranks_info = [None] * world
         dist.all_gather_object(ranks_info, me)

@@ -36,50 +36,93 @@ struct TieArgs {
     int cap;
 };
 
+#define TIE_ROWS 4                 // rows a wave tests per pass over the columns (one set of LDS reads serves all of them)
 __global__ __launch_bounds__(TIE_PASS_BS) void lap_tie_edges_kernel(TieArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lsm[];
     const int n = a.n, b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     double *price = (double *)lsm;
-    float *ptx = (float *)(price + n), *pty = ptx + n, *ptz = pty + n;
-    __shared__ float s_lo[TIE_PASS_BS / 64], s_hi[TIE_PASS_BS / 64];
+    float *ptx = (float *)(price + n), *pty = ptx + n, *ptz = pty + n, *pf = ptz + n;
+    __shared__ float s_lo[TIE_PASS_BS / 64], s_hi[TIE_PASS_BS / 64], s_pm[TIE_PASS_BS / 64];
     const float *S_ = a.src + (size_t)b * n * 3, *T_ = a.tgt + (size_t)b * n * 3;
     // the cost scale of the solvers' tolerances (lap.hip, points form): the diagonal of the clouds' common box
-    float lo = INFINITY, hi = -INFINITY;
+    float lo = INFINITY, hi = -INFINITY, pm = 0.f;
     for (int e = tid; e < 3 * n; e += TIE_PASS_BS) {
         const float sv = S_[e], tv = T_[e];
         (e % 3 == 0 ? ptx : (e % 3 == 1 ? pty : ptz))[e / 3] = tv;
         lo = fminf(lo, fminf(sv, tv)); hi = fmaxf(hi, fmaxf(sv, tv));
     }
-    for (int j = tid; j < n; j += TIE_PASS_BS) price[j] = a.price[(size_t)b * n + j];
+    // (the fp32 copies of the potentials are taken relative to the problem's first: only differences of potentials enter the
+    // test, and a run's potentials drift -- thousands of re-solves each lower some -- until their magnitude, not their spread,
+    // would set the margin: measured, every pair then passed the filter and the kernel took 100 us instead of 30)
+    const double pref = a.price[(size_t)b * n];
+    for (int j = tid; j < n; j += TIE_PASS_BS) {
+        const double pj = a.price[(size_t)b * n + j];
+        price[j] = pj; pf[j] = (float)(pj - pref);
+        pm = fmaxf(pm, fabsf((float)(pj - pref)));
+    }
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o, 64)); hi = fmaxf(hi, __shfl_xor(hi, o, 64)); }
-    if (lane == 0) { s_lo[wv] = lo; s_hi[wv] = hi; }
+    for (int o = 32; o >= 1; o >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, o, 64)); hi = fmaxf(hi, __shfl_xor(hi, o, 64)); pm = fmaxf(pm, __shfl_xor(pm, o, 64));
+    }
+    if (lane == 0) { s_lo[wv] = lo; s_hi[wv] = hi; s_pm[wv] = pm; }
     __syncthreads();
-    for (int w = 0; w < TIE_PASS_BS / 64; ++w) { lo = fminf(lo, s_lo[w]); hi = fmaxf(hi, s_hi[w]); }
+    for (int w = 0; w < TIE_PASS_BS / 64; ++w) { lo = fminf(lo, s_lo[w]); hi = fmaxf(hi, s_hi[w]); pm = fmaxf(pm, s_pm[w]); }
     double mx = 1.7320508 * (double)(hi - lo);
     if (!(mx > 0.0)) mx = 1.0;
     const double tol = mx * 1e-13;
     int *edges = a.edges + (size_t)b * a.cap * 2;
-    for (int i = blockIdx.y * (TIE_PASS_BS / 64) + wv; i < n; i += gridDim.y * (TIE_PASS_BS / 64)) {
-        const int c = a.col4row[(size_t)b * n + i];
-        if (c < 0 || c >= n) {                                         // not an assignment: nothing to say about it
-            if (lane == 0) atomicMax(&a.tie[b], 3);
-            continue;
+    // Nearly no pair is tight, and the exact test costs a correctly rounded square root (a dozen instructions), a conversion
+    // and two double-precision operations per pair.  In front of it, in fp32 and without the root: c_ij <= t := (u_i + margin) - p_j,
+    // i.e. t >= 0 and the SQUARED distance <= t^2 (1 + 2^-20) -- the margin is eight times the worst rounding of the two rounded
+    // potentials and of the subtraction (2^-24 each of |p_j|, |u_i| and the difference), the factor covers the root's and the
+    // square's roundings (2^-23 in all): a superset of the tight pairs passes, the exact test decides.
+    const int rows_per = TIE_ROWS * (TIE_PASS_BS / 64) * gridDim.y;
+    for (int i0 = (blockIdx.y * (TIE_PASS_BS / 64) + wv) * TIE_ROWS; i0 < n; i0 += rows_per) {
+        float ax[TIE_ROWS], ay[TIE_ROWS], az[TIE_ROWS], curf[TIE_ROWS], marg[TIE_ROWS];      // curf: u_i + margin, rounded
+        double cur[TIE_ROWS];
+        int c[TIE_ROWS];
+#pragma unroll
+        for (int r = 0; r < TIE_ROWS; ++r) {
+            const int i = i0 + r < n ? i0 + r : n - 1;                  // (a wave's last rows may repeat row n - 1: masked below)
+            c[r] = a.col4row[(size_t)b * n + i];
+            if (c[r] < 0 || c[r] >= n) {                                // not an assignment: nothing to say about it
+                if (lane == 0) atomicMax(&a.tie[b], 3);
+                c[r] = 0;
+            }
+            ax[r] = S_[3 * i]; ay[r] = S_[3 * i + 1]; az[r] = S_[3 * i + 2];
+            cur[r] = (double)sqrtf(reart_sqdist3(ax[r], ay[r], az[r], ptx[c[r]], pty[c[r]], ptz[c[r]])) + price[c[r]];
+            curf[r] = (float)(cur[r] - pref);
+            marg[r] = 4.76837158203125e-7f * (2.f * pm + 2.f * (float)mx + fabsf(curf[r]));      // 2^-21 x ...
+            curf[r] += marg[r];                                         // u_i + margin (the margin also covers this rounding)
         }
-        const float ax = S_[3 * i], ay = S_[3 * i + 1], az = S_[3 * i + 2];
-        const double cur = (double)sqrtf(reart_sqdist3(ax, ay, az, ptx[c], pty[c], ptz[c])) + price[c];
         for (int j0 = 0; j0 < n; j0 += 64) {
             const int j = j0 + lane;
-            bool hit = false;
-            if (j < n && j != c) hit = ((double)sqrtf(reart_sqdist3(ax, ay, az, ptx[j], pty[j], ptz[j])) + price[j]) - cur <= tol;
-            const unsigned long long m = __ballot(hit);
-            if (m) {
-                int base = 0;
-                if (lane == 0) base = atomicAdd(&a.n_edges[b], __builtin_popcountll(m));
-                base = __builtin_amdgcn_readfirstlane(base);
-                if (hit) {
-                    const int at = base + __builtin_popcountll(m & ((1ull << lane) - 1ull));
-                    if (at < a.cap) { edges[2 * at] = i; edges[2 * at + 1] = j; }
+            const bool in = j < n;
+            const int jj = in ? j : n - 1;
+            const float tx = ptx[jj], ty = pty[jj], tz = ptz[jj], pj = pf[jj];
+            unsigned near = 0;
+#pragma unroll
+            for (int r = 0; r < TIE_ROWS; ++r) {
+                const float t = curf[r] - pj;
+                near |= ((t >= 0.f && reart_sqdist3(ax[r], ay[r], az[r], tx, ty, tz) <= (t * t) * 1.00000095367431640625f) ? 1u : 0u) << r;
+            }
+            if (!in) near = 0;
+            if (__ballot(near != 0)) {
+#pragma unroll
+                for (int r = 0; r < TIE_ROWS; ++r) {
+                    bool hit = false;
+                    if (((near >> r) & 1u) && i0 + r < n && j != c[r])
+                        hit = ((double)sqrtf(reart_sqdist3(ax[r], ay[r], az[r], tx, ty, tz)) + price[j]) - cur[r] <= tol;
+                    const unsigned long long m = __ballot(hit);
+                    if (m) {
+                        int base = 0;
+                        if (lane == 0) base = atomicAdd(&a.n_edges[b], __builtin_popcountll(m));
+                        base = __builtin_amdgcn_readfirstlane(base);
+                        if (hit) {
+                            const int at = base + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+                            if (at < a.cap) { edges[2 * at] = i0 + r; edges[2 * at + 1] = j; }
+                        }
+                    }
                 }
             }
         }
@@ -158,13 +201,15 @@ extern "C" int reart_lap_ties(const float *src, const float *tgt, int B, int n, 
     if (B == 0) return REART_OK;
     if (!src || !tgt || !col4row || !price || !tie || !edges || !n_edges) return REART_ERR_INVALID_ARG;
     TieArgs a{src, tgt, B, n, col4row, price, tie, edges, n_edges, cap};
-    if (hipMemsetAsync(tie, 0, sizeof(int) * (size_t)B, (hipStream_t)stream) != hipSuccess ||
-        hipMemsetAsync(n_edges, 0, sizeof(int) * (size_t)B, (hipStream_t)stream) != hipSuccess)
+    if (n_edges == tie + B) {                                          // one buffer of 2 B ints (reart_amd/utils/lap.py): one fill
+        if (hipMemsetAsync(tie, 0, sizeof(int) * 2 * (size_t)B, (hipStream_t)stream) != hipSuccess) return REART_ERR_LAUNCH;
+    } else if (hipMemsetAsync(tie, 0, sizeof(int) * (size_t)B, (hipStream_t)stream) != hipSuccess ||
+               hipMemsetAsync(n_edges, 0, sizeof(int) * (size_t)B, (hipStream_t)stream) != hipSuccess)
         return REART_ERR_LAUNCH;
     int per = (2 * 256 + B - 1) / B;                                   // workgroups per problem: two per compute unit over the batch
     const int per_max = (n + TIE_PASS_BS / 64 - 1) / (TIE_PASS_BS / 64);
     per = per < 1 ? 1 : (per > per_max ? per_max : per);
-    const size_t lds_pass = (size_t)n * (8 + 12);
+    const size_t lds_pass = (size_t)n * (8 + 16);
     const size_t lds_cyc = (size_t)n * (4 * 4 + 1) + 4 * (size_t)TIE_LDS_EDGES + 16;
     if ((lds_pass > REART_LDS_DEFAULT_CAP &&
          hipFuncSetAttribute((const void *)lap_tie_edges_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pass) != hipSuccess) ||

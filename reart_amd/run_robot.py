@@ -621,10 +621,9 @@ def main(args):
     random.seed(args.manual_seed)
     if not torch.cuda.is_available():
         raise SystemExit("reart_amd runs on an AMD GPU only (no CPU fallback)")
-    if getattr(args, "deterministic", False):
-        from reart_amd.utils import lap as _lap
+    from reart_amd.utils import lap as _lap
 
-        _lap.CANONICAL_TIES = True
+    _lap.CANONICAL_TIES = bool(getattr(args, "deterministic", True))
     if args.evaluate and args.resume is None:
         raise ValueError("need model path to evaluate!")      # run_robot.py:86-87
     device = torch.device("cuda")
@@ -831,11 +830,13 @@ def build_parser():
     # additions
     p.add_argument("--synthetic", action="store_true", help="generated articulated sequence instead of --seq_path")
     p.add_argument("--synthetic_frames", default=20, type=int)
-    p.add_argument("--deterministic", action="store_true",
-                   help="the assignment refreshes return a function of the cost matrix alone, like the reference's scipy call "
-                        "(run_robot.py:172-176): when several assignments are optimal the raced GPU solvers return whichever "
-                        "finished first; with this flag every solve is checked for ties (reart_lap_ties) and a tied problem "
-                        "takes the lexicographically smallest optimum -- two runs under one --manual_seed are then the same run")
+    p.add_argument("--deterministic", dest="deterministic", action="store_true", default=True,
+                   help="(default) the assignment refreshes return a function of the cost matrix alone, like the reference's scipy "
+                        "call (run_robot.py:172-176): when several assignments are optimal the raced GPU solvers return whichever "
+                        "finished first, so every solve is checked for ties (reart_lap_ties) and a tied problem takes the "
+                        "lexicographically smallest optimum -- two runs under one --manual_seed are the same run (run_robot.py:37-49)")
+    p.add_argument("--no_deterministic", dest="deterministic", action="store_false",
+                   help="skip the tie check (about 2 %% of a projection iteration): tied optima are settled by whichever racer wins")
     return p
 
 

@@ -611,8 +611,9 @@ def build_cli():
     p.add_argument("--lambda_assign", default=3e-1, type=float)
     p.add_argument("--corr_model_path", default="pretrained/corr_model.pth.tar")
     p.add_argument("--normalize_file", default="data/category_normalize_scale.pkl", type=str)
-    p.add_argument("--deterministic", action="store_true",
-                   help="assignment refreshes settle tied optima canonically (run_robot.py --deterministic): a sweep repeats run to run")
+    p.add_argument("--deterministic", dest="deterministic", action="store_true", default=True,
+                   help="(default) assignment refreshes settle tied optima canonically (run_robot.py --deterministic): a sweep repeats run to run")
+    p.add_argument("--no_deterministic", dest="deterministic", action="store_false")
     return p
 
 
@@ -711,10 +712,9 @@ def main(argv=None, runner=None):
             raise SystemExit(f"rank {rank}: no GPU {local_rank} on this node ({torch.cuda.device_count()} visible)")
         torch.cuda.set_device(local_rank)
         device = torch.device("cuda", local_rank)
-        if args.deterministic:
-            from .utils import lap as _lap
+        from .utils import lap as _lap
 
-            _lap.CANONICAL_TIES = True
+        _lap.CANONICAL_TIES = bool(args.deterministic)
     else:
         device = torch.device("cpu")
     if launch.under_launcher() and not dist.is_initialized():

@@ -56,7 +56,12 @@ def snapshot_values(cano_pc, seg_part, trans_list, cano_idx, sample):
         vals += list(eval_flow(complete[1:] - complete[:-1], gt, acc1_thre=0.005, acc2_thre=0.01, as_tensors=True))
         names += ["epe", "acc5", "acc10", "angle"]
     if "gt_cano_part" in sample:
-        vals.append(eval_seg(torch.as_tensor(sample["gt_cano_part"]).long().to(dev), seg_part, as_tensor=True))
+        gt_part = sample["gt_cano_part"]
+        # the table holds every label of both sides: the ground truth's largest (read on the host when the sample lives there --
+        # the loader's numpy arrays; a device tensor is taken to stay below 128) and the model's parts
+        gt_max = int(gt_part.max()) if not (torch.is_tensor(gt_part) and gt_part.is_cuda) else 127
+        vals.append(eval_seg(torch.as_tensor(gt_part).long().to(dev), seg_part, as_tensor=True,
+                             num_labels=max(gt_max + 1, int(trans_list.shape[1]), 1)))
         names.append("ri")
     if "complete_gt_pc_list" in sample:
         gt = torch.as_tensor(sample["complete_gt_pc_list"]).float().to(dev)

@@ -29,12 +29,15 @@ def eval_seg(gt_segm, pd_segm, as_tensor=False, num_labels=128):
     count follows from the contingency table: agreeing ordered pairs = N^2 - sum_a n_a^2 - sum_b n_b^2 + 2 sum_ab n_ab^2."""
     gt, pd = gt_segm.long().reshape(-1), pd_segm.long().reshape(-1).to(gt_segm.device)
     n = gt.numel()
-    if as_tensor:      # no host sync: a fixed table of ``num_labels`` x ``num_labels`` cells (labels are part indices, far below 128)
-        s = num_labels
+    if as_tensor:      # no host sync: a fixed table of ``num_labels`` x ``num_labels`` cells (the caller sizes it from the data it
+        # holds: tail.snapshot_values).  A label outside the table would be dropped from the table but not from n^2 -- a wrong
+        # index, silently (ADVICE r05): the result is NaN instead
+        s = int(num_labels)
         ar = torch.arange(s, device=gt.device)
         table = (gt[:, None] == ar[None, :]).double().T @ (pd[:, None] == ar[None, :]).double()     # contingency table (no atomics)
         agree = n * n - (table.sum(1) ** 2).sum() - (table.sum(0) ** 2).sum() + 2 * (table ** 2).sum()
-        return (agree / (n * n)).float()
+        outside = ((gt < 0) | (gt >= s) | (pd < 0) | (pd >= s)).any()
+        return torch.where(outside, torch.full_like(agree, float("nan")), agree / (n * n)).float()
     s = int(max(gt.max(), pd.max())) + 1
     table = torch.bincount(gt * s + pd, minlength=s * s).reshape(s, s).double()
     agree = n * n - (table.sum(1) ** 2).sum() - (table.sum(0) ** 2).sum() + 2 * (table ** 2).sum()

@@ -288,8 +288,8 @@ class TieBreaker:
 
     def __init__(self, B, n, device):
         self.B, self.n, self.device, self.cap = B, n, device, 8 * n
-        self.tie = torch.zeros((B,), dtype=torch.int32, device=device)
-        self.n_edges = torch.zeros((B,), dtype=torch.int32, device=device)
+        both = torch.zeros((2 * B,), dtype=torch.int32, device=device)    # flags and counts side by side: one fill per call
+        self.tie, self.n_edges = both[:B], both[B:]
         self.edges = torch.empty((B, self.cap, 2), dtype=torch.int32, device=device)
         self.tie_host = torch.zeros((B,), dtype=torch.int32).pin_memory()
         self.flagged = self.changed = self.overflows = 0

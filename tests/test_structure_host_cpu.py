@@ -53,3 +53,19 @@ def test_joint_tree_orderings_match_networkx(seed):
     assert tree.nodes == ref["nodes"]
     assert tree.reverse_topo == ref["reverse_topo"]
     assert {k: list(v) for k, v in tree.paths_to_base.items()} == {k: list(v) for k, v in ref["paths_to_base"].items()}
+
+
+def test_rand_index_table_is_sized_from_the_data():
+    """utils/eval_utils.py:25-36 (Rand index).  ADVICE r05: the sync-free form used a fixed 128 x 128 table and silently
+    dropped labels beyond it; now the caller sizes the table and a label outside it gives NaN, not a wrong index."""
+    import torch
+
+    from reart_amd.utils.eval_utils import eval_seg
+
+    rng = np.random.default_rng(0)
+    gt, pd = torch.from_numpy(rng.integers(0, 200, 500)), torch.from_numpy(rng.integers(0, 7, 500))
+    same = (gt[:, None] == gt[None, :]) == (pd[:, None] == pd[None, :])                       # the reference's N x N form
+    want = float(same.double().mean())
+    assert abs(float(eval_seg(gt, pd)) - want) < 1e-6
+    assert abs(float(eval_seg(gt, pd, as_tensor=True, num_labels=200)) - want) < 1e-6
+    assert np.isnan(float(eval_seg(gt, pd, as_tensor=True, num_labels=128)))

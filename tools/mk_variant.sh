@@ -7,7 +7,8 @@ tag=$1; expr=$2; shift 2
 mkdir -p build
 sed -e "$expr" lap_mw.hip > build/lap_mw_$tag.hip
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wall -Wno-unused-function -I. "$@" -c build/lap_mw_$tag.hip -o build/lap_mw_$tag.o
-objs="build/assign.o build/flow.o build/gemm.o build/grid.o build/kinematic.o build/knn.o build/lap.o build/lib.o build/model.o build/pointnet.o build/prune.o build/smnn.o build/step.o build/structure.o"
+objs=""
+for f in *.hip; do [ "$f" != lap_mw.hip ] && objs="$objs build/${f%.hip}.o"; done      # every product object but lap_mw.o (make first)
 if [[ " $* " == *REART_PRUNE_PHASE* ]]; then objs="${objs/build\/lap.o/build/lap_phase.o}"; objs="${objs/build\/prune.o/build/prune_phase.o}"; fi
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o libreart_hip_$tag.so $objs build/lap_mw_$tag.o
 echo built libreart_hip_$tag.so

@@ -11,7 +11,10 @@ if "--projection" in sys.argv:
     import argparse, json
     import torch
     import bench
-    a = argparse.Namespace(steps=1500, warmup=150, no_cpu_baseline=True, cpu_budget=3.0, frames=20, points=4096)
+    a = argparse.Namespace(steps=15000, warmup=0, no_cpu_baseline=True, cpu_budget=3.0, frames=20, points=4096, one_mode=True)
+    a.deterministic = "--no-deterministic" not in sys.argv
+    from reart_amd.utils import lap as _lap
+    _lap.CANONICAL_TIES = a.deterministic
     t0 = time.perf_counter()
     out = bench.bench_nao_projection(a, torch.device("cuda:0"), n_iter=None, windows=15)
     c, r = out["config"], out["roofline"]
