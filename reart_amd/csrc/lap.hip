@@ -870,6 +870,34 @@ __device__ __forceinline__ void lap_row_top2_pts(float ax, float ay, float az, c
 }
 
 
+// The row's smallest c_ij + p_j and its lowest column ALONE (no second minimum), from a seed (v1, j1) every lane holds -- the
+// row's own column when the caller has one: for most rows of a re-solve that IS the minimum.  A column can only matter if
+// c <= v1 - p_j, i.e. if its SQUARED distance <= (v1 - p_j)^2: the correctly rounded square root (a dozen instructions), the
+// conversion and the sum are skipped for every column that fails this -- nearly all of them once v1 is close to the minimum.
+// The test errs on the side of passing (slack for the rounding of the difference, 1 + 2^-20 for the root's and the square's),
+// and what passes goes through the same expression and the same tie rule (the lowest column) as lap_row_top2_pts:
+// the same (v1, j1), bit for bit.
+__device__ __forceinline__ void lap_row_min_pts_seeded(float ax, float ay, float az, const float *__restrict__ tx,
+                                                       const float *__restrict__ ty, const float *__restrict__ tz,
+                                                       const double *__restrict__ p, int n, int lane, double &v1, int &j1) {
+    for (int j0 = lane; j0 < n; j0 += 64 * 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + 64 * u;
+            if (j < n) {
+                const double pj = p[j];
+                const float sq = reart_sqdist3(ax, ay, az, tx[j], ty[j], tz[j]);
+                const double T = (v1 - pj) + (fabs(v1) + fabs(pj)) * 8.9e-16;
+                if (T >= 0.0 && (double)sq <= (T * T) * 1.00000095367431640625) {
+                    const double v = (double)sqrtf(sq) + pj;
+                    if (v < v1 || (v == v1 && j < j1)) { v1 = v; j1 = j; }
+                }
+            }
+        }
+    }
+    lap_wave_argmin_fast(v1, j1);
+}
+
 // MODE 0: the whole re-solve in one launch.  MODE 1: the sequential part only -- row potentials come from lap_jv_pass_kernel
 // (pre_*), the certificate is left to the next two launches (certified[b] = 2: pending).  MODE 2: certificate of a pending
 // matrix whose first round (lap_jv_pass_kernel, pass_mode 1) found a violation: the Jacobi rounds from the solve's prices.
@@ -1300,15 +1328,21 @@ __global__ __launch_bounds__(JV_PASS_BS) void lap_jv_pass_kernel(JvArgs a) {
         double v1, v2;
         int j1;
         float ax = 0.f, ay = 0.f, az = 0.f;
+        const int c = a.col4row[(size_t)b * n + i];
+        const bool has = c >= 0 && c < n;
+        double cur = 0.0;
         if (PTS) {
+            // only the minimum and its column are kept of a pass (pre_v1 / pre_j1; the certificate compares v1 with cur): the
+            // scan starts from the row's own column and skips what cannot beat it (lap_row_min_pts_seeded: same v1, j1)
             ax = S_[3 * i]; ay = S_[3 * i + 1]; az = S_[3 * i + 2];
-            lap_row_top2_pts(ax, ay, az, ptx, pty, ptz, price, 0, n, lane, v1, j1, v2);
-        } else lap_row_top2(C + (size_t)i * n, price, n, lane, v1, j1, v2);
+            if (has) cur = (double)sqrtf(reart_sqdist3(ax, ay, az, ptx[c], pty[c], ptz[c])) + price[c];
+            v1 = has ? cur : INFINITY; j1 = has ? c : 0x7fffffff;
+            lap_row_min_pts_seeded(ax, ay, az, ptx, pty, ptz, price, n, lane, v1, j1);
+        } else {
+            lap_row_top2(C + (size_t)i * n, price, n, lane, v1, j1, v2);
+            if (has) cur = (double)C[(size_t)i * n + c] + price[c];
+        }
         if (lane == 0) {
-            const int c = a.col4row[(size_t)b * n + i];
-            const bool has = c >= 0 && c < n;
-            double cur = 0.0;
-            if (has) cur = (double)(PTS ? sqrtf(reart_sqdist3(ax, ay, az, ptx[c], pty[c], ptz[c])) : C[(size_t)i * n + c]) + price[c];
             if (a.pass_mode == 0) {
                 a.pre_v1[(size_t)b * n + i] = v1; a.pre_j1[(size_t)b * n + i] = j1; a.pre_cur[(size_t)b * n + i] = cur;
             } else if (!has || cur - v1 > tol) atomicOr(&a.cert_bad[b], 1);
@@ -1316,12 +1350,75 @@ __global__ __launch_bounds__(JV_PASS_BS) void lap_jv_pass_kernel(JvArgs a) {
     }
 }
 
+// The points form of the passes, as it is launched since round 6.  The generic kernel above spent its 61 us per pass (9 x 2048^2)
+// WAITING, not computing: eight serial round trips of its staging loop, then one more per row for the row's point and column,
+// with eight waves on a compute unit to hide them -- taking the square roots out of its scan changed nothing.  Here: one
+// workgroup of 16 waves per compute unit (one staged copy of the targets and potentials serves 16 waves); the staging loop's
+// loads are all in flight before the first LDS store; a wave fetches the points and columns of ALL its rows at once (lane k holds
+// row k) and reads them back with v_readlane.  Same scan (lap_row_min_pts_seeded), same results.
+#define JV_PASSP_BS 1024
+__global__ __launch_bounds__(JV_PASSP_BS) void lap_jv_pass_pts_kernel(JvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lsm[];
+    constexpr int NW = JV_PASSP_BS / 64, NJ = (JV_PTS_NMAX + JV_PASSP_BS - 1) / JV_PASSP_BS;
+    const int n = a.n, b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (a.pass_mode == 1 && a.certified[b] != 2) return;
+    double *price = (double *)lsm;
+    float *ptx = (float *)(price + n), *pty = ptx + n, *ptz = pty + n;
+    const double *pin = a.pass_mode == 0 ? a.price_in : a.price_out;
+    const float *S_ = a.src + (size_t)b * n * 3, *T_ = a.tgt + (size_t)b * n * 3;
+    {
+        double pv[NJ];
+        float vx[NJ], vy[NJ], vz[NJ];
+#pragma unroll
+        for (int k = 0; k < NJ; ++k) {
+            const int j = tid + k * JV_PASSP_BS, jj = j < n ? j : 0;
+            pv[k] = pin ? pin[(size_t)b * n + jj] : 0.0;
+            vx[k] = T_[3 * jj]; vy[k] = T_[3 * jj + 1]; vz[k] = T_[3 * jj + 2];
+        }
+#pragma unroll
+        for (int k = 0; k < NJ; ++k) {
+            const int j = tid + k * JV_PASSP_BS;
+            if (j < n) { price[j] = pv[k]; ptx[j] = vx[k]; pty[j] = vy[k]; ptz[j] = vz[k]; }
+        }
+    }
+    // this wave's rows: first, first + stride, ...; lane k fetches row k of every block of 64 of them
+    const int first = blockIdx.y * NW + wv, stride = gridDim.y * NW;
+    const int nrows = first < n ? (n - first + stride - 1) / stride : 0;
+    const double tol = a.pass_mode == 1 ? a.scale[b] * 1e-13 : 0.0;
+    for (int k0 = 0; k0 < nrows; k0 += 64) {
+        const int il = first + (k0 + lane) * stride, ic = il < n ? il : 0;
+        const float lx = S_[3 * ic], ly = S_[3 * ic + 1], lz = S_[3 * ic + 2];
+        const int lc = a.col4row[(size_t)b * n + ic];
+        if (k0 == 0) __syncthreads();                    // (the staged copies; the rows' loads are in flight across it)
+        const int kn = nrows - k0 < 64 ? nrows - k0 : 64;
+        for (int k = 0; k < kn; ++k) {
+            const int i = first + (k0 + k) * stride;
+            const float ax = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lx), k));
+            const float ay = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ly), k));
+            const float az = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lz), k));
+            const int c = __builtin_amdgcn_readlane(lc, k);
+            const bool has = c >= 0 && c < n;
+            double cur = 0.0;
+            if (has) cur = (double)sqrtf(reart_sqdist3(ax, ay, az, ptx[c], pty[c], ptz[c])) + price[c];
+            double v1 = has ? cur : INFINITY;
+            int j1 = has ? c : 0x7fffffff;
+            lap_row_min_pts_seeded(ax, ay, az, ptx, pty, ptz, price, n, lane, v1, j1);
+            if (lane == 0) {
+                if (a.pass_mode == 0) {
+                    a.pre_v1[(size_t)b * n + i] = v1; a.pre_j1[(size_t)b * n + i] = j1; a.pre_cur[(size_t)b * n + i] = cur;
+                } else if (!has || cur - v1 > tol) atomicOr(&a.cert_bad[b], 1);
+            }
+        }
+    }
+    if (nrows == 0) __syncthreads();                     // (every wave of the workgroup meets the barrier above exactly once)
+}
+
 // Re-solve from the assignment in col4row and the potentials in price_in (both from an earlier solve of a similar batch,
 // reart_lap_auction* or these functions); same outputs and the same certificate as reart_lap_auction.
 // the state arrays of the many-compute-unit row reduction, behind the race layout
 static size_t jv_mc_extra_bytes(int B, int n) {
     return reart_align_up(sizeof(double) * (size_t)B * n, 256) + 6 * reart_align_up(sizeof(int) * (size_t)B * n, 256) +
-           reart_align_up(sizeof(int) * 8 * (size_t)B, 256);
+           reart_align_up(sizeof(int) * 8 * ((size_t)B + 1), 256);      // (+ one block of launch-wide counters behind the problems')
 }
 extern "C" size_t reart_lap_mc_workspace_bytes(int B, int n, int racers) {
     const size_t r = reart_lap_race_workspace_bytes(B, n, racers);
@@ -1364,12 +1461,21 @@ static int jv_launch(JvArgs a, void *workspace, size_t workspace_bytes, void *st
         a.scale = (double *)w; w += reart_align_up(sizeof(double) * (size_t)a.B, 256);
         a.cert_bad = (int *)w;
     }
-    int per = (2 * 256 + a.B - 1) / a.B;                       // workgroups per matrix: two per compute unit over the batch
-    const int per_max = (a.n + JV_PASS_BS / 64 - 1) / (JV_PASS_BS / 64);
+    int per = PTS ? (256 + a.B - 1) / a.B : (2 * 256 + a.B - 1) / a.B;   // workgroups per matrix: one of 16 waves (points) / two of 4 per compute unit over the batch
+    const int pass_waves = (PTS ? JV_PASSP_BS : JV_PASS_BS) / 64;
+    const int per_max = (a.n + pass_waves - 1) / pass_waves;
     per = per < 1 ? 1 : (per > per_max ? per_max : per);
     const size_t lds_pass = (size_t)a.n * (8 + (PTS ? 12 : 0));
+    auto launch_pass = [&]() {
+        if (PTS) hipLaunchKernelGGL(lap_jv_pass_pts_kernel, dim3(a.B, per), dim3(JV_PASSP_BS), lds_pass, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((lap_jv_pass_kernel<false>), dim3(a.B, per), dim3(JV_PASS_BS), lds_pass, (hipStream_t)stream, a);
+    };
+    if (lds_pass > REART_LDS_DEFAULT_CAP &&
+        hipFuncSetAttribute(PTS ? (const void *)lap_jv_pass_pts_kernel : (const void *)lap_jv_pass_kernel<false>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pass) != hipSuccess)
+        return REART_ERR_LAUNCH;
     a.pass_mode = 0;
-    hipLaunchKernelGGL((lap_jv_pass_kernel<PTS>), dim3(a.B, per), dim3(JV_PASS_BS), lds_pass, (hipStream_t)stream, a);
+    launch_pass();
     REART_CHECK_LAUNCH();
     if (racers > 1) {
         // the racers' common start: copies of the assignment and the potentials (the winner overwrites the originals while
@@ -1404,7 +1510,7 @@ static int jv_launch(JvArgs a, void *workspace, size_t workspace_bytes, void *st
     }
     a.done = nullptr;
     a.pass_mode = 1;
-    hipLaunchKernelGGL((lap_jv_pass_kernel<PTS>), dim3(a.B, per), dim3(JV_PASS_BS), lds_pass, (hipStream_t)stream, a);
+    launch_pass();
     REART_CHECK_LAUNCH();
     a.price_in = a.price_out;                                  // the certificate continues from the solve's potentials
     hipLaunchKernelGGL((lap_jv_kernel<JVBS, PTS, 2>), dim3(a.B), dim3(JVBS), lds, (hipStream_t)stream, a);

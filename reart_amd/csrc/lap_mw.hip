@@ -305,6 +305,7 @@ __global__ __launch_bounds__(64 * NW) void lap_jvmw_kernel(JvArgs a) {
         if (tid == 0) {
             int *c = a.mc_cnt + 8 * b;
             c[0] = nfree; c[1] = 0; c[2] = 0; c[3] = 0; c[4] = 0; c[5] = st_freed; c[6] = 0; c[7] = sh.flag;
+            if (b == 0) a.mc_cnt[8 * a.B] = 0;                          // launch-wide: row-reduction teams that have run out of rows
             a.scale[b] = mx;
         }
         return;
@@ -801,6 +802,14 @@ __global__ __launch_bounds__(64 * NW) void lap_jvmw_kernel(JvArgs a) {
 // (9 x 1024^2) 12.1 / 11.2 s / - for the whole run, kinematic projection (19 x 2048^2) 62.5 / 64.9 / 64.4 iterations/s; on 8
 // workgroups per problem (13, 16 or 28: no better -- more commits collide).  JvArgs.mc_chain overrides.
 #define MW_MC_CHAIN 128
+// ... and that longest chain is nearly always a HOPELESS one: a row the searches end up with burns its whole budget first, so
+// with one to four such rows per problem (the typical re-solve of the projection) the launch lasts 128 steps x 3 us = 0.4 ms
+// while the other thousand chains are done after 0.1 (tools/replay_kernels.py: arr 418 us of a 1 310 us solve with <= 8 rows
+// left).  Cutting every chain at 32 or 64 steps loses (rows that would have settled go to the searches: recipe +6 %).  So the
+// cut depends on who is still running: a chain that has used MW_ARR_TAIL_STEPS steps gives up once all but 1 / MW_ARR_TAIL_DIV of
+// the launch's teams have run out of rows -- while the chip is busy a long chain delays nobody, at the end it delays everybody.
+#define MW_ARR_TAIL_STEPS 32
+#define MW_ARR_TAIL_DIV 16
 
 // Between the set-up and the row reduction: every unowned column's price is lowered until the first MATCHED row is indifferent
 // between it and its own column (the step the searches' part of lap_jvmw_kernel explains; here for all the columns the
@@ -965,6 +974,7 @@ __global__ __launch_bounds__(256) void lap_mc_trees_kernel(JvArgs a) {
 // and inherits that column's ROOT (a search that reaches it walks to that unowned column; the root is what a search uses up).
 // One workgroup per problem: a thread owns the rows of its columns (M_i = min over the forest of c_it + q_t and the column
 // that attains it in registers), a round is one workgroup arg-min + one distance per row.  MW_FOREST_R rounds.
+#define MW_FOREST_PER 32     // > 0: the growth stops after this many rows per row LEFT for the searches (cnt[2]), at most MW_FOREST_R
 #define MW_FOREST_R 512       // measured 0 / 48 / 128 / 256 / 512 / 1024: recipe 3.57 / 3.58 / 3.51 / 3.37 / 3.33 / 3.70 ms per refresh, projection 78.8 / 77.9 / 80.4 / 82.4 / 86.7 / 86.8 it/s
 template <int CPL>
 __global__ __launch_bounds__(512) void lap_mc_forest_kernel(JvArgs a) {
@@ -1023,7 +1033,7 @@ __global__ __launch_bounds__(512) void lap_mc_forest_kernel(JvArgs a) {
     }
     double off = 0.0;
     int nf = nf0;
-    const int rounds = MW_FOREST_R;     // rows the growth stops after (measured per-problem targets, 16 / 32 / 64 per row left: no better)
+    const int rounds = MW_FOREST_PER > 0 ? min(MW_FOREST_R, MW_FOREST_PER * cnt[2]) : MW_FOREST_R;     // rows the growth stops after
     // The growth is a shortest-path computation like the searches' (the label of an outside row: L_i = M_i - u_i, the shift
     // at which it becomes tight to the forest; a row that joins at shift o offers its column at q + o to everybody else) and
     // runs in BUCKETS like them: all outside rows with a label below (closest label) + width join together, label-correcting
@@ -1288,7 +1298,7 @@ __global__ __launch_bounds__(64 * TW) void lap_mc_arr_team_kernel(JvArgs a) {
     const float *S_ = a.src + (size_t)b * n * 3, *T_ = a.tgt + (size_t)b * n * 3;
     const int nfree = cnt[0];
     __shared__ double s_v1[2][TW], s_v2[2][TW], s_p[2][TW];
-    __shared__ int s_j1[2][TW], s_o[2][TW], s_q[2], s_ok[2];
+    __shared__ int s_j1[2][TW], s_o[2][TW], s_q[2], s_ok[2], s_fin[2];
     jv_f2 tcx[CW / 2], tcy[CW / 2], tcz[CW / 2];
     int col[CW];
 #pragma unroll
@@ -1300,6 +1310,8 @@ __global__ __launch_bounds__(64 * TW) void lap_mc_arr_team_kernel(JvArgs a) {
     auto ld_i = [](const int *p) -> int { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     auto ld_d = [](const double *p) -> double { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     int my_arr = 0, my_conf = 0, par = 0, qpar = 0, opar = 0;
+    int *fin = a.mc_cnt + 8 * a.B;                        // launch-wide: teams that have run out of rows
+    const int teams = gridDim.x * gridDim.y, tail_at = teams - teams / MW_ARR_TAIL_DIV;
     for (;;) {
         if (threadIdx.x == 0) s_q[qpar] = __hip_atomic_fetch_add(&cnt[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
@@ -1312,6 +1324,8 @@ __global__ __launch_bounds__(64 * TW) void lap_mc_arr_team_kernel(JvArgs a) {
         for (int budget = a.mc_chain; ; ) {
             double pr[CW];
             int ow[CW];
+            int fin_now = 0;
+            if (threadIdx.x == 0) fin_now = ld_i(fin);       // (in the same round of reads as the prices)
 #pragma unroll
             for (int k = 0; k < CW; ++k) {
                 pr[k] = col[k] < n ? ld_d(price + col[k]) : INFINITY;
@@ -1335,7 +1349,9 @@ __global__ __launch_bounds__(64 * TW) void lap_mc_arr_team_kernel(JvArgs a) {
             const double pw = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(pl), hl), __builtin_amdgcn_readlane(__double2loint(pl), hl));
             const int owv = __builtin_amdgcn_readlane(ol, hl);
             if (lane == 0) { s_v1[par][wv] = v1; s_v2[par][wv] = v2; s_j1[par][wv] = j1; s_p[par][wv] = pw; s_o[par][wv] = owv; }
+            if (threadIdx.x == 0) s_fin[par] = fin_now;
             __syncthreads();
+            const bool tail = s_fin[par] >= tail_at && a.mc_chain - budget >= MW_ARR_TAIL_STEPS;      // uniform across the team
             v1 = lane < TW ? s_v1[par][lane] : INFINITY; v2 = lane < TW ? s_v2[par][lane] : INFINITY;
             j1 = lane < TW ? s_j1[par][lane] : 0x7fffffff;
             int win = lane;
@@ -1347,7 +1363,7 @@ __global__ __launch_bounds__(64 * TW) void lap_mc_arr_team_kernel(JvArgs a) {
             if (!(v1 < INFINITY)) { if (threadIdx.x == 0) __hip_atomic_store(&cnt[6], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
             if (own == MW_LOCKED && ++spins < (1 << 14)) { ++my_conf; continue; }     // somebody is committing on it: look again
             const bool tie = !(v1 < v2);
-            if (own == MW_LOCKED || --budget < 0 || (tie && own >= 0)) {       // (a lock that never opens: never observed) / out of budget / an exact tie on an owned column
+            if (own == MW_LOCKED || --budget < 0 || (tie && own >= 0) || (tail && own >= 0)) {   // (a lock that never opens: never observed) / out of budget / an exact tie on an owned column / the launch's tail
                 if (threadIdx.x == 0) next[__hip_atomic_fetch_add(&cnt[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = i;
                 break;
             }
@@ -1378,6 +1394,7 @@ __global__ __launch_bounds__(64 * TW) void lap_mc_arr_team_kernel(JvArgs a) {
         }
     }
     if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(fin, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(&cnt[3], my_arr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(&cnt[4], my_conf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }

@@ -21,7 +21,7 @@
 #include "common.h"
 #include "lap_dev.h"
 
-#define TIE_PASS_BS 256
+#define TIE_PASS_BS 1024
 #define TIE_CYC_BS 1024
 #define TIE_LDS_EDGES 12288        // tight pairs one workgroup keeps in LDS (48 KB); more: tie[b] = 2, the host looks itself
 
@@ -37,36 +37,63 @@ struct TieArgs {
 };
 
 #define TIE_ROWS 4                 // rows a wave tests per pass over the columns (one set of LDS reads serves all of them)
+// One workgroup of 16 waves per compute unit; the staging loads are all in flight before the first LDS store, and a wave fetches
+// the points and columns of all its rows at once (lane k holds row k): as four waves per workgroup with a load per row the
+// kernel spent 100 us waiting for round trips whatever its scan cost (the same finding as lap_jv_pass_pts_kernel, lap.hip).
 __global__ __launch_bounds__(TIE_PASS_BS) void lap_tie_edges_kernel(TieArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lsm[];
+    constexpr int NW = TIE_PASS_BS / 64, NJ = (LAP_NMAX + TIE_PASS_BS - 1) / TIE_PASS_BS;
     const int n = a.n, b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     double *price = (double *)lsm;
     float *ptx = (float *)(price + n), *pty = ptx + n, *ptz = pty + n, *pf = ptz + n;
-    __shared__ float s_lo[TIE_PASS_BS / 64], s_hi[TIE_PASS_BS / 64], s_pm[TIE_PASS_BS / 64];
+    __shared__ float s_lo[NW], s_hi[NW], s_pm[NW];
     const float *S_ = a.src + (size_t)b * n * 3, *T_ = a.tgt + (size_t)b * n * 3;
-    // the cost scale of the solvers' tolerances (lap.hip, points form): the diagonal of the clouds' common box
-    float lo = INFINITY, hi = -INFINITY, pm = 0.f;
-    for (int e = tid; e < 3 * n; e += TIE_PASS_BS) {
-        const float sv = S_[e], tv = T_[e];
-        (e % 3 == 0 ? ptx : (e % 3 == 1 ? pty : ptz))[e / 3] = tv;
-        lo = fminf(lo, fminf(sv, tv)); hi = fmaxf(hi, fmaxf(sv, tv));
-    }
     // (the fp32 copies of the potentials are taken relative to the problem's first: only differences of potentials enter the
     // test, and a run's potentials drift -- thousands of re-solves each lower some -- until their magnitude, not their spread,
-    // would set the margin: measured, every pair then passed the filter and the kernel took 100 us instead of 30)
+    // would set the margin)
     const double pref = a.price[(size_t)b * n];
-    for (int j = tid; j < n; j += TIE_PASS_BS) {
-        const double pj = a.price[(size_t)b * n + j];
-        price[j] = pj; pf[j] = (float)(pj - pref);
-        pm = fmaxf(pm, fabsf((float)(pj - pref)));
+    // the cost scale of the solvers' tolerances (lap.hip, points form): the diagonal of the clouds' common box
+    float lo = INFINITY, hi = -INFINITY, pm = 0.f;
+    {
+        double pv[NJ];
+        float vx[NJ], vy[NJ], vz[NJ], wx[NJ], wy[NJ], wz[NJ];
+#pragma unroll
+        for (int k = 0; k < NJ; ++k) {
+            const int j = tid + k * TIE_PASS_BS, jj = j < n ? j : 0;
+            pv[k] = a.price[(size_t)b * n + jj];
+            vx[k] = T_[3 * jj]; vy[k] = T_[3 * jj + 1]; vz[k] = T_[3 * jj + 2];
+            wx[k] = S_[3 * jj]; wy[k] = S_[3 * jj + 1]; wz[k] = S_[3 * jj + 2];
+        }
+#pragma unroll
+        for (int k = 0; k < NJ; ++k) {
+            const int j = tid + k * TIE_PASS_BS;
+            if (j < n) {
+                price[j] = pv[k]; pf[j] = (float)(pv[k] - pref);
+                ptx[j] = vx[k]; pty[j] = vy[k]; ptz[j] = vz[k];
+                pm = fmaxf(pm, fabsf((float)(pv[k] - pref)));
+                lo = fminf(lo, fminf(fminf(fminf(vx[k], vy[k]), vz[k]), fminf(fminf(wx[k], wy[k]), wz[k])));
+                hi = fmaxf(hi, fmaxf(fmaxf(fmaxf(vx[k], vy[k]), vz[k]), fmaxf(fmaxf(wx[k], wy[k]), wz[k])));
+            }
+        }
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
         lo = fminf(lo, __shfl_xor(lo, o, 64)); hi = fmaxf(hi, __shfl_xor(hi, o, 64)); pm = fmaxf(pm, __shfl_xor(pm, o, 64));
     }
     if (lane == 0) { s_lo[wv] = lo; s_hi[wv] = hi; s_pm[wv] = pm; }
+    // this wave's rows, TIE_ROWS consecutive ones per step: block t of the wave starts at row (first + t * stride) * TIE_ROWS;
+    // lane k fetches row k of the wave's sequence (their loads are in flight across the barrier)
+    const int first = blockIdx.y * NW + wv, stride = gridDim.y * NW;
+    const int nblk_all = (n + TIE_ROWS - 1) / TIE_ROWS;
+    const int nblk = first < nblk_all ? (nblk_all - first + stride - 1) / stride : 0;
+    auto row_of = [&](int q) { return (first + (q / TIE_ROWS) * stride) * TIE_ROWS + q % TIE_ROWS; };      // q-th row of the wave
+    int q0 = 0;
+    int il = row_of(lane);
+    int ic = il < n ? il : n - 1;
+    float lx = S_[3 * ic], ly = S_[3 * ic + 1], lz = S_[3 * ic + 2];
+    int lc = a.col4row[(size_t)b * n + ic];
     __syncthreads();
-    for (int w = 0; w < TIE_PASS_BS / 64; ++w) { lo = fminf(lo, s_lo[w]); hi = fmaxf(hi, s_hi[w]); pm = fmaxf(pm, s_pm[w]); }
+    for (int w = 0; w < NW; ++w) { lo = fminf(lo, s_lo[w]); hi = fmaxf(hi, s_hi[w]); pm = fmaxf(pm, s_pm[w]); }
     double mx = 1.7320508 * (double)(hi - lo);
     if (!(mx > 0.0)) mx = 1.0;
     const double tol = mx * 1e-13;
@@ -76,24 +103,31 @@ __global__ __launch_bounds__(TIE_PASS_BS) void lap_tie_edges_kernel(TieArgs a) {
     // i.e. t >= 0 and the SQUARED distance <= t^2 (1 + 2^-20) -- the margin is eight times the worst rounding of the two rounded
     // potentials and of the subtraction (2^-24 each of |p_j|, |u_i| and the difference), the factor covers the root's and the
     // square's roundings (2^-23 in all): a superset of the tight pairs passes, the exact test decides.
-    const int rows_per = TIE_ROWS * (TIE_PASS_BS / 64) * gridDim.y;
-    for (int i0 = (blockIdx.y * (TIE_PASS_BS / 64) + wv) * TIE_ROWS; i0 < n; i0 += rows_per) {
-        float ax[TIE_ROWS], ay[TIE_ROWS], az[TIE_ROWS], curf[TIE_ROWS], marg[TIE_ROWS];      // curf: u_i + margin, rounded
+    for (int t = 0; t < nblk; ++t) {
+        if (TIE_ROWS * t - q0 >= 64) {                                  // the next 64 rows of the wave's sequence
+            q0 = TIE_ROWS * t;
+            il = row_of(q0 + lane); ic = il < n ? il : n - 1;
+            lx = S_[3 * ic]; ly = S_[3 * ic + 1]; lz = S_[3 * ic + 2];
+            lc = a.col4row[(size_t)b * n + ic];
+        }
+        const int i0 = (first + t * stride) * TIE_ROWS;
+        float ax[TIE_ROWS], ay[TIE_ROWS], az[TIE_ROWS], curf[TIE_ROWS];      // curf: u_i + margin, rounded, relative to pref
         double cur[TIE_ROWS];
         int c[TIE_ROWS];
 #pragma unroll
         for (int r = 0; r < TIE_ROWS; ++r) {
-            const int i = i0 + r < n ? i0 + r : n - 1;                  // (a wave's last rows may repeat row n - 1: masked below)
-            c[r] = a.col4row[(size_t)b * n + i];
+            const int k = TIE_ROWS * t - q0 + r;                        // (rows beyond n - 1 repeat row n - 1: masked below)
+            ax[r] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lx), k));
+            ay[r] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ly), k));
+            az[r] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lz), k));
+            c[r] = __builtin_amdgcn_readlane(lc, k);
             if (c[r] < 0 || c[r] >= n) {                                // not an assignment: nothing to say about it
                 if (lane == 0) atomicMax(&a.tie[b], 3);
                 c[r] = 0;
             }
-            ax[r] = S_[3 * i]; ay[r] = S_[3 * i + 1]; az[r] = S_[3 * i + 2];
             cur[r] = (double)sqrtf(reart_sqdist3(ax[r], ay[r], az[r], ptx[c[r]], pty[c[r]], ptz[c[r]])) + price[c[r]];
             curf[r] = (float)(cur[r] - pref);
-            marg[r] = 4.76837158203125e-7f * (2.f * pm + 2.f * (float)mx + fabsf(curf[r]));      // 2^-21 x ...
-            curf[r] += marg[r];                                         // u_i + margin (the margin also covers this rounding)
+            curf[r] += 4.76837158203125e-7f * (2.f * pm + 2.f * (float)mx + fabsf(curf[r]));      // + margin: 2^-21 x ... (covers this rounding too)
         }
         for (int j0 = 0; j0 < n; j0 += 64) {
             const int j = j0 + lane;
@@ -103,8 +137,8 @@ __global__ __launch_bounds__(TIE_PASS_BS) void lap_tie_edges_kernel(TieArgs a) {
             unsigned near = 0;
 #pragma unroll
             for (int r = 0; r < TIE_ROWS; ++r) {
-                const float t = curf[r] - pj;
-                near |= ((t >= 0.f && reart_sqdist3(ax[r], ay[r], az[r], tx, ty, tz) <= (t * t) * 1.00000095367431640625f) ? 1u : 0u) << r;
+                const float tt = curf[r] - pj;
+                near |= ((tt >= 0.f && reart_sqdist3(ax[r], ay[r], az[r], tx, ty, tz) <= (tt * tt) * 1.00000095367431640625f) ? 1u : 0u) << r;
             }
             if (!in) near = 0;
             if (__ballot(near != 0)) {
@@ -206,8 +240,8 @@ extern "C" int reart_lap_ties(const float *src, const float *tgt, int B, int n, 
     } else if (hipMemsetAsync(tie, 0, sizeof(int) * (size_t)B, (hipStream_t)stream) != hipSuccess ||
                hipMemsetAsync(n_edges, 0, sizeof(int) * (size_t)B, (hipStream_t)stream) != hipSuccess)
         return REART_ERR_LAUNCH;
-    int per = (2 * 256 + B - 1) / B;                                   // workgroups per problem: two per compute unit over the batch
-    const int per_max = (n + TIE_PASS_BS / 64 - 1) / (TIE_PASS_BS / 64);
+    int per = (256 + B - 1) / B;                                       // workgroups (16 waves) per problem: one per compute unit over the batch
+    const int per_max = ((n + TIE_ROWS - 1) / TIE_ROWS + TIE_PASS_BS / 64 - 1) / (TIE_PASS_BS / 64);
     per = per < 1 ? 1 : (per > per_max ? per_max : per);
     const size_t lds_pass = (size_t)n * (8 + 16);
     const size_t lds_cyc = (size_t)n * (4 * 4 + 1) + 4 * (size_t)TIE_LDS_EDGES + 16;

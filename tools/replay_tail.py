@@ -87,6 +87,8 @@ def main(path):
         print(f"  {name} ({len(m)}): sum of medians {m.sum():.2f} ms | mean {m.mean():.3f} | p50 {np.median(m):.3f} | max {m.max():.3f} | "
               f"search steps of the slowest problem, mean {steps[sl].max(1).mean():.0f} | cost checksum {cost[sl].sum():.9f}")
     print("  per solve (median ms):", " ".join(f"{v:.2f}" for v in med))
+    if os.environ.get("RAW_OUT"):           # the statistics words and times per solve, for tools/replay_kernels.py
+        np.savez(os.environ["RAW_OUT"] + "." + os.path.basename(path), raws=raws, med=med, reps=REPS)
     if os.environ.get("TIMES_OUT"):
         np.save(os.environ["TIMES_OUT"] + "." + os.path.basename(path) + ".npy", med)
     if os.environ.get("BUCKET_STATS"):
