@@ -430,7 +430,10 @@ def run_secondary(args, dev, barrier):
             # the default line stays within the 5 KB the driver records: a secondary leg carries numbers; the labels of its
             # metric / kernel / units are in the full line of `python bench.py --config <name>` and in DESIGN.md section 6
             if isinstance(sec[name].get("roofline"), dict):
-                sec[name]["roofline"] = {k: v for k, v in sec[name]["roofline"].items() if k not in ("kernel", "unit", "traffic")}
+                drop = ("kernel", "unit", "traffic", "steps_slowest_problem", "search_steps_slowest_problem", "steps_mean_problem",
+                        "sequential_steps_slowest_problem", "search_steps_mean_problem", "row_reduction_steps_mean_problem",
+                        "backward_rounds_mean_problem")                    # (the step counts behind frac: in the full line of --config <name>)
+                sec[name]["roofline"] = {k: v for k, v in sec[name]["roofline"].items() if k not in drop}
             for key in ("cpu_baseline", "cpu_baseline_torch"):
                 if isinstance(sec[name].get(key), dict):
                     sec[name][key] = {k: v for k, v in sec[name][key].items() if k not in ("sample", "unit", "kind")}
@@ -443,6 +446,10 @@ def run_secondary(args, dev, barrier):
                                         "lap_fallbacks", "deterministic", "ties", "other_mode"),
                      "kinematic": ("lap_fallbacks",)}.get(name, ())
             sec[name].update({k: full["config"][k] for k in extra if k in full["config"]})
+            if isinstance(sec[name].get("other_mode"), dict):            # the other mode of the projection: rate and percentiles only
+                sec[name]["other_mode"] = {k: sec[name]["other_mode"][k] for k in ("deterministic", "value", "solve_ms_p50", "solve_ms_p95")}
+            if isinstance(sec[name].get("ties"), dict):
+                sec[name]["ties"] = [sec[name]["ties"]["flagged"], sec[name]["ties"]["changed"]]      # [problems flagged, problems changed]
         except Exception as exc:                                  # a secondary figure never costs the headline line
             sec[name] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
         torch.cuda.synchronize()
@@ -1125,12 +1132,10 @@ def main():
                     "kernel": "knn_group_kernel (Chamfer K=1 both directions + flow K=3, one launch)" if use_flow else "knn_group_kernel (Chamfer K=1, both directions)",
                     "kernel_ms": round(k_ms, 5), "launches_measured": prof["launches"],
                     "slow_box": bool(use_flow and T == 20 and N == 4096 and args.steps >= 300 and k_ms > 1.25 * 0.0329),
-                    "workgroup_busy_ms": round(1e3 * prof["workgroup_seconds"] / prof["launches"], 4),
                     "executed_pairs_per_launch": round(executed, 1),
                     "algorithmic_pairs_per_launch": nn_pairs, "algorithmic_speedup": round(nn_pairs / executed, 3),
-                    "algorithmic_tflops": round(nn_flops / t_nn / 1e12, 2), "algorithmic_frac": round(nn_flops / t_nn / 1e12 / FP32_PEAK_TFLOPS, 4),
-                    "hbm_gbs": round(nn_bytes / t_nn / 1e9, 3), "hbm_frac": round(nn_bytes / t_nn / 1e9 / HBM_PEAK_GBS, 6),
-                    "algorithmic_bytes": nn_bytes}
+                    "algorithmic_frac": round(nn_flops / t_nn / 1e12 / FP32_PEAK_TFLOPS, 4),
+                    "hbm_gbs": round(nn_bytes / t_nn / 1e9, 3), "algorithmic_bytes": nn_bytes}
             if use_flow and P_BENCH == 20:
                 try:       # the five-launch chain with free arithmetic, measured now (an aid: never costs the line)
                     fl_us, fl_small = step_chain_floor(dev, N, B)
@@ -1185,9 +1190,9 @@ def main():
                     t_ = time.perf_counter()
                     O_.linear_sum_assignment(c1)
                     cpu_lap = 1e3 * (time.perf_counter() - t_)
+                    # (kind: port -- the oracle's structure extraction once; scipy on 1 of the T-1 matrices)
                     cpu_tail = {"structure_ms": round(cpu_struct, 1), "assignment_ms_per_matrix": round(cpu_lap, 1),
-                                "matrices": int(eng.pc_list.shape[0]), "kind": "port",
-                                "sample": "oracle structure once; scipy on 1 of T-1 matrices"}
+                                "matrices": int(eng.pc_list.shape[0])}
                 end_of_run = {"structure_ms": round(ms_struct, 3), "energy_ms": round(ms_energy, 3), "cpu_baseline": cpu_tail,
                               "parts": int(trans_s.shape[1]), "total_err": round(en["total_err"], 6),
                               "ass_err": round(en["ass_err"], 6), "screw_err": round(en["screw_err"], 6),

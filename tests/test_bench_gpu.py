@@ -29,7 +29,7 @@ def test_headline_line_contract(dev):
     assert c["frames"] == 20 and c["points"] == 4096 and c["flow"] is True and c["eager_steps"] == 0 and c["graph_replays"] >= 1
     r = d["roofline"]
     assert r["bound"] == "valu" and 0 < r["frac"] < 1 and r["kernel_ms"] < d["ms_per_step"]
-    assert r["algorithmic_frac"] > r["frac"] and r["hbm_frac"] < 0.2 and r["executed_pairs_per_launch"] < r["algorithmic_pairs_per_launch"]
+    assert r["algorithmic_frac"] > r["frac"] and r["hbm_gbs"] < 0.2 * 8000 and r["executed_pairs_per_launch"] < r["algorithmic_pairs_per_launch"]
     assert r["traffic"] is None or isinstance(r["traffic"], (int, float))        # a number of bytes (or null), as the contract says
     # the launch chain with its arithmetic removed, measured in the run: below the step, the small kernels' share below the whole
     assert 0 < r["step_floor_small_kernels_us"] < r["step_floor_us"] < 1e3 * d["ms_per_step"] and 0 < r["step_floor_frac"] < 1
@@ -69,6 +69,14 @@ def test_default_line_fits_the_drivers_record(dev):
     assert 0 < sec["nao_recipe"]["roofline"]["frac_search_only"] <= sec["nao_recipe"]["roofline"]["frac"] < 1
     assert sec["nao_recipe"]["snapshots"] == 150 and sec["nao_projection"]["snapshots"] == 151
     assert len(sec["nao_projection"]["iterations_per_s_by_window"]) == 3
+    # BASELINE configs[4] on its own data (VERDICT r05 missing #2): CPU baseline, latency fraction, and both modes of the loop
+    pr = sec["nao_projection"]
+    assert pr["cpu_baseline"]["value"] > 0 and pr["cpu_baseline"]["cores"] >= 1
+    assert 0 < pr["roofline"]["frac_search_only"] <= pr["roofline"]["frac"] < 1
+    assert pr["deterministic"] is True and pr["other_mode"]["deterministic"] is False and pr["other_mode"]["value"] > 0
+    assert len(pr["ties"]) == 2 and pr["ties"][0] >= pr["ties"][1] >= 0
+    assert sec["nao"]["cpu_baseline_torch"]["value"] > 0
+    assert d["ranks"][0]["it_per_s"] > 1000 and d["ranks"][0]["elapsed_s"] > 0
 
 
 def test_nao_config_line(dev):
