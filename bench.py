@@ -78,6 +78,13 @@ def _pcts(ms):
             "solve_ms_max": round(float(a.max()), 4)}
 
 
+def _ties_of(lap_state):
+    """[problems flagged by reart_lap_ties, problems whose assignment the canonical choice changed] of a loop, or None when the
+    loop ran without the tie check (--no-deterministic)."""
+    tb = (lap_state or {}).get("tie_breaker")
+    return None if tb is None else [int(tb.flagged), int(tb.changed)]
+
+
 def step_chain_floor(dev, N, B, P=20, H=128):
     """The headline iteration's launch chain with its arithmetic removed (reart_relax_step_floor): five dependent launches with
     the grids, block sizes and LDS footprints of the step's kernels at this configuration (rocprofv3 kernel trace) and the
@@ -394,7 +401,7 @@ def bench_kinematic(args, dev, rank, world, distributed, barrier):
                    "parts": int(trans_s.shape[1]), "assign_gap": args.assign_gap, "downsample": args.downsample,
                    "lap_solves_in_timed_region": loop.lap_solves - solves0 - 0, "lap_fallbacks": int(getattr(loop, "lap_fallbacks", -1)),
                    "parallelism": f"instances x{world}",
-                   "loop": type(loop).__name__},
+                   "loop": type(loop).__name__, "deterministic": bool(_ties_of(loop.lap_state) is not None), "ties": _ties_of(loop.lap_state)},
         "roofline": roof, "cpu_baseline": cpu,
         "final_losses": {k: float(v.detach()) for k, v in losses.items()},
     }
@@ -441,10 +448,10 @@ def run_secondary(args, dev, barrier):
                     sec[name].pop(key, None)
             extra = {"nao": ("matches_per_pair", "pairs_with_ground_truth_references", "correspondence_stage_s", "loop_s", "whole_run_s"),
                      "nao_recipe": ("correspondence_stage_s", "chamfer_phase_s", "assignment_phase_s", "loop_s", "whole_run_s",
-                                    "assign_refreshes", "ms_per_refresh", "ms_per_solve", "first_solve_ms", "lap_fallbacks", "snapshots"),
+                                    "assign_refreshes", "ms_per_refresh", "ms_per_solve", "first_solve_ms", "lap_fallbacks", "snapshots", "ties"),
                      "nao_projection": ("n_iter", "of", "snapshots", "iterations_per_s_by_window", "wall_s", "projected_whole_run_s",
                                         "lap_fallbacks", "deterministic", "ties", "other_mode"),
-                     "kinematic": ("lap_fallbacks",)}.get(name, ())
+                     "kinematic": ("lap_fallbacks", "ties")}.get(name, ())
             sec[name].update({k: full["config"][k] for k in extra if k in full["config"]})
             if isinstance(sec[name].get("other_mode"), dict):            # the other mode of the projection: rate and percentiles only
                 sec[name]["other_mode"] = {k: sec[name]["other_mode"][k] for k in ("deterministic", "value", "solve_ms_p50", "solve_ms_p95")}
@@ -591,7 +598,8 @@ def bench_nao_recipe(args, dev, keep=None):
                    "loop_s": round(t_cd + t_as, 4), "whole_run_s": round(whole, 4), "assign_refreshes": rep["assign_refreshes"],
                    "ms_per_refresh": round(1e3 * t_as / max(rep["assign_refreshes"], 1), 4),
                    "ms_per_solve": round(solve_ms, 4), "first_solve_ms": round(rep.get("first_solve_ms", 0.0), 3),
-                   "lap_fallbacks": rep["lap_fallbacks"], "snapshots": snap.count, "snapshot_gap": snap_gap},
+                   "lap_fallbacks": rep["lap_fallbacks"], "snapshots": snap.count, "snapshot_gap": snap_gap,
+                   "deterministic": bool(_ties_of(phase.lap_state) is not None), "ties": _ties_of(phase.lap_state)},
         "roofline": {"bound": "latency", "achieved": round(bound_ms, 4), "peak": round(solve_ms, 4),
                      "unit": "ms per re-solve (floor / measured)", "frac": round(bound_ms / solve_ms, 4) if solve_ms > 0 else None,
                      "frac_search_only": round(float(st[:, 3].mean()) * floor_us.value * 1e-3 / solve_ms, 4) if st.size and solve_ms > 0 else None,

@@ -568,16 +568,24 @@ int reart_lap_resolve_points_mc(const float *src, const float *tgt, int B, int n
  * linear_sum_assignment, a pure function of the cost matrix, run_robot.py:172-176, so a run repeats under --manual_seed,
  * run_robot.py:37-49; the raced solvers above return SOME optimum.)  Inputs: the points of reart_lap_resolve_points, the
  * optimum col4row [B,n] and its column potentials price [B,n] as those calls leave them; n <= 4096.  Outputs (caller-owned):
- *   edges [B,cap,2]  (row, column) of every pair off the assignment that is tight under the potentials,
- *                    c_ij + p_j - (c_i,s(i) + p_s(i)) <= 1e-13 x cost scale (the certificate's tolerance), costs by
- *                    reart_cdist's expression; n_edges [B] their number (pairs beyond cap are counted, not stored);
- *   tie [B]          0: no alternating cycle among the tight pairs -- the optimum is unique; 1: rows on or between cycles
- *                    exist -- other optima of the same cost may (the host decides: reart_amd/utils/lap.py
- *                    canonical_among_ties); 2: more tight pairs than the kernel holds (n_edges > cap or > 12 288);
- *                    3: col4row is not an assignment.
+ *   cols [B,n,K]   per row the columns j != s(i) whose pair is tight under the potentials,
+ *                  c_ij + p_j - (c_i,s(i) + p_s(i)) <= 1e-13 x cost scale (the certificate's tolerance), costs by reart_cdist's
+ *                  expression -- the first K of them (1 <= K <= 32); cnt [B,n] how many the row has (may exceed K);
+ *   tie [B]        0: no alternating cycle among the tight pairs -- the optimum is unique; 1: there is one -- other optima of
+ *                  the same cost exist (the host chooses: reart_amd/utils/lap.py canonical_among_ties); 2: a row has more
+ *                  than K tight pairs (the host lists them itself); 3: col4row is not an assignment.
  * Two launches on `stream`, no workspace, no host synchronisation. */
 int reart_lap_ties(const float *src, const float *tgt, int B, int n, const int32_t *col4row, const double *price,
-                   int32_t *tie, int32_t *edges, int32_t *n_edges, int cap, void *stream);
+                   int32_t *tie, int32_t *cols, int32_t *cnt, int K, void *stream);
+
+/* reart_lap_resolve_points_mc followed by the tie check of reart_lap_ties, with the tight pairs listed by the solve's own
+ * certificate pass (its scan meets exactly the pairs within the tolerance of the row's minimum: no second pass over the costs).
+ * Same inputs / outputs as the two calls; n >= 512.  A problem whose certificate needed more rounds than the pass (its
+ * potentials moved afterwards) comes back with tie = 2: the host lists its pairs itself.  Reference: run_robot.py:172-176 (the
+ * refresh as a function of the cost matrix), run_robot.py:37-49 (runs repeat under --manual_seed). */
+int reart_lap_resolve_points_mc_ties(const float *src, const float *tgt, int B, int n, int racers, int arr_wgs, int32_t *col4row,
+                                     int32_t *certified, const double *price_in, double *price_out, int32_t *tie, int32_t *cols,
+                                     int32_t *cnt, int K, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Device-side glue of an assignment refresh (run_robot.py:165-178), so that a loop which re-solves on the GPU touches the host
  * only for the B certificate flags (csrc/assign.hip):

@@ -75,6 +75,7 @@ PROTOTYPES = {
     "reart_gather_points": (c_int, [P, P, c_int, c_int, c_int, P, P]),
     "reart_assign_pairs": (c_int, [P, P, P, c_int, c_int, c_int, P, P]),
     "reart_lap_ties": (c_int, [P, P, c_int, c_int, P, P, P, P, P, c_int, P]),
+    "reart_lap_resolve_points_mc_ties": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, c_int, P, c_size_t, P]),
     "reart_lap_step_floor": (c_int, [c_int, c_int, c_int, P, c_size_t, ctypes.POINTER(ctypes.c_double), P]),
     "reart_relax_step_floor": (c_int, [ctypes.POINTER(c_int), c_int, c_int, P, c_size_t, P]),
     "reart_cdist": (c_int, [P, P, c_int, c_int, c_int, P, P]),

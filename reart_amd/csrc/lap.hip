@@ -877,23 +877,45 @@ __device__ __forceinline__ void lap_row_top2_pts(float ax, float ay, float az, c
 // The test errs on the side of passing (slack for the rounding of the difference, 1 + 2^-20 for the root's and the square's),
 // and what passes goes through the same expression and the same tie rule (the lowest column) as lap_row_top2_pts:
 // the same (v1, j1), bit for bit.
+// EMIT (the certificate pass of a --deterministic solve, ties.hip): the columns that pass the test against cur + tol are exactly
+// the candidates for TIGHT pairs of the row -- c_ij + p_j - cur <= tol, the cycle check's edges -- so the pass lists them on
+// the way: their columns into the row's slots edges[0 .. cap), their number into *n_edges; the row's own column left out.
+template <bool EMIT = false>
 __device__ __forceinline__ void lap_row_min_pts_seeded(float ax, float ay, float az, const float *__restrict__ tx,
                                                        const float *__restrict__ ty, const float *__restrict__ tz,
-                                                       const double *__restrict__ p, int n, int lane, double &v1, int &j1) {
+                                                       const double *__restrict__ p, int n, int lane, double &v1, int &j1,
+                                                       int row = 0, int own = -1, double cur = 0.0, double tol = 0.0, int *edges = nullptr,
+                                                       int *n_edges = nullptr, int cap = 0) {
+    unsigned long long hits = 0ull;                       // EMIT: bit q = this lane's q-th column (64 q + lane) is a tight pair of the row
+    int q = 0;
     for (int j0 = lane; j0 < n; j0 += 64 * 4) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 4; ++u, ++q) {
             const int j = j0 + 64 * u;
             if (j < n) {
                 const double pj = p[j];
                 const float sq = reart_sqdist3(ax, ay, az, tx[j], ty[j], tz[j]);
-                const double T = (v1 - pj) + (fabs(v1) + fabs(pj)) * 8.9e-16;
+                const double T = ((EMIT ? cur + tol : v1) - pj) + (fabs(v1) + fabs(pj)) * 8.9e-16;      // (EMIT: v1 <= cur, the seed)
                 if (T >= 0.0 && (double)sq <= (T * T) * 1.00000095367431640625) {
                     const double v = (double)sqrtf(sq) + pj;
+                    if (EMIT && j != own && v - cur <= tol) hits |= 1ull << q;
                     if (v < v1 || (v == v1 && j < j1)) { v1 = v; j1 = j; }
                 }
             }
         }
+    }
+    if (EMIT) {       // the row's pairs, lowest lane first, into the row's OWN slots (a list shared by all rows behind one atomic
+                      // counter serialised a thousand reservations per problem on one address: +35 us per pass at 9 x 1024^2)
+        int cnt = 0;
+        for (unsigned long long m = __ballot(hits != 0ull); m; m = __ballot(hits != 0ull)) {
+            const int l = __ffsll((long long)m) - 1;
+            int col = 0;
+            if (lane == l) { const int s_ = __ffsll((long long)hits) - 1; hits &= hits - 1ull; col = 64 * s_ + lane; }
+            col = __builtin_amdgcn_readlane(col, l);
+            if (lane == 0 && cnt < cap) edges[cnt] = col;
+            ++cnt;
+        }
+        if (lane == 0) *n_edges = cnt;
     }
     lap_wave_argmin_fast(v1, j1);
 }
@@ -1402,7 +1424,13 @@ __global__ __launch_bounds__(JV_PASSP_BS) void lap_jv_pass_pts_kernel(JvArgs a) 
             if (has) cur = (double)sqrtf(reart_sqdist3(ax, ay, az, ptx[c], pty[c], ptz[c])) + price[c];
             double v1 = has ? cur : INFINITY;
             int j1 = has ? c : 0x7fffffff;
-            lap_row_min_pts_seeded(ax, ay, az, ptx, pty, ptz, price, n, lane, v1, j1);
+            if (a.pass_mode == 1 && a.tie_edges && has)
+                lap_row_min_pts_seeded<true>(ax, ay, az, ptx, pty, ptz, price, n, lane, v1, j1, i, c, cur, tol,
+                                             a.tie_edges + ((size_t)b * n + i) * a.tie_cap, a.tie_n + (size_t)b * n + i, a.tie_cap);
+            else {
+                lap_row_min_pts_seeded(ax, ay, az, ptx, pty, ptz, price, n, lane, v1, j1);
+                if (a.pass_mode == 1 && a.tie_edges && lane == 0) a.tie_n[(size_t)b * n + i] = 0;
+            }
             if (lane == 0) {
                 if (a.pass_mode == 0) {
                     a.pre_v1[(size_t)b * n + i] = v1; a.pre_j1[(size_t)b * n + i] = j1; a.pre_cur[(size_t)b * n + i] = cur;
@@ -1428,7 +1456,8 @@ extern "C" size_t reart_lap_mc_workspace_bytes(int B, int n, int racers) {
 // per_wave: 0 = one row at a time (lap_jv_kernel), 1 = row reduction one chain per wave (lap_mw.hip), 2 = row reduction on
 // arr_wgs workgroups per problem (lap_mw.hip, three launches)
 template <bool PTS>
-static int jv_launch(JvArgs a, void *workspace, size_t workspace_bytes, void *stream, int racers = 1, int per_wave = 0, int arr_wgs = 0) {
+static int jv_launch(JvArgs a, void *workspace, size_t workspace_bytes, void *stream, int racers = 1, int per_wave = 0, int arr_wgs = 0,
+                     int *tie_out = nullptr) {
     if (a.B < 0 || a.n < 1 || a.n > (PTS ? JV_PTS_NMAX : LAP_NMAX)) return REART_ERR_INVALID_ARG;
     if (racers < 1 || racers > JV_RACE_MAX) return REART_ERR_INVALID_ARG;
     if (a.B == 0) return REART_OK;
@@ -1515,6 +1544,8 @@ static int jv_launch(JvArgs a, void *workspace, size_t workspace_bytes, void *st
     a.price_in = a.price_out;                                  // the certificate continues from the solve's potentials
     hipLaunchKernelGGL((lap_jv_kernel<JVBS, PTS, 2>), dim3(a.B), dim3(JVBS), lds, (hipStream_t)stream, a);
     REART_CHECK_LAUNCH();
+    if (PTS && a.tie_edges && tie_out)                         // the cycle check over the pairs the pass listed (cert_bad: the rounds above moved the potentials)
+        return reart_internal_tie_cycles(a.B, a.n, a.col4row, tie_out, a.tie_edges, a.tie_n, a.tie_cap, a.cert_bad, (hipStream_t)stream);
     return REART_OK;
 }
 
@@ -1589,6 +1620,20 @@ extern "C" int reart_lap_resolve_points_mc(const float *src, const float *tgt, i
     a.src = src; a.tgt = tgt; a.B = B; a.n = n; a.col4row = col4row; a.certified = certified; a.price_in = price_in;
     a.price_out = price_out;
     return jv_launch<true>(a, workspace, workspace_bytes, stream, racers, 2, arr_wgs);
+}
+
+extern "C" int reart_lap_resolve_points_mc_ties(const float *src, const float *tgt, int B, int n, int racers, int arr_wgs, int32_t *col4row,
+                                                int32_t *certified, const double *price_in, double *price_out, int32_t *tie, int32_t *edges,
+                                                int32_t *n_edges, int cap, void *workspace, size_t workspace_bytes, void *stream) {
+    if ((!src || !tgt) && B > 0) return REART_ERR_INVALID_ARG;
+    if (racers < 1 || arr_wgs < 1 || arr_wgs > 256 || cap < 1 || cap > 32 || ((!tie || !edges || !n_edges) && B > 0)) return REART_ERR_INVALID_ARG;
+    if (workspace_bytes < reart_lap_mc_workspace_bytes(B, n, racers)) return REART_ERR_INVALID_ARG;
+    if (n < JV_SPLIT_NMIN) return REART_ERR_UNSUPPORTED;       // (below the three-launch form there is no separate certificate pass)
+    JvArgs a = {};
+    a.src = src; a.tgt = tgt; a.B = B; a.n = n; a.col4row = col4row; a.certified = certified; a.price_in = price_in;
+    a.price_out = price_out;
+    a.tie_edges = edges; a.tie_n = n_edges; a.tie_cap = cap;
+    return jv_launch<true>(a, workspace, workspace_bytes, stream, racers, 2, arr_wgs, tie);
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -158,7 +158,16 @@ struct JvArgs {
     int mc_chain;              // steps after which a chain leaves its row to the path searches
     const int *col_start;
     const double *price_start;
+    // --deterministic (ties.hip): the certificate pass also lists the pairs off the assignment that are tight under the final
+    // potentials -- its scan meets exactly those -- for the cycle check that follows the solve; null: not asked for
+    int *tie_edges, *tie_n;    // [B][n][tie_cap] every row's tight columns (its first tie_cap) | [B][n] how many it has
+    int tie_cap;
 };
+
+// ties.hip: the cycle check over pair lists a solve's certificate pass wrote (reart_lap_resolve_points_mc_ties); `stale` [B]
+// nullable: problems whose potentials moved after the pass (certificate rounds) get tie = 2
+int reart_internal_tie_cycles(int B, int n, const int *col4row, int *tie, const int *cols, const int *cnt, int K, const int *stale,
+                              hipStream_t stream);
 
 // lap_mw.hip: the sequential part of a points-form re-solve with one search per WAVE (see there); same inputs and
 // outputs as lap_jv_kernel<., true, 1>.  Returns REART_ERR_UNSUPPORTED when n exceeds what its waves hold in registers.

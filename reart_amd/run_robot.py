@@ -162,9 +162,13 @@ class AssignmentPhase:
         off = ((8 * B * n + 255) // 256) * 256                            # the solver's statistics: [B][4] ints behind the potentials
         if self.collect_stats:
             ws[off:off + 16 * B].zero_()
-        _lib.check(L.reart_lap_resolve_points_mc(_lib.ptr(self._src_pts), _lib.ptr(self.tgt_pts), B, n, racers, arr, _lib.ptr(cols),
-                                                 _lib.ptr(self._cert), _lib.ptr(prices), _lib.ptr(prices), _lib.ptr(ws), ws.numel(), stream),
-                   "reart_lap_resolve_points_mc")
+        tb = lap._tie_breaker(st, B, n, eng.device) if lap.CANONICAL_TIES else None      # --deterministic: tied optima take the canonical one
+        if tb is not None:
+            tb.resolve_mc(self._src_pts, self.tgt_pts, racers, arr, cols, self._cert, prices, ws)
+        else:
+            _lib.check(L.reart_lap_resolve_points_mc(_lib.ptr(self._src_pts), _lib.ptr(self.tgt_pts), B, n, racers, arr, _lib.ptr(cols),
+                                                     _lib.ptr(self._cert), _lib.ptr(prices), _lib.ptr(prices), _lib.ptr(ws), ws.numel(), stream),
+                       "reart_lap_resolve_points_mc")
         st["resolve_form"] = "mc"
         pairs = lambda: _lib.check(L.reart_assign_pairs(_lib.ptr(cols), _lib.ptr(self._slot), _lib.ptr(self._tgt_stored), B, N, n,
                                                         _lib.ptr(eng._assign_map), stream), "reart_assign_pairs")
@@ -172,12 +176,8 @@ class AssignmentPhase:
         self._cert_host.copy_(self._cert, non_blocking=True)
         if self.collect_stats:
             self._stats_host.copy_(ws[off:off + 16 * B].view(torch.int32), non_blocking=True)
-        tb = None
-        if lap.CANONICAL_TIES:                                            # --deterministic: tied optima take the canonical one
-            tb = lap._tie_breaker(st, B, n, eng.device)
-            tb.launch(self._src_pts, self.tgt_pts, cols, prices)
         torch.cuda.current_stream().synchronize()
-        if tb is not None and tb.settle(self._src_pts, self.tgt_pts, st, skip=set((self._cert_host == 0).nonzero().flatten().tolist())):
+        if tb is not None and tb.settle(self._src_pts, self.tgt_pts, st, skip=lambda: set((self._cert_host == 0).nonzero().flatten().tolist())):
             pairs()
         if self.collect_stats:
             sth = self._stats_host.numpy().reshape(B, 4)
@@ -358,9 +358,13 @@ class AssignmentPhaseBatch:
         self._cert.zero_()
         ws = _lib.workspace(L.reart_lap_mc_workspace_bytes(K * B, n, racers), dev)
         cols, prices = st["cols"], st["prices"]
-        _lib.check(L.reart_lap_resolve_points_mc(_lib.ptr(self._src_all), _lib.ptr(self.tgt_all), K * B, n, racers, arr, _lib.ptr(cols),
-                                                 _lib.ptr(self._cert), _lib.ptr(prices), _lib.ptr(prices), _lib.ptr(ws), ws.numel(), stream),
-                   "reart_lap_resolve_points_mc")
+        tb = lap._tie_breaker(st, K * B, n, dev) if lap.CANONICAL_TIES else None
+        if tb is not None:
+            tb.resolve_mc(self._src_all, self.tgt_all, racers, arr, cols, self._cert, prices, ws)
+        else:
+            _lib.check(L.reart_lap_resolve_points_mc(_lib.ptr(self._src_all), _lib.ptr(self.tgt_all), K * B, n, racers, arr, _lib.ptr(cols),
+                                                     _lib.ptr(self._cert), _lib.ptr(prices), _lib.ptr(prices), _lib.ptr(ws), ws.numel(), stream),
+                       "reart_lap_resolve_points_mc")
         st["resolve_form"] = "mc"
 
         def pairs():
@@ -370,12 +374,8 @@ class AssignmentPhaseBatch:
                                                 _lib.ptr(ph.eng._assign_map), stream), "reart_assign_pairs")
         pairs()
         self._cert_host.copy_(self._cert, non_blocking=True)
-        tb = None
-        if lap.CANONICAL_TIES:
-            tb = lap._tie_breaker(st, K * B, n, dev)
-            tb.launch(self._src_all, self.tgt_all, cols, prices)
         torch.cuda.current_stream().synchronize()
-        if tb is not None and tb.settle(self._src_all, self.tgt_all, st, skip=set((self._cert_host == 0).nonzero().flatten().tolist())):
+        if tb is not None and tb.settle(self._src_all, self.tgt_all, st, skip=lambda: set((self._cert_host == 0).nonzero().flatten().tolist())):
             pairs()
         fb = 0
         for b in (self._cert_host == 0).nonzero().flatten().tolist():

@@ -284,36 +284,65 @@ class TieBreaker:
     """reart_lap_ties behind a solve of B problems of n columns, and the host's canonical choice for the problems it flags.
     ``launch`` queues the two kernels and the copy of the B flags behind the solve (no synchronisation); after the caller's
     own synchronisation ``settle`` rewrites ``state["cols"]`` of every flagged problem IN PLACE and returns how many
-    problems changed."""
+    problems changed.  Buffers (caller-owned, as the C ABI wants them): per row ``K`` slots for the columns of its tight pairs
+    and a count."""
 
     def __init__(self, B, n, device):
-        self.B, self.n, self.device, self.cap = B, n, device, 8 * n
-        both = torch.zeros((2 * B,), dtype=torch.int32, device=device)    # flags and counts side by side: one fill per call
-        self.tie, self.n_edges = both[:B], both[B:]
-        self.edges = torch.empty((B, self.cap, 2), dtype=torch.int32, device=device)
+        self.B, self.n, self.device = B, n, device
+        # slots per row.  Measured over the recipe's refreshes on nao (tools/exp_tie_counts.py): 46 % of the rows have no tight
+        # pair off the assignment, 40 % one, 0.03 % more than eight -- but 27 % of the PROBLEMS hold such a row (the rows of a
+        # region the searches flooded), 1 % one above 16, the largest 22.  A row beyond its slots sends its problem to the host
+        # (flag 2), so the slots cover what occurs: 24 (the cycle check keeps n x K x 2 bytes in LDS: 8 above 2048 columns)
+        self.K = 24 if n <= 2048 else 8
+        self.tie = torch.zeros((B,), dtype=torch.int32, device=device)
+        self.n_edges = torch.zeros((B, n), dtype=torch.int32, device=device)            # tight pairs per row
+        self.edges = torch.zeros((B, n, self.K), dtype=torch.int32, device=device)      # their columns (the first K)
         self.tie_host = torch.zeros((B,), dtype=torch.int32).pin_memory()
+        self._tie_np = self.tie_host.numpy()              # (the same memory: the per-solve question "any flag?" without a tensor op)
         self.flagged = self.changed = self.overflows = 0
         self.log = None                                   # set to [] to keep (problem, old cols, new cols, pairs) of every change
 
     def launch(self, src, tgt, cols, prices):
         _lib.check(_lib.lib().reart_lap_ties(_lib.ptr(src), _lib.ptr(tgt), self.B, self.n, _lib.ptr(cols), _lib.ptr(prices),
-                                             _lib.ptr(self.tie), _lib.ptr(self.edges), _lib.ptr(self.n_edges), self.cap, _lib.stream()),
+                                             _lib.ptr(self.tie), _lib.ptr(self.edges), _lib.ptr(self.n_edges), self.K, _lib.stream()),
                    "reart_lap_ties")
         self.tie_host.copy_(self.tie, non_blocking=True)
 
+    def resolve_mc(self, src, tgt, racers, arr, cols, cert, prices, ws):
+        """reart_lap_resolve_points_mc_ties: the in-place re-solve with the tie check behind it -- the tight pairs come out of
+        the solve's own certificate pass (no second scan of the costs); queues the copy of the flags like ``launch``."""
+        _lib.check(_lib.lib().reart_lap_resolve_points_mc_ties(_lib.ptr(src), _lib.ptr(tgt), self.B, self.n, racers, arr, _lib.ptr(cols),
+                                                               _lib.ptr(cert), _lib.ptr(prices), _lib.ptr(prices), _lib.ptr(self.tie),
+                                                               _lib.ptr(self.edges), _lib.ptr(self.n_edges), self.K, _lib.ptr(ws),
+                                                               ws.numel(), _lib.stream()), "reart_lap_resolve_points_mc_ties")
+        self.tie_host.copy_(self.tie, non_blocking=True)
+
+    def pairs_of(self, b):
+        """[E,2] int64 (row, column) of problem b's tight pairs as the kernels listed them (rows with more than K: the first K)."""
+        cnt = self.n_edges[b].cpu().numpy().clip(0, self.K)
+        cols = self.edges[b].cpu().numpy()
+        keep = np.arange(self.K)[None, :] < cnt[:, None]
+        rows = np.broadcast_to(np.arange(self.n)[:, None], keep.shape)
+        return np.stack((rows[keep], cols[keep]), axis=1).astype(np.int64)
+
     def settle(self, src, tgt, state, skip=()):
-        """``skip``: problems whose solve did not certify (they went to the host solver)."""
+        """``skip``: problems whose solve did not certify (they went to the host solver) -- a collection, or a callable that
+        returns one (only asked when some problem is flagged: the normal solve has none)."""
+        if not self._tie_np.any():
+            return 0
+        if callable(skip):
+            skip = skip()
         changed = 0
         cols, prices = state["cols"], state["prices"]
-        for b in self.tie_host.nonzero().flatten().tolist():
-            if b in skip or int(self.tie_host[b]) == 3:
+        for b in np.nonzero(self._tie_np)[0].tolist():
+            if b in skip or int(self._tie_np[b]) == 3:
                 continue
             self.flagged += 1
-            if int(self.tie_host[b]) == 2:
+            if int(self._tie_np[b]) == 2:
                 self.overflows += 1
                 pairs = tight_pairs_host(src[b], tgt[b], cols[b], prices[b])
             else:
-                pairs = self.edges[b, :int(self.n_edges[b].item())].cpu().numpy()
+                pairs = self.pairs_of(b)
             old = cols[b].cpu().numpy()
             new, moved = canonical_among_ties(old, pairs)
             if moved:
@@ -524,22 +553,22 @@ class InPlaceResolve:
         off = ((8 * B * n + 255) // 256) * 256                            # the solver's statistics: [B][4] ints behind the potentials
         if stats:
             ws[off:off + 16 * B].zero_()
-        _lib.check(L.reart_lap_resolve_points_mc(_lib.ptr(src), _lib.ptr(tgt), B, n, racers, arr, _lib.ptr(cols), _lib.ptr(self.cert),
-                                                 _lib.ptr(prices), _lib.ptr(prices), _lib.ptr(ws), ws.numel(), stream),
-                   "reart_lap_resolve_points_mc")
+        tb = _tie_breaker(state, B, n, self.device) if CANONICAL_TIES else None      # --deterministic: the tied problems, with the solve
+        if tb is not None:
+            tb.resolve_mc(src, tgt, racers, arr, cols, self.cert, prices, ws)
+        else:
+            _lib.check(L.reart_lap_resolve_points_mc(_lib.ptr(src), _lib.ptr(tgt), B, n, racers, arr, _lib.ptr(cols), _lib.ptr(self.cert),
+                                                     _lib.ptr(prices), _lib.ptr(prices), _lib.ptr(ws), ws.numel(), stream),
+                       "reart_lap_resolve_points_mc")
         state["resolve_form"] = "mc"
         self.cert_host.copy_(self.cert, non_blocking=True)
         if stats:
             self.stats_host.copy_(ws[off:off + 16 * B].view(torch.int32), non_blocking=True)
-        tb = None
-        if CANONICAL_TIES:                                                # --deterministic: the tied problems, behind the solve
-            tb = _tie_breaker(state, B, n, self.device)
-            tb.launch(src, tgt, cols, prices)
         torch.cuda.current_stream().synchronize()
         fb = 0
         bad = (self.cert_host == 0).nonzero().flatten().tolist()
         if tb is not None:
-            tb.settle(src, tgt, state, skip=set(bad))
+            tb.settle(src, tgt, state, skip=bad)
         for b in bad:                                                     # certificate did not close: exact host solve
             from scipy.optimize import linear_sum_assignment
 

@@ -29,17 +29,13 @@ def _plant_two_swap(src, tgt, b, i, k, ci, ck, x0=5.0):
 
 
 def _ties(dev, src, tgt, cols, prices):
-    from reart_amd import _lib
+    from reart_amd.utils import lap
 
     B, n = cols.shape
-    cap = 8 * n
-    tie = torch.zeros((B,), dtype=torch.int32, device=dev)
-    ne = torch.zeros((B,), dtype=torch.int32, device=dev)
-    edges = torch.empty((B, cap, 2), dtype=torch.int32, device=dev)
-    _lib.check(_lib.lib().reart_lap_ties(_lib.ptr(src), _lib.ptr(tgt), B, n, _lib.ptr(cols), _lib.ptr(prices), _lib.ptr(tie), _lib.ptr(edges),
-                                         _lib.ptr(ne), cap, _lib.stream()), "reart_lap_ties")
+    tb = lap.TieBreaker(B, n, dev)
+    tb.launch(src, tgt, cols, prices)
     torch.cuda.synchronize()
-    return tie.cpu().numpy(), [edges[b, :int(ne[b])].cpu().numpy() for b in range(B)]
+    return tb.tie_host.numpy().copy(), [tb.pairs_of(b) for b in range(B)]
 
 
 @pytest.mark.parametrize("n", [512, 700, 2048])
@@ -112,6 +108,19 @@ def test_every_entry_of_the_loops_settles_ties(dev):
                 fb, _ = lap.InPlaceResolve(2, n, dev)(src, tgt, state)
                 assert fb == 0
                 got = state["cols"][0].cpu().numpy()
+                # the pairs the solve's own certificate pass listed (reart_lap_resolve_points_mc_ties) = the host's, as sets
+                tb = state["tie_breaker"]
+                torch.cuda.synchronize()
+                for b in range(2):
+                    listed = tb.pairs_of(b)
+                    c_b = state["cols"][b].clone()
+                    if b == 0:
+                        c_b[20], c_b[100] = 400, 17            # (as the solve left it, before the canonical choice)
+                    host = lap.tight_pairs_host(src[b], tgt[b], c_b, state["prices"][b])
+                    want, have = set(map(tuple, host.tolist())), set(map(tuple, listed.tolist()))
+                    # (the solver may have returned either optimum of the tied pair: the listed pairs are those of ITS optimum)
+                    assert have == want or b == 0, (b, len(have), len(want))
+                assert tb.tie_host.tolist() == [1, 0]
             assert got[20] == 17 and got[100] == 400, entry
         assert state["tie_breaker"].flagged >= 3
     finally:

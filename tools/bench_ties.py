@@ -27,4 +27,4 @@ for shift in (0.0, -50.0, 1e4):
         tb.launch(src2, tgt, state["cols"], prices)
     e1.record(); torch.cuda.synchronize()
     print(f"B={B} n={n} potentials shifted by {shift:g}: {1e3 * e0.elapsed_time(e1) / 50:.1f} us per call (two launches + fill + flag copy), "
-          f"flags {tb.tie_host.tolist()}, tight pairs {tb.n_edges.cpu().tolist()}")
+          f"flags {tb.tie_host.tolist()}, tight pairs {tb.n_edges.sum(1).cpu().tolist()}")

@@ -89,16 +89,12 @@ def dissect(i, ra, rb):
             print(f"    the fp32 costs of those rows to those columns:\n{np.array2string(sub, precision=10)}")
         for tag, r in (("A", ra), ("B", rb)):
             cols, prices = r["cols"][i], r["prices"][i]
-            cap = 8 * n
-            tie = torch.zeros((B,), dtype=torch.int32, device=dev)
-            ne = torch.zeros((B,), dtype=torch.int32, device=dev)
-            ed = torch.empty((B, cap, 2), dtype=torch.int32, device=dev)
-            _lib.check(_lib.lib().reart_lap_ties(_lib.ptr(src), _lib.ptr(tgt), B, n, _lib.ptr(cols), _lib.ptr(prices), _lib.ptr(tie), _lib.ptr(ed),
-                                                 _lib.ptr(ne), cap, _lib.stream()), "reart_lap_ties")
+            tb_ = lap.TieBreaker(B, n, dev)
+            tb_.launch(src, tgt, cols, prices)
             torch.cuda.synchronize()
-            pairs = ed[p_, :int(ne[p_])].cpu().numpy()
+            tie, pairs = tb_.tie_host, tb_.pairs_of(p_)
             new, moved = lap.canonical_among_ties(cols[p_].cpu().numpy(), pairs)
-            print(f"    reart_lap_ties on run {tag}: flags {tie.cpu().tolist()}, tight pairs of problem {p_}: {int(ne[p_])}; canonical optimum moves {moved} rows"
+            print(f"    reart_lap_ties on run {tag}: flags {tie.tolist()}, tight pairs of problem {p_}: {len(pairs)}; canonical optimum moves {moved} rows"
                   f" -> equals run A's {np.array_equal(new, ca)}, run B's {np.array_equal(new, cb)}")
 
 
