@@ -808,8 +808,13 @@ __global__ __launch_bounds__(64 * NW) void lap_jvmw_kernel(JvArgs a) {
 // left).  Cutting every chain at 32 or 64 steps loses (rows that would have settled go to the searches: recipe +6 %).  So the
 // cut depends on who is still running: a chain that has used MW_ARR_TAIL_STEPS steps gives up once all but 1 / MW_ARR_TAIL_DIV of
 // the launch's teams have run out of rows -- while the chip is busy a long chain delays nobody, at the end it delays everybody.
+// ... and on what the row's problem already has in store for the searches: where many rows are left anyway the searches are the
+// long part of the solve and every further row costs a search of its own (hold-out sets, tools/holdout.sh: 11 x 896^2 with 17
+// rows left lost 6 % to an unconditional cut), so the cut applies only while fewer than MW_ARR_TAIL_LEFT rows of the problem
+// have been given up (4 / 8 / 16 / no limit on the hold-out sets and nao: 16 is never the worst, the others each are somewhere).
 #define MW_ARR_TAIL_STEPS 32
 #define MW_ARR_TAIL_DIV 16
+#define MW_ARR_TAIL_LEFT 16
 
 // Between the set-up and the row reduction: every unowned column's price is lowered until the first MATCHED row is indifferent
 // between it and its own column (the step the searches' part of lap_jvmw_kernel explains; here for all the columns the
@@ -974,7 +979,11 @@ __global__ __launch_bounds__(256) void lap_mc_trees_kernel(JvArgs a) {
 // and inherits that column's ROOT (a search that reaches it walks to that unowned column; the root is what a search uses up).
 // One workgroup per problem: a thread owns the rows of its columns (M_i = min over the forest of c_it + q_t and the column
 // that attains it in registers), a round is one workgroup arg-min + one distance per row.  MW_FOREST_R rounds.
-#define MW_FOREST_PER 32     // > 0: the growth stops after this many rows per row LEFT for the searches (cnt[2]), at most MW_FOREST_R
+// With one to four rows left for the searches (the typical re-solve of the nao projection) a forest of 512 rows costs 0.44 ms for
+// searches that take 0.16 (tools/replay_kernels.py): such a problem grows MW_FOREST_PER rows per row left.  NOT in proportion
+// for every problem: with 10-20 rows left (the hold-out sequences of tools/holdout.sh, the recipe) a smaller forest loses 6-9 %.
+#define MW_FOREST_FEW 4
+#define MW_FOREST_PER 32
 #define MW_FOREST_R 512       // measured 0 / 48 / 128 / 256 / 512 / 1024: recipe 3.57 / 3.58 / 3.51 / 3.37 / 3.33 / 3.70 ms per refresh, projection 78.8 / 77.9 / 80.4 / 82.4 / 86.7 / 86.8 it/s
 template <int CPL>
 __global__ __launch_bounds__(512) void lap_mc_forest_kernel(JvArgs a) {
@@ -1033,7 +1042,7 @@ __global__ __launch_bounds__(512) void lap_mc_forest_kernel(JvArgs a) {
     }
     double off = 0.0;
     int nf = nf0;
-    const int rounds = MW_FOREST_PER > 0 ? min(MW_FOREST_R, MW_FOREST_PER * cnt[2]) : MW_FOREST_R;     // rows the growth stops after
+    const int rounds = cnt[2] <= MW_FOREST_FEW ? min(MW_FOREST_R, MW_FOREST_PER * cnt[2]) : MW_FOREST_R;     // rows the growth stops after
     // The growth is a shortest-path computation like the searches' (the label of an outside row: L_i = M_i - u_i, the shift
     // at which it becomes tight to the forest; a row that joins at shift o offers its column at q + o to everybody else) and
     // runs in BUCKETS like them: all outside rows with a label below (closest label) + width join together, label-correcting
@@ -1324,8 +1333,14 @@ __global__ __launch_bounds__(64 * TW) void lap_mc_arr_team_kernel(JvArgs a) {
         for (int budget = a.mc_chain; ; ) {
             double pr[CW];
             int ow[CW];
+            // (in the same round of reads as the prices -- but only by chains long enough for the cut to apply: read by every
+            // team at every step, the launch-wide counter was one address hammered from all eight XCDs, and every step of every
+            // chain waited for it: +8 % on the recipe's solves)
             int fin_now = 0;
-            if (threadIdx.x == 0) fin_now = ld_i(fin);       // (in the same round of reads as the prices)
+            if (threadIdx.x == 0 && a.mc_chain - budget >= MW_ARR_TAIL_STEPS) {
+                fin_now = ld_i(fin);
+                if (ld_i(&cnt[2]) >= MW_ARR_TAIL_LEFT) fin_now = 0;      // the problem has rows for the searches anyway: no cut
+            }
 #pragma unroll
             for (int k = 0; k < CW; ++k) {
                 pr[k] = col[k] < n ? ld_d(price + col[k]) : INFINITY;

@@ -33,15 +33,16 @@ def _box_points(rng, size, n):
     return pts
 
 
-def make_sequence(T=20, n_parts=8, pts_per_part=512, seed=2, n_ref=3000, with_flow=True):
-    """-> dict(complete [T,N,3] f32, part [N] i64, ref_idx/ref_loc/ref_flow lists for the T-1 pairs)."""
+def make_sequence(T=20, n_parts=8, pts_per_part=512, seed=2, n_ref=3000, with_flow=True, amp_scale=1.0):
+    """-> dict(complete [T,N,3] f32, part [N] i64, ref_idx/ref_loc/ref_flow lists for the T-1 pairs).
+    ``amp_scale`` scales every joint's angular amplitude (hold-out sets of the solver's constants: tools/exp_tail.py)."""
     rng = np.random.default_rng(seed)
     sizes = rng.uniform(0.04, 0.12, (n_parts, 3))
     parent = [-1] + [int(rng.integers(0, i)) for i in range(1, n_parts)]
     # joint placement: child attached at a random face centre of the parent
     attach = rng.uniform(-0.5, 0.5, (n_parts, 3))
     axes = rng.normal(size=(n_parts, 3))
-    amp = rng.uniform(0.2, 0.8, n_parts)
+    amp = rng.uniform(0.2, 0.8, n_parts) * float(amp_scale)
     phi = rng.uniform(0, 2 * np.pi, n_parts)
     N = n_parts * pts_per_part
 

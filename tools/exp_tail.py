@@ -75,21 +75,33 @@ def main():
     from reart_amd.relax import RelaxEngine
     from reart_amd.run_robot import AssignmentPhase
 
-    g = load_nao_demo()
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-    cano, pcs, c = t(g["cano"]), t(g["pc_list"]), int(g["cano_idx"])
     n_iter, assign_iter = int(os.environ.get("ITERS", 15000)), int(os.environ.get("ASSIGN_ITER", 5000))
-    rng = np.random.default_rng(0)
-    gt_pos = t(g["complete_gt_pc_list"])
-    sel = [torch.from_numpy(rng.permutation(gt_pos.shape[1])[:3000]).to(dev) for _ in range(pcs.shape[0])]
-    refs = [gt_pos[k][s] for k, s in enumerate(sel)]
-    flows = [t(g["gt_flow_list"][k])[s] for k, s in enumerate(sel)]
+    ds_recipe, ds_proj = int(os.environ.get("DS", 4)), int(os.environ.get("DS_PROJ", 2))
+    if os.environ.get("SEQ", "").startswith("synthetic:"):
+        # a HOLD-OUT sequence (the solver's constants were tuned on nao alone):
+        # SEQ=synthetic:seed,parts,points per part,frames,amplitude scale -- reart_amd.synthetic.make_sequence, canonical frame T // 2
+        from reart_amd.synthetic import make_sequence, split_canonical
+        sd, parts, ppp, T, amp = os.environ["SEQ"].split(":", 1)[1].split(",")
+        seq = make_sequence(T=int(T), n_parts=int(parts), pts_per_part=int(ppp), seed=int(sd), n_ref=3000, with_flow=True, amp_scale=float(amp))
+        c = int(T) // 2
+        cano_h, pcs_h = split_canonical(seq["complete"], c)
+        cano, pcs = t(cano_h), t(pcs_h)
+        refs, flows = [t(r) for r in seq["ref_loc"]], [t(f) for f in seq["ref_flow"]]
+    else:
+        g = load_nao_demo()
+        cano, pcs, c = t(g["cano"]), t(g["pc_list"]), int(g["cano_idx"])
+        rng = np.random.default_rng(0)
+        gt_pos = t(g["complete_gt_pc_list"])
+        sel = [torch.from_numpy(rng.permutation(gt_pos.shape[1])[:3000]).to(dev) for _ in range(pcs.shape[0])]
+        refs = [gt_pos[k][s] for k, s in enumerate(sel)]
+        flows = [t(g["gt_flow_list"][k])[s] for k, s in enumerate(sel)]
     torch.manual_seed(2)
     model = BaseModel(num_parts=20, pose_len=pcs.shape[0]).to(dev)
     eng = RelaxEngine(cano, pcs, model, c, refs, flows, n_iter=n_iter, seed=2)
     i = eng.capture(steps_per_graph=50)
     eng.step(assign_iter - i)
-    phase = AssignmentPhase(eng, cano, pcs, 4, 5, 0.3)
+    phase = AssignmentPhase(eng, cano, pcs, ds_recipe, 5, 0.3)
     phase.events, phase.collect_stats = [], True
     before, srcs = [], []
     orig = phase._refresh_on_device
@@ -111,7 +123,7 @@ def main():
     if MODE == "recipe":
         ms = [a.elapsed_time(b) for a, b in phase.events][-len(before):]
         raw = phase.stats_raw[-len(before):]
-        order, _ = table(ms, raw, "recipe 9 x 1024^2, reart_lap_resolve_points_mc")
+        order, _ = table(ms, raw, f"recipe {pcs.shape[0]} x {phase.n}^2, reart_lap_resolve_points_mc")
         if DUMP:
             np.savez_compressed(DUMP, tgt=phase.tgt_pts.cpu().numpy(), idx=order, ms=np.asarray(ms)[order],
                                 src=np.stack([srcs[s].cpu().numpy() for s in order]),
@@ -128,7 +140,7 @@ def main():
     result = {"pred_cano_part": seg_s.cpu().numpy(), "pred_pose_list": trans_s.cpu().numpy(),
               "joint_connection": conn_s.cpu().numpy().tolist(), "cano_idx": c}
     a = rr.build_parser().parse_args(["--model", "kinematic", "--use_flow_loss", "--use_assign_loss", "--assign_iter", "0",
-                                      "--downsample", "2", "--assign_gap", "1", "--cano_idx", str(c)])
+                                      "--downsample", str(ds_proj), "--assign_gap", "1", "--cano_idx", str(c)])
     with contextlib.redirect_stdout(sys.stderr):
         kin = rr.build_kinematic_from_base(result, cano, pcs, a).to(dev)
     loop = rr.make_projection_loop(a, kin, cano, pcs, refs, flows)
@@ -158,7 +170,7 @@ def main():
           + " ".join(f"{500 / (b[1] - (marks[k - 1][1] if k else 0.0)):.0f}" for k, b in enumerate(marks)))
     ms = [x.elapsed_time(y) for x, y in loop.lap_events][-len(bef):]
     raw = np.asarray(raw)
-    order, _ = table(ms, raw, "projection 9 x 2048^2")
+    order, _ = table(ms, raw, f"projection {pcs.shape[0]} x {loop.tgt_pts.shape[1]}^2")
     if DUMP:
         np.savez_compressed(DUMP, tgt=loop.tgt_pts.cpu().numpy(), idx=order, ms=np.asarray(ms)[order],
                             src=np.stack([srcp[s].cpu().numpy() for s in order]),
