@@ -321,7 +321,9 @@ def test_race_with_warm_racers_over_a_moving_sequence(dev):
 @pytest.mark.parametrize("n,racers,form", [(1024, None, True), (600, None, True), (512, 1, True), (1024, 1, True),
                                             (1024, None, ("mc", 16)), (700, 1, ("mc", 3)), (1024, 2, ("mc", 28)), (1500, 2, ("mc", 4)),
                                             (600, None, ("mc", 0)), (1024, None, ("mc", 0)), (1024, 1, ("mc", 0)),
-                                            (2048, 2, ("mc", 0))])
+                                            (2048, 2, ("mc", 0)),
+                                            # W <= 2: the lazy-price chains (lap_mc_arr_lazy_kernel: the form of launches full of problems)
+                                            (1024, None, ("mc", 1)), (1500, 1, ("mc", 1)), (2048, 2, ("mc", 2)), (700, None, ("mc", 2))])
 def test_resolve_per_wave_gives_the_optimum(dev, n, racers, form):
     """The chain forms of the re-solve.  ``form=True`` and ``("mc", W > 0)``: reart_lap_resolve_points_mc (the chains of a problem
     on W workgroups, lock-free commits on state in memory; True = the default W).  ``("mc", 0)``: reart_lap_resolve_points_mw (the
@@ -398,7 +400,7 @@ def test_resolve_per_wave_at_2048(dev):
             np.testing.assert_array_equal(c, ref[b][1])
 
 
-@pytest.mark.parametrize("form", [True, ("mc", 13), ("mc", 2), ("mc", 0)])
+@pytest.mark.parametrize("form", [True, ("mc", 13), ("mc", 2), ("mc", 1), ("mc", 0)])
 def test_resolve_chain_forms_under_stress(dev, form):
     """The chain forms of the re-solve where their commits collide most: 19 problems of 1024^2 re-solved 12 times in a row while
     a third of the rows jump every time and the target clouds hold exact DUPLICATES (exact ties: a chain must leave the row to
