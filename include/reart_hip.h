@@ -107,6 +107,34 @@ int reart_blend_anchor_motion(const float *query, const float *ref, const float 
                               float *flow, uint8_t *mask,
                               void *workspace, size_t workspace_bytes, void *stream);
 
+/* The T-1 calls of blend_anchor_motion an iteration makes (run_robot.py:194-201: one per frame pair; utils/flow_utils.py:147-170)
+ * as one: query [B,nq,3], ref / ref_flow [B,nr_max,3] (every frame's reference set padded to the longest), ref_len [B] int64 the
+ * true lengths (NULL: all nr_max; each >= k) -> flow [B,nq,3], mask [B,nq].  Bit for bit what B calls of
+ * reart_blend_anchor_motion return (one search over the batch with per-batch target lengths, one blend launch). */
+size_t reart_blend_anchor_motion_batch_workspace_bytes(int B, int nq, int nr_max, int k);
+int reart_blend_anchor_motion_batch(const float *query, const float *ref, const float *ref_flow, const int64_t *ref_len,
+                                    int B, int nq, int nr_max, int k, int euclidean, float *flow, uint8_t *mask,
+                                    void *workspace, size_t workspace_bytes, void *stream);
+
+/* The kinematic projection's iteration between the assignment re-solve and the FK backward, as one call (csrc/kinpost.hip;
+ * run_robot.py:165-209 for `--model kinematic --use_assign_loss [--use_flow_loss]`):
+ *   assignment branch (:177-184)  loss = lambda_assign x sum |pc_src - tgt[cols]|^2 over the n sampled points of every frame, its
+ *                                 gradient scattered to the sampled points' places in dL/d pc_trans (slot_of_point [N]: sample slot
+ *                                 of canonical point p or -1; pc_src [B,n,3] = the sampled points of pc_trans as the solve saw them;
+ *                                 tgt [B,n,3]; cols [B,n] the optimum) -- n = 0: no such branch;
+ *   flow branch (:194-209)        comp = pc_trans[:cano_idx] | cano | pc_trans[cano_idx:]; blend_anchor_motion of every frame pair
+ *                                 (reart_blend_anchor_motion_batch: ref / ref_flow [B,nr_max,3], ref_len [B] or NULL), flow_loss of
+ *                                 comp[1:] - comp[:-1] against it (robust, smooth_weight), times lambda_flow; ref = NULL: none.
+ * Outputs: G [B,N,3] = dL/d pc_trans of both branches (bit for bit what the reference's tensor expressions give through autograd's
+ * operator order), matched [B,n,3] (nullable) the matched targets, losses [3] (device) = the assignment term, the flow term, their
+ * sum.  workspace: reart_kin_post_workspace_bytes(B, N, nr_max or 0, k).  Nine launches on `stream`, no host synchronisation. */
+size_t reart_kin_post_workspace_bytes(int B, int N, int nr_max, int k);
+int reart_kin_post(const float *pc_trans, const float *cano, int B, int N, int cano_idx, const float *pc_src, const float *tgt,
+                   const int32_t *cols, const int32_t *slot_of_point, int n, float lambda_assign, const float *ref,
+                   const float *ref_flow, const int64_t *ref_len, int nr_max, int k, int euclidean, float lambda_flow, int robust,
+                   float smooth_weight, float *G, float *matched, float *losses, void *workspace, size_t workspace_bytes,
+                   void *stream);
+
 /* Replaces flow_loss(gt_flow_list, pred_flow_list, flow_mask_list, robust, smooth_weight)
  * (networks/loss.py:10-21): gt, pred [B,N,3]; mask [B,N] uint8 or NULL (= all ones);
  * loss: device float scalar; grad_pred [B,N,3] or NULL = d loss / d pred. */

@@ -30,6 +30,11 @@ PROTOTYPES = {
     "reart_knn_cuda": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, c_size_t, P]),
     "reart_blend_anchor_motion_workspace_bytes": (c_size_t, [c_int] * 3),
     "reart_blend_anchor_motion": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P, P, c_size_t, P]),
+    "reart_kin_post_workspace_bytes": (c_size_t, [c_int] * 4),
+    "reart_kin_post": (c_int, [P, P, c_int, c_int, c_int, P, P, P, P, c_int, c_float, P, P, P, c_int, c_int, c_int, c_float, c_int, c_float,
+                               P, P, P, P, c_size_t, P]),
+    "reart_blend_anchor_motion_batch_workspace_bytes": (c_size_t, [c_int] * 4),
+    "reart_blend_anchor_motion_batch": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, c_size_t, P]),
     "reart_flow_loss_workspace_bytes": (c_size_t, []),
     "reart_flow_loss": (c_int, [P, P, P, c_int, c_int, c_int, c_float, P, P, P, c_size_t, P]),
     "reart_base_forward": (c_int, [P, c_int, c_int, c_int, P, P, P, c_int, P, P, P, c_float, P, P, P, P, P, P, P]),

@@ -77,6 +77,76 @@ extern "C" int reart_blend_anchor_motion(const float *query, const float *ref, c
     return REART_OK;
 }
 
+// The T-1 blends of one iteration (run_robot.py:194-201 calls blend_anchor_motion once per frame pair) as ONE call: the queries
+// of all frames [B,nq,3], the frames' reference sets padded to a common length [B,nr_max,3] with their true lengths ref_len [B]
+// (NULL: all nr_max) -- one search over the batch (the same exact brute-force kernels with per-batch target lengths, so the same
+// neighbours, distances and tie rule as B separate calls) and one blend launch.  In the kinematic projection loop the nine
+// per-frame calls were 36 launches of 20 us each on side streams: 0.33 ms of an iteration between two re-solves.
+__global__ __launch_bounds__(256) void blend_batch_kernel(const float *__restrict__ dist, const int64_t *__restrict__ idx,
+                                                          const float *__restrict__ ref_flow, int nq, int nr_max, int k,
+                                                          float *__restrict__ flow, uint8_t *__restrict__ mask) {
+    const int n = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (n >= nq) return;
+    const size_t q = (size_t)b * nq + n;
+    const float *rf = ref_flow + (size_t)b * nr_max * 3;
+    float wsum = 0.f, dmin = INFINITY, fmx = -INFINITY;
+    for (int j = 0; j < k; ++j) {
+        float d = dist[q * k + j];
+        if (d < 1e-10f) d = 1e-10f;
+        wsum += 1.0f / d;
+        dmin = fminf(dmin, d);
+        const float *f = rf + 3 * idx[q * k + j];
+        fmx = fmaxf(fmx, (f[0] * f[0] + f[1] * f[1]) + f[2] * f[2]);
+    }
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int j = 0; j < k; ++j) {
+        float d = dist[q * k + j];
+        if (d < 1e-10f) d = 1e-10f;
+        const float wn = (1.0f / d) / wsum;
+        const float *f = rf + 3 * idx[q * k + j];
+        a0 += f[0] * wn; a1 += f[1] * wn; a2 += f[2] * wn;
+    }
+    flow[3 * q] = a0; flow[3 * q + 1] = a1; flow[3 * q + 2] = a2;
+    mask[q] = (dmin <= fmx) || (dmin <= 0.05f);
+}
+
+static size_t blend_batch_ws_layout(int B, int nq, int nr, int k, size_t *o_d, size_t *o_i, size_t *o_knn) {
+    size_t off = 0;
+    *o_d = off; off += reart_align_up(sizeof(float) * (size_t)B * nq * k, 256);
+    *o_i = off; off += reart_align_up(sizeof(int64_t) * (size_t)B * nq * k, 256);
+    *o_knn = off; off += reart_knn_points_workspace_bytes(B, nq, nr, k);
+    return off;
+}
+
+extern "C" size_t reart_blend_anchor_motion_batch_workspace_bytes(int B, int nq, int nr_max, int k) {
+    if (B <= 0 || nq <= 0 || nr_max <= 0 || k <= 0) return 0;
+    size_t a, b, c;
+    return blend_batch_ws_layout(B, nq, nr_max, k, &a, &b, &c);
+}
+
+extern "C" int reart_blend_anchor_motion_batch(const float *query, const float *ref, const float *ref_flow, const int64_t *ref_len,
+                                               int B, int nq, int nr_max, int k, int euclidean, float *flow, uint8_t *mask,
+                                               void *workspace, size_t workspace_bytes, void *stream) {
+    if (B < 0 || nq < 0 || nr_max < 0 || k < 1) return REART_ERR_INVALID_ARG;
+    if (k > REART_MAX_K) return REART_ERR_UNSUPPORTED;
+    if (k > nr_max) return REART_ERR_INVALID_ARG;             // (a frame whose ref_len is below k: the caller's error, like nr < k above)
+    if (B == 0 || nq == 0) return REART_OK;
+    if (!query || !ref || !ref_flow || !flow || !mask || !workspace) return REART_ERR_INVALID_ARG;
+    size_t o_d, o_i, o_knn;
+    if (workspace_bytes < blend_batch_ws_layout(B, nq, nr_max, k, &o_d, &o_i, &o_knn)) return REART_ERR_INVALID_ARG;
+    char *ws = (char *)workspace;
+    float *dist = (float *)(ws + o_d);
+    int64_t *idx = (int64_t *)(ws + o_i);
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t *lent = ref_len;
+    int rc = reart_knn_run(1, &query, &ref, nullptr, ref_len ? &lent : nullptr, B, &nq, &nr_max, k, euclidean ? 1 : 0, &dist, &idx,
+                           ws + o_knn, workspace_bytes - o_knn, st);
+    if (rc != REART_OK) return rc;
+    hipLaunchKernelGGL(blend_batch_kernel, dim3(reart_div_up(nq, 256), B), dim3(256), 0, st, dist, idx, ref_flow, nq, nr_max, k, flow, mask);
+    REART_CHECK_LAUNCH();
+    return REART_OK;
+}
+
 // ---------------------------------------------------------------------------------------
 // flow_loss (networks/loss.py:10-21) and d loss / d pred
 //   L = sum_{b,n} [ m f + smooth (not m) |pred|^2 ],  f = |pred-gt|^2 or Huber(delta=1)

@@ -94,6 +94,27 @@ class KinematicEngine:
         self.losses = {}
         self._pc_src, self._inplace, self._g_pre, self._g_post = None, None, None, None
         self._side = None
+        # reart_kin_post's inputs that never change: the sample slot of every canonical point, the frames' flow references padded
+        # to one length; its buffers (owned here: a captured graph keeps their addresses)
+        n = int(self.src_idx.numel())
+        self._slot = torch.full((self.N,), -1, dtype=torch.int32, device=self.dev)
+        self._slot[self.src_idx] = torch.arange(n, dtype=torch.int32, device=self.dev)
+        self._ref_pad = self._flow_pad = self._ref_len = None
+        self._nr_max = 0
+        if self.refs is not None:
+            lens = [int(r.shape[0]) for r, _ in self.refs]
+            self._nr_max = max(lens)
+            self._ref_pad = torch.zeros((self.B, self._nr_max, 3), dtype=torch.float32, device=self.dev)
+            self._flow_pad = torch.zeros((self.B, self._nr_max, 3), dtype=torch.float32, device=self.dev)
+            for f, (r, fl) in enumerate(self.refs):
+                self._ref_pad[f, :lens[f]] = r
+                self._flow_pad[f, :lens[f]] = fl
+            if min(lens) != self._nr_max:
+                self._ref_len = torch.tensor(lens, dtype=torch.int64, device=self.dev)
+        self._matched_buf = torch.zeros((self.B, n, 3), dtype=torch.float32, device=self.dev)
+        self._loss3 = torch.zeros((3,), dtype=torch.float32, device=self.dev)
+        self._post_ws = torch.empty((max(int(_lib.lib().reart_kin_post_workspace_bytes(self.B, self.N, self._nr_max, 3)), 256),),
+                                    dtype=torch.uint8, device=self.dev)
 
     # ---- pieces -----------------------------------------------------------------------------------------------------
     def _joint_values(self):
@@ -273,8 +294,31 @@ class KinematicEngine:
         self.forward()
         self._pc_src.copy_(self.pc_trans[:, self.src_idx])
 
+    FUSED_POST = True   # reart_kin_post (nine launches); False: the same values as tensor expressions (_post_expressions)
+
     def _post(self):
         """Everything between the solve and Adam: matched targets, assignment (+ flow) loss, dL/d pc_trans, the FK backward."""
+        if not self.FUSED_POST or self.lap_state["cols"].dtype != torch.int32 or (self.refs is not None and min(int(r.shape[0]) for r, _ in self.refs) < 3):
+            return self._post_expressions()
+        L = _lib.lib()
+        n = int(self.src_idx.numel())
+        rc = L.reart_kin_post(_lib.ptr(self.pc_trans), _lib.ptr(self.cano), self.B, self.N, self.cano_idx, _lib.ptr(self._pc_src),
+                              _lib.ptr(self.tgt_pts), _lib.ptr(self.lap_state["cols"]), _lib.ptr(self._slot), n, self.lambda_assign,
+                              _lib.ptr(self._ref_pad), _lib.ptr(self._flow_pad), _lib.ptr(self._ref_len), self._nr_max, 3, self.euclid,
+                              self.lambda_flow, int(self.robust), self.smooth, _lib.ptr(self.G), _lib.ptr(self._matched_buf),
+                              _lib.ptr(self._loss3), _lib.ptr(self._post_ws), self._post_ws.numel(), _lib.stream())
+        _lib.check(rc, "reart_kin_post")
+        self.matched = self._matched_buf
+        losses = {"opt assignment loss": self._loss3[0]}
+        if self.refs is not None:
+            losses["flow Loss"] = self._loss3[1]
+        losses["total Loss"] = self._loss3[2]
+        self._backward()
+        self.losses = losses
+
+    def _post_expressions(self):
+        """_post as the reference's tensor expressions (run_robot.py:177-209) over the per-frame operators: the form reart_kin_post
+        replaced, kept as its check (tests/test_kinematic_engine_gpu.py)."""
         cols = self.lap_state["cols"].long()
         self.matched = self.tgt_pts.gather(1, cols[..., None].expand(-1, -1, 3))
         diff = self._pc_src - self.matched

@@ -395,7 +395,9 @@ CONCURRENT_CALLS = 1
 def _arr_wgs(B):
     # (x 8 chains each: with a team of four waves per chain -- lap_mc_arr_team_kernel -- 128 chains in flight per problem beat
     # 64, recipe refresh 2.68 -> 2.57 ms; 224 are no better)
-    return RESOLVE_ARR_WGS if RESOLVE_ARR_WGS >= 0 else max(1, min(16, 512 // max(B * max(CONCURRENT_CALLS, 1), 1)))
+    # (at least two: with the chip full of problems -- the recipe as a sweep, 4 x 95 in flight -- a problem's ~400 released rows on
+    # the 8 chains of ONE workgroup are what a solve waits for: 20 x 15 000 with energies 26.0 s with 1, 24.3 with 2, 24.6 with 4)
+    return RESOLVE_ARR_WGS if RESOLVE_ARR_WGS >= 0 else max(2, min(16, 512 // max(B * max(CONCURRENT_CALLS, 1), 1)))
 
 
 def _resolve_racers(B, n, race=True):

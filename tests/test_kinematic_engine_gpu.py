@@ -245,3 +245,78 @@ def test_engine_with_root_motion_equals_the_autograd_loop(dev, with_flow):
             np.testing.assert_allclose(getattr(m_eng, name).detach().cpu().numpy(), getattr(m_ref, name).detach().cpu().numpy(),
                                        rtol=0, atol=5e-6, err_msg=f"iteration {i} {name}")
     assert eng.lap_fallbacks == 0 and loop.lap_fallbacks == 0
+
+
+def test_blend_anchor_motion_batch_equals_the_per_frame_calls(dev):
+    """reart_blend_anchor_motion_batch (the T-1 blends of run_robot.py:194-201 as one call; utils/flow_utils.py:147-170): ragged
+    reference sets padded to one length -- flows and masks bit for bit those of the per-frame operator."""
+    from reart_amd import _lib
+    from reart_amd.knn_cuda import KNN
+    from reart_amd.utils.flow_utils import blend_anchor_motion
+
+    rng = np.random.default_rng(7)
+    B, N = 5, 1500
+    lens = [300, 911, 3, 640, 1200]
+    q = t(rng.uniform(-0.3, 0.3, (B, N, 3)).astype(np.float32), dev)
+    refs = [t(rng.uniform(-0.3, 0.3, (m, 3)).astype(np.float32), dev) for m in lens]
+    flows = [t(rng.normal(0, 0.02, (m, 3)).astype(np.float32), dev) for m in lens]
+    refs[1][5] = q[1][17]                                   # an exact hit: the d < 1e-10 clamp
+    nr = max(lens)
+    rp, fp = torch.zeros((B, nr, 3), device=dev), torch.zeros((B, nr, 3), device=dev)
+    for f in range(B):
+        rp[f, :lens[f]], fp[f, :lens[f]] = refs[f], flows[f]
+    ln = torch.tensor(lens, dtype=torch.int64, device=dev)
+    flow = torch.empty((B, N, 3), device=dev)
+    mask = torch.empty((B, N), dtype=torch.bool, device=dev)
+    L = _lib.lib()
+    for euclid in (1, 0):
+        ws = torch.empty((int(L.reart_blend_anchor_motion_batch_workspace_bytes(B, N, nr, 3)),), dtype=torch.uint8, device=dev)
+        _lib.check(L.reart_blend_anchor_motion_batch(_lib.ptr(q), _lib.ptr(rp), _lib.ptr(fp), _lib.ptr(ln), B, N, nr, 3, euclid, _lib.ptr(flow),
+                                                     _lib.ptr(mask), _lib.ptr(ws), ws.numel(), _lib.stream()), "reart_blend_anchor_motion_batch")
+        knn = KNN(k=3, transpose_mode=True)
+        knn._squared = not euclid
+        for f in range(B):
+            fl, mk = blend_anchor_motion(q[f], refs[f], flows[f], knn, return_mask=True)
+            assert torch.equal(flow[f], fl) and torch.equal(mask[f], mk), (euclid, f)
+
+
+@pytest.mark.parametrize("with_flow", [True, False])
+def test_fused_post_equals_the_tensor_expressions(dev, with_flow):
+    """reart_kin_post (run_robot.py:165-209 between the re-solve and the FK backward, nine launches) against the same part as the
+    reference's tensor expressions over the per-frame operators (KinematicEngine._post_expressions): dL/d pc_trans and the matched
+    targets bit for bit, the two losses to 1e-6 (their sums are accumulated in double precision here, in fp32 there), and the
+    parameters after six iterations equal."""
+    from reart_amd.kinematic_engine import KinematicEngine
+
+    k = np.load(os.path.join(G, "kinematic.npz"))
+    cano = t(k["cano_pc"], dev)
+    rng = np.random.default_rng(11)
+    B, N = 9, cano.shape[0]
+    with torch.no_grad():
+        pcs = _model(dev, k, cano)(cano)[0]
+    pcs = (pcs + t(rng.normal(0, 0.004, (B, N, 3)).astype(np.float32), dev)).contiguous()
+    refs = flows = None
+    if with_flow:
+        comp = torch.cat((pcs[:2], cano[None], pcs[2:]), dim=0)
+        sel = [torch.from_numpy(rng.permutation(N)[:400 + 31 * f]).to(dev) for f in range(B)]       # ragged reference sets
+        refs = [comp[f][s] for f, s in enumerate(sel)]
+        flows = [(comp[f + 1][s] - comp[f][s]) * 0.5 for f, s in enumerate(sel)]
+    out = {}
+    for fused in (True, False):
+        m = _model(dev, k, cano)
+        eng = KinematicEngine(m, cano, pcs, 2, refs, flows, assign_iter=0, assign_gap=1, downsample=4)
+        eng.FUSED_POST = fused
+        eng.GRAPHS = False
+        rec = []
+        for i in range(6):
+            losses = eng.iteration(i)
+            rec.append((eng.G.clone(), eng.matched.clone(), {key: float(v) for key, v in losses.items()}))
+        out[fused] = (rec, torch.cat([getattr(m, n_).detach().reshape(-1).clone() for n_ in ("axis_list", "moment_list", "theta_list")]))
+        assert eng.lap_fallbacks == 0
+    for i, ((g1, m1, l1), (g0, m0, l0)) in enumerate(zip(out[True][0], out[False][0])):
+        assert torch.equal(g1, g0), f"iteration {i}: dL/d pc_trans"
+        assert torch.equal(m1, m0), f"iteration {i}: matched targets"
+        assert l1.keys() == l0.keys()
+        for key in l1:
+            assert abs(l1[key] - l0[key]) <= 1e-6 * abs(l0[key]) + 1e-9, (i, key, l1[key], l0[key])
+    assert torch.equal(out[True][1], out[False][1])
