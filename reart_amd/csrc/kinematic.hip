@@ -174,42 +174,42 @@ extern "C" int reart_fk_forward(const int32_t *parent, const int32_t *edge_of_pa
 //      then screw_bwd; per-frame axis/moment contributions go to a [B,E,6] scratch.
 //  (3) axis/moment gradients = sum over frames in ascending order.
 // ---------------------------------------------------------------------------------------
+// Two launches since round 6.  As ONE workgroup per frame the 21 slices' serial walks each waited for their own loads, trip by
+// trip (68 us per launch at 9 x 4096: the longest kernel between two assignment re-solves).  Now a workgroup per (frame, slice):
+// the slice's points -- part labels, gradients, coordinates -- come into LDS in one coalesced batch, twelve threads walk them in
+// the SAME ascending order, and a second launch adds the slices in ascending order: the same additions in the same order.
+#define PG_SLICES (256 / 12)
 __global__ __launch_bounds__(256) void pose_grad_kernel(const float *__restrict__ x,
                                                         const int64_t *__restrict__ part,
                                                         const float *__restrict__ G, int N, int P,
-                                                        float *__restrict__ gpose) {
-    extern __shared__ float s_acc[];  // [16 slices][P*12]
-    const int t = blockIdx.x, tid = threadIdx.x;
-    const int c = tid % 12, slice = tid / 12;  // 21 slices of the point range; 252 active threads
-    const int nsl = 256 / 12;
-    if (slice < nsl) {
-        float *acc = s_acc + (size_t)slice * P * 12;
-        for (int p = 0; p < P; ++p) acc[p * 12 + c] = 0.f;
-        const int per = (N + nsl - 1) / nsl;
-        const int n0 = slice * per, n1 = (n0 + per < N) ? n0 + per : N;
-        // (the same additions in the same order, eight points' loads in flight at a time: one point per trip left every trip
-        // waiting for its own three global loads -- 68 us per launch at 9 x 4096, the longest kernel between two re-solves)
-        constexpr int U = 8;
-        const int gi = c < 9 ? c / 3 : c - 9, xi = c % 3;
-        for (int nb = n0; nb < n1; nb += U) {
-            int pp[U];
-            float vv[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int n = nb + u < n1 ? nb + u : n1 - 1;
-                pp[u] = (int)part[n];
-                const float g = G[3 * ((size_t)t * N + n) + gi];
-                vv[u] = c < 9 ? g * x[3 * (size_t)n + xi] : g;
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (nb + u < n1) acc[pp[u] * 12 + c] += vv[u];
+                                                        float *__restrict__ partial /* [B][PG_SLICES][P*12] */) {
+    extern __shared__ float s_pg[];  // acc [P*12] | g [per*3] | xx [per*3] | pp [per] (ints)
+    const int slice = blockIdx.x, t = blockIdx.y, tid = threadIdx.x;
+    const int per = (N + PG_SLICES - 1) / PG_SLICES;
+    const int n0 = slice * per, n1 = (n0 + per < N) ? n0 + per : N, cnt = n1 > n0 ? n1 - n0 : 0;
+    float *acc = s_pg, *sg = acc + P * 12, *sx = sg + per * 3;
+    int *sp = (int *)(sx + per * 3);
+    for (int e = tid; e < cnt * 3; e += 256) { sg[e] = G[3 * ((size_t)t * N + n0) + e]; sx[e] = x[3 * (size_t)n0 + e]; }
+    for (int e = tid; e < cnt; e += 256) sp[e] = (int)part[n0 + e];
+    for (int e = tid; e < P * 12; e += 256) acc[e] = 0.f;
+    __syncthreads();
+    if (tid < 12) {
+        const int c = tid, gi = c < 9 ? c / 3 : c - 9, xi = c % 3;
+        for (int k = 0; k < cnt; ++k) {
+            const float g = sg[3 * k + gi];
+            acc[sp[k] * 12 + c] += c < 9 ? g * sx[3 * k + xi] : g;
         }
     }
     __syncthreads();
-    for (int e = tid; e < P * 12; e += 256) {
+    float *out = partial + ((size_t)t * PG_SLICES + slice) * P * 12;
+    for (int e = tid; e < P * 12; e += 256) out[e] = acc[e];
+}
+
+__global__ __launch_bounds__(256) void pose_grad_sum_kernel(const float *__restrict__ partial, int P, float *__restrict__ gpose) {
+    const int t = blockIdx.x;
+    for (int e = threadIdx.x; e < P * 12; e += 256) {
         float sum = 0.f;
-        for (int s = 0; s < nsl; ++s) sum += s_acc[(size_t)s * P * 12 + e];
+        for (int s = 0; s < PG_SLICES; ++s) sum += partial[((size_t)t * PG_SLICES + s) * P * 12 + e];
         const int p = e / 12, cc = e % 12;
         // gpose layout 3x4 row-major: entry (i,j) for cc<9 is R[i][j] (i = cc/3, j = cc%3), cc>=9 is t[cc-9]
         const int i = cc < 9 ? cc / 3 : cc - 9, j = cc < 9 ? cc % 3 : 3;
@@ -281,7 +281,8 @@ __global__ __launch_bounds__(256) void lm_reduce_kernel(const float *__restrict_
 
 extern "C" size_t reart_fk_backward_workspace_bytes(int P, int B, int E) {
     if (P <= 0 || B <= 0 || E < 0) return 0;
-    return reart_align_up(sizeof(float) * 12 * (size_t)B * P, 256) + reart_align_up(sizeof(float) * 6 * (size_t)B * (E > 0 ? E : 1), 256);
+    return reart_align_up(sizeof(float) * 12 * (size_t)B * P, 256) + reart_align_up(sizeof(float) * 6 * (size_t)B * (E > 0 ? E : 1), 256) +
+           reart_align_up(sizeof(float) * 12 * (size_t)B * P * PG_SLICES, 256);      // gpose | g_lm | the slices' partial pose gradients
 }
 
 extern "C" int reart_fk_backward(const float *x, const int64_t *part, const float *G, int N,
@@ -299,8 +300,14 @@ extern "C" int reart_fk_backward(const float *x, const int64_t *part, const floa
     hipStream_t st = (hipStream_t)stream;
     float *gpose = (float *)workspace;
     float *g_lm = (float *)((char *)workspace + reart_align_up(sizeof(float) * 12 * (size_t)B * P, 256));
-    const size_t lds = sizeof(float) * (256 / 12) * (size_t)P * 12;
-    hipLaunchKernelGGL(pose_grad_kernel, dim3(B), dim3(256), lds, st, x, part, G, N, P, gpose);
+    float *pg_partial = (float *)((char *)g_lm + reart_align_up(sizeof(float) * 6 * (size_t)B * (E > 0 ? E : 1), 256));
+    const int pg_per = (N + PG_SLICES - 1) / PG_SLICES;
+    const size_t lds = sizeof(float) * ((size_t)P * 12 + 7 * (size_t)pg_per);
+    if (lds > REART_LDS_DEFAULT_CAP &&
+        hipFuncSetAttribute((const void *)pose_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return REART_ERR_LAUNCH;
+    hipLaunchKernelGGL(pose_grad_kernel, dim3(PG_SLICES, B), dim3(256), lds, st, x, part, G, N, P, pg_partial);
+    hipLaunchKernelGGL(pose_grad_sum_kernel, dim3(B), dim3(256), 0, st, pg_partial, P, gpose);
     if (hipMemsetAsync(g_theta, 0, sizeof(float) * (size_t)B * E, st) != hipSuccess) return REART_ERR_LAUNCH;
     if (hipMemsetAsync(g_lm, 0, sizeof(float) * 6 * (size_t)B * E, st) != hipSuccess) return REART_ERR_LAUNCH;
     if (g_distance && hipMemsetAsync(g_distance, 0, sizeof(float) * (size_t)B * E, st) != hipSuccess)
