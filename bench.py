@@ -1121,7 +1121,7 @@ def main():
             executed = prof["pairs"] / prof["launches"]
             ach = executed * 8 / t_nn / 1e12
             traffic = traffic_current = None
-            pmc_file = next((f for f in (os.path.join(ROOT, "profiles", "r05_pmc_search.json"), os.path.join(ROOT, "profiles", "r04_pmc_search.json"))
+            pmc_file = next((f for f in (os.path.join(ROOT, "profiles", "r06_pmc_search.json"), os.path.join(ROOT, "profiles", "r05_pmc_search.json"))
                              if os.path.exists(f)), None)
             if use_flow and T == 20 and N == 4096 and pmc_file:
                 import hashlib

@@ -31,7 +31,7 @@ class KinematicEngine:
 
     def __init__(self, model, cano_pc, pc_list, cano_idx, pc_ref_list=None, flow_ref_list=None, trans_lr=1e-2,
                  weight_decay=0.0, assign_iter=0, assign_gap=5, downsample=4, lambda_assign=3e-1, lambda_flow=1.0,
-                 use_robust_loss=False, smooth_weight=1e-2, knn_squared=False, use_assign_loss=True):
+                 use_robust_loss=False, smooth_weight=1e-2, knn_squared=False, use_assign_loss=True, src_idx=None, tgt_idx=None):
         _lib.require_gpu(cano_pc, pc_list)
         self.root = hasattr(model, "root_6d") and hasattr(model, "root_t")      # networks/model.py:153-158
         self._pris = None
@@ -70,10 +70,15 @@ class KinematicEngine:
         self.lap_steps_log = []
         self.step_count = 0
         # run_robot.py:167-169: both FPS calls sample fixed clouds (start 0 on the reference's CUDA path): once
+        # (``src_idx`` [n] / ``tgt_idx`` [T-1,n]: samples handed in instead -- the reference's CPU sampler starts from a random point,
+        # networks/pointnet2_utils.py:90, so a trajectory the reference produced on a CPU comes with its samples:
+        # tests/golden/kinematic_loop.npz)
         num_fps = self.N // int(downsample)
         zero = torch.zeros(1, dtype=torch.long, device=self.dev)
-        self.src_idx = farthest_point_sample(self.cano[None], num_fps, start=zero, cuda_mode=True)[0]          # [n]
-        tgt_idx = farthest_point_sample(self.pc_list, num_fps, start=zero.expand(self.B), cuda_mode=True)
+        self.src_idx = (farthest_point_sample(self.cano[None], num_fps, start=zero, cuda_mode=True)[0] if src_idx is None
+                        else torch.as_tensor(src_idx, dtype=torch.long, device=self.dev).reshape(-1))          # [n]
+        tgt_idx = (farthest_point_sample(self.pc_list, num_fps, start=zero.expand(self.B), cuda_mode=True) if tgt_idx is None
+                   else torch.as_tensor(tgt_idx, dtype=torch.long, device=self.dev).reshape(self.B, -1))
         # the sampled targets are the COLUMNS of every re-solve of the run: numbered along a Z-order curve (lap.spatial_order)
         from .utils.lap import spatial_order
         self.tgt_order = spatial_order(index_points(self.pc_list, tgt_idx))                                     # [B,n] into the FPS order

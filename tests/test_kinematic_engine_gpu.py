@@ -320,3 +320,44 @@ def test_fused_post_equals_the_tensor_expressions(dev, with_flow):
         for key in l1:
             assert abs(l1[key] - l0[key]) <= 1e-6 * abs(l0[key]) + 1e-9, (i, key, l1[key], l0[key])
     assert torch.equal(out[True][1], out[False][1])
+
+
+@pytest.mark.parametrize("tag", ["plain", "flow"])
+def test_root_motion_loop_follows_the_references_own_trajectory(dev, tag):
+    """the loop of the root-motion / mixed-joint variant against a trajectory the REFERENCE produced
+    (tests/golden/make_golden_kinematic_loop.py: the statements of run_robot.py:154-221 over the reference's own KinematicModel,
+    autograd, torch.cdist + scipy, blend_anchor_motion / flow_loss and torch.optim.Adam; 9 x 1024^2 assignments per iteration),
+    given the reference's two FPS samples: the first assignment equal to scipy's, every parameter after each of the five Adam
+    steps to 2e-5 (measured: 1e-7 ... 5e-6; root_6d / root_t / distance_list included), every loss to 2e-4, nothing through the
+    host solver.  (Measured loss deviations: <= 3e-7 in eight of the ten iterations; 1.2e-4 and 1.7e-5 in one iteration each, back
+    to 1e-7 in the next: the reference's cost matrix is torch.cdist's matrix-product form, the product's is cdist by differences,
+    7 digits apart -- where two assignments tie to 7 digits in the SUM of distances the two sides may take different ones, and
+    the loss is the sum of SQUARED distances.)"""
+    from reart_amd.kinematic_engine import KinematicEngine
+
+    z = np.load(os.path.join(G, "kinematic_loop.npz"))
+    _, model = _root_model(dev)
+    names = ("axis_list", "moment_list", "theta_list", "distance_list", "root_6d", "root_t")
+    for name in names:                                       # the golden starts from the same model (same seeded construction)
+        np.testing.assert_allclose(getattr(model, name).detach().cpu().numpy(), z[f"{tag}_start_{name}"], rtol=0, atol=1e-7)
+    cano, pcs = t(z["cano"], dev), t(z[f"{tag}_pcs"], dev)
+    refs = flows = None
+    if tag == "flow":
+        lens = z["flow_ref_len"]
+        refs = [t(z["flow_refs"][f][:lens[f]], dev) for f in range(len(lens))]
+        flows = [t(z["flow_flows"][f][:lens[f]], dev) for f in range(len(lens))]
+    eng = KinematicEngine(model, cano, pcs, int(z["cano_idx"]), refs, flows, trans_lr=float(z["lr"]), assign_iter=0, assign_gap=1,
+                          downsample=int(z["downsample"]), lambda_assign=float(z["lambda_assign"]), lambda_flow=float(z["lambda_flow"]),
+                          src_idx=z[f"{tag}_src_idx"], tgt_idx=z[f"{tag}_tgt_idx"])
+    assert eng.root and eng._pris is not None
+    for i in range(int(z["iters"])):
+        losses = eng.iteration(i)
+        if i == 0:      # the optimum in the reference's column numbering (the engine numbers its columns along a Z-order curve)
+            cols = eng.tgt_order.gather(1, eng.lap_state["cols"].long()).cpu().numpy()
+            np.testing.assert_array_equal(cols, z[f"{tag}_cols0"])
+        got = [float(losses["opt assignment loss"])] + ([float(losses["flow Loss"])] if tag == "flow" else []) + [float(losses["total Loss"])]
+        np.testing.assert_allclose(got, z[f"{tag}_losses"][i], rtol=2e-4, atol=1e-7, err_msg=f"iteration {i} losses")
+        for name in names:
+            np.testing.assert_allclose(getattr(model, name).detach().cpu().numpy(), z[f"{tag}_traj_{name}"][i], rtol=0, atol=2e-5,
+                                       err_msg=f"iteration {i} {name}")
+    assert eng.lap_fallbacks == 0

@@ -1,12 +1,12 @@
 #!/bin/bash
 # Measurement evidence of a round, collected on the GPU box (gpurun): the bench lines, rocprofv3 kernel stats of the bench
 # commands (restricted to the timed window where warm-up would be averaged in) and the counter passes of the search kernel.
-# Outputs under gpurun_out/prof5/ (the summaries are copied into profiles/ afterwards, named r05_*).
+# Outputs under gpurun_out/prof6/ (the summaries are copied into profiles/ afterwards, named r06_*).
 # Every command runs under `timeout`: a hang must not take the box.  Under rocprofv3 the program itself follows `--`.
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
-O=gpurun_out/prof5
+O=gpurun_out/prof6
 rm -rf $O; mkdir -p $O
 CLEAN="--sweep-instances 0 --no-tail --no-cpu-baseline --no-secondary"
 # gpurun boxes differ: about one in ten runs the search launch 35 % slower than the others (every other kernel the same, four
@@ -38,27 +38,21 @@ f=$(find $O/trace_kinematic -name "*kernel_trace.csv" | head -1)
 timeout 900 rocprofv3 --kernel-trace -f csv -d $O/trace_recipe -- python3 bench.py --config nao_recipe --no-cpu-baseline > $O/bench_nao_recipe_under_rocprof.json 2> $O/trace_recipe.err
 f=$(find $O/trace_recipe -name "*kernel_trace.csv" | head -1)
 [ -n "$f" ] && python3 tools/kernel_window_stats.py "$f" --last 1999 --match lap_ > $O/kernel_stats_nao_recipe_window.csv
-timeout 900 rocprofv3 --kernel-trace -f csv -d $O/trace_projection -- python3 bench.py --config nao_projection --steps 1500 --no-cpu-baseline > $O/bench_nao_projection_1500_under_rocprof.json 2> $O/trace_projection.err
+timeout 900 rocprofv3 --kernel-trace -f csv -d $O/trace_projection -- python3 bench.py --config nao_projection --steps 1500 --no-cpu-baseline --one-mode > $O/bench_nao_projection_1500_under_rocprof.json 2> $O/trace_projection.err
 f=$(find $O/trace_projection -name "*kernel_trace.csv" | head -1)
-[ -n "$f" ] && python3 tools/kernel_window_stats.py "$f" --last 1499 --match lap_ > $O/kernel_stats_nao_projection_window.csv
+# the trace holds the recipe that precedes the projection too: its n = 1024 kernels are `<16, ...>` instances -- the window is everything
+# AFTER the recipe's last search launch, minus the cold first solve (the r05 file mixed the two runs)
+[ -n "$f" ] && python3 tools/kernel_window_stats.py "$f" --after-last "lap_jvmw_kernel<16" --skip 1 --match lap_ > $O/kernel_stats_nao_projection_window.csv
+[ -n "$f" ] && python3 tools/solve_spans.py "$f" --last 1490 > $O/solve_spans_nao_projection.txt
+[ -n "$f" ] && python3 tools/iteration_glue.py "$f" 1000 > $O/iteration_glue_nao_projection.txt
 # 3b. README.md:125 on nao, the whole run (15 000 iterations, a snapshot every 10), and the solve-by-solve account of both recipes
-timeout 900 python3 tools/run_nao.py --projection > $O/run_nao_projection.txt 2> $O/run_nao_projection.err
+timeout 900 python3 tools/run_nao.py --projection 2>/dev/null | grep -v "joint types" > $O/run_nao_projection_det_1.txt
+timeout 900 python3 tools/run_nao.py --projection 2>/dev/null | grep -v "joint types" > $O/run_nao_projection_det_2.txt
+timeout 900 python3 tools/run_nao.py --projection --no-deterministic 2>/dev/null | grep -v "joint types" > $O/run_nao_projection_nodet.txt
+timeout 500 python3 tools/exp_kin_determinism.py 2>&1 | grep -v "amdgpu.ids\|joint types" > $O/exp_kin_determinism.txt
 MODE=recipe timeout 400 python3 tools/exp_tail.py 2>/dev/null | grep -v amdgpu.ids > $O/exp_tail_recipe.txt
 MODE=projection P_ITERS=3000 timeout 400 python3 tools/exp_tail.py 2>/dev/null | grep -v "amdgpu.ids\|joint types" > $O/exp_tail_projection.txt
-# 3d. the re-solve on DUMPED solves (tools/exp_tail.py DUMP=... SAMPLE=40 -> tools/_states/, not in the history: 28 MB): the SAME
-#     problems through a library built from lap_mw.hip as the round found it (libreart_hip_old.so, built here from the history:
-#     git show <round start>:reart_amd/csrc/lap_mw.hip, see tools/mk_variant.sh) and through the product library
-if [ ! -f tools/_states/r05s_recipe.npz ]; then      # (a fresh checkout: take the dumps from runs of the current code)
-  mkdir -p tools/_states
-  MODE=recipe DUMP=tools/_states/r05s_recipe.npz SAMPLE=40 timeout 400 python3 tools/exp_tail.py > /dev/null 2>&1
-  MODE=projection P_ITERS=3000 DUMP=tools/_states/r05s_proj.npz SAMPLE=40 timeout 400 python3 tools/exp_tail.py > /dev/null 2>&1
-fi
-if [ -f reart_amd/csrc/libreart_hip_old.so ] && [ -f tools/_states/r05s_recipe.npz ]; then
-  TAGS="old base@morton old base@morton" timeout 900 tools/ab_tags.sh > $O/replay_tail_ab.txt 2>&1
-fi
-# 3c. workgroup lifetimes of the four small kernels of the headline step (diagnostic build: device clocks)
-make -C reart_amd/csrc stats > /dev/null 2>&1
-REART_LIB=reart_amd/csrc/libreart_hip_stats.so timeout 120 python3 tools/phase_clock.py 2>/dev/null | tail -7 > $O/small_kernel_clocks.txt
+# 3d. the solver's constants on sequences they were not tuned on: tools/holdout.sh (its own gpurun call: builds r4 / r5 variants first)
 # 4. the README recipe as a sweep on one GPU: 20 canonical frames of one generated sequence, both phases in shared launches, the groups concurrently
 rm -rf /tmp/sweep_recipe
 timeout 900 python3 -m reart_amd.sweep --synthetic 1 --synthetic_frames 20 --cano all --n_iter 15000 --use_flow_loss --use_assign_loss --energy --save_root /tmp/sweep_recipe > $O/sweep_recipe.line.json 2> $O/sweep_recipe.err
@@ -70,6 +64,8 @@ for C in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE
 done
 # the counter summary the bench line cites, stamped with the sources it was measured on
 python3 tools/pmc_search_json.py $O > $O/pmc_search.json 2> $O/pmc_search_json.err
+# the bench line of the driver's exact command, last (every leg, both modes of the projection)
+timeout 900 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_default.json 2> $O/bench_driver_default.err
 # keep the merge-back small: only the summaries travel
 find $O -mindepth 1 -maxdepth 1 -type d -exec rm -rf {} +
 ls -la $O
