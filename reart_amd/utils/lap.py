@@ -251,6 +251,9 @@ def canonical_among_ties(cols, edges):
     changed = 0
     for comp in np.unique(lab[e[:, 0]]):
         rows = np.nonzero(lab == comp)[0]
+        if len(rows) > MAX_TIED_ROWS:      # degenerate input (clouds of duplicated points: hundreds of rows tied with each other):
+            canonical_among_ties.skipped += 1      # the solver's optimum stands for this component -- optimal, not canonical
+            continue
         allowed = {int(r): {int(cols[r])} for r in rows}
         for i, j in e[lab[e[:, 0]] == comp]:
             allowed[int(i)].add(int(j))
@@ -261,6 +264,12 @@ def canonical_among_ties(cols, edges):
                 changed += 1
     assert np.array_equal(np.sort(cols), np.arange(n)), "canonical_among_ties: not a permutation"
     return cols, changed
+
+
+# a tied component larger than this is left as the solver returned it (the host's exact choice is a matching problem per row of the
+# component: fine for the 2-20 rows real ties involve, minutes for a cloud of exact duplicates)
+MAX_TIED_ROWS = 256
+canonical_among_ties.skipped = 0
 
 
 def tight_pairs_host(src, tgt, cols, prices):

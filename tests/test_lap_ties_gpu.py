@@ -174,3 +174,71 @@ def test_two_deterministic_projections_are_the_same_run(dev):
     for x, y in zip(a_par, b_par):
         assert torch.equal(x, y)
     assert a_tb[0] >= 1 and b_tb[0] >= 1, "no tie met in 200 iterations: the test did not exercise the mechanism"
+
+
+def test_a_row_with_more_tight_pairs_than_slots_goes_to_the_host(dev):
+    """31 coincident sources against 31 coincident targets: every one of those rows is tied with 30 columns -- more than the K = 24
+    slots a row has in the kernels' pair lists.  The problem comes back with flag 2, the host lists its pairs from the cost matrix
+    (lap.tight_pairs_host) and the canonical optimum gives the rows, in ascending order, the columns in ascending order."""
+    from reart_amd.utils import lap
+
+    n = 512
+    src_h, tgt_h = _problems(dev, 2, n, seed=9)
+    rows = np.arange(40, 40 + 31)
+    colsd = np.arange(300, 300 + 31)
+    src_h[1, rows] = (6.0, 6.0, 6.0)
+    tgt_h[1, colsd] = (6.0, 6.5, 6.0)
+    src, tgt = torch.from_numpy(src_h).to(dev), torch.from_numpy(tgt_h).to(dev)
+    old = lap.CANONICAL_TIES
+    lap.CANONICAL_TIES = True
+    try:
+        state = {}
+        for k in range(2):                                   # cold, then warm (the in-place re-solve lists the pairs itself)
+            if k == 0:
+                lap.linear_sum_assignment_points(src, tgt, state, device_cols=True)
+            else:
+                perm = torch.from_numpy(colsd[np.random.default_rng(k).permutation(31)].astype(np.int32)).to(dev)
+                state["cols"][1, torch.from_numpy(rows).to(dev)] = perm      # any other optimum to start from
+                fb, _ = lap.InPlaceResolve(2, n, dev)(src, tgt, state)
+                assert fb == 0
+            got = state["cols"][1].cpu().numpy()
+            np.testing.assert_array_equal(got[rows], colsd)
+            tb = state["tie_breaker"]
+            assert tb.overflows >= 1 and tb._tie_np.tolist() == [0, 2]
+    finally:
+        lap.CANONICAL_TIES = old
+
+
+def test_massively_tied_clouds_do_not_stall_the_host(dev):
+    """Clouds drawn from 64 distinct points (every cost value occurs thousands of times: hundreds of rows tied with each other): the
+    canonical choice is skipped for components above lap.MAX_TIED_ROWS -- the solver's optimum stands -- and the call returns in
+    seconds with the optimal cost."""
+    import time
+
+    import oracle
+    from reart_amd.utils import lap
+
+    rng = np.random.default_rng(3)
+    B, n = 2, 1024
+    grid = rng.uniform(-0.3, 0.3, (64, 3)).astype(np.float32)
+    tgt_h, src_h = grid[rng.integers(0, 64, (B, n))], grid[rng.integers(0, 64, (B, n))]
+    src, tgt = torch.from_numpy(src_h).to(dev), torch.from_numpy(tgt_h).to(dev)
+    old, lap.CANONICAL_TIES = lap.CANONICAL_TIES, True
+    try:
+        t0 = time.time()
+        state = {}
+        out = lap.linear_sum_assignment_points(src, tgt, state)
+        src2_h = src_h.copy()
+        src2_h[:, :200] = grid[rng.integers(0, 64, (B, 200))]
+        src2 = torch.from_numpy(src2_h).to(dev)
+        out2 = lap.linear_sum_assignment_points(src2, tgt, state)
+        assert time.time() - t0 < 60
+    finally:
+        lap.CANONICAL_TIES = old
+    assert lap.canonical_among_ties.skipped >= 1
+    for pts, res in ((src_h, out), (src2_h, out2)):
+        cost = oracle.cdist(pts, tgt_h)
+        ref = oracle.linear_sum_assignment(cost)
+        for b, (r, c) in enumerate(res):
+            assert sorted(c.tolist()) == list(range(n))
+            assert abs(float(cost[b][r, c].astype(np.float64).sum()) - float(cost[b][ref[b][0], ref[b][1]].astype(np.float64).sum())) <= 1e-9
