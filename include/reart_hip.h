@@ -196,6 +196,13 @@ int reart_adam_step(float *param, const float *grad, float *exp_avg, float *exp_
                     int n, int step, float lr, float beta1, float beta2, float eps,
                     void *stream);
 
+/* The same step on up to 8 tensors in ONE launch (run_robot.py:145-151: one optimizer over theta / axis / moment, each a
+ * few hundred floats): param / grad / exp_avg / exp_avg_sq are HOST arrays of `count` device pointers, n and lr host arrays
+ * of their sizes and learning rates, read at the call.  Same arithmetic per element as reart_adam_step. */
+int reart_adam_step_multi(int count, float *const *param, const float *const *grad, float *const *exp_avg,
+                          float *const *exp_avg_sq, const int *n, const float *lr, int step, float beta1, float beta2,
+                          float eps, void *stream);
+
 /* ------------------------------------------------------------------------ */
 /* Fused relaxation iteration                                                */
 /* ------------------------------------------------------------------------ */
@@ -586,7 +593,8 @@ int reart_lap_resolve_points_mw(const float *src, const float *tgt, int B, int n
  * lap_mc_arr_kernel -- the chains only meet in the column they commit on, so their state lives in memory and a commit is a
  * lock-free compare-and-swap on the column's owner), the path searches then one workgroup per problem and racer.  Three
  * launches between the two whole-chip passes.  512 <= n <= 2048; workspace: reart_lap_mc_workspace_bytes(B, n, racers).
- * Outputs, certificate, statistics and the caveat on the potentials as reart_lap_resolve_points_mw. */
+ * Outputs, certificate, statistics and the caveat on the potentials as reart_lap_resolve_points_mw; certified [B] and the
+ * statistics need no clearing by the caller (the set-up launch defines them: no fill launches in front of a refresh). */
 size_t reart_lap_mc_workspace_bytes(int B, int n, int racers);
 int reart_lap_resolve_points_mc(const float *src, const float *tgt, int B, int n, int racers, int arr_wgs, int32_t *col4row,
                                 int32_t *certified, const double *price_in, double *price_out, void *workspace,

@@ -45,6 +45,7 @@ PROTOTYPES = {
     "reart_compute_pc_transform": (c_int, [P, P, P, c_int, c_int, c_int, P, P]),
     "reart_rotation_6d_to_matrix": (c_int, [P, c_int, P, P]),
     "reart_adam_step": (c_int, [P, P, P, P, c_int, c_int, c_float, c_float, c_float, c_float, P]),
+    "reart_adam_step_multi": (c_int, [c_int, P, P, P, P, P, P, c_int, c_float, c_float, c_float, P]),
     "reart_fps": (c_int, [P, c_int, c_int, c_int, P, c_int, P, P, P]),
     "reart_ball_query": (c_int, [P, P, c_int, c_int, c_int, ctypes.c_double, c_int, c_int, P, P, P]),
     "reart_fk_forward": (c_int, [P, P, P, c_int, P, P, P, P, c_int, c_int, P, P]),

@@ -205,8 +205,15 @@ __global__ __launch_bounds__(256) void pose_grad_kernel(const float *__restrict_
     for (int e = tid; e < P * 12; e += 256) out[e] = acc[e];
 }
 
-__global__ __launch_bounds__(256) void pose_grad_sum_kernel(const float *__restrict__ partial, int P, float *__restrict__ gpose) {
+// (also clears frame t's rows of the joint gradients fk_bwd_kernel accumulates into -- [B,E] theta, [B,E] distance (nullable),
+// [B,E,6] axis/moment terms: three fill launches of their own otherwise, each a 5 us slot of the iteration)
+__global__ __launch_bounds__(256) void pose_grad_sum_kernel(const float *__restrict__ partial, int P, float *__restrict__ gpose, int E,
+                                                            float *__restrict__ g_theta, float *__restrict__ g_dist, float *__restrict__ g_lm) {
     const int t = blockIdx.x;
+    for (int e = threadIdx.x; e < 6 * E; e += 256) {
+        g_lm[(size_t)t * 6 * E + e] = 0.f;
+        if (e < E) { g_theta[(size_t)t * E + e] = 0.f; if (g_dist) g_dist[(size_t)t * E + e] = 0.f; }
+    }
     for (int e = threadIdx.x; e < P * 12; e += 256) {
         float sum = 0.f;
         for (int s = 0; s < PG_SLICES; ++s) sum += partial[((size_t)t * PG_SLICES + s) * P * 12 + e];
@@ -307,11 +314,7 @@ extern "C" int reart_fk_backward(const float *x, const int64_t *part, const floa
         hipFuncSetAttribute((const void *)pose_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return REART_ERR_LAUNCH;
     hipLaunchKernelGGL(pose_grad_kernel, dim3(PG_SLICES, B), dim3(256), lds, st, x, part, G, N, P, pg_partial);
-    hipLaunchKernelGGL(pose_grad_sum_kernel, dim3(B), dim3(256), 0, st, pg_partial, P, gpose);
-    if (hipMemsetAsync(g_theta, 0, sizeof(float) * (size_t)B * E, st) != hipSuccess) return REART_ERR_LAUNCH;
-    if (hipMemsetAsync(g_lm, 0, sizeof(float) * 6 * (size_t)B * E, st) != hipSuccess) return REART_ERR_LAUNCH;
-    if (g_distance && hipMemsetAsync(g_distance, 0, sizeof(float) * (size_t)B * E, st) != hipSuccess)
-        return REART_ERR_LAUNCH;
+    hipLaunchKernelGGL(pose_grad_sum_kernel, dim3(B), dim3(256), 0, st, pg_partial, P, gpose, E, g_theta, g_distance, g_lm);
     hipLaunchKernelGGL(fk_bwd_kernel, dim3(reart_div_up(B, 64)), dim3(64), 0, st, parent, edge_of_part, order, P,
                        axis, moment, theta, distance, B, E, trans, gpose, g_theta, g_distance, g_lm);
     if (E > 0)

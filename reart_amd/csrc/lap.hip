@@ -1514,9 +1514,12 @@ static int jv_launch(JvArgs a, void *workspace, size_t workspace_bytes, void *st
         double *pc = (double *)w;
         int *cc = (int *)(w + bn);
         a.done = (int *)(w + bn * (size_t)racers);
-        if (hipMemcpyAsync(pc, a.price_in, sizeof(double) * (size_t)a.B * a.n, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess ||
-            hipMemcpyAsync(cc, a.col4row, sizeof(int) * (size_t)a.B * a.n, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess ||
-            hipMemsetAsync(a.done, 0, sizeof(int) * (size_t)a.B, (hipStream_t)stream) != hipSuccess)
+        // (the form of lap_mw.hip with the row reduction on many compute units hands its racers the state of that launch: they
+        // read neither copy, and its set-up launch clears the flags -- three launches less per refresh)
+        if (per_wave != 2 &&
+            (hipMemcpyAsync(pc, a.price_in, sizeof(double) * (size_t)a.B * a.n, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess ||
+             hipMemcpyAsync(cc, a.col4row, sizeof(int) * (size_t)a.B * a.n, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess ||
+             hipMemsetAsync(a.done, 0, sizeof(int) * (size_t)a.B, (hipStream_t)stream) != hipSuccess))
             return REART_ERR_LAUNCH;
         a.price_start = pc; a.col_start = cc;
     }

@@ -150,6 +150,7 @@ struct JvArgs {
     // racing form (MODE 1, gridDim.y racers per matrix): the racers read the start from copies (col4row / price_out are
     // written by the winner while others may still be loading) and meet in done[b] (0 = nobody has finished)
     int *done;
+    int *done_clear;           // set-up launch of the lap_mw.hip form (its own `done` is null: it does not race): cleared there, no memset launch
     // lap_mw.hip, form with the row reduction on many compute units: the state between its three launches, in the workspace
     double *mc_price;          // [B][n]
     int *mc_owner, *mc_assigned, *mc_list, *mc_next;       // [B][n] each: column -> row | row -> column | free rows | rows left

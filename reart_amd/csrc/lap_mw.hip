@@ -307,6 +307,11 @@ __global__ __launch_bounds__(64 * NW) void lap_jvmw_kernel(JvArgs a) {
             c[0] = nfree; c[1] = 0; c[2] = 0; c[3] = 0; c[4] = 0; c[5] = st_freed; c[6] = 0; c[7] = sh.flag;
             if (b == 0) a.mc_cnt[8 * a.B] = 0;                          // launch-wide: row-reduction teams that have run out of rows
             a.scale[b] = mx;
+            // the outputs and the racers' meeting point start defined HERE, not by fills in front of the solve (every launch of a
+            // refresh is a 5 us slot of its own, however little it does: tools/solve_gaps.py)
+            a.certified[b] = 0;
+            if (a.done_clear) a.done_clear[b] = 0;
+            if (a.stats) { int *o = a.stats + 4 * b; o[0] = 0; o[1] = 0; o[2] = 0; o[3] = 0; }
         }
         return;
     }
@@ -1445,6 +1450,7 @@ static int mc_launch(const JvArgs &a, int racers, int arr_wgs, hipStream_t strea
          hipFuncSetAttribute((const void *)lap_jvmw_kernel<CPL, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess))
         return REART_ERR_LAUNCH;
     JvArgs s1 = a;
+    s1.done_clear = a.done;
     s1.done = nullptr;                                   // the set-up reads the caller's assignment and potentials themselves
     JvArgs s2 = a;
     if (s2.mc_chain <= 0) s2.mc_chain = MW_MC_CHAIN;

@@ -1174,6 +1174,24 @@ int reart_adam_ex(const AdamArgs &a, hipStream_t st) {
     return REART_OK;
 }
 
+// reart_adam_step for up to 8 tensors in ONE launch (the pointer and size arrays are host arrays, read at the call): the three
+// parameter tensors of the kinematic model were three launches, each a 5 us slot of the iteration whatever its size.
+extern "C" int reart_adam_step_multi(int count, float *const *param, const float *const *grad, float *const *exp_avg,
+                                     float *const *exp_avg_sq, const int *n, const float *lr, int step, float beta1, float beta2,
+                                     float eps, void *stream) {
+    if (count < 0 || count > 8 || step < 1) return REART_ERR_INVALID_ARG;
+    if (count == 0) return REART_OK;
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !n || !lr) return REART_ERR_INVALID_ARG;
+    AdamArgs a = {};
+    for (int k = 0; k < count; ++k) {
+        if (n[k] < 0) return REART_ERR_INVALID_ARG;
+        if (n[k] > 0 && (!param[k] || !grad[k] || !exp_avg[k] || !exp_avg_sq[k])) return REART_ERR_INVALID_ARG;
+        a.seg[k] = {param[k], grad[k], exp_avg[k], exp_avg_sq[k], n[k], lr[k]};
+    }
+    a.nseg = count; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.step = step;
+    return reart_adam_ex(a, (hipStream_t)stream);
+}
+
 extern "C" int reart_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
                                int n, int step, float lr, float beta1, float beta2, float eps,
                                void *stream) {

@@ -36,6 +36,8 @@ struct TieArgs {
     int *cnt;                      // [B][n] out: how many tight pairs the row has (may exceed K)
     int K;
     const int *stale;              // nullable [B]: the potentials moved after the pairs were listed (tie = 2: the host looks itself)
+    int fresh;                     // the cycle kernel is the only writer of tie (no pair-listing launch in front of it): it writes every
+                                   // problem's flag itself, zero included -- no memset launch
 };
 
 #define TIE_ROWS 4                 // rows a wave tests per pass over the columns (one set of LDS reads serves all of them)
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(TIE_CYC_BS) void lap_tie_cycle_kernel(TieArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lsm[];
     const int n = a.n, b = blockIdx.x, tid = threadIdx.x, K = a.K;
     __shared__ int s_or[3];
-    if (a.tie[b] == 3) return;
+    if (!a.fresh && a.tie[b] == 3) return;
     if (a.stale && a.stale[b]) { if (tid == 0) a.tie[b] = 2; return; }
     // Does the row graph hold a cycle?  Peeling rows without a live pair out of them one layer per round takes as many rounds
     // as the longest chain of tight pairs -- hundreds: the tight pairs are mostly what the searches' and the backward growth's
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(TIE_CYC_BS) void lap_tie_cycle_kernel(TieArgs a) {
         dead[i] = d == 0;
     }
     if (wg_or(over)) { if (tid == 0) a.tie[b] = 2; return; }            // a row with more tight pairs than it has slots: the host looks itself
-    if (!wg_or(any)) return;                                            // (tie[b] was cleared by the launch's memset)
+    if (!wg_or(any)) { if (a.fresh && tid == 0) a.tie[b] = 0; return; }   // (otherwise tie[b] was cleared by the launch's memset)
     for (int i = tid; i < n; i += TIE_CYC_BS) {
         const int d = deg[i];
         for (int k = 0; k < d; ++k) nbr[(size_t)i * K + k] = owner[(unsigned)cols[(size_t)i * K + k] < (unsigned)n ? cols[(size_t)i * K + k] : 0];
@@ -239,7 +241,7 @@ __global__ __launch_bounds__(TIE_CYC_BS) void lap_tie_cycle_kernel(TieArgs a) {
     int cyc = 0, junctions = 0;
     for (int i = tid; i < n; i += TIE_CYC_BS) { cyc |= (deg[i] == 1 && deg[ptr[i]] == 1); junctions |= deg[i] > 1; }
     if (wg_or(cyc)) { if (tid == 0) a.tie[b] = 1; return; }
-    if (!wg_or(junctions)) return;                                     // chains only, all of them ending: no cycle
+    if (!wg_or(junctions)) { if (a.fresh && tid == 0) a.tie[b] = 0; return; }   // chains only, all of them ending: no cycle
     for (int round = 0; round <= n; ++round) {                         // a junction dies when every pair out of it leads to a dead end
         int died = 0;
         for (int i = tid; i < n; i += TIE_CYC_BS) {
@@ -254,7 +256,8 @@ __global__ __launch_bounds__(TIE_CYC_BS) void lap_tie_cycle_kernel(TieArgs a) {
     }
     int left = 0;
     for (int i = tid; i < n; i += TIE_CYC_BS) left |= (deg[i] > 1 && !dead[i]);
-    if (wg_or(left) && tid == 0) a.tie[b] = 1;
+    const int cyc2 = wg_or(left);
+    if (tid == 0 && (cyc2 || a.fresh)) a.tie[b] = cyc2 ? 1 : 0;
 }
 
 static int tie_cycle_launch(const TieArgs &a, hipStream_t stream) {
@@ -271,8 +274,7 @@ static int tie_cycle_launch(const TieArgs &a, hipStream_t stream) {
 int reart_internal_tie_cycles(int B, int n, const int *col4row, int *tie, const int *cols, const int *cnt, int K, const int *stale,
                               hipStream_t stream) {
     if (n > LAP_NMAX || K < 1 || K > 32) return REART_ERR_INVALID_ARG;
-    TieArgs a{nullptr, nullptr, B, n, col4row, nullptr, tie, (int *)cols, (int *)cnt, K, stale};
-    if (hipMemsetAsync(tie, 0, sizeof(int) * (size_t)B, stream) != hipSuccess) return REART_ERR_LAUNCH;
+    TieArgs a{nullptr, nullptr, B, n, col4row, nullptr, tie, (int *)cols, (int *)cnt, K, stale, 1};
     return tie_cycle_launch(a, stream);
 }
 
@@ -281,7 +283,7 @@ extern "C" int reart_lap_ties(const float *src, const float *tgt, int B, int n, 
     if (B < 0 || n < 1 || n > LAP_NMAX || K < 1 || K > 32) return REART_ERR_INVALID_ARG;
     if (B == 0) return REART_OK;
     if (!src || !tgt || !col4row || !price || !tie || !cols || !cnt) return REART_ERR_INVALID_ARG;
-    TieArgs a{src, tgt, B, n, col4row, price, tie, cols, cnt, K, nullptr};
+    TieArgs a{src, tgt, B, n, col4row, price, tie, cols, cnt, K, nullptr, 0};
     if (hipMemsetAsync(tie, 0, sizeof(int) * (size_t)B, (hipStream_t)stream) != hipSuccess) return REART_ERR_LAUNCH;
     int per = (256 + B - 1) / B;                                       // workgroups (16 waves) per problem: one per compute unit over the batch
     const int per_max = ((n + TIE_ROWS - 1) / TIE_ROWS + TIE_PASS_BS / 64 - 1) / (TIE_PASS_BS / 64);

@@ -98,6 +98,7 @@ class KinematicEngine:
         self.G_fk = torch.empty_like(self.G) if self.root else self.G
         self.losses = {}
         self._pc_src, self._inplace, self._g_pre, self._g_post = None, None, None, None
+        self._adam_tab = self._src_idx32 = None
         self._side = None
         # reart_kin_post's inputs that never change: the sample slot of every canonical point, the frames' flow references padded
         # to one length; its buffers (owned here: a captured graph keeps their addresses)
@@ -209,15 +210,29 @@ class KinematicEngine:
             g_dist.masked_fill_(~self._pris, 0.0)
 
     def _adam(self):
+        """torch.optim.Adam's step on every parameter tensor (run_robot.py:219-221) in one launch (reart_adam_step_multi)."""
+        import ctypes
+
         L = _lib.lib()
         self.step_count += 1
-        for p, m_, v_ in zip(self.params, self.m, self.v):
+        grads = []
+        for p in self.params:
             g = self.grads[id(p)]
             if self.wd != 0.0:
                 g = g + self.wd * p.detach()          # torch.optim.Adam's L2 form
-            rc = L.reart_adam_step(_lib.ptr(p), _lib.ptr(g), _lib.ptr(m_), _lib.ptr(v_), p.numel(), self.step_count,
-                                   self.lr, 0.9, 0.999, 1e-8, _lib.stream())
-            _lib.check(rc, "reart_adam_step")
+            grads.append(g)
+        if self._adam_tab is None or self.wd != 0.0:      # per launch of at most eight tensors: host arrays of pointers, sizes, rates
+            self._adam_tab = []
+            for a in range(0, len(self.params), 8):
+                ps, gs, ms, vs = self.params[a:a + 8], grads[a:a + 8], self.m[a:a + 8], self.v[a:a + 8]
+                k = len(ps)
+                vp = ctypes.c_void_p * k
+                self._adam_tab.append((k, vp(*[p.data_ptr() for p in ps]), vp(*[g.data_ptr() for g in gs]), vp(*[m_.data_ptr() for m_ in ms]),
+                                       vp(*[v_.data_ptr() for v_ in vs]), (ctypes.c_int * k)(*[p.numel() for p in ps]),
+                                       (ctypes.c_float * k)(*([self.lr] * k))))
+        for k, tp, tg, tm, tv, tn, tl in self._adam_tab:
+            rc = L.reart_adam_step_multi(k, tp, tg, tm, tv, tn, tl, self.step_count, 0.9, 0.999, 1e-8, _lib.stream())
+            _lib.check(rc, "reart_adam_step_multi")
 
     def _flow_terms(self):
         """lambda_flow * flow_loss and its gradient added to self.G (run_robot.py:194-209)."""
@@ -262,15 +277,28 @@ class KinematicEngine:
     GRAPHS = True       # replay the launches around the solve from two captured graphs (False: every launch eagerly)
     SIDE_STREAMS = 6    # streams the per-frame flow blends of an iteration are dealt to
 
-    def _solve(self, pc_src):
-        """The assignment refresh (run_robot.py:165-178) -> the solver's [B,4] statistics; the optimum is in lap_state["cols"]."""
+    def _solve(self, pc_src, behind=None):
+        """The assignment refresh (run_robot.py:165-178) -> the solver's [B,4] statistics; the optimum is in lap_state["cols"].
+        ``behind``: launches that only READ the optimum (the replay of the post graph), queued behind the re-solve BEFORE the host
+        waits for its flags -- the GPU goes straight on while the host wakes up and reads them (75-85 us of every iteration
+        otherwise: tools/solve_gaps.py) -- and queued once more in the rare case that the host then changed the columns (a tied
+        or an uncertified problem).  Returns True when ``behind`` ran."""
         from .utils import lap
 
         B, n = pc_src.shape[:2]
+        ran = False
         if lap.InPlaceResolve.usable(self.lap_state, B, n):
             if self._inplace is None:
                 self._inplace = lap.InPlaceResolve(B, n, self.dev)
-            fb, raw = self._inplace(pc_src, self.tgt_pts, self.lap_state, stats=True)
+            self._inplace.begin(pc_src, self.tgt_pts, self.lap_state, stats=True)
+            if self.lap_events is not None:
+                self.lap_events[-1][1].record()
+            if behind is not None:
+                behind()
+                ran = True
+            fb, raw, changed = self._inplace.finish()
+            if changed and ran:
+                behind()
             st = raw.copy()
             self.lap_state["commit_conflicts"] = (st[:, 1] >> 16) & 0xffff
             st[:, 1] &= 0xffff
@@ -280,6 +308,8 @@ class KinematicEngine:
         else:       # the first solve (cold), sizes outside the chain forms: the general entry (its columns are a new tensor)
             _, fb, st = lap.linear_sum_assignment_points(pc_src.contiguous(), self.tgt_pts, self.lap_state, return_stats="full", device_cols=True)
             self._g_post = None                     # a graph that reads the columns must see the new tensor
+            if self.lap_events is not None:
+                self.lap_events[-1][1].record()
         self.lap_solves += 1
         self.lap_fallbacks += fb
         self.lap_stats = st
@@ -293,11 +323,16 @@ class KinematicEngine:
             seq = seq + np.asarray(self.lap_state["backward_rounds"], dtype=np.int64)
         self.lap_steps_log.append((int(seq.max()), float(seq.mean()), search_only))
         self.lap_winners += np.bincount((st[:, 0] >> 16) & 31, minlength=32)[:32]                  # raced re-solves: who finished first
+        return ran
 
     def _pre(self):
         """Forward of the current parameters and the sampled source points (the solver's input)."""
         self.forward()
-        self._pc_src.copy_(self.pc_trans[:, self.src_idx])
+        if self._src_idx32 is None:
+            self._src_idx32 = self.src_idx.int().contiguous()
+        rc = _lib.lib().reart_gather_points(_lib.ptr(self.pc_trans), _lib.ptr(self._src_idx32), self.B, self.N, int(self._src_idx32.numel()),
+                                            _lib.ptr(self._pc_src), _lib.stream())                 # pc_trans[:, src_idx], one launch
+        _lib.check(rc, "reart_gather_points")
 
     FUSED_POST = True   # reart_kin_post (nine launches); False: the same values as tensor expressions (_post_expressions)
 
@@ -392,15 +427,16 @@ class KinematicEngine:
             self._pre()
             if self.GRAPHS and self.lap_solves >= 2:
                 self._g_pre = self._graph(self._pre)                      # (the warm-up inside recomputes the same forward)
+        posted = False
         if self.lap_state.get("cols") is None or i % self.assign_gap == 0:                       # run_robot.py:165-178
             if self.lap_events is not None:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 ev[0].record()
-            self._solve(self._pc_src)
-            if self.lap_events is not None:
-                ev[1].record()
-                self.lap_events.append(ev)
-        if self._g_post is not None:
+                self.lap_events.append(ev)              # (the end is recorded right behind the re-solve's launches)
+            posted = self._solve(self._pc_src, behind=self._g_post.replay if self._g_post is not None else None)
+        if posted:
+            pass                                        # (the post graph went in behind the re-solve)
+        elif self._g_post is not None:
             self._g_post.replay()
         elif self.GRAPHS and self.lap_solves >= 2 and self._inplace is not None:
             self._g_post = self._graph(self._post)                        # (warm-up + capture; the replay below does the work once more:

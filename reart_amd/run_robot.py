@@ -153,32 +153,42 @@ class AssignmentPhase:
         eng, st, L = self.eng, self.lap_state, _lib.lib()
         B, n, N = self.B, self.n, eng._assign_map.shape[1]
         racers, arr = lap._resolve_racers(B, n), min(lap._arr_wgs(B), 256)
-        stream = _lib.stream()
-        _lib.check(L.reart_gather_points(_lib.ptr(eng._pc_trans), _lib.ptr(self._src_stored), B, N, n, _lib.ptr(self._src_pts), stream),
-                   "reart_gather_points")
-        self._cert.zero_()
-        ws = _lib.workspace(L.reart_lap_mc_workspace_bytes(B, n, racers), eng.device)
+        need = L.reart_lap_mc_workspace_bytes(B, n, racers)
+        if getattr(self, "_ws", None) is None or self._ws.numel() < need:
+            self._ws = torch.empty((need,), dtype=torch.uint8, device=eng.device)       # owned: a captured graph keeps its address
+            self._launches = lap.ReplayedLaunches()
+        ws, stats = self._ws, bool(self.collect_stats)
+        self._launches.guard = self.capture_guard
         cols, prices = st["cols"], st["prices"]
         off = ((8 * B * n + 255) // 256) * 256                            # the solver's statistics: [B][4] ints behind the potentials
-        if self.collect_stats:
-            ws[off:off + 16 * B].zero_()
         tb = lap._tie_breaker(st, B, n, eng.device) if lap.CANONICAL_TIES else None      # --deterministic: tied optima take the canonical one
-        if tb is not None:
-            tb.resolve_mc(self._src_pts, self.tgt_pts, racers, arr, cols, self._cert, prices, ws)
-        else:
-            _lib.check(L.reart_lap_resolve_points_mc(_lib.ptr(self._src_pts), _lib.ptr(self.tgt_pts), B, n, racers, arr, _lib.ptr(cols),
-                                                     _lib.ptr(self._cert), _lib.ptr(prices), _lib.ptr(prices), _lib.ptr(ws), ws.numel(), stream),
-                       "reart_lap_resolve_points_mc")
-        st["resolve_form"] = "mc"
-        pairs = lambda: _lib.check(L.reart_assign_pairs(_lib.ptr(cols), _lib.ptr(self._slot), _lib.ptr(self._tgt_stored), B, N, n,
-                                                        _lib.ptr(eng._assign_map), stream), "reart_assign_pairs")
-        pairs()
-        self._cert_host.copy_(self._cert, non_blocking=True)
-        if self.collect_stats:
-            self._stats_host.copy_(ws[off:off + 16 * B].view(torch.int32), non_blocking=True)
-        torch.cuda.current_stream().synchronize()
-        if tb is not None and tb.settle(self._src_pts, self.tgt_pts, st, skip=lambda: set((self._cert_host == 0).nonzero().flatten().tolist())):
+
+        def pairs():
+            _lib.check(L.reart_assign_pairs(_lib.ptr(cols), _lib.ptr(self._slot), _lib.ptr(self._tgt_stored), B, N, n,
+                                            _lib.ptr(eng._assign_map), _lib.stream()), "reart_assign_pairs")
+
+        def queue():                                                      # every launch and copy of the refresh (lap.ReplayedLaunches)
+            stream = _lib.stream()
+            _lib.check(L.reart_gather_points(_lib.ptr(eng._pc_trans), _lib.ptr(self._src_stored), B, N, n, _lib.ptr(self._src_pts), stream),
+                       "reart_gather_points")
+            if tb is not None:                                            # (flags and statistics are cleared by the call's set-up launch)
+                tb.resolve_mc(self._src_pts, self.tgt_pts, racers, arr, cols, self._cert, prices, ws)
+            else:
+                _lib.check(L.reart_lap_resolve_points_mc(_lib.ptr(self._src_pts), _lib.ptr(self.tgt_pts), B, n, racers, arr, _lib.ptr(cols),
+                                                         _lib.ptr(self._cert), _lib.ptr(prices), _lib.ptr(prices), _lib.ptr(ws), ws.numel(), stream),
+                           "reart_lap_resolve_points_mc")
             pairs()
+            self._cert_host.copy_(self._cert, non_blocking=True)
+            if stats:
+                self._stats_host.copy_(ws[off:off + 16 * B].view(torch.int32), non_blocking=True)
+
+        self._launches.run((eng._pc_trans.data_ptr(), eng._assign_map.data_ptr(), cols.data_ptr(), prices.data_ptr(), racers, arr, stats, id(tb)), queue)
+        st["resolve_form"] = "mc"
+        torch.cuda.current_stream().synchronize()
+        bad = (self._cert_host == 0).nonzero().flatten().tolist()
+        if tb is not None and tb.settle(self._src_pts, self.tgt_pts, st, skip=bad):
+            pairs()
+        self._launches.settle(queue, ok=not bad)
         if self.collect_stats:
             sth = self._stats_host.numpy().reshape(B, 4)
             self.stats_raw.append(sth.copy())
@@ -186,7 +196,7 @@ class AssignmentPhase:
             self.stats_log.append((int((sth[:, 2] + back).max()), float(sth[:, 2].mean()), float((sth[:, 3] >> 8).mean()),
                                    int(sth[:, 2].max()), float(back.mean())))
         fb = 0
-        for b in (self._cert_host == 0).nonzero().flatten().tolist():      # certificate did not close: exact host solve
+        for b in bad:                                                      # certificate did not close: exact host solve
             from scipy.optimize import linear_sum_assignment
 
             fb += 1
@@ -302,10 +312,15 @@ class AssignmentPhaseBatch:
         self._have = False
 
     def refresh(self):
-        if self.work_guard is not None:
+        if self.work_guard is None:
+            first = self._refresh()
+        else:
             with self.work_guard():
-                return self._refresh()
-        return self._refresh()
+                first = self._refresh()
+        due, self._capture_due = getattr(self, "_capture_due", None), None
+        if due is not None:                     # the refresh's own graph (lap.ReplayedLaunches): captured OUTSIDE the reader section
+            self._launches.settle(*due)         # of the gate -- a capture is its writer
+        return first
 
     def _refresh(self):
         from reart_amd.utils.lap import linear_sum_assignment_points
@@ -350,35 +365,46 @@ class AssignmentPhaseBatch:
             self._cert = torch.zeros((K * B,), dtype=torch.int32, device=dev)
             self._cert_host = torch.zeros((K * B,), dtype=torch.int32).pin_memory()
         racers, arr = lap._resolve_racers(K * B, n), min(lap._arr_wgs(K * B), 256)
-        stream = _lib.stream()
-        for k, ph in enumerate(self.parts):
-            N = ph.eng._assign_map.shape[1]
-            _lib.check(L.reart_gather_points(_lib.ptr(ph.eng._pc_trans), _lib.ptr(ph._src_stored), B, N, n,
-                                             _lib.ptr(self._src_all[k * B:]), stream), "reart_gather_points")
-        self._cert.zero_()
-        ws = _lib.workspace(L.reart_lap_mc_workspace_bytes(K * B, n, racers), dev)
+        need = L.reart_lap_mc_workspace_bytes(K * B, n, racers)
+        if getattr(self, "_ws", None) is None or self._ws.numel() < need:
+            self._ws = torch.empty((need,), dtype=torch.uint8, device=dev)              # owned: a captured graph keeps its address
+            self._launches = lap.ReplayedLaunches()
+        ws = self._ws
+        self._launches.guard = self.capture_guard
         cols, prices = st["cols"], st["prices"]
         tb = lap._tie_breaker(st, K * B, n, dev) if lap.CANONICAL_TIES else None
-        if tb is not None:
-            tb.resolve_mc(self._src_all, self.tgt_all, racers, arr, cols, self._cert, prices, ws)
-        else:
-            _lib.check(L.reart_lap_resolve_points_mc(_lib.ptr(self._src_all), _lib.ptr(self.tgt_all), K * B, n, racers, arr, _lib.ptr(cols),
-                                                     _lib.ptr(self._cert), _lib.ptr(prices), _lib.ptr(prices), _lib.ptr(ws), ws.numel(), stream),
-                       "reart_lap_resolve_points_mc")
-        st["resolve_form"] = "mc"
 
         def pairs():
             for k, ph in enumerate(self.parts):
                 N = ph.eng._assign_map.shape[1]
                 _lib.check(L.reart_assign_pairs(_lib.ptr(cols[k * B:]), _lib.ptr(ph._slot), _lib.ptr(ph._tgt_stored), B, N, n,
-                                                _lib.ptr(ph.eng._assign_map), stream), "reart_assign_pairs")
-        pairs()
-        self._cert_host.copy_(self._cert, non_blocking=True)
-        torch.cuda.current_stream().synchronize()
-        if tb is not None and tb.settle(self._src_all, self.tgt_all, st, skip=lambda: set((self._cert_host == 0).nonzero().flatten().tolist())):
+                                                _lib.ptr(ph.eng._assign_map), _lib.stream()), "reart_assign_pairs")
+
+        def queue():                                                      # every launch and copy of the refresh (lap.ReplayedLaunches)
+            stream = _lib.stream()
+            for k, ph in enumerate(self.parts):
+                N = ph.eng._assign_map.shape[1]
+                _lib.check(L.reart_gather_points(_lib.ptr(ph.eng._pc_trans), _lib.ptr(ph._src_stored), B, N, n,
+                                                 _lib.ptr(self._src_all[k * B:]), stream), "reart_gather_points")
+            if tb is not None:                                            # (flags are cleared by the call's set-up launch)
+                tb.resolve_mc(self._src_all, self.tgt_all, racers, arr, cols, self._cert, prices, ws)
+            else:
+                _lib.check(L.reart_lap_resolve_points_mc(_lib.ptr(self._src_all), _lib.ptr(self.tgt_all), K * B, n, racers, arr, _lib.ptr(cols),
+                                                         _lib.ptr(self._cert), _lib.ptr(prices), _lib.ptr(prices), _lib.ptr(ws), ws.numel(), stream),
+                           "reart_lap_resolve_points_mc")
             pairs()
+            self._cert_host.copy_(self._cert, non_blocking=True)
+
+        key = tuple(ph.eng._pc_trans.data_ptr() for ph in self.parts) + tuple(ph.eng._assign_map.data_ptr() for ph in self.parts)
+        self._launches.run(key + (cols.data_ptr(), prices.data_ptr(), racers, arr, id(tb)), queue)
+        st["resolve_form"] = "mc"
+        torch.cuda.current_stream().synchronize()
+        bad = (self._cert_host == 0).nonzero().flatten().tolist()
+        if tb is not None and tb.settle(self._src_all, self.tgt_all, st, skip=bad):
+            pairs()
+        self._capture_due = (queue, not bad)
         fb = 0
-        for b in (self._cert_host == 0).nonzero().flatten().tolist():
+        for b in bad:
             from scipy.optimize import linear_sum_assignment
 
             fb += 1

@@ -2,6 +2,7 @@
 utils/model_utils.py:85-103): ``[linear_sum_assignment(c) for c in cost]`` / ``parallel_lap(cost, nproc)``
 on the GPU (``reart_lap_auction``: epsilon-scaling auction + exact dual certificate).  A matrix whose
 certificate does not close is solved with scipy on the host, so the result is always an optimal assignment."""
+import contextlib
 import os
 
 import numpy as np
@@ -533,6 +534,41 @@ def spatial_order(pts):
     return torch.argsort(code, dim=1, stable=True)
 
 
+class ReplayedLaunches:
+    """The launches of one refresh, queued eagerly until the same ``key`` (every address and launch parameter the closure
+    uses) has come ``after`` times in a row, then captured ONCE into a graph and replayed.  A refresh is ~18 launches (passes,
+    set-up, tighten, row reduction, trees, backward growth, searches, certificate, tie check, the copies of the flags), each too
+    short to hide the ~15 us between two eagerly queued kernels: a quarter of a millisecond of a 1.3 ms solve
+    (profiles/r06_solve_spans_nao_projection.txt).  Same kernels, same arguments.  REART_RESOLVE_GRAPH=0: always eager.
+    ``run(key, fn)`` queues or replays; after the caller's own synchronisation ``settle(fn, ok)`` captures when due -- a
+    capture queues nothing, so the state is as the eager refresh left it (``ok`` False -- a host fallback touched the
+    state -- puts the capture off).  ``guard``: a context-manager factory entered around the capture (the sweep's gate)."""
+
+    ENABLED = os.environ.get("REART_RESOLVE_GRAPH", "1") != "0"
+
+    def __init__(self, after=2):
+        self.after, self.key, self.graph, self.seen, self.replays, self.guard = after, None, None, 0, 0, None
+
+    def run(self, key, fn):
+        if key != self.key:
+            self.key, self.graph, self.seen = key, None, 0
+        if self.graph is not None:
+            self.graph.replay()
+            self.replays += 1
+        else:
+            fn()
+            self.seen += 1
+
+    def settle(self, fn, ok=True):
+        if not self.ENABLED or self.graph is not None or self.seen < self.after or not ok:
+            return
+        with (self.guard() if self.guard is not None else contextlib.nullcontext()):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                fn()
+        self.graph = g
+
+
 class InPlaceResolve:
     """The re-solve of a loop that keeps its problems on the device (run_robot.py:164-187 with the pairs fed straight back to
     the GPU): ``state["cols"]`` (int32 [B,n]) and ``state["prices"]`` (f64 [B,n]) of an earlier solve are re-solved IN PLACE
@@ -546,6 +582,9 @@ class InPlaceResolve:
         self.cert = torch.zeros((B,), dtype=torch.int32, device=device)
         self.cert_host = torch.zeros((B,), dtype=torch.int32).pin_memory()
         self.stats_host = torch.zeros((4 * B,), dtype=torch.int32).pin_memory()
+        self._ws = None                      # owned: a captured graph keeps its address
+        self.launches = ReplayedLaunches()
+        self._event = self._pending = None
 
     @staticmethod
     def usable(state, B, n):
@@ -553,37 +592,64 @@ class InPlaceResolve:
                 and state.get("prices") is not None and state["cols"].dtype == torch.int32 and tuple(state["cols"].shape) == (B, n)
                 and tuple(state["prices"].shape) == (B, n))
 
-    def __call__(self, src, tgt, state, stats=False):
-        """-> (host fallbacks, [B,4] int32 numpy statistics as the kernel wrote them or None)"""
+    def _queue(self, src, tgt, cols, prices, racers, arr, stats, tb):
+        """Every launch and copy of one refresh on the current stream (no synchronisation)."""
         L, B, n = _lib.lib(), self.B, self.n
-        racers, arr = _resolve_racers(B, n), min(_arr_wgs(B), 256)
-        stream = _lib.stream()
-        self.cert.zero_()
-        ws = _lib.workspace(L.reart_lap_mc_workspace_bytes(B, n, racers), self.device)
-        cols, prices = state["cols"], state["prices"]
+        ws = self._ws
         off = ((8 * B * n + 255) // 256) * 256                            # the solver's statistics: [B][4] ints behind the potentials
-        if stats:
-            ws[off:off + 16 * B].zero_()
-        tb = _tie_breaker(state, B, n, self.device) if CANONICAL_TIES else None      # --deterministic: the tied problems, with the solve
+        # (the flags and the statistics start defined inside the call: its set-up launch clears them)
         if tb is not None:
             tb.resolve_mc(src, tgt, racers, arr, cols, self.cert, prices, ws)
         else:
             _lib.check(L.reart_lap_resolve_points_mc(_lib.ptr(src), _lib.ptr(tgt), B, n, racers, arr, _lib.ptr(cols), _lib.ptr(self.cert),
-                                                     _lib.ptr(prices), _lib.ptr(prices), _lib.ptr(ws), ws.numel(), stream),
+                                                     _lib.ptr(prices), _lib.ptr(prices), _lib.ptr(ws), ws.numel(), _lib.stream()),
                        "reart_lap_resolve_points_mc")
-        state["resolve_form"] = "mc"
         self.cert_host.copy_(self.cert, non_blocking=True)
         if stats:
             self.stats_host.copy_(ws[off:off + 16 * B].view(torch.int32), non_blocking=True)
-        torch.cuda.current_stream().synchronize()
-        fb = 0
+
+    def begin(self, src, tgt, state, stats=False):
+        """Queue the refresh on the current stream and record an event behind it; nothing waits.  The caller may queue more
+        work that READS ``state["cols"]`` behind it before ``finish`` -- and must queue that work again if ``finish`` says the
+        columns changed on the host (a tied or an uncertified problem: about one refresh in a thousand)."""
+        L, B, n = _lib.lib(), self.B, self.n
+        racers, arr = _resolve_racers(B, n), min(_arr_wgs(B), 256)
+        need = L.reart_lap_mc_workspace_bytes(B, n, racers)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty((need,), dtype=torch.uint8, device=self.device)
+        cols, prices = state["cols"], state["prices"]
+        tb = _tie_breaker(state, B, n, self.device) if CANONICAL_TIES else None      # --deterministic: the tied problems, with the solve
+        key = (src.data_ptr(), tgt.data_ptr(), cols.data_ptr(), prices.data_ptr(), self._ws.data_ptr(), racers, arr, bool(stats), id(tb))
+        queue = lambda: self._queue(src, tgt, cols, prices, racers, arr, stats, tb)
+        self.launches.run(key, queue)
+        state["resolve_form"] = "mc"
+        if self._event is None:
+            self._event = torch.cuda.Event()
+        self._event.record()
+        self._pending = (src, tgt, state, stats, tb, queue)
+
+    def finish(self):
+        """Wait for the refresh queued by ``begin`` (its event, not the stream) and settle it on the host.
+        -> (host fallbacks, [B,4] int32 numpy statistics as the kernel wrote them or None, columns changed on the host)"""
+        (src, tgt, state, stats, tb, queue), self._pending = self._pending, None
+        B = self.B
+        self._event.synchronize()
+        fb, changed = 0, 0
         bad = (self.cert_host == 0).nonzero().flatten().tolist()
         if tb is not None:
-            tb.settle(src, tgt, state, skip=bad)
+            changed = tb.settle(src, tgt, state, skip=bad)
+        raw = self.stats_host.numpy().reshape(B, 4).copy() if stats else None
+        self.launches.settle(queue, ok=not bad)
         for b in bad:                                                     # certificate did not close: exact host solve
             from scipy.optimize import linear_sum_assignment
 
             fb += 1
             host = linear_sum_assignment(cdist(src[b:b + 1], tgt[b:b + 1])[0].cpu().numpy())[1]
-            _forget_uncertified(state, cols, b, host)
-        return fb, (self.stats_host.numpy().reshape(B, 4).copy() if stats else None)
+            _forget_uncertified(state, state["cols"], b, host)
+        return fb, raw, bool(changed or fb)
+
+    def __call__(self, src, tgt, state, stats=False):
+        """-> (host fallbacks, [B,4] int32 numpy statistics as the kernel wrote them or None)"""
+        self.begin(src, tgt, state, stats)
+        fb, raw, _ = self.finish()
+        return fb, raw

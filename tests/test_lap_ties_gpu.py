@@ -242,3 +242,41 @@ def test_massively_tied_clouds_do_not_stall_the_host(dev):
         for b, (r, c) in enumerate(res):
             assert sorted(c.tolist()) == list(range(n))
             assert abs(float(cost[b][r, c].astype(np.float64).sum()) - float(cost[b][ref[b][0], ref[b][1]].astype(np.float64).sum())) <= 1e-9
+
+
+def test_a_refresh_replays_from_a_graph_and_clears_its_own_flags(dev):
+    """lap.InPlaceResolve on the same buffers: the third refresh on replays a captured graph (lap.ReplayedLaunches) -- the same
+    optimum as scipy on every one, with the flags, the statistics and the racers' meeting point pre-filled with garbage (the
+    call's set-up launch defines them: no fill launches in front of a refresh)."""
+    from scipy.optimize import linear_sum_assignment
+
+    from reart_amd.utils import lap
+
+    B, n = 3, 1024
+    rng = np.random.default_rng(11)
+    src_h, tgt_h = _problems(dev, B, n, seed=9)
+    src, tgt = torch.from_numpy(src_h).to(dev), torch.from_numpy(tgt_h).to(dev)
+    for det in (True, False):
+        old = lap.CANONICAL_TIES
+        lap.CANONICAL_TIES = det
+        try:
+            state = {}
+            lap.linear_sum_assignment_points(src, tgt, state, device_cols=True)
+            assert lap.InPlaceResolve.usable(state, B, n)
+            solve = lap.InPlaceResolve(B, n, dev)
+            for it in range(6):
+                src.add_(torch.from_numpy(rng.normal(scale=2e-3, size=(B, n, 3)).astype(np.float32)).to(dev))      # in place: same address
+                solve.cert.fill_(7)
+                if solve._ws is not None:
+                    solve._ws.fill_(0x5a)
+                fb, raw = solve(src, tgt, state, stats=True)
+                assert fb == 0 and solve.cert_host.tolist() == [1] * B
+                assert (raw[:, 3] & 0xff).tolist() == [1] * B and (raw[:, 2] >= 0).all() and (raw[:, 2] < 10 * n).all()
+                cost = lap.cdist(src, tgt).cpu().numpy().astype(np.float64)
+                for b in range(B):
+                    want = cost[b][linear_sum_assignment(cost[b])].sum()
+                    got = cost[b][np.arange(n), state["cols"][b].cpu().numpy()].sum()
+                    assert abs(got - want) <= n * cost[b].max() * 1e-13 * 4, (det, it, b, got - want)
+            assert solve.launches.replays == (4 if lap.ReplayedLaunches.ENABLED else 0)
+        finally:
+            lap.CANONICAL_TIES = old

@@ -177,3 +177,32 @@ def test_adam_step_matches_torch(dev):
         _lib.check(_lib.lib().reart_adam_step(_lib.ptr(p), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), 777, step, 1e-2,
                                               0.9, 0.999, 1e-8, _lib.stream()), "adam")
         np.testing.assert_allclose(p.cpu().numpy(), pt_.detach().cpu().numpy(), rtol=0, atol=3e-7)
+
+
+def test_adam_step_multi_is_the_single_step_per_tensor(dev):
+    """reart_adam_step_multi (one launch for the kinematic model's parameter tensors, run_robot.py:145-151) against
+    reart_adam_step on each tensor: bit for bit, sizes on both sides of a workgroup, different learning rates."""
+    import ctypes
+
+    from reart_amd import _lib
+
+    rng = np.random.default_rng(1)
+    sizes, lrs = [19 * 7, 1, 256, 1000, 6 * 19], [1e-2, 1e-3, 1e-2, 5e-3, 1e-2]
+    ps = [t(rng.normal(size=n).astype(np.float32), dev) for n in sizes]
+    qs = [p.clone() for p in ps]
+    ms, vs = [torch.zeros_like(p) for p in ps], [torch.zeros_like(p) for p in ps]
+    ms2, vs2 = [torch.zeros_like(p) for p in ps], [torch.zeros_like(p) for p in ps]
+    k = len(ps)
+    vp = ctypes.c_void_p * k
+    for step in range(1, 5):
+        gs = [t(rng.normal(size=n).astype(np.float32), dev) for n in sizes]
+        for p, g, m, v, n, lr in zip(ps, gs, ms, vs, sizes, lrs):
+            _lib.check(_lib.lib().reart_adam_step(_lib.ptr(p), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), n, step, lr, 0.9, 0.999, 1e-8,
+                                                  _lib.stream()), "adam")
+        rc = _lib.lib().reart_adam_step_multi(k, vp(*[q.data_ptr() for q in qs]), vp(*[g.data_ptr() for g in gs]),
+                                              vp(*[m.data_ptr() for m in ms2]), vp(*[v.data_ptr() for v in vs2]),
+                                              (ctypes.c_int * k)(*sizes), (ctypes.c_float * k)(*lrs), step, 0.9, 0.999, 1e-8, _lib.stream())
+        _lib.check(rc, "adam multi")
+        for p, q, m, m2, v, v2 in zip(ps, qs, ms, ms2, vs, vs2):
+            assert torch.equal(p, q) and torch.equal(m, m2) and torch.equal(v, v2)
+    assert _lib.lib().reart_adam_step_multi(9, None, None, None, None, None, None, 1, 0.9, 0.999, 1e-8, _lib.stream()) != 0
