@@ -632,6 +632,10 @@ int reart_lap_resolve_points_mc_ties(const float *src, const float *tgt, int B, 
  *     tgt_index[b][col4row[b][slot_of_point[p]]].  col4row [B,n], slot_of_point [N] (sample slot of canonical point p or -1),
  *     tgt_index [B,n] (index of the r-th sampled target point in frame b's cloud), assign_map [B,N] (reart_relax_buffers). */
 int reart_gather_points(const float *pc, const int32_t *index, int B, int N, int n, float *out, void *stream);
+/*   reart_publish_words: host_out = a[0..na) | b[0..nb) | c[0..nc) (int32 words in device memory; b, c may be empty), written by one
+ *     launch into PINNED host memory (`host_out`: the pointer hipHostMalloc / torch's pin_memory returned) -- the certificate
+ *     flags, tie flags and statistics the host reads after a refresh, without a copy launch each. */
+int reart_publish_words(const int32_t *a, int na, const int32_t *b, int nb, const int32_t *c, int nc, int32_t *host_out, void *stream);
 int reart_assign_pairs(const int32_t *col4row, const int32_t *slot_of_point, const int32_t *tgt_index, int B, int N, int n,
                        int32_t *assign_map, void *stream);
 

@@ -79,6 +79,7 @@ PROTOTYPES = {
     "reart_lap_mc_workspace_bytes": (c_size_t, [c_int] * 3),
     "reart_lap_resolve_points_mc": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, c_size_t, P]),
     "reart_gather_points": (c_int, [P, P, c_int, c_int, c_int, P, P]),
+    "reart_publish_words": (c_int, [P, c_int, P, c_int, P, c_int, P, P]),
     "reart_assign_pairs": (c_int, [P, P, P, c_int, c_int, c_int, P, P]),
     "reart_lap_ties": (c_int, [P, P, c_int, c_int, P, P, P, P, P, c_int, P]),
     "reart_lap_resolve_points_mc_ties": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, c_int, P, c_size_t, P]),

@@ -45,3 +45,21 @@ extern "C" int reart_assign_pairs(const int32_t *col4row, const int32_t *slot_of
     REART_CHECK_LAUNCH();
     return REART_OK;
 }
+
+// The words a refresh's host waits for -- certificate flags, tie flags, the solver's statistics -- written by ONE launch straight
+// into pinned host memory (the pointer hipHostMalloc returned is valid on the device), in the order a | b | c: three device-to-
+// host copies were three launches of ~5 us each at the end of every refresh, behind which the host's wake-up waits.
+__global__ __launch_bounds__(256) void publish_words_kernel(const int32_t *__restrict__ a, int na, const int32_t *__restrict__ b, int nb,
+                                                            const int32_t *__restrict__ c, int nc, int32_t *__restrict__ out) {
+    for (int i = threadIdx.x; i < na + nb + nc; i += 256)
+        out[i] = i < na ? a[i] : (i < na + nb ? b[i - na] : c[i - na - nb]);
+}
+
+extern "C" int reart_publish_words(const int32_t *a, int na, const int32_t *b, int nb, const int32_t *c, int nc, int32_t *host_out,
+                                   void *stream) {
+    if (na < 0 || nb < 0 || nc < 0 || (na && !a) || (nb && !b) || (nc && !c) || !host_out) return REART_ERR_INVALID_ARG;
+    if (na + nb + nc == 0) return REART_OK;
+    hipLaunchKernelGGL(publish_words_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a, na, b, nb, c, nc, host_out);
+    REART_CHECK_LAUNCH();
+    return REART_OK;
+}

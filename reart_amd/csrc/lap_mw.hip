@@ -989,6 +989,7 @@ __global__ __launch_bounds__(256) void lap_mc_trees_kernel(JvArgs a) {
 // for every problem: with 10-20 rows left (the hold-out sequences of tools/holdout.sh, the recipe) a smaller forest loses 6-9 %.
 #define MW_FOREST_FEW 4
 #define MW_FOREST_PER 32
+#define MW_FOREST_W0 1e-8     // first bucket width of the growth, as a fraction of the cost scale
 #define MW_FOREST_R 512       // measured 0 / 48 / 128 / 256 / 512 / 1024: recipe 3.57 / 3.58 / 3.51 / 3.37 / 3.33 / 3.70 ms per refresh, projection 78.8 / 77.9 / 80.4 / 82.4 / 86.7 / 86.8 it/s
 template <int CPL>
 __global__ __launch_bounds__(512) void lap_mc_forest_kernel(JvArgs a) {
@@ -1053,12 +1054,13 @@ __global__ __launch_bounds__(512) void lap_mc_forest_kernel(JvArgs a) {
     // runs in BUCKETS like them: all outside rows with a label below (closest label) + width join together, label-correcting
     // rounds inside the bucket (a member whose label improves offers its column again), one barrier per round.  One row per
     // round and arg-min, the first form, took 512 x 1.15 us of every re-solve.
-    __shared__ float s_fx[2][MW_BK], s_fy[2][MW_BK], s_fz[2][MW_BK];
+    __shared__ __attribute__((aligned(16))) float s_f4[2][MW_BK / 2][8];      // entries in PAIRS: x0 x1 y0 y1 z0 z1 g0 g1 (the searches' layout and filter)
     __shared__ double s_fq[2][MW_BK], s_cmax[2][NW], s_cmin[2][NW];
     __shared__ int s_fj[2][MW_BK], s_fcnt[3], s_cn[2][NW];
     if (tid == 0) { s_fcnt[0] = 0; s_fcnt[1] = 0; s_fcnt[2] = 0; }
-    const double fdelta = a.scale[b] * 1e-12;
-    double bw = a.scale[b] * MW_BUCKET_W0, L[CPT];
+    const double fdelta = a.scale[b] * 1e-12, pref = gprice[0];
+    double bw = a.scale[b] * MW_FOREST_W0, L[CPT];
+    float rk[CPT];
     int brot = 0, bpar = 0, seq = 0, joined = 0;
     unsigned pend = 0u;
     double lo = INFINITY;
@@ -1066,6 +1068,9 @@ __global__ __launch_bounds__(512) void lap_mc_forest_kernel(JvArgs a) {
     for (int k = 0; k < CPT; ++k) {
         L[k] = ((out >> k) & 1u) ? M[k] - u[k] : INFINITY;
         if (!((out >> k) & 1u)) M[k] = -INFINITY;            // never a candidate of the relaxations' filter
+        // (M - pref)(1 + 2^-20) rounded UP to fp32, rewritten whenever M moves; potentials RELATIVE to one of the problem's own: they
+        // drift over a run's refreshes to many times the cost scale, and an fp32 bound of the raw value would let every pair pass
+        rk[k] = ((out >> k) & 1u) ? mw_f32_up((M[k] - pref) * MW_FILTER_K) : -INFINITY;
         lo = fmin(lo, L[k]);
     }
     lo = lap_wave_min_d(lo);
@@ -1094,8 +1099,11 @@ __global__ __launch_bounds__(512) void lap_mc_forest_kernel(JvArgs a) {
                     const int at = at0 + __builtin_popcountll(m & ((1ull << lane) - 1ull));
                     if (want && at < MW_BK) {
                         const int j = tid + k * BS;
-                        s_fx[buf][at] = ltx[j]; s_fy[buf][at] = lty[j]; s_fz[buf][at] = ltz[j];
-                        s_fq[buf][at] = q[j] + fmax(L[k], off); s_fj[buf][at] = j;
+                        const double tq = q[j] + fmax(L[k], off);
+                        float *rec = &s_f4[buf][at >> 1][at & 1];
+                        rec[0] = ltx[j]; rec[2] = lty[j]; rec[4] = ltz[j];
+                        rec[6] = mw_f32_up((fdelta - (tq - pref)) * MW_FILTER_K);
+                        s_fq[buf][at] = tq; s_fj[buf][at] = j;
                         pend &= ~(1u << k);
                     }
                 }
@@ -1107,24 +1115,45 @@ __global__ __launch_bounds__(512) void lap_mc_forest_kernel(JvArgs a) {
             if (ne == 0) break;
             ne = ne < MW_BK ? ne : MW_BK;
             ++seq;
-            for (int e = 0; e < ne; ++e) {
-                const float tx = s_fx[buf][e], ty = s_fy[buf][e], tz = s_fz[buf][e];
-                const double tq = s_fq[buf][e];
-                const int js = s_fj[buf][e];
+            // v = c + tq improves M iff c < M - tq =: T.  The searches' filter (lap_jvmw_kernel, bucket rounds) mirrored: all fp32, T from
+            // two UPPER bounds (the row's M, the entry's delta - tq, both times 1 + 2^-20 and rounded up), the squared distance as an
+            // estimate with fused multiply-adds, T |T| for T > 0 && T^2, two ENTRIES per packed operand; the pairs that pass -- a
+            // superset of those that improve -- take the exact expression in the entries' order, so the result is bit for bit the
+            // unfiltered one.  (The first form -- per pair a double-precision T, a conversion and two double products -- was ~16
+            // instructions per pair against ~6: the kernel is bound by the instructions a compute unit issues.)
+            for (int e = 0; e < ne; e += 2) {
+                const mw_f4 Exy = *(const mw_f4 *)&s_f4[buf][e >> 1][0];
+                mw_f4 Ezg = *(const mw_f4 *)&s_f4[buf][e >> 1][4];
+                if (e + 1 >= ne) Ezg.w = -INFINITY;            // (odd count: the record's second half holds an older round's entry)
+                const jv_f2 ex = {Exy.x, Exy.y}, ey = {Exy.z, Exy.w}, ez = {Ezg.x, Ezg.y}, eg = {Ezg.z, Ezg.w};
+                float s0[CPT], s1[CPT], Q0[CPT], Q1[CPT];
 #pragma unroll
                 for (int k = 0; k < CPT; ++k) {
-                    // v = c + tq improves M iff c < M - tq: the filter of the searches' bucket rounds (square root skipped
-                    // when the squared distance exceeds the bound by more than every rounding on the way)
-                    const float sq = reart_sqdist3(sx[k], sy[k], sz[k], tx, ty, tz);
-                    const double T = (M[k] - tq) + fdelta, Tq = T * 1.000000238418579;
-                    if (T > 0.0 && (double)sq <= Tq * Tq) {
-                        const double v = (double)mw_sqrt(sq) + tq;
-                        if (v < M[k]) {
-                            const double ln = v - u[k];
-                            // a member (or a row this brings into the bucket) whose join shift got smaller offers its column again
-                            if ((ln < hi || ln == lo) && fmax(ln, off) < fmax(L[k], off)) pend |= 1u << k;
-                            M[k] = v; Mt[k] = js; L[k] = ln;
-                        }
+                    const jv_f2 d2 = mw_sq_estimate(ex - sx[k], ey - sy[k], ez - sz[k]);
+                    const jv_f2 T = eg + rk[k];
+                    s0[k] = d2.x; s1[k] = d2.y;
+                    Q0[k] = T.x * fabsf(T.x); Q1[k] = T.y * fabsf(T.y);
+                }
+                bool any = false;
+#pragma unroll
+                for (int k = 0; k < CPT; ++k) any |= (s0[k] <= Q0[k]) | (s1[k] <= Q1[k]);
+                if (any) {
+#pragma unroll
+                    for (int w = 0; w < 2; ++w) {
+                        const float tx = w ? ex.y : ex.x, ty = w ? ey.y : ey.x, tz = w ? ez.y : ez.x;
+#pragma unroll
+                        for (int k = 0; k < CPT; ++k)
+                            if (w ? s1[k] <= Q1[k] : s0[k] <= Q0[k]) {
+                                const double tq = s_fq[buf][e + w];
+                                const double v = (double)mw_sqrt(reart_sqdist3(sx[k], sy[k], sz[k], tx, ty, tz)) + tq;
+                                if (v < M[k]) {
+                                    const double ln = v - u[k];
+                                    // a member (or a row this brings into the bucket) whose join shift got smaller offers its column again
+                                    if ((ln < hi || ln == lo) && fmax(ln, off) < fmax(L[k], off)) pend |= 1u << k;
+                                    M[k] = v; Mt[k] = s_fj[buf][e + w]; L[k] = ln;
+                                    rk[k] = mw_f32_up((v - pref) * MW_FILTER_K);
+                                }
+                            }
                     }
                 }
             }
@@ -1142,7 +1171,7 @@ __global__ __launch_bounds__(512) void lap_mc_forest_kernel(JvArgs a) {
                 out &= ~(1u << k);
                 gtpar[j] = Mt[k]; jp[j] = Mt[k]; oj[j] = o;
                 flist[atomicAdd(&s_n, 1)] = j;
-                M[k] = -INFINITY; L[k] = INFINITY;
+                M[k] = -INFINITY; L[k] = INFINITY; rk[k] = -INFINITY;
                 mxo = fmax(mxo, o);
                 ++nnew;
             } else mn = fmin(mn, L[k]);

@@ -318,14 +318,20 @@ class TieBreaker:
                    "reart_lap_ties")
         self.tie_host.copy_(self.tie, non_blocking=True)
 
-    def resolve_mc(self, src, tgt, racers, arr, cols, cert, prices, ws):
+    def resolve_mc(self, src, tgt, racers, arr, cols, cert, prices, ws, copy=True):
         """reart_lap_resolve_points_mc_ties: the in-place re-solve with the tie check behind it -- the tight pairs come out of
-        the solve's own certificate pass (no second scan of the costs); queues the copy of the flags like ``launch``."""
+        the solve's own certificate pass (no second scan of the costs); queues the copy of the flags like ``launch``
+        (``copy=False``: the caller brings ``tie`` to the host itself and hands it over with ``flags_from``)."""
         _lib.check(_lib.lib().reart_lap_resolve_points_mc_ties(_lib.ptr(src), _lib.ptr(tgt), self.B, self.n, racers, arr, _lib.ptr(cols),
                                                                _lib.ptr(cert), _lib.ptr(prices), _lib.ptr(prices), _lib.ptr(self.tie),
                                                                _lib.ptr(self.edges), _lib.ptr(self.n_edges), self.K, _lib.ptr(ws),
                                                                ws.numel(), _lib.stream()), "reart_lap_resolve_points_mc_ties")
-        self.tie_host.copy_(self.tie, non_blocking=True)
+        if copy:
+            self.tie_host.copy_(self.tie, non_blocking=True)
+
+    def flags_from(self, words):
+        """The B tie flags as the caller read them (a numpy int32 view of its own pinned buffer)."""
+        self._tie_np[:] = words
 
     def pairs_of(self, b):
         """[E,2] int64 (row, column) of problem b's tight pairs as the kernels listed them (rows with more than K: the first K)."""
@@ -580,8 +586,11 @@ class InPlaceResolve:
     def __init__(self, B, n, device):
         self.B, self.n, self.device = B, n, device
         self.cert = torch.zeros((B,), dtype=torch.int32, device=device)
-        self.cert_host = torch.zeros((B,), dtype=torch.int32).pin_memory()
-        self.stats_host = torch.zeros((4 * B,), dtype=torch.int32).pin_memory()
+        # what the host reads after a refresh, in ONE pinned buffer that the refresh's last launch writes (reart_publish_words):
+        # certificate flags | tie flags | the statistics words
+        self.words_host = torch.zeros((6 * B,), dtype=torch.int32).pin_memory()
+        self._words_np = self.words_host.numpy()
+        self.cert_host, self.stats_host = self.words_host[:B], self.words_host[2 * B:]
         self._ws = None                      # owned: a captured graph keeps its address
         self.launches = ReplayedLaunches()
         self._event = self._pending = None
@@ -599,14 +608,15 @@ class InPlaceResolve:
         off = ((8 * B * n + 255) // 256) * 256                            # the solver's statistics: [B][4] ints behind the potentials
         # (the flags and the statistics start defined inside the call: its set-up launch clears them)
         if tb is not None:
-            tb.resolve_mc(src, tgt, racers, arr, cols, self.cert, prices, ws)
+            tb.resolve_mc(src, tgt, racers, arr, cols, self.cert, prices, ws, copy=False)
         else:
             _lib.check(L.reart_lap_resolve_points_mc(_lib.ptr(src), _lib.ptr(tgt), B, n, racers, arr, _lib.ptr(cols), _lib.ptr(self.cert),
                                                      _lib.ptr(prices), _lib.ptr(prices), _lib.ptr(ws), ws.numel(), _lib.stream()),
                        "reart_lap_resolve_points_mc")
-        self.cert_host.copy_(self.cert, non_blocking=True)
-        if stats:
-            self.stats_host.copy_(ws[off:off + 16 * B].view(torch.int32), non_blocking=True)
+        # (without a tie check the middle words repeat the certificate flags: the layout stays put)
+        _lib.check(L.reart_publish_words(_lib.ptr(self.cert), B, _lib.ptr(tb.tie if tb is not None else self.cert), B,
+                                         _lib.c_void_p(ws.data_ptr() + off) if stats else None, 4 * B if stats else 0,
+                                         _lib.c_void_p(self.words_host.data_ptr()), _lib.stream()), "reart_publish_words")
 
     def begin(self, src, tgt, state, stats=False):
         """Queue the refresh on the current stream and record an event behind it; nothing waits.  The caller may queue more
@@ -635,10 +645,12 @@ class InPlaceResolve:
         B = self.B
         self._event.synchronize()
         fb, changed = 0, 0
-        bad = (self.cert_host == 0).nonzero().flatten().tolist()
+        words = self._words_np
+        bad = np.nonzero(words[:B] == 0)[0].tolist()
         if tb is not None:
+            tb.flags_from(words[B:2 * B])
             changed = tb.settle(src, tgt, state, skip=bad)
-        raw = self.stats_host.numpy().reshape(B, 4).copy() if stats else None
+        raw = words[2 * B:].reshape(B, 4).copy() if stats else None
         self.launches.settle(queue, ok=not bad)
         for b in bad:                                                     # certificate did not close: exact host solve
             from scipy.optimize import linear_sum_assignment
