@@ -929,11 +929,16 @@ __global__ __launch_bounds__(256) void lap_mc_trees_kernel(JvArgs a) {
         double off = 0.0, mq = 0.0;
         int mcol = -1, nm = 1;
         unsigned mine = 0u;
-        if (lane == 0) { mcol = jh; mq = ld_d(price + jh); }
+        // lane m keeps the tree's m-th column: its index, its q and its POINT (a round is then one round trip to memory -- the
+        // claim, with the joining column's price and point fetched alongside it -- instead of four one after the other: the
+        // claim, the price, the point for the next scan, the members' points for the parent; 8 -> 5 us per round)
+        float mtx = 0.f, mty = 0.f, mtz = 0.f;
+        if (lane == 0) { mcol = jh; mq = ld_d(price + jh); mtx = T_[3 * jh]; mty = T_[3 * jh + 1]; mtz = T_[3 * jh + 2]; }
         for (int r = 0; r < MW_TREE_K; ++r) {
-            const int tcol = __builtin_amdgcn_readlane(mcol, nm - 1);
             const double tq = bcast_d(mq, nm - 1);
-            const float tx = T_[3 * tcol], ty = T_[3 * tcol + 1], tz = T_[3 * tcol + 2];
+            const float tx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mtx), nm - 1));
+            const float ty = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mty), nm - 1));
+            const float tz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mtz), nm - 1));
             double best = INFINITY;
             int bk = 0x7fffffff;
 #pragma unroll
@@ -947,6 +952,10 @@ __global__ __launch_bounds__(256) void lap_mc_trees_kernel(JvArgs a) {
             if (!(best < INFINITY)) break;
             off += best > 0.0 ? best : 0.0;
             bk = mw_uniform(bk);
+            // (issued before the claim's answer is waited for: an unclaimed column's price is written by nobody -- a tree writes its
+            // own columns only, when it is done -- so the value is the one a read behind a successful claim would return)
+            const double pnew = ld_d(price + bk);
+            const float nbx = T_[3 * bk], nby = T_[3 * bk + 1], nbz = T_[3 * bk + 2];
             int ok = 0;
             if (lane == 0) {
                 int seen = -1;
@@ -964,13 +973,12 @@ __global__ __launch_bounds__(256) void lap_mc_trees_kernel(JvArgs a) {
             double pv = INFINITY;
             int pm = 0x7fffffff;
             if (lane < nm) {
-                pv = (double)mw_sqrt(reart_sqdist3(rx, ry, rz, T_[3 * mcol], T_[3 * mcol + 1], T_[3 * mcol + 2])) + mq;
+                pv = (double)mw_sqrt(reart_sqdist3(rx, ry, rz, mtx, mty, mtz)) + mq;
                 pm = mcol;
             }
             lap_wave_argmin_fast(pv, pm);
-            const double pnew = ld_d(price + bk);
             if (lane == 0) tpar[bk] = pm;
-            if (lane == nm) { mcol = bk; mq = pnew + off; }
+            if (lane == nm) { mcol = bk; mq = pnew + off; mtx = nbx; mty = nby; mtz = nbz; }
             if (lane == (bk & 63)) mine |= 1u << (bk >> 6);
             ++nm;
         }

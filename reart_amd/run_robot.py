@@ -140,8 +140,11 @@ class AssignmentPhase:
         self._src_stored, self._slot, self._tgt_stored = src.int().contiguous(), slot, tgt.int().contiguous()
         self._src_pts = torch.empty((self.B, self.n, 3), device=dev)
         self._cert = torch.zeros((self.B,), dtype=torch.int32, device=dev)
-        self._cert_host = torch.zeros((self.B,), dtype=torch.int32).pin_memory()
-        self._stats_host = torch.zeros((4 * self.B,), dtype=torch.int32).pin_memory()
+        # what the host reads after a refresh -- certificate flags | tie flags | statistics -- in one pinned buffer, written by the
+        # refresh's last launch (reart_publish_words)
+        self._words_host = torch.zeros((6 * self.B,), dtype=torch.int32).pin_memory()
+        self._words_np = self._words_host.numpy()
+        self._cert_host, self._stats_host = self._words_host[:self.B], self._words_host[2 * self.B:]
 
     def _refresh_on_device(self):
         """A refresh after the first, without a host-side tensor operation: gather (reart_gather_points) -> re-solve from the
@@ -172,22 +175,24 @@ class AssignmentPhase:
             _lib.check(L.reart_gather_points(_lib.ptr(eng._pc_trans), _lib.ptr(self._src_stored), B, N, n, _lib.ptr(self._src_pts), stream),
                        "reart_gather_points")
             if tb is not None:                                            # (flags and statistics are cleared by the call's set-up launch)
-                tb.resolve_mc(self._src_pts, self.tgt_pts, racers, arr, cols, self._cert, prices, ws)
+                tb.resolve_mc(self._src_pts, self.tgt_pts, racers, arr, cols, self._cert, prices, ws, copy=False)
             else:
                 _lib.check(L.reart_lap_resolve_points_mc(_lib.ptr(self._src_pts), _lib.ptr(self.tgt_pts), B, n, racers, arr, _lib.ptr(cols),
                                                          _lib.ptr(self._cert), _lib.ptr(prices), _lib.ptr(prices), _lib.ptr(ws), ws.numel(), stream),
                            "reart_lap_resolve_points_mc")
             pairs()
-            self._cert_host.copy_(self._cert, non_blocking=True)
-            if stats:
-                self._stats_host.copy_(ws[off:off + 16 * B].view(torch.int32), non_blocking=True)
+            _lib.check(L.reart_publish_words(_lib.ptr(self._cert), B, _lib.ptr(tb.tie if tb is not None else self._cert), B,
+                                             _lib.c_void_p(ws.data_ptr() + off) if stats else None, 4 * B if stats else 0,
+                                             _lib.c_void_p(self._words_host.data_ptr()), stream), "reart_publish_words")
 
         self._launches.run((eng._pc_trans.data_ptr(), eng._assign_map.data_ptr(), cols.data_ptr(), prices.data_ptr(), racers, arr, stats, id(tb)), queue)
         st["resolve_form"] = "mc"
         torch.cuda.current_stream().synchronize()
-        bad = (self._cert_host == 0).nonzero().flatten().tolist()
-        if tb is not None and tb.settle(self._src_pts, self.tgt_pts, st, skip=bad):
-            pairs()
+        bad = np.nonzero(self._words_np[:B] == 0)[0].tolist()
+        if tb is not None:
+            tb.flags_from(self._words_np[B:2 * B])
+            if tb.settle(self._src_pts, self.tgt_pts, st, skip=bad):
+                pairs()
         self._launches.settle(queue, ok=not bad)
         if self.collect_stats:
             sth = self._stats_host.numpy().reshape(B, 4)
@@ -363,7 +368,9 @@ class AssignmentPhaseBatch:
                 ph._native_tables()
             self._src_all = torch.empty((K * B, n, 3), device=dev)
             self._cert = torch.zeros((K * B,), dtype=torch.int32, device=dev)
-            self._cert_host = torch.zeros((K * B,), dtype=torch.int32).pin_memory()
+            self._words_host = torch.zeros((2 * K * B,), dtype=torch.int32).pin_memory()       # certificate flags | tie flags (reart_publish_words)
+            self._words_np = self._words_host.numpy()
+            self._cert_host = self._words_host[:K * B]
         racers, arr = lap._resolve_racers(K * B, n), min(lap._arr_wgs(K * B), 256)
         need = L.reart_lap_mc_workspace_bytes(K * B, n, racers)
         if getattr(self, "_ws", None) is None or self._ws.numel() < need:
@@ -387,21 +394,24 @@ class AssignmentPhaseBatch:
                 _lib.check(L.reart_gather_points(_lib.ptr(ph.eng._pc_trans), _lib.ptr(ph._src_stored), B, N, n,
                                                  _lib.ptr(self._src_all[k * B:]), stream), "reart_gather_points")
             if tb is not None:                                            # (flags are cleared by the call's set-up launch)
-                tb.resolve_mc(self._src_all, self.tgt_all, racers, arr, cols, self._cert, prices, ws)
+                tb.resolve_mc(self._src_all, self.tgt_all, racers, arr, cols, self._cert, prices, ws, copy=False)
             else:
                 _lib.check(L.reart_lap_resolve_points_mc(_lib.ptr(self._src_all), _lib.ptr(self.tgt_all), K * B, n, racers, arr, _lib.ptr(cols),
                                                          _lib.ptr(self._cert), _lib.ptr(prices), _lib.ptr(prices), _lib.ptr(ws), ws.numel(), stream),
                            "reart_lap_resolve_points_mc")
             pairs()
-            self._cert_host.copy_(self._cert, non_blocking=True)
+            _lib.check(L.reart_publish_words(_lib.ptr(self._cert), K * B, _lib.ptr(tb.tie if tb is not None else self._cert), K * B, None, 0,
+                                             _lib.c_void_p(self._words_host.data_ptr()), stream), "reart_publish_words")
 
         key = tuple(ph.eng._pc_trans.data_ptr() for ph in self.parts) + tuple(ph.eng._assign_map.data_ptr() for ph in self.parts)
         self._launches.run(key + (cols.data_ptr(), prices.data_ptr(), racers, arr, id(tb)), queue)
         st["resolve_form"] = "mc"
         torch.cuda.current_stream().synchronize()
-        bad = (self._cert_host == 0).nonzero().flatten().tolist()
-        if tb is not None and tb.settle(self._src_all, self.tgt_all, st, skip=bad):
-            pairs()
+        bad = np.nonzero(self._words_np[:K * B] == 0)[0].tolist()
+        if tb is not None:
+            tb.flags_from(self._words_np[K * B:])
+            if tb.settle(self._src_all, self.tgt_all, st, skip=bad):
+                pairs()
         self._capture_due = (queue, not bad)
         fb = 0
         for b in bad:
