@@ -45,6 +45,18 @@ f=$(find $O/trace_projection -name "*kernel_trace.csv" | head -1)
 [ -n "$f" ] && python3 tools/kernel_window_stats.py "$f" --after-last "lap_jvmw_kernel<16" --skip 1 --match lap_ > $O/kernel_stats_nao_projection_window.csv
 [ -n "$f" ] && python3 tools/solve_spans.py "$f" --last 1490 > $O/solve_spans_nao_projection.txt
 [ -n "$f" ] && python3 tools/iteration_glue.py "$f" 1000 > $O/iteration_glue_nao_projection.txt
+# launch by launch through a refresh period: every kernel's duration and the idle time in front of it
+[ -n "$f" ] && python3 tools/solve_gaps.py "$f" --last 1400 > $O/solve_gaps_nao_projection.txt
+f=$(find $O/trace_recipe -name "*kernel_trace.csv" | head -1)
+[ -n "$f" ] && python3 tools/solve_gaps.py "$f" --last 1900 > $O/solve_gaps_nao_recipe.txt
+# 3a. per-kernel account of REPLAYED solves (dumps under tools/_states/: git-ignored, present where tools/exp_tail.py DUMP=... took them)
+for d in proj recipe; do
+  if [ -f tools/_states/r05s_$d.npz ]; then
+    ORDER=morton REPS=2 RAW_OUT=$O/raw timeout 500 rocprofv3 --kernel-trace -f csv -d $O/rk_$d -- python3 tools/replay_tail.py tools/_states/r05s_$d.npz > $O/replay_tail_$d.txt 2>&1
+    f=$(find $O/rk_$d -name "*kernel_trace.csv" | head -1)
+    [ -n "$f" ] && python3 tools/replay_kernels.py "$f" $O/raw.r05s_$d.npz > $O/replay_kernels_${d}_after.txt 2>&1
+  fi
+done
 # 3b. README.md:125 on nao, the whole run (15 000 iterations, a snapshot every 10), and the solve-by-solve account of both recipes
 timeout 900 python3 tools/run_nao.py --projection 2>/dev/null | grep -v "joint types" > $O/run_nao_projection_det_1.txt
 timeout 900 python3 tools/run_nao.py --projection 2>/dev/null | grep -v "joint types" > $O/run_nao_projection_det_2.txt
