@@ -359,6 +359,25 @@ int reart_ball_query(const float *xyz, const float *new_xyz, int B, int N, int S
                      double radius, int nsample, int cuda_mode,
                      int32_t *idx32, int64_t *idx64, void *stream);
 
+/* The channel-major operators of the reference's pybind module `pointnet2_cuda` that nothing in the reference calls
+ * (networks/pointnet_lib/src/pointnet2_api.cpp:14-25; only pointnet2_modules.py reaches them, and nothing imports it) --
+ * here so that the module is whole (reart_amd/pointnet2_cuda.py).  int32 indices, caller-allocated outputs.
+ *   reart_pn2_gather_points:       out[b][c][m] = points[b][c][idx[b][m]]; points [B,C,N], idx [B,M], out [B,C,M]
+ *       (gather_points_wrapper, sampling_gpu.cu:8-24; group_points_wrapper, group_points_gpu.cu:39-54, is the same map with
+ *       idx [B, npoints * nsample] and out [B,C,npoints,nsample]);
+ *   reart_pn2_gather_points_grad:  grad_points[b][c][idx[b][m]] += grad_out[b][c][m] (float atomics, as sampling_gpu.cu:46-63 /
+ *       group_points_gpu.cu:8-21; the caller zeroes grad_points, pointnet_lib/pointnet2_utils.py:70,231);
+ *   reart_pn2_three_interpolate:   out[b][c][n] = (w0 p[i0] + w1 p[i1]) + w2 p[i2], p = points[b][c][:]; points [B,C,M],
+ *       idx / weight [B,N,3], out [B,C,N] (interpolate_gpu.cu:149-169);
+ *   reart_pn2_three_interpolate_grad: grad_points[b][c][i_j] += grad_out[b][c][n] * w_j (interpolate_gpu.cu:192-214). */
+int reart_pn2_gather_points(const float *points, const int32_t *idx, int B, int C, int N, int M, float *out, void *stream);
+int reart_pn2_gather_points_grad(const float *grad_out, const int32_t *idx, int B, int C, int N, int M, float *grad_points,
+                                 void *stream);
+int reart_pn2_three_interpolate(const float *points, const int32_t *idx, const float *weight, int B, int C, int M, int N,
+                                float *out, void *stream);
+int reart_pn2_three_interpolate_grad(const float *grad_out, const int32_t *idx, const float *weight, int B, int C, int N, int M,
+                                     float *grad_points, void *stream);
+
 /* ------------------------------------------------------------------------ */
 /* Projection model: screw-joint forward kinematics                          */
 /* ------------------------------------------------------------------------ */

@@ -197,6 +197,56 @@ def ball_query(radius, nsample, xyz, new_xyz, cuda_mode=False, want_margin=False
     return (idx, mg) if want_margin else idx
 
 
+def pn2_gather_points(points, idx):
+    """networks/pointnet_lib/src/sampling_gpu.cu:8-24 (gather_points) and group_points_gpu.cu:39-54 (group_points: the same map
+    over idx [B,npoints,nsample]): points f32 [B,C,N], idx int [B,...] -> out[b][c][...] = points[b][c][idx[b][...]].
+    Parity unpinned: the CUDA kernels cannot run here and the reference holds no vectors for them (dead code there)."""
+    points, idx = _f(points), np.asarray(idx)
+    B, C, _ = points.shape
+    out = np.empty((B, C) + idx.shape[1:], np.float32)
+    for b in range(B):
+        out[b] = points[b][:, idx[b]]
+    return out
+
+
+def pn2_gather_points_grad(grad_out, idx, N):
+    """sampling_gpu.cu:46-63 / group_points_gpu.cu:8-21: grad_points[b][c][idx[b][...]] += grad_out[b][c][...] (the reference
+    adds with float atomics in arrival order; here in float64, rounded once: compare with a tolerance)."""
+    grad_out, idx = _f(grad_out), np.asarray(idx)
+    B, C = grad_out.shape[:2]
+    g = np.zeros((B, C, N), np.float64)
+    for b in range(B):
+        for c in range(C):
+            np.add.at(g[b, c], idx[b].reshape(-1), grad_out[b, c].reshape(-1).astype(np.float64))
+    return g.astype(np.float32)
+
+
+def pn2_three_interpolate(points, idx, weight):
+    """interpolate_gpu.cu:149-169: points f32 [B,C,M], idx int / weight f32 [B,N,3] -> out[b][c][n] = (w0 p[i0] + w1 p[i1]) +
+    w2 p[i2] in fp32 without contraction, p = points[b][c][:]."""
+    points, weight, idx = _f(points), _f(weight), np.asarray(idx)
+    B, C, _ = points.shape
+    N = idx.shape[1]
+    out = np.empty((B, C, N), np.float32)
+    for b in range(B):
+        p = points[b][:, idx[b]]                       # [C,N,3]
+        w = weight[b][None]                            # [1,N,3]
+        out[b] = (w[..., 0] * p[..., 0] + w[..., 1] * p[..., 1]) + w[..., 2] * p[..., 2]
+    return out
+
+
+def pn2_three_interpolate_grad(grad_out, idx, weight, M):
+    """interpolate_gpu.cu:192-214: grad_points[b][c][i_j] += grad_out[b][c][n] * w_j (products in fp32, the sums in float64 here)."""
+    grad_out, weight, idx = _f(grad_out), _f(weight), np.asarray(idx)
+    B, C, N = grad_out.shape
+    g = np.zeros((B, C, M), np.float64)
+    for b in range(B):
+        for c in range(C):
+            for j in range(3):
+                np.add.at(g[b, c], idx[b][:, j], (grad_out[b, c] * weight[b][:, j]).astype(np.float64))
+    return g.astype(np.float32)
+
+
 def three_nn_expanded(xyz1, xyz2):
     """networks/pointnet2_utils.py:33-55 + :327-328: the 3 smallest matmul-expanded squared distances
     (stable ascending) of every xyz1 point in xyz2 -> (dists f32 [B,N,3], idx i64 [B,N,3])."""

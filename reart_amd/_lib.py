@@ -48,6 +48,10 @@ PROTOTYPES = {
     "reart_adam_step_multi": (c_int, [c_int, P, P, P, P, P, P, c_int, c_float, c_float, c_float, P]),
     "reart_fps": (c_int, [P, c_int, c_int, c_int, P, c_int, P, P, P]),
     "reart_ball_query": (c_int, [P, P, c_int, c_int, c_int, ctypes.c_double, c_int, c_int, P, P, P]),
+    "reart_pn2_gather_points": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P]),
+    "reart_pn2_gather_points_grad": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P]),
+    "reart_pn2_three_interpolate": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P]),
+    "reart_pn2_three_interpolate_grad": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P]),
     "reart_fk_forward": (c_int, [P, P, P, c_int, P, P, P, P, c_int, c_int, P, P]),
     "reart_fk_backward_workspace_bytes": (c_size_t, [c_int] * 3),
     "reart_fk_backward": (c_int, [P, P, P, c_int, P, P, P, c_int, P, P, P, P, c_int, c_int, P, P, P, P, P, P,

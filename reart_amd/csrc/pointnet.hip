@@ -244,3 +244,87 @@ extern "C" int reart_ball_query(const float *xyz, const float *new_xyz, int B, i
     REART_CHECK_LAUNCH();
     return REART_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The channel-major gather / interpolate operators of the reference's pybind module that nothing in the reference calls
+// (networks/pointnet_lib/src/pointnet2_api.cpp:11-26; reachable only through pointnet2_modules.py, which is never imported).
+// Pure index work, bound by memory: a thread per output element, the index row read once per (batch, point) and reused
+// across channels by the cache; the backward forms accumulate with float atomics like the reference's (their sums depend on
+// the order of arrival there as here).
+//   gather:  out[b][c][m] = points[b][c][idx[b][m]]                      (sampling_gpu.cu:8-24; group_points_gpu.cu:39-54 is
+//            the same map with m = point * nsample + sample)
+//   scatter: grad_points[b][c][idx[b][m]] += grad_out[b][c][m]           (sampling_gpu.cu:46-63; group_points_gpu.cu:8-21)
+__global__ __launch_bounds__(256) void pn2_gather_kernel(const float *__restrict__ points, const int32_t *__restrict__ idx, int C, int N,
+                                                         int M, float *__restrict__ out) {
+    const int m = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
+    if (m >= M) return;
+    out[((size_t)b * C + c) * M + m] = points[((size_t)b * C + c) * N + idx[(size_t)b * M + m]];
+}
+__global__ __launch_bounds__(256) void pn2_scatter_add_kernel(const float *__restrict__ grad_out, const int32_t *__restrict__ idx, int C, int N,
+                                                              int M, float *__restrict__ grad_points) {
+    const int m = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
+    if (m >= M) return;
+    atomicAdd(grad_points + ((size_t)b * C + c) * N + idx[(size_t)b * M + m], grad_out[((size_t)b * C + c) * M + m]);
+}
+//   interpolate: out[b][c][n] = (w0 p[i0] + w1 p[i1]) + w2 p[i2]          (interpolate_gpu.cu:149-169), p = points[b][c][:]
+//   its backward: grad_points[b][c][i_j] += grad_out[b][c][n] * w_j       (interpolate_gpu.cu:192-214)
+__global__ __launch_bounds__(256) void pn2_interp_kernel(const float *__restrict__ points, const int32_t *__restrict__ idx,
+                                                         const float *__restrict__ weight, int C, int M, int N, float *__restrict__ out) {
+    const int n = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
+    if (n >= N) return;
+    const int32_t *i = idx + ((size_t)b * N + n) * 3;
+    const float *w = weight + ((size_t)b * N + n) * 3, *p = points + ((size_t)b * C + c) * M;
+    out[((size_t)b * C + c) * N + n] = (w[0] * p[i[0]] + w[1] * p[i[1]]) + w[2] * p[i[2]];
+}
+__global__ __launch_bounds__(256) void pn2_interp_grad_kernel(const float *__restrict__ grad_out, const int32_t *__restrict__ idx,
+                                                              const float *__restrict__ weight, int C, int N, int M,
+                                                              float *__restrict__ grad_points) {
+    const int n = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
+    if (n >= N) return;
+    const int32_t *i = idx + ((size_t)b * N + n) * 3;
+    const float *w = weight + ((size_t)b * N + n) * 3;
+    const float g = grad_out[((size_t)b * C + c) * N + n];
+    float *gp = grad_points + ((size_t)b * C + c) * M;
+    atomicAdd(gp + i[0], g * w[0]); atomicAdd(gp + i[1], g * w[1]); atomicAdd(gp + i[2], g * w[2]);
+}
+
+static bool pn2_grid_ok(int B, int C) { return B >= 1 && C >= 1 && B <= 65535 && C <= 65535; }
+
+extern "C" int reart_pn2_gather_points(const float *points, const int32_t *idx, int B, int C, int N, int M, float *out, void *stream) {
+    if (B < 0 || C < 0 || N < 1 || M < 0) return REART_ERR_INVALID_ARG;
+    if (B == 0 || C == 0 || M == 0) return REART_OK;
+    if (!points || !idx || !out || !pn2_grid_ok(B, C)) return REART_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(pn2_gather_kernel, dim3(reart_div_up(M, 256), C, B), dim3(256), 0, (hipStream_t)stream, points, idx, C, N, M, out);
+    REART_CHECK_LAUNCH();
+    return REART_OK;
+}
+extern "C" int reart_pn2_gather_points_grad(const float *grad_out, const int32_t *idx, int B, int C, int N, int M, float *grad_points,
+                                            void *stream) {
+    if (B < 0 || C < 0 || N < 1 || M < 0) return REART_ERR_INVALID_ARG;
+    if (B == 0 || C == 0 || M == 0) return REART_OK;
+    if (!grad_out || !idx || !grad_points || !pn2_grid_ok(B, C)) return REART_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(pn2_scatter_add_kernel, dim3(reart_div_up(M, 256), C, B), dim3(256), 0, (hipStream_t)stream, grad_out, idx, C, N, M,
+                       grad_points);
+    REART_CHECK_LAUNCH();
+    return REART_OK;
+}
+extern "C" int reart_pn2_three_interpolate(const float *points, const int32_t *idx, const float *weight, int B, int C, int M, int N,
+                                           float *out, void *stream) {
+    if (B < 0 || C < 0 || M < 1 || N < 0) return REART_ERR_INVALID_ARG;
+    if (B == 0 || C == 0 || N == 0) return REART_OK;
+    if (!points || !idx || !weight || !out || !pn2_grid_ok(B, C)) return REART_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(pn2_interp_kernel, dim3(reart_div_up(N, 256), C, B), dim3(256), 0, (hipStream_t)stream, points, idx, weight, C, M, N,
+                       out);
+    REART_CHECK_LAUNCH();
+    return REART_OK;
+}
+extern "C" int reart_pn2_three_interpolate_grad(const float *grad_out, const int32_t *idx, const float *weight, int B, int C, int N, int M,
+                                                float *grad_points, void *stream) {
+    if (B < 0 || C < 0 || M < 1 || N < 0) return REART_ERR_INVALID_ARG;
+    if (B == 0 || C == 0 || N == 0) return REART_OK;
+    if (!grad_out || !idx || !weight || !grad_points || !pn2_grid_ok(B, C)) return REART_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(pn2_interp_grad_kernel, dim3(reart_div_up(N, 256), C, B), dim3(256), 0, (hipStream_t)stream, grad_out, idx, weight, C,
+                       N, M, grad_points);
+    REART_CHECK_LAUNCH();
+    return REART_OK;
+}

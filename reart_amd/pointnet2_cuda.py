@@ -1,13 +1,12 @@
-"""Drop-in for the live part of the reference's pybind module ``pointnet2_cuda``
-(``networks/pointnet_lib/src/pointnet2_api.cpp:11-26``): the two wrappers the reference actually
-calls (``furthest_point_sampling_wrapper`` from ``pointnet_lib/pointnet2_utils.py:28``,
-``ball_query_wrapper`` from ``:262``), same argument order, caller-allocated int32 outputs,
-return value 1.  The other eight wrappers are reachable only from ``pointnet2_modules.py``,
-which nothing in the reference imports.  Of those, ``three_nn_wrapper`` has an exact
-counterpart among the entry points that exist (the three nearest by direct-difference squared
-distance, ascending scan: ``reart_knn_points_idx`` with K = 3) and is backed by it; the other seven
-raise NotImplementedError (``three_interpolate_wrapper`` takes precomputed indices and weights in a
-channel-major layout, which ``reart_three_interpolate`` -- fused with the search, point-major -- does not).
+"""Drop-in for the reference's pybind module ``pointnet2_cuda`` (``networks/pointnet_lib/src/pointnet2_api.cpp:11-26``), all
+ten wrappers, same argument order, caller-allocated outputs.  The reference itself calls two of them
+(``furthest_point_sampling_wrapper`` from ``pointnet_lib/pointnet2_utils.py:29``, ``ball_query_wrapper`` from ``:263``); the other
+eight are reachable only from ``pointnet2_modules.py``, which nothing in the reference imports -- they are here so
+that the module is whole: ``three_nn_wrapper`` / ``knn_wrapper`` on the K-nearest search that exists (direct-difference squared
+distance, ascending scan, ties keep the lower index: ``reart_knn_points_idx``, K <= 16), the channel-major gather / group /
+interpolate operators and their backward forms on ``reart_pn2_*`` (csrc/pointnet.hip).  Their parity is against
+restatements of the CUDA kernels in ``oracle/`` (the reference's kernels cannot run here and hold no golden vectors: parity
+unpinned for these eight).
 """
 from . import _lib
 
@@ -44,13 +43,78 @@ def three_nn_wrapper(b, n, m, unknown_tensor, known_tensor, dist2_tensor, idx_te
     return None
 
 
-def _dead(name):
-    def fn(*args, **kwargs):
-        raise NotImplementedError(f"pointnet2_cuda.{name} is dead code in the reference (never called); not built")
-    fn.__name__ = name
-    return fn
+def knn_wrapper(b, n, m, k, unknown_tensor, known_tensor, dist2_tensor, idx_tensor):
+    """interpolate.cpp:27-37 / interpolate_gpu.cu:9-58: unknown f32 [B,N,3], known f32 [B,M,3] -> dist2 f32 [B,N,k], idx i32
+    [B,N,k], the k nearest by the same squared distance, insertion-sorted ascending with strict `<` (ties keep the lower
+    index).  k <= 16 here (the kernel's register list; the reference's bound is its 200-entry local array)."""
+    from .chamferdist_C import knn_points_idx
+
+    if k > 16:
+        raise NotImplementedError("pointnet2_cuda.knn_wrapper: k <= 16 (REART_MAX_K)")
+    _lib.require_gpu(unknown_tensor, known_tensor, dist2_tensor, idx_tensor)
+    idx, dists = knn_points_idx(unknown_tensor.reshape(b, n, 3), known_tensor.reshape(b, m, 3), None, None, k)
+    dist2_tensor.reshape(b, n, k).copy_(dists)
+    idx_tensor.reshape(b, n, k).copy_(idx)
+    return None
 
 
-for _n in ("group_points_wrapper", "group_points_grad_wrapper", "gather_points_wrapper", "gather_points_grad_wrapper",
-           "knn_wrapper", "three_interpolate_wrapper", "three_interpolate_grad_wrapper"):
-    globals()[_n] = _dead(_n)
+def _contig(*ts):
+    for t_ in ts:
+        if not t_.is_contiguous():
+            raise RuntimeError("tensors must be contiguous")       # CHECK_CONTIGUOUS in every wrapper of the reference
+
+
+def gather_points_wrapper(b, c, n, npoints, points_tensor, idx_tensor, out_tensor):
+    """sampling.cpp:11-22 / sampling_gpu.cu:8-24: points f32 [B,C,N], idx i32 [B,npoints] -> out f32 [B,C,npoints]."""
+    _lib.require_gpu(points_tensor, idx_tensor, out_tensor)
+    _contig(points_tensor, idx_tensor, out_tensor)
+    _lib.check(_lib.lib().reart_pn2_gather_points(_lib.ptr(points_tensor), _lib.ptr(idx_tensor), b, c, n, npoints, _lib.ptr(out_tensor),
+                                                  _lib.stream()), "reart_pn2_gather_points")
+    return 1
+
+
+def gather_points_grad_wrapper(b, c, n, npoints, grad_out_tensor, idx_tensor, grad_points_tensor):
+    """sampling.cpp:24-35 / sampling_gpu.cu:46-63: grad_out f32 [B,C,npoints] accumulated into grad_points f32 [B,C,N] (zeroed
+    by the caller, pointnet_lib/pointnet2_utils.py:70)."""
+    _lib.require_gpu(grad_out_tensor, idx_tensor, grad_points_tensor)
+    _contig(grad_out_tensor, idx_tensor, grad_points_tensor)
+    _lib.check(_lib.lib().reart_pn2_gather_points_grad(_lib.ptr(grad_out_tensor), _lib.ptr(idx_tensor), b, c, n, npoints,
+                                                       _lib.ptr(grad_points_tensor), _lib.stream()), "reart_pn2_gather_points_grad")
+    return 1
+
+
+def group_points_wrapper(b, c, n, npoints, nsample, points_tensor, idx_tensor, out_tensor):
+    """group_points.cpp:26-38 / group_points_gpu.cu:39-54: points f32 [B,C,N], idx i32 [B,npoints,nsample] -> out f32
+    [B,C,npoints,nsample]: the gather above over npoints * nsample indices per batch."""
+    _lib.require_gpu(points_tensor, idx_tensor, out_tensor)
+    _contig(points_tensor, idx_tensor, out_tensor)
+    _lib.check(_lib.lib().reart_pn2_gather_points(_lib.ptr(points_tensor), _lib.ptr(idx_tensor), b, c, n, npoints * nsample,
+                                                  _lib.ptr(out_tensor), _lib.stream()), "reart_pn2_gather_points")
+    return 1
+
+
+def group_points_grad_wrapper(b, c, n, npoints, nsample, grad_out_tensor, idx_tensor, grad_points_tensor):
+    """group_points.cpp:12-23 / group_points_gpu.cu:8-21: grad_out f32 [B,C,npoints,nsample] accumulated into grad_points."""
+    _lib.require_gpu(grad_out_tensor, idx_tensor, grad_points_tensor)
+    _contig(grad_out_tensor, idx_tensor, grad_points_tensor)
+    _lib.check(_lib.lib().reart_pn2_gather_points_grad(_lib.ptr(grad_out_tensor), _lib.ptr(idx_tensor), b, c, n, npoints * nsample,
+                                                       _lib.ptr(grad_points_tensor), _lib.stream()), "reart_pn2_gather_points_grad")
+    return 1
+
+
+def three_interpolate_wrapper(b, c, m, n, points_tensor, idx_tensor, weight_tensor, out_tensor):
+    """interpolate.cpp:40-54 / interpolate_gpu.cu:149-169: points f32 [B,C,M], idx i32 / weight f32 [B,N,3] -> out f32 [B,C,N]."""
+    _lib.require_gpu(points_tensor, idx_tensor, weight_tensor, out_tensor)
+    _contig(points_tensor, idx_tensor, weight_tensor, out_tensor)
+    _lib.check(_lib.lib().reart_pn2_three_interpolate(_lib.ptr(points_tensor), _lib.ptr(idx_tensor), _lib.ptr(weight_tensor), b, c, m, n,
+                                                      _lib.ptr(out_tensor), _lib.stream()), "reart_pn2_three_interpolate")
+    return None
+
+
+def three_interpolate_grad_wrapper(b, c, n, m, grad_out_tensor, idx_tensor, weight_tensor, grad_points_tensor):
+    """interpolate.cpp:56-70 / interpolate_gpu.cu:192-214: grad_out f32 [B,C,N] accumulated into grad_points f32 [B,C,M]."""
+    _lib.require_gpu(grad_out_tensor, idx_tensor, weight_tensor, grad_points_tensor)
+    _contig(grad_out_tensor, idx_tensor, weight_tensor, grad_points_tensor)
+    _lib.check(_lib.lib().reart_pn2_three_interpolate_grad(_lib.ptr(grad_out_tensor), _lib.ptr(idx_tensor), _lib.ptr(weight_tensor), b, c, n,
+                                                           m, _lib.ptr(grad_points_tensor), _lib.stream()), "reart_pn2_three_interpolate_grad")
+    return None

@@ -254,3 +254,17 @@ def test_row_mode_host_logic():
     for k in (1, 2, 3, 5, 20):
         v = torch.from_numpy(rng.integers(0, 4, (300, k)))
         np.testing.assert_array_equal(_row_mode(v).numpy(), torch.mode(v, dim=1)[0].numpy())
+
+
+def test_pointnet2_channel_major_restatements_by_hand(oracle):
+    """oracle.pn2_* (the CUDA kernels of the reference's dead pybind entries, sampling_gpu.cu:8-63, group_points_gpu.cu:8-54,
+    interpolate_gpu.cu:149-214) on a case small enough to check by hand; the reference holds no vectors for them."""
+    f = np.arange(2 * 2 * 4, dtype=np.float32).reshape(2, 2, 4)
+    idx = np.array([[3, 3, 0], [1, 2, 2]], np.int32)
+    np.testing.assert_array_equal(oracle.pn2_gather_points(f, idx)[1], [[9, 10, 10], [13, 14, 14]])
+    np.testing.assert_array_equal(oracle.pn2_gather_points(f, idx[:, None, :])[1, :, 0], [[9, 10, 10], [13, 14, 14]])      # group form
+    np.testing.assert_array_equal(oracle.pn2_gather_points_grad(np.ones((2, 2, 3), np.float32), idx, 4)[0], [[1, 0, 0, 2]] * 2)
+    w = np.array([[[0.5, 0.25, 0.25]], [[1, 0, 0]]], np.float32)
+    ii = np.array([[[0, 1, 2]], [[3, 3, 3]]], np.int32)
+    np.testing.assert_array_equal(oracle.pn2_three_interpolate(f, ii, w), [[[0.75], [4.75]], [[11.0], [15.0]]])
+    np.testing.assert_array_equal(oracle.pn2_three_interpolate_grad(np.ones((2, 2, 1), np.float32), ii, w, 4)[0], [[0.5, 0.25, 0.25, 0]] * 2)

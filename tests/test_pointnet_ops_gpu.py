@@ -103,8 +103,59 @@ def test_pointnet2_cuda_wrappers(oracle, dev):
     dd, ii = oracle.knn_points(xyz, new, K=3)
     np.testing.assert_array_equal(i3.cpu().numpy(), ii)
     np.testing.assert_array_equal(d3.cpu().numpy(), dd)
+    # knn_wrapper (interpolate_gpu.cu:9-58): the same search with k columns
+    d8 = torch.zeros((2, 777, 8), dtype=torch.float32, device=dev)
+    i8 = torch.zeros((2, 777, 8), dtype=torch.int32, device=dev)
+    pc.knn_wrapper(2, 777, 64, 8, pts, t(new, dev), d8, i8)
+    dd, ii = oracle.knn_points(xyz, new, K=8)
+    np.testing.assert_array_equal(i8.cpu().numpy(), ii)
+    np.testing.assert_array_equal(d8.cpu().numpy(), dd)
     with pytest.raises(NotImplementedError):
-        pc.three_interpolate_wrapper()
+        pc.knn_wrapper(2, 777, 64, 17, pts, t(new, dev), d8, i8)
+
+
+@pytest.mark.parametrize("B,C,N,M,S", [(2, 5, 777, 64, 16), (1, 1, 1, 1, 1), (3, 128, 4096, 1024, 32), (2, 3, 50, 300, 3)])
+def test_pointnet2_cuda_channel_major_operators(oracle, dev, B, C, N, M, S):
+    """gather / group / three_interpolate and their backward forms (dead in the reference: pointnet2_api.cpp:14-25) against the
+    oracle's restatements of the CUDA kernels: forward bit for bit, the atomically accumulated backward within 1e-5 relative
+    of a float64 sum (repeated indices everywhere: M > N in the last case)."""
+    from reart_amd import pointnet2_cuda as pc
+
+    rng = np.random.default_rng(B * 1000 + C)
+    feat = rng.normal(size=(B, C, N)).astype(np.float32)
+    idx = rng.integers(0, N, size=(B, M)).astype(np.int32)
+    out = torch.empty((B, C, M), device=dev)
+    assert pc.gather_points_wrapper(B, C, N, M, t(feat, dev), t(idx, dev), out) == 1
+    np.testing.assert_array_equal(out.cpu().numpy(), oracle.pn2_gather_points(feat, idx))
+    go = rng.normal(size=(B, C, M)).astype(np.float32)
+    gp = torch.zeros((B, C, N), device=dev)
+    assert pc.gather_points_grad_wrapper(B, C, N, M, t(go, dev), t(idx, dev), gp) == 1
+    ref = oracle.pn2_gather_points_grad(go, idx, N)
+    np.testing.assert_allclose(gp.cpu().numpy(), ref, rtol=1e-5, atol=1e-5 * np.abs(ref).max())
+    # group: idx [B,M,S]
+    gidx = rng.integers(0, N, size=(B, M, S)).astype(np.int32)
+    gout = torch.empty((B, C, M, S), device=dev)
+    assert pc.group_points_wrapper(B, C, N, M, S, t(feat, dev), t(gidx, dev), gout) == 1
+    np.testing.assert_array_equal(gout.cpu().numpy(), oracle.pn2_gather_points(feat, gidx))
+    ggo = rng.normal(size=(B, C, M, S)).astype(np.float32)
+    ggp = torch.zeros((B, C, N), device=dev)
+    assert pc.group_points_grad_wrapper(B, C, N, M, S, t(ggo, dev), t(gidx, dev), ggp) == 1
+    ref = oracle.pn2_gather_points_grad(ggo, gidx, N)
+    np.testing.assert_allclose(ggp.cpu().numpy(), ref, rtol=1e-5, atol=1e-5 * max(np.abs(ref).max(), 1.0))
+    # interpolate: features known at N points, wanted at M (idx / weight [B,M,3])
+    iidx = rng.integers(0, N, size=(B, M, 3)).astype(np.int32)
+    w = rng.uniform(0, 1, size=(B, M, 3)).astype(np.float32)
+    w /= w.sum(-1, keepdims=True)
+    iout = torch.empty((B, C, M), device=dev)
+    pc.three_interpolate_wrapper(B, C, N, M, t(feat, dev), t(iidx, dev), t(w, dev), iout)
+    np.testing.assert_array_equal(iout.cpu().numpy(), oracle.pn2_three_interpolate(feat, iidx, w))
+    igp = torch.zeros((B, C, N), device=dev)
+    pc.three_interpolate_grad_wrapper(B, C, M, N, t(go, dev), t(iidx, dev), t(w, dev), igp)
+    ref = oracle.pn2_three_interpolate_grad(go, iidx, w, N)
+    np.testing.assert_allclose(igp.cpu().numpy(), ref, rtol=1e-5, atol=1e-5 * max(np.abs(ref).max(), 1.0))
+    if C > 1 and N > 1:                                    # CHECK_CONTIGUOUS of the reference's wrappers
+        with pytest.raises(RuntimeError):
+            pc.gather_points_wrapper(B, N, C, M, t(feat, dev).transpose(1, 2), t(idx, dev), out)
 
 
 def test_fps_full_size_properties(dev):
