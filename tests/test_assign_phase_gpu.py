@@ -108,6 +108,18 @@ def test_refresh_glue_entry_points(dev):
     assert torch.equal(amap, want)
     assert L.reart_gather_points(None, _lib.ptr(idx32), B, N, n, _lib.ptr(out), _lib.stream()) == -1
     assert L.reart_assign_pairs(_lib.ptr(cols32), _lib.ptr(slot), _lib.ptr(tgt32), B, N, 0, _lib.ptr(amap), _lib.stream()) == -1
+    # reart_publish_words: three device arrays -> one pinned host buffer, in order, by one launch (no copy launches); b / c may be empty
+    a, b_, c = (torch.arange(k0, k0 + m, dtype=torch.int32, device=dev) for k0, m in ((10, 9), (100, 9), (1000, 36)))
+    host = torch.full((9 + 9 + 36 + 3,), -7, dtype=torch.int32).pin_memory()
+    _lib.check(L.reart_publish_words(_lib.ptr(a), 9, _lib.ptr(b_), 9, _lib.ptr(c), 36, _lib.c_void_p(host.data_ptr()), _lib.stream()),
+               "reart_publish_words")
+    torch.cuda.synchronize()
+    assert host.tolist() == list(range(10, 19)) + list(range(100, 109)) + list(range(1000, 1036)) + [-7] * 3
+    _lib.check(L.reart_publish_words(_lib.ptr(c), 36, None, 0, None, 0, _lib.c_void_p(host.data_ptr()), _lib.stream()), "reart_publish_words")
+    torch.cuda.synchronize()
+    assert host[:36].tolist() == list(range(1000, 1036))
+    assert L.reart_publish_words(None, 3, None, 0, None, 0, _lib.c_void_p(host.data_ptr()), _lib.stream()) == -1
+    assert L.reart_publish_words(_lib.ptr(a), 9, None, 0, None, 0, None, _lib.stream()) == -1
 
 
 def test_device_side_refresh_equals_the_tensor_path(dev):
