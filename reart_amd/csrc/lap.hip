@@ -1446,10 +1446,7 @@ __global__ __launch_bounds__(JV_PASSP_BS) void lap_jv_pass_pts_kernel(JvArgs a) 
 // the state arrays of the many-compute-unit row reduction, behind the race layout
 static size_t jv_mc_extra_bytes(int B, int n) {
     return reart_align_up(sizeof(double) * (size_t)B * n, 256) + 6 * reart_align_up(sizeof(int) * (size_t)B * n, 256) +
-           reart_align_up(sizeof(int) * 8 * ((size_t)B + 1), 256) +      // (+ one block of launch-wide counters behind the problems')
-           // the packed form of the row reduction: words, (base, unit) per problem, two counters per problem
-           reart_align_up(sizeof(unsigned long long) * (size_t)B * n, 256) + reart_align_up(sizeof(double) * 2 * (size_t)B, 256) +
-           reart_align_up(sizeof(int) * 2 * (size_t)B, 256);
+           reart_align_up(sizeof(int) * 8 * ((size_t)B + 1), 256);      // (+ one block of launch-wide counters behind the problems')
 }
 extern "C" size_t reart_lap_mc_workspace_bytes(int B, int n, int racers) {
     const size_t r = reart_lap_race_workspace_bytes(B, n, racers);
@@ -1533,10 +1530,7 @@ static int jv_launch(JvArgs a, void *workspace, size_t workspace_bytes, void *st
         a.mc_price = (double *)w; w += reart_align_up(sizeof(double) * (size_t)a.B * a.n, 256);
         a.mc_owner = (int *)w; w += bi; a.mc_assigned = (int *)w; w += bi; a.mc_list = (int *)w; w += bi; a.mc_next = (int *)w; w += bi;
         a.mc_tree = (int *)w; w += bi; a.mc_tpar = (int *)w; w += bi;
-        a.mc_cnt = (int *)w; w += reart_align_up(sizeof(int) * 8 * ((size_t)a.B + 1), 256);
-        a.mc_pw = (unsigned long long *)w; w += reart_align_up(sizeof(unsigned long long) * (size_t)a.B * a.n, 256);
-        a.mc_pbu = (double *)w; w += reart_align_up(sizeof(double) * 2 * (size_t)a.B, 256);
-        a.mc_sync = (int *)w;
+        a.mc_cnt = (int *)w;
         const int rc = reart_internal_jvmc_launch(a, racers, arr_wgs, (hipStream_t)stream);
         if (rc != REART_OK) return rc;
     } else if (per_wave) {                      // lap_mw.hip: the row reduction one chain per wave

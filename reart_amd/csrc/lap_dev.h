@@ -157,13 +157,6 @@ struct JvArgs {
     int *mc_tree, *mc_tpar;    // [B][n] each: column -> tree (the unowned column it leads to at zero reduced cost; -1 none) | its parent column there
     int *mc_cnt;               // [B][8]: free rows | queue head | rows left | reduction steps | conflicts | released | unsolved | unowned columns
     int mc_chain;              // steps after which a chain leaves its row to the path searches
-    // the row reduction on PACKED words (lap_mc_arr_packed_kernel): per column one 64-bit word = fixed-point price (52 bits, in units of
-    // mc_pbu[2b+1] above mc_pbu[2b]) << 12 | owner (0xFFF: none) -- a commit is ONE compare-and-swap; packed by the set-up launch
-    // (the re-pricing launch rewrites the unowned columns' words), unpacked into mc_price / mc_owner by the row reduction's last team
-    // of a problem
-    unsigned long long *mc_pw; // [B][n]
-    double *mc_pbu;            // [B][2] base, unit
-    int *mc_sync;              // [B][2] (spare) | teams of the row reduction done
     const int *col_start;
     const double *price_start;
     // --deterministic (ties.hip): the certificate pass also lists the pairs off the assignment that are tight under the final

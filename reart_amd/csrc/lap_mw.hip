@@ -29,9 +29,6 @@
 // the base recipe (9 x 1024^2, raced), budget 8 / 16 / 32 / 64: 10.5 / 10.1 / 9.7 / 10.7 ms -- rows left 50-100 / 15-55 / 5-25 /
 // 2-13, of which the last few need searches of hundreds of steps whatever the budget.
 #define MW_ARR_BUDGET 32
-#define MW_PACK_ROOM 8.0      // cost scales below the lowest incoming price that the packed words' base sits
-#define MW_ARR_PACKED 1       // 1: the row reduction of 16+ columns per lane commits with ONE compare-and-swap on packed words
-                              // (lap_mc_arr_packed_kernel); 0: the lock / verify / store / release form (lap_mc_arr_team_kernel)
 #define MW_CHECK 16          // a search looks at the race flag and at its labelled columns every MW_CHECK steps
 // A search that has not met a sink after MW_BUCKET_AFTER one-column steps goes on in BUCKETS (see the search loop): all
 // unlabelled columns within `width` of the closest one are settled together by label-correcting rounds.
@@ -195,7 +192,7 @@ __global__ __launch_bounds__(64 * NW) void lap_jvmw_kernel(JvArgs a) {
     double *hcol = (double *)(ptz + n);                                 // [n] searches: potential of the row that owns the column
     int *tof = (int *)(hcol + n), *tpr = tof + n;                       // [n] each: the column's tree (lap_mc_trees_kernel) | its parent there
     __shared__ MwShared sh;
-    __shared__ double s_red[NW], s_red2[NW];
+    __shared__ double s_red[NW];
     __shared__ int s_cw[NW];
     const bool race = STAGE != 1 && a.done != nullptr;
     const int racer = race ? (int)blockIdx.y : 0;
@@ -294,32 +291,7 @@ __global__ __launch_bounds__(64 * NW) void lap_jvmw_kernel(JvArgs a) {
     __syncthreads();
 
     if (STAGE == 1) {                                   // hand the state to lap_mc_arr_kernel
-        // ... and, from 16 columns per lane on, as PACKED words to lap_mc_arr_packed_kernel: per column price in fixed point (52 bits:
-        // whole units above `base`, rounded DOWN -- by less than 2^-44 of the cost scale, a twentieth of the tolerance the kept rows
-        // are held to) << 12 | owner.  base: MW_PACK_ROOM cost scales below the lowest price (the re-pricing launch lowers the unowned
-        // columns' prices, down to the base at most); unit: 2^-44 of the cost scale, a power of two (every scaling is exact) -- wider when
-        // the prices' spread plus the room the chains may raise them by would not fit the field (never observed; the solve stays
-        // exact, ties get coarser).
-        const bool packed = MW_ARR_PACKED && CPL >= 16 && a.mc_pw;
-        double pbase = 0.0, pinv = 1.0;
-        if (packed) {
-            double lo = INFINITY, hi = -INFINITY;
-            for (int j = tid; j < n; j += BS) { lo = fmin(lo, price[j]); hi = fmax(hi, price[j]); }
-            lo = lap_wave_min_d(lo); hi = -lap_wave_min_d(-hi);
-            __syncthreads();
-            if (lane == 0) { s_red[wv] = lo; s_red2[wv] = hi; }
-            __syncthreads();
-            for (int w = 0; w < NW; ++w) { lo = fmin(lo, s_red[w]); hi = fmax(hi, s_red2[w]); }
-            pbase = lo - MW_PACK_ROOM * mx;
-            double unit = ldexp(1.0, ilogb(mx) - 44);
-            const double span = (hi - pbase) + 64.0 * mx;
-            if (!(span < ldexp(unit, 51))) unit = ldexp(1.0, ilogb(span) - 50);
-            pinv = 1.0 / unit;
-            if (tid == 0) { a.mc_pbu[2 * b] = pbase; a.mc_pbu[2 * b + 1] = unit; }
-        }
         for (int j = tid; j < n; j += BS) {
-            if (packed)
-                a.mc_pw[(size_t)b * n + j] = ((unsigned long long)((price[j] - pbase) * pinv) << 12) | (unsigned long long)(owner[j] >= 0 ? owner[j] : 0xFFF);
             a.mc_price[(size_t)b * n + j] = price[j]; a.mc_owner[(size_t)b * n + j] = owner[j];
             a.mc_assigned[(size_t)b * n + j] = assigned[j]; a.mc_list[(size_t)b * n + j] = flist[j];
             a.mc_tree[(size_t)b * n + j] = -1; a.mc_tpar[(size_t)b * n + j] = -1;
@@ -339,7 +311,6 @@ __global__ __launch_bounds__(64 * NW) void lap_jvmw_kernel(JvArgs a) {
             // refresh is a 5 us slot of its own, however little it does: tools/solve_gaps.py)
             a.certified[b] = 0;
             if (a.done_clear) a.done_clear[b] = 0;
-            if (a.mc_sync) { a.mc_sync[2 * b] = 0; a.mc_sync[2 * b + 1] = 0; }
             if (a.stats) { int *o = a.stats + 4 * b; o[0] = 0; o[1] = 0; o[2] = 0; o[3] = 0; }
         }
         return;
@@ -861,44 +832,30 @@ __global__ __launch_bounds__(64 * MW_NW) void lap_mc_tighten_kernel(JvArgs a) {
     const int n = a.n, b = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int nh = a.mc_cnt[8 * b + 7];
     const int w0 = blockIdx.x * MW_NW + wv, nw = gridDim.x * MW_NW;
+    if (w0 >= nh) return;
     double *price = a.mc_price + (size_t)b * n;
     const int *owner = a.mc_owner + (size_t)b * n, *holes = a.mc_next + (size_t)b * n;
     const float *S_ = a.src + (size_t)b * n * 3, *T_ = a.tgt + (size_t)b * n * 3;
-    const bool packed = MW_ARR_PACKED && CPL >= 16 && a.mc_pw;
-    const double pbase = packed ? a.mc_pbu[2 * b] : 0.0, punit = packed ? a.mc_pbu[2 * b + 1] : 1.0, pinv = 1.0 / punit;
-    if (w0 < nh) {
-        float sx[CPL], sy[CPL], sz[CPL];
-        double u[CPL];
+    float sx[CPL], sy[CPL], sz[CPL];
+    double u[CPL];
 #pragma unroll
-        for (int k = 0; k < CPL; ++k) {
-            const int j = 64 * k + lane;
-            const int i = j < n ? owner[j] : -1;
-            const int ii = i >= 0 ? i : 0, jj = j < n ? j : 0;
-            sx[k] = S_[3 * ii]; sy[k] = S_[3 * ii + 1]; sz[k] = S_[3 * ii + 2];
-            u[k] = i >= 0 ? (double)mw_sqrt(reart_sqdist3(sx[k], sy[k], sz[k], T_[3 * jj], T_[3 * jj + 1], T_[3 * jj + 2])) + price[jj] : INFINITY;
-        }
-        for (int h = w0; h < nh; h += nw) {
-            const int jh = holes[h];
-            const float hx = T_[3 * jh], hy = T_[3 * jh + 1], hz = T_[3 * jh + 2];
-            const double ph = price[jh];
-            double m = INFINITY;
+    for (int k = 0; k < CPL; ++k) {
+        const int j = 64 * k + lane;
+        const int i = j < n ? owner[j] : -1;
+        const int ii = i >= 0 ? i : 0, jj = j < n ? j : 0;
+        sx[k] = S_[3 * ii]; sy[k] = S_[3 * ii + 1]; sz[k] = S_[3 * ii + 2];
+        u[k] = i >= 0 ? (double)mw_sqrt(reart_sqdist3(sx[k], sy[k], sz[k], T_[3 * jj], T_[3 * jj + 1], T_[3 * jj + 2])) + price[jj] : INFINITY;
+    }
+    for (int h = w0; h < nh; h += nw) {
+        const int jh = holes[h];
+        const float hx = T_[3 * jh], hy = T_[3 * jh + 1], hz = T_[3 * jh + 2];
+        const double ph = price[jh];
+        double m = INFINITY;
 #pragma unroll
-            for (int k = 0; k < CPL; ++k)
-                if (u[k] < INFINITY) m = fmin(m, (((double)mw_sqrt(reart_sqdist3(sx[k], sy[k], sz[k], hx, hy, hz)) + ph) - u[k]));
-            m = lap_wave_min_d(m);
-            if (lane == 0 && m > 0.0 && m < INFINITY) {
-                double np = ph - m;
-                if (packed) {
-                    // (the row reduction works on the packed words the set-up wrote: the hole's word follows its price, rounded UP to a
-                    // whole unit -- lowering by less is always feasible -- and never below the words' base)
-                    np = fmax(np, pbase);
-                    const double pf = ceil((np - pbase) * pinv);
-                    np = pbase + pf * punit;
-                    a.mc_pw[(size_t)b * n + jh] = ((unsigned long long)pf << 12) | 0xFFFull;
-                }
-                price[jh] = np;
-            }
-        }
+        for (int k = 0; k < CPL; ++k)
+            if (u[k] < INFINITY) m = fmin(m, (((double)mw_sqrt(reart_sqdist3(sx[k], sy[k], sz[k], hx, hy, hz)) + ph) - u[k]));
+        m = lap_wave_min_d(m);
+        if (lane == 0 && m > 0.0 && m < INFINITY) price[jh] = ph - m;
     }
 }
 // After the row reduction, before the path searches: for every column still unowned, the TREE of matched rows that reach it at
@@ -1500,147 +1457,6 @@ __global__ __launch_bounds__(64 * TW) void lap_mc_arr_team_kernel(JvArgs a) {
     }
 }
 
-// lap_mc_arr_team_kernel on PACKED words: a column's price and owner live in ONE 64-bit word (lap_mc_tighten_kernel packs them:
-// fixed-point price << 12 | owner), so the commit -- "this column still has the owner and the price my decision used; it is mine
-// now, at the raised price" -- is ONE compare-and-swap instead of lock, re-read, store, release: a step is two dependent round
-// trips to memory (the scan, the swap) instead of four, and the scan reads 8 bytes per column instead of 12.  Why one swap
-// suffices: every commit changes the word (the owner always, the price unless the column was unowned), a column once owned stays
-// owned, and prices never fall during the launch -- a word equal to the one the scan saw means nothing was committed on that column
-// since (had the owner changed and come back, the price would have risen on the way, or not at all: then the state IS the one seen).
-// Prices move in whole units (the raise is rounded DOWN: the row stays strictly the cheapest bidder, every other row's constraint
-// only gains slack); a raise below one unit counts as a tie.  Nothing writes `assigned` on the way (a store behind the swap could
-// land after the store of a later displacement): the problem's LAST team rebuilds it from the owners when it unpacks the words
-// into mc_price / mc_owner for the launches that follow.
-template <int CPL, int TW>
-__global__ __launch_bounds__(64 * TW) void lap_mc_arr_packed_kernel(JvArgs a) {
-    constexpr int CW = CPL / TW, LG = TW <= 2 ? 1 : (TW <= 4 ? 2 : 3);
-    static_assert(CPL % TW == 0 && CW >= 2 && CW % 2 == 0 && TW <= 8, "columns per lane of a team wave: an even number");
-    typedef unsigned long long u64;
-    const int n = a.n, b = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    u64 *pw = a.mc_pw + (size_t)b * n;
-    int *next = a.mc_next + (size_t)b * n;
-    const int *flist = a.mc_list + (size_t)b * n;
-    int *cnt = a.mc_cnt + 8 * b;
-    const float *S_ = a.src + (size_t)b * n * 3, *T_ = a.tgt + (size_t)b * n * 3;
-    const int nfree = cnt[0];
-    const double base = a.mc_pbu[2 * b], unit = a.mc_pbu[2 * b + 1], inv = 1.0 / unit;
-    __shared__ double s_v1[2][TW], s_v2[2][TW];
-    __shared__ u64 s_w[2][TW];
-    __shared__ int s_j1[2][TW], s_q[2], s_ok[2], s_fin[2], s_last;
-    jv_f2 tcx[CW / 2], tcy[CW / 2], tcz[CW / 2];
-    int col[CW];
-#pragma unroll
-    for (int k = 0; k < CW; ++k) {
-        col[k] = 64 * (TW * k + wv) + lane;
-        const int j = col[k] < n ? col[k] : 0;
-        tcx[k >> 1][k & 1] = T_[3 * j]; tcy[k >> 1][k & 1] = T_[3 * j + 1]; tcz[k >> 1][k & 1] = T_[3 * j + 2];
-    }
-    auto ld_i = [](const int *p) -> int { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-    auto ld_w = [](const u64 *p) -> u64 { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-    int my_arr = 0, my_conf = 0, par = 0, qpar = 0, opar = 0;
-    int *fin = a.mc_cnt + 8 * a.B;                        // launch-wide: teams that have run out of rows
-    const int teams = gridDim.x * gridDim.y, tail_at = teams - teams / MW_ARR_TAIL_DIV;
-    for (;;) {
-        if (threadIdx.x == 0) s_q[qpar] = __hip_atomic_fetch_add(&cnt[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        const int q = s_q[qpar];
-        qpar ^= 1;
-        if (q >= nfree) break;
-        int i = flist[q];
-        float ax = S_[3 * i], ay = S_[3 * i + 1], az = S_[3 * i + 2];
-        for (int budget = a.mc_chain; ; ) {
-            u64 w[CW];
-            int fin_now = 0;                              // (read only by chains long enough for the cut to apply: see lap_mc_arr_team_kernel)
-            if (threadIdx.x == 0 && a.mc_chain - budget >= MW_ARR_TAIL_STEPS) {
-                fin_now = ld_i(fin);
-                if (ld_i(&cnt[2]) >= MW_ARR_TAIL_LEFT) fin_now = 0;
-            }
-#pragma unroll
-            for (int k = 0; k < CW; ++k) w[k] = col[k] < n ? ld_w(pw + col[k]) : ~0ull;
-            float rc[CW];
-            mw_row_costs<CW>(ax, ay, az, tcx, tcy, tcz, rc);
-            double v1 = INFINITY, v2 = INFINITY;
-            int j1 = 0x7fffffff, slot = 0;
-#pragma unroll
-            for (int k = 0; k < CW; ++k) {
-                const double pk = col[k] < n ? base + (double)(w[k] >> 12) * unit : INFINITY;
-                lap_top2_push((double)rc[k] + pk, col[k], k, v1, j1, v2, slot);
-            }
-            lap_wave_top2_fast(v1, j1, v2, slot);
-            // the word the wave's candidate was judged by, from the lane that holds that column
-            j1 = mw_uniform(j1); slot = mw_uniform(slot);
-            u64 wl = 0;
-#pragma unroll
-            for (int k = 0; k < CW; ++k)
-                if (slot == k) wl = w[k];
-            const int hl = j1 == 0x7fffffff ? 0 : (j1 & 63);
-            const u64 ww = ((u64)(unsigned)__builtin_amdgcn_readlane((int)(wl >> 32), hl) << 32) | (u64)(unsigned)__builtin_amdgcn_readlane((int)wl, hl);
-            if (lane == 0) { s_v1[par][wv] = v1; s_v2[par][wv] = v2; s_j1[par][wv] = j1; s_w[par][wv] = ww; }
-            if (threadIdx.x == 0) s_fin[par] = fin_now;
-            __syncthreads();
-            const bool tail = s_fin[par] >= tail_at && a.mc_chain - budget >= MW_ARR_TAIL_STEPS;      // uniform across the team
-            v1 = lane < TW ? s_v1[par][lane] : INFINITY; v2 = lane < TW ? s_v2[par][lane] : INFINITY;
-            j1 = lane < TW ? s_j1[par][lane] : 0x7fffffff;
-            int win = lane;
-            lap_lanes_top2<LG>(v1, j1, v2, win);
-            win = win < TW ? win : 0;
-            const u64 seen = s_w[par][win];
-            par ^= 1;
-            if (!(v1 < INFINITY)) { if (threadIdx.x == 0) __hip_atomic_store(&cnt[6], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-            const int own = (int)(seen & 0xFFFull) == 0xFFF ? -1 : (int)(seen & 0xFFFull);
-            const u64 pf = seen >> 12;
-            // the raise in whole units, rounded down (v2 - v1 >= 0; a difference beyond the field is out of any budget anyway)
-            const double dv = (v2 - v1) * inv;
-            const u64 inc = (v1 < v2) ? (dv < 4.0e15 ? (u64)dv : (1ull << 52)) : 0ull;
-            const bool tie = inc == 0ull;
-            if (--budget < 0 || (tie && own >= 0) || (tail && own >= 0) || pf + inc >= (1ull << 52)) {
-                // out of budget / a tie (within a unit) on an owned column / the launch's tail / (the price field would overflow: never observed)
-                if (threadIdx.x == 0) next[__hip_atomic_fetch_add(&cnt[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = i;
-                break;
-            }
-            const int in_ = own >= 0 ? own : i;
-            const float nx = S_[3 * in_], ny = S_[3 * in_ + 1], nz = S_[3 * in_ + 2];      // the displaced row's point, fetched while the swap is in flight
-            if (threadIdx.x == 0) {
-                u64 expect = seen;
-                s_ok[opar] = __hip_atomic_compare_exchange_strong(pw + j1, &expect, ((pf + inc) << 12) | (u64)i, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                                  __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
-            }
-            __syncthreads();
-            const int ok = s_ok[opar];
-            opar ^= 1;
-            if (!ok) { ++my_conf; continue; }             // somebody committed on it since the scan: look again
-            ++my_arr;
-            if (own < 0) break;
-            i = own; ax = nx; ay = ny; az = nz;
-        }
-    }
-    // ---- out of rows.  The problem's last team unpacks: prices and owners for the launches that follow, row -> column from the owners
-    __shared__ int s_asg[64 * CPL];
-    __threadfence();
-    if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(fin, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(&cnt[3], my_arr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(&cnt[4], my_conf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = __hip_atomic_fetch_add(a.mc_sync + 2 * b + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
-    double *price = a.mc_price + (size_t)b * n;
-    int *owner = a.mc_owner + (size_t)b * n, *assigned = a.mc_assigned + (size_t)b * n;
-    for (int j = threadIdx.x; j < n; j += 64 * TW) s_asg[j] = -1;
-    __syncthreads();
-    for (int j = threadIdx.x; j < n; j += 64 * TW) {
-        const u64 wj = ld_w(pw + j);
-        const int o = (int)(wj & 0xFFFull) == 0xFFF ? -1 : (int)(wj & 0xFFFull);
-        price[j] = base + (double)(wj >> 12) * unit;
-        owner[j] = o;
-        if (o >= 0) s_asg[o] = j;
-    }
-    __syncthreads();
-    for (int j = threadIdx.x; j < n; j += 64 * TW) assigned[j] = s_asg[j];
-}
-
 int reart_internal_jvmw_nmax() { return 64 * 32; }
 
 // (dynamic LDS is raised to what the launch needs, not to a flat 152 KB: the kernel also holds ~18 KB of static LDS -- the
@@ -1687,10 +1503,7 @@ static int mc_launch(const JvArgs &a, int racers, int arr_wgs, hipStream_t strea
         // from 16 columns per lane on a TEAM of four waves per chain (measured 2 / 4 / 8: the projection's median re-solve 2.29 /
         // 2.12 / 2.14 ms against 2.73 with a wave per chain); arr_wgs x 8 chains in flight per problem, each a workgroup of its own
         constexpr int TW = 4;
-        if (MW_ARR_PACKED && a.mc_pw)
-            hipLaunchKernelGGL((lap_mc_arr_packed_kernel<(CPL >= 16 ? CPL : 16), TW>), dim3(arr_wgs * MW_NW, a.B), dim3(64 * TW), 0, stream, s2);
-        else
-            hipLaunchKernelGGL((lap_mc_arr_team_kernel<(CPL >= 16 ? CPL : 16), TW>), dim3(arr_wgs * MW_NW, a.B), dim3(64 * TW), 0, stream, s2);
+        hipLaunchKernelGGL((lap_mc_arr_team_kernel<(CPL >= 16 ? CPL : 16), TW>), dim3(arr_wgs * MW_NW, a.B), dim3(64 * TW), 0, stream, s2);
     } else
         hipLaunchKernelGGL((lap_mc_arr_kernel<CPL>), dim3(arr_wgs * split, a.B), dim3(64 * MW_NW / split), 0, stream, s2);
     REART_CHECK_LAUNCH();

@@ -75,6 +75,10 @@ def test_default_line_fits_the_drivers_record(dev):
     assert 0 < pr["roofline"]["frac_search_only"] <= pr["roofline"]["frac"] < 1
     assert pr["deterministic"] is True and pr["other_mode"]["deterministic"] is False and pr["other_mode"]["value"] > 0
     assert len(pr["ties"]) == 2 and pr["ties"][0] >= pr["ties"][1] >= 0
+    # 1 500 iterations x 9 problems meet one to three tied problems.  A dozen means the certificate is REPAIRING potentials (such a
+    # problem comes back flagged 2, its pairs stale, and the host lists them): a form of the row reduction that rounded the incoming
+    # prices by 1e-14 of the cost scale did that -- every solver test green, this leg 11 % slower (profiles/r06_lap_arr_packed_variant.hip.txt)
+    assert pr["ties"][0] <= 5, pr["ties"]
     assert sec["nao"]["cpu_baseline_torch"]["value"] > 0
     assert d["ranks"][0]["it_per_s"] > 1000 and d["ranks"][0]["elapsed_s"] > 0
 

@@ -156,7 +156,7 @@ def _projection(dev, canonical, iters=200):
             if (i + 1) % 25 == 0:
                 params.append(torch.cat([getattr(m, n_).detach().reshape(-1).clone() for n_ in ("axis_list", "moment_list", "theta_list")]))
         tb = eng.lap_state.get("tie_breaker")
-        return cols, params, eng.lap_fallbacks, (tb.flagged, tb.changed) if tb is not None else (0, 0)
+        return cols, params, eng.lap_fallbacks, (tb.flagged, tb.changed, tb.overflows) if tb is not None else (0, 0, 0)
     finally:
         lap.CANONICAL_TIES = old
 
@@ -174,6 +174,9 @@ def test_two_deterministic_projections_are_the_same_run(dev):
     for x, y in zip(a_par, b_par):
         assert torch.equal(x, y)
     assert a_tb[0] >= 1 and b_tb[0] >= 1, "no tie met in 200 iterations: the test did not exercise the mechanism"
+    # (no problem came back with stale pairs -- flag 2: its certificate had to repair potentials after the pass that listed them; the
+    # loop that shows a solver which leaves the certificate work is the nao projection: tests/test_bench_gpu.py holds it to that)
+    assert a_tb[2] <= 2 and b_tb[2] <= 2, (a_tb, b_tb)
 
 
 def test_a_row_with_more_tight_pairs_than_slots_goes_to_the_host(dev):
