@@ -816,10 +816,13 @@ __global__ __launch_bounds__(64 * NW) void lap_jvmw_kernel(JvArgs a) {
 // ... and on what the row's problem already has in store for the searches: where many rows are left anyway the searches are the
 // long part of the solve and every further row costs a search of its own (hold-out sets, tools/holdout.sh: 11 x 896^2 with 17
 // rows left lost 6 % to an unconditional cut), so the cut applies only while fewer than MW_ARR_TAIL_LEFT rows of the problem
-// have been given up (4 / 8 / 16 / no limit on the hold-out sets and nao: 16 is never the worst, the others each are somewhere).
+// have been given up (4 / 8 / 16 / no limit on the hold-out sets and nao, replayed dumps: 16 is never the worst, the others each are
+// somewhere; at LOOP level -- tools/ab_loop.sh, tools/holdout_loop.sh: --deterministic loops solve the same problems with every
+// variant, each from the potentials its own solves left -- 32 together with MW_FOREST_FEW 8 is never behind: nao projection 442 ->
+// 458 it/s, hold-out projections +6 / 0 / +3 %, kinematic leg +1 %, recipes +-0; 64 and steps 16 lose).
 #define MW_ARR_TAIL_STEPS 32
 #define MW_ARR_TAIL_DIV 16
-#define MW_ARR_TAIL_LEFT 16
+#define MW_ARR_TAIL_LEFT 32
 
 // Between the set-up and the row reduction: every unowned column's price is lowered until the first MATCHED row is indifferent
 // between it and its own column (the step the searches' part of lap_jvmw_kernel explains; here for all the columns the
@@ -995,7 +998,10 @@ __global__ __launch_bounds__(256) void lap_mc_trees_kernel(JvArgs a) {
 // With one to four rows left for the searches (the typical re-solve of the nao projection) a forest of 512 rows costs 0.44 ms for
 // searches that take 0.16 (tools/replay_kernels.py): such a problem grows MW_FOREST_PER rows per row left.  NOT in proportion
 // for every problem: with 10-20 rows left (the hold-out sequences of tools/holdout.sh, the recipe) a smaller forest loses 6-9 %.
-#define MW_FOREST_FEW 4
+// Up to how many rows left: 4 / 6 / 8 / 12 / 16 at loop level (tools/ab_loop.sh, nao projection, same trajectory): 442 / 447 / 453 /
+// 457 / 451 it/s; 8 with MW_ARR_TAIL_LEFT 32: 458, and the one setting that is behind on none of the hold-out loops
+// (tools/holdout_loop.sh; 12 loses 0.5 % on the recipe).  MW_FOREST_PER 48: 447; MW_FOREST_R 256 / 768: 449 / 425.
+#define MW_FOREST_FEW 8
 #define MW_FOREST_PER 32
 #define MW_FOREST_W0 1e-8     // first bucket width of the growth, as a fraction of the cost scale
 #define MW_FOREST_R 512       // measured 0 / 48 / 128 / 256 / 512 / 1024: recipe 3.57 / 3.58 / 3.51 / 3.37 / 3.33 / 3.70 ms per refresh, projection 78.8 / 77.9 / 80.4 / 82.4 / 86.7 / 86.8 it/s
