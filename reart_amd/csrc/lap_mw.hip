@@ -1002,6 +1002,13 @@ __global__ __launch_bounds__(256) void lap_mc_trees_kernel(JvArgs a) {
 // 457 / 451 it/s; 8 with MW_ARR_TAIL_LEFT 32: 458, and the one setting that is behind on none of the hold-out loops
 // (tools/holdout_loop.sh; 12 loses 0.5 % on the recipe).  MW_FOREST_PER 48: 447; MW_FOREST_R 256 / 768: 449 / 425.
 #define MW_FOREST_FEW 8
+// ... and a problem with MANY rows left grows a larger forest: its searches are the long part of the solve and flood hundreds of
+// columns before they meet the forest (tools/sim_regrow.py: a forest over the whole graph saves 10-25 % of the settled columns
+// of the hard solves).  At loop level (tools/ab_loop.sh / holdout_loop.sh, same trajectories): more than 24 rows left -> 1 024
+// rows: the hold-out projection whose solves are all hard 95.3 -> 98.3 it/s, the other +1.8 %, the kinematic leg 210 -> 215, nao
+// +-0; -> 2 048 rows from 24 / 32 rows left: +5 / +4 % on the hard one, -0.7 % on the other; from 16 or 12 rows left: -5 ... -14 %.
+#define MW_FOREST_MANY 24
+#define MW_FOREST_R_MANY 1024
 #define MW_FOREST_PER 32
 #define MW_FOREST_W0 1e-8     // first bucket width of the growth, as a fraction of the cost scale
 #define MW_FOREST_R 512       // measured 0 / 48 / 128 / 256 / 512 / 1024: recipe 3.57 / 3.58 / 3.51 / 3.37 / 3.33 / 3.70 ms per refresh, projection 78.8 / 77.9 / 80.4 / 82.4 / 86.7 / 86.8 it/s
@@ -1062,7 +1069,7 @@ __global__ __launch_bounds__(512) void lap_mc_forest_kernel(JvArgs a) {
     }
     double off = 0.0;
     int nf = nf0;
-    const int rounds = cnt[2] <= MW_FOREST_FEW ? min(MW_FOREST_R, MW_FOREST_PER * cnt[2]) : MW_FOREST_R;     // rows the growth stops after
+    const int rounds = cnt[2] <= MW_FOREST_FEW ? min(MW_FOREST_R, MW_FOREST_PER * cnt[2]) : (cnt[2] > MW_FOREST_MANY ? MW_FOREST_R_MANY : MW_FOREST_R);     // rows the growth stops after
     // The growth is a shortest-path computation like the searches' (the label of an outside row: L_i = M_i - u_i, the shift
     // at which it becomes tight to the forest; a row that joins at shift o offers its column at q + o to everybody else) and
     // runs in BUCKETS like them: all outside rows with a label below (closest label) + width join together, label-correcting
