@@ -807,6 +807,7 @@ __global__ __launch_bounds__(64 * NW) void lap_jvmw_kernel(JvArgs a) {
 // (9 x 1024^2) 12.1 / 11.2 s / - for the whole run, kinematic projection (19 x 2048^2) 62.5 / 64.9 / 64.4 iterations/s; on 8
 // workgroups per problem (13, 16 or 28: no better -- more commits collide).  JvArgs.mc_chain overrides.
 #define MW_MC_CHAIN 128
+#define MW_MC_CHAIN_FULL 64     // ... with the chip full of problems (see reart_internal_jvmc_launch)
 // ... and that longest chain is nearly always a HOPELESS one: a row the searches end up with burns its whole budget first, so
 // with one to four such rows per problem (the typical re-solve of the projection) the launch lasts 128 steps x 3 us = 0.4 ms
 // while the other thousand chains are done after 0.1 (tools/replay_kernels.py: arr 418 us of a 1 310 us solve with <= 8 rows
@@ -1503,7 +1504,10 @@ static int mc_launch(const JvArgs &a, int racers, int arr_wgs, hipStream_t strea
     s1.done_clear = a.done;
     s1.done = nullptr;                                   // the set-up reads the caller's assignment and potentials themselves
     JvArgs s2 = a;
-    if (s2.mc_chain <= 0) s2.mc_chain = MW_MC_CHAIN;
+    // (a caller that deals a problem no more than two workgroups does so because the chip is full of problems -- the recipe as a
+    // sweep: 4 x 95 in flight --, and there a hopeless chain is not a wait at the end of a launch but compute units taken from the
+    // other groups' work: 20 x 15 000 with energies, deterministic, caps 128 / 64 / 48 / 32: 24.1 / 22.6 / 22.9 / 22.4 s)
+    if (s2.mc_chain <= 0) s2.mc_chain = arr_wgs <= 2 ? MW_MC_CHAIN_FULL : MW_MC_CHAIN;
     hipLaunchKernelGGL((lap_jvmw_kernel<CPL, 1>), dim3(a.B), dim3(64 * MW_NW), lds, stream, s1);
     REART_CHECK_LAUNCH();
     hipLaunchKernelGGL((lap_mc_tighten_kernel<CPL>), dim3(arr_wgs, a.B), dim3(64 * MW_NW), 0, stream, s2);
