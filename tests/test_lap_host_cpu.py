@@ -198,3 +198,59 @@ def test_canonical_among_ties_is_the_lexicographic_minimum_of_all_optima():
         assert tuple(new) == opts[0], (C, start, new, opts[0])
         assert moved == int((new != start).sum())
     assert tied > 300
+
+
+def test_replayed_launches_state_machine(monkeypatch):
+    """lap.ReplayedLaunches (the refresh's launches replayed from a captured graph): eager until the same key has come twice,
+    captured once by settle() -- not while a host fallback touched the state, not when switched off --, replayed from then on,
+    dropped when the key changes; the guard is entered around the capture only.  The graph objects are stand-ins: the logic is
+    the host's."""
+    from reart_amd.utils import lap
+
+    events = []
+
+    class FakeGraph:
+        def replay(self):
+            events.append("replay")
+
+    class FakeCapture:
+        def __init__(self, g, **kw):
+            pass
+
+        def __enter__(self):
+            events.append("capture-begin")
+
+        def __exit__(self, *exc):
+            events.append("capture-end")
+
+    monkeypatch.setattr(torch.cuda, "CUDAGraph", FakeGraph)
+    monkeypatch.setattr(torch.cuda, "graph", FakeCapture)
+    monkeypatch.setattr(lap.ReplayedLaunches, "ENABLED", True)
+    fn = lambda: events.append("queue")
+
+    class Guard:
+        def __enter__(self):
+            events.append("guard-in")
+
+        def __exit__(self, *exc):
+            events.append("guard-out")
+
+    r = lap.ReplayedLaunches()
+    r.guard = Guard
+    r.run(("a", 1), fn); r.settle(fn)                       # first time: eager, too early to capture
+    assert events == ["queue"] and r.graph is None
+    r.run(("a", 1), fn); r.settle(fn, ok=False)             # second time, but the host touched the state: put off
+    assert events == ["queue", "queue"] and r.graph is None
+    r.run(("a", 1), fn); r.settle(fn)                       # captured AFTER the refresh it would have served (the capture queues nothing real)
+    assert events[2:] == ["queue", "guard-in", "capture-begin", "queue", "capture-end", "guard-out"] and r.graph is not None
+    del events[:]
+    r.run(("a", 1), fn); r.settle(fn)
+    r.run(("a", 1), fn); r.settle(fn)
+    assert events == ["replay", "replay"] and r.replays == 2
+    r.run(("b", 1), fn); r.settle(fn)                       # another buffer / launch parameter: eager again, the old graph is gone
+    assert events[2:] == ["queue"] and r.graph is None and r.seen == 1
+    monkeypatch.setattr(lap.ReplayedLaunches, "ENABLED", False)
+    del events[:]
+    for _ in range(4):
+        r.run(("b", 1), fn); r.settle(fn)
+    assert events == ["queue"] * 4 and r.graph is None
