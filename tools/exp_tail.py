@@ -168,6 +168,8 @@ def main():
     el = time.perf_counter() - t0
     print(f"projection: {p_iter} iterations in {el:.2f} s = {p_iter / el:.1f} it/s; fallbacks {loop.lap_fallbacks}; per 500: "
           + " ".join(f"{500 / (b[1] - (marks[k - 1][1] if k else 0.0)):.0f}" for k, b in enumerate(marks)))
+    if getattr(loop, "lap_winners", None) is not None:           # raced re-solves: which racer (order of the free rows) finished first, per problem and solve
+        print("racer that finished first (problems x solves):", " ".join(str(int(v)) for v in loop.lap_winners[:14]))
     ms = [x.elapsed_time(y) for x, y in loop.lap_events][-len(bef):]
     raw = np.asarray(raw)
     order, _ = table(ms, raw, f"projection {pcs.shape[0]} x {loop.tgt_pts.shape[1]}^2")
